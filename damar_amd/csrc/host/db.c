@@ -1,0 +1,547 @@
+/* db.c -- read-block loader, reverse complement and synthetic DB generator.
+ *
+ * Host side of the daligner overlap path: everything here runs on the CPU
+ * before the first kernel launch.  Written from the on-disk formats
+ *  and the behaviour of the reference routines cited per
+ * function; no reference code is reused.
+ */
+#define _GNU_SOURCE
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <strings.h>
+#include <math.h>
+#include <errno.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "damar_db.h"
+
+static void *xmalloc(size_t n, const char *what)
+{ void *p = malloc(n ? n : 1);
+  if (p == NULL)
+    { fprintf(stderr, "damar: out of memory (%s, %zu bytes)\n", what, n);
+      exit(1);
+    }
+  return p;
+}
+
+/* "dir/name.suffix" -> "name"  (db/DB.c:175-210 Root with a suffix) */
+char *damar_root(const char *name, const char *suffix)
+{ const char *base = strrchr(name, '/');
+  size_t      len, slen;
+  char       *out;
+
+  base = (base == NULL) ? name : base + 1;
+  len  = strlen(base);
+  slen = (suffix == NULL) ? 0 : strlen(suffix);
+  if (slen > 0 && len > slen && strcasecmp(base + (len - slen), suffix) == 0)
+    len -= slen;
+  out = (char *) xmalloc(len + 1, "root");
+  memcpy(out, base, len);
+  out[len] = '\0';
+  return out;
+}
+
+static char *dir_of(const char *name)
+{ const char *slash = strrchr(name, '/');
+  char       *out;
+  if (slash == NULL)
+    return strdup(".");
+  out = (char *) xmalloc((size_t) (slash - name) + 1, "dir");
+  memcpy(out, name, (size_t) (slash - name));
+  out[slash - name] = '\0';
+  return out;
+}
+
+/* d<run:3>_<block:5>, "." for the unsplit DB (db/DB.c:1851-1933 getDir) */
+char *damar_get_dir(int run, int block)
+{ char *out = (char *) xmalloc(40, "dir name");
+  if (block == 0)
+    strcpy(out, ".");
+  else
+    sprintf(out, "d%03d_%05d", run, block);
+  return out;
+}
+
+/* Open_DB (db/DB.c:457-680) + Read_All_Sequences (db/DB.c:1547-1608). */
+int damar_read_block(const char *name, HITS_DB *block)
+{ char   *root = damar_root(name, ".db");
+  char   *dir  = dir_of(name);
+  char   *dot;
+  int     part = 0;
+  char    path[4096];
+  FILE   *stub = NULL, *idx = NULL, *bps = NULL;
+  int     nfiles, nblocks, ufirst, ulast, i;
+  long long bsize;
+  HITS_READ *reads;
+
+  dot = strrchr(root, '.');
+  if (dot != NULL && dot[1] != '\0' && dot[1] != '-')
+    { char *end;
+      long  v = strtol(dot + 1, &end, 10);
+      if (*end == '\0' && v > 0)
+        { part = (int) v;
+          *dot = '\0';
+        }
+    }
+
+  snprintf(path, sizeof(path), "%s/%s.db", dir, root);
+  if ((stub = fopen(path, "r")) == NULL)
+    { fprintf(stderr, "damar: cannot open database stub %s\n", path);
+      goto fail;
+    }
+  snprintf(path, sizeof(path), "%s/.%s.idx", dir, root);
+  if ((idx = fopen(path, "r")) == NULL)
+    { fprintf(stderr, "damar: cannot open index %s\n", path);
+      goto fail;
+    }
+  if (fread(block, sizeof(HITS_DB), 1, idx) != 1)
+    { fprintf(stderr, "damar: index %s is junk\n", path);
+      goto fail;
+    }
+
+  if (fscanf(stub, "files = %9d\n", &nfiles) != 1)
+    goto junk;
+  for (i = 0; i < nfiles; i++)
+    { char a[4096], b[4096];
+      int  last;
+      if (fscanf(stub, "  %9d %4095s %4095s\n", &last, a, b) != 3)
+        goto junk;
+    }
+  nblocks = 0;
+  if (fscanf(stub, "blocks = %9d\n", &nblocks) != 1)
+    { if (part != 0)
+        { fprintf(stderr, "damar: DB %s is not partitioned, cannot request block %d\n", root, part);
+          goto fail;
+        }
+    }
+  else
+    { if (fscanf(stub, "size = %9lld\n", &bsize) != 1)
+        goto junk;
+      if (part > nblocks)
+        { fprintf(stderr, "damar: DB %s has only %d blocks\n", root, nblocks);
+          goto fail;
+        }
+    }
+  if (part > 0)
+    { for (i = 1; i <= part; i++)
+        if (fscanf(stub, " %9d\n", &ufirst) != 1)
+          goto junk;
+      if (fscanf(stub, " %9d\n", &ulast) != 1)
+        goto junk;
+    }
+  else
+    { ufirst = 0;
+      ulast  = block->ureads;
+    }
+
+  block->nreads = ulast - ufirst;
+  block->part   = part;
+  block->ufirst = ufirst;
+  block->tracks = NULL;
+
+  reads = (HITS_READ *) xmalloc(sizeof(HITS_READ) * (size_t) (block->nreads + 2), "read index");
+  reads += 1;
+  if (fseeko(idx, (off_t) (sizeof(HITS_DB) + sizeof(HITS_READ) * (size_t) ufirst), SEEK_SET) != 0 ||
+      fread(reads, sizeof(HITS_READ), (size_t) block->nreads, idx) != (size_t) block->nreads)
+    { fprintf(stderr, "damar: index of %s is truncated\n", root);
+      goto fail;
+    }
+  if (part > 0)
+    { int64 tot = 0;
+      int   mx  = 0;
+      for (i = 0; i < block->nreads; i++)
+        { tot += reads[i].rlen;
+          if (reads[i].rlen > mx)
+            mx = reads[i].rlen;
+        }
+      block->totlen = tot;
+      block->maxlen = mx;
+    }
+  ((int *) reads)[-1] = block->nreads;
+  block->reads = reads;
+
+  snprintf(path, sizeof(path), "%s/.%s.", dir, root);
+  block->path = strdup(path);
+  path[strlen(path) - 1] = '\0';
+  strcat(path, ".bps");
+  if ((bps = fopen(path, "r")) == NULL)
+    { fprintf(stderr, "damar: cannot open bases %s\n", path);
+      goto fail;
+    }
+
+  { char  *seq = (char *) xmalloc((size_t) (block->totlen + block->nreads + 4), "block bases");
+    int64  o = 0;
+
+    *seq++ = 4;
+    for (i = 0; i < block->nreads; i++)
+      { int    len  = reads[i].rlen;
+        int    clen = (len + 3) >> 2;
+        int    j;
+        unsigned char *p;
+        char  *s = seq + o;
+
+        if (fseeko(bps, (off_t) reads[i].boff, SEEK_SET) != 0 ||
+            (clen > 0 && fread(s, (size_t) clen, 1, bps) != 1))
+          { fprintf(stderr, "damar: read of %s failed\n", path);
+            goto fail;
+          }
+        p = (unsigned char *) s;
+        for (j = clen - 1; j >= 0; j--)       /* expand in place, back to front */
+          { unsigned byte = p[j];
+            int      q = 4 * j;
+            if (q + 3 < len) s[q + 3] = (char) (byte & 3);
+            if (q + 2 < len) s[q + 2] = (char) ((byte >> 2) & 3);
+            if (q + 1 < len) s[q + 1] = (char) ((byte >> 4) & 3);
+            s[q] = (char) ((byte >> 6) & 3);
+          }
+        s[len] = 4;
+        reads[i].boff = o;
+        o += len + 1;
+      }
+    reads[block->nreads].boff = o;
+    block->bases  = (void *) seq;
+    block->loaded = 1;
+  }
+
+  fclose(bps);
+  fclose(idx);
+  fclose(stub);
+  free(dir);
+  free(root);
+  return 0;
+
+junk:
+  fprintf(stderr, "damar: stub file of %s is junk\n", root);
+fail:
+  if (bps) fclose(bps);
+  if (idx) fclose(idx);
+  if (stub) fclose(stub);
+  free(dir);
+  free(root);
+  return -1;
+}
+
+void damar_close_block(HITS_DB *block)
+{ if (block->loaded && block->bases != NULL)
+    free(((char *) block->bases) - 1);
+  block->bases = NULL;
+  if (block->reads != NULL)
+    free(block->reads - 1);
+  block->reads = NULL;
+  if (block->path != NULL)
+    free(block->path);
+  block->path = NULL;
+}
+
+/* daligner.c:511-570: reverse-complement every read; freq[] is mirrored too. */
+HITS_DB *damar_complement_block(HITS_DB *block, int inplace)
+{ static HITS_DB cstore;
+  HITS_DB *c;
+  char    *seq;
+  int      i;
+  float    x;
+
+  if (block->tracks != NULL)
+    { fprintf(stderr, "damar: mask tracks are not supported on the complement path yet\n");
+      exit(1);
+    }
+  if (inplace)
+    { c   = block;
+      seq = (char *) block->bases;
+    }
+  else
+    { int64 n = block->reads[block->nreads].boff;
+      seq = (char *) xmalloc((size_t) n + 1, "complement block");
+      *seq++ = 4;
+      memcpy(seq, block->bases, (size_t) n);
+      cstore = *block;
+      c = &cstore;
+      c->bases  = (void *) seq;
+      c->tracks = NULL;
+    }
+  x = c->freq[0]; c->freq[0] = c->freq[3]; c->freq[3] = x;
+  x = c->freq[1]; c->freq[1] = c->freq[2]; c->freq[2] = x;
+
+  for (i = 0; i < block->nreads; i++)
+    { char *s = seq + block->reads[i].boff;
+      char *t = s + (block->reads[i].rlen - 1);
+      while (s < t)
+        { char u = *s;
+          *s++ = (char) (3 - *t);
+          *t-- = (char) (3 - u);
+        }
+      if (s == t)
+        *s = (char) (3 - *s);
+    }
+  return c;
+}
+
+/****************************************************************************************
+ *  Synthetic reads: db/simulator.c semantics, written straight into DB files
+ ****************************************************************************************/
+
+void damar_sim_defaults(damar_sim_params *p)
+{ p->genome_mbp = 1.0;
+  p->coverage   = 20.;
+  p->bias       = .5;
+  p->seed       = 1;
+  p->rmean      = 10000;
+  p->rsdev      = 2000;
+  p->rshort     = 4000;
+  p->erate      = .15;
+  p->block_mbp  = 200;
+  p->min_len    = 1000;
+}
+
+#define NORM_STEPS 60000
+#define NORM_MAX   6.0
+
+typedef struct
+{ double cdf[NORM_STEPS + 1];   /* upper half of the N(0,1) cdf, simulator.c:153-182 */
+  double step;
+} NormTable;
+
+static void norm_init(NormTable *t)
+{ double sum = 0., del = NORM_MAX / NORM_STEPS;
+  int    i;
+  t->step = del;
+  for (i = 0; i < NORM_STEPS; i++)
+    { double x = i * del;
+      t->cdf[i] = sum;
+      sum += exp(-.5 * x * x) * del;
+    }
+  t->cdf[NORM_STEPS] = sum;
+  sum *= 2.;
+  for (i = 0; i < NORM_STEPS; i++)
+    t->cdf[i] /= sum;
+  t->cdf[NORM_STEPS] = 1.;
+}
+
+/* simulator.c:184-227 */
+static double norm_sample(const NormTable *t, double x)
+{ double y = (x >= .5) ? x - .5 : .5 - x;
+  int    l = 0, r = NORM_STEPS;
+  while (l < r)
+    { int m = (l + r) >> 1;
+      if (y < t->cdf[m])
+        r = m;
+      else
+        l = m + 1;
+    }
+  y = (r - (t->cdf[r] - y) / (t->cdf[r] - t->cdf[r - 1])) * t->step;
+  return (x < .5) ? -y : y;
+}
+
+typedef struct
+{ FILE  *bps, *idx;
+  int64  off;
+  int64  totlen;
+  int64  count[4];
+  int    maxlen;
+  int    nreads;
+  HITS_READ *recs;
+  int    rmax;
+} DbOut;
+
+static void dbout_add(DbOut *o, const char *seq, int len)
+{ int   clen = (len + 3) >> 2, i;
+  unsigned char *buf = (unsigned char *) xmalloc((size_t) clen + 4, "pack");
+  HITS_READ hr;
+
+  memset(buf, 0, (size_t) clen + 4);
+  for (i = 0; i < len; i++)
+    { o->count[(int) seq[i]] += 1;
+      buf[i >> 2] |= (unsigned char) (seq[i] << (6 - 2 * (i & 3)));
+    }
+  fwrite(buf, 1, (size_t) clen, o->bps);
+  free(buf);
+
+  memset(&hr, 0, sizeof(hr));
+  hr.rlen  = len;
+  hr.boff  = o->off;
+  hr.coff  = -1;
+  hr.flags = DB_BEST;
+  fwrite(&hr, sizeof(hr), 1, o->idx);
+  if (o->nreads >= o->rmax)
+    { o->rmax = (int) (1.5 * o->rmax) + 1024;
+      o->recs = (HITS_READ *) realloc(o->recs, sizeof(HITS_READ) * (size_t) o->rmax);
+    }
+  o->recs[o->nreads] = hr;
+  o->off    += clen;
+  o->totlen += len;
+  if (len > o->maxlen)
+    o->maxlen = len;
+  o->nreads += 1;
+}
+
+int damar_sim_write_db(const damar_sim_params *p, const char *dir, const char *root)
+{ int     genome = (int) (p->genome_mbp * 1000000.);
+  char   *src;
+  char    path[4096];
+  DbOut   out;
+  HITS_DB db;
+  NormTable *nt;
+  double  nmean, nsdev;
+  int64   want, have;
+  char   *rbuf = NULL;
+  int     rcap = 0;
+  int     i, nblocks;
+  FILE   *stub;
+
+  mkdir(dir, 0755);
+  memset(&out, 0, sizeof(out));
+  snprintf(path, sizeof(path), "%s/.%s.bps", dir, root);
+  out.bps = fopen(path, "w");
+  snprintf(path, sizeof(path), "%s/.%s.idx", dir, root);
+  out.idx = fopen(path, "w");
+  if (out.bps == NULL || out.idx == NULL)
+    { fprintf(stderr, "damar: cannot create DB files in %s\n", dir);
+      return -1;
+    }
+  memset(&db, 0, sizeof(db));
+  fwrite(&db, sizeof(db), 1, out.idx);
+
+  /* simulator.c:100-129 random_genome */
+  { double pra = p->bias / 2., prc = (1. - p->bias) / 2. + pra, prg = (1. - p->bias) / 2. + prc;
+    src = (char *) xmalloc((size_t) genome + 1, "genome");
+    srand48(p->seed);
+    for (i = 0; i < genome; i++)
+      { double x = drand48();
+        src[i] = (char) ((x < pra) ? 0 : (x < prc) ? 1 : (x < prg) ? 2 : 3);
+      }
+    src[genome] = 4;
+  }
+
+  /* simulator.c:242-352 shotgun */
+  nsdev = (1. * p->rsdev) / p->rmean;
+  nsdev = log(1. + nsdev * nsdev);
+  nmean = log(1. * p->rmean) - .5 * nsdev;
+  nsdev = sqrt(nsdev);
+  if (genome < p->rshort)
+    { fprintf(stderr, "damar: genome shorter than the shortest read\n");
+      return -1;
+    }
+  nt = (NormTable *) xmalloc(sizeof(NormTable), "normal table");
+  norm_init(nt);
+
+  want = (int64) (p->coverage * genome);
+  have = 0;
+  while (have < want)
+    { int   len, sdl, ins, del, elen, j;
+      char *s, *t;
+
+      len = (int) exp(nmean + nsdev * norm_sample(nt, drand48()));
+      if (len > genome)
+        len = genome;
+      if (len < p->rshort)
+        continue;
+
+      sdl = (int) (len * p->erate);
+      ins = del = 0;
+      for (j = 0; j < sdl; j++)
+        { double x = drand48();
+          if (x < .73333)
+            ins += 1;
+          else if (x < .93333)
+            del += 1;
+        }
+      sdl -= ins;
+      elen = len + (ins - del);
+      s = src + (int) (drand48() * ((genome - len) + .9999999));
+
+      if (elen > rcap)
+        { rcap = ((int) (1.2 * elen)) + 1000;
+          rbuf = (char *) realloc(rbuf, (size_t) rcap + 3);
+        }
+      t = rbuf;
+      while ((len + 1) * drand48() < ins)
+        { *t++ = (char) (4. * drand48());
+          ins -= 1;
+        }
+      for (; len > 0; len--)
+        { if (len * drand48() >= sdl)
+            *t++ = *s;
+          else if (sdl * drand48() >= del)
+            { double x = 3. * drand48();
+              if (x >= *s)
+                x += 1.;
+              *t++ = (char) x;
+              sdl -= 1;
+            }
+          else
+            { del -= 1;
+              sdl -= 1;
+            }
+          s += 1;
+          while (len * drand48() < ins)
+            { *t++ = (char) (4. * drand48());
+              ins -= 1;
+            }
+        }
+      *t = 4;
+
+      if (drand48() >= .5)             /* strand flip; note simulator.c:133-145 uses s <= t */
+        { char *a = rbuf, *b = rbuf + (elen - 1);
+          while (a <= b)
+            { char c = *a;
+              *a++ = (char) (3 - *b);
+              *b-- = (char) (3 - c);
+            }
+        }
+
+      if (elen >= p->min_len)          /* FA2db -x */
+        dbout_add(&out, rbuf, elen);
+      have += elen;
+    }
+  free(rbuf);
+  free(nt);
+  free(src);
+
+  db.ureads = out.nreads;
+  for (i = 0; i < 4; i++)
+    db.freq[i] = (float) ((1. * out.count[i]) / out.totlen);
+  db.totlen = out.totlen;
+  db.maxlen = out.maxlen;
+  db.nreads = 0;   /* FA2db leaves the block fields zero; Open_DB recomputes them */
+  rewind(out.idx);
+  fwrite(&db, sizeof(db), 1, out.idx);
+  fclose(out.idx);
+  fclose(out.bps);
+
+  /* stub + DBsplit partition (db/DBsplit.c:201-234) */
+  snprintf(path, sizeof(path), "%s/%s.db", dir, root);
+  if ((stub = fopen(path, "w")) == NULL)
+    return -1;
+  fprintf(stub, "files = %9d\n", 1);
+  fprintf(stub, "  %9d %s %s\n", out.nreads, "sim", "Sim");
+  { int64 size = p->block_mbp * 1000000ll, tot = 0;
+    int   open = 0;
+    long  pos  = ftell(stub);
+
+    nblocks = 0;
+    fprintf(stub, "blocks = %9d\n", 0);
+    fprintf(stub, "size = %9lld\n", (long long) p->block_mbp);
+    fprintf(stub, " %9d\n", 0);
+    for (i = 0; i < out.nreads; i++)
+      { open += 1;
+        tot  += out.recs[i].rlen;
+        if (tot >= size)
+          { fprintf(stub, " %9d\n", i + 1);
+            tot = 0;
+            open = 0;
+            nblocks += 1;
+          }
+      }
+    if (open > 0)
+      { fprintf(stub, " %9d\n", out.nreads);
+        nblocks += 1;
+      }
+    fseek(stub, pos, SEEK_SET);
+    fprintf(stub, "blocks = %9d\n", nblocks);
+  }
+  fclose(stub);
+  free(out.recs);
+  return nblocks;
+}

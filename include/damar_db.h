@@ -1,0 +1,103 @@
+/* damar_db.h -- in-memory read-block layout consumed by the overlap hot path.
+ *
+ * Binary-compatible with the reference's HITS_DB / HITS_READ / HITS_TRACK
+ * (reference db/DB.h:319-389) so that a block loaded by the reference's own
+ * Open_DB + Read_All_Sequences (db/DB.c:457-680, 1547-1608) can be handed to
+ * this library unchanged, and a block loaded by damar_read_block() can be handed
+ * to the reference.  Only the subset of the DB API that dalign/daligner.c touches
+ * is provided (SURVEY.md section 2, row db/DB.c).
+ */
+#ifndef DAMAR_DB_H
+#define DAMAR_DB_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t  int64;
+typedef uint64_t uint64;
+typedef uint32_t uint32;
+typedef uint16_t uint16;
+typedef uint8_t  uint8;
+typedef int16_t  int16;
+
+#define DB_QV    0x03ff
+#define DB_CSS   0x0400
+#define DB_BEST  0x0800
+
+/* reference db/DB.h:319-326 (32 bytes: rlen@0 boff@8 coff@16 flags@24) */
+typedef struct
+{ int    rlen;
+  int64  boff;
+  int64  coff;
+  int    flags;
+} HITS_READ;
+
+/* reference db/DB.h:336-342 */
+typedef struct _track
+{ struct _track *next;
+  char          *name;
+  int            size;
+  void          *anno;
+  void          *data;
+} HITS_TRACK;
+
+/* reference db/DB.h:361-389 (88 bytes) */
+typedef struct
+{ int         ureads;
+  float       freq[4];
+  int         maxlen;
+  int64       totlen;
+  int         nreads;
+  int         part;
+  int         ufirst;
+  char       *path;
+  int         loaded;
+  void       *bases;
+  HITS_READ  *reads;
+  HITS_TRACK *tracks;
+} HITS_DB;
+
+/* Load block "<root>.<n>" (or a whole unsplit DB "<root>") the way
+ * daligner.c:442-509 read_DB does without mask tracks: stub + .idx + all bases
+ * unpacked to one byte per base (0..3), read i at reads[i].boff, a 4 before the
+ * first read and after every read.  Returns 0, or -1 with a message on stderr. */
+int   damar_read_block(const char *name, HITS_DB *block);
+void  damar_close_block(HITS_DB *block);
+
+/* Out-of-place / in-place reverse complement of a loaded block
+ * (daligner.c:511-628 complement_DB, mask tracks not supported yet). */
+HITS_DB *damar_complement_block(HITS_DB *block, int inplace);
+
+/* "<prefix>" of a path with directory and ".db" suffix removed (db/DB.c Root). */
+char *damar_root(const char *name, const char *suffix);
+/* Output directory name d%03d_%05d (db/DB.c:1851 getDir). */
+char *damar_get_dir(int run, int block);
+
+/* Synthetic input generator = db/simulator.c:100-352 semantics (drand48-exact)
+ * piped through FA2db (db/FA2db.c:611-624, 1114-1131) and DBsplit
+ * (db/DBsplit.c:201-234): writes <dir>/<root>.db, .<root>.idx, .<root>.bps.
+ * Returns the number of blocks, or -1. */
+typedef struct
+{ double genome_mbp;   /* simulator <genlen>            */
+  double coverage;     /* -c (20.)                      */
+  double bias;         /* -b (.5)                       */
+  int    seed;         /* -r                            */
+  int    rmean;        /* -m (10000)                    */
+  int    rsdev;        /* -s (2000)                     */
+  int    rshort;       /* -x (4000)                     */
+  double erate;        /* -e (.15)                      */
+  int    block_mbp;    /* DBsplit -s (200)              */
+  int    min_len;      /* FA2db -x (1000)               */
+} damar_sim_params;
+
+void damar_sim_defaults(damar_sim_params *p);
+int  damar_sim_write_db(const damar_sim_params *p, const char *dir, const char *root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

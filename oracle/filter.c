@@ -1,0 +1,489 @@
+/* filter.c -- ORACLE (test infrastructure): k-mer index, seed merge, seed sort and the
+ * diagonal-band report loop of the daligner overlap path on the CPU.
+ *
+ * Restates reference dalign/filter.c (cited per function) as whole-array passes:
+ * tuple generation, a stable LSD byte sort, a two-list merge and the per-read-pair
+ * report loop.  The reference's NTHREADS fork-join partitioning is reproduced only
+ * where it changes results (the end-of-slice rule of filter.c:2210-2215).
+ */
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <limits.h>
+
+#include "oracle.h"
+#include "../damar_amd/csrc/host/damar_host.h"
+
+#define MAXGRAM        10000      /* filter.c:71 */
+#define PANEL_SIZE     50000      /* filter.c:73 */
+#define PANEL_OVERLAP  10000      /* filter.c:74 */
+
+static void *xalloc(size_t n)
+{ void *p = malloc(n ? n : 1);
+  if (p == NULL)
+    { fprintf(stderr, "oracle: out of memory (%zu)\n", n);
+      exit(1);
+    }
+  return p;
+}
+
+static int pow2_floor_shift(int n)
+{ int s = 0;
+  while ((2 << s) <= n)
+    s += 1;
+  return s;
+}
+
+/* Stable LSD sort of 16-byte records on the listed byte positions (filter.c:230-435). */
+typedef struct { uint64 lo, hi; } Rec16;
+
+static Rec16 *byte_sort(Rec16 *src, Rec16 *tmp, int64 n, const int *bytes, int nbytes)
+{ int p;
+  for (p = 0; p < nbytes; p++)
+    { int64 cnt[256], sum = 0, i;
+      int   b = bytes[p], c;
+      const unsigned char *base = (const unsigned char *) src;
+      Rec16 *x;
+
+      memset(cnt, 0, sizeof(cnt));
+      for (i = 0; i < n; i++)
+        cnt[base[16 * i + b]] += 1;
+      for (c = 0; c < 256; c++)
+        { int64 t = cnt[c]; cnt[c] = sum; sum += t; }
+      for (i = 0; i < n; i++)
+        tmp[cnt[base[16 * i + b]]++] = src[i];
+      x = src; src = tmp; tmp = x;
+    }
+  return src;
+}
+
+/***** K1-K3: Sort_Kmers, filter.c:753-994 *************************************************/
+
+OKmer *oracle_sort_kmers(const HITS_DB *block, const OParams *prm, int *len)
+{ int    K = prm->kmer, nreads = block->nreads;
+  uint64 kmask = (K == 32) ? ~0ull : ((1ull << (2 * K)) - 1);
+  int64  kmers = block->reads[nreads].boff - (int64) K * nreads;
+  OKmer *src, *tmp, *rez;
+  int64  n = 0;
+  int    i, bytes[16], nb = 0;
+  const char *bases = (const char *) block->bases;
+
+  if (block->reads[nreads].boff > 0x7fffffffll)
+    { fprintf(stderr, "oracle: Fatal error, DB blocks are greater than 2Gbp!\n");
+      exit(1);
+    }
+  if (block->tracks != NULL)
+    { fprintf(stderr, "oracle: mask tracks are not restated yet\n");
+      exit(1);
+    }
+  if (kmers <= 0)
+    { *len = 0;
+      return NULL;
+    }
+  src = (OKmer *) xalloc(sizeof(OKmer) * (size_t) (kmers + 2));
+  tmp = (OKmer *) xalloc(sizeof(OKmer) * (size_t) (kmers + 2));
+
+  /* filter.c:528-544: one record per k-mer, rpos = index of its LAST base */
+  for (i = 0; i < nreads; i++)
+    { const char *s = bases + block->reads[i].boff;
+      uint64 c = 0;
+      int    p = 0, x;
+      for (x = 1; x < K; x++)
+        c = (c << 2) | (uint64) s[p++];
+      while ((x = s[p]) != 4)
+        { c = ((c << 2) | (uint64) x) & kmask;
+          src[n].code = c;
+          src[n].rpos = p++;
+          src[n].read = i;
+          n += 1;
+        }
+    }
+  if (n != kmers)
+    { fprintf(stderr, "oracle: k-mer count mismatch %lld vs %lld\n", (long long) n, (long long) kmers);
+      exit(1);
+    }
+  for (i = 0; i < 2 * K; i += 8)           /* filter.c:769-772 */
+    bytes[nb++] = i >> 3;
+  rez = (OKmer *) byte_sort((Rec16 *) src, (Rec16 *) tmp, kmers, bytes, nb);
+  if (rez == tmp)
+    { tmp = src; src = rez; }
+
+  /* filter.c:700-751, 890-939: drop k-mers occurring >= t times in the block */
+  if (prm->suppress > 0)
+    { int64 r = 0, w = 0;
+      while (r < kmers)
+        { int64 e = r + 1;
+          while (e < kmers && src[e].code == src[r].code)
+            e += 1;
+          if (e - r < prm->suppress)
+            while (r < e)
+              tmp[w++] = src[r++];
+          r = e;
+        }
+      kmers = w;
+      rez = tmp; tmp = src; src = rez;
+    }
+  free(tmp);
+  src[kmers].code = 0xffffffffffffffffull;  /* filter.c:941-942 */
+  src[kmers + 1].code = 0;
+  if (kmers <= 0)
+    { free(src);
+      *len = 0;
+      return NULL;
+    }
+  *len = (int) kmers;
+  return src;
+}
+
+/***** K4: count / limit / merge / seed sort, filter.c:1039-1358, 2561-2790 ******************/
+
+/* One equal-code run pair [ja,ia) x [jb,ib): number of seed pairs it yields. */
+static int64 run_count(const OKmer *as, int ja, int ia, const OKmer *bs, int jb, int ib,
+                       int self, int comp, int identity)
+{ int64 ct = 0;
+  int   a, b = jb;
+  if (!self)
+    return (int64) (ia - ja) * (int64) (ib - jb);        /* filter.c:1149-1150 */
+  for (a = ja; a < ia; a++)                               /* filter.c:1085-1113 */
+    { int ar = as[a].read;
+      if (identity)
+        { if (comp)
+            while (b < ib && bs[b].read <= ar) b += 1;
+          else
+            { int ap = as[a].rpos;
+              while (b < ib && bs[b].read < ar) b += 1;
+              while (b < ib && bs[b].read == ar && bs[b].rpos < ap) b += 1;
+            }
+        }
+      else
+        while (b < ib && bs[b].read < ar) b += 1;
+      ct += (b - jb);
+    }
+  return ct;
+}
+
+static int64 run_emit(const OKmer *as, int ja, int ia, const OKmer *bs, int jb, int ib,
+                      int self, int comp, int identity, OSeed *hits, int64 n)
+{ int a, b = jb, c;
+  for (a = ja; a < ia; a++)                               /* filter.c:1250-1300, 1337-1349 */
+    { int ar = as[a].read, ap = as[a].rpos, top;
+      if (!self)
+        top = ib;
+      else
+        { if (identity)
+            { if (comp)
+                while (b < ib && bs[b].read <= ar) b += 1;
+              else
+                { while (b < ib && bs[b].read < ar) b += 1;
+                  while (b < ib && bs[b].read == ar && bs[b].rpos < ap) b += 1;
+                }
+            }
+          else
+            while (b < ib && bs[b].read < ar) b += 1;
+          top = b;
+        }
+      for (c = jb; c < top; c++)
+        { hits[n].bread = bs[c].read;
+          hits[n].aread = ar;
+          hits[n].apos  = ap;
+          hits[n].diag  = ap - bs[c].rpos;
+          n += 1;
+        }
+    }
+  return n;
+}
+
+static int64 db_bytes(const HITS_DB *db)   /* db/DB.c:726 sizeof_DB, no tracks */
+{ return (int64) sizeof(HITS_DB) + (int64) sizeof(HITS_READ) * (db->nreads + 2) +
+         db->totlen + db->nreads + 4 + (db->path ? (int64) strlen(db->path) + 1 : 0);
+}
+
+OSeed *oracle_seed_pairs(const HITS_DB *ablock, const HITS_DB *bblock,
+                         const OKmer *as, int alen, const OKmer *bs, int blen,
+                         int self, int comp, const OParams *prm, int64 *nhits_out, int *limit_out)
+{ int64 *gram = (int64 *) calloc(MAXGRAM, sizeof(int64));
+  int64  nhits = 0, n = 0;
+  int    limit, ia = 0, ib = 0, pass;
+  OSeed *hits = NULL, *tmp, *rez;
+
+  *nhits_out = 0;
+  if (limit_out) *limit_out = 0;
+  if (alen == 0 || blen == 0)
+    { free(gram);
+      return NULL;
+    }
+  limit = INT_MAX;
+  for (pass = 0; pass < 2; pass++)
+    { ia = ib = 0;
+      while (ia < alen && ib < blen)
+        { uint64 ca = as[ia].code, cb = bs[ib].code;
+          if (cb < ca) { ib += 1; continue; }
+          if (cb > ca) { ia += 1; continue; }
+          { int ja = ia, jb = ib;
+            int64 ct;
+            while (ia < alen && as[ia].code == ca) ia += 1;
+            while (ib < blen && bs[ib].code == cb) ib += 1;
+            ct = run_count(as, ja, ia, bs, jb, ib, self, comp, prm->identity);
+            if (pass == 0)
+              { if (ct < MAXGRAM) gram[ct] += 1;
+                nhits += ct;
+              }
+            else if (ct < limit)
+              n = run_emit(as, ja, ia, bs, jb, ib, self, comp, prm->identity, hits, n);
+          }
+        }
+      if (pass == 0)
+        { if (prm->mem_limit > 0)                 /* filter.c:2634-2699 */
+            { int64 avail, tom = 0;
+              int   j;
+              avail = (int64) (prm->mem_limit - (db_bytes(ablock) + db_bytes(bblock))) / 16;
+              if (as == bs || avail > alen + 2 * (int64) blen)
+                avail = (avail - alen) / 2;
+              else
+                avail = avail - (alen + blen);
+              avail = (int64) (avail * .98);
+              for (j = 0; j < MAXGRAM; j++)
+                { tom += j * gram[j];
+                  if (tom > avail)
+                    break;
+                }
+              limit = j;
+              if (limit <= 1)
+                { fprintf(stderr, "oracle: Insufficient memory, reduce block size\n");
+                  exit(1);
+                }
+              nhits = 0;
+              for (j = 1; j < limit; j++)
+                nhits += j * gram[j];
+            }
+          if (limit_out) *limit_out = limit;
+          if (nhits == 0)
+            { free(gram);
+              return NULL;
+            }
+          hits = (OSeed *) xalloc(sizeof(OSeed) * (size_t) (nhits + 1));
+        }
+    }
+  free(gram);
+  if (n != nhits)
+    { fprintf(stderr, "oracle: seed count mismatch %lld vs %lld\n", (long long) n, (long long) nhits);
+      exit(1);
+    }
+
+  /* filter.c:2561-2580: sort on the significant bytes of apos, aread, bread */
+  { int   bytes[16], nb = 0, i, k;
+    int64 p;
+    for (k = 0, p = 1; p < ablock->maxlen; k++) p <<= 8;
+    for (i = 4; i < 4 + k; i++) bytes[nb++] = i;
+    for (k = 0, p = 1; p < ablock->nreads; k++) p <<= 8;
+    for (i = 8; i < 8 + k; i++) bytes[nb++] = i;
+    for (k = 0, p = 1; p < bblock->nreads; k++) p <<= 8;
+    for (i = 12; i < 12 + k; i++) bytes[nb++] = i;
+    tmp = (OSeed *) xalloc(sizeof(OSeed) * (size_t) (nhits + 1));
+    rez = (OSeed *) byte_sort((Rec16 *) hits, (Rec16 *) tmp, nhits, bytes, nb);
+    if (rez == tmp)
+      { free(hits); hits = rez; }
+    else
+      free(tmp);
+  }
+  hits[nhits].aread = 0x7fffffff;               /* filter.c:2778-2781 */
+  hits[nhits].bread = 0x7fffffff;
+  hits[nhits].diag  = 0x7fffffff;
+  hits[nhits].apos  = 0;
+  *nhits_out = nhits;
+  return hits;
+}
+
+/***** K5 (+K6 calls, K7/K8 through the host tail): report_thread, filter.c:2128-2511 **********/
+
+/* Diagonal buckets touched by an A-view path, one bucket of margin (filter.c:2079-2110). */
+static void diagonal_span(const Path *p, int ts, int bshift, int *mind, int *maxd)
+{ const uint16 *pt = (const uint16 *) p->trace;
+  int low, hgh, dd, i, tlen = p->tlen - 2;
+
+  low = hgh = p->abpos - p->bbpos;
+  dd = p->aepos - p->bepos;
+  if (dd < low) low = dd; else if (dd > hgh) hgh = dd;
+  dd = (p->abpos / ts) * ts - p->bbpos;
+  for (i = 1; i < tlen; i += 2)
+    { dd += ts - pt[i];
+      if (dd < low) low = dd; else if (dd > hgh) hgh = dd;
+    }
+  *mind = (low >> bshift) - 1;
+  *maxd = (hgh >> bshift) + 1;
+}
+
+void oracle_report(const HITS_DB *ablock, const HITS_DB *bblock, const OSeed *hits, int64 nhits,
+                   int self, int comp, const OParams *prm, Align_Spec *spec,
+                   int64 *nfilt_out, int64 *ncheck_out, OWaveStats *stats)
+{ const char *abase = (const char *) ablock->bases, *bbase = (const char *) bblock->bases;
+  const HITS_READ *ard = ablock->reads, *brd = bblock->reads;
+  int   K = prm->kmer, H = prm->hitmin, W = prm->binshift, ts = Trace_Spacing(spec);
+  int   maxdiag = ablock->maxlen >> W, mindiag = (-bblock->maxlen) >> W;
+  int   w = maxdiag - mindiag + 1;
+  int  *store = (int *) calloc((size_t) (3 * w + 8), sizeof(int));
+  int  *score = store + 4 - mindiag, *lastp = score + w, *lasta = lastp + w;
+  int   minhit = (H - 1) / K + 1;
+  int   nshift = pow2_floor_shift(prm->nthreads), nthr = 1 << nshift, t;
+  int   maxtp = 2 * (((ablock->maxlen < bblock->maxlen) ? bblock->maxlen : ablock->maxlen) / ts + 2) + 4;
+  uint16 *atr = (uint16 *) xalloc(sizeof(uint16) * (size_t) maxtp);
+  uint16 *btr = (uint16 *) xalloc(sizeof(uint16) * (size_t) maxtp);
+  damar_path *am = NULL, *bm = NULL;
+  int   amax = 0, bmax = 0;
+  damar_tpool tp = { NULL, 0, 0 };
+  Overlap_IO_Buffer *obuf = OVL_IO_Buffer(spec);
+  int64 nfilt = 0, ncheck = 0;
+  int64 beg = 0;
+
+#define PAIR(i) (((uint64) (uint32) hits[i].bread << 32) | (uint32) hits[i].aread)
+
+  for (t = 0; t < nthr; t++)                    /* filter.c:2804-2816 slices on bread edges */
+    { int64 end, nidx, eidx;
+      if (t == nthr - 1)
+        end = nhits;
+      else
+        { end = (nhits * (t + 1)) >> nshift;
+          if (end > 0)
+            { int d = hits[end - 1].bread;
+              while (hits[end].bread == d)
+                end += 1;
+            }
+        }
+      eidx = end - minhit;
+      nidx = beg;
+      while (nidx < eidx)
+        { uint64 cpair = PAIR(nidx);
+          int64  sidx, lidx, h2, f;
+          int    ar, br, alen, blen, doA, doB, na = 0, nb = 0, started = 0, amark2 = 0;
+          Alignment aln;
+          damar_bridge_ctx bctx;
+
+          if (PAIR(nidx + (minhit - 1)) != cpair)      /* filter.c:2215-2220 */
+            { nidx += 1;
+              while (PAIR(nidx) == cpair) nidx += 1;
+              continue;
+            }
+          ar = hits[nidx].aread;
+          br = hits[nidx].bread;
+          alen = ard[ar].rlen;
+          blen = brd[br].rlen;
+          if (alen < prm->hgap_min && blen < prm->hgap_min)
+            { nidx += 1;
+              while (PAIR(nidx) == cpair) nidx += 1;
+              continue;
+            }
+          aln.aseq = (char *) abase + ard[ar].boff;
+          aln.bseq = (char *) bbase + brd[br].boff;
+          aln.alen = alen;
+          aln.blen = blen;
+          aln.flags = (uint32) comp;
+          doA = (alen >= prm->hgap_min);
+          doB = (prm->symmetric && blen >= prm->hgap_min && (ar != br || !self || !comp));
+          tp.top = 0;
+
+          sidx = nidx;
+          while (PAIR(nidx) == cpair)                  /* A-panels, filter.c:2251-2415 */
+            { int amark = amark2 + PANEL_SIZE, apos;
+              uint64 npair;
+              amark2 = amark - PANEL_OVERLAP;
+              h2 = lidx = nidx;
+              do
+                { apos = hits[nidx].apos;
+                  npair = PAIR(nidx + 1);
+                  nidx += 1;
+                  if (apos <= amark2)
+                    h2 = nidx;
+                }
+              while (npair == cpair && apos <= amark);
+
+              if (nidx - lidx >= minhit)
+                { for (f = lidx; f < nidx; f++)         /* pass 1: bucket scores */
+                    { int d = hits[f].diag >> W, ap = hits[f].apos;
+                      if (ap - lastp[d] >= K) score[d] += K; else score[d] += ap - lastp[d];
+                      lastp[d] = ap;
+                    }
+                  for (f = lidx; f < nidx; f++)         /* pass 2: seeds in order */
+                    { int ap = hits[f].apos, dg = hits[f].diag, bp = ap - dg, d = dg >> W;
+                      Path apath, bpath;
+                      int  lo, hi, ae;
+                      if (!(ap > lasta[d] && (score[d] + score[d + 1] >= H || score[d] + score[d - 1] >= H)))
+                        continue;
+                      started = 1;
+                      nfilt += 1;
+                      oracle_local_alignment(aln.aseq, alen, aln.bseq, blen, aln.flags, dg, ap + bp,
+                                             spec, &apath, &bpath, atr, btr, stats);
+                      diagonal_span(&apath, ts, W, &lo, &hi);
+                      if (d < lo) lo = d; else if (d > hi) hi = d;
+                      ae = apath.aepos;
+                      for (d = lo; d <= hi; d++)
+                        if (ae > lasta[d])
+                          lasta[d] = ae;
+                      if ((apath.aepos - apath.abpos) + (apath.bepos - apath.bbpos) >= prm->minover)
+                        { if (doA)
+                            { if (na >= amax)
+                                { amax = (int) (1.2 * na) + 100;
+                                  am = (damar_path *) realloc(am, sizeof(damar_path) * (size_t) amax);
+                                }
+                              am[na].tlen = apath.tlen;   am[na].diffs = apath.diffs;
+                              am[na].abpos = apath.abpos; am[na].bbpos = apath.bbpos;
+                              am[na].aepos = apath.aepos; am[na].bepos = apath.bepos;
+                              am[na].toff = damar_tpool_push(&tp, atr, apath.tlen);
+                              na += 1;
+                            }
+                          if (doB)
+                            { if (nb >= bmax)
+                                { bmax = (int) (1.2 * nb) + 100;
+                                  bm = (damar_path *) realloc(bm, sizeof(damar_path) * (size_t) bmax);
+                                }
+                              bm[nb].tlen = bpath.tlen;   bm[nb].diffs = bpath.diffs;
+                              bm[nb].abpos = bpath.abpos; bm[nb].bbpos = bpath.bbpos;
+                              bm[nb].aepos = bpath.aepos; bm[nb].bepos = bpath.bepos;
+                              bm[nb].toff = damar_tpool_push(&tp, btr, bpath.tlen);
+                              nb += 1;
+                            }
+                        }
+                    }
+                  for (f = lidx; f < nidx; f++)         /* pass 3: reset touched buckets */
+                    { int d = hits[f].diag >> W;
+                      score[d] = lastp[d] = 0;
+                    }
+                }
+              nidx = h2;
+            }
+          for (f = sidx; f < nidx; f++)                 /* filter.c:2417-2432 */
+            { int d0 = hits[f].diag >> W, d;
+              for (d = d0; d <= maxdiag; d++)
+                { if (lasta[d] == 0) break;
+                  lasta[d] = 0;
+                }
+              for (d = d0 - 1; d >= mindiag; d--)
+                { if (lasta[d] == 0) break;
+                  lasta[d] = 0;
+                }
+            }
+          (void) started;
+          bctx.aseq = aln.aseq; bctx.bseq = aln.bseq; bctx.alen = alen; bctx.blen = blen;
+          damar_emit_pair(am, na, bm, nb, &tp, comp, ts, ar + ablock->ufirst, br + bblock->ufirst,
+                          &bctx, obuf, &ncheck);
+        }
+      beg = end;
+    }
+#undef PAIR
+  free(store); free(atr); free(btr); free(am); free(bm); free(tp.val);
+  if (nfilt_out)  *nfilt_out = nfilt;
+  if (ncheck_out) *ncheck_out = ncheck;
+}
+
+void oracle_match_filter(const HITS_DB *ablock, const HITS_DB *bblock,
+                         const OKmer *asort, int alen, const OKmer *bsort, int blen,
+                         int self, int comp, const OParams *prm, Align_Spec *spec,
+                         int64 *counts, OWaveStats *stats)
+{ int64  nhits = 0, nfilt = 0, ncheck = 0;
+  OSeed *hits = oracle_seed_pairs(ablock, bblock, asort, alen, bsort, blen, self, comp, prm, &nhits, NULL);
+  if (hits != NULL)
+    { oracle_report(ablock, bblock, hits, nhits, self, comp, prm, spec, &nfilt, &ncheck, stats);
+      free(hits);
+    }
+  if (counts)
+    { counts[0] = nhits; counts[1] = nfilt; counts[2] = ncheck; }
+}

@@ -1,0 +1,92 @@
+/* oracle.h -- CPU restatement of the daligner overlap hot path.  TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * anything under oracle/.  The product (libdamar_hip.so, the daligner host binary)
+ * never links, loads or executes this code.
+ *
+ * Parity is PINNED: every stage below is checked in tests/ against the real
+ * reference compiled from /root/reference by oracle/Makefile.ref (oracle/_ref/),
+ * and against the golden .las / stage fixtures under tests/golden/ that those
+ * binaries produced (the reference ships no tests or vectors of its own,
+ * SURVEY.md section 4).
+ *
+ * Each function cites the reference file:line whose behaviour it restates.  The
+ * restatement is deliberately written in the data-parallel shape the HIP kernels
+ * use (whole-array passes, wave steps that read the previous wave and write the
+ * next) instead of the reference's threaded in-place sweeps.
+ */
+#ifndef DAMAR_ORACLE_H
+#define DAMAR_ORACLE_H
+
+#include "damar_db.h"
+#include "damar_align.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* filter.c:121-134 (little-endian field order) */
+typedef struct { uint64 code; int rpos; int read; } OKmer;
+typedef struct { int diag; int apos; int aread; int bread; } OSeed;
+
+typedef struct
+{ int kmer;        /* -k */
+  int binshift;    /* -w */
+  int suppress;    /* -t (0 = off) */
+  int hitmin;      /* -h */
+  int nthreads;    /* -j, rounded down to 2^n as filter.c:192-198 */
+  int minover;     /* 2 * -l, as daligner.c:861 */
+  int hgap_min;    /* always 0 through the reference CLI */
+  int symmetric;   /* !-A */
+  int identity;    /* -I */
+  int64 mem_limit; /* bytes; 0 = no cap (filter.c:2634-2702) */
+} OParams;
+
+/* K1+K2+K3: filter.c:458-547 tuple_thread, :328-435 lex_sort, :700-751 -t compaction,
+ * :753-994 Sort_Kmers.  Returns malloc'ed array of *len records in (code, read, rpos)
+ * order followed by the two sentinels, or NULL if the block has no k-mers. */
+OKmer *oracle_sort_kmers(const HITS_DB *block, const OParams *prm, int *len);
+
+/* K4: filter.c:1039-1165 count_thread, :1170-1358 merge_thread, :2634-2699 limit,
+ * :2776 seed sort.  Returns malloc'ed seeds in (bread, aread, apos, bpos) order with
+ * one sentinel record after *nhits. */
+OSeed *oracle_seed_pairs(const HITS_DB *ablock, const HITS_DB *bblock,
+                         const OKmer *asort, int alen, const OKmer *bsort, int blen,
+                         int self, int comp, const OParams *prm, int64 *nhits, int *limit_out);
+
+/* K6: align.c:1904-2097 Local_Alignment for the call shape of filter.c:2316
+ * (low == hgh == diag, no borders).  Fills both paths; traces are written into
+ * caller arrays of at least 2*(max(alen,blen)/tspace+2)+2 values each and the
+ * paths' trace pointers point into them. */
+typedef struct
+{ int64 waves;      /* wave steps, forward + reverse */
+  int64 cells;      /* sum of band widths over waves */
+  int   maxband;
+  int64 pebbles;
+  int   empty_band; /* a wave ran on an empty band (undefined in the reference) */
+} OWaveStats;
+
+void oracle_local_alignment(const char *aseq, int alen, const char *bseq, int blen,
+                            uint32 flags, int diag, int anti, Align_Spec *spec,
+                            Path *apath, Path *bpath, uint16 *atrace, uint16 *btrace,
+                            OWaveStats *stats);
+
+/* K5+K6+K7+K8: filter.c:2128-2511 report_thread over all read pairs, results
+ * appended to OVL_IO_Buffer(spec)[0].  nfilt/ncheck as printed by -v. */
+void oracle_report(const HITS_DB *ablock, const HITS_DB *bblock, const OSeed *hits, int64 nhits,
+                   int self, int comp, const OParams *prm, Align_Spec *spec,
+                   int64 *nfilt, int64 *ncheck, OWaveStats *stats);
+
+/* filter.c:2519-2929 Match_Filter = oracle_seed_pairs + oracle_report */
+void oracle_match_filter(const HITS_DB *ablock, const HITS_DB *bblock,
+                         const OKmer *asort, int alen, const OKmer *bsort, int blen,
+                         int self, int comp, const OParams *prm, Align_Spec *spec,
+                         int64 *counts /* nhits, nfilt, ncheck */, OWaveStats *stats);
+
+/* Redundancy handling shared with the product's host tail (filter.c:1804-2077);
+ * implemented in damar_amd/csrc/host/redundancy.c. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
