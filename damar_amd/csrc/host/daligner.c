@@ -1,0 +1,211 @@
+/* daligner.c -- host driver of the MI355X overlapper: same command line, block-pair
+ * loop, output directories and .las files as the reference's dalign/daligner.c:662-1077,
+ * calling the three-function filter interface of libdamar_hip.so (damar_filter.h).
+ * Host code stays C; every heavy step behind Sort_Kmers / Match_Filter runs on the GPU.
+ *
+ * Not built yet and rejected explicitly: -m mask tracks, -b, -D (dynamic mask server).
+ * -H is accepted and has no effect, exactly like the reference.
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <errno.h>
+#include <sys/stat.h>
+
+#include "damar_filter.h"
+#include "damar_hip.h"
+
+static void usage(void)
+{ fprintf(stderr, "usage:\n");
+  fprintf(stderr, "daligner [-vAIOT] [-k<int(14)>] [-w<int(6)>] [-h<int(35)>] [-t<int>] [-M<int>]\n");
+  fprintf(stderr, "         [-e<double(.70)] [-l<int(1000)>] [-s<int(100)>] [-H<int>] [-j<int>]\n");
+  fprintf(stderr, "         [-r<int(1)>] [-g<gpu ordinal(0)>] <subject:db> <target:db> ...\n");
+}
+
+static void make_subdir(const HITS_DB *block, int run)      /* daligner.c:630-660 */
+{ char *d = damar_get_dir(run, block->part);
+  struct stat s;
+  if (stat(d, &s) != 0)
+    { if (errno == ENOENT)
+        mkdir(d, S_IRWXU | S_IRGRP | S_IXGRP | S_IROTH | S_IXOTH);
+      else
+        { fprintf(stderr, "Cannot create output directory: %s\n", d);
+          exit(1);
+        }
+    }
+  else if (!S_ISDIR(s.st_mode))
+    { fprintf(stderr, "Output directory name: \"%s\" exist - but its not a directory\n", d);
+      exit(1);
+    }
+  free(d);
+}
+
+static void check_reads(const HITS_DB *b, const char *name, int kmer)     /* daligner.c:499-504 */
+{ int i;
+  for (i = 0; i < b->nreads; i++)
+    if (b->reads[i].rlen < kmer)
+      { fprintf(stderr, "[ERROR] - daligner: Block %s contains reads < %dbp long !  Run DBsplit.\n", name, kmer);
+        exit(1);
+      }
+}
+
+int main(int argc, char *argv[])
+{ HITS_DB ablock, bblock, *cblock;
+  char   *afile, *aroot;
+  void   *aindex, *bindex;
+  int     alen, blen;
+  Align_Spec *spec;
+  int     kmer = 14, hitmin = 35, binshift = 6, maxreps = 0;
+  double  ecorr = .70;
+  int     spacing = 100, runid = 1, notrace = 0, nthreads = 4, only_id = 0, gpu = -1;
+  int     c, i;
+
+  MINOVER = 1000;
+  IDENTITY = 0;
+  SYMMETRIC = 1;
+  opterr = 0;
+  while ((c = getopt(argc, argv, "vbOTAIk:w:h:t:M:e:l:s:H:D:m:r:j:g:")) != -1)
+    switch (c)
+    { case 'v': VERBOSE = 1; break;
+      case 'T': notrace = 1; break;
+      case 'I': IDENTITY = 1; break;
+      case 'O': IDENTITY = 1; only_id = 1; break;
+      case 'A': SYMMETRIC = 0; break;
+      case 'k': kmer = atoi(optarg); break;
+      case 'w': binshift = atoi(optarg); break;
+      case 'h': hitmin = atoi(optarg); break;
+      case 't': maxreps = atoi(optarg); break;
+      case 'H': break;
+      case 'e': ecorr = atof(optarg); break;
+      case 'l': MINOVER = atoi(optarg); break;
+      case 's': spacing = atoi(optarg); break;
+      case 'j': nthreads = atoi(optarg); break;
+      case 'r': runid = atoi(optarg); break;
+      case 'g': gpu = atoi(optarg); break;
+      case 'M':
+        { int gb = atoi(optarg);
+          if (gb < 0)
+            fprintf(stderr, "invalid memory limit of (%d)\n", gb);
+          damar_hip_init(gpu < 0 ? 0 : gpu);     /* sets MEM_PHYSICAL before we override the limit */
+          MEM_LIMIT = (uint64) gb * 0x40000000ull;
+          break;
+        }
+      case 'b': case 'm': case 'D':
+        fprintf(stderr, "daligner: option -%c is not supported by this build\n", c);
+        exit(1);
+      default:
+        fprintf(stderr, "Unsupported option: %s\n", argv[optind - 1]);
+        usage();
+        exit(1);
+    }
+  if (kmer < 0 || binshift < 0 || hitmin < 0 || maxreps < 0 || MINOVER < 0 || spacing < 0 || runid < 0)
+    { fprintf(stderr, "daligner: negative option value\n");
+      exit(1);
+    }
+  if (ecorr < .5 || ecorr >= 1.)
+    { fprintf(stderr, "Average correlation must be in [.5,1.) (%g)\n", ecorr);
+      exit(1);
+    }
+  if (optind + 2 > argc)
+    { fprintf(stderr, "[ERROR] - at least one target and one subject block are required\n\n");
+      usage();
+      exit(1);
+    }
+  MINOVER *= 2;
+  if (Set_Filter_Params(kmer, binshift, maxreps, hitmin, nthreads))
+    { fprintf(stderr, "Illegal combination of filter parameters\n");
+      exit(1);
+    }
+  if (gpu >= 0)
+    damar_hip_init(gpu);
+
+  afile = argv[optind++];
+  if (damar_read_block(afile, &ablock))
+    exit(1);
+  check_reads(&ablock, afile, kmer);
+  aroot = damar_root(afile, ".db");
+
+  if (SYMMETRIC)                                   /* daligner.c:911-946 */
+    for (i = optind; i < argc; i++)
+      if (strcmp(afile, argv[i]) != 0)
+        { char *broot = damar_root(argv[i], ".db");
+          char *ad = strrchr(aroot, '.'), *bd = strrchr(broot, '.');
+          size_t la = ad ? (size_t) (ad - aroot + 1) : strlen(aroot);
+          size_t lb = bd ? (size_t) (bd - broot + 1) : strlen(broot);
+          if (strncmp(aroot, broot, la > lb ? la : lb) != 0)
+            { if (VERBOSE)
+                printf("[WARNING] - Daligner is performed on different databases (%s - %s). SYMMETRIC option is disabled!\n",
+                       aroot, broot);
+              SYMMETRIC = 0;
+            }
+          free(broot);
+          if (!SYMMETRIC)
+            break;
+        }
+
+  make_subdir(&ablock, runid);
+  spec = New_Align_Spec(ecorr, spacing, ablock.freq, nthreads, SYMMETRIC, only_id, notrace, 1);
+
+  aindex = NULL;
+  alen = 0;
+  for (i = optind; i < argc; i++)
+    { char *bfile = argv[i];
+      int   same = (strcmp(afile, bfile) == 0);
+      char *broot = NULL;
+
+      if (!same)
+        { if (damar_read_block(bfile, &bblock))
+            exit(1);
+          check_reads(&bblock, bfile, kmer);
+          broot = damar_root(bfile, ".db");
+        }
+      if (i == optind)
+        { if (VERBOSE)
+            printf("\nBuilding index for %s\n", aroot);
+          aindex = Sort_Kmers(&ablock, &alen);
+        }
+      if (!same)
+        { char *d1 = NULL, *d2 = NULL;
+          int   last;
+          if (SYMMETRIC)
+            make_subdir(&bblock, runid);
+          if (VERBOSE)
+            printf("\nBuilding index for %s\n", broot);
+          bindex = Sort_Kmers(&bblock, &blen);
+          Match_Filter(aroot, &ablock, broot, &bblock, aindex, alen, bindex, blen, 0, spec);
+          damar_complement_block(&bblock, 1);
+          if (VERBOSE)
+            printf("\nBuilding index for c(%s)\n", broot);
+          bindex = Sort_Kmers(&bblock, &blen);
+          Match_Filter(aroot, &ablock, broot, &bblock, aindex, alen, bindex, blen, 1, spec);
+
+          last = (bblock.part < ablock.part) ? bblock.ufirst + bblock.nreads - 1
+                                             : ablock.ufirst + ablock.nreads - 1;
+          if (ablock.part > 0) d1 = damar_get_dir(runid, ablock.part);
+          if (bblock.part > 0) d2 = damar_get_dir(runid, bblock.part);
+          Write_Overlap_Buffer(spec, d1, d2, aroot, broot, last);
+          Reset_Overlap_Buffer(spec);
+          free(d1);
+          free(d2);
+          free(broot);
+          damar_close_block(&bblock);
+        }
+      else
+        { char *d1 = NULL;
+          Match_Filter(aroot, &ablock, aroot, &ablock, aindex, alen, aindex, alen, 0, spec);
+          cblock = damar_complement_block(&ablock, 0);
+          if (VERBOSE)
+            printf("\nBuilding index for c(%s)\n", aroot);
+          bindex = Sort_Kmers(cblock, &blen);
+          Match_Filter(aroot, &ablock, aroot, cblock, aindex, alen, bindex, blen, 1, spec);
+          if (ablock.part > 0) d1 = damar_get_dir(runid, ablock.part);
+          Write_Overlap_Buffer(spec, d1, NULL, aroot, aroot, ablock.ufirst + ablock.nreads - 1);
+          Reset_Overlap_Buffer(spec);
+          free(d1);
+          free(((char *) cblock->bases) - 1);
+        }
+    }
+  return 0;
+}

@@ -1,0 +1,97 @@
+/* kernels.h -- host-callable launchers of the gfx950 kernels (internal to the shim). */
+#ifndef DAMAR_KERNELS_H
+#define DAMAR_KERNELS_H
+
+#include "dev_common.h"
+
+/* sort_scan.hip */
+size_t damar_scan_workspace_bytes(u64 n);
+void   damar_exclusive_scan_u32(const u32 *in, u32 *out, u64 n, void *work, u64 *total_dev, hipStream_t st);
+size_t damar_sort_workspace_bytes(u64 n);
+int    damar_radix_sort_u32(u32 *k0, u32 *v0, u32 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st);
+int    damar_radix_sort_u64(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st);
+
+/* A read block resident in HBM. */
+typedef struct
+{ const u8  *bases;     /* byte per base 0..3, 4 = terminator; bases[-1] == 4 (reference layout) */
+  const u32 *boff;      /* [nreads+1] offset of read i in bases                                   */
+  const u32 *coarse;    /* [(total >> COARSE_SHIFT) + 2] read containing position q<<COARSE_SHIFT */
+  u32        nreads;
+  u32        total;     /* boff[nreads]                                                           */
+  int        maxlen;
+} DevBlock;
+
+#define COARSE_SHIFT 9
+
+/* kmer_index.hip */
+void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, u32 *codes, u32 *pos, hipStream_t st);
+void damar_launch_code_table(const u32 *codes, u32 n, int kbits, int tbits, u32 *table, hipStream_t st);
+void damar_launch_suppress_flags(const u32 *codes, u32 n, const u32 *table, int kbits, int tbits, int suppress,
+                                 u32 *keep, hipStream_t st);
+void damar_launch_compact_pairs(const u32 *k, const u32 *v, const u32 *keep, const u32 *off, u32 n,
+                                u32 *ko, u32 *vo, hipStream_t st);
+
+/* seed_merge.hip */
+typedef struct
+{ const u32 *acode, *apos;  u32 alen;  const u32 *atab;
+  const u32 *bcode, *bpos;  u32 blen;  const u32 *btab;
+  int  kbits, atbits, btbits;
+  int  self, comp, identity;
+  u32  limit;
+  DevBlock ablk, bblk;
+  int  pbits, abits;          /* key = bread << (abits+pbits) | aread << pbits | apos */
+} MergeArgs;
+
+void damar_launch_merge_count(const MergeArgs *m, u32 *cnt, u32 *jb, hipStream_t st);
+void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32 *cnt, hipStream_t st);
+void damar_launch_merge_emit(const MergeArgs *m, const u32 *off, const u32 *jb, u64 nhits,
+                             u64 *keys, u32 *vals, hipStream_t st);
+void damar_launch_pair_flags(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
+                             u32 *flags, hipStream_t st);
+void damar_launch_compact_index(const u32 *flags, const u32 *off, u64 n, u32 *out, hipStream_t st);
+
+/* report.hip */
+typedef struct
+{ int abpos, bbpos, aepos, bepos, diffs;
+  int atlen, btlen;
+  int aread, bread;       /* block-local ids */
+  u32 item, seq;          /* work item and order of discovery inside it */
+  u32 toff;               /* offset of the A trace in the trace pool; B trace follows */
+} LaRecord;
+
+typedef struct
+{ /* inputs */
+  const u64 *keys;  const u32 *vals;  u64 nhits;
+  const u32 *work;  u32 nwork;
+  DevBlock ablk, bblk;
+  int  pbits, abits;
+  int  kmer, hitmin, binshift, minhit;
+  int  comp, self, symmetric, minover, hgap_min;
+  int  tspace, ave_path, reach;
+  const short *score, *table;      /* SCORE[32768], TABLE[32768] */
+  /* per-slot scratch */
+  void *state;   u64 state_stride;   int span;        /* ping-pong diagonal state */
+  int  *marks;   u64 marks_stride;                    /* NA/NB                     */
+  void *cells;   u32 cell_cap;                        /* pebbles                   */
+  int  *buckets; u64 bucket_stride;  int bwidth;      /* score|lastp|lasta          */
+  u16  *ttmp;    u32 ttmp_stride;                     /* 2 centred trace buffers   */
+  /* outputs */
+  LaRecord *recs;  u32 rec_cap;
+  u16  *tpool;     u32 tpool_cap;
+  u32  *counters;  /* [0] next work item, [1] records, [2] trace words, [3] error flags,
+                      [4] seed hits (nfilt) */
+} ReportArgs;
+
+#define DAMAR_ERR_CELLS   1u
+#define DAMAR_ERR_RECS    2u
+#define DAMAR_ERR_TPOOL   4u
+#define DAMAR_ERR_BAND    8u
+
+void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st);
+
+/* batch Local_Alignment for tests: task i = (aread, bread, diag, anti) */
+typedef struct { int aread, bread, diag, anti; } LaTask;
+void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
+
+u64 damar_report_state_stride(int span);
+#endif

@@ -1,0 +1,128 @@
+/* kmer_index.hip -- k-mer tuple generation and index helpers for gfx950.
+ *
+ * Restates reference dalign/filter.c:458-547 (tuple_thread, unmasked branch) and
+ * :700-751, 890-939 (the -t frequency suppression) as data-parallel passes.
+ *
+ * Index layout in HBM (differs from the reference's 16-byte KmerPos records on
+ * purpose): codes[i] (u32, 2 bits per base, last base in the low bits, k <= 16) and
+ * pos[i] (u32 offset of the k-mer's LAST base in the block's base array).  The
+ * reference's (read, rpos) pair is recoverable from pos through the block's read
+ * offsets, and because reads are laid out in order, sorting stably by code leaves
+ * entries in the reference's (code, read, rpos) order.  A prefix table
+ * table[q] = first index with (code >> (kbits-tbits)) >= q turns "find the run of
+ * code c" into one table look-up plus a few steps inside a tiny bucket.
+ */
+#include "dev_common.h"
+#include "kernels.h"
+
+/* read containing base offset p (p is inside a read, never on a terminator) */
+__device__ __forceinline__ u32 read_of_pos(const DevBlock &b, u32 p)
+{ u32 r = b.coarse[p >> COARSE_SHIFT];
+  while (b.boff[r + 1] <= p)
+    r += 1;
+  return r;
+}
+
+__global__ __launch_bounds__(256)
+void kmer_tuples(DevBlock blk, int kmer, u32 nkmers, u32 *__restrict__ codes, u32 *__restrict__ pos)
+{ u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= nkmers)
+    return;
+  /* read r owns k-mer indices [boff[r] - r*k, boff[r+1] - (r+1)*k) */
+  u32 lo = 0, hi = blk.nreads;
+  while (hi - lo > 1)
+    { u32 m = (lo + hi) >> 1;
+      if (blk.boff[m] - m * (u32) kmer <= i)
+        lo = m;
+      else
+        hi = m;
+    }
+  u32 p = i + (lo + 1) * (u32) kmer - 1;         /* offset of the k-mer's last base */
+  const u8 *s = blk.bases + (p - (u32) (kmer - 1));
+  u32 c = 0;
+  for (int j = 0; j < kmer; j++)
+    c = (c << 2) | s[j];
+  codes[i] = c;
+  pos[i]   = p;
+}
+
+void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, u32 *codes, u32 *pos, hipStream_t st)
+{ if (nkmers == 0)
+    return;
+  hipLaunchKernelGGL(kmer_tuples, dim3((nkmers + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, codes, pos);
+}
+
+/* table[q] for q in [0, 2^tbits]: written by the element that starts each prefix
+ * change (it also fills the prefixes that do not occur at all). */
+__global__ __launch_bounds__(256)
+void code_table(const u32 *__restrict__ codes, u32 n, int shift, u32 nq, u32 *__restrict__ table)
+{ u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i > n)
+    return;
+  u32 q1 = (i == n) ? nq : (codes[i] >> shift);            /* i == n: virtual end marker */
+  u32 q0 = (i == 0) ? 0u : (codes[i - 1] >> shift) + 1;
+  for (u32 q = q0; q <= q1 && q <= nq; q++)
+    table[q] = i;
+}
+
+void damar_launch_code_table(const u32 *codes, u32 n, int kbits, int tbits, u32 *table, hipStream_t st)
+{ u32 nq = 1u << tbits;
+  hipLaunchKernelGGL(code_table, dim3((n + 1 + 255) / 256), dim3(256), 0, st, codes, n, kbits - tbits, nq, table);
+}
+
+/* run [lb, ub) of code c in a sorted code array, through its prefix table */
+__device__ __forceinline__ void code_run(const u32 *__restrict__ codes, const u32 *__restrict__ table,
+                                         int shift, u32 c, u32 *lb, u32 *ub)
+{ u32 q = c >> shift;
+  u32 lo = table[q], hi = table[q + 1];
+  if (shift == 0)
+    { *lb = lo; *ub = hi; return; }
+  u32 a = lo, b = hi;
+  while (a < b)
+    { u32 m = (a + b) >> 1;
+      if (codes[m] < c) a = m + 1; else b = m;
+    }
+  *lb = a;
+  b = hi;
+  while (a < b)
+    { u32 m = (a + b) >> 1;
+      if (codes[m] <= c) a = m + 1; else b = m;
+    }
+  *ub = a;
+}
+
+__global__ __launch_bounds__(256)
+void suppress_flags(const u32 *__restrict__ codes, u32 n, const u32 *__restrict__ table, int shift,
+                    u32 suppress, u32 *__restrict__ keep)
+{ u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n)
+    return;
+  u32 lb, ub;
+  code_run(codes, table, shift, codes[i], &lb, &ub);
+  keep[i] = (ub - lb < suppress) ? 1u : 0u;
+}
+
+void damar_launch_suppress_flags(const u32 *codes, u32 n, const u32 *table, int kbits, int tbits, int suppress,
+                                 u32 *keep, hipStream_t st)
+{ if (n == 0)
+    return;
+  hipLaunchKernelGGL(suppress_flags, dim3((n + 255) / 256), dim3(256), 0, st, codes, n, table, kbits - tbits,
+                     (u32) suppress, keep);
+}
+
+__global__ __launch_bounds__(256)
+void compact_pairs(const u32 *__restrict__ k, const u32 *__restrict__ v, const u32 *__restrict__ keep,
+                   const u32 *__restrict__ off, u32 n, u32 *__restrict__ ko, u32 *__restrict__ vo)
+{ u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n && keep[i])
+    { ko[off[i]] = k[i];
+      vo[off[i]] = v[i];
+    }
+}
+
+void damar_launch_compact_pairs(const u32 *k, const u32 *v, const u32 *keep, const u32 *off, u32 n,
+                                u32 *ko, u32 *vo, hipStream_t st)
+{ if (n == 0)
+    return;
+  hipLaunchKernelGGL(compact_pairs, dim3((n + 255) / 256), dim3(256), 0, st, k, v, keep, off, n, ko, vo);
+}

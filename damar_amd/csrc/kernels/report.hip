@@ -1,0 +1,856 @@
+/* report.hip -- diagonal-band seed filter and the Local_Alignment O(n*d) wave, gfx950.
+ *
+ * One 64-lane wavefront owns one read pair (one work item) at a time and runs the whole
+ * report loop of reference dalign/filter.c:2128-2432 for it: A-panels, the three bucket
+ * passes, and for every seed that fires a full Local_Alignment (align.c:1904-2097 =
+ * forward_wave :409-1122 + reverse_wave :1126-1898), then Diagonal_Span
+ * (filter.c:2079-2110) and the lasta update that decides which later seeds still
+ * fire.  Work items are pulled from a device-side counter, so waves stay busy until the
+ * list is empty and every wave exits (no spinning, no inter-wave communication).
+ *
+ * The wave: lane = diagonal.  A wave step reads the previous wave's per-diagonal state
+ * (32-byte DState records, ping-pong buffers in the wave's private scratch in HBM, L2
+ * resident) of the diagonal and its two neighbours, picks the predecessor with the
+ * reference's exact comparison order, slides down the snake, drops pebbles (cells
+ * allocated with a ballot prefix count) and writes the next wave's state.  The
+ * order-dependent part of the reference's sweep (new best / trim point, align.c:911-928)
+ * is replayed over the few candidate lanes in sweep order with readlane.  Bands wider
+ * than 64 diagonals are handled by striding lanes over 64-diagonal chunks in sweep order.
+ *
+ * Integer / branchy work: no MFMA.  HBM traffic is the seed list (12 B per seed, read a
+ * few times), the two reads' bases and the emitted trace points; the kernel is bound by
+ * dependent L2 latency and VALU issue, not by HBM bandwidth.
+ */
+#include "dev_common.h"
+#include "kernels.h"
+
+#define HIST_TOP   0x1000000000000000ull      /* bit 60 (align.c:192) */
+#define HIST_FULL  0x0fffffffffffffffull
+#define HIST_LEN   60
+#define TRIM_MASK  0x7fff
+#define TRIM_BITS  15
+#define MAX_TRIM_LAG 200                      /* align.c:195 */
+#define MAX_WAVE_LAG 30                       /* align.c:196 */
+#define PANEL_SIZE     50000                  /* filter.c:73 */
+#define PANEL_OVERLAP  10000                  /* filter.c:74 */
+#define BIG  0x7fffffff
+
+struct __attribute__((aligned(16))) DState
+{ int V, M, HA, HB;
+  u64 T;
+  int HAm, HBm;          /* mark of the pebble at the head of the A / B chain */
+};
+
+struct __attribute__((aligned(16))) Cell { int ptr, diag, diff, mark; };
+
+struct Tip { int a, y, d, ha, hb; };
+
+struct WaveCtx
+{ const u8 *aseq, *bseq;
+  int   alen, blen;
+  int   ts, ave, reach;
+  const short *score, *table;
+  int   minp, maxp, aoff, boff;
+  DState *st0, *st1;        /* indexed by diagonal + koff */
+  int   *NA, *NB;
+  int    koff;
+  Cell  *cells;
+  u32    cell_cap;
+  u32   *err;
+  u16   *atr, *btr;          /* centres of the two trace buffers */
+};
+
+u64 damar_report_state_stride(int span)
+{ return (u64) 2 * (u64) span * sizeof(DState); }
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+/* One direction of the wave.  REV = 0: align.c:409-1122, REV = 1: align.c:1126-1898.
+ * Returns through *res the end point of this direction; traces are written by lane 0. */
+template <int REV>
+__device__ void wave_pass(const WaveCtx &c, int diag, int mida,
+                          int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
+{ const int lane = lane_id();
+  const int TS = c.ts;
+  const int S = REV ? -1 : 1;
+  const u8 *aseq = REV ? c.aseq - 1 : c.aseq;
+  const u8 *bseq = REV ? c.bseq - 1 : c.bseq;
+  DState *cur = c.st0, *nxt = c.st1;
+  const int o = c.koff;
+
+  int low = diag, hgh = diag, dif = 0;
+  int besta = mida, lasta = mida, besty = (mida - diag) >> 1, more = 1;
+  Tip trim, reach;
+  int reachm = -1;
+  int aclip = REV ? -BIG : BIG, bclip = REV ? BIG : -BIG;
+  u32 ncell = 0;
+  const int steplimit = c.alen + c.blen + 64;
+
+  trim.a = reach.a = mida;  trim.y = reach.y = besty;  trim.d = reach.d = 0;
+  trim.ha = reach.ha = 0;   trim.hb = reach.hb = 1;
+
+  /* wave 0 on the seed diagonal: every lane computes the same values, lane 0 stores */
+  { int k = diag, y = (mida - k) >> 1, na, nb, ha, hb, ham, hbm, v;
+    const u8 *a = aseq + k;
+    Cell cl;
+
+    if (!REV)
+      { na = (((y + k) + (TS - c.aoff)) / TS - 1) * TS + c.aoff;
+        nb = ((y + (TS - c.boff)) / TS - 1) * TS + c.boff;
+        ham = na;  hbm = nb;
+      }
+    else
+      { na = (((y + k) + (TS - c.aoff) - 1) / TS - 1) * TS + c.aoff;
+        nb = ((y + (TS - c.boff) - 1) / TS - 1) * TS + c.boff;
+        ham = y + k;  hbm = y;
+      }
+    cl.ptr = -1; cl.diag = k; cl.diff = 0;
+    cl.mark = ham;  if (lane == 0) c.cells[0] = cl;
+    cl.mark = hbm;  if (lane == 0) c.cells[1] = cl;
+    ha = 0;  hb = 1;  ncell = 2;
+    if (!REV) { na += TS; nb += TS; }
+
+    for (;;)
+      { int cb = bseq[y], ca;
+        if (cb == 4)
+          { more = 0; bclip = k; break; }
+        ca = a[y];
+        if (cb != ca)
+          { if (ca == 4) { more = 0; aclip = k; }
+            break;
+          }
+        y += S;
+      }
+    v = (y << 1) + k;
+    while (REV ? (y + k <= na) : (y + k >= na))
+      { cl.ptr = ha; cl.mark = na;
+        if (lane == 0 && ncell < c.cell_cap) c.cells[ncell] = cl;
+        ha = (int) ncell++;  ham = na;  na += S * TS;
+      }
+    while (REV ? (y <= nb) : (y >= nb))
+      { cl.ptr = hb; cl.mark = nb;
+        if (lane == 0 && ncell < c.cell_cap) c.cells[ncell] = cl;
+        hb = (int) ncell++;  hbm = nb;  nb += S * TS;
+      }
+    if (REV ? (v < besta) : (v > besta))
+      { besta = lasta = trim.a = v;
+        besty = trim.y = y;
+        trim.ha = ha;  trim.hb = hb;
+      }
+    if (lane == 0)
+      { DState s;
+        s.V = v; s.M = HIST_LEN; s.HA = ha; s.HB = hb; s.T = HIST_FULL; s.HAm = ham; s.HBm = hbm;
+        cur[k + o] = s;
+        c.NA[k + o] = na;
+        c.NB[k + o] = nb;
+      }
+  }
+  wave_mem_sync();
+
+  /* clipping at sequence ends (align.c:628-658 / 943-975, mirrored 1341-1371 / 1652-1684) */
+#define CLIP_STEP()                                                                        \
+  if (more == 0)                                                                           \
+    { if (bseq[besty] != 4 && aseq[besta - besty] != 4)                                    \
+        more = 1;                                                                          \
+      if (REV ? (low <= aclip) : (hgh >= aclip))                                           \
+        { DState s = cur[aclip + o];                                                       \
+          if (REV) low = aclip + 1; else hgh = aclip - 1;                                  \
+          if (reachm <= s.M)                                                               \
+            { reachm = s.M; reach.a = s.V; reach.y = (s.V - aclip) / 2; reach.d = dif;     \
+              reach.ha = s.HA; reach.hb = s.HB; }                                          \
+        }                                                                                  \
+      if (REV ? (hgh >= bclip) : (low <= bclip))                                           \
+        { DState s = cur[bclip + o];                                                       \
+          if (REV) hgh = bclip - 1; else low = bclip + 1;                                  \
+          if (reachm <= s.M)                                                               \
+            { reachm = s.M; reach.a = s.V; reach.y = (s.V - bclip) / 2; reach.d = dif;     \
+              reach.ha = s.HA; reach.hb = s.HB; }                                          \
+        }                                                                                  \
+      aclip = REV ? -BIG : BIG;                                                            \
+      bclip = REV ? BIG : -BIG;                                                            \
+    }
+
+  CLIP_STEP()
+
+  while (more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
+    { if (hgh < low || dif > steplimit)
+        { if (lane == 0) atomicOr(c.err, DAMAR_ERR_BAND);
+          break;
+        }
+      /* widen the band by one diagonal per side (align.c:675-776 / 1386-1486) */
+      { int nlow = low - 1, nhgh = hgh + 1;
+        const int edge = REV ? BIG : -1;
+        if (nlow >= c.minp)
+          { if (lane == 0)
+              { c.NA[nlow + o] = c.NA[nlow + 1 + o];
+                c.NB[nlow + o] = c.NB[nlow + 1 + o];
+                cur[nlow + o].V = edge;
+              }
+          }
+        else
+          nlow += 1;
+        if (nhgh <= c.maxp)
+          { if (lane == 0)
+              { c.NA[nhgh + o] = c.NA[nhgh - 1 + o];
+                c.NB[nhgh + o] = c.NB[nhgh - 1 + o];
+                cur[nhgh + o].V = edge;
+              }
+          }
+        else
+          nhgh -= 1;
+        low = nlow;  hgh = nhgh;
+        if (lane == 0)
+          { cur[hgh + 1 + o].V = edge;
+            cur[low - 1 + o].V = edge;
+          }
+        dif += 1;
+      }
+      wave_mem_sync();
+
+      /* the new wave, 64 diagonals at a time in sweep order */
+      for (int kb = REV ? low : hgh; REV ? (kb <= hgh) : (kb >= low); kb += REV ? 64 : -64)
+        { const int  k = REV ? kb + lane : kb - lane;
+          const bool act = REV ? (k <= hgh) : (k >= low);
+          int  v = 0, y = 0, m = 0, ha = 0, hb = 0, ham = 0, hbm = 0, na = 0, nb = 0;
+          u64  b = 0;
+          bool ahit = false, bhit = false;
+
+          if (act)
+            { const int ac = cur[k + o].V, am = cur[k - 1 + o].V, ap = cur[k + 1 + o].V;
+              int from;
+              if (!REV)
+                { if (ac < am) from = (am < ap) ? k + 1 : k - 1;
+                  else         from = (ac < ap) ? k + 1 : k;
+                  v = (from == k) ? ac + 2 : ((from == k + 1) ? ap + 1 : am + 1);
+                }
+              else
+                { if (ac > ap) from = (ap > am) ? k - 1 : k + 1;
+                  else         from = (ac > am) ? k - 1 : k;
+                  v = (from == k) ? ac - 2 : ((from == k - 1) ? am - 1 : ap - 1);
+                }
+              const DState p = cur[from + o];
+              m = p.M;  b = p.T;  ha = p.HA;  hb = p.HB;  ham = p.HAm;  hbm = p.HBm;
+              if (b & HIST_TOP)
+                m -= 1;
+              b <<= 1;
+              y = (v - k) >> 1;
+              const u8 *a = aseq + k;
+              for (;;)
+                { int cb = bseq[y], ca;
+                  if (cb == 4)
+                    { bhit = true; break; }
+                  ca = a[y];
+                  if (cb != ca)
+                    { ahit = (ca == 4);
+                      break;
+                    }
+                  y += S;
+                  if ((b & HIST_TOP) == 0)
+                    m += 1;
+                  b = (b << 1) | 1;
+                }
+              v = (y << 1) + k;
+              na = c.NA[k + o];
+              nb = c.NB[k + o];
+            }
+
+          /* pebbles: cells are handed out with a ballot prefix count (align.c:859-909) */
+          for (;;)
+            { bool need = act && (REV ? (y + k <= na) : (y + k >= na));
+              if (!__any(need))
+                break;
+              bool dropit = need && (REV ? (ham > na) : (ham < na));
+              u64  mask = __ballot(dropit);
+              if (mask)
+                { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
+                  if (dropit)
+                    { if (idx < c.cell_cap)
+                        { Cell cl; cl.ptr = ha; cl.diag = k; cl.diff = dif; cl.mark = na;
+                          c.cells[idx] = cl;
+                        }
+                      ha = (int) idx;  ham = na;
+                    }
+                  ncell += (u32) __popcll(mask);
+                }
+              if (need)
+                na += S * TS;
+            }
+          for (;;)
+            { bool need = act && (REV ? (y <= nb) : (y >= nb));
+              if (!__any(need))
+                break;
+              bool dropit = need && (REV ? (hbm > nb) : (hbm < nb));
+              u64  mask = __ballot(dropit);
+              if (mask)
+                { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
+                  if (dropit)
+                    { if (idx < c.cell_cap)
+                        { Cell cl; cl.ptr = hb; cl.diag = k; cl.diff = dif; cl.mark = nb;
+                          c.cells[idx] = cl;
+                        }
+                      hb = (int) idx;  hbm = nb;
+                    }
+                  ncell += (u32) __popcll(mask);
+                }
+              if (need)
+                nb += S * TS;
+            }
+
+          if (act)
+            { DState s;
+              s.V = v; s.M = m; s.HA = ha; s.HB = hb; s.T = b; s.HAm = ham; s.HBm = hbm;
+              nxt[k + o] = s;
+              c.NA[k + o] = na;
+              c.NB[k + o] = nb;
+            }
+
+          /* sequence ends reached in this chunk */
+          { u64 am_ = __ballot(ahit), bm_ = __ballot(bhit);
+            if (am_ | bm_)
+              { more = 0;
+                if (am_)
+                  { int l = REV ? (63 - __clzll(am_)) : (63 - __clzll(am_));   /* largest lane = lowest k (fwd) / highest k (rev) */
+                    int kk = REV ? kb + l : kb - l;
+                    if (REV ? (kk > aclip) : (kk < aclip)) aclip = kk;
+                  }
+                if (bm_)
+                  { int l = __ffsll((long long) bm_) - 1;                       /* smallest lane = highest k (fwd) / lowest k (rev) */
+                    int kk = REV ? kb + l : kb - l;
+                    if (REV ? (kk < bclip) : (kk > bclip)) bclip = kk;
+                  }
+              }
+          }
+
+          /* new best / trim point, candidates replayed in sweep order (align.c:911-928) */
+          { u64 cand = __ballot(act && (REV ? (v < besta) : (v > besta)));
+            while (cand)
+              { int l = __ffsll((long long) cand) - 1;
+                cand &= cand - 1;
+                int vl = bcast_i(v, l);
+                if (REV ? (vl < besta) : (vl > besta))
+                  { besta = vl;
+                    besty = bcast_i(y, l);
+                    if (bcast_i(m, l) >= c.ave)
+                      { u64 bl = bcast_u64(b, l);
+                        lasta = vl;
+                        if (c.table[bl & TRIM_MASK] >= 0 &&
+                            c.table[(bl >> TRIM_BITS) & TRIM_MASK] + c.score[bl & TRIM_MASK] >= 0)
+                          { trim.a = vl;  trim.y = besty;  trim.d = dif;
+                            trim.ha = bcast_i(ha, l);  trim.hb = bcast_i(hb, l);
+                          }
+                      }
+                  }
+              }
+          }
+        }
+      if (ncell > c.cell_cap)
+        { if (lane == 0) atomicOr(c.err, DAMAR_ERR_CELLS);
+          more = 0;
+          ncell = 2;
+          break;
+        }
+      wave_mem_sync();
+      { DState *t = cur; cur = nxt; nxt = t; }
+
+      CLIP_STEP()
+
+      /* prune diagonals lagging more than 30 behind the best (align.c:977-986 / 1686-1695) */
+      { const int n = REV ? besta + MAX_WAVE_LAG : besta - MAX_WAVE_LAG;
+        int newh = low - 1, newl = low;
+        bool found = false;
+        for (int kb = hgh; kb >= low && !found; kb -= 64)
+          { int  k = kb - lane;
+            bool ok = (k >= low) && (REV ? (cur[k + o].V <= n) : (cur[k + o].V >= n));
+            u64  mk = __ballot(ok);
+            if (mk)
+              { newh = kb - (__ffsll((long long) mk) - 1);
+                found = true;
+              }
+          }
+        if (found)
+          { bool f2 = false;
+            for (int kb = low; kb <= newh && !f2; kb += 64)
+              { int  k = kb + lane;
+                bool ok = (k <= newh) && (REV ? (cur[k + o].V <= n) : (cur[k + o].V >= n));
+                u64  mk = __ballot(ok);
+                if (mk)
+                  { newl = kb + (__ffsll((long long) mk) - 1);
+                    f2 = true;
+                  }
+              }
+            low = newl;
+          }
+        hgh = newh;
+      }
+    }
+#undef CLIP_STEP
+
+  /* end point and trace points of this direction: lane 0 walks the two pebble chains */
+  int rx = 0, ry = 0, rd = 0, at = 0, bt = 0;
+  if (lane == 0)
+    { int  trimx, trimy, trimd, ha, hb;
+      u16 *atrace = c.atr, *btrace = c.btr;
+      Cell *cells = c.cells;
+
+      if (reachm >= 0 && c.reach)
+        { trimx = reach.a - reach.y; trimy = reach.y; trimd = reach.d; ha = reach.ha; hb = reach.hb; }
+      else
+        { trimx = trim.a - trim.y; trimy = trim.y; trimd = trim.d; ha = trim.ha; hb = trim.hb; }
+
+      /* reverse both chains in place so they can be walked root -> head */
+      for (int which = 0; which < 2; which++)
+        { int h = which ? hb : ha, prev = -1;
+          while (h >= 0)
+            { int nx = cells[h].ptr;
+              cells[h].ptr = prev;
+              prev = h;
+              h = nx;
+            }
+          if (which) hb = prev; else ha = prev;
+        }
+
+      if (!REV)
+        { int h = ha, k = cells[h].diag, b = (mida - k) / 2, e = 0, n = 0;
+          for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
+            { Cell p = cells[h];
+              int  a = p.mark - p.diag;
+              k = p.diag;
+              atrace[n++] = (u16) (p.diff - e);
+              atrace[n++] = (u16) (a - b);
+              b = a;  e = p.diff;
+            }
+          if (b + k != trimx)
+            { atrace[n++] = (u16) (trimd - e);
+              atrace[n++] = (u16) (trimy - b);
+            }
+          else if (b != trimy && n > 0)
+            { atrace[n - 1] = (u16) (atrace[n - 1] + (trimy - b));
+              atrace[n - 2] = (u16) (atrace[n - 2] + (trimd - e));
+            }
+          at = n;
+
+          h = hb;  k = cells[h].diag;  b = (mida + k) / 2;  e = 0;  n = 0;
+          for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
+            { Cell p = cells[h];
+              int  a = p.mark + p.diag;
+              k = p.diag;
+              btrace[n++] = (u16) (p.diff - e);
+              btrace[n++] = (u16) (a - b);
+              b = a;  e = p.diff;
+            }
+          if (b - k != trimy)
+            { btrace[n++] = (u16) (trimd - e);
+              btrace[n++] = (u16) (trimx - b);
+            }
+          else if (b != trimx && n > 0)
+            { btrace[n - 1] = (u16) (btrace[n - 1] + (trimx - b));
+              btrace[n - 2] = (u16) (btrace[n - 2] + (trimd - e));
+            }
+          bt = n;
+        }
+      else
+        { const int fa = *atlen_io, fb = *btlen_io;
+          int h = ha, k = cells[h].diag, b = cells[h].mark - k, e = 0, n = 0, a, d;
+          bool walk = true;
+          if ((b + k) % TS != c.aoff)
+            { h = cells[h].ptr;
+              if (h < 0)
+                { a = trimy; d = trimd; walk = false; }
+              else
+                { k = cells[h].diag; a = cells[h].mark - k; d = cells[h].diff; }
+              if (fa == 0)
+                { atrace[--n] = (u16) (b - a);
+                  atrace[--n] = (u16) (d - e);
+                }
+              else
+                { atrace[1] = (u16) (atrace[1] + (b - a));
+                  atrace[0] = (u16) (atrace[0] + (d - e));
+                }
+              b = a;  e = d;
+            }
+          if (walk)
+            { for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
+                { k = cells[h].diag;  a = cells[h].mark - k;  d = cells[h].diff;
+                  atrace[--n] = (u16) (b - a);
+                  atrace[--n] = (u16) (d - e);
+                  b = a;  e = d;
+                }
+              if (b + k != trimx)
+                { atrace[--n] = (u16) (b - trimy);
+                  atrace[--n] = (u16) (trimd - e);
+                }
+              else if (b != trimy && (fa - n) > 0)
+                { atrace[n + 1] = (u16) (atrace[n + 1] + (b - trimy));
+                  atrace[n]     = (u16) (atrace[n] + (trimd - e));
+                }
+            }
+          at = -n;
+
+          h = hb;  k = cells[h].diag;  b = cells[h].mark + k;  e = 0;  n = 0;  walk = true;
+          if ((b - k) % TS != c.boff)
+            { h = cells[h].ptr;
+              if (h < 0)
+                { a = trimx; d = trimd; walk = false; }
+              else
+                { k = cells[h].diag; a = cells[h].mark + k; d = cells[h].diff; }
+              if (fb == 0)
+                { btrace[--n] = (u16) (b - a);
+                  btrace[--n] = (u16) (b - a);          /* sic, align.c:1843-1844 */
+                }
+              else
+                { btrace[1] = (u16) (btrace[1] + (b - a));
+                  btrace[0] = (u16) (btrace[0] + (d - e));
+                }
+              b = a;  e = d;
+            }
+          if (walk)
+            { for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
+                { k = cells[h].diag;  a = cells[h].mark + k;  d = cells[h].diff;
+                  btrace[--n] = (u16) (b - a);
+                  btrace[--n] = (u16) (d - e);
+                  b = a;  e = d;
+                }
+              if (b - k != trimy)
+                { btrace[--n] = (u16) (b - trimx);
+                  btrace[--n] = (u16) (trimd - e);
+                }
+              else if (b != trimx && (fb - n) > 0)
+                { btrace[n + 1] = (u16) (btrace[n + 1] + (b - trimx));
+                  btrace[n]     = (u16) (btrace[n] + (trimd - e));
+                }
+            }
+          bt = -n;
+        }
+      rx = trimx;  ry = trimy;  rd = trimd;
+    }
+  rx = uni(rx);  ry = uni(ry);  rd = uni(rd);  at = uni(at);  bt = uni(bt);
+  *ox = rx;  *oy = ry;  *od = rd;
+  if (!REV)
+    { *atlen_io = at;  *btlen_io = bt; }
+  else
+    { *aback = at;  *bback = bt;
+      *atlen_io += at;  *btlen_io += bt;
+    }
+  wave_mem_sync();
+}
+
+struct LaResult
+{ int abpos, bbpos, aepos, bepos, diffs;
+  int atlen, btlen;      /* lengths; traces start at atr - aback / btr - bback */
+  int aback, bback;
+};
+
+/* align.c:1904-2097 for low == hgh == diag, lbord = hbord = -1 */
+__device__ void local_alignment(WaveCtx &c, u32 flags, int diag, int anti, LaResult *r)
+{ const bool selfie = (c.aseq == c.bseq);
+  int ax, ay, ad, bx, by, bd, atlen = 0, btlen = 0, aback = 0, bback = 0;
+
+  c.minp = (selfie && diag >= 0) ? 1 : -BIG;
+  c.maxp = (selfie && diag <= 0) ? -1 : BIG;
+  c.aoff = 0;
+  c.boff = (flags & 1) ? (c.blen % c.ts) : 0;
+
+  wave_pass<0>(c, diag, anti, &ax, &ay, &ad, &atlen, &btlen, &aback, &bback);
+  wave_pass<1>(c, diag, anti, &bx, &by, &bd, &atlen, &btlen, &aback, &bback);
+
+  r->aepos = ax;  r->bepos = ay;
+  r->abpos = bx;  r->bbpos = by;
+  r->diffs = ad + bd;
+  r->atlen = atlen;  r->btlen = btlen;
+  r->aback = aback;  r->bback = bback;
+}
+
+/***** the report loop ******************************************************************/
+
+__device__ __forceinline__ u32 read_len(const DevBlock &b, u32 r) { return b.boff[r + 1] - b.boff[r] - 1; }
+
+struct SlotScratch
+{ DState *st0, *st1;
+  int    *NA, *NB;
+  Cell   *cells;
+  int    *score, *lastp, *lasta;     /* indexed by bucket, already offset by -mindiag */
+  u16    *atr, *btr;
+};
+
+__device__ __forceinline__ SlotScratch slot_scratch(const ReportArgs &a, int slot)
+{ SlotScratch s;
+  char *sb = (char *) a.state + (u64) slot * a.state_stride;
+  s.st0 = (DState *) sb;
+  s.st1 = s.st0 + a.span;
+  s.NA  = a.marks + (u64) slot * a.marks_stride;
+  s.NB  = s.NA + a.span;
+  s.cells = (Cell *) a.cells + (u64) slot * a.cell_cap;
+  int *bk = a.buckets + (u64) slot * a.bucket_stride;
+  int  mind = (-a.bblk.maxlen) >> a.binshift;
+  s.score = bk + 4 - mind;
+  s.lastp = s.score + a.bwidth;
+  s.lasta = s.lastp + a.bwidth;
+  u16 *tt = a.ttmp + (u64) slot * a.ttmp_stride;
+  s.atr = tt + a.ttmp_stride / 4;
+  s.btr = tt + a.ttmp_stride / 2 + a.ttmp_stride / 4;
+  return s;
+}
+
+/* emit one alignment: copies both traces to the pool (B trace reversed pairwise for COMP,
+ * align.c:2033-2056) and writes the record */
+__device__ void emit_record(const ReportArgs &a, const SlotScratch &s, const LaResult &r,
+                            int ar, int br, u32 item, u32 seq)
+{ const int lane = lane_id();
+  u32 ri = 0, to = 0;
+  if (lane == 0)
+    { ri = atomicAdd(&a.counters[1], 1u);
+      to = atomicAdd(&a.counters[2], (u32) (r.atlen + r.btlen));
+    }
+  ri = (u32) uni((int) ri);
+  to = (u32) uni((int) to);
+  if (ri >= a.rec_cap)
+    { if (lane == 0) atomicOr(&a.counters[3], DAMAR_ERR_RECS);
+      return;
+    }
+  if ((u64) to + (u64) (r.atlen + r.btlen) > (u64) a.tpool_cap)
+    { if (lane == 0) atomicOr(&a.counters[3], DAMAR_ERR_TPOOL);
+      return;
+    }
+  const u16 *at = s.atr - r.aback, *bt = s.btr - r.bback;
+  for (int i = lane; i < r.atlen; i += 64)
+    a.tpool[to + i] = at[i];
+  if (a.comp)
+    for (int i = lane; i < r.btlen; i += 64)
+      { int pair = i >> 1, src = (r.btlen - 2 - 2 * pair) + (i & 1);
+        a.tpool[to + r.atlen + i] = bt[src];
+      }
+  else
+    for (int i = lane; i < r.btlen; i += 64)
+      a.tpool[to + r.atlen + i] = bt[i];
+  if (lane == 0)
+    { LaRecord rec;
+      rec.abpos = r.abpos;  rec.bbpos = r.bbpos;  rec.aepos = r.aepos;  rec.bepos = r.bepos;
+      rec.diffs = r.diffs;  rec.atlen = r.atlen;  rec.btlen = r.btlen;
+      rec.aread = ar;  rec.bread = br;  rec.item = item;  rec.seq = seq;  rec.toff = to;
+      a.recs[ri] = rec;
+    }
+}
+
+/* Diagonal_Span (filter.c:2079-2110) on the A-view path just computed; lane 0 */
+__device__ void diagonal_span(const SlotScratch &s, const LaResult &r, int ts, int bshift, int *lo, int *hi)
+{ int low = 0, hgh = 0;
+  if (lane_id() == 0)
+    { const u16 *pt = s.atr - r.aback;
+      int dd, tlen = r.atlen - 2;
+      low = hgh = r.abpos - r.bbpos;
+      dd = r.aepos - r.bepos;
+      if (dd < low) low = dd; else if (dd > hgh) hgh = dd;
+      dd = (r.abpos / ts) * ts - r.bbpos;
+      for (int i = 1; i < tlen; i += 2)
+        { dd += ts - pt[i];
+          if (dd < low) low = dd; else if (dd > hgh) hgh = dd;
+        }
+      low = (low >> bshift) - 1;
+      hgh = (hgh >> bshift) + 1;
+    }
+  *lo = uni(low);
+  *hi = uni(hgh);
+}
+
+__device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item)
+{ const int  lane = lane_id();
+  const u64 *keys = a.keys;
+  const u32 *vals = a.vals;
+  const u64  pmask = (1ull << a.pbits) - 1;
+  const int  K = a.kmer, H = a.hitmin, W = a.binshift, minhit = a.minhit;
+  const int  mind = (-a.bblk.maxlen) >> W, maxd = a.ablk.maxlen >> W;
+
+  u64 nidx = a.work[item];
+  const u64 cpair = keys[nidx] >> a.pbits;
+  const int ar = (int) (cpair & ((1ull << a.abits) - 1)), br = (int) (cpair >> a.abits);
+  const int alen = (int) read_len(a.ablk, ar), blen = (int) read_len(a.bblk, br);
+  if (alen < a.hgap_min && blen < a.hgap_min)
+    return;
+
+  WaveCtx c;
+  c.aseq = a.ablk.bases + a.ablk.boff[ar];
+  c.bseq = a.bblk.bases + a.bblk.boff[br];
+  c.alen = alen;  c.blen = blen;
+  c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
+  c.score = a.score;  c.table = a.table;
+  c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
+  c.koff = blen + 8;
+  c.cells = s.cells;  c.cell_cap = a.cell_cap;
+  c.err = &a.counters[3];
+  c.atr = s.atr;  c.btr = s.btr;
+
+  u32 seq = 0;
+  int amark2 = 0;
+  int clo = BIG, chi = -BIG;          /* range of lasta buckets written for this pair */
+
+  while (nidx < a.nhits && (keys[nidx] >> a.pbits) == cpair)      /* A-panels, filter.c:2251 */
+    { const int amark = amark2 + PANEL_SIZE;
+      amark2 = amark - PANEL_OVERLAP;
+      const u64 lidx = nidx;
+      u64 end = lidx, h2 = lidx;
+      /* consume hits while the pair continues and the hit just consumed has apos <= amark */
+      for (u64 base = lidx; ; base += 64)
+        { u64  f = base + lane;
+          bool in = f < a.nhits && (keys[f] >> a.pbits) == cpair;
+          int  ap = in ? (int) (keys[f] & pmask) : 0;
+          bool nextsame = (f + 1 < a.nhits) && ((keys[f + 1] >> a.pbits) == cpair);
+          bool stop = in && !(nextsame && ap <= amark);
+          u64  le = __ballot(in && ap <= amark2);
+          u64  sm = __ballot(stop);
+          if (sm)
+            { int l = __ffsll((long long) sm) - 1;
+              end = base + l + 1;
+              le &= (l == 63) ? ~0ull : ((1ull << (l + 1)) - 1);
+              if (le) h2 = base + (63 - __clzll(le)) + 1;
+              break;
+            }
+          if (le) h2 = base + (63 - __clzll(le)) + 1;
+          if (!__any(in))            /* cannot happen: a run always ends with a stop */
+            { end = base; break; }
+        }
+      nidx = end;
+
+      if (end - lidx >= (u64) minhit)
+        { /* pass 1: bucket scores (filter.c:2268-2277) */
+          for (u64 base = lidx; base < end; base += 64)
+            { u64  f = base + lane;
+              bool in = f < end;
+              int  ap = in ? (int) (keys[f] & pmask) : 0;
+              int  d  = in ? (((int) vals[f]) >> W) : BIG;
+              int  prev = in ? s.lastp[d] : 0;
+              bool last = in;
+              for (int j = 0; j < 64; j++)
+                { int dj = bcast_i(d, j), aj = bcast_i(ap, j);
+                  if (dj == d)
+                    { if (j < lane) prev = aj;
+                      if (j > lane) last = false;
+                    }
+                }
+              if (in)
+                { int add = (ap - prev >= K) ? K : ap - prev;
+                  atomicAdd(&s.score[d], add);
+                  if (last)
+                    s.lastp[d] = ap;
+                }
+              wave_mem_sync();
+            }
+
+          /* pass 2: seeds in order (filter.c:2283-2405) */
+          for (u64 base = lidx; base < end; base += 64)
+            { u64  f = base + lane;
+              bool in = f < end;
+              int  ap = in ? (int) (keys[f] & pmask) : 0;
+              int  dg = in ? (int) vals[f] : 0;
+              int  d  = dg >> W;
+              bool hot = false;
+              if (in)
+                { int sc = s.score[d];
+                  hot = (sc + s.score[d + 1] >= H) || (sc + s.score[d - 1] >= H);
+                }
+              u64 todo = __ballot(hot);
+              while (todo)
+                { u64 fire = __ballot(hot && ((todo >> lane) & 1) && ap > s.lasta[d]);
+                  if (!fire)
+                    break;
+                  int l = __ffsll((long long) fire) - 1;
+                  todo &= (l == 63) ? 0ull : ~((1ull << (l + 1)) - 1);
+                  const int sap = bcast_i(ap, l), sdg = bcast_i(dg, l), sd = sdg >> W;
+                  const int sbp = sap - sdg;
+                  LaResult r;
+                  int lo, hi;
+
+                  if (lane == 0) atomicAdd(&a.counters[4], 1u);
+                  local_alignment(c, (u32) a.comp, sdg, sap + sbp, &r);
+                  diagonal_span(s, r, a.tspace, W, &lo, &hi);
+                  if (sd < lo) lo = sd; else if (sd > hi) hi = sd;
+                  if (lo < mind - 1) lo = mind - 1;
+                  if (hi > maxd + 1) hi = maxd + 1;
+                  for (int q = lo + lane; q <= hi; q += 64)
+                    if (r.aepos > s.lasta[q])
+                      s.lasta[q] = r.aepos;
+                  if (lo < clo) clo = lo;
+                  if (hi > chi) chi = hi;
+                  wave_mem_sync();
+                  if ((r.aepos - r.abpos) + (r.bepos - r.bbpos) >= a.minover)
+                    emit_record(a, s, r, ar, br, item, seq++);
+                }
+            }
+
+          /* pass 3: reset the touched buckets (filter.c:2407-2411) */
+          for (u64 base = lidx; base < end; base += 64)
+            { u64 f = base + lane;
+              if (f < end)
+                { int d = ((int) vals[f]) >> W;
+                  s.score[d] = 0;
+                  s.lastp[d] = 0;
+                }
+            }
+          wave_mem_sync();
+        }
+      nidx = h2;
+    }
+
+  /* filter.c:2417-2432 leaves lasta all zero again */
+  if (clo <= chi)
+    for (int q = clo + lane; q <= chi; q += 64)
+      s.lasta[q] = 0;
+  wave_mem_sync();
+}
+
+__global__ __launch_bounds__(64)
+void report_kernel(ReportArgs a)
+{ const int slot = blockIdx.x;
+  const SlotScratch s = slot_scratch(a, slot);
+  for (;;)
+    { u32 item = 0;
+      if (lane_id() == 0)
+        item = atomicAdd(&a.counters[0], 1u);
+      item = (u32) uni((int) item);
+      if (item >= a.nwork)
+        break;
+      process_pair(a, s, item);
+    }
+}
+
+void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st)
+{ if (a->nwork == 0)
+    return;
+  hipLaunchKernelGGL(report_kernel, dim3(nslots), dim3(64), 0, st, *a);
+}
+
+/* batch Local_Alignment (tests): one wave per task, result always emitted */
+__global__ __launch_bounds__(64)
+void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
+{ const int slot = blockIdx.x;
+  const SlotScratch s = slot_scratch(a, slot);
+  for (;;)
+    { u32 t = 0;
+      if (lane_id() == 0)
+        t = atomicAdd(&a.counters[0], 1u);
+      t = (u32) uni((int) t);
+      if (t >= ntasks)
+        break;
+      const LaTask tk = tasks[t];
+      WaveCtx c;
+      c.aseq = a.ablk.bases + a.ablk.boff[tk.aread];
+      c.bseq = a.bblk.bases + a.bblk.boff[tk.bread];
+      c.alen = (int) read_len(a.ablk, tk.aread);
+      c.blen = (int) read_len(a.bblk, tk.bread);
+      c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
+      c.score = a.score;  c.table = a.table;
+      c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
+      c.koff = c.blen + 8;
+      c.cells = s.cells;  c.cell_cap = a.cell_cap;
+      c.err = &a.counters[3];
+      c.atr = s.atr;  c.btr = s.btr;
+      LaResult r;
+      local_alignment(c, (u32) a.comp, tk.diag, tk.anti, &r);
+      emit_record(a, s, r, tk.aread, tk.bread, t, 0);
+    }
+}
+
+void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st)
+{ if (ntasks == 0)
+    return;
+  hipLaunchKernelGGL(la_batch_kernel, dim3(nslots), dim3(64), 0, st, *a, tasks, ntasks);
+}

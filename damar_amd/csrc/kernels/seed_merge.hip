@@ -1,0 +1,209 @@
+/* seed_merge.hip -- merge of two sorted k-mer indexes into seed pairs, and the
+ * read-pair work list for the report kernel (gfx950).
+ *
+ * Restates reference dalign/filter.c:1039-1165 (count_thread), :1170-1358
+ * (merge_thread), the slice bookkeeping of :2606-2620 / :2804-2816 and the pre-check
+ * of :2210-2220 as data-parallel passes:
+ *
+ *   merge_count : one thread per A-index entry -> how many B entries pair with it
+ *   (scan)      : hit offsets
+ *   merge_limit : self mode only, drops runs whose mutual count reaches `limit`
+ *   merge_emit  : one thread per seed pair -> 64-bit sort key + diagonal
+ *   pair_flags  : heads of (bread, aread) runs that the report loop would examine
+ *
+ * Seed layout in HBM: key = bread << (abits+pbits) | aread << pbits | apos (u64) and
+ * val = diag (int32), 12 B per seed instead of the reference's 16-byte SeedPair.
+ * Sorting stably on the key's low bits gives the reference's total order (bread,
+ * aread, apos, then bpos ascending) because emission order for one A entry is
+ * B-index order.
+ */
+#include "dev_common.h"
+#include "kernels.h"
+
+__device__ __forceinline__ u32 read_of_pos(const DevBlock &b, u32 p)
+{ u32 r = b.coarse[p >> COARSE_SHIFT];
+  while (b.boff[r + 1] <= p)
+    r += 1;
+  return r;
+}
+
+__device__ __forceinline__ void code_run(const u32 *__restrict__ codes, const u32 *__restrict__ table,
+                                         int shift, u32 c, u32 *lb, u32 *ub)
+{ u32 q = c >> shift;
+  u32 lo = table[q], hi = table[q + 1];
+  if (shift == 0)
+    { *lb = lo; *ub = hi; return; }
+  u32 a = lo, b = hi;
+  while (a < b)
+    { u32 m = (a + b) >> 1;
+      if (codes[m] < c) a = m + 1; else b = m;
+    }
+  *lb = a;
+  b = hi;
+  while (a < b)
+    { u32 m = (a + b) >> 1;
+      if (codes[m] <= c) a = m + 1; else b = m;
+    }
+  *ub = a;
+}
+
+/* number of entries of bpos[jb,ib) strictly below `bound` (bpos ascending in a run) */
+__device__ __forceinline__ u32 count_below(const u32 *__restrict__ bpos, u32 jb, u32 ib, u32 bound)
+{ u32 a = jb, b = ib;
+  while (a < b)
+    { u32 m = (a + b) >> 1;
+      if (bpos[m] < bound) a = m + 1; else b = m;
+    }
+  return a - jb;
+}
+
+__global__ __launch_bounds__(256)
+void merge_count(MergeArgs m, u32 *__restrict__ cnt, u32 *__restrict__ jbout)
+{ u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= m.alen)
+    return;
+  u32 c = m.acode[i], jb, ib, n = 0;
+  code_run(m.bcode, m.btab, m.kbits - m.btbits, c, &jb, &ib);
+  if (ib > jb)
+    { if (!m.self)
+        { u32 ja, ia;                                          /* filter.c:1334-1335 */
+          code_run(m.acode, m.atab, m.kbits - m.atbits, c, &ja, &ia);
+          if ((u64) (ia - ja) * (u64) (ib - jb) < (u64) m.limit)
+            n = ib - jb;
+        }
+      else
+        { u32 p = m.apos[i], bound;                            /* filter.c:1219-1246 */
+          if (m.identity)
+            bound = m.comp ? m.ablk.boff[read_of_pos(m.ablk, p) + 1] : p;
+          else
+            bound = m.ablk.boff[read_of_pos(m.ablk, p)];
+          n = count_below(m.bpos, jb, ib, bound);
+        }
+    }
+  cnt[i]   = n;
+  jbout[i] = jb;
+}
+
+void damar_launch_merge_count(const MergeArgs *m, u32 *cnt, u32 *jb, hipStream_t st)
+{ if (m->alen == 0)
+    return;
+  hipLaunchKernelGGL(merge_count, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, cnt, jb);
+}
+
+/* self mode: a run's mutual count is off[run end] - off[run start]; runs at or over
+ * the limit contribute nothing (filter.c:1248 `if (ct < limit)`). */
+__global__ __launch_bounds__(256)
+void merge_limit(MergeArgs m, const u32 *__restrict__ off, u64 total, u32 *__restrict__ cnt)
+{ u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= m.alen || cnt[i] == 0)
+    return;
+  u32 ja, ia;
+  code_run(m.acode, m.atab, m.kbits - m.atbits, m.acode[i], &ja, &ia);
+  u64 hi = (ia >= m.alen) ? total : (u64) off[ia];
+  if (hi - (u64) off[ja] >= (u64) m.limit)
+    cnt[i] = 0;
+}
+
+void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32 *cnt, hipStream_t st)
+{ if (m->alen == 0)
+    return;
+  hipLaunchKernelGGL(merge_limit, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, cnt);
+}
+
+__global__ __launch_bounds__(256)
+void merge_emit(MergeArgs m, const u32 *__restrict__ off, const u32 *__restrict__ jb, u64 nhits,
+                u64 *__restrict__ keys, u32 *__restrict__ vals)
+{ u64 h = (u64) blockIdx.x * 256u + threadIdx.x;
+  if (h >= nhits)
+    return;
+  /* last A entry whose first hit is <= h */
+  u32 a = 0, b = m.alen;
+  while (b - a > 1)
+    { u32 mid = (a + b) >> 1;
+      if ((u64) off[mid] <= h) a = mid; else b = mid;
+    }
+  u32 bi = jb[a] + (u32) (h - off[a]);
+  u32 pa = m.apos[a], pb = m.bpos[bi];
+  u32 ra = read_of_pos(m.ablk, pa), rb = read_of_pos(m.bblk, pb);
+  u32 xa = pa - m.ablk.boff[ra], xb = pb - m.bblk.boff[rb];
+  keys[h] = ((u64) rb << (m.abits + m.pbits)) | ((u64) ra << m.pbits) | (u64) xa;
+  vals[h] = (u32) ((int) xa - (int) xb);
+}
+
+void damar_launch_merge_emit(const MergeArgs *m, const u32 *off, const u32 *jb, u64 nhits,
+                             u64 *keys, u32 *vals, hipStream_t st)
+{ if (nhits == 0)
+    return;
+  hipLaunchKernelGGL(merge_emit, dim3((u32) ((nhits + 255) / 256)), dim3(256), 0, st, *m, off, jb, nhits, keys, vals);
+}
+
+/* flags[i] = 1 iff hit i starts a (bread,aread) run that report_thread would enter:
+ * the run has >= minhit hits (filter.c:2215: hit i+minhit-1 is the same pair) and does
+ * not start within the last minhit hits of its thread slice (filter.c:2212-2214:
+ * nidx < end - minhit).  Slices end where the reference's NTHREADS partition ends:
+ * first index >= (nhits*t)>>nshift whose bread differs from its predecessor's. */
+__global__ __launch_bounds__(256)
+void pair_flags(const u64 *__restrict__ keys, u64 nhits, int pbits, int bshift, int minhit, int nshift,
+                u32 *__restrict__ flags)
+{ __shared__ u64 send[65];
+  int nthr = 1 << nshift;
+  if ((int) threadIdx.x < nthr)
+    { int t = threadIdx.x;
+      u64 e;
+      if (t == nthr - 1)
+        e = nhits;
+      else
+        { e = (nhits * (u64) (t + 1)) >> nshift;
+          if (e > 0)
+            { u64 d = keys[e - 1] >> bshift, a = e, b = nhits;     /* first index with bread != d */
+              while (a < b)
+                { u64 mid = (a + b) >> 1;
+                  if ((keys[mid] >> bshift) == d) a = mid + 1; else b = mid;
+                }
+              e = a;
+            }
+        }
+      send[t] = e;
+    }
+  __syncthreads();
+  u64 i = (u64) blockIdx.x * 256u + threadIdx.x;
+  if (i >= nhits)
+    return;
+  u64 pr = keys[i] >> pbits;
+  u32 f = 0;
+  if ((i == 0 || (keys[i - 1] >> pbits) != pr) && i + (u64) (minhit - 1) < nhits &&
+      (keys[i + (u64) (minhit - 1)] >> pbits) == pr)
+    { f = 1;
+      for (int t = 0; t < nthr; t++)
+        { u64 e = send[t];
+          if (i < e)
+            { if (i + (u64) minhit >= e) f = 0;
+              break;
+            }
+        }
+    }
+  flags[i] = f;
+}
+
+void damar_launch_pair_flags(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
+                              u32 *flags, hipStream_t st)
+{ if (nhits == 0)
+    return;
+  if (nshift > 6)
+    nshift = 6;
+  hipLaunchKernelGGL(pair_flags, dim3((u32) ((nhits + 255) / 256)), dim3(256), 0, st, keys, nhits, pbits,
+                     abits + pbits, minhit, nshift, flags);
+}
+
+__global__ __launch_bounds__(256)
+void compact_index(const u32 *__restrict__ flags, const u32 *__restrict__ off, u64 n, u32 *__restrict__ out)
+{ u64 i = (u64) blockIdx.x * 256u + threadIdx.x;
+  if (i < n && flags[i])
+    out[off[i]] = (u32) i;
+}
+
+void damar_launch_compact_index(const u32 *flags, const u32 *off, u64 n, u32 *out, hipStream_t st)
+{ if (n == 0)
+    return;
+  hipLaunchKernelGGL(compact_index, dim3((u32) ((n + 255) / 256)), dim3(256), 0, st, flags, off, n, out);
+}

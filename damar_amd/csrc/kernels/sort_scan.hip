@@ -1,0 +1,249 @@
+/* sort_scan.hip -- device-wide exclusive scan and stable LSD radix sort of (key, u32)
+ * pairs for gfx950.
+ *
+ * Replaces the reference's threaded 16-byte-record radix sort (dalign/filter.c:230-435
+ * lex_thread / lex_sort), which it uses for the k-mer index (filter.c:854) and for the
+ * seed pairs (filter.c:2776).  Both orders the reference produces are total orders on
+ * (key, original position), so any stable sort on the same key bits yields the same
+ * sequence.
+ *
+ * Layout: keys and payloads are separate arrays (SoA) so every pass streams
+ * 4/8-byte keys and 4-byte payloads with fully coalesced 256-B wave accesses instead
+ * of the reference's 16-byte AoS records.  HBM-bound: per pass the histogram kernel
+ * reads the keys once, the scatter kernel reads keys+payloads once and writes them
+ * once; the scatter stages each 4096-item tile through LDS so that every digit's
+ * items leave the CU as one contiguous run.
+ */
+#include "dev_common.h"
+#include "kernels.h"
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS   16
+#define SCAN_TILE    (SCAN_THREADS * SCAN_ITEMS)
+
+/***** exclusive scan of u32 -> u32, total returned as u64 *********************************/
+
+__device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32 *lds4, u32 *total)
+{ int l = lane_id(), w = threadIdx.x >> 6;
+  u32 inc = (u32) wave_incl_scan_i((int) v);
+  if (l == 63) lds4[w] = inc;
+  __syncthreads();
+  u32 base = 0, tot = 0;
+  for (int i = 0; i < 4; i++)
+    { u32 s = lds4[i];
+      if (i < w) base += s;
+      tot += s;
+    }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS)
+void scan_tile_sums(const u32 *__restrict__ in, u64 n, u32 *__restrict__ tsum)
+{ __shared__ u32 lds4[4];
+  u64 base = (u64) blockIdx.x * SCAN_TILE + (u64) threadIdx.x * SCAN_ITEMS;
+  u32 s = 0;
+  for (int i = 0; i < SCAN_ITEMS; i++)
+    if (base + i < n) s += in[base + i];
+  u32 tot;
+  block_excl_scan_256(s, lds4, &tot);
+  if (threadIdx.x == 0) tsum[blockIdx.x] = tot;
+}
+
+/* one block: exclusive scan of the tile sums in place (64-bit carry), total to *total */
+__global__ __launch_bounds__(SCAN_THREADS)
+void scan_tile_offsets(u32 *__restrict__ tsum, u32 ntiles, u64 *__restrict__ total)
+{ __shared__ u32 lds4[4];
+  u64 carry = 0;
+  for (u32 b = 0; b < ntiles; b += SCAN_THREADS)
+    { u32 i = b + threadIdx.x;
+      u32 v = (i < ntiles) ? tsum[i] : 0, tot;
+      u32 ex = block_excl_scan_256(v, lds4, &tot);
+      if (i < ntiles) tsum[i] = (u32) (carry + ex);
+      carry += tot;
+    }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS)
+void scan_tile_apply(const u32 *__restrict__ in, u32 *__restrict__ out, u64 n, const u32 *__restrict__ toff)
+{ __shared__ u32 lds4[4];
+  u64 base = (u64) blockIdx.x * SCAN_TILE + (u64) threadIdx.x * SCAN_ITEMS;
+  u32 v[SCAN_ITEMS], s = 0;
+  for (int i = 0; i < SCAN_ITEMS; i++)
+    { v[i] = (base + i < n) ? in[base + i] : 0;
+      s += v[i];
+    }
+  u32 tot;
+  u32 ex = block_excl_scan_256(s, lds4, &tot) + toff[blockIdx.x];
+  for (int i = 0; i < SCAN_ITEMS; i++)
+    { if (base + i < n) out[base + i] = ex;
+      ex += v[i];
+    }
+}
+
+size_t damar_scan_workspace_bytes(u64 n)
+{ u64 ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  return ((((size_t) (ntiles + 1) * sizeof(u32)) + 63) & ~(size_t) 63) + 64;   /* last 64 B: total */
+}
+
+/* out may alias in.  *total_dev (device u64) receives the grand total. */
+void damar_exclusive_scan_u32(const u32 *in, u32 *out, u64 n, void *work, u64 *total_dev, hipStream_t st)
+{ u32 ntiles = (u32) ((n + SCAN_TILE - 1) / SCAN_TILE);
+  u32 *tsum = (u32 *) work;
+  if (n == 0)
+    { HIP_CHECK(hipMemsetAsync(total_dev, 0, sizeof(u64), st));
+      return;
+    }
+  hipLaunchKernelGGL(scan_tile_sums, dim3(ntiles), dim3(SCAN_THREADS), 0, st, in, n, tsum);
+  hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, st, tsum, ntiles, total_dev);
+  hipLaunchKernelGGL(scan_tile_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, st, in, out, n, tsum);
+}
+
+/***** radix sort ******************************************************************************/
+
+#define RS_THREADS 256
+#define RS_ROUNDS  16
+#define RS_TILE    (RS_THREADS * RS_ROUNDS)     /* 4096 items per workgroup            */
+#define RS_WSPAN   (RS_TILE / 4)                /* contiguous items owned by one wave  */
+
+template <typename KeyT>
+__global__ __launch_bounds__(RS_THREADS)
+void radix_hist(const KeyT *__restrict__ keys, u64 n, int shift, u32 mask,
+                u32 *__restrict__ ghist, u32 ntiles)
+{ __shared__ u32 hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  u64 base = (u64) blockIdx.x * RS_TILE;
+  for (int r = 0; r < RS_ROUNDS; r++)
+    { u64 i = base + (u64) r * RS_THREADS + threadIdx.x;
+      if (i < n)
+        atomicAdd(&hist[(u32) (keys[i] >> shift) & mask], 1u);
+    }
+  __syncthreads();
+  ghist[(u64) threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+/* Stable scatter of one tile.  Wave w owns items [w*1024,(w+1)*1024) of the tile in
+ * rounds of 64 consecutive items, so (wave, round, lane) order == input order. */
+template <typename KeyT>
+__global__ __launch_bounds__(RS_THREADS)
+void radix_scatter(const KeyT *__restrict__ kin, const u32 *__restrict__ vin,
+                   KeyT *__restrict__ kout, u32 *__restrict__ vout, u64 n,
+                   int shift, u32 mask, const u32 *__restrict__ gscan, u32 ntiles)
+{ __shared__ KeyT skey[RS_TILE];
+  __shared__ u32  sval[RS_TILE];
+  __shared__ u32  cnt[4][256];
+  __shared__ u32  dstart[256];
+  __shared__ u32  gadj[256];
+  __shared__ u32  lds4[4];
+
+  const int l = lane_id(), w = threadIdx.x >> 6;
+  const u64 tbase = (u64) blockIdx.x * RS_TILE;
+  const u64 wbase = tbase + (u64) w * RS_WSPAN;
+
+  for (int i = 0; i < 4; i++)
+    cnt[i][threadIdx.x] = 0;
+  __syncthreads();
+
+  KeyT key[RS_ROUNDS];
+  u32  val[RS_ROUNDS];
+  u32  rnk[RS_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; r++)
+    { u64  i = wbase + (u64) r * 64 + l;
+      bool ok = i < n;
+      key[r] = ok ? kin[i] : (KeyT) 0;
+      val[r] = ok ? vin[i] : 0u;
+    }
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; r++)
+    { u64  i = wbase + (u64) r * 64 + l;
+      bool ok = i < n;
+      u32  d = (u32) (key[r] >> shift) & mask;
+      u64  peers = __ballot(ok);
+#pragma unroll
+      for (int b = 0; b < 8; b++)
+        { bool bit = (d >> b) & 1;
+          u64  m = __ballot(bit);
+          peers &= bit ? m : ~m;
+        }
+      u32 before = cnt[w][d];
+      u32 mine   = (u32) __popcll(peers & lanes_below(l));
+      rnk[r] = before + mine;
+      if (ok && mine == 0)
+        cnt[w][d] = before + (u32) __popcll(peers);
+    }
+  __syncthreads();
+
+  { u32 c0 = cnt[0][threadIdx.x], c1 = cnt[1][threadIdx.x], c2 = cnt[2][threadIdx.x], c3 = cnt[3][threadIdx.x];
+    u32 tot = c0 + c1 + c2 + c3, all;
+    u32 ex = block_excl_scan_256(tot, lds4, &all);
+    cnt[0][threadIdx.x] = 0;
+    cnt[1][threadIdx.x] = c0;
+    cnt[2][threadIdx.x] = c0 + c1;
+    cnt[3][threadIdx.x] = c0 + c1 + c2;
+    dstart[threadIdx.x] = ex;
+    gadj[threadIdx.x]   = gscan[(u64) threadIdx.x * ntiles + blockIdx.x] - ex;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; r++)
+    { u64 i = wbase + (u64) r * 64 + l;
+      if (i < n)
+        { u32 d  = (u32) (key[r] >> shift) & mask;
+          u32 lp = dstart[d] + cnt[w][d] + rnk[r];
+          skey[lp] = key[r];
+          sval[lp] = val[r];
+        }
+    }
+  __syncthreads();
+
+  u32 have = (n - tbase < (u64) RS_TILE) ? (u32) (n - tbase) : (u32) RS_TILE;
+  for (u32 i = threadIdx.x; i < have; i += RS_THREADS)
+    { KeyT k = skey[i];
+      u32  d = (u32) (k >> shift) & mask;
+      u64  g = (u64) gadj[d] + i;
+      kout[g] = k;
+      vout[g] = sval[i];
+    }
+}
+
+size_t damar_sort_workspace_bytes(u64 n)
+{ u64 ntiles = (n + RS_TILE - 1) / RS_TILE;
+  return (size_t) (256 * ntiles) * sizeof(u32) + damar_scan_workspace_bytes(256 * ntiles) + 256;
+}
+
+/* Sorts on key bits [0, nbits).  Ping-pongs between (k0,v0) and (k1,v1); returns 0 if
+ * the result is in (k0,v0), 1 if in (k1,v1). */
+template <typename KeyT>
+static int radix_sort_impl(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int nbits,
+                           void *work, hipStream_t st)
+{ u32  ntiles = (u32) ((n + RS_TILE - 1) / RS_TILE);
+  u32 *ghist = (u32 *) work;
+  char *swork = (char *) work + (((size_t) 256 * ntiles * sizeof(u32) + 63) & ~(size_t) 63);
+  u64 *tot = (u64 *) (swork + damar_scan_workspace_bytes((u64) 256 * ntiles) - 64);
+  int  side = 0;
+  if (n == 0)
+    return 0;
+  for (int shift = 0; shift < nbits; shift += 8)
+    { int  bits = (nbits - shift < 8) ? nbits - shift : 8;
+      u32  mask = (1u << bits) - 1;
+      KeyT *ki = side ? k1 : k0, *ko = side ? k0 : k1;
+      u32  *vi = side ? v1 : v0, *vo = side ? v0 : v1;
+      hipLaunchKernelGGL(radix_hist<KeyT>, dim3(ntiles), dim3(RS_THREADS), 0, st, ki, n, shift, mask, ghist, ntiles);
+      damar_exclusive_scan_u32(ghist, ghist, (u64) 256 * ntiles, swork, tot, st);
+      hipLaunchKernelGGL(radix_scatter<KeyT>, dim3(ntiles), dim3(RS_THREADS), 0, st,
+                         ki, vi, ko, vo, n, shift, mask, ghist, ntiles);
+      side ^= 1;
+    }
+  return side;
+}
+
+int damar_radix_sort_u32(u32 *k0, u32 *v0, u32 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st)
+{ return radix_sort_impl<u32>(k0, v0, k1, v1, n, nbits, work, st); }
+
+int damar_radix_sort_u64(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st)
+{ return radix_sort_impl<u64>(k0, v0, k1, v1, n, nbits, work, st); }

@@ -1,0 +1,856 @@
+/* shim.hip -- the C-ABI of libdamar_hip.so: the reference's three-function filter
+ * interface (dalign/filter.h:64-70) implemented on one MI355X.
+ *
+ *   Set_Filter_Params  filter.c:171-201
+ *   Sort_Kmers         filter.c:753-994   -> damar_block_upload + damar_index_build
+ *   Match_Filter       filter.c:2519-2929 -> damar_match (+ ownership of btable)
+ *
+ * Everything compute-heavy is a HIP kernel (kernels/ *.hip); this file owns device
+ * memory, orders the launches on one stream, copies the alignment records back and
+ * runs the per-read-pair host tail (host/redundancy.c -> host/las.c).  There is no CPU
+ * fallback: without a HIP device every entry point fails loudly.
+ */
+#include <algorithm>
+#include <vector>
+#include <string.h>
+#include <unistd.h>
+
+#include "kernels/dev_common.h"
+#include "kernels/kernels.h"
+
+extern "C" {
+#include "damar_filter.h"
+#include "damar_hip.h"
+#include "host/damar_host.h"
+}
+
+#define MAXGRAM 10000          /* filter.c:71 */
+
+/***** globals shared with the caller (filter.h:54-62 / daligner.c:131-140) *****************/
+
+extern "C" {
+int    BIASED    = 0;
+int    VERBOSE   = 0;
+int    MINOVER   = 2000;       /* 2 * (-l 1000), daligner.c:695, 861 */
+int    HGAP_MIN  = 0;
+int    SYMMETRIC = 1;
+int    IDENTITY  = 0;
+uint64 MEM_LIMIT    = ~0ull;   /* replaced by the physical memory size at first use */
+uint64 MEM_PHYSICAL = ~0ull;
+}
+
+static int P_kmer = 14, P_hitmin = 35, P_binshift = 6, P_suppress = 0, P_nshift = 2;
+
+extern "C" int Set_Filter_Params(int kmer, int binshift, int suppress, int hitmin, int nthreads)
+{ if (kmer <= 1)
+    return 1;
+  P_kmer = kmer;  P_binshift = binshift;  P_suppress = suppress;  P_hitmin = hitmin;
+  P_nshift = 0;
+  while ((2 << P_nshift) <= nthreads)
+    P_nshift += 1;
+  return 0;
+}
+
+/***** device state ***************************************************************************/
+
+static int          G_ready = 0;
+static hipStream_t  G_st;
+static hipDeviceProp_t G_prop;
+static hipEvent_t   G_ev[16];
+static double       G_ms[DAMAR_T_COUNT];
+static int64        G_cnt[8];
+
+struct Arena { char *base; size_t cap, top; };
+static Arena G_work = { NULL, 0, 0 };       /* per-call temporaries, grow-only */
+static Arena G_hits = { NULL, 0, 0 };       /* seed pairs of the current Match_Filter   */
+
+static void *dmalloc(size_t n)
+{ void *p = NULL;
+  HIP_CHECK(hipMalloc(&p, n ? n : 16));
+  return p;
+}
+
+static void arena_reserve(Arena *a, size_t need)
+{ if (need <= a->cap)
+    { a->top = 0;
+      return;
+    }
+  if (a->base)
+    { HIP_CHECK(hipStreamSynchronize(G_st));
+      HIP_CHECK(hipFree(a->base));
+    }
+  a->cap  = need + (need >> 3) + (1u << 20);
+  a->base = (char *) dmalloc(a->cap);
+  a->top  = 0;
+}
+
+static void *arena_take(Arena *a, size_t n)
+{ size_t at = (a->top + 255) & ~(size_t) 255;
+  if (at + n > a->cap)
+    { fprintf(stderr, "damar: internal error, device arena overflow (%zu + %zu > %zu)\n", at, n, a->cap);
+      exit(1);
+    }
+  a->top = at + n;
+  return a->base + at;
+}
+
+static size_t pad256(size_t n) { return (n + 511) & ~(size_t) 255; }
+
+extern "C" int damar_hip_init(int device)
+{ int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    { fprintf(stderr, "damar: FATAL: no HIP device visible (%s); libdamar_hip has no CPU fallback\n",
+              hipGetErrorString(e));
+      exit(1);
+    }
+  if (device < 0 || device >= ndev)
+    { fprintf(stderr, "damar: FATAL: device %d requested, %d present\n", device, ndev);
+      exit(1);
+    }
+  HIP_CHECK(hipSetDevice(device));
+  HIP_CHECK(hipGetDeviceProperties(&G_prop, device));
+  if (!G_ready)
+    { HIP_CHECK(hipStreamCreate(&G_st));
+      for (int i = 0; i < 16; i++)
+        HIP_CHECK(hipEventCreate(&G_ev[i]));
+      if (MEM_PHYSICAL == ~0ull)
+        { uint64 phys = (uint64) sysconf(_SC_PHYS_PAGES) * (uint64) sysconf(_SC_PAGESIZE);
+          if (MEM_LIMIT == ~0ull)
+            MEM_LIMIT = phys;
+          MEM_PHYSICAL = phys;
+        }
+      G_ready = 1;
+    }
+  return ndev;
+}
+
+static void ensure_init(void)
+{ if (!G_ready)
+    { const char *d = getenv("DAMAR_DEVICE");
+      damar_hip_init(d ? atoi(d) : 0);
+    }
+}
+
+extern "C" const char *damar_hip_device_name(void)
+{ ensure_init();
+  return G_prop.name;
+}
+
+static int G_debug = -1;
+/* DAMAR_DEBUG=1: synchronise after every stage and name it on stderr, so that a device
+ * fault can be attributed to the kernel that caused it. */
+static void stage(const char *name)
+{ if (G_debug < 0)
+    G_debug = (getenv("DAMAR_DEBUG") != NULL);
+  if (G_debug)
+    { hipError_t e = hipStreamSynchronize(G_st);
+      fprintf(stderr, "[damar] stage %-14s %s\n", name, hipGetErrorName(e));
+      fflush(stderr);
+    }
+}
+static void  tick(int i)            { HIP_CHECK(hipEventRecord(G_ev[i], G_st)); }
+static float lap(int i, int j)      { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, G_ev[i], G_ev[j])); return ms; }
+
+extern "C" void damar_last_timings(double *ms)  { memcpy(ms, G_ms, sizeof(G_ms)); }
+extern "C" void damar_last_counters(int64 *c)   { memcpy(c, G_cnt, sizeof(G_cnt)); }
+
+/***** blocks ************************************************************************************/
+
+struct damar_dev_block
+{ DevBlock d;
+  u8  *bases_alloc;        /* starts one byte before d.bases (the leading terminator) */
+  u32 *boff, *coarse;
+  int  nreads;
+};
+
+extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
+{ ensure_init();
+  damar_dev_block *b = (damar_dev_block *) calloc(1, sizeof(damar_dev_block));
+  int    n = block->nreads;
+  int64  total = block->reads[n].boff;
+  if (total > 0x7fffffffll)
+    { fprintf(stderr, "damar: Fatal error, DB blocks are greater than 2Gbp!\n");   /* filter.c:794-798 */
+      exit(1);
+    }
+  std::vector<u32> boff((size_t) n + 1);
+  for (int i = 0; i <= n; i++)
+    boff[i] = (u32) block->reads[i].boff;
+  size_t nq = ((size_t) total >> COARSE_SHIFT) + 2;
+  std::vector<u32> coarse(nq);
+  { u32 r = 0;
+    for (size_t q = 0; q < nq; q++)
+      { u64 p = (u64) q << COARSE_SHIFT;
+        while (r + 1 < (u32) n && (u64) boff[r + 1] <= p)
+          r += 1;
+        coarse[q] = r;
+      }
+  }
+  b->bases_alloc = (u8 *) dmalloc((size_t) total + 64);
+  b->boff   = (u32 *) dmalloc(sizeof(u32) * ((size_t) n + 1));
+  b->coarse = (u32 *) dmalloc(sizeof(u32) * nq);
+  HIP_CHECK(hipMemcpyAsync(b->bases_alloc, ((const char *) block->bases) - 1, (size_t) total + 1,
+                           hipMemcpyHostToDevice, G_st));
+  HIP_CHECK(hipMemcpyAsync(b->boff, boff.data(), sizeof(u32) * ((size_t) n + 1), hipMemcpyHostToDevice, G_st));
+  HIP_CHECK(hipMemcpyAsync(b->coarse, coarse.data(), sizeof(u32) * nq, hipMemcpyHostToDevice, G_st));
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  b->d.bases  = b->bases_alloc + 1;
+  b->d.boff   = b->boff;
+  b->d.coarse = b->coarse;
+  b->d.nreads = (u32) n;
+  b->d.total  = (u32) total;
+  b->d.maxlen = block->maxlen;
+  b->nreads   = n;
+  return b;
+}
+
+extern "C" void damar_block_free(damar_dev_block *b)
+{ if (b == NULL)
+    return;
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  HIP_CHECK(hipFree(b->bases_alloc));
+  HIP_CHECK(hipFree(b->boff));
+  HIP_CHECK(hipFree(b->coarse));
+  free(b);
+}
+
+/***** index **************************************************************************************/
+
+struct damar_dev_index
+{ damar_dev_block *blk;
+  int   own_block;
+  u32  *codes, *pos, *table;
+  u32   n;
+  int   kbits, tbits;
+};
+
+static int ilog2_ceil(u64 n)
+{ int b = 0;
+  while ((1ull << b) < n)
+    b += 1;
+  return b;
+}
+
+extern "C" damar_dev_index *damar_index_build(damar_dev_block *blk, int own_block, int *len)
+{ ensure_init();
+  const int K = P_kmer;
+  if (K > 16)
+    { fprintf(stderr, "damar: FATAL: -k%d: the device index holds 2k <= 32 code bits (k <= 16) in this build\n", K);
+      exit(1);
+    }
+  if (BIASED)
+    { fprintf(stderr, "damar: FATAL: -b (biased k-mers, filter.c:549-688) is not built yet\n");
+      exit(1);
+    }
+  int64 nk64 = (int64) blk->d.total - (int64) K * blk->nreads;
+  if (nk64 <= 0)
+    { *len = 0;
+      if (own_block)
+        damar_block_free(blk);
+      return NULL;
+    }
+  const u32 nk = (u32) nk64;
+  const int kbits = 2 * K;
+  const int npass = (kbits + 7) / 8;
+  damar_dev_index *ix = (damar_dev_index *) calloc(1, sizeof(damar_dev_index));
+  ix->blk = blk;  ix->own_block = own_block;  ix->kbits = kbits;
+  ix->codes = (u32 *) dmalloc(sizeof(u32) * (size_t) nk);
+  ix->pos   = (u32 *) dmalloc(sizeof(u32) * (size_t) nk);
+
+  size_t swb = damar_sort_workspace_bytes(nk);
+  arena_reserve(&G_work, 4 * pad256(sizeof(u32) * (size_t) nk) + pad256(swb) + (1 << 16));
+  u32 *tk = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
+  u32 *tv = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
+  void *sw = arena_take(&G_work, swb);
+
+  /* the sort ping-pongs: start on the side that makes it end in the index's own arrays */
+  u32 *k0 = (npass & 1) ? tk : ix->codes, *v0 = (npass & 1) ? tv : ix->pos;
+  u32 *k1 = (npass & 1) ? ix->codes : tk, *v1 = (npass & 1) ? ix->pos : tv;
+
+  tick(0);
+  damar_launch_kmer_tuples(&blk->d, K, nk, k0, v0, G_st);
+  tick(1);
+  int side = damar_radix_sort_u32(k0, v0, k1, v1, nk, kbits, sw, G_st);
+  tick(2);
+  if ((side ? k1 : k0) != ix->codes)
+    { fprintf(stderr, "damar: internal error, sort ended on the wrong side\n");
+      exit(1);
+    }
+  u32 n = nk;
+  ix->tbits = std::min(kbits, std::max(8, std::min(24, ilog2_ceil(nk) - 2)));
+  ix->table = (u32 *) dmalloc(sizeof(u32) * (((size_t) 1 << ix->tbits) + 2));
+  damar_launch_code_table(ix->codes, n, kbits, ix->tbits, ix->table, G_st);
+
+  if (P_suppress > 0)                       /* filter.c:890-939 */
+    { u32 *keep = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
+      u32 *off  = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
+      void *scw = arena_take(&G_work, damar_scan_workspace_bytes(nk));
+      u64 *tot  = (u64 *) arena_take(&G_work, 64);
+      u64  kept = 0;
+      damar_launch_suppress_flags(ix->codes, n, ix->table, kbits, ix->tbits, P_suppress, keep, G_st);
+      damar_exclusive_scan_u32(keep, off, n, scw, tot, G_st);
+      damar_launch_compact_pairs(ix->codes, ix->pos, keep, off, n, tk, tv, G_st);
+      HIP_CHECK(hipMemcpyAsync(&kept, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      n = (u32) kept;
+      HIP_CHECK(hipMemcpyAsync(ix->codes, tk, sizeof(u32) * (size_t) n, hipMemcpyDeviceToDevice, G_st));
+      HIP_CHECK(hipMemcpyAsync(ix->pos, tv, sizeof(u32) * (size_t) n, hipMemcpyDeviceToDevice, G_st));
+      if (n > 0)
+        damar_launch_code_table(ix->codes, n, kbits, ix->tbits, ix->table, G_st);
+    }
+  tick(3);
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  G_ms[DAMAR_T_TUPLES] = lap(0, 1);
+  G_ms[DAMAR_T_KSORT]  = lap(1, 2);
+  G_ms[DAMAR_T_TABLE]  = lap(2, 3);
+  ix->n = n;
+  if (VERBOSE)
+    { printf("\n   Kmer count = %u\n   Index occupies %.2fGb of HBM\n", n, (8. * n) / 1073741824.);
+      fflush(stdout);
+    }
+  if (n == 0)
+    { damar_index_free(ix);
+      *len = 0;
+      return NULL;
+    }
+  *len = (int) n;
+  return ix;
+}
+
+extern "C" void damar_index_free(damar_dev_index *ix)
+{ if (ix == NULL)
+    return;
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  HIP_CHECK(hipFree(ix->codes));
+  HIP_CHECK(hipFree(ix->pos));
+  if (ix->table)
+    HIP_CHECK(hipFree(ix->table));
+  if (ix->own_block)
+    damar_block_free(ix->blk);
+  free(ix);
+}
+
+extern "C" void damar_index_download(const damar_dev_index *ix, void *out)
+{ struct KP { uint64 code; int rpos; int read; } *kp = (KP *) out;
+  std::vector<u32> codes(ix->n), pos(ix->n), boff((size_t) ix->blk->nreads + 1);
+  HIP_CHECK(hipMemcpy(codes.data(), ix->codes, sizeof(u32) * (size_t) ix->n, hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemcpy(pos.data(), ix->pos, sizeof(u32) * (size_t) ix->n, hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemcpy(boff.data(), ix->blk->boff, sizeof(u32) * boff.size(), hipMemcpyDeviceToHost));
+  for (u32 i = 0; i < ix->n; i++)
+    { u32 r = (u32) (std::upper_bound(boff.begin(), boff.end(), pos[i]) - boff.begin()) - 1;
+      kp[i].code = codes[i];
+      kp[i].rpos = (int) (pos[i] - boff[r]);
+      kp[i].read = (int) r;
+    }
+}
+
+extern "C" void *Sort_Kmers(HITS_DB *block, int *len)
+{ if (block->tracks != NULL)
+    { fprintf(stderr, "damar: FATAL: mask tracks (-m, filter.c:474-526) are not built yet\n");
+      exit(1);
+    }
+  damar_dev_block *b = damar_block_upload(block);
+  return (void *) damar_index_build(b, 1, len);
+}
+
+/***** report scratch ******************************************************************************/
+
+struct ReportScratch
+{ int   nslots, span, bwidth;
+  u32   cell_cap;
+  u32   ttmp_stride;
+  void *state;  int *marks;  void *cells;  int *buckets;  u16 *ttmp;
+  u64   state_stride, marks_stride, bucket_stride;
+  short *tables;             /* SCORE then TABLE */
+  const void *tables_of;     /* host spec they were copied from */
+  u32  *counters;
+  LaRecord *recs;  u32 rec_cap;
+  u16  *tpool;     u32 tpool_cap;
+};
+static ReportScratch RS = {};
+
+static int default_slots(void)
+{ const char *e = getenv("DAMAR_SLOTS");
+  if (e && atoi(e) > 0)
+    return atoi(e);
+  return G_prop.multiProcessorCount * 8;
+}
+
+static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 cell_cap)
+{ int span   = amax + bmax + 64;
+  int bwidth = (amax >> binshift) - ((-bmax) >> binshift) + 1;
+  int mtp    = 2 * (std::max(amax, bmax) / tspace + 2) + 8;
+  u32 tstr   = (u32) (4 * mtp + 32);
+  int nslots = default_slots();
+  if (RS.nslots != nslots || RS.span < span || RS.bwidth < bwidth || RS.cell_cap < cell_cap || RS.ttmp_stride < tstr)
+    { HIP_CHECK(hipStreamSynchronize(G_st));
+      if (RS.state)   { HIP_CHECK(hipFree(RS.state)); HIP_CHECK(hipFree(RS.marks)); HIP_CHECK(hipFree(RS.cells));
+                        HIP_CHECK(hipFree(RS.buckets)); HIP_CHECK(hipFree(RS.ttmp)); }
+      RS.nslots = nslots;
+      RS.span   = std::max(RS.span, span);
+      RS.bwidth = std::max(RS.bwidth, bwidth);
+      RS.cell_cap = std::max(RS.cell_cap, cell_cap);
+      RS.ttmp_stride = std::max(RS.ttmp_stride, tstr);
+      RS.state_stride  = damar_report_state_stride(RS.span);
+      RS.marks_stride  = (u64) 2 * RS.span;
+      RS.bucket_stride = (u64) 3 * RS.bwidth + 16;
+      RS.state   = dmalloc((size_t) RS.state_stride * nslots);
+      RS.marks   = (int *) dmalloc(sizeof(int) * (size_t) RS.marks_stride * nslots);
+      RS.cells   = dmalloc((size_t) 16 * RS.cell_cap * nslots);
+      RS.buckets = (int *) dmalloc(sizeof(int) * (size_t) RS.bucket_stride * nslots);
+      RS.ttmp    = (u16 *) dmalloc(sizeof(u16) * (size_t) RS.ttmp_stride * nslots);
+      HIP_CHECK(hipMemsetAsync(RS.state, 0, (size_t) RS.state_stride * nslots, G_st));
+      HIP_CHECK(hipMemsetAsync(RS.marks, 0, sizeof(int) * (size_t) RS.marks_stride * nslots, G_st));
+    }
+  if (RS.counters == NULL)
+    { RS.counters = (u32 *) dmalloc(64);
+      RS.tables   = (short *) dmalloc(sizeof(short) * 65536);
+    }
+  HIP_CHECK(hipMemsetAsync(RS.buckets, 0, sizeof(int) * (size_t) RS.bucket_stride * RS.nslots, G_st));
+}
+
+static void scratch_outputs(u32 rec_cap, u32 tpool_cap)
+{ if (RS.rec_cap < rec_cap)
+    { HIP_CHECK(hipStreamSynchronize(G_st));
+      if (RS.recs) HIP_CHECK(hipFree(RS.recs));
+      RS.rec_cap = rec_cap + (rec_cap >> 2);
+      RS.recs = (LaRecord *) dmalloc(sizeof(LaRecord) * (size_t) RS.rec_cap);
+    }
+  if (RS.tpool_cap < tpool_cap)
+    { HIP_CHECK(hipStreamSynchronize(G_st));
+      if (RS.tpool) HIP_CHECK(hipFree(RS.tpool));
+      RS.tpool_cap = tpool_cap + (tpool_cap >> 2);
+      RS.tpool = (u16 *) dmalloc(sizeof(u16) * (size_t) RS.tpool_cap);
+    }
+}
+
+static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const damar_dev_block *bb,
+                             int comp, int self, Align_Spec *spec)
+{ memset(ra, 0, sizeof(*ra));
+  ra->ablk = ab->d;  ra->bblk = bb->d;
+  ra->kmer = P_kmer;  ra->hitmin = P_hitmin;  ra->binshift = P_binshift;
+  ra->minhit = (P_hitmin - 1) / P_kmer + 1;
+  ra->comp = comp;  ra->self = self;  ra->symmetric = SYMMETRIC;
+  ra->minover = MINOVER;  ra->hgap_min = HGAP_MIN;
+  ra->tspace = Trace_Spacing(spec);
+  ra->ave_path = damar_spec_ave_path(spec);
+  ra->reach = Overlap_If_Possible(spec);
+  if (RS.tables_of != (const void *) spec)
+    { HIP_CHECK(hipMemcpyAsync(RS.tables, damar_spec_score_table(spec), sizeof(short) * 65536,
+                               hipMemcpyHostToDevice, G_st));
+      RS.tables_of = (const void *) spec;
+    }
+  ra->score = RS.tables;
+  ra->table = RS.tables + 32768;
+  ra->state = RS.state;  ra->state_stride = RS.state_stride;  ra->span = RS.span;
+  ra->marks = RS.marks;  ra->marks_stride = RS.marks_stride;
+  ra->cells = RS.cells;  ra->cell_cap = RS.cell_cap;
+  ra->buckets = RS.buckets;  ra->bucket_stride = RS.bucket_stride;  ra->bwidth = RS.bwidth;
+  ra->ttmp = RS.ttmp;  ra->ttmp_stride = RS.ttmp_stride;
+  ra->recs = RS.recs;  ra->rec_cap = RS.rec_cap;
+  ra->tpool = RS.tpool;  ra->tpool_cap = RS.tpool_cap;
+  ra->counters = RS.counters;
+}
+
+/***** Match_Filter **********************************************************************************/
+
+static std::vector<u64> G_seed_keys;
+static std::vector<u32> G_seed_vals;
+static int  G_seed_pbits = 0, G_seed_abits = 0;
+static int  G_keep_seeds = 0;
+
+static int64 sizeof_db(const HITS_DB *db)      /* db/DB.c:726 sizeof_DB without tracks */
+{ return (int64) sizeof(HITS_DB) + (int64) sizeof(HITS_READ) * (db->nreads + 2) + db->totlen + db->nreads + 4 +
+         (db->path ? (int64) strlen(db->path) + 1 : 0);
+}
+
+struct RecOrder
+{ bool operator()(const LaRecord &x, const LaRecord &y) const
+  { return (x.item != y.item) ? (x.item < y.item) : (x.seq < y.seq); }
+};
+
+extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
+                            damar_dev_index *aidx, damar_dev_index *bidx,
+                            int self, int comp, Align_Spec *spec, int64 *counts)
+{ ensure_init();
+  int64 nhits = 0, nfilt = 0, ncheck = 0;
+  memset(G_cnt, 0, sizeof(G_cnt));
+  for (int i = DAMAR_T_MERGE; i < DAMAR_T_COUNT; i++)
+    G_ms[i] = 0;
+  if (counts)
+    counts[0] = counts[1] = counts[2] = 0;
+  if (aidx == NULL || bidx == NULL || aidx->n == 0 || bidx->n == 0)
+    return;
+  if (aidx->kbits != bidx->kbits || aidx->tbits > aidx->kbits)
+    { fprintf(stderr, "damar: internal error, index parameters differ\n");
+      exit(1);
+    }
+
+  const u32 alen = aidx->n, blen = bidx->n;
+  const int ts = Trace_Spacing(spec);
+  MergeArgs m;
+  memset(&m, 0, sizeof(m));
+  m.acode = aidx->codes;  m.apos = aidx->pos;  m.alen = alen;  m.atab = aidx->table;
+  m.bcode = bidx->codes;  m.bpos = bidx->pos;  m.blen = blen;  m.btab = bidx->table;
+  m.kbits = aidx->kbits;
+  m.self = self;  m.comp = comp;  m.identity = IDENTITY;
+  m.limit = (MEM_LIMIT > 0) ? MAXGRAM : 0x7fffffffu;      /* filter.c:2700-2702 */
+  m.ablk = aidx->blk->d;  m.bblk = bidx->blk->d;
+  m.pbits = std::max(1, ilog2_ceil((u64) ablock->maxlen + 1));
+  m.abits = std::max(1, ilog2_ceil((u64) ablock->nreads));
+  int bbits = std::max(1, ilog2_ceil((u64) bblock->nreads));
+  if (m.pbits + m.abits + bbits > 64)
+    { fprintf(stderr, "damar: FATAL: seed key needs %d bits (> 64)\n", m.pbits + m.abits + bbits);
+      exit(1);
+    }
+  m.atbits = aidx->tbits;
+  m.btbits = bidx->tbits;
+
+  /* ---- merge: count, scan, (limit), emit ---- */
+  size_t need = 3 * pad256(sizeof(u32) * (size_t) alen) + pad256(damar_scan_workspace_bytes(alen)) + 4096;
+  arena_reserve(&G_work, need);       /* grown again below once nhits is known */
+  u32 *cnt = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) alen);
+  u32 *off = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) alen);
+  u32 *jb  = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) alen);
+  void *scw = arena_take(&G_work, damar_scan_workspace_bytes(alen));
+  u64 *tot = (u64 *) arena_take(&G_work, 64);
+  u64  total = 0;
+
+  tick(0);
+  damar_launch_merge_count(&m, cnt, jb, G_st);
+  stage("merge_count");
+  damar_exclusive_scan_u32(cnt, off, alen, scw, tot, G_st);
+  stage("merge_scan");
+  HIP_CHECK(hipMemcpyAsync(&total, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  if (self && total > 0)
+    { u64 before = total;
+      damar_launch_merge_limit(&m, off, total, cnt, G_st);
+      damar_exclusive_scan_u32(cnt, off, alen, scw, tot, G_st);
+      HIP_CHECK(hipMemcpyAsync(&total, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      (void) before;
+    }
+  if (MEM_LIMIT > 0)
+    { /* filter.c:2634-2699: with the counts above every run below MAXGRAM is kept; the
+         reference lowers that cap only if the kept seeds exceed `avail`. */
+      int64 avail = (int64) (MEM_LIMIT - (uint64) (sizeof_db(ablock) + sizeof_db(bblock))) / 16;
+      if (aidx == bidx || avail > (int64) alen + 2 * (int64) blen)
+        avail = (avail - alen) / 2;
+      else
+        avail = avail - ((int64) alen + blen);
+      avail = (int64) (avail * .98);
+      if ((int64) total > avail)
+        { fprintf(stderr, "damar: FATAL: host memory limit would cap mutual k-mer matches below %d "
+                          "(%llu seeds > %lld); the adaptive cap of filter.c:2652-2659 is not built yet\n",
+                  MAXGRAM, (unsigned long long) total, (long long) avail);
+          exit(1);
+        }
+      if (VERBOSE)
+        printf("\n   Capping mutual k-mer matches over %d (effectively -t%d)\n", MAXGRAM, 100);
+    }
+  nhits = (int64) total;
+  if (VERBOSE)
+    { printf("   Hit count = %lld\n", (long long) nhits);
+      fflush(stdout);
+    }
+  if (total >= 0xfffffff0ull)
+    { fprintf(stderr, "damar: FATAL: %llu seed pairs exceed the 32-bit seed index of this build\n",
+              (unsigned long long) total);
+      exit(1);
+    }
+  if (total == 0)
+    { if (counts) counts[0] = 0;
+      return;
+    }
+
+  /* hits known: a second arena holds the seed pairs, their sort space and the work list */
+  arena_reserve(&G_hits, 2 * pad256(sizeof(u64) * (size_t) total) + 4 * pad256(sizeof(u32) * (size_t) total) +
+                         pad256(damar_sort_workspace_bytes(total)) + pad256(damar_scan_workspace_bytes(total)) + 8192);
+  u64 *k0 = (u64 *) arena_take(&G_hits, sizeof(u64) * (size_t) total);
+  u64 *k1 = (u64 *) arena_take(&G_hits, sizeof(u64) * (size_t) total);
+  u32 *v0 = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
+  u32 *v1 = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
+  void *sw = arena_take(&G_hits, damar_sort_workspace_bytes(total));
+  u32 *flags = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
+  u32 *foff  = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
+  void *scw2 = arena_take(&G_hits, damar_scan_workspace_bytes(total));
+
+  damar_launch_merge_emit(&m, off, jb, total, k0, v0, G_st);
+  stage("merge_emit");
+  tick(1);
+  int side = damar_radix_sort_u64(k0, v0, k1, v1, total, m.pbits + m.abits + bbits, sw, G_st);
+  u64 *keys = side ? k1 : k0;
+  u32 *vals = side ? v1 : v0;
+  stage("seed_sort");
+  tick(2);
+
+  /* ---- work list ---- */
+  const int minhit = (P_hitmin - 1) / P_kmer + 1;
+  u64 nwork64 = 0;
+  damar_launch_pair_flags(keys, total, m.pbits, m.abits, minhit, P_nshift, flags, G_st);
+  stage("pair_flags");
+  damar_exclusive_scan_u32(flags, foff, total, scw2, tot, G_st);
+  u32 *work = side ? (u32 *) k0 : (u32 *) k1;          /* the idle key buffer holds the list */
+  damar_launch_compact_index(flags, foff, total, work, G_st);
+  stage("work_list");
+  HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+  tick(3);
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  const u32 nwork = (u32) nwork64;
+  G_ms[DAMAR_T_MERGE] = lap(0, 1);
+  G_ms[DAMAR_T_SSORT] = lap(1, 2);
+  G_ms[DAMAR_T_WORK]  = lap(2, 3);
+  G_cnt[0] = nhits;  G_cnt[1] = nwork;
+
+  if (G_keep_seeds)
+    { G_seed_keys.resize(total);  G_seed_vals.resize(total);
+      HIP_CHECK(hipMemcpy(G_seed_keys.data(), keys, sizeof(u64) * (size_t) total, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(G_seed_vals.data(), vals, sizeof(u32) * (size_t) total, hipMemcpyDeviceToHost));
+      G_seed_pbits = m.pbits;  G_seed_abits = m.abits;
+    }
+
+  /* ---- report kernel (retry with larger buffers if it reports an overflow) ---- */
+  std::vector<LaRecord> recs;
+  std::vector<u16>      tpool;
+  u32 hc[8];
+  if (nwork > 0)
+    { u32 cell_cap = RS.cell_cap ? RS.cell_cap : (1u << 16);
+      u32 rec_cap  = std::max(RS.rec_cap, 2 * nwork + 4096);
+      u32 tp_cap   = std::max(RS.tpool_cap, rec_cap * 256u);
+      for (int attempt = 0; ; attempt++)
+        { ReportArgs ra;
+          scratch_prepare(ablock->maxlen, bblock->maxlen, P_binshift, ts, cell_cap);
+          scratch_outputs(rec_cap, tp_cap);
+          fill_report_args(&ra, aidx->blk, bidx->blk, comp, self, spec);
+          ra.keys = keys;  ra.vals = vals;  ra.nhits = total;
+          ra.work = work;  ra.nwork = nwork;
+          ra.pbits = m.pbits;  ra.abits = m.abits;
+          HIP_CHECK(hipMemsetAsync(RS.counters, 0, 64, G_st));
+          tick(4);
+          stage("report_setup");
+          damar_launch_report(&ra, RS.nslots, G_st);
+          stage("report");
+          tick(5);
+          HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, G_st));
+          HIP_CHECK(hipStreamSynchronize(G_st));
+          HIP_CHECK(hipGetLastError());
+          G_ms[DAMAR_T_REPORT] += lap(4, 5);
+          if (hc[3] == 0)
+            break;
+          if (hc[3] & DAMAR_ERR_BAND)
+            { fprintf(stderr, "damar: FATAL: a Local_Alignment wave ran out of band (empty band or step limit)\n");
+              exit(1);
+            }
+          if (attempt >= 6)
+            { fprintf(stderr, "damar: FATAL: report kernel keeps overflowing its buffers (flags %u)\n", hc[3]);
+              exit(1);
+            }
+          if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
+          if (hc[3] & DAMAR_ERR_RECS)  rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
+          if (hc[3] & DAMAR_ERR_TPOOL) tp_cap  = std::max(2 * tp_cap, hc[2] + 65536);
+          if (VERBOSE)
+            fprintf(stderr, "damar: report kernel overflow (flags %u), retrying with larger buffers\n", hc[3]);
+        }
+      tick(6);
+      recs.resize(hc[1]);
+      tpool.resize(hc[2]);
+      if (hc[1] > 0)
+        { HIP_CHECK(hipMemcpyAsync(recs.data(), RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, G_st));
+          HIP_CHECK(hipMemcpyAsync(tpool.data(), RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, G_st));
+        }
+      tick(7);
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      G_ms[DAMAR_T_D2H] = lap(6, 7);
+      nfilt = hc[4];
+      G_cnt[2] = hc[4];  G_cnt[3] = hc[1];  G_cnt[4] = hc[2];
+    }
+
+  /* ---- host tail: filter.c:2442-2483 per read pair ---- */
+  { double t0 = 0;
+    struct timespec tsp;
+    clock_gettime(CLOCK_MONOTONIC, &tsp);
+    t0 = tsp.tv_sec * 1e3 + tsp.tv_nsec * 1e-6;
+
+    std::sort(recs.begin(), recs.end(), RecOrder());
+    Overlap_IO_Buffer *obuf = OVL_IO_Buffer(spec);
+    std::vector<damar_path> am, bm;
+    damar_tpool tp = { NULL, 0, 0 };
+    const char *abase = (const char *) ablock->bases, *bbase = (const char *) bblock->bases;
+    size_t i = 0;
+    while (i < recs.size())
+      { size_t j = i;
+        while (j < recs.size() && recs[j].item == recs[i].item)
+          j += 1;
+        const int ar = recs[i].aread, br = recs[i].bread;
+        const int al = ablock->reads[ar].rlen, bl = bblock->reads[br].rlen;
+        const int doA = (al >= HGAP_MIN);
+        const int doB = (SYMMETRIC && bl >= HGAP_MIN && (ar != br || !self || !comp));   /* filter.c:2300-2301 */
+        am.clear();  bm.clear();  tp.top = 0;
+        for (size_t q = i; q < j; q++)
+          { const LaRecord &r = recs[q];
+            damar_path p;
+            if (doA)
+              { p.tlen = r.atlen;  p.diffs = r.diffs;
+                p.abpos = r.abpos;  p.bbpos = r.bbpos;  p.aepos = r.aepos;  p.bepos = r.bepos;
+                p.toff = damar_tpool_push(&tp, tpool.data() + r.toff, r.atlen);
+                am.push_back(p);
+              }
+            if (doB)
+              { p.tlen = r.btlen;  p.diffs = r.diffs;
+                if (comp)                                          /* align.c:2039-2042 */
+                  { p.abpos = bl - r.bepos;  p.bbpos = al - r.aepos;
+                    p.aepos = bl - r.bbpos;  p.bepos = al - r.abpos;
+                  }
+                else                                               /* align.c:2059-2062 */
+                  { p.abpos = r.bbpos;  p.bbpos = r.abpos;  p.aepos = r.bepos;  p.bepos = r.aepos; }
+                p.toff = damar_tpool_push(&tp, tpool.data() + r.toff + r.atlen, r.btlen);
+                bm.push_back(p);
+              }
+          }
+        damar_bridge_ctx bctx;
+        bctx.aseq = abase + ablock->reads[ar].boff;  bctx.bseq = bbase + bblock->reads[br].boff;
+        bctx.alen = al;  bctx.blen = bl;
+        damar_emit_pair(am.data(), (int) am.size(), bm.data(), (int) bm.size(), &tp, comp, ts,
+                        ar + ablock->ufirst, br + bblock->ufirst, &bctx, obuf, &ncheck);
+        i = j;
+      }
+    free(tp.val);
+    clock_gettime(CLOCK_MONOTONIC, &tsp);
+    G_ms[DAMAR_T_TAIL] = tsp.tv_sec * 1e3 + tsp.tv_nsec * 1e-6 - t0;
+  }
+
+  if (counts)
+    { counts[0] = nhits;  counts[1] = nfilt;  counts[2] = ncheck; }
+  if (VERBOSE)
+    { printf("\n     %lld %d-mers\n     %lld seed hits\n     %lld confirmed hits\n",
+             (long long) nhits, P_kmer, (long long) nfilt, (long long) ncheck);
+      fflush(stdout);
+    }
+}
+
+extern "C" void Match_Filter(char *aname, HITS_DB *ablock, char *bname, HITS_DB *bblock,
+                             void *atable, int alen, void *btable, int blen, int comp, Align_Spec *asettings)
+{ (void) alen;  (void) blen;
+  if (VERBOSE)
+    { if (comp) printf("\nComparing %s to c(%s)\n", aname, bname);
+      else      printf("\nComparing %s to %s\n", aname, bname);
+    }
+  damar_match(ablock, bblock, (damar_dev_index *) atable, (damar_dev_index *) btable,
+              aname == bname, comp, asettings, NULL);             /* filter.c:2603 pointer equality */
+  if (atable != btable && btable != NULL)                         /* filter.c:2722-2731, 2880-2881 */
+    damar_index_free((damar_dev_index *) btable);
+}
+
+/***** test hooks ***************************************************************************************/
+
+extern "C" int64 damar_last_seeds(void *out, int64 cap)
+{ struct SP { int diag, apos, aread, bread; } *sp = (SP *) out;
+  if (out == NULL)
+    { G_keep_seeds = (cap != 0);
+      return 0;
+    }
+  int64 n = (int64) G_seed_keys.size();
+  for (int64 i = 0; i < n && i < cap; i++)
+    { u64 k = G_seed_keys[(size_t) i];
+      sp[i].apos  = (int) (k & ((1ull << G_seed_pbits) - 1));
+      sp[i].aread = (int) ((k >> G_seed_pbits) & ((1ull << G_seed_abits) - 1));
+      sp[i].bread = (int) (k >> (G_seed_pbits + G_seed_abits));
+      sp[i].diag  = (int) G_seed_vals[(size_t) i];
+    }
+  return n;
+}
+
+extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_block *bblk, int comp,
+                                           Align_Spec *spec, const int *tasks, int ntasks,
+                                           int *paths, int64 *trace_off, uint16 *traces, int64 trace_cap)
+{ ensure_init();
+  if (ntasks <= 0)
+    return 0;
+  const int ts = Trace_Spacing(spec);
+  u32 cell_cap = 1u << 16, rec_cap = (u32) ntasks + 16, tp_cap = (u32) std::min<int64>(trace_cap + 1024, 0x7fffffff);
+  LaTask *dt = (LaTask *) dmalloc(sizeof(LaTask) * (size_t) ntasks);
+  HIP_CHECK(hipMemcpy(dt, tasks, sizeof(LaTask) * (size_t) ntasks, hipMemcpyHostToDevice));
+  u32 hc[8];
+  for (int attempt = 0; ; attempt++)
+    { ReportArgs ra;
+      scratch_prepare(ablk->d.maxlen, bblk->d.maxlen, P_binshift, ts, cell_cap);
+      scratch_outputs(rec_cap, tp_cap);
+      fill_report_args(&ra, ablk, bblk, comp, 0, spec);
+      HIP_CHECK(hipMemsetAsync(RS.counters, 0, 64, G_st));
+      damar_launch_la_batch(&ra, dt, (u32) ntasks, RS.nslots, G_st);
+      HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      HIP_CHECK(hipGetLastError());
+      if (hc[3] == 0)
+        break;
+      if ((hc[3] & DAMAR_ERR_BAND) || attempt >= 6)
+        { fprintf(stderr, "damar: FATAL: batch Local_Alignment failed (flags %u)\n", hc[3]);
+          exit(1);
+        }
+      if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
+      if (hc[3] & DAMAR_ERR_TPOOL)
+        { HIP_CHECK(hipFree(dt));
+          return -1;
+        }
+    }
+  HIP_CHECK(hipFree(dt));
+  std::vector<LaRecord> recs(hc[1]);
+  std::vector<u16> tp(hc[2]);
+  HIP_CHECK(hipMemcpy(recs.data(), RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemcpy(tp.data(), RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost));
+  std::sort(recs.begin(), recs.end(), RecOrder());
+  std::vector<u32> boffa((size_t) ablk->nreads + 1), boffb((size_t) bblk->nreads + 1);
+  HIP_CHECK(hipMemcpy(boffa.data(), ablk->boff, sizeof(u32) * boffa.size(), hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemcpy(boffb.data(), bblk->boff, sizeof(u32) * boffb.size(), hipMemcpyDeviceToHost));
+  int64 top = 0;
+  for (size_t i = 0; i < recs.size(); i++)
+    { const LaRecord &r = recs[i];
+      int *p = paths + 12 * r.item;
+      int  al = (int) (boffa[r.aread + 1] - boffa[r.aread] - 1), bl = (int) (boffb[r.bread + 1] - boffb[r.bread] - 1);
+      p[0] = r.abpos;  p[1] = r.bbpos;  p[2] = r.aepos;  p[3] = r.bepos;  p[4] = r.diffs;  p[5] = r.atlen;
+      if (comp)
+        { p[6] = bl - r.bepos;  p[7] = al - r.aepos;  p[8] = bl - r.bbpos;  p[9] = al - r.abpos; }
+      else
+        { p[6] = r.bbpos;  p[7] = r.abpos;  p[8] = r.bepos;  p[9] = r.aepos; }
+      p[10] = r.diffs;  p[11] = r.btlen;
+      if (top + r.atlen + r.btlen > trace_cap)
+        return -1;
+      trace_off[2 * r.item] = top;
+      memcpy(traces + top, tp.data() + r.toff, sizeof(u16) * (size_t) r.atlen);
+      top += r.atlen;
+      trace_off[2 * r.item + 1] = top;
+      memcpy(traces + top, tp.data() + r.toff + r.atlen, sizeof(u16) * (size_t) r.btlen);
+      top += r.btlen;
+    }
+  return 0;
+}
+
+extern "C" double damar_bench_sort_u32(uint32_t n, int nbits, int reps, uint32_t seed)
+{ ensure_init();
+  std::vector<u32> h(n);
+  u32 x = seed ? seed : 1u, mask = (nbits >= 32) ? 0xffffffffu : ((1u << nbits) - 1);
+  for (u32 i = 0; i < n; i++)
+    { x ^= x << 13;  x ^= x >> 17;  x ^= x << 5;
+      h[i] = x & mask;
+    }
+  u32 *src = (u32 *) dmalloc(sizeof(u32) * (size_t) n);
+  u32 *k0 = (u32 *) dmalloc(sizeof(u32) * (size_t) n), *v0 = (u32 *) dmalloc(sizeof(u32) * (size_t) n);
+  u32 *k1 = (u32 *) dmalloc(sizeof(u32) * (size_t) n), *v1 = (u32 *) dmalloc(sizeof(u32) * (size_t) n);
+  void *sw = dmalloc(damar_sort_workspace_bytes(n));
+  HIP_CHECK(hipMemcpy(src, h.data(), sizeof(u32) * (size_t) n, hipMemcpyHostToDevice));
+  double total = 0;
+  for (int r = 0; r < reps + 1; r++)
+    { HIP_CHECK(hipMemcpyAsync(k0, src, sizeof(u32) * (size_t) n, hipMemcpyDeviceToDevice, G_st));
+      HIP_CHECK(hipMemcpyAsync(v0, src, sizeof(u32) * (size_t) n, hipMemcpyDeviceToDevice, G_st));
+      tick(8);
+      damar_radix_sort_u32(k0, v0, k1, v1, n, nbits, sw, G_st);
+      tick(9);
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      if (r > 0)
+        total += lap(8, 9);
+    }
+  HIP_CHECK(hipFree(src));  HIP_CHECK(hipFree(k0));  HIP_CHECK(hipFree(v0));
+  HIP_CHECK(hipFree(k1));   HIP_CHECK(hipFree(v1));  HIP_CHECK(hipFree(sw));
+  return total / reps;
+}

@@ -1,0 +1,90 @@
+/* damar_hip.h -- device-resident entry points of libdamar_hip.so (C ABI, plain pointers
+ * and sizes only).
+ *
+ * The reference has no FFI boundary: dalign/daligner.c calls Sort_Kmers / Match_Filter
+ * (dalign/filter.h:64-70, declared for this library in damar_filter.h) directly.  Those
+ * two calls hand over HOST buffers, so each of them pays a PCIe copy of the block's
+ * bases.  The functions below split them at the PCIe boundary so that a caller that
+ * keeps blocks resident in HBM (the multi-GPU block-pair scheduler, bench.py) can time
+ * and reuse the device-side work alone:
+ *
+ *   Sort_Kmers(block,&len)            == damar_block_upload + damar_index_build
+ *   Match_Filter(..., atab, btab, ..) == damar_match (+ damar_index_free(btab) when
+ *                                        atab != btab, filter.c:2722-2731, 2880-2881)
+ *
+ * All functions are blocking, single-caller and non-reentrant like the reference's
+ * filter.c (file-scope state); fatal errors print to stderr and
+ * exit(1) like the reference (db/DB.h:84-86).
+ */
+#ifndef DAMAR_HIP_H
+#define DAMAR_HIP_H
+
+#include "damar_db.h"
+#include "damar_align.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Select the GPU (0-based HIP ordinal) and create the stream; returns the number of
+ * visible devices.  Called implicitly with device 0 (or $DAMAR_DEVICE) on first use.
+ * Exits with a message if no HIP device is present: there is no CPU fallback. */
+int   damar_hip_init(int device);
+const char *damar_hip_device_name(void);
+
+/* A read block resident in HBM: bases (1 B/base with the reference's 4-terminators,
+ * db/DB.c:1562-1605), read offsets, coarse position->read table. */
+typedef struct damar_dev_block damar_dev_block;
+damar_dev_block *damar_block_upload(const HITS_DB *block);
+void             damar_block_free(damar_dev_block *blk);
+
+/* The opaque index that Sort_Kmers returns (filter.c:753-994): sorted k-mer codes,
+ * base offsets and the code prefix table, all in HBM.  `own_block` != 0 makes
+ * damar_index_free release the block too. */
+typedef struct damar_dev_index damar_dev_index;
+damar_dev_index *damar_index_build(damar_dev_block *blk, int own_block, int *len);
+void             damar_index_free(damar_dev_index *idx);
+/* Test hook: copy the index back as reference-layout KmerPos records
+ * {uint64 code; int rpos; int read} (filter.c:121-126), out must hold *len records. */
+void             damar_index_download(const damar_dev_index *idx, void *out);
+
+/* Device part + host tail of Match_Filter (filter.c:2519-2929); records are appended
+ * to OVL_IO_Buffer(spec)[0].  counts[0..2] = seed pairs, seed hits (Local_Alignment
+ * calls), confirmed records -- the three numbers daligner -v prints. */
+void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
+                 damar_dev_index *aidx, damar_dev_index *bidx,
+                 int self, int comp, Align_Spec *spec, int64 *counts);
+
+/* Test hook: seed pairs of the last damar_match call as reference-layout SeedPair
+ * records {int diag, apos, aread, bread} (filter.c:128-134) in sorted order.
+ * Returns the number of seed pairs; copies at most `cap` records. */
+int64 damar_last_seeds(void *out, int64 cap);
+
+/* Test hook: batch Local_Alignment (align.c:1904 with low == hgh == diag, no borders)
+ * on the GPU.  tasks[4*i..] = aread, bread, diag, anti (block-local read ids).
+ * paths[12*i..] = A-view abpos,bbpos,aepos,bepos,diffs,tlen then the same for the
+ * B-view; traces of task i start at trace_off[2*i] (A) and trace_off[2*i+1] (B) in
+ * `traces` (capacity trace_cap values).  Returns 0, or -1 if trace_cap is too small. */
+int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_block *bblk, int comp,
+                                Align_Spec *spec, const int *tasks, int ntasks,
+                                int *paths, int64 *trace_off, uint16 *traces, int64 trace_cap);
+
+/* Phase timings (milliseconds, HIP events on the library's stream) of the last
+ * damar_index_build / damar_match: see DAMAR_T_* below. */
+enum { DAMAR_T_TUPLES = 0, DAMAR_T_KSORT, DAMAR_T_TABLE, DAMAR_T_MERGE, DAMAR_T_SSORT,
+       DAMAR_T_WORK, DAMAR_T_REPORT, DAMAR_T_D2H, DAMAR_T_TAIL, DAMAR_T_COUNT };
+void damar_last_timings(double *ms /* [DAMAR_T_COUNT] */);
+
+/* Counters of the last damar_match: [0] seed pairs, [1] work items (read pairs entered),
+ * [2] Local_Alignment calls, [3] records from the device, [4] trace values. */
+void damar_last_counters(int64 *c /* [8] */);
+
+/* Sort kernels alone, for the roofline measurement: sorts n (u32 key, u32 payload)
+ * pairs resident in HBM on `nbits` key bits `reps` times and returns the average
+ * milliseconds per sort (HIP events). */
+double damar_bench_sort_u32(uint32_t n, int nbits, int reps, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
