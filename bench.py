@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned base-pairs/sec of the daligner block-vs-block hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole HPCdaligner block-pair plan (every block against itself
+and all lower blocks, both orientations) over BASELINE.json's config 2: `simulator 27 -c20
+-e.15 -r<seed>` (~50k PacBio-style reads, 540 Mbp) split into 4 blocks of 135 Mbp = 10 block
+pairs.  All read blocks (forward and reverse-complemented bases) are resident in HBM before
+the timed region; the timed region covers k-mer index builds, seed merge + sort, band filter
++ Local_Alignment waves, the device->host copy of the alignments, the host tail and the
+sorted .las files written to tmpfs.  With N > 1 every rank owns one GPU and an independent
+DB of the same configuration (seed 2 + rank): block pairs never exchange data, so there is
+no collective in the data path ("weak" scaling); torch.distributed (RCCL) is used only for
+the barriers around the timed region and the max/sum of the results.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel,
+HIP-event timed on the library's stream) and `cpu_baseline` (the compiled reference
+daligner from oracle/_ref timed on the host cores on a bounded sample; N == 1 only).
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def pow2_floor(n):
+    p = 1
+    while 2 * p <= n:
+        p *= 2
+    return p
+
+
+def cpu_baseline(dbdir, root, sample_block, budget_s=120):
+    """Reference daligner (oracle/_ref, the real thing compiled from /root/reference in the
+    build container) on one block self-comparison, on this host's cores."""
+    from damar_amd import driver
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    ref = os.path.join(ROOT, "oracle", "_ref", "daligner")
+    kind, nthr, exe = "reference", pow2_floor(min(cores, 16)), ref   # >32 threads overflow the reference's alloca (filter.c:767)
+    if not os.path.exists(ref):
+        kind, nthr, exe = "port", 1, os.path.join(ROOT, "oracle", "oracle_daligner")
+    work = tempfile.mkdtemp(prefix="damar_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        for f in ("%s.db" % root, ".%s.idx" % root, ".%s.bps" % root):
+            os.symlink(os.path.join(dbdir, f), os.path.join(work, f))
+        name = "%s.%d" % (root, sample_block)
+        t0 = time.time()
+        subprocess.run([exe, "-k14", "-j%d" % nthr, name, name], cwd=work, check=True,
+                       stdout=subprocess.DEVNULL, timeout=budget_s * 10)
+        dt = time.time() - t0
+        las = os.path.join(work, "d001_%05d" % sample_block, "%s.%s.las" % (name, name))
+        nrec, bp = driver.las_stats(las)
+        return {"value": bp / dt, "unit": "aligned bp/s", "cores": nthr, "kind": kind,
+                "sample": "block %d self-comparison (1 of the plan's block pairs), %d records, %.1f s wall, host has %d cores"
+                          % (sample_block, nrec, dt, cores)}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome", type=float, default=27.0, help="simulator genome size in Mbp (config 2: 27)")
+    ap.add_argument("--coverage", type=float, default=20.0)
+    ap.add_argument("--block", type=int, default=135, help="DBsplit -s block size in Mbp (config 2: 135)")
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--threads-param", type=int, default=4, help="daligner -j (slice rule only)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--keep", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from damar_amd import api, driver
+    L = api.lib()
+    L.damar_hip_init(local if world > 1 else int(os.environ.get("DAMAR_DEVICE", "0")))
+
+    def sync_all():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        L.damar_hip_sync()
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    work = tempfile.mkdtemp(prefix="damar_bench_r%d_" % rank, dir=base)
+    try:
+        # ---- untimed: synthetic DB, blocks to HBM ----
+        t0 = time.time()
+        nblocks = api.sim_write_db(work, "SIM", args.genome, coverage=args.coverage,
+                                   seed=args.seed + rank, block_mbp=args.block)
+        t_gen = time.time() - t0
+        blocks = {}
+        for i in range(1, nblocks + 1):
+            b = driver.Block(os.path.join(work, "SIM.%d" % i))
+            b.upload()
+            b.upload_complement()
+            blocks[i] = b
+        plan_lines = driver.hpc_plan(nblocks)
+        npairs = sum(len(bs) for _, bs in plan_lines)
+        totbp = sum(b.db.totlen for b in blocks.values())
+        nreads = sum(b.db.nreads for b in blocks.values())
+
+        def one_step(tag):
+            out = os.path.join(work, "out_%s" % tag)
+            plan = driver.Plan(j=args.threads_param)
+            for a, bs in plan_lines:
+                plan.run_line(blocks[a], [blocks[b] for b in bs], out)
+            return out, plan
+
+        for w in range(args.warmup):
+            out, _ = one_step("w%d" % w)
+            shutil.rmtree(out, ignore_errors=True)
+
+        sync_all()
+        t0 = time.time()
+        tim, cnts, last_out = {}, [0, 0, 0], None
+        for s in range(args.steps):
+            if last_out:
+                shutil.rmtree(last_out, ignore_errors=True)
+            last_out, plan = one_step("s%d" % s)
+            for k, v in plan.timings.items():
+                tim[k] = tim.get(k, 0.) + v
+            cnts = [c + d for c, d in zip(cnts, plan.counts)]
+        sync_all()
+        elapsed = time.time() - t0
+
+        nrec = bp = trace_vals = 0
+        for dp, _, fs in os.walk(last_out):
+            for f in fs:
+                if f.endswith(".las"):
+                    n, b = driver.las_stats(os.path.join(dp, f))
+                    nrec += n
+                    bp += b
+                    trace_vals += (os.path.getsize(os.path.join(dp, f)) - 12 - 40 * n)
+        if dist is not None:
+            import torch
+            t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            v = torch.tensor([bp, nrec], device="cuda", dtype=torch.float64)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            bp_all, nrec_all = float(v[0].item()), float(v[1].item())
+        else:
+            bp_all, nrec_all = float(bp), float(nrec)
+
+        if rank == 0:
+            steps = max(1, args.steps)
+            launches = {"report": 2 * npairs * steps, "ssort": 2 * npairs * steps,
+                        "ksort": (nblocks + 2 * npairs - nblocks) * steps}
+            # dominant kernel by HIP-event time over the timed region
+            kern = {"report_kernel (band filter + Local_Alignment waves)": tim.get("report", 0.),
+                    "radix sort of seed pairs (hist+scan+scatter, u64 keys)": tim.get("ssort", 0.),
+                    "radix sort of the k-mer index (hist+scan+scatter, u32 keys)": tim.get("ksort", 0.),
+                    "seed merge (count+scan+emit)": tim.get("merge", 0.)}
+            dom = max(kern, key=kern.get)
+            H = cnts[0] / steps                      # seed pairs per step
+            if dom.startswith("report"):
+                # filter 16 B/seed + align 2 B per aligned bp + 2 B per trace value
+                alg = 16. * H + 2. * bp + 2. * trace_vals
+                nl = 2 * npairs
+            elif dom.startswith("radix sort of seed"):
+                alg = 16. * H * 2 * 6                # 16-byte records, read+write, P_s = 6 passes
+                nl = 2 * npairs
+            elif dom.startswith("radix sort of the k-mer"):
+                nbuild = sum(1 + 2 * len(bs) - 1 for _, bs in plan_lines)
+                kmers = totbp - 14 * nreads
+                alg = (16. * 2 * 4) * kmers / nblocks * nbuild   # per build: 16 B x (rd+wr) x 4 passes per k-mer
+                nl = nbuild
+            else:
+                kmers = totbp - 14 * nreads
+                alg = 32. * 2 * kmers / nblocks * 2 * npairs + 16. * H
+                nl = 2 * npairs
+            dom_ms = kern[dom] / steps
+            ach = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.
+            roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "launches_per_step": nl, "avg_launch_ms": dom_ms / nl if nl else 0.,
+                    "algorithmic_bytes_per_step": alg,
+                    "note": "wave kernel is latency/issue bound, not HBM bound (DESIGN.md); "
+                            "phase ms per step: " + ", ".join("%s=%.1f" % (k, v / steps) for k, v in sorted(tim.items()))}
+            cpu = None
+            if world == 1 and not args.no_cpu:
+                try:
+                    cpu = cpu_baseline(work, "SIM", 1)
+                except Exception as e:           # the baseline is reported, never required
+                    cpu = {"value": None, "unit": "aligned bp/s", "cores": 0, "kind": "reference",
+                           "sample": "failed: %s" % e}
+            value = bp_all * args.steps / elapsed
+            line = {"metric": "aligned base-pairs/sec (daligner block-vs-block)",
+                    "value": value, "unit": "aligned bp/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "int32", "data": "synthetic",
+                    "config": {"workload": "config 2: simulator %g -c%g -e.15 -r%d(+rank), DBsplit -s%d -> %d blocks, "
+                                           "%d block pairs x 2 orientations per step, daligner -k14 -w6 -h35 -e.70 -l1000 -s100"
+                                           % (args.genome, args.coverage, args.seed, args.block, nblocks, npairs),
+                               "reads_per_gpu": nreads, "bases_per_gpu": totbp,
+                               "records_per_step": nrec_all, "aligned_bp_per_step": bp_all,
+                               "seed_pairs_per_step": H, "local_alignments_per_step": cnts[1] / steps,
+                               "parallelism": "%d independent GPU(s), one DB each, no data-path collective" % world,
+                               "db_generation_s": t_gen},
+                    "roofline": roof, "cpu_baseline": cpu}
+            print(json.dumps(line))
+            sys.stdout.flush()
+    finally:
+        if not args.keep:
+            shutil.rmtree(work, ignore_errors=True)
+        if dist is not None:
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,11 @@ static void ensure_init(void)
     }
 }
 
+extern "C" void damar_hip_sync(void)
+{ ensure_init();
+  HIP_CHECK(hipDeviceSynchronize());
+}
+
 extern "C" const char *damar_hip_device_name(void)
 { ensure_init();
   return G_prop.name;

@@ -1,0 +1,155 @@
+"""In-process mirror of the block-pair loop of dalign/daligner.c:948-1074 on top of the
+C-ABI library (ctypes), used by tests/ and bench.py so that the timed region can start
+with the read blocks already resident in HBM.  The production host driver is the C binary
+damar_amd/bin/daligner; both call the same library entry points in the same order.
+"""
+import ctypes as C
+import os
+import contextlib
+
+from . import api
+
+
+@contextlib.contextmanager
+def _cwd(path):
+    old = os.getcwd()
+    os.chdir(path)
+    try:
+        yield
+    finally:
+        os.chdir(old)
+
+
+class Block:
+    """A read block loaded on the host (HITS_DB) and, optionally, resident in HBM."""
+
+    def __init__(self, name):
+        self.name = name                       # e.g. "SIM.3"
+        self.root = os.path.basename(name)
+        if self.root.endswith(".db"):
+            self.root = self.root[:-3]
+        self.db = api.read_block(name)
+        self.dev = None
+        self._cdb = None
+        self.cdev = None
+
+    def upload(self):
+        L = api.lib()
+        if self.dev is None:
+            self.dev = L.damar_block_upload(C.byref(self.db))
+        return self.dev
+
+    def upload_complement(self):
+        """Reverse-complemented copy (daligner.c:529-570), resident in HBM as well."""
+        L = api.lib()
+        if self.cdev is None:
+            self._cdb = L.damar_complement_block(C.byref(self.db), 0).contents
+            # damar_complement_block returns a static record: copy it
+            keep = api.HITS_DB()
+            C.memmove(C.byref(keep), C.byref(self._cdb), C.sizeof(api.HITS_DB))
+            self._cdb = keep
+            self.cdev = L.damar_block_upload(C.byref(self._cdb))
+        return self.cdev
+
+    @property
+    def cdb(self):
+        return self._cdb
+
+    def last_read(self):
+        return self.db.ufirst + self.db.nreads - 1
+
+
+class Plan:
+    """daligner <A> <B1> <B2> ... for resident blocks."""
+
+    def __init__(self, k=14, w=6, h=35, t=0, e=.70, l=1000, s=100, j=4, run=1,
+                 symmetric=1, identity=0, verbose=0):
+        self.k, self.w, self.h, self.t, self.e, self.l, self.s, self.j, self.run = k, w, h, t, e, l, s, j, run
+        self.symmetric, self.identity, self.verbose = symmetric, identity, verbose
+        L = api.lib()
+        api.set_globals(verbose=verbose, minover=2 * l, symmetric=symmetric, identity=identity)
+        if L.Set_Filter_Params(k, w, t, h, j):
+            raise ValueError("Illegal combination of filter parameters")
+        self.timings = {}
+        self.counts = [0, 0, 0]
+
+    def _acc(self):
+        for n, v in api.timings().items():
+            self.timings[n] = self.timings.get(n, 0.) + v
+
+    def _build(self, devblock):
+        L = api.lib()
+        n = C.c_int(0)
+        idx = L.damar_index_build(devblock, 0, C.byref(n))
+        t = api.timings()
+        for nme in ("tuples", "ksort", "table"):
+            self.timings[nme] = self.timings.get(nme, 0.) + t[nme]
+        return idx, n.value
+
+    def _match(self, adb, bdb, aidx, bidx, self_, comp, spec):
+        L = api.lib()
+        cnt = (api.c_int64 * 3)()
+        L.damar_match(C.byref(adb), C.byref(bdb), aidx, bidx, self_, comp, spec, cnt)
+        t = api.timings()
+        for nme in ("merge", "ssort", "work", "report", "d2h", "tail"):
+            self.timings[nme] = self.timings.get(nme, 0.) + t[nme]
+        for i in range(3):
+            self.counts[i] += cnt[i]
+
+    def run_line(self, a, bs, outdir):
+        """One plan line: block `a` against every block in `bs` (blocks already uploaded).
+        Writes the .las files under outdir exactly as daligner.c:1006-1021, 1051-1056."""
+        L = api.lib()
+        os.makedirs(outdir, exist_ok=True)
+        with _cwd(outdir):
+            os.makedirs(api.get_dir(self.run, a.db.part), exist_ok=True)
+            spec = L.New_Align_Spec(self.e, self.s, a.db.freq, self.j, self.symmetric, 0, 0, 1)
+            aidx, alen = self._build(a.upload())
+            for b in bs:
+                if b is a or b.name == a.name:
+                    self._match(a.db, a.db, aidx, aidx, 1, 0, spec)
+                    cdev = a.upload_complement()
+                    cidx, clen = self._build(cdev)
+                    self._match(a.db, a.cdb, aidx, cidx, 1, 1, spec)
+                    L.damar_index_free(cidx)
+                    d1 = api.get_dir(self.run, a.db.part).encode() if a.db.part > 0 else None
+                    L.Write_Overlap_Buffer(spec, d1, None, a.root.encode(), a.root.encode(), a.last_read())
+                else:
+                    if self.symmetric:
+                        os.makedirs(api.get_dir(self.run, b.db.part), exist_ok=True)
+                    bidx, blen = self._build(b.upload())
+                    self._match(a.db, b.db, aidx, bidx, 0, 0, spec)
+                    L.damar_index_free(bidx)
+                    cidx, clen = self._build(b.upload_complement())
+                    self._match(a.db, b.cdb, aidx, cidx, 0, 1, spec)
+                    L.damar_index_free(cidx)
+                    last = b.last_read() if b.db.part < a.db.part else a.last_read()
+                    d1 = api.get_dir(self.run, a.db.part).encode() if a.db.part > 0 else None
+                    d2 = api.get_dir(self.run, b.db.part).encode() if b.db.part > 0 else None
+                    L.Write_Overlap_Buffer(spec, d1, d2, a.root.encode(), b.root.encode(), last)
+                L.Reset_Overlap_Buffer(spec)
+            L.damar_index_free(aidx)
+            L.Free_Align_Spec(spec)
+
+
+def hpc_plan(nblocks):
+    """The block-pair work list HPCdaligner emits (HPCdaligner.c:628-788): line i compares
+    block i against blocks i, i-1, ..., 1."""
+    return [(i, list(range(i, 0, -1))) for i in range(1, nblocks + 1)]
+
+
+def las_stats(path):
+    """(records, aligned bp = sum(aepos - abpos)) of a .las file."""
+    import numpy as np
+    with open(path, "rb") as f:
+        raw = f.read()
+    novl = int(np.frombuffer(raw, dtype="<i8", count=1)[0])
+    tspace = int(np.frombuffer(raw, dtype="<i4", count=1, offset=8)[0])
+    tbytes = 1 if tspace <= 125 else 2
+    off, bp = 12, 0
+    for _ in range(novl):
+        rec = np.frombuffer(raw, dtype="<i4", count=10, offset=off)
+        bp += int(rec[4]) - int(rec[2])
+        off += 40 + tbytes * int(rec[0])
+    assert off == len(raw), (off, len(raw))
+    return novl, bp

@@ -31,6 +31,7 @@ extern "C" {
  * Exits with a message if no HIP device is present: there is no CPU fallback. */
 int   damar_hip_init(int device);
 const char *damar_hip_device_name(void);
+void  damar_hip_sync(void);          /* hipDeviceSynchronize on the selected GPU */
 
 /* A read block resident in HBM: bases (1 B/base with the reference's 4-terminators,
  * db/DB.c:1562-1605), read offsets, coarse position->read table. */
