@@ -28,7 +28,7 @@ def load():
                 "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or make -C damar_amd/csrc); damar_amd has no CPU fallback" % p)
         try:
-            _LIB = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+            _LIB = ctypes.CDLL(p)
         except OSError as e:            # pragma: no cover - depends on the machine
             raise LibraryMissing("cannot load %s: %s" % (p, e))
     return _LIB

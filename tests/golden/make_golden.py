@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ from the REAL reference (oracle/_ref, compiled from
+/root/reference by oracle/Makefile.ref).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Fixtures are data: small read databases (.db/.idx/.bps written by damar_amd/bin/simdb, or
+by the reference's own FA2db/DBsplit for the derived-read cases) and the .las files the
+reference daligner produced from them.  No reference source is stored here.
+
+config2_ref_md5.txt is different: md5 of the 16 .las files the reference daligner -j16
+wrote for BASELINE config 2 (`simdb . SIM 27 -c20 -r2 -e.15 -S135`, full HPCdaligner plan)
+on the MI355X box's host (scripts/gpu_c2_parity.sh).
+"""
+import os
+import random
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = os.path.join(ROOT, "oracle", "_ref")
+SIMDB = os.path.join(ROOT, "damar_amd", "bin", "simdb")
+
+# name -> (how to make the DB, daligner options, plan lines)
+CASES = {
+    "tiny2":   dict(sim=["0.1", "-c12", "-r11", "-e.15", "-S1"], opts=["-k14", "-j4"], plan="all"),
+    "tiny_j1": dict(db="tiny2", opts=["-k14", "-j1"], plan=[("1", ["1"])]),
+    "tiny_s":  dict(db="tiny2", opts=["-k14", "-j4", "-s126", "-l800", "-e.75"], plan=[("2", ["2", "1"])]),
+    "tiny_t":  dict(db="tiny2", opts=["-k14", "-j2", "-t12"], plan=[("1", ["1"])]),
+    "tiny_I":  dict(db="tiny2", opts=["-k14", "-j4", "-I"], plan=[("1", ["1"])]),
+    "tiny_A":  dict(db="tiny2", opts=["-k14", "-j4", "-A"], plan=[("2", ["2", "1"])]),
+    "tiny_k12": dict(db="tiny2", opts=["-k12", "-w5", "-h30", "-j4"], plan=[("1", ["1"])]),
+    "indel":   dict(derive="indel", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
+    "noisy":   dict(derive="noisy", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
+    "tandem":  dict(derive="tandem", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
+}
+
+
+def run(cmd, cwd, **kw):
+    subprocess.run(cmd, cwd=cwd, check=True, **kw)
+
+
+def unpack_reads(dbdir, root):
+    import numpy as np
+    idx = np.fromfile(os.path.join(dbdir, ".%s.idx" % root), dtype=np.uint8)
+    nreads = int(np.frombuffer(idx[:4].tobytes(), dtype="<i4")[0])
+    recs = idx[88:88 + 32 * nreads].reshape(nreads, 32)
+    bps = np.fromfile(os.path.join(dbdir, ".%s.bps" % root), dtype=np.uint8)
+    reads = []
+    for r in recs:
+        rlen = int(np.frombuffer(r[0:4].tobytes(), dtype="<i4")[0])
+        boff = int(np.frombuffer(r[8:16].tobytes(), dtype="<i8")[0])
+        b = bps[boff:boff + (rlen + 3) // 4]
+        s = np.stack([(b >> 6) & 3, (b >> 4) & 3, (b >> 2) & 3, b & 3], axis=1).reshape(-1)[:rlen]
+        reads.append("".join("acgt"[x] for x in s))
+    return reads
+
+
+def write_fasta(path, reads):
+    with open(path, "w") as f:
+        for i, s in enumerate(reads):
+            f.write(">Sim/%d/0_%d RQ=0.850\n" % (i + 1, len(s)))
+            for j in range(0, len(s), 80):
+                f.write(s[j:j + 80] + "\n")
+
+
+def rnd_seq(rng, n):
+    return "".join(rng.choice("acgt") for _ in range(n))
+
+
+def derive(kind, work):
+    """SURVEY.md App. E recipes; every derived DB goes through the reference's own FA2db."""
+    rng = random.Random(12345)
+    base = os.path.join(work, "base")
+    os.makedirs(base)
+    if kind == "tandem":
+        units = [40, 75, 120, 200, 350]
+        genome = ""
+        for i in range(6):
+            genome += rnd_seq(rng, 12000)
+            u = rnd_seq(rng, units[i % 5])
+            for c in range(rng.choice([8, 12, 20])):
+                genome += "".join(ch if rng.random() > .03 else rng.choice("acgt") for ch in u)
+        genome += rnd_seq(rng, 12000)
+        reads = []
+        tot = 0
+        comp = {"a": "t", "c": "g", "g": "c", "t": "a"}
+        while tot < 14 * len(genome):
+            ln = max(3000, int(rng.gauss(7000, 1500)))
+            ln = min(ln, len(genome))
+            st = rng.randrange(0, len(genome) - ln + 1)
+            out = []
+            for ch in genome[st:st + ln]:
+                x = rng.random()
+                if x < .03:
+                    continue
+                if x < .08:
+                    ch = rng.choice("acgt")
+                out.append(ch)
+                if rng.random() < .07:
+                    out.append(rng.choice("acgt"))
+            s = "".join(out)
+            if rng.random() < .5:
+                s = "".join(comp[ch] for ch in reversed(s))
+            reads.append(s)
+            tot += len(s)
+    else:
+        run([SIMDB, base, "B", "0.06", "-c14", "-r21", "-e.15", "-S200"], ROOT, stdout=subprocess.DEVNULL)
+        reads = unpack_reads(base, "B")
+        out = []
+        for i, s in enumerate(reads):
+            mid = len(s) // 2
+            if kind == "indel":
+                if i % 3 == 0:
+                    s = s[:mid] + rnd_seq(rng, rng.choice([60, 150, 400])) + s[mid:]
+                elif i % 3 == 1:
+                    s = s[:mid] + s[mid + rng.choice([80, 200]):]
+            else:
+                if i % 2 == 0:
+                    w = rng.randrange(200, 1500)
+                    p = rng.randrange(500, max(501, len(s) - w - 500))
+                    rate = rng.uniform(.35, .75)
+                    seg = "".join(ch if rng.random() > rate else rng.choice("acgt") for ch in s[p:p + w])
+                    if i % 4 == 0:
+                        q = len(seg) // 2
+                        seg = seg[:q] + rnd_seq(rng, rng.randrange(8, 40)) + seg[q:]
+                    s = s[:p] + seg + s[p + w:]
+            out.append(s)
+        reads = out
+    dbdir = os.path.join(work, "db")
+    os.makedirs(dbdir)
+    write_fasta(os.path.join(dbdir, "reads.fasta"), reads)
+    run([os.path.join(REF, "FA2db"), "G", "reads.fasta"], dbdir, stdout=subprocess.DEVNULL)
+    run([os.path.join(REF, "DBsplit"), "-s200", "G"], dbdir, stdout=subprocess.DEVNULL)
+    return dbdir, "G"
+
+
+def main():
+    if not os.path.exists(os.path.join(REF, "daligner")):
+        sys.exit("oracle/_ref/daligner missing: make -C oracle -f Makefile.ref")
+    import tempfile
+    dbs = {}
+    for name, c in CASES.items():
+        out = os.path.join(HERE, name)
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out)
+        with tempfile.TemporaryDirectory() as work:
+            if "sim" in c:
+                run([SIMDB, out, "G"] + c["sim"], ROOT, stdout=subprocess.DEVNULL)
+                dbs[name] = out
+                dbdir, root = out, "G"
+            elif "derive" in c:
+                dbdir, root = derive(c["derive"], work)
+                for f in ("G.db", ".G.idx", ".G.bps"):
+                    shutil.copy(os.path.join(dbdir, f), os.path.join(out, f))
+                dbdir = out
+            else:
+                dbdir, root = dbs[c["db"]], "G"
+            nblocks = int(open(os.path.join(dbdir, "G.db")).read().split("blocks =")[1].split()[0])
+            plan = c["plan"]
+            if plan == "all":
+                plan = [(str(a), [str(b) for b in range(a, 0, -1)]) for a in range(1, nblocks + 1)]
+            rdir = os.path.join(work, "run")
+            os.makedirs(rdir)
+            for f in ("G.db", ".G.idx", ".G.bps"):
+                os.symlink(os.path.join(dbdir, f), os.path.join(rdir, f))
+            for a, bs in plan:
+                run([os.path.join(REF, "daligner")] + c["opts"] + ["G." + a] + ["G." + b for b in bs], rdir,
+                    stdout=subprocess.DEVNULL)
+            n = 0
+            for dp, _, fs in os.walk(rdir):
+                for f in fs:
+                    if f.endswith(".las"):
+                        rel = os.path.relpath(os.path.join(dp, f), rdir)
+                        os.makedirs(os.path.join(out, "las", os.path.dirname(rel)), exist_ok=True)
+                        shutil.copy(os.path.join(dp, f), os.path.join(out, "las", rel))
+                        n += 1
+            with open(os.path.join(out, "case.txt"), "w") as f:
+                f.write("db %s\nopts %s\n" % (c.get("db", name), " ".join(c["opts"])))
+                for a, bs in plan:
+                    f.write("line %s %s\n" % (a, " ".join(bs)))
+            print(name, "->", n, ".las files")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""ctypes access to oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY (see oracle/oracle.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from damar_amd.api import HITS_DB, c_int64
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+KMER_DT = np.dtype([("code", "<u8"), ("rpos", "<i4"), ("read", "<i4")])
+SEED_DT = np.dtype([("diag", "<i4"), ("apos", "<i4"), ("aread", "<i4"), ("bread", "<i4")])
+
+
+class OParams(C.Structure):
+    _fields_ = [("kmer", C.c_int), ("binshift", C.c_int), ("suppress", C.c_int), ("hitmin", C.c_int),
+                ("nthreads", C.c_int), ("minover", C.c_int), ("hgap_min", C.c_int), ("symmetric", C.c_int),
+                ("identity", C.c_int), ("mem_limit", c_int64)]
+
+
+class Path(C.Structure):
+    _fields_ = [("trace", C.c_void_p), ("tlen", C.c_int), ("diffs", C.c_int), ("abpos", C.c_int),
+                ("bbpos", C.c_int), ("aepos", C.c_int), ("bepos", C.c_int)]
+
+
+_L = None
+
+
+def lib():
+    global _L
+    if _L is None:
+        _L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        _L.damar_read_block.argtypes = [C.c_char_p, C.POINTER(HITS_DB)]
+        _L.damar_complement_block.argtypes = [C.POINTER(HITS_DB), C.c_int]
+        _L.damar_complement_block.restype = C.POINTER(HITS_DB)
+        _L.oracle_sort_kmers.argtypes = [C.POINTER(HITS_DB), C.POINTER(OParams), C.POINTER(C.c_int)]
+        _L.oracle_sort_kmers.restype = C.c_void_p
+        _L.oracle_seed_pairs.argtypes = [C.POINTER(HITS_DB), C.POINTER(HITS_DB), C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_int, C.POINTER(OParams), C.POINTER(c_int64),
+                                         C.POINTER(C.c_int)]
+        _L.oracle_seed_pairs.restype = C.c_void_p
+        _L.oracle_local_alignment.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                              C.c_void_p, C.POINTER(Path), C.POINTER(Path), C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
+        _L.New_Align_Spec.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        _L.New_Align_Spec.restype = C.c_void_p
+        _L.free.argtypes = [C.c_void_p]
+    return _L
+
+
+def params(k=14, w=6, h=35, t=0, j=4, l=1000, symmetric=1, identity=0):
+    p = OParams()
+    p.kmer, p.binshift, p.suppress, p.hitmin, p.nthreads = k, w, t, h, j
+    p.minover, p.hgap_min, p.symmetric, p.identity = 2 * l, 0, symmetric, identity
+    p.mem_limit = 64 << 30
+    return p
+
+
+def read_block(name):
+    db = HITS_DB()
+    if lib().damar_read_block(name.encode(), C.byref(db)) != 0:
+        raise RuntimeError(name)
+    return db
+
+
+def sort_kmers(db, prm):
+    n = C.c_int(0)
+    p = lib().oracle_sort_kmers(C.byref(db), C.byref(prm), C.byref(n))
+    arr = np.ctypeslib.as_array((C.c_char * (16 * n.value)).from_address(p)).view(KMER_DT).copy() if p else np.zeros(0, KMER_DT)
+    return p, n.value, arr
+
+
+def seed_pairs(adb, bdb, ap, alen, bp, blen, self_, comp, prm):
+    nh, lim = c_int64(0), C.c_int(0)
+    p = lib().oracle_seed_pairs(C.byref(adb), C.byref(bdb), ap, alen, bp, blen, self_, comp, C.byref(prm),
+                                C.byref(nh), C.byref(lim))
+    if not p:
+        return np.zeros(0, SEED_DT)
+    arr = np.ctypeslib.as_array((C.c_char * (16 * nh.value)).from_address(p)).view(SEED_DT).copy()
+    lib().free(p)
+    return arr
+
+
+def local_alignment(adb, bdb, ar, br, comp, diag, anti, spec, maxtp):
+    a, b = Path(), Path()
+    at = (C.c_uint16 * maxtp)()
+    bt = (C.c_uint16 * maxtp)()
+    ra, rb = adb.reads[ar], bdb.reads[br]
+    lib().oracle_local_alignment(adb.bases + ra.boff, ra.rlen, bdb.bases + rb.boff, rb.rlen, comp, diag, anti,
+                                 spec, C.byref(a), C.byref(b), at, bt, None)
+    pa = [a.abpos, a.bbpos, a.aepos, a.bepos, a.diffs, a.tlen]
+    pb = [b.abpos, b.bbpos, b.aepos, b.bepos, b.diffs, b.tlen]
+    return pa + pb, list(at[:a.tlen]), list(bt[:b.tlen])

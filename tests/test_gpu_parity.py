@@ -1,0 +1,244 @@
+"""Parity of the HIP path (through the C-ABI of libdamar_hip.so) with the oracle, the golden
+reference outputs and known answers.  Everything here needs a real MI355X."""
+import ctypes as C
+import hashlib
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN, golden_cases, read_case, link_db, compare_las, opts_to_plan_kwargs
+
+pytestmark = pytest.mark.gpu
+
+NEEDS_BRIDGE = {"tandem"}
+
+
+@pytest.fixture(scope="module")
+def gpu(built):
+    from damar_amd import api
+    L = api.lib()
+    assert L.damar_hip_init(0) >= 1
+    return L
+
+
+def run_plan(case, workdir):
+    from damar_amd import driver
+    link_db(case["dbdir"], workdir)
+    plan = driver.Plan(**opts_to_plan_kwargs(case["opts"]))
+    blocks = {}
+    for a, bs in case["lines"]:
+        for x in [a] + bs:
+            if x not in blocks:
+                blocks[x] = driver.Block(os.path.join(workdir, "G." + x))
+    for a, bs in case["lines"]:
+        plan.run_line(blocks[a], [blocks[b] for b in bs], workdir)
+    return plan
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_gpu_las_equals_reference_golden(gpu, tmp_path, name):
+    if name in NEEDS_BRIDGE:
+        pytest.xfail("Bridge realignment is not built yet (host/bridge.c stops the run loudly)")
+    case = read_case(name)
+    run_plan(case, str(tmp_path))
+    assert compare_las(case, str(tmp_path)) == []
+
+
+def test_gpu_cli_binary_equals_reference_golden(gpu, tmp_path):
+    """The C host driver (the drop-in daligner command) on the 2-block fixture."""
+    import subprocess
+    case = read_case("tiny2")
+    link_db(case["dbdir"], str(tmp_path))
+    for a, bs in case["lines"]:
+        subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "daligner")] + case["opts"] + ["G." + a] +
+                       ["G." + b for b in bs], cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL)
+    assert compare_las(case, str(tmp_path)) == []
+
+
+def _index_as_records(L, idx, n):
+    import oracle_api as O
+    buf = np.zeros(n, dtype=O.KMER_DT)
+    L.damar_index_download(idx, buf.ctypes.data)
+    return buf
+
+
+@pytest.mark.parametrize("k,t", [(14, 0), (12, 0), (14, 10), (16, 0)])
+def test_gpu_kmer_index_equals_oracle(gpu, k, t):
+    """K1-K3: the device index in reference KmerPos layout vs oracle_sort_kmers."""
+    import oracle_api as O
+    from damar_amd import api
+    L = gpu
+    name = os.path.join(GOLDEN, "tiny2", "G.1")
+    db = api.read_block(name)
+    assert L.Set_Filter_Params(k, 6, t, 35, 4) == 0
+    n = C.c_int(0)
+    blk = L.damar_block_upload(C.byref(db))
+    idx = L.damar_index_build(blk, 0, C.byref(n))
+    got = _index_as_records(L, idx, n.value)
+    odb = O.read_block(name)
+    p, on, want = O.sort_kmers(odb, O.params(k=k, t=t))
+    assert on == n.value and n.value > 0
+    assert np.array_equal(got, want)
+    O.lib().free(p)
+    L.damar_index_free(idx)
+    L.damar_block_free(blk)
+    L.Set_Filter_Params(14, 6, 0, 35, 4)
+
+
+@pytest.mark.parametrize("comp", [0, 1])
+@pytest.mark.parametrize("cross", [0, 1])
+def test_gpu_seed_pairs_equal_oracle(gpu, comp, cross):
+    """K4 + seed sort: sorted SeedPair list vs oracle_seed_pairs, self and cross blocks."""
+    import oracle_api as O
+    from damar_amd import api
+    L = gpu
+    L.Set_Filter_Params(14, 6, 0, 35, 4)
+    api.set_globals()
+    an = os.path.join(GOLDEN, "tiny2", "G.2")
+    bn = os.path.join(GOLDEN, "tiny2", "G.1") if cross else an
+    adb, bdb = api.read_block(an), api.read_block(bn)
+    oadb, obdb = O.read_block(an), O.read_block(bn)
+    if comp:
+        L.damar_complement_block(C.byref(bdb), 1)
+        O.lib().damar_complement_block(C.byref(obdb), 1)
+    prm = O.params()
+    pa, na, _ = O.sort_kmers(oadb, prm)
+    if cross or comp:
+        pb, nb, _ = O.sort_kmers(obdb, prm)
+    else:
+        pb, nb = pa, na
+    want = O.seed_pairs(oadb, obdb, pa, na, pb, nb, 0 if cross else 1, comp, prm)
+
+    n = C.c_int(0)
+    ablk = L.damar_block_upload(C.byref(adb))
+    aidx = L.damar_index_build(ablk, 0, C.byref(n))
+    if cross or comp:
+        bblk = L.damar_block_upload(C.byref(bdb))
+        bidx = L.damar_index_build(bblk, 0, C.byref(n))
+    else:
+        bblk, bidx = None, aidx
+    spec = L.New_Align_Spec(.70, 100, adb.freq, 4, 1, 0, 0, 1)
+    L.damar_last_seeds(None, 1)                       # keep the seeds of the next match
+    cnt = (api.c_int64 * 3)()
+    L.damar_match(C.byref(adb), C.byref(bdb), aidx, bidx, 0 if cross else 1, comp, spec, cnt)
+    got = np.zeros(int(cnt[0]), dtype=O.SEED_DT)
+    assert L.damar_last_seeds(got.ctypes.data, len(got)) == len(want)
+    L.damar_last_seeds(None, 0)
+    assert len(got) == len(want) and len(want) > 1000
+    assert np.array_equal(got, want)
+    if bblk:
+        L.damar_index_free(bidx)
+        L.damar_block_free(bblk)
+    L.damar_index_free(aidx)
+    L.damar_block_free(ablk)
+
+
+@pytest.mark.parametrize("comp", [0, 1])
+def test_gpu_local_alignment_batch_equals_oracle(gpu, comp):
+    """K6 alone: thousands of (read pair, diagonal, anti-diagonal) seeds -- including seeds the
+    band filter would never fire -- through the wave kernel vs oracle_local_alignment."""
+    import oracle_api as O
+    from damar_amd import api
+    L = gpu
+    L.Set_Filter_Params(14, 6, 0, 35, 4)
+    an, bn = os.path.join(GOLDEN, "indel", "G.1"), os.path.join(GOLDEN, "indel", "G.1")
+    adb, bdb = api.read_block(an), api.read_block(bn)
+    oadb, obdb = O.read_block(an), O.read_block(bn)
+    if comp:
+        L.damar_complement_block(C.byref(bdb), 1)
+        O.lib().damar_complement_block(C.byref(obdb), 1)
+    prm = O.params()
+    pa, na, _ = O.sort_kmers(oadb, prm)
+    pb, nb, _ = O.sort_kmers(obdb, prm)
+    seeds = O.seed_pairs(oadb, obdb, pa, na, pb, nb, 0, comp, prm)
+    rng = random.Random(5 + comp)
+    pick = sorted(rng.sample(range(len(seeds)), 1500))
+    tasks = []
+    for i in pick:
+        s = seeds[i]
+        if s["aread"] == s["bread"] and not comp:
+            continue                                   # selfie seeds need aseq == bseq pointers
+        tasks += [int(s["aread"]), int(s["bread"]), int(s["diag"]), int(2 * s["apos"] - s["diag"])]
+    nt = len(tasks) // 4
+    ospec = O.lib().New_Align_Spec(.70, 100, oadb.freq, 1, 1, 0, 0, 1)
+    spec = L.New_Align_Spec(.70, 100, adb.freq, 1, 1, 0, 0, 1)
+    ablk, bblk = L.damar_block_upload(C.byref(adb)), L.damar_block_upload(C.byref(bdb))
+    paths = (C.c_int * (12 * nt))()
+    toff = (api.c_int64 * (2 * nt))()
+    cap = nt * 1200
+    traces = (C.c_uint16 * cap)()
+    assert L.damar_local_alignment_batch(ablk, bblk, comp, spec, (C.c_int * len(tasks))(*tasks), nt,
+                                         paths, toff, traces, cap) == 0
+    maxtp = 4 * (max(adb.maxlen, bdb.maxlen) // 100 + 4)
+    bad = 0
+    for t in range(nt):
+        ar, br, dg, anti = tasks[4 * t:4 * t + 4]
+        want, wat, wbt = O.local_alignment(oadb, obdb, ar, br, comp, dg, anti, ospec, maxtp)
+        got = list(paths[12 * t:12 * t + 12])
+        gat = list(traces[toff[2 * t]:toff[2 * t] + got[5]])
+        gbt = list(traces[toff[2 * t + 1]:toff[2 * t + 1] + got[11]])
+        if got != want or gat != wat or gbt != wbt:
+            bad += 1
+    assert nt > 1000 and bad == 0
+    L.damar_block_free(ablk)
+    L.damar_block_free(bblk)
+
+
+def test_gpu_config1_known_answer(gpu, tmp_path):
+    """BASELINE config 1 (simulator 0.5 -c20 -r1 -e.15, 930 reads, 10 Mbp): the reference's
+    .las md5 08bcb3ac... (reproduced in this repo's build container)."""
+    from damar_amd import api, driver
+    d = str(tmp_path)
+    assert api.sim_write_db(d, "SIM", 0.5, coverage=20., seed=1, block_mbp=200) == 1
+    blk = driver.Block(os.path.join(d, "SIM.1"))
+    plan = driver.Plan(j=4)
+    plan.run_line(blk, [blk], d)
+    las = os.path.join(d, "d001_00001", "SIM.1.SIM.1.las")
+    assert os.path.getsize(las) == 4982214
+    assert hashlib.md5(open(las, "rb").read()).hexdigest() == "08bcb3acacfb24a16fb3d18daeab5ff0"
+    assert plan.counts == [1475304 + 1473761, 8314 + 8377, 15632 + 15630]
+    n, bp = driver.las_stats(las)
+    assert (n, bp) == (31262, 184279123)
+
+
+def _check_las_invariants(path, tspace=100):
+    """LAcheck-style properties (utils/LAcheck.c -p -s): sorted by the 7 keys, trace sums
+    consistent with the B interval, diffs = sum of per-segment diffs."""
+    raw = open(path, "rb").read()
+    novl = int(np.frombuffer(raw, "<i8", 1)[0])
+    off, prev = 12, None
+    for _ in range(novl):
+        r = np.frombuffer(raw, "<i4", 10, off)
+        tlen, diffs, ab, bb, ae, be, flags, ar, br = [int(x) for x in r[:9]]
+        tr = np.frombuffer(raw, np.uint8, tlen, off + 40)
+        off += 40 + tlen
+        assert tlen % 2 == 0 and ae > ab and be > bb
+        assert int(tr[1::2].sum()) == be - bb
+        assert int(tr[0::2].sum()) == diffs
+        assert tlen // 2 == (ae - 1) // tspace - ab // tspace + 1 or tlen // 2 == ae // tspace - ab // tspace + (ae % tspace != 0)
+        key = (ar, br, flags & 1, ab, ae, bb, be)
+        assert prev is None or prev <= key
+        prev = key
+    assert off == len(raw)
+    return novl
+
+
+def test_gpu_config2_block_pairs_known_answer(gpu, tmp_path):
+    """BASELINE config 2 at full size (540 Mbp, 4 blocks of 135 Mbp): two of the ten block
+    pairs against the md5 of the files the reference wrote for them (tests/golden/
+    config2_ref_md5.txt), plus size-independent .las invariants on every file."""
+    from damar_amd import api, driver
+    d = str(tmp_path)
+    assert api.sim_write_db(d, "SIM", 27., coverage=20., seed=2, block_mbp=135) == 4
+    want = {}
+    for ln in open(os.path.join(GOLDEN, "config2_ref_md5.txt")):
+        m, f = ln.split()
+        want[f] = m
+    b1, b2 = driver.Block(os.path.join(d, "SIM.1")), driver.Block(os.path.join(d, "SIM.2"))
+    plan = driver.Plan(j=16)
+    plan.run_line(b2, [b2, b1], d)
+    for f in ("d001_00002/SIM.2.SIM.2.las", "d001_00002/SIM.2.SIM.1.las", "d001_00001/SIM.1.SIM.2.las"):
+        assert hashlib.md5(open(os.path.join(d, f), "rb").read()).hexdigest() == want[f], f
+        assert _check_las_invariants(os.path.join(d, f)) > 50000

@@ -1,0 +1,105 @@
+"""Host-side pieces of the path: synthetic DB writer, block loader, complement, .las I/O."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN
+
+
+def md5(p):
+    return hashlib.md5(open(p, "rb").read()).hexdigest()
+
+
+def test_simdb_is_deterministic_and_matches_golden_db(built, tmp_path):
+    from damar_amd import api
+    nb = api.sim_write_db(str(tmp_path), "G", 0.1, coverage=12., seed=11, block_mbp=1)
+    assert nb == 2
+    for f in ("G.db", ".G.bps"):
+        assert md5(os.path.join(str(tmp_path), f)) == md5(os.path.join(GOLDEN, "tiny2", f))
+    a = np.fromfile(os.path.join(str(tmp_path), ".G.idx"), dtype=np.uint8)
+    b = np.fromfile(os.path.join(GOLDEN, "tiny2", ".G.idx"), dtype=np.uint8)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "FA2db")), reason="needs oracle/_ref")
+def test_simdb_equals_simulator_fa2db_dbsplit(built, tmp_path):
+    """simulate->DB writer vs the reference's own simulator | FA2db ; DBsplit."""
+    from damar_amd import api
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    d1, d2 = str(tmp_path / "a"), str(tmp_path / "b")
+    os.makedirs(d1)
+    with open(os.path.join(d1, "sim.fasta"), "w") as f:
+        subprocess.run([os.path.join(ref, "simulator"), "0.2", "-c10", "-r5", "-e.15"], stdout=f, check=True)
+    subprocess.run([os.path.join(ref, "FA2db"), "G", "sim.fasta"], cwd=d1, check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ref, "DBsplit"), "-s1", "G"], cwd=d1, check=True, stdout=subprocess.DEVNULL)
+    api.sim_write_db(d2, "G", 0.2, coverage=10., seed=5, block_mbp=1)
+    assert md5(os.path.join(d1, ".G.bps")) == md5(os.path.join(d2, ".G.bps"))
+    assert open(os.path.join(d1, "G.db")).read() == open(os.path.join(d2, "G.db")).read()
+    a = np.fromfile(os.path.join(d1, ".G.idx"), dtype=np.uint8).copy()
+    b = np.fromfile(os.path.join(d2, ".G.idx"), dtype=np.uint8).copy()
+    assert len(a) == len(b)
+    for x in (a, b):                       # struct padding and dumped pointers
+        x[44:48] = 0
+        x[48:88] = 0
+        r = x[88:].reshape(-1, 32)
+        r[:, 4:8] = 0
+        r[:, 28:32] = 0
+    assert np.array_equal(a, b)
+
+
+def test_read_block_layout(built):
+    from damar_amd import api
+    db = api.read_block(os.path.join(GOLDEN, "tiny2", "G.2"))
+    assert db.part == 2 and db.nreads > 0 and db.ufirst > 0
+    bases = (C.c_char * (db.reads[db.nreads].boff)).from_address(db.bases)
+    assert C.c_char.from_address(db.bases - 1).value == b"\x04"       # db/DB.c:1570
+    tot, mx = 0, 0
+    for i in range(db.nreads):
+        r = db.reads[i]
+        assert bases[r.boff + r.rlen] == b"\x04"
+        assert db.reads[i + 1].boff == r.boff + r.rlen + 1
+        tot += r.rlen
+        mx = max(mx, r.rlen)
+    assert tot == db.totlen and mx == db.maxlen
+    raw = np.frombuffer(bases, dtype=np.uint8)
+    assert raw.max() == 4
+    api.lib().damar_close_block(C.byref(db))
+
+
+def test_complement_is_an_involution(built):
+    from damar_amd import api
+    L = api.lib()
+    db = api.read_block(os.path.join(GOLDEN, "tiny2", "G.1"))
+    n = db.reads[db.nreads].boff
+    before = bytes((C.c_char * n).from_address(db.bases))
+    f0 = list(db.freq)
+    L.damar_complement_block(C.byref(db), 1)
+    mid = bytes((C.c_char * n).from_address(db.bases))
+    assert mid != before and list(db.freq) == [f0[3], f0[2], f0[1], f0[0]]
+    r0 = db.reads[0]
+    assert mid[r0.boff] == 3 - before[r0.boff + r0.rlen - 1]
+    L.damar_complement_block(C.byref(db), 1)
+    assert bytes((C.c_char * n).from_address(db.bases)) == before
+    L.damar_close_block(C.byref(db))
+
+
+def test_get_dir_and_las_stats(built):
+    from damar_amd import api, driver
+    assert api.get_dir(1, 1) == "d001_00001"
+    assert api.get_dir(12, 345) == "d012_00345"
+    assert api.get_dir(3, 0) == "."
+    n, bp = driver.las_stats(os.path.join(GOLDEN, "tiny2", "las", "d001_00001", "G.1.G.1.las"))
+    assert n > 100 and bp > 100000
+    assert driver.hpc_plan(3) == [(1, [1]), (2, [2, 1]), (3, [3, 2, 1])]
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from damar_amd import lib as dl
+    monkeypatch.setattr(dl, "_LIB", None)
+    monkeypatch.setattr(dl, "lib_path", lambda: "/nonexistent/libdamar_hip.so")
+    with pytest.raises(dl.LibraryMissing):
+        dl.load()
