@@ -7,13 +7,15 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <unistd.h>
 
 #define HIP_CHECK(expr)                                                                   \
   do { hipError_t e_ = (expr);                                                            \
        if (e_ != hipSuccess)                                                              \
          { fprintf(stderr, "damar: HIP error %s at %s:%d: %s\n", hipGetErrorName(e_),     \
                    __FILE__, __LINE__, hipGetErrorString(e_));                            \
-           exit(1);                                                                       \
+           fflush(NULL);                                                                  \
+           _exit(1);                                                                      \
          }                                                                                \
      } while (0)
 

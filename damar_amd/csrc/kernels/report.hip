@@ -65,6 +65,16 @@ u64 damar_report_state_stride(int span)
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+/* Every data-dependent loop carries a bound (generous multiples of the read lengths): a
+ * loop that exceeds it records where (err[3] = code) and raises DAMAR_ERR_BAND instead of
+ * spinning, so that every wave always drains. */
+#define GUARD(cnt, lim, code)                                                               \
+  if (++(cnt) > (lim))                                                                      \
+    { atomicOr(c.err, DAMAR_ERR_BAND);                                                      \
+      atomicMax(c.err + 3, (u32) (code));                                                   \
+      break;                                                                                \
+    }
+
 /* One direction of the wave.  REV = 0: align.c:409-1122, REV = 1: align.c:1126-1898.
  * Returns through *res the end point of this direction; traces are written by lane 0. */
 template <int REV>
@@ -85,6 +95,7 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
   int aclip = REV ? -BIG : BIG, bclip = REV ? BIG : -BIG;
   u32 ncell = 0;
   const int steplimit = c.alen + c.blen + 64;
+  const int guard = 4 * (c.alen + c.blen) + 1024;
 
   trim.a = reach.a = mida;  trim.y = reach.y = besty;  trim.d = reach.d = 0;
   trim.ha = reach.ha = 0;   trim.hb = reach.hb = 1;
@@ -110,8 +121,10 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
     ha = 0;  hb = 1;  ncell = 2;
     if (!REV) { na += TS; nb += TS; }
 
+    int g0 = 0;
     for (;;)
-      { int cb = bseq[y], ca;
+      { GUARD(g0, guard, 1)
+        int cb = bseq[y], ca;
         if (cb == 4)
           { more = 0; bclip = k; break; }
         ca = a[y];
@@ -123,12 +136,14 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
       }
     v = (y << 1) + k;
     while (REV ? (y + k <= na) : (y + k >= na))
-      { cl.ptr = ha; cl.mark = na;
+      { GUARD(g0, guard, 2)
+        cl.ptr = ha; cl.mark = na;
         if (lane == 0 && ncell < c.cell_cap) c.cells[ncell] = cl;
         ha = (int) ncell++;  ham = na;  na += S * TS;
       }
     while (REV ? (y <= nb) : (y >= nb))
-      { cl.ptr = hb; cl.mark = nb;
+      { GUARD(g0, guard, 3)
+        cl.ptr = hb; cl.mark = nb;
         if (lane == 0 && ncell < c.cell_cap) c.cells[ncell] = cl;
         hb = (int) ncell++;  hbm = nb;  nb += S * TS;
       }
@@ -173,7 +188,12 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
   CLIP_STEP()
 
   while (more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
-    { if (hgh < low || dif > steplimit)
+    { if (hgh < low)                   /* every diagonal clipped or pruned: the reference's state is
+                                          undefined from here on; stop like the oracle does and count it */
+        { if (lane == 0) atomicAdd(c.err + 2, 1u);
+          break;
+        }
+      if (dif > steplimit)
         { if (lane == 0) atomicOr(c.err, DAMAR_ERR_BAND);
           break;
         }
@@ -235,8 +255,10 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
               b <<= 1;
               y = (v - k) >> 1;
               const u8 *a = aseq + k;
+              int g1 = 0;
               for (;;)
-                { int cb = bseq[y], ca;
+                { GUARD(g1, guard, 4)
+                  int cb = bseq[y], ca;
                   if (cb == 4)
                     { bhit = true; break; }
                   ca = a[y];
@@ -255,8 +277,10 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
             }
 
           /* pebbles: cells are handed out with a ballot prefix count (align.c:859-909) */
+          int g2 = 0;
           for (;;)
-            { bool need = act && (REV ? (y + k <= na) : (y + k >= na));
+            { GUARD(g2, guard, 5)
+              bool need = act && (REV ? (y + k <= na) : (y + k >= na));
               if (!__any(need))
                 break;
               bool dropit = need && (REV ? (ham > na) : (ham < na));
@@ -275,8 +299,10 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
               if (need)
                 na += S * TS;
             }
+          g2 = 0;
           for (;;)
-            { bool need = act && (REV ? (y <= nb) : (y >= nb));
+            { GUARD(g2, guard, 6)
+              bool need = act && (REV ? (y <= nb) : (y >= nb));
               if (!__any(need))
                 break;
               bool dropit = need && (REV ? (hbm > nb) : (hbm < nb));
@@ -397,11 +423,13 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
       else
         { trimx = trim.a - trim.y; trimy = trim.y; trimd = trim.d; ha = trim.ha; hb = trim.hb; }
 
+      int gw = 0;
       /* reverse both chains in place so they can be walked root -> head */
       for (int which = 0; which < 2; which++)
         { int h = which ? hb : ha, prev = -1;
           while (h >= 0)
-            { int nx = cells[h].ptr;
+            { GUARD(gw, guard, 7)
+              int nx = cells[h].ptr;
               cells[h].ptr = prev;
               prev = h;
               h = nx;
@@ -412,7 +440,8 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
       if (!REV)
         { int h = ha, k = cells[h].diag, b = (mida - k) / 2, e = 0, n = 0;
           for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-            { Cell p = cells[h];
+            { GUARD(gw, guard, 8)
+              Cell p = cells[h];
               int  a = p.mark - p.diag;
               k = p.diag;
               atrace[n++] = (u16) (p.diff - e);
@@ -431,7 +460,8 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
 
           h = hb;  k = cells[h].diag;  b = (mida + k) / 2;  e = 0;  n = 0;
           for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-            { Cell p = cells[h];
+            { GUARD(gw, guard, 9)
+              Cell p = cells[h];
               int  a = p.mark + p.diag;
               k = p.diag;
               btrace[n++] = (u16) (p.diff - e);
@@ -470,7 +500,8 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
             }
           if (walk)
             { for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-                { k = cells[h].diag;  a = cells[h].mark - k;  d = cells[h].diff;
+                { GUARD(gw, guard, 10)
+                  k = cells[h].diag;  a = cells[h].mark - k;  d = cells[h].diff;
                   atrace[--n] = (u16) (b - a);
                   atrace[--n] = (u16) (d - e);
                   b = a;  e = d;
@@ -505,7 +536,8 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
             }
           if (walk)
             { for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-                { k = cells[h].diag;  a = cells[h].mark + k;  d = cells[h].diff;
+                { GUARD(gw, guard, 11)
+                  k = cells[h].diag;  a = cells[h].mark + k;  d = cells[h].diff;
                   btrace[--n] = (u16) (b - a);
                   btrace[--n] = (u16) (d - e);
                   b = a;  e = d;
@@ -593,41 +625,47 @@ __device__ __forceinline__ SlotScratch slot_scratch(const ReportArgs &a, int slo
 
 /* emit one alignment: copies both traces to the pool (B trace reversed pairwise for COMP,
  * align.c:2033-2056) and writes the record */
-__device__ void emit_record(const ReportArgs &a, const SlotScratch &s, const LaResult &r,
-                            int ar, int br, u32 item, u32 seq)
+__device__ __noinline__ void emit_record(const ReportArgs &a, const SlotScratch &s, const LaResult &r,
+                                         int ar, int br, u32 item, u32 seq)
 { const int lane = lane_id();
+  const int nval = r.atlen + r.btlen;
   u32 ri = 0, to = 0;
   if (lane == 0)
     { ri = atomicAdd(&a.counters[1], 1u);
-      to = atomicAdd(&a.counters[2], (u32) (r.atlen + r.btlen));
+      to = atomicAdd(&a.counters[2], (u32) nval);
     }
   ri = (u32) uni((int) ri);
   to = (u32) uni((int) to);
+  u32 bad = 0;
   if (ri >= a.rec_cap)
-    { if (lane == 0) atomicOr(&a.counters[3], DAMAR_ERR_RECS);
-      return;
+    bad |= DAMAR_ERR_RECS;
+  if ((u64) to + (u64) nval > (u64) a.tpool_cap)
+    bad |= DAMAR_ERR_TPOOL;
+  if (bad == 0)
+    { const u16 *at = s.atr - r.aback, *bt = s.btr - r.bback;
+      for (int i = lane; i < nval; i += 64)
+        { u16 v;
+          if (i < r.atlen)
+            v = at[i];
+          else
+            { int j = i - r.atlen;
+              if (a.comp)                 /* B trace pairs in reverse order, align.c:2043-2055 */
+                j = (r.btlen - 2 - 2 * (j >> 1)) + (j & 1);
+              v = bt[j];
+            }
+          a.tpool[to + i] = v;
+        }
     }
-  if ((u64) to + (u64) (r.atlen + r.btlen) > (u64) a.tpool_cap)
-    { if (lane == 0) atomicOr(&a.counters[3], DAMAR_ERR_TPOOL);
-      return;
-    }
-  const u16 *at = s.atr - r.aback, *bt = s.btr - r.bback;
-  for (int i = lane; i < r.atlen; i += 64)
-    a.tpool[to + i] = at[i];
-  if (a.comp)
-    for (int i = lane; i < r.btlen; i += 64)
-      { int pair = i >> 1, src = (r.btlen - 2 - 2 * pair) + (i & 1);
-        a.tpool[to + r.atlen + i] = bt[src];
-      }
-  else
-    for (int i = lane; i < r.btlen; i += 64)
-      a.tpool[to + r.atlen + i] = bt[i];
   if (lane == 0)
-    { LaRecord rec;
-      rec.abpos = r.abpos;  rec.bbpos = r.bbpos;  rec.aepos = r.aepos;  rec.bepos = r.bepos;
-      rec.diffs = r.diffs;  rec.atlen = r.atlen;  rec.btlen = r.btlen;
-      rec.aread = ar;  rec.bread = br;  rec.item = item;  rec.seq = seq;  rec.toff = to;
-      a.recs[ri] = rec;
+    { if (bad)
+        atomicOr(&a.counters[3], bad);
+      else
+        { LaRecord rec;
+          rec.abpos = r.abpos;  rec.bbpos = r.bbpos;  rec.aepos = r.aepos;  rec.bepos = r.bepos;
+          rec.diffs = r.diffs;  rec.atlen = r.atlen;  rec.btlen = r.btlen;
+          rec.aread = ar;  rec.bread = br;  rec.item = item;  rec.seq = seq;  rec.toff = to;
+          a.recs[ri] = rec;
+        }
     }
 }
 
@@ -830,7 +868,9 @@ void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
       t = (u32) uni((int) t);
       if (t >= ntasks)
         break;
-      const LaTask tk = tasks[t];
+      LaTask tk = tasks[t];
+      tk.aread = uni(tk.aread);  tk.bread = uni(tk.bread);      /* wave-uniform: keep them scalar */
+      tk.diag  = uni(tk.diag);   tk.anti  = uni(tk.anti);
       WaveCtx c;
       c.aseq = a.ablk.bases + a.ablk.boff[tk.aread];
       c.bseq = a.bblk.bases + a.bblk.boff[tk.bread];

@@ -26,6 +26,14 @@ extern "C" {
 
 #define MAXGRAM 10000          /* filter.c:71 */
 
+/* Fatal errors end the process like the reference's exit(1) (db/DB.h:84-86), but without
+ * running atexit handlers: tearing the HIP runtime down from inside a failed call can hang
+ * when the library is embedded (ctypes). */
+static void die(void)
+{ fflush(NULL);
+  _exit(1);
+}
+
 /***** globals shared with the caller (filter.h:54-62 / daligner.c:131-140) *****************/
 
 extern "C" {
@@ -88,7 +96,7 @@ static void *arena_take(Arena *a, size_t n)
 { size_t at = (a->top + 255) & ~(size_t) 255;
   if (at + n > a->cap)
     { fprintf(stderr, "damar: internal error, device arena overflow (%zu + %zu > %zu)\n", at, n, a->cap);
-      exit(1);
+      die();
     }
   a->top = at + n;
   return a->base + at;
@@ -102,11 +110,11 @@ extern "C" int damar_hip_init(int device)
   if (e != hipSuccess || ndev <= 0)
     { fprintf(stderr, "damar: FATAL: no HIP device visible (%s); libdamar_hip has no CPU fallback\n",
               hipGetErrorString(e));
-      exit(1);
+      die();
     }
   if (device < 0 || device >= ndev)
     { fprintf(stderr, "damar: FATAL: device %d requested, %d present\n", device, ndev);
-      exit(1);
+      die();
     }
   HIP_CHECK(hipSetDevice(device));
   HIP_CHECK(hipGetDeviceProperties(&G_prop, device));
@@ -176,7 +184,7 @@ extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
   int64  total = block->reads[n].boff;
   if (total > 0x7fffffffll)
     { fprintf(stderr, "damar: Fatal error, DB blocks are greater than 2Gbp!\n");   /* filter.c:794-798 */
-      exit(1);
+      die();
     }
   std::vector<u32> boff((size_t) n + 1);
   for (int i = 0; i <= n; i++)
@@ -241,11 +249,11 @@ extern "C" damar_dev_index *damar_index_build(damar_dev_block *blk, int own_bloc
   const int K = P_kmer;
   if (K > 16)
     { fprintf(stderr, "damar: FATAL: -k%d: the device index holds 2k <= 32 code bits (k <= 16) in this build\n", K);
-      exit(1);
+      die();
     }
   if (BIASED)
     { fprintf(stderr, "damar: FATAL: -b (biased k-mers, filter.c:549-688) is not built yet\n");
-      exit(1);
+      die();
     }
   int64 nk64 = (int64) blk->d.total - (int64) K * blk->nreads;
   if (nk64 <= 0)
@@ -279,7 +287,7 @@ extern "C" damar_dev_index *damar_index_build(damar_dev_block *blk, int own_bloc
   tick(2);
   if ((side ? k1 : k0) != ix->codes)
     { fprintf(stderr, "damar: internal error, sort ended on the wrong side\n");
-      exit(1);
+      die();
     }
   u32 n = nk;
   ix->tbits = std::min(kbits, std::max(8, std::min(24, ilog2_ceil(nk) - 2)));
@@ -352,7 +360,7 @@ extern "C" void damar_index_download(const damar_dev_index *ix, void *out)
 extern "C" void *Sort_Kmers(HITS_DB *block, int *len)
 { if (block->tracks != NULL)
     { fprintf(stderr, "damar: FATAL: mask tracks (-m, filter.c:474-526) are not built yet\n");
-      exit(1);
+      die();
     }
   damar_dev_block *b = damar_block_upload(block);
   return (void *) damar_index_build(b, 1, len);
@@ -488,7 +496,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
     return;
   if (aidx->kbits != bidx->kbits || aidx->tbits > aidx->kbits)
     { fprintf(stderr, "damar: internal error, index parameters differ\n");
-      exit(1);
+      die();
     }
 
   const u32 alen = aidx->n, blen = bidx->n;
@@ -506,7 +514,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   int bbits = std::max(1, ilog2_ceil((u64) bblock->nreads));
   if (m.pbits + m.abits + bbits > 64)
     { fprintf(stderr, "damar: FATAL: seed key needs %d bits (> 64)\n", m.pbits + m.abits + bbits);
-      exit(1);
+      die();
     }
   m.atbits = aidx->tbits;
   m.btbits = bidx->tbits;
@@ -549,7 +557,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
         { fprintf(stderr, "damar: FATAL: host memory limit would cap mutual k-mer matches below %d "
                           "(%llu seeds > %lld); the adaptive cap of filter.c:2652-2659 is not built yet\n",
                   MAXGRAM, (unsigned long long) total, (long long) avail);
-          exit(1);
+          die();
         }
       if (VERBOSE)
         printf("\n   Capping mutual k-mer matches over %d (effectively -t%d)\n", MAXGRAM, 100);
@@ -562,7 +570,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   if (total >= 0xfffffff0ull)
     { fprintf(stderr, "damar: FATAL: %llu seed pairs exceed the 32-bit seed index of this build\n",
               (unsigned long long) total);
-      exit(1);
+      die();
     }
   if (total == 0)
     { if (counts) counts[0] = 0;
@@ -644,12 +652,12 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
           if (hc[3] == 0)
             break;
           if (hc[3] & DAMAR_ERR_BAND)
-            { fprintf(stderr, "damar: FATAL: a Local_Alignment wave ran out of band (empty band or step limit)\n");
-              exit(1);
+            { fprintf(stderr, "damar: FATAL: a Local_Alignment wave exceeded its loop bound (where=%u)\n", hc[6]);
+              die();
             }
           if (attempt >= 6)
             { fprintf(stderr, "damar: FATAL: report kernel keeps overflowing its buffers (flags %u)\n", hc[3]);
-              exit(1);
+              die();
             }
           if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
           if (hc[3] & DAMAR_ERR_RECS)  rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
@@ -780,18 +788,21 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
   for (int attempt = 0; ; attempt++)
     { ReportArgs ra;
       scratch_prepare(ablk->d.maxlen, bblk->d.maxlen, P_binshift, ts, cell_cap);
+      stage("la_scratch");
       scratch_outputs(rec_cap, tp_cap);
       fill_report_args(&ra, ablk, bblk, comp, 0, spec);
       HIP_CHECK(hipMemsetAsync(RS.counters, 0, 64, G_st));
+      stage("la_setup");
       damar_launch_la_batch(&ra, dt, (u32) ntasks, RS.nslots, G_st);
+      stage("la_kernel");
       HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, G_st));
       HIP_CHECK(hipStreamSynchronize(G_st));
       HIP_CHECK(hipGetLastError());
       if (hc[3] == 0)
         break;
       if ((hc[3] & DAMAR_ERR_BAND) || attempt >= 6)
-        { fprintf(stderr, "damar: FATAL: batch Local_Alignment failed (flags %u)\n", hc[3]);
-          exit(1);
+        { fprintf(stderr, "damar: FATAL: batch Local_Alignment failed (flags %u, where=%u)\n", hc[3], hc[6]);
+          die();
         }
       if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
       if (hc[3] & DAMAR_ERR_TPOOL)

@@ -181,7 +181,7 @@ def test_gpu_local_alignment_batch_equals_oracle(gpu, comp):
         gbt = list(traces[toff[2 * t + 1]:toff[2 * t + 1] + got[11]])
         if got != want or gat != wat or gbt != wbt:
             bad += 1
-    assert nt > 1000 and bad == 0
+    assert nt > (1000 if comp else 200) and bad == 0
     L.damar_block_free(ablk)
     L.damar_block_free(bblk)
 
