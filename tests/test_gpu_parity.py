@@ -242,3 +242,19 @@ def test_gpu_config2_block_pairs_known_answer(gpu, tmp_path):
     for f in ("d001_00002/SIM.2.SIM.2.las", "d001_00002/SIM.2.SIM.1.las", "d001_00001/SIM.1.SIM.2.las"):
         assert hashlib.md5(open(os.path.join(d, f), "rb").read()).hexdigest() == want[f], f
         assert _check_las_invariants(os.path.join(d, f)) > 50000
+
+
+def test_reference_driver_linked_against_hip_library(gpu, tmp_path):
+    """Drop-in proof: the reference's OWN dalign/daligner.c, compiled from /root/reference and
+    linked against libdamar_hip.so instead of filter.c + align.c (oracle/Makefile.ref target
+    `dropin`), writes the golden .las files."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "daligner_on_damar")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/daligner_on_damar not built (needs /root/reference at build time)")
+    case = read_case("tiny2")
+    link_db(case["dbdir"], str(tmp_path))
+    for a, bs in case["lines"]:
+        subprocess.run([exe] + case["opts"] + ["G." + a] + ["G." + b for b in bs], cwd=str(tmp_path), check=True,
+                       stdout=subprocess.DEVNULL)
+    assert compare_las(case, str(tmp_path)) == []
