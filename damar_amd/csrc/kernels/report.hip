@@ -75,10 +75,65 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
       break;                                                                                \
     }
 
+
+/* Eight bases per step.  load8 returns bytes p[0..7] of an arbitrarily aligned address as a
+ * little-endian u64 from three aligned dword loads (the bases buffer is padded by 64 bytes on
+ * both sides, so the extra bytes are always mapped). */
+__device__ __forceinline__ u64 load8(const u8 *p)
+{ const uintptr_t ad = (uintptr_t) p;
+  const u32 *q = (const u32 *) (ad & ~(uintptr_t) 3);
+  const u32 sh = (u32) (ad & 3);
+  const u32 w0 = q[0], w1 = q[1], w2 = q[2];
+  const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+  const u32 hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+  return ((u64) hi << 32) | lo;
+}
+
+/* The snake of align.c:832-856 / 1542-1566: slide along the diagonal while a[y] == b[y],
+ * stopping at the first mismatch or terminator (4).  A `4` in B is tested first, exactly as
+ * the reference does.  Each match shifts a 1 into the history b and raises m when the bit
+ * leaving the 60-column window was a 0; n matches at once examine bits 60..61-n of b. */
+template <int REV>
+__device__ __forceinline__ void snake(const u8 *a, const u8 *bq, int &y, int &m, u64 &b,
+                                      bool &ahit, bool &bhit, int guard, u32 *err)
+{ const u64 LO7 = 0x7f7f7f7f7f7f7f7full, HI8 = 0x8080808080808080ull;
+  int g = 0;
+  for (;;)
+    { if (++g > guard)
+        { atomicOr(err, DAMAR_ERR_BAND);
+          atomicMax(err + 3, 15u);
+          break;
+        }
+      const u64 wa = REV ? load8(a + y - 7) : load8(a + y);
+      const u64 wb = REV ? load8(bq + y - 7) : load8(bq + y);
+      const u64 d  = wa ^ wb;
+      const u64 nz = (((d & LO7) + LO7) | d) & HI8;              /* bytes with a != b  */
+      const u64 e  = wb ^ 0x0404040404040404ull;
+      const u64 z4 = ~(((e & LO7) + LO7) | e) & HI8;             /* bytes with b == 4  */
+      const u64 stop = nz | z4;
+      int n;
+      if (!REV) n = stop ? ((__ffsll((long long) stop) - 1) >> 3) : 8;
+      else      n = stop ? (__clzll((long long) stop) >> 3) : 8;
+      if (n > 0)
+        { const u32 passed = (u32) (b >> (61 - n)) & ((1u << n) - 1);
+          m += n - __popc(passed);
+          b = (b << n) | ((1ull << n) - 1);
+          y += REV ? -n : n;
+        }
+      if (stop)
+        { const int bi = REV ? 7 - n : n;
+          const u32 cb = (u32) (wb >> (8 * bi)) & 0xff, ca = (u32) (wa >> (8 * bi)) & 0xff;
+          if (cb == 4) bhit = true;
+          else if (ca == 4) ahit = true;
+          break;
+        }
+    }
+}
+
 /* One direction of the wave.  REV = 0: align.c:409-1122, REV = 1: align.c:1126-1898.
  * Returns through *res the end point of this direction; traces are written by lane 0. */
 template <int REV>
-__device__ void wave_pass(const WaveCtx &c, int diag, int mida,
+__device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
                           int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
 { const int lane = lane_id();
   const int TS = c.ts;
@@ -100,7 +155,11 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
   trim.a = reach.a = mida;  trim.y = reach.y = besty;  trim.d = reach.d = 0;
   trim.ha = reach.ha = 0;   trim.hb = reach.hb = 1;
 
-  /* wave 0 on the seed diagonal: every lane computes the same values, lane 0 stores */
+  /* Per-lane band state of the register path: lane (k & 63) owns diagonal k. */
+  int rV = 0, rM = 0, rHA = 0, rHB = 0, rHAm = 0, rHBm = 0, rNA = 0, rNB = 0;
+  u64 rT = 0;
+
+  /* wave 0 on the seed diagonal: every lane computes the same values */
   { int k = diag, y = (mida - k) >> 1, na, nb, ha, hb, ham, hbm, v;
     const u8 *a = aseq + k;
     Cell cl;
@@ -122,18 +181,11 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
     if (!REV) { na += TS; nb += TS; }
 
     int g0 = 0;
-    for (;;)
-      { GUARD(g0, guard, 1)
-        int cb = bseq[y], ca;
-        if (cb == 4)
-          { more = 0; bclip = k; break; }
-        ca = a[y];
-        if (cb != ca)
-          { if (ca == 4) { more = 0; aclip = k; }
-            break;
-          }
-        y += S;
-      }
+    { int m0 = 0;  u64 b0 = 0;  bool ah = false, bh = false;
+      snake<REV>(a, bseq, y, m0, b0, ah, bh, guard, c.err);
+      if (bh)      { more = 0; bclip = k; }
+      else if (ah) { more = 0; aclip = k; }
+    }
     v = (y << 1) + k;
     while (REV ? (y + k <= na) : (y + k >= na))
       { GUARD(g0, guard, 2)
@@ -152,13 +204,250 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
         besty = trim.y = y;
         trim.ha = ha;  trim.hb = hb;
       }
-    if (lane == 0)
-      { DState s;
-        s.V = v; s.M = HIST_LEN; s.HA = ha; s.HB = hb; s.T = HIST_FULL; s.HAm = ham; s.HBm = hbm;
-        cur[k + o] = s;
-        c.NA[k + o] = na;
-        c.NB[k + o] = nb;
+    rV = v;  rM = HIST_LEN;  rT = HIST_FULL;  rHA = ha;  rHB = hb;  rHAm = ham;  rHBm = hbm;
+    rNA = na;  rNB = nb;
+  }
+
+  /***** register path: the band (<= 64 diagonals) lives in VGPRs, neighbours by lane shuffle *****/
+  bool stopped = false;
+  { const int edge = REV ? BIG : -1;
+
+#define LANE_OF(k)   ((k) & 63)
+#define ROTR(x, sh)  (((sh) & 63) ? (((x) >> ((sh) & 63)) | ((x) << (64 - ((sh) & 63)))) : (x))
+
+    /* clipping with the state read from the owning lane (align.c:628-658 / 943-975) */
+#define CLIP_REG()                                                                         \
+    if (more == 0)                                                                         \
+      { if (bseq[besty] != 4 && aseq[besta - besty] != 4)                                  \
+          more = 1;                                                                        \
+        if (REV ? (low <= aclip) : (hgh >= aclip))                                         \
+          { const int l_ = LANE_OF(aclip);                                                 \
+            const int m_ = bcast_i(rM, l_), v_ = bcast_i(rV, l_);                          \
+            if (REV) low = aclip + 1; else hgh = aclip - 1;                                \
+            if (reachm <= m_)                                                              \
+              { reachm = m_; reach.a = v_; reach.y = (v_ - aclip) / 2; reach.d = dif;      \
+                reach.ha = bcast_i(rHA, l_); reach.hb = bcast_i(rHB, l_); }                \
+          }                                                                                \
+        if (REV ? (hgh >= bclip) : (low <= bclip))                                         \
+          { const int l_ = LANE_OF(bclip);                                                 \
+            const int m_ = bcast_i(rM, l_), v_ = bcast_i(rV, l_);                          \
+            if (REV) hgh = bclip - 1; else low = bclip + 1;                                \
+            if (reachm <= m_)                                                              \
+              { reachm = m_; reach.a = v_; reach.y = (v_ - bclip) / 2; reach.d = dif;      \
+                reach.ha = bcast_i(rHA, l_); reach.hb = bcast_i(rHB, l_); }                \
+          }                                                                                \
+        aclip = REV ? -BIG : BIG;                                                          \
+        bclip = REV ? BIG : -BIG;                                                          \
       }
+
+    CLIP_REG()
+
+    while (more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
+      { if (hgh < low)
+          { if (lane == 0) atomicAdd(c.err + 2, 1u);
+            stopped = true;
+            break;
+          }
+        if (dif > steplimit)
+          { if (lane == 0) atomicOr(c.err, DAMAR_ERR_BAND);
+            stopped = true;
+            break;
+          }
+        if (hgh - low + 3 > 64)        /* would not fit the wavefront: continue in memory */
+          break;
+
+        /* widen (align.c:675-776 / 1386-1486): a new edge lane gets V = edge and its inner
+           neighbour's NA/NB */
+        { const int upNA = __shfl(rNA, (lane + 1) & 63), upNB = __shfl(rNB, (lane + 1) & 63);
+          const int dnNA = __shfl(rNA, (lane - 1) & 63), dnNB = __shfl(rNB, (lane - 1) & 63);
+          int nlow = low - 1, nhgh = hgh + 1;
+          if (nlow >= c.minp)
+            { if (lane == LANE_OF(nlow)) { rV = edge; rNA = upNA; rNB = upNB; } }
+          else
+            nlow += 1;
+          if (nhgh <= c.maxp)
+            { if (lane == LANE_OF(nhgh)) { rV = edge; rNA = dnNA; rNB = dnNB; } }
+          else
+            nhgh -= 1;
+          low = nlow;  hgh = nhgh;
+          dif += 1;
+        }
+
+        const int  k   = low + ((lane - low) & 63);
+        const bool act = k <= hgh;
+        int  v, y = 0, m, ha, hb, ham, hbm;
+        u64  b;
+        bool ahit = false, bhit = false;
+
+        { const int ac = rV;
+          int am = __shfl(rV, (lane - 1) & 63), ap = __shfl(rV, (lane + 1) & 63);
+          int dl;                                     /* predecessor = k + dl */
+          if (k - 1 < low) am = edge;
+          if (k + 1 > hgh) ap = edge;
+          if (!REV)
+            { if (ac < am) dl = (am < ap) ? 1 : -1;
+              else         dl = (ac < ap) ? 1 : 0;
+              v = (dl == 0) ? ac + 2 : ((dl == 1) ? ap + 1 : am + 1);
+            }
+          else
+            { if (ac > ap) dl = (ap > am) ? -1 : 1;
+              else         dl = (ac > am) ? -1 : 0;
+              v = (dl == 0) ? ac - 2 : ((dl == -1) ? am - 1 : ap - 1);
+            }
+          const int src = (lane + dl) & 63;
+          m   = __shfl(rM, src);
+          ha  = __shfl(rHA, src);
+          hb  = __shfl(rHB, src);
+          ham = __shfl(rHAm, src);
+          hbm = __shfl(rHBm, src);
+          { u32 tlo = (u32) __shfl((int) (u32) rT, src), thi = (u32) __shfl((int) (u32) (rT >> 32), src);
+            b = ((u64) thi << 32) | tlo;
+          }
+        }
+
+        if (act)
+          { if (b & HIST_TOP)
+              m -= 1;
+            b <<= 1;
+            y = (v - k) >> 1;
+            snake<REV>(aseq + k, bseq, y, m, b, ahit, bhit, guard, c.err);
+            v = (y << 1) + k;
+          }
+        else
+          { v = edge; m = 0; b = 0; ha = hb = 0; ham = hbm = 0; }
+
+        /* pebbles (align.c:859-909): almost never needed, so test once for the whole wave */
+        int na = rNA, nb = rNB;
+        if (__any(act && (REV ? ((y + k <= na) || (y <= nb)) : ((y + k >= na) || (y >= nb)))))
+          { int g2 = 0;
+            for (;;)
+              { GUARD(g2, guard, 13)
+                bool need = act && (REV ? (y + k <= na) : (y + k >= na));
+                if (!__any(need))
+                  break;
+                bool dropit = need && (REV ? (ham > na) : (ham < na));
+                u64  mask = __ballot(dropit);
+                if (mask)
+                  { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
+                    if (dropit)
+                      { if (idx < c.cell_cap)
+                          { Cell cl; cl.ptr = ha; cl.diag = k; cl.diff = dif; cl.mark = na;
+                            c.cells[idx] = cl;
+                          }
+                        ha = (int) idx;  ham = na;
+                      }
+                    ncell += (u32) __popcll(mask);
+                  }
+                if (need)
+                  na += S * TS;
+              }
+            g2 = 0;
+            for (;;)
+              { GUARD(g2, guard, 14)
+                bool need = act && (REV ? (y <= nb) : (y >= nb));
+                if (!__any(need))
+                  break;
+                bool dropit = need && (REV ? (hbm > nb) : (hbm < nb));
+                u64  mask = __ballot(dropit);
+                if (mask)
+                  { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
+                    if (dropit)
+                      { if (idx < c.cell_cap)
+                          { Cell cl; cl.ptr = hb; cl.diag = k; cl.diff = dif; cl.mark = nb;
+                            c.cells[idx] = cl;
+                          }
+                        hb = (int) idx;  hbm = nb;
+                      }
+                    ncell += (u32) __popcll(mask);
+                  }
+                if (need)
+                  nb += S * TS;
+              }
+          }
+
+        /* commit the new wave */
+        rV = v;  rM = m;  rT = b;  rHA = ha;  rHB = hb;  rHAm = ham;  rHBm = hbm;
+        if (act) { rNA = na;  rNB = nb; }
+
+        /* sequence ends reached (bit i of the rotated masks = diagonal low + i) */
+        { u64 am_ = __ballot(ahit), bm_ = __ballot(bhit);
+          if (am_ | bm_)
+            { more = 0;
+              if (am_)
+                { u64 r = ROTR(am_, low);
+                  aclip = REV ? low + (63 - __clzll(r)) : low + (__ffsll((long long) r) - 1);
+                }
+              if (bm_)
+                { u64 r = ROTR(bm_, low);
+                  bclip = REV ? low + (__ffsll((long long) r) - 1) : low + (63 - __clzll(r));
+                }
+            }
+        }
+
+        /* new best / trim point in sweep order (align.c:911-928 / 1620-1637) */
+        { u64 cand = __ballot(act && (REV ? (v < besta) : (v > besta)));
+          if (cand)
+            { cand = ROTR(cand, low);
+              while (cand)
+                { int i = REV ? (__ffsll((long long) cand) - 1) : (63 - __clzll(cand));
+                  cand &= ~(1ull << i);
+                  const int l = LANE_OF(low + i);
+                  const int vl = bcast_i(v, l);
+                  if (REV ? (vl < besta) : (vl > besta))
+                    { besta = vl;
+                      besty = bcast_i(y, l);
+                      if (bcast_i(m, l) >= c.ave)
+                        { u64 bl = bcast_u64(b, l);
+                          lasta = vl;
+                          if (c.table[bl & TRIM_MASK] >= 0 &&
+                              c.table[(bl >> TRIM_BITS) & TRIM_MASK] + c.score[bl & TRIM_MASK] >= 0)
+                            { trim.a = vl;  trim.y = besty;  trim.d = dif;
+                              trim.ha = bcast_i(ha, l);  trim.hb = bcast_i(hb, l);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (ncell > c.cell_cap)
+          { if (lane == 0) atomicOr(c.err, DAMAR_ERR_CELLS);
+            more = 0;
+            ncell = 2;
+            stopped = true;
+            break;
+          }
+
+        CLIP_REG()
+
+        /* prune (align.c:977-986 / 1686-1695) */
+        { const int n = REV ? besta + MAX_WAVE_LAG : besta - MAX_WAVE_LAG;
+          const int kk = low + ((lane - low) & 63);
+          u64 keep = __ballot((kk <= hgh) && (REV ? (rV <= n) : (rV >= n)));
+          if (keep == 0)
+            hgh = low - 1;
+          else
+            { u64 r = ROTR(keep, low);
+              const int l0 = low;
+              low = l0 + (__ffsll((long long) r) - 1);
+              hgh = l0 + (63 - __clzll(r));
+            }
+        }
+      }
+#undef CLIP_REG
+
+    /* leaving the register path with work left: spill the band to the memory buffers */
+    if (!stopped && more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
+      { const int k = low + ((lane - low) & 63);
+        if (k <= hgh)
+          { DState s;
+            s.V = rV; s.M = rM; s.HA = rHA; s.HB = rHB; s.T = rT; s.HAm = rHAm; s.HBm = rHBm;
+            cur[k + o] = s;
+            c.NA[k + o] = rNA;
+            c.NB[k + o] = rNB;
+          }
+      }
+    else
+      stopped = true;
   }
   wave_mem_sync();
 
@@ -185,9 +474,8 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
       bclip = REV ? BIG : -BIG;                                                            \
     }
 
-  CLIP_STEP()
-
-  while (more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
+  /***** memory path: bands wider than the wavefront (rare), state in the slot's DState buffers *****/
+  while (!stopped && more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
     { if (hgh < low)                   /* every diagonal clipped or pruned: the reference's state is
                                           undefined from here on; stop like the oracle does and count it */
         { if (lane == 0) atomicAdd(c.err + 2, 1u);
@@ -254,23 +542,7 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
                 m -= 1;
               b <<= 1;
               y = (v - k) >> 1;
-              const u8 *a = aseq + k;
-              int g1 = 0;
-              for (;;)
-                { GUARD(g1, guard, 4)
-                  int cb = bseq[y], ca;
-                  if (cb == 4)
-                    { bhit = true; break; }
-                  ca = a[y];
-                  if (cb != ca)
-                    { ahit = (ca == 4);
-                      break;
-                    }
-                  y += S;
-                  if ((b & HIST_TOP) == 0)
-                    m += 1;
-                  b = (b << 1) | 1;
-                }
+              snake<REV>(aseq + k, bseq, y, m, b, ahit, bhit, guard, c.err);
               v = (y << 1) + k;
               na = c.NA[k + o];
               nb = c.NB[k + o];

@@ -172,7 +172,7 @@ extern "C" void damar_last_counters(int64 *c)   { memcpy(c, G_cnt, sizeof(G_cnt)
 
 struct damar_dev_block
 { DevBlock d;
-  u8  *bases_alloc;        /* starts one byte before d.bases (the leading terminator) */
+  u8  *bases_alloc;        /* d.bases = bases_alloc + 64; d.bases[-1] is the leading terminator */
   u32 *boff, *coarse;
   int  nreads;
 };
@@ -199,15 +199,16 @@ extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
         coarse[q] = r;
       }
   }
-  b->bases_alloc = (u8 *) dmalloc((size_t) total + 64);
+  b->bases_alloc = (u8 *) dmalloc((size_t) total + 192);      /* 64 B of padding on both sides */
+  HIP_CHECK(hipMemsetAsync(b->bases_alloc, 4, (size_t) total + 192, G_st));
   b->boff   = (u32 *) dmalloc(sizeof(u32) * ((size_t) n + 1));
   b->coarse = (u32 *) dmalloc(sizeof(u32) * nq);
-  HIP_CHECK(hipMemcpyAsync(b->bases_alloc, ((const char *) block->bases) - 1, (size_t) total + 1,
+  HIP_CHECK(hipMemcpyAsync(b->bases_alloc + 63, ((const char *) block->bases) - 1, (size_t) total + 1,
                            hipMemcpyHostToDevice, G_st));
   HIP_CHECK(hipMemcpyAsync(b->boff, boff.data(), sizeof(u32) * ((size_t) n + 1), hipMemcpyHostToDevice, G_st));
   HIP_CHECK(hipMemcpyAsync(b->coarse, coarse.data(), sizeof(u32) * nq, hipMemcpyHostToDevice, G_st));
   HIP_CHECK(hipStreamSynchronize(G_st));
-  b->d.bases  = b->bases_alloc + 1;
+  b->d.bases  = b->bases_alloc + 64;
   b->d.boff   = b->boff;
   b->d.coarse = b->coarse;
   b->d.nreads = (u32) n;
