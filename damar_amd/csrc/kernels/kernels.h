@@ -74,6 +74,7 @@ typedef struct
   int  *marks;   u64 marks_stride;                    /* NA/NB                     */
   void *cells;   u32 cell_cap;                        /* pebbles                   */
   int  *buckets; u64 bucket_stride;  int bwidth;      /* score|lastp|lasta          */
+  int  bucket_bits;                                   /* bits needed for bucket - mindiag */
   u16  *ttmp;    u32 ttmp_stride;                     /* 2 centred trace buffers   */
   /* outputs */
   LaRecord *recs;  u32 rec_cap;

@@ -70,8 +70,8 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
  * spinning, so that every wave always drains. */
 #define GUARD(cnt, lim, code)                                                               \
   if (++(cnt) > (lim))                                                                      \
-    { atomicOr(c.err, DAMAR_ERR_BAND);                                                      \
-      atomicMax(c.err + 3, (u32) (code));                                                   \
+    { atomicOr(errw, DAMAR_ERR_BAND);                                                       \
+      atomicMax(errw + 3, (u32) (code));                                                    \
       break;                                                                                \
     }
 
@@ -133,7 +133,7 @@ __device__ __forceinline__ void snake(const u8 *a, const u8 *bq, int &y, int &m,
 /* One direction of the wave.  REV = 0: align.c:409-1122, REV = 1: align.c:1126-1898.
  * Returns through *res the end point of this direction; traces are written by lane 0. */
 template <int REV>
-__device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
+__device__ void wave_pass(const WaveCtx &c, int diag, int mida,
                           int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
 { const int lane = lane_id();
   const int TS = c.ts;
@@ -142,6 +142,16 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
   const u8 *bseq = REV ? c.bseq - 1 : c.bseq;
   DState *cur = c.st0, *nxt = c.st1;
   const int o = c.koff;
+  /* everything that is the same in all 64 lanes is forced into SGPRs (readfirstlane): the
+     band bounds, the best/trim bookkeeping and every loop condition are scalar */
+  diag = uni(diag);
+  mida = uni(mida);
+  const int minp = c.minp, maxp = c.maxp, aoff = c.aoff, boff = c.boff;
+  const int ave = c.ave, do_reach = c.reach;
+  const u32 cell_cap = c.cell_cap;
+  const short *score_tab = c.score, *trim_tab = c.table;
+  Cell *const cellbuf = c.cells;
+  u32 *const errw = c.err;
 
   int low = diag, hgh = diag, dif = 0;
   int besta = mida, lasta = mida, besty = (mida - diag) >> 1, more = 1;
@@ -165,38 +175,40 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
     Cell cl;
 
     if (!REV)
-      { na = (((y + k) + (TS - c.aoff)) / TS - 1) * TS + c.aoff;
-        nb = ((y + (TS - c.boff)) / TS - 1) * TS + c.boff;
+      { na = (((y + k) + (TS - aoff)) / TS - 1) * TS + aoff;
+        nb = ((y + (TS - boff)) / TS - 1) * TS + boff;
         ham = na;  hbm = nb;
       }
     else
-      { na = (((y + k) + (TS - c.aoff) - 1) / TS - 1) * TS + c.aoff;
-        nb = ((y + (TS - c.boff) - 1) / TS - 1) * TS + c.boff;
+      { na = (((y + k) + (TS - aoff) - 1) / TS - 1) * TS + aoff;
+        nb = ((y + (TS - boff) - 1) / TS - 1) * TS + boff;
         ham = y + k;  hbm = y;
       }
     cl.ptr = -1; cl.diag = k; cl.diff = 0;
-    cl.mark = ham;  if (lane == 0) c.cells[0] = cl;
-    cl.mark = hbm;  if (lane == 0) c.cells[1] = cl;
+    cl.mark = ham;  if (lane == 0) cellbuf[0] = cl;
+    cl.mark = hbm;  if (lane == 0) cellbuf[1] = cl;
     ha = 0;  hb = 1;  ncell = 2;
     if (!REV) { na += TS; nb += TS; }
 
     int g0 = 0;
     { int m0 = 0;  u64 b0 = 0;  bool ah = false, bh = false;
-      snake<REV>(a, bseq, y, m0, b0, ah, bh, guard, c.err);
-      if (bh)      { more = 0; bclip = k; }
-      else if (ah) { more = 0; aclip = k; }
+      snake<REV>(a, bseq, y, m0, b0, ah, bh, guard, errw);
+      y = uni(y);
+      const int hit = uni((bh ? 2 : 0) | (ah ? 1 : 0));
+      if (hit & 2)      { more = 0; bclip = k; }
+      else if (hit & 1) { more = 0; aclip = k; }
     }
     v = (y << 1) + k;
     while (REV ? (y + k <= na) : (y + k >= na))
       { GUARD(g0, guard, 2)
         cl.ptr = ha; cl.mark = na;
-        if (lane == 0 && ncell < c.cell_cap) c.cells[ncell] = cl;
+        if (lane == 0 && ncell < cell_cap) cellbuf[ncell] = cl;
         ha = (int) ncell++;  ham = na;  na += S * TS;
       }
     while (REV ? (y <= nb) : (y >= nb))
       { GUARD(g0, guard, 3)
         cl.ptr = hb; cl.mark = nb;
-        if (lane == 0 && ncell < c.cell_cap) c.cells[ncell] = cl;
+        if (lane == 0 && ncell < cell_cap) cellbuf[ncell] = cl;
         hb = (int) ncell++;  hbm = nb;  nb += S * TS;
       }
     if (REV ? (v < besta) : (v > besta))
@@ -218,7 +230,7 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
     /* clipping with the state read from the owning lane (align.c:628-658 / 943-975) */
 #define CLIP_REG()                                                                         \
     if (more == 0)                                                                         \
-      { if (bseq[besty] != 4 && aseq[besta - besty] != 4)                                  \
+      { if (uni((int) bseq[besty]) != 4 && uni((int) aseq[besta - besty]) != 4)            \
           more = 1;                                                                        \
         if (REV ? (low <= aclip) : (hgh >= aclip))                                         \
           { const int l_ = LANE_OF(aclip);                                                 \
@@ -243,13 +255,16 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
     CLIP_REG()
 
     while (more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
-      { if (hgh < low)
-          { if (lane == 0) atomicAdd(c.err + 2, 1u);
+      { /* pin the wave-uniform bookkeeping to SGPRs */
+        low = uni(low);  hgh = uni(hgh);  dif = uni(dif);  besta = uni(besta);  besty = uni(besty);
+        lasta = uni(lasta);  ncell = (u32) uni((int) ncell);  reachm = uni(reachm);
+        if (hgh < low)
+          { if (lane == 0) atomicAdd(errw + 2, 1u);
             stopped = true;
             break;
           }
         if (dif > steplimit)
-          { if (lane == 0) atomicOr(c.err, DAMAR_ERR_BAND);
+          { if (lane == 0) atomicOr(errw, DAMAR_ERR_BAND);
             stopped = true;
             break;
           }
@@ -261,11 +276,11 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
         { const int upNA = __shfl(rNA, (lane + 1) & 63), upNB = __shfl(rNB, (lane + 1) & 63);
           const int dnNA = __shfl(rNA, (lane - 1) & 63), dnNB = __shfl(rNB, (lane - 1) & 63);
           int nlow = low - 1, nhgh = hgh + 1;
-          if (nlow >= c.minp)
+          if (nlow >= minp)
             { if (lane == LANE_OF(nlow)) { rV = edge; rNA = upNA; rNB = upNB; } }
           else
             nlow += 1;
-          if (nhgh <= c.maxp)
+          if (nhgh <= maxp)
             { if (lane == LANE_OF(nhgh)) { rV = edge; rNA = dnNA; rNB = dnNB; } }
           else
             nhgh -= 1;
@@ -310,7 +325,7 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
               m -= 1;
             b <<= 1;
             y = (v - k) >> 1;
-            snake<REV>(aseq + k, bseq, y, m, b, ahit, bhit, guard, c.err);
+            snake<REV>(aseq + k, bseq, y, m, b, ahit, bhit, guard, errw);
             v = (y << 1) + k;
           }
         else
@@ -330,9 +345,9 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
                 if (mask)
                   { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                     if (dropit)
-                      { if (idx < c.cell_cap)
+                      { if (idx < cell_cap)
                           { Cell cl; cl.ptr = ha; cl.diag = k; cl.diff = dif; cl.mark = na;
-                            c.cells[idx] = cl;
+                            cellbuf[idx] = cl;
                           }
                         ha = (int) idx;  ham = na;
                       }
@@ -352,9 +367,9 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
                 if (mask)
                   { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                     if (dropit)
-                      { if (idx < c.cell_cap)
+                      { if (idx < cell_cap)
                           { Cell cl; cl.ptr = hb; cl.diag = k; cl.diff = dif; cl.mark = nb;
-                            c.cells[idx] = cl;
+                            cellbuf[idx] = cl;
                           }
                         hb = (int) idx;  hbm = nb;
                       }
@@ -396,11 +411,11 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
                   if (REV ? (vl < besta) : (vl > besta))
                     { besta = vl;
                       besty = bcast_i(y, l);
-                      if (bcast_i(m, l) >= c.ave)
+                      if (bcast_i(m, l) >= ave)
                         { u64 bl = bcast_u64(b, l);
                           lasta = vl;
-                          if (c.table[bl & TRIM_MASK] >= 0 &&
-                              c.table[(bl >> TRIM_BITS) & TRIM_MASK] + c.score[bl & TRIM_MASK] >= 0)
+                          if (uni((int) trim_tab[bl & TRIM_MASK]) >= 0 &&
+                              uni((int) trim_tab[(bl >> TRIM_BITS) & TRIM_MASK]) + uni((int) score_tab[bl & TRIM_MASK]) >= 0)
                             { trim.a = vl;  trim.y = besty;  trim.d = dif;
                               trim.ha = bcast_i(ha, l);  trim.hb = bcast_i(hb, l);
                             }
@@ -409,8 +424,8 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
                 }
             }
         }
-        if (ncell > c.cell_cap)
-          { if (lane == 0) atomicOr(c.err, DAMAR_ERR_CELLS);
+        if (ncell > cell_cap)
+          { if (lane == 0) atomicOr(errw, DAMAR_ERR_CELLS);
             more = 0;
             ncell = 2;
             stopped = true;
@@ -454,10 +469,11 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
   /* clipping at sequence ends (align.c:628-658 / 943-975, mirrored 1341-1371 / 1652-1684) */
 #define CLIP_STEP()                                                                        \
   if (more == 0)                                                                           \
-    { if (bseq[besty] != 4 && aseq[besta - besty] != 4)                                    \
+    { if (uni((int) bseq[besty]) != 4 && uni((int) aseq[besta - besty]) != 4)              \
         more = 1;                                                                          \
       if (REV ? (low <= aclip) : (hgh >= aclip))                                           \
         { DState s = cur[aclip + o];                                                       \
+          s.M = uni(s.M); s.V = uni(s.V); s.HA = uni(s.HA); s.HB = uni(s.HB);              \
           if (REV) low = aclip + 1; else hgh = aclip - 1;                                  \
           if (reachm <= s.M)                                                               \
             { reachm = s.M; reach.a = s.V; reach.y = (s.V - aclip) / 2; reach.d = dif;     \
@@ -465,6 +481,7 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
         }                                                                                  \
       if (REV ? (hgh >= bclip) : (low <= bclip))                                           \
         { DState s = cur[bclip + o];                                                       \
+          s.M = uni(s.M); s.V = uni(s.V); s.HA = uni(s.HA); s.HB = uni(s.HB);              \
           if (REV) hgh = bclip - 1; else low = bclip + 1;                                  \
           if (reachm <= s.M)                                                               \
             { reachm = s.M; reach.a = s.V; reach.y = (s.V - bclip) / 2; reach.d = dif;     \
@@ -478,17 +495,17 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
   while (!stopped && more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
     { if (hgh < low)                   /* every diagonal clipped or pruned: the reference's state is
                                           undefined from here on; stop like the oracle does and count it */
-        { if (lane == 0) atomicAdd(c.err + 2, 1u);
+        { if (lane == 0) atomicAdd(errw + 2, 1u);
           break;
         }
       if (dif > steplimit)
-        { if (lane == 0) atomicOr(c.err, DAMAR_ERR_BAND);
+        { if (lane == 0) atomicOr(errw, DAMAR_ERR_BAND);
           break;
         }
       /* widen the band by one diagonal per side (align.c:675-776 / 1386-1486) */
       { int nlow = low - 1, nhgh = hgh + 1;
         const int edge = REV ? BIG : -1;
-        if (nlow >= c.minp)
+        if (nlow >= minp)
           { if (lane == 0)
               { c.NA[nlow + o] = c.NA[nlow + 1 + o];
                 c.NB[nlow + o] = c.NB[nlow + 1 + o];
@@ -497,7 +514,7 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
           }
         else
           nlow += 1;
-        if (nhgh <= c.maxp)
+        if (nhgh <= maxp)
           { if (lane == 0)
               { c.NA[nhgh + o] = c.NA[nhgh - 1 + o];
                 c.NB[nhgh + o] = c.NB[nhgh - 1 + o];
@@ -542,7 +559,7 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
                 m -= 1;
               b <<= 1;
               y = (v - k) >> 1;
-              snake<REV>(aseq + k, bseq, y, m, b, ahit, bhit, guard, c.err);
+              snake<REV>(aseq + k, bseq, y, m, b, ahit, bhit, guard, errw);
               v = (y << 1) + k;
               na = c.NA[k + o];
               nb = c.NB[k + o];
@@ -560,9 +577,9 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
               if (mask)
                 { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                   if (dropit)
-                    { if (idx < c.cell_cap)
+                    { if (idx < cell_cap)
                         { Cell cl; cl.ptr = ha; cl.diag = k; cl.diff = dif; cl.mark = na;
-                          c.cells[idx] = cl;
+                          cellbuf[idx] = cl;
                         }
                       ha = (int) idx;  ham = na;
                     }
@@ -582,9 +599,9 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
               if (mask)
                 { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                   if (dropit)
-                    { if (idx < c.cell_cap)
+                    { if (idx < cell_cap)
                         { Cell cl; cl.ptr = hb; cl.diag = k; cl.diff = dif; cl.mark = nb;
-                          c.cells[idx] = cl;
+                          cellbuf[idx] = cl;
                         }
                       hb = (int) idx;  hbm = nb;
                     }
@@ -628,11 +645,11 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
                 if (REV ? (vl < besta) : (vl > besta))
                   { besta = vl;
                     besty = bcast_i(y, l);
-                    if (bcast_i(m, l) >= c.ave)
+                    if (bcast_i(m, l) >= ave)
                       { u64 bl = bcast_u64(b, l);
                         lasta = vl;
-                        if (c.table[bl & TRIM_MASK] >= 0 &&
-                            c.table[(bl >> TRIM_BITS) & TRIM_MASK] + c.score[bl & TRIM_MASK] >= 0)
+                        if (uni((int) trim_tab[bl & TRIM_MASK]) >= 0 &&
+                            uni((int) trim_tab[(bl >> TRIM_BITS) & TRIM_MASK]) + uni((int) score_tab[bl & TRIM_MASK]) >= 0)
                           { trim.a = vl;  trim.y = besty;  trim.d = dif;
                             trim.ha = bcast_i(ha, l);  trim.hb = bcast_i(hb, l);
                           }
@@ -641,8 +658,8 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
               }
           }
         }
-      if (ncell > c.cell_cap)
-        { if (lane == 0) atomicOr(c.err, DAMAR_ERR_CELLS);
+      if (ncell > cell_cap)
+        { if (lane == 0) atomicOr(errw, DAMAR_ERR_CELLS);
           more = 0;
           ncell = 2;
           break;
@@ -688,9 +705,9 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
   if (lane == 0)
     { int  trimx, trimy, trimd, ha, hb;
       u16 *atrace = c.atr, *btrace = c.btr;
-      Cell *cells = c.cells;
+      Cell *cells = cellbuf;
 
-      if (reachm >= 0 && c.reach)
+      if (reachm >= 0 && do_reach)
         { trimx = reach.a - reach.y; trimy = reach.y; trimd = reach.d; ha = reach.ha; hb = reach.hb; }
       else
         { trimx = trim.a - trim.y; trimy = trim.y; trimd = trim.d; ha = trim.ha; hb = trim.hb; }
@@ -754,7 +771,7 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
         { const int fa = *atlen_io, fb = *btlen_io;
           int h = ha, k = cells[h].diag, b = cells[h].mark - k, e = 0, n = 0, a, d;
           bool walk = true;
-          if ((b + k) % TS != c.aoff)
+          if ((b + k) % TS != aoff)
             { h = cells[h].ptr;
               if (h < 0)
                 { a = trimy; d = trimd; walk = false; }
@@ -790,7 +807,7 @@ __device__ __noinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
           at = -n;
 
           h = hb;  k = cells[h].diag;  b = cells[h].mark + k;  e = 0;  n = 0;  walk = true;
-          if ((b - k) % TS != c.boff)
+          if ((b - k) % TS != boff)
             { h = cells[h].ptr;
               if (h < 0)
                 { a = trimx; d = trimd; walk = false; }
@@ -1028,14 +1045,21 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
               int  ap = in ? (int) (keys[f] & pmask) : 0;
               int  d  = in ? (((int) vals[f]) >> W) : BIG;
               int  prev = in ? s.lastp[d] : 0;
-              bool last = in;
-              for (int j = 0; j < 64; j++)
-                { int dj = bcast_i(d, j), aj = bcast_i(ap, j);
-                  if (dj == d)
-                    { if (j < lane) prev = aj;
-                      if (j > lane) last = false;
-                    }
-                }
+              /* lanes of this chunk that fall into the same bucket: the nearest one below
+                 supplies lastp, the highest one stores it (match-any over the bucket bits) */
+              u64  peers = __ballot(in);
+              { const u32 db = (u32) (d - mind);
+                for (int bit = 0; bit < a.bucket_bits; bit++)
+                  { const bool one = (db >> bit) & 1;
+                    const u64  mk = __ballot(one);
+                    peers &= one ? mk : ~mk;
+                  }
+              }
+              const u64  below = peers & lanes_below(lane);
+              const int  pl = below ? 63 - __clzll((long long) below) : lane;
+              const int  pap = __shfl(ap, pl);
+              if (below) prev = pap;
+              const bool last = in && ((peers >> lane) >> 1) == 0;
               if (in)
                 { int add = (ap - prev >= K) ? K : ap - prev;
                   atomicAdd(&s.score[d], add);
@@ -1107,7 +1131,7 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
   wave_mem_sync();
 }
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64, 2)
 void report_kernel(ReportArgs a)
 { const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);
@@ -1129,7 +1153,7 @@ void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st)
 }
 
 /* batch Local_Alignment (tests): one wave per task, result always emitted */
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64, 2)
 void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
 { const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);

@@ -460,6 +460,7 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   ra->marks = RS.marks;  ra->marks_stride = RS.marks_stride;
   ra->cells = RS.cells;  ra->cell_cap = RS.cell_cap;
   ra->buckets = RS.buckets;  ra->bucket_stride = RS.bucket_stride;  ra->bwidth = RS.bwidth;
+  ra->bucket_bits = ilog2_ceil((u64) RS.bwidth + 2);
   ra->ttmp = RS.ttmp;  ra->ttmp_stride = RS.ttmp_stride;
   ra->recs = RS.recs;  ra->rec_cap = RS.rec_cap;
   ra->tpool = RS.tpool;  ra->tpool_cap = RS.tpool_cap;
