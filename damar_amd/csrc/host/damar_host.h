@@ -27,6 +27,9 @@ typedef struct
 
 int64 damar_tpool_push(damar_tpool *tp, const uint16 *src, int n);
 
+/* how often the rare branches of the host tail ran (tests assert the fixtures reach them) */
+extern int64 damar_stat_redundancy_calls, damar_stat_fusions, damar_stat_bridges;
+
 /* What Bridge needs beyond the paths: the two sequences (filter.c:1998, 2025). */
 typedef struct
 { const char *aseq, *bseq;

@@ -12,6 +12,8 @@
 
 #include "damar_host.h"
 
+int64 damar_stat_redundancy_calls = 0, damar_stat_fusions = 0, damar_stat_bridges = 0;
+
 static int iabs(int x) { return x < 0 ? -x : x; }
 
 static void tpool_reserve(damar_tpool *tp, int64 extra)
@@ -100,6 +102,7 @@ static void fuse(damar_path *p1, int ap, const damar_path *p2, damar_tpool *tp, 
   int    n = 0, diff = 0, k;
   uint16 *dst;
 
+  damar_stat_fusions += 1;
   tpool_reserve(tp, len);
   at  = tp->top;
   tp->top += len;
@@ -127,6 +130,8 @@ int damar_handle_redundancies(damar_path *am, int n, damar_path *bm, int comp, i
                               damar_tpool *tp, const damar_bridge_ctx *bridge)
 { int hasB = (bm != NULL);
   int j, k, dist, awhen = 0, bwhen = 0, out;
+
+  damar_stat_redundancy_calls += 1;
 
   /* pass 1: alignments that share a trace point are fused (filter.c:1833-1946) */
   for (j = 1; j < n; j++)

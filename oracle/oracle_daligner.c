@@ -9,6 +9,7 @@
 #include <sys/stat.h>
 
 #include "oracle.h"
+#include "../damar_amd/csrc/host/damar_host.h"
 
 static void make_dir(const char *d)
 { struct stat s;
@@ -133,6 +134,9 @@ int main(int argc, char *argv[])
           free(d1);
         }
     }
+  if (verbose)
+    printf("redundancy calls %lld fusions %lld bridges %lld\n", (long long) damar_stat_redundancy_calls,
+           (long long) damar_stat_fusions, (long long) damar_stat_bridges);
   if (verbose)
     printf("waves %lld cells %lld maxband %d pebbles %lld emptyband %d\n", (long long) st.waves,
            (long long) st.cells, st.maxband, (long long) st.pebbles, st.empty_band);

@@ -35,6 +35,8 @@ CASES = {
     "indel":   dict(derive="indel", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "noisy":   dict(derive="noisy", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "tandem":  dict(derive="tandem", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
+    "fusion":  dict(derive="fusion32", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
+    "fusion2": dict(derive="fusion31", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
 }
 
 
@@ -106,6 +108,23 @@ def derive(kind, work):
                 s = "".join(comp[ch] for ch in reversed(s))
             reads.append(s)
             tot += len(s)
+    elif kind.startswith("fusion"):
+        # 300-800 bp windows with 25-45 % substitutions in every other read: the alignment
+        # breaks inside the window and the two pieces share a trace point -> Fusion
+        seed = int(kind[6:])
+        rng = random.Random(seed)
+        run([SIMDB, base, "B", "0.15", "-c20", "-r%d" % seed, "-e.15", "-S200"], ROOT, stdout=subprocess.DEVNULL)
+        reads = unpack_reads(base, "B")
+        out = []
+        for i, s in enumerate(reads):
+            if i % 2 == 0:
+                w = rng.randrange(300, 800)
+                p = rng.randrange(500, max(501, len(s) - w - 500))
+                rate = rng.uniform(.25, .45)
+                seg = "".join(ch if rng.random() > rate else rng.choice("acgt") for ch in s[p:p + w])
+                s = s[:p] + seg + s[p + w:]
+            out.append(s)
+        reads = out
     else:
         run([SIMDB, base, "B", "0.06", "-c14", "-r21", "-e.15", "-S200"], ROOT, stdout=subprocess.DEVNULL)
         reads = unpack_reads(base, "B")
@@ -142,7 +161,12 @@ def main():
         sys.exit("oracle/_ref/daligner missing: make -C oracle -f Makefile.ref")
     import tempfile
     dbs = {}
+    only = set(sys.argv[1:])
     for name, c in CASES.items():
+        if only and name not in only:
+            if "sim" in c:
+                dbs[name] = os.path.join(HERE, name)
+            continue
         out = os.path.join(HERE, name)
         shutil.rmtree(out, ignore_errors=True)
         os.makedirs(out)

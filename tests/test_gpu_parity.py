@@ -12,7 +12,7 @@ from conftest import ROOT, GOLDEN, golden_cases, read_case, link_db, compare_las
 
 pytestmark = pytest.mark.gpu
 
-NEEDS_BRIDGE = {"tandem"}
+NEEDS_BRIDGE = set()
 
 
 @pytest.fixture(scope="module")
