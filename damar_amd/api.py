@@ -73,6 +73,10 @@ def _lib():
         L.damar_index_download.argtypes = [C.c_void_p, C.c_void_p]
         L.damar_match.argtypes = [C.POINTER(HITS_DB), C.POINTER(HITS_DB), C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_void_p, C.POINTER(c_int64)]
+        L.damar_tandem_set_params.argtypes = [C.c_int] * 4
+        L.damar_tandem_set_params.restype = C.c_int
+        L.Match_Self.argtypes = [C.c_char_p, C.POINTER(HITS_DB), C.c_void_p]
+        L.damar_match_self.argtypes = [C.POINTER(HITS_DB), C.c_void_p, C.c_void_p, C.POINTER(c_int64)]
         L.damar_last_seeds.argtypes = [C.c_void_p, c_int64]
         L.damar_last_seeds.restype = c_int64
         L.damar_local_alignment_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,

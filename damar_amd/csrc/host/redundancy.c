@@ -220,8 +220,9 @@ int damar_handle_redundancies(damar_path *am, int n, damar_path *bm, int comp, i
     }
 
   /* pass 2: narrow parallel overlaps are bridged by an exact realignment
-   * (filter.c:1950-2059) */
-  for (j = 1; j < n; j++)
+   * (filter.c:1950-2059).  datander's variant (scrub/tandem.c:767-850) has no such pass:
+   * its callers hand in bridge == NULL. */
+  for (j = 1; bridge != NULL && j < n; j++)
     { damar_path *jp = am + j;
       if (jp->abpos < 0)
         continue;

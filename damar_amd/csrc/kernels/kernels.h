@@ -31,6 +31,11 @@ void damar_launch_suppress_flags(const u32 *codes, u32 n, const u32 *table, int 
 void damar_launch_compact_pairs(const u32 *k, const u32 *v, const u32 *keep, const u32 *off, u32 n,
                                 u32 *ko, u32 *vo, hipStream_t st);
 
+/* datander: distance to the previous equal k-mer of the same read, scattered back to position
+ * order (dist[k-mer index]); scrub/tandem.c:556-589 + the (read,rpos) re-sort of :1298 */
+void damar_launch_tandem_links(const DevBlock *blk, int kmer, const u32 *codes, const u32 *pos, u32 n,
+                               int *dist, hipStream_t st);
+
 /* seed_merge.hip */
 typedef struct
 { const u32 *acode, *apos;  u32 alen;  const u32 *atab;
@@ -89,6 +94,8 @@ typedef struct
 #define DAMAR_ERR_BAND    8u
 
 void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st);
+/* datander report: one work item per read of a.ablk, dist as produced by damar_launch_tandem_links */
+void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots, hipStream_t st);
 
 /* batch Local_Alignment for tests: task i = (aread, bread, diag, anti) */
 typedef struct { int aread, bread, diag, anti; } LaTask;

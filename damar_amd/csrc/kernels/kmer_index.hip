@@ -126,3 +126,33 @@ void damar_launch_compact_pairs(const u32 *k, const u32 *v, const u32 *keep, con
     return;
   hipLaunchKernelGGL(compact_pairs, dim3((n + 255) / 256), dim3(256), 0, st, k, v, keep, off, n, ko, vo);
 }
+
+/* datander links (scrub/tandem.c:556-589).  Sorted entry i of a run of equal codes gets the
+ * distance to entry i-1 if both lie in the same read, else 0; the reference never overwrites
+ * the code of sorted entry 0, so that one keeps its k-mer code.  The result is stored at the
+ * k-mer's index in position order, which is what the reference's re-sort on (read, rpos)
+ * produces (every position owns exactly one k-mer). */
+__global__ __launch_bounds__(256)
+void tandem_links(DevBlock blk, int kmer, const u32 *__restrict__ codes, const u32 *__restrict__ pos, u32 n,
+                  int *__restrict__ dist)
+{ u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n)
+    return;
+  const u32 p = pos[i], r = read_of_pos(blk, p);
+  int d = 0;
+  if (i == 0)
+    d = (int) codes[0];
+  else if (codes[i] == codes[i - 1])
+    { const u32 q = pos[i - 1];
+      if (q >= blk.boff[r])                 /* same read: entries of a run are in position order */
+        d = (int) (p - q);
+    }
+  dist[p - (r + 1) * (u32) kmer + 1] = d;
+}
+
+void damar_launch_tandem_links(const DevBlock *blk, int kmer, const u32 *codes, const u32 *pos, u32 n,
+                               int *dist, hipStream_t st)
+{ if (n == 0)
+    return;
+  hipLaunchKernelGGL(tandem_links, dim3((n + 255) / 256), dim3(256), 0, st, *blk, kmer, codes, pos, n, dist);
+}

@@ -1131,6 +1131,150 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
   wave_mem_sync();
 }
 
+/* datander: scrub/tandem.c:895-1175 report_thread for one read.  code[apos] (apos = index of
+ * a k-mer's last base + 1, in [K, alen]) is the distance to the previous equal k-mer of the
+ * read, or 0.  Same three bucket passes as process_pair, but the "hits" are the positions of
+ * the read itself and the alignment is the read against itself (selfie: minp = 1). */
+__device__ void process_read(const ReportArgs &a, const SlotScratch &s, const int *dist, u32 item)
+{ const int  lane = lane_id();
+  const int  K = a.kmer, H = a.hitmin, W = a.binshift;
+  const int  mind = (-a.bblk.maxlen) >> W, maxd = a.ablk.maxlen >> W;
+  const int  ar = (int) item;
+  const int  alen = (int) read_len(a.ablk, ar);
+  const int *code = dist + ((u64) a.ablk.boff[ar] - (u64) ar * (u64) K) - K;      /* code[apos] */
+
+  WaveCtx c;
+  c.aseq = a.ablk.bases + a.ablk.boff[ar];
+  c.bseq = c.aseq;
+  c.alen = alen;  c.blen = alen;
+  c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
+  c.score = a.score;  c.table = a.table;
+  c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
+  c.koff = alen + 8;
+  c.cells = s.cells;  c.cell_cap = a.cell_cap;
+  c.err = &a.counters[3];
+  c.atr = s.atr;  c.btr = s.btr;
+
+  u32 seq = 0;
+  int clo = BIG, chi = -BIG;
+  int amarkb = K, amarke = PANEL_SIZE;
+  if (amarke >= alen)
+    amarke = alen + 1;
+  for (;;)
+    { /* pass 1 (tandem.c:986-996) */
+      for (int base = amarkb; base < amarke; base += 64)
+        { const int  apos = base + lane;
+          const int  dg = (apos < amarke) ? code[apos] : 0;
+          const bool in = dg != 0;
+          const int  d = dg >> W;
+          int  prev = in ? s.lastp[d] : 0;
+          u64  peers = __ballot(in);
+          { const u32 db = (u32) (d - mind);
+            for (int bit = 0; bit < a.bucket_bits; bit++)
+              { const bool one = (db >> bit) & 1;
+                const u64  mk = __ballot(one);
+                peers &= one ? mk : ~mk;
+              }
+          }
+          const u64  below = peers & lanes_below(lane);
+          const int  pl = below ? 63 - __clzll((long long) below) : lane;
+          const int  pap = __shfl(apos, pl);
+          if (below) prev = pap;
+          const bool last = in && ((peers >> lane) >> 1) == 0;
+          if (in)
+            { int add = (apos - prev >= K) ? K : apos - prev;
+              atomicAdd(&s.score[d], add);
+              if (last)
+                s.lastp[d] = apos;
+            }
+          wave_mem_sync();
+        }
+
+      /* pass 2 (tandem.c:1000-1099) */
+      for (int base = amarkb; base < amarke; base += 64)
+        { const int  apos = base + lane;
+          const int  dg = (apos < amarke) ? code[apos] : 0;
+          const bool in = dg != 0;
+          const int  d = dg >> W;
+          bool hot = false;
+          if (in)
+            { int sc = s.score[d];
+              hot = (sc + s.score[d + 1] >= H) || (sc + s.score[d - 1] >= H);
+            }
+          u64 todo = __ballot(hot);
+          while (todo)
+            { u64 fire = __ballot(hot && ((todo >> lane) & 1) && apos > s.lasta[d]);
+              if (!fire)
+                break;
+              int l = __ffsll((long long) fire) - 1;
+              todo &= (l == 63) ? 0ull : ~((1ull << (l + 1)) - 1);
+              const int sap = base + l, sdg = bcast_i(dg, l), sd = sdg >> W;
+              const int sbp = sap - sdg;
+              LaResult r;
+              int lo, hi;
+
+              if (lane == 0) atomicAdd(&a.counters[4], 1u);
+              local_alignment(c, 0u, sdg, sap + sbp, &r);
+              diagonal_span(s, r, a.tspace, W, &lo, &hi);
+              if (sd < lo) lo = sd; else if (sd > hi) hi = sd;
+              if (lo < mind - 1) lo = mind - 1;
+              if (hi > maxd + 1) hi = maxd + 1;
+              for (int q = lo + lane; q <= hi; q += 64)
+                if (r.aepos > s.lasta[q])
+                  s.lasta[q] = r.aepos;
+              if (lo < clo) clo = lo;
+              if (hi > chi) chi = hi;
+              wave_mem_sync();
+              if ((r.aepos - r.abpos) + (r.bepos - r.bbpos) >= a.minover)
+                emit_record(a, s, r, ar, ar, item, seq++);
+            }
+        }
+
+      /* pass 3 (tandem.c:1103-1109) */
+      for (int base = amarkb; base < amarke; base += 64)
+        { const int apos = base + lane;
+          const int dg = (apos < amarke) ? code[apos] : 0;
+          if (dg != 0)
+            { s.score[dg >> W] = 0;
+              s.lastp[dg >> W] = 0;
+            }
+        }
+      wave_mem_sync();
+
+      if (amarke > alen)
+        break;
+      amarkb = amarke - PANEL_OVERLAP;
+      amarke = amarkb + PANEL_SIZE;
+      if (amarke > alen)
+        amarke = alen + 1;
+    }
+  if (clo <= chi)
+    for (int q = clo + lane; q <= chi; q += 64)
+      s.lasta[q] = 0;
+  wave_mem_sync();
+}
+
+__global__ __launch_bounds__(64, 2)
+void tandem_kernel(ReportArgs a, const int *dist)
+{ const int slot = blockIdx.x;
+  const SlotScratch s = slot_scratch(a, slot);
+  for (;;)
+    { u32 item = 0;
+      if (lane_id() == 0)
+        item = atomicAdd(&a.counters[0], 1u);
+      item = (u32) uni((int) item);
+      if (item >= a.nwork)
+        break;
+      process_read(a, s, dist, item);
+    }
+}
+
+void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots, hipStream_t st)
+{ if (a->nwork == 0)
+    return;
+  hipLaunchKernelGGL(tandem_kernel, dim3(nslots), dim3(64), 0, st, *a, dist);
+}
+
 __global__ __launch_bounds__(64, 2)
 void report_kernel(ReportArgs a)
 { const int slot = blockIdx.x;

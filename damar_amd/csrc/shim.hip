@@ -245,9 +245,8 @@ static int ilog2_ceil(u64 n)
   return b;
 }
 
-extern "C" damar_dev_index *damar_index_build(damar_dev_block *blk, int own_block, int *len)
+static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *len, int K, int suppress)
 { ensure_init();
-  const int K = P_kmer;
   if (K > 16)
     { fprintf(stderr, "damar: FATAL: -k%d: the device index holds 2k <= 32 code bits (k <= 16) in this build\n", K);
       die();
@@ -295,13 +294,13 @@ extern "C" damar_dev_index *damar_index_build(damar_dev_block *blk, int own_bloc
   ix->table = (u32 *) dmalloc(sizeof(u32) * (((size_t) 1 << ix->tbits) + 2));
   damar_launch_code_table(ix->codes, n, kbits, ix->tbits, ix->table, G_st);
 
-  if (P_suppress > 0)                       /* filter.c:890-939 */
+  if (suppress > 0)                         /* filter.c:890-939 */
     { u32 *keep = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
       u32 *off  = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
       void *scw = arena_take(&G_work, damar_scan_workspace_bytes(nk));
       u64 *tot  = (u64 *) arena_take(&G_work, 64);
       u64  kept = 0;
-      damar_launch_suppress_flags(ix->codes, n, ix->table, kbits, ix->tbits, P_suppress, keep, G_st);
+      damar_launch_suppress_flags(ix->codes, n, ix->table, kbits, ix->tbits, suppress, keep, G_st);
       damar_exclusive_scan_u32(keep, off, n, scw, tot, G_st);
       damar_launch_compact_pairs(ix->codes, ix->pos, keep, off, n, tk, tv, G_st);
       HIP_CHECK(hipMemcpyAsync(&kept, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
@@ -329,6 +328,10 @@ extern "C" damar_dev_index *damar_index_build(damar_dev_block *blk, int own_bloc
     }
   *len = (int) n;
   return ix;
+}
+
+extern "C" damar_dev_index *damar_index_build(damar_dev_block *blk, int own_block, int *len)
+{ return index_build_k(blk, own_block, len, P_kmer, P_suppress);
 }
 
 extern "C" void damar_index_free(damar_dev_index *ix)
@@ -628,7 +631,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   /* ---- report kernel (retry with larger buffers if it reports an overflow) ---- */
   std::vector<LaRecord> recs;
   std::vector<u16>      tpool;
-  u32 hc[8];
+  u32 hc[16];
   if (nwork > 0)
     { u32 cell_cap = RS.cell_cap ? RS.cell_cap : (1u << 16);
       u32 rec_cap  = std::max(RS.rec_cap, 2 * nwork + 4096);
@@ -755,6 +758,126 @@ extern "C" void Match_Filter(char *aname, HITS_DB *ablock, char *bname, HITS_DB 
               aname == bname, comp, asettings, NULL);             /* filter.c:2603 pointer equality */
   if (atable != btable && btable != NULL)                         /* filter.c:2722-2731, 2880-2881 */
     damar_index_free((damar_dev_index *) btable);
+}
+
+
+/***** datander: Match_Self (scrub/tandem.c:1182-1428) ************************************************/
+
+static int T_kmer = 12, T_binshift = 4, T_hitmin = 35, T_nshift = 2;
+
+/* scrub/tandem.h:58 Set_Filter_Params(kmer, binshift, hitmin, nthreads): the 4-argument
+ * variant of datander.  It cannot share a name with filter.h's 5-argument function inside one
+ * library, so it is exported under this name; libdamar_tandem.so (csrc/tandem_abi.c) carries
+ * the reference name for a datander.c that links against it. */
+extern "C" int damar_tandem_set_params(int kmer, int binshift, int hitmin, int nthreads)
+{ if (kmer <= 1)
+    return 1;
+  T_kmer = kmer;  T_binshift = binshift;  T_hitmin = hitmin;
+  T_nshift = 0;
+  while ((2 << T_nshift) <= nthreads)
+    T_nshift += 1;
+  return 0;
+}
+
+extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Align_Spec *spec, int64 *counts)
+{ ensure_init();
+  int64 nfilt = 0, ncheck = 0;
+  int   n = 0;
+  if (counts)
+    counts[0] = counts[1] = counts[2] = 0;
+  memset(G_cnt, 0, sizeof(G_cnt));
+  damar_dev_index *ix = index_build_k(blk, 0, &n, T_kmer, 0);
+  if (ix == NULL)
+    return;
+  const int ts = Trace_Spacing(spec);
+  int *dist = (int *) dmalloc(sizeof(int) * (size_t) n);
+  tick(0);
+  damar_launch_tandem_links(&blk->d, T_kmer, ix->codes, ix->pos, (u32) n, dist, G_st);
+  tick(1);
+
+  std::vector<LaRecord> recs;
+  std::vector<u16>      tpool;
+  u32 hc[16];
+  { const int sk = P_kmer, sh = P_hitmin, sb = P_binshift;        /* the report args read the P_* set */
+    P_kmer = T_kmer;  P_hitmin = T_hitmin;  P_binshift = T_binshift;
+    u32 cell_cap = RS.cell_cap ? RS.cell_cap : (1u << 16);
+    u32 rec_cap  = std::max(RS.rec_cap, (u32) (4 * ablock->nreads + 4096));
+    u32 tp_cap   = std::max(RS.tpool_cap, rec_cap * 64u);
+    for (int attempt = 0; ; attempt++)
+      { ReportArgs ra;
+        scratch_prepare(ablock->maxlen, ablock->maxlen, T_binshift, ts, cell_cap);
+        scratch_outputs(rec_cap, tp_cap);
+        fill_report_args(&ra, blk, blk, 0, 1, spec);
+        ra.nwork = (u32) ablock->nreads;
+        HIP_CHECK(hipMemsetAsync(RS.counters, 0, 64, G_st));
+        tick(4);
+        damar_launch_tandem_report(&ra, dist, RS.nslots, G_st);
+        tick(5);
+        HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, G_st));
+        HIP_CHECK(hipStreamSynchronize(G_st));
+        HIP_CHECK(hipGetLastError());
+        G_ms[DAMAR_T_REPORT] = lap(4, 5);
+        if (hc[3] == 0)
+          break;
+        if ((hc[3] & DAMAR_ERR_BAND) || attempt >= 6)
+          { fprintf(stderr, "damar: FATAL: tandem report kernel failed (flags %u, where=%u)\n", hc[3], hc[6]);
+            die();
+          }
+        if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
+        if (hc[3] & DAMAR_ERR_RECS)  rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
+        if (hc[3] & DAMAR_ERR_TPOOL) tp_cap  = std::max(2 * tp_cap, hc[2] + 65536);
+      }
+    P_kmer = sk;  P_hitmin = sh;  P_binshift = sb;
+  }
+  recs.resize(hc[1]);
+  tpool.resize(hc[2]);
+  if (hc[1] > 0)
+    { HIP_CHECK(hipMemcpy(recs.data(), RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(tpool.data(), RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost));
+    }
+  nfilt = hc[4];
+  HIP_CHECK(hipFree(dist));
+  damar_index_free(ix);
+
+  /* host tail: scrub/tandem.c:1140-1166 (fusion/containment only, A records only) */
+  std::sort(recs.begin(), recs.end(), RecOrder());
+  Overlap_IO_Buffer *obuf = OVL_IO_Buffer(spec);
+  std::vector<damar_path> am;
+  damar_tpool tp = { NULL, 0, 0 };
+  size_t i = 0;
+  while (i < recs.size())
+    { size_t j = i;
+      while (j < recs.size() && recs[j].item == recs[i].item)
+        j += 1;
+      am.clear();  tp.top = 0;
+      for (size_t q = i; q < j; q++)
+        { const LaRecord &r = recs[q];
+          damar_path p;
+          p.tlen = r.atlen;  p.diffs = r.diffs;
+          p.abpos = r.abpos;  p.bbpos = r.bbpos;  p.aepos = r.aepos;  p.bepos = r.bepos;
+          p.toff = damar_tpool_push(&tp, tpool.data() + r.toff, r.atlen);
+          am.push_back(p);
+        }
+      const int ar = recs[i].aread + ablock->ufirst;
+      damar_emit_pair(am.data(), (int) am.size(), NULL, 0, &tp, 0, ts, ar, ar, NULL, obuf, &ncheck);
+      i = j;
+    }
+  free(tp.val);
+  G_cnt[0] = n;  G_cnt[2] = nfilt;  G_cnt[3] = hc[1];
+  if (counts)
+    { counts[0] = n;  counts[1] = nfilt;  counts[2] = ncheck; }
+  if (VERBOSE)
+    { printf("\n     %lld seed hits\n     %lld confirmed hits\n", (long long) nfilt, (long long) ncheck);
+      fflush(stdout);
+    }
+}
+
+extern "C" void Match_Self(char *aname, HITS_DB *ablock, Align_Spec *settings)
+{ if (VERBOSE)
+    printf("\nIndexing %s\n\nComparing %s to itself\n", aname, aname);
+  damar_dev_block *b = damar_block_upload(ablock);
+  damar_match_self(ablock, b, settings, NULL);
+  damar_block_free(b);
 }
 
 /***** test hooks ***************************************************************************************/

@@ -132,6 +132,24 @@ class Plan:
             L.Free_Align_Spec(spec)
 
 
+def run_datander(block, outdir, k=12, w=4, h=35, e=.70, l=500, s=100, j=4, verbose=0, out="tan"):
+    """scrub/datander.c:226-258 for one block: Match_Self + tan/<blk>.<blk>.las."""
+    L = api.lib()
+    api.set_globals(verbose=verbose, minover=2 * l)
+    if L.damar_tandem_set_params(k, w, h, j):
+        raise ValueError("Illegal combination of filter parameters")
+    os.makedirs(os.path.join(outdir, out), exist_ok=True)
+    with _cwd(outdir):
+        spec = L.New_Align_Spec(e, s, block.db.freq, j, 1, 0, 0, 0)
+        cnt = (api.c_int64 * 3)()
+        L.damar_match_self(C.byref(block.db), block.upload(), spec, cnt)
+        L.Write_Overlap_Buffer(spec, out.encode(), out.encode(), block.root.encode(), block.root.encode(),
+                               block.last_read())
+        L.Reset_Overlap_Buffer(spec)
+        L.Free_Align_Spec(spec)
+    return list(cnt)
+
+
 def hpc_plan(nblocks):
     """The block-pair work list HPCdaligner emits (HPCdaligner.c:628-788): line i compares
     block i against blocks i, i-1, ..., 1."""

@@ -56,6 +56,14 @@ void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
                  damar_dev_index *aidx, damar_dev_index *bidx,
                  int self, int comp, Align_Spec *spec, int64 *counts);
 
+/* datander (scrub/tandem.h:58-60): the 4-argument parameter call under a library-unique
+ * name, and Match_Self with the block already resident in HBM.  counts = k-mers, seed hits,
+ * confirmed records. */
+int  damar_tandem_set_params(int kmer, int binshift, int hitmin, int nthreads);
+void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Align_Spec *spec, int64 *counts);
+/* scrub/tandem.h:60, scrub/tandem.c:1182 */
+void Match_Self(char *aname, HITS_DB *ablock, Align_Spec *settings);
+
 /* Test hook: seed pairs of the last damar_match call as reference-layout SeedPair
  * records {int diag, apos, aread, bread} (filter.c:128-134) in sorted order.
  * Returns the number of seed pairs; copies at most `cap` records. */

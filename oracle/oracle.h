@@ -83,6 +83,12 @@ void oracle_match_filter(const HITS_DB *ablock, const HITS_DB *bblock,
                          int self, int comp, const OParams *prm, Align_Spec *spec,
                          int64 *counts /* nhits, nfilt, ncheck */, OWaveStats *stats);
 
+/* datander: scrub/tandem.c:1182-1428 Match_Self (k=12, w=4, h=35, l=500 by default,
+ * Align_Spec built with reach = 0, scrub/datander.c:141-146, 251).  counts = k-mers, seed
+ * hits, confirmed records. */
+void oracle_match_self(const HITS_DB *block, const OParams *prm, Align_Spec *spec,
+                       int64 *counts, OWaveStats *stats);
+
 /* Redundancy handling shared with the product's host tail (filter.c:1804-2077);
  * implemented in damar_amd/csrc/host/redundancy.c. */
 

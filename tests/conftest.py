@@ -35,7 +35,7 @@ def golden_cases():
 
 def read_case(name):
     d = os.path.join(GOLDEN, name)
-    db, opts, lines = None, [], []
+    db, opts, lines, tool = None, [], [], "daligner"
     for ln in open(os.path.join(d, "case.txt")):
         w = ln.split()
         if w[0] == "db":
@@ -44,11 +44,13 @@ def read_case(name):
             opts = w[1:]
         elif w[0] == "line":
             lines.append((w[1], w[2:]))
+        elif w[0] == "tool":
+            tool = w[1]
     las = []
     for dp, _, fs in os.walk(os.path.join(d, "las")):
         for f in fs:
             las.append(os.path.relpath(os.path.join(dp, f), os.path.join(d, "las")))
-    return dict(name=name, dbdir=os.path.join(GOLDEN, db), opts=opts, lines=lines,
+    return dict(name=name, dbdir=os.path.join(GOLDEN, db), opts=opts, lines=lines, tool=tool,
                 lasdir=os.path.join(d, "las"), las=sorted(las))
 
 
@@ -59,7 +61,10 @@ def link_db(dbdir, dst, root="G"):
 
 
 def run_cli(exe, case, workdir):
+    """exe: the daligner-like binary; datander cases use its sibling *datander binary."""
     link_db(case["dbdir"], workdir)
+    if case["tool"] == "datander":
+        exe = exe.replace("daligner", "datander")
     for a, bs in case["lines"]:
         subprocess.run([exe] + case["opts"] + ["G." + a] + ["G." + b for b in bs], cwd=workdir, check=True,
                        stdout=subprocess.DEVNULL)

@@ -37,6 +37,10 @@ CASES = {
     "tandem":  dict(derive="tandem", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "fusion":  dict(derive="fusion32", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "fusion2": dict(derive="fusion31", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
+    # datander (scrub/datander.c) on the tandem-array reads and on plain reads (0 records)
+    "tan_tandem": dict(db="tandem", tool="datander", opts=["-j4"], plan=[("1", [])]),
+    "tan_k10":    dict(db="tandem", tool="datander", opts=["-k10", "-w3", "-h28", "-l400", "-j2"], plan=[("1", [])]),
+    "tan_plain":  dict(db="tiny2", tool="datander", opts=["-j4"], plan=[("1", []), ("2", [])]),
 }
 
 
@@ -181,7 +185,7 @@ def main():
                     shutil.copy(os.path.join(dbdir, f), os.path.join(out, f))
                 dbdir = out
             else:
-                dbdir, root = dbs[c["db"]], "G"
+                dbdir, root = os.path.join(HERE, c["db"]), "G"
             nblocks = int(open(os.path.join(dbdir, "G.db")).read().split("blocks =")[1].split()[0])
             plan = c["plan"]
             if plan == "all":
@@ -191,8 +195,11 @@ def main():
             for f in ("G.db", ".G.idx", ".G.bps"):
                 os.symlink(os.path.join(dbdir, f), os.path.join(rdir, f))
             for a, bs in plan:
-                run([os.path.join(REF, "daligner")] + c["opts"] + ["G." + a] + ["G." + b for b in bs], rdir,
-                    stdout=subprocess.DEVNULL)
+                if c.get("tool") == "datander":
+                    run([os.path.join(REF, "datander")] + c["opts"] + ["G." + a], rdir, stdout=subprocess.DEVNULL)
+                else:
+                    run([os.path.join(REF, "daligner")] + c["opts"] + ["G." + a] + ["G." + b for b in bs], rdir,
+                        stdout=subprocess.DEVNULL)
             n = 0
             for dp, _, fs in os.walk(rdir):
                 for f in fs:
@@ -202,7 +209,7 @@ def main():
                         shutil.copy(os.path.join(dp, f), os.path.join(out, "las", rel))
                         n += 1
             with open(os.path.join(out, "case.txt"), "w") as f:
-                f.write("db %s\nopts %s\n" % (c.get("db", name), " ".join(c["opts"])))
+                f.write("db %s\nopts %s\ntool %s\n" % (c.get("db", name), " ".join(c["opts"]), c.get("tool", "daligner")))
                 for a, bs in plan:
                     f.write("line %s %s\n" % (a, " ".join(bs)))
             print(name, "->", n, ".las files")

@@ -26,6 +26,11 @@ def gpu(built):
 def run_plan(case, workdir):
     from damar_amd import driver
     link_db(case["dbdir"], workdir)
+    if case["tool"] == "datander":
+        kw = opts_to_plan_kwargs(case["opts"])
+        for a, _ in case["lines"]:
+            driver.run_datander(driver.Block(os.path.join(workdir, "G." + a)), workdir, **kw)
+        return None
     plan = driver.Plan(**opts_to_plan_kwargs(case["opts"]))
     blocks = {}
     for a, bs in case["lines"]:
@@ -46,14 +51,12 @@ def test_gpu_las_equals_reference_golden(gpu, tmp_path, name):
     assert compare_las(case, str(tmp_path)) == []
 
 
-def test_gpu_cli_binary_equals_reference_golden(gpu, tmp_path):
-    """The C host driver (the drop-in daligner command) on the 2-block fixture."""
-    import subprocess
-    case = read_case("tiny2")
-    link_db(case["dbdir"], str(tmp_path))
-    for a, bs in case["lines"]:
-        subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "daligner")] + case["opts"] + ["G." + a] +
-                       ["G." + b for b in bs], cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL)
+@pytest.mark.parametrize("name", ["tiny2", "tan_tandem"])
+def test_gpu_cli_binary_equals_reference_golden(gpu, tmp_path, name):
+    """The C host drivers (the drop-in daligner / datander commands)."""
+    from conftest import run_cli
+    case = read_case(name)
+    run_cli(os.path.join(ROOT, "damar_amd", "bin", "daligner"), case, str(tmp_path))
     assert compare_las(case, str(tmp_path)) == []
 
 
