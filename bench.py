@@ -131,6 +131,7 @@ def main():
             plan = driver.Plan(j=args.threads_param)
             for a, bs in plan_lines:
                 plan.run_line(blocks[a], [blocks[b] for b in bs], out)
+            plan.finish()        # drains the asynchronous host tail: every .las is closed
             return out, plan
 
         for w in range(args.warmup):

@@ -73,6 +73,9 @@ def _lib():
         L.damar_index_download.argtypes = [C.c_void_p, C.c_void_p]
         L.damar_match.argtypes = [C.POINTER(HITS_DB), C.POINTER(HITS_DB), C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_void_p, C.POINTER(c_int64)]
+        L.damar_set_async.argtypes = [C.c_int]
+        L.damar_async_totals.argtypes = [C.POINTER(c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.damar_write_overlaps.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.damar_tandem_set_params.argtypes = [C.c_int] * 4
         L.damar_tandem_set_params.restype = C.c_int
         L.Match_Self.argtypes = [C.c_char_p, C.POINTER(HITS_DB), C.c_void_p]

@@ -148,6 +148,12 @@ int main(int argc, char *argv[])
   make_subdir(&ablock, runid);
   spec = New_Align_Spec(ecorr, spacing, ablock.freq, nthreads, SYMMETRIC, only_id, notrace, 1);
 
+  /* The host tail (redundancy handling, sort, .las write) of a block pair runs on a worker
+     thread while the GPU starts on the next pair; B blocks stay alive until it is done. */
+  damar_set_async(1);
+  HITS_DB *pending = (HITS_DB *) malloc(sizeof(HITS_DB) * (size_t) (argc + 2));
+  int      npending = 0;
+
   aindex = NULL;
   alen = 0;
   for (i = optind; i < argc; i++)
@@ -185,12 +191,16 @@ int main(int argc, char *argv[])
                                              : ablock.ufirst + ablock.nreads - 1;
           if (ablock.part > 0) d1 = damar_get_dir(runid, ablock.part);
           if (bblock.part > 0) d2 = damar_get_dir(runid, bblock.part);
-          Write_Overlap_Buffer(spec, d1, d2, aroot, broot, last);
-          Reset_Overlap_Buffer(spec);
+          damar_write_overlaps(spec, d1, d2, aroot, broot, last);
           free(d1);
           free(d2);
           free(broot);
-          damar_close_block(&bblock);
+          pending[npending++] = bblock;            /* closed after the drain below */
+          if (npending >= 4)
+            { damar_async_drain();
+              while (npending > 0)
+                damar_close_block(&pending[--npending]);
+            }
         }
       else
         { char *d1 = NULL;
@@ -201,11 +211,15 @@ int main(int argc, char *argv[])
           bindex = Sort_Kmers(cblock, &blen);
           Match_Filter(aroot, &ablock, aroot, cblock, aindex, alen, bindex, blen, 1, spec);
           if (ablock.part > 0) d1 = damar_get_dir(runid, ablock.part);
-          Write_Overlap_Buffer(spec, d1, NULL, aroot, aroot, ablock.ufirst + ablock.nreads - 1);
-          Reset_Overlap_Buffer(spec);
+          damar_write_overlaps(spec, d1, NULL, aroot, aroot, ablock.ufirst + ablock.nreads - 1);
           free(d1);
+          damar_async_drain();                     /* the complemented copy is a static record */
           free(((char *) cblock->bases) - 1);
         }
     }
+  damar_async_drain();
+  while (npending > 0)
+    damar_close_block(&pending[--npending]);
+  damar_set_async(0);
   return 0;
 }

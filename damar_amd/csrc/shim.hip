@@ -12,6 +12,11 @@
  */
 #include <algorithm>
 #include <vector>
+#include <deque>
+#include <string>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <string.h>
 #include <unistd.h>
 
@@ -470,6 +475,195 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   ra->counters = RS.counters;
 }
 
+
+/***** host tail (filter.c:2442-2483 per read pair) and its optional worker thread *********************/
+
+struct RecOrder
+{ bool operator()(const LaRecord &x, const LaRecord &y) const
+  { return (x.item != y.item) ? (x.item < y.item) : (x.seq < y.seq); }
+};
+
+static double now_ms(void)
+{ struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
+static int64 run_tail(std::vector<LaRecord> &recs, const std::vector<u16> &tpool,
+                      const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec)
+{ int64 ncheck = 0;
+  const int ts = Trace_Spacing(spec);
+  std::sort(recs.begin(), recs.end(), RecOrder());
+  Overlap_IO_Buffer *obuf = OVL_IO_Buffer(spec);
+  std::vector<damar_path> am, bm;
+  damar_tpool tp = { NULL, 0, 0 };
+  const char *abase = (const char *) ablock->bases, *bbase = (const char *) bblock->bases;
+  size_t i = 0;
+  while (i < recs.size())
+    { size_t j = i;
+      while (j < recs.size() && recs[j].item == recs[i].item)
+        j += 1;
+      const int ar = recs[i].aread, br = recs[i].bread;
+      const int al = ablock->reads[ar].rlen, bl = bblock->reads[br].rlen;
+      const int doA = (al >= HGAP_MIN);
+      const int doB = (SYMMETRIC && bl >= HGAP_MIN && (ar != br || !self || !comp));   /* filter.c:2300-2301 */
+      am.clear();  bm.clear();  tp.top = 0;
+      for (size_t q = i; q < j; q++)
+        { const LaRecord &r = recs[q];
+          damar_path p;
+          if (doA)
+            { p.tlen = r.atlen;  p.diffs = r.diffs;
+              p.abpos = r.abpos;  p.bbpos = r.bbpos;  p.aepos = r.aepos;  p.bepos = r.bepos;
+              p.toff = damar_tpool_push(&tp, tpool.data() + r.toff, r.atlen);
+              am.push_back(p);
+            }
+          if (doB)
+            { p.tlen = r.btlen;  p.diffs = r.diffs;
+              if (comp)                                          /* align.c:2039-2042 */
+                { p.abpos = bl - r.bepos;  p.bbpos = al - r.aepos;
+                  p.aepos = bl - r.bbpos;  p.bepos = al - r.abpos;
+                }
+              else                                               /* align.c:2059-2062 */
+                { p.abpos = r.bbpos;  p.bbpos = r.abpos;  p.aepos = r.bepos;  p.bepos = r.aepos; }
+              p.toff = damar_tpool_push(&tp, tpool.data() + r.toff + r.atlen, r.btlen);
+              bm.push_back(p);
+            }
+        }
+      damar_bridge_ctx bctx;
+      bctx.aseq = abase + ablock->reads[ar].boff;  bctx.bseq = bbase + bblock->reads[br].boff;
+      bctx.alen = al;  bctx.blen = bl;
+      damar_emit_pair(am.data(), (int) am.size(), bm.data(), (int) bm.size(), &tp, comp, ts,
+                      ar + ablock->ufirst, br + bblock->ufirst, &bctx, obuf, &ncheck);
+      i = j;
+    }
+  free(tp.val);
+  return ncheck;
+}
+
+/* Asynchronous mode (damar_set_async(1)): the host tail of a Match_Filter and the sort+write
+ * of Write_Overlap_Buffer run on one worker thread in submission order, so the GPU already
+ * works on the next block pair meanwhile.  The overlap buffers of an Align_Spec are then
+ * touched by the worker only; damar_async_drain() must be called before the blocks or the
+ * Align_Spec involved are released, and before the counters are read. */
+struct TailJob
+{ int kind;                                  /* 0 = tail of one Match_Filter, 1 = write + reset */
+  std::vector<LaRecord> recs;
+  std::vector<u16>      tpool;
+  const HITS_DB *ablock, *bblock;
+  int  self, comp;
+  Align_Spec *spec;
+  std::string d1, d2, a, b;
+  bool has1, has2;
+  int  last;
+};
+
+/* Heap objects that are never destroyed: at process exit the worker may still be parked in
+ * A_cv.wait(), and destroying a condition variable with a waiter (static destructors) hangs. */
+static bool                     A_on = false;
+static std::thread             *A_threadp = NULL;
+static std::mutex              &A_mu    = *new std::mutex();
+static std::condition_variable &A_cv    = *new std::condition_variable();
+static std::condition_variable &A_idle  = *new std::condition_variable();
+static std::deque<TailJob *>   &A_queue = *new std::deque<TailJob *>();
+static bool                     A_busy = false, A_quit = false;
+static int64                   A_ncheck = 0;
+static double                  A_tail_ms = 0, A_write_ms = 0;
+
+static void async_worker(void)
+{ for (;;)
+    { TailJob *job;
+      { std::unique_lock<std::mutex> lk(A_mu);
+        A_cv.wait(lk, [] { return A_quit || !A_queue.empty(); });
+        if (A_queue.empty())
+          return;
+        job = A_queue.front();
+        A_queue.pop_front();
+        A_busy = true;
+      }
+      double t0 = now_ms();
+      if (job->kind == 0)
+        { int64 n = run_tail(job->recs, job->tpool, job->ablock, job->bblock, job->self, job->comp, job->spec);
+          std::lock_guard<std::mutex> lk(A_mu);
+          A_ncheck += n;
+          A_tail_ms += now_ms() - t0;
+        }
+      else
+        { Write_Overlap_Buffer(job->spec, job->has1 ? (char *) job->d1.c_str() : NULL,
+                               job->has2 ? (char *) job->d2.c_str() : NULL,
+                               (char *) job->a.c_str(), (char *) job->b.c_str(), job->last);
+          Reset_Overlap_Buffer(job->spec);
+          std::lock_guard<std::mutex> lk(A_mu);
+          A_write_ms += now_ms() - t0;
+        }
+      delete job;
+      { std::lock_guard<std::mutex> lk(A_mu);
+        A_busy = false;
+      }
+      A_idle.notify_all();
+    }
+}
+
+static void async_submit(TailJob *job)
+{ { std::lock_guard<std::mutex> lk(A_mu);
+    A_queue.push_back(job);
+  }
+  A_cv.notify_one();
+}
+
+extern "C" void damar_async_drain(void)
+{ if (!A_on)
+    return;
+  std::unique_lock<std::mutex> lk(A_mu);
+  A_idle.wait(lk, [] { return A_queue.empty() && !A_busy; });
+}
+
+extern "C" void damar_set_async(int on)
+{ if (on && !A_on)
+    { A_quit = false;
+      A_threadp = new std::thread(async_worker);
+      A_on = true;
+    }
+  else if (!on && A_on)
+    { damar_async_drain();
+      { std::lock_guard<std::mutex> lk(A_mu);
+        A_quit = true;
+      }
+      A_cv.notify_all();
+      A_threadp->join();
+      delete A_threadp;
+      A_threadp = NULL;
+      A_on = false;
+    }
+}
+
+/* totals since the last call: confirmed records, tail ms, write ms (drains first) */
+extern "C" void damar_async_totals(int64 *ncheck, double *tail_ms, double *write_ms)
+{ damar_async_drain();
+  std::lock_guard<std::mutex> lk(A_mu);
+  if (ncheck)   *ncheck = A_ncheck;
+  if (tail_ms)  *tail_ms = A_tail_ms;
+  if (write_ms) *write_ms = A_write_ms;
+  A_ncheck = 0;  A_tail_ms = 0;  A_write_ms = 0;
+}
+
+/* Write_Overlap_Buffer + Reset_Overlap_Buffer (daligner.c:1020-1021, 1055-1056), queued behind
+ * the pending tails in asynchronous mode, immediate otherwise. */
+extern "C" void damar_write_overlaps(Align_Spec *spec, const char *d1, const char *d2,
+                                     const char *ablock, const char *bblock, int lastRead)
+{ if (!A_on)
+    { Write_Overlap_Buffer(spec, (char *) d1, (char *) d2, (char *) ablock, (char *) bblock, lastRead);
+      Reset_Overlap_Buffer(spec);
+      return;
+    }
+  TailJob *job = new TailJob();
+  job->kind = 1;  job->spec = spec;
+  job->has1 = d1 != NULL;  job->has2 = d2 != NULL;
+  if (d1) job->d1 = d1;
+  if (d2) job->d2 = d2;
+  job->a = ablock;  job->b = bblock;  job->last = lastRead;
+  async_submit(job);
+}
+
 /***** Match_Filter **********************************************************************************/
 
 static std::vector<u64> G_seed_keys;
@@ -482,10 +676,6 @@ static int64 sizeof_db(const HITS_DB *db)      /* db/DB.c:726 sizeof_DB without 
          (db->path ? (int64) strlen(db->path) + 1 : 0);
 }
 
-struct RecOrder
-{ bool operator()(const LaRecord &x, const LaRecord &y) const
-  { return (x.item != y.item) ? (x.item < y.item) : (x.seq < y.seq); }
-};
 
 extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
                             damar_dev_index *aidx, damar_dev_index *bidx,
@@ -684,59 +874,20 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
       G_cnt[2] = hc[4];  G_cnt[3] = hc[1];  G_cnt[4] = hc[2];
     }
 
-  /* ---- host tail: filter.c:2442-2483 per read pair ---- */
-  { double t0 = 0;
-    struct timespec tsp;
-    clock_gettime(CLOCK_MONOTONIC, &tsp);
-    t0 = tsp.tv_sec * 1e3 + tsp.tv_nsec * 1e-6;
-
-    std::sort(recs.begin(), recs.end(), RecOrder());
-    Overlap_IO_Buffer *obuf = OVL_IO_Buffer(spec);
-    std::vector<damar_path> am, bm;
-    damar_tpool tp = { NULL, 0, 0 };
-    const char *abase = (const char *) ablock->bases, *bbase = (const char *) bblock->bases;
-    size_t i = 0;
-    while (i < recs.size())
-      { size_t j = i;
-        while (j < recs.size() && recs[j].item == recs[i].item)
-          j += 1;
-        const int ar = recs[i].aread, br = recs[i].bread;
-        const int al = ablock->reads[ar].rlen, bl = bblock->reads[br].rlen;
-        const int doA = (al >= HGAP_MIN);
-        const int doB = (SYMMETRIC && bl >= HGAP_MIN && (ar != br || !self || !comp));   /* filter.c:2300-2301 */
-        am.clear();  bm.clear();  tp.top = 0;
-        for (size_t q = i; q < j; q++)
-          { const LaRecord &r = recs[q];
-            damar_path p;
-            if (doA)
-              { p.tlen = r.atlen;  p.diffs = r.diffs;
-                p.abpos = r.abpos;  p.bbpos = r.bbpos;  p.aepos = r.aepos;  p.bepos = r.bepos;
-                p.toff = damar_tpool_push(&tp, tpool.data() + r.toff, r.atlen);
-                am.push_back(p);
-              }
-            if (doB)
-              { p.tlen = r.btlen;  p.diffs = r.diffs;
-                if (comp)                                          /* align.c:2039-2042 */
-                  { p.abpos = bl - r.bepos;  p.bbpos = al - r.aepos;
-                    p.aepos = bl - r.bbpos;  p.bepos = al - r.abpos;
-                  }
-                else                                               /* align.c:2059-2062 */
-                  { p.abpos = r.bbpos;  p.bbpos = r.abpos;  p.aepos = r.bepos;  p.bepos = r.aepos; }
-                p.toff = damar_tpool_push(&tp, tpool.data() + r.toff + r.atlen, r.btlen);
-                bm.push_back(p);
-              }
-          }
-        damar_bridge_ctx bctx;
-        bctx.aseq = abase + ablock->reads[ar].boff;  bctx.bseq = bbase + bblock->reads[br].boff;
-        bctx.alen = al;  bctx.blen = bl;
-        damar_emit_pair(am.data(), (int) am.size(), bm.data(), (int) bm.size(), &tp, comp, ts,
-                        ar + ablock->ufirst, br + bblock->ufirst, &bctx, obuf, &ncheck);
-        i = j;
-      }
-    free(tp.val);
-    clock_gettime(CLOCK_MONOTONIC, &tsp);
-    G_ms[DAMAR_T_TAIL] = tsp.tv_sec * 1e3 + tsp.tv_nsec * 1e-6 - t0;
-  }
+  /* ---- host tail: filter.c:2442-2483 per read pair (worker thread in asynchronous mode) ---- */
+  if (A_on)
+    { TailJob *job = new TailJob();
+      job->kind = 0;
+      job->recs.swap(recs);
+      job->tpool.swap(tpool);
+      job->ablock = ablock;  job->bblock = bblock;  job->self = self;  job->comp = comp;  job->spec = spec;
+      async_submit(job);
+    }
+  else
+    { double t0 = now_ms();
+      ncheck = run_tail(recs, tpool, ablock, bblock, self, comp, spec);
+      G_ms[DAMAR_T_TAIL] = now_ms() - t0;
+    }
 
   if (counts)
     { counts[0] = nhits;  counts[1] = nfilt;  counts[2] = ncheck; }

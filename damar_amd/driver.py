@@ -63,7 +63,7 @@ class Plan:
     """daligner <A> <B1> <B2> ... for resident blocks."""
 
     def __init__(self, k=14, w=6, h=35, t=0, e=.70, l=1000, s=100, j=4, run=1,
-                 symmetric=1, identity=0, verbose=0):
+                 symmetric=1, identity=0, verbose=0, async_tail=True):
         self.k, self.w, self.h, self.t, self.e, self.l, self.s, self.j, self.run = k, w, h, t, e, l, s, j, run
         self.symmetric, self.identity, self.verbose = symmetric, identity, verbose
         L = api.lib()
@@ -72,6 +72,22 @@ class Plan:
             raise ValueError("Illegal combination of filter parameters")
         self.timings = {}
         self.counts = [0, 0, 0]
+        self.async_tail = async_tail
+        self._specs = []
+        L.damar_set_async(1 if async_tail else 0)
+
+    def finish(self):
+        """Drain the asynchronous host tail, release the Align_Specs, fold in the counters."""
+        L = api.lib()
+        n, t, w = api.c_int64(0), C.c_double(0), C.c_double(0)
+        L.damar_async_totals(C.byref(n), C.byref(t), C.byref(w))
+        if self.async_tail:
+            self.counts[2] += n.value
+            self.timings["tail"] = self.timings.get("tail", 0.) + t.value
+            self.timings["write"] = self.timings.get("write", 0.) + w.value
+        for sp in self._specs:
+            L.Free_Align_Spec(sp)
+        self._specs = []
 
     def _acc(self):
         for n, v in api.timings().items():
@@ -101,6 +117,10 @@ class Plan:
         Writes the .las files under outdir exactly as daligner.c:1006-1021, 1051-1056."""
         L = api.lib()
         os.makedirs(outdir, exist_ok=True)
+        outabs = os.path.abspath(outdir)
+
+        def odir(part):          # absolute: the write may run later on the worker thread
+            return os.path.join(outabs, api.get_dir(self.run, part)).encode() if part > 0 else None
         with _cwd(outdir):
             os.makedirs(api.get_dir(self.run, a.db.part), exist_ok=True)
             spec = L.New_Align_Spec(self.e, self.s, a.db.freq, self.j, self.symmetric, 0, 0, 1)
@@ -112,8 +132,7 @@ class Plan:
                     cidx, clen = self._build(cdev)
                     self._match(a.db, a.cdb, aidx, cidx, 1, 1, spec)
                     L.damar_index_free(cidx)
-                    d1 = api.get_dir(self.run, a.db.part).encode() if a.db.part > 0 else None
-                    L.Write_Overlap_Buffer(spec, d1, None, a.root.encode(), a.root.encode(), a.last_read())
+                    L.damar_write_overlaps(spec, odir(a.db.part), None, a.root.encode(), a.root.encode(), a.last_read())
                 else:
                     if self.symmetric:
                         os.makedirs(api.get_dir(self.run, b.db.part), exist_ok=True)
@@ -124,12 +143,11 @@ class Plan:
                     self._match(a.db, b.cdb, aidx, cidx, 0, 1, spec)
                     L.damar_index_free(cidx)
                     last = b.last_read() if b.db.part < a.db.part else a.last_read()
-                    d1 = api.get_dir(self.run, a.db.part).encode() if a.db.part > 0 else None
-                    d2 = api.get_dir(self.run, b.db.part).encode() if b.db.part > 0 else None
-                    L.Write_Overlap_Buffer(spec, d1, d2, a.root.encode(), b.root.encode(), last)
-                L.Reset_Overlap_Buffer(spec)
+                    L.damar_write_overlaps(spec, odir(a.db.part), odir(b.db.part), a.root.encode(), b.root.encode(), last)
             L.damar_index_free(aidx)
-            L.Free_Align_Spec(spec)
+            self._specs.append(spec)
+            if not self.async_tail or a.db.part <= 0 or any(b.db.part <= 0 for b in bs):
+                self.finish()            # unsplit DBs write relative paths: finish inside this cwd
 
 
 def run_datander(block, outdir, k=12, w=4, h=35, e=.70, l=500, s=100, j=4, verbose=0, out="tan"):

@@ -80,6 +80,7 @@ def main():
     dist.barrier()
     t0 = time.time()
     run_rank(dbprefix, nblocks, outdir, rank, world, runner)
+    runner.plan.finish()
     torch.cuda.synchronize()
     dist.barrier()
     el, cnt = reduce_stats(dist, torch.device("cuda", local), time.time() - t0, runner.plan.counts)

@@ -56,6 +56,19 @@ void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
                  damar_dev_index *aidx, damar_dev_index *bidx,
                  int self, int comp, Align_Spec *spec, int64 *counts);
 
+/* Asynchronous host tail: with damar_set_async(1) the per-read-pair tail of damar_match /
+ * Match_Filter (redundancy handling, trace compression, buffer append) and the sort + write of
+ * damar_write_overlaps run on one worker thread in submission order while the GPU proceeds
+ * with the next block pair.  Call damar_async_drain() before releasing the blocks or the
+ * Align_Spec, and before reading record counts (counts[2] of damar_match is 0 in this mode;
+ * damar_async_totals returns the sum). */
+void damar_set_async(int on);
+void damar_async_drain(void);
+void damar_async_totals(int64 *ncheck, double *tail_ms, double *write_ms);
+/* Write_Overlap_Buffer + Reset_Overlap_Buffer (daligner.c:1020-1021), queued in async mode */
+void damar_write_overlaps(Align_Spec *spec, const char *dirName1, const char *dirName2,
+                          const char *ablock, const char *bblock, int lastRead);
+
 /* datander (scrub/tandem.h:58-60): the 4-argument parameter call under a library-unique
  * name, and Match_Self with the block already resident in HBM.  counts = k-mers, seed hits,
  * confirmed records. */

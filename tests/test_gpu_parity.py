@@ -39,6 +39,7 @@ def run_plan(case, workdir):
                 blocks[x] = driver.Block(os.path.join(workdir, "G." + x))
     for a, bs in case["lines"]:
         plan.run_line(blocks[a], [blocks[b] for b in bs], workdir)
+    plan.finish()
     return plan
 
 
@@ -98,6 +99,7 @@ def test_gpu_seed_pairs_equal_oracle(gpu, comp, cross):
     from damar_amd import api
     L = gpu
     L.Set_Filter_Params(14, 6, 0, 35, 4)
+    L.damar_set_async(0)
     api.set_globals()
     an = os.path.join(GOLDEN, "tiny2", "G.2")
     bn = os.path.join(GOLDEN, "tiny2", "G.1") if cross else an
@@ -198,6 +200,7 @@ def test_gpu_config1_known_answer(gpu, tmp_path):
     blk = driver.Block(os.path.join(d, "SIM.1"))
     plan = driver.Plan(j=4)
     plan.run_line(blk, [blk], d)
+    plan.finish()
     las = os.path.join(d, "d001_00001", "SIM.1.SIM.1.las")
     assert os.path.getsize(las) == 4982214
     assert hashlib.md5(open(las, "rb").read()).hexdigest() == "08bcb3acacfb24a16fb3d18daeab5ff0"
@@ -242,6 +245,7 @@ def test_gpu_config2_block_pairs_known_answer(gpu, tmp_path):
     b1, b2 = driver.Block(os.path.join(d, "SIM.1")), driver.Block(os.path.join(d, "SIM.2"))
     plan = driver.Plan(j=16)
     plan.run_line(b2, [b2, b1], d)
+    plan.finish()
     for f in ("d001_00002/SIM.2.SIM.2.las", "d001_00002/SIM.2.SIM.1.las", "d001_00001/SIM.1.SIM.2.las"):
         assert hashlib.md5(open(os.path.join(d, f), "rb").read()).hexdigest() == want[f], f
         assert _check_las_invariants(os.path.join(d, f)) > 50000
