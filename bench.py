@@ -92,8 +92,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        backend = os.environ.get("DAMAR_BENCH_BACKEND", "nccl")     # "gloo" only to rehearse on one GPU
+        if os.environ.get("DAMAR_BENCH_SHARE_GPU"):
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from damar_amd import api, driver
     L = api.lib()
@@ -161,10 +167,11 @@ def main():
                     trace_vals += (os.path.getsize(os.path.join(dp, f)) - 12 - 40 * n)
         if dist is not None:
             import torch
-            t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+            rdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            v = torch.tensor([bp, nrec], device="cuda", dtype=torch.float64)
+            v = torch.tensor([bp, nrec], device=rdev, dtype=torch.float64)
             dist.all_reduce(v, op=dist.ReduceOp.SUM)
             bp_all, nrec_all = float(v[0].item()), float(v[1].item())
         else:

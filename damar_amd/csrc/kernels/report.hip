@@ -79,9 +79,12 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 /* Eight bases per step.  load8 returns bytes p[0..7] of an arbitrarily aligned address as a
  * little-endian u64 from three aligned dword loads (the bases buffer is padded by 64 bytes on
  * both sides, so the extra bytes are always mapped). */
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef int v4i __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ u64 load8(const u8 *p)
 { const uintptr_t ad = (uintptr_t) p;
-  const u32 *q = (const u32 *) (ad & ~(uintptr_t) 3);
+  const GLOBAL_AS u32 *q = (const GLOBAL_AS u32 *) (ad & ~(uintptr_t) 3);      /* HBM, not "flat" */
   const u32 sh = (u32) (ad & 3);
   const u32 w0 = q[0], w1 = q[1], w2 = q[2];
   const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
@@ -97,14 +100,9 @@ template <int REV>
 __device__ __forceinline__ void snake(const u8 *a, const u8 *bq, int &y, int &m, u64 &b,
                                       bool &ahit, bool &bhit, int guard, u32 *err)
 { const u64 LO7 = 0x7f7f7f7f7f7f7f7full, HI8 = 0x8080808080808080ull;
-  int g = 0;
+  (void) guard;  (void) err;      /* bounded by construction: every read ends in a 4, the buffer in 64 of them */
   for (;;)
-    { if (++g > guard)
-        { atomicOr(err, DAMAR_ERR_BAND);
-          atomicMax(err + 3, 15u);
-          break;
-        }
-      const u64 wa = REV ? load8(a + y - 7) : load8(a + y);
+    { const u64 wa = REV ? load8(a + y - 7) : load8(a + y);
       const u64 wb = REV ? load8(bq + y - 7) : load8(bq + y);
       const u64 d  = wa ^ wb;
       const u64 nz = (((d & LO7) + LO7) | d) & HI8;              /* bytes with a != b  */
@@ -132,39 +130,73 @@ __device__ __forceinline__ void snake(const u8 *a, const u8 *bq, int &y, int &m,
 
 /* One direction of the wave.  REV = 0: align.c:409-1122, REV = 1: align.c:1126-1898.
  * Returns through *res the end point of this direction; traces are written by lane 0. */
+/* The wave-uniform bookkeeping of one direction, handed between the three stages below.  The
+ * stages are separate (noinline) functions so that the hot register loop is compiled -- and
+ * gets its registers allocated -- on its own: the rare wide-band loop and the lane-0 trace walk
+ * no longer add to its VGPR count. */
+struct WaveState
+{ int low, hgh, dif, besta, besty, lasta, more, reachm, aclip, bclip;
+  u32 ncell;
+  Tip trim, reach;
+  int stopped;
+};
+
+#define WS_LOAD(ws)                                                                          \
+  int low = uni(ws.low), hgh = uni(ws.hgh), dif = uni(ws.dif), besta = uni(ws.besta);        \
+  int besty = uni(ws.besty), lasta = uni(ws.lasta), more = uni(ws.more), reachm = uni(ws.reachm); \
+  int aclip = uni(ws.aclip), bclip = uni(ws.bclip);                                          \
+  u32 ncell = (u32) uni((int) ws.ncell);                                                     \
+  Tip trim, reach;                                                                           \
+  trim.a = uni(ws.trim.a); trim.y = uni(ws.trim.y); trim.d = uni(ws.trim.d);                 \
+  trim.ha = uni(ws.trim.ha); trim.hb = uni(ws.trim.hb);                                      \
+  reach.a = uni(ws.reach.a); reach.y = uni(ws.reach.y); reach.d = uni(ws.reach.d);           \
+  reach.ha = uni(ws.reach.ha); reach.hb = uni(ws.reach.hb);                                  \
+  (void) low; (void) hgh; (void) dif; (void) besta; (void) besty; (void) lasta; (void) more; \
+  (void) reachm; (void) aclip; (void) bclip; (void) ncell;
+
+#define WS_STORE(ws)                                                                         \
+  ws.low = low; ws.hgh = hgh; ws.dif = dif; ws.besta = besta; ws.besty = besty;              \
+  ws.lasta = lasta; ws.more = more; ws.reachm = reachm; ws.aclip = aclip; ws.bclip = bclip;  \
+  ws.ncell = ncell; ws.trim = trim; ws.reach = reach;
+
+/* Stage 1: wave 0 on the seed diagonal, then the register path (bands of <= 64 diagonals).
+ * Leaves ws.stopped = 0 only if the band outgrew the wavefront: the band state is then in
+ * the slot's DState buffers and stage 2 continues. */
 template <int REV>
-__device__ void wave_pass(const WaveCtx &c, int diag, int mida,
-                          int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
-{ const int lane = lane_id();
+__device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, WaveState &ws)
+{
+  const int lane = lane_id();
   const int TS = c.ts;
   const int S = REV ? -1 : 1;
   const u8 *aseq = REV ? c.aseq - 1 : c.aseq;
   const u8 *bseq = REV ? c.bseq - 1 : c.bseq;
   DState *cur = c.st0, *nxt = c.st1;
   const int o = c.koff;
-  /* everything that is the same in all 64 lanes is forced into SGPRs (readfirstlane): the
-     band bounds, the best/trim bookkeeping and every loop condition are scalar */
-  diag = uni(diag);
-  mida = uni(mida);
   const int minp = c.minp, maxp = c.maxp, aoff = c.aoff, boff = c.boff;
   const int ave = c.ave, do_reach = c.reach;
   const u32 cell_cap = c.cell_cap;
   const short *score_tab = c.score, *trim_tab = c.table;
   Cell *const cellbuf = c.cells;
+  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) c.cells;          /* one 16-byte store per pebble */
   u32 *const errw = c.err;
-
+  const int steplimit = c.alen + c.blen + 64;
+  const int guard = 4 * (c.alen + c.blen) + 1024;
+  (void) lane; (void) TS; (void) S; (void) aseq; (void) bseq; (void) cur; (void) nxt; (void) o;
+  (void) minp; (void) maxp; (void) aoff; (void) boff; (void) ave; (void) do_reach; (void) cell_cap;
+  (void) score_tab; (void) trim_tab; (void) cellbuf; (void) gcell; (void) errw; (void) steplimit; (void) guard;
+  /* everything that is the same in all 64 lanes is forced into SGPRs (readfirstlane): the
+     band bounds, the best/trim bookkeeping and every loop condition are scalar */
+  diag = uni(diag);
+  mida = uni(mida);
   int low = diag, hgh = diag, dif = 0;
   int besta = mida, lasta = mida, besty = (mida - diag) >> 1, more = 1;
   Tip trim, reach;
   int reachm = -1;
   int aclip = REV ? -BIG : BIG, bclip = REV ? BIG : -BIG;
   u32 ncell = 0;
-  const int steplimit = c.alen + c.blen + 64;
-  const int guard = 4 * (c.alen + c.blen) + 1024;
 
   trim.a = reach.a = mida;  trim.y = reach.y = besty;  trim.d = reach.d = 0;
   trim.ha = reach.ha = 0;   trim.hb = reach.hb = 1;
-
   /* Per-lane band state of the register path: lane (k & 63) owns diagonal k. */
   int rV = 0, rM = 0, rHA = 0, rHB = 0, rHAm = 0, rHBm = 0, rNA = 0, rNB = 0;
   u64 rT = 0;
@@ -334,10 +366,8 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
         /* pebbles (align.c:859-909): almost never needed, so test once for the whole wave */
         int na = rNA, nb = rNB;
         if (__any(act && (REV ? ((y + k <= na) || (y <= nb)) : ((y + k >= na) || (y >= nb)))))
-          { int g2 = 0;
-            for (;;)
-              { GUARD(g2, guard, 13)
-                bool need = act && (REV ? (y + k <= na) : (y + k >= na));
+          { for (;;)
+              { bool need = act && (REV ? (y + k <= na) : (y + k >= na));
                 if (!__any(need))
                   break;
                 bool dropit = need && (REV ? (ham > na) : (ham < na));
@@ -346,8 +376,8 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
                   { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                     if (dropit)
                       { if (idx < cell_cap)
-                          { Cell cl; cl.ptr = ha; cl.diag = k; cl.diff = dif; cl.mark = na;
-                            cellbuf[idx] = cl;
+                          { v4i cl = { ha, k, dif, na };
+                            gcell[idx] = cl;
                           }
                         ha = (int) idx;  ham = na;
                       }
@@ -356,10 +386,8 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
                 if (need)
                   na += S * TS;
               }
-            g2 = 0;
             for (;;)
-              { GUARD(g2, guard, 14)
-                bool need = act && (REV ? (y <= nb) : (y >= nb));
+              { bool need = act && (REV ? (y <= nb) : (y >= nb));
                 if (!__any(need))
                   break;
                 bool dropit = need && (REV ? (hbm > nb) : (hbm < nb));
@@ -368,8 +396,8 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
                   { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                     if (dropit)
                       { if (idx < cell_cap)
-                          { Cell cl; cl.ptr = hb; cl.diag = k; cl.diff = dif; cl.mark = nb;
-                            cellbuf[idx] = cl;
+                          { v4i cl = { hb, k, dif, nb };
+                            gcell[idx] = cl;
                           }
                         hb = (int) idx;  hbm = nb;
                       }
@@ -464,7 +492,37 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
     else
       stopped = true;
   }
+  ws.stopped = stopped ? 1 : 0;
+  WS_STORE(ws)
   wave_mem_sync();
+}
+
+/* Stage 2: the same wave steps with the band in memory, for bands wider than the wavefront. */
+template <int REV>
+__device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
+{
+  const int lane = lane_id();
+  const int TS = c.ts;
+  const int S = REV ? -1 : 1;
+  const u8 *aseq = REV ? c.aseq - 1 : c.aseq;
+  const u8 *bseq = REV ? c.bseq - 1 : c.bseq;
+  DState *cur = c.st0, *nxt = c.st1;
+  const int o = c.koff;
+  const int minp = c.minp, maxp = c.maxp, aoff = c.aoff, boff = c.boff;
+  const int ave = c.ave, do_reach = c.reach;
+  const u32 cell_cap = c.cell_cap;
+  const short *score_tab = c.score, *trim_tab = c.table;
+  Cell *const cellbuf = c.cells;
+  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) c.cells;          /* one 16-byte store per pebble */
+  u32 *const errw = c.err;
+  const int steplimit = c.alen + c.blen + 64;
+  const int guard = 4 * (c.alen + c.blen) + 1024;
+  (void) lane; (void) TS; (void) S; (void) aseq; (void) bseq; (void) cur; (void) nxt; (void) o;
+  (void) minp; (void) maxp; (void) aoff; (void) boff; (void) ave; (void) do_reach; (void) cell_cap;
+  (void) score_tab; (void) trim_tab; (void) cellbuf; (void) gcell; (void) errw; (void) steplimit; (void) guard;
+  mida = uni(mida);
+  WS_LOAD(ws)
+  const bool stopped = false;
 
   /* clipping at sequence ends (align.c:628-658 / 943-975, mirrored 1341-1371 / 1652-1684) */
 #define CLIP_STEP()                                                                        \
@@ -699,6 +757,36 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
       }
     }
 #undef CLIP_STEP
+  WS_STORE(ws)
+  wave_mem_sync();
+}
+
+/* Stage 3: end point of this direction and its trace points (lane 0 walks the pebble chains). */
+template <int REV>
+__device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveState &ws,
+                                         int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
+{
+  const int lane = lane_id();
+  const int TS = c.ts;
+  const int S = REV ? -1 : 1;
+  const u8 *aseq = REV ? c.aseq - 1 : c.aseq;
+  const u8 *bseq = REV ? c.bseq - 1 : c.bseq;
+  DState *cur = c.st0, *nxt = c.st1;
+  const int o = c.koff;
+  const int minp = c.minp, maxp = c.maxp, aoff = c.aoff, boff = c.boff;
+  const int ave = c.ave, do_reach = c.reach;
+  const u32 cell_cap = c.cell_cap;
+  const short *score_tab = c.score, *trim_tab = c.table;
+  Cell *const cellbuf = c.cells;
+  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) c.cells;          /* one 16-byte store per pebble */
+  u32 *const errw = c.err;
+  const int steplimit = c.alen + c.blen + 64;
+  const int guard = 4 * (c.alen + c.blen) + 1024;
+  (void) lane; (void) TS; (void) S; (void) aseq; (void) bseq; (void) cur; (void) nxt; (void) o;
+  (void) minp; (void) maxp; (void) aoff; (void) boff; (void) ave; (void) do_reach; (void) cell_cap;
+  (void) score_tab; (void) trim_tab; (void) cellbuf; (void) gcell; (void) errw; (void) steplimit; (void) guard;
+  mida = uni(mida);
+  WS_LOAD(ws)
 
   /* end point and trace points of this direction: lane 0 walks the two pebble chains */
   int rx = 0, ry = 0, rd = 0, at = 0, bt = 0;
@@ -853,6 +941,16 @@ __device__ void wave_pass(const WaveCtx &c, int diag, int mida,
       *atlen_io += at;  *btlen_io += bt;
     }
   wave_mem_sync();
+}
+
+template <int REV>
+__device__ __forceinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
+                                          int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
+{ WaveState ws;
+  wave_reg<REV>(c, diag, mida, ws);
+  if (!uni(ws.stopped))
+    wave_mem<REV>(c, mida, ws);
+  wave_finish<REV>(c, mida, ws, ox, oy, od, atlen_io, btlen_io, aback, bback);
 }
 
 struct LaResult
@@ -1254,7 +1352,7 @@ __device__ void process_read(const ReportArgs &a, const SlotScratch &s, const in
   wave_mem_sync();
 }
 
-__global__ __launch_bounds__(64, 2)
+__global__ __launch_bounds__(64, 4)
 void tandem_kernel(ReportArgs a, const int *dist)
 { const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);
@@ -1275,7 +1373,7 @@ void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots
   hipLaunchKernelGGL(tandem_kernel, dim3(nslots), dim3(64), 0, st, *a, dist);
 }
 
-__global__ __launch_bounds__(64, 2)
+__global__ __launch_bounds__(64, 4)
 void report_kernel(ReportArgs a)
 { const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);
@@ -1297,7 +1395,7 @@ void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st)
 }
 
 /* batch Local_Alignment (tests): one wave per task, result always emitted */
-__global__ __launch_bounds__(64, 2)
+__global__ __launch_bounds__(64, 4)
 void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
 { const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);
