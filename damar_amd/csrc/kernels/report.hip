@@ -96,11 +96,15 @@ __device__ __forceinline__ u64 load8(const u8 *p)
  * stopping at the first mismatch or terminator (4).  A `4` in B is tested first, exactly as
  * the reference does.  Each match shifts a 1 into the history b and raises m when the bit
  * leaving the 60-column window was a 0; n matches at once examine bits 60..61-n of b. */
+/* Returns 0, or 1 if the snake stopped on A's terminator, 2 if on B's (B is tested first).
+ * Everything is passed and returned by value so that nothing lives in scratch memory. */
+struct SnakeOut { int y, m, hit; u64 b; };
+
 template <int REV>
-__device__ __forceinline__ void snake(const u8 *a, const u8 *bq, int &y, int &m, u64 &b,
-                                      bool &ahit, bool &bhit, int guard, u32 *err)
+__device__ __forceinline__ SnakeOut snake(const u8 *a, const u8 *bq, int y, int m, u64 b)
 { const u64 LO7 = 0x7f7f7f7f7f7f7f7full, HI8 = 0x8080808080808080ull;
-  (void) guard;  (void) err;      /* bounded by construction: every read ends in a 4, the buffer in 64 of them */
+  int hit = 0;
+  /* bounded by construction: every read ends in a 4, the buffer in 64 of them */
   for (;;)
     { const u64 wa = REV ? load8(a + y - 7) : load8(a + y);
       const u64 wb = REV ? load8(bq + y - 7) : load8(bq + y);
@@ -121,11 +125,13 @@ __device__ __forceinline__ void snake(const u8 *a, const u8 *bq, int &y, int &m,
       if (stop)
         { const int bi = REV ? 7 - n : n;
           const u32 cb = (u32) (wb >> (8 * bi)) & 0xff, ca = (u32) (wa >> (8 * bi)) & 0xff;
-          if (cb == 4) bhit = true;
-          else if (ca == 4) ahit = true;
+          hit = (cb == 4) ? 2 : ((ca == 4) ? 1 : 0);
           break;
         }
     }
+  SnakeOut o;
+  o.y = y;  o.m = m;  o.b = b;  o.hit = hit;
+  return o;
 }
 
 /* One direction of the wave.  REV = 0: align.c:409-1122, REV = 1: align.c:1126-1898.
@@ -198,7 +204,7 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
   trim.a = reach.a = mida;  trim.y = reach.y = besty;  trim.d = reach.d = 0;
   trim.ha = reach.ha = 0;   trim.hb = reach.hb = 1;
   /* Per-lane band state of the register path: lane (k & 63) owns diagonal k. */
-  int rV = 0, rM = 0, rHA = 0, rHB = 0, rHAm = 0, rHBm = 0, rNA = 0, rNB = 0;
+  int rV = 0, rM = 0, rHA = 0, rHB = 0, rNA = 0, rNB = 0;
   u64 rT = 0;
 
   /* wave 0 on the seed diagonal: every lane computes the same values */
@@ -223,10 +229,9 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
     if (!REV) { na += TS; nb += TS; }
 
     int g0 = 0;
-    { int m0 = 0;  u64 b0 = 0;  bool ah = false, bh = false;
-      snake<REV>(a, bseq, y, m0, b0, ah, bh, guard, errw);
-      y = uni(y);
-      const int hit = uni((bh ? 2 : 0) | (ah ? 1 : 0));
+    { const SnakeOut so = snake<REV>(a, bseq, y, 0, 0ull);
+      y = uni(so.y);
+      const int hit = uni(so.hit);
       if (hit & 2)      { more = 0; bclip = k; }
       else if (hit & 1) { more = 0; aclip = k; }
     }
@@ -248,7 +253,7 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
         besty = trim.y = y;
         trim.ha = ha;  trim.hb = hb;
       }
-    rV = v;  rM = HIST_LEN;  rT = HIST_FULL;  rHA = ha;  rHB = hb;  rHAm = ham;  rHBm = hbm;
+    rV = v;  rM = HIST_LEN;  rT = HIST_FULL;  rHA = ha;  rHB = hb;  (void) ham;  (void) hbm;
     rNA = na;  rNB = nb;
   }
 
@@ -345,8 +350,7 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
           m   = __shfl(rM, src);
           ha  = __shfl(rHA, src);
           hb  = __shfl(rHB, src);
-          ham = __shfl(rHAm, src);
-          hbm = __shfl(rHBm, src);
+          ham = hbm = 0;            /* the head marks are fetched from the cells only when a mark is crossed */
           { u32 tlo = (u32) __shfl((int) (u32) rT, src), thi = (u32) __shfl((int) (u32) (rT >> 32), src);
             b = ((u64) thi << 32) | tlo;
           }
@@ -357,7 +361,10 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
               m -= 1;
             b <<= 1;
             y = (v - k) >> 1;
-            snake<REV>(aseq + k, bseq, y, m, b, ahit, bhit, guard, errw);
+            { const SnakeOut so = snake<REV>(aseq + k, bseq, y, m, b);
+              y = so.y;  m = so.m;  b = so.b;
+              ahit = so.hit == 1;  bhit = so.hit == 2;
+            }
             v = (y << 1) + k;
           }
         else
@@ -366,7 +373,12 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
         /* pebbles (align.c:859-909): almost never needed, so test once for the whole wave */
         int na = rNA, nb = rNB;
         if (__any(act && (REV ? ((y + k <= na) || (y <= nb)) : ((y + k >= na) || (y >= nb)))))
-          { for (;;)
+          { /* marks of the two chain heads (cells may have been written by other lanes of this
+               wave in earlier steps: make those stores visible, read past the L1) */
+            wave_mem_sync();
+            ham = act ? __hip_atomic_load(&cellbuf[ha].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            hbm = act ? __hip_atomic_load(&cellbuf[hb].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            for (;;)
               { bool need = act && (REV ? (y + k <= na) : (y + k >= na));
                 if (!__any(need))
                   break;
@@ -409,7 +421,7 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
           }
 
         /* commit the new wave */
-        rV = v;  rM = m;  rT = b;  rHA = ha;  rHB = hb;  rHAm = ham;  rHBm = hbm;
+        rV = v;  rM = m;  rT = b;  rHA = ha;  rHB = hb;
         if (act) { rNA = na;  rNB = nb; }
 
         /* sequence ends reached (bit i of the rotated masks = diagonal low + i) */
@@ -481,9 +493,12 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
     /* leaving the register path with work left: spill the band to the memory buffers */
     if (!stopped && more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
       { const int k = low + ((lane - low) & 63);
+        wave_mem_sync();
         if (k <= hgh)
           { DState s;
-            s.V = rV; s.M = rM; s.HA = rHA; s.HB = rHB; s.T = rT; s.HAm = rHAm; s.HBm = rHBm;
+            s.V = rV; s.M = rM; s.HA = rHA; s.HB = rHB; s.T = rT;
+            s.HAm = __hip_atomic_load(&cellbuf[rHA].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s.HBm = __hip_atomic_load(&cellbuf[rHB].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             cur[k + o] = s;
             c.NA[k + o] = rNA;
             c.NB[k + o] = rNB;
@@ -617,7 +632,10 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
                 m -= 1;
               b <<= 1;
               y = (v - k) >> 1;
-              snake<REV>(aseq + k, bseq, y, m, b, ahit, bhit, guard, errw);
+              { const SnakeOut so = snake<REV>(aseq + k, bseq, y, m, b);
+                y = so.y;  m = so.m;  b = so.b;
+                ahit = so.hit == 1;  bhit = so.hit == 2;
+              }
               v = (y << 1) + k;
               na = c.NA[k + o];
               nb = c.NB[k + o];
