@@ -79,6 +79,11 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 /* Eight bases per step.  load8 returns bytes p[0..7] of an arbitrarily aligned address as a
  * little-endian u64 from three aligned dword loads (the bases buffer is padded by 64 bytes on
  * both sides, so the extra bytes are always mapped). */
+/* value of the next-higher / next-lower lane, cyclic over the 64 lanes: one DPP move each
+ * (wave_rol:1 / wave_ror:1), no LDS round trip */
+__device__ __forceinline__ int lane_up(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_dn(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x13c, 0xf, 0xf, false); }
+
 #define GLOBAL_AS __attribute__((address_space(1)))
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -310,8 +315,8 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
 
         /* widen (align.c:675-776 / 1386-1486): a new edge lane gets V = edge and its inner
            neighbour's NA/NB */
-        { const int upNA = __shfl(rNA, (lane + 1) & 63), upNB = __shfl(rNB, (lane + 1) & 63);
-          const int dnNA = __shfl(rNA, (lane - 1) & 63), dnNB = __shfl(rNB, (lane - 1) & 63);
+        { const int upNA = lane_up(rNA), upNB = lane_up(rNB);
+          const int dnNA = lane_dn(rNA), dnNB = lane_dn(rNB);
           int nlow = low - 1, nhgh = hgh + 1;
           if (nlow >= minp)
             { if (lane == LANE_OF(nlow)) { rV = edge; rNA = upNA; rNB = upNB; } }
@@ -332,7 +337,12 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
         bool ahit = false, bhit = false;
 
         { const int ac = rV;
-          int am = __shfl(rV, (lane - 1) & 63), ap = __shfl(rV, (lane + 1) & 63);
+          int am = lane_dn(rV), ap = lane_up(rV);
+          /* both neighbours' inherited state, fetched before the choice is known */
+          const int mU = lane_up(rM), mD = lane_dn(rM), haU = lane_up(rHA), haD = lane_dn(rHA);
+          const int hbU = lane_up(rHB), hbD = lane_dn(rHB);
+          const int tlU = lane_up((int) (u32) rT), tlD = lane_dn((int) (u32) rT);
+          const int thU = lane_up((int) (u32) (rT >> 32)), thD = lane_dn((int) (u32) (rT >> 32));
           int dl;                                     /* predecessor = k + dl */
           if (k - 1 < low) am = edge;
           if (k + 1 > hgh) ap = edge;
@@ -346,12 +356,12 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
               else         dl = (ac > am) ? -1 : 0;
               v = (dl == 0) ? ac - 2 : ((dl == -1) ? am - 1 : ap - 1);
             }
-          const int src = (lane + dl) & 63;
-          m   = __shfl(rM, src);
-          ha  = __shfl(rHA, src);
-          hb  = __shfl(rHB, src);
+          m   = (dl == 0) ? rM  : ((dl > 0) ? mU  : mD);
+          ha  = (dl == 0) ? rHA : ((dl > 0) ? haU : haD);
+          hb  = (dl == 0) ? rHB : ((dl > 0) ? hbU : hbD);
           ham = hbm = 0;            /* the head marks are fetched from the cells only when a mark is crossed */
-          { u32 tlo = (u32) __shfl((int) (u32) rT, src), thi = (u32) __shfl((int) (u32) (rT >> 32), src);
+          { const u32 tlo = (dl == 0) ? (u32) rT : (u32) ((dl > 0) ? tlU : tlD);
+            const u32 thi = (dl == 0) ? (u32) (rT >> 32) : (u32) ((dl > 0) ? thU : thD);
             b = ((u64) thi << 32) | tlo;
           }
         }
