@@ -51,8 +51,8 @@ void damar_launch_merge_count(const MergeArgs *m, u32 *cnt, u32 *jb, hipStream_t
 void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32 *cnt, hipStream_t st);
 void damar_launch_merge_emit(const MergeArgs *m, const u32 *off, const u32 *jb, u64 nhits,
                              u64 *keys, u32 *vals, hipStream_t st);
-void damar_launch_pair_flags(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
-                             u32 *flags, hipStream_t st);
+void damar_launch_pair_flags(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, int minhit,
+                             int nshift, int binshift, u32 *flags, hipStream_t st);
 void damar_launch_compact_index(const u32 *flags, const u32 *off, u64 n, u32 *out, hipStream_t st);
 
 /* report.hip */

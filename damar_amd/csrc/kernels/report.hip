@@ -35,6 +35,20 @@
 #define PANEL_OVERLAP  10000                  /* filter.c:74 */
 #define BIG  0x7fffffff
 
+#ifdef DAMAR_PROF
+__device__ unsigned long long g_prof[32];
+#define PROF_ADD(i, v) do { if (lane_id() == 0) atomicAdd(&g_prof[i], (unsigned long long) (v)); } while (0)
+extern "C" void damar_prof_read(unsigned long long *out, int reset)
+{ hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof));
+  if (reset)
+    { unsigned long long z[32] = {0};
+      hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+    }
+}
+#else
+#define PROF_ADD(i, v) do { } while (0)
+#endif
+
 struct __attribute__((aligned(16))) DState
 { int V, M, HA, HB;
   u64 T;
@@ -264,6 +278,9 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
 
   /***** register path: the band (<= 64 diagonals) lives in VGPRs, neighbours by lane shuffle *****/
   bool stopped = false;
+#ifdef DAMAR_PROF
+  int pf_first16 = -1, pf_first32 = -1;
+#endif
   { const int edge = REV ? BIG : -1;
 
 #define LANE_OF(k)   ((k) & 63)
@@ -312,6 +329,10 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
           }
         if (hgh - low + 3 > 64)        /* would not fit the wavefront: continue in memory */
           break;
+#ifdef DAMAR_PROF
+        if (hgh - low + 3 > 16 && pf_first16 < 0) pf_first16 = dif;
+        if (hgh - low + 3 > 32 && pf_first32 < 0) pf_first32 = dif;
+#endif
 
         /* widen (align.c:675-776 / 1386-1486): a new edge lane gets V = edge and its inner
            neighbour's NA/NB */
@@ -518,6 +539,14 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
       stopped = true;
   }
   ws.stopped = stopped ? 1 : 0;
+#ifdef DAMAR_PROF
+  PROF_ADD(0, 1);
+  PROF_ADD(1, dif);
+  if (pf_first16 < 0) { PROF_ADD(2, dif); PROF_ADD(11, 1); }
+  PROF_ADD(3, pf_first16 < 0 ? dif : pf_first16);
+  if (pf_first32 < 0) { PROF_ADD(4, dif); PROF_ADD(12, 1); }
+  PROF_ADD(5, pf_first32 < 0 ? dif : pf_first32);
+#endif
   WS_STORE(ws)
   wave_mem_sync();
 }
@@ -975,10 +1004,22 @@ template <int REV>
 __device__ __forceinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
                                           int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
 { WaveState ws;
+#ifdef DAMAR_PROF
+  const unsigned long long t0 = wall_clock64();
+#endif
   wave_reg<REV>(c, diag, mida, ws);
+#ifdef DAMAR_PROF
+  const unsigned long long t1 = wall_clock64();
+#endif
   if (!uni(ws.stopped))
     wave_mem<REV>(c, mida, ws);
+#ifdef DAMAR_PROF
+  const unsigned long long t2 = wall_clock64();
+#endif
   wave_finish<REV>(c, mida, ws, ox, oy, od, atlen_io, btlen_io, aback, bback);
+#ifdef DAMAR_PROF
+  PROF_ADD(15, t1 - t0);  PROF_ADD(13, t2 - t1);  PROF_ADD(14, wall_clock64() - t2);
+#endif
 }
 
 struct LaResult
@@ -1135,6 +1176,10 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
   u32 seq = 0;
   int amark2 = 0;
   int clo = BIG, chi = -BIG;          /* range of lasta buckets written for this pair */
+#ifdef DAMAR_PROF
+  int pf_nla = 0;
+  const unsigned long long pf_p0 = wall_clock64();
+#endif
 
   while (nidx < a.nhits && (keys[nidx] >> a.pbits) == cpair)      /* A-panels, filter.c:2251 */
     { const int amark = amark2 + PANEL_SIZE;
@@ -1162,6 +1207,11 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
             { end = base; break; }
         }
       nidx = end;
+#ifdef DAMAR_PROF
+      PROF_ADD(17, end - lidx);  PROF_ADD(18, 1);
+      const unsigned long long pf_s1 = wall_clock64();
+      PROF_ADD(19, pf_s1 - pf_p0);       /* note: cumulative from pair start (first panel only meaningful) */
+#endif
 
       if (end - lidx >= (u64) minhit)
         { /* pass 1: bucket scores (filter.c:2268-2277) */
@@ -1195,6 +1245,10 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
               wave_mem_sync();
             }
 
+#ifdef DAMAR_PROF
+          const unsigned long long pf_s2 = wall_clock64();
+          PROF_ADD(20, pf_s2 - pf_s1);
+#endif
           /* pass 2: seeds in order (filter.c:2283-2405) */
           for (u64 base = lidx; base < end; base += 64)
             { u64  f = base + lane;
@@ -1220,7 +1274,15 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
                   int lo, hi;
 
                   if (lane == 0) atomicAdd(&a.counters[4], 1u);
+#ifdef DAMAR_PROF
+                  const unsigned long long pf_t0 = wall_clock64();
+#endif
                   local_alignment(c, (u32) a.comp, sdg, sap + sbp, &r);
+#ifdef DAMAR_PROF
+                  PROF_ADD(pf_nla ? 7 : 6, wall_clock64() - pf_t0);
+                  PROF_ADD(pf_nla ? 10 : 9, 1);
+                  pf_nla++;
+#endif
                   diagonal_span(s, r, a.tspace, W, &lo, &hi);
                   if (sd < lo) lo = sd; else if (sd > hi) hi = sd;
                   if (lo < mind - 1) lo = mind - 1;
@@ -1236,6 +1298,10 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
                 }
             }
 
+#ifdef DAMAR_PROF
+          const unsigned long long pf_s3 = wall_clock64();
+          PROF_ADD(21, pf_s3 - pf_s2);
+#endif
           /* pass 3: reset the touched buckets (filter.c:2407-2411) */
           for (u64 base = lidx; base < end; base += 64)
             { u64 f = base + lane;
@@ -1246,6 +1312,9 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
                 }
             }
           wave_mem_sync();
+#ifdef DAMAR_PROF
+          PROF_ADD(22, wall_clock64() - pf_s3);
+#endif
         }
       nidx = h2;
     }
@@ -1255,6 +1324,10 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
     for (int q = clo + lane; q <= chi; q += 64)
       s.lasta[q] = 0;
   wave_mem_sync();
+#ifdef DAMAR_PROF
+  PROF_ADD(8, wall_clock64() - pf_p0);
+  PROF_ADD(16, 1);
+#endif
 }
 
 /* datander: scrub/tandem.c:895-1175 report_thread for one read.  code[apos] (apos = index of

@@ -142,9 +142,10 @@ void damar_launch_merge_emit(const MergeArgs *m, const u32 *off, const u32 *jb, 
  * not start within the last minhit hits of its thread slice (filter.c:2212-2214:
  * nidx < end - minhit).  Slices end where the reference's NTHREADS partition ends:
  * first index >= (nhits*t)>>nshift whose bread differs from its predecessor's. */
+#define SCREEN_MAX 48
 __global__ __launch_bounds__(256)
-void pair_flags(const u64 *__restrict__ keys, u64 nhits, int pbits, int bshift, int minhit, int nshift,
-                u32 *__restrict__ flags)
+void pair_flags(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits, int bshift,
+                int minhit, int nshift, int binshift, u32 *__restrict__ flags)
 { __shared__ u64 send[65];
   int nthr = 1 << nshift;
   if ((int) threadIdx.x < nthr)
@@ -181,18 +182,42 @@ void pair_flags(const u64 *__restrict__ keys, u64 nhits, int pbits, int bshift, 
               break;
             }
         }
+      /* Screen: a seed can only fire if its bucket and a neighbour score >= hitmin together
+         (filter.c:2297), every seed adds at most kmer to its bucket, so some two adjacent
+         buckets must hold >= minhit seeds of this pair.  Short runs (the vast majority: chance
+         k-mer matches between unrelated reads) are checked here; the report kernel never sees
+         the ones that cannot fire, and would not have emitted anything for them. */
+      if (f)
+        { int n = minhit;
+          while (n <= SCREEN_MAX && i + (u64) n < nhits && (keys[i + (u64) n] >> pbits) == pr)
+            n += 1;
+          if (n <= SCREEN_MAX)
+            { bool ok = false;
+              for (int x = 0; x < n && !ok; x++)
+                { const int dx = ((int) vals[i + (u64) x]) >> binshift;
+                  int cnt = 0;
+                  for (int y = 0; y < n; y++)
+                    { const int dy = ((int) vals[i + (u64) y]) >> binshift;
+                      cnt += (dy == dx || dy == dx + 1) ? 1 : 0;
+                    }
+                  ok = cnt >= minhit;
+                }
+              if (!ok)
+                f = 0;
+            }
+        }
     }
   flags[i] = f;
 }
 
-void damar_launch_pair_flags(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
-                              u32 *flags, hipStream_t st)
+void damar_launch_pair_flags(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, int minhit,
+                              int nshift, int binshift, u32 *flags, hipStream_t st)
 { if (nhits == 0)
     return;
   if (nshift > 6)
     nshift = 6;
-  hipLaunchKernelGGL(pair_flags, dim3((u32) ((nhits + 255) / 256)), dim3(256), 0, st, keys, nhits, pbits,
-                     abits + pbits, minhit, nshift, flags);
+  hipLaunchKernelGGL(pair_flags, dim3((u32) ((nhits + 255) / 256)), dim3(256), 0, st, keys, vals, nhits, pbits,
+                     abits + pbits, minhit, nshift, binshift, flags);
 }
 
 __global__ __launch_bounds__(256)

@@ -796,7 +796,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   /* ---- work list ---- */
   const int minhit = (P_hitmin - 1) / P_kmer + 1;
   u64 nwork64 = 0;
-  damar_launch_pair_flags(keys, total, m.pbits, m.abits, minhit, P_nshift, flags, G_st);
+  damar_launch_pair_flags(keys, vals, total, m.pbits, m.abits, minhit, P_nshift, P_binshift, flags, G_st);
   stage("pair_flags");
   damar_exclusive_scan_u32(flags, foff, total, scw2, tot, G_st);
   u32 *work = side ? (u32 *) k0 : (u32 *) k1;          /* the idle key buffer holds the list */
