@@ -52,7 +52,11 @@ void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32
 void damar_launch_merge_emit(const MergeArgs *m, const u32 *off, const u32 *jb, u64 nhits,
                              u64 *keys, u32 *vals, hipStream_t st);
 void damar_launch_pair_flags(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, int minhit,
-                             int nshift, int binshift, u32 *flags, hipStream_t st);
+                             int nshift, int binshift, int kmer, int hitmin, u32 *flags, hipStream_t st);
+#define WORK_COST_BITS 16
+#define WORK_COST_MAX  ((1u << WORK_COST_BITS) - 1)
+void damar_launch_work_cost(const u64 *keys, u64 nhits, int pbits, const u32 *work, u32 nwork, u32 coarse,
+                            u32 *key, u32 *val, hipStream_t st);
 void damar_launch_compact_index(const u32 *flags, const u32 *off, u64 n, u32 *out, hipStream_t st);
 
 /* report.hip */
@@ -84,6 +88,7 @@ typedef struct
   /* outputs */
   LaRecord *recs;  u32 rec_cap;
   u16  *tpool;     u32 tpool_cap;
+  const u32 *order; /* processing order of the work items (largest first), or NULL          */
   u32  *counters;  /* [0] next work item, [1] records, [2] trace words, [3] error flags,
                       [4] seed hits (nfilt) */
 } ReportArgs;

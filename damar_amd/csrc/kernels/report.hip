@@ -1478,6 +1478,11 @@ __global__ __launch_bounds__(64, 4)
 void report_kernel(ReportArgs a)
 { const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);
+#ifdef DAMAR_PROF
+  const unsigned long long pf_k0 = wall_clock64();
+  struct PfExit { unsigned long long t0; __device__ ~PfExit() { unsigned long long d = wall_clock64() - t0;
+    if (lane_id() == 0) { atomicAdd(&g_prof[23], d); atomicAdd(&g_prof[25], 1ull); atomicMax(&g_prof[24], d); } } } pf_exit = { pf_k0 };
+#endif
   for (;;)
     { u32 item = 0;
       if (lane_id() == 0)
@@ -1485,6 +1490,8 @@ void report_kernel(ReportArgs a)
       item = (u32) uni((int) item);
       if (item >= a.nwork)
         break;
+      if (a.order)
+        item = (u32) uni((int) a.order[item]);
       process_pair(a, s, item);
     }
 }

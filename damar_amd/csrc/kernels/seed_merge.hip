@@ -142,10 +142,11 @@ void damar_launch_merge_emit(const MergeArgs *m, const u32 *off, const u32 *jb, 
  * not start within the last minhit hits of its thread slice (filter.c:2212-2214:
  * nidx < end - minhit).  Slices end where the reference's NTHREADS partition ends:
  * first index >= (nhits*t)>>nshift whose bread differs from its predecessor's. */
-#define SCREEN_MAX 48
+#define SCREEN_MAX   48
+#define SCREEN_PANEL 50000                     /* PANEL_SIZE, filter.c:73 */
 __global__ __launch_bounds__(256)
 void pair_flags(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits, int bshift,
-                int minhit, int nshift, int binshift, u32 *__restrict__ flags)
+                int minhit, int nshift, int binshift, int kmer, int hitmin, u32 *__restrict__ flags)
 { __shared__ u64 send[65];
   int nthr = 1 << nshift;
   if ((int) threadIdx.x < nthr)
@@ -170,7 +171,7 @@ void pair_flags(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 
   u64 i = (u64) blockIdx.x * 256u + threadIdx.x;
   if (i >= nhits)
     return;
-  u64 pr = keys[i] >> pbits;
+  const u64 pr = keys[i] >> pbits, pmask = (1ull << pbits) - 1;
   u32 f = 0;
   if ((i == 0 || (keys[i - 1] >> pbits) != pr) && i + (u64) (minhit - 1) < nhits &&
       (keys[i + (u64) (minhit - 1)] >> pbits) == pr)
@@ -182,25 +183,30 @@ void pair_flags(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 
               break;
             }
         }
-      /* Screen: a seed can only fire if its bucket and a neighbour score >= hitmin together
-         (filter.c:2297), every seed adds at most kmer to its bucket, so some two adjacent
-         buckets must hold >= minhit seeds of this pair.  Short runs (the vast majority: chance
-         k-mer matches between unrelated reads) are checked here; the report kernel never sees
-         the ones that cannot fire, and would not have emitted anything for them. */
+      /* Screen (the vast majority of runs are a few chance k-mer matches between unrelated
+         reads).  A run that fits one A-panel (filter.c:2251: all apos <= PANEL_SIZE) gets its
+         bucket scores computed here exactly as pass 1 of the report loop does (filter.c:2268-2277:
+         a seed adds min(kmer, apos - previous apos in its bucket)); a seed fires only if its
+         bucket plus a neighbour reach hitmin (filter.c:2297).  Runs that cannot fire are dropped
+         from the work list: the report kernel would not have emitted anything for them. */
       if (f)
         { int n = minhit;
           while (n <= SCREEN_MAX && i + (u64) n < nhits && (keys[i + (u64) n] >> pbits) == pr)
             n += 1;
-          if (n <= SCREEN_MAX)
+          if (n <= SCREEN_MAX && (int) (keys[i + (u64) (n - 1)] & pmask) <= SCREEN_PANEL)
             { bool ok = false;
               for (int x = 0; x < n && !ok; x++)
                 { const int dx = ((int) vals[i + (u64) x]) >> binshift;
-                  int cnt = 0;
+                  int s0 = 0, s1 = 0, p0 = 0, p1 = 0;
                   for (int y = 0; y < n; y++)
                     { const int dy = ((int) vals[i + (u64) y]) >> binshift;
-                      cnt += (dy == dx || dy == dx + 1) ? 1 : 0;
+                      const int ap = (int) (keys[i + (u64) y] & pmask);
+                      if (dy == dx)
+                        { s0 += (ap - p0 >= kmer) ? kmer : ap - p0;  p0 = ap; }
+                      else if (dy == dx + 1)
+                        { s1 += (ap - p1 >= kmer) ? kmer : ap - p1;  p1 = ap; }
                     }
-                  ok = cnt >= minhit;
+                  ok = s0 + s1 >= hitmin;
                 }
               if (!ok)
                 f = 0;
@@ -211,13 +217,13 @@ void pair_flags(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 
 }
 
 void damar_launch_pair_flags(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, int minhit,
-                              int nshift, int binshift, u32 *flags, hipStream_t st)
+                              int nshift, int binshift, int kmer, int hitmin, u32 *flags, hipStream_t st)
 { if (nhits == 0)
     return;
   if (nshift > 6)
     nshift = 6;
   hipLaunchKernelGGL(pair_flags, dim3((u32) ((nhits + 255) / 256)), dim3(256), 0, st, keys, vals, nhits, pbits,
-                     abits + pbits, minhit, nshift, binshift, flags);
+                     abits + pbits, minhit, nshift, binshift, kmer, hitmin, flags);
 }
 
 __global__ __launch_bounds__(256)
@@ -231,4 +237,34 @@ void damar_launch_compact_index(const u32 *flags, const u32 *off, u64 n, u32 *ou
 { if (n == 0)
     return;
   hipLaunchKernelGGL(compact_index, dim3((u32) ((n + 255) / 256)), dim3(256), 0, st, flags, off, n, out);
+}
+
+/* Largest-first processing order for the report kernel: one alignment is a long serial chain of
+ * wave steps, so a long read pair started late would leave the rest of the chip idle at the end
+ * of the launch.  The number of seeds of a pair is a good stand-in for the length of its
+ * alignment; key[j] sorts ascending into "most seeds first". */
+__global__ __launch_bounds__(256)
+void work_cost(const u64 *__restrict__ keys, u64 nhits, int pbits, const u32 *__restrict__ work, u32 nwork,
+               u32 coarse, u32 *__restrict__ key, u32 *__restrict__ val)
+{ u32 j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= nwork)
+    return;
+  const u64 i = work[j], pr = keys[i] >> pbits;
+  u64 a = i + 1, b = (j + 1 < nwork) ? (u64) work[j + 1] : nhits;       /* run ends at or before the next head */
+  while (a < b)
+    { u64 mid = (a + b) >> 1;
+      if ((keys[mid] >> pbits) == pr) a = mid + 1; else b = mid;
+    }
+  u64 n = a - i;
+  if (n > WORK_COST_MAX)
+    n = WORK_COST_MAX;
+  key[j] = coarse ? (n >= coarse ? 0u : 1u) : (u32) (WORK_COST_MAX - n);
+  val[j] = j;
+}
+
+void damar_launch_work_cost(const u64 *keys, u64 nhits, int pbits, const u32 *work, u32 nwork, u32 coarse,
+                            u32 *key, u32 *val, hipStream_t st)
+{ if (nwork == 0)
+    return;
+  hipLaunchKernelGGL(work_cost, dim3((nwork + 255) / 256), dim3(256), 0, st, keys, nhits, pbits, work, nwork, coarse, key, val);
 }

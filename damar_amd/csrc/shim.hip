@@ -76,6 +76,7 @@ static int64        G_cnt[8];
 struct Arena { char *base; size_t cap, top; };
 static Arena G_work = { NULL, 0, 0 };       /* per-call temporaries, grow-only */
 static Arena G_hits = { NULL, 0, 0 };       /* seed pairs of the current Match_Filter   */
+static Arena G_ord  = { NULL, 0, 0 };       /* processing order of the work list        */
 
 static void *dmalloc(size_t n)
 { void *p = NULL;
@@ -796,7 +797,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   /* ---- work list ---- */
   const int minhit = (P_hitmin - 1) / P_kmer + 1;
   u64 nwork64 = 0;
-  damar_launch_pair_flags(keys, vals, total, m.pbits, m.abits, minhit, P_nshift, P_binshift, flags, G_st);
+  damar_launch_pair_flags(keys, vals, total, m.pbits, m.abits, minhit, P_nshift, P_binshift, P_kmer, P_hitmin, flags, G_st);
   stage("pair_flags");
   damar_exclusive_scan_u32(flags, foff, total, scw2, tot, G_st);
   u32 *work = side ? (u32 *) k0 : (u32 *) k1;          /* the idle key buffer holds the list */
@@ -818,6 +819,26 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
       G_seed_pbits = m.pbits;  G_seed_abits = m.abits;
     }
 
+  /* ---- largest pairs first (the order only schedules the kernel: records carry their work
+          item's rank in the reference's order) ---- */
+  const u32 *order = NULL;
+  static int order_mode = -1;
+  if (order_mode < 0)
+    { const char *e = getenv("DAMAR_ORDER");
+      order_mode = e ? atoi(e) : 0;
+    }
+  if (nwork > 1 && order_mode > 0)
+    { arena_reserve(&G_ord, 4 * pad256(sizeof(u32) * (size_t) nwork) + pad256(damar_sort_workspace_bytes(nwork)) + 4096);
+      u32 *ok0 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
+      u32 *ov0 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
+      u32 *ok1 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
+      u32 *ov1 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
+      void *osw = arena_take(&G_ord, damar_sort_workspace_bytes(nwork));
+      damar_launch_work_cost(keys, total, m.pbits, work, nwork, order_mode > 1 ? (u32) order_mode : 0u, ok0, ov0, G_st);
+      order = damar_radix_sort_u32(ok0, ov0, ok1, ov1, nwork, WORK_COST_BITS, osw, G_st) ? ov1 : ov0;
+      stage("work_order");
+    }
+
   /* ---- report kernel (retry with larger buffers if it reports an overflow) ---- */
   std::vector<LaRecord> recs;
   std::vector<u16>      tpool;
@@ -834,6 +855,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
           ra.keys = keys;  ra.vals = vals;  ra.nhits = total;
           ra.work = work;  ra.nwork = nwork;
           ra.pbits = m.pbits;  ra.abits = m.abits;
+          ra.order = order;
           HIP_CHECK(hipMemsetAsync(RS.counters, 0, 64, G_st));
           tick(4);
           stage("report_setup");

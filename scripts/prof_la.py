@@ -14,6 +14,7 @@ L.damar_prof_read(out, 0)
 names = ["passes", "steps", "steps_in_passes_fit16", "steps_before_over16", "steps_in_passes_fit32",
          "steps_before_over32", "clk_firstLA", "clk_laterLA", "clk_pair", "n_firstLA", "n_laterLA",
          "passes_fit16", "passes_fit32", "clk_wave_mem", "clk_finish", "clk_wave_reg",
-         "pairs", "seeds_scanned", "panels", "clk_to_scan_end", "clk_pass1", "clk_pass2_incl_LA", "clk_pass3"]
+         "pairs", "seeds_scanned", "panels", "clk_to_scan_end", "clk_pass1", "clk_pass2_incl_LA", "clk_pass3",
+         "clk_waves_busy_sum", "clk_wave_max(last launch max)", "waves"]
 for n, v in zip(names, out):
     print("%-24s %d" % (n, v))
