@@ -180,7 +180,7 @@ def main():
         if rank == 0:
             steps = max(1, args.steps)
             launches = {"report": 2 * npairs * steps, "ssort": 2 * npairs * steps,
-                        "ksort": (nblocks + 2 * npairs - nblocks) * steps}
+                        "ksort": plan.index_builds * steps}
             # dominant kernel by HIP-event time over the timed region
             kern = {"report_kernel (band filter + Local_Alignment waves)": tim.get("report", 0.),
                     "radix sort of seed pairs (hist+scan+scatter, u64 keys)": tim.get("ssort", 0.),
@@ -196,7 +196,7 @@ def main():
                 alg = 16. * H * 2 * 6                # 16-byte records, read+write, P_s = 6 passes
                 nl = 2 * npairs
             elif dom.startswith("radix sort of the k-mer"):
-                nbuild = sum(1 + 2 * len(bs) - 1 for _, bs in plan_lines)
+                nbuild = plan.index_builds
                 kmers = totbp - 14 * nreads
                 alg = (16. * 2 * 4) * kmers / nblocks * nbuild   # per build: 16 B x (rd+wr) x 4 passes per k-mer
                 nl = nbuild

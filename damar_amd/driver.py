@@ -74,6 +74,8 @@ class Plan:
         self.counts = [0, 0, 0]
         self.async_tail = async_tail
         self._specs = []
+        self._idx = {}           # (block name, comp) -> k-mer index resident in HBM for this job
+        self.index_builds = 0
         L.damar_set_async(1 if async_tail else 0)
 
     def finish(self):
@@ -88,19 +90,31 @@ class Plan:
         for sp in self._specs:
             L.Free_Align_Spec(sp)
         self._specs = []
+        for idx in self._idx.values():
+            L.damar_index_free(idx)
+        self._idx = {}
 
     def _acc(self):
         for n, v in api.timings().items():
             self.timings[n] = self.timings.get(n, 0.) + v
 
-    def _build(self, devblock):
-        L = api.lib()
-        n = C.c_int(0)
-        idx = L.damar_index_build(devblock, 0, C.byref(n))
-        t = api.timings()
-        for nme in ("tuples", "ksort", "table"):
-            self.timings[nme] = self.timings.get(nme, 0.) + t[nme]
-        return idx, n.value
+    def _index(self, block, comp):
+        """Sort_Kmers of a block (or of its complement), once per job: the reference rebuilds an
+        index for every command line that names the block (daligner.c:1000, 1025-1047) because
+        each line is its own process; here the sorted index (8 B per k-mer) simply stays in HBM
+        until finish()."""
+        key = (block.name, comp)
+        idx = self._idx.get(key)
+        if idx is None:
+            L = api.lib()
+            n = C.c_int(0)
+            idx = L.damar_index_build(block.upload_complement() if comp else block.upload(), 0, C.byref(n))
+            t = api.timings()
+            for nme in ("tuples", "ksort", "table"):
+                self.timings[nme] = self.timings.get(nme, 0.) + t[nme]
+            self._idx[key] = idx
+            self.index_builds += 1
+        return idx
 
     def _match(self, adb, bdb, aidx, bidx, self_, comp, spec):
         L = api.lib()
@@ -124,27 +138,21 @@ class Plan:
         with _cwd(outdir):
             os.makedirs(api.get_dir(self.run, a.db.part), exist_ok=True)
             spec = L.New_Align_Spec(self.e, self.s, a.db.freq, self.j, self.symmetric, 0, 0, 1)
-            aidx, alen = self._build(a.upload())
+            aidx = self._index(a, 0)
             for b in bs:
                 if b is a or b.name == a.name:
                     self._match(a.db, a.db, aidx, aidx, 1, 0, spec)
-                    cdev = a.upload_complement()
-                    cidx, clen = self._build(cdev)
+                    cidx = self._index(a, 1)
                     self._match(a.db, a.cdb, aidx, cidx, 1, 1, spec)
-                    L.damar_index_free(cidx)
                     L.damar_write_overlaps(spec, odir(a.db.part), None, a.root.encode(), a.root.encode(), a.last_read())
                 else:
                     if self.symmetric:
                         os.makedirs(api.get_dir(self.run, b.db.part), exist_ok=True)
-                    bidx, blen = self._build(b.upload())
-                    self._match(a.db, b.db, aidx, bidx, 0, 0, spec)
-                    L.damar_index_free(bidx)
-                    cidx, clen = self._build(b.upload_complement())
+                    self._match(a.db, b.db, aidx, self._index(b, 0), 0, 0, spec)
+                    cidx = self._index(b, 1)
                     self._match(a.db, b.cdb, aidx, cidx, 0, 1, spec)
-                    L.damar_index_free(cidx)
                     last = b.last_read() if b.db.part < a.db.part else a.last_read()
                     L.damar_write_overlaps(spec, odir(a.db.part), odir(b.db.part), a.root.encode(), b.root.encode(), last)
-            L.damar_index_free(aidx)
             self._specs.append(spec)
             if not self.async_tail or a.db.part <= 0 or any(b.db.part <= 0 for b in bs):
                 self.finish()            # unsplit DBs write relative paths: finish inside this cwd
