@@ -98,6 +98,7 @@ typedef struct
 #define DAMAR_ERR_TPOOL   4u
 #define DAMAR_ERR_BAND    8u
 
+int  damar_report_waves_per_simd(void);
 void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st);
 /* datander report: one work item per read of a.ablk, dist as produced by damar_launch_tandem_links */
 void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots, hipStream_t st);

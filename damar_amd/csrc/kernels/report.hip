@@ -34,6 +34,13 @@
 #define PANEL_SIZE     50000                  /* filter.c:73 */
 #define PANEL_OVERLAP  10000                  /* filter.c:74 */
 #define BIG  0x7fffffff
+#ifndef REPORT_WAVES_PER_SIMD
+#define REPORT_WAVES_PER_SIMD 8               /* VGPR budget = 512 / this; the shim sizes the grid to match */
+#endif
+/* The register path of the wave (wave_reg) needs 56 VGPRs; the rare stages (bands wider than
+   the wavefront, the seed scan) spill a little under the 64-register budget, which buys twice
+   the resident alignments per CU: the kernel is bound by the latency of its serial chains. */
+int damar_report_waves_per_simd(void) { return REPORT_WAVES_PER_SIMD; }
 
 #ifdef DAMAR_PROF
 __device__ unsigned long long g_prof[32];
@@ -78,6 +85,15 @@ u64 damar_report_state_stride(int span)
 { return (u64) 2 * (u64) span * sizeof(DState); }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+/* the same for a pointer: arguments of a (noinline) device function arrive in VGPRs and count
+   as lane-varying until they are pinned, and so does everything loaded through them */
+template <typename T>
+__device__ __forceinline__ T *uni_ptr(T *p)
+{ const u64 v = (u64) (uintptr_t) p;
+  const u32 lo = (u32) __builtin_amdgcn_readfirstlane((int) (u32) v);
+  const u32 hi = (u32) __builtin_amdgcn_readfirstlane((int) (u32) (v >> 32));
+  return (T *) (uintptr_t) (((u64) hi << 32) | lo);
+}
 
 /* Every data-dependent loop carries a bound (generous multiples of the read lengths): a
  * loop that exceeds it records where (err[3] = code) and raises DAMAR_ERR_BAND instead of
@@ -95,8 +111,8 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
  * both sides, so the extra bytes are always mapped). */
 /* value of the next-higher / next-lower lane, cyclic over the 64 lanes: one DPP move each
  * (wave_rol:1 / wave_ror:1), no LDS round trip */
-__device__ __forceinline__ int lane_up(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, false); }
-__device__ __forceinline__ int lane_dn(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x13c, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_up(int v) { return __builtin_amdgcn_mov_dpp(v, 0x134, 0xf, 0xf, true); }
+__device__ __forceinline__ int lane_dn(int v) { return __builtin_amdgcn_mov_dpp(v, 0x13c, 0xf, 0xf, true); }
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -191,21 +207,21 @@ template <int REV>
 __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, WaveState &ws)
 {
   const int lane = lane_id();
-  const int TS = c.ts;
+  const int TS = uni(c.ts);
   const int S = REV ? -1 : 1;
-  const u8 *aseq = REV ? c.aseq - 1 : c.aseq;
-  const u8 *bseq = REV ? c.bseq - 1 : c.bseq;
-  DState *cur = c.st0, *nxt = c.st1;
-  const int o = c.koff;
-  const int minp = c.minp, maxp = c.maxp, aoff = c.aoff, boff = c.boff;
-  const int ave = c.ave, do_reach = c.reach;
-  const u32 cell_cap = c.cell_cap;
-  const short *score_tab = c.score, *trim_tab = c.table;
-  Cell *const cellbuf = c.cells;
-  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) c.cells;          /* one 16-byte store per pebble */
-  u32 *const errw = c.err;
-  const int steplimit = c.alen + c.blen + 64;
-  const int guard = 4 * (c.alen + c.blen) + 1024;
+  const u8 *aseq = uni_ptr(REV ? c.aseq - 1 : c.aseq);
+  const u8 *bseq = uni_ptr(REV ? c.bseq - 1 : c.bseq);
+  DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
+  const int o = uni(c.koff);
+  const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
+  const int ave = uni(c.ave), do_reach = uni(c.reach);
+  const u32 cell_cap = (u32) uni((int) c.cell_cap);
+  const short *score_tab = uni_ptr(c.score), *trim_tab = uni_ptr(c.table);
+  Cell *const cellbuf = uni_ptr(c.cells);
+  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) cellbuf;          /* one 16-byte store per pebble */
+  u32 *const errw = uni_ptr(c.err);
+  const int steplimit = uni(c.alen + c.blen + 64);
+  const int guard = uni(4 * (c.alen + c.blen) + 1024);
   (void) lane; (void) TS; (void) S; (void) aseq; (void) bseq; (void) cur; (void) nxt; (void) o;
   (void) minp; (void) maxp; (void) aoff; (void) boff; (void) ave; (void) do_reach; (void) cell_cap;
   (void) score_tab; (void) trim_tab; (void) cellbuf; (void) gcell; (void) errw; (void) steplimit; (void) guard;
@@ -556,21 +572,21 @@ template <int REV>
 __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
 {
   const int lane = lane_id();
-  const int TS = c.ts;
+  const int TS = uni(c.ts);
   const int S = REV ? -1 : 1;
-  const u8 *aseq = REV ? c.aseq - 1 : c.aseq;
-  const u8 *bseq = REV ? c.bseq - 1 : c.bseq;
-  DState *cur = c.st0, *nxt = c.st1;
-  const int o = c.koff;
-  const int minp = c.minp, maxp = c.maxp, aoff = c.aoff, boff = c.boff;
-  const int ave = c.ave, do_reach = c.reach;
-  const u32 cell_cap = c.cell_cap;
-  const short *score_tab = c.score, *trim_tab = c.table;
-  Cell *const cellbuf = c.cells;
-  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) c.cells;          /* one 16-byte store per pebble */
-  u32 *const errw = c.err;
-  const int steplimit = c.alen + c.blen + 64;
-  const int guard = 4 * (c.alen + c.blen) + 1024;
+  const u8 *aseq = uni_ptr(REV ? c.aseq - 1 : c.aseq);
+  const u8 *bseq = uni_ptr(REV ? c.bseq - 1 : c.bseq);
+  DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
+  const int o = uni(c.koff);
+  const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
+  const int ave = uni(c.ave), do_reach = uni(c.reach);
+  const u32 cell_cap = (u32) uni((int) c.cell_cap);
+  const short *score_tab = uni_ptr(c.score), *trim_tab = uni_ptr(c.table);
+  Cell *const cellbuf = uni_ptr(c.cells);
+  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) cellbuf;          /* one 16-byte store per pebble */
+  u32 *const errw = uni_ptr(c.err);
+  const int steplimit = uni(c.alen + c.blen + 64);
+  const int guard = uni(4 * (c.alen + c.blen) + 1024);
   (void) lane; (void) TS; (void) S; (void) aseq; (void) bseq; (void) cur; (void) nxt; (void) o;
   (void) minp; (void) maxp; (void) aoff; (void) boff; (void) ave; (void) do_reach; (void) cell_cap;
   (void) score_tab; (void) trim_tab; (void) cellbuf; (void) gcell; (void) errw; (void) steplimit; (void) guard;
@@ -824,21 +840,21 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
                                          int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
 {
   const int lane = lane_id();
-  const int TS = c.ts;
+  const int TS = uni(c.ts);
   const int S = REV ? -1 : 1;
-  const u8 *aseq = REV ? c.aseq - 1 : c.aseq;
-  const u8 *bseq = REV ? c.bseq - 1 : c.bseq;
-  DState *cur = c.st0, *nxt = c.st1;
-  const int o = c.koff;
-  const int minp = c.minp, maxp = c.maxp, aoff = c.aoff, boff = c.boff;
-  const int ave = c.ave, do_reach = c.reach;
-  const u32 cell_cap = c.cell_cap;
-  const short *score_tab = c.score, *trim_tab = c.table;
-  Cell *const cellbuf = c.cells;
-  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) c.cells;          /* one 16-byte store per pebble */
-  u32 *const errw = c.err;
-  const int steplimit = c.alen + c.blen + 64;
-  const int guard = 4 * (c.alen + c.blen) + 1024;
+  const u8 *aseq = uni_ptr(REV ? c.aseq - 1 : c.aseq);
+  const u8 *bseq = uni_ptr(REV ? c.bseq - 1 : c.bseq);
+  DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
+  const int o = uni(c.koff);
+  const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
+  const int ave = uni(c.ave), do_reach = uni(c.reach);
+  const u32 cell_cap = (u32) uni((int) c.cell_cap);
+  const short *score_tab = uni_ptr(c.score), *trim_tab = uni_ptr(c.table);
+  Cell *const cellbuf = uni_ptr(c.cells);
+  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) cellbuf;          /* one 16-byte store per pebble */
+  u32 *const errw = uni_ptr(c.err);
+  const int steplimit = uni(c.alen + c.blen + 64);
+  const int guard = uni(4 * (c.alen + c.blen) + 1024);
   (void) lane; (void) TS; (void) S; (void) aseq; (void) bseq; (void) cur; (void) nxt; (void) o;
   (void) minp; (void) maxp; (void) aoff; (void) boff; (void) ave; (void) do_reach; (void) cell_cap;
   (void) score_tab; (void) trim_tab; (void) cellbuf; (void) gcell; (void) errw; (void) steplimit; (void) guard;
@@ -1453,7 +1469,7 @@ __device__ void process_read(const ReportArgs &a, const SlotScratch &s, const in
   wave_mem_sync();
 }
 
-__global__ __launch_bounds__(64, 4)
+__global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
 void tandem_kernel(ReportArgs a, const int *dist)
 { const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);
@@ -1474,7 +1490,7 @@ void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots
   hipLaunchKernelGGL(tandem_kernel, dim3(nslots), dim3(64), 0, st, *a, dist);
 }
 
-__global__ __launch_bounds__(64, 4)
+__global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
 void report_kernel(ReportArgs a)
 { const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);
@@ -1503,7 +1519,7 @@ void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st)
 }
 
 /* batch Local_Alignment (tests): one wave per task, result always emitted */
-__global__ __launch_bounds__(64, 4)
+__global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
 void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
 { const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);

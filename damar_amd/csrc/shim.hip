@@ -396,7 +396,7 @@ static int default_slots(void)
 { const char *e = getenv("DAMAR_SLOTS");
   if (e && atoi(e) > 0)
     return atoi(e);
-  return G_prop.multiProcessorCount * 16;      /* 4 waves per SIMD: report_kernel is built for <= 128 VGPRs */
+  return G_prop.multiProcessorCount * 4 * damar_report_waves_per_simd();      /* every wave slot of the chip */
 }
 
 static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 cell_cap)
