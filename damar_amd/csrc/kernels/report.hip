@@ -486,10 +486,19 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
             }
         }
 
-        /* new best / trim point in sweep order (align.c:911-928 / 1620-1637) */
-        { u64 cand = __ballot(act && (REV ? (v < besta) : (v > besta)));
+        /* new best / trim point in sweep order (align.c:911-928 / 1620-1637).  Every lane that
+           could become the new best looks its own history up in TABLE/SCORE first (one round
+           trip for the whole band), so the serial sweep below touches no memory. */
+        { const bool mine = act && (REV ? (v < besta) : (v > besta));
+          u64 cand = __ballot(mine);
           if (cand)
-            { cand = ROTR(cand, low);
+            { int tok = 0;
+              if (mine && m >= ave)
+                { const int t0 = trim_tab[b & TRIM_MASK], t1 = trim_tab[(b >> TRIM_BITS) & TRIM_MASK];
+                  const int s0 = score_tab[b & TRIM_MASK];
+                  tok = ((t0 >= 0) & (t1 + s0 >= 0)) ? 1 : 0;
+                }
+              cand = ROTR(cand, low);
               while (cand)
                 { int i = REV ? (__ffsll((long long) cand) - 1) : (63 - __clzll(cand));
                   cand &= ~(1ull << i);
@@ -499,10 +508,8 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
                     { besta = vl;
                       besty = bcast_i(y, l);
                       if (bcast_i(m, l) >= ave)
-                        { u64 bl = bcast_u64(b, l);
-                          lasta = vl;
-                          if (uni((int) trim_tab[bl & TRIM_MASK]) >= 0 &&
-                              uni((int) trim_tab[(bl >> TRIM_BITS) & TRIM_MASK]) + uni((int) score_tab[bl & TRIM_MASK]) >= 0)
+                        { lasta = vl;
+                          if (bcast_i(tok, l))
                             { trim.a = vl;  trim.y = besty;  trim.d = dif;
                               trim.ha = bcast_i(ha, l);  trim.hb = bcast_i(hb, l);
                             }
