@@ -14,6 +14,8 @@ int    damar_radix_sort_u64(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u64 n, int nbits
 /* A read block resident in HBM. */
 typedef struct
 { const u8  *bases;     /* byte per base 0..3, 4 = terminator; bases[-1] == 4 (reference layout) */
+  const u32 *pk;        /* the same positions at 2 bits per base (terminators read as 0): word w
+                           holds bases 16w .. 16w+15, base 16w in bits 0-1; PK_PAD words either side */
   const u32 *boff;      /* [nreads+1] offset of read i in bases                                   */
   const u32 *coarse;    /* [(total >> COARSE_SHIFT) + 2] read containing position q<<COARSE_SHIFT */
   u32        nreads;
@@ -22,6 +24,10 @@ typedef struct
 } DevBlock;
 
 #define COARSE_SHIFT 9
+#define PK_PAD 4
+
+/* pk[w] for w in [-PK_PAD, total/16 + PK_PAD] from bases (which carry 64 padding bytes either side) */
+void damar_launch_pack_bases(const u8 *bases, u32 total, u32 *pk, hipStream_t st);
 
 /* kmer_index.hip */
 void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, u32 *codes, u32 *pos, hipStream_t st);

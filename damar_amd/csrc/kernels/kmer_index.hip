@@ -156,3 +156,21 @@ void damar_launch_tandem_links(const DevBlock *blk, int kmer, const u32 *codes, 
     return;
   hipLaunchKernelGGL(tandem_links, dim3((n + 255) / 256), dim3(256), 0, st, *blk, kmer, codes, pos, n, dist);
 }
+
+/* 2-bit packed copy of a block's bases for the alignment wave (16 bases per dword) */
+__global__ __launch_bounds__(256)
+void pack_bases(const u8 *__restrict__ bases, long long nwords, u32 *__restrict__ pk)
+{ long long w = (long long) blockIdx.x * 256 + threadIdx.x - PK_PAD;
+  if (w >= nwords - PK_PAD)
+    return;
+  const u8 *s = bases + 16 * w;                     /* >= bases - 64: inside the padding */
+  u32 v = 0;
+  for (int j = 0; j < 16; j++)
+    v |= (u32) (s[j] & 3) << (2 * j);
+  pk[w] = v;
+}
+
+void damar_launch_pack_bases(const u8 *bases, u32 total, u32 *pk, hipStream_t st)
+{ long long nwords = (long long) (total >> 4) + 1 + 2 * PK_PAD;      /* words -PK_PAD .. total/16 + PK_PAD */
+  hipLaunchKernelGGL(pack_bases, dim3((u32) ((nwords + 255) / 256)), dim3(256), 0, st, bases, nwords, pk);
+}

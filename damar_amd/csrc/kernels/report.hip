@@ -68,6 +68,8 @@ struct Tip { int a, y, d, ha, hb; };
 
 struct WaveCtx
 { const u8 *aseq, *bseq;
+  const u32 *apk, *bpk;     /* the blocks' 2-bit packed bases and the reads' offsets in them */
+  u32   a0, b0;
   int   alen, blen;
   int   ts, ave, reach;
   const short *score, *table;
@@ -169,6 +171,56 @@ __device__ __forceinline__ SnakeOut snake(const u8 *a, const u8 *bq, int y, int 
   return o;
 }
 
+/* The same snake on the 2-bit packed copy of the block: 16 bases per step from two dword
+ * loads per sequence.  The packed form has no terminators, so the slide is bounded by the
+ * bases left in each read (na in A, nb in B); stopping on a bound is the terminator case of
+ * the reference, B first.  A lane that is already past an end (never seen in practice; the
+ * reference would then compare whatever follows in memory) takes the byte path above, which
+ * reads exactly what the reference reads. */
+__device__ __forceinline__ u32 load16(const u32 *pk, int p)           /* bases p .. p+15, base p in bits 0-1 */
+{ const GLOBAL_AS u32 *q = (const GLOBAL_AS u32 *) pk + (p >> 4);
+  const u32 lo = q[0], hi = q[1];
+  return __builtin_amdgcn_alignbit(hi, lo, (u32) (p & 15) * 2);
+}
+
+template <int REV>
+__device__ __forceinline__ SnakeOut snake_pk(const u32 *apk, const u32 *bpk, int ap, int bp, int na, int nb,
+                                             int y, int m, u64 b)
+{ /* fwd: ap/bp = positions of the next bases to compare; rev: of the first ones below */
+  for (;;)
+    { const u32 wa = REV ? load16(apk, ap - 15) : load16(apk, ap);
+      const u32 wb = REV ? load16(bpk, bp - 15) : load16(bpk, bp);
+      const u32 x = wa ^ wb;
+      int n;
+      if (!REV) n = x ? ((__ffs((int) x) - 1) >> 1) : 16;
+      else      n = x ? (__clz((int) x) >> 1) : 16;
+      const int lim = na < nb ? na : nb;
+      if (n > lim) n = lim;
+      if (n > 0)
+        { const u32 passed = (u32) (b >> (61 - n)) & ((1u << n) - 1);
+          m += n - __popc(passed);
+          b = (b << n) | ((1ull << n) - 1);
+          y  += REV ? -n : n;
+          ap += REV ? -n : n;
+          bp += REV ? -n : n;
+          na -= n;  nb -= n;
+        }
+      if (n < 16 || lim == 16)
+        break;
+    }
+  SnakeOut o;
+  o.y = y;  o.m = m;  o.b = b;
+  o.hit = (nb == 0) ? 2 : ((na == 0) ? 1 : 0);
+  return o;
+}
+
+/* the snake of diagonal k from B position y (both stages of the wave call this) */
+#define SNAKE_AT(k, y, m, b)                                                                    \
+  (((u32) ((y) + (k)) > (u32) alen || (u32) (y) > (u32) blen)                                   \
+     ? snake<REV>(aseq + (k), bseq, (y), (m), (b))                                              \
+     : (REV ? snake_pk<1>(apk, bpk, (int) a0 + (k) + (y) - 1, (int) b0 + (y) - 1, (y) + (k), (y), (y), (m), (b)) \
+            : snake_pk<0>(apk, bpk, (int) a0 + (k) + (y), (int) b0 + (y), alen - ((y) + (k)), blen - (y), (y), (m), (b))))
+
 /* One direction of the wave.  REV = 0: align.c:409-1122, REV = 1: align.c:1126-1898.
  * Returns through *res the end point of this direction; traces are written by lane 0. */
 /* The wave-uniform bookkeeping of one direction, handed between the three stages below.  The
@@ -211,6 +263,10 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
   const int S = REV ? -1 : 1;
   const u8 *aseq = uni_ptr(REV ? c.aseq - 1 : c.aseq);
   const u8 *bseq = uni_ptr(REV ? c.bseq - 1 : c.bseq);
+  const u32 *apk = uni_ptr(c.apk), *bpk = uni_ptr(c.bpk);
+  const u32 a0 = (u32) uni((int) c.a0), b0 = (u32) uni((int) c.b0);
+  const int alen = uni(c.alen), blen = uni(c.blen);
+  (void) apk; (void) bpk; (void) a0; (void) b0; (void) alen; (void) blen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
   const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
@@ -264,7 +320,7 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
     if (!REV) { na += TS; nb += TS; }
 
     int g0 = 0;
-    { const SnakeOut so = snake<REV>(a, bseq, y, 0, 0ull);
+    { const SnakeOut so = SNAKE_AT(k, y, 0, 0ull);
       y = uni(so.y);
       const int hit = uni(so.hit);
       if (hit & 2)      { more = 0; bclip = k; }
@@ -408,7 +464,7 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
               m -= 1;
             b <<= 1;
             y = (v - k) >> 1;
-            { const SnakeOut so = snake<REV>(aseq + k, bseq, y, m, b);
+            { const SnakeOut so = SNAKE_AT(k, y, m, b);
               y = so.y;  m = so.m;  b = so.b;
               ahit = so.hit == 1;  bhit = so.hit == 2;
             }
@@ -583,6 +639,10 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
   const int S = REV ? -1 : 1;
   const u8 *aseq = uni_ptr(REV ? c.aseq - 1 : c.aseq);
   const u8 *bseq = uni_ptr(REV ? c.bseq - 1 : c.bseq);
+  const u32 *apk = uni_ptr(c.apk), *bpk = uni_ptr(c.bpk);
+  const u32 a0 = (u32) uni((int) c.a0), b0 = (u32) uni((int) c.b0);
+  const int alen = uni(c.alen), blen = uni(c.blen);
+  (void) apk; (void) bpk; (void) a0; (void) b0; (void) alen; (void) blen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
   const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
@@ -694,7 +754,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
                 m -= 1;
               b <<= 1;
               y = (v - k) >> 1;
-              { const SnakeOut so = snake<REV>(aseq + k, bseq, y, m, b);
+              { const SnakeOut so = SNAKE_AT(k, y, m, b);
                 y = so.y;  m = so.m;  b = so.b;
                 ahit = so.hit == 1;  bhit = so.hit == 2;
               }
@@ -851,6 +911,10 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
   const int S = REV ? -1 : 1;
   const u8 *aseq = uni_ptr(REV ? c.aseq - 1 : c.aseq);
   const u8 *bseq = uni_ptr(REV ? c.bseq - 1 : c.bseq);
+  const u32 *apk = uni_ptr(c.apk), *bpk = uni_ptr(c.bpk);
+  const u32 a0 = (u32) uni((int) c.a0), b0 = (u32) uni((int) c.b0);
+  const int alen = uni(c.alen), blen = uni(c.blen);
+  (void) apk; (void) bpk; (void) a0; (void) b0; (void) alen; (void) blen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
   const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
@@ -1187,6 +1251,8 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
   WaveCtx c;
   c.aseq = a.ablk.bases + a.ablk.boff[ar];
   c.bseq = a.bblk.bases + a.bblk.boff[br];
+  c.apk = a.ablk.pk;  c.a0 = a.ablk.boff[ar];
+  c.bpk = a.bblk.pk;  c.b0 = a.bblk.boff[br];
   c.alen = alen;  c.blen = blen;
   c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
   c.score = a.score;  c.table = a.table;
@@ -1368,6 +1434,7 @@ __device__ void process_read(const ReportArgs &a, const SlotScratch &s, const in
   WaveCtx c;
   c.aseq = a.ablk.bases + a.ablk.boff[ar];
   c.bseq = c.aseq;
+  c.apk = c.bpk = a.ablk.pk;  c.a0 = c.b0 = a.ablk.boff[ar];
   c.alen = alen;  c.blen = alen;
   c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
   c.score = a.score;  c.table = a.table;
@@ -1543,6 +1610,8 @@ void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
       WaveCtx c;
       c.aseq = a.ablk.bases + a.ablk.boff[tk.aread];
       c.bseq = a.bblk.bases + a.bblk.boff[tk.bread];
+      c.apk = a.ablk.pk;  c.a0 = a.ablk.boff[tk.aread];
+      c.bpk = a.bblk.pk;  c.b0 = a.bblk.boff[tk.bread];
       c.alen = (int) read_len(a.ablk, tk.aread);
       c.blen = (int) read_len(a.bblk, tk.bread);
       c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;

@@ -178,6 +178,7 @@ extern "C" void damar_last_counters(int64 *c)   { memcpy(c, G_cnt, sizeof(G_cnt)
 
 struct damar_dev_block
 { DevBlock d;
+  u32 *pk_alloc;
   u8  *bases_alloc;        /* d.bases = bases_alloc + 64; d.bases[-1] is the leading terminator */
   u32 *boff, *coarse;
   int  nreads;
@@ -215,6 +216,10 @@ extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
   HIP_CHECK(hipMemcpyAsync(b->coarse, coarse.data(), sizeof(u32) * nq, hipMemcpyHostToDevice, G_st));
   HIP_CHECK(hipStreamSynchronize(G_st));
   b->d.bases  = b->bases_alloc + 64;
+  b->pk_alloc = (u32 *) dmalloc(sizeof(u32) * (((size_t) total >> 4) + 1 + 2 * PK_PAD));
+  b->d.pk     = b->pk_alloc + PK_PAD;
+  damar_launch_pack_bases(b->d.bases, (u32) total, b->pk_alloc + PK_PAD, G_st);
+  HIP_CHECK(hipStreamSynchronize(G_st));
   b->d.boff   = b->boff;
   b->d.coarse = b->coarse;
   b->d.nreads = (u32) n;
@@ -229,6 +234,7 @@ extern "C" void damar_block_free(damar_dev_block *b)
     return;
   HIP_CHECK(hipStreamSynchronize(G_st));
   HIP_CHECK(hipFree(b->bases_alloc));
+  HIP_CHECK(hipFree(b->pk_alloc));
   HIP_CHECK(hipFree(b->boff));
   HIP_CHECK(hipFree(b->coarse));
   free(b);
