@@ -258,7 +258,10 @@ void work_cost(const u64 *__restrict__ keys, u64 nhits, int pbits, const u32 *__
   u64 n = a - i;
   if (n > WORK_COST_MAX)
     n = WORK_COST_MAX;
-  key[j] = coarse ? (n >= coarse ? 0u : 1u) : (u32) (WORK_COST_MAX - n);
+  if (coarse == 1)              /* size classes (powers of two): largest class first, reference order inside */
+    key[j] = (u32) __clz((int) n) - (32 - WORK_COST_BITS);
+  else
+    key[j] = coarse ? (n >= coarse ? 0u : 1u) : (u32) (WORK_COST_MAX - n);
   val[j] = j;
 }
 

@@ -6,7 +6,8 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "FETCH_SIZE WRITE_SIZE"; do
+if [ $# -eq 0 ]; then set -- "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS"; fi
+for set in "$@"; do
   tag=$(echo $set | tr ' ' '_')
   timeout -k 10 280 rocprofv3 --pmc $set --kernel-trace -d $OUT/$tag -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > $OUT/$tag.log 2>&1
   echo "== $set"
