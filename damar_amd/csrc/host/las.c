@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include "damar_align.h"
+#include "damar_host.h"
 
 #define TRIM_BITS   15
 #define TRIM_SIZE   (1 << TRIM_BITS)
@@ -292,11 +293,11 @@ static int split_block_name(const char *name, char *root, size_t cap)
   return atoi(dot + 1);
 }
 
-/* align.c:6166-6367 */
-void Write_Overlap_Buffer(Align_Spec *spec, char *dir1, char *dir2, char *ablock, char *bblock, int lastRead)
-{ Spec   *s = (Spec *) spec;
-  int     tspace = s->trace_space;
-  int     tbytes = s->iobuf[0].tbytes;
+/* align.c:6166-6367 on an explicit set of per-thread buffers */
+static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
+                          const char *dir1, const char *dir2, const char *ablock, const char *bblock, int lastRead)
+{ int     tspace = s->trace_space;
+  int     tbytes = iobuf[0].tbytes;
   int     i, j, n = 0, total = 0;
   Keyed  *all;
   char    aroot[2048], broot[2048];
@@ -306,14 +307,14 @@ void Write_Overlap_Buffer(Align_Spec *spec, char *dir1, char *dir2, char *ablock
   int64   nh;
 
   for (i = 0; i < s->nthreads; i++)
-    total += s->iobuf[i].otop;
+    total += iobuf[i].otop;
   all = (Keyed *) malloc(sizeof(Keyed) * (size_t) (total > 0 ? total : 1));
   if (all == NULL)
     { fprintf(stderr, "[ERROR] - Write_Overlap_Buffer: Cannot create file overlap buffer for all threads\n");
       exit(1);
     }
   for (i = 0; i < s->nthreads; i++)
-    { Overlap_IO_Buffer *b = s->iobuf + i;
+    { Overlap_IO_Buffer *b = iobuf + i;
       for (j = 0; j < b->otop; j++)
         { if (s->only_identity && b->ovls[j].aread != b->ovls[j].bread)
             continue;
@@ -377,6 +378,47 @@ void Write_Overlap_Buffer(Align_Spec *spec, char *dir1, char *dir2, char *ablock
       }
     }
   free(all);
+}
+
+
+void Write_Overlap_Buffer(Align_Spec *spec, char *dir1, char *dir2, char *ablock, char *bblock, int lastRead)
+{ Spec *s = (Spec *) spec;
+  damar_write_params p;
+  p.trace_space = s->trace_space;  p.nthreads = s->nthreads;
+  p.symmetric = s->symmetric;      p.only_identity = s->only_identity;
+  write_buffers(&p, s->iobuf, dir1, dir2, ablock, bblock, lastRead);
+}
+
+/* For a writer thread: take the filled buffers away from the Align_Spec (which continues with
+ * fresh, empty ones) so that sorting and writing them can overlap with the next block pair. */
+Overlap_IO_Buffer *damar_detach_overlap_buffers(Align_Spec *spec, damar_write_params *p)
+{ Spec *s = (Spec *) spec;
+  Overlap_IO_Buffer *old = s->iobuf;
+  int i;
+  p->trace_space = s->trace_space;  p->nthreads = s->nthreads;
+  p->symmetric = s->symmetric;      p->only_identity = s->only_identity;
+  s->iobuf = (Overlap_IO_Buffer *) calloc((size_t) s->nthreads, sizeof(Overlap_IO_Buffer));
+  for (i = 0; i < s->nthreads; i++)
+    { Overlap_IO_Buffer *b = CreateOverlapBuffer(s->nthreads, old[i].tbytes, old[i].no_trace);
+      if (b == NULL)
+        { fprintf(stderr, "[ERROR] - Cannot allocate overlap buffers\n");
+          exit(1);
+        }
+      s->iobuf[i] = *b;
+      free(b);
+    }
+  return old;
+}
+
+void damar_write_detached(const damar_write_params *p, Overlap_IO_Buffer *bufs,
+                          const char *dir1, const char *dir2, const char *ablock, const char *bblock, int lastRead)
+{ int i;
+  write_buffers(p, bufs, dir1, dir2, ablock, bblock, lastRead);
+  for (i = 0; i < p->nthreads; i++)
+    { free(bufs[i].ovls);
+      free(bufs[i].trace);
+    }
+  free(bufs);
 }
 
 /* align.c:6369-6380 */

@@ -71,6 +71,10 @@ static hipStream_t  G_st;
 static hipDeviceProp_t G_prop;
 static hipEvent_t   G_ev[16];
 static double       G_ms[DAMAR_T_COUNT];
+static double       H_ms[8];              /* host wall clock per phase (DAMAR_HOSTPROF=1 prints them at drain) */
+static const char  *H_name[8] = { "index_build", "match:front", "match:order", "match:report", "match:d2h",
+                                  "match:submit", "match:total", "" };
+static double now_ms(void);
 static int64        G_cnt[8];
 
 struct Arena { char *base; size_t cap, top; };
@@ -343,7 +347,10 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
 }
 
 extern "C" damar_dev_index *damar_index_build(damar_dev_block *blk, int own_block, int *len)
-{ return index_build_k(blk, own_block, len, P_kmer, P_suppress);
+{ double t0 = now_ms();
+  damar_dev_index *ix = index_build_k(blk, own_block, len, P_kmer, P_suppress);
+  H_ms[0] += now_ms() - t0;
+  return ix;
 }
 
 extern "C" void damar_index_free(damar_dev_index *ix)
@@ -496,19 +503,59 @@ static double now_ms(void)
   return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
 }
 
-static int64 run_tail(std::vector<LaRecord> &recs, const std::vector<u16> &tpool,
+/* Page-locked landing buffers for the records and trace points of one report launch, recycled
+ * through a small pool: the download runs at PCIe speed and nothing is allocated or touched
+ * for the first time inside the timed loop. */
+struct HostBuf
+{ LaRecord *recs;   size_t rec_cap;
+  u16      *tpool;  size_t tp_cap;
+  size_t    nrec, ntp;
+};
+static std::mutex             &HB_mu   = *new std::mutex();
+static std::vector<HostBuf *> &HB_free = *new std::vector<HostBuf *>();
+
+static HostBuf *hostbuf_get(size_t nrec, size_t ntp)
+{ HostBuf *h = NULL;
+  { std::lock_guard<std::mutex> lk(HB_mu);
+    if (!HB_free.empty())
+      { h = HB_free.back();
+        HB_free.pop_back();
+      }
+  }
+  if (h == NULL)
+    h = new HostBuf();
+  if (h->rec_cap < nrec)
+    { if (h->recs) HIP_CHECK(hipHostFree(h->recs));
+      h->rec_cap = nrec + (nrec >> 2) + 4096;
+      HIP_CHECK(hipHostMalloc((void **) &h->recs, sizeof(LaRecord) * h->rec_cap, hipHostMallocDefault));
+    }
+  if (h->tp_cap < ntp)
+    { if (h->tpool) HIP_CHECK(hipHostFree(h->tpool));
+      h->tp_cap = ntp + (ntp >> 2) + 65536;
+      HIP_CHECK(hipHostMalloc((void **) &h->tpool, sizeof(u16) * h->tp_cap, hipHostMallocDefault));
+    }
+  h->nrec = nrec;  h->ntp = ntp;
+  return h;
+}
+
+static void hostbuf_put(HostBuf *h)
+{ std::lock_guard<std::mutex> lk(HB_mu);
+  HB_free.push_back(h);
+}
+
+static int64 run_tail(LaRecord *recs, size_t nrecs, const u16 *tpool,
                       const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec)
 { int64 ncheck = 0;
   const int ts = Trace_Spacing(spec);
-  std::sort(recs.begin(), recs.end(), RecOrder());
+  std::sort(recs, recs + nrecs, RecOrder());
   Overlap_IO_Buffer *obuf = OVL_IO_Buffer(spec);
   std::vector<damar_path> am, bm;
   damar_tpool tp = { NULL, 0, 0 };
   const char *abase = (const char *) ablock->bases, *bbase = (const char *) bblock->bases;
   size_t i = 0;
-  while (i < recs.size())
+  while (i < nrecs)
     { size_t j = i;
-      while (j < recs.size() && recs[j].item == recs[i].item)
+      while (j < nrecs && recs[j].item == recs[i].item)
         j += 1;
       const int ar = recs[i].aread, br = recs[i].bread;
       const int al = ablock->reads[ar].rlen, bl = bblock->reads[br].rlen;
@@ -521,7 +568,7 @@ static int64 run_tail(std::vector<LaRecord> &recs, const std::vector<u16> &tpool
           if (doA)
             { p.tlen = r.atlen;  p.diffs = r.diffs;
               p.abpos = r.abpos;  p.bbpos = r.bbpos;  p.aepos = r.aepos;  p.bepos = r.bepos;
-              p.toff = damar_tpool_push(&tp, tpool.data() + r.toff, r.atlen);
+              p.toff = damar_tpool_push(&tp, tpool + r.toff, r.atlen);
               am.push_back(p);
             }
           if (doB)
@@ -532,7 +579,7 @@ static int64 run_tail(std::vector<LaRecord> &recs, const std::vector<u16> &tpool
                 }
               else                                               /* align.c:2059-2062 */
                 { p.abpos = r.bbpos;  p.bbpos = r.abpos;  p.aepos = r.bepos;  p.bepos = r.aepos; }
-              p.toff = damar_tpool_push(&tp, tpool.data() + r.toff + r.atlen, r.btlen);
+              p.toff = damar_tpool_push(&tp, tpool + r.toff + r.atlen, r.btlen);
               bm.push_back(p);
             }
         }
@@ -547,98 +594,143 @@ static int64 run_tail(std::vector<LaRecord> &recs, const std::vector<u16> &tpool
   return ncheck;
 }
 
-/* Asynchronous mode (damar_set_async(1)): the host tail of a Match_Filter and the sort+write
- * of Write_Overlap_Buffer run on one worker thread in submission order, so the GPU already
- * works on the next block pair meanwhile.  The overlap buffers of an Align_Spec are then
- * touched by the worker only; damar_async_drain() must be called before the blocks or the
+/* Asynchronous mode (damar_set_async(1)): the host side runs as a two-stage pipeline behind
+ * the GPU.  Stage 1 (one thread) does the tail of each Match_Filter in submission order and,
+ * for a write request, detaches the filled overlap buffers from the Align_Spec; stage 2 (a
+ * second thread) sorts and writes the detached buffers.  The overlap buffers of an Align_Spec
+ * are touched by stage 1 only; damar_async_drain() must be called before the blocks or the
  * Align_Spec involved are released, and before the counters are read. */
 struct TailJob
 { int kind;                                  /* 0 = tail of one Match_Filter, 1 = write + reset */
-  std::vector<LaRecord> recs;
-  std::vector<u16>      tpool;
+  HostBuf *hb;
   const HITS_DB *ablock, *bblock;
   int  self, comp;
   Align_Spec *spec;
   std::string d1, d2, a, b;
   bool has1, has2;
   int  last;
+  damar_write_params wp;                     /* stage 2 */
+  Overlap_IO_Buffer *bufs;
 };
 
-/* Heap objects that are never destroyed: at process exit the worker may still be parked in
- * A_cv.wait(), and destroying a condition variable with a waiter (static destructors) hangs. */
-static bool                     A_on = false;
-static std::thread             *A_threadp = NULL;
-static std::mutex              &A_mu    = *new std::mutex();
-static std::condition_variable &A_cv    = *new std::condition_variable();
-static std::condition_variable &A_idle  = *new std::condition_variable();
-static std::deque<TailJob *>   &A_queue = *new std::deque<TailJob *>();
-static bool                     A_busy = false, A_quit = false;
-static int64                   A_ncheck = 0;
-static double                  A_tail_ms = 0, A_write_ms = 0;
+/* Heap objects that are never destroyed: at process exit a worker may still be parked in
+ * wait(), and destroying a condition variable with a waiter (static destructors) hangs. */
+struct Stage
+{ std::mutex              mu;
+  std::condition_variable cv, idle;
+  std::deque<TailJob *>   queue;
+  bool                    busy, quit;
+  std::thread            *thread;
+  Stage() : busy(false), quit(false), thread(NULL) {}
+};
+static bool   A_on = false;
+static Stage &A_s1 = *new Stage();
+static Stage &A_s2 = *new Stage();
+static std::mutex &A_mu = *new std::mutex();            /* the totals below */
+static int64  A_ncheck = 0;
+static double A_tail_ms = 0, A_write_ms = 0;
 
-static void async_worker(void)
+static void stage_submit(Stage &st, TailJob *job)
+{ { std::lock_guard<std::mutex> lk(st.mu);
+    st.queue.push_back(job);
+  }
+  st.cv.notify_one();
+}
+
+static TailJob *stage_next(Stage &st)
+{ std::unique_lock<std::mutex> lk(st.mu);
+  st.cv.wait(lk, [&st] { return st.quit || !st.queue.empty(); });
+  if (st.queue.empty())
+    return NULL;
+  TailJob *job = st.queue.front();
+  st.queue.pop_front();
+  st.busy = true;
+  return job;
+}
+
+static void stage_done(Stage &st)
+{ { std::lock_guard<std::mutex> lk(st.mu);
+    st.busy = false;
+  }
+  st.idle.notify_all();
+}
+
+static void stage_drain(Stage &st)
+{ std::unique_lock<std::mutex> lk(st.mu);
+  st.idle.wait(lk, [&st] { return st.queue.empty() && !st.busy; });
+}
+
+static void tail_worker(void)
 { for (;;)
-    { TailJob *job;
-      { std::unique_lock<std::mutex> lk(A_mu);
-        A_cv.wait(lk, [] { return A_quit || !A_queue.empty(); });
-        if (A_queue.empty())
-          return;
-        job = A_queue.front();
-        A_queue.pop_front();
-        A_busy = true;
-      }
+    { TailJob *job = stage_next(A_s1);
+      if (job == NULL)
+        return;
       double t0 = now_ms();
       if (job->kind == 0)
-        { int64 n = run_tail(job->recs, job->tpool, job->ablock, job->bblock, job->self, job->comp, job->spec);
+        { int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, job->ablock, job->bblock,
+                             job->self, job->comp, job->spec);
+          hostbuf_put(job->hb);
+          delete job;
           std::lock_guard<std::mutex> lk(A_mu);
           A_ncheck += n;
           A_tail_ms += now_ms() - t0;
         }
       else
-        { Write_Overlap_Buffer(job->spec, job->has1 ? (char *) job->d1.c_str() : NULL,
-                               job->has2 ? (char *) job->d2.c_str() : NULL,
-                               (char *) job->a.c_str(), (char *) job->b.c_str(), job->last);
-          Reset_Overlap_Buffer(job->spec);
+        { job->bufs = damar_detach_overlap_buffers(job->spec, &job->wp);
+          stage_submit(A_s2, job);
           std::lock_guard<std::mutex> lk(A_mu);
-          A_write_ms += now_ms() - t0;
+          A_tail_ms += now_ms() - t0;
         }
+      stage_done(A_s1);
+    }
+}
+
+static void write_worker(void)
+{ for (;;)
+    { TailJob *job = stage_next(A_s2);
+      if (job == NULL)
+        return;
+      double t0 = now_ms();
+      damar_write_detached(&job->wp, job->bufs, job->has1 ? job->d1.c_str() : NULL,
+                           job->has2 ? job->d2.c_str() : NULL, job->a.c_str(), job->b.c_str(), job->last);
       delete job;
       { std::lock_guard<std::mutex> lk(A_mu);
-        A_busy = false;
+        A_write_ms += now_ms() - t0;
       }
-      A_idle.notify_all();
+      stage_done(A_s2);
     }
 }
 
 static void async_submit(TailJob *job)
-{ { std::lock_guard<std::mutex> lk(A_mu);
-    A_queue.push_back(job);
-  }
-  A_cv.notify_one();
+{ stage_submit(A_s1, job);
 }
 
 extern "C" void damar_async_drain(void)
 { if (!A_on)
     return;
-  std::unique_lock<std::mutex> lk(A_mu);
-  A_idle.wait(lk, [] { return A_queue.empty() && !A_busy; });
+  stage_drain(A_s1);           /* stage 1 feeds stage 2: drain in pipeline order */
+  stage_drain(A_s2);
 }
 
 extern "C" void damar_set_async(int on)
 { if (on && !A_on)
-    { A_quit = false;
-      A_threadp = new std::thread(async_worker);
+    { A_s1.quit = A_s2.quit = false;
+      A_s1.thread = new std::thread(tail_worker);
+      A_s2.thread = new std::thread(write_worker);
       A_on = true;
     }
   else if (!on && A_on)
     { damar_async_drain();
-      { std::lock_guard<std::mutex> lk(A_mu);
-        A_quit = true;
-      }
-      A_cv.notify_all();
-      A_threadp->join();
-      delete A_threadp;
-      A_threadp = NULL;
+      Stage *st[2] = { &A_s1, &A_s2 };
+      for (int i = 0; i < 2; i++)
+        { { std::lock_guard<std::mutex> lk(st[i]->mu);
+            st[i]->quit = true;
+          }
+          st[i]->cv.notify_all();
+          st[i]->thread->join();
+          delete st[i]->thread;
+          st[i]->thread = NULL;
+        }
       A_on = false;
     }
 }
@@ -646,6 +738,14 @@ extern "C" void damar_set_async(int on)
 /* totals since the last call: confirmed records, tail ms, write ms (drains first) */
 extern "C" void damar_async_totals(int64 *ncheck, double *tail_ms, double *write_ms)
 { damar_async_drain();
+  if (getenv("DAMAR_HOSTPROF"))
+    { fprintf(stderr, "damar host wall ms:");
+      for (int i = 0; i < 7; i++)
+        { fprintf(stderr, " %s=%.1f", H_name[i], H_ms[i]);
+          H_ms[i] = 0;
+        }
+      fprintf(stderr, "\n");
+    }
   std::lock_guard<std::mutex> lk(A_mu);
   if (ncheck)   *ncheck = A_ncheck;
   if (tail_ms)  *tail_ms = A_tail_ms;
@@ -688,6 +788,8 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
                             damar_dev_index *aidx, damar_dev_index *bidx,
                             int self, int comp, Align_Spec *spec, int64 *counts)
 { ensure_init();
+  const double h0 = now_ms();
+  double h1 = h0, h2 = h0, h3 = h0, h4 = h0;
   int64 nhits = 0, nfilt = 0, ncheck = 0;
   memset(G_cnt, 0, sizeof(G_cnt));
   for (int i = DAMAR_T_MERGE; i < DAMAR_T_COUNT; i++)
@@ -825,6 +927,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
       G_seed_pbits = m.pbits;  G_seed_abits = m.abits;
     }
 
+  h1 = now_ms();
   /* ---- largest pairs first (the order only schedules the kernel: records carry their work
           item's rank in the reference's order) ---- */
   const u32 *order = NULL;
@@ -845,9 +948,9 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
       stage("work_order");
     }
 
+  h2 = now_ms();
   /* ---- report kernel (retry with larger buffers if it reports an overflow) ---- */
-  std::vector<LaRecord> recs;
-  std::vector<u16>      tpool;
+  HostBuf *hb = NULL;
   u32 hc[16];
   if (nwork > 0)
     { u32 cell_cap = RS.cell_cap ? RS.cell_cap : (1u << 16);
@@ -889,11 +992,11 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
             fprintf(stderr, "damar: report kernel overflow (flags %u), retrying with larger buffers\n", hc[3]);
         }
       tick(6);
-      recs.resize(hc[1]);
-      tpool.resize(hc[2]);
+      h3 = now_ms();
+      hb = hostbuf_get(hc[1], hc[2]);
       if (hc[1] > 0)
-        { HIP_CHECK(hipMemcpyAsync(recs.data(), RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, G_st));
-          HIP_CHECK(hipMemcpyAsync(tpool.data(), RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, G_st));
+        { HIP_CHECK(hipMemcpyAsync(hb->recs, RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, G_st));
+          HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, G_st));
         }
       tick(7);
       HIP_CHECK(hipStreamSynchronize(G_st));
@@ -902,21 +1005,29 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
       G_cnt[2] = hc[4];  G_cnt[3] = hc[1];  G_cnt[4] = hc[2];
     }
 
+  h4 = now_ms();
   /* ---- host tail: filter.c:2442-2483 per read pair (worker thread in asynchronous mode) ---- */
+  if (hb == NULL)
+    hb = hostbuf_get(0, 0);
   if (A_on)
     { TailJob *job = new TailJob();
       job->kind = 0;
-      job->recs.swap(recs);
-      job->tpool.swap(tpool);
+      job->hb = hb;
       job->ablock = ablock;  job->bblock = bblock;  job->self = self;  job->comp = comp;  job->spec = spec;
       async_submit(job);
     }
   else
     { double t0 = now_ms();
-      ncheck = run_tail(recs, tpool, ablock, bblock, self, comp, spec);
+      ncheck = run_tail(hb->recs, hb->nrec, hb->tpool, ablock, bblock, self, comp, spec);
+      hostbuf_put(hb);
       G_ms[DAMAR_T_TAIL] = now_ms() - t0;
     }
 
+  { const double h5 = now_ms();
+    if (h3 == h0) h3 = h4;                 /* no work: no report, no download */
+    H_ms[1] += h1 - h0;  H_ms[2] += h2 - h1;  H_ms[3] += h3 - h2;  H_ms[4] += h4 - h3;  H_ms[5] += h5 - h4;
+    H_ms[6] += h5 - h0;
+  }
   if (counts)
     { counts[0] = nhits;  counts[1] = nfilt;  counts[2] = ncheck; }
   if (VERBOSE)
