@@ -57,12 +57,15 @@ void damar_launch_merge_count(const MergeArgs *m, u32 *cnt, u32 *jb, hipStream_t
 void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32 *cnt, hipStream_t st);
 void damar_launch_merge_emit(const MergeArgs *m, const u32 *off, const u32 *jb, u64 nhits,
                              u64 *keys, u32 *vals, hipStream_t st);
-void damar_launch_pair_flags(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, int minhit,
-                             int nshift, int binshift, int kmer, int hitmin, u32 *flags, hipStream_t st);
+void damar_launch_pair_flags(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
+                             u64 *send /* 64 entries of scratch */, u32 *flags, hipStream_t st);
 #define WORK_COST_BITS 16
 #define WORK_COST_MAX  ((1u << WORK_COST_BITS) - 1)
 void damar_launch_work_cost(const u64 *keys, u64 nhits, int pbits, const u32 *work, u32 nwork, u32 coarse,
                             u32 *key, u32 *val, hipStream_t st);
+void damar_launch_pair_screen(const u64 *keys, const u32 *vals, u64 nhits, int pbits, const u32 *heads, u32 nheads,
+                              int minhit, int binshift, int kmer, int hitmin, u32 *keep, hipStream_t st);
+void damar_launch_compact_u32(const u32 *src, const u32 *keep, const u32 *off, u32 n, u32 *out, hipStream_t st);
 void damar_launch_compact_index(const u32 *flags, const u32 *off, u64 n, u32 *out, hipStream_t st);
 
 /* report.hip */

@@ -144,34 +144,37 @@ void damar_launch_merge_emit(const MergeArgs *m, const u32 *off, const u32 *jb, 
  * first index >= (nhits*t)>>nshift whose bread differs from its predecessor's. */
 #define SCREEN_MAX   48
 #define SCREEN_PANEL 50000                     /* PANEL_SIZE, filter.c:73 */
-__global__ __launch_bounds__(256)
-void pair_flags(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits, int bshift,
-                int minhit, int nshift, int binshift, int kmer, int hitmin, u32 *__restrict__ flags)
-{ __shared__ u64 send[65];
-  int nthr = 1 << nshift;
-  if ((int) threadIdx.x < nthr)
-    { int t = threadIdx.x;
-      u64 e;
-      if (t == nthr - 1)
-        e = nhits;
-      else
-        { e = (nhits * (u64) (t + 1)) >> nshift;
-          if (e > 0)
-            { u64 d = keys[e - 1] >> bshift, a = e, b = nhits;     /* first index with bread != d */
-              while (a < b)
-                { u64 mid = (a + b) >> 1;
-                  if ((keys[mid] >> bshift) == d) a = mid + 1; else b = mid;
-                }
-              e = a;
+/* ends of the reference's NTHREADS slices: once per launch, not once per block */
+__global__ __launch_bounds__(64)
+void slice_ends(const u64 *__restrict__ keys, u64 nhits, int bshift, int nshift, u64 *__restrict__ send)
+{ const int nthr = 1 << nshift, t = threadIdx.x;
+  if (t >= nthr)
+    return;
+  u64 e;
+  if (t == nthr - 1)
+    e = nhits;
+  else
+    { e = (nhits * (u64) (t + 1)) >> nshift;
+      if (e > 0)
+        { u64 d = keys[e - 1] >> bshift, a = e, b = nhits;     /* first index with bread != d */
+          while (a < b)
+            { u64 mid = (a + b) >> 1;
+              if ((keys[mid] >> bshift) == d) a = mid + 1; else b = mid;
             }
+          e = a;
         }
-      send[t] = e;
     }
-  __syncthreads();
+  send[t] = e;
+}
+
+__global__ __launch_bounds__(256)
+void pair_flags(const u64 *__restrict__ keys, u64 nhits, int pbits, int minhit, int nshift,
+                const u64 *__restrict__ send, u32 *__restrict__ flags)
+{ const int nthr = 1 << nshift;
   u64 i = (u64) blockIdx.x * 256u + threadIdx.x;
   if (i >= nhits)
     return;
-  const u64 pr = keys[i] >> pbits, pmask = (1ull << pbits) - 1;
+  const u64 pr = keys[i] >> pbits;
   u32 f = 0;
   if ((i == 0 || (keys[i - 1] >> pbits) != pr) && i + (u64) (minhit - 1) < nhits &&
       (keys[i + (u64) (minhit - 1)] >> pbits) == pr)
@@ -183,47 +186,83 @@ void pair_flags(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 
               break;
             }
         }
-      /* Screen (the vast majority of runs are a few chance k-mer matches between unrelated
-         reads).  A run that fits one A-panel (filter.c:2251: all apos <= PANEL_SIZE) gets its
-         bucket scores computed here exactly as pass 1 of the report loop does (filter.c:2268-2277:
-         a seed adds min(kmer, apos - previous apos in its bucket)); a seed fires only if its
-         bucket plus a neighbour reach hitmin (filter.c:2297).  Runs that cannot fire are dropped
-         from the work list: the report kernel would not have emitted anything for them. */
-      if (f)
-        { int n = minhit;
-          while (n <= SCREEN_MAX && i + (u64) n < nhits && (keys[i + (u64) n] >> pbits) == pr)
-            n += 1;
-          if (n <= SCREEN_MAX && (int) (keys[i + (u64) (n - 1)] & pmask) <= SCREEN_PANEL)
-            { bool ok = false;
-              for (int x = 0; x < n && !ok; x++)
-                { const int dx = ((int) vals[i + (u64) x]) >> binshift;
-                  int s0 = 0, s1 = 0, p0 = 0, p1 = 0;
-                  for (int y = 0; y < n; y++)
-                    { const int dy = ((int) vals[i + (u64) y]) >> binshift;
-                      const int ap = (int) (keys[i + (u64) y] & pmask);
-                      if (dy == dx)
-                        { s0 += (ap - p0 >= kmer) ? kmer : ap - p0;  p0 = ap; }
-                      else if (dy == dx + 1)
-                        { s1 += (ap - p1 >= kmer) ? kmer : ap - p1;  p1 = ap; }
-                    }
-                  ok = s0 + s1 >= hitmin;
-                }
-              if (!ok)
-                f = 0;
-            }
-        }
     }
   flags[i] = f;
 }
 
-void damar_launch_pair_flags(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, int minhit,
-                              int nshift, int binshift, int kmer, int hitmin, u32 *flags, hipStream_t st)
+void damar_launch_pair_flags(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
+                             u64 *send /* 64 entries of scratch */, u32 *flags, hipStream_t st)
 { if (nhits == 0)
     return;
   if (nshift > 6)
     nshift = 6;
-  hipLaunchKernelGGL(pair_flags, dim3((u32) ((nhits + 255) / 256)), dim3(256), 0, st, keys, vals, nhits, pbits,
-                     abits + pbits, minhit, nshift, binshift, kmer, hitmin, flags);
+  hipLaunchKernelGGL(slice_ends, dim3(1), dim3(64), 0, st, keys, nhits, abits + pbits, nshift, send);
+  hipLaunchKernelGGL(pair_flags, dim3((u32) ((nhits + 255) / 256)), dim3(256), 0, st, keys, nhits, pbits,
+                     minhit, nshift, send, flags);
+}
+
+/* Screen of the run heads (the vast majority of runs are a few chance k-mer matches between
+ * unrelated reads).  A run that fits one A-panel (filter.c:2251: all apos <= PANEL_SIZE) gets its
+ * bucket scores computed here exactly as pass 1 of the report loop does (filter.c:2268-2277:
+ * a seed adds min(kmer, apos - previous apos in its bucket)); a seed fires only if its bucket
+ * plus a neighbour reach hitmin (filter.c:2297).  Runs that cannot fire are dropped from the
+ * work list: the report kernel would not have emitted anything for them.  One thread per head,
+ * heads compacted first so that the wavefronts are full. */
+__global__ __launch_bounds__(256)
+void pair_screen(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits,
+                 const u32 *__restrict__ heads, u32 nheads, int minhit, int binshift, int kmer, int hitmin,
+                 u32 *__restrict__ keep)
+{ u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nheads)
+    return;
+  const u64 i = heads[t];
+  const u64 pr = keys[i] >> pbits, pmask = (1ull << pbits) - 1;
+  u32 f = 1;
+  int n = minhit;
+  while (n <= SCREEN_MAX && i + (u64) n < nhits && (keys[i + (u64) n] >> pbits) == pr)
+    n += 1;
+  if (n <= SCREEN_MAX && (int) (keys[i + (u64) (n - 1)] & pmask) <= SCREEN_PANEL)
+    { bool ok = false;
+      for (int x = 0; x < n && !ok; x++)
+        { const int dx = ((int) vals[i + (u64) x]) >> binshift;
+          int s0 = 0, s1 = 0, p0 = 0, p1 = 0;
+          for (int y = 0; y < n; y++)
+            { const int dy = ((int) vals[i + (u64) y]) >> binshift;
+              const int ap = (int) (keys[i + (u64) y] & pmask);
+              if (dy == dx)
+                { s0 += (ap - p0 >= kmer) ? kmer : ap - p0;  p0 = ap; }
+              else if (dy == dx + 1)
+                { s1 += (ap - p1 >= kmer) ? kmer : ap - p1;  p1 = ap; }
+            }
+          ok = s0 + s1 >= hitmin;
+        }
+      if (!ok)
+        f = 0;
+    }
+  keep[t] = f;
+}
+
+void damar_launch_pair_screen(const u64 *keys, const u32 *vals, u64 nhits, int pbits, const u32 *heads, u32 nheads,
+                              int minhit, int binshift, int kmer, int hitmin, u32 *keep, hipStream_t st)
+{ if (nheads == 0)
+    return;
+  hipLaunchKernelGGL(pair_screen, dim3((nheads + 255) / 256), dim3(256), 0, st, keys, vals, nhits, pbits, heads, nheads,
+                     minhit, binshift, kmer, hitmin, keep);
+}
+
+/* out[off[i]] = src[i] for the kept entries */
+__global__ __launch_bounds__(256)
+void compact_u32(const u32 *__restrict__ src, const u32 *__restrict__ keep, const u32 *__restrict__ off, u32 n,
+                 u32 *__restrict__ out)
+{ u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n && keep[i])
+    out[off[i]] = src[i];
+}
+
+void damar_launch_compact_u32(const u32 *src, const u32 *keep, const u32 *off, u32 n, u32 *out, hipStream_t st)
+{ if (n == 0)
+    return;
+  hipLaunchKernelGGL(compact_u32, dim3((n + 255) / 256), dim3(256), 0, st, src, keep, off, n, out);
 }
 
 __global__ __launch_bounds__(256)

@@ -73,7 +73,7 @@ static hipEvent_t   G_ev[16];
 static double       G_ms[DAMAR_T_COUNT];
 static double       H_ms[8];              /* host wall clock per phase (DAMAR_HOSTPROF=1 prints them at drain) */
 static const char  *H_name[8] = { "index_build", "match:front", "match:order", "match:report", "match:d2h",
-                                  "match:submit", "match:total", "" };
+                                  "match:submit", "match:total", "final_drain" };
 static double now_ms(void);
 static int64        G_cnt[8];
 
@@ -737,10 +737,12 @@ extern "C" void damar_set_async(int on)
 
 /* totals since the last call: confirmed records, tail ms, write ms (drains first) */
 extern "C" void damar_async_totals(int64 *ncheck, double *tail_ms, double *write_ms)
-{ damar_async_drain();
+{ const double d0 = now_ms();
+  damar_async_drain();
+  H_ms[7] += now_ms() - d0;
   if (getenv("DAMAR_HOSTPROF"))
     { fprintf(stderr, "damar host wall ms:");
-      for (int i = 0; i < 7; i++)
+      for (int i = 0; i < 8; i++)
         { fprintf(stderr, " %s=%.1f", H_name[i], H_ms[i]);
           H_ms[i] = 0;
         }
@@ -892,6 +894,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   u32 *flags = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
   u32 *foff  = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
   void *scw2 = arena_take(&G_hits, damar_scan_workspace_bytes(total));
+  u64 *sends = (u64 *) arena_take(&G_hits, 64 * sizeof(u64));
 
   damar_launch_merge_emit(&m, off, jb, total, k0, v0, G_st);
   stage("merge_emit");
@@ -905,13 +908,25 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   /* ---- work list ---- */
   const int minhit = (P_hitmin - 1) / P_kmer + 1;
   u64 nwork64 = 0;
-  damar_launch_pair_flags(keys, vals, total, m.pbits, m.abits, minhit, P_nshift, P_binshift, P_kmer, P_hitmin, flags, G_st);
+  damar_launch_pair_flags(keys, total, m.pbits, m.abits, minhit, P_nshift, sends, flags, G_st);
   stage("pair_flags");
   damar_exclusive_scan_u32(flags, foff, total, scw2, tot, G_st);
-  u32 *work = side ? (u32 *) k0 : (u32 *) k1;          /* the idle key buffer holds the list */
-  damar_launch_compact_index(flags, foff, total, work, G_st);
-  stage("work_list");
+  u32 *heads = side ? (u32 *) k0 : (u32 *) k1;         /* the idle key buffer holds the run heads */
+  damar_launch_compact_index(flags, foff, total, heads, G_st);
+  stage("run_heads");
   HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  const u32 nheads = (u32) nwork64;
+  /* screen the heads (dense, one thread each), compact the survivors: flags/foff are reused */
+  u32 *work = heads + pad256(sizeof(u32) * (size_t) nheads) / sizeof(u32);
+  nwork64 = 0;
+  if (nheads > 0)
+    { damar_launch_pair_screen(keys, vals, total, m.pbits, heads, nheads, minhit, P_binshift, P_kmer, P_hitmin, flags, G_st);
+      damar_exclusive_scan_u32(flags, foff, nheads, scw2, tot, G_st);
+      damar_launch_compact_u32(heads, flags, foff, nheads, work, G_st);
+      stage("work_list");
+      HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+    }
   tick(3);
   HIP_CHECK(hipStreamSynchronize(G_st));
   const u32 nwork = (u32) nwork64;
