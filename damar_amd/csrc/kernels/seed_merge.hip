@@ -110,31 +110,69 @@ void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32
   hipLaunchKernelGGL(merge_limit, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, cnt);
 }
 
+/* One workgroup per tile of DAMAR_SCAN_TILE A entries: the tile's hit counts are scanned in
+ * LDS, then the tile's hits are dealt out to the threads in order, each finding its A entry by
+ * a search of the LDS prefix (no walk over the global offsets), so the seed pairs leave in
+ * fully coalesced runs. */
+#define ME_ITEMS (DAMAR_SCAN_TILE / 256)
 __global__ __launch_bounds__(256)
-void merge_emit(MergeArgs m, const u32 *__restrict__ off, const u32 *__restrict__ jb, u64 nhits,
-                u64 *__restrict__ keys, u32 *__restrict__ vals)
-{ u64 h = (u64) blockIdx.x * 256u + threadIdx.x;
-  if (h >= nhits)
-    return;
-  /* last A entry whose first hit is <= h */
-  u32 a = 0, b = m.alen;
-  while (b - a > 1)
-    { u32 mid = (a + b) >> 1;
-      if ((u64) off[mid] <= h) a = mid; else b = mid;
+void merge_emit(MergeArgs m, const u32 *__restrict__ cnt, const u32 *__restrict__ toff,
+                const u32 *__restrict__ jb, u64 nhits, u64 *__restrict__ keys, u32 *__restrict__ vals)
+{ __shared__ u32 loc[DAMAR_SCAN_TILE + 1];
+  __shared__ u32 wsum[4];
+  const u32 a0 = blockIdx.x * (u32) DAMAR_SCAN_TILE;
+  const int l = lane_id(), w = threadIdx.x >> 6;
+  /* thread t owns entries [t*ME_ITEMS, (t+1)*ME_ITEMS) of the tile */
+  u32 v[ME_ITEMS], s = 0;
+  for (int i = 0; i < ME_ITEMS; i++)
+    { const u32 a = a0 + threadIdx.x * ME_ITEMS + i;
+      v[i] = (a < m.alen) ? cnt[a] : 0;
+      s += v[i];
     }
-  u32 bi = jb[a] + (u32) (h - off[a]);
-  u32 pa = m.apos[a], pb = m.bpos[bi];
-  u32 ra = read_of_pos(m.ablk, pa), rb = read_of_pos(m.bblk, pb);
-  u32 xa = pa - m.ablk.boff[ra], xb = pb - m.bblk.boff[rb];
-  keys[h] = ((u64) rb << (m.abits + m.pbits)) | ((u64) ra << m.pbits) | (u64) xa;
-  vals[h] = (u32) ((int) xa - (int) xb);
+  u32 inc = (u32) wave_incl_scan_i((int) s);
+  if (l == 63) wsum[w] = inc;
+  __syncthreads();
+  u32 base = 0, T = 0;
+  for (int i = 0; i < 4; i++)
+    { const u32 x = wsum[i];
+      if (i < w) base += x;
+      T += x;
+    }
+  u32 ex = base + inc - s;
+  for (int i = 0; i < ME_ITEMS; i++)
+    { loc[threadIdx.x * ME_ITEMS + i] = ex;
+      ex += v[i];
+    }
+  if (threadIdx.x == 255)
+    loc[DAMAR_SCAN_TILE] = T;
+  __syncthreads();
+  const u64 h0 = toff[blockIdx.x];
+  for (u32 t = threadIdx.x; t < T; t += 256)
+    { /* last entry whose first hit is <= t */
+      u32 a = 0, b = DAMAR_SCAN_TILE;
+      while (b - a > 1)
+        { const u32 mid = (a + b) >> 1;
+          if (loc[mid] <= t) a = mid; else b = mid;
+        }
+      const u32 ai = a0 + a;
+      const u32 bi = jb[ai] + (t - loc[a]);
+      const u32 pa = m.apos[ai], pb = m.bpos[bi];
+      const u32 ra = read_of_pos(m.ablk, pa), rb = read_of_pos(m.bblk, pb);
+      const u32 xa = pa - m.ablk.boff[ra], xb = pb - m.bblk.boff[rb];
+      const u64 h = h0 + t;
+      if (h < nhits)
+        { keys[h] = ((u64) rb << (m.abits + m.pbits)) | ((u64) ra << m.pbits) | (u64) xa;
+          vals[h] = (u32) ((int) xa - (int) xb);
+        }
+    }
 }
 
-void damar_launch_merge_emit(const MergeArgs *m, const u32 *off, const u32 *jb, u64 nhits,
+void damar_launch_merge_emit(const MergeArgs *m, const u32 *cnt, const u32 *toff, const u32 *jb, u64 nhits,
                              u64 *keys, u32 *vals, hipStream_t st)
 { if (nhits == 0)
     return;
-  hipLaunchKernelGGL(merge_emit, dim3((u32) ((nhits + 255) / 256)), dim3(256), 0, st, *m, off, jb, nhits, keys, vals);
+  const u32 ntiles = (m->alen + DAMAR_SCAN_TILE - 1) / DAMAR_SCAN_TILE;
+  hipLaunchKernelGGL(merge_emit, dim3(ntiles), dim3(256), 0, st, *m, cnt, toff, jb, nhits, keys, vals);
 }
 
 /* flags[i] = 1 iff hit i starts a (bread,aread) run that report_thread would enter:

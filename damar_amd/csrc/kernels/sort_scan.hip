@@ -101,6 +101,19 @@ void damar_exclusive_scan_u32(const u32 *in, u32 *out, u64 n, void *work, u64 *t
   hipLaunchKernelGGL(scan_tile_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, st, in, out, n, tsum);
 }
 
+/* First two phases only: work[t] = exclusive offset of tile t (SCAN_TILE items per tile),
+ * *total_dev = grand total.  For consumers that rebuild the offsets inside a tile themselves. */
+void damar_tile_offsets_u32(const u32 *in, u64 n, void *work, u64 *total_dev, hipStream_t st)
+{ u32 ntiles = (u32) ((n + SCAN_TILE - 1) / SCAN_TILE);
+  u32 *tsum = (u32 *) work;
+  if (n == 0)
+    { HIP_CHECK(hipMemsetAsync(total_dev, 0, sizeof(u64), st));
+      return;
+    }
+  hipLaunchKernelGGL(scan_tile_sums, dim3(ntiles), dim3(SCAN_THREADS), 0, st, in, n, tsum);
+  hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, st, tsum, ntiles, total_dev);
+}
+
 /***** radix sort ******************************************************************************/
 
 #define RS_THREADS 256

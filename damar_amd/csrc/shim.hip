@@ -838,17 +838,20 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   tick(0);
   damar_launch_merge_count(&m, cnt, jb, G_st);
   stage("merge_count");
-  damar_exclusive_scan_u32(cnt, off, alen, scw, tot, G_st);
+  /* the emit kernel rebuilds the offsets inside a tile of counts itself: only the tile offsets
+     are needed, except by the self-mode limit pass, which looks at whole runs */
+  if (self)
+    damar_exclusive_scan_u32(cnt, off, alen, scw, tot, G_st);
+  else
+    damar_tile_offsets_u32(cnt, alen, scw, tot, G_st);
   stage("merge_scan");
   HIP_CHECK(hipMemcpyAsync(&total, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
   HIP_CHECK(hipStreamSynchronize(G_st));
   if (self && total > 0)
-    { u64 before = total;
-      damar_launch_merge_limit(&m, off, total, cnt, G_st);
-      damar_exclusive_scan_u32(cnt, off, alen, scw, tot, G_st);
+    { damar_launch_merge_limit(&m, off, total, cnt, G_st);
+      damar_tile_offsets_u32(cnt, alen, scw, tot, G_st);
       HIP_CHECK(hipMemcpyAsync(&total, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
       HIP_CHECK(hipStreamSynchronize(G_st));
-      (void) before;
     }
   if (MEM_LIMIT > 0)
     { /* filter.c:2634-2699: with the counts above every run below MAXGRAM is kept; the
@@ -896,7 +899,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   void *scw2 = arena_take(&G_hits, damar_scan_workspace_bytes(total));
   u64 *sends = (u64 *) arena_take(&G_hits, 64 * sizeof(u64));
 
-  damar_launch_merge_emit(&m, off, jb, total, k0, v0, G_st);
+  damar_launch_merge_emit(&m, cnt, (const u32 *) scw, jb, total, k0, v0, G_st);
   stage("merge_emit");
   tick(1);
   int side = damar_radix_sort_u64(k0, v0, k1, v1, total, m.pbits + m.abits + bbits, sw, G_st);
