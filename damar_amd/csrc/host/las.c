@@ -293,6 +293,56 @@ static int split_block_name(const char *name, char *root, size_t cap)
   return atoi(dot + 1);
 }
 
+/* The order of by_overlap (a total order, so any sorting method gives the same sequence):
+ * records are dealt into their A-read's bucket first, which leaves only a handful per bucket
+ * to order by the remaining keys. */
+static Keyed *sort_keyed(Keyed *all, int n)
+{ int     lo, hi, i, j, k;
+  int    *first;
+  Keyed  *out;
+
+  if (n < 64)
+    { qsort(all, (size_t) n, sizeof(Keyed), by_overlap);
+      return all;
+    }
+  lo = hi = all[0].ovl.aread;
+  for (i = 1; i < n; i++)
+    { if (all[i].ovl.aread < lo) lo = all[i].ovl.aread;
+      if (all[i].ovl.aread > hi) hi = all[i].ovl.aread;
+    }
+  first = (int *) calloc((size_t) (hi - lo) + 2, sizeof(int));
+  out   = (Keyed *) malloc(sizeof(Keyed) * (size_t) n);
+  if (first == NULL || out == NULL)
+    { free(first);  free(out);
+      qsort(all, (size_t) n, sizeof(Keyed), by_overlap);
+      return all;
+    }
+  for (i = 0; i < n; i++)
+    first[all[i].ovl.aread - lo + 1] += 1;
+  for (i = 1; i <= hi - lo + 1; i++)
+    first[i] += first[i - 1];
+  for (i = 0; i < n; i++)
+    out[first[all[i].ovl.aread - lo]++] = all[i];
+  /* first[b] is now the end of bucket b */
+  for (i = 0, k = 0; k <= hi - lo; k++)
+    { int e = first[k];
+      if (e - i > 24)
+        qsort(out + i, (size_t) (e - i), sizeof(Keyed), by_overlap);
+      else
+        for (j = i + 1; j < e; j++)
+          { Keyed x = out[j];
+            int   r = j;
+            while (r > i && by_overlap(&out[r - 1], &x) > 0)
+              { out[r] = out[r - 1];  r -= 1; }
+            out[r] = x;
+          }
+      i = e;
+    }
+  free(first);
+  free(all);
+  return out;
+}
+
 /* align.c:6166-6367 on an explicit set of per-thread buffers */
 static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
                           const char *dir1, const char *dir2, const char *ablock, const char *bblock, int lastRead)
@@ -325,7 +375,7 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
           n += 1;
         }
     }
-  qsort(all, (size_t) n, sizeof(Keyed), by_overlap);
+  all = sort_keyed(all, n);
 
   aid = split_block_name(ablock, aroot, sizeof(aroot));
   bid = split_block_name(bblock, broot, sizeof(broot));

@@ -547,7 +547,28 @@ static int64 run_tail(LaRecord *recs, size_t nrecs, const u16 *tpool,
                       const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec)
 { int64 ncheck = 0;
   const int ts = Trace_Spacing(spec);
-  std::sort(recs, recs + nrecs, RecOrder());
+  /* (work item, sequence) order = the reference's order of read pairs and of the alignments
+     inside one: a counting sort on the item (a wave emits the records of its item in sequence
+     order; the insertion pass below only guards that) */
+  std::vector<u32> ord(nrecs);
+  { u32 maxitem = 0;
+    for (size_t q = 0; q < nrecs; q++)
+      if (recs[q].item > maxitem) maxitem = recs[q].item;
+    std::vector<u32> first((size_t) maxitem + 2, 0);
+    for (size_t q = 0; q < nrecs; q++)
+      first[recs[q].item + 1] += 1;
+    for (size_t q = 1; q < first.size(); q++)
+      first[q] += first[q - 1];
+    for (size_t q = 0; q < nrecs; q++)
+      ord[first[recs[q].item]++] = (u32) q;
+    for (size_t q = 1; q < nrecs; q++)
+      { const u32 x = ord[q];
+        size_t r = q;
+        while (r > 0 && recs[ord[r - 1]].item == recs[x].item && recs[ord[r - 1]].seq > recs[x].seq)
+          { ord[r] = ord[r - 1];  r -= 1; }
+        ord[r] = x;
+      }
+  }
   Overlap_IO_Buffer *obuf = OVL_IO_Buffer(spec);
   std::vector<damar_path> am, bm;
   damar_tpool tp = { NULL, 0, 0 };
@@ -555,15 +576,15 @@ static int64 run_tail(LaRecord *recs, size_t nrecs, const u16 *tpool,
   size_t i = 0;
   while (i < nrecs)
     { size_t j = i;
-      while (j < nrecs && recs[j].item == recs[i].item)
+      while (j < nrecs && recs[ord[j]].item == recs[ord[i]].item)
         j += 1;
-      const int ar = recs[i].aread, br = recs[i].bread;
+      const int ar = recs[ord[i]].aread, br = recs[ord[i]].bread;
       const int al = ablock->reads[ar].rlen, bl = bblock->reads[br].rlen;
       const int doA = (al >= HGAP_MIN);
       const int doB = (SYMMETRIC && bl >= HGAP_MIN && (ar != br || !self || !comp));   /* filter.c:2300-2301 */
       am.clear();  bm.clear();  tp.top = 0;
       for (size_t q = i; q < j; q++)
-        { const LaRecord &r = recs[q];
+        { const LaRecord &r = recs[ord[q]];
           damar_path p;
           if (doA)
             { p.tlen = r.atlen;  p.diffs = r.diffs;
