@@ -400,7 +400,7 @@ int damar_bridge_pair(const damar_bridge_ctx *ctx, damar_path *jp, damar_path *k
   splice(p1, &box, p2, tp, ts);
   *jp = *p1;
   kp->abpos = -1;
-  damar_stat_bridges += 1;
+  __atomic_fetch_add(&damar_stat_bridges, 1, __ATOMIC_RELAXED);
 
   if (b1 != NULL)
     { /* the B view: roles of the sequences swapped (filter.c:1825-1829, 2025) */

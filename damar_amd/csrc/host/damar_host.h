@@ -51,6 +51,8 @@ void damar_emit_pair(damar_path *am, int na, damar_path *bm, int nb, damar_tpool
                      int comp, int ts, int aread, int bread,
                      const damar_bridge_ctx *bridge, Overlap_IO_Buffer *obuf, int64 *nrec);
 
+int damar_append_overlap_buffer(Overlap_IO_Buffer *dst, const Overlap_IO_Buffer *src);
+
 /* Detached overlap buffers for a writer thread (las.c) */
 typedef struct { int trace_space, nthreads, symmetric, only_identity; } damar_write_params;
 Overlap_IO_Buffer *damar_detach_overlap_buffers(Align_Spec *spec, damar_write_params *p);

@@ -206,6 +206,43 @@ int AddOverlapToBuffer(Overlap_IO_Buffer *b, Overlap *ovl, int tbytes)
   return 0;
 }
 
+/* Append every overlap of src (with its trace) to dst, in order: what AddOverlapToBuffer would
+ * have produced had the records been added to dst directly. */
+int damar_append_overlap_buffer(Overlap_IO_Buffer *dst, const Overlap_IO_Buffer *src)
+{ int    i;
+  uint64 base;
+
+  if (src->otop == 0)
+    return 0;
+  if (dst->otop + src->otop > dst->omax)
+    { dst->omax = (int) ((dst->otop + src->otop) * 1.2) + 1000;
+      dst->ovls = (Overlap *) realloc(dst->ovls, sizeof(Overlap) * (size_t) dst->omax);
+      if (dst->ovls == NULL)
+        return 1;
+    }
+  base = dst->ttop;
+  if (!dst->no_trace && src->ttop > 0)
+    { uint64 need = dst->ttop + src->ttop;
+      if (need >= dst->tmax * (uint64) dst->tbytes)
+        { while (need >= dst->tmax * (uint64) dst->tbytes)
+            dst->tmax = (uint64) (dst->tmax * 1.2) + 1000;
+          dst->trace = realloc(dst->trace, (size_t) dst->tmax * (size_t) dst->tbytes);
+          if (dst->trace == NULL)
+            return 1;
+        }
+      memcpy(((char *) dst->trace) + dst->ttop, src->trace, (size_t) src->ttop);
+      dst->ttop += src->ttop;
+    }
+  memcpy(dst->ovls + dst->otop, src->ovls, sizeof(Overlap) * (size_t) src->otop);
+  for (i = 0; i < src->otop; i++)
+    { Overlap *o = dst->ovls + dst->otop + i;
+      if (o->path.trace != NULL)
+        o->path.trace = (void *) (uintptr_t) ((uintptr_t) o->path.trace + base);
+    }
+  dst->otop += src->otop;
+  return 0;
+}
+
 /* align.c:3375-3396 */
 int Compress_TraceTo8(Overlap *ovl, int check)
 { uint16 *t16 = (uint16 *) ovl->path.trace;

@@ -102,7 +102,7 @@ static void fuse(damar_path *p1, int ap, const damar_path *p2, damar_tpool *tp, 
   int    n = 0, diff = 0, k;
   uint16 *dst;
 
-  damar_stat_fusions += 1;
+  __atomic_fetch_add(&damar_stat_fusions, 1, __ATOMIC_RELAXED);
   tpool_reserve(tp, len);
   at  = tp->top;
   tp->top += len;
@@ -131,7 +131,7 @@ int damar_handle_redundancies(damar_path *am, int n, damar_path *bm, int comp, i
 { int hasB = (bm != NULL);
   int j, k, dist, awhen = 0, bwhen = 0, out;
 
-  damar_stat_redundancy_calls += 1;
+  __atomic_fetch_add(&damar_stat_redundancy_calls, 1, __ATOMIC_RELAXED);
 
   /* pass 1: alignments that share a trace point are fused (filter.c:1833-1946) */
   for (j = 1; j < n; j++)

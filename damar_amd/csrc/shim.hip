@@ -543,40 +543,19 @@ static void hostbuf_put(HostBuf *h)
   HB_free.push_back(h);
 }
 
-static int64 run_tail(LaRecord *recs, size_t nrecs, const u16 *tpool,
-                      const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec)
+/* One contiguous range [lo, hi) of the ordered records (whole read pairs): filter.c:2442-2483
+ * per pair, results appended to obuf. */
+static int64 tail_range(const LaRecord *recs, const u32 *ord, size_t lo, size_t hi, const u16 *tpool,
+                        const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, int ts,
+                        Overlap_IO_Buffer *obuf)
 { int64 ncheck = 0;
-  const int ts = Trace_Spacing(spec);
-  /* (work item, sequence) order = the reference's order of read pairs and of the alignments
-     inside one: a counting sort on the item (a wave emits the records of its item in sequence
-     order; the insertion pass below only guards that) */
-  std::vector<u32> ord(nrecs);
-  { u32 maxitem = 0;
-    for (size_t q = 0; q < nrecs; q++)
-      if (recs[q].item > maxitem) maxitem = recs[q].item;
-    std::vector<u32> first((size_t) maxitem + 2, 0);
-    for (size_t q = 0; q < nrecs; q++)
-      first[recs[q].item + 1] += 1;
-    for (size_t q = 1; q < first.size(); q++)
-      first[q] += first[q - 1];
-    for (size_t q = 0; q < nrecs; q++)
-      ord[first[recs[q].item]++] = (u32) q;
-    for (size_t q = 1; q < nrecs; q++)
-      { const u32 x = ord[q];
-        size_t r = q;
-        while (r > 0 && recs[ord[r - 1]].item == recs[x].item && recs[ord[r - 1]].seq > recs[x].seq)
-          { ord[r] = ord[r - 1];  r -= 1; }
-        ord[r] = x;
-      }
-  }
-  Overlap_IO_Buffer *obuf = OVL_IO_Buffer(spec);
   std::vector<damar_path> am, bm;
   damar_tpool tp = { NULL, 0, 0 };
   const char *abase = (const char *) ablock->bases, *bbase = (const char *) bblock->bases;
-  size_t i = 0;
-  while (i < nrecs)
+  size_t i = lo;
+  while (i < hi)
     { size_t j = i;
-      while (j < nrecs && recs[ord[j]].item == recs[ord[i]].item)
+      while (j < hi && recs[ord[j]].item == recs[ord[i]].item)
         j += 1;
       const int ar = recs[ord[i]].aread, br = recs[ord[i]].bread;
       const int al = ablock->reads[ar].rlen, bl = bblock->reads[br].rlen;
@@ -612,6 +591,82 @@ static int64 run_tail(LaRecord *recs, size_t nrecs, const u16 *tpool,
       i = j;
     }
   free(tp.val);
+  return ncheck;
+}
+
+static int tail_threads(void)
+{ static int n = 0;
+  if (n == 0)
+    { const char *e = getenv("DAMAR_TAIL_THREADS");
+      n = e ? atoi(e) : 4;
+      if (n < 1) n = 1;
+      if (n > 64) n = 64;
+    }
+  return n;
+}
+
+static int64 run_tail(LaRecord *recs, size_t nrecs, const u16 *tpool,
+                      const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec)
+{ const int ts = Trace_Spacing(spec);
+  /* (work item, sequence) order = the reference's order of read pairs and of the alignments
+     inside one: a counting sort on the item (a wave emits the records of its item in sequence
+     order; the insertion pass below only guards that) */
+  std::vector<u32> ord(nrecs);
+  { u32 maxitem = 0;
+    for (size_t q = 0; q < nrecs; q++)
+      if (recs[q].item > maxitem) maxitem = recs[q].item;
+    std::vector<u32> first((size_t) maxitem + 2, 0);
+    for (size_t q = 0; q < nrecs; q++)
+      first[recs[q].item + 1] += 1;
+    for (size_t q = 1; q < first.size(); q++)
+      first[q] += first[q - 1];
+    for (size_t q = 0; q < nrecs; q++)
+      ord[first[recs[q].item]++] = (u32) q;
+    for (size_t q = 1; q < nrecs; q++)
+      { const u32 x = ord[q];
+        size_t r = q;
+        while (r > 0 && recs[ord[r - 1]].item == recs[x].item && recs[ord[r - 1]].seq > recs[x].seq)
+          { ord[r] = ord[r - 1];  r -= 1; }
+        ord[r] = x;
+      }
+  }
+  Overlap_IO_Buffer *obuf = OVL_IO_Buffer(spec);
+  const int nthr = (nrecs >= 8192) ? tail_threads() : 1;
+  if (nthr == 1)
+    return tail_range(recs, ord.data(), 0, nrecs, tpool, ablock, bblock, self, comp, ts, obuf);
+
+  /* Read pairs are independent: cut the ordered records into nthr ranges at pair boundaries,
+     let each thread fill a private buffer, append the buffers in order. */
+  std::vector<size_t> cut(nthr + 1, nrecs);
+  cut[0] = 0;
+  for (int t = 1; t < nthr; t++)
+    { size_t c = std::max(cut[t - 1], nrecs * (size_t) t / nthr);
+      while (c < nrecs && c > 0 && recs[ord[c]].item == recs[ord[c - 1]].item)
+        c += 1;
+      cut[t] = c;
+    }
+  std::vector<Overlap_IO_Buffer *> part(nthr, (Overlap_IO_Buffer *) NULL);
+  std::vector<int64> got(nthr, 0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthr; t++)
+    { part[t] = CreateOverlapBuffer(4 * nthr, obuf->tbytes ? obuf->tbytes : 1, obuf->no_trace);
+      if (part[t] == NULL)
+        die();
+      th.emplace_back([&, t] { got[t] = tail_range(recs, ord.data(), cut[t], cut[t + 1], tpool, ablock, bblock,
+                                                    self, comp, ts, part[t]); });
+    }
+  int64 ncheck = 0;
+  for (int t = 0; t < nthr; t++)
+    { th[t].join();
+      if (damar_append_overlap_buffer(obuf, part[t]))
+        { fprintf(stderr, "damar: FATAL: out of memory appending overlaps\n");
+          die();
+        }
+      free(part[t]->ovls);
+      free(part[t]->trace);
+      free(part[t]);
+      ncheck += got[t];
+    }
   return ncheck;
 }
 
