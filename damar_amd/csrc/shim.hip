@@ -1379,3 +1379,73 @@ extern "C" double damar_bench_sort_u32(uint32_t n, int nbits, int reps, uint32_t
   HIP_CHECK(hipFree(k1));   HIP_CHECK(hipFree(v1));  HIP_CHECK(hipFree(sw));
   return total / reps;
 }
+
+/***** align.h:223-259: Work_Data and the single-call Local_Alignment ***********************************/
+
+struct WorkData
+{ Path   bpath;
+  std::vector<uint16> atrace, btrace;
+};
+
+extern "C" Work_Data *New_Work_Data(void)             /* align.c:135-160 */
+{ return (Work_Data *) new WorkData();
+}
+
+extern "C" void Free_Work_Data(Work_Data *work)       /* align.c:162-173 */
+{ delete (WorkData *) work;
+}
+
+/* align.c:1904-2097 for one pair of sequences, computed by the same wave kernel as Match_Filter
+ * (one task through the batch path: the two sequences travel to HBM and back per call, so this
+ * entry point is for callers that need the reference's API, not for throughput).  Supported call
+ * shape: the one filter.c:2316 uses, low == hgh (seed diagonal) and no borders (lbord, hbord < 0);
+ * anything else exits as the reference's batch-mode errors do.  align->aseq/bseq follow the
+ * block layout (a 4 before the first and after the last base). */
+extern "C" Path *Local_Alignment(Alignment *align, Work_Data *work, Align_Spec *spec,
+                                 int low, int hgh, int anti, int lbord, int hbord)
+{ ensure_init();
+  WorkData *w = (WorkData *) work;
+  if (low != hgh || lbord >= 0 || hbord >= 0)
+    { fprintf(stderr, "damar: Local_Alignment: only the seed-diagonal call shape (low == hgh, no borders) is built\n");
+      exit(1);
+    }
+  HITS_DB   db[2];
+  HITS_READ rd[2][2];
+  std::vector<char> buf[2];
+  const char *seq[2] = { align->aseq, align->bseq };
+  const int   len[2] = { align->alen, align->blen };
+  const int   same = (align->aseq == align->bseq);
+  for (int i = 0; i < 2; i++)
+    { memset(&db[i], 0, sizeof(HITS_DB));
+      memset(rd[i], 0, sizeof(rd[i]));
+      buf[i].assign((size_t) len[i] + 2, 4);
+      memcpy(buf[i].data() + 1, seq[i], (size_t) len[i]);
+      rd[i][0].rlen = len[i];  rd[i][0].boff = 0;  rd[i][1].boff = len[i] + 1;
+      db[i].nreads = db[i].ureads = 1;  db[i].maxlen = len[i];  db[i].totlen = len[i];
+      db[i].bases = buf[i].data() + 1;  db[i].reads = rd[i];
+    }
+  damar_dev_block *ab = damar_block_upload(&db[0]);
+  damar_dev_block *bb = same ? ab : damar_block_upload(&db[1]);
+  const int mtp = 2 * (std::max(len[0], len[1]) / Trace_Spacing(spec) + 2) + 8;
+  std::vector<uint16> tr((size_t) 4 * mtp + 64);
+  int   task[4] = { 0, 0, low, anti }, paths[12];
+  int64 toff[2];
+  if (damar_local_alignment_batch(ab, bb, (int) (align->flags & COMP_FLAG), spec, task, 1, paths, toff,
+                                  tr.data(), (int64) tr.size()))
+    { fprintf(stderr, "damar: Local_Alignment: trace buffer too small\n");
+      exit(1);
+    }
+  damar_block_free(ab);
+  if (!same)
+    damar_block_free(bb);
+  Path *ap = align->path;
+  ap->abpos = paths[0];  ap->bbpos = paths[1];  ap->aepos = paths[2];  ap->bepos = paths[3];
+  ap->diffs = paths[4];  ap->tlen = paths[5];
+  w->atrace.assign(tr.begin() + toff[0], tr.begin() + toff[0] + paths[5]);
+  ap->trace = w->atrace.data();
+  w->bpath.abpos = paths[6];  w->bpath.bbpos = paths[7];  w->bpath.aepos = paths[8];  w->bpath.bepos = paths[9];
+  w->bpath.diffs = paths[10];  w->bpath.tlen = paths[11];
+  w->btrace.assign(tr.begin() + toff[1], tr.begin() + toff[1] + paths[11]);
+  w->bpath.trace = w->btrace.data();
+  return &w->bpath;
+}

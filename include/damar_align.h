@@ -72,6 +72,15 @@ int         Num_Threads(Align_Spec *spec);
 int         Only_Identity(Align_Spec *spec);
 int         Symmetric(Align_Spec *spec);
 
+/* align.h:223-259.  Local_Alignment runs the same wave kernel as Match_Filter for ONE pair of
+ * sequences; built for the call shape of filter.c:2316 (low == hgh = seed diagonal, lbord and
+ * hbord < 0).  It fills align->path (A-view, trace = uint16 pairs) and returns the B-view path;
+ * both point into `work` and stay valid until the next call with it (align.h:245-249). */
+Work_Data *New_Work_Data(void);
+void       Free_Work_Data(Work_Data *work);
+Path      *Local_Alignment(Alignment *align, Work_Data *work, Align_Spec *spec,
+                           int low, int hgh, int anti, int lbord, int hbord);
+
 /* align.c:5969-6102, 6166-6380 */
 Overlap_IO_Buffer *CreateOverlapBuffer(int nthreads, int tbytes, int no_trace);
 Overlap_IO_Buffer *OVL_IO_Buffer(Align_Spec *spec);

@@ -38,7 +38,8 @@ def test_library_exports_every_declared_symbol(built):
 def test_reference_interface_names_and_globals(built):
     L = ctypes.CDLL(os.path.join(ROOT, "damar_amd", "libdamar_hip.so"))
     for fn in ("Set_Filter_Params", "Sort_Kmers", "Match_Filter", "New_Align_Spec", "Write_Overlap_Buffer",
-               "Reset_Overlap_Buffer", "AddOverlapToBuffer", "OVL_IO_Buffer", "Compress_TraceTo8"):
+               "Reset_Overlap_Buffer", "AddOverlapToBuffer", "OVL_IO_Buffer", "Compress_TraceTo8",
+               "New_Work_Data", "Free_Work_Data", "Local_Alignment", "Match_Self"):
         assert hasattr(L, fn)
     for g in ("BIASED", "VERBOSE", "MINOVER", "HGAP_MIN", "SYMMETRIC", "IDENTITY"):
         ctypes.c_int.in_dll(L, g)

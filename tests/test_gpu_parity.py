@@ -191,6 +191,57 @@ def test_gpu_local_alignment_batch_equals_oracle(gpu, comp):
     L.damar_block_free(bblk)
 
 
+def test_gpu_local_alignment_c_abi_single_call(gpu):
+    """align.h's own entry points (New_Work_Data / Local_Alignment / Free_Work_Data) for the call
+    shape of filter.c:2316: A-view path through align->path, B-view path returned, vs the oracle."""
+    import oracle_api as O
+    from damar_amd import api
+    L = gpu
+
+    class Alignment(C.Structure):
+        _fields_ = [("path", C.POINTER(O.Path)), ("flags", C.c_uint32), ("aseq", C.c_void_p), ("bseq", C.c_void_p),
+                    ("alen", C.c_int), ("blen", C.c_int)]
+    L.New_Work_Data.restype = C.c_void_p
+    L.Free_Work_Data.argtypes = [C.c_void_p]
+    L.Local_Alignment.restype = C.POINTER(O.Path)
+    L.Local_Alignment.argtypes = [C.POINTER(Alignment), C.c_void_p, C.c_void_p] + [C.c_int] * 5
+    L.Set_Filter_Params(14, 6, 0, 35, 4)
+    an = os.path.join(GOLDEN, "indel", "G.1")
+    adb, oadb = api.read_block(an), O.read_block(an)
+    prm = O.params()
+    pa, na, _ = O.sort_kmers(oadb, prm)
+    seeds = O.seed_pairs(oadb, oadb, pa, na, pa, na, 1, 0, prm)
+    rng = random.Random(11)
+    ospec = O.lib().New_Align_Spec(.70, 100, oadb.freq, 1, 1, 0, 0, 1)
+    spec = L.New_Align_Spec(.70, 100, adb.freq, 1, 1, 0, 0, 1)
+    work = L.New_Work_Data()
+    maxtp = 4 * (adb.maxlen // 100 + 4)
+    done = 0
+    for i in rng.sample(range(len(seeds)), 40):
+        s = seeds[i]
+        ar, br, dg = int(s["aread"]), int(s["bread"]), int(s["diag"])
+        if ar == br:
+            continue
+        anti = int(2 * s["apos"] - s["diag"])
+        ap = O.Path()
+        al = Alignment()
+        al.path = C.pointer(ap)
+        al.flags = 0
+        al.aseq = adb.bases + adb.reads[ar].boff
+        al.bseq = adb.bases + adb.reads[br].boff
+        al.alen, al.blen = adb.reads[ar].rlen, adb.reads[br].rlen
+        bp = L.Local_Alignment(C.byref(al), work, spec, dg, dg, anti, -1, -1).contents
+        want, wat, wbt = O.local_alignment(oadb, oadb, ar, br, 0, dg, anti, ospec, maxtp)
+        got = [ap.abpos, ap.bbpos, ap.aepos, ap.bepos, ap.diffs, ap.tlen,
+               bp.abpos, bp.bbpos, bp.aepos, bp.bepos, bp.diffs, bp.tlen]
+        assert got == want
+        assert list(C.cast(ap.trace, C.POINTER(C.c_uint16))[:ap.tlen]) == wat
+        assert list(C.cast(bp.trace, C.POINTER(C.c_uint16))[:bp.tlen]) == wbt
+        done += 1
+    assert done >= 20
+    L.Free_Work_Data(work)
+
+
 def test_gpu_config1_known_answer(gpu, tmp_path):
     """BASELINE config 1 (simulator 0.5 -c20 -r1 -e.15, 930 reads, 10 Mbp): the reference's
     .las md5 08bcb3ac... (reproduced in this repo's build container)."""
