@@ -57,6 +57,8 @@ typedef struct
 
 void damar_launch_merge_count(const MergeArgs *m, u32 *cnt, u32 *jb, hipStream_t st);
 void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32 *cnt, hipStream_t st);
+void damar_launch_merge_hitgram(const MergeArgs *m, const u32 *off, u64 total, u32 ngram, unsigned long long *gram,
+                                hipStream_t st);
 /* cnt = hits per A entry, toff = exclusive offset of each DAMAR_SCAN_TILE-sized tile of cnt */
 void damar_launch_merge_emit(const MergeArgs *m, const u32 *cnt, const u32 *toff, const u32 *jb, u64 nhits,
                              u64 *keys, u32 *vals, hipStream_t st);

@@ -110,6 +110,39 @@ void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32
   hipLaunchKernelGGL(merge_limit, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, cnt);
 }
 
+/* hitgram[ct] = number of equal-code runs whose mutual count is ct (< ngram), filter.c:1039-1165
+ * count_thread.  Only launched when the host must lower the cap under memory pressure
+ * (filter.c:2634-2699), so plain global atomics will do.  Cross: ct = na * nb; self: the run's
+ * count is the sum of its entries' counts = off[run end] - off[run start] of the current scan. */
+__global__ __launch_bounds__(256)
+void merge_hitgram(MergeArgs m, const u32 *__restrict__ off, u64 total, u32 ngram, unsigned long long *__restrict__ gram)
+{ u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= m.alen)
+    return;
+  const u32 c = m.acode[i];
+  if (i > 0 && m.acode[i - 1] == c)
+    return;                                     /* one thread per run of A */
+  u32 jb, ib, ja, ia;
+  code_run(m.bcode, m.btab, m.kbits - m.btbits, c, &jb, &ib);
+  if (ib <= jb)
+    return;
+  code_run(m.acode, m.atab, m.kbits - m.atbits, c, &ja, &ia);
+  u64 ct;
+  if (!m.self)
+    ct = (u64) (ia - ja) * (u64) (ib - jb);
+  else
+    ct = ((ia >= m.alen) ? total : (u64) off[ia]) - (u64) off[ja];
+  if (ct < (u64) ngram)
+    atomicAdd(&gram[ct], 1ull);
+}
+
+void damar_launch_merge_hitgram(const MergeArgs *m, const u32 *off, u64 total, u32 ngram, unsigned long long *gram,
+                                hipStream_t st)
+{ if (m->alen == 0)
+    return;
+  hipLaunchKernelGGL(merge_hitgram, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, ngram, gram);
+}
+
 /* One workgroup per tile of DAMAR_SCAN_TILE A entries: the tile's hit counts are scanned in
  * LDS, then the tile's hits are dealt out to the threads in order, each finding its A entry by
  * a search of the LDS prefix (no walk over the global offsets), so the seed pairs leave in

@@ -71,6 +71,7 @@ static hipStream_t  G_st;
 static hipDeviceProp_t G_prop;
 static hipEvent_t   G_ev[16];
 static double       G_ms[DAMAR_T_COUNT];
+static int          G_limit = 0;          /* the mutual-count cap the last Match_Filter used */
 static double       H_ms[8];              /* host wall clock per phase (DAMAR_HOSTPROF=1 prints them at drain) */
 static const char  *H_name[8] = { "index_build", "match:front", "match:order", "match:report", "match:d2h",
                                   "match:submit", "match:total", "final_drain" };
@@ -177,6 +178,7 @@ static float lap(int i, int j)      { float ms = 0; HIP_CHECK(hipEventElapsedTim
 
 extern "C" void damar_last_timings(double *ms)  { memcpy(ms, G_ms, sizeof(G_ms)); }
 extern "C" void damar_last_counters(int64 *c)   { memcpy(c, G_cnt, sizeof(G_cnt)); }
+extern "C" int  damar_last_limit(void)          { return G_limit; }
 
 /***** blocks ************************************************************************************/
 
@@ -930,8 +932,10 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
       HIP_CHECK(hipStreamSynchronize(G_st));
     }
   if (MEM_LIMIT > 0)
-    { /* filter.c:2634-2699: with the counts above every run below MAXGRAM is kept; the
-         reference lowers that cap only if the kept seeds exceed `avail`. */
+    { /* filter.c:2634-2699.  The counts above keep every run below MAXGRAM; the reference lowers
+         that cap to the first mutual count at which the kept seeds no longer fit `avail`.  That
+         only happens under memory pressure, so the histogram is built only then. */
+      int   limit = MAXGRAM;
       int64 avail = (int64) (MEM_LIMIT - (uint64) (sizeof_db(ablock) + sizeof_db(bblock))) / 16;
       if (aidx == bidx || avail > (int64) alen + 2 * (int64) blen)
         avail = (avail - alen) / 2;
@@ -939,14 +943,60 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
         avail = avail - ((int64) alen + blen);
       avail = (int64) (avail * .98);
       if ((int64) total > avail)
-        { fprintf(stderr, "damar: FATAL: host memory limit would cap mutual k-mer matches below %d "
-                          "(%llu seeds > %lld); the adaptive cap of filter.c:2652-2659 is not built yet\n",
-                  MAXGRAM, (unsigned long long) total, (long long) avail);
-          die();
+        { std::vector<unsigned long long> histo(MAXGRAM);
+          unsigned long long *dgram = (unsigned long long *) dmalloc(sizeof(unsigned long long) * MAXGRAM);
+          HIP_CHECK(hipMemsetAsync(dgram, 0, sizeof(unsigned long long) * MAXGRAM, G_st));
+          if (self)                   /* run totals of the counts as they stand (runs >= MAXGRAM already dropped) */
+            damar_exclusive_scan_u32(cnt, off, alen, scw, tot, G_st);
+          damar_launch_merge_hitgram(&m, off, total, MAXGRAM, dgram, G_st);
+          HIP_CHECK(hipMemcpyAsync(histo.data(), dgram, sizeof(unsigned long long) * MAXGRAM, hipMemcpyDeviceToHost, G_st));
+          HIP_CHECK(hipStreamSynchronize(G_st));
+          HIP_CHECK(hipFree(dgram));
+          int64 tom = 0;
+          int   j;
+          for (j = 0; j < MAXGRAM; j++)
+            { tom += (int64) j * (int64) histo[j];
+              if (tom > avail)
+                break;
+            }
+          limit = j;
+          if (limit <= 1)
+            { fprintf(stderr, "\nError: Insufficient ");
+              if (MEM_LIMIT == MEM_PHYSICAL)
+                fprintf(stderr, " physical memory (%.1fGb), reduce block size\n", (1. * MEM_LIMIT) / 0x40000000ll);
+              else
+                { fprintf(stderr, " memory allocation (%.1fGb),", (1. * MEM_LIMIT) / 0x40000000ll);
+                  fprintf(stderr, " reduce block size or increase allocation\n");
+                }
+              fflush(stderr);
+              exit(1);
+            }
+          if (limit < 10)
+            { fprintf(stderr, "\nWarning: Sensitivity hampered by low ");
+              if (MEM_LIMIT == MEM_PHYSICAL)
+                fprintf(stderr, " physical memory (%.1fGb), reduce block size\n", (1. * MEM_LIMIT) / 0x40000000ll);
+              else
+                { fprintf(stderr, " memory allocation (%.1fGb),", (1. * MEM_LIMIT) / 0x40000000ll);
+                  fprintf(stderr, " reduce block size or increase allocation\n");
+                }
+              fflush(stderr);
+            }
+          /* recount with the lower cap */
+          m.limit = (u32) limit;
+          if (self)
+            damar_launch_merge_limit(&m, off, total, cnt, G_st);
+          else
+            damar_launch_merge_count(&m, cnt, jb, G_st);
+          damar_tile_offsets_u32(cnt, alen, scw, tot, G_st);
+          HIP_CHECK(hipMemcpyAsync(&total, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+          HIP_CHECK(hipStreamSynchronize(G_st));
         }
+      G_limit = limit;
       if (VERBOSE)
-        printf("\n   Capping mutual k-mer matches over %d (effectively -t%d)\n", MAXGRAM, 100);
+        printf("\n   Capping mutual k-mer matches over %d (effectively -t%d)\n", limit, (int) sqrt(1. * limit));
     }
+  else
+    G_limit = 0x7fffffff;
   nhits = (int64) total;
   if (VERBOSE)
     { printf("   Hit count = %lld\n", (long long) nhits);

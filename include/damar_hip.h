@@ -82,6 +82,10 @@ void Match_Self(char *aname, HITS_DB *ablock, Align_Spec *settings);
  * Returns the number of seed pairs; copies at most `cap` records. */
 int64 damar_last_seeds(void *out, int64 cap);
 
+/* The cap on mutual k-mer matches per code that the last damar_match applied (filter.c:2634-2702:
+ * 10000 unless the host memory limit forces it lower; INT32_MAX when MEM_LIMIT is 0). */
+int damar_last_limit(void);
+
 /* Test hook: batch Local_Alignment (align.c:1904 with low == hgh == diag, no borders)
  * on the GPU.  tasks[4*i..] = aread, bread, diag, anti (block-local read ids).
  * paths[12*i..] = A-view abpos,bbpos,aepos,bepos,diffs,tlen then the same for the

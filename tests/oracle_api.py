@@ -74,11 +74,16 @@ def seed_pairs(adb, bdb, ap, alen, bp, blen, self_, comp, prm):
     nh, lim = c_int64(0), C.c_int(0)
     p = lib().oracle_seed_pairs(C.byref(adb), C.byref(bdb), ap, alen, bp, blen, self_, comp, C.byref(prm),
                                 C.byref(nh), C.byref(lim))
+    global LAST_LIMIT
+    LAST_LIMIT = lim.value
     if not p:
         return np.zeros(0, SEED_DT)
     arr = np.ctypeslib.as_array((C.c_char * (16 * nh.value)).from_address(p)).view(SEED_DT).copy()
     lib().free(p)
     return arr
+
+
+LAST_LIMIT = 0          # the cap on mutual k-mer matches the last seed_pairs() call selected
 
 
 def local_alignment(adb, bdb, ar, br, comp, diag, anti, spec, maxtp):

@@ -140,6 +140,73 @@ def test_gpu_seed_pairs_equal_oracle(gpu, comp, cross):
     L.damar_block_free(ablk)
 
 
+@pytest.mark.parametrize("cross", [0, 1])
+def test_gpu_memory_limit_lowers_the_cap_like_the_oracle(gpu, cross):
+    """filter.c:2634-2699: when the seeds would not fit the host memory limit the cap on mutual
+    k-mer matches drops from 10000 to the first count at which they no longer fit.  MEM_LIMIT is
+    squeezed until the oracle's rule selects a cap well below 10000; the GPU path must select the
+    same cap and keep exactly the same seeds."""
+    import oracle_api as O
+    from damar_amd import api
+    L = gpu
+    L.Set_Filter_Params(14, 6, 0, 35, 4)
+    L.damar_set_async(0)
+    api.set_globals()
+    an = os.path.join(GOLDEN, "tandem", "G.1")          # repeat-rich reads: many codes with large counts
+    adb, oadb = api.read_block(an), O.read_block(an)
+    bdb, obdb = api.read_block(an), O.read_block(an)
+    if cross:
+        L.damar_complement_block(C.byref(bdb), 1)
+        O.lib().damar_complement_block(C.byref(obdb), 1)
+    prm = O.params()
+    pa, na, _ = O.sort_kmers(oadb, prm)
+    pb, nb = (O.sort_kmers(obdb, prm)[:2]) if cross else (pa, na)
+    full = len(O.seed_pairs(oadb, obdb, pa, na, pb, nb, 0 if cross else 1, cross, prm))
+    dbb = 88 + 32 * (oadb.nreads + 2) + oadb.totlen + oadb.nreads + 4 + len(oadb.path or b"") + 1
+    want, mem = None, 0
+    for frac in (.9, .8, .7, .6):                       # avail as a fraction of the uncapped seeds
+        avail = int(full * frac / .98) + 8
+        words = (2 * avail + na) if not cross else (avail + na + nb)     # undo filter.c:2646-2650
+        if cross and words > na + 2 * nb:
+            words = 2 * avail + na
+        mem = 16 * words + 2 * dbb
+        prm.mem_limit = mem
+        w = O.seed_pairs(oadb, obdb, pa, na, pb, nb, 0 if cross else 1, cross, prm)
+        if 2 < O.LAST_LIMIT < 5000 and 0 < len(w) < full:
+            want = w
+            break
+    assert want is not None, "no memory limit found that lowers the cap on this fixture"
+    lim = O.LAST_LIMIT
+    memvar = C.c_uint64.in_dll(L, "MEM_LIMIT")
+    old = memvar.value
+    try:
+        memvar.value = mem
+        n = C.c_int(0)
+        ablk = L.damar_block_upload(C.byref(adb))
+        aidx = L.damar_index_build(ablk, 0, C.byref(n))
+        if cross:
+            bblk = L.damar_block_upload(C.byref(bdb))
+            bidx = L.damar_index_build(bblk, 0, C.byref(n))
+        else:
+            bblk, bidx = None, aidx
+        spec = L.New_Align_Spec(.70, 100, adb.freq, 4, 1, 0, 0, 1)
+        L.damar_last_seeds(None, 1)
+        cnt = (api.c_int64 * 3)()
+        L.damar_match(C.byref(adb), C.byref(bdb), aidx, bidx, 0 if cross else 1, cross, spec, cnt)
+        got = np.zeros(int(cnt[0]), dtype=O.SEED_DT)
+        assert L.damar_last_seeds(got.ctypes.data, len(got)) == len(want)
+        L.damar_last_seeds(None, 0)
+        assert L.damar_last_limit() == lim
+        assert np.array_equal(got, want)
+    finally:
+        memvar.value = old
+    if bblk:
+        L.damar_index_free(bidx)
+        L.damar_block_free(bblk)
+    L.damar_index_free(aidx)
+    L.damar_block_free(ablk)
+
+
 @pytest.mark.parametrize("comp", [0, 1])
 def test_gpu_local_alignment_batch_equals_oracle(gpu, comp):
     """K6 alone: thousands of (read pair, diagonal, anti-diagonal) seeds -- including seeds the
