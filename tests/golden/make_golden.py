@@ -11,6 +11,11 @@ reference daligner produced from them.  No reference source is stored here.
 config2_ref_md5.txt is different: md5 of the 16 .las files the reference daligner -j16
 wrote for BASELINE config 2 (`simdb . SIM 27 -c20 -r2 -e.15 -S135`, full HPCdaligner plan)
 on the MI355X box's host (scripts/gpu_c2_parity.sh).
+
+`make_golden.py memlimit` prints the known answer of the memory-limit case (filter.c:2634-2699
+under -M1): `simdb . R 0.1 -c250 -r5 -e.15 -S200 ; daligner -v -k14 -M1 -j8 R R` with the real
+reference -> caps 210 / 184, hit counts 16,418,362 / 13,604,118, R.las 164343834 bytes, md5
+759225b7cbbae785076eec906a56859f (tests/test_gpu_parity.py::test_gpu_cli_memory_limit_known_answer).
 """
 import os
 import random
@@ -160,9 +165,25 @@ def derive(kind, work):
     return dbdir, "G"
 
 
+def memlimit():
+    import hashlib
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        run([SIMDB, d, "R", "0.1", "-c250", "-r5", "-e.15", "-S200"], d, stdout=subprocess.DEVNULL)
+        out = subprocess.run([os.path.join(REF, "daligner"), "-v", "-k14", "-M1", "-j8", "R", "R"], cwd=d, check=True,
+                             stdout=subprocess.PIPE, text=True).stdout
+        for ln in out.splitlines():
+            if "Capping" in ln or "Hit count" in ln:
+                print(ln.strip())
+        las = os.path.join(d, "R.las")
+        print(os.path.getsize(las), hashlib.md5(open(las, "rb").read()).hexdigest())
+
+
 def main():
     if not os.path.exists(os.path.join(REF, "daligner")):
         sys.exit("oracle/_ref/daligner missing: make -C oracle -f Makefile.ref")
+    if sys.argv[1:] == ["memlimit"]:
+        return memlimit()
     import tempfile
     dbs = {}
     only = set(sys.argv[1:])

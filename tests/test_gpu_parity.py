@@ -61,6 +61,24 @@ def test_gpu_cli_binary_equals_reference_golden(gpu, tmp_path, name):
     assert compare_las(case, str(tmp_path)) == []
 
 
+def test_gpu_cli_memory_limit_known_answer(gpu, tmp_path):
+    """daligner -M1 on a 25 Mbp block of 250x coverage: the REAL reference (oracle/_ref/daligner
+    -v -k14 -M1 -j8 R R in the build container, tests/golden/make_golden.py memlimit) lowers the
+    cap on mutual k-mer matches to 210 (N) / 184 (C) and writes this .las."""
+    import subprocess
+    d = str(tmp_path)
+    subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "simdb"), d, "R", "0.1", "-c250", "-r5", "-e.15", "-S200"],
+                   check=True, stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "daligner"), "-v", "-k14", "-M1", "-j8", "R", "R"],
+                         cwd=d, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240).stdout
+    caps = [ln.split()[5] for ln in out.splitlines() if "Capping mutual k-mer matches over" in ln]
+    assert caps == ["210", "184"]
+    assert "Hit count = 16418362" in out and "Hit count = 13604118" in out          # the reference prints 16,418,362
+    las = os.path.join(d, "R.las")
+    assert os.path.getsize(las) == 164343834
+    assert hashlib.md5(open(las, "rb").read()).hexdigest() == "759225b7cbbae785076eec906a56859f"
+
+
 def _index_as_records(L, idx, n):
     import oracle_api as O
     buf = np.zeros(n, dtype=O.KMER_DT)
