@@ -431,11 +431,6 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
 
         { const int ac = rV;
           int am = lane_dn(rV), ap = lane_up(rV);
-          /* both neighbours' inherited state, fetched before the choice is known */
-          const int mU = lane_up(rM), mD = lane_dn(rM), haU = lane_up(rHA), haD = lane_dn(rHA);
-          const int hbU = lane_up(rHB), hbD = lane_dn(rHB);
-          const int tlU = lane_up((int) (u32) rT), tlD = lane_dn((int) (u32) rT);
-          const int thU = lane_up((int) (u32) (rT >> 32)), thD = lane_dn((int) (u32) (rT >> 32));
           int dl;                                     /* predecessor = k + dl */
           if (k - 1 < low) am = edge;
           if (k + 1 > hgh) ap = edge;
@@ -449,14 +444,17 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
               else         dl = (ac > am) ? -1 : 0;
               v = (dl == 0) ? ac - 2 : ((dl == -1) ? am - 1 : ap - 1);
             }
-          m   = (dl == 0) ? rM  : ((dl > 0) ? mU  : mD);
-          ha  = (dl == 0) ? rHA : ((dl > 0) ? haU : haD);
-          hb  = (dl == 0) ? rHB : ((dl > 0) ? hbU : hbD);
-          ham = hbm = 0;            /* the head marks are fetched from the cells only when a mark is crossed */
-          { const u32 tlo = (dl == 0) ? (u32) rT : (u32) ((dl > 0) ? tlU : tlD);
-            const u32 thi = (dl == 0) ? (u32) (rT >> 32) : (u32) ((dl > 0) ? thU : thD);
+          /* the predecessor's inherited state through the LDS crossbar (ds_bpermute: no VALU
+             cycles, and the wave is bound by VALU issue), one gather per field */
+          { const int src = ((lane + dl) & 63) << 2;
+            m  = __builtin_amdgcn_ds_bpermute(src, rM);
+            ha = __builtin_amdgcn_ds_bpermute(src, rHA);
+            hb = __builtin_amdgcn_ds_bpermute(src, rHB);
+            const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+            const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
             b = ((u64) thi << 32) | tlo;
           }
+          ham = hbm = 0;            /* the head marks are fetched from the cells only when a mark is crossed */
         }
 
         if (act)
