@@ -135,12 +135,12 @@ __device__ __forceinline__ u64 load8(const u8 *p)
  * leaving the 60-column window was a 0; n matches at once examine bits 60..61-n of b. */
 /* Returns 0, or 1 if the snake stopped on A's terminator, 2 if on B's (B is tested first).
  * Everything is passed and returned by value so that nothing lives in scratch memory. */
-struct SnakeOut { int y, m, hit; u64 b; };
+struct SnakeOut { int y, m; bool ahit, bhit; u64 b; };   /* stopped on A's / B's terminator (B is tested first) */
 
 template <int REV>
 __device__ __forceinline__ SnakeOut snake(const u8 *a, const u8 *bq, int y, int m, u64 b)
 { const u64 LO7 = 0x7f7f7f7f7f7f7f7full, HI8 = 0x8080808080808080ull;
-  int hit = 0;
+  bool ahit = false, bhit = false;
   /* bounded by construction: every read ends in a 4, the buffer in 64 of them */
   for (;;)
     { const u64 wa = REV ? load8(a + y - 7) : load8(a + y);
@@ -162,12 +162,13 @@ __device__ __forceinline__ SnakeOut snake(const u8 *a, const u8 *bq, int y, int 
       if (stop)
         { const int bi = REV ? 7 - n : n;
           const u32 cb = (u32) (wb >> (8 * bi)) & 0xff, ca = (u32) (wa >> (8 * bi)) & 0xff;
-          hit = (cb == 4) ? 2 : ((ca == 4) ? 1 : 0);
+          bhit = (cb == 4);
+          ahit = !bhit && (ca == 4);
           break;
         }
     }
   SnakeOut o;
-  o.y = y;  o.m = m;  o.b = b;  o.hit = hit;
+  o.y = y;  o.m = m;  o.b = b;  o.ahit = ahit;  o.bhit = bhit;
   return o;
 }
 
@@ -178,9 +179,13 @@ __device__ __forceinline__ SnakeOut snake(const u8 *a, const u8 *bq, int y, int 
  * reference would then compare whatever follows in memory) takes the byte path above, which
  * reads exactly what the reference reads. */
 __device__ __forceinline__ u32 load16(const u32 *pk, int p)           /* bases p .. p+15, base p in bits 0-1 */
-{ const GLOBAL_AS u32 *q = (const GLOBAL_AS u32 *) pk + (p >> 4);
-  const u32 lo = q[0], hi = q[1];
-  return __builtin_amdgcn_alignbit(hi, lo, (u32) (p & 15) * 2);
+{ /* byte offset of the dword holding base p, from a base moved back by the padding so that the
+     offset is unsigned (p >= -16 always): scalar base + 32-bit lane offset, no 64-bit lane maths */
+  const u32 off = ((u32) (p + 16 * PK_PAD) >> 2) & ~3u;
+  typedef u32 v2u __attribute__((ext_vector_type(2)));
+  const GLOBAL_AS v2u *q = (const GLOBAL_AS v2u *) ((const GLOBAL_AS char *) (pk - PK_PAD) + off);
+  const v2u w = *q;
+  return __builtin_amdgcn_alignbit(w.y, w.x, (u32) p * 2);             /* the shift uses bits 0-4: 2*(p & 15) */
 }
 
 template <int REV>
@@ -191,35 +196,36 @@ __device__ __forceinline__ SnakeOut snake_pk(const u32 *apk, const u32 *bpk, int
     { const u32 wa = REV ? load16(apk, ap - 15) : load16(apk, ap);
       const u32 wb = REV ? load16(bpk, bp - 15) : load16(bpk, bp);
       const u32 x = wa ^ wb;
-      int n;
-      if (!REV) n = x ? ((__ffs((int) x) - 1) >> 1) : 16;
-      else      n = x ? (__clz((int) x) >> 1) : 16;
+      u32 run;
+      if (!REV) run = x ? (u32) __builtin_ctz(x) >> 1 : 16u;
+      else      run = x ? (u32) __builtin_clz(x) >> 1 : 16u;
       const int lim = na < nb ? na : nb;
-      if (n > lim) n = lim;
-      if (n > 0)
-        { const u32 passed = (u32) (b >> (61 - n)) & ((1u << n) - 1);
-          m += n - __popc(passed);
-          b = (b << n) | ((1ull << n) - 1);
-          y  += REV ? -n : n;
-          ap += REV ? -n : n;
-          bp += REV ? -n : n;
-          na -= n;  nb -= n;
-        }
+      const int n = (int) run < lim ? (int) run : lim;
+      /* n == 0 leaves m and b as they are */
+      { const u32 passed = (u32) (b >> (61 - n)) & ((1u << n) - 1);
+        m += n - __popc(passed);
+        b = (b << n) | (u64) ((1u << n) - 1);
+        y  += REV ? -n : n;
+        ap += REV ? -n : n;
+        bp += REV ? -n : n;
+        na -= n;  nb -= n;
+      }
       if (n < 16 || lim == 16)
         break;
     }
   SnakeOut o;
   o.y = y;  o.m = m;  o.b = b;
-  o.hit = (nb == 0) ? 2 : ((na == 0) ? 1 : 0);
+  o.bhit = (nb == 0);
+  o.ahit = (nb != 0) && (na == 0);
   return o;
 }
 
 /* the snake of diagonal k from B position y (both stages of the wave call this) */
 #define SNAKE_AT(k, y, m, b)                                                                    \
-  (((u32) ((y) + (k)) > (u32) alen || (u32) (y) > (u32) blen)                                   \
+  (((u32) ((y) + (k)) > (u32) valen || (u32) (y) > (u32) vblen)                                 \
      ? snake<REV>(aseq + (k), bseq, (y), (m), (b))                                              \
-     : (REV ? snake_pk<1>(apk, bpk, (int) a0 + (k) + (y) - 1, (int) b0 + (y) - 1, (y) + (k), (y), (y), (m), (b)) \
-            : snake_pk<0>(apk, bpk, (int) a0 + (k) + (y), (int) b0 + (y), alen - ((y) + (k)), blen - (y), (y), (m), (b))))
+     : (REV ? snake_pk<1>(apk, bpk, va0 + (k) + (y) - 1, vb0 + (y) - 1, (y) + (k), (y), (y), (m), (b)) \
+            : snake_pk<0>(apk, bpk, va0 + (k) + (y), vb0 + (y), valen - ((y) + (k)), vblen - (y), (y), (m), (b))))
 
 /* One direction of the wave.  REV = 0: align.c:409-1122, REV = 1: align.c:1126-1898.
  * Returns through *res the end point of this direction; traces are written by lane 0. */
@@ -264,9 +270,10 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
   const u8 *aseq = uni_ptr(REV ? c.aseq - 1 : c.aseq);
   const u8 *bseq = uni_ptr(REV ? c.bseq - 1 : c.bseq);
   const u32 *apk = uni_ptr(c.apk), *bpk = uni_ptr(c.bpk);
-  const u32 a0 = (u32) uni((int) c.a0), b0 = (u32) uni((int) c.b0);
-  const int alen = uni(c.alen), blen = uni(c.blen);
-  (void) apk; (void) bpk; (void) a0; (void) b0; (void) alen; (void) blen;
+  /* the reads' geometry is only used in per-lane arithmetic: kept in VGPRs (the same value in
+     every lane) so that it does not compete for the scalar registers of the loop control */
+  const int va0 = (int) c.a0, vb0 = (int) c.b0, valen = c.alen, vblen = c.blen;
+  (void) apk; (void) bpk; (void) va0; (void) vb0; (void) valen; (void) vblen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
   const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
@@ -322,9 +329,8 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
     int g0 = 0;
     { const SnakeOut so = SNAKE_AT(k, y, 0, 0ull);
       y = uni(so.y);
-      const int hit = uni(so.hit);
-      if (hit & 2)      { more = 0; bclip = k; }
-      else if (hit & 1) { more = 0; aclip = k; }
+      if (uni((int) so.bhit))      { more = 0; bclip = k; }
+      else if (uni((int) so.ahit)) { more = 0; aclip = k; }
     }
     v = (y << 1) + k;
     while (REV ? (y + k <= na) : (y + k >= na))
@@ -385,6 +391,7 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
 
     CLIP_REG()
 
+    const int src_me = lane << 2, src_up = ((lane + 1) & 63) << 2, src_dn = ((lane - 1) & 63) << 2;   /* bpermute addresses */
     while (more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
       { /* pin the wave-uniform bookkeeping to SGPRs */
         low = uni(low);  hgh = uni(hgh);  dif = uni(dif);  besta = uni(besta);  besty = uni(besty);
@@ -411,14 +418,13 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
         { const int upNA = lane_up(rNA), upNB = lane_up(rNB);
           const int dnNA = lane_dn(rNA), dnNB = lane_dn(rNB);
           int nlow = low - 1, nhgh = hgh + 1;
-          if (nlow >= minp)
-            { if (lane == LANE_OF(nlow)) { rV = edge; rNA = upNA; rNB = upNB; } }
-          else
-            nlow += 1;
-          if (nhgh <= maxp)
-            { if (lane == LANE_OF(nhgh)) { rV = edge; rNA = dnNA; rNB = dnNB; } }
-          else
-            nhgh -= 1;
+          if (nlow < minp) nlow += 1;
+          if (nhgh > maxp) nhgh -= 1;
+          const bool newlo = (nlow < low) && lane == LANE_OF(nlow);
+          const bool newhi = (nhgh > hgh) && lane == LANE_OF(nhgh);
+          rV  = (newlo || newhi) ? edge : rV;
+          rNA = newlo ? upNA : (newhi ? dnNA : rNA);
+          rNB = newlo ? upNB : (newhi ? dnNB : rNB);
           low = nlow;  hgh = nhgh;
           dif += 1;
         }
@@ -431,22 +437,23 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
 
         { const int ac = rV;
           int am = lane_dn(rV), ap = lane_up(rV);
-          int dl;                                     /* predecessor = k + dl */
           if (k - 1 < low) am = edge;
           if (k + 1 > hgh) ap = edge;
+          /* align.c:700-720 / 1411-1431 as max/min: the own diagonal wins ties, then k-1 over k+1
+             (forward) resp. k+1 over k-1 (reverse) */
+          int  nbv;
+          bool take, up;                              /* predecessor = neighbour? the upper one? */
           if (!REV)
-            { if (ac < am) dl = (am < ap) ? 1 : -1;
-              else         dl = (ac < ap) ? 1 : 0;
-              v = (dl == 0) ? ac + 2 : ((dl == 1) ? ap + 1 : am + 1);
+            { nbv = am > ap ? am : ap;  take = ac < nbv;  up = am < ap;
+              v = take ? nbv + 1 : ac + 2;
             }
           else
-            { if (ac > ap) dl = (ap > am) ? -1 : 1;
-              else         dl = (ac > am) ? -1 : 0;
-              v = (dl == 0) ? ac - 2 : ((dl == -1) ? am - 1 : ap - 1);
+            { nbv = am < ap ? am : ap;  take = ac > nbv;  up = !(ap > am);
+              v = take ? nbv - 1 : ac - 2;
             }
           /* the predecessor's inherited state through the LDS crossbar (ds_bpermute: no VALU
              cycles, and the wave is bound by VALU issue), one gather per field */
-          { const int src = ((lane + dl) & 63) << 2;
+          { const int src = take ? (up ? src_up : src_dn) : src_me;
             m  = __builtin_amdgcn_ds_bpermute(src, rM);
             ha = __builtin_amdgcn_ds_bpermute(src, rHA);
             hb = __builtin_amdgcn_ds_bpermute(src, rHB);
@@ -464,12 +471,11 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
             y = (v - k) >> 1;
             { const SnakeOut so = SNAKE_AT(k, y, m, b);
               y = so.y;  m = so.m;  b = so.b;
-              ahit = so.hit == 1;  bhit = so.hit == 2;
+              ahit = so.ahit;  bhit = so.bhit;
             }
             v = (y << 1) + k;
           }
-        else
-          { v = edge; m = 0; b = 0; ha = hb = 0; ham = hbm = 0; }
+        /* (lanes outside the band: only V = edge is ever looked at, by the neighbours) */
 
         /* pebbles (align.c:859-909): almost never needed, so test once for the whole wave */
         int na = rNA, nb = rNB;
@@ -522,8 +528,8 @@ __device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, Wave
           }
 
         /* commit the new wave */
-        rV = v;  rM = m;  rT = b;  rHA = ha;  rHB = hb;
-        if (act) { rNA = na;  rNB = nb; }
+        rV = act ? v : edge;
+        if (act) { rM = m;  rT = b;  rHA = ha;  rHB = hb;  rNA = na;  rNB = nb; }
 
         /* sequence ends reached (bit i of the rotated masks = diagonal low + i) */
         { u64 am_ = __ballot(ahit), bm_ = __ballot(bhit);
@@ -638,9 +644,10 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
   const u8 *aseq = uni_ptr(REV ? c.aseq - 1 : c.aseq);
   const u8 *bseq = uni_ptr(REV ? c.bseq - 1 : c.bseq);
   const u32 *apk = uni_ptr(c.apk), *bpk = uni_ptr(c.bpk);
-  const u32 a0 = (u32) uni((int) c.a0), b0 = (u32) uni((int) c.b0);
-  const int alen = uni(c.alen), blen = uni(c.blen);
-  (void) apk; (void) bpk; (void) a0; (void) b0; (void) alen; (void) blen;
+  /* the reads' geometry is only used in per-lane arithmetic: kept in VGPRs (the same value in
+     every lane) so that it does not compete for the scalar registers of the loop control */
+  const int va0 = (int) c.a0, vb0 = (int) c.b0, valen = c.alen, vblen = c.blen;
+  (void) apk; (void) bpk; (void) va0; (void) vb0; (void) valen; (void) vblen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
   const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
@@ -754,7 +761,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
               y = (v - k) >> 1;
               { const SnakeOut so = SNAKE_AT(k, y, m, b);
                 y = so.y;  m = so.m;  b = so.b;
-                ahit = so.hit == 1;  bhit = so.hit == 2;
+                ahit = so.ahit;  bhit = so.bhit;
               }
               v = (y << 1) + k;
               na = c.NA[k + o];
@@ -910,9 +917,10 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
   const u8 *aseq = uni_ptr(REV ? c.aseq - 1 : c.aseq);
   const u8 *bseq = uni_ptr(REV ? c.bseq - 1 : c.bseq);
   const u32 *apk = uni_ptr(c.apk), *bpk = uni_ptr(c.bpk);
-  const u32 a0 = (u32) uni((int) c.a0), b0 = (u32) uni((int) c.b0);
-  const int alen = uni(c.alen), blen = uni(c.blen);
-  (void) apk; (void) bpk; (void) a0; (void) b0; (void) alen; (void) blen;
+  /* the reads' geometry is only used in per-lane arithmetic: kept in VGPRs (the same value in
+     every lane) so that it does not compete for the scalar registers of the loop control */
+  const int va0 = (int) c.a0, vb0 = (int) c.b0, valen = c.alen, vblen = c.blen;
+  (void) apk; (void) bpk; (void) va0; (void) vb0; (void) valen; (void) vblen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
   const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
