@@ -67,6 +67,8 @@ def _lib():
         L.damar_block_upload.argtypes = [C.POINTER(HITS_DB)]
         L.damar_block_upload.restype = C.c_void_p
         L.damar_block_free.argtypes = [C.c_void_p]
+        L.damar_load_masks.argtypes = [C.POINTER(HITS_DB), C.POINTER(C.c_char_p), C.c_int]
+        L.damar_load_masks.restype = C.c_int
         L.damar_index_build.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.damar_index_build.restype = C.c_void_p
         L.damar_index_free.argtypes = [C.c_void_p]

@@ -19,7 +19,7 @@
 
 static void usage(void)
 { fprintf(stderr, "usage:\n");
-  fprintf(stderr, "daligner [-vAIOT] [-k<int(14)>] [-w<int(6)>] [-h<int(35)>] [-t<int>] [-M<int>]\n");
+  fprintf(stderr, "daligner [-vAIOT] [-k<int(14)>] [-w<int(6)>] [-h<int(35)>] [-t<int>] [-M<int>] [-m<track>]+\n");
   fprintf(stderr, "         [-e<double(.70)] [-l<int(1000)>] [-s<int(100)>] [-H<int>] [-j<int>]\n");
   fprintf(stderr, "         [-r<int(1)>] [-g<gpu ordinal(0)>] <subject:db> <target:db> ...\n");
 }
@@ -61,6 +61,8 @@ int main(int argc, char *argv[])
   double  ecorr = .70;
   int     spacing = 100, runid = 1, notrace = 0, nthreads = 4, only_id = 0, gpu = -1;
   int     c, i;
+  char   *mask[64];                     /* -m tracks, daligner.c:788-795 */
+  int     mtop = 0;
 
   MINOVER = 1000;
   IDENTITY = 0;
@@ -92,7 +94,14 @@ int main(int argc, char *argv[])
           MEM_LIMIT = (uint64) gb * 0x40000000ull;
           break;
         }
-      case 'b': case 'm': case 'D':
+      case 'm':
+        if (mtop >= 64)
+          { fprintf(stderr, "daligner: too many -m tracks\n");
+            exit(1);
+          }
+        mask[mtop++] = optarg;
+        break;
+      case 'b': case 'D':
         fprintf(stderr, "daligner: option -%c is not supported by this build\n", c);
         exit(1);
       default:
@@ -124,6 +133,10 @@ int main(int argc, char *argv[])
   afile = argv[optind++];
   if (damar_read_block(afile, &ablock))
     exit(1);
+  if (damar_load_masks(&ablock, mask, mtop))
+    { printf("[ERROR] - Unable to load track!\n");
+      exit(1);
+    }
   check_reads(&ablock, afile, kmer);
   aroot = damar_root(afile, ".db");
 
@@ -164,6 +177,10 @@ int main(int argc, char *argv[])
       if (!same)
         { if (damar_read_block(bfile, &bblock))
             exit(1);
+          if (damar_load_masks(&bblock, mask, mtop))
+            { printf("[ERROR] - Unable to load track!\n");
+              exit(1);
+            }
           check_reads(&bblock, bfile, kmer);
           broot = damar_root(bfile, ".db");
         }

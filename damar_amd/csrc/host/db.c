@@ -162,9 +162,8 @@ int damar_read_block(const char *name, HITS_DB *block)
   ((int *) reads)[-1] = block->nreads;
   block->reads = reads;
 
-  snprintf(path, sizeof(path), "%s/.%s.", dir, root);
+  snprintf(path, sizeof(path), "%s/.%s", dir, root);        /* db/DB.c Open_DB: path = pwd "/." root */
   block->path = strdup(path);
-  path[strlen(path) - 1] = '\0';
   strcat(path, ".bps");
   if ((bps = fopen(path, "r")) == NULL)
     { fprintf(stderr, "damar: cannot open bases %s\n", path);
@@ -223,8 +222,21 @@ fail:
   return -1;
 }
 
+static void free_tracks(HITS_TRACK *t)
+{ while (t != NULL)
+    { HITS_TRACK *n = t->next;
+      free(t->name);
+      free(t->anno);
+      free(t->data);
+      free(t);
+      t = n;
+    }
+}
+
 void damar_close_block(HITS_DB *block)
-{ if (block->loaded && block->bases != NULL)
+{ free_tracks(block->tracks);
+  block->tracks = NULL;
+  if (block->loaded && block->bases != NULL)
     free(((char *) block->bases) - 1);
   block->bases = NULL;
   if (block->reads != NULL)
@@ -243,10 +255,6 @@ HITS_DB *damar_complement_block(HITS_DB *block, int inplace)
   int      i;
   float    x;
 
-  if (block->tracks != NULL)
-    { fprintf(stderr, "damar: mask tracks are not supported on the complement path yet\n");
-      exit(1);
-    }
   if (inplace)
     { c   = block;
       seq = (char *) block->bases;
@@ -275,7 +283,201 @@ HITS_DB *damar_complement_block(HITS_DB *block, int inplace)
       if (s == t)
         *s = (char) (3 - *s);
     }
+
+  /* daligner.c:572-626: the mask intervals of every read are mirrored, [b,e) -> [rlen-e, rlen-b),
+     which also reverses their order.  Not in place: a copy for the complemented block (released
+     by the next call with inplace == 0, like the static block record itself). */
+  { static HITS_TRACK *ctracks = NULL;
+    HITS_TRACK *src;
+    if (!inplace)
+      { free_tracks(ctracks);
+        ctracks = NULL;
+      }
+    for (src = block->tracks; src != NULL; src = src->next)
+      { int64 *tano = (int64 *) src->anno, *anno;
+        int   *tata = (int *) src->data, *data;
+        HITS_TRACK *trg;
+        if (inplace)
+          { anno = tano;  data = tata;  trg = src; }
+        else
+          { data = (int *) xmalloc(sizeof(int) * (size_t) (tano[block->nreads] + 1), "mask data");
+            anno = (int64 *) xmalloc(sizeof(int64) * (size_t) (block->nreads + 1), "mask index");
+            trg  = (HITS_TRACK *) xmalloc(sizeof(HITS_TRACK), "mask header");
+            trg->name = strdup(src->name);
+            trg->size = 4;
+            trg->anno = (void *) anno;
+            trg->data = (void *) data;
+            trg->next = c->tracks;
+            c->tracks = trg;
+            ctracks   = c->tracks;
+          }
+        for (i = 0; i < block->nreads; i++)
+          { int   rlen = block->reads[i].rlen;
+            int64 j = tano[i + 1] - 1, k = tano[i];
+            anno[i] = tano[i];
+            while (k < j)
+              { int y = tata[j];
+                data[j--] = rlen - tata[k];
+                data[k++] = rlen - y;
+              }
+            if (k == j)
+              data[k] = rlen - tata[k];
+          }
+        anno[block->nreads] = tano[block->nreads];
+      }
+  }
   return c;
+}
+
+/* daligner.c:442-497 read_DB's mask part: load every named interval track of the block
+ * (db/DB.c:1113 Load_Track: <path>.<track>.anno = int tracklen, int size, size-byte offsets;
+ * <path>.<track>.data = int pairs [beg,end) per read; per-block files <path>.<part>.<track>.*
+ * take precedence) and leave ONE track on block->tracks: anno = int64[nreads+1] in units of
+ * ints, data = the union of the intervals (daligner.c:263-439 Merge_Size / Merge_Tracks; the
+ * union is formed by sorting: overlapping or abutting intervals merge, which selects the same
+ * k-mers as the reference's heap sweep whatever order it meets equal coordinates in).
+ * Returns 0, or -1 after printing what is wrong.  The compressed .a2/.d2 form of
+ * lib/tracks.c is not read. */
+typedef struct { int beg, end; } Ival;
+
+static int ival_cmp(const void *x, const void *y)
+{ const Ival *a = (const Ival *) x, *b = (const Ival *) y;
+  if (a->beg != b->beg) return (a->beg < b->beg) ? -1 : 1;
+  if (a->end != b->end) return (a->end < b->end) ? -1 : 1;
+  return 0;
+}
+
+int damar_load_masks(HITS_DB *block, char **names, int n)
+{ int64 **offs;
+  int   **dats;
+  int     t, i, nreads = block->nreads, rc = -1;
+  char    path[4400];
+
+  if (n <= 0)
+    return 0;
+  offs = (int64 **) calloc((size_t) n, sizeof(int64 *));
+  dats = (int **) calloc((size_t) n, sizeof(int *));
+  for (t = 0; t < n; t++)
+    { FILE *af = NULL, *df = NULL;
+      int   tracklen, size, ispart = 0, ureads;
+      if (block->part > 0)
+        { snprintf(path, sizeof(path), "%s.%d.%s.anno", block->path, block->part, names[t]);
+          af = fopen(path, "r");
+          ispart = (af != NULL);
+        }
+      if (af == NULL)
+        { snprintf(path, sizeof(path), "%s.%s.anno", block->path, names[t]);
+          af = fopen(path, "r");
+        }
+      if (af == NULL)
+        { fprintf(stderr, "damar: Track '%s' does not exist\n", names[t]);
+          goto done;
+        }
+      if (ispart)
+        snprintf(path, sizeof(path), "%s.%d.%s.data", block->path, block->part, names[t]);
+      else
+        snprintf(path, sizeof(path), "%s.%s.data", block->path, names[t]);
+      df = fopen(path, "r");
+      if (fread(&tracklen, sizeof(int), 1, af) != 1 || fread(&size, sizeof(int), 1, af) != 1 ||
+          (size != 4 && size != 8) || df == NULL)
+        { fprintf(stderr, "damar: Track '%s' annotation file is junk\n", names[t]);
+          fclose(af);  if (df) fclose(df);
+          goto done;
+        }
+      ureads = ispart ? nreads : block->ureads;
+      if (tracklen != ureads)
+        { fprintf(stderr, "damar: Track '%s' not same size as database (track: %d, db: %d)!\n",
+                  names[t], tracklen, ureads);
+          fclose(af);  fclose(df);
+          goto done;
+        }
+      if (!ispart && block->part > 0)
+        fseeko(af, (off_t) size * block->ufirst, SEEK_CUR);
+      offs[t] = (int64 *) xmalloc(sizeof(int64) * (size_t) (nreads + 1), "mask index");
+      for (i = 0; i <= nreads; i++)
+        { int64 v = 0;
+          int   v4;
+          if ((size == 8 ? fread(&v, 8, 1, af) : fread(&v4, 4, 1, af)) != 1)
+            { fprintf(stderr, "damar: Track '%s' annotation file is junk\n", names[t]);
+              fclose(af);  fclose(df);
+              goto done;
+            }
+          offs[t][i] = (size == 8) ? v : (int64) v4;
+        }
+      { int64 o0 = offs[t][0], dlen = offs[t][nreads] - offs[t][0];
+        dats[t] = (int *) xmalloc((size_t) dlen + 8, "mask data");
+        fseeko(df, (off_t) o0, SEEK_SET);
+        if (dlen > 0 && fread(dats[t], (size_t) dlen, 1, df) != 1)
+          { fprintf(stderr, "damar: Track '%s' data file size mismatch. Expected %lld\n", names[t], (long long) dlen);
+            fclose(af);  fclose(df);
+            goto done;
+          }
+        for (i = 0; i <= nreads; i++)
+          offs[t][i] = (offs[t][i] - o0) / (int64) sizeof(int);     /* daligner.c:475-477: units of ints */
+      }
+      fclose(af);
+      fclose(df);
+    }
+
+  { int64  total = 0, top = 0;
+    int64 *anno;
+    int   *data;
+    Ival  *iv;
+    int    cap = 0;
+    HITS_TRACK *trk;
+    for (t = 0; t < n; t++)
+      total += offs[t][nreads];
+    anno = (int64 *) xmalloc(sizeof(int64) * (size_t) (nreads + 1), "mask index");
+    data = (int *) xmalloc(sizeof(int) * (size_t) (total + 2), "mask data");
+    iv = NULL;
+    for (i = 0; i < nreads; i++)
+      { int m = 0, q;
+        anno[i] = top;
+        for (t = 0; t < n; t++)
+          m += (int) ((offs[t][i + 1] - offs[t][i]) / 2);
+        if (m > cap)
+          { cap = m + 64;
+            iv = (Ival *) realloc(iv, sizeof(Ival) * (size_t) cap);
+          }
+        m = 0;
+        for (t = 0; t < n; t++)
+          { int64 a;
+            for (a = offs[t][i]; a + 1 < offs[t][i + 1]; a += 2)
+              { iv[m].beg = dats[t][a];  iv[m].end = dats[t][a + 1];  m += 1; }
+          }
+        if (n > 1)
+          qsort(iv, (size_t) m, sizeof(Ival), ival_cmp);
+        for (q = 0; q < m; q++)
+          { if (q > 0 && top > anno[i] && iv[q].beg <= data[top - 1])
+              { if (iv[q].end > data[top - 1])
+                  data[top - 1] = iv[q].end;
+              }
+            else
+              { data[top++] = iv[q].beg;
+                data[top++] = iv[q].end;
+              }
+          }
+      }
+    anno[nreads] = top;
+    free(iv);
+    trk = (HITS_TRACK *) xmalloc(sizeof(HITS_TRACK), "mask header");
+    trk->name = strdup(n > 1 ? "merge" : names[0]);
+    trk->size = 8;
+    trk->anno = (void *) anno;
+    trk->data = (void *) data;
+    trk->next = NULL;
+    free_tracks(block->tracks);
+    block->tracks = trk;
+  }
+  rc = 0;
+done:
+  for (t = 0; t < n; t++)
+    { free(offs[t]);
+      free(dats[t]);
+    }
+  free(offs);
+  free(dats);
+  return rc;
 }
 
 /****************************************************************************************

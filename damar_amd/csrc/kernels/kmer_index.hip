@@ -52,6 +52,33 @@ void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, u32 *co
   hipLaunchKernelGGL(kmer_tuples, dim3((nkmers + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, codes, pos);
 }
 
+/* The masked branch of tuple_thread (filter.c:474-526): between two mask intervals of a read
+ * (and before the first / after the last) lies an unmasked stretch [p, q); the reference emits
+ * exactly the k-mers with p <= first base and last base < q.  The intervals of a read are sorted
+ * and disjoint, so the k-mer [s, e] is kept unless the first interval that ends after s begins
+ * at or before e (an empty interval [b, b) still splits a stretch, as in the reference). */
+__global__ __launch_bounds__(256)
+void mask_flags(DevBlock blk, int kmer, const u32 *__restrict__ pos, u32 n, u32 *__restrict__ keep)
+{ u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n)
+    return;
+  const u32 p = pos[i], r = read_of_pos(blk, p);
+  const int e = (int) (p - blk.boff[r]), s = e - (kmer - 1);
+  u32 lo = blk.moff[r] >> 1, hi = blk.moff[r + 1] >> 1;
+  const u32 end = hi;
+  while (lo < hi)                               /* first interval with end > s */
+    { const u32 mid = (lo + hi) >> 1;
+      if (blk.mdat[2 * mid + 1] > s) hi = mid; else lo = mid + 1;
+    }
+  keep[i] = (lo < end && blk.mdat[2 * lo] <= e) ? 0u : 1u;
+}
+
+void damar_launch_mask_flags(const DevBlock *blk, int kmer, const u32 *pos, u32 n, u32 *keep, hipStream_t st)
+{ if (n == 0)
+    return;
+  hipLaunchKernelGGL(mask_flags, dim3((n + 255) / 256), dim3(256), 0, st, *blk, kmer, pos, n, keep);
+}
+
 /* table[q] for q in [0, 2^tbits]: written by the element that starts each prefix
  * change (it also fills the prefixes that do not occur at all). */
 __global__ __launch_bounds__(256)

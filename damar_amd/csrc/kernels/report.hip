@@ -34,6 +34,9 @@
 #define PANEL_SIZE     50000                  /* filter.c:73 */
 #define PANEL_OVERLAP  10000                  /* filter.c:74 */
 #define BIG  0x7fffffff
+#ifndef WAVE_REG_INLINE
+#define WAVE_REG_INLINE __noinline__          /* the register stage as its own function: see wave_reg */
+#endif
 #ifndef REPORT_WAVES_PER_SIMD
 #define REPORT_WAVES_PER_SIMD 8               /* VGPR budget = 512 / this; the shim sizes the grid to match */
 #endif
@@ -262,7 +265,7 @@ struct WaveState
  * Leaves ws.stopped = 0 only if the band outgrew the wavefront: the band state is then in
  * the slot's DState buffers and stage 2 continues. */
 template <int REV>
-__device__ __noinline__ void wave_reg(const WaveCtx &c, int diag, int mida, WaveState &ws)
+__device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, WaveState &ws)
 {
   const int lane = lane_id();
   const int TS = uni(c.ts);

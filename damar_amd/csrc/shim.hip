@@ -185,6 +185,8 @@ extern "C" int  damar_last_limit(void)          { return G_limit; }
 struct damar_dev_block
 { DevBlock d;
   u32 *pk_alloc;
+  u32 *moff;
+  int *mdat;
   u8  *bases_alloc;        /* d.bases = bases_alloc + 64; d.bases[-1] is the leading terminator */
   u32 *boff, *coarse;
   int  nreads;
@@ -231,6 +233,20 @@ extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
   b->d.nreads = (u32) n;
   b->d.total  = (u32) total;
   b->d.maxlen = block->maxlen;
+  if (block->tracks != NULL)                  /* the merged mask track of daligner.c:442-497 */
+    { const int64 *anno = (const int64 *) block->tracks->anno;
+      const int   *data = (const int *) block->tracks->data;
+      std::vector<u32> moff((size_t) n + 1);
+      for (int i = 0; i <= n; i++)
+        moff[i] = (u32) anno[i];
+      b->moff = (u32 *) dmalloc(sizeof(u32) * ((size_t) n + 1));
+      b->mdat = (int *) dmalloc(sizeof(int) * ((size_t) anno[n] + 2));
+      HIP_CHECK(hipMemcpy(b->moff, moff.data(), sizeof(u32) * ((size_t) n + 1), hipMemcpyHostToDevice));
+      if (anno[n] > 0)
+        HIP_CHECK(hipMemcpy(b->mdat, data, sizeof(int) * (size_t) anno[n], hipMemcpyHostToDevice));
+      b->d.moff = b->moff;
+      b->d.mdat = b->mdat;
+    }
   b->nreads   = n;
   return b;
 }
@@ -241,6 +257,8 @@ extern "C" void damar_block_free(damar_dev_block *b)
   HIP_CHECK(hipStreamSynchronize(G_st));
   HIP_CHECK(hipFree(b->bases_alloc));
   HIP_CHECK(hipFree(b->pk_alloc));
+  if (b->moff) HIP_CHECK(hipFree(b->moff));
+  if (b->mdat) HIP_CHECK(hipFree(b->mdat));
   HIP_CHECK(hipFree(b->boff));
   HIP_CHECK(hipFree(b->coarse));
   free(b);
@@ -280,8 +298,9 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
         damar_block_free(blk);
       return NULL;
     }
-  const u32 nk = (u32) nk64;
+  u32 nk = (u32) nk64;
   const int kbits = 2 * K;
+  const bool masked = blk->d.moff != NULL;
   const int npass = (kbits + 7) / 8;
   damar_dev_index *ix = (damar_dev_index *) calloc(1, sizeof(damar_dev_index));
   ix->blk = blk;  ix->own_block = own_block;  ix->kbits = kbits;
@@ -289,17 +308,45 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
   ix->pos   = (u32 *) dmalloc(sizeof(u32) * (size_t) nk);
 
   size_t swb = damar_sort_workspace_bytes(nk);
-  arena_reserve(&G_work, 4 * pad256(sizeof(u32) * (size_t) nk) + pad256(swb) + (1 << 16));
+  arena_reserve(&G_work, 4 * pad256(sizeof(u32) * (size_t) nk) + pad256(swb) + pad256(damar_scan_workspace_bytes(nk)) + (1 << 16));
   u32 *tk = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
   u32 *tv = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
   void *sw = arena_take(&G_work, swb);
+  u32 *keep = NULL, *off = NULL;
+  void *scw = NULL;
+  u64 *tot = NULL;
+  if (masked || suppress > 0)
+    { keep = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
+      off  = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
+      scw  = arena_take(&G_work, damar_scan_workspace_bytes(nk));
+      tot  = (u64 *) arena_take(&G_work, 64);
+    }
 
   /* the sort ping-pongs: start on the side that makes it end in the index's own arrays */
   u32 *k0 = (npass & 1) ? tk : ix->codes, *v0 = (npass & 1) ? tv : ix->pos;
   u32 *k1 = (npass & 1) ? ix->codes : tk, *v1 = (npass & 1) ? ix->pos : tv;
 
   tick(0);
-  damar_launch_kmer_tuples(&blk->d, K, nk, k0, v0, G_st);
+  if (!masked)
+    damar_launch_kmer_tuples(&blk->d, K, nk, k0, v0, G_st);
+  else
+    { /* filter.c:474-526 + the filler squeeze of :855-888: only k-mers inside one unmasked
+         stretch enter the index; dropping them before the sort leaves the same sorted list */
+      u32 *k9 = (k0 == tk) ? ix->codes : tk, *v9 = (v0 == tv) ? ix->pos : tv;
+      u64  kept = 0;
+      damar_launch_kmer_tuples(&blk->d, K, nk, k9, v9, G_st);
+      damar_launch_mask_flags(&blk->d, K, v9, nk, keep, G_st);
+      damar_exclusive_scan_u32(keep, off, nk, scw, tot, G_st);
+      damar_launch_compact_pairs(k9, v9, keep, off, nk, k0, v0, G_st);
+      HIP_CHECK(hipMemcpyAsync(&kept, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      nk = (u32) kept;
+      if (nk == 0)
+        { damar_index_free(ix);
+          *len = 0;
+          return NULL;
+        }
+    }
   tick(1);
   int side = damar_radix_sort_u32(k0, v0, k1, v1, nk, kbits, sw, G_st);
   tick(2);
@@ -313,11 +360,7 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
   damar_launch_code_table(ix->codes, n, kbits, ix->tbits, ix->table, G_st);
 
   if (suppress > 0)                         /* filter.c:890-939 */
-    { u32 *keep = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
-      u32 *off  = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
-      void *scw = arena_take(&G_work, damar_scan_workspace_bytes(nk));
-      u64 *tot  = (u64 *) arena_take(&G_work, 64);
-      u64  kept = 0;
+    { u64  kept = 0;
       damar_launch_suppress_flags(ix->codes, n, ix->table, kbits, ix->tbits, suppress, keep, G_st);
       damar_exclusive_scan_u32(keep, off, n, scw, tot, G_st);
       damar_launch_compact_pairs(ix->codes, ix->pos, keep, off, n, tk, tv, G_st);
@@ -383,10 +426,7 @@ extern "C" void damar_index_download(const damar_dev_index *ix, void *out)
 }
 
 extern "C" void *Sort_Kmers(HITS_DB *block, int *len)
-{ if (block->tracks != NULL)
-    { fprintf(stderr, "damar: FATAL: mask tracks (-m, filter.c:474-526) are not built yet\n");
-      die();
-    }
+{ /* block->tracks, if any, is the merged mask of daligner.c:442-497: it travels with the block */
   damar_dev_block *b = damar_block_upload(block);
   return (void *) damar_index_build(b, 1, len);
 }

@@ -29,9 +29,25 @@ class Block:
         if self.root.endswith(".db"):
             self.root = self.root[:-3]
         self.db = api.read_block(name)
+        self.masks = None
         self.dev = None
         self._cdb = None
         self.cdev = None
+
+    def load_masks(self, names):
+        """-m tracks (daligner.c:442-497): must happen before the block goes to HBM."""
+        names = list(names or [])
+        if self.masks is None:
+            if self.dev is not None or self.cdev is not None:
+                if names:
+                    raise RuntimeError("mask tracks must be loaded before the block is uploaded")
+            elif names:
+                arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+                if api.lib().damar_load_masks(C.byref(self.db), arr, len(names)) != 0:
+                    raise RuntimeError("cannot load mask tracks %r of %s" % (names, self.name))
+            self.masks = names
+        elif self.masks != names:
+            raise RuntimeError("block %s already carries masks %r" % (self.name, self.masks))
 
     def upload(self):
         L = api.lib()
@@ -63,9 +79,10 @@ class Plan:
     """daligner <A> <B1> <B2> ... for resident blocks."""
 
     def __init__(self, k=14, w=6, h=35, t=0, e=.70, l=1000, s=100, j=4, run=1,
-                 symmetric=1, identity=0, verbose=0, async_tail=True):
+                 symmetric=1, identity=0, verbose=0, async_tail=True, masks=None):
         self.k, self.w, self.h, self.t, self.e, self.l, self.s, self.j, self.run = k, w, h, t, e, l, s, j, run
         self.symmetric, self.identity, self.verbose = symmetric, identity, verbose
+        self.masks = list(masks or [])
         L = api.lib()
         api.set_globals(verbose=verbose, minover=2 * l, symmetric=symmetric, identity=identity)
         if L.Set_Filter_Params(k, w, t, h, j):
@@ -106,6 +123,7 @@ class Plan:
         key = (block.name, comp)
         idx = self._idx.get(key)
         if idx is None:
+            block.load_masks(self.masks)
             L = api.lib()
             n = C.c_int(0)
             idx = L.damar_index_build(block.upload_complement() if comp else block.upload(), 0, C.byref(n))

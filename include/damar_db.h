@@ -72,6 +72,13 @@ void  damar_close_block(HITS_DB *block);
  * (daligner.c:511-628 complement_DB, mask tracks not supported yet). */
 HITS_DB *damar_complement_block(HITS_DB *block, int inplace);
 
+/* daligner.c:442-497 (read_DB) + 263-439 (Merge_Size, Merge_Tracks): load the named interval
+ * tracks (-m options) of the block and leave their union as the single mask track on
+ * block->tracks (anno = int64[nreads+1] in ints, data = [beg,end) pairs), which Sort_Kmers
+ * honours (filter.c:474-526) and damar_complement_block mirrors (daligner.c:572-626).
+ * Returns 0, -1 on error. */
+int damar_load_masks(HITS_DB *block, char **names, int n);
+
 /* "<prefix>" of a path with directory and ".db" suffix removed (db/DB.c Root). */
 char *damar_root(const char *name, const char *suffix);
 /* Output directory name d%03d_%05d (db/DB.c:1851 getDir). */

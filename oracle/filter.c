@@ -72,10 +72,6 @@ OKmer *oracle_sort_kmers(const HITS_DB *block, const OParams *prm, int *len)
     { fprintf(stderr, "oracle: Fatal error, DB blocks are greater than 2Gbp!\n");
       exit(1);
     }
-  if (block->tracks != NULL)
-    { fprintf(stderr, "oracle: mask tracks are not restated yet\n");
-      exit(1);
-    }
   if (kmers <= 0)
     { *len = 0;
       return NULL;
@@ -83,6 +79,38 @@ OKmer *oracle_sort_kmers(const HITS_DB *block, const OParams *prm, int *len)
   src = (OKmer *) xalloc(sizeof(OKmer) * (size_t) (kmers + 2));
   tmp = (OKmer *) xalloc(sizeof(OKmer) * (size_t) (kmers + 2));
 
+  /* filter.c:474-526, masked branch: block->tracks is the merged interval track (anno in ints,
+     data = [beg,end) pairs); k-mers are taken from every stretch [p,q) between two intervals
+     (before the first, after the last) that holds at least K bases.  The reference pads the
+     list with code=~0 fillers and squeezes them out after the sort (filter.c:855-888); leaving
+     them out up front yields the same sorted list. */
+  if (block->tracks != NULL)
+    { const int64 *anno = (const int64 *) block->tracks->anno;
+      const int   *point = (const int *) block->tracks->data;
+      for (i = 0; i < nreads; i++)
+        { const char *s = bases + block->reads[i].boff;
+          int64 a, b = anno[i], f = anno[i + 1];
+          for (a = b; a <= f; a += 2)
+            { int p = (a == b) ? 0 : point[a - 1];
+              int q = (a == f) ? block->reads[i].rlen : point[a];
+              if (p + K <= q)
+                { uint64 c = 0;
+                  int    x;
+                  for (x = 1; x < K; x++)
+                    c = (c << 2) | (uint64) s[p++];
+                  while (p < q)
+                    { c = ((c << 2) | (uint64) s[p]) & kmask;
+                      src[n].code = c;
+                      src[n].rpos = p++;
+                      src[n].read = i;
+                      n += 1;
+                    }
+                }
+            }
+        }
+      kmers = n;
+    }
+  else
   /* filter.c:528-544: one record per k-mer, rpos = index of its LAST base */
   for (i = 0; i < nreads; i++)
     { const char *s = bases + block->reads[i].boff;

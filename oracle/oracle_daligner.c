@@ -1,6 +1,6 @@
 /* oracle_daligner.c -- ORACLE (test infrastructure): command-line driver of the CPU
  * restatement, same options, block-pair loop and output files as the reference's
- * dalign/daligner.c:662-1077 (mask tracks, -b, -D not restated).  Used by tests/ and by
+ * dalign/daligner.c:662-1077 (-b, -D not restated).  Used by tests/ and by
  * bench.py's cpu_baseline leg only. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,6 +29,8 @@ int main(int argc, char *argv[])
   Align_Spec *spec;
   OWaveStats st;
   int64   cnt[3];
+  char   *mask[64];
+  int     mtop = 0;
 
   memset(&prm, 0, sizeof(prm));
   memset(&st, 0, sizeof(st));
@@ -54,6 +56,7 @@ int main(int argc, char *argv[])
       case 'j': nthreads = atoi(optarg); break;
       case 'M': prm.mem_limit = atoi(optarg) * 0x40000000ll; break;
       case 'r': runid = atoi(optarg); break;
+      case 'm': if (mtop < 64) mask[mtop++] = optarg; break;       /* daligner.c:788-795 */
       default:
         fprintf(stderr, "oracle_daligner: unsupported option -%c\n", optopt ? optopt : c);
         return 1;
@@ -66,7 +69,7 @@ int main(int argc, char *argv[])
   prm.nthreads = nthreads;
 
   afile = argv[optind++];
-  if (damar_read_block(afile, &ablock))
+  if (damar_read_block(afile, &ablock) || damar_load_masks(&ablock, mask, mtop))
     return 1;
   aroot = damar_root(afile, ".db");
   if (prm.symmetric)                                     /* daligner.c:911-946 */
@@ -93,7 +96,7 @@ int main(int argc, char *argv[])
         { char *broot = damar_root(bfile, ".db");
           char *d1 = NULL, *d2 = NULL;
           int   last;
-          if (damar_read_block(bfile, &bblock))
+          if (damar_read_block(bfile, &bblock) || damar_load_masks(&bblock, mask, mtop))
             return 1;
           if (prm.symmetric)
             { char *d = damar_get_dir(runid, bblock.part);

@@ -56,8 +56,9 @@ def read_case(name):
 
 def link_db(dbdir, dst, root="G"):
     os.makedirs(dst, exist_ok=True)
-    for f in ("%s.db" % root, ".%s.idx" % root, ".%s.bps" % root):
-        os.symlink(os.path.join(dbdir, f), os.path.join(dst, f))
+    for f in sorted(os.listdir(dbdir)):
+        if f == "%s.db" % root or f.startswith(".%s." % root):          # stub, .idx, .bps and track files
+            os.symlink(os.path.join(dbdir, f), os.path.join(dst, f))
 
 
 def run_cli(exe, case, workdir):
@@ -82,6 +83,8 @@ def opts_to_plan_kwargs(opts):
             kw["identity"] = 1
         elif f == "A":
             kw["symmetric"] = 0
+        elif f == "m":
+            kw.setdefault("masks", []).append(v)
     return kw
 
 

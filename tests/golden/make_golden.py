@@ -42,6 +42,11 @@ CASES = {
     "tandem":  dict(derive="tandem", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "fusion":  dict(derive="fusion32", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "fusion2": dict(derive="fusion31", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
+    # mask tracks (-m): a DBdust track made by the reference's own DBdust on reads with
+    # low-complexity inserts, and a second, synthetic interval track (so that the merge of
+    # daligner.c:263-439 and the per-block slicing of the track files are exercised)
+    "mask_dust": dict(derive="lowcomp", tracks=["dust"], opts=["-k14", "-j4", "-mdust"], plan="all"),
+    "mask_two":  dict(db="mask_dust", tracks=["dust", "rnd"], opts=["-k14", "-j4", "-mdust", "-mrnd"], plan="all"),
     # datander (scrub/datander.c) on the tandem-array reads and on plain reads (0 records)
     "tan_tandem": dict(db="tandem", tool="datander", opts=["-j4"], plan=[("1", [])]),
     "tan_k10":    dict(db="tandem", tool="datander", opts=["-k10", "-w3", "-h28", "-l400", "-j2"], plan=[("1", [])]),
@@ -117,6 +122,22 @@ def derive(kind, work):
                 s = "".join(comp[ch] for ch in reversed(s))
             reads.append(s)
             tot += len(s)
+    elif kind == "lowcomp":
+        # homopolymer and short-period stretches dropped into ordinary simulated reads: what
+        # DBdust masks, and what floods the seed filter with chance k-mer hits when unmasked
+        run([SIMDB, base, "B", "0.1", "-c14", "-r31", "-e.15", "-S200"], ROOT, stdout=subprocess.DEVNULL)
+        reads = unpack_reads(base, "B")
+        out = []
+        for i, s in enumerate(reads):
+            for _ in range(rng.choice([1, 2, 3])):
+                p = rng.randrange(200, len(s) - 200)
+                unit = rng.choice(["a", "t", "c", "g", "at", "ac", "gt", "ag", "aat", "ggc"])
+                ln = rng.randrange(25, 140)
+                ins = (unit * (ln // len(unit) + 1))[:ln]
+                ins = "".join(ch if rng.random() > .02 else rng.choice("acgt") for ch in ins)
+                s = s[:p] + ins + s[p:]
+            out.append(s)
+        reads = out
     elif kind.startswith("fusion"):
         # 300-800 bp windows with 25-45 % substitutions in every other read: the alignment
         # breaks inside the window and the two pieces share a trace point -> Fusion
@@ -161,8 +182,48 @@ def derive(kind, work):
     os.makedirs(dbdir)
     write_fasta(os.path.join(dbdir, "reads.fasta"), reads)
     run([os.path.join(REF, "FA2db"), "G", "reads.fasta"], dbdir, stdout=subprocess.DEVNULL)
-    run([os.path.join(REF, "DBsplit"), "-s200", "G"], dbdir, stdout=subprocess.DEVNULL)
+    run([os.path.join(REF, "DBsplit"), "-s1" if kind == "lowcomp" else "-s200", "G"], dbdir, stdout=subprocess.DEVNULL)
     return dbdir, "G"
+
+
+def read_lengths(dbdir, root):
+    import numpy as np
+    idx = np.fromfile(os.path.join(dbdir, ".%s.idx" % root), dtype=np.uint8)
+    nreads = int(np.frombuffer(idx[:4].tobytes(), dtype="<i4")[0])
+    recs = idx[88:88 + 32 * nreads].reshape(nreads, 32)
+    return [int(np.frombuffer(r[0:4].tobytes(), dtype="<i4")[0]) for r in recs]
+
+
+def make_tracks(dbdir, root, tracks):
+    """Interval tracks in the DAZZ_DB layout (db/DB.c:1113 Load_Track): .anno = int tracklen,
+    int size(8), int64 byte offsets[tracklen+1]; .data = int pairs [beg,end)."""
+    import struct
+    for t in tracks:
+        if t == "dust":
+            run([os.path.join(REF, "DBdust"), root], dbdir, stdout=subprocess.DEVNULL)
+        else:
+            rng = random.Random(77)
+            lens = read_lengths(dbdir, root)
+            offs, data = [0], []
+            for ln in lens:
+                pts = sorted(rng.sample(range(0, ln), 2 * rng.choice([0, 1, 1, 2, 3])))
+                for b, e in zip(pts[0::2], pts[1::2]):
+                    e = min(ln, b + min(e - b, 400) + 1)
+                    data += [b, e]
+                # keep them disjoint and sorted as a real track is
+                clean = []
+                for b, e in zip(data[offs[-1] // 4::2], data[offs[-1] // 4 + 1::2]):
+                    if clean and b <= clean[-1][1]:
+                        clean[-1][1] = max(clean[-1][1], e)
+                    else:
+                        clean.append([b, e])
+                data = data[:offs[-1] // 4] + [x for iv in clean for x in iv]
+                offs.append(4 * len(data))
+            with open(os.path.join(dbdir, ".%s.%s.anno" % (root, t)), "wb") as f:
+                f.write(struct.pack("<ii", len(lens), 8))
+                f.write(struct.pack("<%dq" % len(offs), *offs))
+            with open(os.path.join(dbdir, ".%s.%s.data" % (root, t)), "wb") as f:
+                f.write(struct.pack("<%di" % len(data), *data))
 
 
 def memlimit():
@@ -207,13 +268,18 @@ def main():
                 dbdir = out
             else:
                 dbdir, root = os.path.join(HERE, c["db"]), "G"
+            tfiles = []
+            for t in c.get("tracks", []):
+                if not os.path.exists(os.path.join(dbdir, ".G.%s.anno" % t)):
+                    make_tracks(dbdir, "G", [t])
+                tfiles += [".G.%s.anno" % t, ".G.%s.data" % t]
             nblocks = int(open(os.path.join(dbdir, "G.db")).read().split("blocks =")[1].split()[0])
             plan = c["plan"]
             if plan == "all":
                 plan = [(str(a), [str(b) for b in range(a, 0, -1)]) for a in range(1, nblocks + 1)]
             rdir = os.path.join(work, "run")
             os.makedirs(rdir)
-            for f in ("G.db", ".G.idx", ".G.bps"):
+            for f in ["G.db", ".G.idx", ".G.bps"] + tfiles:
                 os.symlink(os.path.join(dbdir, f), os.path.join(rdir, f))
             for a, bs in plan:
                 if c.get("tool") == "datander":

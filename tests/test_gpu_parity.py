@@ -52,7 +52,7 @@ def test_gpu_las_equals_reference_golden(gpu, tmp_path, name):
     assert compare_las(case, str(tmp_path)) == []
 
 
-@pytest.mark.parametrize("name", ["tiny2", "tan_tandem"])
+@pytest.mark.parametrize("name", ["tiny2", "tan_tandem", "mask_two"])
 def test_gpu_cli_binary_equals_reference_golden(gpu, tmp_path, name):
     """The C host drivers (the drop-in daligner / datander commands)."""
     from conftest import run_cli
@@ -387,7 +387,8 @@ def test_gpu_config2_block_pairs_known_answer(gpu, tmp_path):
         assert _check_las_invariants(os.path.join(d, f)) > 50000
 
 
-def test_reference_driver_linked_against_hip_library(gpu, tmp_path):
+@pytest.mark.parametrize("name", ["tiny2", "mask_two"])
+def test_reference_driver_linked_against_hip_library(gpu, tmp_path, name):
     """Drop-in proof: the reference's OWN dalign/daligner.c, compiled from /root/reference and
     linked against libdamar_hip.so instead of filter.c + align.c (oracle/Makefile.ref target
     `dropin`), writes the golden .las files."""
@@ -395,7 +396,7 @@ def test_reference_driver_linked_against_hip_library(gpu, tmp_path):
     exe = os.path.join(ROOT, "oracle", "_ref", "daligner_on_damar")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/daligner_on_damar not built (needs /root/reference at build time)")
-    case = read_case("tiny2")
+    case = read_case(name)          # mask_two: the reference's own read_DB loads and merges the tracks
     link_db(case["dbdir"], str(tmp_path))
     for a, bs in case["lines"]:
         subprocess.run([exe] + case["opts"] + ["G." + a] + ["G." + b for b in bs], cwd=str(tmp_path), check=True,
