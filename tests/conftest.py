@@ -77,6 +77,8 @@ def opts_to_plan_kwargs(opts):
         f, v = o[1], o[2:]
         if f in "kwhtlsj":
             kw[f] = int(v)
+        elif f == "r":
+            kw["run"] = int(v)
         elif f == "e":
             kw["e"] = float(v)
         elif f == "I":

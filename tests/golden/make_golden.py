@@ -47,6 +47,9 @@ CASES = {
     # daligner.c:263-439 and the per-block slicing of the track files are exercised)
     "mask_dust": dict(derive="lowcomp", tracks=["dust"], opts=["-k14", "-j4", "-mdust"], plan="all"),
     "mask_two":  dict(db="mask_dust", tracks=["dust", "rnd"], opts=["-k14", "-j4", "-mdust", "-mrnd"], plan="all"),
+    # the production parameterisation of the reference's scripts
+    "prod":      dict(db="mask_dust", tracks=["dust", "rnd"],
+                      opts=["-k14", "-e0.7", "-l700", "-I", "-mdust", "-mrnd", "-j4", "-r2"], plan="all"),
     # datander (scrub/datander.c) on the tandem-array reads and on plain reads (0 records)
     "tan_tandem": dict(db="tandem", tool="datander", opts=["-j4"], plan=[("1", [])]),
     "tan_k10":    dict(db="tandem", tool="datander", opts=["-k10", "-w3", "-h28", "-l400", "-j2"], plan=[("1", [])]),
