@@ -69,6 +69,7 @@ def _lib():
         L.damar_block_free.argtypes = [C.c_void_p]
         L.damar_load_masks.argtypes = [C.POINTER(HITS_DB), C.POINTER(C.c_char_p), C.c_int]
         L.damar_load_masks.restype = C.c_int
+        L.damar_async_d2h_ms.restype = C.c_double
         L.damar_index_build.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.damar_index_build.restype = C.c_void_p
         L.damar_index_free.argtypes = [C.c_void_p]

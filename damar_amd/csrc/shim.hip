@@ -68,6 +68,9 @@ extern "C" int Set_Filter_Params(int kmer, int binshift, int suppress, int hitmi
 
 static int          G_ready = 0;
 static hipStream_t  G_st;
+static hipStream_t   G_copy;                /* record downloads of the asynchronous mode */
+static hipEvent_t    G_report_done;
+static hipEvent_t    G_last_d2h = NULL;     /* the next report kernel must not overwrite the buffers before it */
 static hipDeviceProp_t G_prop;
 static hipEvent_t   G_ev[16];
 static double       G_ms[DAMAR_T_COUNT];
@@ -131,6 +134,8 @@ extern "C" int damar_hip_init(int device)
   HIP_CHECK(hipGetDeviceProperties(&G_prop, device));
   if (!G_ready)
     { HIP_CHECK(hipStreamCreate(&G_st));
+      HIP_CHECK(hipStreamCreate(&G_copy));
+      HIP_CHECK(hipEventCreate(&G_report_done));
       for (int i = 0; i < 16; i++)
         HIP_CHECK(hipEventCreate(&G_ev[i]));
       if (MEM_PHYSICAL == ~0ull)
@@ -455,7 +460,11 @@ static int default_slots(void)
 }
 
 static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 cell_cap)
-{ int span   = amax + bmax + 64;
+{ if (G_last_d2h != NULL)        /* whatever is launched next overwrites the record buffers */
+    { HIP_CHECK(hipStreamWaitEvent(G_st, G_last_d2h, 0));
+      G_last_d2h = NULL;
+    }
+  int span   = amax + bmax + 64;
   int bwidth = (amax >> binshift) - ((-bmax) >> binshift) + 1;
   int mtp    = 2 * (std::max(amax, bmax) / tspace + 2) + 8;
   u32 tstr   = (u32) (4 * mtp + 32);
@@ -490,12 +499,14 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
 static void scratch_outputs(u32 rec_cap, u32 tpool_cap)
 { if (RS.rec_cap < rec_cap)
     { HIP_CHECK(hipStreamSynchronize(G_st));
+      HIP_CHECK(hipStreamSynchronize(G_copy));
       if (RS.recs) HIP_CHECK(hipFree(RS.recs));
       RS.rec_cap = rec_cap + (rec_cap >> 2);
       RS.recs = (LaRecord *) dmalloc(sizeof(LaRecord) * (size_t) RS.rec_cap);
     }
   if (RS.tpool_cap < tpool_cap)
     { HIP_CHECK(hipStreamSynchronize(G_st));
+      HIP_CHECK(hipStreamSynchronize(G_copy));
       if (RS.tpool) HIP_CHECK(hipFree(RS.tpool));
       RS.tpool_cap = tpool_cap + (tpool_cap >> 2);
       RS.tpool = (u16 *) dmalloc(sizeof(u16) * (size_t) RS.tpool_cap);
@@ -552,6 +563,8 @@ struct HostBuf
 { LaRecord *recs;   size_t rec_cap;
   u16      *tpool;  size_t tp_cap;
   size_t    nrec, ntp;
+  hipEvent_t e0, e1;               /* around the download; e1 is what the tail thread waits for */
+  bool      pending;
 };
 static std::mutex             &HB_mu   = *new std::mutex();
 static std::vector<HostBuf *> &HB_free = *new std::vector<HostBuf *>();
@@ -565,7 +578,12 @@ static HostBuf *hostbuf_get(size_t nrec, size_t ntp)
       }
   }
   if (h == NULL)
-    h = new HostBuf();
+    { h = new HostBuf();
+      memset(h, 0, sizeof(*h));
+      HIP_CHECK(hipEventCreate(&h->e0));
+      HIP_CHECK(hipEventCreate(&h->e1));
+    }
+  h->pending = false;
   if (h->rec_cap < nrec)
     { if (h->recs) HIP_CHECK(hipHostFree(h->recs));
       h->rec_cap = nrec + (nrec >> 2) + 4096;
@@ -746,7 +764,7 @@ static Stage &A_s1 = *new Stage();
 static Stage &A_s2 = *new Stage();
 static std::mutex &A_mu = *new std::mutex();            /* the totals below */
 static int64  A_ncheck = 0;
-static double A_tail_ms = 0, A_write_ms = 0;
+static double A_tail_ms = 0, A_write_ms = 0, A_d2h_ms = 0;
 
 static void stage_submit(Stage &st, TailJob *job)
 { { std::lock_guard<std::mutex> lk(st.mu);
@@ -785,7 +803,15 @@ static void tail_worker(void)
         return;
       double t0 = now_ms();
       if (job->kind == 0)
-        { int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, job->ablock, job->bblock,
+        { if (job->hb->pending)
+            { float ms = 0;
+              HIP_CHECK(hipEventSynchronize(job->hb->e1));
+              HIP_CHECK(hipEventElapsedTime(&ms, job->hb->e0, job->hb->e1));
+              std::lock_guard<std::mutex> lk(A_mu);
+              A_d2h_ms += ms;
+              t0 = now_ms();
+            }
+          int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, job->ablock, job->bblock,
                              job->self, job->comp, job->spec);
           hostbuf_put(job->hb);
           delete job;
@@ -871,6 +897,15 @@ extern "C" void damar_async_totals(int64 *ncheck, double *tail_ms, double *write
   if (tail_ms)  *tail_ms = A_tail_ms;
   if (write_ms) *write_ms = A_write_ms;
   A_ncheck = 0;  A_tail_ms = 0;  A_write_ms = 0;
+}
+
+/* milliseconds the downloads of the asynchronous mode took since the last call (drains first) */
+extern "C" double damar_async_d2h_ms(void)
+{ damar_async_drain();
+  std::lock_guard<std::mutex> lk(A_mu);
+  double v = A_d2h_ms;
+  A_d2h_ms = 0;
+  return v;
 }
 
 /* Write_Overlap_Buffer + Reset_Overlap_Buffer (daligner.c:1020-1021, 1055-1056), queued behind
@@ -1178,13 +1213,26 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
       tick(6);
       h3 = now_ms();
       hb = hostbuf_get(hc[1], hc[2]);
+      hipStream_t cs = A_on ? G_copy : G_st;
+      if (A_on)
+        HIP_CHECK(hipEventRecord(hb->e0, cs));       /* (the report kernel has completed: the host synced on it) */
       if (hc[1] > 0)
-        { HIP_CHECK(hipMemcpyAsync(hb->recs, RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, G_st));
-          HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, G_st));
+        { HIP_CHECK(hipMemcpyAsync(hb->recs, RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, cs));
+          HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, cs));
         }
       tick(7);
-      HIP_CHECK(hipStreamSynchronize(G_st));
-      G_ms[DAMAR_T_D2H] = lap(6, 7);
+      if (A_on)
+        { /* asynchronous mode: the download runs on its own stream beside the next Match_Filter's
+             merge and sorts; the tail thread waits for it, and so does the next report kernel
+             (which would overwrite the device buffers) */
+          HIP_CHECK(hipEventRecord(hb->e1, cs));
+          hb->pending = true;
+          G_last_d2h = hb->e1;
+        }
+      else
+        { HIP_CHECK(hipStreamSynchronize(G_st));
+          G_ms[DAMAR_T_D2H] = lap(6, 7);
+        }
       nfilt = hc[4];
       G_cnt[2] = hc[4];  G_cnt[3] = hc[1];  G_cnt[4] = hc[2];
     }

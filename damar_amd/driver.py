@@ -104,6 +104,7 @@ class Plan:
             self.counts[2] += n.value
             self.timings["tail"] = self.timings.get("tail", 0.) + t.value
             self.timings["write"] = self.timings.get("write", 0.) + w.value
+            self.timings["d2h"] = self.timings.get("d2h", 0.) + L.damar_async_d2h_ms()
         for sp in self._specs:
             L.Free_Align_Spec(sp)
         self._specs = []

@@ -65,6 +65,7 @@ void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
 void damar_set_async(int on);
 void damar_async_drain(void);
 void damar_async_totals(int64 *ncheck, double *tail_ms, double *write_ms);
+double damar_async_d2h_ms(void);        /* time of the asynchronous record downloads since the last call */
 /* Write_Overlap_Buffer + Reset_Overlap_Buffer (daligner.c:1020-1021), queued in async mode */
 void damar_write_overlaps(Align_Spec *spec, const char *dirName1, const char *dirName2,
                           const char *ablock, const char *bblock, int lastRead);
