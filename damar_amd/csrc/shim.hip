@@ -360,7 +360,16 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
       die();
     }
   u32 n = nk;
-  ix->tbits = std::min(kbits, std::max(8, std::min(24, ilog2_ceil(nk) - 2)));
+  /* Prefix table resolution: one entry per code when that is affordable (2^28 entries = 1 GB for
+     k = 14; HBM is sized for it), so that a code's run is two adjacent table entries and no
+     dependent search at all -- the merge kernels are bound by the length of that chain. */
+  { static int tmax = -1;
+    if (tmax < 0)
+      { const char *e = getenv("DAMAR_TBITS");
+        tmax = e ? atoi(e) : 28;
+      }
+    ix->tbits = std::min(kbits, std::max(8, std::min(tmax, ilog2_ceil(nk) + 1)));
+  }
   ix->table = (u32 *) dmalloc(sizeof(u32) * (((size_t) 1 << ix->tbits) + 2));
   damar_launch_code_table(ix->codes, n, kbits, ix->tbits, ix->table, G_st);
 
