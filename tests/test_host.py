@@ -103,3 +103,26 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(dl, "lib_path", lambda: "/nonexistent/libdamar_hip.so")
     with pytest.raises(dl.LibraryMissing):
         dl.load()
+
+
+def test_lamerge_equals_reference(built, tmp_path):
+    """LAmerge (the step after daligner in every plan, HPCdaligner.c:790-808): the merged block
+    file equals what the reference's utils/LAmerge wrote for the same directory
+    (tests/golden/lamerge_ref_md5.txt, generated with oracle/_ref/LAmerge), with and without -s."""
+    import hashlib
+    import shutil
+    import subprocess
+    from conftest import GOLDEN, ROOT, link_db, read_case
+    exe = os.path.join(ROOT, "damar_amd", "bin", "LAmerge")
+    n = 0
+    for ln in open(os.path.join(GOLDEN, "lamerge_ref_md5.txt")):
+        md5, name, sub, flag = ln.split()
+        case = read_case(name)
+        w = os.path.join(str(tmp_path), "%s_%s_%d" % (name, sub, n))
+        link_db(case["dbdir"], w)
+        shutil.copytree(os.path.join(case["lasdir"], sub), os.path.join(w, sub))
+        subprocess.run([exe] + (["-s"] if flag == "-s" else []) + ["-n", "8", "G", "m.las", sub], cwd=w, check=True,
+                       stdout=subprocess.DEVNULL)
+        assert hashlib.md5(open(os.path.join(w, "m.las"), "rb").read()).hexdigest() == md5, ln
+        n += 1
+    assert n >= 8
