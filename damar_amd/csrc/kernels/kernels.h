@@ -9,6 +9,7 @@ size_t damar_scan_workspace_bytes(u64 n);
 void   damar_exclusive_scan_u32(const u32 *in, u32 *out, u64 n, void *work, u64 *total_dev, hipStream_t st);
 #define DAMAR_SCAN_TILE 4096      /* items per scan tile (sort_scan.hip) */
 void   damar_tile_offsets_u32(const u32 *in, u64 n, void *work, u64 *total_dev, hipStream_t st);
+void   damar_scan_tile_counts(u32 *tcount, u32 ntiles, u64 *total_dev, hipStream_t st);
 size_t damar_sort_workspace_bytes(u64 n);
 int    damar_radix_sort_u32(u32 *k0, u32 *v0, u32 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st);
 int    damar_radix_sort_u64(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st);
@@ -66,8 +67,9 @@ void damar_launch_merge_hitgram(const MergeArgs *m, const u32 *off, u64 total, u
 /* cnt = hits per A entry, toff = exclusive offset of each DAMAR_SCAN_TILE-sized tile of cnt */
 void damar_launch_merge_emit(const MergeArgs *m, const u32 *cnt, const u32 *toff, const u32 *jb, u64 nhits,
                              u64 *keys, u32 *vals, hipStream_t st);
-void damar_launch_pair_flags(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
-                             u64 *send /* 64 entries of scratch */, u32 *flags, hipStream_t st);
+void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
+                             u64 *send /* 64 entries of scratch */, u64 *bits, void *scan_work, u64 *total_dev,
+                             u32 *heads, hipStream_t st);
 #define WORK_COST_BITS 16
 #define WORK_COST_MAX  ((1u << WORK_COST_BITS) - 1)
 void damar_launch_work_cost(const u64 *keys, u64 nhits, int pbits, const u32 *work, u32 nwork, u32 coarse,

@@ -238,38 +238,80 @@ void slice_ends(const u64 *__restrict__ keys, u64 nhits, int bshift, int nshift,
   send[t] = e;
 }
 
+/* One workgroup per tile of DAMAR_SCAN_TILE seeds: the head predicate of every seed as one bit
+ * (64 seeds per ballot word), and the tile's head count.  The list of heads is then expanded
+ * from the bit words (pair_heads_expand) after a scan over the tile counts only -- no 4-byte
+ * flag and offset per seed, no device-wide scan over all seeds. */
+#define PH_ROUNDS (DAMAR_SCAN_TILE / 256)
 __global__ __launch_bounds__(256)
-void pair_flags(const u64 *__restrict__ keys, u64 nhits, int pbits, int minhit, int nshift,
-                const u64 *__restrict__ send, u32 *__restrict__ flags)
-{ const int nthr = 1 << nshift;
-  u64 i = (u64) blockIdx.x * 256u + threadIdx.x;
-  if (i >= nhits)
-    return;
-  const u64 pr = keys[i] >> pbits;
-  u32 f = 0;
-  if ((i == 0 || (keys[i - 1] >> pbits) != pr) && i + (u64) (minhit - 1) < nhits &&
-      (keys[i + (u64) (minhit - 1)] >> pbits) == pr)
-    { f = 1;
-      for (int t = 0; t < nthr; t++)
-        { u64 e = send[t];
-          if (i < e)
-            { if (i + (u64) minhit >= e) f = 0;
-              break;
+void pair_heads_mark(const u64 *__restrict__ keys, u64 nhits, int pbits, int minhit, int nshift,
+                     const u64 *__restrict__ send, u64 *__restrict__ bits, u32 *__restrict__ tcount)
+{ __shared__ u32 wsum[4];
+  const int nthr = 1 << nshift;
+  const int l = lane_id(), w = threadIdx.x >> 6;
+  const u64 base = (u64) blockIdx.x * DAMAR_SCAN_TILE;
+  u32 mine = 0;
+  for (int r = 0; r < PH_ROUNDS; r++)
+    { const u64 i = base + (u64) r * 256u + threadIdx.x;
+      bool f = false;
+      if (i < nhits)
+        { const u64 pr = keys[i] >> pbits;
+          if ((i == 0 || (keys[i - 1] >> pbits) != pr) && i + (u64) (minhit - 1) < nhits &&
+              (keys[i + (u64) (minhit - 1)] >> pbits) == pr)
+            { f = true;
+              for (int t = 0; t < nthr; t++)
+                { u64 e = send[t];
+                  if (i < e)
+                    { if (i + (u64) minhit >= e) f = false;
+                      break;
+                    }
+                }
             }
         }
+      const u64 m = __ballot(f);
+      if (l == 0)
+        { bits[(base >> 6) + (u64) r * 4 + w] = m;
+          mine += (u32) __popcll(m);
+        }
     }
-  flags[i] = f;
+  if (l == 0) wsum[w] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    tcount[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-void damar_launch_pair_flags(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
-                             u64 *send /* 64 entries of scratch */, u32 *flags, hipStream_t st)
+/* toff = exclusive scan of tcount; one wave per tile: lane j owns bit word j of the tile */
+__global__ __launch_bounds__(64)
+void pair_heads_expand(const u64 *__restrict__ bits, const u32 *__restrict__ toff, u32 *__restrict__ heads)
+{ const u64 wi = (u64) blockIdx.x * 64u + threadIdx.x;
+  u64 m = bits[wi];
+  const int c = __popcll(m);
+  u32 o = toff[blockIdx.x] + (u32) (wave_incl_scan_i(c) - c);
+  const u32 first = (u32) (wi << 6);
+  while (m)
+    { const int b = __ffsll((long long) m) - 1;
+      m &= m - 1;
+      heads[o++] = first + (u32) b;
+    }
+}
+
+/* heads = ascending indices of the run heads; *total_dev = their number.  bits: 64 u64 words per
+ * tile of DAMAR_SCAN_TILE seeds; scan_work: damar_scan_workspace_bytes(nhits) */
+void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
+                             u64 *send /* 64 entries of scratch */, u64 *bits, void *scan_work, u64 *total_dev,
+                             u32 *heads, hipStream_t st)
 { if (nhits == 0)
-    return;
+    { HIP_CHECK(hipMemsetAsync(total_dev, 0, sizeof(u64), st));
+      return;
+    }
   if (nshift > 6)
     nshift = 6;
+  const u32 ntiles = (u32) ((nhits + DAMAR_SCAN_TILE - 1) / DAMAR_SCAN_TILE);
+  u32 *tcount = (u32 *) scan_work;
   hipLaunchKernelGGL(slice_ends, dim3(1), dim3(64), 0, st, keys, nhits, abits + pbits, nshift, send);
-  hipLaunchKernelGGL(pair_flags, dim3((u32) ((nhits + 255) / 256)), dim3(256), 0, st, keys, nhits, pbits,
-                     minhit, nshift, send, flags);
+  hipLaunchKernelGGL(pair_heads_mark, dim3(ntiles), dim3(256), 0, st, keys, nhits, pbits, minhit, nshift, send, bits, tcount);
+  damar_scan_tile_counts(tcount, ntiles, total_dev, st);
+  hipLaunchKernelGGL(pair_heads_expand, dim3(ntiles), dim3(64), 0, st, bits, tcount, heads);
 }
 
 /* Screen of the run heads (the vast majority of runs are a few chance k-mer matches between

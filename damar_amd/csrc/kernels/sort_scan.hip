@@ -114,6 +114,11 @@ void damar_tile_offsets_u32(const u32 *in, u64 n, void *work, u64 *total_dev, hi
   hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, st, tsum, ntiles, total_dev);
 }
 
+/* in-place exclusive scan of `ntiles` counts (one workgroup), *total_dev = their sum */
+void damar_scan_tile_counts(u32 *tcount, u32 ntiles, u64 *total_dev, hipStream_t st)
+{ hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, st, tcount, ntiles, total_dev);
+}
+
 /***** radix sort ******************************************************************************/
 
 #define RS_THREADS 256

@@ -1121,11 +1121,9 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   /* ---- work list ---- */
   const int minhit = (P_hitmin - 1) / P_kmer + 1;
   u64 nwork64 = 0;
-  damar_launch_pair_flags(keys, total, m.pbits, m.abits, minhit, P_nshift, sends, flags, G_st);
-  stage("pair_flags");
-  damar_exclusive_scan_u32(flags, foff, total, scw2, tot, G_st);
   u32 *heads = side ? (u32 *) k0 : (u32 *) k1;         /* the idle key buffer holds the run heads */
-  damar_launch_compact_index(flags, foff, total, heads, G_st);
+  damar_launch_pair_heads(keys, total, m.pbits, m.abits, minhit, P_nshift, sends, (u64 *) foff /* bit words */,
+                          scw2, tot, heads, G_st);
   stage("run_heads");
   HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
   HIP_CHECK(hipStreamSynchronize(G_st));
