@@ -23,21 +23,20 @@ __device__ __forceinline__ u32 read_of_pos(const DevBlock &b, u32 p)
   return r;
 }
 
+/* One thread per base position p: the read through the coarse table (two dependent look-ups
+ * instead of a search over all reads), then the k-mer ENDING at p if the read has K bases up to
+ * there.  Read r owns k-mer indices [boff[r] - r*k, boff[r+1] - (r+1)*k), in position order. */
 __global__ __launch_bounds__(256)
 void kmer_tuples(DevBlock blk, int kmer, u32 nkmers, u32 *__restrict__ codes, u32 *__restrict__ pos)
-{ u32 i = blockIdx.x * 256u + threadIdx.x;
+{ const u32 p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= blk.total)
+    return;
+  const u32 r = read_of_pos(blk, p), b0 = blk.boff[r];
+  if (p - b0 < (u32) (kmer - 1) || p + 1 == blk.boff[r + 1])       /* too close to the start / the terminator */
+    return;
+  const u32 i = p - (r + 1) * (u32) kmer + 1;
   if (i >= nkmers)
     return;
-  /* read r owns k-mer indices [boff[r] - r*k, boff[r+1] - (r+1)*k) */
-  u32 lo = 0, hi = blk.nreads;
-  while (hi - lo > 1)
-    { u32 m = (lo + hi) >> 1;
-      if (blk.boff[m] - m * (u32) kmer <= i)
-        lo = m;
-      else
-        hi = m;
-    }
-  u32 p = i + (lo + 1) * (u32) kmer - 1;         /* offset of the k-mer's last base */
   const u8 *s = blk.bases + (p - (u32) (kmer - 1));
   u32 c = 0;
   for (int j = 0; j < kmer; j++)
@@ -49,7 +48,7 @@ void kmer_tuples(DevBlock blk, int kmer, u32 nkmers, u32 *__restrict__ codes, u3
 void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, u32 *codes, u32 *pos, hipStream_t st)
 { if (nkmers == 0)
     return;
-  hipLaunchKernelGGL(kmer_tuples, dim3((nkmers + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, codes, pos);
+  hipLaunchKernelGGL(kmer_tuples, dim3((blk->total + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, codes, pos);
 }
 
 /* The masked branch of tuple_thread (filter.c:474-526): between two mask intervals of a read
