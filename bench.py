@@ -206,11 +206,21 @@ def main():
                 nl = 2 * npairs
             dom_ms = kern[dom] / steps
             ach = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.
+            # HBM bytes per launch of the dominant kernel from the TCC counters: they cannot be read
+            # from inside this process, so the figure of the separate rocprofv3 --pmc passes over this
+            # very command (scripts/gpu_traffic.sh) is carried in profiles/r01_traffic.json
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                if dom.startswith(tj["kernel"]):
+                    traffic = tj["bytes_per_launch"]
+            except Exception:
+                traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                     "launches_per_step": nl, "avg_launch_ms": dom_ms / nl if nl else 0.,
                     "algorithmic_bytes_per_step": alg,
-                    "note": "wave kernel is latency/issue bound, not HBM bound (DESIGN.md); "
+                    "note": "wave kernel is VALU-issue bound (VALU pipes ~97 % busy, profiles/), not HBM bound; "
                             "phase ms per step: " + ", ".join("%s=%.1f" % (k, v / steps) for k, v in sorted(tim.items()))}
             cpu = None
             if world == 1 and not args.no_cpu:
