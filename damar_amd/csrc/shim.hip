@@ -448,7 +448,7 @@ extern "C" void *Sort_Kmers(HITS_DB *block, int *len)
 /***** report scratch ******************************************************************************/
 
 struct ReportScratch
-{ int   nslots, span, bwidth;
+{ int nslots_wanted; int   nslots, span, bwidth;
   u32   cell_cap;
   u32   ttmp_stride;
   void *state;  int *marks;  void *cells;  int *buckets;  u16 *ttmp;
@@ -459,7 +459,7 @@ struct ReportScratch
   LaRecord *recs;  u32 rec_cap;
   u16  *tpool;     u32 tpool_cap;
 };
-static ReportScratch RS = {};
+static ReportScratch RS = {};   /* (nslots_wanted: the slot count asked for when nslots was last sized) */
 
 static int default_slots(void)
 { const char *e = getenv("DAMAR_SLOTS");
@@ -478,10 +478,33 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
   int mtp    = 2 * (std::max(amax, bmax) / tspace + 2) + 8;
   u32 tstr   = (u32) (4 * mtp + 32);
   int nslots = default_slots();
-  if (RS.nslots != nslots || RS.span < span || RS.bwidth < bwidth || RS.cell_cap < cell_cap || RS.ttmp_stride < tstr)
+  bool grow = RS.span < span || RS.bwidth < bwidth || RS.cell_cap < cell_cap || RS.ttmp_stride < tstr;
+  if (grow || (RS.nslots != nslots && RS.nslots_wanted != nslots))
     { HIP_CHECK(hipStreamSynchronize(G_st));
       if (RS.state)   { HIP_CHECK(hipFree(RS.state)); HIP_CHECK(hipFree(RS.marks)); HIP_CHECK(hipFree(RS.cells));
-                        HIP_CHECK(hipFree(RS.buckets)); HIP_CHECK(hipFree(RS.ttmp)); }
+                        HIP_CHECK(hipFree(RS.buckets)); HIP_CHECK(hipFree(RS.ttmp)); RS.state = NULL; }
+      /* the scratch of all wave slots must fit what is left of HBM (very long reads: the
+         per-slot band buffers grow with alen + blen): fewer resident alignments then, never a
+         failed allocation in the middle of a run */
+      RS.nslots_wanted = nslots;
+      { size_t freeb = 0, totb = 0;
+        const u64 nspan = (u64) std::max(RS.span, span), ncell = std::max(RS.cell_cap, cell_cap);
+        const u64 per = damar_report_state_stride((int) nspan) + 4ull * 2 * nspan + 16ull * ncell +
+                        4ull * (3ull * std::max(RS.bwidth, bwidth) + 16) + 2ull * std::max(RS.ttmp_stride, tstr);
+        HIP_CHECK(hipMemGetInfo(&freeb, &totb));
+        const u64 budget = (u64) (freeb * 0.6);
+        if ((u64) nslots * per > budget)
+          { int fit = (int) (budget / per);
+            if (fit < 64)
+              { fprintf(stderr, "damar: FATAL: not enough device memory for the alignment scratch (%.1f MB per wave slot, %.1f GB free)\n",
+                        per / 1048576., freeb / 1073741824.);
+                die();
+              }
+            if (VERBOSE)
+              fprintf(stderr, "damar: %d instead of %d resident alignments (%.1f MB of scratch each)\n", fit, nslots, per / 1048576.);
+            nslots = fit;
+          }
+      }
       RS.nslots = nslots;
       RS.span   = std::max(RS.span, span);
       RS.bwidth = std::max(RS.bwidth, bwidth);

@@ -31,6 +31,9 @@ SIMDB = os.path.join(ROOT, "damar_amd", "bin", "simdb")
 # name -> (how to make the DB, daligner options, plan lines)
 CASES = {
     "tiny2":   dict(sim=["0.1", "-c12", "-r11", "-e.15", "-S1"], opts=["-k14", "-j4"], plan="all"),
+    # reads of 60-160 kb: several 50 kb A-panels per read pair (filter.c:2251), long waves
+    "long":    dict(sim=["0.4", "-c6", "-r41", "-e.15", "-m110000", "-s25000", "-x60000", "-S200"], opts=["-k14", "-j4"],
+                    plan=[("1", ["1"])]),
     "tiny_j1": dict(db="tiny2", opts=["-k14", "-j1"], plan=[("1", ["1"])]),
     "tiny_s":  dict(db="tiny2", opts=["-k14", "-j4", "-s126", "-l800", "-e.75"], plan=[("2", ["2", "1"])]),
     "tiny_t":  dict(db="tiny2", opts=["-k14", "-j2", "-t12"], plan=[("1", ["1"])]),
