@@ -15,6 +15,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <zlib.h>
+
 #include "damar_db.h"
 
 static void *xmalloc(size_t n, const char *what)
@@ -336,8 +338,88 @@ HITS_DB *damar_complement_block(HITS_DB *block, int inplace)
  * ints, data = the union of the intervals (daligner.c:263-439 Merge_Size / Merge_Tracks; the
  * union is formed by sorting: overlapping or abutting intervals merge, which selects the same
  * k-mers as the reference's heap sweep whatever order it meets equal coordinates in).
- * Returns 0, or -1 after printing what is wrong.  The compressed .a2/.d2 form of
- * lib/tracks.c is not read. */
+ * Returns 0, or -1 after printing what is wrong.  lib/tracks.c's compressed .a2/.d2 form is
+ * tried first, as track_load does. */
+/* lib/tracks.c:20-131 track_load, compressed form: <path>.<track>.a2 = 64-byte header {u16 version,
+ * u16 size, u32 pad, u64 len, u64 clen, u64 cdlen, 4 reserved u64} + clen bytes, <path>.<track>.d2 =
+ * cdlen bytes; both payloads are runs of {u64 n, n bytes of zlib stream}, each stream inflating to
+ * at most 8 MiB (lib/compression.c).  anno = u64 byte offsets for ALL reads of the database; the
+ * block's slice is cut out here.  Returns 1 if loaded, 0 if there is no .a2 file, -1 on error. */
+static int inflate_chunks(const unsigned char *in, uint64 ilen, unsigned char *out, uint64 olen)
+{ uint64 ip = 0, op = 0;
+  while (ip < ilen)
+    { uint64 clen;
+      uLongf dlen;
+      if (ip + 8 > ilen)
+        return -1;
+      memcpy(&clen, in + ip, 8);
+      ip += 8;
+      if (ip + clen > ilen)
+        return -1;
+      dlen = (uLongf) (olen - op);
+      if (uncompress(out + op, &dlen, in + ip, (uLong) clen) != Z_OK)
+        return -1;
+      ip += clen;
+      op += dlen;
+    }
+  return 0;
+}
+
+static int load_a2(const HITS_DB *block, const char *name, int64 **offs_out, int **data_out)
+{ char   path[4400];
+  FILE  *af, *df;
+  struct { uint16 version, size; uint32 pad; uint64 len, clen, cdlen, r1, r2, r3, r4; } h;
+  unsigned char *cbuf = NULL, *dbuf = NULL;
+  uint64 *anno = NULL;
+  int64  *offs;
+  int    *data;
+  int     i, nreads = block->nreads, rc = -1;
+
+  snprintf(path, sizeof(path), "%s.%s.a2", block->path, name);
+  if ((af = fopen(path, "r")) == NULL)
+    return 0;
+  snprintf(path, sizeof(path), "%s.%s.d2", block->path, name);
+  df = fopen(path, "r");
+  if (fread(&h, sizeof(h), 1, af) != 1 || h.size != 8 || df == NULL)
+    { fprintf(stderr, "damar: could not read header / data of track %s\n", name);
+      goto done;
+    }
+  if ((block->part == 0 && h.len != (uint64) nreads) || h.len < (uint64) (block->ufirst + nreads))
+    { fprintf(stderr, "damar: invalid track length in header of track %s\n", name);
+      goto done;
+    }
+  cbuf = (unsigned char *) xmalloc((size_t) h.clen + 8, "track");
+  anno = (uint64 *) xmalloc(8 * (size_t) (h.len + 1), "track");
+  if ((h.clen > 0 && fread(cbuf, (size_t) h.clen, 1, af) != 1) ||
+      inflate_chunks(cbuf, h.clen, (unsigned char *) anno, 8 * (h.len + 1)))
+    { fprintf(stderr, "damar: failed to read anno track %s\n", name);
+      goto done;
+    }
+  free(cbuf);
+  cbuf = (unsigned char *) xmalloc((size_t) h.cdlen + 8, "track");
+  dbuf = (unsigned char *) xmalloc((size_t) anno[h.len] + 8, "track");
+  if ((h.cdlen > 0 && fread(cbuf, (size_t) h.cdlen, 1, df) != 1) ||
+      inflate_chunks(cbuf, h.cdlen, dbuf, anno[h.len]))
+    { fprintf(stderr, "damar: failed to read data track %s\n", name);
+      goto done;
+    }
+  { const uint64 o0 = anno[block->ufirst], dlen = anno[block->ufirst + nreads] - o0;
+    offs = (int64 *) xmalloc(sizeof(int64) * (size_t) (nreads + 1), "mask index");
+    data = (int *) xmalloc((size_t) dlen + 8, "mask data");
+    for (i = 0; i <= nreads; i++)
+      offs[i] = (int64) ((anno[block->ufirst + i] - o0) / sizeof(int));
+    memcpy(data, dbuf + o0, (size_t) dlen);
+    *offs_out = offs;
+    *data_out = data;
+  }
+  rc = 1;
+done:
+  free(cbuf);  free(dbuf);  free(anno);
+  fclose(af);
+  if (df) fclose(df);
+  return rc;
+}
+
 typedef struct { int beg, end; } Ival;
 
 static int ival_cmp(const void *x, const void *y)
@@ -360,6 +442,12 @@ int damar_load_masks(HITS_DB *block, char **names, int n)
   for (t = 0; t < n; t++)
     { FILE *af = NULL, *df = NULL;
       int   tracklen, size, ispart = 0, ureads;
+      { int got = load_a2(block, names[t], &offs[t], &dats[t]);       /* lib/tracks.c tries this form first */
+        if (got < 0)
+          goto done;
+        if (got > 0)
+          continue;
+      }
       if (block->part > 0)
         { snprintf(path, sizeof(path), "%s.%d.%s.anno", block->path, block->part, names[t]);
           af = fopen(path, "r");

@@ -50,6 +50,8 @@ CASES = {
     # daligner.c:263-439 and the per-block slicing of the track files are exercised)
     "mask_dust": dict(derive="lowcomp", tracks=["dust"], opts=["-k14", "-j4", "-mdust"], plan="all"),
     "mask_two":  dict(db="mask_dust", tracks=["dust", "rnd"], opts=["-k14", "-j4", "-mdust", "-mrnd"], plan="all"),
+    # the same two tracks, the second one stored in lib/tracks.c's compressed .a2/.d2 form
+    "mask_a2":   dict(db="mask_dust", tracks=["dust", "rz"], opts=["-k14", "-j4", "-mdust", "-mrz"], plan="all"),
     # the production parameterisation of the reference's scripts
     "prod":      dict(db="mask_dust", tracks=["dust", "rnd"],
                       opts=["-k14", "-e0.7", "-l700", "-I", "-mdust", "-mrnd", "-j4", "-r2"], plan="all"),
@@ -204,9 +206,32 @@ def make_tracks(dbdir, root, tracks):
     """Interval tracks in the DAZZ_DB layout (db/DB.c:1113 Load_Track): .anno = int tracklen,
     int size(8), int64 byte offsets[tracklen+1]; .data = int pairs [beg,end)."""
     import struct
+    import zlib
     for t in tracks:
         if t == "dust":
             run([os.path.join(REF, "DBdust"), root], dbdir, stdout=subprocess.DEVNULL)
+        elif t == "rz":
+            # the intervals of "rnd" in the compressed form: header {u16 version=2, u16 size=8, u32 pad,
+            # u64 len, clen, cdlen, 4 x u64 reserved}, payloads = {u64 n, n bytes of zlib stream}*
+            if not os.path.exists(os.path.join(dbdir, ".%s.rnd.anno" % root)):
+                make_tracks(dbdir, root, ["rnd"])
+            a = open(os.path.join(dbdir, ".%s.rnd.anno" % root), "rb").read()
+            d = open(os.path.join(dbdir, ".%s.rnd.data" % root), "rb").read()
+            n = struct.unpack("<i", a[:4])[0]
+            anno = a[8:]
+
+            def chunks(buf, step=8 * 1024 * 1024):
+                out = b""
+                for i in range(0, len(buf), step):
+                    z = zlib.compress(buf[i:i + step])
+                    out += struct.pack("<Q", len(z)) + z
+                return out
+            ca, cd = chunks(anno), chunks(d)
+            with open(os.path.join(dbdir, ".%s.rz.a2" % root), "wb") as f:
+                f.write(struct.pack("<HHIQQQQQQQ", 2, 8, 0, n, len(ca), len(cd), 0, 0, 0, 0))
+                f.write(ca)
+            with open(os.path.join(dbdir, ".%s.rz.d2" % root), "wb") as f:
+                f.write(cd)
         else:
             rng = random.Random(77)
             lens = read_lengths(dbdir, root)
@@ -276,9 +301,10 @@ def main():
                 dbdir, root = os.path.join(HERE, c["db"]), "G"
             tfiles = []
             for t in c.get("tracks", []):
-                if not os.path.exists(os.path.join(dbdir, ".G.%s.anno" % t)):
+                ext = (".a2", ".d2") if t == "rz" else (".anno", ".data")
+                if not os.path.exists(os.path.join(dbdir, ".G.%s%s" % (t, ext[0]))):
                     make_tracks(dbdir, "G", [t])
-                tfiles += [".G.%s.anno" % t, ".G.%s.data" % t]
+                tfiles += [".G.%s%s" % (t, e) for e in ext]
             nblocks = int(open(os.path.join(dbdir, "G.db")).read().split("blocks =")[1].split()[0])
             plan = c["plan"]
             if plan == "all":
