@@ -97,7 +97,7 @@ def _lib():
     return L
 
 
-def set_globals(verbose=0, minover=2000, symmetric=1, identity=0, hgap_min=0):
+def set_globals(verbose=0, minover=2000, symmetric=1, identity=0, hgap_min=0, biased=0):
     """The globals daligner.c:131-140 shares with filter.c (MINOVER is already doubled)."""
     L = _lib()
     C.c_int.in_dll(L, "VERBOSE").value = verbose
@@ -105,6 +105,7 @@ def set_globals(verbose=0, minover=2000, symmetric=1, identity=0, hgap_min=0):
     C.c_int.in_dll(L, "SYMMETRIC").value = symmetric
     C.c_int.in_dll(L, "IDENTITY").value = identity
     C.c_int.in_dll(L, "HGAP_MIN").value = hgap_min
+    C.c_int.in_dll(L, "BIASED").value = biased
 
 
 def sim_write_db(directory, root, genome_mbp, coverage=20., seed=1, erate=.15, block_mbp=200,

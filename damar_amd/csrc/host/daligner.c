@@ -19,7 +19,7 @@
 
 static void usage(void)
 { fprintf(stderr, "usage:\n");
-  fprintf(stderr, "daligner [-vAIOT] [-k<int(14)>] [-w<int(6)>] [-h<int(35)>] [-t<int>] [-M<int>] [-m<track>]+\n");
+  fprintf(stderr, "daligner [-vbAIOT] [-k<int(14)>] [-w<int(6)>] [-h<int(35)>] [-t<int>] [-M<int>] [-m<track>]+\n");
   fprintf(stderr, "         [-e<double(.70)] [-l<int(1000)>] [-s<int(100)>] [-H<int>] [-j<int>]\n");
   fprintf(stderr, "         [-r<int(1)>] [-g<gpu ordinal(0)>] <subject:db> <target:db> ...\n");
 }
@@ -101,7 +101,8 @@ int main(int argc, char *argv[])
           }
         mask[mtop++] = optarg;
         break;
-      case 'b': case 'D':
+      case 'b': BIASED = 1; break;
+      case 'D':
         fprintf(stderr, "daligner: option -%c is not supported by this build\n", c);
         exit(1);
       default:

@@ -38,6 +38,9 @@ void damar_launch_pack_bases(const u8 *bases, u32 total, u32 *pk, hipStream_t st
 void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, u32 *codes, u32 *pos, hipStream_t st);
 /* keep[i] = 1 iff k-mer i lies inside one unmasked stretch of its read (filter.c:474-526) */
 void damar_launch_mask_flags(const DevBlock *blk, int kmer, const u32 *pos, u32 n, u32 *keep, hipStream_t st);
+/* -b: keep[] (cleared by the caller, blk->total entries) marks the block offsets where a k-mer ends */
+void damar_launch_biased_tuples(const DevBlock *blk, int kmer, const int *logbase, u32 *codes, u32 *pos, u32 *keep,
+                                hipStream_t st);
 void damar_launch_code_table(const u32 *codes, u32 n, int kbits, int tbits, u32 *table, hipStream_t st);
 void damar_launch_suppress_flags(const u32 *codes, u32 n, const u32 *table, int kbits, int tbits, int suppress,
                                  u32 *keep, hipStream_t st);

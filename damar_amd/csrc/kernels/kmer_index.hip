@@ -78,6 +78,77 @@ void damar_launch_mask_flags(const DevBlock *blk, int kmer, const u32 *pos, u32 
   hipLaunchKernelGGL(mask_flags, dim3((n + 255) / 256), dim3(256), 0, st, *blk, kmer, pos, n, keep);
 }
 
+/* -b (filter.c:549-688): the window walk is a serial state machine along a read, so one thread
+ * walks one read (a block holds >= 10^4 reads; this runs once per index build).  A k-mer that
+ * ends at block offset P is left at codes[P] / pos[P] with keep[P] = 1 (keep is cleared by the
+ * caller); the usual compaction then puts them in (read, rpos) order.  Masked reads are walked
+ * stretch by stretch, including the reference's end-of-stretch case (:602: the growing loop stops
+ * at the end of a stretch but the window is still offered, with rpos = the stretch end). */
+__global__ __launch_bounds__(64)
+void biased_tuples(DevBlock blk, int kmer, int lb0, int lb1, int lb2, int lb3,
+                   u32 *__restrict__ codes, u32 *__restrict__ pos, u32 *__restrict__ keep)
+{ const u32 r = blockIdx.x * 64u + threadIdx.x;
+  if (r >= blk.nreads)
+    return;
+  const int  LogNorm = 10000 * kmer, LogThresh = 10000 * (kmer - 2);
+  const u32  kmask = (kmer == 16) ? 0xffffffffu : ((1u << (2 * kmer)) - 1);
+  const u32  b0 = blk.boff[r];
+  const int  rlen = (int) (blk.boff[r + 1] - b0) - 1;
+  const u8  *s = blk.bases + b0;
+  const bool masked = blk.moff != NULL;
+  const u32  sb = masked ? blk.moff[r] : 0, sf = masked ? blk.moff[r + 1] : 0;
+#define LB(x) ((x) == 0 ? lb0 : ((x) == 1 ? lb1 : ((x) == 2 ? lb2 : lb3)))
+  for (u32 sa = sb; sa <= sf; sa += 2)
+    { int p = (sa == sb) ? 0 : blk.mdat[sa - 1];
+      const int q = (sa == sf) ? rlen : blk.mdat[sa];
+      if (p + kmer > q)
+        continue;
+      u64 c = 0;
+      int a = 0, k = 1;
+      bool stop = false;
+      while (p < q)
+        { int x = s[p];
+          a += LB(x);
+          c = (c << 2) | (u64) x;
+          while (a < LogNorm && k < kmer)
+            { if (++p >= q)
+                { stop = !masked;
+                  break;
+                }
+              k += 1;
+              x = s[p];
+              a += LB(x);
+              c = (c << 2) | (u64) x;
+            }
+          if (stop)
+            break;
+          for (;;)
+            { const int u = a - LB((int) s[p - k + 1]);
+              if (u < LogNorm) break;
+              a = u;
+              k -= 1;
+            }
+          if (a > LogThresh)
+            { const u32 P = b0 + (u32) p;
+              codes[P] = (u32) (c << (2 * kmer - 2 * k)) & kmask;
+              pos[P]   = P;
+              keep[P]  = 1u;
+            }
+          p += 1;
+          a -= LB((int) s[p - k]);
+        }
+    }
+#undef LB
+}
+
+void damar_launch_biased_tuples(const DevBlock *blk, int kmer, const int *logbase, u32 *codes, u32 *pos, u32 *keep,
+                                hipStream_t st)
+{ if (blk->nreads == 0)
+    return;
+  hipLaunchKernelGGL(biased_tuples, dim3((blk->nreads + 63) / 64), dim3(64), 0, st, *blk, kmer,
+                     logbase[0], logbase[1], logbase[2], logbase[3], codes, pos, keep);
+}
+
 /* table[q] for q in [0, 2^tbits]: written by the element that starts each prefix
  * change (it also fills the prefixes that do not occur at all). */
 __global__ __launch_bounds__(256)

@@ -189,6 +189,7 @@ extern "C" int  damar_last_limit(void)          { return G_limit; }
 
 struct damar_dev_block
 { DevBlock d;
+  float freq[4];           /* base frequencies of the block (-b) */
   u32 *pk_alloc;
   u32 *moff;
   int *mdat;
@@ -235,6 +236,8 @@ extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
   HIP_CHECK(hipStreamSynchronize(G_st));
   b->d.boff   = b->boff;
   b->d.coarse = b->coarse;
+  for (int i = 0; i < 4; i++)
+    b->freq[i] = block->freq[i];
   b->d.nreads = (u32) n;
   b->d.total  = (u32) total;
   b->d.maxlen = block->maxlen;
@@ -286,14 +289,16 @@ static int ilog2_ceil(u64 n)
   return b;
 }
 
-static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *len, int K, int suppress)
+static int  B_have = 0, B_log[4];        /* -b log weights, fixed by the first biased Sort_Kmers of the process */
+
+/* A new job in the same process (the in-process driver, tests): forget the -b weights, as a
+ * fresh daligner process would. */
+extern "C" void damar_bias_reset(void) { B_have = 0; }
+
+static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *len, int K, int suppress, int use_bias)
 { ensure_init();
   if (K > 16)
     { fprintf(stderr, "damar: FATAL: -k%d: the device index holds 2k <= 32 code bits (k <= 16) in this build\n", K);
-      die();
-    }
-  if (BIASED)
-    { fprintf(stderr, "damar: FATAL: -b (biased k-mers, filter.c:549-688) is not built yet\n");
       die();
     }
   int64 nk64 = (int64) blk->d.total - (int64) K * blk->nreads;
@@ -306,24 +311,34 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
   u32 nk = (u32) nk64;
   const int kbits = 2 * K;
   const bool masked = blk->d.moff != NULL;
+  const bool biased = use_bias != 0;
+  /* -b (filter.c:774-789): the log weights are set by the FIRST block a process sorts and then
+     kept (the reference tests a static pointer), also for complemented and other blocks */
+  if (biased && !B_have)
+    { const double scale = -10000. / log(4.);
+      for (int i = 0; i < 4; i++)
+        B_log[i] = (int) ceil(scale * log((double) blk->freq[i]));
+      B_have = 1;
+    }
+  const u32 cap = biased ? blk->d.total : nk;          /* -b can leave one k-mer per base */
   const int npass = (kbits + 7) / 8;
   damar_dev_index *ix = (damar_dev_index *) calloc(1, sizeof(damar_dev_index));
   ix->blk = blk;  ix->own_block = own_block;  ix->kbits = kbits;
-  ix->codes = (u32 *) dmalloc(sizeof(u32) * (size_t) nk);
-  ix->pos   = (u32 *) dmalloc(sizeof(u32) * (size_t) nk);
+  ix->codes = (u32 *) dmalloc(sizeof(u32) * (size_t) cap);
+  ix->pos   = (u32 *) dmalloc(sizeof(u32) * (size_t) cap);
 
-  size_t swb = damar_sort_workspace_bytes(nk);
-  arena_reserve(&G_work, 4 * pad256(sizeof(u32) * (size_t) nk) + pad256(swb) + pad256(damar_scan_workspace_bytes(nk)) + (1 << 16));
-  u32 *tk = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
-  u32 *tv = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
+  size_t swb = damar_sort_workspace_bytes(cap);
+  arena_reserve(&G_work, 4 * pad256(sizeof(u32) * (size_t) cap) + pad256(swb) + pad256(damar_scan_workspace_bytes(cap)) + (1 << 16));
+  u32 *tk = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) cap);
+  u32 *tv = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) cap);
   void *sw = arena_take(&G_work, swb);
   u32 *keep = NULL, *off = NULL;
   void *scw = NULL;
   u64 *tot = NULL;
-  if (masked || suppress > 0)
-    { keep = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
-      off  = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) nk);
-      scw  = arena_take(&G_work, damar_scan_workspace_bytes(nk));
+  if (masked || biased || suppress > 0)
+    { keep = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) cap);
+      off  = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) cap);
+      scw  = arena_take(&G_work, damar_scan_workspace_bytes(cap));
       tot  = (u64 *) arena_take(&G_work, 64);
     }
 
@@ -332,7 +347,26 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
   u32 *k1 = (npass & 1) ? ix->codes : tk, *v1 = (npass & 1) ? ix->pos : tv;
 
   tick(0);
-  if (!masked)
+  if (biased)
+    { /* filter.c:549-688: windows of adaptive length, walked read by read; then the same squeeze */
+      u32 *k9 = (k0 == tk) ? ix->codes : tk, *v9 = (v0 == tv) ? ix->pos : tv;
+      u64  kept = 0;
+      HIP_CHECK(hipMemsetAsync(keep, 0, sizeof(u32) * (size_t) cap, G_st));
+      damar_launch_biased_tuples(&blk->d, K, B_log, k9, v9, keep, G_st);
+      damar_exclusive_scan_u32(keep, off, cap, scw, tot, G_st);
+      damar_launch_compact_pairs(k9, v9, keep, off, cap, k0, v0, G_st);
+      HIP_CHECK(hipMemcpyAsync(&kept, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      nk = (u32) kept;
+      if (nk == 0)
+        { damar_index_free(ix);
+          *len = 0;
+          return NULL;
+        }
+      if (VERBOSE)
+        printf("\n   Revised kmer count = %u\n", nk);
+    }
+  else if (!masked)
     damar_launch_kmer_tuples(&blk->d, K, nk, k0, v0, G_st);
   else
     { /* filter.c:474-526 + the filler squeeze of :855-888: only k-mers inside one unmasked
@@ -407,7 +441,7 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
 
 extern "C" damar_dev_index *damar_index_build(damar_dev_block *blk, int own_block, int *len)
 { double t0 = now_ms();
-  damar_dev_index *ix = index_build_k(blk, own_block, len, P_kmer, P_suppress);
+  damar_dev_index *ix = index_build_k(blk, own_block, len, P_kmer, P_suppress, BIASED);
   H_ms[0] += now_ms() - t0;
   return ix;
 }
@@ -1338,7 +1372,7 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
   if (counts)
     counts[0] = counts[1] = counts[2] = 0;
   memset(G_cnt, 0, sizeof(G_cnt));
-  damar_dev_index *ix = index_build_k(blk, 0, &n, T_kmer, 0);
+  damar_dev_index *ix = index_build_k(blk, 0, &n, T_kmer, 0, 0);
   if (ix == NULL)
     return;
   const int ts = Trace_Spacing(spec);

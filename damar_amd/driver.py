@@ -79,12 +79,13 @@ class Plan:
     """daligner <A> <B1> <B2> ... for resident blocks."""
 
     def __init__(self, k=14, w=6, h=35, t=0, e=.70, l=1000, s=100, j=4, run=1,
-                 symmetric=1, identity=0, verbose=0, async_tail=True, masks=None):
+                 symmetric=1, identity=0, verbose=0, async_tail=True, masks=None, biased=0):
         self.k, self.w, self.h, self.t, self.e, self.l, self.s, self.j, self.run = k, w, h, t, e, l, s, j, run
         self.symmetric, self.identity, self.verbose = symmetric, identity, verbose
         self.masks = list(masks or [])
         L = api.lib()
-        api.set_globals(verbose=verbose, minover=2 * l, symmetric=symmetric, identity=identity)
+        api.set_globals(verbose=verbose, minover=2 * l, symmetric=symmetric, identity=identity, biased=biased)
+        L.damar_bias_reset()
         if L.Set_Filter_Params(k, w, t, h, j):
             raise ValueError("Illegal combination of filter parameters")
         self.timings = {}

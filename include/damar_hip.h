@@ -87,6 +87,11 @@ int64 damar_last_seeds(void *out, int64 cap);
  * 10000 unless the host memory limit forces it lower; INT32_MAX when MEM_LIMIT is 0). */
 int damar_last_limit(void);
 
+/* -b: the reference derives its log base weights from the first block a PROCESS sorts and keeps
+ * them (filter.c:774-789).  A caller that runs several jobs in one process calls this between
+ * them to get what separate daligner processes would compute. */
+void damar_bias_reset(void);
+
 /* Test hook: batch Local_Alignment (align.c:1904 with low == hgh == diag, no borders)
  * on the GPU.  tasks[4*i..] = aread, bread, diag, anti (block-local read ids).
  * paths[12*i..] = A-view abpos,bbpos,aepos,bepos,diffs,tlen then the same for the

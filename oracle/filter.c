@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <limits.h>
+#include <math.h>
 
 #include "oracle.h"
 #include "../damar_amd/csrc/host/damar_host.h"
@@ -76,9 +77,73 @@ OKmer *oracle_sort_kmers(const HITS_DB *block, const OParams *prm, int *len)
     { *len = 0;
       return NULL;
     }
-  src = (OKmer *) xalloc(sizeof(OKmer) * (size_t) (kmers + 2));
-  tmp = (OKmer *) xalloc(sizeof(OKmer) * (size_t) (kmers + 2));
+  { int64 room = prm->biased ? block->reads[nreads].boff : kmers;      /* -b can yield one k-mer per base */
+    src = (OKmer *) xalloc(sizeof(OKmer) * (size_t) (room + 2));
+    tmp = (OKmer *) xalloc(sizeof(OKmer) * (size_t) (room + 2));
+  }
 
+  /* filter.c:549-688 + 774-789, -b: a window ending at p grows (up to K bases) until the summed
+     -log4 frequency of its bases reaches K "average" bases, then sheds bases from its left end
+     while it still does; it yields a k-mer (left-aligned in 2K bits) if its weight exceeds K-2.
+     The weights come from the FIRST block a process sorts (static NormShift != NULL test). */
+  if (prm->biased)
+    { static int have = 0, LogBase[4];
+      const int LogNorm = 10000 * K, LogThresh = 10000 * (K - 2);
+      const HITS_TRACK *trk = block->tracks;
+      if (!have)
+        { double scale = -10000. / log(4.);
+          for (i = 0; i < 4; i++)
+            LogBase[i] = (int) ceil(scale * log(block->freq[i]));
+          have = 1;
+        }
+      for (i = 0; i < nreads; i++)
+        { const char *s = bases + block->reads[i].boff;
+          const int64 *anno = trk ? (const int64 *) trk->anno : NULL;
+          const int   *point = trk ? (const int *) trk->data : NULL;
+          int64 sa, sb = trk ? anno[i] : 0, sf = trk ? anno[i + 1] : 0;
+          for (sa = sb; sa <= sf; sa += 2)
+            { int p = (sa == sb) ? 0 : point[sa - 1];
+              int q = (sa == sf) ? block->reads[i].rlen : point[sa];
+              uint64 c = 0;
+              int    a = 0, k = 1, x, stop = 0;
+              if (p + K > q)
+                continue;
+              while (p < q)
+                { x = s[p];
+                  a += LogBase[x];
+                  c = (c << 2) | (uint64) x;
+                  while (a < LogNorm && k < K)
+                    { if (++p >= q)
+                        { stop = (trk == NULL);      /* unmasked: goto eoread2 (filter.c:648); masked: only this loop ends (:602) */
+                          break;
+                        }
+                      k += 1;
+                      x = s[p];
+                      a += LogBase[x];
+                      c = (c << 2) | (uint64) x;
+                    }
+                  if (stop)
+                    break;
+                  for (;;)
+                    { int u = a - LogBase[(int) s[p - k + 1]];
+                      if (u < LogNorm) break;
+                      a = u;
+                      k -= 1;
+                    }
+                  if (a > LogThresh)
+                    { src[n].code = (c << (2 * K - 2 * k)) & kmask;
+                      src[n].rpos = p;
+                      src[n].read = i;
+                      n += 1;
+                    }
+                  p += 1;
+                  a -= LogBase[(int) s[p - k]];
+                }
+            }
+        }
+      kmers = n;
+    }
+  else
   /* filter.c:474-526, masked branch: block->tracks is the merged interval track (anno in ints,
      data = [beg,end) pairs); k-mers are taken from every stretch [p,q) between two intervals
      (before the first, after the last) that holds at least K bases.  The reference pads the

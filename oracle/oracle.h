@@ -40,6 +40,7 @@ typedef struct
   int symmetric;   /* !-A */
   int identity;    /* -I */
   int64 mem_limit; /* bytes; 0 = no cap (filter.c:2634-2702) */
+  int   biased;    /* -b (filter.c:549-688); the log weights are fixed by the first block sorted */
 } OParams;
 
 /* K1+K2+K3: filter.c:458-547 tuple_thread, :328-435 lex_sort, :700-751 -t compaction,

@@ -56,6 +56,7 @@ int main(int argc, char *argv[])
       case 'j': nthreads = atoi(optarg); break;
       case 'M': prm.mem_limit = atoi(optarg) * 0x40000000ll; break;
       case 'r': runid = atoi(optarg); break;
+      case 'b': prm.biased = 1; break;
       case 'm': if (mtop < 64) mask[mtop++] = optarg; break;       /* daligner.c:788-795 */
       default:
         fprintf(stderr, "oracle_daligner: unsupported option -%c\n", optopt ? optopt : c);

@@ -87,6 +87,8 @@ def opts_to_plan_kwargs(opts):
             kw["symmetric"] = 0
         elif f == "m":
             kw.setdefault("masks", []).append(v)
+        elif f == "b":
+            kw["biased"] = 1
     return kw
 
 

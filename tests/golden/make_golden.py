@@ -52,6 +52,9 @@ CASES = {
     "mask_two":  dict(db="mask_dust", tracks=["dust", "rnd"], opts=["-k14", "-j4", "-mdust", "-mrnd"], plan="all"),
     # the same two tracks, the second one stored in lib/tracks.c's compressed .a2/.d2 form
     "mask_a2":   dict(db="mask_dust", tracks=["dust", "rz"], opts=["-k14", "-j4", "-mdust", "-mrz"], plan="all"),
+    # -b (biased k-mers, filter.c:549-688) on reads of skewed base composition, plain and masked
+    "bias":      dict(sim=["0.1", "-c12", "-r51", "-e.15", "-b.3", "-S1"], opts=["-k14", "-j4", "-b"], plan="all"),
+    "bias_mask": dict(db="mask_dust", tracks=["dust", "rnd"], opts=["-k14", "-j4", "-b", "-mdust", "-mrnd"], plan="all"),
     # the production parameterisation of the reference's scripts
     "prod":      dict(db="mask_dust", tracks=["dust", "rnd"],
                       opts=["-k14", "-e0.7", "-l700", "-I", "-mdust", "-mrnd", "-j4", "-r2"], plan="all"),

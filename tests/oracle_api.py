@@ -15,7 +15,7 @@ SEED_DT = np.dtype([("diag", "<i4"), ("apos", "<i4"), ("aread", "<i4"), ("bread"
 class OParams(C.Structure):
     _fields_ = [("kmer", C.c_int), ("binshift", C.c_int), ("suppress", C.c_int), ("hitmin", C.c_int),
                 ("nthreads", C.c_int), ("minover", C.c_int), ("hgap_min", C.c_int), ("symmetric", C.c_int),
-                ("identity", C.c_int), ("mem_limit", c_int64)]
+                ("identity", C.c_int), ("mem_limit", c_int64), ("biased", C.c_int)]
 
 
 class Path(C.Structure):

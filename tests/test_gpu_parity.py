@@ -52,7 +52,7 @@ def test_gpu_las_equals_reference_golden(gpu, tmp_path, name):
     assert compare_las(case, str(tmp_path)) == []
 
 
-@pytest.mark.parametrize("name", ["tiny2", "tan_tandem", "mask_two"])
+@pytest.mark.parametrize("name", ["tiny2", "tan_tandem", "mask_two", "bias_mask"])
 def test_gpu_cli_binary_equals_reference_golden(gpu, tmp_path, name):
     """The C host drivers (the drop-in daligner / datander commands)."""
     from conftest import run_cli
