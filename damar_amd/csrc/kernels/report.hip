@@ -359,6 +359,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
 
   /***** register path: the band (<= 64 diagonals) lives in VGPRs, neighbours by lane shuffle *****/
   bool stopped = false;
+  u32  err_flags = 0, err_empty = 0;          /* wave-uniform, reported once after the loop */
 #ifdef DAMAR_PROF
   int pf_first16 = -1, pf_first32 = -1;
 #endif
@@ -396,16 +397,17 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
 
     const int src_me = lane << 2, src_up = ((lane + 1) & 63) << 2, src_dn = ((lane - 1) & 63) << 2;   /* bpermute addresses */
     while (more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
-      { /* pin the wave-uniform bookkeeping to SGPRs */
-        low = uni(low);  hgh = uni(hgh);  dif = uni(dif);  besta = uni(besta);  besty = uni(besty);
-        lasta = uni(lasta);  ncell = (u32) uni((int) ncell);  reachm = uni(reachm);
+      { /* (the bookkeeping is wave-uniform by construction -- ballots, readlanes, pinned inputs --
+           and the compiler's uniformity analysis agrees, so it lives in SGPRs across iterations) */
         if (hgh < low)
-          { if (lane == 0) atomicAdd(errw + 2, 1u);
+          { err_empty += 1;          /* (reported after the loop: a lane-0 branch in here would make
+                                        the compiler treat the loop exit, and with it all the
+                                        loop-carried bookkeeping, as lane-varying) */
             stopped = true;
             break;
           }
         if (dif > steplimit)
-          { if (lane == 0) atomicOr(errw, DAMAR_ERR_BAND);
+          { err_flags |= DAMAR_ERR_BAND;
             stopped = true;
             break;
           }
@@ -582,7 +584,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
             }
         }
         if (ncell > cell_cap)
-          { if (lane == 0) atomicOr(errw, DAMAR_ERR_CELLS);
+          { err_flags |= DAMAR_ERR_CELLS;
             more = 0;
             ncell = 2;
             stopped = true;
@@ -606,6 +608,10 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
         }
       }
 #undef CLIP_REG
+    if ((err_flags | err_empty) && lane == 0)
+      { if (err_flags) atomicOr(errw, err_flags);
+        if (err_empty) atomicAdd(errw + 2, err_empty);
+      }
 
     /* leaving the register path with work left: spill the band to the memory buffers */
     if (!stopped && more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
