@@ -28,6 +28,10 @@ typedef unsigned char      u8;
 
 #ifdef __HIPCC__
 __device__ __forceinline__ int  lane_id()            { return (int) (threadIdx.x & 63); }
+/* Ballot of a condition that is already a lane mask: HIP's __ballot(int) first turns the bool into
+   0/1 per lane and compares it again (two VALU instructions); the builtin takes the mask as it is. */
+__device__ __forceinline__ u64  wballot(bool p)      { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wany(bool p)         { return __builtin_amdgcn_ballot_w64(p) != 0; }
 __device__ __forceinline__ u64  lanes_below(int l)   { return (l == 0) ? 0ull : (~0ull >> (64 - l)); }
 __device__ __forceinline__ int  bcast_i(int v, int l){ return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int  first_i(int v)       { return __builtin_amdgcn_readfirstlane(v); }

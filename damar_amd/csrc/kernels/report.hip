@@ -181,14 +181,15 @@ __device__ __forceinline__ SnakeOut snake(const u8 *a, const u8 *bq, int y, int 
  * the reference, B first.  A lane that is already past an end (never seen in practice; the
  * reference would then compare whatever follows in memory) takes the byte path above, which
  * reads exactly what the reference reads. */
-__device__ __forceinline__ u32 load16(const u32 *pk, int p)           /* bases p .. p+15, base p in bits 0-1 */
-{ /* byte offset of the dword holding base p, from a base moved back by the padding so that the
-     offset is unsigned (p >= -16 always): scalar base + 32-bit lane offset, no 64-bit lane maths */
-  const u32 off = ((u32) (p + 16 * PK_PAD) >> 2) & ~3u;
-  typedef u32 v2u __attribute__((ext_vector_type(2)));
+/* pb = p + 16*PK_PAD: the position biased by the front padding, so that the dword offset from
+   (pk - PK_PAD) is unsigned (p >= -16 always): scalar base + 32-bit lane offset, no 64-bit lane
+   maths, and the bias costs nothing in the shift (128 bits = 0 mod 32) */
+__device__ __forceinline__ u32 load16(const u32 *pk, u32 pb)          /* bases p .. p+15, base p in bits 0-1 */
+{ typedef u32 v2u __attribute__((ext_vector_type(2)));
+  const u32 off = (pb >> 2) & ~3u;
   const GLOBAL_AS v2u *q = (const GLOBAL_AS v2u *) ((const GLOBAL_AS char *) (pk - PK_PAD) + off);
   const v2u w = *q;
-  return __builtin_amdgcn_alignbit(w.y, w.x, (u32) p * 2);             /* the shift uses bits 0-4: 2*(p & 15) */
+  return __builtin_amdgcn_alignbit(w.y, w.x, pb * 2);                  /* the shift uses bits 0-4: 2*(p & 15) */
 }
 
 template <int REV>
@@ -196,8 +197,8 @@ __device__ __forceinline__ SnakeOut snake_pk(const u32 *apk, const u32 *bpk, int
                                              int y, int m, u64 b)
 { /* fwd: ap/bp = positions of the next bases to compare; rev: of the first ones below */
   for (;;)
-    { const u32 wa = REV ? load16(apk, ap - 15) : load16(apk, ap);
-      const u32 wb = REV ? load16(bpk, bp - 15) : load16(bpk, bp);
+    { const u32 wa = REV ? load16(apk, (u32) (ap - 15)) : load16(apk, (u32) ap);
+      const u32 wb = REV ? load16(bpk, (u32) (bp - 15)) : load16(bpk, (u32) bp);
       const u32 x = wa ^ wb;
       u32 run;
       if (!REV) run = x ? (u32) __builtin_ctz(x) >> 1 : 16u;
@@ -228,7 +229,7 @@ __device__ __forceinline__ SnakeOut snake_pk(const u32 *apk, const u32 *bpk, int
   (((u32) ((y) + (k)) > (u32) valen || (u32) (y) > (u32) vblen)                                 \
      ? snake<REV>(aseq + (k), bseq, (y), (m), (b))                                              \
      : (REV ? snake_pk<1>(apk, bpk, va0 + (k) + (y) - 1, vb0 + (y) - 1, (y) + (k), (y), (y), (m), (b)) \
-            : snake_pk<0>(apk, bpk, va0 + (k) + (y), vb0 + (y), valen - ((y) + (k)), vblen - (y), (y), (m), (b))))
+            : snake_pk<0>(apk, bpk, va0 + (k) + (y), vb0 + (y), valen - ((y) + (k)), vblen - (y), (y), (m), (b))))   /* va0, vb0 carry the padding bias */
 
 /* One direction of the wave.  REV = 0: align.c:409-1122, REV = 1: align.c:1126-1898.
  * Returns through *res the end point of this direction; traces are written by lane 0. */
@@ -275,7 +276,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
   const u32 *apk = uni_ptr(c.apk), *bpk = uni_ptr(c.bpk);
   /* the reads' geometry is only used in per-lane arithmetic: kept in VGPRs (the same value in
      every lane) so that it does not compete for the scalar registers of the loop control */
-  const int va0 = (int) c.a0, vb0 = (int) c.b0, valen = c.alen, vblen = c.blen;
+  const int va0 = (int) c.a0 + 16 * PK_PAD, vb0 = (int) c.b0 + 16 * PK_PAD, valen = c.alen, vblen = c.blen;
   (void) apk; (void) bpk; (void) va0; (void) vb0; (void) valen; (void) vblen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
@@ -484,7 +485,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
 
         /* pebbles (align.c:859-909): almost never needed, so test once for the whole wave */
         int na = rNA, nb = rNB;
-        if (__any(act && (REV ? ((y + k <= na) || (y <= nb)) : ((y + k >= na) || (y >= nb)))))
+        if (wany(act && (REV ? ((y + k <= na) || (y <= nb)) : ((y + k >= na) || (y >= nb)))))
           { /* marks of the two chain heads (cells may have been written by other lanes of this
                wave in earlier steps: make those stores visible, read past the L1) */
             wave_mem_sync();
@@ -492,10 +493,10 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
             hbm = act ? __hip_atomic_load(&cellbuf[hb].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
             for (;;)
               { bool need = act && (REV ? (y + k <= na) : (y + k >= na));
-                if (!__any(need))
+                if (!wany(need))
                   break;
                 bool dropit = need && (REV ? (ham > na) : (ham < na));
-                u64  mask = __ballot(dropit);
+                u64  mask = wballot(dropit);
                 if (mask)
                   { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                     if (dropit)
@@ -512,10 +513,10 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
               }
             for (;;)
               { bool need = act && (REV ? (y <= nb) : (y >= nb));
-                if (!__any(need))
+                if (!wany(need))
                   break;
                 bool dropit = need && (REV ? (hbm > nb) : (hbm < nb));
-                u64  mask = __ballot(dropit);
+                u64  mask = wballot(dropit);
                 if (mask)
                   { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                     if (dropit)
@@ -537,7 +538,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
         if (act) { rM = m;  rT = b;  rHA = ha;  rHB = hb;  rNA = na;  rNB = nb; }
 
         /* sequence ends reached (bit i of the rotated masks = diagonal low + i) */
-        { u64 am_ = __ballot(ahit), bm_ = __ballot(bhit);
+        { u64 am_ = wballot(ahit), bm_ = wballot(bhit);
           if (am_ | bm_)
             { more = 0;
               if (am_)
@@ -555,7 +556,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
            could become the new best looks its own history up in TABLE/SCORE first (one round
            trip for the whole band), so the serial sweep below touches no memory. */
         { const bool mine = act && (REV ? (v < besta) : (v > besta));
-          u64 cand = __ballot(mine);
+          u64 cand = wballot(mine);
           if (cand)
             { int tok = 0;
               if (mine && m >= ave)
@@ -596,7 +597,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
         /* prune (align.c:977-986 / 1686-1695) */
         { const int n = REV ? besta + MAX_WAVE_LAG : besta - MAX_WAVE_LAG;
           const int kk = low + ((lane - low) & 63);
-          u64 keep = __ballot((kk <= hgh) && (REV ? (rV <= n) : (rV >= n)));
+          u64 keep = wballot((kk <= hgh) && (REV ? (rV <= n) : (rV >= n)));
           if (keep == 0)
             hgh = low - 1;
           else
@@ -655,7 +656,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
   const u32 *apk = uni_ptr(c.apk), *bpk = uni_ptr(c.bpk);
   /* the reads' geometry is only used in per-lane arithmetic: kept in VGPRs (the same value in
      every lane) so that it does not compete for the scalar registers of the loop control */
-  const int va0 = (int) c.a0, vb0 = (int) c.b0, valen = c.alen, vblen = c.blen;
+  const int va0 = (int) c.a0 + 16 * PK_PAD, vb0 = (int) c.b0 + 16 * PK_PAD, valen = c.alen, vblen = c.blen;
   (void) apk; (void) bpk; (void) va0; (void) vb0; (void) valen; (void) vblen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
@@ -782,10 +783,10 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
           for (;;)
             { GUARD(g2, guard, 5)
               bool need = act && (REV ? (y + k <= na) : (y + k >= na));
-              if (!__any(need))
+              if (!wany(need))
                 break;
               bool dropit = need && (REV ? (ham > na) : (ham < na));
-              u64  mask = __ballot(dropit);
+              u64  mask = wballot(dropit);
               if (mask)
                 { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                   if (dropit)
@@ -804,10 +805,10 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
           for (;;)
             { GUARD(g2, guard, 6)
               bool need = act && (REV ? (y <= nb) : (y >= nb));
-              if (!__any(need))
+              if (!wany(need))
                 break;
               bool dropit = need && (REV ? (hbm > nb) : (hbm < nb));
-              u64  mask = __ballot(dropit);
+              u64  mask = wballot(dropit);
               if (mask)
                 { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                   if (dropit)
@@ -832,7 +833,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
             }
 
           /* sequence ends reached in this chunk */
-          { u64 am_ = __ballot(ahit), bm_ = __ballot(bhit);
+          { u64 am_ = wballot(ahit), bm_ = wballot(bhit);
             if (am_ | bm_)
               { more = 0;
                 if (am_)
@@ -849,7 +850,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
           }
 
           /* new best / trim point, candidates replayed in sweep order (align.c:911-928) */
-          { u64 cand = __ballot(act && (REV ? (v < besta) : (v > besta)));
+          { u64 cand = wballot(act && (REV ? (v < besta) : (v > besta)));
             while (cand)
               { int l = __ffsll((long long) cand) - 1;
                 cand &= cand - 1;
@@ -888,7 +889,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
         for (int kb = hgh; kb >= low && !found; kb -= 64)
           { int  k = kb - lane;
             bool ok = (k >= low) && (REV ? (cur[k + o].V <= n) : (cur[k + o].V >= n));
-            u64  mk = __ballot(ok);
+            u64  mk = wballot(ok);
             if (mk)
               { newh = kb - (__ffsll((long long) mk) - 1);
                 found = true;
@@ -899,7 +900,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
             for (int kb = low; kb <= newh && !f2; kb += 64)
               { int  k = kb + lane;
                 bool ok = (k <= newh) && (REV ? (cur[k + o].V <= n) : (cur[k + o].V >= n));
-                u64  mk = __ballot(ok);
+                u64  mk = wballot(ok);
                 if (mk)
                   { newl = kb + (__ffsll((long long) mk) - 1);
                     f2 = true;
@@ -928,7 +929,7 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
   const u32 *apk = uni_ptr(c.apk), *bpk = uni_ptr(c.bpk);
   /* the reads' geometry is only used in per-lane arithmetic: kept in VGPRs (the same value in
      every lane) so that it does not compete for the scalar registers of the loop control */
-  const int va0 = (int) c.a0, vb0 = (int) c.b0, valen = c.alen, vblen = c.blen;
+  const int va0 = (int) c.a0 + 16 * PK_PAD, vb0 = (int) c.b0 + 16 * PK_PAD, valen = c.alen, vblen = c.blen;
   (void) apk; (void) bpk; (void) va0; (void) vb0; (void) valen; (void) vblen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
@@ -1297,8 +1298,8 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
           int  ap = in ? (int) (keys[f] & pmask) : 0;
           bool nextsame = (f + 1 < a.nhits) && ((keys[f + 1] >> a.pbits) == cpair);
           bool stop = in && !(nextsame && ap <= amark);
-          u64  le = __ballot(in && ap <= amark2);
-          u64  sm = __ballot(stop);
+          u64  le = wballot(in && ap <= amark2);
+          u64  sm = wballot(stop);
           if (sm)
             { int l = __ffsll((long long) sm) - 1;
               end = base + l + 1;
@@ -1307,7 +1308,7 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
               break;
             }
           if (le) h2 = base + (63 - __clzll(le)) + 1;
-          if (!__any(in))            /* cannot happen: a run always ends with a stop */
+          if (!wany(in))            /* cannot happen: a run always ends with a stop */
             { end = base; break; }
         }
       nidx = end;
@@ -1327,11 +1328,11 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
               int  prev = in ? s.lastp[d] : 0;
               /* lanes of this chunk that fall into the same bucket: the nearest one below
                  supplies lastp, the highest one stores it (match-any over the bucket bits) */
-              u64  peers = __ballot(in);
+              u64  peers = wballot(in);
               { const u32 db = (u32) (d - mind);
                 for (int bit = 0; bit < a.bucket_bits; bit++)
                   { const bool one = (db >> bit) & 1;
-                    const u64  mk = __ballot(one);
+                    const u64  mk = wballot(one);
                     peers &= one ? mk : ~mk;
                   }
               }
@@ -1365,9 +1366,9 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
                 { int sc = s.score[d];
                   hot = (sc + s.score[d + 1] >= H) || (sc + s.score[d - 1] >= H);
                 }
-              u64 todo = __ballot(hot);
+              u64 todo = wballot(hot);
               while (todo)
-                { u64 fire = __ballot(hot && ((todo >> lane) & 1) && ap > s.lasta[d]);
+                { u64 fire = wballot(hot && ((todo >> lane) & 1) && ap > s.lasta[d]);
                   if (!fire)
                     break;
                   int l = __ffsll((long long) fire) - 1;
@@ -1472,11 +1473,11 @@ __device__ void process_read(const ReportArgs &a, const SlotScratch &s, const in
           const bool in = dg != 0;
           const int  d = dg >> W;
           int  prev = in ? s.lastp[d] : 0;
-          u64  peers = __ballot(in);
+          u64  peers = wballot(in);
           { const u32 db = (u32) (d - mind);
             for (int bit = 0; bit < a.bucket_bits; bit++)
               { const bool one = (db >> bit) & 1;
-                const u64  mk = __ballot(one);
+                const u64  mk = wballot(one);
                 peers &= one ? mk : ~mk;
               }
           }
@@ -1505,9 +1506,9 @@ __device__ void process_read(const ReportArgs &a, const SlotScratch &s, const in
             { int sc = s.score[d];
               hot = (sc + s.score[d + 1] >= H) || (sc + s.score[d - 1] >= H);
             }
-          u64 todo = __ballot(hot);
+          u64 todo = wballot(hot);
           while (todo)
-            { u64 fire = __ballot(hot && ((todo >> lane) & 1) && apos > s.lasta[d]);
+            { u64 fire = wballot(hot && ((todo >> lane) & 1) && apos > s.lasta[d]);
               if (!fire)
                 break;
               int l = __ffsll((long long) fire) - 1;
