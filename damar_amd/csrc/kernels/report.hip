@@ -138,7 +138,7 @@ __device__ __forceinline__ u64 load8(const u8 *p)
  * leaving the 60-column window was a 0; n matches at once examine bits 60..61-n of b. */
 /* Returns 0, or 1 if the snake stopped on A's terminator, 2 if on B's (B is tested first).
  * Everything is passed and returned by value so that nothing lives in scratch memory. */
-struct SnakeOut { int y, m; bool ahit, bhit; u64 b; };   /* stopped on A's / B's terminator (B is tested first) */
+struct SnakeOut { int y, m, na, nb; u64 b; };   /* nb == 0: stopped on B's terminator; else na == 0: on A's (B is tested first) */
 
 template <int REV>
 __device__ __forceinline__ SnakeOut snake(const u8 *a, const u8 *bq, int y, int m, u64 b)
@@ -171,7 +171,7 @@ __device__ __forceinline__ SnakeOut snake(const u8 *a, const u8 *bq, int y, int 
         }
     }
   SnakeOut o;
-  o.y = y;  o.m = m;  o.b = b;  o.ahit = ahit;  o.bhit = bhit;
+  o.y = y;  o.m = m;  o.b = b;  o.nb = bhit ? 0 : 1;  o.na = ahit ? 0 : 1;
   return o;
 }
 
@@ -218,9 +218,7 @@ __device__ __forceinline__ SnakeOut snake_pk(const u32 *apk, const u32 *bpk, int
         break;
     }
   SnakeOut o;
-  o.y = y;  o.m = m;  o.b = b;
-  o.bhit = (nb == 0);
-  o.ahit = (nb != 0) && (na == 0);
+  o.y = y;  o.m = m;  o.b = b;  o.na = na;  o.nb = nb;
   return o;
 }
 
@@ -333,8 +331,8 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
     int g0 = 0;
     { const SnakeOut so = SNAKE_AT(k, y, 0, 0ull);
       y = uni(so.y);
-      if (uni((int) so.bhit))      { more = 0; bclip = k; }
-      else if (uni((int) so.ahit)) { more = 0; aclip = k; }
+      if (uni(so.nb) == 0)      { more = 0; bclip = k; }
+      else if (uni(so.na) == 0) { more = 0; aclip = k; }
     }
     v = (y << 1) + k;
     while (REV ? (y + k <= na) : (y + k >= na))
@@ -439,7 +437,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
         const bool act = k <= hgh;
         int  v, y = 0, m, ha, hb, ham, hbm;
         u64  b;
-        bool ahit = false, bhit = false;
+        int  ena = 1, enb = 1;                  /* bases left in A / B where the snake stopped */
 
         { const int ac = rV;
           int am = lane_dn(rV), ap = lane_up(rV);
@@ -477,10 +475,13 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
             y = (v - k) >> 1;
             { const SnakeOut so = SNAKE_AT(k, y, m, b);
               y = so.y;  m = so.m;  b = so.b;
-              ahit = so.ahit;  bhit = so.bhit;
+              ena = so.na;  enb = so.nb;
             }
             v = (y << 1) + k;
           }
+        /* the end-of-read flags as plain compares after the join (a bool carried out of the
+           branch would be turned into 0/1 per lane and compared again) */
+        const bool bhit = act && enb == 0, ahit = act && enb != 0 && ena == 0;
         /* (lanes outside the band: only V = edge is ever looked at, by the neighbours) */
 
         /* pebbles (align.c:859-909): almost never needed, so test once for the whole wave */
@@ -771,7 +772,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
               y = (v - k) >> 1;
               { const SnakeOut so = SNAKE_AT(k, y, m, b);
                 y = so.y;  m = so.m;  b = so.b;
-                ahit = so.ahit;  bhit = so.bhit;
+                bhit = so.nb == 0;  ahit = so.nb != 0 && so.na == 0;
               }
               v = (y << 1) + k;
               na = c.NA[k + o];
