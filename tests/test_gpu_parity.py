@@ -402,3 +402,35 @@ def test_reference_driver_linked_against_hip_library(gpu, tmp_path, name):
         subprocess.run([exe] + case["opts"] + ["G." + a] + ["G." + b for b in bs], cwd=str(tmp_path), check=True,
                        stdout=subprocess.DEVNULL)
     assert compare_las(case, str(tmp_path)) == []
+
+
+def test_gpu_sparse_coverage_equals_oracle(gpu, tmp_path):
+    """Hardly any true overlaps (0.4x coverage): almost every read pair dies in the screen or in the
+    band filter, some block pairs produce no record at all; the .las files (header-only ones
+    included) must equal the oracle's."""
+    import subprocess
+    from damar_amd import api, driver
+    d = str(tmp_path)
+    nb = api.sim_write_db(d, "S", 3.0, coverage=.4, seed=9, block_mbp=1)
+    assert nb == 2
+    blocks = {i: driver.Block(os.path.join(d, "S.%d" % i)) for i in (1, 2)}
+    plan = driver.Plan(j=4)
+    out = os.path.join(d, "gpu")
+    for a, bs in driver.hpc_plan(2):
+        plan.run_line(blocks[a], [blocks[b] for b in bs], out)
+    plan.finish()
+    orc = os.path.join(d, "orc")
+    os.makedirs(orc)
+    for f in ("S.db", ".S.idx", ".S.bps"):
+        os.symlink(os.path.join(d, f), os.path.join(orc, f))
+    for a, bs in driver.hpc_plan(2):
+        subprocess.run([os.path.join(ROOT, "oracle", "oracle_daligner"), "-k14", "-j4", "S.%d" % a] + ["S.%d" % b for b in bs],
+                       cwd=orc, check=True, stdout=subprocess.DEVNULL)
+    n = 0
+    for dp, _, fs in os.walk(orc):
+        for f in fs:
+            if f.endswith(".las"):
+                rel = os.path.relpath(os.path.join(dp, f), orc)
+                assert open(os.path.join(dp, f), "rb").read() == open(os.path.join(out, rel), "rb").read(), rel
+                n += 1
+    assert n == 4
