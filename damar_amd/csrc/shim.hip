@@ -92,6 +92,43 @@ static void *dmalloc(size_t n)
   return p;
 }
 
+/* The k-mer index arrays (8 B per k-mer plus a table of up to 1 GB) come and go with every index:
+ * hipMalloc / hipFree of such sizes costs tens of milliseconds each and synchronises the device,
+ * so released buffers are parked here and handed out again (best fit within 25 % slack).  The
+ * pool is bounded; what does not fit is really freed. */
+struct PoolBuf { void *p; size_t n; };
+static std::vector<PoolBuf> &DP_free = *new std::vector<PoolBuf>();
+static size_t DP_bytes = 0;
+static const size_t DP_LIMIT = (size_t) 48 << 30;
+
+static void *dpool_get(size_t n, size_t *got)
+{ int best = -1;
+  for (size_t i = 0; i < DP_free.size(); i++)
+    if (DP_free[i].n >= n && DP_free[i].n <= n + (n >> 2) + (1 << 20) && (best < 0 || DP_free[i].n < DP_free[best].n))
+      best = (int) i;
+  if (best >= 0)
+    { PoolBuf b = DP_free[best];
+      DP_free.erase(DP_free.begin() + best);
+      DP_bytes -= b.n;
+      *got = b.n;
+      return b.p;
+    }
+  *got = n;
+  return dmalloc(n);
+}
+
+static void dpool_put(void *p, size_t n)
+{ if (p == NULL)
+    return;
+  if (DP_bytes + n > DP_LIMIT || DP_free.size() >= 64)
+    { HIP_CHECK(hipFree(p));
+      return;
+    }
+  PoolBuf b = { p, n };
+  DP_free.push_back(b);
+  DP_bytes += n;
+}
+
 static void arena_reserve(Arena *a, size_t need)
 { if (need <= a->cap)
     { a->top = 0;
@@ -275,7 +312,8 @@ extern "C" void damar_block_free(damar_dev_block *b)
 /***** index **************************************************************************************/
 
 struct damar_dev_index
-{ damar_dev_block *blk;
+{ size_t codes_bytes, pos_bytes, table_bytes;      /* what the pool gave (dpool_get) */
+  damar_dev_block *blk;
   int   own_block;
   u32  *codes, *pos, *table;
   u32   n;
@@ -324,8 +362,8 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
   const int npass = (kbits + 7) / 8;
   damar_dev_index *ix = (damar_dev_index *) calloc(1, sizeof(damar_dev_index));
   ix->blk = blk;  ix->own_block = own_block;  ix->kbits = kbits;
-  ix->codes = (u32 *) dmalloc(sizeof(u32) * (size_t) cap);
-  ix->pos   = (u32 *) dmalloc(sizeof(u32) * (size_t) cap);
+  ix->codes = (u32 *) dpool_get(sizeof(u32) * (size_t) cap, &ix->codes_bytes);
+  ix->pos   = (u32 *) dpool_get(sizeof(u32) * (size_t) cap, &ix->pos_bytes);
 
   size_t swb = damar_sort_workspace_bytes(cap);
   arena_reserve(&G_work, 4 * pad256(sizeof(u32) * (size_t) cap) + pad256(swb) + pad256(damar_scan_workspace_bytes(cap)) + (1 << 16));
@@ -404,7 +442,7 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
       }
     ix->tbits = std::min(kbits, std::max(8, std::min(tmax, ilog2_ceil(nk) + 1)));
   }
-  ix->table = (u32 *) dmalloc(sizeof(u32) * (((size_t) 1 << ix->tbits) + 2));
+  ix->table = (u32 *) dpool_get(sizeof(u32) * (((size_t) 1 << ix->tbits) + 2), &ix->table_bytes);
   damar_launch_code_table(ix->codes, n, kbits, ix->tbits, ix->table, G_st);
 
   if (suppress > 0)                         /* filter.c:890-939 */
@@ -450,10 +488,9 @@ extern "C" void damar_index_free(damar_dev_index *ix)
 { if (ix == NULL)
     return;
   HIP_CHECK(hipStreamSynchronize(G_st));
-  HIP_CHECK(hipFree(ix->codes));
-  HIP_CHECK(hipFree(ix->pos));
-  if (ix->table)
-    HIP_CHECK(hipFree(ix->table));
+  dpool_put(ix->codes, ix->codes_bytes);       /* (the stream was synchronised above: nothing reads them any more) */
+  dpool_put(ix->pos, ix->pos_bytes);
+  dpool_put(ix->table, ix->table_bytes);
   if (ix->own_block)
     damar_block_free(ix->blk);
   free(ix);
