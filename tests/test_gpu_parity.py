@@ -434,3 +434,47 @@ def test_gpu_sparse_coverage_equals_oracle(gpu, tmp_path):
                 assert open(os.path.join(dp, f), "rb").read() == open(os.path.join(out, rel), "rb").read(), rel
                 n += 1
     assert n == 4
+
+
+def test_gpu_random_option_combinations_equal_oracle(gpu, tmp_path):
+    """Differential sweep of the option space on a small two-block database: every combination is
+    run through the in-process driver on the GPU and through oracle_daligner on the CPU (the oracle
+    itself is pinned on each option family by the reference goldens); all .las must be identical."""
+    import itertools
+    import subprocess
+    from damar_amd import driver
+    rng = random.Random(2024)
+    dbdir = os.path.join(GOLDEN, "mask_dust")
+    combos = []
+    for _ in range(10):
+        o = dict(k=rng.choice([10, 12, 14, 16]), w=rng.choice([4, 5, 6, 7]), h=rng.choice([25, 35, 50]),
+                 e=rng.choice([.65, .7, .8]), l=rng.choice([500, 1000, 2000]), s=rng.choice([50, 100, 126, 200]),
+                 t=rng.choice([0, 0, 8, 20]), j=rng.choice([1, 2, 4, 8]))
+        o["identity"] = rng.choice([0, 1])
+        o["symmetric"] = rng.choice([1, 1, 0])
+        o["masks"] = rng.choice([[], ["dust"], ["dust", "rnd"]])
+        o["biased"] = rng.choice([0, 0, 1])
+        combos.append(o)
+    for n, o in enumerate(combos):
+        gdir, odir = os.path.join(str(tmp_path), "g%d" % n), os.path.join(str(tmp_path), "o%d" % n)
+        link_db(dbdir, gdir)
+        link_db(dbdir, odir)
+        blocks = {i: driver.Block(os.path.join(gdir, "G.%d" % i)) for i in (1, 2)}
+        plan = driver.Plan(**o)
+        for a, bs in driver.hpc_plan(2):
+            plan.run_line(blocks[a], [blocks[b] for b in bs], gdir)
+        plan.finish()
+        opts = ["-k%d" % o["k"], "-w%d" % o["w"], "-h%d" % o["h"], "-e%g" % o["e"], "-l%d" % o["l"], "-s%d" % o["s"],
+                "-j%d" % o["j"]] + (["-t%d" % o["t"]] if o["t"] else []) + (["-I"] if o["identity"] else []) + \
+               ([] if o["symmetric"] else ["-A"]) + ["-m" + m for m in o["masks"]] + (["-b"] if o["biased"] else [])
+        for a, bs in driver.hpc_plan(2):
+            subprocess.run([os.path.join(ROOT, "oracle", "oracle_daligner")] + opts + ["G.%d" % a] + ["G.%d" % b for b in bs],
+                           cwd=odir, check=True, stdout=subprocess.DEVNULL)
+        nlas = 0
+        for dp, _, fs in os.walk(odir):
+            for f in fs:
+                if f.endswith(".las"):
+                    rel = os.path.relpath(os.path.join(dp, f), odir)
+                    assert open(os.path.join(dp, f), "rb").read() == open(os.path.join(gdir, rel), "rb").read(), (opts, rel)
+                    nlas += 1
+        assert nlas >= 3, opts
