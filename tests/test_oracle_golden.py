@@ -40,3 +40,38 @@ def test_fixtures_reach_the_rare_branches(built, tmp_path, name, what):
     m = re.search(r"redundancy calls (\d+) fusions (\d+) bridges (\d+)", out)
     got = dict(zip(["redundancy calls", "fusions", "bridges"], map(int, m.groups())))
     assert got[what] > 0, got
+
+
+def test_oracle_random_option_combinations_equal_reference(built, tmp_path):
+    """The same kind of sweep one level down: the oracle against the REAL reference binary
+    (oracle/_ref/daligner, present wherever /root/reference was at build time) over random
+    combinations of options, so that the oracle is pinned across the option space and not only on
+    the per-family golden cases."""
+    import random
+    import subprocess
+    from conftest import GOLDEN, ROOT, link_db
+    ref = os.path.join(ROOT, "oracle", "_ref", "daligner")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/daligner not built")
+    rng = random.Random(77)
+    dbdir = os.path.join(GOLDEN, "mask_dust")
+    for n in range(8):
+        opts = ["-k%d" % rng.choice([10, 12, 14, 16, 18]), "-w%d" % rng.choice([4, 5, 6, 7]), "-h%d" % rng.choice([25, 35, 50]),
+                "-e%g" % rng.choice([.65, .7, .8]), "-l%d" % rng.choice([500, 1000, 2000]), "-s%d" % rng.choice([50, 100, 126, 200]),
+                "-j%d" % rng.choice([1, 2, 4, 8])]
+        t = rng.choice([0, 0, 8, 20])
+        opts += (["-t%d" % t] if t else []) + (["-I"] if rng.random() < .5 else []) + (["-A"] if rng.random() < .3 else [])
+        opts += rng.choice([[], ["-mdust"], ["-mdust", "-mrnd"]]) + (["-b"] if rng.random() < .3 else [])
+        rdir, odir = os.path.join(str(tmp_path), "r%d" % n), os.path.join(str(tmp_path), "o%d" % n)
+        link_db(dbdir, rdir)
+        link_db(dbdir, odir)
+        for exe, d in ((ref, rdir), (os.path.join(ROOT, "oracle", "oracle_daligner"), odir)):
+            subprocess.run([exe] + opts + ["G.2", "G.2", "G.1"], cwd=d, check=True, stdout=subprocess.DEVNULL)
+        nlas = 0
+        for dp, _, fs in os.walk(rdir):
+            for f in fs:
+                if f.endswith(".las"):
+                    rel = os.path.relpath(os.path.join(dp, f), rdir)
+                    assert open(os.path.join(dp, f), "rb").read() == open(os.path.join(odir, rel), "rb").read(), (opts, rel)
+                    nlas += 1
+        assert nlas >= 2, opts
