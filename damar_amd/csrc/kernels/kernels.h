@@ -35,17 +35,18 @@ typedef struct
 void damar_launch_pack_bases(const u8 *bases, u32 total, u32 *pk, hipStream_t st);
 
 /* kmer_index.hip */
-void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, u32 *codes, u32 *pos, hipStream_t st);
+/* codes: u32 (k <= 16) or, with wide != 0, u64 (k <= 32) */
+void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, void *codes, int wide, u32 *pos, hipStream_t st);
 /* keep[i] = 1 iff k-mer i lies inside one unmasked stretch of its read (filter.c:474-526) */
 void damar_launch_mask_flags(const DevBlock *blk, int kmer, const u32 *pos, u32 n, u32 *keep, hipStream_t st);
 /* -b: keep[] (cleared by the caller, blk->total entries) marks the block offsets where a k-mer ends */
-void damar_launch_biased_tuples(const DevBlock *blk, int kmer, const int *logbase, u32 *codes, u32 *pos, u32 *keep,
-                                hipStream_t st);
-void damar_launch_code_table(const u32 *codes, u32 n, int kbits, int tbits, u32 *table, hipStream_t st);
-void damar_launch_suppress_flags(const u32 *codes, u32 n, const u32 *table, int kbits, int tbits, int suppress,
+void damar_launch_biased_tuples(const DevBlock *blk, int kmer, const int *logbase, void *codes, int wide, u32 *pos,
+                                u32 *keep, hipStream_t st);
+void damar_launch_code_table(const void *codes, int wide, u32 n, int kbits, int tbits, u32 *table, hipStream_t st);
+void damar_launch_suppress_flags(const void *codes, int wide, u32 n, const u32 *table, int kbits, int tbits, int suppress,
                                  u32 *keep, hipStream_t st);
-void damar_launch_compact_pairs(const u32 *k, const u32 *v, const u32 *keep, const u32 *off, u32 n,
-                                u32 *ko, u32 *vo, hipStream_t st);
+void damar_launch_compact_pairs(const void *k, int wide, const u32 *v, const u32 *keep, const u32 *off, u32 n,
+                                void *ko, u32 *vo, hipStream_t st);
 
 /* datander: distance to the previous equal k-mer of the same read, scattered back to position
  * order (dist[k-mer index]); scrub/tandem.c:556-589 + the (read,rpos) re-sort of :1298 */
@@ -54,8 +55,9 @@ void damar_launch_tandem_links(const DevBlock *blk, int kmer, const u32 *codes, 
 
 /* seed_merge.hip */
 typedef struct
-{ const u32 *acode, *apos;  u32 alen;  const u32 *atab;
-  const u32 *bcode, *bpos;  u32 blen;  const u32 *btab;
+{ const void *acode;  const u32 *apos;  u32 alen;  const u32 *atab;      /* codes: u32, or u64 when wide */
+  const void *bcode;  const u32 *bpos;  u32 blen;  const u32 *btab;
+  int  wide;
   int  kbits, atbits, btbits;
   int  self, comp, identity;
   u32  limit;

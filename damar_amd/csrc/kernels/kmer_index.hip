@@ -4,7 +4,7 @@
  * :700-751, 890-939 (the -t frequency suppression) as data-parallel passes.
  *
  * Index layout in HBM (differs from the reference's 16-byte KmerPos records on
- * purpose): codes[i] (u32, 2 bits per base, last base in the low bits, k <= 16) and
+ * purpose): codes[i] (u32 for k <= 16, u64 for k <= 32; 2 bits per base, last base in the low bits) and
  * pos[i] (u32 offset of the k-mer's LAST base in the block's base array).  The
  * reference's (read, rpos) pair is recoverable from pos through the block's read
  * offsets, and because reads are laid out in order, sorting stably by code leaves
@@ -26,8 +26,9 @@ __device__ __forceinline__ u32 read_of_pos(const DevBlock &b, u32 p)
 /* One thread per base position p: the read through the coarse table (two dependent look-ups
  * instead of a search over all reads), then the k-mer ENDING at p if the read has K bases up to
  * there.  Read r owns k-mer indices [boff[r] - r*k, boff[r+1] - (r+1)*k), in position order. */
+template <typename CodeT>
 __global__ __launch_bounds__(256)
-void kmer_tuples(DevBlock blk, int kmer, u32 nkmers, u32 *__restrict__ codes, u32 *__restrict__ pos)
+void kmer_tuples(DevBlock blk, int kmer, u32 nkmers, CodeT *__restrict__ codes, u32 *__restrict__ pos)
 { const u32 p = blockIdx.x * 256u + threadIdx.x;
   if (p >= blk.total)
     return;
@@ -38,17 +39,20 @@ void kmer_tuples(DevBlock blk, int kmer, u32 nkmers, u32 *__restrict__ codes, u3
   if (i >= nkmers)
     return;
   const u8 *s = blk.bases + (p - (u32) (kmer - 1));
-  u32 c = 0;
+  CodeT c = 0;
   for (int j = 0; j < kmer; j++)
-    c = (c << 2) | s[j];
+    c = (CodeT) (c << 2) | (CodeT) s[j];
   codes[i] = c;
   pos[i]   = p;
 }
 
-void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, u32 *codes, u32 *pos, hipStream_t st)
+void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, void *codes, int wide, u32 *pos, hipStream_t st)
 { if (nkmers == 0)
     return;
-  hipLaunchKernelGGL(kmer_tuples, dim3((blk->total + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, codes, pos);
+  if (wide)
+    hipLaunchKernelGGL(kmer_tuples<u64>, dim3((blk->total + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, (u64 *) codes, pos);
+  else
+    hipLaunchKernelGGL(kmer_tuples<u32>, dim3((blk->total + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, (u32 *) codes, pos);
 }
 
 /* The masked branch of tuple_thread (filter.c:474-526): between two mask intervals of a read
@@ -84,14 +88,15 @@ void damar_launch_mask_flags(const DevBlock *blk, int kmer, const u32 *pos, u32 
  * caller); the usual compaction then puts them in (read, rpos) order.  Masked reads are walked
  * stretch by stretch, including the reference's end-of-stretch case (:602: the growing loop stops
  * at the end of a stretch but the window is still offered, with rpos = the stretch end). */
+template <typename CodeT>
 __global__ __launch_bounds__(64)
 void biased_tuples(DevBlock blk, int kmer, int lb0, int lb1, int lb2, int lb3,
-                   u32 *__restrict__ codes, u32 *__restrict__ pos, u32 *__restrict__ keep)
+                   CodeT *__restrict__ codes, u32 *__restrict__ pos, u32 *__restrict__ keep)
 { const u32 r = blockIdx.x * 64u + threadIdx.x;
   if (r >= blk.nreads)
     return;
   const int  LogNorm = 10000 * kmer, LogThresh = 10000 * (kmer - 2);
-  const u32  kmask = (kmer == 16) ? 0xffffffffu : ((1u << (2 * kmer)) - 1);
+  const u64  kmask = (kmer == 32) ? ~0ull : ((1ull << (2 * kmer)) - 1);
   const u32  b0 = blk.boff[r];
   const int  rlen = (int) (blk.boff[r + 1] - b0) - 1;
   const u8  *s = blk.bases + b0;
@@ -130,7 +135,7 @@ void biased_tuples(DevBlock blk, int kmer, int lb0, int lb1, int lb2, int lb3,
             }
           if (a > LogThresh)
             { const u32 P = b0 + (u32) p;
-              codes[P] = (u32) (c << (2 * kmer - 2 * k)) & kmask;
+              codes[P] = (CodeT) ((c << (2 * kmer - 2 * k)) & kmask);
               pos[P]   = P;
               keep[P]  = 1u;
             }
@@ -141,36 +146,45 @@ void biased_tuples(DevBlock blk, int kmer, int lb0, int lb1, int lb2, int lb3,
 #undef LB
 }
 
-void damar_launch_biased_tuples(const DevBlock *blk, int kmer, const int *logbase, u32 *codes, u32 *pos, u32 *keep,
-                                hipStream_t st)
+void damar_launch_biased_tuples(const DevBlock *blk, int kmer, const int *logbase, void *codes, int wide, u32 *pos,
+                                u32 *keep, hipStream_t st)
 { if (blk->nreads == 0)
     return;
-  hipLaunchKernelGGL(biased_tuples, dim3((blk->nreads + 63) / 64), dim3(64), 0, st, *blk, kmer,
-                     logbase[0], logbase[1], logbase[2], logbase[3], codes, pos, keep);
+  if (wide)
+    hipLaunchKernelGGL(biased_tuples<u64>, dim3((blk->nreads + 63) / 64), dim3(64), 0, st, *blk, kmer,
+                       logbase[0], logbase[1], logbase[2], logbase[3], (u64 *) codes, pos, keep);
+  else
+    hipLaunchKernelGGL(biased_tuples<u32>, dim3((blk->nreads + 63) / 64), dim3(64), 0, st, *blk, kmer,
+                       logbase[0], logbase[1], logbase[2], logbase[3], (u32 *) codes, pos, keep);
 }
 
 /* table[q] for q in [0, 2^tbits]: written by the element that starts each prefix
  * change (it also fills the prefixes that do not occur at all). */
+template <typename CodeT>
 __global__ __launch_bounds__(256)
-void code_table(const u32 *__restrict__ codes, u32 n, int shift, u32 nq, u32 *__restrict__ table)
+void code_table(const CodeT *__restrict__ codes, u32 n, int shift, u32 nq, u32 *__restrict__ table)
 { u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i > n)
     return;
-  u32 q1 = (i == n) ? nq : (codes[i] >> shift);            /* i == n: virtual end marker */
-  u32 q0 = (i == 0) ? 0u : (codes[i - 1] >> shift) + 1;
+  u32 q1 = (i == n) ? nq : (u32) (codes[i] >> shift);      /* i == n: virtual end marker */
+  u32 q0 = (i == 0) ? 0u : (u32) (codes[i - 1] >> shift) + 1;
   for (u32 q = q0; q <= q1 && q <= nq; q++)
     table[q] = i;
 }
 
-void damar_launch_code_table(const u32 *codes, u32 n, int kbits, int tbits, u32 *table, hipStream_t st)
+void damar_launch_code_table(const void *codes, int wide, u32 n, int kbits, int tbits, u32 *table, hipStream_t st)
 { u32 nq = 1u << tbits;
-  hipLaunchKernelGGL(code_table, dim3((n + 1 + 255) / 256), dim3(256), 0, st, codes, n, kbits - tbits, nq, table);
+  if (wide)
+    hipLaunchKernelGGL(code_table<u64>, dim3((n + 1 + 255) / 256), dim3(256), 0, st, (const u64 *) codes, n, kbits - tbits, nq, table);
+  else
+    hipLaunchKernelGGL(code_table<u32>, dim3((n + 1 + 255) / 256), dim3(256), 0, st, (const u32 *) codes, n, kbits - tbits, nq, table);
 }
 
 /* run [lb, ub) of code c in a sorted code array, through its prefix table */
-__device__ __forceinline__ void code_run(const u32 *__restrict__ codes, const u32 *__restrict__ table,
-                                         int shift, u32 c, u32 *lb, u32 *ub)
-{ u32 q = c >> shift;
+template <typename CodeT>
+__device__ __forceinline__ void code_run(const CodeT *__restrict__ codes, const u32 *__restrict__ table,
+                                         int shift, CodeT c, u32 *lb, u32 *ub)
+{ u32 q = (u32) (c >> shift);
   u32 lo = table[q], hi = table[q + 1];
   if (shift == 0)
     { *lb = lo; *ub = hi; return; }
@@ -188,8 +202,9 @@ __device__ __forceinline__ void code_run(const u32 *__restrict__ codes, const u3
   *ub = a;
 }
 
+template <typename CodeT>
 __global__ __launch_bounds__(256)
-void suppress_flags(const u32 *__restrict__ codes, u32 n, const u32 *__restrict__ table, int shift,
+void suppress_flags(const CodeT *__restrict__ codes, u32 n, const u32 *__restrict__ table, int shift,
                     u32 suppress, u32 *__restrict__ keep)
 { u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n)
@@ -199,17 +214,22 @@ void suppress_flags(const u32 *__restrict__ codes, u32 n, const u32 *__restrict_
   keep[i] = (ub - lb < suppress) ? 1u : 0u;
 }
 
-void damar_launch_suppress_flags(const u32 *codes, u32 n, const u32 *table, int kbits, int tbits, int suppress,
+void damar_launch_suppress_flags(const void *codes, int wide, u32 n, const u32 *table, int kbits, int tbits, int suppress,
                                  u32 *keep, hipStream_t st)
 { if (n == 0)
     return;
-  hipLaunchKernelGGL(suppress_flags, dim3((n + 255) / 256), dim3(256), 0, st, codes, n, table, kbits - tbits,
-                     (u32) suppress, keep);
+  if (wide)
+    hipLaunchKernelGGL(suppress_flags<u64>, dim3((n + 255) / 256), dim3(256), 0, st, (const u64 *) codes, n, table, kbits - tbits,
+                       (u32) suppress, keep);
+  else
+    hipLaunchKernelGGL(suppress_flags<u32>, dim3((n + 255) / 256), dim3(256), 0, st, (const u32 *) codes, n, table, kbits - tbits,
+                       (u32) suppress, keep);
 }
 
+template <typename CodeT>
 __global__ __launch_bounds__(256)
-void compact_pairs(const u32 *__restrict__ k, const u32 *__restrict__ v, const u32 *__restrict__ keep,
-                   const u32 *__restrict__ off, u32 n, u32 *__restrict__ ko, u32 *__restrict__ vo)
+void compact_pairs(const CodeT *__restrict__ k, const u32 *__restrict__ v, const u32 *__restrict__ keep,
+                   const u32 *__restrict__ off, u32 n, CodeT *__restrict__ ko, u32 *__restrict__ vo)
 { u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i < n && keep[i])
     { ko[off[i]] = k[i];
@@ -217,11 +237,14 @@ void compact_pairs(const u32 *__restrict__ k, const u32 *__restrict__ v, const u
     }
 }
 
-void damar_launch_compact_pairs(const u32 *k, const u32 *v, const u32 *keep, const u32 *off, u32 n,
-                                u32 *ko, u32 *vo, hipStream_t st)
+void damar_launch_compact_pairs(const void *k, int wide, const u32 *v, const u32 *keep, const u32 *off, u32 n,
+                                void *ko, u32 *vo, hipStream_t st)
 { if (n == 0)
     return;
-  hipLaunchKernelGGL(compact_pairs, dim3((n + 255) / 256), dim3(256), 0, st, k, v, keep, off, n, ko, vo);
+  if (wide)
+    hipLaunchKernelGGL(compact_pairs<u64>, dim3((n + 255) / 256), dim3(256), 0, st, (const u64 *) k, v, keep, off, n, (u64 *) ko, vo);
+  else
+    hipLaunchKernelGGL(compact_pairs<u32>, dim3((n + 255) / 256), dim3(256), 0, st, (const u32 *) k, v, keep, off, n, (u32 *) ko, vo);
 }
 
 /* datander links (scrub/tandem.c:556-589).  Sorted entry i of a run of equal codes gets the

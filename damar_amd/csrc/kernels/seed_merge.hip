@@ -27,9 +27,10 @@ __device__ __forceinline__ u32 read_of_pos(const DevBlock &b, u32 p)
   return r;
 }
 
-__device__ __forceinline__ void code_run(const u32 *__restrict__ codes, const u32 *__restrict__ table,
-                                         int shift, u32 c, u32 *lb, u32 *ub)
-{ u32 q = c >> shift;
+template <typename CodeT>
+__device__ __forceinline__ void code_run(const CodeT *__restrict__ codes, const u32 *__restrict__ table,
+                                         int shift, CodeT c, u32 *lb, u32 *ub)
+{ u32 q = (u32) (c >> shift);
   u32 lo = table[q], hi = table[q + 1];
   if (shift == 0)
     { *lb = lo; *ub = hi; return; }
@@ -57,17 +58,20 @@ __device__ __forceinline__ u32 count_below(const u32 *__restrict__ bpos, u32 jb,
   return a - jb;
 }
 
+template <typename CodeT>
 __global__ __launch_bounds__(256)
 void merge_count(MergeArgs m, u32 *__restrict__ cnt, u32 *__restrict__ jbout)
 { u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= m.alen)
     return;
-  u32 c = m.acode[i], jb, ib, n = 0;
-  code_run(m.bcode, m.btab, m.kbits - m.btbits, c, &jb, &ib);
+  const CodeT *acode = (const CodeT *) m.acode, *bcode = (const CodeT *) m.bcode;
+  const CodeT c = acode[i];
+  u32 jb, ib, n = 0;
+  code_run<CodeT>(bcode, m.btab, m.kbits - m.btbits, c, &jb, &ib);
   if (ib > jb)
     { if (!m.self)
         { u32 ja, ia;                                          /* filter.c:1334-1335 */
-          code_run(m.acode, m.atab, m.kbits - m.atbits, c, &ja, &ia);
+          code_run<CodeT>(acode, m.atab, m.kbits - m.atbits, c, &ja, &ia);
           if ((u64) (ia - ja) * (u64) (ib - jb) < (u64) m.limit)
             n = ib - jb;
         }
@@ -87,18 +91,23 @@ void merge_count(MergeArgs m, u32 *__restrict__ cnt, u32 *__restrict__ jbout)
 void damar_launch_merge_count(const MergeArgs *m, u32 *cnt, u32 *jb, hipStream_t st)
 { if (m->alen == 0)
     return;
-  hipLaunchKernelGGL(merge_count, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, cnt, jb);
+  if (m->wide)
+    hipLaunchKernelGGL(merge_count<u64>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, cnt, jb);
+  else
+    hipLaunchKernelGGL(merge_count<u32>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, cnt, jb);
 }
 
 /* self mode: a run's mutual count is off[run end] - off[run start]; runs at or over
  * the limit contribute nothing (filter.c:1248 `if (ct < limit)`). */
+template <typename CodeT>
 __global__ __launch_bounds__(256)
 void merge_limit(MergeArgs m, const u32 *__restrict__ off, u64 total, u32 *__restrict__ cnt)
 { u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= m.alen || cnt[i] == 0)
     return;
   u32 ja, ia;
-  code_run(m.acode, m.atab, m.kbits - m.atbits, m.acode[i], &ja, &ia);
+  const CodeT *acode = (const CodeT *) m.acode;
+  code_run<CodeT>(acode, m.atab, m.kbits - m.atbits, acode[i], &ja, &ia);
   u64 hi = (ia >= m.alen) ? total : (u64) off[ia];
   if (hi - (u64) off[ja] >= (u64) m.limit)
     cnt[i] = 0;
@@ -107,26 +116,31 @@ void merge_limit(MergeArgs m, const u32 *__restrict__ off, u64 total, u32 *__res
 void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32 *cnt, hipStream_t st)
 { if (m->alen == 0)
     return;
-  hipLaunchKernelGGL(merge_limit, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, cnt);
+  if (m->wide)
+    hipLaunchKernelGGL(merge_limit<u64>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, cnt);
+  else
+    hipLaunchKernelGGL(merge_limit<u32>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, cnt);
 }
 
 /* hitgram[ct] = number of equal-code runs whose mutual count is ct (< ngram), filter.c:1039-1165
  * count_thread.  Only launched when the host must lower the cap under memory pressure
  * (filter.c:2634-2699), so plain global atomics will do.  Cross: ct = na * nb; self: the run's
  * count is the sum of its entries' counts = off[run end] - off[run start] of the current scan. */
+template <typename CodeT>
 __global__ __launch_bounds__(256)
 void merge_hitgram(MergeArgs m, const u32 *__restrict__ off, u64 total, u32 ngram, unsigned long long *__restrict__ gram)
 { u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= m.alen)
     return;
-  const u32 c = m.acode[i];
-  if (i > 0 && m.acode[i - 1] == c)
+  const CodeT *acode = (const CodeT *) m.acode, *bcode = (const CodeT *) m.bcode;
+  const CodeT c = acode[i];
+  if (i > 0 && acode[i - 1] == c)
     return;                                     /* one thread per run of A */
   u32 jb, ib, ja, ia;
-  code_run(m.bcode, m.btab, m.kbits - m.btbits, c, &jb, &ib);
+  code_run<CodeT>(bcode, m.btab, m.kbits - m.btbits, c, &jb, &ib);
   if (ib <= jb)
     return;
-  code_run(m.acode, m.atab, m.kbits - m.atbits, c, &ja, &ia);
+  code_run<CodeT>(acode, m.atab, m.kbits - m.atbits, c, &ja, &ia);
   u64 ct;
   if (!m.self)
     ct = (u64) (ia - ja) * (u64) (ib - jb);
@@ -140,7 +154,10 @@ void damar_launch_merge_hitgram(const MergeArgs *m, const u32 *off, u64 total, u
                                 hipStream_t st)
 { if (m->alen == 0)
     return;
-  hipLaunchKernelGGL(merge_hitgram, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, ngram, gram);
+  if (m->wide)
+    hipLaunchKernelGGL(merge_hitgram<u64>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, ngram, gram);
+  else
+    hipLaunchKernelGGL(merge_hitgram<u32>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, ngram, gram);
 }
 
 /* One workgroup per tile of DAMAR_SCAN_TILE A entries: the tile's hit counts are scanned in

@@ -315,9 +315,10 @@ struct damar_dev_index
 { size_t codes_bytes, pos_bytes, table_bytes;      /* what the pool gave (dpool_get) */
   damar_dev_block *blk;
   int   own_block;
-  u32  *codes, *pos, *table;
+  void *codes;                 /* u32 per k-mer, u64 when wide (k > 16) */
+  u32  *pos, *table;
   u32   n;
-  int   kbits, tbits;
+  int   kbits, tbits, wide;
 };
 
 static int ilog2_ceil(u64 n)
@@ -335,8 +336,8 @@ extern "C" void damar_bias_reset(void) { B_have = 0; }
 
 static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *len, int K, int suppress, int use_bias)
 { ensure_init();
-  if (K > 16)
-    { fprintf(stderr, "damar: FATAL: -k%d: the device index holds 2k <= 32 code bits (k <= 16) in this build\n", K);
+  if (K > 32)
+    { fprintf(stderr, "damar: FATAL: -k%d: a k-mer code holds at most 32 bases\n", K);
       die();
     }
   int64 nk64 = (int64) blk->d.total - (int64) K * blk->nreads;
@@ -348,6 +349,8 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
     }
   u32 nk = (u32) nk64;
   const int kbits = 2 * K;
+  const int wide = K > 16;                  /* codes as u64 (filter.c's KmerPos.code is 64 bits wide) */
+  const size_t cs = wide ? sizeof(u64) : sizeof(u32);
   const bool masked = blk->d.moff != NULL;
   const bool biased = use_bias != 0;
   /* -b (filter.c:774-789): the log weights are set by the FIRST block a process sorts and then
@@ -361,13 +364,14 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
   const u32 cap = biased ? blk->d.total : nk;          /* -b can leave one k-mer per base */
   const int npass = (kbits + 7) / 8;
   damar_dev_index *ix = (damar_dev_index *) calloc(1, sizeof(damar_dev_index));
-  ix->blk = blk;  ix->own_block = own_block;  ix->kbits = kbits;
-  ix->codes = (u32 *) dpool_get(sizeof(u32) * (size_t) cap, &ix->codes_bytes);
+  ix->blk = blk;  ix->own_block = own_block;  ix->kbits = kbits;  ix->wide = wide;
+  ix->codes = dpool_get(cs * (size_t) cap, &ix->codes_bytes);
   ix->pos   = (u32 *) dpool_get(sizeof(u32) * (size_t) cap, &ix->pos_bytes);
 
   size_t swb = damar_sort_workspace_bytes(cap);
-  arena_reserve(&G_work, 4 * pad256(sizeof(u32) * (size_t) cap) + pad256(swb) + pad256(damar_scan_workspace_bytes(cap)) + (1 << 16));
-  u32 *tk = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) cap);
+  arena_reserve(&G_work, pad256(cs * (size_t) cap) + 3 * pad256(sizeof(u32) * (size_t) cap) + pad256(swb) +
+                         pad256(damar_scan_workspace_bytes(cap)) + (1 << 16));
+  void *tk = arena_take(&G_work, cs * (size_t) cap);
   u32 *tv = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) cap);
   void *sw = arena_take(&G_work, swb);
   u32 *keep = NULL, *off = NULL;
@@ -381,18 +385,29 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
     }
 
   /* the sort ping-pongs: start on the side that makes it end in the index's own arrays */
-  u32 *k0 = (npass & 1) ? tk : ix->codes, *v0 = (npass & 1) ? tv : ix->pos;
-  u32 *k1 = (npass & 1) ? ix->codes : tk, *v1 = (npass & 1) ? ix->pos : tv;
+  void *k0 = (npass & 1) ? tk : ix->codes, *k1 = (npass & 1) ? ix->codes : tk;
+  u32  *v0 = (npass & 1) ? tv : ix->pos,   *v1 = (npass & 1) ? ix->pos : tv;
 
   tick(0);
-  if (biased)
-    { /* filter.c:549-688: windows of adaptive length, walked read by read; then the same squeeze */
-      u32 *k9 = (k0 == tk) ? ix->codes : tk, *v9 = (v0 == tv) ? ix->pos : tv;
-      u64  kept = 0;
-      HIP_CHECK(hipMemsetAsync(keep, 0, sizeof(u32) * (size_t) cap, G_st));
-      damar_launch_biased_tuples(&blk->d, K, B_log, k9, v9, keep, G_st);
-      damar_exclusive_scan_u32(keep, off, cap, scw, tot, G_st);
-      damar_launch_compact_pairs(k9, v9, keep, off, cap, k0, v0, G_st);
+  if (biased || masked)
+    { /* filter.c:474-526 / 549-688 + the filler squeeze of :855-888: only k-mers inside one
+         unmasked stretch (resp. the windows the -b walk yields) enter the index; dropping the rest
+         before the sort leaves the same sorted list */
+      void *k9 = (k0 == tk) ? ix->codes : tk;
+      u32  *v9 = (v0 == tv) ? ix->pos : tv;
+      u64   kept = 0;
+      u32   nin = nk;
+      if (biased)
+        { nin = cap;
+          HIP_CHECK(hipMemsetAsync(keep, 0, sizeof(u32) * (size_t) cap, G_st));
+          damar_launch_biased_tuples(&blk->d, K, B_log, k9, wide, v9, keep, G_st);
+        }
+      else
+        { damar_launch_kmer_tuples(&blk->d, K, nk, k9, wide, v9, G_st);
+          damar_launch_mask_flags(&blk->d, K, v9, nk, keep, G_st);
+        }
+      damar_exclusive_scan_u32(keep, off, nin, scw, tot, G_st);
+      damar_launch_compact_pairs(k9, wide, v9, keep, off, nin, k0, v0, G_st);
       HIP_CHECK(hipMemcpyAsync(&kept, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
       HIP_CHECK(hipStreamSynchronize(G_st));
       nk = (u32) kept;
@@ -401,31 +416,14 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
           *len = 0;
           return NULL;
         }
-      if (VERBOSE)
+      if (VERBOSE && biased)
         printf("\n   Revised kmer count = %u\n", nk);
     }
-  else if (!masked)
-    damar_launch_kmer_tuples(&blk->d, K, nk, k0, v0, G_st);
   else
-    { /* filter.c:474-526 + the filler squeeze of :855-888: only k-mers inside one unmasked
-         stretch enter the index; dropping them before the sort leaves the same sorted list */
-      u32 *k9 = (k0 == tk) ? ix->codes : tk, *v9 = (v0 == tv) ? ix->pos : tv;
-      u64  kept = 0;
-      damar_launch_kmer_tuples(&blk->d, K, nk, k9, v9, G_st);
-      damar_launch_mask_flags(&blk->d, K, v9, nk, keep, G_st);
-      damar_exclusive_scan_u32(keep, off, nk, scw, tot, G_st);
-      damar_launch_compact_pairs(k9, v9, keep, off, nk, k0, v0, G_st);
-      HIP_CHECK(hipMemcpyAsync(&kept, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
-      HIP_CHECK(hipStreamSynchronize(G_st));
-      nk = (u32) kept;
-      if (nk == 0)
-        { damar_index_free(ix);
-          *len = 0;
-          return NULL;
-        }
-    }
+    damar_launch_kmer_tuples(&blk->d, K, nk, k0, wide, v0, G_st);
   tick(1);
-  int side = damar_radix_sort_u32(k0, v0, k1, v1, nk, kbits, sw, G_st);
+  int side = wide ? damar_radix_sort_u64((u64 *) k0, v0, (u64 *) k1, v1, nk, kbits, sw, G_st)
+                  : damar_radix_sort_u32((u32 *) k0, v0, (u32 *) k1, v1, nk, kbits, sw, G_st);
   tick(2);
   if ((side ? k1 : k0) != ix->codes)
     { fprintf(stderr, "damar: internal error, sort ended on the wrong side\n");
@@ -443,20 +441,20 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
     ix->tbits = std::min(kbits, std::max(8, std::min(tmax, ilog2_ceil(nk) + 1)));
   }
   ix->table = (u32 *) dpool_get(sizeof(u32) * (((size_t) 1 << ix->tbits) + 2), &ix->table_bytes);
-  damar_launch_code_table(ix->codes, n, kbits, ix->tbits, ix->table, G_st);
+  damar_launch_code_table(ix->codes, wide, n, kbits, ix->tbits, ix->table, G_st);
 
   if (suppress > 0)                         /* filter.c:890-939 */
     { u64  kept = 0;
-      damar_launch_suppress_flags(ix->codes, n, ix->table, kbits, ix->tbits, suppress, keep, G_st);
+      damar_launch_suppress_flags(ix->codes, wide, n, ix->table, kbits, ix->tbits, suppress, keep, G_st);
       damar_exclusive_scan_u32(keep, off, n, scw, tot, G_st);
-      damar_launch_compact_pairs(ix->codes, ix->pos, keep, off, n, tk, tv, G_st);
+      damar_launch_compact_pairs(ix->codes, wide, ix->pos, keep, off, n, tk, tv, G_st);
       HIP_CHECK(hipMemcpyAsync(&kept, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
       HIP_CHECK(hipStreamSynchronize(G_st));
       n = (u32) kept;
-      HIP_CHECK(hipMemcpyAsync(ix->codes, tk, sizeof(u32) * (size_t) n, hipMemcpyDeviceToDevice, G_st));
+      HIP_CHECK(hipMemcpyAsync(ix->codes, tk, cs * (size_t) n, hipMemcpyDeviceToDevice, G_st));
       HIP_CHECK(hipMemcpyAsync(ix->pos, tv, sizeof(u32) * (size_t) n, hipMemcpyDeviceToDevice, G_st));
       if (n > 0)
-        damar_launch_code_table(ix->codes, n, kbits, ix->tbits, ix->table, G_st);
+        damar_launch_code_table(ix->codes, wide, n, kbits, ix->tbits, ix->table, G_st);
     }
   tick(3);
   HIP_CHECK(hipStreamSynchronize(G_st));
@@ -465,7 +463,7 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
   G_ms[DAMAR_T_TABLE]  = lap(2, 3);
   ix->n = n;
   if (VERBOSE)
-    { printf("\n   Kmer count = %u\n   Index occupies %.2fGb of HBM\n", n, (8. * n) / 1073741824.);
+    { printf("\n   Kmer count = %u\n   Index occupies %.2fGb of HBM\n", n, ((cs + 4.) * n) / 1073741824.);
       fflush(stdout);
     }
   if (n == 0)
@@ -498,8 +496,16 @@ extern "C" void damar_index_free(damar_dev_index *ix)
 
 extern "C" void damar_index_download(const damar_dev_index *ix, void *out)
 { struct KP { uint64 code; int rpos; int read; } *kp = (KP *) out;
-  std::vector<u32> codes(ix->n), pos(ix->n), boff((size_t) ix->blk->nreads + 1);
-  HIP_CHECK(hipMemcpy(codes.data(), ix->codes, sizeof(u32) * (size_t) ix->n, hipMemcpyDeviceToHost));
+  std::vector<u32> pos(ix->n), boff((size_t) ix->blk->nreads + 1);
+  std::vector<u64> codes(ix->n);
+  if (ix->wide)
+    HIP_CHECK(hipMemcpy(codes.data(), ix->codes, sizeof(u64) * (size_t) ix->n, hipMemcpyDeviceToHost));
+  else
+    { std::vector<u32> c32(ix->n);
+      HIP_CHECK(hipMemcpy(c32.data(), ix->codes, sizeof(u32) * (size_t) ix->n, hipMemcpyDeviceToHost));
+      for (u32 i = 0; i < ix->n; i++)
+        codes[i] = c32[i];
+    }
   HIP_CHECK(hipMemcpy(pos.data(), ix->pos, sizeof(u32) * (size_t) ix->n, hipMemcpyDeviceToHost));
   HIP_CHECK(hipMemcpy(boff.data(), ix->blk->boff, sizeof(u32) * boff.size(), hipMemcpyDeviceToHost));
   for (u32 i = 0; i < ix->n; i++)
@@ -1067,6 +1073,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   memset(&m, 0, sizeof(m));
   m.acode = aidx->codes;  m.apos = aidx->pos;  m.alen = alen;  m.atab = aidx->table;
   m.bcode = bidx->codes;  m.bpos = bidx->pos;  m.blen = blen;  m.btab = bidx->table;
+  m.wide = aidx->wide;
   m.kbits = aidx->kbits;
   m.self = self;  m.comp = comp;  m.identity = IDENTITY;
   m.limit = (MEM_LIMIT > 0) ? MAXGRAM : 0x7fffffffu;      /* filter.c:2700-2702 */
@@ -1415,7 +1422,11 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
   const int ts = Trace_Spacing(spec);
   int *dist = (int *) dmalloc(sizeof(int) * (size_t) n);
   tick(0);
-  damar_launch_tandem_links(&blk->d, T_kmer, ix->codes, ix->pos, (u32) n, dist, G_st);
+  if (ix->wide)
+    { fprintf(stderr, "damar: FATAL: datander -k%d: tandem seeds are built for k <= 16\n", T_kmer);
+      die();
+    }
+  damar_launch_tandem_links(&blk->d, T_kmer, (const u32 *) ix->codes, ix->pos, (u32) n, dist, G_st);
   tick(1);
 
   std::vector<LaRecord> recs;

@@ -86,7 +86,7 @@ def _index_as_records(L, idx, n):
     return buf
 
 
-@pytest.mark.parametrize("k,t", [(14, 0), (12, 0), (14, 10), (16, 0)])
+@pytest.mark.parametrize("k,t", [(14, 0), (12, 0), (14, 10), (16, 0), (17, 0), (24, 6), (32, 0)])
 def test_gpu_kmer_index_equals_oracle(gpu, k, t):
     """K1-K3: the device index in reference KmerPos layout vs oracle_sort_kmers."""
     import oracle_api as O
@@ -447,7 +447,7 @@ def test_gpu_random_option_combinations_equal_oracle(gpu, tmp_path):
     dbdir = os.path.join(GOLDEN, "mask_dust")
     combos = []
     for _ in range(10):
-        o = dict(k=rng.choice([10, 12, 14, 16]), w=rng.choice([4, 5, 6, 7]), h=rng.choice([25, 35, 50]),
+        o = dict(k=rng.choice([10, 12, 14, 16, 18, 21]), w=rng.choice([4, 5, 6, 7]), h=rng.choice([25, 35, 50]),
                  e=rng.choice([.65, .7, .8]), l=rng.choice([500, 1000, 2000]), s=rng.choice([50, 100, 126, 200]),
                  t=rng.choice([0, 0, 8, 20]), j=rng.choice([1, 2, 4, 8]))
         o["identity"] = rng.choice([0, 1])
@@ -455,6 +455,7 @@ def test_gpu_random_option_combinations_equal_oracle(gpu, tmp_path):
         o["masks"] = rng.choice([[], ["dust"], ["dust", "rnd"]])
         o["biased"] = rng.choice([0, 0, 1])
         combos.append(o)
+    combos[0]["k"], combos[1]["k"] = 20, 27            # wide (64-bit) codes in any case
     for n, o in enumerate(combos):
         gdir, odir = os.path.join(str(tmp_path), "g%d" % n), os.path.join(str(tmp_path), "o%d" % n)
         link_db(dbdir, gdir)
