@@ -8,6 +8,10 @@ pairs are dealt longest-first to the least-loaded rank; a rank then runs its pai
 by A block so that the A index is built once per group, like one daligner plan line.
 
     torchrun --nproc-per-node 8 -m damar_amd.multi <dbdir>/<root> <nblocks> <outdir>
+
+When all pairs are done the per-pair files of every block directory are merged into one sorted
+<root>.<b>.las (LAmerge, the next step of every HPCdaligner plan), block directories dealt over
+the ranks.
 """
 import os
 import sys
@@ -53,6 +57,24 @@ def run_rank(dbprefix, nblocks, outdir, rank, world, runner):
     return mine
 
 
+def merge_blocks(dbprefix, nblocks, outdir, rank, world, run=1):
+    """After every rank has finished its pairs (barrier!): the LAmerge step of the plan
+    (HPCdaligner.c:790-808), one block directory per call, dealt round-robin over the ranks.
+    Writes <root>.<b>.las next to the block directories; returns the files this rank wrote."""
+    import subprocess
+    from . import api, lib
+    root = os.path.basename(dbprefix)
+    done = []
+    for b in range(1, nblocks + 1):
+        if (b - 1) % world != rank:
+            continue
+        out = "%s.%d.las" % (root, b)
+        subprocess.run([lib.bin_path("LAmerge"), "-n", "8", dbprefix, out, api.get_dir(run, b)], cwd=outdir, check=True,
+                       stdout=subprocess.DEVNULL)
+        done.append(os.path.join(outdir, out))
+    return done
+
+
 def gpu_runner(plan_kwargs=None):
     from . import driver
     cache = {}
@@ -82,6 +104,8 @@ def main():
     run_rank(dbprefix, nblocks, outdir, rank, world, runner)
     runner.plan.finish()
     torch.cuda.synchronize()
+    dist.barrier()
+    merge_blocks(dbprefix, nblocks, outdir, rank, world)
     dist.barrier()
     el, cnt = reduce_stats(dist, torch.device("cuda", local), time.time() - t0, runner.plan.counts)
     if rank == 0:

@@ -23,6 +23,10 @@ dist.barrier()
 t0 = time.time()
 mine = multi.run_rank(os.path.join(work, "G"), 2, work, rank, world, oracle_runner)
 npairs = sum(len(v) for v in mine.values())
+dist.barrier()
+merged = multi.merge_blocks(os.path.join(work, "G"), 2, work, rank, world)
+assert len(merged) == 1 and os.path.exists(merged[0])
+dist.barrier()
 el, tot = multi.reduce_stats(dist, torch.device("cpu"), time.time() - t0, [npairs, rank + 1])
 if rank == 0:
     assert tot == [3.0, 3.0], tot
@@ -58,3 +62,10 @@ def test_two_rank_gloo_plan_equals_golden(built, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
     assert "OK" in r.stdout
     assert compare_las(case, work) == []
+    # the merged block files equal what the reference's LAmerge wrote for the same directories
+    import hashlib
+    want = {ln.split()[2]: ln.split()[0] for ln in open(os.path.join(GOLDEN, "lamerge_ref_md5.txt"))
+            if ln.split()[1] == "tiny2" and ln.split()[3] == "-"}
+    for b in (1, 2):
+        got = hashlib.md5(open(os.path.join(work, "G.%d.las" % b), "rb").read()).hexdigest()
+        assert got == want["d001_%05d" % b]
