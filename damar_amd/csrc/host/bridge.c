@@ -270,8 +270,9 @@ static int tp_below(const damar_path *path, int *x, int isA, const damar_tpool *
   return a;
 }
 
-static int *g_vec = NULL;   static int g_vmax = 0;
-static uint16 *g_tr = NULL; static int g_tmax = 0;
+/* work buffers of the realignment, per thread: the host tail runs read-pair ranges on several threads */
+static __thread int *g_vec = NULL;   static __thread int g_vmax = 0;
+static __thread uint16 *g_tr = NULL; static __thread int g_tmax = 0;
 
 /* filter.c:1456-1571 without its debug branches.  The realigned box is left in *box (trace
  * in the static work buffer, valid until the next call). */
@@ -414,4 +415,10 @@ int damar_bridge_pair(const damar_bridge_ctx *ctx, damar_path *jp, damar_path *k
       bm[j] = *b1;
     }
   return 0;
+}
+
+/* Frees the calling thread's realignment buffers (worker threads call this before they end). */
+void damar_bridge_release(void)
+{ free(g_vec);  g_vec = NULL;  g_vmax = 0;
+  free(g_tr);   g_tr = NULL;   g_tmax = 0;
 }

@@ -44,6 +44,8 @@ int damar_bridge_pair(const damar_bridge_ctx *ctx, damar_path *jp, damar_path *k
                       int aovl, int bovl, int comp, int ts, damar_tpool *tp,
                       damar_path *bm, int j);
 
+void damar_bridge_release(void);       /* frees the calling thread's work buffers */
+
 int  damar_handle_redundancies(damar_path *am, int n, damar_path *bm, int comp, int ts,
                                damar_tpool *tp, const damar_bridge_ctx *bridge);
 

@@ -760,6 +760,7 @@ static int64 tail_range(const LaRecord *recs, const u32 *ord, size_t lo, size_t 
       i = j;
     }
   free(tp.val);
+  damar_bridge_release();
   return ncheck;
 }
 
@@ -800,7 +801,12 @@ static int64 run_tail(LaRecord *recs, size_t nrecs, const u16 *tpool,
       }
   }
   Overlap_IO_Buffer *obuf = OVL_IO_Buffer(spec);
-  const int nthr = (nrecs >= 8192) ? tail_threads() : 1;
+  static size_t tmin = 0;                  /* below this many records one thread does it (DAMAR_TAIL_MIN) */
+  if (tmin == 0)
+    { const char *e = getenv("DAMAR_TAIL_MIN");
+      tmin = (e && atol(e) > 0) ? (size_t) atol(e) : 8192;
+    }
+  const int nthr = (nrecs >= tmin) ? tail_threads() : 1;
   if (nthr == 1)
     return tail_range(recs, ord.data(), 0, nrecs, tpool, ablock, bblock, self, comp, ts, obuf);
 

@@ -479,3 +479,18 @@ def test_gpu_random_option_combinations_equal_oracle(gpu, tmp_path):
                     assert open(os.path.join(dp, f), "rb").read() == open(os.path.join(gdir, rel), "rb").read(), (opts, rel)
                     nlas += 1
         assert nlas >= 3, opts
+
+
+@pytest.mark.parametrize("name", ["tandem", "fusion", "noisy"])
+def test_gpu_threaded_host_tail_with_redundancies(gpu, tmp_path, name):
+    """The host tail splits the read pairs of one launch over several threads; force that path
+    (DAMAR_TAIL_MIN=1, 7 threads) on the cases that exercise Handle_Redundancies, Fusion and the
+    Bridge realignment (per-thread work buffers), through the CLI binary."""
+    import subprocess
+    case = read_case(name)
+    link_db(case["dbdir"], str(tmp_path))
+    env = dict(os.environ, DAMAR_TAIL_MIN="1", DAMAR_TAIL_THREADS="7")
+    for a, bs in case["lines"]:
+        subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "daligner")] + case["opts"] + ["G." + a] + ["G." + b for b in bs],
+                       cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL, env=env)
+    assert compare_las(case, str(tmp_path)) == []
