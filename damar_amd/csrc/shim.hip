@@ -155,6 +155,8 @@ static void *arena_take(Arena *a, size_t n)
 
 static size_t pad256(size_t n) { return (n + 511) & ~(size_t) 255; }
 
+static int G_device = 0;      /* the device of this process; threads that touch HIP select it first */
+
 extern "C" int damar_hip_init(int device)
 { int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -168,6 +170,7 @@ extern "C" int damar_hip_init(int device)
       die();
     }
   HIP_CHECK(hipSetDevice(device));
+  G_device = device;
   HIP_CHECK(hipGetDeviceProperties(&G_prop, device));
   if (!G_ready)
     { HIP_CHECK(hipStreamCreate(&G_st));
@@ -920,6 +923,7 @@ static void tail_worker(void)
       if (job->kind == 0)
         { if (job->hb->pending)
             { float ms = 0;
+              HIP_CHECK(hipSetDevice(G_device));          /* the current device is a per-thread setting */
               HIP_CHECK(hipEventSynchronize(job->hb->e1));
               HIP_CHECK(hipEventElapsedTime(&ms, job->hb->e0, job->hb->e1));
               std::lock_guard<std::mutex> lk(A_mu);
