@@ -230,6 +230,7 @@ extern "C" int  damar_last_limit(void)          { return G_limit; }
 struct damar_dev_block
 { DevBlock d;
   float freq[4];           /* base frequencies of the block (-b) */
+  int   minlen;            /* shortest read */
   u32 *pk_alloc;
   u32 *moff;
   int *mdat;
@@ -250,6 +251,9 @@ extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
   std::vector<u32> boff((size_t) n + 1);
   for (int i = 0; i <= n; i++)
     boff[i] = (u32) block->reads[i].boff;
+  int minlen = 0x7fffffff;
+  for (int i = 0; i < n; i++)
+    minlen = std::min(minlen, (int) (boff[i + 1] - boff[i]) - 1);
   size_t nq = ((size_t) total >> COARSE_SHIFT) + 2;
   std::vector<u32> coarse(nq);
   { u32 r = 0;
@@ -278,6 +282,7 @@ extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
   b->d.coarse = b->coarse;
   for (int i = 0; i < 4; i++)
     b->freq[i] = block->freq[i];
+  b->minlen = minlen;
   b->d.nreads = (u32) n;
   b->d.total  = (u32) total;
   b->d.maxlen = block->maxlen;
@@ -341,6 +346,10 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
 { ensure_init();
   if (K > 32)
     { fprintf(stderr, "damar: FATAL: -k%d: a k-mer code holds at most 32 bases\n", K);
+      die();
+    }
+  if (blk->nreads > 0 && blk->minlen < K)      /* daligner.c:499-504: the k-mer slots assume rlen >= k */
+    { fprintf(stderr, "[ERROR] - daligner: Block contains reads < %dbp long !  Run DBsplit.\n", K);
       die();
     }
   int64 nk64 = (int64) blk->d.total - (int64) K * blk->nreads;
