@@ -356,7 +356,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
     rNA = na;  rNB = nb;
   }
 
-  /***** register path: the band (<= 64 diagonals) lives in VGPRs, neighbours by lane shuffle *****/
+  /***** register path: the band (<= 64 diagonals) lives in VGPRs, neighbour V by DPP rotate, predecessor state by ds_bpermute *****/
   bool stopped = false;
   u32  err_flags = 0, err_empty = 0;          /* wave-uniform, reported once after the loop */
 #ifdef DAMAR_PROF
