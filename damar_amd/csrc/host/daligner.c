@@ -166,6 +166,7 @@ int main(int argc, char *argv[])
      thread while the GPU starts on the next pair; B blocks stay alive until it is done. */
   damar_set_async(1);
   HITS_DB *pending = (HITS_DB *) malloc(sizeof(HITS_DB) * (size_t) (argc + 2));
+  char   **cbases = (char **) malloc(sizeof(char *) * (size_t) (argc + 2));
   int      npending = 0;
 
   aindex = NULL;
@@ -199,11 +200,15 @@ int main(int argc, char *argv[])
             printf("\nBuilding index for %s\n", broot);
           bindex = Sort_Kmers(&bblock, &blen);
           Match_Filter(aroot, &ablock, broot, &bblock, aindex, alen, bindex, blen, 0, spec);
-          damar_complement_block(&bblock, 1);
+          /* the reference complements B in place (daligner.c:1034); here the host tail of the
+             forward comparison may still be reading B's bases on its thread, so the complement
+             is a copy (released with the block after the drain) */
+          cblock = damar_complement_block(&bblock, 0);
+          cbases[npending] = ((char *) cblock->bases) - 1;
           if (VERBOSE)
             printf("\nBuilding index for c(%s)\n", broot);
-          bindex = Sort_Kmers(&bblock, &blen);
-          Match_Filter(aroot, &ablock, broot, &bblock, aindex, alen, bindex, blen, 1, spec);
+          bindex = Sort_Kmers(cblock, &blen);
+          Match_Filter(aroot, &ablock, broot, cblock, aindex, alen, bindex, blen, 1, spec);
 
           last = (bblock.part < ablock.part) ? bblock.ufirst + bblock.nreads - 1
                                              : ablock.ufirst + ablock.nreads - 1;
@@ -217,7 +222,10 @@ int main(int argc, char *argv[])
           if (npending >= 4)
             { damar_async_drain();
               while (npending > 0)
-                damar_close_block(&pending[--npending]);
+                { npending -= 1;
+                  free(cbases[npending]);
+                  damar_close_block(&pending[npending]);
+                }
             }
         }
       else
@@ -237,7 +245,10 @@ int main(int argc, char *argv[])
     }
   damar_async_drain();
   while (npending > 0)
-    damar_close_block(&pending[--npending]);
+    { npending -= 1;
+      free(cbases[npending]);
+      damar_close_block(&pending[npending]);
+    }
   damar_set_async(0);
   return 0;
 }

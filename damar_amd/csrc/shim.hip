@@ -866,7 +866,8 @@ static int64 run_tail(LaRecord *recs, size_t nrecs, const u16 *tpool,
 struct TailJob
 { int kind;                                  /* 0 = tail of one Match_Filter, 1 = write + reset */
   HostBuf *hb;
-  const HITS_DB *ablock, *bblock;
+  HITS_DB ablock, bblock;                    /* copies of the block records: the caller may reuse its structs
+                                                (the read tables and bases they point to must stay alive) */
   int  self, comp;
   Align_Spec *spec;
   std::string d1, d2, a, b;
@@ -939,7 +940,7 @@ static void tail_worker(void)
               A_d2h_ms += ms;
               t0 = now_ms();
             }
-          int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, job->ablock, job->bblock,
+          int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, &job->ablock, &job->bblock,
                              job->self, job->comp, job->spec);
           hostbuf_put(job->hb);
           delete job;
@@ -1372,7 +1373,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
     { TailJob *job = new TailJob();
       job->kind = 0;
       job->hb = hb;
-      job->ablock = ablock;  job->bblock = bblock;  job->self = self;  job->comp = comp;  job->spec = spec;
+      job->ablock = *ablock;  job->bblock = *bblock;  job->self = self;  job->comp = comp;  job->spec = spec;
       async_submit(job);
     }
   else
