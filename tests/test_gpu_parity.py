@@ -494,3 +494,33 @@ def test_gpu_threaded_host_tail_with_redundancies(gpu, tmp_path, name):
         subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "daligner")] + case["opts"] + ["G." + a] + ["G." + b for b in bs],
                        cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL, env=env)
     assert compare_las(case, str(tmp_path)) == []
+
+
+def test_gpu_cli_plan_line_with_several_b_blocks_equals_reference(gpu, tmp_path):
+    """One plan line against three B blocks through the C driver, with the host tail slowed to a
+    single thread so that it lags behind the GPU: the driver reuses its block records for the next
+    B block while tails are still pending (they must work on their own copies).  Checked against
+    the real reference binary where it exists (GPU box and build container)."""
+    import subprocess
+    ref = os.path.join(ROOT, "oracle", "_ref", "daligner")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/daligner not built")
+    d = str(tmp_path)
+    subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "simdb"), d, "S", "3.0", "-c20", "-r13", "-e.15", "-S15"],
+                   check=True, stdout=subprocess.DEVNULL)
+    line = ["S.4", "S.4", "S.3", "S.2", "S.1"]
+    for sub, exe, env in (("ref", ref, None),
+                          ("gpu", os.path.join(ROOT, "damar_amd", "bin", "daligner"), dict(os.environ, DAMAR_TAIL_THREADS="1"))):
+        w = os.path.join(d, sub)
+        os.makedirs(w)
+        for f in ("S.db", ".S.idx", ".S.bps"):
+            os.symlink(os.path.join(d, f), os.path.join(w, f))
+        subprocess.run([exe, "-k14", "-j8"] + line, cwd=w, check=True, stdout=subprocess.DEVNULL, env=env, timeout=300)
+    n = 0
+    for dp, _, fs in os.walk(os.path.join(d, "ref")):
+        for f in fs:
+            if f.endswith(".las"):
+                rel = os.path.relpath(os.path.join(dp, f), os.path.join(d, "ref"))
+                assert open(os.path.join(dp, f), "rb").read() == open(os.path.join(d, "gpu", rel), "rb").read(), rel
+                n += 1
+    assert n == 7
