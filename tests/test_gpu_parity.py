@@ -524,3 +524,25 @@ def test_gpu_cli_plan_line_with_several_b_blocks_equals_reference(gpu, tmp_path)
                 assert open(os.path.join(dp, f), "rb").read() == open(os.path.join(d, "gpu", rel), "rb").read(), rel
                 n += 1
     assert n == 7
+
+
+def test_gpu_multi_module_one_rank_rccl(gpu, tmp_path):
+    """python -m damar_amd.multi under torchrun with one rank on the GPU (RCCL process group, plan,
+    LAmerge step): per-pair files equal the golden ones, merged block files equal the reference
+    LAmerge's."""
+    import subprocess
+    import sys
+    case = read_case("tiny2")
+    w = str(tmp_path)
+    link_db(case["dbdir"], w)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29578", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29578", "-m", "damar_amd.multi",
+                        os.path.join(w, "G"), "2", w], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert compare_las(case, w) == []
+    want = {ln.split()[2]: ln.split()[0] for ln in open(os.path.join(GOLDEN, "lamerge_ref_md5.txt"))
+            if ln.split()[1] == "tiny2" and ln.split()[3] == "-"}
+    for b in (1, 2):
+        assert hashlib.md5(open(os.path.join(w, "G.%d.las" % b), "rb").read()).hexdigest() == want["d001_%05d" % b]
