@@ -367,10 +367,11 @@ def _check_las_invariants(path, tspace=100):
     return novl
 
 
-def test_gpu_config2_block_pairs_known_answer(gpu, tmp_path):
-    """BASELINE config 2 at full size (540 Mbp, 4 blocks of 135 Mbp): two of the ten block
-    pairs against the md5 of the files the reference wrote for them (tests/golden/
-    config2_ref_md5.txt), plus size-independent .las invariants on every file."""
+def test_gpu_config2_full_plan_known_answer(gpu, tmp_path):
+    """BASELINE config 2 at full size (540 Mbp, 4 blocks of 135 Mbp, all 10 block pairs, 16 .las
+    files): every file against the md5 of what the reference daligner wrote (tests/golden/
+    config2_ref_md5.txt), the LAcheck-style invariants on three of them, and the aligned-bp total
+    that bench.py's metric is built from."""
     from damar_amd import api, driver
     d = str(tmp_path)
     assert api.sim_write_db(d, "SIM", 27., coverage=20., seed=2, block_mbp=135) == 4
@@ -378,12 +379,21 @@ def test_gpu_config2_block_pairs_known_answer(gpu, tmp_path):
     for ln in open(os.path.join(GOLDEN, "config2_ref_md5.txt")):
         m, f = ln.split()
         want[f] = m
-    b1, b2 = driver.Block(os.path.join(d, "SIM.1")), driver.Block(os.path.join(d, "SIM.2"))
+    assert len(want) == 16
+    blocks = {i: driver.Block(os.path.join(d, "SIM.%d" % i)) for i in range(1, 5)}
     plan = driver.Plan(j=16)
-    plan.run_line(b2, [b2, b1], d)
+    for a, bs in driver.hpc_plan(4):
+        plan.run_line(blocks[a], [blocks[b] for b in bs], d)
     plan.finish()
+    assert plan.index_builds == 8
+    nrec = bp = 0
+    for f, m in sorted(want.items()):
+        assert hashlib.md5(open(os.path.join(d, f), "rb").read()).hexdigest() == m, f
+        n, b = driver.las_stats(os.path.join(d, f))
+        nrec += n
+        bp += b
+    assert (nrec, bp) == (1676758, 9893531852)
     for f in ("d001_00002/SIM.2.SIM.2.las", "d001_00002/SIM.2.SIM.1.las", "d001_00001/SIM.1.SIM.2.las"):
-        assert hashlib.md5(open(os.path.join(d, f), "rb").read()).hexdigest() == want[f], f
         assert _check_las_invariants(os.path.join(d, f)) > 50000
 
 
