@@ -240,6 +240,7 @@ struct WaveState
   u32 ncell;
   Tip trim, reach;
   int stopped;
+  int bad;                /* the pebble pool overflowed: chain heads may be out of range, skip the trace walk */
 };
 
 #define WS_LOAD(ws)                                                                          \
@@ -359,6 +360,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
   /***** register path: the band (<= 64 diagonals) lives in VGPRs, neighbour V by DPP rotate, predecessor state by ds_bpermute *****/
   bool stopped = false;
   u32  err_flags = 0, err_empty = 0;          /* wave-uniform, reported once after the loop */
+  int  bad = 0;
 #ifdef DAMAR_PROF
   int pf_first16 = -1, pf_first32 = -1;
 #endif
@@ -590,6 +592,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
             more = 0;
             ncell = 2;
             stopped = true;
+            bad = 1;
             break;
           }
 
@@ -633,6 +636,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
       stopped = true;
   }
   ws.stopped = stopped ? 1 : 0;
+  ws.bad = bad;
 #ifdef DAMAR_PROF
   PROF_ADD(0, 1);
   PROF_ADD(1, dif);
@@ -876,6 +880,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
         { if (lane == 0) atomicOr(errw, DAMAR_ERR_CELLS);
           more = 0;
           ncell = 2;
+          ws.bad = 1;
           break;
         }
       wave_mem_sync();
@@ -949,9 +954,11 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
   mida = uni(mida);
   WS_LOAD(ws)
 
-  /* end point and trace points of this direction: lane 0 walks the two pebble chains */
+  /* end point and trace points of this direction: lane 0 walks the two pebble chains (not after
+     a pebble-pool overflow: the launch is repeated with a larger pool, and the chain heads of
+     this pass may point past the pool) */
   int rx = 0, ry = 0, rd = 0, at = 0, bt = 0;
-  if (lane == 0)
+  if (lane == 0 && !uni(ws.bad))
     { int  trimx, trimy, trimd, ha, hb;
       u16 *atrace = c.atr, *btrace = c.btr;
       Cell *cells = cellbuf;

@@ -556,3 +556,19 @@ def test_gpu_multi_module_one_rank_rccl(gpu, tmp_path):
             if ln.split()[1] == "tiny2" and ln.split()[3] == "-"}
     for b in (1, 2):
         assert hashlib.md5(open(os.path.join(w, "G.%d.las" % b), "rb").read()).hexdigest() == want["d001_%05d" % b]
+
+
+@pytest.mark.parametrize("name", ["tiny2", "tandem"])
+def test_gpu_buffer_overflow_relaunch(gpu, tmp_path, name):
+    """The report kernel never writes past its record, trace or pebble buffers: it raises a flag
+    and the host launches it again with larger ones.  Start from absurdly small buffers
+    (DAMAR_TEST_SMALL_CAPS) and require the usual golden output."""
+    import subprocess
+    case = read_case(name)
+    link_db(case["dbdir"], str(tmp_path))
+    env = dict(os.environ, DAMAR_TEST_SMALL_CAPS="1")
+    for a, bs in case["lines"]:
+        r = subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "daligner"), "-v"] + case["opts"] + ["G." + a] + ["G." + b for b in bs],
+                           cwd=str(tmp_path), check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+        assert "retrying with larger buffers" in r.stdout
+    assert compare_las(case, str(tmp_path)) == []
