@@ -1206,7 +1206,7 @@ __device__ __noinline__ void emit_record(const ReportArgs &a, const SlotScratch 
   u32 bad = 0;
   if (ri >= a.rec_cap)
     bad |= DAMAR_ERR_RECS;
-  if ((u64) to + (u64) nval > (u64) a.tpool_cap)
+  if ((u64) to + (u64) nval > (u64) a.tpool_cap || to > 0xf0000000u)       /* (the 32-bit counter must never wrap) */
     bad |= DAMAR_ERR_TPOOL;
   if (bad == 0)
     { const u16 *at = s.atr - r.aback, *bt = s.btr - r.bback;

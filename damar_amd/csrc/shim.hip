@@ -1302,7 +1302,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   if (nwork > 0)
     { u32 cell_cap = RS.cell_cap ? RS.cell_cap : (1u << 16);
       u32 rec_cap  = std::max(RS.rec_cap, 2 * nwork + 4096);
-      u32 tp_cap   = std::max(RS.tpool_cap, rec_cap * 256u);
+      u32 tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(RS.tpool_cap, (u64) rec_cap * 256u));
       if (getenv("DAMAR_TEST_SMALL_CAPS") && RS.rec_cap == 0)      /* tests: start far too small, so that the
                                                                       overflow flags and the re-launch are exercised */
         { cell_cap = 64;  rec_cap = 16;  tp_cap = 512; }
@@ -1337,7 +1337,13 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
             }
           if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
           if (hc[3] & DAMAR_ERR_RECS)  rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
-          if (hc[3] & DAMAR_ERR_TPOOL) tp_cap  = std::max(2 * tp_cap, hc[2] + 65536);
+          if (hc[3] & DAMAR_ERR_TPOOL)
+            { if (tp_cap >= 0xe0000000u)
+                { fprintf(stderr, "damar: FATAL: more than 2^32 trace values in one comparison, use smaller blocks\n");
+                  die();
+                }
+              tp_cap = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(2ull * tp_cap, (u64) hc[2] + 65536));
+            }
           if (VERBOSE)
             fprintf(stderr, "damar: report kernel overflow (flags %u), retrying with larger buffers\n", hc[3]);
         }
