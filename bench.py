@@ -235,9 +235,10 @@ def main():
                     "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                     "dtype": "int32", "data": "synthetic",
-                    "config": {"workload": "config 2: simulator %g -c%g -e.15 -r%d(+rank), DBsplit -s%d -> %d blocks, "
+                    "config": {"workload": "%s: simulator %g -c%g -e.15 -r%d(+rank), DBsplit -s%d -> %d blocks, "
                                            "%d block pairs x 2 orientations per step, daligner -k14 -w6 -h35 -e.70 -l1000 -s100"
-                                           % (args.genome, args.coverage, args.seed, args.block, nblocks, npairs),
+                                           % ("config 2" if (args.genome, args.coverage, args.block) == (27.0, 20.0, 135) else "custom",
+                                              args.genome, args.coverage, args.seed, args.block, nblocks, npairs),
                                "reads_per_gpu": nreads, "bases_per_gpu": totbp,
                                "records_per_step": nrec_all, "aligned_bp_per_step": bp_all,
                                "seed_pairs_per_step": H, "local_alignments_per_step": cnts[1] / steps,
