@@ -645,11 +645,11 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   ra->tspace = Trace_Spacing(spec);
   ra->ave_path = damar_spec_ave_path(spec);
   ra->reach = Overlap_If_Possible(spec);
-  if (RS.tables_of != (const void *) spec)
-    { HIP_CHECK(hipMemcpyAsync(RS.tables, damar_spec_score_table(spec), sizeof(short) * 65536,
-                               hipMemcpyHostToDevice, G_st));
-      RS.tables_of = (const void *) spec;
-    }
+  /* SCORE/TABLE of this Align_Spec, every time (128 KB): remembering "the tables of spec X are
+     already up" by X's address went wrong when a freed spec's address came back for a new one
+     with another -e */
+  HIP_CHECK(hipMemcpyAsync(RS.tables, damar_spec_score_table(spec), sizeof(short) * 65536,
+                           hipMemcpyHostToDevice, G_st));
   ra->score = RS.tables;
   ra->table = RS.tables + 32768;
   ra->state = RS.state;  ra->state_stride = RS.state_stride;  ra->span = RS.span;
