@@ -572,3 +572,23 @@ def test_gpu_buffer_overflow_relaunch(gpu, tmp_path, name):
                            cwd=str(tmp_path), check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
         assert "retrying with larger buffers" in r.stdout
     assert compare_las(case, str(tmp_path)) == []
+
+
+def test_gpu_successive_jobs_with_different_correlation(gpu, tmp_path):
+    """Several jobs in one process with different -e (so different SCORE/TABLE): every job must use
+    its own tables even when the allocator hands a new Align_Spec the address of a freed one."""
+    import subprocess
+    from damar_amd import driver
+    dbdir = os.path.join(GOLDEN, "noisy")
+    for n, e in enumerate([.8, .65, .75, .65, .8]):
+        gdir, odir = os.path.join(str(tmp_path), "g%d" % n), os.path.join(str(tmp_path), "o%d" % n)
+        link_db(dbdir, gdir)
+        link_db(dbdir, odir)
+        blk = driver.Block(os.path.join(gdir, "G.1"))
+        plan = driver.Plan(e=e, l=500)
+        plan.run_line(blk, [blk], gdir)
+        plan.finish()
+        subprocess.run([os.path.join(ROOT, "oracle", "oracle_daligner"), "-k14", "-j4", "-e%g" % e, "-l500", "G.1", "G.1"],
+                       cwd=odir, check=True, stdout=subprocess.DEVNULL)
+        rel = os.path.join("d001_00001", "G.1.G.1.las")
+        assert open(os.path.join(odir, rel), "rb").read() == open(os.path.join(gdir, rel), "rb").read(), e
