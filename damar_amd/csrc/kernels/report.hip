@@ -200,9 +200,10 @@ __device__ __forceinline__ SnakeOut snake_pk(const u32 *apk, const u32 *bpk, int
     { const u32 wa = REV ? load16(apk, (u32) (ap - 15)) : load16(apk, (u32) ap);
       const u32 wb = REV ? load16(bpk, (u32) (bp - 15)) : load16(bpk, (u32) bp);
       const u32 x = wa ^ wb;
-      u32 run;
-      if (!REV) run = x ? (u32) __builtin_ctz(x) >> 1 : 16u;
-      else      run = x ? (u32) __builtin_clz(x) >> 1 : 16u;
+      /* equal leading bases of the window, 16 if all are: a guard bit just outside the 32 bits
+         keeps the count defined for x == 0 (one find-first-bit plus a min, no compare/select) */
+      const u32 run = (REV ? (u32) __builtin_clzll(((u64) x << 32) | 0x80000000ull)
+                           : (u32) __builtin_ctzll((u64) x | (1ull << 32))) >> 1;
       const int lim = na < nb ? na : nb;
       const int n = (int) run < lim ? (int) run : lim;
       /* n == 0 leaves m and b as they are */
@@ -600,8 +601,8 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
 
         /* prune (align.c:977-986 / 1686-1695) */
         { const int n = REV ? besta + MAX_WAVE_LAG : besta - MAX_WAVE_LAG;
-          const int kk = low + ((lane - low) & 63);
-          u64 keep = wballot((kk <= hgh) && (REV ? (rV <= n) : (rV >= n)));
+          /* (k is still this lane's diagonal: clipping only narrows [low, hgh]) */
+          u64 keep = wballot(act && (k >= low) && (k <= hgh) && (REV ? (rV <= n) : (rV >= n)));
           if (keep == 0)
             hgh = low - 1;
           else
