@@ -90,6 +90,14 @@ void oracle_match_filter(const HITS_DB *ablock, const HITS_DB *bblock,
 void oracle_match_self(const HITS_DB *block, const OParams *prm, Align_Spec *spec,
                        int64 *counts, OWaveStats *stats);
 
+/* (f)4, the next consumer of the records: align.c:5577-5692 Compute_Trace_PTS + :4892-5261 iter_np.
+ * path->trace holds the 16-bit trace-point pairs; script (at least aepos-abpos + bepos-bbpos values)
+ * receives the edit script (negative = A position, positive = B position, 1-based), *diffs the summed
+ * segment distances.  mode -1 / 0 / 1 = LOWERMOST / GREEDIEST / UPPERMOST.  Returns the script length, or
+ * -1 where the reference exits ("Bad alignment between trace points"). */
+int oracle_compute_trace_pts(const char *aseq, int alen, const char *bseq, int blen, const Path *path,
+                             int tspace, int mode, int *script, int *diffs);
+
 /* Redundancy handling shared with the product's host tail (filter.c:1804-2077);
  * implemented in damar_amd/csrc/host/redundancy.c. */
 

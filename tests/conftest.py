@@ -17,7 +17,7 @@ def pytest_configure(config):
 def built():
     """Native pieces must exist (build() makes them); tests never rebuild silently."""
     need = ["damar_amd/libdamar_hip.so", "damar_amd/bin/daligner", "damar_amd/bin/simdb",
-            "oracle/liboracle.so", "oracle/oracle_daligner"]
+            "oracle/liboracle.so", "oracle/oracle_daligner", "oracle/oracle_lastrace"]
     missing = [f for f in need if not os.path.exists(os.path.join(ROOT, f))]
     if missing:
         import __graft_entry__ as g

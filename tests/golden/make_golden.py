@@ -274,11 +274,35 @@ def memlimit():
         print(os.path.getsize(las), hashlib.md5(open(las, "rb").read()).hexdigest())
 
 
+def trace_md5():
+    """md5 of the dumps the REAL Compute_Trace_PTS leaves for every golden .las (oracle/ref_lastrace.c
+    around align.c:5577, all three modes) -> trace_ref_md5.txt, the fixture that pins oracle/trace.c."""
+    import hashlib
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    lines = []
+    with tempfile.TemporaryDirectory() as d:
+        for name in conftest.golden_cases():
+            c = conftest.read_case(name)
+            for las in c["las"]:
+                for mode in (0, -1, 1):
+                    out = os.path.join(d, "t.bin")
+                    run([os.path.join(REF, "ref_lastrace"), os.path.join(c["dbdir"], "G"),
+                         os.path.join(c["lasdir"], las), out, str(mode)], d)
+                    lines.append("%s %s %s %d" % (hashlib.md5(open(out, "rb").read()).hexdigest(), name, las, mode))
+    with open(os.path.join(HERE, "trace_ref_md5.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("%d dumps" % len(lines))
+
+
 def main():
     if not os.path.exists(os.path.join(REF, "daligner")):
         sys.exit("oracle/_ref/daligner missing: make -C oracle -f Makefile.ref")
     if sys.argv[1:] == ["memlimit"]:
         return memlimit()
+    if sys.argv[1:] == ["trace"]:
+        return trace_md5()
     import tempfile
     dbs = {}
     only = set(sys.argv[1:])
