@@ -133,4 +133,46 @@ typedef struct { int aread, bread, diag, anti; } LaTask;
 void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
 
 u64 damar_report_state_stride(int span);
+
+/* trace_pts.hip: Compute_Trace_PTS for batches of records (align.c:5577-5692, 4892-5261) */
+typedef struct
+{ u32 aread, bread;       /* block-local read ids */
+  u32 flags;              /* bit 0 = B complemented (COMP_FLAG), bit 1 = A and B are one buffer */
+  int abpos, bbpos, aepos, bepos;
+  u32 poff;               /* first trace-point value of the record in the point array */
+  int tlen;               /* trace-point values (pairs diffs, B length) */
+  u32 seg0;               /* index of the record's first segment */
+  u32 stage0;             /* first staging slot of the record (segment s gets dmax + |M_s - N_s| slots) */
+  int dmax;               /* largest trace-point difference count of the record (align.c:5614-5621) */
+} TraceRecIn;
+
+typedef struct
+{ u32 apos, bpos;         /* first base of the segment in the blocks' base arrays (B: last, if complemented) */
+  int a0, b0;             /* the same as offsets into the two reads (script values)  */
+  u32 mn;                 /* M | N << 16                                             */
+  u32 flags;              /* TraceRecIn.flags & 3, bit 2 = void (record failed the bounds check), dmax << 8 */
+  u32 stage;              /* slot of the segment in the staging area                 */
+  u32 rec;
+} TraceSeg;
+
+typedef struct
+{ const TraceSeg *segs;
+  const u32 *list;  u32 nwork;          /* segment ids to do (NULL = 0 .. nwork-1)     */
+  const u8 *abases, *bbases;
+  short *vf;  signed char *hf;  u32 cap; /* per-thread stripes of cap cells             */
+  int *stage;  u32 *count;  int *dist;
+  u32 *over;  u32 over_cap;  u32 *nover;  u32 *need;  u32 *err;
+} TraceArgs;
+
+#define DAMAR_TRACE_ERR_POINTS 1u       /* trace point out of bounds (align.c:5575)   */
+#define DAMAR_TRACE_ERR_ALIGN  2u       /* bad alignment between trace points (:4890) */
+
+/* pts: the records' trace points as stored in the .las (tbytes 1 or 2) */
+void damar_launch_trace_layout(const TraceRecIn *recs, u32 nrecs, const void *pts, int tbytes, int tspace,
+                               const DevBlock *ablk, const DevBlock *bblk, TraceSeg *segs, u32 *err, hipStream_t st);
+void damar_launch_trace_waves(const TraceArgs *t, int mode, u32 nblocks, hipStream_t st);
+void damar_launch_trace_gather(const TraceRecIn *recs, u32 nrecs, const u32 *count, const int *dist, u32 *segoff,
+                               u32 *tlen, int *diffs, hipStream_t st);
+void damar_launch_trace_pack(const TraceSeg *segs, u32 nsegs, const u32 *count, const u32 *segoff, const u32 *recoff,
+                             const int *stage, int *script, hipStream_t st);
 #endif

@@ -1664,6 +1664,7 @@ extern "C" double damar_bench_sort_u32(uint32_t n, int nbits, int reps, uint32_t
 struct WorkData
 { Path   bpath;
   std::vector<uint16> atrace, btrace;
+  std::vector<int>    script;          /* Compute_Trace_PTS */
 };
 
 extern "C" Work_Data *New_Work_Data(void)             /* align.c:135-160 */
@@ -1727,4 +1728,306 @@ extern "C" Path *Local_Alignment(Alignment *align, Work_Data *work, Align_Spec *
   w->btrace.assign(tr.begin() + toff[1], tr.begin() + toff[1] + paths[11]);
   w->bpath.trace = w->btrace.data();
   return &w->bpath;
+}
+
+/***** (f)4: trace-point expansion, align.c:5577-5692 Compute_Trace_PTS for batches of records *********/
+
+struct DBuf
+{ void  *p = nullptr;
+  size_t cap = 0;
+  void *need(size_t n)
+  { if (n > cap)
+      { if (p) HIP_CHECK(hipFree(p));
+        cap = n + n / 4 + 4096;
+        HIP_CHECK(hipMalloc(&p, cap));
+      }
+    return p;
+  }
+  void drop() { if (p) HIP_CHECK(hipFree(p));  p = nullptr;  cap = 0; }
+};
+
+static DBuf T_recs, T_pts, T_segs, T_count, T_dist, T_segoff, T_stage, T_vf, T_hf, T_over, T_ctr, T_tlen,
+            T_diffs, T_script, T_scan, T_bvf, T_bhf;
+static double T_ms[4];        /* of the last damar_trace_pts: trace_waves kernel, layout..pack on the device, whole call, inside the batches (wall) */
+static int64  T_cnt[4];       /* records, segments, deferred segments, script values */
+
+extern "C" void damar_trace_release(void)
+{ DBuf *all[] = { &T_recs, &T_pts, &T_segs, &T_count, &T_dist, &T_segoff, &T_stage, &T_vf, &T_hf, &T_over, &T_ctr,
+                  &T_tlen, &T_diffs, &T_script, &T_scan, &T_bvf, &T_bhf };
+  for (DBuf *b : all) b->drop();
+}
+
+extern "C" void damar_trace_last(double *ms, int64 *cnt)
+{ for (int i = 0; i < 4; i++) { ms[i] = T_ms[i];  cnt[i] = T_cnt[i]; }
+}
+
+/* staging slots one record needs = sum over its segments of dmax + |M - N| (the script of a segment has at
+   most D + |del| <= dmax + |del| values); also dmax and the segment count */
+template <typename PT>
+static void trace_record_shape(const Path *path, const PT *p, int tspace, int *dmax_out, int *nseg_out, int64 *slots_out)
+{ const int tlen = path->tlen;
+  int dmax = 0;
+  for (int d = 0; d + 1 < tlen; d += 2)
+    if ((int) p[d] > dmax) dmax = (int) p[d];
+  const int nseg = tlen >= 2 ? tlen / 2 : 1;
+  int ab = path->abpos, ae = (ab / tspace) * tspace, bb = path->bbpos;
+  int64 slots = 0;
+  for (int s = 0; s < nseg; s++)
+    { int be;
+      if (s + 1 < nseg) { ae += tspace; be = bb + (int) p[2 * s + 1]; }
+      else              { ae = path->aepos; be = path->bepos; }
+      const int del = (ae - ab) - (be - bb);
+      slots += dmax + (del < 0 ? -del : del);
+      ab = ae;
+      bb = be;
+    }
+  *dmax_out = dmax;  *nseg_out = nseg;  *slots_out = slots;
+}
+
+static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int bfirst, const Overlap *ovls, int64 r0, int64 r1,
+                       int tbytes, int tspace, int mode, int same, const std::vector<TraceRecIn> &recs, const std::vector<u8> &pts,
+                       u32 nsegs, u64 nslots, int64 *soff, int *diffs, std::vector<int> &script)
+{ const u32 nrecs = (u32) (r1 - r0);
+  static u32 cap = 0, maxblocks = 0;
+  if (cap == 0)
+    { const char *e = getenv("DAMAR_TRACE_CAP");
+      cap = e ? (u32) atoi(e) : 2048u;
+      if (cap < 64) cap = 64;
+      e = getenv("DAMAR_TRACE_BLOCKS");
+      maxblocks = e ? (u32) atoi(e) : (u32) (G_prop.multiProcessorCount * 32);
+      if (maxblocks < 1) maxblocks = 1;
+    }
+  const double h0 = now_ms();
+  TraceRecIn *d_recs = (TraceRecIn *) T_recs.need(sizeof(TraceRecIn) * (size_t) nrecs);
+  void       *d_pts  = T_pts.need(pts.size() + 64);
+  TraceSeg   *d_segs = (TraceSeg *) T_segs.need(sizeof(TraceSeg) * (size_t) nsegs);
+  u32 *d_count  = (u32 *) T_count.need(sizeof(u32) * (size_t) nsegs);
+  int *d_dist   = (int *) T_dist.need(sizeof(int) * (size_t) nsegs);
+  u32 *d_segoff = (u32 *) T_segoff.need(sizeof(u32) * (size_t) nsegs);
+  int *d_stage  = (int *) T_stage.need(sizeof(int) * (size_t) (nslots + 16));
+  u32 *d_over   = (u32 *) T_over.need(sizeof(u32) * (size_t) nsegs);
+  u32 *d_ctr    = (u32 *) T_ctr.need(256);                    /* [0] deferred, [1] cells needed, [2] error flags; u64 total at +64 */
+  u32 *d_tlen   = (u32 *) T_tlen.need(sizeof(u32) * (size_t) (nrecs + 1));
+  int *d_diffs  = (int *) T_diffs.need(sizeof(int) * (size_t) nrecs);
+  void *d_scan  = T_scan.need(damar_scan_workspace_bytes(nrecs));
+  const u32 nblocks = std::min(maxblocks, (nsegs + 63) / 64);
+  const size_t nthreads = (size_t) nblocks * 64;
+  short       *d_vf = (short *) T_vf.need(sizeof(short) * nthreads * cap);
+  signed char *d_hf = (signed char *) T_hf.need(nthreads * cap);
+
+  hipEvent_t e0, e1, e2, e3;
+  HIP_CHECK(hipEventCreate(&e0));  HIP_CHECK(hipEventCreate(&e1));
+  HIP_CHECK(hipEventCreate(&e2));  HIP_CHECK(hipEventCreate(&e3));
+  HIP_CHECK(hipMemcpyAsync(d_recs, recs.data(), sizeof(TraceRecIn) * (size_t) nrecs, hipMemcpyHostToDevice, G_st));
+  if (!pts.empty())
+    HIP_CHECK(hipMemcpyAsync(d_pts, pts.data(), pts.size(), hipMemcpyHostToDevice, G_st));
+  HIP_CHECK(hipMemsetAsync(d_ctr, 0, 256, G_st));
+  HIP_CHECK(hipEventRecord(e0, G_st));
+  damar_launch_trace_layout(d_recs, nrecs, d_pts, tbytes, tspace, ad, bd, d_segs, d_ctr + 2, G_st);
+  TraceArgs t;
+  memset(&t, 0, sizeof(t));
+  t.segs = d_segs;  t.list = NULL;  t.nwork = nsegs;
+  t.abases = ad->bases;  t.bbases = bd->bases;
+  t.vf = d_vf;  t.hf = d_hf;  t.cap = cap;
+  t.stage = d_stage;  t.count = d_count;  t.dist = d_dist;
+  t.over = d_over;  t.over_cap = nsegs;  t.nover = d_ctr;  t.need = d_ctr + 1;  t.err = d_ctr + 2;
+  HIP_CHECK(hipEventRecord(e1, G_st));
+  damar_launch_trace_waves(&t, mode, nblocks, G_st);
+  HIP_CHECK(hipEventRecord(e2, G_st));
+  u32 ctr[4];
+  HIP_CHECK(hipMemcpyAsync(ctr, d_ctr, sizeof(ctr), hipMemcpyDeviceToHost, G_st));
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  float wms = 0;
+  HIP_CHECK(hipEventElapsedTime(&wms, e1, e2));
+  T_ms[0] += wms;
+  if (ctr[0] > 0 && !(ctr[2] & DAMAR_TRACE_ERR_POINTS))
+    { /* segments whose waves outgrew the stripe: again, with stripes that hold dmax + 3 rows */
+      const u32 need = ctr[1];
+      size_t bthreads = ((size_t) ctr[0] + 63) / 64 * 64;
+      const size_t budget = (size_t) 8 << 30;
+      while (bthreads > 64 && bthreads * need * 3 > budget) bthreads /= 2;
+      bthreads = (bthreads + 63) / 64 * 64;
+      if (bthreads * need * 3 > ((size_t) 64 << 30))
+        { fprintf(stderr, "damar: trace expansion: a segment needs %u wave cells, more than this build provides\n", need);
+          return 1;
+        }
+      t.vf = (short *) T_bvf.need(sizeof(short) * bthreads * need);
+      t.hf = (signed char *) T_bhf.need(bthreads * need);
+      t.cap = need;
+      t.list = d_over;  t.nwork = ctr[0];
+      HIP_CHECK(hipMemsetAsync(d_ctr, 0, 8, G_st));
+      HIP_CHECK(hipEventRecord(e1, G_st));
+      damar_launch_trace_waves(&t, mode, (u32) (bthreads / 64), G_st);
+      HIP_CHECK(hipEventRecord(e2, G_st));
+      u32 c2[4];
+      HIP_CHECK(hipMemcpyAsync(c2, d_ctr, sizeof(c2), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      HIP_CHECK(hipEventElapsedTime(&wms, e1, e2));
+      T_ms[0] += wms;
+      T_cnt[2] += ctr[0];
+      if (c2[0] != 0)
+        { fprintf(stderr, "damar: trace expansion: internal error, %u segments deferred twice\n", c2[0]);
+          return 1;
+        }
+      ctr[2] |= c2[2];
+    }
+  if (ctr[2] & DAMAR_TRACE_ERR_POINTS)
+    { fprintf(stderr, "damar: Trace point out of bounds (Compute_Trace), source DB likely incorrect\n");   /* align.c:5575 */
+      return 1;
+    }
+  if (ctr[2] & DAMAR_TRACE_ERR_ALIGN)
+    { fprintf(stderr, "damar: Bad alignment between trace points (Compute_Trace), source DB likely incorrect\n");   /* :4890 */
+      return 1;
+    }
+  damar_launch_trace_gather(d_recs, nrecs, d_count, d_dist, d_segoff, d_tlen, d_diffs, G_st);
+  u64 *d_tot = (u64 *) ((char *) d_ctr + 64);
+  damar_exclusive_scan_u32(d_tlen, d_tlen, nrecs, d_scan, d_tot, G_st);
+  u64 total = 0;
+  HIP_CHECK(hipMemcpyAsync(&total, d_tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  if (total >= 0xfffffff0ull)
+    { fprintf(stderr, "damar: trace expansion: batch script exceeds 32-bit offsets\n");
+      return 1;
+    }
+  int *d_script = (int *) T_script.need(sizeof(int) * (size_t) (total + 16));
+  damar_launch_trace_pack(d_segs, nsegs, d_count, d_segoff, d_tlen, d_stage, d_script, G_st);
+  HIP_CHECK(hipEventRecord(e3, G_st));
+  std::vector<u32> hoff(nrecs);
+  const size_t base = script.size();
+  script.resize(base + (size_t) total);
+  HIP_CHECK(hipMemcpyAsync(hoff.data(), d_tlen, sizeof(u32) * (size_t) nrecs, hipMemcpyDeviceToHost, G_st));
+  HIP_CHECK(hipMemcpyAsync(diffs + r0, d_diffs, sizeof(int) * (size_t) nrecs, hipMemcpyDeviceToHost, G_st));
+  if (total > 0)
+    HIP_CHECK(hipMemcpyAsync(script.data() + base, d_script, sizeof(int) * (size_t) total, hipMemcpyDeviceToHost, G_st));
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  float dms = 0;
+  HIP_CHECK(hipEventElapsedTime(&dms, e0, e3));
+  T_ms[1] += dms;
+  for (u32 i = 0; i < nrecs; i++)
+    soff[r0 + i] = (int64) base + hoff[i];
+  soff[r1] = (int64) base + (int64) total;
+  HIP_CHECK(hipEventDestroy(e0));  HIP_CHECK(hipEventDestroy(e1));
+  HIP_CHECK(hipEventDestroy(e2));  HIP_CHECK(hipEventDestroy(e3));
+  T_ms[3] += now_ms() - h0;
+  T_cnt[0] += nrecs;  T_cnt[1] += nsegs;  T_cnt[3] += (int64) total;
+  (void) ovls; (void) afirst; (void) bfirst; (void) same;
+  return 0;
+}
+
+/* ovls[i].path.trace = the record's trace points as read from the .las (tbytes 1 or 2 per value);
+ * aread / bread are DB read ids, afirst / bfirst the ids of the blocks' first reads.  same != 0: A and B of
+ * every record are one buffer (align.c:4933-4951; LAshow never is).  On return *script_out is a malloc'ed
+ * array holding all edit scripts, record i at [soff[i], soff[i+1]), diffs[i] its summed distance. */
+extern "C" int damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_block *bblk, int bfirst,
+                               const Overlap *ovls, int64 novl, int tbytes, int tspace, int mode, int same,
+                               int64 *soff, int *diffs, int **script_out)
+{ ensure_init();
+  const double t0 = now_ms();
+  for (int i = 0; i < 4; i++) { T_ms[i] = 0;  T_cnt[i] = 0; }
+  std::vector<int> script;
+  std::vector<TraceRecIn> recs;
+  std::vector<u8> pts;
+  const u32 max_segs = 1u << 24;
+  const u64 max_slots = 1ull << 30;
+  int64 r0 = 0;
+  u32   nsegs = 0;
+  u64   nslots = 0;
+  soff[0] = 0;
+  for (int64 i = 0; i <= novl; i++)
+    { int dmax = 0, nseg = 0;
+      int64 slots = 0;
+      if (i < novl)
+        { const Overlap *o = ovls + i;
+          const int64 ar = (int64) o->aread - afirst, br = (int64) o->bread - bfirst;
+          if (ar < 0 || ar >= ablk->nreads || br < 0 || br >= bblk->nreads || o->path.tlen < 0 || (o->path.tlen & 1))
+            { fprintf(stderr, "damar: trace expansion: record %lld does not belong to the two blocks\n", (long long) i);
+              return 1;
+            }
+          if (tbytes == 1) trace_record_shape(&o->path, (const uint8 *) o->path.trace, tspace, &dmax, &nseg, &slots);
+          else             trace_record_shape(&o->path, (const uint16 *) o->path.trace, tspace, &dmax, &nseg, &slots);
+        }
+      if (i == novl || nsegs + (u32) nseg > max_segs || nslots + (u64) slots > max_slots)
+        { if (i > r0)
+            { if (trace_batch(&ablk->d, afirst, &bblk->d, bfirst, ovls, r0, i, tbytes, tspace, mode, same, recs, pts,
+                              nsegs, nslots, soff, diffs, script))
+                return 1;
+            }
+          recs.clear();  pts.clear();
+          r0 = i;  nsegs = 0;  nslots = 0;
+          if (i == novl) break;
+          if ((u64) slots > max_slots || (u32) nseg > max_segs)
+            { fprintf(stderr, "damar: trace expansion: record %lld is larger than a batch\n", (long long) i);
+              return 1;
+            }
+        }
+      const Overlap *o = ovls + i;
+      TraceRecIn in;
+      in.aread = (u32) (o->aread - afirst);  in.bread = (u32) (o->bread - bfirst);
+      in.flags = (o->flags & COMP_FLAG ? 1u : 0u) | (same ? 2u : 0u);
+      in.abpos = o->path.abpos;  in.bbpos = o->path.bbpos;  in.aepos = o->path.aepos;  in.bepos = o->path.bepos;
+      in.poff = (u32) (pts.size() / (size_t) tbytes);
+      in.tlen = o->path.tlen;
+      in.seg0 = nsegs;
+      in.stage0 = (u32) nslots;
+      in.dmax = dmax;
+      recs.push_back(in);
+      const u8 *src = (const u8 *) o->path.trace;
+      pts.insert(pts.end(), src, src + (size_t) o->path.tlen * (size_t) tbytes);
+      nsegs += (u32) nseg;
+      nslots += (u64) slots;
+    }
+  int *out = (int *) malloc(sizeof(int) * (script.size() + 1));
+  if (out == NULL)
+    { fprintf(stderr, "damar: out of memory (edit scripts)\n");
+      return 1;
+    }
+  memcpy(out, script.data(), sizeof(int) * script.size());
+  *script_out = out;
+  T_ms[2] = now_ms() - t0;
+  return 0;
+}
+
+/* align.c:5577-5692 for one record, through the batch path (the two sequences travel to HBM per call: this
+ * entry point is for callers that need the reference's API; LAshow-like loops over a .las belong on
+ * damar_trace_pts).  As in the reference, align->path->trace holds 16-bit trace-point pairs on entry (after
+ * Decompress_TraceTo16), bseq is already complemented where the record says so, and on return path->trace
+ * points to the edit script inside `work`, tlen and diffs are updated.  Returns 0, or 1 after the
+ * reference's message where the reference's EXIT(1) paths are. */
+extern "C" int Compute_Trace_PTS(Alignment *align, Work_Data *work, int trace_spacing, int mode)
+{ ensure_init();
+  WorkData *w = (WorkData *) work;
+  HITS_DB   db[2];
+  HITS_READ rd[2][2];
+  std::vector<char> buf[2];
+  const char *seq[2] = { align->aseq, align->bseq };
+  const int   len[2] = { align->alen, align->blen };
+  const int   same = (align->aseq == align->bseq);
+  for (int i = 0; i < 2; i++)
+    { memset(&db[i], 0, sizeof(HITS_DB));
+      memset(rd[i], 0, sizeof(rd[i]));
+      buf[i].assign((size_t) len[i] + 2, 4);
+      memcpy(buf[i].data() + 1, seq[i], (size_t) len[i]);
+      rd[i][0].rlen = len[i];  rd[i][0].boff = 0;  rd[i][1].boff = len[i] + 1;
+      db[i].nreads = db[i].ureads = 1;  db[i].maxlen = len[i];  db[i].totlen = len[i];
+      db[i].bases = buf[i].data() + 1;  db[i].reads = rd[i];
+    }
+  damar_dev_block *ab = damar_block_upload(&db[0]);
+  damar_dev_block *bb = same ? ab : damar_block_upload(&db[1]);
+  Overlap o;
+  memset(&o, 0, sizeof(o));
+  o.path = *align->path;
+  int64 soff[2];
+  int   diffs = 0, *script = NULL;
+  const int rc = damar_trace_pts(ab, 0, bb, 0, &o, 1, 2, trace_spacing, mode, same, soff, &diffs, &script);
+  damar_block_free(ab);
+  if (!same)
+    damar_block_free(bb);
+  if (rc)
+    return 1;
+  w->script.assign(script, script + soff[1]);
+  free(script);
+  align->path->trace = w->script.data();
+  align->path->tlen  = (int) soff[1];
+  align->path->diffs = diffs;
+  return 0;
 }

@@ -81,6 +81,16 @@ void       Free_Work_Data(Work_Data *work);
 Path      *Local_Alignment(Alignment *align, Work_Data *work, Align_Spec *spec,
                            int low, int hgh, int anti, int lbord, int hbord);
 
+/* align.h:279-283, align.c:5577-5692: expand the trace points of align->path (16-bit pairs, as after
+ * Decompress_TraceTo16; bseq already complemented for COMP records) into the edit script of the
+ * alignment: a negative value -x = a dash before A[x], a positive value x = a dash before B[x] (1-based),
+ * path->trace then points into `work`, path->tlen / path->diffs are updated.  Computed on the GPU by the
+ * kernels of the batch entry damar_trace_pts (damar_hip.h), which is the one to use for whole .las files. */
+#define LOWERMOST -1
+#define GREEDIEST  0
+#define UPPERMOST  1
+int Compute_Trace_PTS(Alignment *align, Work_Data *work, int trace_spacing, int mode);
+
 /* align.c:5969-6102, 6166-6380 */
 Overlap_IO_Buffer *CreateOverlapBuffer(int nthreads, int tbytes, int no_trace);
 Overlap_IO_Buffer *OVL_IO_Buffer(Align_Spec *spec);

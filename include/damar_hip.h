@@ -101,6 +101,24 @@ int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_block *bblk, in
                                 Align_Spec *spec, const int *tasks, int ntasks,
                                 int *paths, int64 *trace_off, uint16 *traces, int64 trace_cap);
 
+/* SURVEY 8(f)4, the next consumer of the records: Compute_Trace_PTS (align.c:5577-5692 + iter_np
+ * :4892-5261) for every record of an Overlap array, the way utils/LAshow.c:245-262 calls it per record.
+ * ablk / bblk hold the A and B reads (B forward: the complement of COMP records is read in place);
+ * ovls[i].aread / bread are DB read ids, afirst / bfirst the ids of the blocks' first reads;
+ * ovls[i].path.trace = the trace points as stored in the .las, tbytes (1 or 2) bytes per value.
+ * same != 0 applies the one-buffer rule of align.c:4933-4951 (LAshow never does).
+ * On success returns 0: *script = malloc'ed array of all edit scripts, record i at
+ * [soff[i], soff[i+1]) (soff has novl + 1 entries), diffs[i] = its summed segment distances.
+ * Returns 1 after the reference's message where the reference exits (trace point out of bounds,
+ * bad alignment between trace points). */
+int  damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_block *bblk, int bfirst,
+                     const Overlap *ovls, int64 novl, int tbytes, int tspace, int mode, int same,
+                     int64 *soff, int *diffs, int **script);
+/* ms[4]: trace_waves kernel, all kernels of the call (HIP events), whole call, inside the batches (wall);
+ * cnt[4]: records, segments, segments deferred to the large-stripe launch, script values */
+void damar_trace_last(double *ms, int64 *cnt);
+void damar_trace_release(void);          /* frees the cached device buffers of damar_trace_pts */
+
 /* Phase timings (milliseconds, HIP events on the library's stream) of the last
  * damar_index_build / damar_match: see DAMAR_T_* below. */
 enum { DAMAR_T_TUPLES = 0, DAMAR_T_KSORT, DAMAR_T_TABLE, DAMAR_T_MERGE, DAMAR_T_SSORT,

@@ -1,0 +1,123 @@
+"""(f)4 on the GPU: damar_trace_pts / Compute_Trace_PTS (kernels/trace_pts.hip) against the REAL reference.
+
+The expected values are the md5 of the dumps oracle/ref_lastrace wrote around the reference's own
+Compute_Trace_PTS (tests/golden/trace_ref_md5.txt); damar_amd/bin/lastrace writes the same format from the
+GPU results, so equality is byte for byte: every edit-script value and every difference count."""
+import ctypes
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, read_case
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_lines():
+    out = []
+    for ln in open(os.path.join(GOLDEN, "trace_ref_md5.txt")):
+        md5, name, las, mode = ln.split()
+        out.append((md5, name, las, int(mode)))
+    return out
+
+
+def run_tool(c, las, mode, out, extra_env=None):
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    db = os.path.join(c["dbdir"], "G")
+    subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "lastrace"), "-m%d" % mode, db, db,
+                    os.path.join(c["lasdir"], las), out], check=True, env=env)
+    return hashlib.md5(open(out, "rb").read()).hexdigest()
+
+
+def test_trace_expansion_equals_reference_on_golden(built, tmp_path):
+    n = 0
+    for md5, name, las, mode in ref_lines():
+        got = run_tool(read_case(name), las, mode, str(tmp_path / "g.bin"))
+        assert got == md5, (name, las, mode)
+        n += 1
+    assert n >= 100
+
+
+def test_trace_expansion_small_stripes_take_the_deferred_launch(built, tmp_path):
+    """Stripes of 96 cells hold only the first few waves: almost every segment overflows and is redone by
+    the second launch with large stripes; results must not change."""
+    want = {(n, l, m): h for h, n, l, m in ref_lines()}
+    for name in ("tiny_I", "fusion", "tan_tandem", "tiny_s"):
+        c = read_case(name)
+        for las in c["las"]:
+            for mode in (0, 1, -1):
+                got = run_tool(c, las, mode, str(tmp_path / "g.bin"), {"DAMAR_TRACE_CAP": "96", "DAMAR_TRACE_BLOCKS": "7"})
+                assert got == want[(name, las, mode)], (name, las, mode)
+
+
+def test_compute_trace_pts_c_abi_single_record(built):
+    """align.h's Compute_Trace_PTS(align, work, tspace, mode) for single records against the oracle."""
+    from damar_amd import api
+    lib = api.lib()
+    ora = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+
+    class Path(ctypes.Structure):
+        _fields_ = [("trace", ctypes.c_void_p), ("tlen", ctypes.c_int), ("diffs", ctypes.c_int),
+                    ("abpos", ctypes.c_int), ("bbpos", ctypes.c_int), ("aepos", ctypes.c_int), ("bepos", ctypes.c_int)]
+
+    class Alignment(ctypes.Structure):
+        _fields_ = [("path", ctypes.POINTER(Path)), ("flags", ctypes.c_uint32), ("aseq", ctypes.c_void_p),
+                    ("bseq", ctypes.c_void_p), ("alen", ctypes.c_int), ("blen", ctypes.c_int)]
+
+    lib.New_Work_Data.restype = ctypes.c_void_p
+    lib.Compute_Trace_PTS.argtypes = [ctypes.POINTER(Alignment), ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.Free_Work_Data.argtypes = [ctypes.c_void_p]
+    ora.oracle_compute_trace_pts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.POINTER(Path), ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(5)
+    work = lib.New_Work_Data()
+    tspace = 100
+    for trial in range(6):
+        alen = int(rng.integers(900, 2500))
+        a = rng.integers(0, 4, alen).astype(np.int8)
+        # B = A with indels and substitutions; trace points from the true correspondence
+        b, pts, diffs, last_b = [], [], 0, 0
+        abpos, aepos = int(rng.integers(0, 150)), alen - int(rng.integers(0, 150))
+        for i in range(abpos, aepos):
+            r = rng.random()
+            if r < 0.05:
+                diffs += 1                      # deletion from B
+            elif r < 0.10:
+                b += [int(rng.integers(0, 4)), int(a[i])]
+                diffs += 1
+            elif r < 0.15:
+                b.append(int((a[i] + 1 + rng.integers(0, 3)) % 4))
+                diffs += 1
+            else:
+                b.append(int(a[i]))
+            if (i + 1) % tspace == 0 or i + 1 == aepos:
+                pts += [min(diffs + 2, 60000), len(b) - last_b]
+                last_b, diffs = len(b), 0
+        pre = rng.integers(0, 4, int(rng.integers(0, 90))).astype(np.int8)
+        bseq = np.concatenate([[4], pre, np.array(b, dtype=np.int8), rng.integers(0, 4, 40).astype(np.int8), [4]]).astype(np.int8)
+        aseq = np.concatenate([[4], a, [4]]).astype(np.int8)
+        blen = len(bseq) - 2
+        for mode in (0, 1, -1):
+            res = []
+            for which in ("gpu", "oracle"):
+                tp = np.array(pts, dtype=np.uint16)
+                p = Path(tp.ctypes.data, len(tp), 0, abpos, len(pre), aepos, len(pre) + len(b))
+                al = Alignment(ctypes.pointer(p), 0, aseq.ctypes.data + 1, bseq.ctypes.data + 1, alen, blen)
+                if which == "gpu":
+                    assert lib.Compute_Trace_PTS(ctypes.byref(al), work, tspace, mode) == 0
+                    out = np.ctypeslib.as_array(ctypes.cast(p.trace, ctypes.POINTER(ctypes.c_int)), shape=(max(p.tlen, 1),))[:p.tlen].copy()
+                    res.append((out.tolist(), p.diffs))
+                else:
+                    script = np.zeros(alen + blen + 16, dtype=np.int32)
+                    d = ctypes.c_int(0)
+                    n = ora.oracle_compute_trace_pts(aseq.ctypes.data + 1, alen, bseq.ctypes.data + 1, blen, ctypes.byref(p),
+                                                     tspace, mode, script.ctypes.data, ctypes.byref(d))
+                    assert n >= 0
+                    res.append((script[:n].tolist(), d.value))
+            assert res[0] == res[1], (trial, mode)
+    lib.Free_Work_Data(work)
