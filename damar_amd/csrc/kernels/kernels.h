@@ -159,6 +159,7 @@ typedef struct
 { const TraceSeg *segs;
   const u32 *list;  u32 nwork;          /* segment ids to do (NULL = 0 .. nwork-1)     */
   const u8 *abases, *bbases;
+  const u32 *apk, *bpk;               /* the same bases at 2 bits (DevBlock.pk)      */
   short *vf;  signed char *hf;  u32 cap; /* per-thread stripes of cap cells             */
   int *stage;  u32 *count;  int *dist;
   u32 *over;  u32 over_cap;  u32 *nover;  u32 *need;  u32 *err;
@@ -171,6 +172,8 @@ typedef struct
 void damar_launch_trace_layout(const TraceRecIn *recs, u32 nrecs, const void *pts, int tbytes, int tspace,
                                const DevBlock *ablk, const DevBlock *bblk, TraceSeg *segs, u32 *err, hipStream_t st);
 void damar_launch_trace_waves(const TraceArgs *t, int mode, u32 nblocks, hipStream_t st);
+size_t damar_trace_slot_area_cells(void);
+void damar_launch_trace_waves_slots(const TraceArgs *t, int mode, u32 nblocks, hipStream_t st);
 void damar_launch_trace_gather(const TraceRecIn *recs, u32 nrecs, const u32 *count, const int *dist, u32 *segoff,
                                u32 *tlen, int *diffs, hipStream_t st);
 void damar_launch_trace_pack(const TraceSeg *segs, u32 nsegs, const u32 *count, const u32 *segoff, const u32 *recoff,

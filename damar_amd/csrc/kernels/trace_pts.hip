@@ -70,20 +70,6 @@ void trace_layout(const TraceRecIn *__restrict__ recs, u32 nrecs, const PT *__re
     }
 }
 
-/* packed row layout of one segment's waves: rows -2, -1, 0, 1, ... ; row D >= 0 spans the diagonals
-   low0 - D/2 - 1 .. hgh0 + D/2 + 1 (one sentinel either side), rows -2 and -1 like row 0 */
-struct RowMap
-{ int w0, low0;
-  __device__ __forceinline__ int start(int D) const
-  { const int m = D > 0 ? D >> 1 : 0, q = D > 0 ? (D - 1) >> 1 : 0;
-    return (D + 2) * w0 + 2 * m * q;
-  }
-  __device__ __forceinline__ int at(int D, int k) const
-  { const int m = D > 0 ? D >> 1 : 0;
-    return start(D) + k - (low0 - m - 1);
-  }
-};
-
 /* the three-way choice of align.c:4981-5004: ties go to the free neighbour, then to the substitution */
 __device__ __forceinline__ int choose(int am, int ac, int ap, int mcode, int pcode, int &code)
 { if (ac < am)
@@ -96,176 +82,384 @@ __device__ __forceinline__ int choose(int am, int ac, int ap, int mcode, int pco
   return ap;
 }
 
+/***** where the waves of a segment live ************************************************************
+ *
+ * Row D >= 0 spans the diagonals low0 - D/2 - 1 .. hgh0 + D/2 + 1 (one sentinel either side), rows -2
+ * and -1 the span of row 0.  Two layouts:
+ *
+ *  Stripe   the lane's own stripe of `cap` cells, rows packed back to back.  Any segment fits a stripe
+ *           that is large enough; the lanes of a wavefront touch 64 different cache lines per access.
+ *  Slots    one area per wavefront, cell (row, slot) of the 64 lanes side by side (128 bytes of int16).
+ *           A row is laid out in the order in which a wave is computed -- hgh+1, hgh, ... down to del,
+ *           and low-1, low, ... up to del -- so that the 64 lanes, which the hardware steps through the
+ *           loops together, sit on the same slot at the same time whatever their del: one cache line
+ *           per access.
+ */
+struct Stripe
+{ short *vf;  signed char *hf;  u32 cap;
+  int w0, low0, del;
+  __device__ __forceinline__ void shape(int d)
+  { del = d;
+    w0 = (d < 0 ? -d : d) + 3;
+    low0 = d < 0 ? d : 0;
+  }
+  __device__ __forceinline__ int start(int D) const
+  { const int m = D > 0 ? D >> 1 : 0, q = D > 0 ? (D - 1) >> 1 : 0;
+    return (D + 2) * w0 + 2 * m * q;
+  }
+  __device__ __forceinline__ int at(int D, int k) const
+  { const int m = D > 0 ? D >> 1 : 0;
+    return start(D) + k - (low0 - m - 1);
+  }
+  __device__ __forceinline__ bool fits(int D) const        { return (u32) start(D + 1) <= cap; }
+  __device__ __forceinline__ u32  rows_needed(int dmax) const { return (u32) start(dmax + 1); }
+  __device__ __forceinline__ int  v(int D, int k) const    { return vf[at(D, k)]; }
+  __device__ __forceinline__ int  va(int D, int k) const   { return v(D, k); }     /* k >= del */
+  __device__ __forceinline__ int  vb(int D, int k) const   { return v(D, k); }     /* k <= del */
+  __device__ __forceinline__ void setv(int D, int k, int x){ vf[at(D, k)] = (short) x; }
+  __device__ __forceinline__ int  h(int D, int k) const    { return hf[at(D, k)]; }
+  __device__ __forceinline__ void seth(int D, int k, int x){ hf[at(D, k)] = (signed char) x; }
+  __device__ __forceinline__ void put_above(int D, int k, int x, int code) { setv(D, k, x);  seth(D, k, code); }
+  __device__ __forceinline__ void put_below(int D, int k, int x, int code) { setv(D, k, x);  seth(D, k, code); }
+  __device__ __forceinline__ void put_del(int D, int x, int code)          { setv(D, del, x);  seth(D, del, code); }
+  static const int recompute = 0;
+};
+
+#define SLOT_SS    40                      /* slots either side: sentinel, diagonals, del */
+#define SLOT_RS    (2 * SLOT_SS)
+#define SLOT_ROWS  64                      /* rows -2 .. 61 */
+#define SLOT_MAXB  240                     /* bases of A / of B staged into LDS */
+#define SLOT_WORDS 17                      /* (15 + 240 + 15) / 16 + 1 */
+
+/* A row is kept as two runs of slots, both ending at diagonal del, which is therefore stored twice:
+   "above" = hgh+1, hgh, ..., del (slots 0 ..), "below" = low-1, low, ..., del (slots SS ..).  Within a
+   run the slot is linear in k, so the loops of a wave step through consecutive lines.  The furthest
+   points fit a byte here (-2 .. SLOT_MAXB, kept + 2).  RING: only the rows of waves D, D-1, D-2 are live
+   (GREEDIEST never reads an older furthest point: the script positions are found again by sliding along
+   the chosen path), so four rows are reused in turn and stay in the caches; the predecessor codes always
+   keep every row. */
+template <int RING>
+struct Slots
+{ u8 *vf;  signed char *hf;                /* already offset by the lane */
+  int del, low0, hgh0, rows;
+  static const int recompute = RING;
+  __device__ __forceinline__ void shape(int d)
+  { del = d;
+    low0 = d < 0 ? d : 0;
+    hgh0 = d < 0 ? 0 : d;
+  }
+  __device__ __forceinline__ int above(int D, int k) const          /* slot of k in [del, hgh(D) + 1] */
+  { const int m = D > 0 ? D >> 1 : 0;
+    return hgh0 + m + 1 - k;
+  }
+  __device__ __forceinline__ int below(int D, int k) const          /* slot of k in [low(D) - 1, del] */
+  { const int m = D > 0 ? D >> 1 : 0;
+    return SLOT_SS + (k - (low0 - m - 1));
+  }
+  __device__ __forceinline__ int slot(int D, int k) const  { return k >= del ? above(D, k) : below(D, k); }
+  __device__ __forceinline__ int vrow(int D) const         { return RING ? ((D + 2) & 3) : D + 2; }
+  __device__ __forceinline__ int vi(int D, int sl) const   { return (vrow(D) * SLOT_RS + sl) * 64; }
+  __device__ __forceinline__ int hi(int D, int sl) const   { return ((D + 2) * SLOT_RS + sl) * 64; }
+  __device__ __forceinline__ bool fits(int D) const
+  { const int m = D >> 1;
+    return D + 2 < rows && hgh0 + m + 1 - del < SLOT_SS && del - (low0 - m - 1) < SLOT_SS;
+  }
+  __device__ __forceinline__ int  v(int D, int k) const    { return (int) vf[vi(D, slot(D, k))] - 2; }
+  __device__ __forceinline__ int  va(int D, int k) const   { return (int) vf[vi(D, above(D, k))] - 2; }
+  __device__ __forceinline__ int  vb(int D, int k) const   { return (int) vf[vi(D, below(D, k))] - 2; }
+  __device__ __forceinline__ void setv(int D, int k, int x)
+  { if (k >= del) vf[vi(D, above(D, k))] = (u8) (x + 2);
+    if (k <= del) vf[vi(D, below(D, k))] = (u8) (x + 2);
+  }
+  __device__ __forceinline__ int  h(int D, int k) const    { return hf[hi(D, slot(D, k))]; }
+  __device__ __forceinline__ void seth(int D, int k, int x){ hf[hi(D, slot(D, k))] = (signed char) x; }
+  __device__ __forceinline__ void put_above(int D, int k, int x, int code)
+  { const int sl = above(D, k);  vf[vi(D, sl)] = (u8) (x + 2);  hf[hi(D, sl)] = (signed char) code; }
+  __device__ __forceinline__ void put_below(int D, int k, int x, int code)
+  { const int sl = below(D, k);  vf[vi(D, sl)] = (u8) (x + 2);  hf[hi(D, sl)] = (signed char) code; }
+  __device__ __forceinline__ void put_del(int D, int x, int code)
+  { const int sl = above(D, del);  vf[vi(D, sl)] = (u8) (x + 2);  hf[hi(D, sl)] = (signed char) code;
+    vf[vi(D, below(D, del))] = (u8) (x + 2);
+  }
+};
+
+/***** how a snake is followed ************************************************************************/
+
+/* base by base on the blocks' byte arrays (any segment; B read backwards and complemented for COMP) */
+struct ByteBases
+{ const u8 *A, *B;
+  int sgn, comp;
+  __device__ __forceinline__ int a(int i) const { return A[i]; }
+  __device__ __forceinline__ int b(int j) const
+  { const int x = B[sgn * j];
+    return (comp && x < 4) ? 3 - x : x;
+  }
+  __device__ __forceinline__ int slide(int k, int j, int lim) const
+  { while (j < lim && b(j) == a(k + j)) j++;
+    return j;
+  }
+};
+
+/* 16 bases per step on 2-bit copies of the two segments in LDS (word w of lane l at [w * 64 + l]) */
+struct LdsBases
+{ const u32 *la, *lb;                      /* already offset by the lane */
+  int oa, ob;                              /* position of A[0] / B[0] in the packed copies */
+  __device__ __forceinline__ u32 win(const u32 *x, int pos) const
+  { const int w = pos >> 4;
+    return __builtin_amdgcn_alignbit(x[(w + 1) * 64], x[w * 64], (u32) pos * 2);
+  }
+  __device__ __forceinline__ int slide(int k, int j, int lim) const
+  { while (j < lim)
+      { const u32 x = win(la, oa + k + j) ^ win(lb, ob + j);
+        const int run = (int) ((u32) __builtin_ctzll((u64) x | (1ull << 32)) >> 1);
+        j = min(j + run, lim);
+        if (run < 16) break;
+      }
+    return j;
+  }
+};
+
+__device__ __forceinline__ u32 pk_window(const u32 *pk, u32 pb)       /* 16 bases from biased position pb */
+{ const u32 *q = (pk - PK_PAD) + (pb >> 4);
+  return __builtin_amdgcn_alignbit(q[1], q[0], pb * 2);
+}
+
+/***** one segment: waves, reversal, script (align.c:4892-5261) ***************************************
+ * returns 0 = done, 1 = the waves do not fit the cell storage, 2 = D > dmax (align.c:4966)           */
+template <int MODE, class Cells, class Snake>
+__device__ __forceinline__ int expand_segment(Cells &w, const Snake &sn, const ByteBases &bb, const TraceSeg &g,
+                                              int M, int N, int dmax, int *out, int &nout, int &dist)
+{ const int del = M - N;
+  int low = del < 0 ? del : 0, hgh = del < 0 ? 0 : del;
+  int posl = -dmax, posh = dmax;
+  if (g.flags & 2u)                                       /* both reads are one buffer (align.c:4933-4951) */
+    { const int off = g.b0 - g.a0;
+      if (off < 0) { if (off + 1 > posl) posl = off + 1; }
+      else         { if (off - 1 < posh) posh = off - 1; }
+    }
+  if (!w.fits(0))
+    return 1;
+  for (int k = low - 1; k <= hgh + 1; k++)
+    { w.setv(-2, k, -2);
+      w.setv(-1, k, -2);
+    }
+  w.setv(-1, 0, -1);
+  low += 1;
+  hgh -= 1;
+
+  int D;
+  for (D = 0; ; D++)
+    { if (D > dmax) return 2;
+      if (!w.fits(D)) return 1;
+      if ((D & 1) == 0)
+        { if (low > posl) low -= 1;
+          if (hgh < posh) hgh += 1;
+        }
+      w.setv(D, hgh + 1, -2);
+      w.setv(D, low - 1, -2);
+      int j = -2, code;
+      for (int k = hgh; k > del; k--)
+        { j = choose(w.va(D - 2, k - 1), w.va(D - 1, k) + 1, j + 1, -1, 4, code);
+          j = sn.slide(k, j, min(N, M - k));
+          w.put_above(D, k, j, code);
+        }
+      j = -2;
+      for (int k = low; k < del; k++)
+        { j = choose(j, w.vb(D - 1, k) + 1, w.vb(D - 2, k + 1) + 1, 2, 1, code);
+          j = sn.slide(k, j, min(N, M - k));
+          w.put_below(D, k, j, code);
+        }
+      j = choose(j, w.va(D - 1, del) + 1, w.va(D, del + 1) + 1, 2, 4, code);
+      j = sn.slide(del, j, N);
+      w.put_del(D, j, code);
+      if (j >= N) break;
+    }
+
+  /* predecessor links -> successor links, from (D, del) back to (0, 0) (align.c:5042-5215) */
+  int e, h, m, c = N, k = del;
+  w.seth(0, 0, 3);
+  e = w.h(D, k);
+  w.seth(D, k, 3);
+  while (e != 3)
+    { h = k + e;
+      if (e > 1) h -= 3;
+      else if (e == 0) D -= 1;
+      else D -= 2;
+      if (MODE == 1 && h < k)
+        { m = k < 0 ? -k : 0;
+          const int x = w.v(D, h);
+          if (x <= c) c = x - 1;
+          while (c >= m && bb.a(k + c) == bb.b(c)) c -= 1;
+          if (e == -1)
+            { if (c <= w.v(D + 2, k + 1))          { e = 4; h = k + 1; D = D + 2; }
+              else if (c == w.v(D + 1, k))         { e = 0; h = k;     D = D + 1; }
+              else w.setv(D, h, c + 1);
+            }
+          else
+            { m = (k == del) ? D : D - 2;
+              if (c <= w.v(m, k + 1))              { e = (k == del) ? 4 : 1; h = k + 1; D = m; }
+              else if (c == w.v(D - 1, k))         { e = 0; h = k; D = D - 1; }
+              else w.setv(D, h, c + 1);
+            }
+        }
+      else if (MODE == -1 && h > k)
+        { m = k < 0 ? -k : 0;
+          const int x = w.v(D, h);
+          if (x < c) c = x;
+          while (c >= m && bb.a(k + c) == bb.b(c)) c -= 1;
+          if (e == 1)
+            { if (c < w.v(D + 2, k - 1))           { e = 2; h = k - 1; D = D + 2; }
+              else if (c == w.v(D + 1, k))         { e = 0; h = k;     D = D + 1; }
+              else { w.setv(D, h, c);  c -= 1; }
+            }
+          else
+            { m = (k == del) ? D : D - 2;
+              if (c < w.v(m, k - 1))               { e = (k == del) ? 2 : -1; h = k - 1; D = m; }
+              else if (c == w.v(D - 1, k))         { e = 0; h = k; D = D - 1; }
+              else { w.setv(D, h, c);  c -= 1; }
+            }
+        }
+      m = w.h(D, h);
+      w.seth(D, h, e);
+      e = m;
+      k = h;
+    }
+
+  /* forward again: one script value per indel (align.c:5217-5256) */
+  int n = 0, jstart = 0;
+  k = D = 0;
+  e = w.h(0, 0);
+  while (e != 3)
+    { h = k - e;
+      /* the furthest point of the path's cell: kept, or found again by sliding from where the path
+         entered the diagonal (the predecessor's point, one further unless the move kept the B index) */
+      c = Cells::recompute ? sn.slide(k, jstart, min(N, M - k)) : w.v(D, k);
+      jstart = (e == -1 || e == 2) ? c : c + 1;
+      if (e > 1) h += 3;
+      else if (e == 0) D += 1;
+      else D += 2;
+      if (h > k)      out[n++] = g.b0 + c + 1;
+      else if (h < k) out[n++] = -(g.a0 + c + k + 1);
+      k = h;
+      e = w.h(D, h);
+    }
+  nout = n;
+  dist = D + (del < 0 ? -del : del);
+  return 0;
+}
+
+/* any segment, one lane each, cells in per-lane stripes: the launch for what trace_waves_slots defers */
 template <int MODE>
 __global__ __launch_bounds__(TP_THREADS)
 void trace_waves(TraceArgs t)
 { const u32 tid = blockIdx.x * TP_THREADS + threadIdx.x;
   const u32 nthreads = gridDim.x * TP_THREADS;
-  short       *const vf = t.vf + (size_t) tid * t.cap;
-  signed char *const hf = t.hf + (size_t) tid * t.cap;
-  const u8 *const abase = t.abases;
-  const u8 *const bbase = t.bbases;
+  Stripe w;
+  w.vf = t.vf + (size_t) tid * t.cap;
+  w.hf = t.hf + (size_t) tid * t.cap;
+  w.cap = t.cap;
 
   for (u32 it = tid; it < t.nwork; it += nthreads)
     { const u32 s = t.list ? t.list[it] : it;
       const TraceSeg g = t.segs[s];
-      if (g.flags & 4u)
-        { t.count[s] = 0;  t.dist[s] = 0;
-          continue;
-        }
-      const int M = (int) (g.mn & 0xffffu), N = (int) (g.mn >> 16);
-      const int del = M - N;
-      const int dmax = (int) (g.flags >> 8);
-      const int comp = (int) (g.flags & 1u);
-      const int sgn = comp ? -1 : 1;
-      const u8 *const A = abase + g.apos;
-      const u8 *const B = bbase + g.bpos;
-#define BV(j)  ({ const int v_ = B[sgn * (j)]; (comp && v_ < 4) ? 3 - v_ : v_; })
-      RowMap rm;
-      rm.w0 = (del < 0 ? -del : del) + 3;
-      rm.low0 = del < 0 ? del : 0;
-      int low = rm.low0, hgh = del < 0 ? 0 : del;
-      int posl = -dmax, posh = dmax;
-      if (g.flags & 2u)                                   /* both reads are one buffer (align.c:4933-4951) */
-        { const int off = g.b0 - g.a0;
-          if (off < 0) { if (off + 1 > posl) posl = off + 1; }
-          else         { if (off - 1 < posh) posh = off - 1; }
-        }
-      int D = 0, status = 0;                              /* 1 = scratch exhausted, 2 = D > dmax */
-      if ((u32) rm.start(1) > t.cap)
-        status = 1;
-      else
-        { for (int k = low - 1; k <= hgh + 1; k++)
-            { vf[rm.at(-2, k)] = -2;
-              vf[rm.at(-1, k)] = -2;
+      int n = 0, dist = 0;
+      if (!(g.flags & 4u))
+        { const int M = (int) (g.mn & 0xffffu), N = (int) (g.mn >> 16);
+          const int dmax = (int) (g.flags >> 8);
+          ByteBases bb;
+          bb.comp = (int) (g.flags & 1u);
+          bb.sgn = bb.comp ? -1 : 1;
+          bb.A = t.abases + g.apos;
+          bb.B = t.bbases + g.bpos;
+          w.shape(M - N);
+          const int status = expand_segment<MODE>(w, bb, bb, g, M, N, dmax, t.stage + g.stage, n, dist);
+          if (status == 1)
+            { const u32 o = atomicAdd(t.nover, 1u);
+              if (o < t.over_cap) t.over[o] = s;
+              atomicMax(t.need, w.rows_needed(dmax));     /* rows -2 .. dmax of this segment */
             }
-          vf[rm.at(-1, 0)] = -1;
+          else if (status == 2)
+            atomicOr(t.err, DAMAR_TRACE_ERR_ALIGN);       /* "Bad alignment between trace points" */
+          if (status) { n = 0;  dist = 0; }
         }
-      low += 1;
-      hgh -= 1;
+      t.count[s] = (u32) n;
+      t.dist[s]  = dist;
+    }
+}
 
-      for (D = 0; status == 0; D++)
-        { if (D > dmax) { status = 2; break; }
-          if ((u32) rm.start(D + 1) > t.cap) { status = 1; break; }
-          if ((D & 1) == 0)
-            { if (low > posl) low -= 1;
-              if (hgh < posh) hgh += 1;
-            }
-          const int r0 = rm.at(D, 0), r1 = rm.at(D - 1, 0), r2 = rm.at(D - 2, 0);   /* column of k = 0 */
-          vf[r0 + hgh + 1] = -2;
-          vf[r0 + low - 1] = -2;
-          int j = -2, code;
-          for (int k = hgh; k > del; k--)
-            { j = choose(vf[r2 + k - 1], vf[r1 + k] + 1, j + 1, -1, 4, code);
-              hf[r0 + k] = (signed char) code;
-              const int lim = min(N, M - k);
-              const u8 *a = A + k;
-              while (j < lim && BV(j) == a[j]) j++;
-              vf[r0 + k] = (short) j;
-            }
-          j = -2;
-          for (int k = low; k < del; k++)
-            { j = choose(j, vf[r1 + k] + 1, vf[r2 + k + 1] + 1, 2, 1, code);
-              hf[r0 + k] = (signed char) code;
-              const int lim = min(N, M - k);
-              const u8 *a = A + k;
-              while (j < lim && BV(j) == a[j]) j++;
-              vf[r0 + k] = (short) j;
-            }
-          j = choose(j, vf[r1 + del] + 1, vf[r0 + del + 1] + 1, 2, 4, code);
-          hf[r0 + del] = (signed char) code;
-          { const u8 *a = A + del;
-            while (j < N && BV(j) == a[j]) j++;
-          }
-          vf[r0 + del] = (short) j;
-          if (j >= N) break;
-        }
-      if (status == 1)
-        { const u32 o = atomicAdd(t.nover, 1u);           /* deferred to the launch with large stripes */
-          if (o < t.over_cap) t.over[o] = s;
-          atomicMax(t.need, (u32) rm.start(dmax + 1));    /* rows -2 .. dmax of this segment */
-          t.count[s] = 0;  t.dist[s] = 0;
-          continue;
-        }
-      if (status == 2)
-        { atomicOr(t.err, DAMAR_TRACE_ERR_ALIGN);         /* align.c:4966: "Bad alignment between trace points" */
-          t.count[s] = 0;  t.dist[s] = 0;
-          continue;
-        }
+/* the common case: 64 consecutive segments per wavefront, cells in the wavefront's slot area, forward
+   snakes on 2-bit copies of the segments in LDS.  Defers segments with more than SLOT_MAXB bases a side,
+   waves wider than SLOT_SS diagonals either side of del or more than SLOT_ROWS - 3 waves, and the
+   one-buffer case. */
+template <int MODE>
+__global__ __launch_bounds__(TP_THREADS)
+void trace_waves_slots(TraceArgs t)
+{ __shared__ u32 lds[2 * SLOT_WORDS * 64];
+  const int lane = (int) threadIdx.x;
+  const size_t area = (size_t) SLOT_ROWS * SLOT_RS * 64;
+  Slots<MODE == 0> w;
+  w.vf = (u8 *) t.vf + (size_t) blockIdx.x * area + lane;
+  w.hf = t.hf + (size_t) blockIdx.x * area + lane;
+  w.rows = min((int) t.cap, SLOT_ROWS);
+  u32 *const la = lds + lane, *const lb = lds + SLOT_WORDS * 64 + lane;
+  const u32 nbatch = (t.nwork + 63) / 64;
 
-      /* predecessor links -> successor links, from (D, del) back to (0, 0) (align.c:5042-5215) */
-      { int e, h, m, c = N, k = del;
-        hf[rm.at(0, 0)] = 3;
-        { const int x = rm.at(D, k);  e = hf[x];  hf[x] = 3; }
-        while (e != 3)
-          { h = k + e;
-            if (e > 1) h -= 3;
-            else if (e == 0) D -= 1;
-            else D -= 2;
-            if (MODE == 1 && h < k)
-              { const u8 *a = A + k;
-                m = k < 0 ? -k : 0;
-                const int x = rm.at(D, h);
-                if (vf[x] <= c) c = vf[x] - 1;
-                while (c >= m && a[c] == BV(c)) c -= 1;
-                if (e == -1)
-                  { if (c <= vf[rm.at(D + 2, k + 1)])      { e = 4; h = k + 1; D = D + 2; }
-                    else if (c == vf[rm.at(D + 1, k)])     { e = 0; h = k;     D = D + 1; }
-                    else vf[x] = (short) (c + 1);
-                  }
-                else
-                  { m = (k == del) ? D : D - 2;
-                    if (c <= vf[rm.at(m, k + 1)])          { e = (k == del) ? 4 : 1; h = k + 1; D = m; }
-                    else if (c == vf[rm.at(D - 1, k)])     { e = 0; h = k; D = D - 1; }
-                    else vf[x] = (short) (c + 1);
-                  }
+  for (u32 batch = blockIdx.x; batch < nbatch; batch += gridDim.x)
+    { const u32 s = batch * 64 + (u32) lane;
+      if (s >= t.nwork) continue;
+      const TraceSeg g = t.segs[s];
+      int n = 0, dist = 0;
+      if (!(g.flags & 4u))
+        { const int M = (int) (g.mn & 0xffffu), N = (int) (g.mn >> 16);
+          const int dmax = (int) (g.flags >> 8);
+          int status = 1;
+          if (M <= SLOT_MAXB && N <= SLOT_MAXB && !(g.flags & 2u))
+            { ByteBases bb;
+              bb.comp = (int) (g.flags & 1u);
+              bb.sgn = bb.comp ? -1 : 1;
+              bb.A = t.abases + g.apos;
+              bb.B = t.bbases + g.bpos;
+              LdsBases sn;
+              sn.la = la;  sn.lb = lb;
+              sn.oa = (int) (g.apos & 15u);
+              { const u32 *src = t.apk + (g.apos >> 4);
+                const int nw = ((sn.oa + M + 15) >> 4) + 1;
+                for (int i = 0; i < nw; i++) la[i * 64] = src[i];
               }
-            else if (MODE == -1 && h > k)
-              { const u8 *a = A + k;
-                m = k < 0 ? -k : 0;
-                const int x = rm.at(D, h);
-                if (vf[x] < c) c = vf[x];
-                while (c >= m && a[c] == BV(c)) c -= 1;
-                if (e == 1)
-                  { if (c < vf[rm.at(D + 2, k - 1)])       { e = 2; h = k - 1; D = D + 2; }
-                    else if (c == vf[rm.at(D + 1, k)])     { e = 0; h = k;     D = D + 1; }
-                    else { vf[x] = (short) c;  c -= 1; }
-                  }
-                else
-                  { m = (k == del) ? D : D - 2;
-                    if (c < vf[rm.at(m, k - 1)])           { e = (k == del) ? 2 : -1; h = k - 1; D = m; }
-                    else if (c == vf[rm.at(D - 1, k)])     { e = 0; h = k; D = D - 1; }
-                    else { vf[x] = (short) c;  c -= 1; }
-                  }
-              }
-            { const int x = rm.at(D, h);
-              m = hf[x];
-              hf[x] = (signed char) e;
-              e = m;
+              if (!bb.comp)
+                { sn.ob = (int) (g.bpos & 15u);
+                  const u32 *src = t.bpk + (g.bpos >> 4);
+                  const int nw = ((sn.ob + N + 15) >> 4) + 1;
+                  for (int i = 0; i < nw; i++) lb[i * 64] = src[i];
+                }
+              else
+                { /* B'[j] = 3 - B[bpos - j]: word i of the copy = the 16 bases ending at bpos - 16 i,
+                     order reversed (bit reversal, then the two bits of each base swapped back), complemented */
+                  sn.ob = 0;
+                  const int nw = ((N + 15) >> 4) + 1;
+                  for (int i = 0; i < nw; i++)
+                    { u32 x = pk_window(t.bpk, g.bpos - 16u * (u32) i - 15u + 16u * PK_PAD);
+                      x = __builtin_bitreverse32(x);
+                      x = ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+                      lb[i * 64] = ~x;
+                    }
+                }
+              w.shape(M - N);
+              status = expand_segment<MODE>(w, sn, bb, g, M, N, dmax, t.stage + g.stage, n, dist);
             }
-            k = h;
-          }
-
-        /* forward again: one script value per indel (align.c:5217-5256) */
-        int *out = t.stage + g.stage;
-        int n = 0;
-        k = D = 0;
-        e = hf[rm.at(0, 0)];
-        while (e != 3)
-          { h = k - e;
-            c = vf[rm.at(D, k)];
-            if (e > 1) h += 3;
-            else if (e == 0) D += 1;
-            else D += 2;
-            if (h > k)      out[n++] = g.b0 + c + 1;
-            else if (h < k) out[n++] = -(g.a0 + c + k + 1);
-            k = h;
-            e = hf[rm.at(D, h)];
-          }
-        t.count[s] = (u32) n;
-        t.dist[s]  = D + (del < 0 ? -del : del);
-      }
-#undef BV
+          if (status == 1)
+            { const u32 o = atomicAdd(t.nover, 1u);       /* deferred to the launch with per-lane stripes */
+              if (o < t.over_cap) t.over[o] = s;
+              Stripe st;
+              st.shape(M - N);
+              atomicMax(t.need, st.rows_needed(dmax));
+            }
+          else if (status == 2)
+            atomicOr(t.err, DAMAR_TRACE_ERR_ALIGN);
+          if (status) { n = 0;  dist = 0; }
+        }
+      t.count[s] = (u32) n;
+      t.dist[s]  = dist;
     }
 }
 
@@ -317,6 +511,16 @@ void damar_launch_trace_waves(const TraceArgs *t, int mode, u32 nblocks, hipStre
   if (mode == 0)      hipLaunchKernelGGL(trace_waves<0>,  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
   else if (mode > 0)  hipLaunchKernelGGL(trace_waves<1>,  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
   else                hipLaunchKernelGGL(trace_waves<-1>, dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
+}
+
+size_t damar_trace_slot_area_cells(void) { return (size_t) SLOT_ROWS * SLOT_RS * 64; }
+
+/* t->vf / t->hf: nblocks areas of damar_trace_slot_area_cells() cells; t->list must be NULL */
+void damar_launch_trace_waves_slots(const TraceArgs *t, int mode, u32 nblocks, hipStream_t st)
+{ if (t->nwork == 0) return;
+  if (mode == 0)      hipLaunchKernelGGL(trace_waves_slots<0>,  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
+  else if (mode > 0)  hipLaunchKernelGGL(trace_waves_slots<1>,  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
+  else                hipLaunchKernelGGL(trace_waves_slots<-1>, dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
 }
 
 void damar_launch_trace_gather(const TraceRecIn *recs, u32 nrecs, const u32 *count, const int *dist, u32 *segoff,

@@ -1786,15 +1786,15 @@ static void trace_record_shape(const Path *path, const PT *p, int tspace, int *d
 
 static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int bfirst, const Overlap *ovls, int64 r0, int64 r1,
                        int tbytes, int tspace, int mode, int same, const std::vector<TraceRecIn> &recs, const std::vector<u8> &pts,
-                       u32 nsegs, u64 nslots, int64 *soff, int *diffs, std::vector<int> &script)
+                       u32 nsegs, u64 nslots, int64 *soff, int *diffs, int **script, int64 *nscript)
 { const u32 nrecs = (u32) (r1 - r0);
-  static u32 cap = 0, maxblocks = 0;
-  if (cap == 0)
-    { const char *e = getenv("DAMAR_TRACE_CAP");
-      cap = e ? (u32) atoi(e) : 2048u;
-      if (cap < 64) cap = 64;
+  static u32 rows = 0, maxblocks = 0;
+  if (rows == 0)
+    { const char *e = getenv("DAMAR_TRACE_ROWS");        /* test hook: fewer rows -> more segments deferred */
+      rows = e ? (u32) atoi(e) : 64u;
+      if (rows < 4) rows = 4;
       e = getenv("DAMAR_TRACE_BLOCKS");
-      maxblocks = e ? (u32) atoi(e) : (u32) (G_prop.multiProcessorCount * 32);
+      maxblocks = e ? (u32) atoi(e) : (u32) (G_prop.multiProcessorCount * 16);
       if (maxblocks < 1) maxblocks = 1;
     }
   const double h0 = now_ms();
@@ -1811,9 +1811,9 @@ static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int b
   int *d_diffs  = (int *) T_diffs.need(sizeof(int) * (size_t) nrecs);
   void *d_scan  = T_scan.need(damar_scan_workspace_bytes(nrecs));
   const u32 nblocks = std::min(maxblocks, (nsegs + 63) / 64);
-  const size_t nthreads = (size_t) nblocks * 64;
-  short       *d_vf = (short *) T_vf.need(sizeof(short) * nthreads * cap);
-  signed char *d_hf = (signed char *) T_hf.need(nthreads * cap);
+  const size_t area = damar_trace_slot_area_cells();
+  short       *d_vf = (short *) T_vf.need(sizeof(short) * (size_t) nblocks * area);
+  signed char *d_hf = (signed char *) T_hf.need((size_t) nblocks * area);
 
   hipEvent_t e0, e1, e2, e3;
   HIP_CHECK(hipEventCreate(&e0));  HIP_CHECK(hipEventCreate(&e1));
@@ -1828,11 +1828,12 @@ static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int b
   memset(&t, 0, sizeof(t));
   t.segs = d_segs;  t.list = NULL;  t.nwork = nsegs;
   t.abases = ad->bases;  t.bbases = bd->bases;
-  t.vf = d_vf;  t.hf = d_hf;  t.cap = cap;
+  t.apk = ad->pk;  t.bpk = bd->pk;
+  t.vf = d_vf;  t.hf = d_hf;  t.cap = rows;
   t.stage = d_stage;  t.count = d_count;  t.dist = d_dist;
   t.over = d_over;  t.over_cap = nsegs;  t.nover = d_ctr;  t.need = d_ctr + 1;  t.err = d_ctr + 2;
   HIP_CHECK(hipEventRecord(e1, G_st));
-  damar_launch_trace_waves(&t, mode, nblocks, G_st);
+  damar_launch_trace_waves_slots(&t, mode, nblocks, G_st);
   HIP_CHECK(hipEventRecord(e2, G_st));
   u32 ctr[4];
   HIP_CHECK(hipMemcpyAsync(ctr, d_ctr, sizeof(ctr), hipMemcpyDeviceToHost, G_st));
@@ -1841,7 +1842,7 @@ static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int b
   HIP_CHECK(hipEventElapsedTime(&wms, e1, e2));
   T_ms[0] += wms;
   if (ctr[0] > 0 && !(ctr[2] & DAMAR_TRACE_ERR_POINTS))
-    { /* segments whose waves outgrew the stripe: again, with stripes that hold dmax + 3 rows */
+    { /* segments the slot kernel does not take: one lane each on stripes that hold dmax + 3 rows */
       const u32 need = ctr[1];
       size_t bthreads = ((size_t) ctr[0] + 63) / 64 * 64;
       const size_t budget = (size_t) 8 << 30;
@@ -1893,12 +1894,19 @@ static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int b
   damar_launch_trace_pack(d_segs, nsegs, d_count, d_segoff, d_tlen, d_stage, d_script, G_st);
   HIP_CHECK(hipEventRecord(e3, G_st));
   std::vector<u32> hoff(nrecs);
-  const size_t base = script.size();
-  script.resize(base + (size_t) total);
+  const size_t base = (size_t) *nscript;
+  { int *grown = (int *) realloc(*script, sizeof(int) * (base + (size_t) total + 1));
+    if (grown == NULL)
+      { fprintf(stderr, "damar: out of memory (edit scripts)\n");
+        return 1;
+      }
+    *script = grown;
+    *nscript = (int64) (base + (size_t) total);
+  }
   HIP_CHECK(hipMemcpyAsync(hoff.data(), d_tlen, sizeof(u32) * (size_t) nrecs, hipMemcpyDeviceToHost, G_st));
   HIP_CHECK(hipMemcpyAsync(diffs + r0, d_diffs, sizeof(int) * (size_t) nrecs, hipMemcpyDeviceToHost, G_st));
   if (total > 0)
-    HIP_CHECK(hipMemcpyAsync(script.data() + base, d_script, sizeof(int) * (size_t) total, hipMemcpyDeviceToHost, G_st));
+    HIP_CHECK(hipMemcpyAsync(*script + base, d_script, sizeof(int) * (size_t) total, hipMemcpyDeviceToHost, G_st));
   HIP_CHECK(hipStreamSynchronize(G_st));
   float dms = 0;
   HIP_CHECK(hipEventElapsedTime(&dms, e0, e3));
@@ -1924,7 +1932,9 @@ extern "C" int damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_bloc
 { ensure_init();
   const double t0 = now_ms();
   for (int i = 0; i < 4; i++) { T_ms[i] = 0;  T_cnt[i] = 0; }
-  std::vector<int> script;
+  int  *script = NULL;
+  int64 nscript = 0;
+  *script_out = NULL;
   std::vector<TraceRecIn> recs;
   std::vector<u8> pts;
   const u32 max_segs = 1u << 24;
@@ -1941,6 +1951,7 @@ extern "C" int damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_bloc
           const int64 ar = (int64) o->aread - afirst, br = (int64) o->bread - bfirst;
           if (ar < 0 || ar >= ablk->nreads || br < 0 || br >= bblk->nreads || o->path.tlen < 0 || (o->path.tlen & 1))
             { fprintf(stderr, "damar: trace expansion: record %lld does not belong to the two blocks\n", (long long) i);
+              free(script);
               return 1;
             }
           if (tbytes == 1) trace_record_shape(&o->path, (const uint8 *) o->path.trace, tspace, &dmax, &nseg, &slots);
@@ -1949,14 +1960,17 @@ extern "C" int damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_bloc
       if (i == novl || nsegs + (u32) nseg > max_segs || nslots + (u64) slots > max_slots)
         { if (i > r0)
             { if (trace_batch(&ablk->d, afirst, &bblk->d, bfirst, ovls, r0, i, tbytes, tspace, mode, same, recs, pts,
-                              nsegs, nslots, soff, diffs, script))
-                return 1;
+                              nsegs, nslots, soff, diffs, &script, &nscript))
+                { free(script);
+                  return 1;
+                }
             }
           recs.clear();  pts.clear();
           r0 = i;  nsegs = 0;  nslots = 0;
           if (i == novl) break;
           if ((u64) slots > max_slots || (u32) nseg > max_segs)
             { fprintf(stderr, "damar: trace expansion: record %lld is larger than a batch\n", (long long) i);
+              free(script);
               return 1;
             }
         }
@@ -1976,13 +1990,9 @@ extern "C" int damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_bloc
       nsegs += (u32) nseg;
       nslots += (u64) slots;
     }
-  int *out = (int *) malloc(sizeof(int) * (script.size() + 1));
-  if (out == NULL)
-    { fprintf(stderr, "damar: out of memory (edit scripts)\n");
-      return 1;
-    }
-  memcpy(out, script.data(), sizeof(int) * script.size());
-  *script_out = out;
+  if (script == NULL)
+    script = (int *) malloc(sizeof(int));
+  *script_out = script;
   T_ms[2] = now_ms() - t0;
   return 0;
 }

@@ -50,7 +50,7 @@ def test_trace_expansion_small_stripes_take_the_deferred_launch(built, tmp_path)
         c = read_case(name)
         for las in c["las"]:
             for mode in (0, 1, -1):
-                got = run_tool(c, las, mode, str(tmp_path / "g.bin"), {"DAMAR_TRACE_CAP": "96", "DAMAR_TRACE_BLOCKS": "7"})
+                got = run_tool(c, las, mode, str(tmp_path / "g.bin"), {"DAMAR_TRACE_ROWS": "9", "DAMAR_TRACE_BLOCKS": "7"})
                 assert got == want[(name, las, mode)], (name, las, mode)
 
 
