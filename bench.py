@@ -71,6 +71,48 @@ def cpu_baseline(dbdir, root, sample_block, budget_s=120):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def trace_expand_leg(dbdir, root, out_dir, with_cpu):
+    """Not part of `value`: the next consumer of the records (Compute_Trace_PTS) on the block-1
+    self-comparison .las the timed step has just written -- trace points -> edit scripts with
+    damar_trace_pts (bin/lastrace -v reports the HIP-event times), next to the reference's own
+    Compute_Trace_PTS on one host thread (oracle/_ref/ref_lastrace, or the oracle's port) on the same file,
+    outputs compared byte for byte."""
+    import re
+    name = "%s.1" % root
+    las = os.path.join(out_dir, "d001_00001", "%s.%s.las" % (name, name))
+    blk = os.path.join(dbdir, name)
+    gout = os.path.join(dbdir, "trace_gpu.bin")
+    tool = os.path.join(ROOT, "damar_amd", "bin", "lastrace")
+    best = None
+    for _ in range(2):                                   # first call pays the buffer allocations
+        txt = subprocess.run([tool, "-v", blk, blk, las, gout], check=True, stdout=subprocess.PIPE, text=True).stdout
+        m = re.search(r"(\d+) records, (\d+) segments \((\d+) deferred\), (\d+) script values; waves ([\d.]+) ms, "
+                      r"device ([\d.]+) ms, call ([\d.]+) ms", txt)
+        cur = dict(records=int(m.group(1)), segments=int(m.group(2)), deferred=int(m.group(3)),
+                   script_values=int(m.group(4)), kernel_ms=float(m.group(5)), device_ms=float(m.group(6)),
+                   call_ms=float(m.group(7)))
+        if best is None or cur["kernel_ms"] < best["kernel_ms"]:
+            best = cur
+    best["workload"] = "block 1 self-comparison of the step, mode GREEDIEST"
+    best["segments_per_s"] = best["segments"] / (best["device_ms"] * 1e-3)
+    best["note"] = ("kernel_ms = trace_waves_slots, device_ms = all kernels of the call (HIP events), call_ms adds the "
+                    "PCIe copies of points and scripts; not included in `value`")
+    if with_cpu:
+        ref = os.path.join(ROOT, "oracle", "_ref", "ref_lastrace")
+        kind, exe = ("reference", ref) if os.path.exists(ref) else ("port", os.path.join(ROOT, "oracle", "oracle_lastrace"))
+        cout = os.path.join(dbdir, "trace_cpu.bin")
+        t0 = time.time()
+        subprocess.run([exe, os.path.join(dbdir, root), las, cout, "0"], check=True)
+        dt = time.time() - t0
+        same = subprocess.run(["cmp", "-s", gout, cout]).returncode == 0
+        best["cpu"] = {"value": best["segments"] / dt, "unit": "segments/s", "cores": 1, "kind": kind,
+                       "sample": "the same file, %.1f s wall including opening the DB" % dt}
+        best["identical_to_cpu"] = same
+        os.unlink(cout)
+    os.unlink(gout)
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +124,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--threads-param", type=int, default=4, help="daligner -j (slice rule only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-trace", action="store_true", help="skip the trace-expansion leg (SURVEY 8(f)4)")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
@@ -229,6 +272,12 @@ def main():
                 except Exception as e:           # the baseline is reported, never required
                     cpu = {"value": None, "unit": "aligned bp/s", "cores": 0, "kind": "reference",
                            "sample": "failed: %s" % e}
+            trace = None
+            if world == 1 and not args.no_trace:
+                try:
+                    trace = trace_expand_leg(work, "SIM", last_out, not args.no_cpu)
+                except Exception as e:
+                    trace = {"error": str(e)}
             value = bp_all * args.steps / elapsed
             line = {"metric": "aligned base-pairs/sec (daligner block-vs-block)",
                     "value": value, "unit": "aligned bp/s", "n_gpus": world, "steps": args.steps,
@@ -244,7 +293,7 @@ def main():
                                "seed_pairs_per_step": H, "local_alignments_per_step": cnts[1] / steps,
                                "parallelism": "%d independent GPU(s), one DB each, no data-path collective" % world,
                                "db_generation_s": t_gen},
-                    "roofline": roof, "cpu_baseline": cpu}
+                    "roofline": roof, "cpu_baseline": cpu, "trace_expand": trace}
             print(json.dumps(line))
             sys.stdout.flush()
     finally:
