@@ -121,3 +121,30 @@ def test_compute_trace_pts_c_abi_single_record(built):
                     res.append((script[:n].tolist(), d.value))
             assert res[0] == res[1], (trial, mode)
     lib.Free_Work_Data(work)
+
+
+@pytest.mark.parametrize("spacing", [40, 300, 1000])
+def test_trace_expansion_other_spacings_against_oracle(built, tmp_path, spacing):
+    """Trace spacings the golden files do not have: -s40 (short segments), -s300 and -s1000 (16-bit trace
+    points; segments longer than the 240 bases the slot kernel stages, so every one takes the per-lane
+    stripe kernel).  Records by the GPU daligner, edit scripts GPU vs oracle (which is pinned to the
+    reference), all three modes."""
+    from conftest import link_db
+    d = str(tmp_path / "w")
+    link_db(os.path.join(GOLDEN, "tiny2"), d)
+    subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "daligner"), "-k14", "-j4", "-s%d" % spacing, "G.1", "G.2", "G.1"],
+                   cwd=d, check=True, stdout=subprocess.DEVNULL)
+    n = 0
+    for dp, _, fs in os.walk(d):
+        for f in fs:
+            if not f.endswith(".las"):
+                continue
+            las = os.path.join(dp, f)
+            for mode in (0, 1, -1):
+                g, o = str(tmp_path / "g.bin"), str(tmp_path / "o.bin")
+                subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "lastrace"), "-m%d" % mode, os.path.join(d, "G"),
+                                os.path.join(d, "G"), las, g], check=True)
+                subprocess.run([os.path.join(ROOT, "oracle", "oracle_lastrace"), os.path.join(d, "G"), las, o, str(mode)], check=True)
+                assert open(g, "rb").read() == open(o, "rb").read(), (f, mode)
+                n += 1
+    assert n >= 6
