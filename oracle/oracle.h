@@ -97,6 +97,9 @@ void oracle_match_self(const HITS_DB *block, const OParams *prm, Align_Spec *spe
  * -1 where the reference exits ("Bad alignment between trace points"). */
 int oracle_compute_trace_pts(const char *aseq, int alen, const char *bseq, int blen, const Path *path,
                              int tspace, int mode, int *script, int *diffs);
+/* align.c:5694-5830 Compute_Trace_MID + :5263-5573 middle_np: the same between the segments' mid points */
+int oracle_compute_trace_mid(const char *aseq, int alen, const char *bseq, int blen, const Path *path,
+                             int tspace, int mode, int *script, int *diffs);
 
 /* Redundancy handling shared with the product's host tail (filter.c:1804-2077);
  * implemented in damar_amd/csrc/host/redundancy.c. */

@@ -1,7 +1,7 @@
 /* oracle_lastrace.c -- TEST INFRASTRUCTURE.  Same command line and dump format as ref_lastrace.c, with the
  * oracle's restatement (trace.c) in place of the reference's Compute_Trace_PTS:
  *
- *     oracle_lastrace <db root> <file.las> <out.bin> [mode]
+ *     oracle_lastrace <db root> <file.las> <out.bin> [mode [mid]]        (mid: Compute_Trace_MID)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -14,7 +14,7 @@ int main(int argc, char *argv[])
 { HITS_DB db;
   FILE   *in, *out;
   int64   novl, i;
-  int     tspace, tbytes, mode = 0, j;
+  int     tspace, tbytes, mode = 0, mid = 0, j;
   Overlap ovl;
   uint16 *pts = NULL;
   int    *script = NULL;
@@ -26,6 +26,7 @@ int main(int argc, char *argv[])
       return 1;
     }
   if (argc > 4) mode = atoi(argv[4]);
+  if (argc > 5) mid = (strcmp(argv[5], "mid") == 0);
   if (damar_read_block(argv[1], &db)) return 1;
   if ((in = fopen(argv[2], "rb")) == NULL || (out = fopen(argv[3], "wb")) == NULL)
     { fprintf(stderr, "oracle_lastrace: cannot open files\n");
@@ -78,7 +79,8 @@ int main(int argc, char *argv[])
         { smax = 2 * need;
           script = (int *) realloc(script, sizeof(int) * (size_t) smax);
         }
-      ns = oracle_compute_trace_pts(aseq, alen, bseq, blen, &ovl.path, tspace, mode, script, &diffs);
+      ns = mid ? oracle_compute_trace_mid(aseq, alen, bseq, blen, &ovl.path, tspace, mode, script, &diffs)
+               : oracle_compute_trace_pts(aseq, alen, bseq, blen, &ovl.path, tspace, mode, script, &diffs);
       if (ns < 0)
         { fprintf(stderr, "oracle_lastrace: bad alignment between trace points, record %lld\n", (long long) i);
           return 1;

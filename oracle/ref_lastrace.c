@@ -10,7 +10,7 @@
  * The oracle's restatement (oracle/trace.c, oracle_lastrace) writes the same format; tests compare the two
  * byte for byte, and the md5 of these dumps for the golden cases is committed under tests/golden/.
  *
- *     ref_lastrace <db root> <file.las> <out.bin> [mode: -1 LOWERMOST | 0 GREEDIEST | 1 UPPERMOST]
+ *     ref_lastrace <db root> <file.las> <out.bin> [mode: -1 LOWERMOST | 0 GREEDIEST | 1 UPPERMOST [mid]]
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,7 +24,7 @@ int main(int argc, char *argv[])
 { HITS_DB db;
   FILE   *in, *out;
   int64   novl, i;
-  int     tspace, tbytes, mode = 0, tmax = 0;
+  int     tspace, tbytes, mode = 0, mid = 0, tmax = 0;
   Overlap ovl;
   Alignment aln;
   Work_Data *work;
@@ -36,6 +36,7 @@ int main(int argc, char *argv[])
       return 1;
     }
   if (argc > 4) mode = atoi(argv[4]);
+  if (argc > 5) mid = (strcmp(argv[5], "mid") == 0);          /* Compute_Trace_MID, as corrector/LAcorrect.c:545 */
   if (Open_DB(argv[1], &db) < 0) return 1;
   if ((in = fopen(argv[2], "rb")) == NULL || (out = fopen(argv[3], "wb")) == NULL)
     { fprintf(stderr, "ref_lastrace: cannot open files\n");
@@ -73,7 +74,7 @@ int main(int argc, char *argv[])
       aln.path = &ovl.path;
       if (ovl.flags & COMP_FLAG) Complement_Seq(bbuf, aln.blen);
       { void *keep = ovl.path.trace;                 /* the call redirects path.trace into the work data */
-        if (Compute_Trace_PTS(&aln, work, tspace, mode)) return 1;
+        if (mid ? Compute_Trace_MID(&aln, work, tspace, mode) : Compute_Trace_PTS(&aln, work, tspace, mode)) return 1;
         rec[0] = ovl.aread;  rec[1] = ovl.bread;  rec[2] = ovl.flags;
         rec[3] = ovl.path.diffs;  rec[4] = ovl.path.tlen;
         fwrite(rec, sizeof(int32_t), 5, out);

@@ -281,19 +281,21 @@ def trace_md5():
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import conftest
-    lines = []
     with tempfile.TemporaryDirectory() as d:
-        for name in conftest.golden_cases():
-            c = conftest.read_case(name)
-            for las in c["las"]:
-                for mode in (0, -1, 1):
-                    out = os.path.join(d, "t.bin")
-                    run([os.path.join(REF, "ref_lastrace"), os.path.join(c["dbdir"], "G"),
-                         os.path.join(c["lasdir"], las), out, str(mode)], d)
-                    lines.append("%s %s %s %d" % (hashlib.md5(open(out, "rb").read()).hexdigest(), name, las, mode))
-    with open(os.path.join(HERE, "trace_ref_md5.txt"), "w") as f:
-        f.write("\n".join(lines) + "\n")
-    print("%d dumps" % len(lines))
+        # the same for Compute_Trace_MID (align.c:5694, as corrector/LAcorrect.c:545 calls it) -> trace_mid_ref_md5.txt
+        for fixture, extra in (("trace_ref_md5.txt", []), ("trace_mid_ref_md5.txt", ["mid"])):
+            lines = []
+            for name in conftest.golden_cases():
+                c = conftest.read_case(name)
+                for las in c["las"]:
+                    for mode in (0, -1, 1):
+                        out = os.path.join(d, "t.bin")
+                        run([os.path.join(REF, "ref_lastrace"), os.path.join(c["dbdir"], "G"),
+                             os.path.join(c["lasdir"], las), out, str(mode)] + extra, d)
+                        lines.append("%s %s %s %d" % (hashlib.md5(open(out, "rb").read()).hexdigest(), name, las, mode))
+            with open(os.path.join(HERE, fixture), "w") as f:
+                f.write("\n".join(lines) + "\n")
+            print("%s: %d dumps" % (fixture, len(lines)))
 
 
 def main():

@@ -12,25 +12,34 @@ import pytest
 from conftest import GOLDEN, ROOT, read_case
 
 
-def ref_lines():
+def ref_lines(fixture="trace_ref_md5.txt"):
     out = []
-    for ln in open(os.path.join(GOLDEN, "trace_ref_md5.txt")):
+    for ln in open(os.path.join(GOLDEN, fixture)):
         md5, name, las, mode = ln.split()
         out.append((md5, name, las, int(mode)))
     return out
 
 
-def test_oracle_trace_equals_reference_on_golden(built, tmp_path):
+@pytest.mark.parametrize("fixture,extra", [("trace_ref_md5.txt", []), ("trace_mid_ref_md5.txt", ["mid"])])
+def test_oracle_trace_equals_reference_on_golden(built, tmp_path, fixture, extra):
+    """Compute_Trace_PTS (align.c:5577) and Compute_Trace_MID (align.c:5694), every golden record, three modes."""
+    from concurrent.futures import ThreadPoolExecutor
     tool = os.path.join(ROOT, "oracle", "oracle_lastrace")
-    n = 0
-    for md5, name, las, mode in ref_lines():
+
+    def one(job):
+        i, (md5, name, las, mode) = job
         c = read_case(name)
-        out = str(tmp_path / "o.bin")
-        subprocess.run([tool, os.path.join(c["dbdir"], "G"), os.path.join(c["lasdir"], las), out, str(mode)], check=True)
+        out = str(tmp_path / ("o%d.bin" % i))
+        subprocess.run([tool, os.path.join(c["dbdir"], "G"), os.path.join(c["lasdir"], las), out, str(mode)] + extra, check=True)
         got = hashlib.md5(open(out, "rb").read()).hexdigest()
-        assert got == md5, (name, las, mode)
-        n += 1
-    assert n >= 100
+        os.unlink(out)
+        return got == md5, (name, las, mode, extra)
+
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+        res = list(pool.map(one, enumerate(ref_lines(fixture))))
+    bad = [what for ok, what in res if not ok]
+    assert not bad, bad
+    assert len(res) >= 100
 
 
 def test_oracle_trace_equals_reference_live(built, tmp_path):
@@ -44,6 +53,7 @@ def test_oracle_trace_equals_reference_live(built, tmp_path):
         for mode in (0, 1, -1):
             a, b = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
             args = [os.path.join(c["dbdir"], "G"), os.path.join(c["lasdir"], las)]
-            subprocess.run([ref] + args + [a, str(mode)], check=True)
-            subprocess.run([os.path.join(ROOT, "oracle", "oracle_lastrace")] + args + [b, str(mode)], check=True)
-            assert open(a, "rb").read() == open(b, "rb").read()
+            for extra in ([], ["mid"]):
+                subprocess.run([ref] + args + [a, str(mode)] + extra, check=True)
+                subprocess.run([os.path.join(ROOT, "oracle", "oracle_lastrace")] + args + [b, str(mode)] + extra, check=True)
+                assert open(a, "rb").read() == open(b, "rb").read()
