@@ -144,6 +144,7 @@ typedef struct
   u32 seg0;               /* index of the record's first segment */
   u32 stage0;             /* first staging slot of the record (segment s gets dmax + |M_s - N_s| slots) */
   int dmax;               /* largest trace-point difference count of the record (align.c:5614-5621) */
+  u32 slots;              /* staging slots set aside for the record */
 } TraceRecIn;
 
 typedef struct
@@ -162,20 +163,24 @@ typedef struct
   const u32 *apk, *bpk;               /* the same bases at 2 bits (DevBlock.pk)      */
   short *vf;  signed char *hf;  u32 cap; /* per-thread stripes of cap cells             */
   int *stage;  u32 *count;  int *dist;
+  int *mid;                             /* kind 1: A and B offset of each segment's mid point */
   u32 *over;  u32 over_cap;  u32 *nover;  u32 *need;  u32 *err;
 } TraceArgs;
 
 #define DAMAR_TRACE_ERR_POINTS 1u       /* trace point out of bounds (align.c:5575)   */
 #define DAMAR_TRACE_ERR_ALIGN  2u       /* bad alignment between trace points (:4890) */
+#define DAMAR_TRACE_ERR_INTERNAL 4u      /* staging bound of the mid-point pieces violated */
 
 /* pts: the records' trace points as stored in the .las (tbytes 1 or 2) */
 void damar_launch_trace_layout(const TraceRecIn *recs, u32 nrecs, const void *pts, int tbytes, int tspace,
                                const DevBlock *ablk, const DevBlock *bblk, TraceSeg *segs, u32 *err, hipStream_t st);
-void damar_launch_trace_waves(const TraceArgs *t, int mode, u32 nblocks, hipStream_t st);
+void damar_launch_trace_waves(const TraceArgs *t, int mode, int kind, u32 nblocks, hipStream_t st);
 size_t damar_trace_slot_area_cells(void);
-void damar_launch_trace_waves_slots(const TraceArgs *t, int mode, u32 nblocks, hipStream_t st);
-void damar_launch_trace_gather(const TraceRecIn *recs, u32 nrecs, const u32 *count, const int *dist, u32 *segoff,
+void damar_launch_trace_waves_slots(const TraceArgs *t, int mode, int kind, u32 nblocks, hipStream_t st);
+void damar_launch_trace_gather(const TraceRecIn *recs, u32 nrecs, int mid, const u32 *count, const int *dist, u32 *segoff,
                                u32 *tlen, int *diffs, hipStream_t st);
+void damar_launch_trace_mid_layout(const TraceRecIn *recs, u32 nrecs, const TraceSeg *segs, const int *mid,
+                                   const DevBlock *ablk, const DevBlock *bblk, TraceSeg *out, u32 *err, hipStream_t st);
 void damar_launch_trace_pack(const TraceSeg *segs, u32 nsegs, const u32 *count, const u32 *segoff, const u32 *recoff,
                              const int *stage, int *script, hipStream_t st);
 #endif

@@ -224,9 +224,57 @@ __device__ __forceinline__ u32 pk_window(const u32 *pk, u32 pb)       /* 16 base
   return __builtin_amdgcn_alignbit(q[1], q[0], pb * 2);
 }
 
-/***** one segment: waves, reversal, script (align.c:4892-5261) ***************************************
- * returns 0 = done, 1 = the waves do not fit the cell storage, 2 = D > dmax (align.c:4966)           */
-template <int MODE, class Cells, class Snake>
+/* One edge back from cell (D, k) with predecessor code e: the cell it came from, after the re-routing of
+   UPPERMOST (align.c:5056-5120) / LOWERMOST (:5122-5186); the same text serves iter_np and middle_np.
+   c is the reference's running B index.  Returns the predecessor's diagonal; D, e, c are updated. */
+template <int MODE, class Cells>
+__device__ __forceinline__ int back_edge(Cells &w, const ByteBases &bb, int del, int &D, int k, int &e, int &c)
+{ int h = k + e, m;
+  if (e > 1) h -= 3;
+  else if (e == 0) D -= 1;
+  else D -= 2;
+  if (MODE == 1 && h < k)
+    { m = k < 0 ? -k : 0;
+      const int x = w.v(D, h);
+      if (x <= c) c = x - 1;
+      while (c >= m && bb.a(k + c) == bb.b(c)) c -= 1;
+      if (e == -1)
+        { if (c <= w.v(D + 2, k + 1))          { e = 4; h = k + 1; D = D + 2; }
+          else if (c == w.v(D + 1, k))         { e = 0; h = k;     D = D + 1; }
+          else w.setv(D, h, c + 1);
+        }
+      else
+        { m = (k == del) ? D : D - 2;
+          if (c <= w.v(m, k + 1))              { e = (k == del) ? 4 : 1; h = k + 1; D = m; }
+          else if (c == w.v(D - 1, k))         { e = 0; h = k; D = D - 1; }
+          else w.setv(D, h, c + 1);
+        }
+    }
+  else if (MODE == -1 && h > k)
+    { m = k < 0 ? -k : 0;
+      const int x = w.v(D, h);
+      if (x < c) c = x;
+      while (c >= m && bb.a(k + c) == bb.b(c)) c -= 1;
+      if (e == 1)
+        { if (c < w.v(D + 2, k - 1))           { e = 2; h = k - 1; D = D + 2; }
+          else if (c == w.v(D + 1, k))         { e = 0; h = k;     D = D + 1; }
+          else { w.setv(D, h, c);  c -= 1; }
+        }
+      else
+        { m = (k == del) ? D : D - 2;
+          if (c < w.v(m, k - 1))               { e = (k == del) ? 2 : -1; h = k - 1; D = m; }
+          else if (c == w.v(D - 1, k))         { e = 0; h = k; D = D - 1; }
+          else { w.setv(D, h, c);  c -= 1; }
+        }
+    }
+  return h;
+}
+
+/***** one segment: waves, then the script (iter_np, align.c:4892-5261) or the mid point (middle_np,
+ * :5263-5573).  Returns 0 = done, 1 = the waves do not fit the cell storage, 2 = D > dmax (align.c:4966).
+ * KIND 0: out receives the nout script values, dist = D + |del|.  KIND 1: out[0], out[1] = the A and B
+ * offsets of the mid point.                                                                          */
+template <int MODE, int KIND, class Cells, class Snake>
 __device__ __forceinline__ int expand_segment(Cells &w, const Snake &sn, const ByteBases &bb, const TraceSeg &g,
                                               int M, int N, int dmax, int *out, int &nout, int &dist)
 { const int del = M - N;
@@ -275,50 +323,28 @@ __device__ __forceinline__ int expand_segment(Cells &w, const Snake &sn, const B
       if (j >= N) break;
     }
 
-  /* predecessor links -> successor links, from (D, del) back to (0, 0) (align.c:5042-5215) */
   int e, h, m, c = N, k = del;
+  if (KIND == 1)
+    { /* ceil((D + |del|) / 2) edges back from the end: the furthest point of that cell is the mid point */
+      int d = D + (del < 0 ? -del : del);
+      for (const int f = d / 2; d > f; d--)
+        { e = w.h(D, k);
+          k = back_edge<MODE>(w, bb, del, D, k, e, c);
+        }
+      const int x = w.v(D, k);
+      out[0] = g.a0 + k + x;
+      out[1] = g.b0 + x;
+      nout = 0;
+      dist = 0;
+      return 0;
+    }
+
+  /* predecessor links -> successor links, from (D, del) back to (0, 0) (align.c:5042-5215) */
   w.seth(0, 0, 3);
   e = w.h(D, k);
   w.seth(D, k, 3);
   while (e != 3)
-    { h = k + e;
-      if (e > 1) h -= 3;
-      else if (e == 0) D -= 1;
-      else D -= 2;
-      if (MODE == 1 && h < k)
-        { m = k < 0 ? -k : 0;
-          const int x = w.v(D, h);
-          if (x <= c) c = x - 1;
-          while (c >= m && bb.a(k + c) == bb.b(c)) c -= 1;
-          if (e == -1)
-            { if (c <= w.v(D + 2, k + 1))          { e = 4; h = k + 1; D = D + 2; }
-              else if (c == w.v(D + 1, k))         { e = 0; h = k;     D = D + 1; }
-              else w.setv(D, h, c + 1);
-            }
-          else
-            { m = (k == del) ? D : D - 2;
-              if (c <= w.v(m, k + 1))              { e = (k == del) ? 4 : 1; h = k + 1; D = m; }
-              else if (c == w.v(D - 1, k))         { e = 0; h = k; D = D - 1; }
-              else w.setv(D, h, c + 1);
-            }
-        }
-      else if (MODE == -1 && h > k)
-        { m = k < 0 ? -k : 0;
-          const int x = w.v(D, h);
-          if (x < c) c = x;
-          while (c >= m && bb.a(k + c) == bb.b(c)) c -= 1;
-          if (e == 1)
-            { if (c < w.v(D + 2, k - 1))           { e = 2; h = k - 1; D = D + 2; }
-              else if (c == w.v(D + 1, k))         { e = 0; h = k;     D = D + 1; }
-              else { w.setv(D, h, c);  c -= 1; }
-            }
-          else
-            { m = (k == del) ? D : D - 2;
-              if (c < w.v(m, k - 1))               { e = (k == del) ? 2 : -1; h = k - 1; D = m; }
-              else if (c == w.v(D - 1, k))         { e = 0; h = k; D = D - 1; }
-              else { w.setv(D, h, c);  c -= 1; }
-            }
-        }
+    { h = back_edge<MODE>(w, bb, del, D, k, e, c);
       m = w.h(D, h);
       w.seth(D, h, e);
       e = m;
@@ -349,7 +375,7 @@ __device__ __forceinline__ int expand_segment(Cells &w, const Snake &sn, const B
 }
 
 /* any segment, one lane each, cells in per-lane stripes: the launch for what trace_waves_slots defers */
-template <int MODE>
+template <int MODE, int KIND>
 __global__ __launch_bounds__(TP_THREADS)
 void trace_waves(TraceArgs t)
 { const u32 tid = blockIdx.x * TP_THREADS + threadIdx.x;
@@ -372,7 +398,8 @@ void trace_waves(TraceArgs t)
           bb.A = t.abases + g.apos;
           bb.B = t.bbases + g.bpos;
           w.shape(M - N);
-          const int status = expand_segment<MODE>(w, bb, bb, g, M, N, dmax, t.stage + g.stage, n, dist);
+          const int status = expand_segment<MODE, KIND>(w, bb, bb, g, M, N, dmax,
+                                                        KIND ? t.mid + 2 * (size_t) s : t.stage + g.stage, n, dist);
           if (status == 1)
             { const u32 o = atomicAdd(t.nover, 1u);
               if (o < t.over_cap) t.over[o] = s;
@@ -391,13 +418,13 @@ void trace_waves(TraceArgs t)
    snakes on 2-bit copies of the segments in LDS.  Defers segments with more than SLOT_MAXB bases a side,
    waves wider than SLOT_SS diagonals either side of del or more than SLOT_ROWS - 3 waves, and the
    one-buffer case. */
-template <int MODE>
+template <int MODE, int KIND>
 __global__ __launch_bounds__(TP_THREADS)
 void trace_waves_slots(TraceArgs t)
 { __shared__ u32 lds[2 * SLOT_WORDS * 64];
   const int lane = (int) threadIdx.x;
   const size_t area = (size_t) SLOT_ROWS * SLOT_RS * 64;
-  Slots<MODE == 0> w;
+  Slots<(MODE == 0 && KIND == 0)> w;       /* the mid point is read from an older row: keep them all */
   w.vf = (u8 *) t.vf + (size_t) blockIdx.x * area + lane;
   w.hf = t.hf + (size_t) blockIdx.x * area + lane;
   w.rows = min((int) t.cap, SLOT_ROWS);
@@ -445,7 +472,8 @@ void trace_waves_slots(TraceArgs t)
                     }
                 }
               w.shape(M - N);
-              status = expand_segment<MODE>(w, sn, bb, g, M, N, dmax, t.stage + g.stage, n, dist);
+              status = expand_segment<MODE, KIND>(w, sn, bb, g, M, N, dmax,
+                                                  KIND ? t.mid + 2 * (size_t) s : t.stage + g.stage, n, dist);
             }
           if (status == 1)
             { const u32 o = atomicAdd(t.nover, 1u);       /* deferred to the launch with per-lane stripes */
@@ -463,22 +491,80 @@ void trace_waves_slots(TraceArgs t)
     }
 }
 
+/* mid != 0: the record has one piece more than trace-point segments, its pieces start at seg0 + r, and the
+   distance of the piece that ends on the last mid point counts twice (align.c:5812-5822) */
 __global__ __launch_bounds__(256)
-void trace_gather(const TraceRecIn *__restrict__ recs, u32 nrecs, const u32 *__restrict__ count,
+void trace_gather(const TraceRecIn *__restrict__ recs, u32 nrecs, int mid, const u32 *__restrict__ count,
                   const int *__restrict__ dist, u32 *__restrict__ segoff, u32 *__restrict__ tlen, int *__restrict__ diffs)
 { const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrecs) return;
   const TraceRecIn in = recs[r];
-  const int nseg = in.tlen >= 2 ? in.tlen / 2 : 1;
+  const int nseg = (in.tlen >= 2 ? in.tlen / 2 : 1) + (mid ? 1 : 0);
+  const u32 s0 = in.seg0 + (mid ? r : 0u);
   u32 n = 0;
   int d = 0;
   for (int s = 0; s < nseg; s++)
-    { segoff[in.seg0 + s] = n;
-      n += count[in.seg0 + s];
-      d += dist[in.seg0 + s];
+    { segoff[s0 + s] = n;
+      n += count[s0 + s];
+      d += dist[s0 + s];
     }
+  if (mid)
+    d += dist[s0 + nseg - 2];
   tlen[r] = n;
   diffs[r] = d;
+}
+
+/* Compute_Trace_MID (align.c:5694-5830): the pieces between successive mid points.  Record r with n
+   trace-point segments becomes n + 1 pieces at seg0 + r: start .. mid 0, mid 0 .. mid 1, ..., last mid .. end. */
+__global__ __launch_bounds__(256)
+void trace_mid_layout(const TraceRecIn *__restrict__ recs, u32 nrecs, const TraceSeg *__restrict__ segs,
+                      const int *__restrict__ mid, DevBlock ablk, DevBlock bblk, TraceSeg *__restrict__ out,
+                      u32 *__restrict__ err)
+{ const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrecs) return;
+  const TraceRecIn in = recs[r];
+  const int nseg = in.tlen >= 2 ? in.tlen / 2 : 1;
+  const u32 aoff = ablk.boff[in.aread];
+  const u32 boff = bblk.boff[in.bread], blen = bblk.boff[in.bread + 1] - boff - 1;
+  const int comp = (int) (in.flags & 1u);
+  const bool dead = (segs[in.seg0].flags & 4u) != 0;
+  int as = in.abpos, bs = in.bbpos;
+  u32 so = in.stage0;
+  bool bad = false;
+  for (int i = 0; i <= nseg; i++)
+    { int af, bf;
+      if (i < nseg) { af = mid[2 * (size_t) (in.seg0 + i)];  bf = mid[2 * (size_t) (in.seg0 + i) + 1]; }
+      else          { af = in.aepos;  bf = in.bepos; }
+      TraceSeg g = {};
+      g.rec = r;
+      const int M = af - as, N = bf - bs;
+      if (dead || M < 0 || N < 0 || M > 32000 || N > 32000)
+        { g.flags = 4u;
+          bad = bad || !dead;
+        }
+      else
+        { const int del = M - N;
+          const u32 cap = (u32) (in.dmax + (del < 0 ? -del : del));
+          if (so + cap > in.stage0 + in.slots)
+            { g.flags = 4u;
+              bad = true;
+            }
+          else
+            { g.apos = aoff + (u32) as;
+              g.bpos = comp ? boff + blen - 1 - (u32) bs : boff + (u32) bs;
+              g.a0 = as;  g.b0 = bs;
+              g.mn = (u32) M | ((u32) N << 16);
+              g.flags = (in.flags & 3u) | ((u32) in.dmax << 8);
+              g.stage = so;
+              so += cap;
+            }
+        }
+      out[in.seg0 + r + i] = g;
+      as = af;
+      bs = bf;
+    }
+  if (bad)
+    atomicOr(err, DAMAR_TRACE_ERR_INTERNAL);
 }
 
 __global__ __launch_bounds__(256)
@@ -506,27 +592,43 @@ void damar_launch_trace_layout(const TraceRecIn *recs, u32 nrecs, const void *pt
                        *ablk, *bblk, segs, err);
 }
 
-void damar_launch_trace_waves(const TraceArgs *t, int mode, u32 nblocks, hipStream_t st)
+#define LAUNCH_BY_MODE(kern)                                                                            \
+  do { if (kind == 0)                                                                                    \
+         { if (mode == 0)      hipLaunchKernelGGL((kern<0, 0>),  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);   \
+           else if (mode > 0)  hipLaunchKernelGGL((kern<1, 0>),  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);   \
+           else                hipLaunchKernelGGL((kern<-1, 0>), dim3(nblocks), dim3(TP_THREADS), 0, st, *t);   \
+         }                                                                                               \
+       else                                                                                              \
+         { if (mode == 0)      hipLaunchKernelGGL((kern<0, 1>),  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);   \
+           else if (mode > 0)  hipLaunchKernelGGL((kern<1, 1>),  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);   \
+           else                hipLaunchKernelGGL((kern<-1, 1>), dim3(nblocks), dim3(TP_THREADS), 0, st, *t);   \
+         }                                                                                               \
+     } while (0)
+
+/* kind 0: scripts into t->stage / count / dist; kind 1: mid points into t->mid (2 ints per segment) */
+void damar_launch_trace_waves(const TraceArgs *t, int mode, int kind, u32 nblocks, hipStream_t st)
 { if (t->nwork == 0) return;
-  if (mode == 0)      hipLaunchKernelGGL(trace_waves<0>,  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
-  else if (mode > 0)  hipLaunchKernelGGL(trace_waves<1>,  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
-  else                hipLaunchKernelGGL(trace_waves<-1>, dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
+  LAUNCH_BY_MODE(trace_waves);
 }
 
 size_t damar_trace_slot_area_cells(void) { return (size_t) SLOT_ROWS * SLOT_RS * 64; }
 
 /* t->vf / t->hf: nblocks areas of damar_trace_slot_area_cells() cells; t->list must be NULL */
-void damar_launch_trace_waves_slots(const TraceArgs *t, int mode, u32 nblocks, hipStream_t st)
+void damar_launch_trace_waves_slots(const TraceArgs *t, int mode, int kind, u32 nblocks, hipStream_t st)
 { if (t->nwork == 0) return;
-  if (mode == 0)      hipLaunchKernelGGL(trace_waves_slots<0>,  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
-  else if (mode > 0)  hipLaunchKernelGGL(trace_waves_slots<1>,  dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
-  else                hipLaunchKernelGGL(trace_waves_slots<-1>, dim3(nblocks), dim3(TP_THREADS), 0, st, *t);
+  LAUNCH_BY_MODE(trace_waves_slots);
 }
 
-void damar_launch_trace_gather(const TraceRecIn *recs, u32 nrecs, const u32 *count, const int *dist, u32 *segoff,
+void damar_launch_trace_gather(const TraceRecIn *recs, u32 nrecs, int mid, const u32 *count, const int *dist, u32 *segoff,
                                u32 *tlen, int *diffs, hipStream_t st)
 { if (nrecs == 0) return;
-  hipLaunchKernelGGL(trace_gather, dim3((nrecs + 255) / 256), dim3(256), 0, st, recs, nrecs, count, dist, segoff, tlen, diffs);
+  hipLaunchKernelGGL(trace_gather, dim3((nrecs + 255) / 256), dim3(256), 0, st, recs, nrecs, mid, count, dist, segoff, tlen, diffs);
+}
+
+void damar_launch_trace_mid_layout(const TraceRecIn *recs, u32 nrecs, const TraceSeg *segs, const int *mid,
+                                   const DevBlock *ablk, const DevBlock *bblk, TraceSeg *out, u32 *err, hipStream_t st)
+{ if (nrecs == 0) return;
+  hipLaunchKernelGGL(trace_mid_layout, dim3((nrecs + 255) / 256), dim3(256), 0, st, recs, nrecs, segs, mid, *ablk, *bblk, out, err);
 }
 
 void damar_launch_trace_pack(const TraceSeg *segs, u32 nsegs, const u32 *count, const u32 *segoff, const u32 *recoff,

@@ -1747,13 +1747,13 @@ struct DBuf
 };
 
 static DBuf T_recs, T_pts, T_segs, T_count, T_dist, T_segoff, T_stage, T_vf, T_hf, T_over, T_ctr, T_tlen,
-            T_diffs, T_script, T_scan, T_bvf, T_bhf;
+            T_diffs, T_script, T_scan, T_bvf, T_bhf, T_mid, T_segs2;
 static double T_ms[4];        /* of the last damar_trace_pts: trace_waves kernel, layout..pack on the device, whole call, inside the batches (wall) */
 static int64  T_cnt[4];       /* records, segments, deferred segments, script values */
 
 extern "C" void damar_trace_release(void)
 { DBuf *all[] = { &T_recs, &T_pts, &T_segs, &T_count, &T_dist, &T_segoff, &T_stage, &T_vf, &T_hf, &T_over, &T_ctr,
-                  &T_tlen, &T_diffs, &T_script, &T_scan, &T_bvf, &T_bhf };
+                  &T_tlen, &T_diffs, &T_script, &T_scan, &T_bvf, &T_bhf, &T_mid, &T_segs2 };
   for (DBuf *b : all) b->drop();
 }
 
@@ -1784,56 +1784,19 @@ static void trace_record_shape(const Path *path, const PT *p, int tspace, int *d
   *dmax_out = dmax;  *nseg_out = nseg;  *slots_out = slots;
 }
 
-static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int bfirst, const Overlap *ovls, int64 r0, int64 r1,
-                       int tbytes, int tspace, int mode, int same, const std::vector<TraceRecIn> &recs, const std::vector<u8> &pts,
-                       u32 nsegs, u64 nslots, int64 *soff, int *diffs, int **script, int64 *nscript)
-{ const u32 nrecs = (u32) (r1 - r0);
-  static u32 rows = 0, maxblocks = 0;
-  if (rows == 0)
-    { const char *e = getenv("DAMAR_TRACE_ROWS");        /* test hook: fewer rows -> more segments deferred */
-      rows = e ? (u32) atoi(e) : 64u;
-      if (rows < 4) rows = 4;
-      e = getenv("DAMAR_TRACE_BLOCKS");
-      maxblocks = e ? (u32) atoi(e) : (u32) (G_prop.multiProcessorCount * 16);
-      if (maxblocks < 1) maxblocks = 1;
-    }
-  const double h0 = now_ms();
-  TraceRecIn *d_recs = (TraceRecIn *) T_recs.need(sizeof(TraceRecIn) * (size_t) nrecs);
-  void       *d_pts  = T_pts.need(pts.size() + 64);
-  TraceSeg   *d_segs = (TraceSeg *) T_segs.need(sizeof(TraceSeg) * (size_t) nsegs);
-  u32 *d_count  = (u32 *) T_count.need(sizeof(u32) * (size_t) nsegs);
-  int *d_dist   = (int *) T_dist.need(sizeof(int) * (size_t) nsegs);
-  u32 *d_segoff = (u32 *) T_segoff.need(sizeof(u32) * (size_t) nsegs);
-  int *d_stage  = (int *) T_stage.need(sizeof(int) * (size_t) (nslots + 16));
-  u32 *d_over   = (u32 *) T_over.need(sizeof(u32) * (size_t) nsegs);
-  u32 *d_ctr    = (u32 *) T_ctr.need(256);                    /* [0] deferred, [1] cells needed, [2] error flags; u64 total at +64 */
-  u32 *d_tlen   = (u32 *) T_tlen.need(sizeof(u32) * (size_t) (nrecs + 1));
-  int *d_diffs  = (int *) T_diffs.need(sizeof(int) * (size_t) nrecs);
-  void *d_scan  = T_scan.need(damar_scan_workspace_bytes(nrecs));
-  const u32 nblocks = std::min(maxblocks, (nsegs + 63) / 64);
+/* One wave phase over `nwork` segments: the slot kernel, then the stripe kernel for what it deferred.
+   kind 0 = scripts, 1 = mid points.  Returns the error flags, or ~0u after a message. */
+static u32 trace_wave_phase(TraceArgs t, int mode, int kind, u32 nwork, u32 rows, u32 maxblocks, u32 *d_ctr,
+                            hipEvent_t e1, hipEvent_t e2)
+{ const u32 nblocks = std::min(maxblocks, (nwork + 63) / 64);
   const size_t area = damar_trace_slot_area_cells();
-  short       *d_vf = (short *) T_vf.need(sizeof(short) * (size_t) nblocks * area);
-  signed char *d_hf = (signed char *) T_hf.need((size_t) nblocks * area);
-
-  hipEvent_t e0, e1, e2, e3;
-  HIP_CHECK(hipEventCreate(&e0));  HIP_CHECK(hipEventCreate(&e1));
-  HIP_CHECK(hipEventCreate(&e2));  HIP_CHECK(hipEventCreate(&e3));
-  HIP_CHECK(hipMemcpyAsync(d_recs, recs.data(), sizeof(TraceRecIn) * (size_t) nrecs, hipMemcpyHostToDevice, G_st));
-  if (!pts.empty())
-    HIP_CHECK(hipMemcpyAsync(d_pts, pts.data(), pts.size(), hipMemcpyHostToDevice, G_st));
-  HIP_CHECK(hipMemsetAsync(d_ctr, 0, 256, G_st));
-  HIP_CHECK(hipEventRecord(e0, G_st));
-  damar_launch_trace_layout(d_recs, nrecs, d_pts, tbytes, tspace, ad, bd, d_segs, d_ctr + 2, G_st);
-  TraceArgs t;
-  memset(&t, 0, sizeof(t));
-  t.segs = d_segs;  t.list = NULL;  t.nwork = nsegs;
-  t.abases = ad->bases;  t.bbases = bd->bases;
-  t.apk = ad->pk;  t.bpk = bd->pk;
-  t.vf = d_vf;  t.hf = d_hf;  t.cap = rows;
-  t.stage = d_stage;  t.count = d_count;  t.dist = d_dist;
-  t.over = d_over;  t.over_cap = nsegs;  t.nover = d_ctr;  t.need = d_ctr + 1;  t.err = d_ctr + 2;
+  t.vf = (short *) T_vf.need(sizeof(short) * (size_t) nblocks * area);
+  t.hf = (signed char *) T_hf.need((size_t) nblocks * area);
+  t.cap = rows;
+  t.list = NULL;  t.nwork = nwork;
+  HIP_CHECK(hipMemsetAsync(d_ctr, 0, 8, G_st));
   HIP_CHECK(hipEventRecord(e1, G_st));
-  damar_launch_trace_waves_slots(&t, mode, nblocks, G_st);
+  damar_launch_trace_waves_slots(&t, mode, kind, nblocks, G_st);
   HIP_CHECK(hipEventRecord(e2, G_st));
   u32 ctr[4];
   HIP_CHECK(hipMemcpyAsync(ctr, d_ctr, sizeof(ctr), hipMemcpyDeviceToHost, G_st));
@@ -1850,15 +1813,15 @@ static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int b
       bthreads = (bthreads + 63) / 64 * 64;
       if (bthreads * need * 3 > ((size_t) 64 << 30))
         { fprintf(stderr, "damar: trace expansion: a segment needs %u wave cells, more than this build provides\n", need);
-          return 1;
+          return ~0u;
         }
       t.vf = (short *) T_bvf.need(sizeof(short) * bthreads * need);
       t.hf = (signed char *) T_bhf.need(bthreads * need);
       t.cap = need;
-      t.list = d_over;  t.nwork = ctr[0];
+      t.list = t.over;  t.nwork = ctr[0];
       HIP_CHECK(hipMemsetAsync(d_ctr, 0, 8, G_st));
       HIP_CHECK(hipEventRecord(e1, G_st));
-      damar_launch_trace_waves(&t, mode, (u32) (bthreads / 64), G_st);
+      damar_launch_trace_waves(&t, mode, kind, (u32) (bthreads / 64), G_st);
       HIP_CHECK(hipEventRecord(e2, G_st));
       u32 c2[4];
       HIP_CHECK(hipMemcpyAsync(c2, d_ctr, sizeof(c2), hipMemcpyDeviceToHost, G_st));
@@ -1868,19 +1831,83 @@ static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int b
       T_cnt[2] += ctr[0];
       if (c2[0] != 0)
         { fprintf(stderr, "damar: trace expansion: internal error, %u segments deferred twice\n", c2[0]);
-          return 1;
+          return ~0u;
         }
       ctr[2] |= c2[2];
     }
   if (ctr[2] & DAMAR_TRACE_ERR_POINTS)
     { fprintf(stderr, "damar: Trace point out of bounds (Compute_Trace), source DB likely incorrect\n");   /* align.c:5575 */
-      return 1;
+      return ~0u;
     }
   if (ctr[2] & DAMAR_TRACE_ERR_ALIGN)
     { fprintf(stderr, "damar: Bad alignment between trace points (Compute_Trace), source DB likely incorrect\n");   /* :4890 */
-      return 1;
+      return ~0u;
     }
-  damar_launch_trace_gather(d_recs, nrecs, d_count, d_dist, d_segoff, d_tlen, d_diffs, G_st);
+  if (ctr[2] & DAMAR_TRACE_ERR_INTERNAL)
+    { fprintf(stderr, "damar: trace expansion: internal error, staging bound of the mid-point pieces violated\n");
+      return ~0u;
+    }
+  return ctr[2];
+}
+
+/* kind 0: Compute_Trace_PTS, the script of every trace-point segment.  kind 1: Compute_Trace_MID: a first
+   wave phase finds the mid point of every segment, the pieces between successive mid points (one more
+   than segments per record) are laid out anew and the script phase runs on those. */
+static int trace_batch(const DevBlock *ad, const DevBlock *bd, int64 r0, int64 r1, int tbytes, int tspace, int mode, int kind,
+                       const std::vector<TraceRecIn> &recs, const std::vector<u8> &pts,
+                       u32 nsegs, u64 nslots, int64 *soff, int *diffs, int **script, int64 *nscript)
+{ const u32 nrecs = (u32) (r1 - r0);
+  static u32 rows = 0, maxblocks = 0;
+  if (rows == 0)
+    { const char *e = getenv("DAMAR_TRACE_ROWS");        /* test hook: fewer rows -> more segments deferred */
+      rows = e ? (u32) atoi(e) : 64u;
+      if (rows < 4) rows = 4;
+      e = getenv("DAMAR_TRACE_BLOCKS");
+      maxblocks = e ? (u32) atoi(e) : (u32) (G_prop.multiProcessorCount * 16);
+      if (maxblocks < 1) maxblocks = 1;
+    }
+  const double h0 = now_ms();
+  const u32 nwork = nsegs + (kind ? nrecs : 0u);             /* segments of the script phase */
+  TraceRecIn *d_recs = (TraceRecIn *) T_recs.need(sizeof(TraceRecIn) * (size_t) nrecs);
+  void       *d_pts  = T_pts.need(pts.size() + 64);
+  TraceSeg   *d_segs = (TraceSeg *) T_segs.need(sizeof(TraceSeg) * (size_t) nsegs);
+  u32 *d_count  = (u32 *) T_count.need(sizeof(u32) * (size_t) nwork);
+  int *d_dist   = (int *) T_dist.need(sizeof(int) * (size_t) nwork);
+  u32 *d_segoff = (u32 *) T_segoff.need(sizeof(u32) * (size_t) nwork);
+  int *d_stage  = (int *) T_stage.need(sizeof(int) * (size_t) (nslots + 16));
+  u32 *d_over   = (u32 *) T_over.need(sizeof(u32) * (size_t) nwork);
+  u32 *d_ctr    = (u32 *) T_ctr.need(256);                    /* [0] deferred, [1] cells needed, [2] error flags; u64 total at +64 */
+  u32 *d_tlen   = (u32 *) T_tlen.need(sizeof(u32) * (size_t) (nrecs + 1));
+  int *d_diffs  = (int *) T_diffs.need(sizeof(int) * (size_t) nrecs);
+  void *d_scan  = T_scan.need(damar_scan_workspace_bytes(nrecs));
+
+  hipEvent_t e0, e1, e2, e3;
+  HIP_CHECK(hipEventCreate(&e0));  HIP_CHECK(hipEventCreate(&e1));
+  HIP_CHECK(hipEventCreate(&e2));  HIP_CHECK(hipEventCreate(&e3));
+  HIP_CHECK(hipMemcpyAsync(d_recs, recs.data(), sizeof(TraceRecIn) * (size_t) nrecs, hipMemcpyHostToDevice, G_st));
+  if (!pts.empty())
+    HIP_CHECK(hipMemcpyAsync(d_pts, pts.data(), pts.size(), hipMemcpyHostToDevice, G_st));
+  HIP_CHECK(hipMemsetAsync(d_ctr, 0, 256, G_st));
+  HIP_CHECK(hipEventRecord(e0, G_st));
+  damar_launch_trace_layout(d_recs, nrecs, d_pts, tbytes, tspace, ad, bd, d_segs, d_ctr + 2, G_st);
+  TraceArgs t;
+  memset(&t, 0, sizeof(t));
+  t.segs = d_segs;
+  t.abases = ad->bases;  t.bbases = bd->bases;
+  t.apk = ad->pk;  t.bpk = bd->pk;
+  t.stage = d_stage;  t.count = d_count;  t.dist = d_dist;
+  t.over = d_over;  t.over_cap = nwork;  t.nover = d_ctr;  t.need = d_ctr + 1;  t.err = d_ctr + 2;
+  if (kind)
+    { t.mid = (int *) T_mid.need(sizeof(int) * 2 * (size_t) nsegs);
+      if (trace_wave_phase(t, mode, 1, nsegs, rows, maxblocks, d_ctr, e1, e2) == ~0u)
+        return 1;
+      TraceSeg *d_segs2 = (TraceSeg *) T_segs2.need(sizeof(TraceSeg) * (size_t) nwork);
+      damar_launch_trace_mid_layout(d_recs, nrecs, d_segs, t.mid, ad, bd, d_segs2, d_ctr + 2, G_st);
+      t.segs = d_segs = d_segs2;
+    }
+  if (trace_wave_phase(t, mode, 0, nwork, rows, maxblocks, d_ctr, e1, e2) == ~0u)
+    return 1;
+  damar_launch_trace_gather(d_recs, nrecs, kind, d_count, d_dist, d_segoff, d_tlen, d_diffs, G_st);
   u64 *d_tot = (u64 *) ((char *) d_ctr + 64);
   damar_exclusive_scan_u32(d_tlen, d_tlen, nrecs, d_scan, d_tot, G_st);
   u64 total = 0;
@@ -1891,7 +1918,7 @@ static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int b
       return 1;
     }
   int *d_script = (int *) T_script.need(sizeof(int) * (size_t) (total + 16));
-  damar_launch_trace_pack(d_segs, nsegs, d_count, d_segoff, d_tlen, d_stage, d_script, G_st);
+  damar_launch_trace_pack(d_segs, nwork, d_count, d_segoff, d_tlen, d_stage, d_script, G_st);
   HIP_CHECK(hipEventRecord(e3, G_st));
   std::vector<u32> hoff(nrecs);
   const size_t base = (size_t) *nscript;
@@ -1917,8 +1944,7 @@ static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int b
   HIP_CHECK(hipEventDestroy(e0));  HIP_CHECK(hipEventDestroy(e1));
   HIP_CHECK(hipEventDestroy(e2));  HIP_CHECK(hipEventDestroy(e3));
   T_ms[3] += now_ms() - h0;
-  T_cnt[0] += nrecs;  T_cnt[1] += nsegs;  T_cnt[3] += (int64) total;
-  (void) ovls; (void) afirst; (void) bfirst; (void) same;
+  T_cnt[0] += nrecs;  T_cnt[1] += nwork;  T_cnt[3] += (int64) total;
   return 0;
 }
 
@@ -1926,9 +1952,9 @@ static int trace_batch(const DevBlock *ad, int afirst, const DevBlock *bd, int b
  * aread / bread are DB read ids, afirst / bfirst the ids of the blocks' first reads.  same != 0: A and B of
  * every record are one buffer (align.c:4933-4951; LAshow never is).  On return *script_out is a malloc'ed
  * array holding all edit scripts, record i at [soff[i], soff[i+1]), diffs[i] its summed distance. */
-extern "C" int damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_block *bblk, int bfirst,
-                               const Overlap *ovls, int64 novl, int tbytes, int tspace, int mode, int same,
-                               int64 *soff, int *diffs, int **script_out)
+static int trace_expand(damar_dev_block *ablk, int afirst, damar_dev_block *bblk, int bfirst,
+                        const Overlap *ovls, int64 novl, int tbytes, int tspace, int mode, int same, int kind,
+                        int64 *soff, int *diffs, int **script_out)
 { ensure_init();
   const double t0 = now_ms();
   for (int i = 0; i < 4; i++) { T_ms[i] = 0;  T_cnt[i] = 0; }
@@ -1956,10 +1982,12 @@ extern "C" int damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_bloc
             }
           if (tbytes == 1) trace_record_shape(&o->path, (const uint8 *) o->path.trace, tspace, &dmax, &nseg, &slots);
           else             trace_record_shape(&o->path, (const uint16 *) o->path.trace, tspace, &dmax, &nseg, &slots);
+          if (kind)            /* pieces between mid points: |del'| <= |del| of the two segments + 2 (dmax + |del|) drift */
+            slots = 3 * slots + 3 * (int64) dmax;
         }
       if (i == novl || nsegs + (u32) nseg > max_segs || nslots + (u64) slots > max_slots)
         { if (i > r0)
-            { if (trace_batch(&ablk->d, afirst, &bblk->d, bfirst, ovls, r0, i, tbytes, tspace, mode, same, recs, pts,
+            { if (trace_batch(&ablk->d, &bblk->d, r0, i, tbytes, tspace, mode, kind, recs, pts,
                               nsegs, nslots, soff, diffs, &script, &nscript))
                 { free(script);
                   return 1;
@@ -1984,6 +2012,7 @@ extern "C" int damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_bloc
       in.seg0 = nsegs;
       in.stage0 = (u32) nslots;
       in.dmax = dmax;
+      in.slots = (u32) slots;
       recs.push_back(in);
       const u8 *src = (const u8 *) o->path.trace;
       pts.insert(pts.end(), src, src + (size_t) o->path.tlen * (size_t) tbytes);
@@ -1997,13 +2026,26 @@ extern "C" int damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_bloc
   return 0;
 }
 
+extern "C" int damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_block *bblk, int bfirst,
+                               const Overlap *ovls, int64 novl, int tbytes, int tspace, int mode, int same,
+                               int64 *soff, int *diffs, int **script_out)
+{ return trace_expand(ablk, afirst, bblk, bfirst, ovls, novl, tbytes, tspace, mode, same, 0, soff, diffs, script_out);
+}
+
+/* the same arguments, Compute_Trace_MID (align.c:5694-5830): the script between the segments' mid points */
+extern "C" int damar_trace_mid(damar_dev_block *ablk, int afirst, damar_dev_block *bblk, int bfirst,
+                               const Overlap *ovls, int64 novl, int tbytes, int tspace, int mode, int same,
+                               int64 *soff, int *diffs, int **script_out)
+{ return trace_expand(ablk, afirst, bblk, bfirst, ovls, novl, tbytes, tspace, mode, same, 1, soff, diffs, script_out);
+}
+
 /* align.c:5577-5692 for one record, through the batch path (the two sequences travel to HBM per call: this
  * entry point is for callers that need the reference's API; LAshow-like loops over a .las belong on
  * damar_trace_pts).  As in the reference, align->path->trace holds 16-bit trace-point pairs on entry (after
  * Decompress_TraceTo16), bseq is already complemented where the record says so, and on return path->trace
  * points to the edit script inside `work`, tlen and diffs are updated.  Returns 0, or 1 after the
  * reference's message where the reference's EXIT(1) paths are. */
-extern "C" int Compute_Trace_PTS(Alignment *align, Work_Data *work, int trace_spacing, int mode)
+static int compute_trace(Alignment *align, Work_Data *work, int trace_spacing, int mode, int kind)
 { ensure_init();
   WorkData *w = (WorkData *) work;
   HITS_DB   db[2];
@@ -2028,7 +2070,7 @@ extern "C" int Compute_Trace_PTS(Alignment *align, Work_Data *work, int trace_sp
   o.path = *align->path;
   int64 soff[2];
   int   diffs = 0, *script = NULL;
-  const int rc = damar_trace_pts(ab, 0, bb, 0, &o, 1, 2, trace_spacing, mode, same, soff, &diffs, &script);
+  const int rc = trace_expand(ab, 0, bb, 0, &o, 1, 2, trace_spacing, mode, same, kind, soff, &diffs, &script);
   damar_block_free(ab);
   if (!same)
     damar_block_free(bb);
@@ -2040,4 +2082,12 @@ extern "C" int Compute_Trace_PTS(Alignment *align, Work_Data *work, int trace_sp
   align->path->tlen  = (int) soff[1];
   align->path->diffs = diffs;
   return 0;
+}
+
+extern "C" int Compute_Trace_PTS(Alignment *align, Work_Data *work, int trace_spacing, int mode)   /* align.c:5577 */
+{ return compute_trace(align, work, trace_spacing, mode, 0);
+}
+
+extern "C" int Compute_Trace_MID(Alignment *align, Work_Data *work, int trace_spacing, int mode)   /* align.c:5694 */
+{ return compute_trace(align, work, trace_spacing, mode, 1);
 }

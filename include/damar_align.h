@@ -90,6 +90,9 @@ Path      *Local_Alignment(Alignment *align, Work_Data *work, Align_Spec *spec,
 #define GREEDIEST  0
 #define UPPERMOST  1
 int Compute_Trace_PTS(Alignment *align, Work_Data *work, int trace_spacing, int mode);
+/* align.c:5694-5830: the same contract, the script computed between the MID points of the trace-point
+ * segments (corrector/LAcorrect.c:545); path->diffs reproduces the reference's sum. */
+int Compute_Trace_MID(Alignment *align, Work_Data *work, int trace_spacing, int mode);
 
 /* align.c:5969-6102, 6166-6380 */
 Overlap_IO_Buffer *CreateOverlapBuffer(int nthreads, int tbytes, int no_trace);

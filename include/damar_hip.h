@@ -114,6 +114,10 @@ int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_block *bblk, in
 int  damar_trace_pts(damar_dev_block *ablk, int afirst, damar_dev_block *bblk, int bfirst,
                      const Overlap *ovls, int64 novl, int tbytes, int tspace, int mode, int same,
                      int64 *soff, int *diffs, int **script);
+/* The same for Compute_Trace_MID (align.c:5694-5830 + middle_np :5263-5573, corrector/LAcorrect.c:545) */
+int  damar_trace_mid(damar_dev_block *ablk, int afirst, damar_dev_block *bblk, int bfirst,
+                     const Overlap *ovls, int64 novl, int tbytes, int tspace, int mode, int same,
+                     int64 *soff, int *diffs, int **script);
 /* ms[4]: trace_waves kernel, all kernels of the call (HIP events), whole call, inside the batches (wall);
  * cnt[4]: records, segments, segments deferred to the large-stripe launch, script values */
 void damar_trace_last(double *ms, int64 *cnt);

@@ -17,6 +17,14 @@ for m in ${MODES:-0 1 -1}; do
     timeout -k 10 300 $ROOT/damar_amd/bin/lastrace -v -m$m SIM.$A SIM.$B $LAS gpu_$m.bin
   done
 done
+for rep in 1 2; do
+  echo "Compute_Trace_MID:"; timeout -k 10 300 $ROOT/damar_amd/bin/lastrace -v -M SIM.$A SIM.$B $LAS gpu_mid.bin
+done
+if [ -n "$REF" ]; then
+  t0=$(date +%s%N); $ROOT/oracle/_ref/ref_lastrace SIM $LAS ref_mid.bin 0 mid; t1=$(date +%s%N)
+  echo "reference Compute_Trace_MID mode 0, 1 thread: $(( (t1 - t0) / 1000000 )) ms (DB open included)"
+  cmp gpu_mid.bin ref_mid.bin && echo "MID: IDENTICAL to the reference"
+fi
 if [ -n "$REF" ]; then
   for m in ${MODES:-0}; do
     t0=$(date +%s%N); $ROOT/oracle/_ref/ref_lastrace SIM $LAS ref_$m.bin $m; t1=$(date +%s%N)

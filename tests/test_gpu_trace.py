@@ -16,42 +16,57 @@ from conftest import GOLDEN, ROOT, read_case
 pytestmark = pytest.mark.gpu
 
 
-def ref_lines():
+def ref_lines(fixture="trace_ref_md5.txt"):
     out = []
-    for ln in open(os.path.join(GOLDEN, "trace_ref_md5.txt")):
+    for ln in open(os.path.join(GOLDEN, fixture)):
         md5, name, las, mode = ln.split()
         out.append((md5, name, las, int(mode)))
     return out
 
 
-def run_tool(c, las, mode, out, extra_env=None):
+def run_jobs(jobs, tmp_path, extra_env=None):
+    """jobs = [(case dict, las, mode, mid)] -> md5 of each dump; one lastrace process for all of them."""
     env = dict(os.environ)
     env.update(extra_env or {})
-    db = os.path.join(c["dbdir"], "G")
-    subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "lastrace"), "-m%d" % mode, db, db,
-                    os.path.join(c["lasdir"], las), out], check=True, env=env)
-    return hashlib.md5(open(out, "rb").read()).hexdigest()
+    lst = str(tmp_path / "jobs.txt")
+    with open(lst, "w") as f:
+        for i, (c, las, mode, mid) in enumerate(jobs):
+            db = os.path.join(c["dbdir"], "G")
+            f.write("%d %d %s %s %s %s\n" % (mode, 1 if mid else 0, db, db, os.path.join(c["lasdir"], las), str(tmp_path / ("g%d.bin" % i))))
+    subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "lastrace"), "-L" + lst], check=True, env=env)
+    out = []
+    for i in range(len(jobs)):
+        p = str(tmp_path / ("g%d.bin" % i))
+        out.append(hashlib.md5(open(p, "rb").read()).hexdigest())
+        os.unlink(p)
+    return out
 
 
-def test_trace_expansion_equals_reference_on_golden(built, tmp_path):
-    n = 0
-    for md5, name, las, mode in ref_lines():
-        got = run_tool(read_case(name), las, mode, str(tmp_path / "g.bin"))
-        assert got == md5, (name, las, mode)
-        n += 1
-    assert n >= 100
+@pytest.mark.parametrize("fixture,mid", [("trace_ref_md5.txt", False), ("trace_mid_ref_md5.txt", True)])
+def test_trace_expansion_equals_reference_on_golden(built, tmp_path, fixture, mid):
+    """Compute_Trace_PTS (align.c:5577) and Compute_Trace_MID (align.c:5694): every golden record, 3 modes."""
+    lines = ref_lines(fixture)
+    got = run_jobs([(read_case(name), las, mode, mid) for _, name, las, mode in lines], tmp_path)
+    bad = [(name, las, mode, mid) for (md5, name, las, mode), g in zip(lines, got) if g != md5]
+    assert not bad, bad
+    assert len(lines) >= 100
 
 
 def test_trace_expansion_small_stripes_take_the_deferred_launch(built, tmp_path):
-    """Stripes of 96 cells hold only the first few waves: almost every segment overflows and is redone by
-    the second launch with large stripes; results must not change."""
-    want = {(n, l, m): h for h, n, l, m in ref_lines()}
-    for name in ("tiny_I", "fusion", "tan_tandem", "tiny_s"):
-        c = read_case(name)
-        for las in c["las"]:
-            for mode in (0, 1, -1):
-                got = run_tool(c, las, mode, str(tmp_path / "g.bin"), {"DAMAR_TRACE_ROWS": "9", "DAMAR_TRACE_BLOCKS": "7"})
-                assert got == want[(name, las, mode)], (name, las, mode)
+    """With the slot kernel squeezed to 9 rows (waves 0..6) almost every segment is deferred and redone by
+    the per-lane stripe kernel; results must not change."""
+    jobs, want = [], []
+    for fixture, mid in (("trace_ref_md5.txt", False), ("trace_mid_ref_md5.txt", True)):
+        ref = {(n, l, m): h for h, n, l, m in ref_lines(fixture)}
+        for name in ("tiny_I", "fusion", "tan_tandem", "tiny_s"):
+            c = read_case(name)
+            for las in c["las"]:
+                for mode in (0, 1, -1):
+                    jobs.append((c, las, mode, mid))
+                    want.append(ref[(name, las, mode)])
+    got = run_jobs(jobs, tmp_path, {"DAMAR_TRACE_ROWS": "9", "DAMAR_TRACE_BLOCKS": "7"})
+    bad = [(j[0]["name"], j[1], j[2], j[3]) for j, g, w in zip(jobs, got, want) if g != w]
+    assert not bad, bad
 
 
 def test_compute_trace_pts_c_abi_single_record(built):
@@ -70,6 +85,10 @@ def test_compute_trace_pts_c_abi_single_record(built):
 
     lib.New_Work_Data.restype = ctypes.c_void_p
     lib.Compute_Trace_PTS.argtypes = [ctypes.POINTER(Alignment), ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.Compute_Trace_MID.argtypes = [ctypes.POINTER(Alignment), ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    ora.oracle_compute_trace_mid.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.POINTER(Path), ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.POINTER(ctypes.c_int)]
     lib.Free_Work_Data.argtypes = [ctypes.c_void_p]
     ora.oracle_compute_trace_pts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.POINTER(Path), ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
@@ -102,24 +121,24 @@ def test_compute_trace_pts_c_abi_single_record(built):
         bseq = np.concatenate([[4], pre, np.array(b, dtype=np.int8), rng.integers(0, 4, 40).astype(np.int8), [4]]).astype(np.int8)
         aseq = np.concatenate([[4], a, [4]]).astype(np.int8)
         blen = len(bseq) - 2
-        for mode in (0, 1, -1):
+        for mode, kind in ((0, 0), (1, 0), (-1, 0), (0, 1), (1, 1), (-1, 1)):
             res = []
             for which in ("gpu", "oracle"):
                 tp = np.array(pts, dtype=np.uint16)
                 p = Path(tp.ctypes.data, len(tp), 0, abpos, len(pre), aepos, len(pre) + len(b))
                 al = Alignment(ctypes.pointer(p), 0, aseq.ctypes.data + 1, bseq.ctypes.data + 1, alen, blen)
                 if which == "gpu":
-                    assert lib.Compute_Trace_PTS(ctypes.byref(al), work, tspace, mode) == 0
+                    assert (lib.Compute_Trace_MID if kind else lib.Compute_Trace_PTS)(ctypes.byref(al), work, tspace, mode) == 0
                     out = np.ctypeslib.as_array(ctypes.cast(p.trace, ctypes.POINTER(ctypes.c_int)), shape=(max(p.tlen, 1),))[:p.tlen].copy()
                     res.append((out.tolist(), p.diffs))
                 else:
                     script = np.zeros(alen + blen + 16, dtype=np.int32)
                     d = ctypes.c_int(0)
-                    n = ora.oracle_compute_trace_pts(aseq.ctypes.data + 1, alen, bseq.ctypes.data + 1, blen, ctypes.byref(p),
+                    n = (ora.oracle_compute_trace_mid if kind else ora.oracle_compute_trace_pts)(aseq.ctypes.data + 1, alen, bseq.ctypes.data + 1, blen, ctypes.byref(p),
                                                      tspace, mode, script.ctypes.data, ctypes.byref(d))
                     assert n >= 0
                     res.append((script[:n].tolist(), d.value))
-            assert res[0] == res[1], (trial, mode)
+            assert res[0] == res[1], (trial, mode, kind)
     lib.Free_Work_Data(work)
 
 
@@ -140,11 +159,12 @@ def test_trace_expansion_other_spacings_against_oracle(built, tmp_path, spacing)
             if not f.endswith(".las"):
                 continue
             las = os.path.join(dp, f)
-            for mode in (0, 1, -1):
+            for mode, mid in ((0, 0), (1, 0), (-1, 0), (0, 1), (1, 1)):
                 g, o = str(tmp_path / "g.bin"), str(tmp_path / "o.bin")
-                subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "lastrace"), "-m%d" % mode, os.path.join(d, "G"),
-                                os.path.join(d, "G"), las, g], check=True)
-                subprocess.run([os.path.join(ROOT, "oracle", "oracle_lastrace"), os.path.join(d, "G"), las, o, str(mode)], check=True)
-                assert open(g, "rb").read() == open(o, "rb").read(), (f, mode)
+                subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "lastrace"), "-m%d" % mode] + (["-M"] if mid else []) +
+                               [os.path.join(d, "G"), os.path.join(d, "G"), las, g], check=True)
+                subprocess.run([os.path.join(ROOT, "oracle", "oracle_lastrace"), os.path.join(d, "G"), las, o, str(mode)] +
+                               (["mid"] if mid else []), check=True)
+                assert open(g, "rb").read() == open(o, "rb").read(), (f, mode, mid)
                 n += 1
     assert n >= 6
