@@ -172,15 +172,19 @@ typedef struct
 #define DAMAR_TRACE_ERR_INTERNAL 4u      /* staging bound of the mid-point pieces violated */
 
 /* pts: the records' trace points as stored in the .las (tbytes 1 or 2) */
+/* key / val: per segment its own difference count (<= 255) and its index, for the work order */
 void damar_launch_trace_layout(const TraceRecIn *recs, u32 nrecs, const void *pts, int tbytes, int tspace,
-                               const DevBlock *ablk, const DevBlock *bblk, TraceSeg *segs, u32 *err, hipStream_t st);
+                               const DevBlock *ablk, const DevBlock *bblk, TraceSeg *segs, u32 *key, u32 *val, u32 *err,
+                               hipStream_t st);
 void damar_launch_trace_waves(const TraceArgs *t, int mode, int kind, u32 nblocks, hipStream_t st);
 size_t damar_trace_slot_area_cells(void);
+size_t damar_trace_slot_vf_bytes(int mode, int kind);
 void damar_launch_trace_waves_slots(const TraceArgs *t, int mode, int kind, u32 nblocks, hipStream_t st);
 void damar_launch_trace_gather(const TraceRecIn *recs, u32 nrecs, int mid, const u32 *count, const int *dist, u32 *segoff,
                                u32 *tlen, int *diffs, hipStream_t st);
 void damar_launch_trace_mid_layout(const TraceRecIn *recs, u32 nrecs, const TraceSeg *segs, const int *mid,
-                                   const DevBlock *ablk, const DevBlock *bblk, TraceSeg *out, u32 *err, hipStream_t st);
+                                   const DevBlock *ablk, const DevBlock *bblk, TraceSeg *out, u32 *key, u32 *val, u32 *err,
+                                   hipStream_t st);
 void damar_launch_trace_pack(const TraceSeg *segs, u32 nsegs, const u32 *count, const u32 *segoff, const u32 *recoff,
                              const int *stage, int *script, hipStream_t st);
 #endif

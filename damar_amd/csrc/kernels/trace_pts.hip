@@ -30,7 +30,8 @@
 template <typename PT>
 __global__ __launch_bounds__(256)
 void trace_layout(const TraceRecIn *__restrict__ recs, u32 nrecs, const PT *__restrict__ pts, int tspace,
-                  DevBlock ablk, DevBlock bblk, TraceSeg *__restrict__ segs, u32 *__restrict__ err)
+                  DevBlock ablk, DevBlock bblk, TraceSeg *__restrict__ segs, u32 *__restrict__ key, u32 *__restrict__ val,
+                  u32 *__restrict__ err)
 { const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrecs) return;
   const TraceRecIn in = recs[r];
@@ -55,10 +56,15 @@ void trace_layout(const TraceRecIn *__restrict__ recs, u32 nrecs, const PT *__re
       g.bpos = comp ? boff + blen - 1 - (u32) bb : boff + (u32) bb;
       g.a0 = ab;  g.b0 = bb;
       g.mn = (u32) M | ((u32) N << 16);
-      g.flags = (in.flags & 3u) | ((u32) in.dmax << 8);
+      /* the segment's own difference count (0 for a record without trace points) orders the work: lanes of
+         one wavefront should need about the same number of waves */
+      const u32 own = tlen >= 2 ? min((u32) p[2 * s], 255u) : 0u;
+      g.flags = (in.flags & 3u) | ((u32) min(in.dmax, 65535) << 8) | (own << 24);
       g.stage = so;
       g.rec = r;
       segs[in.seg0 + s] = g;
+      key[in.seg0 + s] = own;
+      val[in.seg0 + s] = in.seg0 + s;
       so += (u32) (in.dmax + (del < 0 ? -del : del));
       ab = ae;
       bb = be;
@@ -66,7 +72,9 @@ void trace_layout(const TraceRecIn *__restrict__ recs, u32 nrecs, const PT *__re
   if (s < nseg)
     { atomicOr(err, DAMAR_TRACE_ERR_POINTS);
       for (s = 0; s < nseg; s++)                          /* void segments: the host stops on the flag */
-        { TraceSeg g = {};  g.rec = r;  g.flags = 4u;  segs[in.seg0 + s] = g; }
+        { TraceSeg g = {};  g.rec = r;  g.flags = 4u;  segs[in.seg0 + s] = g;
+          key[in.seg0 + s] = 0;  val[in.seg0 + s] = in.seg0 + s;
+        }
     }
 }
 
@@ -391,7 +399,7 @@ void trace_waves(TraceArgs t)
       int n = 0, dist = 0;
       if (!(g.flags & 4u))
         { const int M = (int) (g.mn & 0xffffu), N = (int) (g.mn >> 16);
-          const int dmax = (int) (g.flags >> 8);
+          const int dmax = (int) ((g.flags >> 8) & 0xffffu);
           ByteBases bb;
           bb.comp = (int) (g.flags & 1u);
           bb.sgn = bb.comp ? -1 : 1;
@@ -424,21 +432,23 @@ void trace_waves_slots(TraceArgs t)
 { __shared__ u32 lds[2 * SLOT_WORDS * 64];
   const int lane = (int) threadIdx.x;
   const size_t area = (size_t) SLOT_ROWS * SLOT_RS * 64;
-  Slots<(MODE == 0 && KIND == 0)> w;       /* the mid point is read from an older row: keep them all */
-  w.vf = (u8 *) t.vf + (size_t) blockIdx.x * area + lane;
+  const int ring = (MODE == 0 && KIND == 0);               /* the mid point is read from an older row: keep them all */
+  Slots<ring> w;
+  w.vf = (u8 *) t.vf + (size_t) blockIdx.x * (ring ? (size_t) 4 * SLOT_RS * 64 : area) + lane;
   w.hf = t.hf + (size_t) blockIdx.x * area + lane;
   w.rows = min((int) t.cap, SLOT_ROWS);
   u32 *const la = lds + lane, *const lb = lds + SLOT_WORDS * 64 + lane;
   const u32 nbatch = (t.nwork + 63) / 64;
 
   for (u32 batch = blockIdx.x; batch < nbatch; batch += gridDim.x)
-    { const u32 s = batch * 64 + (u32) lane;
-      if (s >= t.nwork) continue;
+    { const u32 it = batch * 64 + (u32) lane;
+      if (it >= t.nwork) continue;
+      const u32 s = t.list ? t.list[it] : it;
       const TraceSeg g = t.segs[s];
       int n = 0, dist = 0;
       if (!(g.flags & 4u))
         { const int M = (int) (g.mn & 0xffffu), N = (int) (g.mn >> 16);
-          const int dmax = (int) (g.flags >> 8);
+          const int dmax = (int) ((g.flags >> 8) & 0xffffu);
           int status = 1;
           if (M <= SLOT_MAXB && N <= SLOT_MAXB && !(g.flags & 2u))
             { ByteBases bb;
@@ -519,7 +529,7 @@ void trace_gather(const TraceRecIn *__restrict__ recs, u32 nrecs, int mid, const
 __global__ __launch_bounds__(256)
 void trace_mid_layout(const TraceRecIn *__restrict__ recs, u32 nrecs, const TraceSeg *__restrict__ segs,
                       const int *__restrict__ mid, DevBlock ablk, DevBlock bblk, TraceSeg *__restrict__ out,
-                      u32 *__restrict__ err)
+                      u32 *__restrict__ key, u32 *__restrict__ val, u32 *__restrict__ err)
 { const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrecs) return;
   const TraceRecIn in = recs[r];
@@ -537,6 +547,7 @@ void trace_mid_layout(const TraceRecIn *__restrict__ recs, u32 nrecs, const Trac
       else          { af = in.aepos;  bf = in.bepos; }
       TraceSeg g = {};
       g.rec = r;
+      u32 own = 0;
       const int M = af - as, N = bf - bs;
       if (dead || M < 0 || N < 0 || M > 32000 || N > 32000)
         { g.flags = 4u;
@@ -554,12 +565,17 @@ void trace_mid_layout(const TraceRecIn *__restrict__ recs, u32 nrecs, const Trac
               g.bpos = comp ? boff + blen - 1 - (u32) bs : boff + (u32) bs;
               g.a0 = as;  g.b0 = bs;
               g.mn = (u32) M | ((u32) N << 16);
-              g.flags = (in.flags & 3u) | ((u32) in.dmax << 8);
+              /* about half the differences of the two segments the piece overlaps */
+              const u32 d0 = i > 0 ? segs[in.seg0 + i - 1].flags >> 24 : 0u, d1 = i < nseg ? segs[in.seg0 + i].flags >> 24 : 0u;
+              own = min((d0 + d1 + 1) / 2, 255u);
+              g.flags = (in.flags & 3u) | ((u32) min(in.dmax, 65535) << 8) | (own << 24);
               g.stage = so;
               so += cap;
             }
         }
       out[in.seg0 + r + i] = g;
+      key[in.seg0 + r + i] = own;
+      val[in.seg0 + r + i] = in.seg0 + r + i;
       as = af;
       bs = bf;
     }
@@ -582,14 +598,15 @@ void trace_pack(const TraceSeg *__restrict__ segs, u32 nsegs, const u32 *__restr
 }
 
 void damar_launch_trace_layout(const TraceRecIn *recs, u32 nrecs, const void *pts, int tbytes, int tspace,
-                               const DevBlock *ablk, const DevBlock *bblk, TraceSeg *segs, u32 *err, hipStream_t st)
+                               const DevBlock *ablk, const DevBlock *bblk, TraceSeg *segs, u32 *key, u32 *val, u32 *err,
+                               hipStream_t st)
 { if (nrecs == 0) return;
   if (tbytes == 1)
     hipLaunchKernelGGL(trace_layout<u8>, dim3((nrecs + 255) / 256), dim3(256), 0, st, recs, nrecs, (const u8 *) pts, tspace,
-                       *ablk, *bblk, segs, err);
+                       *ablk, *bblk, segs, key, val, err);
   else
     hipLaunchKernelGGL(trace_layout<u16>, dim3((nrecs + 255) / 256), dim3(256), 0, st, recs, nrecs, (const u16 *) pts, tspace,
-                       *ablk, *bblk, segs, err);
+                       *ablk, *bblk, segs, key, val, err);
 }
 
 #define LAUNCH_BY_MODE(kern)                                                                            \
@@ -612,6 +629,8 @@ void damar_launch_trace_waves(const TraceArgs *t, int mode, int kind, u32 nblock
 }
 
 size_t damar_trace_slot_area_cells(void) { return (size_t) SLOT_ROWS * SLOT_RS * 64; }
+/* bytes of furthest points per workgroup: four live rows for GREEDIEST scripts, every row otherwise */
+size_t damar_trace_slot_vf_bytes(int mode, int kind) { return (mode == 0 && kind == 0) ? (size_t) 4 * SLOT_RS * 64 : (size_t) SLOT_ROWS * SLOT_RS * 64; }
 
 /* t->vf / t->hf: nblocks areas of damar_trace_slot_area_cells() cells; t->list must be NULL */
 void damar_launch_trace_waves_slots(const TraceArgs *t, int mode, int kind, u32 nblocks, hipStream_t st)
@@ -626,9 +645,11 @@ void damar_launch_trace_gather(const TraceRecIn *recs, u32 nrecs, int mid, const
 }
 
 void damar_launch_trace_mid_layout(const TraceRecIn *recs, u32 nrecs, const TraceSeg *segs, const int *mid,
-                                   const DevBlock *ablk, const DevBlock *bblk, TraceSeg *out, u32 *err, hipStream_t st)
+                                   const DevBlock *ablk, const DevBlock *bblk, TraceSeg *out, u32 *key, u32 *val, u32 *err,
+                                   hipStream_t st)
 { if (nrecs == 0) return;
-  hipLaunchKernelGGL(trace_mid_layout, dim3((nrecs + 255) / 256), dim3(256), 0, st, recs, nrecs, segs, mid, *ablk, *bblk, out, err);
+  hipLaunchKernelGGL(trace_mid_layout, dim3((nrecs + 255) / 256), dim3(256), 0, st, recs, nrecs, segs, mid, *ablk, *bblk, out,
+                     key, val, err);
 }
 
 void damar_launch_trace_pack(const TraceSeg *segs, u32 nsegs, const u32 *count, const u32 *segoff, const u32 *recoff,

@@ -1747,13 +1747,13 @@ struct DBuf
 };
 
 static DBuf T_recs, T_pts, T_segs, T_count, T_dist, T_segoff, T_stage, T_vf, T_hf, T_over, T_ctr, T_tlen,
-            T_diffs, T_script, T_scan, T_bvf, T_bhf, T_mid, T_segs2;
+            T_diffs, T_script, T_scan, T_bvf, T_bhf, T_mid, T_segs2, T_key, T_val, T_key1, T_val1, T_sortw;
 static double T_ms[4];        /* of the last damar_trace_pts: trace_waves kernel, layout..pack on the device, whole call, inside the batches (wall) */
 static int64  T_cnt[4];       /* records, segments, deferred segments, script values */
 
 extern "C" void damar_trace_release(void)
 { DBuf *all[] = { &T_recs, &T_pts, &T_segs, &T_count, &T_dist, &T_segoff, &T_stage, &T_vf, &T_hf, &T_over, &T_ctr,
-                  &T_tlen, &T_diffs, &T_script, &T_scan, &T_bvf, &T_bhf, &T_mid, &T_segs2 };
+                  &T_tlen, &T_diffs, &T_script, &T_scan, &T_bvf, &T_bhf, &T_mid, &T_segs2, &T_key, &T_val, &T_key1, &T_val1, &T_sortw };
   for (DBuf *b : all) b->drop();
 }
 
@@ -1787,13 +1787,25 @@ static void trace_record_shape(const Path *path, const PT *p, int tspace, int *d
 /* One wave phase over `nwork` segments: the slot kernel, then the stripe kernel for what it deferred.
    kind 0 = scripts, 1 = mid points.  Returns the error flags, or ~0u after a message. */
 static u32 trace_wave_phase(TraceArgs t, int mode, int kind, u32 nwork, u32 rows, u32 maxblocks, u32 *d_ctr,
-                            hipEvent_t e1, hipEvent_t e2)
+                            u32 *d_key, u32 *d_val, hipEvent_t e1, hipEvent_t e2)
 { const u32 nblocks = std::min(maxblocks, (nwork + 63) / 64);
+  /* work order: segments with equal difference counts side by side in a wavefront */
+  static int ordered = -1;
+  if (ordered < 0)
+    { const char *e = getenv("DAMAR_TRACE_ORDER");
+      ordered = e ? atoi(e) : 1;
+    }
+  const u32 *order = NULL;
+  if (ordered)
+    { u32 *k1 = (u32 *) T_key1.need(sizeof(u32) * (size_t) nwork), *v1 = (u32 *) T_val1.need(sizeof(u32) * (size_t) nwork);
+      void *sw = T_sortw.need(damar_sort_workspace_bytes(nwork));
+      order = damar_radix_sort_u32(d_key, d_val, k1, v1, nwork, 8, sw, G_st) ? v1 : d_val;
+    }
   const size_t area = damar_trace_slot_area_cells();
-  t.vf = (short *) T_vf.need(sizeof(short) * (size_t) nblocks * area);
+  t.vf = (short *) T_vf.need((size_t) nblocks * damar_trace_slot_vf_bytes(mode, kind));
   t.hf = (signed char *) T_hf.need((size_t) nblocks * area);
   t.cap = rows;
-  t.list = NULL;  t.nwork = nwork;
+  t.list = order;  t.nwork = nwork;
   HIP_CHECK(hipMemsetAsync(d_ctr, 0, 8, G_st));
   HIP_CHECK(hipEventRecord(e1, G_st));
   damar_launch_trace_waves_slots(&t, mode, kind, nblocks, G_st);
@@ -1880,6 +1892,8 @@ static int trace_batch(const DevBlock *ad, const DevBlock *bd, int64 r0, int64 r
   u32 *d_tlen   = (u32 *) T_tlen.need(sizeof(u32) * (size_t) (nrecs + 1));
   int *d_diffs  = (int *) T_diffs.need(sizeof(int) * (size_t) nrecs);
   void *d_scan  = T_scan.need(damar_scan_workspace_bytes(nrecs));
+  u32 *d_key    = (u32 *) T_key.need(sizeof(u32) * (size_t) nwork);
+  u32 *d_val    = (u32 *) T_val.need(sizeof(u32) * (size_t) nwork);
 
   hipEvent_t e0, e1, e2, e3;
   HIP_CHECK(hipEventCreate(&e0));  HIP_CHECK(hipEventCreate(&e1));
@@ -1889,7 +1903,7 @@ static int trace_batch(const DevBlock *ad, const DevBlock *bd, int64 r0, int64 r
     HIP_CHECK(hipMemcpyAsync(d_pts, pts.data(), pts.size(), hipMemcpyHostToDevice, G_st));
   HIP_CHECK(hipMemsetAsync(d_ctr, 0, 256, G_st));
   HIP_CHECK(hipEventRecord(e0, G_st));
-  damar_launch_trace_layout(d_recs, nrecs, d_pts, tbytes, tspace, ad, bd, d_segs, d_ctr + 2, G_st);
+  damar_launch_trace_layout(d_recs, nrecs, d_pts, tbytes, tspace, ad, bd, d_segs, d_key, d_val, d_ctr + 2, G_st);
   TraceArgs t;
   memset(&t, 0, sizeof(t));
   t.segs = d_segs;
@@ -1899,13 +1913,13 @@ static int trace_batch(const DevBlock *ad, const DevBlock *bd, int64 r0, int64 r
   t.over = d_over;  t.over_cap = nwork;  t.nover = d_ctr;  t.need = d_ctr + 1;  t.err = d_ctr + 2;
   if (kind)
     { t.mid = (int *) T_mid.need(sizeof(int) * 2 * (size_t) nsegs);
-      if (trace_wave_phase(t, mode, 1, nsegs, rows, maxblocks, d_ctr, e1, e2) == ~0u)
+      if (trace_wave_phase(t, mode, 1, nsegs, rows, maxblocks, d_ctr, d_key, d_val, e1, e2) == ~0u)
         return 1;
       TraceSeg *d_segs2 = (TraceSeg *) T_segs2.need(sizeof(TraceSeg) * (size_t) nwork);
-      damar_launch_trace_mid_layout(d_recs, nrecs, d_segs, t.mid, ad, bd, d_segs2, d_ctr + 2, G_st);
+      damar_launch_trace_mid_layout(d_recs, nrecs, d_segs, t.mid, ad, bd, d_segs2, d_key, d_val, d_ctr + 2, G_st);
       t.segs = d_segs = d_segs2;
     }
-  if (trace_wave_phase(t, mode, 0, nwork, rows, maxblocks, d_ctr, e1, e2) == ~0u)
+  if (trace_wave_phase(t, mode, 0, nwork, rows, maxblocks, d_ctr, d_key, d_val, e1, e2) == ~0u)
     return 1;
   damar_launch_trace_gather(d_recs, nrecs, kind, d_count, d_dist, d_segoff, d_tlen, d_diffs, G_st);
   u64 *d_tot = (u64 *) ((char *) d_ctr + 64);
