@@ -148,7 +148,8 @@ struct Stripe
    keep every row. */
 template <int RING>
 struct Slots
-{ u8 *vf;  signed char *hf;                /* already offset by the lane */
+{ u8 *vf;  signed char *hf;                /* the wavefront's area: uniform, so that accesses are scalar base + lane offset */
+  u32 lane;
   int del, low0, hgh0, rows;
   static const int recompute = RING;
   __device__ __forceinline__ void shape(int d)
@@ -166,8 +167,8 @@ struct Slots
   }
   __device__ __forceinline__ int slot(int D, int k) const  { return k >= del ? above(D, k) : below(D, k); }
   __device__ __forceinline__ int vrow(int D) const         { return RING ? ((D + 2) & 3) : D + 2; }
-  __device__ __forceinline__ int vi(int D, int sl) const   { return (vrow(D) * SLOT_RS + sl) * 64; }
-  __device__ __forceinline__ int hi(int D, int sl) const   { return ((D + 2) * SLOT_RS + sl) * 64; }
+  __device__ __forceinline__ u32 vi(int D, int sl) const   { return (u32) ((vrow(D) * SLOT_RS + sl) * 64) + lane; }
+  __device__ __forceinline__ u32 hi(int D, int sl) const   { return (u32) (((D + 2) * SLOT_RS + sl) * 64) + lane; }
   __device__ __forceinline__ bool fits(int D) const
   { const int m = D >> 1;
     return D + 2 < rows && hgh0 + m + 1 - del < SLOT_SS && del - (low0 - m - 1) < SLOT_SS;
@@ -434,8 +435,9 @@ void trace_waves_slots(TraceArgs t)
   const size_t area = (size_t) SLOT_ROWS * SLOT_RS * 64;
   const int ring = (MODE == 0 && KIND == 0);               /* the mid point is read from an older row: keep them all */
   Slots<ring> w;
-  w.vf = (u8 *) t.vf + (size_t) blockIdx.x * (ring ? (size_t) 4 * SLOT_RS * 64 : area) + lane;
-  w.hf = t.hf + (size_t) blockIdx.x * area + lane;
+  w.vf = (u8 *) t.vf + (size_t) blockIdx.x * (ring ? (size_t) 4 * SLOT_RS * 64 : area);
+  w.hf = t.hf + (size_t) blockIdx.x * area;
+  w.lane = (u32) lane;
   w.rows = min((int) t.cap, SLOT_ROWS);
   u32 *const la = lds + lane, *const lb = lds + SLOT_WORDS * 64 + lane;
   const u32 nbatch = (t.nwork + 63) / 64;
