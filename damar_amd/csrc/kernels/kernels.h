@@ -165,6 +165,7 @@ typedef struct
   int *stage;  u32 *count;  int *dist;
   int *mid;                             /* kind 1: A and B offset of each segment's mid point */
   u32 *over;  u32 over_cap;  u32 *nover;  u32 *need;  u32 *err;
+  u32 *next;                            /* slot kernel: next batch of 64 segments to hand out */
 } TraceArgs;
 
 #define DAMAR_TRACE_ERR_POINTS 1u       /* trace point out of bounds (align.c:5575)   */

@@ -58,12 +58,12 @@ void trace_layout(const TraceRecIn *__restrict__ recs, u32 nrecs, const PT *__re
       g.mn = (u32) M | ((u32) N << 16);
       /* the segment's own difference count (0 for a record without trace points) orders the work: lanes of
          one wavefront should need about the same number of waves */
-      const u32 own = tlen >= 2 ? min((u32) p[2 * s], 255u) : 0u;
+      const u32 own = tlen >= 2 ? min((u32) p[2 * s], 255u) : 0u;     /* (sorted on 255 - own: heaviest first) */
       g.flags = (in.flags & 3u) | ((u32) min(in.dmax, 65535) << 8) | (own << 24);
       g.stage = so;
       g.rec = r;
       segs[in.seg0 + s] = g;
-      key[in.seg0 + s] = own;
+      key[in.seg0 + s] = 255u - own;
       val[in.seg0 + s] = in.seg0 + s;
       so += (u32) (in.dmax + (del < 0 ? -del : del));
       ab = ae;
@@ -73,7 +73,7 @@ void trace_layout(const TraceRecIn *__restrict__ recs, u32 nrecs, const PT *__re
     { atomicOr(err, DAMAR_TRACE_ERR_POINTS);
       for (s = 0; s < nseg; s++)                          /* void segments: the host stops on the flag */
         { TraceSeg g = {};  g.rec = r;  g.flags = 4u;  segs[in.seg0 + s] = g;
-          key[in.seg0 + s] = 0;  val[in.seg0 + s] = in.seg0 + s;
+          key[in.seg0 + s] = 255u;  val[in.seg0 + s] = in.seg0 + s;
         }
     }
 }
@@ -442,8 +442,13 @@ void trace_waves_slots(TraceArgs t)
   u32 *const la = lds + lane, *const lb = lds + SLOT_WORDS * 64 + lane;
   const u32 nbatch = (t.nwork + 63) / 64;
 
-  for (u32 batch = blockIdx.x; batch < nbatch; batch += gridDim.x)
-    { const u32 it = batch * 64 + (u32) lane;
+  for (;;)
+    { /* batches are handed out in order (heaviest segments first), one atomic per wavefront */
+      u32 batch = 0;
+      if (lane == 0) batch = atomicAdd(t.next, 1u);
+      batch = (u32) __builtin_amdgcn_readfirstlane((int) batch);
+      if (batch >= nbatch) break;
+      const u32 it = batch * 64 + (u32) lane;
       if (it >= t.nwork) continue;
       const u32 s = t.list ? t.list[it] : it;
       const TraceSeg g = t.segs[s];
@@ -576,7 +581,7 @@ void trace_mid_layout(const TraceRecIn *__restrict__ recs, u32 nrecs, const Trac
             }
         }
       out[in.seg0 + r + i] = g;
-      key[in.seg0 + r + i] = own;
+      key[in.seg0 + r + i] = 255u - own;
       val[in.seg0 + r + i] = in.seg0 + r + i;
       as = af;
       bs = bf;

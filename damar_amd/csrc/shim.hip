@@ -1806,7 +1806,9 @@ static u32 trace_wave_phase(TraceArgs t, int mode, int kind, u32 nwork, u32 rows
   t.hf = (signed char *) T_hf.need((size_t) nblocks * area);
   t.cap = rows;
   t.list = order;  t.nwork = nwork;
+  t.next = d_ctr + 4;
   HIP_CHECK(hipMemsetAsync(d_ctr, 0, 8, G_st));
+  HIP_CHECK(hipMemsetAsync(d_ctr + 4, 0, 4, G_st));
   HIP_CHECK(hipEventRecord(e1, G_st));
   damar_launch_trace_waves_slots(&t, mode, kind, nblocks, G_st);
   HIP_CHECK(hipEventRecord(e2, G_st));
