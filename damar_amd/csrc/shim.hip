@@ -1979,8 +1979,11 @@ static int trace_expand(damar_dev_block *ablk, int afirst, damar_dev_block *bblk
   *script_out = NULL;
   std::vector<TraceRecIn> recs;
   std::vector<u8> pts;
-  const u32 max_segs = 1u << 24;
+  u32 max_segs = 1u << 24;                                   /* per batch: segments, staging slots */
   const u64 max_slots = 1ull << 30;
+  { const char *e = getenv("DAMAR_TRACE_MAXSEGS");           /* test hook: many small batches */
+    if (e && atoi(e) > 0) max_segs = (u32) atoi(e);
+  }
   int64 r0 = 0;
   u32   nsegs = 0;
   u64   nslots = 0;

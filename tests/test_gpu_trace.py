@@ -69,6 +69,22 @@ def test_trace_expansion_small_stripes_take_the_deferred_launch(built, tmp_path)
     assert not bad, bad
 
 
+def test_trace_expansion_in_many_batches(built, tmp_path):
+    """A file is cut into batches of at most 2^24 segments; with the limit lowered to 3000 the golden files take
+    up to a hundred batches each, whose scripts, offsets and difference counts must concatenate unchanged."""
+    jobs, want = [], []
+    for fixture, mid in (("trace_ref_md5.txt", False), ("trace_mid_ref_md5.txt", True)):
+        ref = {(n, l, m): h for h, n, l, m in ref_lines(fixture)}
+        for name in ("tiny_I", "prod", "tan_tandem"):
+            c = read_case(name)
+            for las in c["las"]:
+                jobs.append((c, las, 0, mid))
+                want.append(ref[(name, las, 0)])
+    got = run_jobs(jobs, tmp_path, {"DAMAR_TRACE_MAXSEGS": "3000"})
+    bad = [(j[0]["name"], j[1], j[3]) for j, g, w in zip(jobs, got, want) if g != w]
+    assert not bad, bad
+
+
 def test_compute_trace_pts_c_abi_single_record(built):
     """align.h's Compute_Trace_PTS(align, work, tspace, mode) for single records against the oracle."""
     from damar_amd import api
