@@ -40,7 +40,23 @@ for it in range(n):
                 if open(os.path.join(dp, f), "rb").read() != open(os.path.join(gdir, rel), "rb").read():
                     ok = False
                     print("MISMATCH", name, opts, rel, flush=True)
+    # the records' next consumer: edit scripts of one of the files, random mode / PTS or MID, GPU vs oracle
+    las = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(gdir) for f in fs if f.endswith(".las"))
+    tr = ""
+    if las:
+        f = rng.choice(las)
+        mode, mid = rng.choice([0, 0, 1, -1]), rng.choice([0, 1])
+        g, oo = os.path.join(w, "g.bin"), os.path.join(w, "o.bin")
+        r1 = subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "lastrace"), "-m%d" % mode] + (["-M"] if mid else []) +
+                            [os.path.join(gdir, "G"), os.path.join(gdir, "G"), f, g])
+        r2 = subprocess.run([os.path.join(ROOT, "oracle", "oracle_lastrace"), os.path.join(gdir, "G"), f, oo, str(mode)] +
+                            (["mid"] if mid else []))
+        same = r1.returncode == r2.returncode and (r1.returncode != 0 or open(g, "rb").read() == open(oo, "rb").read())
+        tr = " trace(m%d,%s)=%s" % (mode, "MID" if mid else "PTS", "ok" if same else "BAD")
+        if r1.returncode != 0:
+            tr += "[both report a bad alignment]" if same else "[exit codes differ]"
+        ok = ok and same
     bad += not ok
-    print(it, name, " ".join(opts), "ok" if ok else "BAD", flush=True)
+    print(it, name, " ".join(opts), ("ok" if ok else "BAD") + tr, flush=True)
     shutil.rmtree(w)
 print("combos", n, "bad", bad)
