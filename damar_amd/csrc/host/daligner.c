@@ -51,6 +51,17 @@ static void check_reads(const HITS_DB *b, const char *name, int kmer)     /* dal
       }
 }
 
+/* DAMAR_CLIPROF=1: wall clock of the driver's phases on stderr at exit */
+#include <time.h>
+static double P_ms[8];
+static const char *P_name[8] = { "read_block", "Sort_Kmers", "Match_Filter", "complement", "write_submit", "drain", "", "" };
+static double wall_ms(void)
+{ struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+#define TIMED(slot, stmt) do { double t0_ = wall_ms(); stmt; P_ms[slot] += wall_ms() - t0_; } while (0)
+
 int main(int argc, char *argv[])
 { HITS_DB ablock, bblock, *cblock;
   char   *afile, *aroot;
@@ -132,8 +143,11 @@ int main(int argc, char *argv[])
     damar_hip_init(gpu);
 
   afile = argv[optind++];
-  if (damar_read_block(afile, &ablock))
-    exit(1);
+  { double t0_ = wall_ms();
+    if (damar_read_block(afile, &ablock))
+      exit(1);
+    P_ms[0] += wall_ms() - t0_;
+  }
   if (damar_load_masks(&ablock, mask, mtop))
     { printf("[ERROR] - Unable to load track!\n");
       exit(1);
@@ -177,8 +191,10 @@ int main(int argc, char *argv[])
       char *broot = NULL;
 
       if (!same)
-        { if (damar_read_block(bfile, &bblock))
+        { double t0_ = wall_ms();
+          if (damar_read_block(bfile, &bblock))
             exit(1);
+          P_ms[0] += wall_ms() - t0_;
           if (damar_load_masks(&bblock, mask, mtop))
             { printf("[ERROR] - Unable to load track!\n");
               exit(1);
@@ -189,7 +205,7 @@ int main(int argc, char *argv[])
       if (i == optind)
         { if (VERBOSE)
             printf("\nBuilding index for %s\n", aroot);
-          aindex = Sort_Kmers(&ablock, &alen);
+          TIMED(1, aindex = Sort_Kmers(&ablock, &alen));
         }
       if (!same)
         { char *d1 = NULL, *d2 = NULL;
@@ -198,29 +214,29 @@ int main(int argc, char *argv[])
             make_subdir(&bblock, runid);
           if (VERBOSE)
             printf("\nBuilding index for %s\n", broot);
-          bindex = Sort_Kmers(&bblock, &blen);
-          Match_Filter(aroot, &ablock, broot, &bblock, aindex, alen, bindex, blen, 0, spec);
+          TIMED(1, bindex = Sort_Kmers(&bblock, &blen));
+          TIMED(2, Match_Filter(aroot, &ablock, broot, &bblock, aindex, alen, bindex, blen, 0, spec));
           /* the reference complements B in place (daligner.c:1034); here the host tail of the
              forward comparison may still be reading B's bases on its thread, so the complement
              is a copy (released with the block after the drain) */
-          cblock = damar_complement_block(&bblock, 0);
+          TIMED(3, cblock = damar_complement_block(&bblock, 0));
           cbases[npending] = ((char *) cblock->bases) - 1;
           if (VERBOSE)
             printf("\nBuilding index for c(%s)\n", broot);
-          bindex = Sort_Kmers(cblock, &blen);
-          Match_Filter(aroot, &ablock, broot, cblock, aindex, alen, bindex, blen, 1, spec);
+          TIMED(1, bindex = Sort_Kmers(cblock, &blen));
+          TIMED(2, Match_Filter(aroot, &ablock, broot, cblock, aindex, alen, bindex, blen, 1, spec));
 
           last = (bblock.part < ablock.part) ? bblock.ufirst + bblock.nreads - 1
                                              : ablock.ufirst + ablock.nreads - 1;
           if (ablock.part > 0) d1 = damar_get_dir(runid, ablock.part);
           if (bblock.part > 0) d2 = damar_get_dir(runid, bblock.part);
-          damar_write_overlaps(spec, d1, d2, aroot, broot, last);
+          TIMED(4, damar_write_overlaps(spec, d1, d2, aroot, broot, last));
           free(d1);
           free(d2);
           free(broot);
           pending[npending++] = bblock;            /* closed after the drain below */
           if (npending >= 4)
-            { damar_async_drain();
+            { TIMED(5, damar_async_drain());
               while (npending > 0)
                 { npending -= 1;
                   free(cbases[npending]);
@@ -230,25 +246,31 @@ int main(int argc, char *argv[])
         }
       else
         { char *d1 = NULL;
-          Match_Filter(aroot, &ablock, aroot, &ablock, aindex, alen, aindex, alen, 0, spec);
-          cblock = damar_complement_block(&ablock, 0);
+          TIMED(2, Match_Filter(aroot, &ablock, aroot, &ablock, aindex, alen, aindex, alen, 0, spec));
+          TIMED(3, cblock = damar_complement_block(&ablock, 0));
           if (VERBOSE)
             printf("\nBuilding index for c(%s)\n", aroot);
-          bindex = Sort_Kmers(cblock, &blen);
-          Match_Filter(aroot, &ablock, aroot, cblock, aindex, alen, bindex, blen, 1, spec);
+          TIMED(1, bindex = Sort_Kmers(cblock, &blen));
+          TIMED(2, Match_Filter(aroot, &ablock, aroot, cblock, aindex, alen, bindex, blen, 1, spec));
           if (ablock.part > 0) d1 = damar_get_dir(runid, ablock.part);
-          damar_write_overlaps(spec, d1, NULL, aroot, aroot, ablock.ufirst + ablock.nreads - 1);
+          TIMED(4, damar_write_overlaps(spec, d1, NULL, aroot, aroot, ablock.ufirst + ablock.nreads - 1));
           free(d1);
-          damar_async_drain();                     /* the complemented copy is a static record */
+          TIMED(5, damar_async_drain());                     /* the complemented copy is a static record */
           free(((char *) cblock->bases) - 1);
         }
     }
-  damar_async_drain();
+  TIMED(5, damar_async_drain());
   while (npending > 0)
     { npending -= 1;
       free(cbases[npending]);
       damar_close_block(&pending[npending]);
     }
   damar_set_async(0);
+  if (getenv("DAMAR_CLIPROF"))
+    { fprintf(stderr, "cli: wall ms:");
+      for (i = 0; i < 6; i++)
+        fprintf(stderr, " %s=%.1f", P_name[i], P_ms[i]);
+      fprintf(stderr, "\n");
+    }
   return 0;
 }

@@ -104,7 +104,7 @@ typedef struct
   int  tspace, ave_path, reach;
   const short *score, *table;      /* SCORE[32768], TABLE[32768] */
   /* per-slot scratch */
-  void *state;   u64 state_stride;   int span;        /* ping-pong diagonal state */
+  void *state;   u64 state_stride;   int span;        /* ping-pong diagonal state: rings of `span` (2^n) diagonals */
   int  *marks;   u64 marks_stride;                    /* NA/NB                     */
   void *cells;   u32 cell_cap;                        /* pebbles                   */
   int  *buckets; u64 bucket_stride;  int bwidth;      /* score|lastp|lasta          */
@@ -122,6 +122,7 @@ typedef struct
 #define DAMAR_ERR_RECS    2u
 #define DAMAR_ERR_TPOOL   4u
 #define DAMAR_ERR_BAND    8u
+#define DAMAR_ERR_WIDE   16u    /* a band outgrew the ring of diagonals of the slot buffers: relaunch with a larger ring */
 
 int  damar_report_waves_per_simd(void);
 void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st);

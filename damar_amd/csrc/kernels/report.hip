@@ -65,6 +65,9 @@ struct __attribute__((aligned(16))) DState
   int HAm, HBm;          /* mark of the pebble at the head of the A / B chain */
 };
 
+/* slot of diagonal e in the per-slot band arrays: the band is contiguous and never wider than the ring */
+#define RI(e) (((u32) ((e) + o)) & rmask)
+
 struct __attribute__((aligned(16))) Cell { int ptr, diag, diff, mark; };
 
 struct Tip { int a, y, d, ha, hb; };
@@ -77,7 +80,8 @@ struct WaveCtx
   int   ts, ave, reach;
   const short *score, *table;
   int   minp, maxp, aoff, boff;
-  DState *st0, *st1;        /* indexed by diagonal + koff */
+  DState *st0, *st1;        /* indexed by (diagonal + koff) modulo ring: RI() */
+  int     ring;
   int   *NA, *NB;
   int    koff;
   Cell  *cells;
@@ -280,6 +284,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
   (void) apk; (void) bpk; (void) va0; (void) vb0; (void) valen; (void) vblen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
+  const u32 rmask = (u32) uni(c.ring) - 1u;      /* the band lives in a ring of c.ring diagonals */
   const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
   const int ave = uni(c.ave), do_reach = uni(c.reach);
   const u32 cell_cap = (u32) uni((int) c.cell_cap);
@@ -628,9 +633,9 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
             s.V = rV; s.M = rM; s.HA = rHA; s.HB = rHB; s.T = rT;
             s.HAm = __hip_atomic_load(&cellbuf[rHA].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s.HBm = __hip_atomic_load(&cellbuf[rHB].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            cur[k + o] = s;
-            c.NA[k + o] = rNA;
-            c.NB[k + o] = rNB;
+            cur[RI(k)] = s;
+            c.NA[RI(k)] = rNA;
+            c.NB[RI(k)] = rNB;
           }
       }
     else
@@ -666,6 +671,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
   (void) apk; (void) bpk; (void) va0; (void) vb0; (void) valen; (void) vblen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
+  const u32 rmask = (u32) uni(c.ring) - 1u;      /* the band lives in a ring of c.ring diagonals */
   const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
   const int ave = uni(c.ave), do_reach = uni(c.reach);
   const u32 cell_cap = (u32) uni((int) c.cell_cap);
@@ -688,7 +694,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
     { if (uni((int) bseq[besty]) != 4 && uni((int) aseq[besta - besty]) != 4)              \
         more = 1;                                                                          \
       if (REV ? (low <= aclip) : (hgh >= aclip))                                           \
-        { DState s = cur[aclip + o];                                                       \
+        { DState s = cur[RI(aclip)];                                                       \
           s.M = uni(s.M); s.V = uni(s.V); s.HA = uni(s.HA); s.HB = uni(s.HB);              \
           if (REV) low = aclip + 1; else hgh = aclip - 1;                                  \
           if (reachm <= s.M)                                                               \
@@ -696,7 +702,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
               reach.ha = s.HA; reach.hb = s.HB; }                                          \
         }                                                                                  \
       if (REV ? (hgh >= bclip) : (low <= bclip))                                           \
-        { DState s = cur[bclip + o];                                                       \
+        { DState s = cur[RI(bclip)];                                                       \
           s.M = uni(s.M); s.V = uni(s.V); s.HA = uni(s.HA); s.HB = uni(s.HB);              \
           if (REV) hgh = bclip - 1; else low = bclip + 1;                                  \
           if (reachm <= s.M)                                                               \
@@ -718,31 +724,37 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
         { if (lane == 0) atomicOr(errw, DAMAR_ERR_BAND);
           break;
         }
+      if ((u32) (hgh - low + 8) > rmask)          /* band + sentinels + this step's widening must fit the ring */
+        { if (lane == 0) atomicOr(errw, DAMAR_ERR_WIDE);
+          more = 0;
+          ws.bad = 1;                             /* the launch is repeated with a larger ring: no trace walk */
+          break;
+        }
       /* widen the band by one diagonal per side (align.c:675-776 / 1386-1486) */
       { int nlow = low - 1, nhgh = hgh + 1;
         const int edge = REV ? BIG : -1;
         if (nlow >= minp)
           { if (lane == 0)
-              { c.NA[nlow + o] = c.NA[nlow + 1 + o];
-                c.NB[nlow + o] = c.NB[nlow + 1 + o];
-                cur[nlow + o].V = edge;
+              { c.NA[RI(nlow)] = c.NA[RI(nlow + 1)];
+                c.NB[RI(nlow)] = c.NB[RI(nlow + 1)];
+                cur[RI(nlow)].V = edge;
               }
           }
         else
           nlow += 1;
         if (nhgh <= maxp)
           { if (lane == 0)
-              { c.NA[nhgh + o] = c.NA[nhgh - 1 + o];
-                c.NB[nhgh + o] = c.NB[nhgh - 1 + o];
-                cur[nhgh + o].V = edge;
+              { c.NA[RI(nhgh)] = c.NA[RI(nhgh - 1)];
+                c.NB[RI(nhgh)] = c.NB[RI(nhgh - 1)];
+                cur[RI(nhgh)].V = edge;
               }
           }
         else
           nhgh -= 1;
         low = nlow;  hgh = nhgh;
         if (lane == 0)
-          { cur[hgh + 1 + o].V = edge;
-            cur[low - 1 + o].V = edge;
+          { cur[RI(hgh + 1)].V = edge;
+            cur[RI(low - 1)].V = edge;
           }
         dif += 1;
       }
@@ -757,7 +769,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
           bool ahit = false, bhit = false;
 
           if (act)
-            { const int ac = cur[k + o].V, am = cur[k - 1 + o].V, ap = cur[k + 1 + o].V;
+            { const int ac = cur[RI(k)].V, am = cur[RI(k - 1)].V, ap = cur[RI(k + 1)].V;
               int from;
               if (!REV)
                 { if (ac < am) from = (am < ap) ? k + 1 : k - 1;
@@ -769,7 +781,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
                   else         from = (ac > am) ? k - 1 : k;
                   v = (from == k) ? ac - 2 : ((from == k - 1) ? am - 1 : ap - 1);
                 }
-              const DState p = cur[from + o];
+              const DState p = cur[RI(from)];
               m = p.M;  b = p.T;  ha = p.HA;  hb = p.HB;  ham = p.HAm;  hbm = p.HBm;
               if (b & HIST_TOP)
                 m -= 1;
@@ -780,8 +792,8 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
                 bhit = so.nb == 0;  ahit = so.nb != 0 && so.na == 0;
               }
               v = (y << 1) + k;
-              na = c.NA[k + o];
-              nb = c.NB[k + o];
+              na = c.NA[RI(k)];
+              nb = c.NB[RI(k)];
             }
 
           /* pebbles: cells are handed out with a ballot prefix count (align.c:859-909) */
@@ -833,9 +845,9 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
           if (act)
             { DState s;
               s.V = v; s.M = m; s.HA = ha; s.HB = hb; s.T = b; s.HAm = ham; s.HBm = hbm;
-              nxt[k + o] = s;
-              c.NA[k + o] = na;
-              c.NB[k + o] = nb;
+              nxt[RI(k)] = s;
+              c.NA[RI(k)] = na;
+              c.NB[RI(k)] = nb;
             }
 
           /* sequence ends reached in this chunk */
@@ -895,7 +907,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
         bool found = false;
         for (int kb = hgh; kb >= low && !found; kb -= 64)
           { int  k = kb - lane;
-            bool ok = (k >= low) && (REV ? (cur[k + o].V <= n) : (cur[k + o].V >= n));
+            bool ok = (k >= low) && (REV ? (cur[RI(k)].V <= n) : (cur[RI(k)].V >= n));
             u64  mk = wballot(ok);
             if (mk)
               { newh = kb - (__ffsll((long long) mk) - 1);
@@ -906,7 +918,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
           { bool f2 = false;
             for (int kb = low; kb <= newh && !f2; kb += 64)
               { int  k = kb + lane;
-                bool ok = (k <= newh) && (REV ? (cur[k + o].V <= n) : (cur[k + o].V >= n));
+                bool ok = (k <= newh) && (REV ? (cur[RI(k)].V <= n) : (cur[RI(k)].V >= n));
                 u64  mk = wballot(ok);
                 if (mk)
                   { newl = kb + (__ffsll((long long) mk) - 1);
@@ -940,6 +952,7 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
   (void) apk; (void) bpk; (void) va0; (void) vb0; (void) valen; (void) vblen;
   DState *cur = uni_ptr(c.st0), *nxt = uni_ptr(c.st1);
   const int o = uni(c.koff);
+  const u32 rmask = (u32) uni(c.ring) - 1u;      /* the band lives in a ring of c.ring diagonals */
   const int minp = uni(c.minp), maxp = uni(c.maxp), aoff = uni(c.aoff), boff = uni(c.boff);
   const int ave = uni(c.ave), do_reach = uni(c.reach);
   const u32 cell_cap = (u32) uni((int) c.cell_cap);
@@ -1282,7 +1295,7 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
   c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
   c.score = a.score;  c.table = a.table;
   c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
-  c.koff = blen + 8;
+  c.koff = blen + 8;  c.ring = a.span;
   c.cells = s.cells;  c.cell_cap = a.cell_cap;
   c.err = &a.counters[3];
   c.atr = s.atr;  c.btr = s.btr;
@@ -1464,7 +1477,7 @@ __device__ void process_read(const ReportArgs &a, const SlotScratch &s, const in
   c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
   c.score = a.score;  c.table = a.table;
   c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
-  c.koff = alen + 8;
+  c.koff = alen + 8;  c.ring = a.span;
   c.cells = s.cells;  c.cell_cap = a.cell_cap;
   c.err = &a.counters[3];
   c.atr = s.atr;  c.btr = s.btr;
@@ -1642,7 +1655,7 @@ void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
       c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
       c.score = a.score;  c.table = a.table;
       c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
-      c.koff = c.blen + 8;
+      c.koff = c.blen + 8;  c.ring = a.span;
       c.cells = s.cells;  c.cell_cap = a.cell_cap;
       c.err = &a.counters[3];
       c.atr = s.atr;  c.btr = s.btr;

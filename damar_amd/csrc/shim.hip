@@ -189,10 +189,21 @@ extern "C" int damar_hip_init(int device)
   return ndev;
 }
 
+static double Q_ms[4];      /* DAMAR_HOSTPROF: scratch_prepare, scratch_outputs */
+
+static void hostprof_at_exit(void)
+{ fprintf(stderr, "damar host wall ms (at exit):");
+  for (int i = 0; i < 8; i++)
+    fprintf(stderr, " %s=%.1f", H_name[i], H_ms[i]);
+  fprintf(stderr, " | scratch_prepare=%.1f scratch_outputs=%.1f\n", Q_ms[0], Q_ms[1]);
+}
+
 static void ensure_init(void)
 { if (!G_ready)
     { const char *d = getenv("DAMAR_DEVICE");
       damar_hip_init(d ? atoi(d) : 0);
+      if (getenv("DAMAR_HOSTPROF"))
+        atexit(hostprof_at_exit);
     }
 }
 
@@ -557,19 +568,38 @@ static int default_slots(void)
   return G_prop.multiProcessorCount * 4 * damar_report_waves_per_simd();      /* every wave slot of the chip */
 }
 
+static int G_ring = 0;
+
 static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 cell_cap)
 { if (G_last_d2h != NULL)        /* whatever is launched next overwrites the record buffers */
     { HIP_CHECK(hipStreamWaitEvent(G_st, G_last_d2h, 0));
       G_last_d2h = NULL;
     }
-  int span   = amax + bmax + 64;
+  /* The band state of a slot (used only while a band is wider than the 64 lanes) is a ring of G_ring
+     diagonals, not one entry per diagonal of the pair: 4096 instead of alen + blen keeps the scratch of
+     8192 slots at a few GB (the driver stalls for seconds whenever a process first grows past ~24 GB).
+     A band that outgrows the ring raises DAMAR_ERR_WIDE and the launch is repeated with a larger one. */
+  if (G_ring == 0)
+    { const char *e = getenv("DAMAR_RING");
+      G_ring = e ? atoi(e) : 4096;
+      if (G_ring < 128) G_ring = 128;
+      while (G_ring & (G_ring - 1)) G_ring += G_ring & -G_ring;      /* next power of two */
+    }
+  int span = 128;
+  while (span < amax + bmax + 72) span *= 2;
+  if (span > G_ring) span = G_ring;
   int bwidth = (amax >> binshift) - ((-bmax) >> binshift) + 1;
   int mtp    = 2 * (std::max(amax, bmax) / tspace + 2) + 8;
   u32 tstr   = (u32) (4 * mtp + 32);
+  /* the longest reads differ a little from block to block: sizes are taken with a quarter of headroom so
+     that a plan line does not rebuild the scratch for every B block */
+  if (RS.bwidth < bwidth)      bwidth = ((bwidth + bwidth / 4) + 255) & ~255;
+  if (RS.ttmp_stride < tstr)   tstr   = ((tstr + tstr / 4) + 255u) & ~255u;
   int nslots = default_slots();
   bool grow = RS.span < span || RS.bwidth < bwidth || RS.cell_cap < cell_cap || RS.ttmp_stride < tstr;
   if (grow || (RS.nslots != nslots && RS.nslots_wanted != nslots))
-    { HIP_CHECK(hipStreamSynchronize(G_st));
+    { const double g0 = now_ms();
+      HIP_CHECK(hipStreamSynchronize(G_st));
       if (RS.state)   { HIP_CHECK(hipFree(RS.state)); HIP_CHECK(hipFree(RS.marks)); HIP_CHECK(hipFree(RS.cells));
                         HIP_CHECK(hipFree(RS.buckets)); HIP_CHECK(hipFree(RS.ttmp)); RS.state = NULL; }
       /* the scratch of all wave slots must fit what is left of HBM (very long reads: the
@@ -580,7 +610,9 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
         const u64 nspan = (u64) std::max(RS.span, span), ncell = std::max(RS.cell_cap, cell_cap);
         const u64 per = damar_report_state_stride((int) nspan) + 4ull * 2 * nspan + 16ull * ncell +
                         4ull * (3ull * std::max(RS.bwidth, bwidth) + 16) + 2ull * std::max(RS.ttmp_stride, tstr);
+        const double g1 = now_ms();
         HIP_CHECK(hipMemGetInfo(&freeb, &totb));
+        if (getenv("DAMAR_HOSTPROF")) fprintf(stderr, "damar: scratch grow: sync+free %.1f ms, hipMemGetInfo %.1f ms\n", g1 - g0, now_ms() - g1);
         const u64 budget = (u64) (freeb * 0.6);
         if ((u64) nslots * per > budget)
           { int fit = (int) (budget / per);
@@ -602,6 +634,7 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
       RS.state_stride  = damar_report_state_stride(RS.span);
       RS.marks_stride  = (u64) 2 * RS.span;
       RS.bucket_stride = (u64) 3 * RS.bwidth + 16;
+      const double g2 = now_ms();
       RS.state   = dmalloc((size_t) RS.state_stride * nslots);
       RS.marks   = (int *) dmalloc(sizeof(int) * (size_t) RS.marks_stride * nslots);
       RS.cells   = dmalloc((size_t) 16 * RS.cell_cap * nslots);
@@ -609,6 +642,10 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
       RS.ttmp    = (u16 *) dmalloc(sizeof(u16) * (size_t) RS.ttmp_stride * nslots);
       HIP_CHECK(hipMemsetAsync(RS.state, 0, (size_t) RS.state_stride * nslots, G_st));
       HIP_CHECK(hipMemsetAsync(RS.marks, 0, sizeof(int) * (size_t) RS.marks_stride * nslots, G_st));
+      if (getenv("DAMAR_HOSTPROF"))
+        fprintf(stderr, "damar: scratch grow: 5 allocations of %.2f GB in all %.1f ms (span %d bwidth %d cells %u)\n",
+                ((double) RS.state_stride + 4. * RS.marks_stride + 16. * RS.cell_cap + 4. * RS.bucket_stride + 2. * RS.ttmp_stride) * nslots / 1073741824.,
+                now_ms() - g2, RS.span, RS.bwidth, RS.cell_cap);
     }
   if (RS.counters == NULL)
     { RS.counters = (u32 *) dmalloc(64);
@@ -1308,8 +1345,12 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
         { cell_cap = 64;  rec_cap = 16;  tp_cap = 512; }
       for (int attempt = 0; ; attempt++)
         { ReportArgs ra;
+          double q0 = now_ms();
           scratch_prepare(ablock->maxlen, bblock->maxlen, P_binshift, ts, cell_cap);
+          double q1 = now_ms();
           scratch_outputs(rec_cap, tp_cap);
+          double q2 = now_ms();
+          Q_ms[0] += q1 - q0;  Q_ms[1] += q2 - q1;
           fill_report_args(&ra, aidx->blk, bidx->blk, comp, self, spec);
           ra.keys = keys;  ra.vals = vals;  ra.nhits = total;
           ra.work = work;  ra.nwork = nwork;
@@ -1327,7 +1368,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
           G_ms[DAMAR_T_REPORT] += lap(4, 5);
           if (hc[3] == 0)
             break;
-          if ((hc[3] & DAMAR_ERR_BAND) && !(hc[3] & DAMAR_ERR_CELLS))
+          if ((hc[3] & DAMAR_ERR_BAND) && !(hc[3] & (DAMAR_ERR_CELLS | DAMAR_ERR_WIDE)))
             { fprintf(stderr, "damar: FATAL: a Local_Alignment wave exceeded its loop bound (where=%u)\n", hc[6]);
               die();
             }
@@ -1336,6 +1377,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
               die();
             }
           if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
+          if (hc[3] & DAMAR_ERR_WIDE)  G_ring *= 4;
           if (hc[3] & DAMAR_ERR_RECS)  rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
           if (hc[3] & DAMAR_ERR_TPOOL)
             { if (tp_cap >= 0xe0000000u)
@@ -1482,11 +1524,12 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
         G_ms[DAMAR_T_REPORT] = lap(4, 5);
         if (hc[3] == 0)
           break;
-        if (((hc[3] & DAMAR_ERR_BAND) && !(hc[3] & DAMAR_ERR_CELLS)) || attempt >= 6)
+        if (((hc[3] & DAMAR_ERR_BAND) && !(hc[3] & (DAMAR_ERR_CELLS | DAMAR_ERR_WIDE))) || attempt >= 6)
           { fprintf(stderr, "damar: FATAL: tandem report kernel failed (flags %u, where=%u)\n", hc[3], hc[6]);
             die();
           }
         if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
+        if (hc[3] & DAMAR_ERR_WIDE)  G_ring *= 4;
         if (hc[3] & DAMAR_ERR_RECS)  rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
         if (hc[3] & DAMAR_ERR_TPOOL) tp_cap  = std::max(2 * tp_cap, hc[2] + 65536);
       }
@@ -1588,11 +1631,12 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
       HIP_CHECK(hipGetLastError());
       if (hc[3] == 0)
         break;
-      if (((hc[3] & DAMAR_ERR_BAND) && !(hc[3] & DAMAR_ERR_CELLS)) || attempt >= 6)
+      if (((hc[3] & DAMAR_ERR_BAND) && !(hc[3] & (DAMAR_ERR_CELLS | DAMAR_ERR_WIDE))) || attempt >= 6)
         { fprintf(stderr, "damar: FATAL: batch Local_Alignment failed (flags %u, where=%u)\n", hc[3], hc[6]);
           die();
         }
       if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
+      if (hc[3] & DAMAR_ERR_WIDE)  G_ring *= 4;
       if (hc[3] & DAMAR_ERR_TPOOL)
         { HIP_CHECK(hipFree(dt));
           return -1;

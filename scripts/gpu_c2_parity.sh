@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 W=${WORKDIR:-/dev/shm/damar_c2}
 J=${J:-16}
 rm -rf "$W" && mkdir -p "$W/ref" "$W/gpu" && cd "$W"
-$ROOT/damar_amd/bin/simdb . SIM ${GENOME:-27} -c20 -r${SEED:-2} -e.15 -S${BLOCK:-135} > nblocks.txt
+$ROOT/damar_amd/bin/simdb . SIM ${GENOME:-27} -c${COV:-20} -r${SEED:-2} -e.15 -S${BLOCK:-135} > nblocks.txt
 NB=$(cat nblocks.txt); echo "blocks: $NB"
 for d in ref gpu; do for f in SIM.db .SIM.idx .SIM.bps; do ln -s $W/$f $W/$d/$f; done; done
 echo "== reference plan (-j$J)"

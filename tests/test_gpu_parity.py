@@ -574,6 +574,75 @@ def test_gpu_buffer_overflow_relaunch(gpu, tmp_path, name):
     assert compare_las(case, str(tmp_path)) == []
 
 
+def _write_db(directory, root, reads):
+    """A one-block DB (.db stub, .idx, .bps in the layout of db/DB.h) from Python sequences over 0..3."""
+    import struct
+    from damar_amd import api
+    os.makedirs(directory, exist_ok=True)
+    tot = sum(len(r) for r in reads)
+    cnt = [sum(r.count(c) for r in reads) for c in range(4)]
+    hdr = api.HITS_DB()
+    hdr.ureads = len(reads)
+    for c in range(4):
+        hdr.freq[c] = cnt[c] / tot
+    hdr.maxlen = max(len(r) for r in reads)
+    hdr.totlen = tot
+    with open(os.path.join(directory, ".%s.idx" % root), "wb") as idx, open(os.path.join(directory, ".%s.bps" % root), "wb") as bps:
+        idx.write(bytes(hdr))
+        off = 0
+        for r in reads:
+            rec = api.HITS_READ()
+            rec.rlen, rec.boff, rec.coff, rec.flags = len(r), off, -1, 0x800
+            idx.write(bytes(rec))
+            packed = bytearray((len(r) + 3) // 4)
+            for i, c in enumerate(r):
+                packed[i >> 2] |= c << (6 - 2 * (i & 3))
+            bps.write(bytes(packed))
+            off += len(packed)
+    with open(os.path.join(directory, "%s.db" % root), "w") as f:
+        f.write("files = %9d\n  %9d %s %s\n" % (1, len(reads), "syn", "Syn"))
+        f.write("blocks = %9d\nsize = %9d\n %9d\n %9d\n" % (1, 200, 0, len(reads)))
+
+
+def test_gpu_band_ring_overflow_relaunch(gpu, tmp_path):
+    """Bands wider than the wavefront live in per-slot rings of diagonals (4096 by default); a band that
+    outgrows its ring raises a flag and the launch is repeated with larger rings.  Reads made of noisy
+    short-period tandem arrays at -e.55 keep up to 240 diagonals alive: with rings of 128 diagonals (DAMAR_RING)
+    the relaunch must happen and the .las must equal the oracle's, as it must with the default rings."""
+    import subprocess
+    rng = random.Random(1)
+    unit = [rng.randrange(4) for _ in range(3)]
+    core = [rng.randrange(4) for _ in range(900)] + unit * 1500 + [rng.randrange(4) for _ in range(900)]
+
+    def noisy(seq, rate):
+        out = []
+        for c in seq:
+            x = rng.random()
+            if x < rate / 3:
+                continue
+            if x < 2 * rate / 3:
+                out += [rng.randrange(4), c]
+            elif x < rate:
+                out.append((c + 1 + rng.randrange(3)) % 4)
+            else:
+                out.append(c)
+        return out
+    reads = [noisy(core, .15) for _ in range(8)]       # the oracle reports bands up to 240 diagonals at -e.55
+    odir = str(tmp_path / "o")
+    _write_db(odir, "G", reads)
+    opts = ["-k14", "-j4", "-l800", "-e.55"]
+    subprocess.run([os.path.join(ROOT, "oracle", "oracle_daligner")] + opts + ["G.1", "G.1"], cwd=odir, check=True, stdout=subprocess.DEVNULL)
+    want = open(os.path.join(odir, "d001_00001", "G.1.G.1.las"), "rb").read()
+    assert len(want) > 10000
+    for ring, expect in (("128", True), ("4096", False)):
+        gdir = str(tmp_path / ("g" + ring))
+        _write_db(gdir, "G", reads)
+        r = subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "daligner"), "-v"] + opts + ["G.1", "G.1"], cwd=gdir, check=True,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, DAMAR_RING=ring))
+        assert open(os.path.join(gdir, "d001_00001", "G.1.G.1.las"), "rb").read() == want, ring
+        assert ("retrying with larger buffers" in r.stdout) == expect, (ring, r.stdout[-600:])
+
+
 def test_gpu_successive_jobs_with_different_correlation(gpu, tmp_path):
     """Several jobs in one process with different -e (so different SCORE/TABLE): every job must use
     its own tables even when the allocator hands a new Align_Spec the address of a freed one."""
