@@ -67,6 +67,16 @@ char *damar_get_dir(int run, int block)
 }
 
 /* Open_DB (db/DB.c:457-680) + Read_All_Sequences (db/DB.c:1547-1608). */
+static uint32 unpack4[256];            /* the four bases of a .bps byte, first base in the low byte */
+
+static void unpack4_init(void)
+{ int b;
+  if (unpack4[255] != 0)
+    return;
+  for (b = 0; b < 256; b++)
+    unpack4[b] = (uint32) ((b >> 6) & 3) | ((uint32) ((b >> 4) & 3) << 8) | ((uint32) ((b >> 2) & 3) << 16) | ((uint32) (b & 3) << 24);
+}
+
 int damar_read_block(const char *name, HITS_DB *block)
 { char   *root = damar_root(name, ".db");
   char   *dir  = dir_of(name);
@@ -78,6 +88,7 @@ int damar_read_block(const char *name, HITS_DB *block)
   long long bsize;
   HITS_READ *reads;
 
+  unpack4_init();
   dot = strrchr(root, '.');
   if (dot != NULL && dot[1] != '\0' && dot[1] != '-')
     { char *end;
@@ -189,7 +200,8 @@ int damar_read_block(const char *name, HITS_DB *block)
             goto fail;
           }
         p = (unsigned char *) s;
-        for (j = clen - 1; j >= 0; j--)       /* expand in place, back to front */
+        j = clen - 1;                         /* expand in place, back to front: the last, possibly */
+        if (j >= 0)                           /* partial, byte base by base, the others 4 bases per look-up */
           { unsigned byte = p[j];
             int      q = 4 * j;
             if (q + 3 < len) s[q + 3] = (char) (byte & 3);
@@ -197,6 +209,8 @@ int damar_read_block(const char *name, HITS_DB *block)
             if (q + 1 < len) s[q + 1] = (char) ((byte >> 4) & 3);
             s[q] = (char) ((byte >> 6) & 3);
           }
+        for (j = clen - 2; j >= 0; j--)
+          memcpy(s + 4 * j, &unpack4[p[j]], 4);
         s[len] = 4;
         reads[i].boff = o;
         o += len + 1;
@@ -250,6 +264,31 @@ void damar_close_block(HITS_DB *block)
 }
 
 /* daligner.c:511-570: reverse-complement every read; freq[] is mirrored too. */
+/* daligner.c:511-570: reverse complement of one read in place.  Eight bases per step from both ends:
+   the complement of a base 0..3 is 3 - x = x ^ 3, the reversal a byte swap of the 64-bit word. */
+static void rc_inplace(char *s, int len)
+{ char *a = s, *b = s + len;
+  while (b - a >= 16)
+    { uint64 x, y;
+      b -= 8;
+      memcpy(&x, a, 8);
+      memcpy(&y, b, 8);
+      x = __builtin_bswap64(x) ^ 0x0303030303030303ull;
+      y = __builtin_bswap64(y) ^ 0x0303030303030303ull;
+      memcpy(a, &y, 8);
+      memcpy(b, &x, 8);
+      a += 8;
+    }
+  b -= 1;
+  while (a < b)
+    { char c = *a;
+      *a++ = (char) (3 - *b);
+      *b-- = (char) (3 - c);
+    }
+  if (a == b)
+    *a = (char) (3 - *a);
+}
+
 HITS_DB *damar_complement_block(HITS_DB *block, int inplace)
 { static HITS_DB cstore;
   HITS_DB *c;
@@ -275,16 +314,7 @@ HITS_DB *damar_complement_block(HITS_DB *block, int inplace)
   x = c->freq[1]; c->freq[1] = c->freq[2]; c->freq[2] = x;
 
   for (i = 0; i < block->nreads; i++)
-    { char *s = seq + block->reads[i].boff;
-      char *t = s + (block->reads[i].rlen - 1);
-      while (s < t)
-        { char u = *s;
-          *s++ = (char) (3 - *t);
-          *t-- = (char) (3 - u);
-        }
-      if (s == t)
-        *s = (char) (3 - *s);
-    }
+    rc_inplace(seq + block->reads[i].boff, block->reads[i].rlen);
 
   /* daligner.c:572-626: the mask intervals of every read are mirrored, [b,e) -> [rlen-e, rlen-b),
      which also reverses their order.  Not in place: a copy for the complemented block (released
