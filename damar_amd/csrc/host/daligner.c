@@ -3,7 +3,8 @@
  * calling the three-function filter interface of libdamar_hip.so (damar_filter.h).
  * Host code stays C; every heavy step behind Sort_Kmers / Match_Filter runs on the GPU.
  *
- * Not built yet and rejected explicitly: -m mask tracks, -b, -D (dynamic mask server).
+ * The B blocks of the line are read, checked and reverse-complemented one or two ahead on a second
+ * thread while the GPU works on the current one.  Rejected explicitly: -D (dynamic mask server).
  * -H is accepted and has no effect, exactly like the reference.
  */
 #define _GNU_SOURCE
@@ -13,6 +14,7 @@
 #include <unistd.h>
 #include <errno.h>
 #include <sys/stat.h>
+#include <pthread.h>
 
 #include "damar_filter.h"
 #include "damar_hip.h"
@@ -54,7 +56,7 @@ static void check_reads(const HITS_DB *b, const char *name, int kmer)     /* dal
 /* DAMAR_CLIPROF=1: wall clock of the driver's phases on stderr at exit */
 #include <time.h>
 static double P_ms[8];
-static const char *P_name[8] = { "read_block", "Sort_Kmers", "Match_Filter", "complement", "write_submit", "drain", "", "" };
+static const char *P_name[8] = { "read_block(2nd thread)", "Sort_Kmers", "Match_Filter", "complement(2nd thread)", "write_submit", "drain", "wait_for_block", "" };
 static double wall_ms(void)
 { struct timespec t;
   clock_gettime(CLOCK_MONOTONIC, &t);
@@ -62,8 +64,77 @@ static double wall_ms(void)
 }
 #define TIMED(slot, stmt) do { double t0_ = wall_ms(); stmt; P_ms[slot] += wall_ms() - t0_; } while (0)
 
+/* ---- B blocks prepared ahead (read_DB + Merge_Tracks + complement_DB of daligner.c:958-1034) ---- */
+typedef struct
+{ int     same;          /* the B block is the A block */
+  HITS_DB blk;           /* forward block (unused if same) */
+  HITS_DB cblk;          /* reverse-complemented copy */
+} Prepared;
+
+#define PF_DEPTH 2
+static struct
+{ char **names;  int n;
+  const char *afile;  HITS_DB *ablock;
+  char **mask;  int mtop, kmer;
+  Prepared *items;
+  int produced, consumed;
+  pthread_mutex_t mu;
+  pthread_cond_t  cv;
+} PF;
+
+static void *prepare_blocks(void *arg)
+{ int i;
+  (void) arg;
+  for (i = 0; i < PF.n; i++)
+    { Prepared *it = PF.items + i;
+      pthread_mutex_lock(&PF.mu);
+      while (PF.produced - PF.consumed >= PF_DEPTH)
+        pthread_cond_wait(&PF.cv, &PF.mu);
+      pthread_mutex_unlock(&PF.mu);
+      it->same = (strcmp(PF.afile, PF.names[i]) == 0);
+      if (!it->same)
+        { double t0 = wall_ms();
+          if (damar_read_block(PF.names[i], &it->blk))
+            exit(1);
+          if (damar_load_masks(&it->blk, PF.mask, PF.mtop))
+            { printf("[ERROR] - Unable to load track!\n");
+              exit(1);
+            }
+          check_reads(&it->blk, PF.names[i], PF.kmer);
+          P_ms[0] += wall_ms() - t0;
+        }
+      { double t0 = wall_ms();
+        damar_complement_copy(it->same ? PF.ablock : &it->blk, &it->cblk);
+        P_ms[3] += wall_ms() - t0;
+      }
+      pthread_mutex_lock(&PF.mu);
+      PF.produced += 1;
+      pthread_cond_broadcast(&PF.cv);
+      pthread_mutex_unlock(&PF.mu);
+    }
+  return NULL;
+}
+
+static Prepared *next_prepared(int i)
+{ double t0 = wall_ms();
+  pthread_mutex_lock(&PF.mu);
+  while (PF.produced <= i)
+    pthread_cond_wait(&PF.cv, &PF.mu);
+  pthread_mutex_unlock(&PF.mu);
+  P_ms[6] += wall_ms() - t0;
+  return PF.items + i;
+}
+
+static void done_with(int i)
+{ (void) i;
+  pthread_mutex_lock(&PF.mu);
+  PF.consumed += 1;
+  pthread_cond_broadcast(&PF.cv);
+  pthread_mutex_unlock(&PF.mu);
+}
+
 int main(int argc, char *argv[])
-{ HITS_DB ablock, bblock, *cblock;
+{ HITS_DB ablock;
   char   *afile, *aroot;
   void   *aindex, *bindex;
   int     alen, blen;
@@ -179,96 +250,99 @@ int main(int argc, char *argv[])
   /* The host tail (redundancy handling, sort, .las write) of a block pair runs on a worker
      thread while the GPU starts on the next pair; B blocks stay alive until it is done. */
   damar_set_async(1);
-  HITS_DB *pending = (HITS_DB *) malloc(sizeof(HITS_DB) * (size_t) (argc + 2));
-  char   **cbases = (char **) malloc(sizeof(char *) * (size_t) (argc + 2));
-  int      npending = 0;
+  { const int nb = argc - optind;
+    Prepared *pending[8];
+    int       npending = 0, k;
+    pthread_t th;
 
-  aindex = NULL;
-  alen = 0;
-  for (i = optind; i < argc; i++)
-    { char *bfile = argv[i];
-      int   same = (strcmp(afile, bfile) == 0);
-      char *broot = NULL;
+    PF.names = argv + optind;  PF.n = nb;
+    PF.afile = afile;  PF.ablock = &ablock;
+    PF.mask = mask;  PF.mtop = mtop;  PF.kmer = kmer;
+    PF.items = (Prepared *) calloc((size_t) nb + 1, sizeof(Prepared));
+    PF.produced = PF.consumed = 0;
+    pthread_mutex_init(&PF.mu, NULL);
+    pthread_cond_init(&PF.cv, NULL);
+    if (pthread_create(&th, NULL, prepare_blocks, NULL) != 0)
+      { fprintf(stderr, "daligner: cannot start the block reader thread\n");
+        exit(1);
+      }
 
-      if (!same)
-        { double t0_ = wall_ms();
-          if (damar_read_block(bfile, &bblock))
-            exit(1);
-          P_ms[0] += wall_ms() - t0_;
-          if (damar_load_masks(&bblock, mask, mtop))
-            { printf("[ERROR] - Unable to load track!\n");
-              exit(1);
-            }
-          check_reads(&bblock, bfile, kmer);
-          broot = damar_root(bfile, ".db");
-        }
-      if (i == optind)
-        { if (VERBOSE)
-            printf("\nBuilding index for %s\n", aroot);
-          TIMED(1, aindex = Sort_Kmers(&ablock, &alen));
-        }
-      if (!same)
-        { char *d1 = NULL, *d2 = NULL;
-          int   last;
-          if (SYMMETRIC)
-            make_subdir(&bblock, runid);
-          if (VERBOSE)
-            printf("\nBuilding index for %s\n", broot);
-          TIMED(1, bindex = Sort_Kmers(&bblock, &blen));
-          TIMED(2, Match_Filter(aroot, &ablock, broot, &bblock, aindex, alen, bindex, blen, 0, spec));
-          /* the reference complements B in place (daligner.c:1034); here the host tail of the
-             forward comparison may still be reading B's bases on its thread, so the complement
-             is a copy (released with the block after the drain) */
-          TIMED(3, cblock = damar_complement_block(&bblock, 0));
-          cbases[npending] = ((char *) cblock->bases) - 1;
-          if (VERBOSE)
-            printf("\nBuilding index for c(%s)\n", broot);
-          TIMED(1, bindex = Sort_Kmers(cblock, &blen));
-          TIMED(2, Match_Filter(aroot, &ablock, broot, cblock, aindex, alen, bindex, blen, 1, spec));
+    aindex = NULL;
+    alen = 0;
+    for (k = 0; k < nb; k++)
+      { char     *bfile = argv[optind + k];
+        Prepared *it;
+        char     *broot = NULL;
 
-          last = (bblock.part < ablock.part) ? bblock.ufirst + bblock.nreads - 1
-                                             : ablock.ufirst + ablock.nreads - 1;
-          if (ablock.part > 0) d1 = damar_get_dir(runid, ablock.part);
-          if (bblock.part > 0) d2 = damar_get_dir(runid, bblock.part);
-          TIMED(4, damar_write_overlaps(spec, d1, d2, aroot, broot, last));
-          free(d1);
-          free(d2);
-          free(broot);
-          pending[npending++] = bblock;            /* closed after the drain below */
-          if (npending >= 4)
-            { TIMED(5, damar_async_drain());
-              while (npending > 0)
-                { npending -= 1;
-                  free(cbases[npending]);
-                  damar_close_block(&pending[npending]);
-                }
-            }
-        }
-      else
-        { char *d1 = NULL;
-          TIMED(2, Match_Filter(aroot, &ablock, aroot, &ablock, aindex, alen, aindex, alen, 0, spec));
-          TIMED(3, cblock = damar_complement_block(&ablock, 0));
-          if (VERBOSE)
-            printf("\nBuilding index for c(%s)\n", aroot);
-          TIMED(1, bindex = Sort_Kmers(cblock, &blen));
-          TIMED(2, Match_Filter(aroot, &ablock, aroot, cblock, aindex, alen, bindex, blen, 1, spec));
-          if (ablock.part > 0) d1 = damar_get_dir(runid, ablock.part);
-          TIMED(4, damar_write_overlaps(spec, d1, NULL, aroot, aroot, ablock.ufirst + ablock.nreads - 1));
-          free(d1);
-          TIMED(5, damar_async_drain());                     /* the complemented copy is a static record */
-          free(((char *) cblock->bases) - 1);
-        }
-    }
-  TIMED(5, damar_async_drain());
-  while (npending > 0)
-    { npending -= 1;
-      free(cbases[npending]);
-      damar_close_block(&pending[npending]);
-    }
+        if (k == 0)
+          { if (VERBOSE)
+              printf("\nBuilding index for %s\n", aroot);
+            TIMED(1, aindex = Sort_Kmers(&ablock, &alen));
+          }
+        it = next_prepared(k);
+        if (!it->same)
+          { char *d1 = NULL, *d2 = NULL;
+            int   last;
+            broot = damar_root(bfile, ".db");
+            if (SYMMETRIC)
+              make_subdir(&it->blk, runid);
+            if (VERBOSE)
+              printf("\nBuilding index for %s\n", broot);
+            TIMED(1, bindex = Sort_Kmers(&it->blk, &blen));
+            TIMED(2, Match_Filter(aroot, &ablock, broot, &it->blk, aindex, alen, bindex, blen, 0, spec));
+            if (VERBOSE)
+              printf("\nBuilding index for c(%s)\n", broot);
+            TIMED(1, bindex = Sort_Kmers(&it->cblk, &blen));
+            TIMED(2, Match_Filter(aroot, &ablock, broot, &it->cblk, aindex, alen, bindex, blen, 1, spec));
+
+            last = (it->blk.part < ablock.part) ? it->blk.ufirst + it->blk.nreads - 1
+                                                : ablock.ufirst + ablock.nreads - 1;
+            if (ablock.part > 0)  d1 = damar_get_dir(runid, ablock.part);
+            if (it->blk.part > 0) d2 = damar_get_dir(runid, it->blk.part);
+            TIMED(4, damar_write_overlaps(spec, d1, d2, aroot, broot, last));
+            free(d1);
+            free(d2);
+            free(broot);
+          }
+        else
+          { char *d1 = NULL;
+            TIMED(2, Match_Filter(aroot, &ablock, aroot, &ablock, aindex, alen, aindex, alen, 0, spec));
+            if (VERBOSE)
+              printf("\nBuilding index for c(%s)\n", aroot);
+            TIMED(1, bindex = Sort_Kmers(&it->cblk, &blen));
+            TIMED(2, Match_Filter(aroot, &ablock, aroot, &it->cblk, aindex, alen, bindex, blen, 1, spec));
+            if (ablock.part > 0) d1 = damar_get_dir(runid, ablock.part);
+            TIMED(4, damar_write_overlaps(spec, d1, NULL, aroot, aroot, ablock.ufirst + ablock.nreads - 1));
+            free(d1);
+          }
+        /* the host tail of this pair may still read the two B blocks on its thread: they are released after
+           a drain, a few pairs later; the reader thread may go on to the next block right away */
+        pending[npending++] = it;
+        done_with(k);
+        if (npending >= 4)
+          { TIMED(5, damar_async_drain());
+            while (npending > 0)
+              { Prepared *p = pending[--npending];
+                damar_free_complement(&p->cblk);
+                if (!p->same)
+                  damar_close_block(&p->blk);
+              }
+          }
+      }
+    TIMED(5, damar_async_drain());
+    while (npending > 0)
+      { Prepared *p = pending[--npending];
+        damar_free_complement(&p->cblk);
+        if (!p->same)
+          damar_close_block(&p->blk);
+      }
+    pthread_join(th, NULL);
+    free(PF.items);
+  }
   damar_set_async(0);
   if (getenv("DAMAR_CLIPROF"))
     { fprintf(stderr, "cli: wall ms:");
-      for (i = 0; i < 6; i++)
+      for (i = 0; i < 7; i++)
         fprintf(stderr, " %s=%.1f", P_name[i], P_ms[i]);
       fprintf(stderr, "\n");
     }

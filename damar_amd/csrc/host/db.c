@@ -289,76 +289,88 @@ static void rc_inplace(char *s, int len)
     *a = (char) (3 - *a);
 }
 
-HITS_DB *damar_complement_block(HITS_DB *block, int inplace)
-{ static HITS_DB cstore;
-  HITS_DB *c;
-  char    *seq;
-  int      i;
-  float    x;
-
-  if (inplace)
-    { c   = block;
-      seq = (char *) block->bases;
+/* Mirror the mask intervals of every read, [b,e) -> [rlen-e, rlen-b) (which also reverses their order),
+   daligner.c:572-626: from (tano, tata) into (anno, data), which may be the same arrays. */
+static void mirror_track(const HITS_DB *block, const int64 *tano, const int *tata, int64 *anno, int *data)
+{ int i;
+  for (i = 0; i < block->nreads; i++)
+    { int   rlen = block->reads[i].rlen;
+      int64 j = tano[i + 1] - 1, k = tano[i];
+      anno[i] = tano[i];
+      while (k < j)
+        { int y = tata[j];
+          data[j--] = rlen - tata[k];
+          data[k++] = rlen - y;
+        }
+      if (k == j)
+        data[k] = rlen - tata[k];
     }
-  else
-    { int64 n = block->reads[block->nreads].boff;
-      seq = (char *) xmalloc((size_t) n + 1, "complement block");
-      *seq++ = 4;
-      memcpy(seq, block->bases, (size_t) n);
-      cstore = *block;
-      c = &cstore;
-      c->bases  = (void *) seq;
-      c->tracks = NULL;
-    }
-  x = c->freq[0]; c->freq[0] = c->freq[3]; c->freq[3] = x;
-  x = c->freq[1]; c->freq[1] = c->freq[2]; c->freq[2] = x;
+  anno[block->nreads] = tano[block->nreads];
+}
 
+/* Reverse-complemented copy of a loaded block into *out (daligner.c:511-628 on a copy): own bases and own
+   mask tracks, everything else (reads, path) shared with `block`, which must outlive it.  Re-entrant: the
+   command-line driver prepares the next block on a second thread.  Release with damar_free_complement. */
+void damar_complement_copy(const HITS_DB *block, HITS_DB *out)
+{ int64 n = block->reads[block->nreads].boff;
+  char *seq = (char *) xmalloc((size_t) n + 1, "complement block");
+  const HITS_TRACK *src;
+  float x;
+  int   i;
+
+  *seq++ = 4;
+  memcpy(seq, block->bases, (size_t) n);
+  *out = *block;
+  out->bases  = (void *) seq;
+  out->tracks = NULL;
+  x = out->freq[0]; out->freq[0] = out->freq[3]; out->freq[3] = x;
+  x = out->freq[1]; out->freq[1] = out->freq[2]; out->freq[2] = x;
   for (i = 0; i < block->nreads; i++)
     rc_inplace(seq + block->reads[i].boff, block->reads[i].rlen);
+  for (src = block->tracks; src != NULL; src = src->next)
+    { const int64 *tano = (const int64 *) src->anno;
+      HITS_TRACK  *trg = (HITS_TRACK *) xmalloc(sizeof(HITS_TRACK), "mask header");
+      trg->name = strdup(src->name);
+      trg->size = 4;
+      trg->data = xmalloc(sizeof(int) * (size_t) (tano[block->nreads] + 1), "mask data");
+      trg->anno = xmalloc(sizeof(int64) * (size_t) (block->nreads + 1), "mask index");
+      trg->next = out->tracks;
+      out->tracks = trg;
+      mirror_track(block, tano, (const int *) src->data, (int64 *) trg->anno, (int *) trg->data);
+    }
+}
 
-  /* daligner.c:572-626: the mask intervals of every read are mirrored, [b,e) -> [rlen-e, rlen-b),
-     which also reverses their order.  Not in place: a copy for the complemented block (released
-     by the next call with inplace == 0, like the static block record itself). */
-  { static HITS_TRACK *ctracks = NULL;
-    HITS_TRACK *src;
-    if (!inplace)
-      { free_tracks(ctracks);
-        ctracks = NULL;
-      }
-    for (src = block->tracks; src != NULL; src = src->next)
-      { int64 *tano = (int64 *) src->anno, *anno;
-        int   *tata = (int *) src->data, *data;
-        HITS_TRACK *trg;
-        if (inplace)
-          { anno = tano;  data = tata;  trg = src; }
-        else
-          { data = (int *) xmalloc(sizeof(int) * (size_t) (tano[block->nreads] + 1), "mask data");
-            anno = (int64 *) xmalloc(sizeof(int64) * (size_t) (block->nreads + 1), "mask index");
-            trg  = (HITS_TRACK *) xmalloc(sizeof(HITS_TRACK), "mask header");
-            trg->name = strdup(src->name);
-            trg->size = 4;
-            trg->anno = (void *) anno;
-            trg->data = (void *) data;
-            trg->next = c->tracks;
-            c->tracks = trg;
-            ctracks   = c->tracks;
-          }
-        for (i = 0; i < block->nreads; i++)
-          { int   rlen = block->reads[i].rlen;
-            int64 j = tano[i + 1] - 1, k = tano[i];
-            anno[i] = tano[i];
-            while (k < j)
-              { int y = tata[j];
-                data[j--] = rlen - tata[k];
-                data[k++] = rlen - y;
-              }
-            if (k == j)
-              data[k] = rlen - tata[k];
-          }
-        anno[block->nreads] = tano[block->nreads];
-      }
-  }
-  return c;
+void damar_free_complement(HITS_DB *c)
+{ if (c->bases != NULL)
+    free(((char *) c->bases) - 1);
+  free_tracks(c->tracks);
+  c->bases = NULL;
+  c->tracks = NULL;
+}
+
+HITS_DB *damar_complement_block(HITS_DB *block, int inplace)
+{ static HITS_DB cstore;
+  static int     have = 0;
+  HITS_TRACK *t;
+  float x;
+  int   i;
+
+  if (!inplace)
+    { /* the copy is a static record (like the reference's static cblock, daligner.c:529): its mask tracks
+         are released by the next call, its bases belong to the caller */
+      if (have)
+        free_tracks(cstore.tracks);
+      damar_complement_copy(block, &cstore);
+      have = 1;
+      return &cstore;
+    }
+  x = block->freq[0]; block->freq[0] = block->freq[3]; block->freq[3] = x;
+  x = block->freq[1]; block->freq[1] = block->freq[2]; block->freq[2] = x;
+  for (i = 0; i < block->nreads; i++)
+    rc_inplace((char *) block->bases + block->reads[i].boff, block->reads[i].rlen);
+  for (t = block->tracks; t != NULL; t = t->next)
+    mirror_track(block, (const int64 *) t->anno, (const int *) t->data, (int64 *) t->anno, (int *) t->data);
+  return block;
 }
 
 /* daligner.c:442-497 read_DB's mask part: load every named interval track of the block

@@ -72,6 +72,11 @@ void  damar_close_block(HITS_DB *block);
  * (daligner.c:511-628 complement_DB, mask tracks not supported yet). */
 HITS_DB *damar_complement_block(HITS_DB *block, int inplace);
 
+/* The same as a re-entrant copy into *out: own bases and own (mirrored) mask tracks, reads and path shared
+ * with `block`; released by damar_free_complement.  The command-line driver prepares blocks ahead with it. */
+void  damar_complement_copy(const HITS_DB *block, HITS_DB *out);
+void  damar_free_complement(HITS_DB *c);
+
 /* daligner.c:442-497 (read_DB) + 263-439 (Merge_Size, Merge_Tracks): load the named interval
  * tracks (-m options) of the block and leave their union as the single mask track on
  * block->tracks (anno = int64[nreads+1] in ints, data = [beg,end) pairs), which Sort_Kmers
