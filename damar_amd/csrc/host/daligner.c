@@ -56,7 +56,7 @@ static void check_reads(const HITS_DB *b, const char *name, int kmer)     /* dal
 /* DAMAR_CLIPROF=1: wall clock of the driver's phases on stderr at exit */
 #include <time.h>
 static double P_ms[8];
-static const char *P_name[8] = { "read_block(2nd thread)", "Sort_Kmers", "Match_Filter", "complement(2nd thread)", "write_submit", "drain", "wait_for_block", "" };
+static const char *P_name[8] = { "read_block(2nd thread)", "Sort_Kmers", "Match_Filter", "complement(2nd thread)", "write_submit", "drain", "wait_for_block", "upload(2nd thread)" };
 static double wall_ms(void)
 { struct timespec t;
   clock_gettime(CLOCK_MONOTONIC, &t);
@@ -102,10 +102,16 @@ static void *prepare_blocks(void *arg)
             }
           check_reads(&it->blk, PF.names[i], PF.kmer);
           P_ms[0] += wall_ms() - t0;
+          t0 = wall_ms();
+          damar_block_preload(&it->blk);          /* to HBM on its own stream; Sort_Kmers picks it up */
+          P_ms[7] += wall_ms() - t0;
         }
       { double t0 = wall_ms();
         damar_complement_copy(it->same ? PF.ablock : &it->blk, &it->cblk);
         P_ms[3] += wall_ms() - t0;
+        t0 = wall_ms();
+        damar_block_preload(&it->cblk);
+        P_ms[7] += wall_ms() - t0;
       }
       pthread_mutex_lock(&PF.mu);
       PF.produced += 1;
@@ -262,6 +268,7 @@ int main(int argc, char *argv[])
     PF.produced = PF.consumed = 0;
     pthread_mutex_init(&PF.mu, NULL);
     pthread_cond_init(&PF.cv, NULL);
+    damar_hip_init(gpu < 0 ? 0 : gpu);            /* before the second thread makes its first HIP call */
     if (pthread_create(&th, NULL, prepare_blocks, NULL) != 0)
       { fprintf(stderr, "daligner: cannot start the block reader thread\n");
         exit(1);
@@ -342,7 +349,7 @@ int main(int argc, char *argv[])
   damar_set_async(0);
   if (getenv("DAMAR_CLIPROF"))
     { fprintf(stderr, "cli: wall ms:");
-      for (i = 0; i < 7; i++)
+      for (i = 0; i < 8; i++)
         fprintf(stderr, " %s=%.1f", P_name[i], P_ms[i]);
       fprintf(stderr, "\n");
     }

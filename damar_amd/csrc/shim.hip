@@ -250,9 +250,45 @@ struct damar_dev_block
   int  nreads;
 };
 
+static damar_dev_block *block_upload_on(const HITS_DB *block, hipStream_t st);
+
 extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
 { ensure_init();
-  damar_dev_block *b = (damar_dev_block *) calloc(1, sizeof(damar_dev_block));
+  return block_upload_on(block, G_st);
+}
+
+/* Blocks uploaded ahead of their Sort_Kmers call (the command-line driver prepares the next B block on a
+   second thread): on their own stream, so the copy runs beside the kernels of the current block pair.
+   Sort_Kmers takes a preloaded block by the address of its bases. */
+static std::mutex PL_mu;
+static std::vector<std::pair<const void *, damar_dev_block *>> PL_ready;
+static hipStream_t PL_st = NULL;
+
+extern "C" void damar_block_preload(const HITS_DB *block)
+{ ensure_init();
+  HIP_CHECK(hipSetDevice(G_device));          /* the current device is a per-thread setting */
+  { std::lock_guard<std::mutex> lk(PL_mu);
+    if (PL_st == NULL)
+      HIP_CHECK(hipStreamCreateWithFlags(&PL_st, hipStreamNonBlocking));
+  }
+  damar_dev_block *b = block_upload_on(block, PL_st);
+  std::lock_guard<std::mutex> lk(PL_mu);
+  PL_ready.push_back(std::make_pair((const void *) block->bases, b));
+}
+
+static damar_dev_block *take_preloaded(const HITS_DB *block)
+{ std::lock_guard<std::mutex> lk(PL_mu);
+  for (size_t i = 0; i < PL_ready.size(); i++)
+    if (PL_ready[i].first == (const void *) block->bases)
+      { damar_dev_block *b = PL_ready[i].second;
+        PL_ready.erase(PL_ready.begin() + i);
+        return b;
+      }
+  return NULL;
+}
+
+static damar_dev_block *block_upload_on(const HITS_DB *block, hipStream_t st)
+{ damar_dev_block *b = (damar_dev_block *) calloc(1, sizeof(damar_dev_block));
   int    n = block->nreads;
   int64  total = block->reads[n].boff;
   if (total > 0x7fffffffll)
@@ -276,19 +312,19 @@ extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
       }
   }
   b->bases_alloc = (u8 *) dmalloc((size_t) total + 192);      /* 64 B of padding on both sides */
-  HIP_CHECK(hipMemsetAsync(b->bases_alloc, 4, (size_t) total + 192, G_st));
+  HIP_CHECK(hipMemsetAsync(b->bases_alloc, 4, (size_t) total + 192, st));
   b->boff   = (u32 *) dmalloc(sizeof(u32) * ((size_t) n + 1));
   b->coarse = (u32 *) dmalloc(sizeof(u32) * nq);
   HIP_CHECK(hipMemcpyAsync(b->bases_alloc + 63, ((const char *) block->bases) - 1, (size_t) total + 1,
-                           hipMemcpyHostToDevice, G_st));
-  HIP_CHECK(hipMemcpyAsync(b->boff, boff.data(), sizeof(u32) * ((size_t) n + 1), hipMemcpyHostToDevice, G_st));
-  HIP_CHECK(hipMemcpyAsync(b->coarse, coarse.data(), sizeof(u32) * nq, hipMemcpyHostToDevice, G_st));
-  HIP_CHECK(hipStreamSynchronize(G_st));
+                           hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(b->boff, boff.data(), sizeof(u32) * ((size_t) n + 1), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(b->coarse, coarse.data(), sizeof(u32) * nq, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
   b->d.bases  = b->bases_alloc + 64;
   b->pk_alloc = (u32 *) dmalloc(sizeof(u32) * (((size_t) total >> 4) + 1 + 2 * PK_PAD));
   b->d.pk     = b->pk_alloc + PK_PAD;
-  damar_launch_pack_bases(b->d.bases, (u32) total, b->pk_alloc + PK_PAD, G_st);
-  HIP_CHECK(hipStreamSynchronize(G_st));
+  damar_launch_pack_bases(b->d.bases, (u32) total, b->pk_alloc + PK_PAD, st);
+  HIP_CHECK(hipStreamSynchronize(st));
   b->d.boff   = b->boff;
   b->d.coarse = b->coarse;
   for (int i = 0; i < 4; i++)
@@ -305,9 +341,10 @@ extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
         moff[i] = (u32) anno[i];
       b->moff = (u32 *) dmalloc(sizeof(u32) * ((size_t) n + 1));
       b->mdat = (int *) dmalloc(sizeof(int) * ((size_t) anno[n] + 2));
-      HIP_CHECK(hipMemcpy(b->moff, moff.data(), sizeof(u32) * ((size_t) n + 1), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpyAsync(b->moff, moff.data(), sizeof(u32) * ((size_t) n + 1), hipMemcpyHostToDevice, st));
       if (anno[n] > 0)
-        HIP_CHECK(hipMemcpy(b->mdat, data, sizeof(int) * (size_t) anno[n], hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(b->mdat, data, sizeof(int) * (size_t) anno[n], hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipStreamSynchronize(st));
       b->d.moff = b->moff;
       b->d.mdat = b->mdat;
     }
@@ -541,7 +578,9 @@ extern "C" void damar_index_download(const damar_dev_index *ix, void *out)
 
 extern "C" void *Sort_Kmers(HITS_DB *block, int *len)
 { /* block->tracks, if any, is the merged mask of daligner.c:442-497: it travels with the block */
-  damar_dev_block *b = damar_block_upload(block);
+  damar_dev_block *b = take_preloaded(block);
+  if (b == NULL)
+    b = damar_block_upload(block);
   return (void *) damar_index_build(b, 1, len);
 }
 

@@ -37,6 +37,9 @@ void  damar_hip_sync(void);          /* hipDeviceSynchronize on the selected GPU
  * db/DB.c:1562-1605), read offsets, coarse position->read table. */
 typedef struct damar_dev_block damar_dev_block;
 damar_dev_block *damar_block_upload(const HITS_DB *block);
+/* The same on a stream of its own, remembered by the address of block->bases until Sort_Kmers(block) takes
+ * it: lets a second host thread upload the next block while the GPU works (one caller thread at a time). */
+void damar_block_preload(const HITS_DB *block);
 void             damar_block_free(damar_dev_block *blk);
 
 /* The opaque index that Sort_Kmers returns (filter.c:753-994): sorted k-mer codes,
