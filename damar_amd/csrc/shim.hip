@@ -88,7 +88,13 @@ static Arena G_ord  = { NULL, 0, 0 };       /* processing order of the work list
 
 static void *dmalloc(size_t n)
 { void *p = NULL;
+  static int prof = -1;
+  if (prof < 0)
+    prof = getenv("DAMAR_HOSTPROF") != NULL;
+  const double t0 = prof ? now_ms() : 0.;
   HIP_CHECK(hipMalloc(&p, n ? n : 16));
+  if (prof && now_ms() - t0 > 50.)            /* the driver's occasional multi-second allocations */
+    fprintf(stderr, "damar: hipMalloc of %.3f GB took %.0f ms\n", n / 1073741824., now_ms() - t0);
   return p;
 }
 
@@ -608,6 +614,10 @@ static int default_slots(void)
 }
 
 static int G_ring = 0;
+/* pebbles per slot to start with: an alignment drops about 200 per kb and direction; a pool that overflows is
+   quadrupled and the launch repeated.  Kept small because the driver clears what it hands out: an 8 GB pool
+   (65536 cells x 8192 slots) cost every process 0.25 - 0.8 s in hipMalloc. */
+#define DEFAULT_CELLS (1u << 14)
 
 static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 cell_cap)
 { if (G_last_d2h != NULL)        /* whatever is launched next overwrites the record buffers */
@@ -1376,7 +1386,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   HostBuf *hb = NULL;
   u32 hc[16];
   if (nwork > 0)
-    { u32 cell_cap = RS.cell_cap ? RS.cell_cap : (1u << 16);
+    { u32 cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
       u32 rec_cap  = std::max(RS.rec_cap, 2 * nwork + 4096);
       u32 tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(RS.tpool_cap, (u64) rec_cap * 256u));
       if (getenv("DAMAR_TEST_SMALL_CAPS") && RS.rec_cap == 0)      /* tests: start far too small, so that the
@@ -1544,7 +1554,7 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
   u32 hc[16];
   { const int sk = P_kmer, sh = P_hitmin, sb = P_binshift;        /* the report args read the P_* set */
     P_kmer = T_kmer;  P_hitmin = T_hitmin;  P_binshift = T_binshift;
-    u32 cell_cap = RS.cell_cap ? RS.cell_cap : (1u << 16);
+    u32 cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
     u32 rec_cap  = std::max(RS.rec_cap, (u32) (4 * ablock->nreads + 4096));
     u32 tp_cap   = std::max(RS.tpool_cap, rec_cap * 64u);
     for (int attempt = 0; ; attempt++)
@@ -1651,7 +1661,7 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
   if (ntasks <= 0)
     return 0;
   const int ts = Trace_Spacing(spec);
-  u32 cell_cap = 1u << 16, rec_cap = (u32) ntasks + 16, tp_cap = (u32) std::min<int64>(trace_cap + 1024, 0x7fffffff);
+  u32 cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS, rec_cap = (u32) ntasks + 16, tp_cap = (u32) std::min<int64>(trace_cap + 1024, 0x7fffffff);
   LaTask *dt = (LaTask *) dmalloc(sizeof(LaTask) * (size_t) ntasks);
   HIP_CHECK(hipMemcpy(dt, tasks, sizeof(LaTask) * (size_t) ntasks, hipMemcpyHostToDevice));
   u32 hc[8];
