@@ -77,8 +77,8 @@ void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, i
                              u32 *heads, hipStream_t st);
 #define WORK_COST_BITS 16
 #define WORK_COST_MAX  ((1u << WORK_COST_BITS) - 1)
-void damar_launch_work_cost(const u64 *keys, u64 nhits, int pbits, const u32 *work, u32 nwork, u32 coarse,
-                            u32 *key, u32 *val, hipStream_t st);
+void damar_launch_work_cost(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, const u32 *aboff,
+                            const u32 *bboff, const u32 *work, u32 nwork, u32 coarse, u32 *key, u32 *val, hipStream_t st);
 void damar_launch_pair_screen(const u64 *keys, const u32 *vals, u64 nhits, int pbits, const u32 *heads, u32 nheads,
                               int minhit, int binshift, int kmer, int hitmin, u32 *keep, hipStream_t st);
 void damar_launch_compact_u32(const u32 *src, const u32 *keep, const u32 *off, u32 n, u32 *out, hipStream_t st);

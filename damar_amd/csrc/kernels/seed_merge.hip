@@ -413,8 +413,9 @@ void damar_launch_compact_index(const u32 *flags, const u32 *off, u64 n, u32 *ou
  * of the launch.  The number of seeds of a pair is a good stand-in for the length of its
  * alignment; key[j] sorts ascending into "most seeds first". */
 __global__ __launch_bounds__(256)
-void work_cost(const u64 *__restrict__ keys, u64 nhits, int pbits, const u32 *__restrict__ work, u32 nwork,
-               u32 coarse, u32 *__restrict__ key, u32 *__restrict__ val)
+void work_cost(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits, int abits,
+               const u32 *__restrict__ aboff, const u32 *__restrict__ bboff,
+               const u32 *__restrict__ work, u32 nwork, u32 coarse, u32 *__restrict__ key, u32 *__restrict__ val)
 { u32 j = blockIdx.x * 256u + threadIdx.x;
   if (j >= nwork)
     return;
@@ -425,6 +426,18 @@ void work_cost(const u64 *__restrict__ keys, u64 nhits, int pbits, const u32 *__
       if ((keys[mid] >> pbits) == pr) a = mid + 1; else b = mid;
     }
   u64 n = a - i;
+  if (coarse >= 0xfffffffdu)    /* cost = the expected length of the alignment instead of a seed count: the wave kernel's
+                                   launch ends with its longest serial chains, so those must start first */
+    { const u64 pm = (1ull << pbits) - 1;
+      const u64 ext = (keys[a - 1] & pm) - (keys[i] & pm);              /* extent of the seeds on A */
+      const u32 ra = (u32) (pr & ((1ull << abits) - 1)), rb = (u32) (pr >> abits);
+      const int alen = (int) (aboff[ra + 1] - aboff[ra]) - 1, blen = (int) (bboff[rb + 1] - bboff[rb]) - 1;
+      const int d = (int) vals[i];                                      /* diagonal a - b of the first seed */
+      const int geo = min(alen, blen + d) - max(0, d);                  /* overlap of the two reads on it */
+      u64 len = (coarse == 0xffffffffu) ? ext : (coarse == 0xfffffffeu ? (u64) max(geo, 0) : max(ext, (u64) max(geo, 0)));
+      n = len >> (pbits > 16 ? pbits - 16 : 0);
+      coarse = 0;
+    }
   if (n > WORK_COST_MAX)
     n = WORK_COST_MAX;
   if (coarse == 1)              /* size classes (powers of two): largest class first, reference order inside */
@@ -434,9 +447,10 @@ void work_cost(const u64 *__restrict__ keys, u64 nhits, int pbits, const u32 *__
   val[j] = j;
 }
 
-void damar_launch_work_cost(const u64 *keys, u64 nhits, int pbits, const u32 *work, u32 nwork, u32 coarse,
-                            u32 *key, u32 *val, hipStream_t st)
+void damar_launch_work_cost(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, const u32 *aboff,
+                            const u32 *bboff, const u32 *work, u32 nwork, u32 coarse, u32 *key, u32 *val, hipStream_t st)
 { if (nwork == 0)
     return;
-  hipLaunchKernelGGL(work_cost, dim3((nwork + 255) / 256), dim3(256), 0, st, keys, nhits, pbits, work, nwork, coarse, key, val);
+  hipLaunchKernelGGL(work_cost, dim3((nwork + 255) / 256), dim3(256), 0, st, keys, vals, nhits, pbits, abits, aboff, bboff,
+                     work, nwork, coarse, key, val);
 }

@@ -1367,7 +1367,10 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   static int order_mode = -1;
   if (order_mode < 0)
     { const char *e = getenv("DAMAR_ORDER");
-      order_mode = e ? atoi(e) : 1;      /* 0 = reference order, 1 = most seeds first, 2 = size classes, n = >= n first */
+      order_mode = e ? atoi(e) : 11;     /* 0 = reference order, 1 = most seeds first, 2 = size classes, 9 = longest seed
+                                            extent first, 10 = longest geometric overlap first, 11 = the larger of the two
+                                            (default: 356 ms of report kernel per config-2 step against 370 for 1, 361 for
+                                            9, 411 for 10), other n = runs of >= n seeds first */
     }
   if (nwork > 1 && order_mode > 0)
     { arena_reserve(&G_ord, 4 * pad256(sizeof(u32) * (size_t) nwork) + pad256(damar_sort_workspace_bytes(nwork)) + 4096);
@@ -1376,7 +1379,9 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
       u32 *ok1 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
       u32 *ov1 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
       void *osw = arena_take(&G_ord, damar_sort_workspace_bytes(nwork));
-      damar_launch_work_cost(keys, total, m.pbits, work, nwork, order_mode == 2 ? 1u : (order_mode > 2 ? (u32) order_mode : 0u), ok0, ov0, G_st);
+      const u32 cmode = order_mode == 2 ? 1u : order_mode == 9 ? 0xffffffffu : order_mode == 10 ? 0xfffffffeu :
+                        order_mode == 11 ? 0xfffffffdu : (order_mode > 2 ? (u32) order_mode : 0u);
+      damar_launch_work_cost(keys, vals, total, m.pbits, m.abits, m.ablk.boff, m.bblk.boff, work, nwork, cmode, ok0, ov0, G_st);
       order = damar_radix_sort_u32(ok0, ov0, ok1, ov1, nwork, WORK_COST_BITS, osw, G_st) ? ov1 : ov0;
       stage("work_order");
     }
