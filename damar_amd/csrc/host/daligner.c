@@ -268,6 +268,8 @@ int main(int argc, char *argv[])
     PF.produced = PF.consumed = 0;
     pthread_mutex_init(&PF.mu, NULL);
     pthread_cond_init(&PF.cv, NULL);
+    if (gpu < 0 && getenv("DAMAR_DEVICE") != NULL)
+      gpu = atoi(getenv("DAMAR_DEVICE"));
     damar_hip_init(gpu < 0 ? 0 : gpu);            /* before the second thread makes its first HIP call */
     if (pthread_create(&th, NULL, prepare_blocks, NULL) != 0)
       { fprintf(stderr, "daligner: cannot start the block reader thread\n");
