@@ -105,6 +105,51 @@ def test_missing_library_fails_loudly(monkeypatch):
         dl.load()
 
 
+def test_complement_copy_equals_in_place_complement_with_masks(built):
+    """damar_complement_copy (the re-entrant copy the command-line driver makes on its second thread) against
+    the in-place complement_DB restatement, on a block with a merged mask track: bases, base frequencies and
+    the mirrored mask intervals (daligner.c:511-628)."""
+    from damar_amd import api
+    L = api.lib()
+    L.damar_complement_copy.argtypes = [C.POINTER(api.HITS_DB), C.POINTER(api.HITS_DB)]
+    L.damar_free_complement.argtypes = [C.POINTER(api.HITS_DB)]
+    L.damar_load_masks.argtypes = [C.POINTER(api.HITS_DB), C.POINTER(C.c_char_p), C.c_int]
+
+    class Track(C.Structure):
+        pass
+    Track._fields_ = [("next", C.POINTER(Track)), ("name", C.c_char_p), ("size", C.c_int), ("anno", C.c_void_p), ("data", C.c_void_p)]
+
+    def masks(db):
+        t = C.cast(db.tracks, C.POINTER(Track))
+        assert bool(t)
+        n = db.nreads
+        anno = np.ctypeslib.as_array(C.cast(t.contents.anno, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
+        data = np.ctypeslib.as_array(C.cast(t.contents.data, C.POINTER(C.c_int32)), shape=(max(int(anno[n]), 1),))[:int(anno[n])].copy()
+        return anno, data
+    name = os.path.join(ROOT, "tests", "golden", "mask_dust", "G.1").encode()
+    a, b = api.HITS_DB(), api.HITS_DB()
+    names = (C.c_char_p * 2)(b"dust", b"rnd")
+    for db in (a, b):
+        assert L.damar_read_block(name, C.byref(db)) == 0
+        assert L.damar_load_masks(C.byref(db), names, 2) == 0
+    cp = api.HITS_DB()
+    L.damar_complement_copy(C.byref(a), C.byref(cp))
+    L.damar_complement_block(C.byref(b), 1)
+    tot = a.reads[a.nreads].boff
+    got = np.ctypeslib.as_array(C.cast(cp.bases, C.POINTER(C.c_int8)), shape=(tot,))
+    want = np.ctypeslib.as_array(C.cast(b.bases, C.POINTER(C.c_int8)), shape=(tot,))
+    assert (got == want).all()
+    assert list(cp.freq) == list(b.freq)
+    ga, gd = masks(cp)
+    wa, wd = masks(b)
+    assert (ga == wa).all() and (gd == wd).all() and len(gd) > 100
+    fwd = np.ctypeslib.as_array(C.cast(a.bases, C.POINTER(C.c_int8)), shape=(tot,))
+    assert not (fwd == got).all()                      # the original is untouched and differs
+    L.damar_free_complement(C.byref(cp))
+    L.damar_close_block(C.byref(a))
+    L.damar_close_block(C.byref(b))
+
+
 def test_lamerge_equals_reference(built, tmp_path):
     """LAmerge (the step after daligner in every plan, HPCdaligner.c:790-808): the merged block
     file equals what the reference's utils/LAmerge wrote for the same directory
