@@ -1,0 +1,303 @@
+/* fa2db.c -- FASTA -> database, the creation path of the reference's db/FA2db.c: writes
+ * <path>.db (stub), .<path>.idx (HITS_DB header + one HITS_READ per read), .<path>.bps (2-bit bases) and the two
+ * tracks every FA2db run leaves, .<path>.seqID.{anno,data} (index of the read inside its FASTA file) and
+ * .<path>.pacbio.{anno,data} (well, begin, end of reads with a PacBio header), byte for byte as the reference
+ * does for the same input (FA2db.c:611-651 addReadToDB, 652-905 readFastaFile, 1063-1130 main; FA2x.c:63-94,
+ * 154-300 tracks; fileUtils.c:8-46 isPacBioHeader) -- except for the fields of the .idx header that the
+ * reference leaves uninitialised, which are zero here.
+ *
+ *     FA2db [-v] [-x<int(1000)>] <path:db> <input:fasta> ...
+ *
+ * Built: creating a database from .fasta / .fa files, -x.  Not built (rejected with a message): appending to
+ * an existing database (-a and the implicit append), -b, -Q, -c, -f.  Host code, C, no GPU.
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "damar_db.h"
+
+#define MAX_NAME 10000                     /* db/DB.h */
+
+typedef struct
+{ char  *name;
+  uint64 *anno;   int64 amax;               /* bytes of data per read, then offsets */
+  int    *data;   int64 dtop, dmax;
+} Track;
+
+static Track T_seq = { "seqID", NULL, 0, NULL, 0, 0 }, T_pac = { "pacbio", NULL, 0, NULL, 0, 0 };
+static int   T_pac_used = 0;
+
+static void track_add(Track *t, int64 read, int value)                   /* FA2x.c:63-94 */
+{ if (read >= t->amax)
+    { int64 n = (int64) (read * 1.2 + 1000);
+      t->anno = (uint64 *) realloc(t->anno, sizeof(uint64) * (size_t) n);
+      memset(t->anno + t->amax, 0, sizeof(uint64) * (size_t) (n - t->amax));
+      t->amax = n;
+    }
+  if (t->dtop >= t->dmax)
+    { t->dmax = (int64) (t->dtop * 1.2 + 1000);
+      t->data = (int *) realloc(t->data, sizeof(int) * (size_t) t->dmax);
+    }
+  t->anno[read] += sizeof(int);
+  t->data[t->dtop++] = value;
+}
+
+static void track_write(Track *t, const char *dir, const char *root, int ureads)      /* FA2x.c:154-300 */
+{ char   path[2 * MAX_NAME + 64];
+  FILE  *f;
+  uint64 off = 0;
+  int    i, tlen = ureads, tsize = (int) sizeof(uint64);
+
+  if (ureads + 1 > t->amax)
+    { t->anno = (uint64 *) realloc(t->anno, sizeof(uint64) * (size_t) (ureads + 1));
+      memset(t->anno + t->amax, 0, sizeof(uint64) * (size_t) (ureads + 1 - t->amax));
+      t->amax = ureads + 1;
+    }
+  for (i = 0; i <= ureads; i++)
+    { uint64 c = t->anno[i];
+      t->anno[i] = off;
+      off += c;
+    }
+  snprintf(path, sizeof(path), "%s/.%s.%s.anno", dir, root, t->name);
+  if ((f = fopen(path, "w")) == NULL)
+    { fprintf(stderr, "[WARNING] Cannot create file %s. Skip track %s.\n", path, t->name);
+      return;
+    }
+  fwrite(&tlen, sizeof(int), 1, f);
+  fwrite(&tsize, sizeof(int), 1, f);
+  fwrite(t->anno, sizeof(uint64), (size_t) ureads + 1, f);
+  fclose(f);
+  snprintf(path, sizeof(path), "%s/.%s.%s.data", dir, root, t->name);
+  if ((f = fopen(path, "w")) == NULL)
+    return;
+  fwrite(t->data, sizeof(int), (size_t) t->dtop, f);
+  fclose(f);
+}
+
+static int is_pacbio_header(const char *h)                               /* fileUtils.c:8-46 */
+{ const char *end = strchr(h, ' '), *p;
+  int n = 0;
+  if (end == NULL)
+    end = h + strlen(h) - 1;
+  for (p = strchr(h, '/'); p != NULL && p < end; p = strchr(p + 1, '/'))
+    n += 1;
+  return n == 2;
+}
+
+static const char *base_name(const char *path)
+{ const char *s = strrchr(path, '/');
+  return s ? s + 1 : path;
+}
+
+typedef struct
+{ FILE *idx, *bps, *stub;
+  int64 off, totlen, count[4];
+  int   ureads, maxlen, minlen, verbose, nadded;
+} Out;
+
+static void add_read(Out *o, char *seq, int len, int seqid, int pac, int well, int beg, int end)   /* FA2db.c:611-651 */
+{ static unsigned char *buf = NULL;
+  static int bmax = 0;
+  int clen = (len + 3) >> 2, i;
+  HITS_READ hr;
+
+  if (clen + 4 > bmax)
+    { bmax = 2 * clen + 1024;
+      buf = (unsigned char *) realloc(buf, (size_t) bmax);
+    }
+  memset(buf, 0, (size_t) clen + 4);
+  for (i = 0; i < len; i++)
+    { int x;
+      switch (seq[i])
+      { case 'c': case 'C': x = 1; break;
+        case 'g': case 'G': x = 2; break;
+        case 't': case 'T': x = 3; break;
+        default:            x = 0;                  /* FA2db.c:84-87: everything else counts as 'a' */
+      }
+      o->count[x] += 1;
+      buf[i >> 2] |= (unsigned char) (x << (6 - 2 * (i & 3)));
+    }
+  memset(&hr, 0, sizeof(hr));
+  hr.boff  = o->off;
+  hr.rlen  = len;
+  hr.coff  = -1;
+  hr.flags = DB_BEST;
+  fwrite(buf, 1, (size_t) clen, o->bps);
+  fwrite(&hr, sizeof(hr), 1, o->idx);
+  track_add(&T_seq, o->ureads, seqid);
+  if (pac)
+    { track_add(&T_pac, o->ureads, well);
+      track_add(&T_pac, o->ureads, beg);
+      track_add(&T_pac, o->ureads, end);
+      T_pac_used = 1;
+    }
+  o->off    += clen;
+  o->ureads += 1;
+  o->totlen += len;
+  if (len > o->maxlen)
+    o->maxlen = len;
+}
+
+static void read_fasta(Out *o, const char *name)                          /* FA2db.c:652-905 */
+{ char   path[2 * MAX_NAME + 16], core[MAX_NAME + 8], prolog[MAX_NAME + 8];
+  char  *line = NULL, *seq = NULL, header[MAX_NAME + 8];
+  size_t lcap = 0;
+  ssize_t n;
+  int    smax = 0, rlen = 0, seqid = -1, have = 0;
+  FILE  *in;
+  const char *b = base_name(name);
+  size_t bl = strlen(b);
+
+  if (bl > 6 && strcmp(b + bl - 6, ".fasta") == 0) bl -= 6;
+  else if (bl > 3 && strcmp(b + bl - 3, ".fa") == 0) bl -= 3;
+  if (bl >= MAX_NAME)
+    { fprintf(stderr, "File name over %d chars: '%.200s'\n", MAX_NAME, b);
+      exit(1);
+    }
+  memcpy(core, b, bl);
+  core[bl] = '\0';
+  snprintf(path, sizeof(path), "%.*s%s.fasta", (int) (b - name), name, core);
+  if ((in = fopen(path, "r")) == NULL)
+    { snprintf(path, sizeof(path), "%.*s%s.fa", (int) (b - name), name, core);
+      if ((in = fopen(path, "r")) == NULL)
+        { fprintf(stderr, "FA2db: cannot open %s.fasta or %s.fa\n", core, core);
+          exit(1);
+        }
+    }
+  if ((n = getline(&line, &lcap, in)) < 1)
+    { fprintf(stderr, "Skipping '%s', file is empty!\n", core);
+      fclose(in);
+      free(line);
+      return;
+    }
+  if (o->verbose)
+    fprintf(stderr, "Adding '%s' ...\n", core);
+  o->nadded += 1;
+  if (n > MAX_NAME - 2 || line[n - 1] != '\n')
+    { fprintf(stderr, "File %s.fasta, Line 1: Fasta line is too long (> %d chars)\n", core, MAX_NAME - 2);
+      exit(1);
+    }
+  if (line[0] != '>')
+    { fprintf(stderr, "File %s.fasta, Line 1: First header in fasta file is missing\n", core);
+      exit(1);
+    }
+  if (is_pacbio_header(line + 1))
+    { const char *slash = strchr(line + 1, '/');
+      snprintf(prolog, sizeof(prolog), "%.*s", (int) (slash - (line + 1)), line + 1);
+    }
+  else
+    strcpy(prolog, "DAZZ_READ");
+
+  for (;;)                                           /* line holds a header here, or n < 0 at the end */
+    { int pac = 0, well = -1, beg = -1, end = -1;
+
+      if (n < 0)
+        break;
+      snprintf(header, sizeof(header), "%s", line + 1);
+      seqid += 1;
+      if (is_pacbio_header(header))
+        { const char *slash = strchr(header, '/');
+          pac = (sscanf(slash + 1, "%d/%d_%d\n", &well, &beg, &end) == 3);
+        }
+      rlen = 0;
+      have = 0;
+      while ((n = getline(&line, &lcap, in)) >= 0)
+        { if (line[0] == '>')
+            { have = 1;
+              break;
+            }
+          if (n > 0 && line[n - 1] == '\n')
+            n -= 1;
+          if (rlen + n + 1 > smax)
+            { smax = (int) (1.2 * (rlen + n)) + 1000;
+              seq = (char *) realloc(seq, (size_t) smax);
+            }
+          memcpy(seq + rlen, line, (size_t) n);
+          rlen += (int) n;
+        }
+      if (rlen >= o->minlen)
+        add_read(o, seq, rlen, seqid, pac, well, beg, end);
+      else if (o->verbose > 1)
+        fprintf(stderr, "Warning: skipping read of length %d\n", rlen);
+      if (!have)
+        break;
+    }
+  fprintf(o->stub, "  %9d %s %s\n", o->ureads, core, prolog);
+  fclose(in);
+  free(line);
+  free(seq);
+}
+
+int main(int argc, char *argv[])
+{ Out     o;
+  HITS_DB db;
+  char   *root, *dir, path[2 * MAX_NAME + 16];
+  int     c, i, nfiles;
+
+  memset(&o, 0, sizeof(o));
+  o.minlen = 1000;
+  opterr = 0;
+  while ((c = getopt(argc, argv, "vabQx:c:f:")) != -1)
+    switch (c)
+    { case 'v': o.verbose += 1; break;
+      case 'x': o.minlen = atoi(optarg); break;
+      case 'a': case 'b': case 'Q': case 'c': case 'f':
+        fprintf(stderr, "FA2db: option -%c is not built in this tool (creation from .fasta files and -x only)\n", c);
+        exit(1);
+      default:
+        fprintf(stderr, "usage: FA2db [-v] [-x<int(1000)>] <path:db> <input:fasta> ...\n");
+        exit(1);
+    }
+  if (o.minlen < 0)
+    { fprintf(stderr, "invalid min read length of %d\n", o.minlen);
+      exit(1);
+    }
+  if (argc - optind < 2)
+    { fprintf(stderr, "usage: FA2db [-v] [-x<int(1000)>] <path:db> <input:fasta> ...\n");
+      exit(1);
+    }
+  root = damar_root(argv[optind], ".db");
+  { const char *s = strrchr(argv[optind], '/');
+    dir = s ? strndup(argv[optind], (size_t) (s - argv[optind])) : strdup(".");
+  }
+  snprintf(path, sizeof(path), "%s/%s.db", dir, root);
+  if (access(path, F_OK) == 0)
+    { fprintf(stderr, "FA2db: %s exists; appending to a database is not built in this tool\n", path);
+      exit(1);
+    }
+  o.stub = fopen(path, "w");
+  snprintf(path, sizeof(path), "%s/.%s.idx", dir, root);
+  o.idx = fopen(path, "w");
+  snprintf(path, sizeof(path), "%s/.%s.bps", dir, root);
+  o.bps = fopen(path, "w");
+  if (o.stub == NULL || o.idx == NULL || o.bps == NULL)
+    { fprintf(stderr, "FA2db: cannot create the database files of %s\n", root);
+      exit(1);
+    }
+  memset(&db, 0, sizeof(db));
+  fwrite(&db, sizeof(db), 1, o.idx);                  /* place holder, rewritten below (FA2db.c:1114-1131) */
+  nfiles = argc - optind - 1;
+  fprintf(o.stub, "files = %9d\n", nfiles);
+  for (i = optind + 1; i < argc; i++)
+    read_fasta(&o, argv[i]);
+
+  db.ureads = o.ureads;
+  for (c = 0; c < 4; c++)
+    db.freq[c] = (float) ((1. * o.count[c]) / o.totlen);
+  db.totlen = o.totlen;
+  db.maxlen = o.maxlen;
+  rewind(o.idx);
+  fwrite(&db, sizeof(db), 1, o.idx);
+  rewind(o.stub);                                      /* files actually added (empty ones are skipped) */
+  fprintf(o.stub, "files = %9d\n", o.nadded);
+  fclose(o.stub);
+  fclose(o.idx);
+  fclose(o.bps);
+  track_write(&T_seq, dir, root, o.ureads);
+  if (T_pac_used)
+    track_write(&T_pac, dir, root, o.ureads);
+  return 0;
+}

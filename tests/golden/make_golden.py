@@ -274,6 +274,23 @@ def memlimit():
         print(os.path.getsize(las), hashlib.md5(open(las, "rb").read()).hexdigest())
 
 
+def fa2db_md5():
+    """The reference's FA2db + DBsplit on the FASTA files of tests/test_host.py::fasta_inputs ->
+    fa2db_ref_md5.txt (md5 per database file; of the .idx only the fields the reference defines)."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_host
+    with tempfile.TemporaryDirectory() as d:
+        files = test_host.fasta_inputs(d)
+        run([os.path.join(REF, "FA2db"), "-x1000", "T"] + files, d, stderr=subprocess.DEVNULL)
+        run([os.path.join(REF, "DBsplit"), "-s1", "T"], d)
+        dig = test_host.db_digest(d)
+    with open(os.path.join(HERE, "fa2db_ref_md5.txt"), "w") as f:
+        for name, md5 in sorted(dig.items()):
+            f.write("%s %s\n" % (md5, name))
+    print(dig)
+
+
 def trace_md5():
     """md5 of the dumps the REAL Compute_Trace_PTS leaves for every golden .las (oracle/ref_lastrace.c
     around align.c:5577, all three modes) -> trace_ref_md5.txt, the fixture that pins oracle/trace.c."""
@@ -305,6 +322,8 @@ def main():
         return memlimit()
     if sys.argv[1:] == ["trace"]:
         return trace_md5()
+    if sys.argv[1:] == ["fa2db"]:
+        return fa2db_md5()
     import tempfile
     dbs = {}
     only = set(sys.argv[1:])

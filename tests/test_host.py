@@ -150,6 +150,82 @@ def test_complement_copy_equals_in_place_complement_with_masks(built):
     L.damar_close_block(C.byref(b))
 
 
+def fasta_inputs(d):
+    """Three FASTA files that exercise FA2db's header rules: PacBio headers with several reads per well,
+    short reads that -x drops (their file index still counts), upper / lower case and N, long and short
+    lines; headers that are not PacBio; a file whose first header is not PacBio but later ones are."""
+    import random
+    rng = random.Random(11)
+
+    def seq(n, alphabet="acgt"):
+        return "".join(rng.choice(alphabet) for _ in range(n))
+    with open(os.path.join(d, "pb.fasta"), "w") as f:
+        for i in range(40):
+            n = rng.choice([300, 999, 1000, 1001, 2500, 7000, 12000])
+            s = seq(n, "acgtACGTnN")
+            f.write(">m140913_050931_42139_c1_s1_p0/%d/%d_%d RQ=0.85%d\n" % (i // 2 + 7, 10 * i, 10 * i + n, i % 10))
+            w = rng.choice([60, 70, 80, 100000])
+            for j in range(0, n, w):
+                f.write(s[j:j + w] + "\n")
+    with open(os.path.join(d, "plain.fa"), "w") as f:
+        for i in range(15):
+            f.write(">read_%d some text\n%s\n" % (i, seq(rng.choice([1500, 3000, 800]))))
+    with open(os.path.join(d, "mixed.fasta"), "w") as f:
+        for i in range(12):
+            n = rng.choice([1200, 5000])
+            f.write((">Sim/%d/0_%d RQ=0.850" % (i + 1, n) if i % 3 else ">odd/%d" % i) + "\n" + seq(n) + "\n")
+    return ["pb.fasta", "plain.fa", "mixed.fasta"]
+
+
+def db_digest(d, root="T"):
+    """md5 of every file of a database; of the .idx only the fields the reference defines (it leaves the
+    padding of its records and the tail of the header uninitialised)."""
+    import struct
+    out = {}
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".fasta") or f.endswith(".fa"):
+            continue
+        raw = open(os.path.join(d, f), "rb").read()
+        if f == ".%s.idx" % root:
+            n = (len(raw) - 88) // 32
+            raw = raw[:32] + b"".join(struct.pack("<iqqi", *struct.unpack_from("<i4xqqi4x", raw, 88 + 32 * i)) for i in range(n))
+        out[f] = hashlib.md5(raw).hexdigest()
+    return out
+
+
+def test_fa2db_and_dbsplit_equal_reference(built, tmp_path):
+    """bin/FA2db + bin/DBsplit against the reference's tools on the same FASTA files: stub, .bps,
+    the defined fields of the .idx, and the seqID / pacbio tracks (tests/golden/fa2db_ref_md5.txt, made with
+    oracle/_ref/FA2db and DBsplit by `make_golden.py fa2db`; compared live as well where oracle/_ref exists)."""
+    own = str(tmp_path / "own")
+    os.makedirs(own)
+    files = fasta_inputs(own)
+    tools = os.path.join(ROOT, "damar_amd", "bin")
+    subprocess.run([os.path.join(tools, "FA2db"), "-x1000", "T"] + files, cwd=own, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(tools, "DBsplit"), "-s1", "T"], cwd=own, check=True)
+    got = db_digest(own)
+    want = dict(ln.split()[::-1] for ln in open(os.path.join(GOLDEN, "fa2db_ref_md5.txt")))
+    assert got == want
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    if os.path.exists(os.path.join(ref, "FA2db")):
+        live = str(tmp_path / "ref")
+        os.makedirs(live)
+        fasta_inputs(live)
+        subprocess.run([os.path.join(ref, "FA2db"), "-x1000", "T"] + files, cwd=live, check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([os.path.join(ref, "DBsplit"), "-s1", "T"], cwd=live, check=True)
+        assert db_digest(live) == got
+    # the database is usable: the block loader reads it
+    from damar_amd import api
+    db = api.read_block(os.path.join(own, "T.1"))
+    assert db.nreads > 10 and db.maxlen == 12000
+    api.lib().damar_close_block(C.byref(db))
+    # what is not built is refused, not ignored
+    r = subprocess.run([os.path.join(tools, "FA2db"), "-b", "U"] + files, cwd=own, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "not built" in r.stderr
+    r = subprocess.run([os.path.join(tools, "FA2db"), "T"] + files, cwd=own, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "appending" in r.stderr
+
+
 def test_lamerge_equals_reference(built, tmp_path):
     """LAmerge (the step after daligner in every plan, HPCdaligner.c:790-808): the merged block
     file equals what the reference's utils/LAmerge wrote for the same directory
