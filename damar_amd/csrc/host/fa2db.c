@@ -159,6 +159,17 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
     }
   memcpy(core, b, bl);
   core[bl] = '\0';
+  { static char **seen = NULL;                       /* FA2db.c:676-688: a file cannot be added twice */
+    static int    nseen = 0;
+    int j;
+    for (j = 0; j < nseen; j++)
+      if (strcmp(seen[j], core) == 0)
+        { fprintf(stderr, "File %s.fasta is already in database\n", core);
+          exit(1);
+        }
+    seen = (char **) realloc(seen, sizeof(char *) * (size_t) (nseen + 1));
+    seen[nseen++] = strdup(core);
+  }
   snprintf(path, sizeof(path), "%.*s%s.fasta", (int) (b - name), name, core);
   if ((in = fopen(path, "r")) == NULL)
     { snprintf(path, sizeof(path), "%.*s%s.fa", (int) (b - name), name, core);
