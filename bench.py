@@ -84,10 +84,9 @@ def trace_expand_leg(dbdir, root, out_dir, with_cpu):
     gout = os.path.join(dbdir, "trace_gpu.bin")
     tool = os.path.join(ROOT, "damar_amd", "bin", "lastrace")
     best = None
-    for _ in range(2):                                   # first call pays the buffer allocations
-        txt = subprocess.run([tool, "-v", blk, blk, las, gout], check=True, stdout=subprocess.PIPE, text=True).stdout
-        m = re.search(r"(\d+) records, (\d+) segments \((\d+) deferred\), (\d+) script values; waves ([\d.]+) ms, "
-                      r"device ([\d.]+) ms, call ([\d.]+) ms", txt)
+    txt = subprocess.run([tool, "-v", "-R3", blk, blk, las, gout], check=True, stdout=subprocess.PIPE, text=True).stdout
+    for m in re.finditer(r"(\d+) records, (\d+) segments \((\d+) deferred\), (\d+) script values; waves ([\d.]+) ms, "
+                         r"device ([\d.]+) ms, call ([\d.]+) ms", txt):     # 3 calls in one process: the first allocates
         cur = dict(records=int(m.group(1)), segments=int(m.group(2)), deferred=int(m.group(3)),
                    script_values=int(m.group(4)), kernel_ms=float(m.group(5)), device_ms=float(m.group(6)),
                    call_ms=float(m.group(7)))

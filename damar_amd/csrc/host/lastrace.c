@@ -24,7 +24,7 @@
 
 #define OVL_IO ((int) (sizeof(Overlap) - sizeof(void *)))
 
-static int verbose = 0;
+static int verbose = 0, reps = 1;         /* -R<n>: repeat the expansion (timing: the first call allocates) */
 
 /* one file: A / B block names, .las, output, mode, mid (0 = Compute_Trace_PTS, 1 = Compute_Trace_MID) */
 static void run_job(const char *aname, const char *bname, const char *lasname, const char *outname, int mode, int mid)
@@ -79,16 +79,22 @@ static void run_job(const char *aname, const char *bname, const char *lasname, c
   bblk = same_block ? ablk : damar_block_upload(&bdb);
   soff  = (int64 *) malloc(sizeof(int64) * (size_t) (novl + 1));
   diffs = (int *) malloc(sizeof(int) * (size_t) (novl + 1));
-  if ((mid ? damar_trace_mid : damar_trace_pts)(ablk, adb.ufirst, bblk, same_block ? adb.ufirst : bdb.ufirst, ovls, novl,
-                                               tbytes, tspace, mode, 0, soff, diffs, &script))
-    exit(1);
-  if (verbose)
-    { double ms[4];
-      int64  cnt[4];
-      damar_trace_last(ms, cnt);
-      printf("lastrace: %lld records, %lld segments (%lld deferred), %lld script values; waves %.2f ms, device %.2f ms, call %.2f ms\n",
-             (long long) cnt[0], (long long) cnt[1], (long long) cnt[2], (long long) cnt[3], ms[0], ms[1], ms[2]);
-    }
+  { int rep;
+    for (rep = 0; rep < reps; rep++)
+      { free(script);
+        script = NULL;
+        if ((mid ? damar_trace_mid : damar_trace_pts)(ablk, adb.ufirst, bblk, same_block ? adb.ufirst : bdb.ufirst, ovls, novl,
+                                                     tbytes, tspace, mode, 0, soff, diffs, &script))
+          exit(1);
+        if (verbose)
+          { double ms[4];
+            int64  cnt[4];
+            damar_trace_last(ms, cnt);
+            printf("lastrace: %lld records, %lld segments (%lld deferred), %lld script values; waves %.2f ms, device %.2f ms, call %.2f ms\n",
+                   (long long) cnt[0], (long long) cnt[1], (long long) cnt[2], (long long) cnt[3], ms[0], ms[1], ms[2]);
+          }
+      }
+  }
 
   if ((out = fopen(outname, "wb")) == NULL)
     { fprintf(stderr, "lastrace: cannot create %s\n", outname);
@@ -120,13 +126,14 @@ int main(int argc, char *argv[])
   char *list = NULL;
 
   opterr = 0;
-  while ((c = getopt(argc, argv, "vMg:m:L:")) != -1)
+  while ((c = getopt(argc, argv, "vMg:m:L:R:")) != -1)
     switch (c)
     { case 'g': gpu = atoi(optarg); break;
       case 'm': mode = atoi(optarg); break;
       case 'v': verbose = 1; break;
       case 'M': mid = 1; break;
       case 'L': list = optarg; break;
+      case 'R': reps = atoi(optarg) > 0 ? atoi(optarg) : 1; break;
       default:
         fprintf(stderr, "Unsupported option: %s\n", argv[optind - 1]);
         exit(1);
