@@ -6,10 +6,10 @@
  * 154-300 tracks; fileUtils.c:8-46 isPacBioHeader) -- except for the fields of the .idx header that the
  * reference leaves uninitialised, which are zero here.
  *
- *     FA2db [-v] [-x<int(1000)>] <path:db> <input:fasta> ...
+ *     FA2db [-v] [-x<int(1000)>] <path:db> (-f<file of fasta names> | <input:fasta> ...)
  *
- * Built: creating a database from .fasta / .fa files, -x.  Not built (rejected with a message): appending to
- * an existing database (-a and the implicit append), -b, -Q, -c, -f.  Host code, C, no GPU.
+ * Built: creating a database from .fasta / .fa files, -x, -f.  Not built (rejected with a message): appending
+ * to an existing database (-a and the implicit append), -b, -Q, -c.  Host code, C, no GPU.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -247,6 +247,7 @@ int main(int argc, char *argv[])
   HITS_DB db;
   char   *root, *dir, path[2 * MAX_NAME + 16];
   int     c, i, nfiles;
+  FILE   *flist = NULL;
 
   memset(&o, 0, sizeof(o));
   o.minlen = 1000;
@@ -255,8 +256,14 @@ int main(int argc, char *argv[])
     switch (c)
     { case 'v': o.verbose += 1; break;
       case 'x': o.minlen = atoi(optarg); break;
-      case 'a': case 'b': case 'Q': case 'c': case 'f':
-        fprintf(stderr, "FA2db: option -%c is not built in this tool (creation from .fasta files and -x only)\n", c);
+      case 'f':
+        if ((flist = fopen(optarg, "r")) == NULL)
+          { fprintf(stderr, "Cannot open file of inputs '%s'\n", optarg);
+            exit(1);
+          }
+        break;
+      case 'a': case 'b': case 'Q': case 'c':
+        fprintf(stderr, "FA2db: option -%c is not built in this tool (creation from .fasta files, -x and -f only)\n", c);
         exit(1);
       default:
         fprintf(stderr, "usage: FA2db [-v] [-x<int(1000)>] <path:db> <input:fasta> ...\n");
@@ -266,8 +273,8 @@ int main(int argc, char *argv[])
     { fprintf(stderr, "invalid min read length of %d\n", o.minlen);
       exit(1);
     }
-  if (argc - optind < 2)
-    { fprintf(stderr, "usage: FA2db [-v] [-x<int(1000)>] <path:db> <input:fasta> ...\n");
+  if ((flist == NULL && argc - optind < 2) || argc - optind < 1)
+    { fprintf(stderr, "usage: FA2db [-v] [-x<int(1000)>] <path:db> (-f<file> | <input:fasta> ...)\n");
       exit(1);
     }
   root = damar_root(argv[optind], ".db");
@@ -292,8 +299,20 @@ int main(int argc, char *argv[])
   fwrite(&db, sizeof(db), 1, o.idx);                  /* place holder, rewritten below (FA2db.c:1114-1131) */
   nfiles = argc - optind - 1;
   fprintf(o.stub, "files = %9d\n", nfiles);
-  for (i = optind + 1; i < argc; i++)
-    read_fasta(&o, argv[i]);
+  if (flist != NULL)                                   /* fileUtils.c:62-95: one name per line */
+    { char nm[MAX_NAME + 8];
+      while (fgets(nm, sizeof(nm), flist) != NULL)
+        { size_t l = strlen(nm);
+          if (l > 0 && nm[l - 1] == '\n')
+            nm[l - 1] = '\0';
+          if (nm[0] != '\0')
+            read_fasta(&o, nm);
+        }
+      fclose(flist);
+    }
+  else
+    for (i = optind + 1; i < argc; i++)
+      read_fasta(&o, argv[i]);
 
   db.ureads = o.ureads;
   for (c = 0; c < 4; c++)

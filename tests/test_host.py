@@ -219,6 +219,16 @@ def test_fa2db_and_dbsplit_equal_reference(built, tmp_path):
     db = api.read_block(os.path.join(own, "T.1"))
     assert db.nreads > 10 and db.maxlen == 12000
     api.lib().damar_close_block(C.byref(db))
+    # -f: the same files named in a list file give the same database
+    lst = str(tmp_path / "lst")
+    os.makedirs(lst)
+    fasta_inputs(lst)
+    open(os.path.join(lst, "files.txt"), "w").write("\n".join(files) + "\n")
+    subprocess.run([os.path.join(tools, "FA2db"), "-x1000", "-ffiles.txt", "T"], cwd=lst, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(tools, "DBsplit"), "-s1", "T"], cwd=lst, check=True)
+    d = db_digest(lst)
+    d.pop("files.txt")
+    assert d == got
     # what is not built is refused, not ignored
     r = subprocess.run([os.path.join(tools, "FA2db"), "-b", "U"] + files, cwd=own, stderr=subprocess.PIPE, text=True)
     assert r.returncode != 0 and "not built" in r.stderr
