@@ -661,3 +661,38 @@ def test_gpu_successive_jobs_with_different_correlation(gpu, tmp_path):
                        cwd=odir, check=True, stdout=subprocess.DEVNULL)
         rel = os.path.join("d001_00001", "G.1.G.1.las")
         assert open(os.path.join(odir, rel), "rb").read() == open(os.path.join(gdir, rel), "rb").read(), e
+
+
+def test_gpu_pipeline_from_fasta_with_the_repository_tools(gpu, tmp_path):
+    """The whole tool chain a user runs, with this repository's binaries only: the reads of the tiny2 fixture as
+    FASTA -> bin/FA2db -> bin/DBsplit -s1 -> bin/daligner (HPCdaligner plan of 2 blocks) -> bin/LAmerge ->
+    bin/lastrace.  The database must equal the fixture's (so every .las equals the reference's golden files),
+    the merged block files the reference LAmerge's, the edit scripts the reference Compute_Trace_PTS's."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(GOLDEN))
+    import make_golden as MG
+    d = str(tmp_path)
+    reads = MG.unpack_reads(os.path.join(GOLDEN, "tiny2"), "G")
+    MG.write_fasta(os.path.join(d, "sim.fasta"), reads)
+    tools = os.path.join(ROOT, "damar_amd", "bin")
+    subprocess.run([os.path.join(tools, "FA2db"), "G", "sim.fasta"], cwd=d, check=True)
+    subprocess.run([os.path.join(tools, "DBsplit"), "-s1", "G"], cwd=d, check=True)
+    assert open(os.path.join(d, ".G.bps"), "rb").read() == open(os.path.join(GOLDEN, "tiny2", ".G.bps"), "rb").read()
+    assert open(os.path.join(d, "G.db")).read() == open(os.path.join(GOLDEN, "tiny2", "G.db")).read()
+    case = read_case("tiny2")
+    for a, bs in case["lines"]:
+        subprocess.run([os.path.join(tools, "daligner")] + case["opts"] + ["G." + a] + ["G." + b for b in bs], cwd=d, check=True,
+                       stdout=subprocess.DEVNULL)
+    assert compare_las(case, d) == []
+    want = {ln.split()[2]: ln.split()[0] for ln in open(os.path.join(GOLDEN, "lamerge_ref_md5.txt"))
+            if ln.split()[1] == "tiny2" and ln.split()[3] == "-"}
+    for b in (1, 2):
+        subprocess.run([os.path.join(tools, "LAmerge"), "-n", "8", "G", "G.%d.las" % b, "d001_%05d" % b], cwd=d, check=True,
+                       stdout=subprocess.DEVNULL)
+        assert hashlib.md5(open(os.path.join(d, "G.%d.las" % b), "rb").read()).hexdigest() == want["d001_%05d" % b]
+    ref = {(n, l, m): h for h, n, l, m in (ln.split() for ln in open(os.path.join(GOLDEN, "trace_ref_md5.txt")))}
+    las = case["las"][0]
+    subprocess.run([os.path.join(tools, "lastrace"), os.path.join(d, "G"), os.path.join(d, "G"), os.path.join(d, las),
+                    os.path.join(d, "t.bin")], check=True)
+    assert hashlib.md5(open(os.path.join(d, "t.bin"), "rb").read()).hexdigest() == ref[("tiny2", las, "0")]
