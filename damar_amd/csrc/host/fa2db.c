@@ -6,10 +6,11 @@
  * 154-300 tracks; fileUtils.c:8-46 isPacBioHeader) -- except for the fields of the .idx header that the
  * reference leaves uninitialised, which are zero here.
  *
- *     FA2db [-v] [-x<int(1000)>] <path:db> (-f<file of fasta names> | <input:fasta> ...)
+ *     FA2db [-v] [-a] [-x<int(1000)>] <path:db> (-f<file of fasta names> | <input:fasta> ...)
  *
- * Built: creating a database from .fasta / .fa files, -x, -f.  Not built (rejected with a message): appending
- * to an existing database (-a and the implicit append), -b, -Q, -c.  Host code, C, no GPU.
+ * Built: creating a database from .fasta / .fa files and adding files to an existing one (its block
+ * partition is extended, FA2db.c:908-975; -a starts a new block), -x, -f.  Not built (rejected with a
+ * message): -b, -Q, -c.  Host code, C, no GPU.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -45,33 +46,58 @@ static void track_add(Track *t, int64 read, int value)                   /* FA2x
   t->data[t->dtop++] = value;
 }
 
-static void track_write(Track *t, const char *dir, const char *root, int ureads)      /* FA2x.c:154-300 */
+/* FA2x.c:96-300: the reads up to `first` belong to an existing database.  Their offsets stay in the track's
+   .anno file if it is there and consistent (its last offset is where the new data starts); the offsets of the
+   new reads are written over that last entry, the data are appended. */
+static void track_write(Track *t, const char *dir, const char *root, int first, int ureads)
 { char   path[2 * MAX_NAME + 64];
   FILE  *f;
   uint64 off = 0;
-  int    i, tlen = ureads, tsize = (int) sizeof(uint64);
+  int    i, tlen = ureads, tsize = (int) sizeof(uint64), exists = 0;
 
   if (ureads + 1 > t->amax)
     { t->anno = (uint64 *) realloc(t->anno, sizeof(uint64) * (size_t) (ureads + 1));
       memset(t->anno + t->amax, 0, sizeof(uint64) * (size_t) (ureads + 1 - t->amax));
       t->amax = ureads + 1;
     }
-  for (i = 0; i <= ureads; i++)
+  snprintf(path, sizeof(path), "%s/.%s.%s.anno", dir, root, t->name);
+  if ((f = fopen(path, "r")) != NULL)
+    { int    olen, osize;
+      uint64 last;
+      exists = 1;
+      if (fread(&olen, sizeof(int), 1, f) == 1 && olen == first && fread(&osize, sizeof(int), 1, f) == 1 &&
+          fseek(f, (long) (sizeof(uint64) * (size_t) first), SEEK_CUR) == 0 && fread(&last, sizeof(uint64), 1, f) == 1)
+        off = last;
+      fclose(f);
+    }
+  for (i = first; i <= ureads; i++)
     { uint64 c = t->anno[i];
       t->anno[i] = off;
       off += c;
     }
-  snprintf(path, sizeof(path), "%s/.%s.%s.anno", dir, root, t->name);
-  if ((f = fopen(path, "w")) == NULL)
-    { fprintf(stderr, "[WARNING] Cannot create file %s. Skip track %s.\n", path, t->name);
-      return;
+  if (exists)
+    { if ((f = fopen(path, "r+")) == NULL)
+        { fprintf(stderr, "[ERROR] - Cannot open file %s for appending track %s\n", path, t->name);
+          exit(1);
+        }
+      fwrite(&tlen, sizeof(int), 1, f);
+      fwrite(&tsize, sizeof(int), 1, f);
+      fflush(f);
+      fseeko(f, -(off_t) sizeof(uint64), SEEK_END);
+      fwrite(t->anno + first, sizeof(uint64), (size_t) (tlen + 1 - first), f);
     }
-  fwrite(&tlen, sizeof(int), 1, f);
-  fwrite(&tsize, sizeof(int), 1, f);
-  fwrite(t->anno, sizeof(uint64), (size_t) ureads + 1, f);
+  else
+    { if ((f = fopen(path, "w")) == NULL)
+        { fprintf(stderr, "[WARNING] Cannot create file %s. Skip track %s.\n", path, t->name);
+          return;
+        }
+      fwrite(&tlen, sizeof(int), 1, f);
+      fwrite(&tsize, sizeof(int), 1, f);
+      fwrite(t->anno, sizeof(uint64), (size_t) ureads + 1, f);
+    }
   fclose(f);
   snprintf(path, sizeof(path), "%s/.%s.%s.data", dir, root, t->name);
-  if ((f = fopen(path, "w")) == NULL)
+  if ((f = fopen(path, "a")) == NULL)
     return;
   fwrite(t->data, sizeof(int), (size_t) t->dtop, f);
   fclose(f);
@@ -85,6 +111,19 @@ static int is_pacbio_header(const char *h)                               /* file
   for (p = strchr(h, '/'); p != NULL && p < end; p = strchr(p + 1, '/'))
     n += 1;
   return n == 2;
+}
+
+static char **F_seen = NULL;
+static int    F_nseen = 0;
+
+static int file_seen(const char *core)             /* remembers it if it is new */
+{ int j;
+  for (j = 0; j < F_nseen; j++)
+    if (strcmp(F_seen[j], core) == 0)
+      return 1;
+  F_seen = (char **) realloc(F_seen, sizeof(char *) * (size_t) (F_nseen + 1));
+  F_seen[F_nseen++] = strdup(core);
+  return 0;
 }
 
 static const char *base_name(const char *path)
@@ -159,17 +198,10 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
     }
   memcpy(core, b, bl);
   core[bl] = '\0';
-  { static char **seen = NULL;                       /* FA2db.c:676-688: a file cannot be added twice */
-    static int    nseen = 0;
-    int j;
-    for (j = 0; j < nseen; j++)
-      if (strcmp(seen[j], core) == 0)
-        { fprintf(stderr, "File %s.fasta is already in database\n", core);
-          exit(1);
-        }
-    seen = (char **) realloc(seen, sizeof(char *) * (size_t) (nseen + 1));
-    seen[nseen++] = strdup(core);
-  }
+  if (file_seen(core))                               /* FA2db.c:676-688: a file cannot be added twice */
+    { fprintf(stderr, "File %s.fasta is already in database\n", core);
+      exit(1);
+    }
   snprintf(path, sizeof(path), "%.*s%s.fasta", (int) (b - name), name, core);
   if ((in = fopen(path, "r")) == NULL)
     { snprintf(path, sizeof(path), "%.*s%s.fa", (int) (b - name), name, core);
@@ -245,9 +277,9 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
 int main(int argc, char *argv[])
 { Out     o;
   HITS_DB db;
-  char   *root, *dir, path[2 * MAX_NAME + 16];
-  int     c, i, nfiles;
-  FILE   *flist = NULL;
+  char   *root, *dir, path[2 * MAX_NAME + 16], newstub[2 * MAX_NAME + 16];
+  int     c, i, ofiles = 0, first = 0, newblock = 0;
+  FILE   *flist = NULL, *istub;
 
   memset(&o, 0, sizeof(o));
   o.minlen = 1000;
@@ -256,17 +288,18 @@ int main(int argc, char *argv[])
     switch (c)
     { case 'v': o.verbose += 1; break;
       case 'x': o.minlen = atoi(optarg); break;
+      case 'a': newblock = 1; break;
       case 'f':
         if ((flist = fopen(optarg, "r")) == NULL)
           { fprintf(stderr, "Cannot open file of inputs '%s'\n", optarg);
             exit(1);
           }
         break;
-      case 'a': case 'b': case 'Q': case 'c':
-        fprintf(stderr, "FA2db: option -%c is not built in this tool (creation from .fasta files, -x and -f only)\n", c);
+      case 'b': case 'Q': case 'c':
+        fprintf(stderr, "FA2db: option -%c is not built in this tool (-v, -a, -x and -f are)\n", c);
         exit(1);
       default:
-        fprintf(stderr, "usage: FA2db [-v] [-x<int(1000)>] <path:db> <input:fasta> ...\n");
+        fprintf(stderr, "usage: FA2db [-va] [-x<int(1000)>] <path:db> (-f<file> | <input:fasta> ...)\n");
         exit(1);
     }
   if (o.minlen < 0)
@@ -274,7 +307,7 @@ int main(int argc, char *argv[])
       exit(1);
     }
   if ((flist == NULL && argc - optind < 2) || argc - optind < 1)
-    { fprintf(stderr, "usage: FA2db [-v] [-x<int(1000)>] <path:db> (-f<file> | <input:fasta> ...)\n");
+    { fprintf(stderr, "usage: FA2db [-va] [-x<int(1000)>] <path:db> (-f<file> | <input:fasta> ...)\n");
       exit(1);
     }
   root = damar_root(argv[optind], ".db");
@@ -282,23 +315,55 @@ int main(int argc, char *argv[])
     dir = s ? strndup(argv[optind], (size_t) (s - argv[optind])) : strdup(".");
   }
   snprintf(path, sizeof(path), "%s/%s.db", dir, root);
-  if (access(path, F_OK) == 0)
-    { fprintf(stderr, "FA2db: %s exists; appending to a database is not built in this tool\n", path);
-      exit(1);
-    }
-  o.stub = fopen(path, "w");
-  snprintf(path, sizeof(path), "%s/.%s.idx", dir, root);
-  o.idx = fopen(path, "w");
-  snprintf(path, sizeof(path), "%s/.%s.bps", dir, root);
-  o.bps = fopen(path, "w");
-  if (o.stub == NULL || o.idx == NULL || o.bps == NULL)
-    { fprintf(stderr, "FA2db: cannot create the database files of %s\n", root);
+  snprintf(newstub, sizeof(newstub), "%s/%s.dbx", dir, root);       /* FA2db.c:571: the new image replaces the old */
+  istub = fopen(path, "r");
+  if ((o.stub = fopen(newstub, "w+")) == NULL)
+    { fprintf(stderr, "FA2db: cannot create %s\n", newstub);
       exit(1);
     }
   memset(&db, 0, sizeof(db));
-  fwrite(&db, sizeof(db), 1, o.idx);                  /* place holder, rewritten below (FA2db.c:1114-1131) */
-  nfiles = argc - optind - 1;
-  fprintf(o.stub, "files = %9d\n", nfiles);
+  if (istub == NULL)
+    { snprintf(path, sizeof(path), "%s/.%s.idx", dir, root);
+      o.idx = fopen(path, "w+");
+      snprintf(path, sizeof(path), "%s/.%s.bps", dir, root);
+      o.bps = fopen(path, "w+");
+      if (o.idx == NULL || o.bps == NULL)
+        { fprintf(stderr, "FA2db: cannot create the database files of %s\n", root);
+          exit(1);
+        }
+      fwrite(&db, sizeof(db), 1, o.idx);             /* place holder, rewritten below (FA2db.c:1114-1131) */
+      fprintf(o.stub, "files = %9d\n", 0);
+    }
+  else                                               /* FA2db.c:533-590: add to an existing database */
+    { if (fscanf(istub, "files = %9d\n", &ofiles) != 1)
+        { fprintf(stderr, "FA2db: stub file of %s is junk\n", root);
+          exit(1);
+        }
+      snprintf(path, sizeof(path), "%s/.%s.idx", dir, root);
+      o.idx = fopen(path, "r+");
+      snprintf(path, sizeof(path), "%s/.%s.bps", dir, root);
+      o.bps = fopen(path, "r+");
+      if (o.idx == NULL || o.bps == NULL || fread(&db, sizeof(db), 1, o.idx) != 1)
+        { fprintf(stderr, "FA2db: cannot open the database files of %s\n", root);
+          exit(1);
+        }
+      fseeko(o.bps, 0, SEEK_END);
+      fseeko(o.idx, 0, SEEK_END);
+      first = o.ureads = db.ureads;
+      o.off = ftello(o.bps);
+      fprintf(o.stub, "files = %9d\n", 0);
+      for (i = 0; i < ofiles; i++)
+        { int  last;
+          char fname[MAX_NAME + 8], prolog[MAX_NAME + 8];
+          if (fscanf(istub, "  %9d %s %s\n", &last, fname, prolog) != 3)
+            { fprintf(stderr, "FA2db: stub file of %s is junk\n", root);
+              exit(1);
+            }
+          file_seen(fname);
+          fprintf(o.stub, "  %9d %s %s\n", last, fname, prolog);
+        }
+      o.nadded = ofiles;
+    }
   if (flist != NULL)                                   /* fileUtils.c:62-95: one name per line */
     { char nm[MAX_NAME + 8];
       while (fgets(nm, sizeof(nm), flist) != NULL)
@@ -314,20 +379,85 @@ int main(int argc, char *argv[])
     for (i = optind + 1; i < argc; i++)
       read_fasta(&o, argv[i]);
 
+  if (istub == NULL)                                   /* FA2db.c:1093-1110 */
+    { for (c = 0; c < 4; c++)
+        db.freq[c] = (float) ((1. * o.count[c]) / o.totlen);
+      db.totlen = o.totlen;
+      db.maxlen = o.maxlen;
+    }
+  else
+    { for (c = 0; c < 4; c++)
+        db.freq[c] = (float) ((db.freq[c] * db.totlen + (1. * o.count[c])) / (db.totlen + o.totlen));
+      db.totlen += o.totlen;
+      if (o.maxlen > db.maxlen)
+        db.maxlen = o.maxlen;
+    }
   db.ureads = o.ureads;
-  for (c = 0; c < 4; c++)
-    db.freq[c] = (float) ((1. * o.count[c]) / o.totlen);
-  db.totlen = o.totlen;
-  db.maxlen = o.maxlen;
+
+  { int nblock;                                        /* FA2db.c:908-975: extend an existing block partition */
+    if (istub != NULL && fscanf(istub, "blocks = %9d\n", &nblock) == 1)
+      { long long size;
+        long  pos = ftell(o.stub);
+        int   ufirst = 0, ireads = 0;
+        int64 tot = 0;
+        HITS_READ rec;
+        if (o.verbose)
+          fprintf(stderr, "Updating block partition ...\n");
+        fprintf(o.stub, "blocks = %9d\n", 0);
+        if (fscanf(istub, "size = %9lld\n", &size) != 1)
+          { fprintf(stderr, "FA2db: stub file of %s is junk\n", root);
+            exit(1);
+          }
+        fprintf(o.stub, "size = %9lld\n", size);
+        size *= 1000000ll;
+        if (!newblock)
+          nblock -= 1;
+        for (i = 0; i <= nblock; i++)
+          { if (fscanf(istub, " %9d\n", &ufirst) != 1)
+              { fprintf(stderr, "FA2db: stub file of %s is junk\n", root);
+                exit(1);
+              }
+            fprintf(o.stub, " %9d\n", ufirst);
+          }
+        fflush(o.idx);
+        fseeko(o.idx, (off_t) (sizeof(HITS_DB) + sizeof(HITS_READ) * (size_t) ufirst), SEEK_SET);
+        for (i = ufirst; i < o.ureads; i++)
+          { if (fread(&rec, sizeof(HITS_READ), 1, o.idx) != 1)
+              { fprintf(stderr, "FA2db: index of %s is truncated\n", root);
+                exit(1);
+              }
+            ireads += 1;
+            tot += rec.rlen;
+            if (tot >= size)
+              { fprintf(o.stub, " %9d\n", i + 1);
+                tot = 0;
+                ireads = 0;
+                nblock += 1;
+              }
+          }
+        if (ireads > 0)
+          { fprintf(o.stub, " %9d\n", o.ureads);
+            nblock += 1;
+          }
+        fseek(o.stub, pos, SEEK_SET);
+        fprintf(o.stub, "blocks = %9d\n", nblock);
+      }
+  }
   rewind(o.idx);
   fwrite(&db, sizeof(db), 1, o.idx);
-  rewind(o.stub);                                      /* files actually added (empty ones are skipped) */
+  rewind(o.stub);                                      /* files actually in the database (empty ones are skipped) */
   fprintf(o.stub, "files = %9d\n", o.nadded);
+  if (istub != NULL)
+    fclose(istub);
   fclose(o.stub);
   fclose(o.idx);
   fclose(o.bps);
-  track_write(&T_seq, dir, root, o.ureads);
-  if (T_pac_used)
-    track_write(&T_pac, dir, root, o.ureads);
+  snprintf(path, sizeof(path), "%s/%s.db", dir, root);
+  rename(newstub, path);
+  if (o.ureads > first)                                /* FA2x.c:192: no read added, no track touched */
+    { track_write(&T_seq, dir, root, first, o.ureads);
+      if (T_pac_used)
+        track_write(&T_pac, dir, root, first, o.ureads);
+    }
   return 0;
 }

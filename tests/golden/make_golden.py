@@ -289,6 +289,13 @@ def fa2db_md5():
         for name, md5 in sorted(dig.items()):
             f.write("%s %s\n" % (md5, name))
     print(dig)
+    with tempfile.TemporaryDirectory() as d:          # adding to an existing database, then -a
+        test_host.fasta_inputs(d)
+        dig = test_host.append_sequence(REF, d)
+    with open(os.path.join(HERE, "fa2db_append_ref_md5.txt"), "w") as f:
+        for name, md5 in sorted(dig.items()):
+            f.write("%s %s\n" % (md5, name))
+    print(dig)
 
 
 def trace_md5():

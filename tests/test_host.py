@@ -193,6 +193,15 @@ def db_digest(d, root="T"):
     return out
 
 
+def append_sequence(tools, d):
+    """FA2db pb; DBsplit -s1; FA2db plain (the partition is extended); FA2db -a mixed (a new block)."""
+    for cmd in (["FA2db", "-x1000", "T", "pb.fasta"], ["DBsplit", "-s1", "T"], ["FA2db", "-x1000", "T", "plain.fa"],
+                ["FA2db", "-x1000", "-a", "T", "mixed.fasta"]):
+        subprocess.run([os.path.join(tools, cmd[0])] + cmd[1:], cwd=d, check=True, stderr=subprocess.DEVNULL)
+    append_sequence.__wrapped_last__ = db_digest(d)
+    return append_sequence.__wrapped_last__
+
+
 def test_fa2db_and_dbsplit_equal_reference(built, tmp_path):
     """bin/FA2db + bin/DBsplit against the reference's tools on the same FASTA files: stub, .bps,
     the defined fields of the .idx, and the seqID / pacbio tracks (tests/golden/fa2db_ref_md5.txt, made with
@@ -229,11 +238,21 @@ def test_fa2db_and_dbsplit_equal_reference(built, tmp_path):
     d = db_digest(lst)
     d.pop("files.txt")
     assert d == got
-    # what is not built is refused, not ignored
+    # adding files to an existing, partitioned database (FA2db.c:533-590, 908-975), then -a (new block)
+    app = str(tmp_path / "app")
+    os.makedirs(app)
+    fasta_inputs(app)
+    assert append_sequence(tools, app) == dict(ln.split()[::-1] for ln in open(os.path.join(GOLDEN, "fa2db_append_ref_md5.txt")))
+    if os.path.exists(os.path.join(ref, "FA2db")):
+        live = str(tmp_path / "appref")
+        os.makedirs(live)
+        fasta_inputs(live)
+        assert append_sequence(ref, live) == append_sequence.__wrapped_last__
+    # what is not built is refused, not ignored; a file cannot be added twice
     r = subprocess.run([os.path.join(tools, "FA2db"), "-b", "U"] + files, cwd=own, stderr=subprocess.PIPE, text=True)
     assert r.returncode != 0 and "not built" in r.stderr
-    r = subprocess.run([os.path.join(tools, "FA2db"), "T"] + files, cwd=own, stderr=subprocess.PIPE, text=True)
-    assert r.returncode != 0 and "appending" in r.stderr
+    r = subprocess.run([os.path.join(tools, "FA2db"), "T", files[0]], cwd=own, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "already in database" in r.stderr
 
 
 def test_lamerge_equals_reference(built, tmp_path):
