@@ -6,11 +6,11 @@
  * 154-300 tracks; fileUtils.c:8-46 isPacBioHeader) -- except for the fields of the .idx header that the
  * reference leaves uninitialised, which are zero here.
  *
- *     FA2db [-v] [-a] [-x<int(1000)>] <path:db> (-f<file of fasta names> | <input:fasta> ...)
+ *     FA2db [-v] [-a] [-b] [-x<int(1000)>] <path:db> (-f<file of fasta names> | <input:fasta> ...)
  *
  * Built: creating a database from .fasta / .fa files and adding files to an existing one (its block
- * partition is extended, FA2db.c:908-975; -a starts a new block), -x, -f.  Not built (rejected with a
- * message): -b, -Q, -c.  Host code, C, no GPU.
+ * partition is extended, FA2db.c:908-975; -a starts a new block), -b (longest read of a well), -x, -f.  Not built
+ * (rejected with a message): -Q, -c.  Host code, C, no GPU.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -134,7 +134,7 @@ static const char *base_name(const char *path)
 typedef struct
 { FILE *idx, *bps, *stub;
   int64 off, totlen, count[4];
-  int   ureads, maxlen, minlen, verbose, nadded;
+  int   ureads, maxlen, minlen, verbose, nadded, best;
 } Out;
 
 static void add_read(Out *o, char *seq, int len, int seqid, int pac, int well, int beg, int end)   /* FA2db.c:611-651 */
@@ -186,6 +186,9 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
   size_t lcap = 0;
   ssize_t n;
   int    smax = 0, rlen = 0, seqid = -1, have = 0;
+  int    cnt[2] = { -1, -1 }, nxt = 0;
+  char  *bseq = NULL;                                 /* -b: the best read of the current well */
+  int    bmax = 0, blen = 0, bseqid = 0, bpac = 0, bwell = 0, bbeg = 0, bend = 0;
   FILE  *in;
   const char *b = base_name(name);
   size_t bl = strlen(b);
@@ -240,7 +243,11 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
       if (n < 0)
         break;
       snprintf(header, sizeof(header), "%s", line + 1);
-      seqid += 1;
+      /* FA2db.c:744-750: the index inside the file is counted per read record of the reference's two
+         alternating records; without -b only one of them is ever parsed into, so it is the plain index,
+         with -b each counts the headers parsed into it -- reproduced as it is */
+      cnt[nxt] += 1;
+      seqid = cnt[nxt];
       if (is_pacbio_header(header))
         { const char *slash = strchr(header, '/');
           pac = (sscanf(slash + 1, "%d/%d_%d\n", &well, &beg, &end) == 3);
@@ -261,13 +268,38 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
           memcpy(seq + rlen, line, (size_t) n);
           rlen += (int) n;
         }
-      if (rlen >= o->minlen)
+      if (rlen < o->minlen)
+        { if (o->verbose > 1)
+            fprintf(stderr, "Warning: skipping read of length %d\n", rlen);
+        }
+      else if (!o->best)
         add_read(o, seq, rlen, seqid, pac, well, beg, end);
-      else if (o->verbose > 1)
-        fprintf(stderr, "Warning: skipping read of length %d\n", rlen);
+      else
+        { /* -b (FA2db.c:858-893): of consecutive reads of one well only the longest enters the database (the
+             first of equally long ones; reads without a PacBio header all count as well -1) */
+          if (bseq != NULL && bwell == well)
+            { if (blen < rlen)
+                goto take;
+            }
+          else
+            { if (bseq != NULL)
+                add_read(o, bseq, blen, bseqid, bpac, bwell, bbeg, bend);
+            take:
+              if (rlen + 1 > bmax)
+                { bmax = rlen + rlen / 4 + 1000;
+                  bseq = (char *) realloc(bseq, (size_t) bmax);
+                }
+              memcpy(bseq, seq, (size_t) rlen);
+              blen = rlen;  bseqid = seqid;  bpac = pac;  bwell = well;  bbeg = beg;  bend = end;
+              nxt ^= 1;                              /* the record just parsed is the best one now: parse into the other */
+            }
+        }
       if (!have)
         break;
     }
+  if (o->best && bseq != NULL)
+    add_read(o, bseq, blen, bseqid, bpac, bwell, bbeg, bend);
+  free(bseq);
   fprintf(o->stub, "  %9d %s %s\n", o->ureads, core, prolog);
   fclose(in);
   free(line);
@@ -289,14 +321,15 @@ int main(int argc, char *argv[])
     { case 'v': o.verbose += 1; break;
       case 'x': o.minlen = atoi(optarg); break;
       case 'a': newblock = 1; break;
+      case 'b': o.best = 1; break;
       case 'f':
         if ((flist = fopen(optarg, "r")) == NULL)
           { fprintf(stderr, "Cannot open file of inputs '%s'\n", optarg);
             exit(1);
           }
         break;
-      case 'b': case 'Q': case 'c':
-        fprintf(stderr, "FA2db: option -%c is not built in this tool (-v, -a, -x and -f are)\n", c);
+      case 'Q': case 'c':
+        fprintf(stderr, "FA2db: option -%c is not built in this tool (-v, -a, -b, -x and -f are)\n", c);
         exit(1);
       default:
         fprintf(stderr, "usage: FA2db [-va] [-x<int(1000)>] <path:db> (-f<file> | <input:fasta> ...)\n");

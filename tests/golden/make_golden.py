@@ -296,6 +296,14 @@ def fa2db_md5():
         for name, md5 in sorted(dig.items()):
             f.write("%s %s\n" % (md5, name))
     print(dig)
+    with tempfile.TemporaryDirectory() as d:          # -b
+        files = test_host.fasta_inputs(d)
+        run([os.path.join(REF, "FA2db"), "-x1000", "-b", "T"] + files, d, stderr=subprocess.DEVNULL)
+        dig = test_host.db_digest(d)
+    with open(os.path.join(HERE, "fa2db_best_ref_md5.txt"), "w") as f:
+        for name, md5 in sorted(dig.items()):
+            f.write("%s %s\n" % (md5, name))
+    print(dig)
 
 
 def trace_md5():

@@ -249,8 +249,14 @@ def test_fa2db_and_dbsplit_equal_reference(built, tmp_path):
         fasta_inputs(live)
         assert append_sequence(ref, live) == append_sequence.__wrapped_last__
     # what is not built is refused, not ignored; a file cannot be added twice
-    r = subprocess.run([os.path.join(tools, "FA2db"), "-b", "U"] + files, cwd=own, stderr=subprocess.PIPE, text=True)
+    r = subprocess.run([os.path.join(tools, "FA2db"), "-Q", "U"] + files, cwd=own, stderr=subprocess.PIPE, text=True)
     assert r.returncode != 0 and "not built" in r.stderr
+    # -b: only the longest read of a well (FA2db.c:858-893, the per-record file indices of the seqID track included)
+    bst = str(tmp_path / "best")
+    os.makedirs(bst)
+    fasta_inputs(bst)
+    subprocess.run([os.path.join(tools, "FA2db"), "-x1000", "-b", "T"] + files, cwd=bst, check=True, stderr=subprocess.DEVNULL)
+    assert db_digest(bst) == dict(ln.split()[::-1] for ln in open(os.path.join(GOLDEN, "fa2db_best_ref_md5.txt")))
     r = subprocess.run([os.path.join(tools, "FA2db"), "T", files[0]], cwd=own, stderr=subprocess.PIPE, text=True)
     assert r.returncode != 0 and "already in database" in r.stderr
 
