@@ -16,17 +16,25 @@ for it in range(n):
                           erate=rng.choice([.10, .15, .18]))
     o = dict(j=rng.choice([1, 4, 16]), symmetric=rng.choice([1, 1, 0]), identity=rng.choice([0, 1]), t=rng.choice([0, 0, 15]),
              l=rng.choice([1000, 1500]))
-    blocks = {i: driver.Block(os.path.join(w, "R.%d" % i)) for i in range(1, nb + 1)}
     gdir = os.path.join(w, "g")
-    plan = driver.Plan(**o)
-    for a, bs in driver.hpc_plan(nb):
-        plan.run_line(blocks[a], [blocks[b] for b in bs], gdir)
-    plan.finish()
+    opts = ["-k14", "-j%d" % o["j"], "-l%d" % o["l"]] + (["-t%d" % o["t"]] if o["t"] else []) + (["-I"] if o["identity"] else []) + \
+           ([] if o["symmetric"] else ["-A"])
+    if os.environ.get("DAMAR_STRESS_CLI"):     # the command-line driver (block reader thread, preloaded blocks) instead
+        os.makedirs(gdir)
+        for f in ("R.db", ".R.idx", ".R.bps"):
+            os.symlink(os.path.join(w, f), os.path.join(gdir, f))
+        for a, bs in driver.hpc_plan(nb):
+            subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "daligner")] + opts + ["R.%d" % a] + ["R.%d" % b for b in bs],
+                           cwd=gdir, check=True, stdout=subprocess.DEVNULL)
+    else:
+        blocks = {i: driver.Block(os.path.join(w, "R.%d" % i)) for i in range(1, nb + 1)}
+        plan = driver.Plan(**o)
+        for a, bs in driver.hpc_plan(nb):
+            plan.run_line(blocks[a], [blocks[b] for b in bs], gdir)
+        plan.finish()
     odir = os.path.join(w, "o"); os.makedirs(odir)
     for f in ("R.db", ".R.idx", ".R.bps"):
         os.symlink(os.path.join(w, f), os.path.join(odir, f))
-    opts = ["-k14", "-j%d" % o["j"], "-l%d" % o["l"]] + (["-t%d" % o["t"]] if o["t"] else []) + (["-I"] if o["identity"] else []) + \
-           ([] if o["symmetric"] else ["-A"])
     for a, bs in driver.hpc_plan(nb):
         subprocess.run([os.path.join(ROOT, "oracle", "oracle_daligner")] + opts + ["R.%d" % a] + ["R.%d" % b for b in bs],
                        cwd=odir, check=True, stdout=subprocess.DEVNULL)
