@@ -16,7 +16,12 @@ the barriers around the timed region and the max/sum of the results.
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel,
 HIP-event timed on the library's stream) and `cpu_baseline` (the compiled reference
-daligner from oracle/_ref timed on the host cores on a bounded sample; N == 1 only).
+daligner from oracle/_ref timed on the host cores on a bounded sample; N == 1 only).  A further
+key, `trace_expand` (N == 1 only, outside the timed region and not part of `value`), reports the
+records' next consumer of SURVEY 8(f)4 -- trace points to edit scripts, Compute_Trace_PTS -- on the
+block-1 self-comparison the step has just written: HIP-event times of damar_trace_pts, the
+reference's Compute_Trace_PTS on one host thread on the same file, and whether the two outputs
+are identical.
 """
 import argparse
 import json
