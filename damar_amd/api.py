@@ -27,7 +27,8 @@ class HITS_DB(C.Structure):            # db/DB.h:361-389
 class SimParams(C.Structure):          # include/damar_db.h damar_sim_params
     _fields_ = [("genome_mbp", C.c_double), ("coverage", C.c_double), ("bias", C.c_double),
                 ("seed", C.c_int), ("rmean", C.c_int), ("rsdev", C.c_int), ("rshort", C.c_int),
-                ("erate", C.c_double), ("block_mbp", C.c_int), ("min_len", C.c_int)]
+                ("erate", C.c_double), ("block_mbp", C.c_int), ("min_len", C.c_int),
+                ("tandem_frac", C.c_double), ("max_blocks", C.c_int)]
 
 
 T_NAMES = ["tuples", "ksort", "table", "merge", "ssort", "work", "report", "d2h", "tail"]
@@ -73,6 +74,12 @@ def _lib():
         L.damar_index_build.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.damar_index_build.restype = C.c_void_p
         L.damar_index_free.argtypes = [C.c_void_p]
+        L.damar_index_bytes.argtypes = [C.c_void_p]
+        L.damar_index_bytes.restype = C.c_uint64
+        L.damar_complement_copy.argtypes = [C.POINTER(HITS_DB), C.POINTER(HITS_DB)]
+        L.damar_free_complement.argtypes = [C.POINTER(HITS_DB)]
+        L.damar_async_drain.argtypes = []
+        L.damar_set_bread_range.argtypes = [C.c_int, C.c_int]
         L.damar_index_download.argtypes = [C.c_void_p, C.c_void_p]
         L.damar_match.argtypes = [C.POINTER(HITS_DB), C.POINTER(HITS_DB), C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_void_p, C.POINTER(c_int64)]
@@ -109,13 +116,15 @@ def set_globals(verbose=0, minover=2000, symmetric=1, identity=0, hgap_min=0, bi
 
 
 def sim_write_db(directory, root, genome_mbp, coverage=20., seed=1, erate=.15, block_mbp=200,
-                 rmean=10000, rsdev=2000, rshort=4000):
+                 rmean=10000, rsdev=2000, rshort=4000, tandem_frac=0., max_blocks=0):
     """db/simulator.c | FA2db | DBsplit equivalent (include/damar_db.h); returns #blocks."""
     L = _lib()
     p = SimParams()
     L.damar_sim_defaults(C.byref(p))
     p.genome_mbp, p.coverage, p.seed, p.erate, p.block_mbp = genome_mbp, coverage, seed, erate, block_mbp
     p.rmean, p.rsdev, p.rshort = rmean, rsdev, rshort
+    p.tandem_frac = tandem_frac
+    p.max_blocks = max_blocks
     nb = L.damar_sim_write_db(C.byref(p), directory.encode(), root.encode())
     if nb < 0:
         raise RuntimeError("damar_sim_write_db failed")

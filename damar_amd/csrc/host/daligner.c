@@ -6,6 +6,14 @@
  * The B blocks of the line are read, checked and reverse-complemented one or two ahead on a second
  * thread while the GPU works on the current one.  Rejected explicitly: -D (dynamic mask server).
  * -H is accepted and has no effect, exactly like the reference.
+ *
+ * Plan mode, `daligner [options] -P <plan file | ->`: every `daligner ...` line of an HPCdaligner plan
+ * (dalign/HPCdaligner.c:628-788) in ONE process.  The reference runs one process per line
+ * (daligner.c:662-1077), so every line reads its blocks again and sorts their k-mers again; here a block
+ * is read, reverse-complemented, uploaded and indexed once and stays resident (HBM: 1.25 B per base and
+ * strand + 8 B per k-mer + the prefix table) for all the lines that name it, least recently used blocks
+ * released beyond DAMAR_PLAN_BLOCKS (default 64).  Options in front of -P apply to every line; a line's own
+ * options are parsed on top of them.  Output files are those of the separate commands.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -24,6 +32,7 @@ static void usage(void)
   fprintf(stderr, "daligner [-vbAIOT] [-k<int(14)>] [-w<int(6)>] [-h<int(35)>] [-t<int>] [-M<int>] [-m<track>]+\n");
   fprintf(stderr, "         [-e<double(.70)] [-l<int(1000)>] [-s<int(100)>] [-H<int>] [-j<int>]\n");
   fprintf(stderr, "         [-r<int(1)>] [-g<gpu ordinal(0)>] <subject:db> <target:db> ...\n");
+  fprintf(stderr, "daligner [options] -P <HPCdaligner plan file, or - for stdin>\n");
 }
 
 static void make_subdir(const HITS_DB *block, int run)      /* daligner.c:630-660 */
@@ -44,13 +53,19 @@ static void make_subdir(const HITS_DB *block, int run)      /* daligner.c:630-66
   free(d);
 }
 
-static void check_reads(const HITS_DB *b, const char *name, int kmer)     /* daligner.c:499-504 */
+static int check_reads_ok(const HITS_DB *b, const char *name, int kmer)     /* daligner.c:499-504 */
 { int i;
   for (i = 0; i < b->nreads; i++)
     if (b->reads[i].rlen < kmer)
       { fprintf(stderr, "[ERROR] - daligner: Block %s contains reads < %dbp long !  Run DBsplit.\n", name, kmer);
-        exit(1);
+        return 0;
       }
+  return 1;
+}
+
+static void check_reads(const HITS_DB *b, const char *name, int kmer)
+{ if (!check_reads_ok(b, name, kmer))
+    exit(1);
 }
 
 /* DAMAR_CLIPROF=1: wall clock of the driver's phases on stderr at exit */
@@ -82,6 +97,14 @@ static struct
   pthread_cond_t  cv;
 } PF;
 
+/* a failure on the reader thread: the main thread may be inside HIP calls and the tail workers running, so
+   no exit handlers (the library's die() leaves the same way) */
+static void reader_fail(void)
+{ fflush(stdout);
+  fflush(stderr);
+  _exit(1);
+}
+
 static void *prepare_blocks(void *arg)
 { int i;
   (void) arg;
@@ -95,12 +118,13 @@ static void *prepare_blocks(void *arg)
       if (!it->same)
         { double t0 = wall_ms();
           if (damar_read_block(PF.names[i], &it->blk))
-            exit(1);
+            reader_fail();
           if (damar_load_masks(&it->blk, PF.mask, PF.mtop))
             { printf("[ERROR] - Unable to load track!\n");
-              exit(1);
+              reader_fail();
             }
-          check_reads(&it->blk, PF.names[i], PF.kmer);
+          if (check_reads_ok(&it->blk, PF.names[i], PF.kmer) == 0)
+            reader_fail();
           P_ms[0] += wall_ms() - t0;
           t0 = wall_ms();
           damar_block_preload(&it->blk);          /* to HBM on its own stream; Sort_Kmers picks it up */
@@ -139,57 +163,60 @@ static void done_with(int i)
   pthread_mutex_unlock(&PF.mu);
 }
 
-int main(int argc, char *argv[])
-{ HITS_DB ablock;
-  char   *afile, *aroot;
-  void   *aindex, *bindex;
-  int     alen, blen;
-  Align_Spec *spec;
-  int     kmer = 14, hitmin = 35, binshift = 6, maxreps = 0;
-  double  ecorr = .70;
-  int     spacing = 100, runid = 1, notrace = 0, nthreads = 4, only_id = 0, gpu = -1;
-  int     c, i;
-  char   *mask[64];                     /* -m tracks, daligner.c:788-795 */
-  int     mtop = 0;
+typedef struct
+{ int    kmer, hitmin, binshift, maxreps, spacing, runid, notrace, nthreads, only_id, gpu;
+  double ecorr;
+  int    minover, identity, symmetric, biased, verbose;
+  int    have_mem;  int mem_gb;
+  char  *mask[64];
+  int    mtop;
+  char  *plan;
+} Opts;
 
-  MINOVER = 1000;
-  IDENTITY = 0;
-  SYMMETRIC = 1;
+static void default_opts(Opts *o)
+{ memset(o, 0, sizeof(*o));
+  o->kmer = 14;  o->hitmin = 35;  o->binshift = 6;  o->ecorr = .70;  o->spacing = 100;  o->runid = 1;
+  o->nthreads = 4;  o->gpu = -1;  o->minover = 1000;  o->symmetric = 1;
+}
+
+/* daligner.c:721-812; returns the index of the first non-option argument */
+static int parse_opts(int argc, char *argv[], Opts *o)
+{ int c;
   opterr = 0;
-  while ((c = getopt(argc, argv, "vbOTAIk:w:h:t:M:e:l:s:H:D:m:r:j:g:")) != -1)
+  optind = 1;
+  while ((c = getopt(argc, argv, "vbOTAIk:w:h:t:M:e:l:s:H:D:m:r:j:g:P:")) != -1)
     switch (c)
-    { case 'v': VERBOSE = 1; break;
-      case 'T': notrace = 1; break;
-      case 'I': IDENTITY = 1; break;
-      case 'O': IDENTITY = 1; only_id = 1; break;
-      case 'A': SYMMETRIC = 0; break;
-      case 'k': kmer = atoi(optarg); break;
-      case 'w': binshift = atoi(optarg); break;
-      case 'h': hitmin = atoi(optarg); break;
-      case 't': maxreps = atoi(optarg); break;
+    { case 'v': o->verbose = 1; break;
+      case 'T': o->notrace = 1; break;
+      case 'I': o->identity = 1; break;
+      case 'O': o->identity = 1; o->only_id = 1; break;
+      case 'A': o->symmetric = 0; break;
+      case 'k': o->kmer = atoi(optarg); break;
+      case 'w': o->binshift = atoi(optarg); break;
+      case 'h': o->hitmin = atoi(optarg); break;
+      case 't': o->maxreps = atoi(optarg); break;
       case 'H': break;
-      case 'e': ecorr = atof(optarg); break;
-      case 'l': MINOVER = atoi(optarg); break;
-      case 's': spacing = atoi(optarg); break;
-      case 'j': nthreads = atoi(optarg); break;
-      case 'r': runid = atoi(optarg); break;
-      case 'g': gpu = atoi(optarg); break;
+      case 'e': o->ecorr = atof(optarg); break;
+      case 'l': o->minover = atoi(optarg); break;
+      case 's': o->spacing = atoi(optarg); break;
+      case 'j': o->nthreads = atoi(optarg); break;
+      case 'r': o->runid = atoi(optarg); break;
+      case 'g': o->gpu = atoi(optarg); break;
+      case 'P': o->plan = optarg; break;
       case 'M':
-        { int gb = atoi(optarg);
-          if (gb < 0)
-            fprintf(stderr, "invalid memory limit of (%d)\n", gb);
-          damar_hip_init(gpu < 0 ? 0 : gpu);     /* sets MEM_PHYSICAL before we override the limit */
-          MEM_LIMIT = (uint64) gb * 0x40000000ull;
-          break;
-        }
+        o->mem_gb = atoi(optarg);
+        if (o->mem_gb < 0)
+          fprintf(stderr, "invalid memory limit of (%d)\n", o->mem_gb);
+        o->have_mem = 1;
+        break;
       case 'm':
-        if (mtop >= 64)
+        if (o->mtop >= 64)
           { fprintf(stderr, "daligner: too many -m tracks\n");
             exit(1);
           }
-        mask[mtop++] = optarg;
+        o->mask[o->mtop++] = optarg;
         break;
-      case 'b': BIASED = 1; break;
+      case 'b': o->biased = 1; break;
       case 'D':
         fprintf(stderr, "daligner: option -%c is not supported by this build\n", c);
         exit(1);
@@ -198,26 +225,84 @@ int main(int argc, char *argv[])
         usage();
         exit(1);
     }
-  if (kmer < 0 || binshift < 0 || hitmin < 0 || maxreps < 0 || MINOVER < 0 || spacing < 0 || runid < 0)
+  if (o->kmer < 0 || o->binshift < 0 || o->hitmin < 0 || o->maxreps < 0 || o->minover < 0 || o->spacing < 0 || o->runid < 0)
     { fprintf(stderr, "daligner: negative option value\n");
       exit(1);
     }
-  if (ecorr < .5 || ecorr >= 1.)
-    { fprintf(stderr, "Average correlation must be in [.5,1.) (%g)\n", ecorr);
+  if (o->ecorr < .5 || o->ecorr >= 1.)
+    { fprintf(stderr, "Average correlation must be in [.5,1.) (%g)\n", o->ecorr);
       exit(1);
     }
+  return optind;
+}
+
+/* the device is chosen once per process, after all options are known: -g, then DAMAR_DEVICE, then 0; only
+   then may -M override the memory limit (damar_hip_init sets MEM_LIMIT / MEM_PHYSICAL on its first call) */
+static void select_device(const Opts *o)
+{ int gpu = o->gpu;
+  if (gpu < 0 && getenv("DAMAR_DEVICE") != NULL)
+    gpu = atoi(getenv("DAMAR_DEVICE"));
+  damar_hip_init(gpu < 0 ? 0 : gpu);
+  if (o->have_mem)
+    MEM_LIMIT = (uint64) o->mem_gb * 0x40000000ull;
+}
+
+static void apply_opts(const Opts *o)
+{ VERBOSE = o->verbose;
+  IDENTITY = o->identity;
+  SYMMETRIC = o->symmetric;
+  BIASED = o->biased;
+  MINOVER = 2 * o->minover;                        /* daligner.c:861 */
+  if (Set_Filter_Params(o->kmer, o->binshift, o->maxreps, o->hitmin, o->nthreads))
+    { fprintf(stderr, "Illegal combination of filter parameters\n");
+      exit(1);
+    }
+}
+
+static int symmetric_for(const char *afile, const char *aroot, char **bfiles, int nb)     /* daligner.c:911-946 */
+{ int i;
+  for (i = 0; i < nb; i++)
+    if (strcmp(afile, bfiles[i]) != 0)
+      { char *broot = damar_root(bfiles[i], ".db");
+        char *ad = strrchr(aroot, '.'), *bd = strrchr(broot, '.');
+        size_t la = ad ? (size_t) (ad - aroot + 1) : strlen(aroot);
+        size_t lb = bd ? (size_t) (bd - broot + 1) : strlen(broot);
+        int differ = strncmp(aroot, broot, la > lb ? la : lb) != 0;
+        if (differ && VERBOSE)
+          printf("[WARNING] - Daligner is performed on different databases (%s - %s). SYMMETRIC option is disabled!\n",
+                 aroot, broot);
+        free(broot);
+        if (differ)
+          return 0;
+      }
+  return 1;
+}
+
+static int plan_main(const Opts *base, const char *planfile);
+
+int main(int argc, char *argv[])
+{ HITS_DB ablock;
+  char   *afile, *aroot;
+  void   *aindex, *bindex;
+  int     alen, blen;
+  Align_Spec *spec;
+  Opts    O;
+  int     kmer, runid, nthreads;
+  char  **mask;
+  int     mtop, i;
+
+  default_opts(&O);
+  optind = parse_opts(argc, argv, &O);
+  if (O.plan != NULL)
+    return plan_main(&O, O.plan);
+  kmer = O.kmer;  runid = O.runid;  nthreads = O.nthreads;  mask = O.mask;  mtop = O.mtop;
   if (optind + 2 > argc)
     { fprintf(stderr, "[ERROR] - at least one target and one subject block are required\n\n");
       usage();
       exit(1);
     }
-  MINOVER *= 2;
-  if (Set_Filter_Params(kmer, binshift, maxreps, hitmin, nthreads))
-    { fprintf(stderr, "Illegal combination of filter parameters\n");
-      exit(1);
-    }
-  if (gpu >= 0)
-    damar_hip_init(gpu);
+  select_device(&O);
+  apply_opts(&O);
 
   afile = argv[optind++];
   { double t0_ = wall_ms();
@@ -232,26 +317,11 @@ int main(int argc, char *argv[])
   check_reads(&ablock, afile, kmer);
   aroot = damar_root(afile, ".db");
 
-  if (SYMMETRIC)                                   /* daligner.c:911-946 */
-    for (i = optind; i < argc; i++)
-      if (strcmp(afile, argv[i]) != 0)
-        { char *broot = damar_root(argv[i], ".db");
-          char *ad = strrchr(aroot, '.'), *bd = strrchr(broot, '.');
-          size_t la = ad ? (size_t) (ad - aroot + 1) : strlen(aroot);
-          size_t lb = bd ? (size_t) (bd - broot + 1) : strlen(broot);
-          if (strncmp(aroot, broot, la > lb ? la : lb) != 0)
-            { if (VERBOSE)
-                printf("[WARNING] - Daligner is performed on different databases (%s - %s). SYMMETRIC option is disabled!\n",
-                       aroot, broot);
-              SYMMETRIC = 0;
-            }
-          free(broot);
-          if (!SYMMETRIC)
-            break;
-        }
+  if (SYMMETRIC)
+    SYMMETRIC = symmetric_for(afile, aroot, argv + optind, argc - optind);
 
   make_subdir(&ablock, runid);
-  spec = New_Align_Spec(ecorr, spacing, ablock.freq, nthreads, SYMMETRIC, only_id, notrace, 1);
+  spec = New_Align_Spec(O.ecorr, O.spacing, ablock.freq, nthreads, SYMMETRIC, O.only_id, O.notrace, 1);
 
   /* The host tail (redundancy handling, sort, .las write) of a block pair runs on a worker
      thread while the GPU starts on the next pair; B blocks stay alive until it is done. */
@@ -268,9 +338,7 @@ int main(int argc, char *argv[])
     PF.produced = PF.consumed = 0;
     pthread_mutex_init(&PF.mu, NULL);
     pthread_cond_init(&PF.cv, NULL);
-    if (gpu < 0 && getenv("DAMAR_DEVICE") != NULL)
-      gpu = atoi(getenv("DAMAR_DEVICE"));
-    damar_hip_init(gpu < 0 ? 0 : gpu);            /* before the second thread makes its first HIP call */
+    /* (the device was selected above, before the second thread makes its first HIP call) */
     if (pthread_create(&th, NULL, prepare_blocks, NULL) != 0)
       { fprintf(stderr, "daligner: cannot start the block reader thread\n");
         exit(1);
@@ -351,6 +419,247 @@ int main(int argc, char *argv[])
   damar_set_async(0);
   if (getenv("DAMAR_CLIPROF"))
     { fprintf(stderr, "cli: wall ms:");
+      for (i = 0; i < 8; i++)
+        fprintf(stderr, " %s=%.1f", P_name[i], P_ms[i]);
+      fprintf(stderr, "\n");
+    }
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * Plan mode: many `daligner` lines, one process, blocks and k-mer indexes resident (see the header).
+ * The C mirror of damar_amd/driver.py's Plan on the device-resident entry points of damar_hip.h.
+ * ------------------------------------------------------------------------------------------------- */
+
+typedef struct
+{ char    *name;
+  HITS_DB  blk, cblk;
+  damar_dev_block *dev[2];          /* forward / complement bases in HBM */
+  damar_dev_index *idx[2];          /* their k-mer indexes */
+  int      ilen[2];
+  long     used;                    /* LRU stamp */
+  int      busy;                    /* named by the pair being computed */
+} PBlock;
+
+static PBlock *PB;
+static int     PB_n, PB_cap, PB_max = 64;
+static long    PB_clock;
+static int     PB_builds;
+
+static void pblock_release(PBlock *b)
+{ int c;
+  for (c = 0; c < 2; c++)
+    { if (b->idx[c] != NULL) damar_index_free(b->idx[c]);
+      if (b->dev[c] != NULL) damar_block_free(b->dev[c]);
+      b->idx[c] = NULL;  b->dev[c] = NULL;
+    }
+  damar_free_complement(&b->cblk);
+  damar_close_block(&b->blk);
+  free(b->name);
+}
+
+static void pblock_flush_indexes(void)             /* the filter parameters changed: indexes are stale */
+{ int i, c;
+  for (i = 0; i < PB_n; i++)
+    for (c = 0; c < 2; c++)
+      if (PB[i].idx[c] != NULL)
+        { damar_index_free(PB[i].idx[c]);
+          PB[i].idx[c] = NULL;
+        }
+}
+
+static PBlock *pblock_get(const char *name, const Opts *o)
+{ int i;
+  for (i = 0; i < PB_n; i++)
+    if (strcmp(PB[i].name, name) == 0)
+      { PB[i].used = ++PB_clock;
+        return PB + i;
+      }
+  if (PB_n >= PB_max)                               /* evict the least recently used idle block */
+    { int v = -1;
+      for (i = 0; i < PB_n; i++)
+        if (!PB[i].busy && (v < 0 || PB[i].used < PB[v].used))
+          v = i;
+      if (v >= 0)
+        { damar_async_drain();                      /* the host tail may still read its bases */
+          pblock_release(PB + v);
+          PB[v] = PB[--PB_n];
+        }
+    }
+  if (PB_n >= PB_cap)
+    { PB_cap = 2 * PB_cap + 16;
+      PB = (PBlock *) realloc(PB, sizeof(PBlock) * (size_t) PB_cap);
+      if (PB == NULL)
+        { fprintf(stderr, "daligner: out of memory (block table)\n");
+          exit(1);
+        }
+    }
+  { PBlock *b = PB + PB_n++;
+    double t0 = wall_ms();
+    memset(b, 0, sizeof(*b));
+    b->name = strdup(name);
+    if (damar_read_block(name, &b->blk))
+      exit(1);
+    if (damar_load_masks(&b->blk, (char **) o->mask, o->mtop))
+      { printf("[ERROR] - Unable to load track!\n");
+        exit(1);
+      }
+    check_reads(&b->blk, name, o->kmer);
+    P_ms[0] += wall_ms() - t0;
+    t0 = wall_ms();
+    damar_complement_copy(&b->blk, &b->cblk);
+    P_ms[3] += wall_ms() - t0;
+    b->used = ++PB_clock;
+    return b;
+  }
+}
+
+static damar_dev_index *pblock_index(PBlock *b, int comp)
+{ if (b->idx[comp] == NULL)
+    { double t0 = wall_ms();
+      if (b->dev[comp] == NULL)
+        b->dev[comp] = damar_block_upload(comp ? &b->cblk : &b->blk);
+      P_ms[7] += wall_ms() - t0;
+      t0 = wall_ms();
+      b->idx[comp] = damar_index_build(b->dev[comp], 0, &b->ilen[comp]);
+      P_ms[1] += wall_ms() - t0;
+      PB_builds += 1;
+    }
+  return b->idx[comp];
+}
+
+/* one plan line: daligner.c:948-1074 */
+static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
+{ static Opts last;
+  static int  have_last = 0;
+  PBlock *a;
+  char   *aroot;
+  Align_Spec *spec;
+  int64   cnt[3];
+  int     k;
+
+  if (have_last && (last.kmer != o->kmer || last.maxreps != o->maxreps || last.biased != o->biased || last.mtop != o->mtop))
+    { damar_async_drain();
+      pblock_flush_indexes();
+      if (last.mtop != o->mtop)                   /* other mask tracks: the blocks themselves are stale */
+        { while (PB_n > 0)
+            pblock_release(PB + --PB_n);
+        }
+    }
+  last = *o;  have_last = 1;
+  apply_opts(o);
+  a = pblock_get(afile, o);
+  a->busy = 1;
+  aroot = damar_root(afile, ".db");
+  if (SYMMETRIC)
+    SYMMETRIC = symmetric_for(afile, aroot, bfiles, nb);
+  make_subdir(&a->blk, o->runid);
+  spec = New_Align_Spec(o->ecorr, o->spacing, a->blk.freq, o->nthreads, SYMMETRIC, o->only_id, o->notrace, 1);
+  for (k = 0; k < nb; k++)
+    { double t0;
+      if (strcmp(afile, bfiles[k]) == 0)
+        { char *d1 = NULL;
+          damar_dev_index *ai = pblock_index(a, 0), *ci;
+          t0 = wall_ms();
+          damar_match(&a->blk, &a->blk, ai, ai, 1, 0, spec, cnt);
+          P_ms[2] += wall_ms() - t0;
+          ci = pblock_index(a, 1);
+          t0 = wall_ms();
+          damar_match(&a->blk, &a->cblk, ai, ci, 1, 1, spec, cnt);
+          P_ms[2] += wall_ms() - t0;
+          if (a->blk.part > 0) d1 = damar_get_dir(o->runid, a->blk.part);
+          TIMED(4, damar_write_overlaps(spec, d1, NULL, aroot, aroot, a->blk.ufirst + a->blk.nreads - 1));
+          free(d1);
+        }
+      else
+        { PBlock *b;
+          char   *broot = damar_root(bfiles[k], ".db"), *d1 = NULL, *d2 = NULL;
+          damar_dev_index *ai, *bi;
+          int     last_read;
+          b = pblock_get(bfiles[k], o);
+          a = pblock_get(afile, o);              /* (the table may have moved) */
+          b->busy = 1;
+          if (SYMMETRIC)
+            make_subdir(&b->blk, o->runid);
+          ai = pblock_index(a, 0);
+          bi = pblock_index(b, 0);
+          t0 = wall_ms();
+          damar_match(&a->blk, &b->blk, ai, bi, 0, 0, spec, cnt);
+          P_ms[2] += wall_ms() - t0;
+          bi = pblock_index(b, 1);
+          t0 = wall_ms();
+          damar_match(&a->blk, &b->cblk, ai, bi, 0, 1, spec, cnt);
+          P_ms[2] += wall_ms() - t0;
+          last_read = (b->blk.part < a->blk.part) ? b->blk.ufirst + b->blk.nreads - 1 : a->blk.ufirst + a->blk.nreads - 1;
+          if (a->blk.part > 0) d1 = damar_get_dir(o->runid, a->blk.part);
+          if (b->blk.part > 0) d2 = damar_get_dir(o->runid, b->blk.part);
+          TIMED(4, damar_write_overlaps(spec, d1, d2, aroot, broot, last_read));
+          free(d1);
+          free(d2);
+          free(broot);
+          b->busy = 0;
+        }
+    }
+  a = pblock_get(afile, o);
+  a->busy = 0;
+  /* the queued tail of this line uses `spec`: drain before releasing it (once per line, not per pair) */
+  TIMED(5, damar_async_drain());
+  Free_Align_Spec(spec);
+  free(aroot);
+}
+
+static int plan_main(const Opts *base, const char *planfile)
+{ FILE  *f = (strcmp(planfile, "-") == 0) ? stdin : fopen(planfile, "r");
+  char  *line = NULL;
+  size_t cap = 0;
+  int    nlines = 0, i;
+
+  if (f == NULL)
+    { fprintf(stderr, "daligner: cannot open plan %s\n", planfile);
+      exit(1);
+    }
+  if (getenv("DAMAR_PLAN_BLOCKS") != NULL && atoi(getenv("DAMAR_PLAN_BLOCKS")) >= 2)
+    PB_max = atoi(getenv("DAMAR_PLAN_BLOCKS"));
+  select_device(base);
+  damar_set_async(1);
+  while (getline(&line, &cap, f) > 0)
+    { char *tok[4096], *sp = NULL, *t;
+      int   n = 0, first;
+      Opts  o = *base;
+      for (t = strtok_r(line, " \t\r\n", &sp); t != NULL && n < 4095; t = strtok_r(NULL, " \t\r\n", &sp))
+        tok[n++] = t;
+      tok[n] = NULL;
+      if (n == 0)
+        continue;
+      { const char *b0 = strrchr(tok[0], '/');
+        b0 = b0 ? b0 + 1 : tok[0];
+        if (strcmp(b0, "daligner") != 0)              /* comments, LAmerge lines, ... */
+          continue;
+      }
+      o.plan = NULL;
+      first = parse_opts(n, tok, &o);
+      if (o.plan != NULL)
+        { fprintf(stderr, "daligner: -P inside a plan\n");
+          exit(1);
+        }
+      if (first + 2 > n)
+        { fprintf(stderr, "[ERROR] - at least one target and one subject block are required\n\n");
+          exit(1);
+        }
+      plan_line(&o, tok[first], tok + first + 1, n - first - 1);
+      nlines += 1;
+    }
+  damar_async_drain();
+  for (i = 0; i < PB_n; i++)
+    pblock_release(PB + i);
+  PB_n = 0;
+  free(PB);
+  free(line);
+  if (f != stdin)
+    fclose(f);
+  damar_set_async(0);
+  if (getenv("DAMAR_CLIPROF"))
+    { fprintf(stderr, "cli: %d plan lines, %d index builds; wall ms:", nlines, PB_builds);
       for (i = 0; i < 8; i++)
         fprintf(stderr, " %s=%.1f", P_name[i], P_ms[i]);
       fprintf(stderr, "\n");

@@ -625,6 +625,52 @@ void damar_sim_defaults(damar_sim_params *p)
   p->erate      = .15;
   p->block_mbp  = 200;
   p->min_len    = 1000;
+  p->tandem_frac = 0.;
+  p->max_blocks = 0;
+}
+
+/* glibc's srand48/drand48 restated inline (X' = 0x5DEECE66D X + 0xB mod 2^48, value X / 2^48: the
+   library builds the same double from the 48 bits): the stream is the one db/simulator.c draws from,
+   at a third of the cost of the library call -- config 4 draws 5e10 numbers */
+static uint64_t sim_x48;
+static inline void   sim_srand48(long seed) { sim_x48 = (((uint64_t) (uint32_t) seed) << 16) | 0x330Eull; }
+static inline double sim_drand48(void)
+{ sim_x48 = (sim_x48 * 0x5DEECE66Dull + 0xBull) & 0xFFFFFFFFFFFFull;
+  return (double) sim_x48 * (1.0 / 281474976710656.0);
+}
+#define srand48 sim_srand48
+#define drand48 sim_drand48
+
+/* second, independent stream for the tandem implants (-T): xorshift64* */
+static uint64_t sim_tx;
+static inline uint64_t tan_next(void)
+{ sim_tx ^= sim_tx >> 12;  sim_tx ^= sim_tx << 25;  sim_tx ^= sim_tx >> 27;
+  return sim_tx * 0x2545F4914F6CDD1Dull;
+}
+static inline int tan_range(int lo, int hi)       /* uniform in [lo, hi] */
+{ return lo + (int) (tan_next() % (uint64_t) (hi - lo + 1)); }
+
+/* plain simulator reads hold no tandem repeats, so datander finds nothing in them.
+   Overwrite a stretch of the read with `copies` copies of a random unit of 50-500 bp, each copy
+   with 3 % substitutions (the recipe of SURVEY App. E, applied per read). */
+static void tandem_implant(char *seq, int len)
+{ int unit = tan_range(50, 500), copies = tan_range(5, 40), span, pos, c, i;
+  char u[500];
+  if (unit * copies > len / 2)
+    copies = (len / 2) / unit;
+  if (copies < 3)
+    return;
+  span = unit * copies;
+  pos  = tan_range(0, len - span);
+  for (i = 0; i < unit; i++)
+    u[i] = (char) (tan_next() & 3);
+  for (c = 0; c < copies; c++)
+    for (i = 0; i < unit; i++)
+      { char b = u[i];
+        if (tan_next() % 100 < 3)
+          b = (char) ((b + 1 + (int) (tan_next() % 3)) & 3);
+        seq[pos + c * unit + i] = b;
+      }
 }
 
 #define NORM_STEPS 60000
@@ -719,7 +765,8 @@ int damar_sim_write_db(const damar_sim_params *p, const char *dir, const char *r
   int64   want, have;
   char   *rbuf = NULL;
   int     rcap = 0;
-  int     i, nblocks;
+  int     i, nblocks, blk_done = 0;
+  int64   blk_tot = 0;
   FILE   *stub;
 
   mkdir(dir, 0755);
@@ -739,6 +786,7 @@ int damar_sim_write_db(const damar_sim_params *p, const char *dir, const char *r
   { double pra = p->bias / 2., prc = (1. - p->bias) / 2. + pra, prg = (1. - p->bias) / 2. + prc;
     src = (char *) xmalloc((size_t) genome + 1, "genome");
     srand48(p->seed);
+    sim_tx = 0x9E3779B97F4A7C15ull ^ ((uint64_t) (uint32_t) p->seed * 0xD1B54A32D192ED03ull);
     for (i = 0; i < genome; i++)
       { double x = drand48();
         src[i] = (char) ((x < pra) ? 0 : (x < prc) ? 1 : (x < prg) ? 2 : 3);
@@ -823,8 +871,21 @@ int damar_sim_write_db(const damar_sim_params *p, const char *dir, const char *r
             }
         }
 
+      if (p->tandem_frac > 0. && (double) (tan_next() >> 11) * (1.0 / 9007199254740992.0) < p->tandem_frac)
+        tandem_implant(rbuf, elen);
+
       if (elen >= p->min_len)          /* FA2db -x */
-        dbout_add(&out, rbuf, elen);
+        { dbout_add(&out, rbuf, elen);
+          if (p->max_blocks > 0)       /* stop once the first max_blocks blocks are complete (they do not
+                                          depend on what would follow: the generator is sequential) */
+            { blk_tot += elen;
+              if (blk_tot >= p->block_mbp * 1000000ll)
+                { blk_tot = 0;
+                  if (++blk_done >= p->max_blocks)
+                    break;
+                }
+            }
+        }
       have += elen;
     }
   free(rbuf);

@@ -20,7 +20,9 @@
 
 #include "damar_db.h"
 
-#define MAX_NAME 10000                     /* db/DB.h */
+#define MAX_NAME 204800                    /* db/DB.h:398 (200*1024) */
+#define STR_(x) #x
+#define STR(x) STR_(x)
 
 typedef struct
 { char  *name;
@@ -388,7 +390,7 @@ int main(int argc, char *argv[])
       for (i = 0; i < ofiles; i++)
         { int  last;
           char fname[MAX_NAME + 8], prolog[MAX_NAME + 8];
-          if (fscanf(istub, "  %9d %s %s\n", &last, fname, prolog) != 3)
+          if (fscanf(istub, "  %9d %" STR(MAX_NAME) "s %" STR(MAX_NAME) "s\n", &last, fname, prolog) != 3)
             { fprintf(stderr, "FA2db: stub file of %s is junk\n", root);
               exit(1);
             }

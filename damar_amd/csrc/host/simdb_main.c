@@ -1,7 +1,9 @@
 /* simdb -- write a synthetic PacBio-style read database (simulator | FA2db | DBsplit
  * equivalent, see damar_db.h) so that the GPU box can make BASELINE.json's inputs
  * from seeds alone.  usage: simdb <dir> <root> <genome_Mbp> [-cCOV] [-rSEED] [-eERR]
- *                                 [-mMEAN] [-sSDEV] [-xSHORT] [-bBIAS] [-SBLOCK_MBP] */
+ *                                 [-mMEAN] [-sSDEV] [-xSHORT] [-bBIAS] [-SBLOCK_MBP]
+ *                                 [-TFRAC: implant a tandem array into this fraction of the reads]
+ *                                 [-NBLOCKS: only the first BLOCKS blocks of that database] */
 #include <stdio.h>
 #include <stdlib.h>
 #include "damar_db.h"
@@ -11,7 +13,7 @@ int main(int argc, char *argv[])
   int i, nb;
 
   if (argc < 4)
-    { fprintf(stderr, "usage: simdb <dir> <root> <genome_Mbp> [-c -r -e -m -s -x -b -S]\n");
+    { fprintf(stderr, "usage: simdb <dir> <root> <genome_Mbp> [-c -r -e -m -s -x -b -S -T -N]\n");
       return 1;
     }
   damar_sim_defaults(&p);
@@ -27,6 +29,8 @@ int main(int argc, char *argv[])
         case 'x': p.rshort    = atoi(argv[i] + 2); break;
         case 'b': p.bias      = atof(argv[i] + 2); break;
         case 'S': p.block_mbp = atoi(argv[i] + 2); break;
+        case 'T': p.tandem_frac = atof(argv[i] + 2); break;
+        case 'N': p.max_blocks = atoi(argv[i] + 2); break;
         default:
           fprintf(stderr, "simdb: unknown option %s\n", argv[i]);
           return 1;

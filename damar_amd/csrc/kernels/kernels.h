@@ -80,7 +80,7 @@ void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, i
 void damar_launch_work_cost(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, const u32 *aboff,
                             const u32 *bboff, const u32 *work, u32 nwork, u32 coarse, u32 *key, u32 *val, hipStream_t st);
 void damar_launch_pair_screen(const u64 *keys, const u32 *vals, u64 nhits, int pbits, const u32 *heads, u32 nheads,
-                              int minhit, int binshift, int kmer, int hitmin, u32 *keep, hipStream_t st);
+                              int minhit, int binshift, int kmer, int hitmin, int abits, u32 b_lo, u32 b_hi, u32 *keep, hipStream_t st);
 void damar_launch_compact_u32(const u32 *src, const u32 *keep, const u32 *off, u32 n, u32 *out, hipStream_t st);
 void damar_launch_compact_index(const u32 *flags, const u32 *off, u64 n, u32 *out, hipStream_t st);
 

@@ -341,7 +341,7 @@ void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, i
 __global__ __launch_bounds__(256)
 void pair_screen(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits,
                  const u32 *__restrict__ heads, u32 nheads, int minhit, int binshift, int kmer, int hitmin,
-                 u32 *__restrict__ keep)
+                 int abits, u32 b_lo, u32 b_hi, u32 *__restrict__ keep)
 { u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= nheads)
     return;
@@ -349,6 +349,12 @@ void pair_screen(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64
   const u64 pr = keys[i] >> pbits, pmask = (1ull << pbits) - 1;
   u32 f = 1;
   int n = minhit;
+  { const u32 rb = (u32) (pr >> abits);          /* a scheduler may hand this call a B-read range only */
+    if (rb < b_lo || rb >= b_hi)
+      { keep[t] = 0;
+        return;
+      }
+  }
   while (n <= SCREEN_MAX && i + (u64) n < nhits && (keys[i + (u64) n] >> pbits) == pr)
     n += 1;
   if (n <= SCREEN_MAX && (int) (keys[i + (u64) (n - 1)] & pmask) <= SCREEN_PANEL)
@@ -373,11 +379,12 @@ void pair_screen(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64
 }
 
 void damar_launch_pair_screen(const u64 *keys, const u32 *vals, u64 nhits, int pbits, const u32 *heads, u32 nheads,
-                              int minhit, int binshift, int kmer, int hitmin, u32 *keep, hipStream_t st)
+                              int minhit, int binshift, int kmer, int hitmin, int abits, u32 b_lo, u32 b_hi,
+                              u32 *keep, hipStream_t st)
 { if (nheads == 0)
     return;
   hipLaunchKernelGGL(pair_screen, dim3((nheads + 255) / 256), dim3(256), 0, st, keys, vals, nhits, pbits, heads, nheads,
-                     minhit, binshift, kmer, hitmin, keep);
+                     minhit, binshift, kmer, hitmin, abits, b_lo, b_hi, keep);
 }
 
 /* out[off[i]] = src[i] for the kept entries */

@@ -53,6 +53,17 @@ uint64 MEM_PHYSICAL = ~0ull;
 }
 
 static int P_kmer = 14, P_hitmin = 35, P_binshift = 6, P_suppress = 0, P_nshift = 2;
+static u32 P_bread_lo = 0, P_bread_hi = 0xffffffffu;      /* damar_set_bread_range */
+
+/* Restrict the following damar_match / Match_Filter calls to the read pairs whose B read (block-local
+ * index) lies in [lo, hi): the index merge and the seed sort still see the whole block pair, so the seed
+ * list, the reference's thread slices (filter.c:2804-2816) and with them every record of the range are
+ * exactly those of the unrestricted call.  A multi-GPU scheduler splits one block pair over several GPUs
+ * this way; the parts' files merge into the unsplit files.  hi < 0 lifts the restriction. */
+extern "C" void damar_set_bread_range(int lo, int hi)
+{ P_bread_lo = lo < 0 ? 0u : (u32) lo;
+  P_bread_hi = hi < 0 ? 0xffffffffu : (u32) hi;
+}
 
 extern "C" int Set_Filter_Params(int kmer, int binshift, int suppress, int hitmin, int nthreads)
 { if (kmer <= 1)
@@ -175,11 +186,23 @@ extern "C" int damar_hip_init(int device)
     { fprintf(stderr, "damar: FATAL: device %d requested, %d present\n", device, ndev);
       die();
     }
+  if (G_ready && device != G_device)
+    { /* the streams, events and every pooled buffer of this process live on the first device: a second one
+         would launch on streams of the first with memory of the second */
+      fprintf(stderr, "damar: FATAL: device %d requested after the library was initialised on device %d "
+                      "(one GPU per process)\n", device, G_device);
+      die();
+    }
   HIP_CHECK(hipSetDevice(device));
   G_device = device;
   HIP_CHECK(hipGetDeviceProperties(&G_prop, device));
   if (!G_ready)
-    { HIP_CHECK(hipStreamCreate(&G_st));
+    { if (strncmp(G_prop.gcnArchName, "gfx950", 6) != 0 && getenv("DAMAR_ANY_ARCH") == NULL)
+        { fprintf(stderr, "damar: FATAL: device %d is %s; the kernels of this library are built for gfx950 (MI355X)\n",
+                  device, G_prop.gcnArchName);
+          die();
+        }
+      HIP_CHECK(hipStreamCreate(&G_st));
       HIP_CHECK(hipStreamCreate(&G_copy));
       HIP_CHECK(hipEventCreate(&G_report_done));
       for (int i = 0; i < 16; i++)
@@ -219,8 +242,11 @@ extern "C" void damar_hip_sync(void)
 }
 
 extern "C" const char *damar_hip_device_name(void)
-{ ensure_init();
-  return G_prop.name;
+{ static char name[400];
+  ensure_init();
+  snprintf(name, sizeof(name), "%s (%s, %d CUs)", G_prop.name[0] ? G_prop.name : "AMD GPU", G_prop.gcnArchName,
+           G_prop.multiProcessorCount);
+  return name;
 }
 
 static int G_debug = -1;
@@ -559,6 +585,10 @@ extern "C" void damar_index_free(damar_dev_index *ix)
     damar_block_free(ix->blk);
   free(ix);
 }
+
+/* HBM held by one index (what its three buffers took from the pool): lets a scheduler bound residency */
+extern "C" uint64_t damar_index_bytes(const damar_dev_index *ix)
+{ return ix == NULL ? 0 : (uint64_t) (ix->codes_bytes + ix->pos_bytes + ix->table_bytes); }
 
 extern "C" void damar_index_download(const damar_dev_index *ix, void *out)
 { struct KP { uint64 code; int rpos; int read; } *kp = (KP *) out;
@@ -1339,7 +1369,8 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   u32 *work = heads + pad256(sizeof(u32) * (size_t) nheads) / sizeof(u32);
   nwork64 = 0;
   if (nheads > 0)
-    { damar_launch_pair_screen(keys, vals, total, m.pbits, heads, nheads, minhit, P_binshift, P_kmer, P_hitmin, flags, G_st);
+    { damar_launch_pair_screen(keys, vals, total, m.pbits, heads, nheads, minhit, P_binshift, P_kmer, P_hitmin, m.abits,
+                               P_bread_lo, P_bread_hi, flags, G_st);
       damar_exclusive_scan_u32(flags, foff, nheads, scw2, tot, G_st);
       damar_launch_compact_u32(heads, flags, foff, nheads, work, G_st);
       stage("work_list");
@@ -1995,9 +2026,12 @@ static int trace_batch(const DevBlock *ad, const DevBlock *bd, int64 r0, int64 r
   u32 *d_key    = (u32 *) T_key.need(sizeof(u32) * (size_t) nwork);
   u32 *d_val    = (u32 *) T_val.need(sizeof(u32) * (size_t) nwork);
 
-  hipEvent_t e0, e1, e2, e3;
-  HIP_CHECK(hipEventCreate(&e0));  HIP_CHECK(hipEventCreate(&e1));
-  HIP_CHECK(hipEventCreate(&e2));  HIP_CHECK(hipEventCreate(&e3));
+  struct Events            /* destroyed on every return path */
+  { hipEvent_t e[4];
+    Events()  { for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreate(&e[i])); }
+    ~Events() { for (int i = 0; i < 4; i++) (void) hipEventDestroy(e[i]); }
+  } evs;
+  hipEvent_t e0 = evs.e[0], e1 = evs.e[1], e2 = evs.e[2], e3 = evs.e[3];
   HIP_CHECK(hipMemcpyAsync(d_recs, recs.data(), sizeof(TraceRecIn) * (size_t) nrecs, hipMemcpyHostToDevice, G_st));
   if (!pts.empty())
     HIP_CHECK(hipMemcpyAsync(d_pts, pts.data(), pts.size(), hipMemcpyHostToDevice, G_st));
@@ -2055,8 +2089,6 @@ static int trace_batch(const DevBlock *ad, const DevBlock *bd, int64 r0, int64 r
   for (u32 i = 0; i < nrecs; i++)
     soff[r0 + i] = (int64) base + hoff[i];
   soff[r1] = (int64) base + (int64) total;
-  HIP_CHECK(hipEventDestroy(e0));  HIP_CHECK(hipEventDestroy(e1));
-  HIP_CHECK(hipEventDestroy(e2));  HIP_CHECK(hipEventDestroy(e3));
   T_ms[3] += now_ms() - h0;
   T_cnt[0] += nrecs;  T_cnt[1] += nwork;  T_cnt[3] += (int64) total;
   return 0;

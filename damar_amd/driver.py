@@ -56,16 +56,35 @@ class Block:
         return self.dev
 
     def upload_complement(self):
-        """Reverse-complemented copy (daligner.c:529-570), resident in HBM as well."""
+        """Reverse-complemented copy (daligner.c:529-570) in a record this object owns, resident in HBM
+        as well."""
         L = api.lib()
         if self.cdev is None:
-            self._cdb = L.damar_complement_block(C.byref(self.db), 0).contents
-            # damar_complement_block returns a static record: copy it
-            keep = api.HITS_DB()
-            C.memmove(C.byref(keep), C.byref(self._cdb), C.sizeof(api.HITS_DB))
-            self._cdb = keep
+            self._cdb = api.HITS_DB()
+            L.damar_complement_copy(C.byref(self.db), C.byref(self._cdb))
             self.cdev = L.damar_block_upload(C.byref(self._cdb))
         return self.cdev
+
+    def release_device(self):
+        """Give the block's HBM back (bases of both strands); the host copy stays.  The caller must have
+        released every index built on it first (Plan.drop_block does)."""
+        L = api.lib()
+        for d in (self.dev, self.cdev):
+            if d is not None:
+                L.damar_block_free(d)
+        self.dev = self.cdev = None
+
+    def close(self):
+        """Release everything: device blocks, the complement's host bases and masks, the host block."""
+        L = api.lib()
+        L.damar_async_drain()                 # the host tail reads the blocks' bases (bridges)
+        self.release_device()
+        if self._cdb is not None:
+            L.damar_free_complement(C.byref(self._cdb))
+            self._cdb = None
+        if self.db is not None:
+            L.damar_close_block(C.byref(self.db))
+            self.db = None
 
     @property
     def cdb(self):
@@ -79,9 +98,11 @@ class Plan:
     """daligner <A> <B1> <B2> ... for resident blocks."""
 
     def __init__(self, k=14, w=6, h=35, t=0, e=.70, l=1000, s=100, j=4, run=1,
-                 symmetric=1, identity=0, verbose=0, async_tail=True, masks=None, biased=0):
+                 symmetric=1, identity=0, verbose=0, async_tail=True, masks=None, biased=0,
+                 only_identity=0, no_trace=0, index_cache_bytes=None):
         self.k, self.w, self.h, self.t, self.e, self.l, self.s, self.j, self.run = k, w, h, t, e, l, s, j, run
         self.symmetric, self.identity, self.verbose = symmetric, identity, verbose
+        self.only_identity, self.no_trace = only_identity, no_trace      # daligner -O, -T (daligner.c:731-739)
         self.masks = list(masks or [])
         L = api.lib()
         api.set_globals(verbose=verbose, minover=2 * l, symmetric=symmetric, identity=identity, biased=biased)
@@ -92,7 +113,14 @@ class Plan:
         self.counts = [0, 0, 0]
         self.async_tail = async_tail
         self._specs = []
-        self._idx = {}           # (block name, comp) -> k-mer index resident in HBM for this job
+        self._spec_of = {}
+        self._idx = {}           # (block name, comp) -> k-mer index resident in HBM for this job (LRU order)
+        self._idx_bytes = 0
+        # residency cap of the index cache (each index: 8 B per k-mer + a prefix table of up to 1 GB): least
+        # recently used indexes are released beyond it.  Default: a third of a 288 GB MI355X.
+        self.index_cache_bytes = (96 << 30) if index_cache_bytes is None else index_cache_bytes
+        self._pinned = ()
+        self._line_a = None
         self.index_builds = 0
         L.damar_set_async(1 if async_tail else 0)
 
@@ -109,9 +137,33 @@ class Plan:
         for sp in self._specs:
             L.Free_Align_Spec(sp)
         self._specs = []
+        self._spec_of = {}
         for idx in self._idx.values():
             L.damar_index_free(idx)
         self._idx = {}
+        self._idx_bytes = 0
+
+    def drop_block(self, block):
+        """Release the indexes of a block (both strands) and its HBM copy: for a scheduler that knows the
+        block is not needed again soon."""
+        L = api.lib()
+        for comp in (0, 1):
+            idx = self._idx.pop((block.name, comp), None)
+            if idx is not None:
+                self._idx_bytes -= L.damar_index_bytes(idx)
+                L.damar_index_free(idx)
+        block.release_device()
+
+    def _evict(self):
+        L = api.lib()
+        for key in list(self._idx):
+            if self._idx_bytes <= self.index_cache_bytes:
+                break
+            if key in self._pinned:
+                continue
+            idx = self._idx.pop(key)
+            self._idx_bytes -= L.damar_index_bytes(idx)
+            L.damar_index_free(idx)
 
     def _acc(self):
         for n, v in api.timings().items():
@@ -123,7 +175,10 @@ class Plan:
         each line is its own process; here the sorted index (8 B per k-mer) simply stays in HBM
         until finish()."""
         key = (block.name, comp)
-        idx = self._idx.get(key)
+        self._pinned = (self._line_a, key)    # the A index of the running line and this one stay resident
+        idx = self._idx.pop(key, None)
+        if idx is not None:
+            self._idx[key] = idx              # most recently used last
         if idx is None:
             block.load_masks(self.masks)
             L = api.lib()
@@ -133,7 +188,9 @@ class Plan:
             for nme in ("tuples", "ksort", "table"):
                 self.timings[nme] = self.timings.get(nme, 0.) + t[nme]
             self._idx[key] = idx
+            self._idx_bytes += L.damar_index_bytes(idx)
             self.index_builds += 1
+            self._evict()
         return idx
 
     def _match(self, adb, bdb, aidx, bidx, self_, comp, spec):
@@ -146,21 +203,40 @@ class Plan:
         for i in range(3):
             self.counts[i] += cnt[i]
 
-    def run_line(self, a, bs, outdir):
-        """One plan line: block `a` against every block in `bs` (blocks already uploaded).
-        Writes the .las files under outdir exactly as daligner.c:1006-1021, 1051-1056."""
+    def _spec(self, a):
+        """One Align_Spec per A block and job (its tables depend on the block's base frequencies,
+        daligner.c:951); its overlap buffer is reset by every damar_write_overlaps."""
+        L = api.lib()
+        sp = self._spec_of.get(a.name)
+        if sp is None:
+            sp = L.New_Align_Spec(self.e, self.s, a.db.freq, self.j, self.symmetric, self.only_identity,
+                                  self.no_trace, 1)
+            self._spec_of[a.name] = sp
+            self._specs.append(sp)
+        return sp
+
+    def run_pair(self, a, b, outdir, part=0, nparts=1):
+        """One block pair of a plan line, both orientations (daligner.c:958-1056 for one B argument); the
+        .las files go under outdir exactly as daligner.c:1006-1021, 1051-1056 name them.  With nparts > 1
+        only the read pairs whose B read falls into the part's share of B's reads are processed
+        (damar_set_bread_range): the parts' files merge into the unsplit pair's files (multi.merge_parts)."""
         L = api.lib()
         os.makedirs(outdir, exist_ok=True)
         outabs = os.path.abspath(outdir)
 
-        def odir(part):          # absolute: the write may run later on the worker thread
-            return os.path.join(outabs, api.get_dir(self.run, part)).encode() if part > 0 else None
+        def odir(part_no):       # absolute: the write may run later on the worker thread
+            return os.path.join(outabs, api.get_dir(self.run, part_no)).encode() if part_no > 0 else None
         with _cwd(outdir):
             os.makedirs(api.get_dir(self.run, a.db.part), exist_ok=True)
-            spec = L.New_Align_Spec(self.e, self.s, a.db.freq, self.j, self.symmetric, 0, 0, 1)
+            self._line_a = (a.name, 0)
+            spec = self._spec(a)
             aidx = self._index(a, 0)
-            for b in bs:
-                if b is a or b.name == a.name:
+            same = b is a or b.name == a.name
+            if nparts > 1:
+                nb = (a if same else b).db.nreads
+                L.damar_set_bread_range(nb * part // nparts, nb * (part + 1) // nparts)
+            try:
+                if same:
                     self._match(a.db, a.db, aidx, aidx, 1, 0, spec)
                     cidx = self._index(a, 1)
                     self._match(a.db, a.cdb, aidx, cidx, 1, 1, spec)
@@ -173,9 +249,16 @@ class Plan:
                     self._match(a.db, b.cdb, aidx, cidx, 0, 1, spec)
                     last = b.last_read() if b.db.part < a.db.part else a.last_read()
                     L.damar_write_overlaps(spec, odir(a.db.part), odir(b.db.part), a.root.encode(), b.root.encode(), last)
-            self._specs.append(spec)
-            if not self.async_tail or a.db.part <= 0 or any(b.db.part <= 0 for b in bs):
+            finally:
+                if nparts > 1:
+                    L.damar_set_bread_range(0, -1)
+            if not self.async_tail or a.db.part <= 0 or b.db.part <= 0:
                 self.finish()            # unsplit DBs write relative paths: finish inside this cwd
+
+    def run_line(self, a, bs, outdir):
+        """One plan line: block `a` against every block in `bs` (daligner <A> <B1> <B2> ...)."""
+        for b in bs:
+            self.run_pair(a, b, outdir)
 
 
 def run_datander(block, outdir, k=12, w=4, h=35, e=.70, l=500, s=100, j=4, verbose=0, out="tan"):

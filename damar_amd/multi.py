@@ -1,19 +1,29 @@
 """Block-pair scheduling over the GPUs of one node.
 
-Block pairs of the HPCdaligner plan are independent (each writes its own .las files), so
-they are sharded over ranks with no collective in the data path: one process per GPU
-(torchrun / RCCL is used only for the start/end barriers and for summing the counters).
-Cross-block pairs cost about twice a self pair (two B index builds, twice the seeds), so
-pairs are dealt longest-first to the least-loaded rank; a rank then runs its pairs grouped
-by A block so that the A index is built once per group, like one daligner plan line.
+The work list is the HPCdaligner plan (dalign/HPCdaligner.c:628-788: block a against blocks a, a-1, ... 1);
+the loop it replaces is the `for B` loop of dalign/daligner.c:958 plus the cluster scheduler above it.
+Block pairs are independent (each writes its own .las files), so there is no collective in the data
+path: one process per GPU, every rank holds the read blocks, and the pairs are handed out DYNAMICALLY
+from one shared cursor -- an atomic counter in the job's torch.distributed store (rank 0's TCP store; the
+"trivial work queue" of BASELINE.json's north_star).  A rank that finishes early simply pulls the next
+unit, so a slow pair, a slow GPU or a busy host core delays nobody else (work stealing without victims).
+RCCL is used only for the barriers around the job and the final reduction of the counters.
+
+Units are ordered for the queue: cross pairs first (two index builds + twice the seeds of a self pair),
+row-major like the plan so that a rank's consecutive pulls mostly share the A block (its k-mer index is
+built once and stays in that rank's LRU index cache), self pairs last to even out the tail.  When the
+plan has fewer than two units per rank (config 2 on 8 GPUs: 10 pairs), cross pairs are split by B-read
+range (damar_set_bread_range): every part runs the index merge and the seed sort of the whole pair and
+then only its share of the read pairs -- the dominant 60 % -- and the parts' sorted files are merged
+into exactly the files the unsplit pair writes.
 
     torchrun --nproc-per-node 8 -m damar_amd.multi <dbdir>/<root> <nblocks> <outdir>
 
 When all pairs are done the per-pair files of every block directory are merged into one sorted
-<root>.<b>.las (LAmerge, the next step of every HPCdaligner plan), block directories dealt over
-the ranks.
+<root>.<b>.las (LAmerge, the next step of every HPCdaligner plan), block directories dealt over the ranks.
 """
 import os
+import subprocess
 import sys
 import time
 
@@ -23,7 +33,8 @@ def pair_cost(a, b):
 
 
 def shard_pairs(nblocks, world):
-    """[(rank -> {a: [b, ...]})]: every pair (a, b<=a) exactly once, LPT-balanced."""
+    """Static alternative to the queue: [(rank -> {a: [b, ...]})], every pair (a, b<=a) exactly once,
+    longest-processing-time balanced.  Kept for callers without a shared store."""
     pairs = [(a, b) for a in range(1, nblocks + 1) for b in range(a, 0, -1)]
     pairs.sort(key=lambda p: (-pair_cost(*p), p))
     load = [0.0] * world
@@ -38,18 +49,76 @@ def shard_pairs(nblocks, world):
     return out, load
 
 
-def reduce_stats(dist, device, elapsed, values):
-    """max of the elapsed time and sum of the counters over all ranks (rank-0 report)."""
-    import torch
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    v = torch.tensor([float(x) for x in values], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(v, op=dist.ReduceOp.SUM)
-    return float(t.item()), [float(x) for x in v.tolist()]
+def work_units(nblocks, world, units_per_rank=2):
+    """The queue's contents: (a, b, part, nparts) with b <= a, cross pairs first in plan order, then the
+    self pairs.  nparts > 1 only when the plan is too coarse for `world` ranks."""
+    cross = [(a, b) for a in range(1, nblocks + 1) for b in range(a - 1, 0, -1)]
+    selfs = [(a, a) for a in range(1, nblocks + 1)]
+    npairs = len(cross) + len(selfs)
+    ncross = nself = 1
+    if world > 1 and npairs < units_per_rank * world:
+        # cost units (cross = 2, self = 1) per rank wanted: split so that every rank gets about units_per_rank pieces
+        ncross = -(-units_per_rank * world // npairs)          # ceil
+        nself = max(1, ncross // 2)
+    units = [(a, b, i, ncross) for a, b in cross for i in range(ncross)]
+    units += [(a, b, i, nself) for a, b in selfs for i in range(nself)]
+    return units
+
+
+class LocalQueue:
+    """Single-process stand-in for the shared cursor."""
+
+    def __init__(self, n):
+        self.n, self.i = n, 0
+
+    def next(self):
+        i = self.i
+        self.i += 1
+        return i if i < self.n else None
+
+
+class StoreQueue:
+    """Shared cursor over `n` units: one atomic add per pull on the job's torch.distributed store (served by
+    rank 0).  `name` must be new for every pass (e.g. "step3")."""
+
+    def __init__(self, store, name, n):
+        self.store, self.key, self.n = store, "damar/cursor/%s" % name, n
+
+    def next(self):
+        i = self.store.add(self.key, 1) - 1
+        return i if i < self.n else None
+
+
+def default_store():
+    """The store torch.distributed's process group was initialised with (torchrun: TCP store on rank 0)."""
+    import torch.distributed as dist
+    from torch.distributed import distributed_c10d
+    if not dist.is_initialized():
+        raise RuntimeError("init_process_group first")
+    return distributed_c10d._get_default_store()
+
+
+def part_dir(outdir, a, b, part, nparts):
+    return os.path.join(outdir, "_parts", "%d.%d" % (a, b), "p%dof%d" % (part, nparts))
+
+
+def run_queue(dbprefix, units, outdir, queue, runner):
+    """Pull units until the queue is empty.  runner(a_name, b_name, outdir, part, nparts) computes one unit;
+    a split unit is written under part_dir().  Returns the units this rank ran."""
+    mine = []
+    while True:
+        i = queue.next()
+        if i is None:
+            break
+        a, b, part, nparts = units[i]
+        dst = outdir if nparts == 1 else part_dir(outdir, a, b, part, nparts)
+        runner("%s.%d" % (dbprefix, a), "%s.%d" % (dbprefix, b), dst, part, nparts)
+        mine.append(units[i])
+    return mine
 
 
 def run_rank(dbprefix, nblocks, outdir, rank, world, runner):
-    """runner(a_block_name, [b_block_names], outdir) performs one group of pairs."""
+    """Static variant (shard_pairs): runner(a_block_name, [b_block_names], outdir) performs one group."""
     shards, _ = shard_pairs(nblocks, world)
     mine = shards[rank]
     for a in sorted(mine):
@@ -57,11 +126,37 @@ def run_rank(dbprefix, nblocks, outdir, rank, world, runner):
     return mine
 
 
+def merge_parts(dbprefix, units, outdir, rank, world, run=1):
+    """After every rank has finished (barrier!): the files of split pairs.  Every part holds the records of
+    its B-read range, sorted; records of one (aread, bread) pair never span parts, so a merge on the record
+    order (bin/LAmerge on the named files) restores exactly the file of the unsplit pair.  Split pairs are
+    dealt round-robin over the ranks.  Returns the files written."""
+    from . import api, lib
+    root = os.path.basename(dbprefix)
+    split = sorted({(a, b, n) for a, b, _, n in units if n > 1})
+    done = []
+    for j, (a, b, n) in enumerate(split):
+        if j % world != rank:
+            continue
+        rels = [os.path.join(api.get_dir(run, a), "%s.%d.%s.%d.las" % (root, a, root, b))]
+        if a != b:
+            rels.append(os.path.join(api.get_dir(run, b), "%s.%d.%s.%d.las" % (root, b, root, a)))
+        for rel in rels:
+            srcs = [os.path.join(part_dir(outdir, a, b, p, n), rel) for p in range(n)]
+            srcs = [s for s in srcs if os.path.exists(s)]
+            if not srcs:
+                continue
+            os.makedirs(os.path.dirname(os.path.join(outdir, rel)), exist_ok=True)
+            subprocess.run([lib.bin_path("LAmerge"), dbprefix, os.path.join(outdir, rel)] + srcs, check=True,
+                           stdout=subprocess.DEVNULL)
+            done.append(os.path.join(outdir, rel))
+    return done
+
+
 def merge_blocks(dbprefix, nblocks, outdir, rank, world, run=1):
     """After every rank has finished its pairs (barrier!): the LAmerge step of the plan
     (HPCdaligner.c:790-808), one block directory per call, dealt round-robin over the ranks.
     Writes <root>.<b>.las next to the block directories; returns the files this rank wrote."""
-    import subprocess
     from . import api, lib
     root = os.path.basename(dbprefix)
     done = []
@@ -75,17 +170,74 @@ def merge_blocks(dbprefix, nblocks, outdir, rank, world, run=1):
     return done
 
 
+def reduce_stats(dist, device, elapsed, values):
+    """max of the elapsed time and sum of the counters over all ranks (rank-0 report)."""
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    v = torch.tensor([float(x) for x in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    return float(t.item()), [float(x) for x in v.tolist()]
+
+
+class GpuRunner:
+    """One rank's executor: a driver.Plan (LRU index cache bounded by `index_cache_bytes`) and the read
+    blocks it has opened.  `resident` blocks (uploaded before the timed region by the caller) are kept;
+    blocks the runner opens itself are closed again once more than `max_blocks` are open (least recently
+    used first), so neither HBM nor host memory grows with the number of blocks of the database."""
+
+    def __init__(self, plan_kwargs=None, resident=None, max_blocks=8):
+        from . import driver
+        self.driver = driver
+        self.plan = driver.Plan(**(plan_kwargs or {}))
+        self.resident = dict(resident or {})
+        self.cache = {}                  # name -> Block, LRU order
+        self.max_blocks = max_blocks
+
+    def block(self, name, keep=()):
+        if name in self.resident:
+            return self.resident[name]
+        blk = self.cache.pop(name, None)
+        if blk is None:
+            blk = self.driver.Block(name)
+        self.cache[name] = blk
+        for old in list(self.cache):
+            if len(self.cache) <= self.max_blocks:
+                break
+            if old == name or old in keep:
+                continue
+            victim = self.cache.pop(old)
+            self.plan.drop_block(victim)
+            victim.close()
+        return blk
+
+    def __call__(self, a, b, outdir, part=0, nparts=1):
+        ba = self.block(a)
+        bb = ba if b == a else self.block(b, keep=(a,))
+        self.plan.run_pair(ba, bb, outdir, part, nparts)
+
+    def run_line(self, a, bs, outdir):
+        for b in bs:
+            self(a, b, outdir)
+
+    def finish(self):
+        self.plan.finish()
+
+    def close(self):
+        self.plan.finish()
+        for blk in self.cache.values():
+            blk.close()
+        self.cache = {}
+
+
 def gpu_runner(plan_kwargs=None):
-    from . import driver
-    cache = {}
-    plan = driver.Plan(**(plan_kwargs or {}))
+    """runner(a, [b...], outdir) for run_rank (static sharding)."""
+    r = GpuRunner(plan_kwargs)
 
     def run(a, bs, outdir):
-        for n in [a] + bs:
-            if n not in cache:
-                cache[n] = driver.Block(n)
-        plan.run_line(cache[a], [cache[b] for b in bs], outdir)
-    run.plan = plan
+        r.run_line(a, bs, outdir)
+    run.plan = r.plan
+    run.runner = r
     return run
 
 
@@ -98,18 +250,24 @@ def main():
     dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from . import api
     api.lib().damar_hip_init(local)
-    runner = gpu_runner()
+    runner = GpuRunner()
+    units = work_units(nblocks, world)
+    queue = StoreQueue(default_store(), "main", len(units))
     dist.barrier()
     t0 = time.time()
-    run_rank(dbprefix, nblocks, outdir, rank, world, runner)
-    runner.plan.finish()
+    mine = run_queue(dbprefix, units, outdir, queue, runner)
+    runner.finish()
     torch.cuda.synchronize()
+    dist.barrier()
+    merge_parts(dbprefix, units, outdir, rank, world)
     dist.barrier()
     merge_blocks(dbprefix, nblocks, outdir, rank, world)
     dist.barrier()
-    el, cnt = reduce_stats(dist, torch.device("cuda", local), time.time() - t0, runner.plan.counts)
+    el, cnt = reduce_stats(dist, torch.device("cuda", local), time.time() - t0, runner.plan.counts + [len(mine)])
     if rank == 0:
-        print("pairs done in %.2f s over %d GPUs: %d seed pairs, %d alignments, %d records" % (el, world, *cnt))
+        print("%d units done in %.2f s over %d GPUs: %d seed pairs, %d alignments, %d records"
+              % (cnt[3], el, world, cnt[0], cnt[1], cnt[2]))
+    runner.close()
     dist.destroy_process_group()
 
 

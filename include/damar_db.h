@@ -104,6 +104,8 @@ typedef struct
   double erate;        /* -e (.15)                      */
   int    block_mbp;    /* DBsplit -s (200)              */
   int    min_len;      /* FA2db -x (1000)               */
+  double tandem_frac;  /* fraction of reads that get a tandem array implanted (0: none) */
+  int    max_blocks;   /* > 0: stop when this many blocks are complete (the leading blocks of the full DB) */
 } damar_sim_params;
 
 void damar_sim_defaults(damar_sim_params *p);

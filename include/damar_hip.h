@@ -48,6 +48,7 @@ void             damar_block_free(damar_dev_block *blk);
 typedef struct damar_dev_index damar_dev_index;
 damar_dev_index *damar_index_build(damar_dev_block *blk, int own_block, int *len);
 void             damar_index_free(damar_dev_index *idx);
+uint64_t         damar_index_bytes(const damar_dev_index *idx);   /* HBM the index holds, for residency caps */
 /* Test hook: copy the index back as reference-layout KmerPos records
  * {uint64 code; int rpos; int read} (filter.c:121-126), out must hold *len records. */
 void             damar_index_download(const damar_dev_index *idx, void *out);
@@ -58,6 +59,13 @@ void             damar_index_download(const damar_dev_index *idx, void *out);
 void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
                  damar_dev_index *aidx, damar_dev_index *bidx,
                  int self, int comp, Align_Spec *spec, int64 *counts);
+
+/* Restrict the following damar_match / Match_Filter calls to the read pairs whose B read (block-local
+ * index) lies in [lo, hi); hi < 0 lifts the restriction.  The records of a range are exactly those the
+ * unrestricted call writes for these B reads (the merge and the sort still cover the whole pair), so a
+ * scheduler can split one block pair over several GPUs and merge the parts' files ("split big
+ * pairs ... legal because report work is independent per (bread,aread) run"). */
+void damar_set_bread_range(int lo, int hi);
 
 /* Asynchronous host tail: with damar_set_async(1) the per-read-pair tail of damar_match /
  * Match_Filter (redundancy handling, trace compression, buffer append) and the sort + write of

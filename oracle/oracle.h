@@ -65,6 +65,7 @@ typedef struct
   int   maxband;
   int64 pebbles;
   int   empty_band; /* a wave ran on an empty band (undefined in the reference) */
+  int64 bandhist[130]; /* wave steps by number of diagonals computed in the step (129 = more) */
 } OWaveStats;
 
 void oracle_local_alignment(const char *aseq, int alen, const char *bseq, int blen,

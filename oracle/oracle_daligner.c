@@ -144,5 +144,12 @@ int main(int argc, char *argv[])
   if (verbose)
     printf("waves %lld cells %lld maxband %d pebbles %lld emptyband %d\n", (long long) st.waves,
            (long long) st.cells, st.maxband, (long long) st.pebbles, st.empty_band);
+  if (verbose && getenv("DAMAR_ORACLE_BANDHIST"))
+    { int i;
+      printf("bandhist");
+      for (i = 0; i < 130; i++)
+        printf(" %lld", (long long) st.bandhist[i]);
+      printf("\n");
+    }
   return 0;
 }

@@ -218,6 +218,8 @@ static void forward(const Ctx *c, Band *w, int diag, int mida,
       w->V[cur][hgh + 1 + o] = w->V[cur][low - 1 + o] = -1;
       dif += 1;
 
+      if (c->st)
+        c->st->bandhist[hgh - low + 1 > 129 ? 129 : hgh - low + 1] += 1;
       /* every diagonal of the new wave from the old wave (align.c:781-909) */
       for (k = low; k <= hgh; k++)
         { int ac = w->V[cur][k + o], am = w->V[cur][k - 1 + o], ap = w->V[cur][k + 1 + o];
@@ -491,6 +493,8 @@ static void reverse(const Ctx *c, Band *w, int diag, int mida,
       w->V[cur][hgh + 1 + o] = w->V[cur][low - 1 + o] = INT_MAX;
       dif += 1;
 
+      if (c->st)
+        c->st->bandhist[hgh - low + 1 > 129 ? 129 : hgh - low + 1] += 1;
       for (k = low; k <= hgh; k++)
         { int ac = w->V[cur][k + o], am = w->V[cur][k - 1 + o], ap = w->V[cur][k + 1 + o];
           int from, v, y, m, ha, hb;

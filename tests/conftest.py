@@ -89,6 +89,11 @@ def opts_to_plan_kwargs(opts):
             kw.setdefault("masks", []).append(v)
         elif f == "b":
             kw["biased"] = 1
+        elif f == "O":                  # daligner.c:737-739: -O implies -I
+            kw["only_identity"] = 1
+            kw["identity"] = 1
+        elif f == "T":
+            kw["no_trace"] = 1
     return kw
 
 

@@ -40,6 +40,11 @@ CASES = {
     "tiny_I":  dict(db="tiny2", opts=["-k14", "-j4", "-I"], plan=[("1", ["1"])]),
     "tiny_A":  dict(db="tiny2", opts=["-k14", "-j4", "-A"], plan=[("2", ["2", "1"])]),
     "tiny_k12": dict(db="tiny2", opts=["-k12", "-w5", "-h30", "-j4"], plan=[("1", ["1"])]),
+    # -O (only identity overlaps survive Write_Overlap_Buffer, align.c:6172-6200; needs -I and reads that
+    # overlap themselves off the main diagonal -- the tandem-array reads -- to produce any)
+    # and -T (no trace points stored, align.c:5989, 6040, 6086)
+    "tan_O":   dict(db="tandem", opts=["-k14", "-j4", "-I", "-O"], plan=[("1", ["1"])]),
+    "tiny_T":  dict(db="tiny2", opts=["-k14", "-j4", "-T"], plan=[("2", ["2", "1"])]),
     "indel":   dict(derive="indel", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "noisy":   dict(derive="noisy", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "tandem":  dict(derive="tandem", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
@@ -330,9 +335,88 @@ def trace_md5():
             print("%s: %d dumps" % (fixture, len(lines)))
 
 
+# BASELINE config 4 (`simulator 248 -c80 -m15000 -s3000 -e.15 -r4`, DBsplit -s78 -> 256 blocks) is too
+# large to run whole anywhere but on an 8-GPU node; parity is checked on seeded random samples of its
+# block pairs.  "lead": pairs among the first C4_LEAD blocks, which `simdb -N<C4_LEAD>` reproduces
+# without generating the other 18 Gbp (the generator is sequential, so they are the same blocks);
+# "full": pairs from the whole 256 x 256 triangle (needs the whole DB: ~2.5 min of simdb).
+C4_SIM = ["248", "-c80", "-m15000", "-s3000", "-e.15", "-r4", "-S78"]
+C4_LEAD = 24
+
+
+def c4_samples(nblocks=256):
+    rng = random.Random(4)
+    lead, full = [], []
+    while len(lead) < 8:
+        a, b = rng.randint(1, C4_LEAD), rng.randint(1, C4_LEAD)
+        p = (max(a, b), min(a, b))
+        if p not in lead and (len(lead) >= 2 or a == b):          # the first two are self pairs
+            lead.append(p)
+    while len(full) < 8:
+        a, b = rng.randint(1, nblocks), rng.randint(1, nblocks)
+        p = (max(a, b), min(a, b))
+        if p not in full and (len(full) >= 2 or a == b):
+            full.append(p)
+    return lead, full
+
+
+def big_md5(dbdir=None):
+    """config4_ref_md5.txt and config5_ref_md5.txt: md5 of what the REAL reference writes for the sampled
+    block pairs of config 4 and for datander on config-2-scale blocks (plain and with tandem arrays
+    implanted by `simdb -T.3`).  `python make_golden.py big [<dir holding the full config-4 DB>]`."""
+    import hashlib
+    import tempfile
+
+    def md5(path):
+        return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+    with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
+        if dbdir is None:
+            dbdir = d
+            run([SIMDB, d, "SIM"] + C4_SIM, d, stdout=subprocess.DEVNULL)
+        nblocks = int(open(os.path.join(dbdir, "SIM.db")).read().split("blocks =")[1].split()[0])
+        lead, full = c4_samples(nblocks)
+        rdir = os.path.join(d, "run")
+        os.makedirs(rdir)
+        for f in ("SIM.db", ".SIM.idx", ".SIM.bps"):
+            os.symlink(os.path.join(dbdir, f), os.path.join(rdir, f))
+        lines = ["# config 4: simdb . SIM %s -> %d blocks; reference daligner -k14 -j8 SIM.<a> SIM.<b>" % (" ".join(C4_SIM), nblocks),
+                 "# <md5> <sample> <a> <b> <file>"]
+        for tag, pairs in (("lead", lead), ("full", full)):
+            for a, b in pairs:
+                shutil.rmtree(os.path.join(rdir, "d001_%05d" % a), ignore_errors=True)
+                shutil.rmtree(os.path.join(rdir, "d001_%05d" % b), ignore_errors=True)
+                run([os.path.join(REF, "daligner"), "-k14", "-j8", "SIM.%d" % a, "SIM.%d" % b], rdir, stdout=subprocess.DEVNULL)
+                for x, y in ((a, b), (b, a)) if a != b else ((a, b),):
+                    rel = "d001_%05d/SIM.%d.SIM.%d.las" % (x, x, y)
+                    lines.append("%s %s %d %d %s" % (md5(os.path.join(rdir, rel)), tag, a, b, rel))
+                print(tag, a, b, flush=True)
+        with open(os.path.join(HERE, "config4_ref_md5.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
+        lines = ["# config 5: reference datander -j8 SIM.<block> on the config-2 DB (simdb . SIM 27 -c20 -r2 -e.15 -S135),",
+                 "# plain and with tandem arrays implanted into 30 % of the reads (simdb ... -T.3)",
+                 "# <md5> <variant> <block> <records>"]
+        for tag, extra in (("plain", []), ("tandem", ["-T.3"])):
+            w = os.path.join(d, tag)
+            os.makedirs(w)
+            run([SIMDB, w, "SIM", "27", "-c20", "-r2", "-e.15", "-S135"] + extra, w, stdout=subprocess.DEVNULL)
+            for blk in (1, 4):
+                run([os.path.join(REF, "datander"), "-j8", "SIM.%d" % blk], w, stdout=subprocess.DEVNULL)
+                las = os.path.join(w, "tan", "SIM.%d.SIM.%d.las" % (blk, blk))
+                import struct
+                novl = struct.unpack("<q", open(las, "rb").read(8))[0]
+                lines.append("%s %s %d %d" % (md5(las), tag, blk, novl))
+                print(tag, blk, novl, flush=True)
+        with open(os.path.join(HERE, "config5_ref_md5.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
 def main():
     if not os.path.exists(os.path.join(REF, "daligner")):
         sys.exit("oracle/_ref/daligner missing: make -C oracle -f Makefile.ref")
+    if sys.argv[1:2] == ["big"]:
+        return big_md5(sys.argv[2] if len(sys.argv) > 2 else None)
     if sys.argv[1:] == ["memlimit"]:
         return memlimit()
     if sys.argv[1:] == ["trace"]:

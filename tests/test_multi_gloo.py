@@ -36,6 +36,130 @@ dist.destroy_process_group()
 '''
 
 
+QUEUE_WORKER = r'''
+import os, sys, subprocess, time, shutil, struct, tempfile
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from damar_amd import multi
+root, work, nblocks, upr = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+firsts = [int(x) for x in open(os.path.join(work, "G.db")).read().split("size =")[1].split()[1:]]
+
+def filter_las(src, dst, keep):
+    raw = open(src, "rb").read()
+    novl, tspace = struct.unpack("<qi", raw[:12])
+    tb = 1 if tspace <= 125 else 2
+    off, out, n = 12, [], 0
+    for _ in range(novl):
+        rec = struct.unpack("<10i", raw[off:off + 40])
+        size = 40 + tb * rec[0]
+        if keep(rec[7], rec[8]):
+            out.append(raw[off:off + size]); n += 1
+        off += size
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    open(dst, "wb").write(struct.pack("<qi", n, tspace) + b"".join(out))
+
+def oracle_runner(a, b, outdir, part, nparts):
+    # test stand-in for the GPU: the CPU oracle computes the whole pair, the part keeps its B-read range
+    ia, ib = int(a.rsplit(".", 1)[1]), int(b.rsplit(".", 1)[1])
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in ("G.db", ".G.idx", ".G.bps"):
+            os.symlink(os.path.join(work, f), os.path.join(tmp, f))
+        subprocess.run([os.path.join(root, "oracle", "oracle_daligner"), "-k14", "-j4", "G.%d" % ia, "G.%d" % ib],
+                       cwd=tmp, check=True, stdout=subprocess.DEVNULL)
+        nb = firsts[ib] - firsts[ib - 1]
+        lo, hi = firsts[ib - 1] + nb * part // nparts, firsts[ib - 1] + nb * (part + 1) // nparts
+        for dp, _, fs in os.walk(tmp):
+            for f in fs:
+                if not f.endswith(".las"):
+                    continue
+                rel = os.path.relpath(os.path.join(dp, f), tmp)
+                if ia == ib:
+                    keep = lambda ar, br: lo <= min(ar, br) < hi
+                elif f == "G.%d.G.%d.las" % (ia, ib):
+                    keep = lambda ar, br: lo <= br < hi
+                else:
+                    keep = lambda ar, br: lo <= ar < hi
+                filter_las(os.path.join(dp, f), os.path.join(outdir, rel), keep)
+
+units = multi.work_units(nblocks, world, units_per_rank=upr)
+queue = multi.StoreQueue(multi.default_store(), "t", len(units))
+dist.barrier()
+mine = multi.run_queue(os.path.join(work, "G"), units, work, queue, oracle_runner)
+dist.barrier()
+merged = multi.merge_parts(os.path.join(work, "G"), units, work, rank, world)
+dist.barrier()
+el, tot = multi.reduce_stats(dist, torch.device("cpu"), 1.0, [len(mine), len(merged)])
+if rank == 0:
+    assert tot[0] == len(units), (tot, len(units))
+    print("OK units=%d split=%d merged=%d" % (len(units), sum(1 for u in units if u[3] > 1), int(tot[1])))
+dist.destroy_process_group()
+'''
+
+
+def test_work_units_cover_every_pair_once():
+    from damar_amd import multi
+    for nb, world, upr in [(4, 1, 2), (4, 8, 2), (17, 8, 2), (2, 2, 4), (3, 4, 3)]:
+        units = multi.work_units(nb, world, upr)
+        pairs = {}
+        for a, b, i, n in units:
+            assert 1 <= b <= a <= nb and 0 <= i < n
+            pairs.setdefault((a, b), []).append((i, n))
+        assert sorted(pairs) == sorted((a, b) for a in range(1, nb + 1) for b in range(1, a + 1))
+        for parts in pairs.values():
+            n = parts[0][1]
+            assert sorted(parts) == [(i, n) for i in range(n)]
+        if world > 1:
+            assert len(units) >= min(upr * world, 2 * len(pairs)) or all(n > 1 for _, _, _, n in units if _ != 0)
+        # cross pairs come first, self pairs last
+        kinds = [a == b for a, b, _, _ in units]
+        assert kinds == sorted(kinds)
+        q = multi.LocalQueue(len(units))
+        got = []
+        while True:
+            i = q.next()
+            if i is None:
+                break
+            got.append(i)
+        assert got == list(range(len(units)))
+
+
+def _run_workers(script_text, work, args, port):
+    script = os.path.join(work, "worker.py")
+    open(script, "w").write(script_text)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), script, ROOT, work] + args,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    return r.stdout
+
+
+def test_two_rank_gloo_dynamic_queue_equals_golden(built, tmp_path):
+    """The shared cursor hands the 3 block pairs of the 2-block fixture to 2 ranks; the union of their files
+    is the reference's golden output."""
+    case = read_case("tiny2")
+    work = str(tmp_path)
+    for f in ("G.db", ".G.idx", ".G.bps"):
+        os.symlink(os.path.join(case["dbdir"], f), os.path.join(work, f))
+    out = _run_workers(QUEUE_WORKER, work, ["2", "1"], 29541)
+    assert "OK units=3 split=0" in out, out[-2000:]
+    assert compare_las(case, work) == []
+
+
+def test_two_rank_gloo_split_pairs_merge_to_golden(built, tmp_path):
+    """Too few pairs for the ranks: every pair is split by B-read range, the parts are computed by whichever
+    rank pulls them, and the merged part files are byte-identical to the reference's files."""
+    case = read_case("tiny2")
+    work = str(tmp_path)
+    for f in ("G.db", ".G.idx", ".G.bps"):
+        os.symlink(os.path.join(case["dbdir"], f), os.path.join(work, f))
+    out = _run_workers(QUEUE_WORKER, work, ["2", "4"], 29545)
+    assert "OK units=" in out and "split=0" not in out, out[-2000:]
+    assert compare_las(case, work) == []
+
+
 def test_shard_pairs_cover_and_balance():
     from damar_amd import multi
     for nb, world in [(4, 1), (4, 2), (16, 8), (5, 3)]:
