@@ -103,6 +103,7 @@ typedef struct
   int  comp, self, symmetric, minover, hgap_min;
   int  tspace, ave_path, reach;
   const short *score, *table;      /* SCORE[32768], TABLE[32768] */
+  int  mscore, dscore;             /* the two column scores the tables are built from (align.c:282-284) */
   /* per-slot scratch */
   void *state;   u64 state_stride;   int span;        /* ping-pong diagonal state: rings of `span` (2^n) diagonals */
   int  *marks;   u64 marks_stride;                    /* NA/NB                     */
@@ -132,6 +133,10 @@ void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots
 /* batch Local_Alignment for tests: task i = (aread, bread, diag, anti) */
 typedef struct { int aread, bread, diag, anti; } LaTask;
 void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
+/* two read pairs (or batch tasks, tasks != NULL) per wavefront: report_packed.h; nslots must be even */
+void damar_launch_report2(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
+#define DAMAR_PACKED_MAX_MARKS 4000       /* trace-grid indexes ride in 12 bits of a packed chain head */
+#define DAMAR_PACKED_MAX_CELLS (1u << 20)
 
 u64 damar_report_state_stride(int span);
 

@@ -1670,3 +1670,5 @@ void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks,
     return;
   hipLaunchKernelGGL(la_batch_kernel, dim3(nslots), dim3(64), 0, st, *a, tasks, ntasks);
 }
+
+#include "report_packed.h"

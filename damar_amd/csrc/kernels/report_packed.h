@@ -1,0 +1,991 @@
+/* report_packed.h -- the report loop with TWO read pairs per wavefront (included by report.hip).
+ *
+ * Why: the live band of a Local_Alignment wave is 12 diagonals wide on average and 99.96 % of the wave
+ * steps fit 32 lanes (profiles/: band histogram of the oracle), so one alignment per 64-lane wavefront
+ * leaves five lanes in six idle -- and round 1's kernel kept every per-alignment scalar (band bounds, best
+ * and trim points, loop control) in SGPRs: 139 scalar instructions per wave step on the ONE scalar unit the
+ * four SIMDs of a CU share (76 % of its calibrated issue rate, tools/roofcal.hip), 51 % on the vector side.
+ * Here each 32-lane half of a wavefront owns a read pair: everything that is uniform per alignment lives in
+ * VGPRs (the same value in the 32 lanes of a half), computed by vector instructions whose cost does not
+ * depend on the number of alignments they serve, and the scalar unit only steers the loops.
+ *
+ * Reference semantics are those of report.hip (same citations: dalign/filter.c:2128-2432 report_thread,
+ * dalign/align.c:409-1122 forward_wave, :1126-1898 reverse_wave, :1904-2097 Local_Alignment); what differs is
+ * the mapping onto the machine:
+ *   - lane s of a half owns diagonal k = kbase + s (reverse) or kbase - s (forward): the reference's sweep
+ *     order (align.c:781 hgh..low, :1490 low..hgh) is ascending lane order in both directions, no ring
+ *     wrap; the band is re-centred in the half (7 lane shuffles) when it drifts to an edge;
+ *   - the half is a state machine (scan the pair's seeds -> Local_Alignment task -> lasta update -> ...),
+ *     so that the two halves run their wave steps in lockstep whatever their seeds look like;
+ *   - the popcount M of the match history is not carried: M == popcount(T & (2^61 - 1)) at all times
+ *     (align.c:827-829, 853-855 keep exactly that invariant), taken where it is needed;
+ *   - the mark of the pebble at a chain head rides in the top 12 bits of the head index (as a trace-grid
+ *     index), NA/NB are grid indexes too: no cell is read back inside the wave loop;
+ *   - new best / last / trim point (align.c:911-928) by a prefix maximum in sweep order instead of a serial
+ *     replay; TABLE/SCORE (2 x 64 KB in HBM) are replaced by one 1 KB table in LDS: the test
+ *     "TABLE[lo15] >= 0 && TABLE[hi15] + SCORE[lo15] >= 0" says that every suffix of the last 30 columns
+ *     scores >= 0, and the minimum suffix score of 30 columns composes from 8-bit chunks.
+ * A band that needs more than the 32 lanes leaves the packed loop: its state goes to the slot's memory
+ * buffers and the full-wave memory path (wave_mem) finishes that direction.
+ */
+
+#define PK_BIAS   3                       /* grid index = (mark - off) / TS + PK_BIAS, always >= 1 */
+#define PK_HBITS  20                      /* pebble index bits in a packed chain head (cell_cap <= 2^20) */
+#define PK_HMASK  ((1 << PK_HBITS) - 1)
+
+__device__ __forceinline__ u32 hmask(u64 m, int hb) { return (u32) (m >> hb); }           /* this half's 32 bits */
+__device__ __forceinline__ int hget(int v, int hb, int s) { return __builtin_amdgcn_ds_bpermute((hb + s) << 2, v); }
+__device__ __forceinline__ int upd_dpp_shr(int old, int v, int n)      /* lane i <- lane i-n within a row of 16 */
+{ switch (n)
+    { case 1:  return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xf, 0xf, false);
+      case 2:  return __builtin_amdgcn_update_dpp(old, v, 0x112, 0xf, 0xf, false);
+      case 4:  return __builtin_amdgcn_update_dpp(old, v, 0x114, 0xf, 0xf, false);
+      default: return __builtin_amdgcn_update_dpp(old, v, 0x118, 0xf, 0xf, false);
+    }
+}
+
+/* per-half pair context and direction bookkeeping: every field holds the same value in the 32 lanes of a half */
+struct PkPair
+{ int  a0, b0;              /* offsets of the two reads in the blocks' base arrays */
+  int  alen, blen;
+  int  minp, maxp, aoff, boff;
+};
+
+struct PkDir
+{ int low, hgh, dif, besta, besty, lasta, more, reachm, aclip, bclip, kbase;
+  int ncell;
+  Tip trim, reach;
+  int ovf;                  /* the band outgrew the half: continue on the full-wave path */
+  int bad;
+};
+
+/* one 8-column chunk of the trim test: low half = minimum suffix score, high half = total */
+__device__ __forceinline__ void pk_fill_trimtab(u32 *tab, int mscore, int dscore)
+{ for (int x = lane_id(); x < 256; x += 64)
+    { int sc = 0, mn = 0x7fff;
+      for (int i = 0; i < 8; i++)
+        { sc += ((x >> i) & 1) ? mscore : -dscore;           /* bit 0 = newest column */
+          mn = sc < mn ? sc : mn;
+        }
+      tab[x] = ((u32) mn & 0xffffu) | ((u32) sc << 16);
+    }
+}
+
+/* every suffix of the newest 30 columns of b scores >= 0 (align.c:917-919 on TABLE/SCORE) */
+__device__ __forceinline__ bool pk_trim_ok(const u32 *tab, u64 b)
+{ const u32 lo = (u32) b;
+  const u32 e0 = tab[lo & 0xff], e1 = tab[(lo >> 8) & 0xff], e2 = tab[(lo >> 16) & 0xff];
+  const u32 e3 = tab[((lo >> 24) & 0x3f) | 0xc0];           /* 6 columns; older ones padded with matches */
+  int s = (int) e0 >> 16, mn = (int) (short) e0, t;
+  t = s + (int) (short) e1;  mn = t < mn ? t : mn;  s += (int) e1 >> 16;
+  t = s + (int) (short) e2;  mn = t < mn ? t : mn;  s += (int) e2 >> 16;
+  t = s + (int) (short) e3;  mn = t < mn ? t : mn;
+  return mn >= 0;
+}
+
+__device__ __forceinline__ int pk_popc61(u64 b)
+{ return __popc((u32) b) + __popc((u32) (b >> 32) & 0x1fffffffu); }
+
+/* One direction of the wave for the two halves of the wavefront.  `on` = this half runs a task.  Leaves the
+ * band state in the lane registers passed by reference and the bookkeeping in D. */
+template <int REV>
+__device__ __forceinline__ void pk_wave(const ReportArgs &a, const u32 *trimtab, bool on, const PkPair &p, u32 cbase,
+                                        int diag, int mida, PkDir &D,
+                                        int &rV, u64 &rT, int &rHA, int &rHB, int &rNA, int &rNB)
+{ const int lane = lane_id(), hb = lane & 32, s = lane & 31;
+  const int KS = REV ? 1 : -1, S = REV ? -1 : 1;
+  const int edge = REV ? BIG : -1;
+  const int TS = uni(a.tspace), ave = uni(a.ave_path);
+  const u32 *apk = uni_ptr(a.ablk.pk), *bpk = uni_ptr(a.bblk.pk);
+  const u8 *abase = uni_ptr(a.ablk.bases), *bbase = uni_ptr(a.bblk.bases);
+  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) uni_ptr((Cell *) a.cells);
+  const int cell_cap = (int) uni((int) a.cell_cap);
+  u32 *const errw = uni_ptr(&a.counters[3]);
+  const u8 *aseq = abase + p.a0 + (REV ? -1 : 0), *bseq = bbase + p.b0 + (REV ? -1 : 0);
+  const int va0 = p.a0 + 16 * PK_PAD, vb0 = p.b0 + 16 * PK_PAD, valen = p.alen, vblen = p.blen;
+  const int offa = p.aoff - PK_BIAS * TS, offb = p.boff - PK_BIAS * TS;      /* mark = index * TS + off */
+  const int steplimit = p.alen + p.blen + 64;
+  const int guard = 4 * (p.alen + p.blen) + 1024;
+  (void) aseq; (void) bseq;
+
+  int low = diag, hgh = diag, dif = 0;
+  int besta = mida, lasta = mida, besty = (mida - diag) >> 1, more = 1, reachm = -1;
+  int aclip = REV ? -BIG : BIG, bclip = REV ? BIG : -BIG;
+  int ncell = 2;
+  int kbase = diag - KS * 15;
+  Tip trim, reach;
+  trim.a = reach.a = mida;  trim.y = reach.y = besty;  trim.d = reach.d = 0;
+  trim.ha = reach.ha = 0;   trim.hb = reach.hb = 1;
+  int ovf = 0, bad = 0;
+  u32 err_flags = 0, err_empty = 0;
+
+  rV = edge;  rT = 0;  rHA = 0;  rHB = 0;  rNA = 0;  rNB = 0;
+
+  /* wave 0 on the seed diagonal (align.c:491-626 / 1203-1340): every lane of the half computes the same values */
+  if (on)
+    { const int k = diag;
+      int y = (mida - k) >> 1, nai, nbi, hai, hbi, ha = 0, hb_ = 1, v;
+      int qa, qb;
+      if (!REV)
+        { qa = ((y + k) + (TS - p.aoff)) / TS;  qb = (y + (TS - p.boff)) / TS; }
+      else
+        { qa = ((y + k) + (TS - p.aoff) - 1) / TS;  qb = (y + (TS - p.boff) - 1) / TS; }
+      nai = qa - 1 + PK_BIAS;  nbi = qb - 1 + PK_BIAS;
+      hai = REV ? nai + 1 : nai;  hbi = REV ? nbi + 1 : nbi;       /* reverse: the true start, rounded up to the grid */
+      if (s == 0)
+        { v4i c0 = { -1, k, 0, REV ? y + k : nai * TS + offa };
+          v4i c1 = { -1, k, 0, REV ? y : nbi * TS + offb };
+          gcell[cbase] = c0;
+          gcell[cbase + 1] = c1;
+        }
+      if (!REV) { nai += 1;  nbi += 1; }
+      { const SnakeOut so = SNAKE_AT(k, y, 0, 0ull);
+        y = so.y;
+        if (so.nb == 0)      { more = 0; bclip = k; }
+        else if (so.na == 0) { more = 0; aclip = k; }
+      }
+      v = (y << 1) + k;
+      int g0 = 0;
+      for (;;)
+        { const int na = nai * TS + offa;
+          if (!(REV ? (y + k <= na) : (y + k >= na)))
+            break;
+          GUARD(g0, guard, 2)
+          if (s == 0 && ncell < cell_cap)
+            { v4i cl = { ha, k, 0, na };
+              gcell[cbase + (u32) ncell] = cl;
+            }
+          ha = ncell++;  hai = nai;  nai += S;
+        }
+      for (;;)
+        { const int nb = nbi * TS + offb;
+          if (!(REV ? (y <= nb) : (y >= nb)))
+            break;
+          GUARD(g0, guard, 3)
+          if (s == 0 && ncell < cell_cap)
+            { v4i cl = { hb_, k, 0, nb };
+              gcell[cbase + (u32) ncell] = cl;
+            }
+          hb_ = ncell++;  hbi = nbi;  nbi += S;
+        }
+      if (REV ? (v < besta) : (v > besta))
+        { besta = lasta = trim.a = v;
+          besty = trim.y = y;
+          trim.ha = ha;  trim.hb = hb_;
+        }
+      if (s == 15)
+        { rV = v;  rT = HIST_FULL;
+          rHA = ha | (hai << PK_HBITS);  rHB = hb_ | (hbi << PK_HBITS);
+        }
+      rNA = nai;  rNB = nbi;
+    }
+
+  /* clipping at sequence ends (align.c:628-658 / 943-975), per half */
+#define PK_CLIP()                                                                                      \
+  if (wany(on && more == 0))                                                                           \
+    { const bool cl_ = on && more == 0;                                                                \
+      int m_ = pk_popc61(rT);                                                                          \
+      if (cl_)                                                                                         \
+        { if (bseq[besty] != 4 && aseq[besta - besty] != 4)                                            \
+            more = 1;                                                                                  \
+        }                                                                                              \
+      { const bool ca_ = cl_ && (REV ? (low <= aclip) : (hgh >= aclip));                               \
+        const int  sl_ = ca_ ? KS * (aclip - kbase) : 0;                                               \
+        const int  mm_ = hget(m_, hb, sl_), vv_ = hget(rV, hb, sl_);                                   \
+        const int  ha_ = hget(rHA, hb, sl_), hb2_ = hget(rHB, hb, sl_);                                \
+        if (ca_)                                                                                       \
+          { if (REV) low = aclip + 1; else hgh = aclip - 1;                                            \
+            if (reachm <= mm_)                                                                         \
+              { reachm = mm_; reach.a = vv_; reach.y = (vv_ - aclip) / 2; reach.d = dif;               \
+                reach.ha = ha_ & PK_HMASK; reach.hb = hb2_ & PK_HMASK; }                               \
+          }                                                                                            \
+      }                                                                                                \
+      { const bool cb_ = cl_ && (REV ? (hgh >= bclip) : (low <= bclip));                               \
+        const int  sl_ = cb_ ? KS * (bclip - kbase) : 0;                                               \
+        const int  mm_ = hget(m_, hb, sl_), vv_ = hget(rV, hb, sl_);                                   \
+        const int  ha_ = hget(rHA, hb, sl_), hb2_ = hget(rHB, hb, sl_);                                \
+        if (cb_)                                                                                       \
+          { if (REV) hgh = bclip - 1; else low = bclip + 1;                                            \
+            if (reachm <= mm_)                                                                         \
+              { reachm = mm_; reach.a = vv_; reach.y = (vv_ - bclip) / 2; reach.d = dif;               \
+                reach.ha = ha_ & PK_HMASK; reach.hb = hb2_ & PK_HMASK; }                               \
+          }                                                                                            \
+      }                                                                                                \
+      if (cl_)                                                                                         \
+        { aclip = REV ? -BIG : BIG;                                                                    \
+          bclip = REV ? BIG : -BIG;                                                                    \
+        }                                                                                              \
+    }
+
+  PK_CLIP()
+
+  for (;;)
+    { on = on && more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG));
+      if (on && hgh < low)
+        { err_empty += 1;  on = false; }
+      if (on && dif > steplimit)
+        { err_flags |= DAMAR_ERR_BAND;  on = false; }
+      if (on && hgh - low + 3 > 32)                 /* would not fit the half: continue on the full-wave path */
+        { ovf = 1;  on = false; }
+      if (!wany(on))
+        break;
+
+      /* keep the band (plus the two lanes it may grow by) inside the half */
+      { const int slo = REV ? low - kbase : kbase - hgh, shi = REV ? hgh - kbase : kbase - low;
+        const bool mv = on && (slo < 1 || shi > 30);
+        if (wany(mv))
+          { const int dl = mv ? ((32 - (shi - slo + 1)) >> 1) - slo : 0;
+            const int src = (hb + ((s - dl) & 31)) << 2;
+            rV  = __builtin_amdgcn_ds_bpermute(src, rV);
+            rHA = __builtin_amdgcn_ds_bpermute(src, rHA);
+            rHB = __builtin_amdgcn_ds_bpermute(src, rHB);
+            rNA = __builtin_amdgcn_ds_bpermute(src, rNA);
+            rNB = __builtin_amdgcn_ds_bpermute(src, rNB);
+            { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+              const u32 th = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+              rT = ((u64) th << 32) | tl;
+            }
+            kbase -= KS * dl;
+          }
+      }
+
+      int  k = kbase + KS * s;
+      bool act = false;
+      int  v = edge, y = 0, ha = 0, hb_ = 0, nai = rNA, nbi = rNB;
+      u64  b = 0;
+      int  ena = 1, enb = 1;
+
+      /* widen (align.c:675-776 / 1386-1486) and pick the predecessor (align.c:793-825 / 1502-1534) */
+      { const int upV = lane_up(rV), dnV = lane_dn(rV);
+        const int upNA = lane_up(rNA), dnNA = lane_dn(rNA), upNB = lane_up(rNB), dnNB = lane_dn(rNB);
+        if (on)
+          { int nlow = low - 1, nhgh = hgh + 1;
+            if (nlow < p.minp) nlow += 1;
+            if (nhgh > p.maxp) nhgh -= 1;
+            const bool newlo = (nlow < low) && k == nlow, newhi = (nhgh > hgh) && k == nhgh;
+            /* the value of diagonal k+1 sits in lane s+KS, that of k-1 in lane s-KS */
+            const int kpNA = REV ? upNA : dnNA, kmNA = REV ? dnNA : upNA;
+            const int kpNB = REV ? upNB : dnNB, kmNB = REV ? dnNB : upNB;
+            if (newlo || newhi) rV = edge;
+            rNA = newlo ? kpNA : (newhi ? kmNA : rNA);
+            rNB = newlo ? kpNB : (newhi ? kmNB : rNB);
+            nai = rNA;  nbi = rNB;
+            /* (the neighbours' V was fetched before the new edge lanes were set: an edge lane's own old V is never
+               a neighbour of an active diagonal's predecessor choice except as `edge`, enforced below) */
+            act = k >= nlow && k <= nhgh;
+            int am = REV ? dnV : upV, ap = REV ? upV : dnV;              /* V[k-1], V[k+1] of the previous wave */
+            if (k - 1 < low || k - 1 > hgh) am = edge;                   /* outside the previous band */
+            if (k + 1 > hgh || k + 1 < low) ap = edge;
+            const int ac = (k < low || k > hgh) ? edge : rV;
+            low = nlow;  hgh = nhgh;
+            dif += 1;
+            int  nbv;
+            bool take, upk;                                              /* predecessor = a neighbour? diagonal k+1? */
+            if (!REV)
+              { nbv = am > ap ? am : ap;  take = ac < nbv;  upk = am < ap;
+                v = take ? nbv + 1 : ac + 2;
+              }
+            else
+              { nbv = am < ap ? am : ap;  take = ac > nbv;  upk = !(ap > am);
+                v = take ? nbv - 1 : ac - 2;
+              }
+            /* lane of the predecessor: k+1 -> s+KS, k-1 -> s-KS */
+            const int ds = take ? (upk ? KS : -KS) : 0;
+            const int src = (lane + ds) << 2;
+            ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
+            hb_ = __builtin_amdgcn_ds_bpermute(src, rHB);
+            const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+            const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+            b = ((u64) thi << 32) | tlo;
+          }
+      }
+
+      if (act)
+        { b <<= 1;
+          y = (v - k) >> 1;
+          { const SnakeOut so = SNAKE_AT(k, y, 0, b);
+            y = so.y;  b = so.b;
+            ena = so.na;  enb = so.nb;
+          }
+          v = (y << 1) + k;
+        }
+      const bool bhit = act && enb == 0, ahit = act && enb != 0 && ena == 0;
+
+      /* pebbles (align.c:859-909 / 1569-1618): marks as grid indexes, the head's mark in the head */
+      { int na = nai * TS + offa, nb = nbi * TS + offb;
+        bool needa = act && (REV ? (y + k <= na) : (y + k >= na));
+        bool needb = act && (REV ? (y <= nb) : (y >= nb));
+        if (wany(needa || needb))
+          { int hai = (int) ((u32) ha >> PK_HBITS), hbi = (int) ((u32) hb_ >> PK_HBITS);
+            int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
+            int g2 = 0;
+            for (;;)
+              { if (!wany(needa))
+                  break;
+                GUARD(g2, guard, 5)
+                const bool dropit = needa && (REV ? (hai > nai) : (hai < nai));
+                const u64  mask = wballot(dropit);
+                if (mask)
+                  { const u32 hm = hmask(mask, hb);
+                    const int idx = ncell + __popc(hm & ((1u << s) - 1u));
+                    if (dropit)
+                      { if (idx < cell_cap)
+                          { v4i cl = { hax, k, dif, na };
+                            gcell[cbase + (u32) idx] = cl;
+                          }
+                        hax = idx;  hai = nai;
+                      }
+                    ncell += __popc(hm);
+                  }
+                if (needa)
+                  { nai += S;  na += S * TS; }
+                needa = act && (REV ? (y + k <= na) : (y + k >= na));
+              }
+            for (;;)
+              { if (!wany(needb))
+                  break;
+                GUARD(g2, guard, 6)
+                const bool dropit = needb && (REV ? (hbi > nbi) : (hbi < nbi));
+                const u64  mask = wballot(dropit);
+                if (mask)
+                  { const u32 hm = hmask(mask, hb);
+                    const int idx = ncell + __popc(hm & ((1u << s) - 1u));
+                    if (dropit)
+                      { if (idx < cell_cap)
+                          { v4i cl = { hbx, k, dif, nb };
+                            gcell[cbase + (u32) idx] = cl;
+                          }
+                        hbx = idx;  hbi = nbi;
+                      }
+                    ncell += __popc(hm);
+                  }
+                if (needb)
+                  { nbi += S;  nb += S * TS; }
+                needb = act && (REV ? (y <= nb) : (y >= nb));
+              }
+            ha = hax | (hai << PK_HBITS);  hb_ = hbx | (hbi << PK_HBITS);
+          }
+      }
+
+      /* commit the new wave */
+      if (on)
+        { rV = act ? v : edge;
+          if (act) { rT = b;  rHA = ha;  rHB = hb_;  rNA = nai;  rNB = nbi; }
+        }
+
+      /* sequence ends reached: the largest sweep index for A, the smallest for B (as wave_mem's chunks) */
+      { const u64 amw = wballot(ahit), bmw = wballot(bhit);
+        if (amw | bmw)
+          { const u32 am_ = hmask(amw, hb), bm_ = hmask(bmw, hb);
+            if (on && (am_ | bm_))
+              { more = 0;
+                if (am_) aclip = kbase + KS * (31 - __clz((int) am_));
+                if (bm_) bclip = kbase + KS * (__ffs((int) bm_) - 1);
+              }
+          }
+      }
+
+      /* new best / last / trim point in sweep order (align.c:911-928 / 1620-1637): record breakers of a
+         prefix maximum; their v is strictly monotone, so the LAST breaker with the wanted property is the one the
+         serial sweep leaves behind */
+      { const bool cand = act && (REV ? (v < besta) : (v > besta));
+        if (wany(cand))
+          { const int worst = REV ? BIG : -BIG;
+            int x = cand ? v : worst;
+            for (int n = 1; n < 16; n <<= 1)
+              { const int t = upd_dpp_shr(worst, x, n);
+                x = REV ? (t < x ? t : x) : (t > x ? t : x);
+              }
+            { const int t = __builtin_amdgcn_update_dpp(worst, x, 0x142, 0xa, 0xf, false);     /* row_bcast:15 -> rows 1, 3 */
+              x = REV ? (t < x ? t : x) : (t > x ? t : x);
+            }
+            int e = __builtin_amdgcn_update_dpp(worst, x, 0x138, 0xf, 0xf, false);             /* wave_shr:1 */
+            if (s == 0) e = worst;
+            const bool rb = cand && (REV ? (v < e) : (v > e));
+            bool mok = false, tok = false;
+            if (rb)
+              { mok = pk_popc61(b) >= ave;
+                if (mok)
+                  tok = pk_trim_ok(trimtab, b);
+              }
+            const u32 m1 = hmask(wballot(rb), hb), m2 = hmask(wballot(rb && mok), hb), m3 = hmask(wballot(rb && tok), hb);
+            const int l1 = m1 ? 31 - __clz((int) m1) : 0, l2 = m2 ? 31 - __clz((int) m2) : 0, l3 = m3 ? 31 - __clz((int) m3) : 0;
+            const int v1 = hget(v, hb, l1), v2 = hget(v, hb, l2), v3 = hget(v, hb, l3);
+            const int h3a = hget(ha, hb, l3), h3b = hget(hb_, hb, l3);
+            if (m1)
+              { besta = v1;  besty = (v1 - (kbase + KS * l1)) >> 1; }
+            if (m2)
+              lasta = v2;
+            if (m3)
+              { trim.a = v3;  trim.y = (v3 - (kbase + KS * l3)) >> 1;  trim.d = dif;
+                trim.ha = h3a & PK_HMASK;  trim.hb = h3b & PK_HMASK;
+              }
+          }
+      }
+      if (on && ncell > cell_cap)
+        { err_flags |= DAMAR_ERR_CELLS;
+          more = 0;  ncell = 2;  bad = 1;  on = false;
+        }
+
+      PK_CLIP()
+
+      /* prune (align.c:977-986 / 1686-1695) */
+      { const int n = REV ? besta + MAX_WAVE_LAG : besta - MAX_WAVE_LAG;
+        const u32 keep = hmask(wballot(on && act && (k >= low) && (k <= hgh) && (REV ? (rV <= n) : (rV >= n))), hb);
+        if (on)
+          { if (keep == 0)
+              hgh = low - 1;
+            else
+              { const int s0 = __ffs((int) keep) - 1, s1 = 31 - __clz((int) keep);
+                if (REV) { low = kbase + s0;  hgh = kbase + s1; }
+                else     { hgh = kbase - s0;  low = kbase - s1; }
+              }
+          }
+      }
+    }
+#undef PK_CLIP
+  if ((err_flags | err_empty) && s == 0)
+    { if (err_flags) atomicOr(errw, err_flags);
+      if (err_empty) atomicAdd(errw + 2, err_empty);
+    }
+  D.low = low;  D.hgh = hgh;  D.dif = dif;  D.besta = besta;  D.besty = besty;  D.lasta = lasta;  D.more = more;
+  D.reachm = reachm;  D.aclip = aclip;  D.bclip = bclip;  D.kbase = kbase;  D.ncell = ncell;
+  D.trim = trim;  D.reach = reach;  D.ovf = ovf;  D.bad = bad;
+}
+
+/* A half whose band outgrew it: hand the direction to the full-wave memory path (wave_mem<REV>).  Called for one
+ * half at a time with every lane of the wavefront active; `hsel` is that half's lane base (0 or 32, wave-uniform). */
+template <int REV>
+__device__ __noinline__ void pk_overflow(const ReportArgs &a, const SlotScratch &sc, const PkPair &p, int hsel, int mida,
+                                         PkDir &D, int rV, u64 rT, int rHA, int rHB, int rNA, int rNB,
+                                         WaveCtx &c, WaveState &ws)
+{ const int lane = lane_id();
+  const int KS = REV ? 1 : -1;
+  const int TS = a.tspace;
+  /* the half's uniform values, as scalars */
+  const int src = hsel;
+  c.aseq = a.ablk.bases + (u32) bcast_i(p.a0, src);
+  c.bseq = a.bblk.bases + (u32) bcast_i(p.b0, src);
+  c.apk = a.ablk.pk;  c.a0 = (u32) bcast_i(p.a0, src);
+  c.bpk = a.bblk.pk;  c.b0 = (u32) bcast_i(p.b0, src);
+  c.alen = bcast_i(p.alen, src);  c.blen = bcast_i(p.blen, src);
+  c.ts = TS;  c.ave = a.ave_path;  c.reach = a.reach;
+  c.score = a.score;  c.table = a.table;
+  c.minp = bcast_i(p.minp, src);  c.maxp = bcast_i(p.maxp, src);
+  c.aoff = bcast_i(p.aoff, src);  c.boff = bcast_i(p.boff, src);
+  /* (the scratch pointers differ between the halves: take those of the half concerned) */
+#define PK_PTR_OF(T, ptr) ((T) (uintptr_t) (((u64) (u32) bcast_i((int) (u32) ((u64) (uintptr_t) (ptr) >> 32), src) << 32) | \
+                                            (u32) bcast_i((int) (u32) (u64) (uintptr_t) (ptr), src)))
+  c.st0 = PK_PTR_OF(DState *, sc.st0);  c.st1 = PK_PTR_OF(DState *, sc.st1);
+  c.NA = PK_PTR_OF(int *, sc.NA);  c.NB = PK_PTR_OF(int *, sc.NB);
+  c.koff = c.blen + 8;  c.ring = a.span;
+  c.cells = PK_PTR_OF(Cell *, sc.cells);  c.cell_cap = a.cell_cap;
+  c.err = &a.counters[3];
+  c.atr = PK_PTR_OF(u16 *, sc.atr);  c.btr = PK_PTR_OF(u16 *, sc.btr);
+#undef PK_PTR_OF
+  ws.low = bcast_i(D.low, src);  ws.hgh = bcast_i(D.hgh, src);  ws.dif = bcast_i(D.dif, src);
+  ws.besta = bcast_i(D.besta, src);  ws.besty = bcast_i(D.besty, src);  ws.lasta = bcast_i(D.lasta, src);
+  ws.more = bcast_i(D.more, src);  ws.reachm = bcast_i(D.reachm, src);
+  ws.aclip = bcast_i(D.aclip, src);  ws.bclip = bcast_i(D.bclip, src);
+  ws.ncell = (u32) bcast_i(D.ncell, src);
+  ws.trim.a = bcast_i(D.trim.a, src);  ws.trim.y = bcast_i(D.trim.y, src);  ws.trim.d = bcast_i(D.trim.d, src);
+  ws.trim.ha = bcast_i(D.trim.ha, src);  ws.trim.hb = bcast_i(D.trim.hb, src);
+  ws.reach.a = bcast_i(D.reach.a, src);  ws.reach.y = bcast_i(D.reach.y, src);  ws.reach.d = bcast_i(D.reach.d, src);
+  ws.reach.ha = bcast_i(D.reach.ha, src);  ws.reach.hb = bcast_i(D.reach.hb, src);
+  ws.stopped = 0;  ws.bad = 0;
+  /* the band of that half to the slot's DState ring, marks as values again */
+  { const int kbase = bcast_i(D.kbase, src);
+    const int o = c.koff;
+    const u32 rmask = (u32) c.ring - 1u;
+    const int offa = c.aoff - PK_BIAS * TS, offb = c.boff - PK_BIAS * TS;
+    if ((lane & 32) == hsel)
+      { const int k = kbase + KS * (lane & 31);
+        if (k >= ws.low && k <= ws.hgh)
+          { DState st;
+            st.V = rV;  st.M = pk_popc61(rT);  st.HA = rHA & PK_HMASK;  st.HB = rHB & PK_HMASK;  st.T = rT;
+            st.HAm = (int) ((u32) rHA >> PK_HBITS) * TS + offa;
+            st.HBm = (int) ((u32) rHB >> PK_HBITS) * TS + offb;
+            c.st0[RI(k)] = st;
+            c.NA[RI(k)] = rNA * TS + offa;
+            c.NB[RI(k)] = rNB * TS + offb;
+          }
+      }
+  }
+  wave_mem_sync();
+  wave_mem<REV>(c, mida, ws);
+}
+
+/* End point and trace points of one direction (align.c:1001-1118 / 1699-1898) for the halves with `fin`: the first
+ * lane of the half walks the two pebble chains exactly as wave_finish<REV> does.  In/out per half: atlen, btlen. */
+template <int REV>
+__device__ __noinline__ void pk_finish(Cell *cells, u16 *atrace, u16 *btrace, bool fin, int TS, int aoff, int boff,
+                                       int do_reach, int guard, u32 *errw, int mida, int reachm,
+                                       int ta, int ty, int td, int tha, int thb,
+                                       int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
+{ const int lane = lane_id(), hb = lane & 32, s = lane & 31;
+  int rx = 0, ry = 0, rd = 0, at = 0, bt = 0;
+  (void) do_reach; (void) reachm;
+  if (fin && s == 0)
+    { int trimx = ta - ty, trimy = ty, trimd = td, ha = tha, hb_ = thb;
+      int gw = 0;
+      for (int which = 0; which < 2; which++)
+        { int h = which ? hb_ : ha, prev = -1;
+          while (h >= 0)
+            { GUARD(gw, guard, 7)
+              int nx = cells[h].ptr;
+              cells[h].ptr = prev;
+              prev = h;
+              h = nx;
+            }
+          if (which) hb_ = prev; else ha = prev;
+        }
+      if (!REV)
+        { int h = ha, k = cells[h].diag, b = (mida - k) / 2, e = 0, n = 0;
+          for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
+            { GUARD(gw, guard, 8)
+              Cell p = cells[h];
+              int  a = p.mark - p.diag;
+              k = p.diag;
+              atrace[n++] = (u16) (p.diff - e);
+              atrace[n++] = (u16) (a - b);
+              b = a;  e = p.diff;
+            }
+          if (b + k != trimx)
+            { atrace[n++] = (u16) (trimd - e);
+              atrace[n++] = (u16) (trimy - b);
+            }
+          else if (b != trimy && n > 0)
+            { atrace[n - 1] = (u16) (atrace[n - 1] + (trimy - b));
+              atrace[n - 2] = (u16) (atrace[n - 2] + (trimd - e));
+            }
+          at = n;
+          h = hb_;  k = cells[h].diag;  b = (mida + k) / 2;  e = 0;  n = 0;
+          for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
+            { GUARD(gw, guard, 9)
+              Cell p = cells[h];
+              int  a = p.mark + p.diag;
+              k = p.diag;
+              btrace[n++] = (u16) (p.diff - e);
+              btrace[n++] = (u16) (a - b);
+              b = a;  e = p.diff;
+            }
+          if (b - k != trimy)
+            { btrace[n++] = (u16) (trimd - e);
+              btrace[n++] = (u16) (trimx - b);
+            }
+          else if (b != trimx && n > 0)
+            { btrace[n - 1] = (u16) (btrace[n - 1] + (trimx - b));
+              btrace[n - 2] = (u16) (btrace[n - 2] + (trimd - e));
+            }
+          bt = n;
+        }
+      else
+        { const int fa = *atlen_io, fb = *btlen_io;
+          int h = ha, k = cells[h].diag, b = cells[h].mark - k, e = 0, n = 0, a, d;
+          bool walk = true;
+          if ((b + k) % TS != aoff)
+            { h = cells[h].ptr;
+              if (h < 0)
+                { a = trimy; d = trimd; walk = false; }
+              else
+                { k = cells[h].diag; a = cells[h].mark - k; d = cells[h].diff; }
+              if (fa == 0)
+                { atrace[--n] = (u16) (b - a);
+                  atrace[--n] = (u16) (d - e);
+                }
+              else
+                { atrace[1] = (u16) (atrace[1] + (b - a));
+                  atrace[0] = (u16) (atrace[0] + (d - e));
+                }
+              b = a;  e = d;
+            }
+          if (walk)
+            { for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
+                { GUARD(gw, guard, 10)
+                  k = cells[h].diag;  a = cells[h].mark - k;  d = cells[h].diff;
+                  atrace[--n] = (u16) (b - a);
+                  atrace[--n] = (u16) (d - e);
+                  b = a;  e = d;
+                }
+              if (b + k != trimx)
+                { atrace[--n] = (u16) (b - trimy);
+                  atrace[--n] = (u16) (trimd - e);
+                }
+              else if (b != trimy && (fa - n) > 0)
+                { atrace[n + 1] = (u16) (atrace[n + 1] + (b - trimy));
+                  atrace[n]     = (u16) (atrace[n] + (trimd - e));
+                }
+            }
+          at = -n;
+          h = hb_;  k = cells[h].diag;  b = cells[h].mark + k;  e = 0;  n = 0;  walk = true;
+          if ((b - k) % TS != boff)
+            { h = cells[h].ptr;
+              if (h < 0)
+                { a = trimx; d = trimd; walk = false; }
+              else
+                { k = cells[h].diag; a = cells[h].mark + k; d = cells[h].diff; }
+              if (fb == 0)
+                { btrace[--n] = (u16) (b - a);
+                  btrace[--n] = (u16) (b - a);          /* sic, align.c:1843-1844 */
+                }
+              else
+                { btrace[1] = (u16) (btrace[1] + (b - a));
+                  btrace[0] = (u16) (btrace[0] + (d - e));
+                }
+              b = a;  e = d;
+            }
+          if (walk)
+            { for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
+                { GUARD(gw, guard, 11)
+                  k = cells[h].diag;  a = cells[h].mark + k;  d = cells[h].diff;
+                  btrace[--n] = (u16) (b - a);
+                  btrace[--n] = (u16) (d - e);
+                  b = a;  e = d;
+                }
+              if (b - k != trimy)
+                { btrace[--n] = (u16) (b - trimx);
+                  btrace[--n] = (u16) (trimd - e);
+                }
+              else if (b != trimx && (fb - n) > 0)
+                { btrace[n + 1] = (u16) (btrace[n + 1] + (b - trimx));
+                  btrace[n]     = (u16) (btrace[n] + (trimd - e));
+                }
+            }
+          bt = -n;
+        }
+      rx = trimx;  ry = trimy;  rd = trimd;
+    }
+  wave_mem_sync();
+  rx = hget(rx, hb, 0);  ry = hget(ry, hb, 0);  rd = hget(rd, hb, 0);  at = hget(at, hb, 0);  bt = hget(bt, hb, 0);
+  if (fin)
+    { *ox = rx;  *oy = ry;  *od = rd;
+      if (!REV)
+        { *atlen_io = at;  *btlen_io = bt; }
+      else
+        { *aback = at;  *bback = bt;
+          *atlen_io += at;  *btlen_io += bt;
+        }
+    }
+}
+
+/* one direction for both halves: packed loop, the full-wave path for a half that outgrew its lanes, trace walk */
+template <int REV>
+__device__ __forceinline__ void pk_pass(const ReportArgs &a, const u32 *trimtab, const SlotScratch &sc, bool task,
+                                        const PkPair &p, u32 cbase, int diag, int mida,
+                                        int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
+{ const int lane = lane_id(), hb = lane & 32;
+  PkDir D;
+  int rV, rHA, rHB, rNA, rNB;
+  u64 rT;
+  pk_wave<REV>(a, trimtab, task, p, cbase, diag, mida, D, rV, rT, rHA, rHB, rNA, rNB);
+  /* the direction's end point: the trim point, or the reach candidate (align.c:1009-1016) */
+  int reachm = D.reachm, ta = D.trim.a, ty = D.trim.y, td = D.trim.d, tha = D.trim.ha, thb = D.trim.hb;
+  int ra = D.reach.a, ry = D.reach.y, rd = D.reach.d, rha = D.reach.ha, rhb = D.reach.hb, bad = D.bad;
+  { const u64 ov = wballot(task && D.ovf);
+    if (ov)
+      for (int h = 0; h < 64; h += 32)
+        if ((ov >> h) & 1)
+          { WaveCtx c;
+            WaveState ws;
+            pk_overflow<REV>(a, sc, p, h, bcast_i(mida, h), D, rV, rT, rHA, rHB, rNA, rNB, c, ws);
+            if (hb == h)
+              { reachm = ws.reachm;  ta = ws.trim.a;  ty = ws.trim.y;  td = ws.trim.d;  tha = ws.trim.ha;  thb = ws.trim.hb;
+                ra = ws.reach.a;  ry = ws.reach.y;  rd = ws.reach.d;  rha = ws.reach.ha;  rhb = ws.reach.hb;
+                bad = ws.bad;
+              }
+          }
+  }
+  wave_mem_sync();
+  if (reachm >= 0 && a.reach)
+    { ta = ra;  ty = ry;  td = rd;  tha = rha;  thb = rhb; }
+  pk_finish<REV>(sc.cells, sc.atr, sc.btr, task && !bad, a.tspace, p.aoff, p.boff, a.reach,
+                 4 * (p.alen + p.blen) + 1024, &a.counters[3], mida, reachm, ta, ty, td, tha, thb,
+                 ox, oy, od, atlen_io, btlen_io, aback, bback);
+}
+
+/* emit one alignment per half with `keep` (emit_record for 32 lanes): both traces to the pool (B trace reversed
+ * pairwise for COMP, align.c:2033-2056) and the record */
+__device__ __forceinline__ void pk_emit(const ReportArgs &a, const SlotScratch &sc, bool keep, const LaResult &r,
+                                        int ar, int br, u32 item, u32 seq)
+{ const int lane = lane_id(), hb = lane & 32, s = lane & 31;
+  const int nval = r.atlen + r.btlen;
+  u32 ri = 0, to = 0;
+  if (keep && s == 0)
+    { ri = atomicAdd(&a.counters[1], 1u);
+      to = atomicAdd(&a.counters[2], (u32) nval);
+    }
+  ri = (u32) hget((int) ri, hb, 0);
+  to = (u32) hget((int) to, hb, 0);
+  if (keep)
+    { u32 bad = 0;
+      if (ri >= a.rec_cap)
+        bad |= DAMAR_ERR_RECS;
+      if ((u64) to + (u64) nval > (u64) a.tpool_cap || to > 0xf0000000u)       /* (the 32-bit counter must never wrap) */
+        bad |= DAMAR_ERR_TPOOL;
+      if (bad == 0)
+        { const u16 *at = sc.atr - r.aback, *bt = sc.btr - r.bback;
+          for (int i = s; i < nval; i += 32)
+            { u16 v;
+              if (i < r.atlen)
+                v = at[i];
+              else
+                { int j = i - r.atlen;
+                  if (a.comp)                 /* B trace pairs in reverse order, align.c:2043-2055 */
+                    j = (r.btlen - 2 - 2 * (j >> 1)) + (j & 1);
+                  v = bt[j];
+                }
+              a.tpool[to + i] = v;
+            }
+        }
+      if (s == 0)
+        { if (bad)
+            atomicOr(&a.counters[3], bad);
+          else
+            { LaRecord rec;
+              rec.abpos = r.abpos;  rec.bbpos = r.bbpos;  rec.aepos = r.aepos;  rec.bepos = r.bepos;
+              rec.diffs = r.diffs;  rec.atlen = r.atlen;  rec.btlen = r.btlen;
+              rec.aread = ar;  rec.bread = br;  rec.item = item;  rec.seq = seq;  rec.toff = to;
+              a.recs[ri] = rec;
+            }
+        }
+    }
+}
+
+/***** the per-half state machine of the report loop ******************************************************/
+
+enum { PK_ITEM = 0, PK_PANEL, PK_FIRE, PK_DONE };
+
+__global__ __launch_bounds__(64, 4)
+void report2_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
+{ __shared__ u32 trimtab[256];
+  const int lane = lane_id(), hb = lane & 32, s = lane & 31;
+  const int slot = 2 * (int) blockIdx.x + (hb >> 5);
+  const SlotScratch sc = slot_scratch(a, slot);
+  const u32 cbase = (u32) slot * a.cell_cap;
+  const u64 *keys = a.keys;
+  const u32 *vals = a.vals;
+  const u64 pmask = (1ull << a.pbits) - 1;
+  const int K = a.kmer, H = a.hitmin, W = a.binshift, minhit = a.minhit;
+  const int mind = (-a.bblk.maxlen) >> W, maxd = a.ablk.maxlen >> W;
+  const bool batch = tasks != NULL;
+
+  pk_fill_trimtab(trimtab, a.mscore, a.dscore);
+  __syncthreads();
+
+  int  phase = PK_ITEM;
+  u32  item = 0, seq = 0;
+  u64  nidx = 0, cpair = 0, lidx = 0, end = 0, h2 = 0, fp = 0;
+  int  ar = 0, br = 0, amark2 = 0, clo = BIG, chi = -BIG;
+  PkPair p;
+  p.a0 = p.b0 = 0;  p.alen = p.blen = 0;  p.minp = -BIG;  p.maxp = BIG;  p.aoff = p.boff = 0;
+
+  for (;;)
+    { bool task = false;
+      int  sdg = 0, sap = 0, sd = 0;
+
+      /* A: every half advances its scan until it has an alignment to compute or has run out of work */
+      while (wany(phase != PK_DONE && !task))
+        { if (phase == PK_ITEM && !task)
+            { u32 it = 0;
+              if (s == 0)
+                it = atomicAdd(&a.counters[0], 1u);
+              it = (u32) hget((int) it, hb, 0);
+              if (it >= (batch ? ntasks : a.nwork))
+                phase = PK_DONE;
+              else if (batch)
+                { const LaTask tk = tasks[it];
+                  item = it;  seq = 0;
+                  ar = tk.aread;  br = tk.bread;
+                  p.a0 = (int) a.ablk.boff[ar];  p.b0 = (int) a.bblk.boff[br];
+                  p.alen = (int) read_len(a.ablk, ar);  p.blen = (int) read_len(a.bblk, br);
+                  sdg = tk.diag;  sap = 0;  sd = tk.anti;            /* (sd carries the anti-diagonal of a batch task) */
+                  task = true;
+                }
+              else
+                { item = a.order ? a.order[it] : it;
+                  nidx = a.work[item];
+                  cpair = keys[nidx] >> a.pbits;
+                  ar = (int) (cpair & ((1ull << a.abits) - 1));  br = (int) (cpair >> a.abits);
+                  p.a0 = (int) a.ablk.boff[ar];  p.b0 = (int) a.bblk.boff[br];
+                  p.alen = (int) read_len(a.ablk, ar);  p.blen = (int) read_len(a.bblk, br);
+                  seq = 0;  amark2 = 0;  clo = BIG;  chi = -BIG;
+                  if (!(p.alen < a.hgap_min && p.blen < a.hgap_min))
+                    phase = PK_PANEL;
+                }
+            }
+          else if (phase == PK_PANEL && !task)
+            { if (!(nidx < a.nhits && (keys[nidx] >> a.pbits) == cpair))
+                { /* the pair is done: filter.c:2417-2432 leaves lasta all zero again */
+                  if (clo <= chi)
+                    for (int q = clo + s; q <= chi; q += 32)
+                      sc.lasta[q] = 0;
+                  phase = PK_ITEM;
+                }
+              else
+                { /* one A-panel (filter.c:2251-2266): hits while the pair continues and the hit just consumed has apos <= amark */
+                  const int amark = amark2 + PANEL_SIZE;
+                  amark2 = amark - PANEL_OVERLAP;
+                  lidx = nidx;  end = lidx;  h2 = lidx;
+                  for (u64 base = lidx; ; base += 32)
+                    { const u64  f = base + s;
+                      const bool in = f < a.nhits && (keys[f] >> a.pbits) == cpair;
+                      const int  ap = in ? (int) (keys[f] & pmask) : 0;
+                      const bool nextsame = (f + 1 < a.nhits) && ((keys[f + 1] >> a.pbits) == cpair);
+                      const bool stop = in && !(nextsame && ap <= amark);
+                      u32 le = hmask(wballot(in && ap <= amark2), hb);
+                      const u32 sm = hmask(wballot(stop), hb);
+                      if (sm)
+                        { const int l = __ffs((int) sm) - 1;
+                          end = base + l + 1;
+                          le &= (l == 31) ? ~0u : ((1u << (l + 1)) - 1);
+                          if (le) h2 = base + (31 - __clz((int) le)) + 1;
+                          break;
+                        }
+                      if (le) h2 = base + (31 - __clz((int) le)) + 1;
+                      if (hmask(wballot(in), hb) == 0)          /* cannot happen: a run always ends with a stop */
+                        { end = base; break; }
+                    }
+                  nidx = end;
+                  if (end - lidx >= (u64) minhit)
+                    { /* pass 1: bucket scores (filter.c:2268-2277) */
+                      for (u64 base = lidx; base < end; base += 32)
+                        { const u64  f = base + s;
+                          const bool in = f < end;
+                          const int  ap = in ? (int) (keys[f] & pmask) : 0;
+                          const int  d  = in ? (((int) vals[f]) >> W) : BIG;
+                          int  prev = in ? sc.lastp[d] : 0;
+                          u32  peers = hmask(wballot(in), hb);
+                          { const u32 db = (u32) (d - mind);
+                            for (int bit = 0; bit < a.bucket_bits; bit++)
+                              { const bool one = (db >> bit) & 1;
+                                const u32  mk = hmask(wballot(one), hb);
+                                peers &= one ? mk : ~mk;
+                              }
+                          }
+                          const u32  below = peers & ((1u << s) - 1u);
+                          const int  pl = below ? 31 - __clz((int) below) : s;
+                          const int  pap = hget(ap, hb, pl);
+                          if (below) prev = pap;
+                          const bool last = in && ((peers >> s) >> 1) == 0;
+                          if (in)
+                            { const int add = (ap - prev >= K) ? K : ap - prev;
+                              atomicAdd(&sc.score[d], add);
+                              if (last)
+                                sc.lastp[d] = ap;
+                            }
+                          wave_mem_sync();
+                        }
+                      fp = lidx;
+                      phase = PK_FIRE;
+                    }
+                  else
+                    nidx = h2;
+                }
+            }
+          else if (phase == PK_FIRE && !task)
+            { /* pass 2 (filter.c:2283-2405): the next seed in order with enough score whose apos is beyond lasta */
+              bool found = false;
+              for (u64 base = fp; base < end; base += 32)
+                { const u64  f = base + s;
+                  const bool in = f < end;
+                  const int  ap = in ? (int) (keys[f] & pmask) : 0;
+                  const int  dg = in ? (int) vals[f] : 0;
+                  const int  d  = dg >> W;
+                  bool fire = false;
+                  if (in)
+                    { const int scv = sc.score[d];
+                      fire = ((scv + sc.score[d + 1] >= H) || (scv + sc.score[d - 1] >= H)) && ap > sc.lasta[d];
+                    }
+                  const u32 fm = hmask(wballot(fire), hb);
+                  if (fm)
+                    { const int l = __ffs((int) fm) - 1;
+                      sap = hget(ap, hb, l);  sdg = hget(dg, hb, l);  sd = sdg >> W;
+                      fp = base + l + 1;
+                      found = true;
+                      break;
+                    }
+                }
+              if (found)
+                task = true;
+              else
+                { /* pass 3: reset the touched buckets (filter.c:2407-2411) */
+                  for (u64 base = lidx; base < end; base += 32)
+                    { const u64 f = base + s;
+                      if (f < end)
+                        { const int d = ((int) vals[f]) >> W;
+                          sc.score[d] = 0;
+                          sc.lastp[d] = 0;
+                        }
+                    }
+                  wave_mem_sync();
+                  nidx = h2;
+                  phase = PK_PANEL;
+                }
+            }
+        }
+      if (!wany(task))
+        break;
+
+      /* B: Local_Alignment (align.c:1904-2097 for low == hgh == diag) for the halves that hold a task */
+      int diag = sdg, anti = batch ? sd : sap + (sap - sdg);
+      const bool selfie = (a.ablk.bases + p.a0 == a.bblk.bases + p.b0);
+      p.minp = (selfie && diag >= 0) ? 1 : -BIG;
+      p.maxp = (selfie && diag <= 0) ? -1 : BIG;
+      p.aoff = 0;
+      p.boff = (a.comp & 1) ? (p.blen % a.tspace) : 0;
+      if (task && s == 0 && !batch)
+        atomicAdd(&a.counters[4], 1u);
+      LaResult r;
+      { int ax = 0, ay = 0, ad = 0, bx = 0, by = 0, bd = 0, atlen = 0, btlen = 0, aback = 0, bback = 0;
+        pk_pass<0>(a, trimtab, sc, task, p, cbase, diag, anti, &ax, &ay, &ad, &atlen, &btlen, &aback, &bback);
+        pk_pass<1>(a, trimtab, sc, task, p, cbase, diag, anti, &bx, &by, &bd, &atlen, &btlen, &aback, &bback);
+        r.aepos = ax;  r.bepos = ay;  r.abpos = bx;  r.bbpos = by;  r.diffs = ad + bd;
+        r.atlen = atlen;  r.btlen = btlen;  r.aback = aback;  r.bback = bback;
+      }
+
+      /* C: what the reference does with the path (filter.c:2318-2380) */
+      if (batch)
+        { pk_emit(a, sc, task, r, ar, br, item, 0);
+          phase = PK_ITEM;
+        }
+      else
+        { int lo = 0, hi = 0;
+          if (task && s == 0)                         /* Diagonal_Span (filter.c:2079-2110) on the A-view path */
+            { const u16 *pt = sc.atr - r.aback;
+              int dd, tlen = r.atlen - 2;
+              lo = hi = r.abpos - r.bbpos;
+              dd = r.aepos - r.bepos;
+              if (dd < lo) lo = dd; else if (dd > hi) hi = dd;
+              dd = (r.abpos / a.tspace) * a.tspace - r.bbpos;
+              for (int i = 1; i < tlen; i += 2)
+                { dd += a.tspace - pt[i];
+                  if (dd < lo) lo = dd; else if (dd > hi) hi = dd;
+                }
+              lo = (lo >> W) - 1;
+              hi = (hi >> W) + 1;
+            }
+          lo = hget(lo, hb, 0);  hi = hget(hi, hb, 0);
+          if (task)
+            { if (sd < lo) lo = sd; else if (sd > hi) hi = sd;
+              if (lo < mind - 1) lo = mind - 1;
+              if (hi > maxd + 1) hi = maxd + 1;
+              for (int q = lo + s; q <= hi; q += 32)
+                if (r.aepos > sc.lasta[q])
+                  sc.lasta[q] = r.aepos;
+              if (lo < clo) clo = lo;
+              if (hi > chi) chi = hi;
+            }
+          wave_mem_sync();
+          const bool keep = task && (r.aepos - r.abpos) + (r.bepos - r.bbpos) >= a.minover;
+          pk_emit(a, sc, keep, r, ar, br, item, seq);
+          if (keep)
+            seq += 1;
+        }
+    }
+}
+
+void damar_launch_report2(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st)
+{ if ((tasks ? ntasks : a->nwork) == 0)
+    return;
+  hipLaunchKernelGGL(report2_kernel, dim3(nslots / 2), dim3(64), 0, st, *a, tasks, ntasks);
+}

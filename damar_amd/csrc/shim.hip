@@ -768,6 +768,10 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
                            hipMemcpyHostToDevice, G_st));
   ra->score = RS.tables;
   ra->table = RS.tables + 32768;
+  { const int16 *sc = damar_spec_score_table(spec);          /* SCORE[x] = matches * mscore - (15 - matches) * dscore */
+    ra->mscore = sc[32767] / 15;
+    ra->dscore = -sc[0] / 15;
+  }
   ra->state = RS.state;  ra->state_stride = RS.state_stride;  ra->span = RS.span;
   ra->marks = RS.marks;  ra->marks_stride = RS.marks_stride;
   ra->cells = RS.cells;  ra->cell_cap = RS.cell_cap;
@@ -779,6 +783,23 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   ra->counters = RS.counters;
 }
 
+
+/* Two read pairs per wavefront (kernels/report_packed.h) unless DAMAR_PACKED=0 or the job is outside what its
+ * packed chain heads can hold (12 bits of trace-grid index, 20 bits of pebble index): then one pair per wavefront. */
+static bool use_packed(const ReportArgs *ra, int amax, int bmax)
+{ static int want = -1;
+  if (want < 0)
+    { const char *e = getenv("DAMAR_PACKED");
+      want = e ? atoi(e) : 1;
+    }
+  if (!want || (RS.nslots & 1) || ra->tspace <= 0)
+    return false;
+  if (std::max(amax, bmax) / ra->tspace + 8 > DAMAR_PACKED_MAX_MARKS || ra->cell_cap > DAMAR_PACKED_MAX_CELLS)
+    return false;
+  if (ra->mscore * 8 > 32000 || ra->dscore * 8 > 32000)
+    return false;
+  return true;
+}
 
 /***** host tail (filter.c:2442-2483 per read pair) and its optional worker thread *********************/
 
@@ -1444,7 +1465,10 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
           HIP_CHECK(hipMemsetAsync(RS.counters, 0, 64, G_st));
           tick(4);
           stage("report_setup");
-          damar_launch_report(&ra, RS.nslots, G_st);
+          if (use_packed(&ra, ablock->maxlen, bblock->maxlen))
+            damar_launch_report2(&ra, NULL, 0, RS.nslots, G_st);
+          else
+            damar_launch_report(&ra, RS.nslots, G_st);
           stage("report");
           tick(5);
           HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, G_st));
@@ -1709,7 +1733,10 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
       fill_report_args(&ra, ablk, bblk, comp, 0, spec);
       HIP_CHECK(hipMemsetAsync(RS.counters, 0, 64, G_st));
       stage("la_setup");
-      damar_launch_la_batch(&ra, dt, (u32) ntasks, RS.nslots, G_st);
+      if (use_packed(&ra, ablk->d.maxlen, bblk->d.maxlen))
+        damar_launch_report2(&ra, dt, (u32) ntasks, RS.nslots, G_st);
+      else
+        damar_launch_la_batch(&ra, dt, (u32) ntasks, RS.nslots, G_st);
       stage("la_kernel");
       HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, G_st));
       HIP_CHECK(hipStreamSynchronize(G_st));
