@@ -126,6 +126,7 @@ typedef struct
 #define DAMAR_ERR_WIDE   16u    /* a band outgrew the ring of diagonals of the slot buffers: relaunch with a larger ring */
 
 int  damar_report_waves_per_simd(void);
+int  damar_report2_waves_per_simd(void);     /* two scratch slots per wavefront */
 void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st);
 /* datander report: one work item per read of a.ablk, dist as produced by damar_launch_tandem_links */
 void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots, hipStream_t st);

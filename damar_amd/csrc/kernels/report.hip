@@ -246,7 +246,12 @@ struct WaveState
   Tip trim, reach;
   int stopped;
   int bad;                /* the pebble pool overflowed: chain heads may be out of range, skip the trace walk */
+  int narrow;             /* continuation entry only: left because the band fits a half-wavefront again */
 };
+
+/* the band state of one lane of the register path (lane (k & 63) owns diagonal k), for the continuation entry */
+struct LaneRegs { int V, M, HA, HB, NA, NB; u64 T; };
+#define PK_NARROW 24      /* a continuation returns to the packed path when hgh - low + 3 <= PK_NARROW */
 
 #define WS_LOAD(ws)                                                                          \
   int low = uni(ws.low), hgh = uni(ws.hgh), dif = uni(ws.dif), besta = uni(ws.besta);        \
@@ -269,8 +274,11 @@ struct WaveState
 /* Stage 1: wave 0 on the seed diagonal, then the register path (bands of <= 64 diagonals).
  * Leaves ws.stopped = 0 only if the band outgrew the wavefront: the band state is then in
  * the slot's DState buffers and stage 2 continues. */
-template <int REV>
-__device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, WaveState &ws)
+/* CONT = 1: enter the loop with the band state of *io and the bookkeeping of ws (a half of report_packed.h's
+   wavefront that outgrew its 32 lanes), and also leave it -- ws.narrow = 1, state back in *io -- once the band
+   fits a half again. */
+template <int REV, int CONT>
+__device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mida, WaveState &ws, LaneRegs *io)
 {
   const int lane = lane_id();
   const int TS = uni(c.ts);
@@ -314,7 +322,16 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
   int rV = 0, rM = 0, rHA = 0, rHB = 0, rNA = 0, rNB = 0;
   u64 rT = 0;
 
+  if (CONT)
+    { low = uni(ws.low);  hgh = uni(ws.hgh);  dif = uni(ws.dif);  besta = uni(ws.besta);  besty = uni(ws.besty);
+      lasta = uni(ws.lasta);  more = uni(ws.more);  reachm = uni(ws.reachm);  aclip = uni(ws.aclip);  bclip = uni(ws.bclip);
+      ncell = (u32) uni((int) ws.ncell);
+      trim.a = uni(ws.trim.a);  trim.y = uni(ws.trim.y);  trim.d = uni(ws.trim.d);  trim.ha = uni(ws.trim.ha);  trim.hb = uni(ws.trim.hb);
+      reach.a = uni(ws.reach.a);  reach.y = uni(ws.reach.y);  reach.d = uni(ws.reach.d);  reach.ha = uni(ws.reach.ha);  reach.hb = uni(ws.reach.hb);
+      rV = io->V;  rM = io->M;  rT = io->T;  rHA = io->HA;  rHB = io->HB;  rNA = io->NA;  rNB = io->NB;
+    }
   /* wave 0 on the seed diagonal: every lane computes the same values */
+  if (!CONT)
   { int k = diag, y = (mida - k) >> 1, na, nb, ha, hb, ham, hbm, v;
     const u8 *a = aseq + k;
     Cell cl;
@@ -364,7 +381,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
   }
 
   /***** register path: the band (<= 64 diagonals) lives in VGPRs, neighbour V by DPP rotate, predecessor state by ds_bpermute *****/
-  bool stopped = false;
+  bool stopped = false, narrow = false;
   u32  err_flags = 0, err_empty = 0;          /* wave-uniform, reported once after the loop */
   int  bad = 0;
 #ifdef DAMAR_PROF
@@ -400,7 +417,8 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
         bclip = REV ? BIG : -BIG;                                                          \
       }
 
-    CLIP_REG()
+    if (!CONT)
+      { CLIP_REG() }
 
     const int src_me = lane << 2, src_up = ((lane + 1) & 63) << 2, src_dn = ((lane - 1) & 63) << 2;   /* bpermute addresses */
     while (more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
@@ -420,6 +438,10 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
           }
         if (hgh - low + 3 > 64)        /* would not fit the wavefront: continue in memory */
           break;
+        if (CONT && hgh - low + 3 <= PK_NARROW)
+          { narrow = true;
+            break;
+          }
 #ifdef DAMAR_PROF
         if (hgh - low + 3 > 16 && pf_first16 < 0) pf_first16 = dif;
         if (hgh - low + 3 > 32 && pf_first32 < 0) pf_first32 = dif;
@@ -625,7 +647,9 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
       }
 
     /* leaving the register path with work left: spill the band to the memory buffers */
-    if (!stopped && more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
+    if (CONT && narrow)
+      { io->V = rV;  io->M = rM;  io->T = rT;  io->HA = rHA;  io->HB = rHB;  io->NA = rNA;  io->NB = rNB; }
+    else if (!stopped && more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
       { const int k = low + ((lane - low) & 63);
         wave_mem_sync();
         if (k <= hgh)
@@ -643,6 +667,7 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
   }
   ws.stopped = stopped ? 1 : 0;
   ws.bad = bad;
+  ws.narrow = narrow ? 1 : 0;
 #ifdef DAMAR_PROF
   PROF_ADD(0, 1);
   PROF_ADD(1, dif);
@@ -654,6 +679,14 @@ __device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, W
   WS_STORE(ws)
   wave_mem_sync();
 }
+
+template <int REV>
+__device__ WAVE_REG_INLINE void wave_reg(const WaveCtx &c, int diag, int mida, WaveState &ws)
+{ wave_reg_impl<REV, 0>(c, diag, mida, ws, NULL); }
+
+template <int REV>
+__device__ __noinline__ void wave_reg_cont(const WaveCtx &c, int mida, WaveState &ws, LaneRegs *io)
+{ wave_reg_impl<REV, 1>(c, 0, mida, ws, io); }
 
 /* Stage 2: the same wave steps with the band in memory, for bands wider than the wavefront. */
 template <int REV>

@@ -29,6 +29,9 @@
  * buffers and the full-wave memory path (wave_mem) finishes that direction.
  */
 
+#ifndef PK_WINDOWS
+#define PK_WINDOWS 0                      /* 1: the snake reads per-lane sliding windows of the packed bases (8 more VGPRs; measured: no gain) */
+#endif
 #define PK_BIAS   3                       /* grid index = (mark - off) / TS + PK_BIAS, always >= 1 */
 #define PK_HBITS  20                      /* pebble index bits in a packed chain head (cell_cap <= 2^20) */
 #define PK_HMASK  ((1 << PK_HBITS) - 1)
@@ -57,6 +60,7 @@ struct PkDir
   Tip trim, reach;
   int ovf;                  /* the band outgrew the half: continue on the full-wave path */
   int bad;
+  int fin;                  /* the direction was finished on the full-wave path */
 };
 
 /* one 8-column chunk of the trim test: low half = minimum suffix score, high half = total */
@@ -72,8 +76,10 @@ __device__ __forceinline__ void pk_fill_trimtab(u32 *tab, int mscore, int dscore
 }
 
 /* every suffix of the newest 30 columns of b scores >= 0 (align.c:917-919 on TABLE/SCORE) */
-__device__ __forceinline__ bool pk_trim_ok(const u32 *tab, u64 b)
-{ const u32 lo = (u32) b;
+typedef const __attribute__((address_space(3))) u32 *PkLds;
+__device__ __forceinline__ bool pk_trim_ok(const u32 *gtab, u64 b)
+{ const PkLds tab = (PkLds) gtab;            /* (a noinline caller only has a generic pointer: say that it is LDS) */
+  const u32 lo = (u32) b;
   const u32 e0 = tab[lo & 0xff], e1 = tab[(lo >> 8) & 0xff], e2 = tab[(lo >> 16) & 0xff];
   const u32 e3 = tab[((lo >> 24) & 0x3f) | 0xc0];           /* 6 columns; older ones padded with matches */
   int s = (int) e0 >> 16, mn = (int) (short) e0, t;
@@ -88,40 +94,48 @@ __device__ __forceinline__ int pk_popc61(u64 b)
 
 /* One direction of the wave for the two halves of the wavefront.  `on` = this half runs a task.  Leaves the
  * band state in the lane registers passed by reference and the bookkeeping in D. */
-template <int REV>
-__device__ __forceinline__ void pk_wave(const ReportArgs &a, const u32 *trimtab, bool on, const PkPair &p, u32 cbase,
-                                        int diag, int mida, PkDir &D,
-                                        int &rV, u64 &rT, int &rHA, int &rHB, int &rNA, int &rNB)
-{ const int lane = lane_id(), hb = lane & 32, s = lane & 31;
-  const int KS = REV ? 1 : -1, S = REV ? -1 : 1;
-  const int edge = REV ? BIG : -1;
-  const int TS = uni(a.tspace), ave = uni(a.ave_path);
-  const u32 *apk = uni_ptr(a.ablk.pk), *bpk = uni_ptr(a.bblk.pk);
-  const u8 *abase = uni_ptr(a.ablk.bases), *bbase = uni_ptr(a.bblk.bases);
-  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) uni_ptr((Cell *) a.cells);
-  const int cell_cap = (int) uni((int) a.cell_cap);
-  u32 *const errw = uni_ptr(&a.counters[3]);
-  const u8 *aseq = abase + p.a0 + (REV ? -1 : 0), *bseq = bbase + p.b0 + (REV ? -1 : 0);
-  const int va0 = p.a0 + 16 * PK_PAD, vb0 = p.b0 + 16 * PK_PAD, valen = p.alen, vblen = p.blen;
-  const int offa = p.aoff - PK_BIAS * TS, offb = p.boff - PK_BIAS * TS;      /* mark = index * TS + off */
-  const int steplimit = p.alen + p.blen + 64;
-  const int guard = 4 * (p.alen + p.blen) + 1024;
-  (void) aseq; (void) bseq;
+/* the names the wave code uses for the half's bookkeeping (fields of D, kept in registers) and constants */
+#define PK_NAMES()                                                                                   \
+  const int lane = lane_id(), hb = lane & 32, s = lane & 31;                                         \
+  const int KS = REV ? 1 : -1, S = REV ? -1 : 1;                                                     \
+  const int edge = REV ? BIG : -1;                                                                   \
+  const int TS = uni(a.tspace), ave = uni(a.ave_path);                                               \
+  const u32 *apk = uni_ptr(a.ablk.pk), *bpk = uni_ptr(a.bblk.pk);                                    \
+  const u8 *abase = uni_ptr(a.ablk.bases), *bbase = uni_ptr(a.bblk.bases);                           \
+  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) uni_ptr((Cell *) a.cells);                          \
+  const int cell_cap = (int) uni((int) a.cell_cap);                                                  \
+  u32 *const errw = uni_ptr(&a.counters[3]);                                                         \
+  const u8 *aseq = abase + p.a0 + (REV ? -1 : 0), *bseq = bbase + p.b0 + (REV ? -1 : 0);            \
+  const int va0 = p.a0 + 16 * PK_PAD, vb0 = p.b0 + 16 * PK_PAD, valen = p.alen, vblen = p.blen;      \
+  const int offa = p.aoff - PK_BIAS * TS, offb = p.boff - PK_BIAS * TS;  /* mark = index * TS + off */ \
+  const int steplimit = p.alen + p.blen + 64;                                                        \
+  const int guard = 4 * (p.alen + p.blen) + 1024;                                                    \
+  int &low = D.low, &hgh = D.hgh, &dif = D.dif, &besta = D.besta, &besty = D.besty, &lasta = D.lasta; \
+  int &more = D.more, &reachm = D.reachm, &aclip = D.aclip, &bclip = D.bclip, &kbase = D.kbase;      \
+  int &ncell = D.ncell, &ovf = D.ovf, &bad = D.bad;                                                  \
+  Tip &trim = D.trim, &reach = D.reach;                                                              \
+  (void) lane; (void) hb; (void) s; (void) KS; (void) S; (void) edge; (void) TS; (void) ave; (void) apk; (void) bpk; \
+  (void) gcell; (void) cell_cap; (void) errw; (void) aseq; (void) bseq; (void) va0; (void) vb0; (void) valen;        \
+  (void) vblen; (void) offa; (void) offb; (void) steplimit; (void) guard;
 
-  int low = diag, hgh = diag, dif = 0;
-  int besta = mida, lasta = mida, besty = (mida - diag) >> 1, more = 1, reachm = -1;
-  int aclip = REV ? -BIG : BIG, bclip = REV ? BIG : -BIG;
-  int ncell = 2;
-  int kbase = diag - KS * 15;
-  Tip trim, reach;
+/* Wave 0 on the seed diagonal (align.c:491-626 / 1203-1340) for the halves with `on`: every lane of the half
+ * computes the same values.  Sets up D and the lane registers of the direction. */
+template <int REV>
+__device__ __forceinline__ void pk_init(const ReportArgs &a, bool on, const PkPair &p, u32 cbase, int diag, int mida, PkDir &D,
+                                        int &rV, u64 &rT, int &rHA, int &rHB, int &rNA, int &rNB)
+{ PK_NAMES()
+  low = diag;  hgh = diag;  dif = 0;
+  besta = mida;  lasta = mida;  besty = (mida - diag) >> 1;  more = 1;  reachm = -1;
+  aclip = REV ? -BIG : BIG;  bclip = REV ? BIG : -BIG;
+  ncell = 2;
+  kbase = diag - KS * 15;
   trim.a = reach.a = mida;  trim.y = reach.y = besty;  trim.d = reach.d = 0;
   trim.ha = reach.ha = 0;   trim.hb = reach.hb = 1;
-  int ovf = 0, bad = 0;
-  u32 err_flags = 0, err_empty = 0;
+  ovf = 0;  bad = 0;
+  D.fin = 0;
 
   rV = edge;  rT = 0;  rHA = 0;  rHB = 0;  rNA = 0;  rNB = 0;
 
-  /* wave 0 on the seed diagonal (align.c:491-626 / 1203-1340): every lane of the half computes the same values */
   if (on)
     { const int k = diag;
       int y = (mida - k) >> 1, nai, nbi, hai, hbi, ha = 0, hb_ = 1, v;
@@ -179,6 +193,22 @@ __device__ __forceinline__ void pk_wave(const ReportArgs &a, const u32 *trimtab,
         }
       rNA = nai;  rNB = nbi;
     }
+}
+
+/* The wave steps of one direction for the two halves of the wavefront (align.c:667-999 / 1378-1697), until
+ * every half has finished the direction or outgrown its 32 lanes (D.ovf). */
+template <int REV>
+__device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab, bool on, const PkPair &p, u32 cbase, PkDir &D,
+                                        int &rV, u64 &rT, int &rHA, int &rHB, int &rNA, int &rNB)
+{ PK_NAMES()
+  u32 err_flags = 0, err_empty = 0;
+  on = on && !D.fin && !ovf;
+#if PK_WINDOWS
+  typedef u32 v2u __attribute__((ext_vector_type(2)));
+  u64 wina = 0, winb = 0;                   /* bases [16 wd, 16 wd + 32) of the two reads, 2 bits each (biased dword index wd) */
+  u32 nxta = 0, nxtb = 0;                   /* the 16 bases that follow in the direction of the wave */
+  int wda = -4096, wdb = -4096;
+#endif
 
   /* clipping at sequence ends (align.c:628-658 / 943-975), per half */
 #define PK_CLIP()                                                                                      \
@@ -219,6 +249,9 @@ __device__ __forceinline__ void pk_wave(const ReportArgs &a, const u32 *trimtab,
 
   PK_CLIP()
 
+#ifdef DAMAR_PROF
+  unsigned long long pf_iters = 0, pf_half = 0;
+#endif
   for (;;)
     { on = on && more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG));
       if (on && hgh < low)
@@ -229,6 +262,9 @@ __device__ __forceinline__ void pk_wave(const ReportArgs &a, const u32 *trimtab,
         { ovf = 1;  on = false; }
       if (!wany(on))
         break;
+#ifdef DAMAR_PROF
+      pf_iters += 1;  pf_half += (unsigned long long) __popcll(wballot(on)) >> 5;
+#endif
 
       /* keep the band (plus the two lanes it may grow by) inside the half */
       { const int slo = REV ? low - kbase : kbase - hgh, shi = REV ? hgh - kbase : kbase - low;
@@ -303,10 +339,68 @@ __device__ __forceinline__ void pk_wave(const ReportArgs &a, const u32 *trimtab,
       if (act)
         { b <<= 1;
           y = (v - k) >> 1;
+#if !PK_WINDOWS
           { const SnakeOut so = SNAKE_AT(k, y, 0, b);
             y = so.y;  b = so.b;
             ena = so.na;  enb = so.nb;
           }
+#else
+          if ((u32) (y + k) > (u32) valen || (u32) y > (u32) vblen)          /* past an end: what the reference reads there */
+            { const SnakeOut so = snake<REV>(aseq + k, bseq, y, 0, b);
+              y = so.y;  b = so.b;
+              ena = so.na;  enb = so.nb;
+            }
+          else
+            { /* the snake (align.c:832-856 / 1542-1566) on this lane's sliding windows of the 2-bit bases: 32 bases of
+                 each read in registers, the next 16 already on their way, so that a step waits for memory only
+                 after a slide longer than a window */
+              int pa = va0 + k + y - (REV ? 16 : 0), pb = vb0 + y - (REV ? 16 : 0);   /* first base of the 16 to compare */
+              ena = REV ? y + k : valen - (y + k);
+              enb = REV ? y : vblen - y;
+              for (;;)
+                { const int qa = pa >> 4, qb = pb >> 4;
+                  if (qa != wda || qb != wdb)
+                    { if (qa == wda + (REV ? -1 : 1))
+                        { wina = REV ? ((wina << 32) | nxta) : ((wina >> 32) | ((u64) nxta << 32));
+                          wda = qa;
+                        }
+                      else if (qa != wda)
+                        { const v2u w = *(const GLOBAL_AS v2u *) ((const GLOBAL_AS char *) (apk - PK_PAD) + 4 * qa);
+                          __builtin_amdgcn_s_waitcnt(0x0f70);      /* vmcnt(0) here, so that the windows are never "in flight"
+                                                                      where the paths join and only a slide waits for its prefetch */
+                          wina = ((u64) w.y << 32) | w.x;
+                          wda = qa;
+                        }
+                      if (qb == wdb + (REV ? -1 : 1))
+                        { winb = REV ? ((winb << 32) | nxtb) : ((winb >> 32) | ((u64) nxtb << 32));
+                          wdb = qb;
+                        }
+                      else if (qb != wdb)
+                        { const v2u w = *(const GLOBAL_AS v2u *) ((const GLOBAL_AS char *) (bpk - PK_PAD) + 4 * qb);
+                          __builtin_amdgcn_s_waitcnt(0x0f70);
+                          winb = ((u64) w.y << 32) | w.x;
+                          wdb = qb;
+                        }
+                      nxta = *(const GLOBAL_AS u32 *) ((const GLOBAL_AS char *) (apk - PK_PAD) + 4 * (wda + (REV ? -1 : 2)));
+                      nxtb = *(const GLOBAL_AS u32 *) ((const GLOBAL_AS char *) (bpk - PK_PAD) + 4 * (wdb + (REV ? -1 : 2)));
+                    }
+                  const u32 wa = __builtin_amdgcn_alignbit((u32) (wina >> 32), (u32) wina, (u32) pa * 2);
+                  const u32 wb = __builtin_amdgcn_alignbit((u32) (winb >> 32), (u32) winb, (u32) pb * 2);
+                  const u32 x = wa ^ wb;
+                  const u32 run = (REV ? (u32) __builtin_clzll(((u64) x << 32) | 0x80000000ull)
+                                       : (u32) __builtin_ctzll((u64) x | (1ull << 32))) >> 1;
+                  const int lim = ena < enb ? ena : enb;
+                  const int n = (int) run < lim ? (int) run : lim;
+                  b = (b << n) | (u64) ((1u << n) - 1);
+                  y  += REV ? -n : n;
+                  pa += REV ? -n : n;
+                  pb += REV ? -n : n;
+                  ena -= n;  enb -= n;
+                  if (n < 16 || lim == 16)
+                    break;
+                }
+            }
+#endif
           v = (y << 1) + k;
         }
       const bool bhit = act && enb == 0, ahit = act && enb != 0 && ena == 0;
@@ -444,38 +538,39 @@ __device__ __forceinline__ void pk_wave(const ReportArgs &a, const u32 *trimtab,
       }
     }
 #undef PK_CLIP
+#ifdef DAMAR_PROF
+  PROF_ADD(26, pf_iters);  PROF_ADD(27, pf_half);  PROF_ADD(28, __popcll(wballot(ovf != 0)) >> 5);  PROF_ADD(29, 1);
+#endif
   if ((err_flags | err_empty) && s == 0)
     { if (err_flags) atomicOr(errw, err_flags);
       if (err_empty) atomicAdd(errw + 2, err_empty);
     }
-  D.low = low;  D.hgh = hgh;  D.dif = dif;  D.besta = besta;  D.besty = besty;  D.lasta = lasta;  D.more = more;
-  D.reachm = reachm;  D.aclip = aclip;  D.bclip = bclip;  D.kbase = kbase;  D.ncell = ncell;
-  D.trim = trim;  D.reach = reach;  D.ovf = ovf;  D.bad = bad;
 }
 
-/* A half whose band outgrew it: hand the direction to the full-wave memory path (wave_mem<REV>).  Called for one
- * half at a time with every lane of the wavefront active; `hsel` is that half's lane base (0 or 32, wave-uniform). */
+/* A half whose band outgrew its 32 lanes borrows the whole wavefront: the band goes to the one-alignment-per-wavefront
+ * register path (wave_reg_cont<REV>: lane (k & 63) owns diagonal k, marks as values) and comes back as soon as it
+ * fits a half again (hgh - low + 3 <= PK_NARROW) -- bands wider than 29 diagonals last a few steps -- or finishes the
+ * direction there (through wave_mem<REV> if it outgrows the wavefront too).  Called for one half at a time with every
+ * lane active; hsel = that half's lane base (0 or 32).  *Dp, *io are per-lane copies: only the half's lanes are changed. */
 template <int REV>
-__device__ __noinline__ void pk_overflow(const ReportArgs &a, const SlotScratch &sc, const PkPair &p, int hsel, int mida,
-                                         PkDir &D, int rV, u64 rT, int rHA, int rHB, int rNA, int rNB,
-                                         WaveCtx &c, WaveState &ws)
+__device__ __noinline__ void pk_solo(const ReportArgs &a, SlotScratch sc, PkPair p, int hsel, int mida, PkDir *Dp, LaneRegs *io)
 { const int lane = lane_id();
   const int KS = REV ? 1 : -1;
   const int TS = a.tspace;
-  /* the half's uniform values, as scalars */
+  const int edge = REV ? BIG : -1;
   const int src = hsel;
-  c.aseq = a.ablk.bases + (u32) bcast_i(p.a0, src);
-  c.bseq = a.bblk.bases + (u32) bcast_i(p.b0, src);
-  c.apk = a.ablk.pk;  c.a0 = (u32) bcast_i(p.a0, src);
-  c.bpk = a.bblk.pk;  c.b0 = (u32) bcast_i(p.b0, src);
+  WaveCtx c;
+  WaveState ws;
+#define PK_PTR_OF(T, ptr) ((T) (uintptr_t) (((u64) (u32) bcast_i((int) (u32) ((u64) (uintptr_t) (ptr) >> 32), src) << 32) | \
+                                            (u32) bcast_i((int) (u32) (u64) (uintptr_t) (ptr), src)))
+  c.a0 = (u32) bcast_i(p.a0, src);  c.b0 = (u32) bcast_i(p.b0, src);
+  c.aseq = a.ablk.bases + c.a0;  c.bseq = a.bblk.bases + c.b0;
+  c.apk = a.ablk.pk;  c.bpk = a.bblk.pk;
   c.alen = bcast_i(p.alen, src);  c.blen = bcast_i(p.blen, src);
   c.ts = TS;  c.ave = a.ave_path;  c.reach = a.reach;
   c.score = a.score;  c.table = a.table;
   c.minp = bcast_i(p.minp, src);  c.maxp = bcast_i(p.maxp, src);
   c.aoff = bcast_i(p.aoff, src);  c.boff = bcast_i(p.boff, src);
-  /* (the scratch pointers differ between the halves: take those of the half concerned) */
-#define PK_PTR_OF(T, ptr) ((T) (uintptr_t) (((u64) (u32) bcast_i((int) (u32) ((u64) (uintptr_t) (ptr) >> 32), src) << 32) | \
-                                            (u32) bcast_i((int) (u32) (u64) (uintptr_t) (ptr), src)))
   c.st0 = PK_PTR_OF(DState *, sc.st0);  c.st1 = PK_PTR_OF(DState *, sc.st1);
   c.NA = PK_PTR_OF(int *, sc.NA);  c.NB = PK_PTR_OF(int *, sc.NB);
   c.koff = c.blen + 8;  c.ring = a.span;
@@ -483,36 +578,81 @@ __device__ __noinline__ void pk_overflow(const ReportArgs &a, const SlotScratch 
   c.err = &a.counters[3];
   c.atr = PK_PTR_OF(u16 *, sc.atr);  c.btr = PK_PTR_OF(u16 *, sc.btr);
 #undef PK_PTR_OF
-  ws.low = bcast_i(D.low, src);  ws.hgh = bcast_i(D.hgh, src);  ws.dif = bcast_i(D.dif, src);
-  ws.besta = bcast_i(D.besta, src);  ws.besty = bcast_i(D.besty, src);  ws.lasta = bcast_i(D.lasta, src);
-  ws.more = bcast_i(D.more, src);  ws.reachm = bcast_i(D.reachm, src);
-  ws.aclip = bcast_i(D.aclip, src);  ws.bclip = bcast_i(D.bclip, src);
-  ws.ncell = (u32) bcast_i(D.ncell, src);
-  ws.trim.a = bcast_i(D.trim.a, src);  ws.trim.y = bcast_i(D.trim.y, src);  ws.trim.d = bcast_i(D.trim.d, src);
-  ws.trim.ha = bcast_i(D.trim.ha, src);  ws.trim.hb = bcast_i(D.trim.hb, src);
-  ws.reach.a = bcast_i(D.reach.a, src);  ws.reach.y = bcast_i(D.reach.y, src);  ws.reach.d = bcast_i(D.reach.d, src);
-  ws.reach.ha = bcast_i(D.reach.ha, src);  ws.reach.hb = bcast_i(D.reach.hb, src);
-  ws.stopped = 0;  ws.bad = 0;
-  /* the band of that half to the slot's DState ring, marks as values again */
-  { const int kbase = bcast_i(D.kbase, src);
-    const int o = c.koff;
-    const u32 rmask = (u32) c.ring - 1u;
-    const int offa = c.aoff - PK_BIAS * TS, offb = c.boff - PK_BIAS * TS;
-    if ((lane & 32) == hsel)
-      { const int k = kbase + KS * (lane & 31);
-        if (k >= ws.low && k <= ws.hgh)
-          { DState st;
-            st.V = rV;  st.M = pk_popc61(rT);  st.HA = rHA & PK_HMASK;  st.HB = rHB & PK_HMASK;  st.T = rT;
-            st.HAm = (int) ((u32) rHA >> PK_HBITS) * TS + offa;
-            st.HBm = (int) ((u32) rHB >> PK_HBITS) * TS + offb;
-            c.st0[RI(k)] = st;
-            c.NA[RI(k)] = rNA * TS + offa;
-            c.NB[RI(k)] = rNB * TS + offb;
-          }
-      }
+  ws.low = bcast_i(Dp->low, src);  ws.hgh = bcast_i(Dp->hgh, src);  ws.dif = bcast_i(Dp->dif, src);
+  ws.besta = bcast_i(Dp->besta, src);  ws.besty = bcast_i(Dp->besty, src);  ws.lasta = bcast_i(Dp->lasta, src);
+  ws.more = bcast_i(Dp->more, src);  ws.reachm = bcast_i(Dp->reachm, src);
+  ws.aclip = bcast_i(Dp->aclip, src);  ws.bclip = bcast_i(Dp->bclip, src);
+  ws.ncell = (u32) bcast_i(Dp->ncell, src);
+  ws.trim.a = bcast_i(Dp->trim.a, src);  ws.trim.y = bcast_i(Dp->trim.y, src);  ws.trim.d = bcast_i(Dp->trim.d, src);
+  ws.trim.ha = bcast_i(Dp->trim.ha, src);  ws.trim.hb = bcast_i(Dp->trim.hb, src);
+  ws.reach.a = bcast_i(Dp->reach.a, src);  ws.reach.y = bcast_i(Dp->reach.y, src);  ws.reach.d = bcast_i(Dp->reach.d, src);
+  ws.reach.ha = bcast_i(Dp->reach.ha, src);  ws.reach.hb = bcast_i(Dp->reach.hb, src);
+  ws.stopped = 0;  ws.bad = 0;  ws.narrow = 0;
+  const int offa = c.aoff - PK_BIAS * TS, offb = c.boff - PK_BIAS * TS;
+
+  /* the half's band into the 64-lane layout, marks as values again */
+  LaneRegs r;
+  { const int kbase = bcast_i(Dp->kbase, src);
+    const int k = ws.low + ((lane - ws.low) & 63);
+    const bool in = k <= ws.hgh;
+    const int sl = (hsel + (in ? KS * (k - kbase) : 0)) << 2;
+    const int nav = io->NA * TS + offa, nbv = io->NB * TS + offb;
+    r.V  = __builtin_amdgcn_ds_bpermute(sl, io->V);
+    r.HA = __builtin_amdgcn_ds_bpermute(sl, io->HA) & PK_HMASK;
+    r.HB = __builtin_amdgcn_ds_bpermute(sl, io->HB) & PK_HMASK;
+    r.NA = __builtin_amdgcn_ds_bpermute(sl, nav);
+    r.NB = __builtin_amdgcn_ds_bpermute(sl, nbv);
+    { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) io->T);
+      const u32 th = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) (io->T >> 32));
+      r.T = ((u64) th << 32) | tl;
+    }
+    r.M = pk_popc61(r.T);
+    if (!in)
+      r.V = edge;
   }
   wave_mem_sync();
-  wave_mem<REV>(c, mida, ws);
+  wave_reg_cont<REV>(c, mida, ws, &r);
+  if (ws.narrow)
+    { /* back into the half, centred */
+      const int w = ws.hgh - ws.low + 1, slo = (32 - w) >> 1;
+      const int kbase = REV ? ws.low - slo : ws.hgh + slo;
+      const int k = kbase + KS * (lane & 31);
+      const bool in = k >= ws.low && k <= ws.hgh;
+      const int sl = (k & 63) << 2;
+      int ha = r.HA, hb_ = r.HB, hai = 0, hbi = 0;
+      wave_mem_sync();
+      if (r.V != edge || true)            /* the mark of each chain head, from its cell */
+        { const int ham = __hip_atomic_load(&c.cells[ha].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int hbm = __hip_atomic_load(&c.cells[hb_].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hai = (ham - offa + TS - 1) / TS;          /* exact on the grid; a reverse root (off the grid) rounds up */
+          hbi = (hbm - offb + TS - 1) / TS;
+        }
+      const int nai = (r.NA - offa) / TS, nbi = (r.NB - offb) / TS;
+      const int pha = ha | (hai << PK_HBITS), phb = hb_ | (hbi << PK_HBITS);
+      const int nV = __builtin_amdgcn_ds_bpermute(sl, r.V);
+      const int nHA = __builtin_amdgcn_ds_bpermute(sl, pha), nHB = __builtin_amdgcn_ds_bpermute(sl, phb);
+      const int nNA = __builtin_amdgcn_ds_bpermute(sl, nai), nNB = __builtin_amdgcn_ds_bpermute(sl, nbi);
+      const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) r.T);
+      const u32 th = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) (r.T >> 32));
+      if ((lane & 32) == hsel)
+        { io->V = in ? nV : edge;  io->HA = nHA;  io->HB = nHB;  io->NA = nNA;  io->NB = nNB;
+          io->T = ((u64) th << 32) | tl;
+          Dp->kbase = kbase;
+          Dp->ovf = 0;
+        }
+    }
+  else
+    { if (!ws.stopped)
+        wave_mem<REV>(c, mida, ws);
+      if ((lane & 32) == hsel)
+        { Dp->ovf = 0;  Dp->fin = 1;  Dp->more = 0;  Dp->bad = ws.bad; }
+    }
+  if ((lane & 32) == hsel)
+    { Dp->low = ws.low;  Dp->hgh = ws.hgh;  Dp->dif = ws.dif;  Dp->besta = ws.besta;  Dp->besty = ws.besty;
+      Dp->lasta = ws.lasta;  Dp->more = (ws.narrow ? ws.more : 0);  Dp->reachm = ws.reachm;
+      Dp->aclip = ws.aclip;  Dp->bclip = ws.bclip;  Dp->ncell = (int) ws.ncell;
+      Dp->trim = ws.trim;  Dp->reach = ws.reach;
+    }
 }
 
 /* End point and trace points of one direction (align.c:1001-1118 / 1699-1898) for the halves with `fin`: the first
@@ -668,39 +808,60 @@ __device__ __noinline__ void pk_finish(Cell *cells, u16 *atrace, u16 *btrace, bo
     }
 }
 
-/* one direction for both halves: packed loop, the full-wave path for a half that outgrew its lanes, trace walk */
+/* One direction for both halves: wave 0, the packed loop, the whole wavefront for a half whose band outgrew its
+ * lanes (and back), trace walk.  Its own function (noinline, inputs by value) so that the wave loop gets its registers
+ * allocated on its own: what the state machine keeps alive sits in the caller's frame, not in the loop's way. */
+struct PkOut { int x, y, d, atlen, btlen, aback, bback; };
+
 template <int REV>
-__device__ __forceinline__ void pk_pass(const ReportArgs &a, const u32 *trimtab, const SlotScratch &sc, bool task,
-                                        const PkPair &p, u32 cbase, int diag, int mida,
-                                        int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
-{ const int lane = lane_id(), hb = lane & 32;
+__device__ __noinline__ void pk_pass(const ReportArgs &a, const u32 *trimtab, SlotScratch sc, int task_, PkPair p, u32 cbase,
+                                     int diag, int mida, PkOut *out)
+{ const bool task = task_ != 0;
   PkDir D;
   int rV, rHA, rHB, rNA, rNB;
   u64 rT;
-  pk_wave<REV>(a, trimtab, task, p, cbase, diag, mida, D, rV, rT, rHA, rHB, rNA, rNB);
-  /* the direction's end point: the trim point, or the reach candidate (align.c:1009-1016) */
-  int reachm = D.reachm, ta = D.trim.a, ty = D.trim.y, td = D.trim.d, tha = D.trim.ha, thb = D.trim.hb;
-  int ra = D.reach.a, ry = D.reach.y, rd = D.reach.d, rha = D.reach.ha, rhb = D.reach.hb, bad = D.bad;
-  { const u64 ov = wballot(task && D.ovf);
-    if (ov)
+#ifdef DAMAR_PROF
+  const unsigned long long pf_t0 = wall_clock64();
+  unsigned long long pf_solo = 0;
+#endif
+  pk_init<REV>(a, task, p, cbase, diag, mida, D, rV, rT, rHA, rHB, rNA, rNB);
+  for (;;)
+    { pk_loop<REV>(a, trimtab, task, p, cbase, D, rV, rT, rHA, rHB, rNA, rNB);
+      const u64 ov = wballot(task && D.ovf);
+      if (!ov)
+        break;
+#ifdef DAMAR_PROF
+      const unsigned long long pf_s0 = wall_clock64();
+#endif
       for (int h = 0; h < 64; h += 32)
         if ((ov >> h) & 1)
-          { WaveCtx c;
-            WaveState ws;
-            pk_overflow<REV>(a, sc, p, h, bcast_i(mida, h), D, rV, rT, rHA, rHB, rNA, rNB, c, ws);
-            if (hb == h)
-              { reachm = ws.reachm;  ta = ws.trim.a;  ty = ws.trim.y;  td = ws.trim.d;  tha = ws.trim.ha;  thb = ws.trim.hb;
-                ra = ws.reach.a;  ry = ws.reach.y;  rd = ws.reach.d;  rha = ws.reach.ha;  rhb = ws.reach.hb;
-                bad = ws.bad;
-              }
+          { PkDir Dc = D;                     /* copies: what a noinline callee may write must not pin the loop's state to memory */
+            LaneRegs io;
+            io.V = rV;  io.M = 0;  io.HA = rHA;  io.HB = rHB;  io.NA = rNA;  io.NB = rNB;  io.T = rT;
+            pk_solo<REV>(a, sc, p, h, bcast_i(mida, h), &Dc, &io);
+            D = Dc;
+            rV = io.V;  rHA = io.HA;  rHB = io.HB;  rNA = io.NA;  rNB = io.NB;  rT = io.T;
           }
-  }
+#ifdef DAMAR_PROF
+      pf_solo += wall_clock64() - pf_s0;
+#endif
+    }
   wave_mem_sync();
-  if (reachm >= 0 && a.reach)
-    { ta = ra;  ty = ry;  td = rd;  tha = rha;  thb = rhb; }
-  pk_finish<REV>(sc.cells, sc.atr, sc.btr, task && !bad, a.tspace, p.aoff, p.boff, a.reach,
-                 4 * (p.alen + p.blen) + 1024, &a.counters[3], mida, reachm, ta, ty, td, tha, thb,
-                 ox, oy, od, atlen_io, btlen_io, aback, bback);
+#ifdef DAMAR_PROF
+  const unsigned long long pf_t2 = wall_clock64();
+#endif
+  /* the direction's end point: the trim point, or the reach candidate (align.c:1009-1016) */
+  int ta = D.trim.a, ty = D.trim.y, td = D.trim.d, tha = D.trim.ha, thb = D.trim.hb;
+  if (D.reachm >= 0 && a.reach)
+    { ta = D.reach.a;  ty = D.reach.y;  td = D.reach.d;  tha = D.reach.ha;  thb = D.reach.hb; }
+  int ox = 0, oy = 0, od = 0, atl = out->atlen, btl = out->btlen, ab = out->aback, bb = out->bback;
+  pk_finish<REV>(sc.cells, sc.atr, sc.btr, task && !D.bad, a.tspace, p.aoff, p.boff, a.reach,
+                 4 * (p.alen + p.blen) + 1024, &a.counters[3], mida, D.reachm, ta, ty, td, tha, thb,
+                 &ox, &oy, &od, &atl, &btl, &ab, &bb);
+  out->x = ox;  out->y = oy;  out->d = od;  out->atlen = atl;  out->btlen = btl;  out->aback = ab;  out->bback = bb;
+#ifdef DAMAR_PROF
+  PROF_ADD(15, pf_t2 - pf_t0 - pf_solo);  PROF_ADD(13, pf_solo);  PROF_ADD(14, wall_clock64() - pf_t2);
+#endif
 }
 
 /* emit one alignment per half with `keep` (emit_record for 32 lanes): both traces to the pool (B trace reversed
@@ -755,7 +916,12 @@ __device__ __forceinline__ void pk_emit(const ReportArgs &a, const SlotScratch &
 
 enum { PK_ITEM = 0, PK_PANEL, PK_FIRE, PK_DONE };
 
-__global__ __launch_bounds__(64, 4)
+#ifndef PK_WAVES
+#define PK_WAVES 4                      /* resident wavefronts per SIMD the packed kernel is compiled for (VGPR budget 512 / PK_WAVES) */
+#endif
+int damar_report2_waves_per_simd(void) { return PK_WAVES; }
+
+__global__ __launch_bounds__(64, PK_WAVES)
 void report2_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
 { __shared__ u32 trimtab[256];
   const int lane = lane_id(), hb = lane & 32, s = lane & 31;
@@ -771,6 +937,10 @@ void report2_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
 
   pk_fill_trimtab(trimtab, a.mscore, a.dscore);
   __syncthreads();
+#ifdef DAMAR_PROF
+  struct PfExit { unsigned long long t0; __device__ ~PfExit() { unsigned long long d = wall_clock64() - t0;
+    if (lane_id() == 0) { atomicAdd(&g_prof[23], d); atomicAdd(&g_prof[25], 1ull); atomicMax(&g_prof[24], d); } } } pf_exit = { (unsigned long long) wall_clock64() };
+#endif
 
   int  phase = PK_ITEM;
   u32  item = 0, seq = 0;
@@ -936,11 +1106,13 @@ void report2_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
       if (task && s == 0 && !batch)
         atomicAdd(&a.counters[4], 1u);
       LaResult r;
-      { int ax = 0, ay = 0, ad = 0, bx = 0, by = 0, bd = 0, atlen = 0, btlen = 0, aback = 0, bback = 0;
-        pk_pass<0>(a, trimtab, sc, task, p, cbase, diag, anti, &ax, &ay, &ad, &atlen, &btlen, &aback, &bback);
-        pk_pass<1>(a, trimtab, sc, task, p, cbase, diag, anti, &bx, &by, &bd, &atlen, &btlen, &aback, &bback);
-        r.aepos = ax;  r.bepos = ay;  r.abpos = bx;  r.bbpos = by;  r.diffs = ad + bd;
-        r.atlen = atlen;  r.btlen = btlen;  r.aback = aback;  r.bback = bback;
+      { PkOut o;
+        o.x = o.y = o.d = o.atlen = o.btlen = o.aback = o.bback = 0;
+        pk_pass<0>(a, trimtab, sc, task ? 1 : 0, p, cbase, diag, anti, &o);
+        r.aepos = o.x;  r.bepos = o.y;  r.diffs = o.d;
+        pk_pass<1>(a, trimtab, sc, task ? 1 : 0, p, cbase, diag, anti, &o);
+        r.abpos = o.x;  r.bbpos = o.y;  r.diffs += o.d;
+        r.atlen = o.atlen;  r.btlen = o.btlen;  r.aback = o.aback;  r.bback = o.bback;
       }
 
       /* C: what the reference does with the path (filter.c:2318-2380) */

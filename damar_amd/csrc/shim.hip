@@ -640,7 +640,8 @@ static int default_slots(void)
 { const char *e = getenv("DAMAR_SLOTS");
   if (e && atoi(e) > 0)
     return atoi(e);
-  return G_prop.multiProcessorCount * 4 * damar_report_waves_per_simd();      /* every wave slot of the chip */
+  /* every wave slot of the chip: one scratch slot per wavefront of the one-pair kernel, two per wavefront of the packed one */
+  return G_prop.multiProcessorCount * 4 * std::max(damar_report_waves_per_simd(), 2 * damar_report2_waves_per_simd());
 }
 
 static int G_ring = 0;
@@ -784,13 +785,16 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
 }
 
 
-/* Two read pairs per wavefront (kernels/report_packed.h) unless DAMAR_PACKED=0 or the job is outside what its
- * packed chain heads can hold (12 bits of trace-grid index, 20 bits of pebble index): then one pair per wavefront. */
+/* Two read pairs per wavefront (kernels/report_packed.h) with DAMAR_PACKED=1, unless the job is outside what its
+ * packed chain heads can hold (12 bits of trace-grid index, 20 bits of pebble index).  Measured on config 2 (profiles/
+ * r02_packed_*): identical output, 385 ms of report kernel per step against 357 ms for one pair per wavefront -- the
+ * packed loop needs 128 VGPRs (4 wavefronts per SIMD instead of 8) and a wave step of one wavefront takes ~4800 cycles
+ * either way -- so one pair per wavefront stays the default. */
 static bool use_packed(const ReportArgs *ra, int amax, int bmax)
 { static int want = -1;
   if (want < 0)
     { const char *e = getenv("DAMAR_PACKED");
-      want = e ? atoi(e) : 1;
+      want = e ? atoi(e) : 0;
     }
   if (!want || (RS.nslots & 1) || ra->tspace <= 0)
     return false;

@@ -66,6 +66,8 @@ typedef struct
   int64 pebbles;
   int   empty_band; /* a wave ran on an empty band (undefined in the reference) */
   int64 bandhist[130]; /* wave steps by number of diagonals computed in the step (129 = more) */
+  int64 dirs, dirs_over31, steps_after_over31;   /* directions, those that ever compute > 31 diagonals, their steps from then on */
+  int   cur_over;
 } OWaveStats;
 
 void oracle_local_alignment(const char *aseq, int alen, const char *bseq, int blen,

@@ -146,6 +146,7 @@ int main(int argc, char *argv[])
            (long long) st.cells, st.maxband, (long long) st.pebbles, st.empty_band);
   if (verbose && getenv("DAMAR_ORACLE_BANDHIST"))
     { int i;
+      printf("directions %lld over31 %lld steps_after %lld\n", (long long) st.dirs, (long long) st.dirs_over31, (long long) st.steps_after_over31);
       printf("bandhist");
       for (i = 0; i < 130; i++)
         printf(" %lld", (long long) st.bandhist[i]);

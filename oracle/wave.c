@@ -110,7 +110,8 @@ typedef struct
 
 static void forward(const Ctx *c, Band *w, int diag, int mida,
                     Path *apath, uint16 *atrace, int *atlen_out, uint16 *btrace, int *btlen_out)
-{ const char *aseq = c->aseq, *bseq = c->bseq;
+{ if (c->st) { c->st->cur_over = 0; c->st->dirs += 1; }
+  const char *aseq = c->aseq, *bseq = c->bseq;
   const int   TS = c->ts;
   int   cur = 0, nxt = 1;
   int   low = diag, hgh = diag, dif = 0;
@@ -219,7 +220,10 @@ static void forward(const Ctx *c, Band *w, int diag, int mida,
       dif += 1;
 
       if (c->st)
-        c->st->bandhist[hgh - low + 1 > 129 ? 129 : hgh - low + 1] += 1;
+        { c->st->bandhist[hgh - low + 1 > 129 ? 129 : hgh - low + 1] += 1;
+          if (hgh - low + 1 > 31 && !c->st->cur_over) { c->st->cur_over = 1; c->st->dirs_over31 += 1; }
+          if (c->st->cur_over) c->st->steps_after_over31 += 1;
+        }
       /* every diagonal of the new wave from the old wave (align.c:781-909) */
       for (k = low; k <= hgh; k++)
         { int ac = w->V[cur][k + o], am = w->V[cur][k - 1 + o], ap = w->V[cur][k + 1 + o];
@@ -388,7 +392,8 @@ static void forward(const Ctx *c, Band *w, int diag, int mida,
 static void reverse(const Ctx *c, Band *w, int diag, int mida,
                     Path *apath, uint16 *atrace, int *atlen_io, int *aback,
                     uint16 *btrace, int *btlen_io, int *bback)
-{ const char *aseq = c->aseq - 1, *bseq = c->bseq - 1;
+{ if (c->st) { c->st->cur_over = 0; c->st->dirs += 1; }
+  const char *aseq = c->aseq - 1, *bseq = c->bseq - 1;
   const int   TS = c->ts;
   int   cur = 0, nxt = 1;
   int   low = diag, hgh = diag, dif = 0;
@@ -494,7 +499,10 @@ static void reverse(const Ctx *c, Band *w, int diag, int mida,
       dif += 1;
 
       if (c->st)
-        c->st->bandhist[hgh - low + 1 > 129 ? 129 : hgh - low + 1] += 1;
+        { c->st->bandhist[hgh - low + 1 > 129 ? 129 : hgh - low + 1] += 1;
+          if (hgh - low + 1 > 31 && !c->st->cur_over) { c->st->cur_over = 1; c->st->dirs_over31 += 1; }
+          if (c->st->cur_over) c->st->steps_after_over31 += 1;
+        }
       for (k = low; k <= hgh; k++)
         { int ac = w->V[cur][k + o], am = w->V[cur][k - 1 + o], ap = w->V[cur][k + 1 + o];
           int from, v, y, m, ha, hb;
