@@ -136,8 +136,8 @@ typedef struct { int aread, bread, diag, anti; } LaTask;
 void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
 /* two read pairs (or batch tasks, tasks != NULL) per wavefront: report_packed.h; nslots must be even */
 void damar_launch_report2(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
-#define DAMAR_PACKED_MAX_MARKS 4000       /* trace-grid indexes ride in 12 bits of a packed chain head */
-#define DAMAR_PACKED_MAX_CELLS (1u << 20)
+#define DAMAR_MAX_MARKS 16000         /* trace-grid indexes ride in the top 14 bits of a chain head (report.hip PK_HBITS) */
+#define DAMAR_MAX_CELLS (1u << 18)    /* pebbles per slot: 18 bits of a chain head */
 
 u64 damar_report_state_stride(int span);
 

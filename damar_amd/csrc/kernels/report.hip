@@ -79,6 +79,7 @@ struct WaveCtx
   int   alen, blen;
   int   ts, ave, reach;
   const short *score, *table;
+  const u32 *trim8;         /* the 8-column trim table in LDS (pk_fill_trimtab) */
   int   minp, maxp, aoff, boff;
   DState *st0, *st1;        /* indexed by (diagonal + koff) modulo ring: RI() */
   int     ring;
@@ -135,6 +136,52 @@ __device__ __forceinline__ u64 load8(const u8 *p)
   const u32 hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
   return ((u64) hi << 32) | lo;
 }
+
+/* ---- shared by the one-pair path below and the two-pair path of report_packed.h ----
+ * Marks as trace-grid indexes: mark = (index - PK_BIAS) * TS + off (off = aoff / boff), so NA/NB are small integers and
+ * the mark of the pebble at a chain head rides in the top bits of the head index: no cell is read back inside the wave
+ * loop (the reference compares cells[HA].mark with NA[k], align.c:861, 885).  A reverse root's mark is the true start
+ * (off the grid, align.c:1276-1283): its index is rounded UP, which leaves every comparison with a grid mark as it is.
+ * M, the popcount of the match history, is not carried: M == popcount(T & (2^61 - 1)) at all times
+ * (align.c:827-829, 853-855 keep exactly that invariant).
+ * TABLE/SCORE (2 x 64 KB in HBM, align.c:286-297) are replaced by one 1 KB table in LDS: the test
+ * "TABLE[lo15] >= 0 && TABLE[hi15] + SCORE[lo15] >= 0" (align.c:917-919) says that every suffix of the newest 30
+ * columns scores >= 0, and the minimum suffix score of 30 columns composes from 8-column chunks. */
+#define PK_BIAS   3                       /* grid index = (mark - off) / TS + PK_BIAS, always >= 1 */
+#define PK_HBITS  18                      /* pebble index bits in a packed chain head (cell_cap <= 2^18): 14 bits of grid index */
+#define PK_HMASK  ((1 << PK_HBITS) - 1)
+
+/* one 8-column chunk of the trim test: low half = minimum suffix score, high half = total */
+__device__ __forceinline__ void pk_fill_trimtab(u32 *tab, int mscore, int dscore)
+{ for (int x = lane_id(); x < 256; x += 64)
+    { int sc = 0, mn = 0x7fff;
+      for (int i = 0; i < 8; i++)
+        { sc += ((x >> i) & 1) ? mscore : -dscore;           /* bit 0 = newest column */
+          mn = sc < mn ? sc : mn;
+        }
+      tab[x] = ((u32) mn & 0xffffu) | ((u32) sc << 16);
+    }
+}
+
+/* every suffix of the newest 30 columns of b scores >= 0 (align.c:917-919 on TABLE/SCORE) */
+typedef const __attribute__((address_space(3))) u32 *PkLds;
+__device__ __forceinline__ bool pk_trim_ok(const u32 *gtab, u64 b)
+{ const PkLds tab = (PkLds) gtab;            /* (a noinline caller only has a generic pointer: say that it is LDS) */
+  const u32 lo = (u32) b;
+  const u32 e0 = tab[lo & 0xff], e1 = tab[(lo >> 8) & 0xff], e2 = tab[(lo >> 16) & 0xff];
+  const u32 e3 = tab[((lo >> 24) & 0x3f) | 0xc0];           /* 6 columns; older ones padded with matches */
+  int s = (int) e0 >> 16, mn = (int) (short) e0, t;
+  t = s + (int) (short) e1;  mn = t < mn ? t : mn;  s += (int) e1 >> 16;
+  t = s + (int) (short) e2;  mn = t < mn ? t : mn;  s += (int) e2 >> 16;
+  t = s + (int) (short) e3;  mn = t < mn ? t : mn;
+  return mn >= 0;
+}
+
+__device__ __forceinline__ int pk_popc61(u64 b)
+{ return __popc((u32) b) + __popc((u32) (b >> 32) & 0x1fffffffu); }
+
+/* One direction of the wave for the two halves of the wavefront.  `on` = this half runs a task.  Leaves the
+ * band state in the lane registers passed by reference and the bookkeeping in D. */
 
 /* The snake of align.c:832-856 / 1542-1566: slide along the diagonal while a[y] == b[y],
  * stopping at the first mismatch or terminator (4).  A `4` in B is tested first, exactly as
@@ -196,13 +243,25 @@ __device__ __forceinline__ u32 load16(const u32 *pk, u32 pb)          /* bases p
   return __builtin_amdgcn_alignbit(w.y, w.x, pb * 2);                  /* the shift uses bits 0-4: 2*(p & 15) */
 }
 
+/* The two windows of a snake step with both loads in flight together and ONE wait: left to itself the compiler
+   reuses the first load's registers for the second and waits for memory twice per step (seen in the ISA). */
+__device__ __forceinline__ void load16x2(const u32 *apk, u32 pa, const u32 *bpk, u32 pb, u32 *wa, u32 *wb)
+{ typedef u32 v2u __attribute__((ext_vector_type(2)));
+  const u32 offa = (pa >> 2) & ~3u, offb = (pb >> 2) & ~3u;
+  v2u a, b;
+  asm volatile("global_load_dwordx2 %0, %2, %4\n\tglobal_load_dwordx2 %1, %3, %5\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(b) : "v"(offa), "v"(offb), "s"(apk - PK_PAD), "s"(bpk - PK_PAD) : "memory");
+  *wa = __builtin_amdgcn_alignbit(a.y, a.x, pa * 2);
+  *wb = __builtin_amdgcn_alignbit(b.y, b.x, pb * 2);
+}
+
 template <int REV>
 __device__ __forceinline__ SnakeOut snake_pk(const u32 *apk, const u32 *bpk, int ap, int bp, int na, int nb,
                                              int y, int m, u64 b)
 { /* fwd: ap/bp = positions of the next bases to compare; rev: of the first ones below */
   for (;;)
-    { const u32 wa = REV ? load16(apk, (u32) (ap - 15)) : load16(apk, (u32) ap);
-      const u32 wb = REV ? load16(bpk, (u32) (bp - 15)) : load16(bpk, (u32) bp);
+    { u32 wa, wb;
+      load16x2(apk, (u32) (REV ? ap - 15 : ap), bpk, (u32) (REV ? bp - 15 : bp), &wa, &wb);
       const u32 x = wa ^ wb;
       /* equal leading bases of the window, 16 if all are: a guard bit just outside the 32 bits
          keeps the count defined for x == 0 (one find-first-bit plus a min, no compare/select) */
@@ -250,7 +309,7 @@ struct WaveState
 };
 
 /* the band state of one lane of the register path (lane (k & 63) owns diagonal k), for the continuation entry */
-struct LaneRegs { int V, M, HA, HB, NA, NB; u64 T; };
+struct LaneRegs { int V, HA, HB, NA, NB; u64 T; };   /* packed heads, grid-index marks (as in the loop) */
 #define PK_NARROW 24      /* a continuation returns to the packed path when hgh - low + 3 <= PK_NARROW */
 
 #define WS_LOAD(ws)                                                                          \
@@ -297,6 +356,9 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
   const int ave = uni(c.ave), do_reach = uni(c.reach);
   const u32 cell_cap = (u32) uni((int) c.cell_cap);
   const short *score_tab = uni_ptr(c.score), *trim_tab = uni_ptr(c.table);
+  const u32 *trim8 = uni_ptr(c.trim8);
+  const int offa = aoff - PK_BIAS * TS, offb = boff - PK_BIAS * TS;        /* mark = index * TS + off */
+  (void) trim8; (void) offa; (void) offb;
   Cell *const cellbuf = uni_ptr(c.cells);
   GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) cellbuf;          /* one 16-byte store per pebble */
   u32 *const errw = uni_ptr(c.err);
@@ -319,7 +381,7 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
   trim.a = reach.a = mida;  trim.y = reach.y = besty;  trim.d = reach.d = 0;
   trim.ha = reach.ha = 0;   trim.hb = reach.hb = 1;
   /* Per-lane band state of the register path: lane (k & 63) owns diagonal k. */
-  int rV = 0, rM = 0, rHA = 0, rHB = 0, rNA = 0, rNB = 0;
+  int rV = 0, rHA = 0, rHB = 0, rNA = 0, rNB = 0;      /* rHA/rHB: pebble index | grid index of its mark << PK_HBITS; rNA/rNB: grid indexes */
   u64 rT = 0;
 
   if (CONT)
@@ -328,29 +390,30 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
       ncell = (u32) uni((int) ws.ncell);
       trim.a = uni(ws.trim.a);  trim.y = uni(ws.trim.y);  trim.d = uni(ws.trim.d);  trim.ha = uni(ws.trim.ha);  trim.hb = uni(ws.trim.hb);
       reach.a = uni(ws.reach.a);  reach.y = uni(ws.reach.y);  reach.d = uni(ws.reach.d);  reach.ha = uni(ws.reach.ha);  reach.hb = uni(ws.reach.hb);
-      rV = io->V;  rM = io->M;  rT = io->T;  rHA = io->HA;  rHB = io->HB;  rNA = io->NA;  rNB = io->NB;
+      rV = io->V;  rT = io->T;  rHA = io->HA;  rHB = io->HB;  rNA = io->NA;  rNB = io->NB;
     }
   /* wave 0 on the seed diagonal: every lane computes the same values */
   if (!CONT)
-  { int k = diag, y = (mida - k) >> 1, na, nb, ha, hb, ham, hbm, v;
+  { int k = diag, y = (mida - k) >> 1, na, nb, nai, nbi, hai, hbi, ha, hb, v;
     const u8 *a = aseq + k;
     Cell cl;
 
     if (!REV)
-      { na = (((y + k) + (TS - aoff)) / TS - 1) * TS + aoff;
-        nb = ((y + (TS - boff)) / TS - 1) * TS + boff;
-        ham = na;  hbm = nb;
+      { nai = ((y + k) + (TS - aoff)) / TS - 1 + PK_BIAS;
+        nbi = (y + (TS - boff)) / TS - 1 + PK_BIAS;
+        hai = nai;  hbi = nbi;
       }
     else
-      { na = (((y + k) + (TS - aoff) - 1) / TS - 1) * TS + aoff;
-        nb = ((y + (TS - boff) - 1) / TS - 1) * TS + boff;
-        ham = y + k;  hbm = y;
+      { nai = ((y + k) + (TS - aoff) - 1) / TS - 1 + PK_BIAS;
+        nbi = (y + (TS - boff) - 1) / TS - 1 + PK_BIAS;
+        hai = nai + 1;  hbi = nbi + 1;            /* the true start, rounded up to the grid */
       }
     cl.ptr = -1; cl.diag = k; cl.diff = 0;
-    cl.mark = ham;  if (lane == 0) cellbuf[0] = cl;
-    cl.mark = hbm;  if (lane == 0) cellbuf[1] = cl;
+    cl.mark = REV ? y + k : nai * TS + offa;  if (lane == 0) cellbuf[0] = cl;
+    cl.mark = REV ? y : nbi * TS + offb;      if (lane == 0) cellbuf[1] = cl;
     ha = 0;  hb = 1;  ncell = 2;
-    if (!REV) { na += TS; nb += TS; }
+    if (!REV) { nai += 1; nbi += 1; }
+    na = nai * TS + offa;  nb = nbi * TS + offb;
 
     int g0 = 0;
     { const SnakeOut so = SNAKE_AT(k, y, 0, 0ull);
@@ -363,21 +426,21 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
       { GUARD(g0, guard, 2)
         cl.ptr = ha; cl.mark = na;
         if (lane == 0 && ncell < cell_cap) cellbuf[ncell] = cl;
-        ha = (int) ncell++;  ham = na;  na += S * TS;
+        ha = (int) ncell++;  hai = nai;  nai += S;  na += S * TS;
       }
     while (REV ? (y <= nb) : (y >= nb))
       { GUARD(g0, guard, 3)
         cl.ptr = hb; cl.mark = nb;
         if (lane == 0 && ncell < cell_cap) cellbuf[ncell] = cl;
-        hb = (int) ncell++;  hbm = nb;  nb += S * TS;
+        hb = (int) ncell++;  hbi = nbi;  nbi += S;  nb += S * TS;
       }
     if (REV ? (v < besta) : (v > besta))
       { besta = lasta = trim.a = v;
         besty = trim.y = y;
         trim.ha = ha;  trim.hb = hb;
       }
-    rV = v;  rM = HIST_LEN;  rT = HIST_FULL;  rHA = ha;  rHB = hb;  (void) ham;  (void) hbm;
-    rNA = na;  rNB = nb;
+    rV = v;  rT = HIST_FULL;  rHA = ha | (hai << PK_HBITS);  rHB = hb | (hbi << PK_HBITS);
+    rNA = nai;  rNB = nbi;
   }
 
   /***** register path: the band (<= 64 diagonals) lives in VGPRs, neighbour V by DPP rotate, predecessor state by ds_bpermute *****/
@@ -399,19 +462,19 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
           more = 1;                                                                        \
         if (REV ? (low <= aclip) : (hgh >= aclip))                                         \
           { const int l_ = LANE_OF(aclip);                                                 \
-            const int m_ = bcast_i(rM, l_), v_ = bcast_i(rV, l_);                          \
+            const int m_ = bcast_i(pk_popc61(rT), l_), v_ = bcast_i(rV, l_);               \
             if (REV) low = aclip + 1; else hgh = aclip - 1;                                \
             if (reachm <= m_)                                                              \
               { reachm = m_; reach.a = v_; reach.y = (v_ - aclip) / 2; reach.d = dif;      \
-                reach.ha = bcast_i(rHA, l_); reach.hb = bcast_i(rHB, l_); }                \
+                reach.ha = bcast_i(rHA, l_) & PK_HMASK; reach.hb = bcast_i(rHB, l_) & PK_HMASK; } \
           }                                                                                \
         if (REV ? (hgh >= bclip) : (low <= bclip))                                         \
           { const int l_ = LANE_OF(bclip);                                                 \
-            const int m_ = bcast_i(rM, l_), v_ = bcast_i(rV, l_);                          \
+            const int m_ = bcast_i(pk_popc61(rT), l_), v_ = bcast_i(rV, l_);               \
             if (REV) hgh = bclip - 1; else low = bclip + 1;                                \
             if (reachm <= m_)                                                              \
               { reachm = m_; reach.a = v_; reach.y = (v_ - bclip) / 2; reach.d = dif;      \
-                reach.ha = bcast_i(rHA, l_); reach.hb = bcast_i(rHB, l_); }                \
+                reach.ha = bcast_i(rHA, l_) & PK_HMASK; reach.hb = bcast_i(rHB, l_) & PK_HMASK; } \
           }                                                                                \
         aclip = REV ? -BIG : BIG;                                                          \
         bclip = REV ? BIG : -BIG;                                                          \
@@ -465,7 +528,7 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
 
         const int  k   = low + ((lane - low) & 63);
         const bool act = k <= hgh;
-        int  v, y = 0, m, ha, hb, ham, hbm;
+        int  v, y = 0, ha, hb;
         u64  b;
         int  ena = 1, enb = 1;                  /* bases left in A / B where the snake stopped */
 
@@ -488,23 +551,19 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
           /* the predecessor's inherited state through the LDS crossbar (ds_bpermute: no VALU
              cycles, and the wave is bound by VALU issue), one gather per field */
           { const int src = take ? (up ? src_up : src_dn) : src_me;
-            m  = __builtin_amdgcn_ds_bpermute(src, rM);
             ha = __builtin_amdgcn_ds_bpermute(src, rHA);
             hb = __builtin_amdgcn_ds_bpermute(src, rHB);
             const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
             const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
             b = ((u64) thi << 32) | tlo;
           }
-          ham = hbm = 0;            /* the head marks are fetched from the cells only when a mark is crossed */
         }
 
         if (act)
-          { if (b & HIST_TOP)
-              m -= 1;
-            b <<= 1;
+          { b <<= 1;
             y = (v - k) >> 1;
-            { const SnakeOut so = SNAKE_AT(k, y, m, b);
-              y = so.y;  m = so.m;  b = so.b;
+            { const SnakeOut so = SNAKE_AT(k, y, 0, b);
+              y = so.y;  b = so.b;
               ena = so.na;  enb = so.nb;
             }
             v = (y << 1) + k;
@@ -514,59 +573,53 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
         const bool bhit = act && enb == 0, ahit = act && enb != 0 && ena == 0;
         /* (lanes outside the band: only V = edge is ever looked at, by the neighbours) */
 
-        /* pebbles (align.c:859-909): almost never needed, so test once for the whole wave */
-        int na = rNA, nb = rNB;
-        if (wany(act && (REV ? ((y + k <= na) || (y <= nb)) : ((y + k >= na) || (y >= nb)))))
-          { /* marks of the two chain heads (cells may have been written by other lanes of this
-               wave in earlier steps: make those stores visible, read past the L1) */
-            wave_mem_sync();
-            ham = act ? __hip_atomic_load(&cellbuf[ha].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            hbm = act ? __hip_atomic_load(&cellbuf[hb].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            for (;;)
-              { bool need = act && (REV ? (y + k <= na) : (y + k >= na));
-                if (!wany(need))
-                  break;
-                bool dropit = need && (REV ? (ham > na) : (ham < na));
-                u64  mask = wballot(dropit);
-                if (mask)
-                  { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
-                    if (dropit)
-                      { if (idx < cell_cap)
-                          { v4i cl = { ha, k, dif, na };
-                            gcell[idx] = cl;
-                          }
-                        ha = (int) idx;  ham = na;
-                      }
-                    ncell += (u32) __popcll(mask);
-                  }
-                if (need)
-                  na += S * TS;
-              }
-            for (;;)
-              { bool need = act && (REV ? (y <= nb) : (y >= nb));
-                if (!wany(need))
-                  break;
-                bool dropit = need && (REV ? (hbm > nb) : (hbm < nb));
-                u64  mask = wballot(dropit);
-                if (mask)
-                  { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
-                    if (dropit)
-                      { if (idx < cell_cap)
-                          { v4i cl = { hb, k, dif, nb };
-                            gcell[idx] = cl;
-                          }
-                        hb = (int) idx;  hbm = nb;
-                      }
-                    ncell += (u32) __popcll(mask);
-                  }
-                if (need)
-                  nb += S * TS;
-              }
-          }
+        /* pebbles (align.c:859-909): marks as grid indexes, the head's mark in the head: nothing is read back */
+        int nai = rNA, nbi = rNB;
+        { bool needa = act && (REV ? (y + k <= nai * TS + offa) : (y + k >= nai * TS + offa));
+          bool needb = act && (REV ? (y <= nbi * TS + offb) : (y >= nbi * TS + offb));
+          if (wany(needa || needb))
+            { while (wany(needa))
+                { const bool dropit = needa && (REV ? ((int) ((u32) ha >> PK_HBITS) > nai) : ((int) ((u32) ha >> PK_HBITS) < nai));
+                  const u64  mask = wballot(dropit);
+                  if (mask)
+                    { const u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
+                      if (dropit)
+                        { if (idx < cell_cap)
+                            { v4i cl = { ha & PK_HMASK, k, dif, nai * TS + offa };
+                              gcell[idx] = cl;
+                            }
+                          ha = (int) idx | (nai << PK_HBITS);
+                        }
+                      ncell += (u32) __popcll(mask);
+                    }
+                  if (needa)
+                    nai += S;
+                  needa = act && (REV ? (y + k <= nai * TS + offa) : (y + k >= nai * TS + offa));
+                }
+              while (wany(needb))
+                { const bool dropit = needb && (REV ? ((int) ((u32) hb >> PK_HBITS) > nbi) : ((int) ((u32) hb >> PK_HBITS) < nbi));
+                  const u64  mask = wballot(dropit);
+                  if (mask)
+                    { const u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
+                      if (dropit)
+                        { if (idx < cell_cap)
+                            { v4i cl = { hb & PK_HMASK, k, dif, nbi * TS + offb };
+                              gcell[idx] = cl;
+                            }
+                          hb = (int) idx | (nbi << PK_HBITS);
+                        }
+                      ncell += (u32) __popcll(mask);
+                    }
+                  if (needb)
+                    nbi += S;
+                  needb = act && (REV ? (y <= nbi * TS + offb) : (y >= nbi * TS + offb));
+                }
+            }
+        }
 
         /* commit the new wave */
         rV = act ? v : edge;
-        if (act) { rM = m;  rT = b;  rHA = ha;  rHB = hb;  rNA = na;  rNB = nb; }
+        if (act) { rT = b;  rHA = ha;  rHB = hb;  rNA = nai;  rNB = nbi; }
 
         /* sequence ends reached (bit i of the rotated masks = diagonal low + i) */
         { u64 am_ = wballot(ahit), bm_ = wballot(bhit);
@@ -590,10 +643,11 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
           u64 cand = wballot(mine);
           if (cand)
             { int tok = 0;
-              if (mine && m >= ave)
-                { const int t0 = trim_tab[b & TRIM_MASK], t1 = trim_tab[(b >> TRIM_BITS) & TRIM_MASK];
-                  const int s0 = score_tab[b & TRIM_MASK];
-                  tok = ((t0 >= 0) & (t1 + s0 >= 0)) ? 1 : 0;
+              int mok = 0;
+              if (mine)
+                { mok = pk_popc61(b) >= ave;
+                  if (mok)
+                    tok = pk_trim_ok(trim8, b) ? 1 : 0;
                 }
               cand = ROTR(cand, low);
               while (cand)
@@ -604,11 +658,11 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
                   if (REV ? (vl < besta) : (vl > besta))
                     { besta = vl;
                       besty = bcast_i(y, l);
-                      if (bcast_i(m, l) >= ave)
+                      if (bcast_i(mok, l))
                         { lasta = vl;
                           if (bcast_i(tok, l))
                             { trim.a = vl;  trim.y = besty;  trim.d = dif;
-                              trim.ha = bcast_i(ha, l);  trim.hb = bcast_i(hb, l);
+                              trim.ha = bcast_i(ha, l) & PK_HMASK;  trim.hb = bcast_i(hb, l) & PK_HMASK;
                             }
                         }
                     }
@@ -648,18 +702,20 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
 
     /* leaving the register path with work left: spill the band to the memory buffers */
     if (CONT && narrow)
-      { io->V = rV;  io->M = rM;  io->T = rT;  io->HA = rHA;  io->HB = rHB;  io->NA = rNA;  io->NB = rNB; }
+      { io->V = rV;  io->T = rT;  io->HA = rHA;  io->HB = rHB;  io->NA = rNA;  io->NB = rNB; }
     else if (!stopped && more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG)))
       { const int k = low + ((lane - low) & 63);
         wave_mem_sync();
         if (k <= hgh)
           { DState s;
-            s.V = rV; s.M = rM; s.HA = rHA; s.HB = rHB; s.T = rT;
-            s.HAm = __hip_atomic_load(&cellbuf[rHA].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s.HBm = __hip_atomic_load(&cellbuf[rHB].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s.V = rV; s.M = pk_popc61(rT); s.HA = rHA & PK_HMASK; s.HB = rHB & PK_HMASK; s.T = rT;
+            /* (TS and the offsets are re-read here on purpose: using the loop's copies after the loop made the compiler
+               move the whole scalar bookkeeping of the loop into VGPRs -- 64 registers, spills, 3x slower) */
+            s.HAm = (int) ((u32) rHA >> PK_HBITS) * uni(c.ts) + uni(c.aoff - PK_BIAS * c.ts);     /* (a reverse root: rounded up to the grid, which no comparison can tell) */
+            s.HBm = (int) ((u32) rHB >> PK_HBITS) * uni(c.ts) + uni(c.boff - PK_BIAS * c.ts);
             cur[RI(k)] = s;
-            c.NA[RI(k)] = rNA;
-            c.NB[RI(k)] = rNB;
+            c.NA[RI(k)] = rNA * uni(c.ts) + uni(c.aoff - PK_BIAS * c.ts);
+            c.NB[RI(k)] = rNB * uni(c.ts) + uni(c.boff - PK_BIAS * c.ts);
           }
       }
     else
@@ -1304,7 +1360,7 @@ __device__ void diagonal_span(const SlotScratch &s, const LaResult &r, int ts, i
   *hi = uni(hgh);
 }
 
-__device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item)
+__device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const SlotScratch &s, u32 item)
 { const int  lane = lane_id();
   const u64 *keys = a.keys;
   const u32 *vals = a.vals;
@@ -1326,7 +1382,7 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
   c.bpk = a.bblk.pk;  c.b0 = a.bblk.boff[br];
   c.alen = alen;  c.blen = blen;
   c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
-  c.score = a.score;  c.table = a.table;
+  c.score = a.score;  c.table = a.table;  c.trim8 = trimtab;
   c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
   c.koff = blen + 8;  c.ring = a.span;
   c.cells = s.cells;  c.cell_cap = a.cell_cap;
@@ -1494,7 +1550,7 @@ __device__ void process_pair(const ReportArgs &a, const SlotScratch &s, u32 item
  * a k-mer's last base + 1, in [K, alen]) is the distance to the previous equal k-mer of the
  * read, or 0.  Same three bucket passes as process_pair, but the "hits" are the positions of
  * the read itself and the alignment is the read against itself (selfie: minp = 1). */
-__device__ void process_read(const ReportArgs &a, const SlotScratch &s, const int *dist, u32 item)
+__device__ void process_read(const ReportArgs &a, const u32 *trimtab, const SlotScratch &s, const int *dist, u32 item)
 { const int  lane = lane_id();
   const int  K = a.kmer, H = a.hitmin, W = a.binshift;
   const int  mind = (-a.bblk.maxlen) >> W, maxd = a.ablk.maxlen >> W;
@@ -1508,7 +1564,7 @@ __device__ void process_read(const ReportArgs &a, const SlotScratch &s, const in
   c.apk = c.bpk = a.ablk.pk;  c.a0 = c.b0 = a.ablk.boff[ar];
   c.alen = alen;  c.blen = alen;
   c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
-  c.score = a.score;  c.table = a.table;
+  c.score = a.score;  c.table = a.table;  c.trim8 = trimtab;
   c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
   c.koff = alen + 8;  c.ring = a.span;
   c.cells = s.cells;  c.cell_cap = a.cell_cap;
@@ -1616,7 +1672,10 @@ __device__ void process_read(const ReportArgs &a, const SlotScratch &s, const in
 
 __global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
 void tandem_kernel(ReportArgs a, const int *dist)
-{ const int slot = blockIdx.x;
+{ __shared__ u32 trimtab[256];
+  pk_fill_trimtab(trimtab, a.mscore, a.dscore);
+  __syncthreads();
+  const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);
   for (;;)
     { u32 item = 0;
@@ -1625,7 +1684,7 @@ void tandem_kernel(ReportArgs a, const int *dist)
       item = (u32) uni((int) item);
       if (item >= a.nwork)
         break;
-      process_read(a, s, dist, item);
+      process_read(a, trimtab, s, dist, item);
     }
 }
 
@@ -1637,7 +1696,10 @@ void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots
 
 __global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
 void report_kernel(ReportArgs a)
-{ const int slot = blockIdx.x;
+{ __shared__ u32 trimtab[256];
+  pk_fill_trimtab(trimtab, a.mscore, a.dscore);
+  __syncthreads();
+  const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);
 #ifdef DAMAR_PROF
   const unsigned long long pf_k0 = wall_clock64();
@@ -1653,7 +1715,7 @@ void report_kernel(ReportArgs a)
         break;
       if (a.order)
         item = (u32) uni((int) a.order[item]);
-      process_pair(a, s, item);
+      process_pair(a, trimtab, s, item);
     }
 }
 
@@ -1666,7 +1728,10 @@ void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st)
 /* batch Local_Alignment (tests): one wave per task, result always emitted */
 __global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
 void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
-{ const int slot = blockIdx.x;
+{ __shared__ u32 trimtab[256];
+  pk_fill_trimtab(trimtab, a.mscore, a.dscore);
+  __syncthreads();
+  const int slot = blockIdx.x;
   const SlotScratch s = slot_scratch(a, slot);
   for (;;)
     { u32 t = 0;
@@ -1686,7 +1751,7 @@ void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
       c.alen = (int) read_len(a.ablk, tk.aread);
       c.blen = (int) read_len(a.bblk, tk.bread);
       c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
-      c.score = a.score;  c.table = a.table;
+      c.score = a.score;  c.table = a.table;  c.trim8 = trimtab;
       c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
       c.koff = c.blen + 8;  c.ring = a.span;
       c.cells = s.cells;  c.cell_cap = a.cell_cap;

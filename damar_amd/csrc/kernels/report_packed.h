@@ -32,10 +32,6 @@
 #ifndef PK_WINDOWS
 #define PK_WINDOWS 0                      /* 1: the snake reads per-lane sliding windows of the packed bases (8 more VGPRs; measured: no gain) */
 #endif
-#define PK_BIAS   3                       /* grid index = (mark - off) / TS + PK_BIAS, always >= 1 */
-#define PK_HBITS  20                      /* pebble index bits in a packed chain head (cell_cap <= 2^20) */
-#define PK_HMASK  ((1 << PK_HBITS) - 1)
-
 __device__ __forceinline__ u32 hmask(u64 m, int hb) { return (u32) (m >> hb); }           /* this half's 32 bits */
 __device__ __forceinline__ int hget(int v, int hb, int s) { return __builtin_amdgcn_ds_bpermute((hb + s) << 2, v); }
 __device__ __forceinline__ int upd_dpp_shr(int old, int v, int n)      /* lane i <- lane i-n within a row of 16 */
@@ -63,37 +59,6 @@ struct PkDir
   int fin;                  /* the direction was finished on the full-wave path */
 };
 
-/* one 8-column chunk of the trim test: low half = minimum suffix score, high half = total */
-__device__ __forceinline__ void pk_fill_trimtab(u32 *tab, int mscore, int dscore)
-{ for (int x = lane_id(); x < 256; x += 64)
-    { int sc = 0, mn = 0x7fff;
-      for (int i = 0; i < 8; i++)
-        { sc += ((x >> i) & 1) ? mscore : -dscore;           /* bit 0 = newest column */
-          mn = sc < mn ? sc : mn;
-        }
-      tab[x] = ((u32) mn & 0xffffu) | ((u32) sc << 16);
-    }
-}
-
-/* every suffix of the newest 30 columns of b scores >= 0 (align.c:917-919 on TABLE/SCORE) */
-typedef const __attribute__((address_space(3))) u32 *PkLds;
-__device__ __forceinline__ bool pk_trim_ok(const u32 *gtab, u64 b)
-{ const PkLds tab = (PkLds) gtab;            /* (a noinline caller only has a generic pointer: say that it is LDS) */
-  const u32 lo = (u32) b;
-  const u32 e0 = tab[lo & 0xff], e1 = tab[(lo >> 8) & 0xff], e2 = tab[(lo >> 16) & 0xff];
-  const u32 e3 = tab[((lo >> 24) & 0x3f) | 0xc0];           /* 6 columns; older ones padded with matches */
-  int s = (int) e0 >> 16, mn = (int) (short) e0, t;
-  t = s + (int) (short) e1;  mn = t < mn ? t : mn;  s += (int) e1 >> 16;
-  t = s + (int) (short) e2;  mn = t < mn ? t : mn;  s += (int) e2 >> 16;
-  t = s + (int) (short) e3;  mn = t < mn ? t : mn;
-  return mn >= 0;
-}
-
-__device__ __forceinline__ int pk_popc61(u64 b)
-{ return __popc((u32) b) + __popc((u32) (b >> 32) & 0x1fffffffu); }
-
-/* One direction of the wave for the two halves of the wavefront.  `on` = this half runs a task.  Leaves the
- * band state in the lane registers passed by reference and the bookkeeping in D. */
 /* the names the wave code uses for the half's bookkeeping (fields of D, kept in registers) and constants */
 #define PK_NAMES()                                                                                   \
   const int lane = lane_id(), hb = lane & 32, s = lane & 31;                                         \
@@ -553,7 +518,8 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
  * direction there (through wave_mem<REV> if it outgrows the wavefront too).  Called for one half at a time with every
  * lane active; hsel = that half's lane base (0 or 32).  *Dp, *io are per-lane copies: only the half's lanes are changed. */
 template <int REV>
-__device__ __noinline__ void pk_solo(const ReportArgs &a, SlotScratch sc, PkPair p, int hsel, int mida, PkDir *Dp, LaneRegs *io)
+__device__ __noinline__ void pk_solo(const ReportArgs &a, const u32 *trimtab, SlotScratch sc, PkPair p, int hsel, int mida,
+                                     PkDir *Dp, LaneRegs *io)
 { const int lane = lane_id();
   const int KS = REV ? 1 : -1;
   const int TS = a.tspace;
@@ -568,7 +534,7 @@ __device__ __noinline__ void pk_solo(const ReportArgs &a, SlotScratch sc, PkPair
   c.apk = a.ablk.pk;  c.bpk = a.bblk.pk;
   c.alen = bcast_i(p.alen, src);  c.blen = bcast_i(p.blen, src);
   c.ts = TS;  c.ave = a.ave_path;  c.reach = a.reach;
-  c.score = a.score;  c.table = a.table;
+  c.score = a.score;  c.table = a.table;  c.trim8 = trimtab;
   c.minp = bcast_i(p.minp, src);  c.maxp = bcast_i(p.maxp, src);
   c.aoff = bcast_i(p.aoff, src);  c.boff = bcast_i(p.boff, src);
   c.st0 = PK_PTR_OF(DState *, sc.st0);  c.st1 = PK_PTR_OF(DState *, sc.st1);
@@ -588,25 +554,21 @@ __device__ __noinline__ void pk_solo(const ReportArgs &a, SlotScratch sc, PkPair
   ws.reach.a = bcast_i(Dp->reach.a, src);  ws.reach.y = bcast_i(Dp->reach.y, src);  ws.reach.d = bcast_i(Dp->reach.d, src);
   ws.reach.ha = bcast_i(Dp->reach.ha, src);  ws.reach.hb = bcast_i(Dp->reach.hb, src);
   ws.stopped = 0;  ws.bad = 0;  ws.narrow = 0;
-  const int offa = c.aoff - PK_BIAS * TS, offb = c.boff - PK_BIAS * TS;
-
-  /* the half's band into the 64-lane layout, marks as values again */
+  /* the half's band into the 64-lane layout (lane (k & 63) owns diagonal k) */
   LaneRegs r;
   { const int kbase = bcast_i(Dp->kbase, src);
     const int k = ws.low + ((lane - ws.low) & 63);
     const bool in = k <= ws.hgh;
     const int sl = (hsel + (in ? KS * (k - kbase) : 0)) << 2;
-    const int nav = io->NA * TS + offa, nbv = io->NB * TS + offb;
     r.V  = __builtin_amdgcn_ds_bpermute(sl, io->V);
-    r.HA = __builtin_amdgcn_ds_bpermute(sl, io->HA) & PK_HMASK;
-    r.HB = __builtin_amdgcn_ds_bpermute(sl, io->HB) & PK_HMASK;
-    r.NA = __builtin_amdgcn_ds_bpermute(sl, nav);
-    r.NB = __builtin_amdgcn_ds_bpermute(sl, nbv);
+    r.HA = __builtin_amdgcn_ds_bpermute(sl, io->HA);
+    r.HB = __builtin_amdgcn_ds_bpermute(sl, io->HB);
+    r.NA = __builtin_amdgcn_ds_bpermute(sl, io->NA);
+    r.NB = __builtin_amdgcn_ds_bpermute(sl, io->NB);
     { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) io->T);
       const u32 th = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) (io->T >> 32));
       r.T = ((u64) th << 32) | tl;
     }
-    r.M = pk_popc61(r.T);
     if (!in)
       r.V = edge;
   }
@@ -619,19 +581,9 @@ __device__ __noinline__ void pk_solo(const ReportArgs &a, SlotScratch sc, PkPair
       const int k = kbase + KS * (lane & 31);
       const bool in = k >= ws.low && k <= ws.hgh;
       const int sl = (k & 63) << 2;
-      int ha = r.HA, hb_ = r.HB, hai = 0, hbi = 0;
-      wave_mem_sync();
-      if (r.V != edge || true)            /* the mark of each chain head, from its cell */
-        { const int ham = __hip_atomic_load(&c.cells[ha].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int hbm = __hip_atomic_load(&c.cells[hb_].mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          hai = (ham - offa + TS - 1) / TS;          /* exact on the grid; a reverse root (off the grid) rounds up */
-          hbi = (hbm - offb + TS - 1) / TS;
-        }
-      const int nai = (r.NA - offa) / TS, nbi = (r.NB - offb) / TS;
-      const int pha = ha | (hai << PK_HBITS), phb = hb_ | (hbi << PK_HBITS);
       const int nV = __builtin_amdgcn_ds_bpermute(sl, r.V);
-      const int nHA = __builtin_amdgcn_ds_bpermute(sl, pha), nHB = __builtin_amdgcn_ds_bpermute(sl, phb);
-      const int nNA = __builtin_amdgcn_ds_bpermute(sl, nai), nNB = __builtin_amdgcn_ds_bpermute(sl, nbi);
+      const int nHA = __builtin_amdgcn_ds_bpermute(sl, r.HA), nHB = __builtin_amdgcn_ds_bpermute(sl, r.HB);
+      const int nNA = __builtin_amdgcn_ds_bpermute(sl, r.NA), nNB = __builtin_amdgcn_ds_bpermute(sl, r.NB);
       const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) r.T);
       const u32 th = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) (r.T >> 32));
       if ((lane & 32) == hsel)
@@ -837,8 +789,8 @@ __device__ __noinline__ void pk_pass(const ReportArgs &a, const u32 *trimtab, Sl
         if ((ov >> h) & 1)
           { PkDir Dc = D;                     /* copies: what a noinline callee may write must not pin the loop's state to memory */
             LaneRegs io;
-            io.V = rV;  io.M = 0;  io.HA = rHA;  io.HB = rHB;  io.NA = rNA;  io.NB = rNB;  io.T = rT;
-            pk_solo<REV>(a, sc, p, h, bcast_i(mida, h), &Dc, &io);
+            io.V = rV;  io.HA = rHA;  io.HB = rHB;  io.NA = rNA;  io.NB = rNB;  io.T = rT;
+            pk_solo<REV>(a, trimtab, sc, p, h, bcast_i(mida, h), &Dc, &io);
             D = Dc;
             rV = io.V;  rHA = io.HA;  rHB = io.HB;  rNA = io.NA;  rNB = io.NB;  rT = io.T;
           }

@@ -650,8 +650,21 @@ static int G_ring = 0;
    (65536 cells x 8192 slots) cost every process 0.25 - 0.8 s in hipMalloc. */
 #define DEFAULT_CELLS (1u << 14)
 
+/* the pebble pool of a slot after an overflow: a chain head holds 18 bits of pebble index (report.hip PK_HBITS) */
+static u32 grow_cells(u32 cell_cap)
+{ if (cell_cap >= DAMAR_MAX_CELLS)
+    { fprintf(stderr, "damar: FATAL: an alignment needs more than %u trace pebbles; use a larger trace spacing (-s)\n", DAMAR_MAX_CELLS);
+      die();
+    }
+  return std::min(cell_cap * 4, DAMAR_MAX_CELLS);
+}
+
 static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 cell_cap)
-{ if (G_last_d2h != NULL)        /* whatever is launched next overwrites the record buffers */
+{ if (tspace <= 0 || std::max(amax, bmax) / tspace + 8 > DAMAR_MAX_MARKS)      /* 14 bits of trace-grid index in a chain head */
+    { fprintf(stderr, "damar: FATAL: reads of %d bases need a trace spacing (-s) of at least %d\n", std::max(amax, bmax),
+              std::max(amax, bmax) / (DAMAR_MAX_MARKS - 8) + 1);
+      die();
+    } if (G_last_d2h != NULL)        /* whatever is launched next overwrites the record buffers */
     { HIP_CHECK(hipStreamWaitEvent(G_st, G_last_d2h, 0));
       G_last_d2h = NULL;
     }
@@ -797,8 +810,6 @@ static bool use_packed(const ReportArgs *ra, int amax, int bmax)
       want = e ? atoi(e) : 0;
     }
   if (!want || (RS.nslots & 1) || ra->tspace <= 0)
-    return false;
-  if (std::max(amax, bmax) / ra->tspace + 8 > DAMAR_PACKED_MAX_MARKS || ra->cell_cap > DAMAR_PACKED_MAX_CELLS)
     return false;
   if (ra->mscore * 8 > 32000 || ra->dscore * 8 > 32000)
     return false;
@@ -1489,7 +1500,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
             { fprintf(stderr, "damar: FATAL: report kernel keeps overflowing its buffers (flags %u)\n", hc[3]);
               die();
             }
-          if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
+          if (hc[3] & DAMAR_ERR_CELLS) cell_cap = grow_cells(cell_cap);
           if (hc[3] & DAMAR_ERR_WIDE)  G_ring *= 4;
           if (hc[3] & DAMAR_ERR_RECS)  rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
           if (hc[3] & DAMAR_ERR_TPOOL)
@@ -1641,7 +1652,7 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
           { fprintf(stderr, "damar: FATAL: tandem report kernel failed (flags %u, where=%u)\n", hc[3], hc[6]);
             die();
           }
-        if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
+        if (hc[3] & DAMAR_ERR_CELLS) cell_cap = grow_cells(cell_cap);
         if (hc[3] & DAMAR_ERR_WIDE)  G_ring *= 4;
         if (hc[3] & DAMAR_ERR_RECS)  rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
         if (hc[3] & DAMAR_ERR_TPOOL) tp_cap  = std::max(2 * tp_cap, hc[2] + 65536);
@@ -1751,7 +1762,7 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
         { fprintf(stderr, "damar: FATAL: batch Local_Alignment failed (flags %u, where=%u)\n", hc[3], hc[6]);
           die();
         }
-      if (hc[3] & DAMAR_ERR_CELLS) cell_cap *= 4;
+      if (hc[3] & DAMAR_ERR_CELLS) cell_cap = grow_cells(cell_cap);
       if (hc[3] & DAMAR_ERR_WIDE)  G_ring *= 4;
       if (hc[3] & DAMAR_ERR_TPOOL)
         { HIP_CHECK(hipFree(dt));
