@@ -447,6 +447,10 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
   bool stopped = false, narrow = false;
   u32  err_flags = 0, err_empty = 0;          /* wave-uniform, reported once after the loop */
   int  bad = 0;
+  if (!CONT && ncell > cell_cap)              /* a seed diagonal that slides over more marks than the pool holds */
+    { err_flags |= DAMAR_ERR_CELLS;
+      more = 0;  ncell = 2;  bad = 1;
+    }
 #ifdef DAMAR_PROF
   int pf_first16 = -1, pf_first32 = -1;
 #endif

@@ -56,7 +56,7 @@ struct PkDir
   Tip trim, reach;
   int ovf;                  /* the band outgrew the half: continue on the full-wave path */
   int bad;
-  int fin;                  /* the direction was finished on the full-wave path */
+  int fin;                  /* the direction is over for this half (ended, failed, or finished on the full-wave path) */
 };
 
 /* the names the wave code uses for the half's bookkeeping (fields of D, kept in registers) and constants */
@@ -70,18 +70,22 @@ struct PkDir
   GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) uni_ptr((Cell *) a.cells);                          \
   const int cell_cap = (int) uni((int) a.cell_cap);                                                  \
   u32 *const errw = uni_ptr(&a.counters[3]);                                                         \
-  const u8 *aseq = abase + p.a0 + (REV ? -1 : 0), *bseq = bbase + p.b0 + (REV ? -1 : 0);            \
-  const int va0 = p.a0 + 16 * PK_PAD, vb0 = p.b0 + 16 * PK_PAD, valen = p.alen, vblen = p.blen;      \
   const int offa = p.aoff - PK_BIAS * TS, offb = p.boff - PK_BIAS * TS;  /* mark = index * TS + off */ \
-  const int steplimit = p.alen + p.blen + 64;                                                        \
-  const int guard = 4 * (p.alen + p.blen) + 1024;                                                    \
   int &low = D.low, &hgh = D.hgh, &dif = D.dif, &besta = D.besta, &besty = D.besty, &lasta = D.lasta; \
   int &more = D.more, &reachm = D.reachm, &aclip = D.aclip, &bclip = D.bclip, &kbase = D.kbase;      \
   int &ncell = D.ncell, &ovf = D.ovf, &bad = D.bad;                                                  \
   Tip &trim = D.trim, &reach = D.reach;                                                              \
   (void) lane; (void) hb; (void) s; (void) KS; (void) S; (void) edge; (void) TS; (void) ave; (void) apk; (void) bpk; \
-  (void) gcell; (void) cell_cap; (void) errw; (void) aseq; (void) bseq; (void) va0; (void) vb0; (void) valen;        \
-  (void) vblen; (void) offa; (void) offb; (void) steplimit; (void) guard;
+  (void) gcell; (void) cell_cap; (void) errw; (void) offa; (void) offb; (void) abase; (void) bbase;
+/* derived on use, so that they do not sit in registers across the wave loop */
+#define aseq      (abase + p.a0 + (REV ? -1 : 0))
+#define bseq      (bbase + p.b0 + (REV ? -1 : 0))
+#define va0       (p.a0 + 16 * PK_PAD)
+#define vb0       (p.b0 + 16 * PK_PAD)
+#define valen     (p.alen)
+#define vblen     (p.blen)
+#define steplimit (p.alen + p.blen + 64)
+#define guard     (4 * (p.alen + p.blen) + 1024)
 
 /* Wave 0 on the seed diagonal (align.c:491-626 / 1203-1340) for the halves with `on`: every lane of the half
  * computes the same values.  Sets up D and the lane registers of the direction. */
@@ -157,13 +161,17 @@ __device__ __forceinline__ void pk_init(const ReportArgs &a, bool on, const PkPa
           rHA = ha | (hai << PK_HBITS);  rHB = hb_ | (hbi << PK_HBITS);
         }
       rNA = nai;  rNB = nbi;
+      if (ncell > cell_cap)              /* a seed diagonal that slides over more marks than the pool holds */
+        { if (s == 0) atomicOr(errw, DAMAR_ERR_CELLS);
+          more = 0;  ncell = 2;  bad = 1;  D.fin = 1;
+        }
     }
 }
 
 /* The wave steps of one direction for the two halves of the wavefront (align.c:667-999 / 1378-1697), until
  * every half has finished the direction or outgrown its 32 lanes (D.ovf). */
 template <int REV>
-__device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab, bool on, const PkPair &p, u32 cbase, PkDir &D,
+__device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab, bool on, bool first, const PkPair &p, u32 cbase, PkDir &D,
                                         int &rV, u64 &rT, int &rHA, int &rHB, int &rNA, int &rNB)
 { PK_NAMES()
   u32 err_flags = 0, err_empty = 0;
@@ -212,17 +220,19 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
         }                                                                                              \
     }
 
-  PK_CLIP()
+  if (first)                 /* (a re-entry after the other half's excursion resumes behind the clipping of its last step) */
+    { PK_CLIP() }
 
 #ifdef DAMAR_PROF
   unsigned long long pf_iters = 0, pf_half = 0;
 #endif
   for (;;)
-    { on = on && more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG));
+    { if (on && !(more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG))))
+        { D.fin = 1;  on = false; }           /* this direction is over for the half: never stepped again */
       if (on && hgh < low)
-        { err_empty += 1;  on = false; }
+        { err_empty += 1;  D.fin = 1;  on = false; }
       if (on && dif > steplimit)
-        { err_flags |= DAMAR_ERR_BAND;  on = false; }
+        { err_flags |= DAMAR_ERR_BAND;  D.fin = 1;  on = false; }
       if (on && hgh - low + 3 > 32)                 /* would not fit the half: continue on the full-wave path */
         { ovf = 1;  on = false; }
       if (!wany(on))
@@ -483,7 +493,7 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
       }
       if (on && ncell > cell_cap)
         { err_flags |= DAMAR_ERR_CELLS;
-          more = 0;  ncell = 2;  bad = 1;  on = false;
+          more = 0;  ncell = 2;  bad = 1;  D.fin = 1;  on = false;
         }
 
       PK_CLIP()
@@ -511,6 +521,15 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
       if (err_empty) atomicAdd(errw + 2, err_empty);
     }
 }
+
+#undef aseq
+#undef bseq
+#undef va0
+#undef vb0
+#undef valen
+#undef vblen
+#undef steplimit
+#undef guard
 
 /* A half whose band outgrew its 32 lanes borrows the whole wavefront: the band goes to the one-alignment-per-wavefront
  * register path (wave_reg_cont<REV>: lane (k & 63) owns diagonal k, marks as values) and comes back as soon as it
@@ -777,8 +796,8 @@ __device__ __noinline__ void pk_pass(const ReportArgs &a, const u32 *trimtab, Sl
   unsigned long long pf_solo = 0;
 #endif
   pk_init<REV>(a, task, p, cbase, diag, mida, D, rV, rT, rHA, rHB, rNA, rNB);
-  for (;;)
-    { pk_loop<REV>(a, trimtab, task, p, cbase, D, rV, rT, rHA, rHB, rNA, rNB);
+  for (bool first = true; ; first = false)
+    { pk_loop<REV>(a, trimtab, task, first, p, cbase, D, rV, rT, rHA, rHB, rNA, rNB);
       const u64 ov = wballot(task && D.ovf);
       if (!ov)
         break;
@@ -869,7 +888,8 @@ __device__ __forceinline__ void pk_emit(const ReportArgs &a, const SlotScratch &
 enum { PK_ITEM = 0, PK_PANEL, PK_FIRE, PK_DONE };
 
 #ifndef PK_WAVES
-#define PK_WAVES 4                      /* resident wavefronts per SIMD the packed kernel is compiled for (VGPR budget 512 / PK_WAVES) */
+#define PK_WAVES 5                      /* resident wavefronts per SIMD the packed kernel is compiled for (VGPR budget 512 / PK_WAVES):
+                                           measured report ms per config-2 step: 4 -> 356, 5 -> 347, 6 -> 676 (the wave loop spills) */
 #endif
 int damar_report2_waves_per_simd(void) { return PK_WAVES; }
 

@@ -798,16 +798,16 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
 }
 
 
-/* Two read pairs per wavefront (kernels/report_packed.h) with DAMAR_PACKED=1, unless the job is outside what its
- * packed chain heads can hold (12 bits of trace-grid index, 20 bits of pebble index).  Measured on config 2 (profiles/
- * r02_packed_*): identical output, 385 ms of report kernel per step against 357 ms for one pair per wavefront -- the
- * packed loop needs 128 VGPRs (4 wavefronts per SIMD instead of 8) and a wave step of one wavefront takes ~4800 cycles
- * either way -- so one pair per wavefront stays the default. */
+/* Two read pairs per wavefront (kernels/report_packed.h) unless DAMAR_PACKED=0.  Measured on config 2 (profiles/r02_*):
+ * identical output, 347 ms of report kernel per step against 366 ms for one pair per wavefront (357 ms at the end of
+ * round 1).  Both kernels are bound by how long ONE wavefront takes for a wave step (~4500-6000 cycles of serial issue,
+ * scalar unit 76 % busy in the one-pair kernel), not by HBM; the packed one advances two alignments per such step but
+ * fits 5 instead of 8 wavefronts per SIMD (96 VGPRs). */
 static bool use_packed(const ReportArgs *ra, int amax, int bmax)
 { static int want = -1;
   if (want < 0)
     { const char *e = getenv("DAMAR_PACKED");
-      want = e ? atoi(e) : 0;
+      want = e ? atoi(e) : 1;
     }
   if (!want || (RS.nslots & 1) || ra->tspace <= 0)
     return false;

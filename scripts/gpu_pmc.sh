@@ -20,7 +20,7 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0][:40]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         n[(k, r["Counter_Name"])] += 1
-for k in sorted(acc, key=lambda k: -sum(acc[k].values()))[:6]:
+for k in sorted(acc, key=lambda k: -sum(acc[k].values()))[:9]:
     print("  %-40s" % k, {c: "%.4g (%d launches)" % (v, n[(k, c)]) for c, v in acc[k].items()})
 PY
 done

@@ -1,19 +1,28 @@
 #!/bin/bash
-# Everything profiles/ records for a round, in one GPU call: rocprofv3 kernel stats of one bench
-# step, SQ instruction / activity counters and TCC traffic of report_kernel (separate --pmc
-# passes), and the plain bench line with the CPU baseline.  Run from the repo root on the GPU box.
+# Everything profiles/ records for a round, in one GPU call (run from the repo root on the GPU box):
+#   1. rocprofv3 --kernel-trace --stats of one bench step                      -> gpurun_out/round/stats
+#   2. SQ instruction / activity / LDS counters, separate --pmc passes         -> pmc_summary.txt
+#   3. TCC FETCH_SIZE / WRITE_SIZE of the report kernel, separate passes        -> traffic_summary.txt
+#   4. the issue-rate calibration (tools/roofcal.hip) under the same counters   -> roofcal*.txt
+#   5. the plain bench line (with cpu_baseline, end_to_end)                     -> bench.json
+# usage: bash scripts/gpu_profile_round.sh [packed]
 set -e
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/round
 rm -rf $OUT; mkdir -p $OUT
+if [ "$1" = packed ]; then export DAMAR_PACKED=1; fi
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-trace > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-trace --no-e2e > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats done"
 cd $ROOT
-bash scripts/gpu_pmc.sh "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" > $OUT/pmc_summary.txt 2>&1
+bash scripts/gpu_pmc.sh "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVES" \
+                        "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" \
+                        "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS GRBM_GUI_ACTIVE" > $OUT/pmc_summary.txt 2>&1
 echo "pmc done"
 bash scripts/gpu_traffic.sh > $OUT/traffic_summary.txt 2>&1
 echo "traffic done"
-timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+bash scripts/gpu_roofcal.sh > $OUT/roofcal_run.txt 2>&1 || true
+echo "roofcal done"
+timeout -k 10 500 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
-tail -c 600 $OUT/bench.json
+tail -c 900 $OUT/bench.json
