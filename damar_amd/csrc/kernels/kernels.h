@@ -50,7 +50,7 @@ void damar_launch_compact_pairs(const void *k, int wide, const u32 *v, const u32
 
 /* datander: distance to the previous equal k-mer of the same read, scattered back to position
  * order (dist[k-mer index]); scrub/tandem.c:556-589 + the (read,rpos) re-sort of :1298 */
-void damar_launch_tandem_links(const DevBlock *blk, int kmer, const u32 *codes, const u32 *pos, u32 n,
+void damar_launch_tandem_links(const DevBlock *blk, int kmer, const void *codes, int wide, const u32 *pos, u32 n,
                                int *dist, hipStream_t st);
 
 /* seed_merge.hip */

@@ -252,8 +252,9 @@ void damar_launch_compact_pairs(const void *k, int wide, const u32 *v, const u32
  * the code of sorted entry 0, so that one keeps its k-mer code.  The result is stored at the
  * k-mer's index in position order, which is what the reference's re-sort on (read, rpos)
  * produces (every position owns exactly one k-mer). */
+template <typename CodeT>
 __global__ __launch_bounds__(256)
-void tandem_links(DevBlock blk, int kmer, const u32 *__restrict__ codes, const u32 *__restrict__ pos, u32 n,
+void tandem_links(DevBlock blk, int kmer, const CodeT *__restrict__ codes, const u32 *__restrict__ pos, u32 n,
                   int *__restrict__ dist)
 { u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n)
@@ -261,7 +262,7 @@ void tandem_links(DevBlock blk, int kmer, const u32 *__restrict__ codes, const u
   const u32 p = pos[i], r = read_of_pos(blk, p);
   int d = 0;
   if (i == 0)
-    d = (int) codes[0];
+    d = (int) codes[0];             /* tandem.c:571-573 leaves the first entry's (truncated) code in place */
   else if (codes[i] == codes[i - 1])
     { const u32 q = pos[i - 1];
       if (q >= blk.boff[r])                 /* same read: entries of a run are in position order */
@@ -270,11 +271,14 @@ void tandem_links(DevBlock blk, int kmer, const u32 *__restrict__ codes, const u
   dist[p - (r + 1) * (u32) kmer + 1] = d;
 }
 
-void damar_launch_tandem_links(const DevBlock *blk, int kmer, const u32 *codes, const u32 *pos, u32 n,
+void damar_launch_tandem_links(const DevBlock *blk, int kmer, const void *codes, int wide, const u32 *pos, u32 n,
                                int *dist, hipStream_t st)
 { if (n == 0)
     return;
-  hipLaunchKernelGGL(tandem_links, dim3((n + 255) / 256), dim3(256), 0, st, *blk, kmer, codes, pos, n, dist);
+  if (wide)       /* k > 16: 64-bit codes, as scrub/tandem.c:132-149 */
+    hipLaunchKernelGGL(tandem_links<u64>, dim3((n + 255) / 256), dim3(256), 0, st, *blk, kmer, (const u64 *) codes, pos, n, dist);
+  else
+    hipLaunchKernelGGL(tandem_links<u32>, dim3((n + 255) / 256), dim3(256), 0, st, *blk, kmer, (const u32 *) codes, pos, n, dist);
 }
 
 /* 2-bit packed copy of a block's bases for the alignment wave (16 bases per dword) */

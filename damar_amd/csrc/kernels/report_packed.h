@@ -174,7 +174,6 @@ template <int REV>
 __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab, bool on, bool first, const PkPair &p, u32 cbase, PkDir &D,
                                         int &rV, u64 &rT, int &rHA, int &rHB, int &rNA, int &rNB)
 { PK_NAMES()
-  u32 err_flags = 0, err_empty = 0;
   on = on && !D.fin && !ovf;
 #if PK_WINDOWS
   typedef u32 v2u __attribute__((ext_vector_type(2)));
@@ -230,9 +229,9 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
     { if (on && !(more && (REV ? (lasta <= besta + MAX_TRIM_LAG) : (lasta >= besta - MAX_TRIM_LAG))))
         { D.fin = 1;  on = false; }           /* this direction is over for the half: never stepped again */
       if (on && hgh < low)
-        { err_empty += 1;  D.fin = 1;  on = false; }
+        { if (s == 0) atomicAdd(errw + 2, 1u);  D.fin = 1;  on = false; }
       if (on && dif > steplimit)
-        { err_flags |= DAMAR_ERR_BAND;  D.fin = 1;  on = false; }
+        { if (s == 0) atomicOr(errw, DAMAR_ERR_BAND);  D.fin = 1;  on = false; }
       if (on && hgh - low + 3 > 32)                 /* would not fit the half: continue on the full-wave path */
         { ovf = 1;  on = false; }
       if (!wany(on))
@@ -492,7 +491,7 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
           }
       }
       if (on && ncell > cell_cap)
-        { err_flags |= DAMAR_ERR_CELLS;
+        { if (s == 0) atomicOr(errw, DAMAR_ERR_CELLS);
           more = 0;  ncell = 2;  bad = 1;  D.fin = 1;  on = false;
         }
 
@@ -516,10 +515,6 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
 #ifdef DAMAR_PROF
   PROF_ADD(26, pf_iters);  PROF_ADD(27, pf_half);  PROF_ADD(28, __popcll(wballot(ovf != 0)) >> 5);  PROF_ADD(29, 1);
 #endif
-  if ((err_flags | err_empty) && s == 0)
-    { if (err_flags) atomicOr(errw, err_flags);
-      if (err_empty) atomicAdd(errw + 2, err_empty);
-    }
 }
 
 #undef aseq
@@ -888,8 +883,9 @@ __device__ __forceinline__ void pk_emit(const ReportArgs &a, const SlotScratch &
 enum { PK_ITEM = 0, PK_PANEL, PK_FIRE, PK_DONE };
 
 #ifndef PK_WAVES
-#define PK_WAVES 5                      /* resident wavefronts per SIMD the packed kernel is compiled for (VGPR budget 512 / PK_WAVES):
-                                           measured report ms per config-2 step: 4 -> 356, 5 -> 347, 6 -> 676 (the wave loop spills) */
+#define PK_WAVES 4                      /* resident wavefronts per SIMD the packed kernel is compiled for (VGPR budget 512 / PK_WAVES).
+                                           Measured report ms per config-2 step: 4 -> 356; 5 -> 347 when the wave loop happens to stay free of
+                                           spills, 845 when it does not (18 scratch accesses per step after an unrelated edit); 6 -> 676 */
 #endif
 int damar_report2_waves_per_simd(void) { return PK_WAVES; }
 

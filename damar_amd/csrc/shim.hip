@@ -799,10 +799,10 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
 
 
 /* Two read pairs per wavefront (kernels/report_packed.h) unless DAMAR_PACKED=0.  Measured on config 2 (profiles/r02_*):
- * identical output, 347 ms of report kernel per step against 366 ms for one pair per wavefront (357 ms at the end of
- * round 1).  Both kernels are bound by how long ONE wavefront takes for a wave step (~4500-6000 cycles of serial issue,
- * scalar unit 76 % busy in the one-pair kernel), not by HBM; the packed one advances two alignments per such step but
- * fits 5 instead of 8 wavefronts per SIMD (96 VGPRs). */
+ * identical output, 356 ms of report kernel per step against 366 ms for one pair per wavefront (357 ms at the end of
+ * round 1).  Both kernels are bound by how long ONE wavefront takes for a wave step (~4500-6000 cycles of serial issue;
+ * the scalar unit is 86 % busy in the one-pair kernel), not by HBM; the packed one advances two alignments per such
+ * step but fits 4 instead of 8 wavefronts per SIMD (its wave loop needs ~100 VGPRs). */
 static bool use_packed(const ReportArgs *ra, int amax, int bmax)
 { static int want = -1;
   if (want < 0)
@@ -1617,11 +1617,7 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
   const int ts = Trace_Spacing(spec);
   int *dist = (int *) dmalloc(sizeof(int) * (size_t) n);
   tick(0);
-  if (ix->wide)
-    { fprintf(stderr, "damar: FATAL: datander -k%d: tandem seeds are built for k <= 16\n", T_kmer);
-      die();
-    }
-  damar_launch_tandem_links(&blk->d, T_kmer, (const u32 *) ix->codes, ix->pos, (u32) n, dist, G_st);
+  damar_launch_tandem_links(&blk->d, T_kmer, ix->codes, ix->wide, ix->pos, (u32) n, dist, G_st);
   tick(1);
 
   std::vector<LaRecord> recs;

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""profiles/rNN_counters.json from one run of scripts/gpu_profile_round.sh (gpurun_out/round/): what bench.py cannot
+measure from inside its own process -- the TCC traffic of the dominant kernel per launch (FETCH_SIZE doubled as the
+gfx950 note of MI355X_MICROARCH.md prescribes for wide reads, an upper bound for this kernel's narrow ones; WRITE_SIZE
+as is) and its instruction issue as a share of the CALIBRATED peaks of tools/roofcal.hip (profiles/r02_roofcal.txt:
+0.456 VALU wave-instructions per cycle per SIMD and 0.953 SALU instructions per cycle per CU at 8 waves per SIMD,
+nominal 2.4 GHz).
+
+  python scripts/make_counters_json.py gpurun_out/round profiles/r02_counters.json [active_lane_frac]
+"""
+import csv
+import json
+import re
+import sys
+
+VALU_PEAK = 0.456 * 2.4e9 * 1024       # wave-instructions per second, whole chip (roofcal, 8 waves/SIMD)
+SALU_PEAK = 0.953 * 2.4e9 * 256        # instructions per second, whole chip
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    lanes = float(sys.argv[3]) if len(sys.argv) > 3 else None
+    stats = list(csv.DictReader(open(src + "/stats/r_kernel_stats.csv")))
+    dom = max(stats, key=lambda r: float(r["TotalDurationNs"]))
+    name = dom["Name"].split("(")[0]
+    dur_s = float(dom["TotalDurationNs"]) * 1e-9
+    calls = int(dom["Calls"])
+    pmc = open(src + "/pmc_summary.txt").read()
+    m = re.search(r"^\s+%s\s+(\{.*\})$" % re.escape(name), pmc, re.M)
+    cnt = {}
+    for mm in re.finditer(r"^\s+%s\s+(\{.*\})$" % re.escape(name), pmc, re.M):
+        for k, v in eval(mm.group(1)).items():
+            cnt[k] = float(v.split()[0])
+    tr = {}
+    for ln in open(src + "/traffic_summary.txt"):
+        mm = re.match(r"\('(\w+)', '(\w+)'\) ([\d.e+]+) (\d+) launches", ln)
+        if mm and mm.group(1) == name:
+            tr[mm.group(2)] = float(mm.group(3)) * 1024.      # KB -> bytes
+    out = {"kernel": "report_kernel" if name.startswith("report") else name, "kernel_symbol": name,
+           "launches": calls, "avg_launch_ms": 1e3 * dur_s / calls,
+           "bytes_per_launch": (2 * tr["FETCH_SIZE"] + tr["WRITE_SIZE"]) / calls if "FETCH_SIZE" in tr and "WRITE_SIZE" in tr else None,
+           "fetch_bytes_per_launch_x2": 2 * tr.get("FETCH_SIZE", 0) / calls, "write_bytes_per_launch": tr.get("WRITE_SIZE", 0) / calls,
+           "valu_frac": cnt["SQ_INSTS_VALU"] / dur_s / VALU_PEAK if "SQ_INSTS_VALU" in cnt else None,
+           "salu_frac": cnt["SQ_INSTS_SALU"] / dur_s / SALU_PEAK if "SQ_INSTS_SALU" in cnt else None,
+           "active_lane_frac": lanes,
+           "lds_bank_conflict_frac": cnt["SQ_LDS_BANK_CONFLICT"] / cnt["SQ_LDS_IDX_ACTIVE"] if cnt.get("SQ_LDS_IDX_ACTIVE") else None,
+           "wave_cycles_share": {k: cnt[k] / cnt["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")
+                                 if k in cnt and cnt.get("SQ_WAVE_CYCLES")},
+           "counters_per_step": cnt,
+           "source": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu "
+                     "--no-trace --no-e2e` (scripts/gpu_profile_round.sh); issue peaks from tools/roofcal.hip (profiles/r02_roofcal.txt)"}
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps({k: out[k] for k in ("kernel_symbol", "avg_launch_ms", "bytes_per_launch", "valu_frac", "salu_frac",
+                                          "active_lane_frac", "lds_bank_conflict_frac", "wave_cycles_share")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,8 @@ CASES = {
     "tan_tandem": dict(db="tandem", tool="datander", opts=["-j4"], plan=[("1", [])]),
     "tan_k10":    dict(db="tandem", tool="datander", opts=["-k10", "-w3", "-h28", "-l400", "-j2"], plan=[("1", [])]),
     "tan_plain":  dict(db="tiny2", tool="datander", opts=["-j4"], plan=[("1", []), ("2", [])]),
+    # k > 16: 64-bit k-mer codes (scrub/tandem.c:132-149)
+    "tan_k18":    dict(db="tandem", tool="datander", opts=["-k18", "-w4", "-h40", "-l400", "-j2"], plan=[("1", [])]),
 }
 
 
