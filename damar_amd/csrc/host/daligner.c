@@ -439,12 +439,58 @@ typedef struct
   int      ilen[2];
   long     used;                    /* LRU stamp */
   int      busy;                    /* named by the pair being computed */
+  int      ready;                   /* 0 while the reader thread is still preparing it */
 } PBlock;
 
-static PBlock *PB;
+static PBlock *PB;                  /* fixed capacity (PB_max + 8): entries never move while the reader thread fills them */
 static int     PB_n, PB_cap, PB_max = 64;
 static long    PB_clock;
 static int     PB_builds;
+static pthread_mutex_t PB_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t  PB_cv = PTHREAD_COND_INITIALIZER;
+static int     PB_ahead;            /* entries [0, PB_ahead) are prepared by the reader thread, in this order */
+static Opts    PB_opts;
+
+/* read, mask, check, reverse-complement and (on the reader thread) upload one block, both strands */
+static void pblock_load(PBlock *b, const Opts *o, int background)
+{ double t0 = wall_ms();
+  if (damar_read_block(b->name, &b->blk))
+    { if (background) reader_fail(); else exit(1); }
+  if (damar_load_masks(&b->blk, (char **) o->mask, o->mtop))
+    { printf("[ERROR] - Unable to load track!\n");
+      if (background) reader_fail(); else exit(1);
+    }
+  if (!check_reads_ok(&b->blk, b->name, o->kmer))
+    { if (background) reader_fail(); else exit(1); }
+  P_ms[0] += wall_ms() - t0;
+  t0 = wall_ms();
+  damar_complement_copy(&b->blk, &b->cblk);
+  P_ms[3] += wall_ms() - t0;
+  if (background)                   /* on the copy stream, beside the kernels of the main thread */
+    { t0 = wall_ms();
+      b->dev[0] = damar_block_upload_bg(&b->blk);
+      b->dev[1] = damar_block_upload_bg(&b->cblk);
+      P_ms[7] += wall_ms() - t0;
+    }
+}
+
+static void *plan_reader(void *arg)
+{ int i;
+  (void) arg;
+  for (i = 0; i < PB_ahead; i++)
+    { pblock_load(PB + i, &PB_opts, 1);
+      pthread_mutex_lock(&PB_mu);
+      PB[i].ready = 1;
+      pthread_cond_broadcast(&PB_cv);
+      pthread_mutex_unlock(&PB_mu);
+    }
+  return NULL;
+}
+
+static void *prewarm_thread(void *arg)
+{ damar_prewarm(*(int *) arg);
+  return NULL;
+}
 
 static void pblock_release(PBlock *b)
 { int c;
@@ -472,43 +518,42 @@ static PBlock *pblock_get(const char *name, const Opts *o)
 { int i;
   for (i = 0; i < PB_n; i++)
     if (strcmp(PB[i].name, name) == 0)
-      { PB[i].used = ++PB_clock;
+      { if (!PB[i].ready)                          /* the reader thread is at it */
+          { double t0 = wall_ms();
+            pthread_mutex_lock(&PB_mu);
+            while (!PB[i].ready)
+              pthread_cond_wait(&PB_cv, &PB_mu);
+            pthread_mutex_unlock(&PB_mu);
+            P_ms[6] += wall_ms() - t0;
+          }
+        PB[i].used = ++PB_clock;
         return PB + i;
       }
-  if (PB_n >= PB_max)                               /* evict the least recently used idle block */
+  if (PB_n >= PB_max)                               /* replace the least recently used idle block */
     { int v = -1;
       for (i = 0; i < PB_n; i++)
-        if (!PB[i].busy && (v < 0 || PB[i].used < PB[v].used))
+        if (!PB[i].busy && PB[i].ready && (v < 0 || PB[i].used < PB[v].used))
           v = i;
       if (v >= 0)
         { damar_async_drain();                      /* the host tail may still read its bases */
           pblock_release(PB + v);
-          PB[v] = PB[--PB_n];
+          memset(PB + v, 0, sizeof(PBlock));
+          PB[v].name = strdup(name);
+          PB[v].ready = 1;
+          pblock_load(PB + v, o, 0);
+          PB[v].used = ++PB_clock;
+          return PB + v;
         }
     }
   if (PB_n >= PB_cap)
-    { PB_cap = 2 * PB_cap + 16;
-      PB = (PBlock *) realloc(PB, sizeof(PBlock) * (size_t) PB_cap);
-      if (PB == NULL)
-        { fprintf(stderr, "daligner: out of memory (block table)\n");
-          exit(1);
-        }
+    { fprintf(stderr, "daligner: block table full (%d blocks busy at once)\n", PB_n);
+      exit(1);
     }
   { PBlock *b = PB + PB_n++;
-    double t0 = wall_ms();
     memset(b, 0, sizeof(*b));
     b->name = strdup(name);
-    if (damar_read_block(name, &b->blk))
-      exit(1);
-    if (damar_load_masks(&b->blk, (char **) o->mask, o->mtop))
-      { printf("[ERROR] - Unable to load track!\n");
-        exit(1);
-      }
-    check_reads(&b->blk, name, o->kmer);
-    P_ms[0] += wall_ms() - t0;
-    t0 = wall_ms();
-    damar_complement_copy(&b->blk, &b->cblk);
-    P_ms[3] += wall_ms() - t0;
+    b->ready = 1;
+    pblock_load(b, o, 0);
     b->used = ++PB_clock;
     return b;
   }
@@ -528,6 +573,9 @@ static damar_dev_index *pblock_index(PBlock *b, int comp)
   return b->idx[comp];
 }
 
+static Align_Spec **PS;             /* the lines' Align_Specs, alive until the asynchronous tail has drained */
+static int PS_n, PS_cap;
+
 /* one plan line: daligner.c:948-1074 */
 static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
 { static Opts last;
@@ -541,7 +589,8 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
   if (have_last && (last.kmer != o->kmer || last.maxreps != o->maxreps || last.biased != o->biased || last.mtop != o->mtop))
     { damar_async_drain();
       pblock_flush_indexes();
-      if (last.mtop != o->mtop)                   /* other mask tracks: the blocks themselves are stale */
+      if (last.mtop != o->mtop)                   /* other mask tracks: the blocks themselves are stale
+                                                     (plan_main starts no reader thread for such a plan) */
         { while (PB_n > 0)
             pblock_release(PB + --PB_n);
         }
@@ -602,9 +651,12 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
     }
   a = pblock_get(afile, o);
   a->busy = 0;
-  /* the queued tail of this line uses `spec`: drain before releasing it (once per line, not per pair) */
-  TIMED(5, damar_async_drain());
-  Free_Align_Spec(spec);
+  /* the queued tail of this line still uses `spec`: it is released when the plan is done (no drain per line) */
+  if (PS_n >= PS_cap)
+    { PS_cap = 2 * PS_cap + 64;
+      PS = (Align_Spec **) realloc(PS, sizeof(Align_Spec *) * (size_t) PS_cap);
+    }
+  PS[PS_n++] = spec;
   free(aroot);
 }
 
@@ -612,7 +664,11 @@ static int plan_main(const Opts *base, const char *planfile)
 { FILE  *f = (strcmp(planfile, "-") == 0) ? stdin : fopen(planfile, "r");
   char  *line = NULL;
   size_t cap = 0;
-  int    nlines = 0, i;
+  char ***ltok = NULL;                 /* the plan's daligner lines, tokenised */
+  int   *lntok = NULL, nl = 0, lcap = 0;
+  int    i, j, same_masks = 1;
+  pthread_t reader;
+  int    have_reader = 0;
 
   if (f == NULL)
     { fprintf(stderr, "daligner: cannot open plan %s\n", planfile);
@@ -620,15 +676,11 @@ static int plan_main(const Opts *base, const char *planfile)
     }
   if (getenv("DAMAR_PLAN_BLOCKS") != NULL && atoi(getenv("DAMAR_PLAN_BLOCKS")) >= 2)
     PB_max = atoi(getenv("DAMAR_PLAN_BLOCKS"));
-  select_device(base);
-  damar_set_async(1);
   while (getline(&line, &cap, f) > 0)
     { char *tok[4096], *sp = NULL, *t;
-      int   n = 0, first;
-      Opts  o = *base;
+      int   n = 0;
       for (t = strtok_r(line, " \t\r\n", &sp); t != NULL && n < 4095; t = strtok_r(NULL, " \t\r\n", &sp))
         tok[n++] = t;
-      tok[n] = NULL;
       if (n == 0)
         continue;
       { const char *b0 = strrchr(tok[0], '/');
@@ -636,30 +688,112 @@ static int plan_main(const Opts *base, const char *planfile)
         if (strcmp(b0, "daligner") != 0)              /* comments, LAmerge lines, ... */
           continue;
       }
-      o.plan = NULL;
-      first = parse_opts(n, tok, &o);
-      if (o.plan != NULL)
-        { fprintf(stderr, "daligner: -P inside a plan\n");
-          exit(1);
+      if (nl >= lcap)
+        { lcap = 2 * lcap + 64;
+          ltok = (char ***) realloc(ltok, sizeof(char **) * (size_t) lcap);
+          lntok = (int *) realloc(lntok, sizeof(int) * (size_t) lcap);
         }
-      if (first + 2 > n)
-        { fprintf(stderr, "[ERROR] - at least one target and one subject block are required\n\n");
-          exit(1);
-        }
-      plan_line(&o, tok[first], tok + first + 1, n - first - 1);
-      nlines += 1;
+      ltok[nl] = (char **) malloc(sizeof(char *) * (size_t) (n + 1));
+      for (j = 0; j < n; j++)
+        ltok[nl][j] = strdup(tok[j]);
+      ltok[nl][n] = NULL;
+      lntok[nl++] = n;
     }
-  damar_async_drain();
+  free(line);
+  if (f != stdin)
+    fclose(f);
+
+  select_device(base);
+  if (getenv("DAMAR_PREWARM_GB") && atoi(getenv("DAMAR_PREWARM_GB")) > 0)
+    { pthread_t th;                     /* grow the HBM footprint next to reading the first blocks (see damar_prewarm) */
+      static int gb;
+      gb = atoi(getenv("DAMAR_PREWARM_GB"));
+      if (pthread_create(&th, NULL, prewarm_thread, &gb) == 0)
+        pthread_detach(th);
+    }
+  damar_set_async(1);
+
+  /* the block table, and what the reader thread prepares ahead: the blocks in order of first use */
+  PB_cap = PB_max + 8;
+  PB = (PBlock *) calloc((size_t) PB_cap, sizeof(PBlock));
+  { Opts o0 = *base, o;
+    int  first0 = 0;
+    for (i = 0; i < nl; i++)
+      { int first;
+        o = *base;  o.plan = NULL;
+        first = parse_opts(lntok[i], ltok[i], &o);
+        if (o.plan != NULL)
+          { fprintf(stderr, "daligner: -P inside a plan\n");
+            exit(1);
+          }
+        if (first + 2 > lntok[i])
+          { fprintf(stderr, "[ERROR] - at least one target and one subject block are required\n\n");
+            exit(1);
+          }
+        if (i == 0)
+          { o0 = o;  first0 = first; }
+        else if (o.mtop != o0.mtop || o.kmer != o0.kmer)
+          same_masks = 0;
+        else
+          for (j = 0; j < o.mtop; j++)
+            if (strcmp(o.mask[j], o0.mask[j]) != 0)
+              same_masks = 0;
+      }
+    (void) first0;
+    if (same_masks && nl > 0 && getenv("DAMAR_PLAN_NOREADER") == NULL)
+      { for (i = 0; i < nl && PB_n < PB_max; i++)
+          { int first;
+            o = *base;  o.plan = NULL;
+            first = parse_opts(lntok[i], ltok[i], &o);
+            for (j = first; j < lntok[i] && PB_n < PB_max; j++)
+              { int k, seen = 0;
+                for (k = 0; k < PB_n; k++)
+                  if (strcmp(PB[k].name, ltok[i][j]) == 0)
+                    seen = 1;
+                if (!seen)
+                  { PB[PB_n].name = strdup(ltok[i][j]);
+                    PB[PB_n].used = ++PB_clock;
+                    PB_n += 1;
+                  }
+              }
+          }
+        PB_ahead = PB_n;
+        PB_opts = o0;
+        if (pthread_create(&reader, NULL, plan_reader, NULL) != 0)
+          { fprintf(stderr, "daligner: cannot start the block reader thread\n");
+            exit(1);
+          }
+        have_reader = 1;
+      }
+  }
+
+  for (i = 0; i < nl; i++)
+    { Opts o = *base;
+      int  first;
+      o.plan = NULL;
+      first = parse_opts(lntok[i], ltok[i], &o);
+      plan_line(&o, ltok[i][first], ltok[i] + first + 1, lntok[i] - first - 1);
+    }
+  TIMED(5, damar_async_drain());
+  if (have_reader)
+    pthread_join(reader, NULL);
+  for (i = 0; i < PS_n; i++)
+    Free_Align_Spec(PS[i]);
+  free(PS);
   for (i = 0; i < PB_n; i++)
     pblock_release(PB + i);
   PB_n = 0;
   free(PB);
-  free(line);
-  if (f != stdin)
-    fclose(f);
+  for (i = 0; i < nl; i++)
+    { for (j = 0; j < lntok[i]; j++)
+        free(ltok[i][j]);
+      free(ltok[i]);
+    }
+  free(ltok);
+  free(lntok);
   damar_set_async(0);
   if (getenv("DAMAR_CLIPROF"))
-    { fprintf(stderr, "cli: %d plan lines, %d index builds; wall ms:", nlines, PB_builds);
+    { fprintf(stderr, "cli: %d plan lines, %d index builds; wall ms:", nl, PB_builds);
       for (i = 0; i < 8; i++)
         fprintf(stderr, " %s=%.1f", P_name[i], P_ms[i]);
       fprintf(stderr, "\n");

@@ -249,6 +249,26 @@ extern "C" const char *damar_hip_device_name(void)
   return name;
 }
 
+/* A cold process pays ~25 ms per GB the first time its HBM footprint grows (the driver maps and clears new
+ * memory; a buffer that is freed and allocated again is handed back at once: build/malloc_test.hip).  A command
+ * that knows it will need tens of GB calls this early on a thread of its own, next to reading its input: the
+ * footprint is grown and released there, and the allocations of the real work find it ready. */
+extern "C" void damar_prewarm(int gigabytes)
+{ ensure_init();
+  HIP_CHECK(hipSetDevice(G_device));
+  std::vector<void *> held;
+  for (int g = 0; g < gigabytes; g += 2)
+    { void *p = NULL;
+      if (hipMalloc(&p, (size_t) 2 << 30) != hipSuccess)
+        { (void) hipGetLastError();
+          break;
+        }
+      held.push_back(p);
+    }
+  for (void *p : held)
+    (void) hipFree(p);
+}
+
 static int G_debug = -1;
 /* DAMAR_DEBUG=1: synchronise after every stage and name it on stderr, so that a device
  * fault can be attributed to the kernel that caused it. */
@@ -306,6 +326,18 @@ extern "C" void damar_block_preload(const HITS_DB *block)
   damar_dev_block *b = block_upload_on(block, PL_st);
   std::lock_guard<std::mutex> lk(PL_mu);
   PL_ready.push_back(std::make_pair((const void *) block->bases, b));
+}
+
+/* damar_block_upload on the preload stream, for a second host thread that prepares blocks ahead of the one that
+ * launches the kernels (hipStreamSynchronize inside: the block is complete when this returns) */
+extern "C" damar_dev_block *damar_block_upload_bg(const HITS_DB *block)
+{ ensure_init();
+  HIP_CHECK(hipSetDevice(G_device));          /* the current device is a per-thread setting */
+  { std::lock_guard<std::mutex> lk(PL_mu);
+    if (PL_st == NULL)
+      HIP_CHECK(hipStreamCreateWithFlags(&PL_st, hipStreamNonBlocking));
+  }
+  return block_upload_on(block, PL_st);
 }
 
 static damar_dev_block *take_preloaded(const HITS_DB *block)

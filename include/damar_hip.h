@@ -32,6 +32,9 @@ extern "C" {
 int   damar_hip_init(int device);
 const char *damar_hip_device_name(void);
 void  damar_hip_sync(void);          /* hipDeviceSynchronize on the selected GPU */
+/* Grow (and release again) the process's HBM footprint by `gigabytes`: a cold process pays ~25 ms per GB the first
+ * time; called on a thread of its own next to reading the input, the real allocations find the memory ready. */
+void  damar_prewarm(int gigabytes);
 
 /* A read block resident in HBM: bases (1 B/base with the reference's 4-terminators,
  * db/DB.c:1562-1605), read offsets, coarse position->read table. */
@@ -40,6 +43,8 @@ damar_dev_block *damar_block_upload(const HITS_DB *block);
 /* The same on a stream of its own, remembered by the address of block->bases until Sort_Kmers(block) takes
  * it: lets a second host thread upload the next block while the GPU works (one caller thread at a time). */
 void damar_block_preload(const HITS_DB *block);
+/* damar_block_upload on that second stream, returning the block: for a host thread that prepares blocks ahead. */
+damar_dev_block *damar_block_upload_bg(const HITS_DB *block);
 void             damar_block_free(damar_dev_block *blk);
 
 /* The opaque index that Sort_Kmers returns (filter.c:753-994): sorted k-mer codes,
