@@ -1509,6 +1509,20 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
           ra.work = work;  ra.nwork = nwork;
           ra.pbits = m.pbits;  ra.abits = m.abits;
           ra.order = order;
+          if (getenv("DAMAR_DUP_WORK") && order)     /* experiment: every item twice (timing only, output is garbage) */
+            { static u32 *dup = NULL;  static size_t dupn = 0;
+              const int f = atoi(getenv("DAMAR_DUP_WORK"));
+              if (dupn < (size_t) f * nwork)
+                { if (dup) HIP_CHECK(hipFree(dup));
+                  dupn = (size_t) f * nwork + 4096;
+                  HIP_CHECK(hipMalloc(&dup, 4 * dupn));
+                }
+              std::vector<u32> ho(nwork), hd((size_t) f * nwork);
+              HIP_CHECK(hipMemcpy(ho.data(), order, 4 * (size_t) nwork, hipMemcpyDeviceToHost));
+              for (size_t i = 0; i < (size_t) f * nwork; i++) hd[i] = ho[i / f];
+              HIP_CHECK(hipMemcpy(dup, hd.data(), 4 * hd.size(), hipMemcpyHostToDevice));
+              ra.order = dup;  ra.nwork = f * nwork;
+            }
           HIP_CHECK(hipMemsetAsync(RS.counters, 0, 64, G_st));
           tick(4);
           stage("report_setup");
