@@ -311,20 +311,25 @@ def main():
             if rank == 0:
                 shutil.rmtree(out, ignore_errors=True)
 
-        sync_all()
-        t0 = time.time()
-        tim, cnts, last_out, nmine, builds = {}, [0, 0, 0], None, 0, 0
+        # Every step is bracketed by barrier + device sync on both sides and the K step times are added up; between two
+        # steps (outside the clock) rank 0 deletes the previous step's output files, which are the harness's, not the path's.
+        tim, cnts, last_out, nmine, builds, nmatch, nlaunch = {}, [0, 0, 0], None, 0, 0, 0, 0
+        elapsed = 0.
         for s in range(args.steps):
             if last_out and rank == 0:
                 shutil.rmtree(last_out, ignore_errors=True)
+            sync_all()
+            t0 = time.time()
             last_out, plan, n = one_step("s%d" % s)
+            sync_all()
+            elapsed += time.time() - t0
             nmine += n
             builds += plan.index_builds
+            nmatch += plan.matches
+            nlaunch += plan.report_launches
             for k, v in plan.timings.items():
                 tim[k] = tim.get(k, 0.) + v
             cnts = [c + d for c, d in zip(cnts, plan.counts)]
-        sync_all()
-        elapsed = time.time() - t0
 
         tkeys = ["report", "ssort", "ksort", "merge", "tuples", "table", "work", "d2h", "tail", "write"]
         if dist is not None:
@@ -333,15 +338,15 @@ def main():
             t = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            v = torch.tensor([tim.get(k, 0.) for k in tkeys] + [float(c) for c in cnts] + [float(nmine), float(builds)],
-                             device=rdev, dtype=torch.float64)
+            v = torch.tensor([tim.get(k, 0.) for k in tkeys] + [float(c) for c in cnts] +
+                             [float(nmatch), float(nlaunch), float(nmine), float(builds)], device=rdev, dtype=torch.float64)
             vmax = v.clone()
             dist.all_reduce(v, op=dist.ReduceOp.SUM)
             dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
             vals = [float(x) for x in v.tolist()]
             tim = dict(zip(tkeys, vals[:len(tkeys)]))
             cnts = vals[len(tkeys):len(tkeys) + 3]
-            units_run, builds = vals[-2], vals[-1]
+            nmatch, nlaunch, units_run, builds = vals[-4], vals[-3], vals[-2], vals[-1]
             units_max = float(vmax[-2].item())
         else:
             units_run, units_max = float(nmine), float(nmine)
@@ -366,7 +371,8 @@ def main():
             steps = max(1, args.steps)
             nrec, bp, trace_vals = sum_las(last_out)
             parity = check_against_reference(last_out, cfg["md5"])
-            nmatch = 2. * units_run / steps                  # damar_match calls per step, all ranks
+            nmatch = float(nmatch) / steps                   # comparisons (block pair x orientation) per step, all ranks
+            nlaunch = float(nlaunch) / steps                 # launches of the report kernel they took
             kern = {"report_kernel (band filter + Local_Alignment waves)": tim.get("report", 0.),
                     "radix sort of seed pairs (hist+scan+scatter, u64 keys)": tim.get("ssort", 0.),
                     "radix sort of the k-mer index (hist+scan+scatter, u32 keys)": tim.get("ksort", 0.),
@@ -374,10 +380,11 @@ def main():
             dom = max(kern, key=kern.get)
             H = cnts[0] / steps                      # seed pairs per step
             nsplit = max(n for _, _, _, n in units)
+            ngroup = max(len(b) if isinstance(b, tuple) else 1 for _, b, _, _ in units)
             if dom.startswith("report"):
                 # filter 16 B/seed + align 2 B per aligned bp + 2 B per trace value
                 alg = 16. * H + 2. * bp + 2. * trace_vals
-                nl = nmatch
+                nl = nlaunch
             elif dom.startswith("radix sort of seed"):
                 alg = 16. * H * 2 * 6                # 16-byte records, read+write, P_s = 6 passes
                 nl = nmatch
@@ -441,10 +448,13 @@ def main():
                                "records_per_step": nrec, "aligned_bp_per_step": bp,
                                "seed_pairs_per_step": H, "local_alignments_per_step": cnts[1] / steps,
                                "index_builds_per_step": builds / steps,
-                               "parallelism": "%d GPU(s), one process each, ONE database; %d work units per step (block pairs%s) "
+                               "comparisons_per_step": nmatch, "report_launches_per_step": nlaunch,
+                               "parallelism": "%d GPU(s), one process each, ONE database; %d work units per step (%s) "
                                               "pulled from a shared cursor, no data-path collective; busiest rank ran %d units"
-                                              % (world, len(units), ", split %d-way by B-read range" % nsplit if nsplit > 1 else "",
-                                                 int(units_max)),
+                                              % (world, len(units),
+                                                 "block pairs split %d-way by B-read range" % nsplit if nsplit > 1 else
+                                                 "one A block against up to %d subject blocks, both orientations, behind one "
+                                                 "launch of the report kernel" % ngroup, int(units_max)),
                                "db_generation_s": t_gen},
                     "parity": parity,
                     "roofline": roof, "cpu_baseline": cpu, "end_to_end": e2e, "trace_expand": trace}

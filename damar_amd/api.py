@@ -33,6 +33,13 @@ class SimParams(C.Structure):          # include/damar_db.h damar_sim_params
 
 T_NAMES = ["tuples", "ksort", "table", "merge", "ssort", "work", "report", "d2h", "tail"]
 
+class MatchJob(C.Structure):           # include/damar_hip.h damar_match_job
+    _fields_ = [("ablock", C.POINTER(HITS_DB)), ("bblock", C.POINTER(HITS_DB)),
+                ("aidx", C.c_void_p), ("bidx", C.c_void_p),
+                ("self_", C.c_int), ("comp", C.c_int),
+                ("spec", C.c_void_p), ("counts", c_int64 * 3)]
+
+
 _proto_done = False
 
 
@@ -83,6 +90,7 @@ def _lib():
         L.damar_index_download.argtypes = [C.c_void_p, C.c_void_p]
         L.damar_match.argtypes = [C.POINTER(HITS_DB), C.POINTER(HITS_DB), C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_void_p, C.POINTER(c_int64)]
+        L.damar_match_batch.argtypes = [C.POINTER(MatchJob), C.c_int]
         L.damar_set_async.argtypes = [C.c_int]
         L.damar_async_totals.argtypes = [C.POINTER(c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.damar_write_overlaps.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]

@@ -573,8 +573,19 @@ static damar_dev_index *pblock_index(PBlock *b, int comp)
   return b->idx[comp];
 }
 
-static Align_Spec **PS;             /* the lines' Align_Specs, alive until the asynchronous tail has drained */
+static Align_Spec **PS;             /* the plan's Align_Specs, alive until the asynchronous tail has drained */
 static int PS_n, PS_cap;
+
+#define LINE_B 8                    /* subject blocks per report launch (x 2 orientations = DAMAR_MAX_JOBS comparisons) */
+
+/* the queued tails and writes still use the spec: it is released when the plan is done (no drain per line) */
+static void plan_keep_spec(Align_Spec *spec)
+{ if (PS_n >= PS_cap)
+    { PS_cap = 2 * PS_cap + 64;
+      PS = (Align_Spec **) realloc(PS, sizeof(Align_Spec *) * (size_t) PS_cap);
+    }
+  PS[PS_n++] = spec;
+}
 
 /* one plan line: daligner.c:948-1074 */
 static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
@@ -582,8 +593,6 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
   static int  have_last = 0;
   PBlock *a;
   char   *aroot;
-  Align_Spec *spec;
-  int64   cnt[3];
   int     k;
 
   if (have_last && (last.kmer != o->kmer || last.maxreps != o->maxreps || last.biased != o->biased || last.mtop != o->mtop))
@@ -603,60 +612,61 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
   if (SYMMETRIC)
     SYMMETRIC = symmetric_for(afile, aroot, bfiles, nb);
   make_subdir(&a->blk, o->runid);
-  spec = New_Align_Spec(o->ecorr, o->spacing, a->blk.freq, o->nthreads, SYMMETRIC, o->only_id, o->notrace, 1);
-  for (k = 0; k < nb; k++)
-    { double t0;
-      if (strcmp(afile, bfiles[k]) == 0)
-        { char *d1 = NULL;
-          damar_dev_index *ai = pblock_index(a, 0), *ci;
-          t0 = wall_ms();
-          damar_match(&a->blk, &a->blk, ai, ai, 1, 0, spec, cnt);
-          P_ms[2] += wall_ms() - t0;
-          ci = pblock_index(a, 1);
-          t0 = wall_ms();
-          damar_match(&a->blk, &a->cblk, ai, ci, 1, 1, spec, cnt);
-          P_ms[2] += wall_ms() - t0;
-          if (a->blk.part > 0) d1 = damar_get_dir(o->runid, a->blk.part);
-          TIMED(4, damar_write_overlaps(spec, d1, NULL, aroot, aroot, a->blk.ufirst + a->blk.nreads - 1));
-          free(d1);
-        }
-      else
-        { PBlock *b;
-          char   *broot = damar_root(bfiles[k], ".db"), *d1 = NULL, *d2 = NULL;
-          damar_dev_index *ai, *bi;
-          int     last_read;
-          b = pblock_get(bfiles[k], o);
-          a = pblock_get(afile, o);              /* (the table may have moved) */
+  /* The line is worked through in groups of up to LINE_B subject blocks: the seed stages of the group's comparisons
+     (both orientations of each block) run one after the other, ONE launch of the report kernel covers them all
+     (damar_match_batch), and the files are written per block as the reference does (daligner.c:1006-1021, 1051-1056).
+     Every subject block has its own Align_Spec, i.e. its own overlap buffers, so that the queued tails and writes
+     of the group cannot mix. */
+  for (k = 0; k < nb; k += LINE_B)
+    { const int n = (nb - k < LINE_B) ? nb - k : LINE_B;
+      damar_match_job jobs[2 * LINE_B];
+      PBlock     *bb[LINE_B];
+      Align_Spec *sp[LINE_B];
+      int     q;
+      double  t0;
+      damar_dev_index *ai = pblock_index(a, 0);
+      memset(jobs, 0, sizeof(jobs));
+      for (q = 0; q < n; q++)
+        { const int same = (strcmp(afile, bfiles[k + q]) == 0);
+          PBlock *b = same ? a : pblock_get(bfiles[k + q], o);
+          damar_match_job *jn = jobs + 2 * q, *jc = jn + 1;
           b->busy = 1;
-          if (SYMMETRIC)
+          bb[q] = b;
+          sp[q] = New_Align_Spec(o->ecorr, o->spacing, a->blk.freq, o->nthreads, SYMMETRIC, o->only_id, o->notrace, 1);
+          plan_keep_spec(sp[q]);
+          if (!same && SYMMETRIC)
             make_subdir(&b->blk, o->runid);
-          ai = pblock_index(a, 0);
-          bi = pblock_index(b, 0);
-          t0 = wall_ms();
-          damar_match(&a->blk, &b->blk, ai, bi, 0, 0, spec, cnt);
-          P_ms[2] += wall_ms() - t0;
-          bi = pblock_index(b, 1);
-          t0 = wall_ms();
-          damar_match(&a->blk, &b->cblk, ai, bi, 0, 1, spec, cnt);
-          P_ms[2] += wall_ms() - t0;
-          last_read = (b->blk.part < a->blk.part) ? b->blk.ufirst + b->blk.nreads - 1 : a->blk.ufirst + a->blk.nreads - 1;
+          jn->ablock = jc->ablock = &a->blk;
+          jn->aidx = jc->aidx = ai;
+          jn->bblock = &b->blk;   jn->bidx = same ? ai : pblock_index(b, 0);
+          jc->bblock = &b->cblk;  jc->bidx = pblock_index(b, 1);
+          jn->self = jc->self = same;
+          jn->comp = 0;  jc->comp = 1;
+          jn->spec = jc->spec = sp[q];
+        }
+      t0 = wall_ms();
+      damar_match_batch(jobs, 2 * n);
+      P_ms[2] += wall_ms() - t0;
+      for (q = 0; q < n; q++)
+        { PBlock *b = bb[q];
+          char   *d1 = NULL, *d2 = NULL;
           if (a->blk.part > 0) d1 = damar_get_dir(o->runid, a->blk.part);
-          if (b->blk.part > 0) d2 = damar_get_dir(o->runid, b->blk.part);
-          TIMED(4, damar_write_overlaps(spec, d1, d2, aroot, broot, last_read));
+          if (b == a)
+            { TIMED(4, damar_write_overlaps(sp[q], d1, NULL, aroot, aroot, a->blk.ufirst + a->blk.nreads - 1)); }
+          else
+            { char *broot = damar_root(bfiles[k + q], ".db");
+              const int last_read = (b->blk.part < a->blk.part) ? b->blk.ufirst + b->blk.nreads - 1
+                                                                : a->blk.ufirst + a->blk.nreads - 1;
+              if (b->blk.part > 0) d2 = damar_get_dir(o->runid, b->blk.part);
+              TIMED(4, damar_write_overlaps(sp[q], d1, d2, aroot, broot, last_read));
+              free(broot);
+              b->busy = 0;
+            }
           free(d1);
           free(d2);
-          free(broot);
-          b->busy = 0;
         }
     }
-  a = pblock_get(afile, o);
   a->busy = 0;
-  /* the queued tail of this line still uses `spec`: it is released when the plan is done (no drain per line) */
-  if (PS_n >= PS_cap)
-    { PS_cap = 2 * PS_cap + 64;
-      PS = (Align_Spec **) realloc(PS, sizeof(Align_Spec *) * (size_t) PS_cap);
-    }
-  PS[PS_n++] = spec;
   free(aroot);
 }
 
@@ -714,7 +724,7 @@ static int plan_main(const Opts *base, const char *planfile)
   damar_set_async(1);
 
   /* the block table, and what the reader thread prepares ahead: the blocks in order of first use */
-  PB_cap = PB_max + 8;
+  PB_cap = PB_max + LINE_B + 2;           /* a group of subject blocks and the A block can be busy beyond PB_max */
   PB = (PBlock *) calloc((size_t) PB_cap, sizeof(PBlock));
   { Opts o0 = *base, o;
     int  first0 = 0;

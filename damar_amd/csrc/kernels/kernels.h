@@ -115,9 +115,19 @@ typedef struct
   LaRecord *recs;  u32 rec_cap;
   u16  *tpool;     u32 tpool_cap;
   const u32 *order; /* processing order of the work items (largest first), or NULL          */
-  u32  *counters;  /* [0] next work item, [1] records, [2] trace words, [3] error flags,
-                      [4] seed hits (nfilt) */
+  u32  *counters;  /* [1] records, [2] trace words, [3] error flags, [6] [7] where a wave gave up; shared by the jobs of a launch */
+  u32  *cursor;    /* next work item of THIS job (counters + 16 + job) */
+  u32  *nfilt;     /* seed hits of THIS job      (counters + 32 + job) */
+  int   job;       /* index of this job in the launch: rides in the top byte of LaRecord.seq */
 } ReportArgs;
+
+/* One launch of a report kernel works through up to DAMAR_MAX_JOBS comparisons (ReportArgs each, in constant memory:
+   wave-uniform reads of a job's fields are scalar loads).  Every wavefront starts with job (block index mod njobs) and
+   moves on to the next when a job's queue is empty, so the long alignments of ALL jobs start at once and the tail of
+   the launch (waiting for the longest alignment) is paid once per launch, not once per comparison. */
+#define DAMAR_MAX_JOBS 16
+#define DAMAR_COUNTER_WORDS 64
+#define DAMAR_SEQ_BITS 24
 
 #define DAMAR_ERR_CELLS   1u
 #define DAMAR_ERR_RECS    2u
@@ -127,7 +137,7 @@ typedef struct
 
 int  damar_report_waves_per_simd(void);
 int  damar_report2_waves_per_simd(void);     /* two scratch slots per wavefront */
-void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st);
+void damar_launch_report(const ReportArgs *jobs, int njobs, int nslots, hipStream_t st);
 /* datander report: one work item per read of a.ablk, dist as produced by damar_launch_tandem_links */
 void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots, hipStream_t st);
 
@@ -135,7 +145,7 @@ void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots
 typedef struct { int aread, bread, diag, anti; } LaTask;
 void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
 /* two read pairs (or batch tasks, tasks != NULL) per wavefront: report_packed.h; nslots must be even */
-void damar_launch_report2(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
+void damar_launch_report2(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
 #define DAMAR_MAX_MARKS 16000         /* trace-grid indexes ride in the top 14 bits of a chain head (report.hip PK_HBITS) */
 #define DAMAR_MAX_CELLS (1u << 18)    /* pebbles per slot: 18 bits of a chain head */
 

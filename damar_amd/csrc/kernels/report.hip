@@ -1270,6 +1270,22 @@ __device__ void local_alignment(WaveCtx &c, u32 flags, int diag, int anti, LaRes
 
 __device__ __forceinline__ u32 read_len(const DevBlock &b, u32 r) { return b.boff[r + 1] - b.boff[r] - 1; }
 
+/* the comparisons of the current launch (kernels.h): constant memory, so that a wave-uniform read of a field is a
+   scalar load also inside the functions that are not inlined (they take the job index, not a reference) */
+__constant__ ReportArgs g_jobs[DAMAR_MAX_JOBS];
+
+static void jobs_upload(const ReportArgs *jobs, int njobs, hipStream_t st)
+{ if (njobs < 1 || njobs > DAMAR_MAX_JOBS)
+    { fprintf(stderr, "damar: internal error, %d jobs in one report launch\n", njobs);
+      abort();
+    }
+  hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_jobs), jobs, sizeof(ReportArgs) * (size_t) njobs, 0, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess)
+    { fprintf(stderr, "damar: FATAL: uploading the report jobs: %s\n", hipGetErrorString(e));
+      abort();
+    }
+}
+
 struct SlotScratch
 { DState *st0, *st1;
   int    *NA, *NB;
@@ -1299,9 +1315,10 @@ __device__ __forceinline__ SlotScratch slot_scratch(const ReportArgs &a, int slo
 
 /* emit one alignment: copies both traces to the pool (B trace reversed pairwise for COMP,
  * align.c:2033-2056) and writes the record */
-__device__ __noinline__ void emit_record(const ReportArgs &a, const SlotScratch &s, const LaResult &r,
+__device__ __noinline__ void emit_record(int job, const SlotScratch &s, const LaResult &r,
                                          int ar, int br, u32 item, u32 seq)
-{ const int lane = lane_id();
+{ const ReportArgs &a = g_jobs[uni(job)];
+  const int lane = lane_id();
   const int nval = r.atlen + r.btlen;
   u32 ri = 0, to = 0;
   if (lane == 0)
@@ -1337,7 +1354,7 @@ __device__ __noinline__ void emit_record(const ReportArgs &a, const SlotScratch 
         { LaRecord rec;
           rec.abpos = r.abpos;  rec.bbpos = r.bbpos;  rec.aepos = r.aepos;  rec.bepos = r.bepos;
           rec.diffs = r.diffs;  rec.atlen = r.atlen;  rec.btlen = r.btlen;
-          rec.aread = ar;  rec.bread = br;  rec.item = item;  rec.seq = seq;  rec.toff = to;
+          rec.aread = ar;  rec.bread = br;  rec.item = item;  rec.seq = seq | ((u32) a.job << DAMAR_SEQ_BITS);  rec.toff = to;
           a.recs[ri] = rec;
         }
     }
@@ -1493,7 +1510,7 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
                   LaResult r;
                   int lo, hi;
 
-                  if (lane == 0) atomicAdd(&a.counters[4], 1u);
+                  if (lane == 0) atomicAdd(a.nfilt, 1u);
 #ifdef DAMAR_PROF
                   const unsigned long long pf_t0 = wall_clock64();
 #endif
@@ -1514,7 +1531,7 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
                   if (hi > chi) chi = hi;
                   wave_mem_sync();
                   if ((r.aepos - r.abpos) + (r.bepos - r.bbpos) >= a.minover)
-                    emit_record(a, s, r, ar, br, item, seq++);
+                    emit_record(a.job, s, r, ar, br, item, seq++);
                 }
             }
 
@@ -1633,7 +1650,7 @@ __device__ void process_read(const ReportArgs &a, const u32 *trimtab, const Slot
               LaResult r;
               int lo, hi;
 
-              if (lane == 0) atomicAdd(&a.counters[4], 1u);
+              if (lane == 0) atomicAdd(a.nfilt, 1u);
               local_alignment(c, 0u, sdg, sap + sbp, &r);
               diagonal_span(s, r, a.tspace, W, &lo, &hi);
               if (sd < lo) lo = sd; else if (sd > hi) hi = sd;
@@ -1646,7 +1663,7 @@ __device__ void process_read(const ReportArgs &a, const u32 *trimtab, const Slot
               if (hi > chi) chi = hi;
               wave_mem_sync();
               if ((r.aepos - r.abpos) + (r.bepos - r.bbpos) >= a.minover)
-                emit_record(a, s, r, ar, ar, item, seq++);
+                emit_record(a.job, s, r, ar, ar, item, seq++);
             }
         }
 
@@ -1675,8 +1692,9 @@ __device__ void process_read(const ReportArgs &a, const u32 *trimtab, const Slot
 }
 
 __global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
-void tandem_kernel(ReportArgs a, const int *dist)
-{ __shared__ u32 trimtab[256];
+void tandem_kernel(const int *dist)
+{ const ReportArgs &a = g_jobs[0];
+  __shared__ u32 trimtab[256];
   pk_fill_trimtab(trimtab, a.mscore, a.dscore);
   __syncthreads();
   const int slot = blockIdx.x;
@@ -1684,7 +1702,7 @@ void tandem_kernel(ReportArgs a, const int *dist)
   for (;;)
     { u32 item = 0;
       if (lane_id() == 0)
-        item = atomicAdd(&a.counters[0], 1u);
+        item = atomicAdd(a.cursor, 1u);
       item = (u32) uni((int) item);
       if (item >= a.nwork)
         break;
@@ -1695,44 +1713,48 @@ void tandem_kernel(ReportArgs a, const int *dist)
 void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots, hipStream_t st)
 { if (a->nwork == 0)
     return;
-  hipLaunchKernelGGL(tandem_kernel, dim3(nslots), dim3(64), 0, st, *a, dist);
+  jobs_upload(a, 1, st);
+  hipLaunchKernelGGL(tandem_kernel, dim3(nslots), dim3(64), 0, st, dist);
 }
 
 __global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
-void report_kernel(ReportArgs a)
+void report_kernel(int njobs)
 { __shared__ u32 trimtab[256];
-  pk_fill_trimtab(trimtab, a.mscore, a.dscore);
+  pk_fill_trimtab(trimtab, g_jobs[0].mscore, g_jobs[0].dscore);
   __syncthreads();
   const int slot = blockIdx.x;
-  const SlotScratch s = slot_scratch(a, slot);
 #ifdef DAMAR_PROF
   const unsigned long long pf_k0 = wall_clock64();
   struct PfExit { unsigned long long t0; __device__ ~PfExit() { unsigned long long d = wall_clock64() - t0;
     if (lane_id() == 0) { atomicAdd(&g_prof[23], d); atomicAdd(&g_prof[25], 1ull); atomicMax(&g_prof[24], d); } } } pf_exit = { pf_k0 };
 #endif
-  for (;;)
-    { u32 item = 0;
-      if (lane_id() == 0)
-        item = atomicAdd(&a.counters[0], 1u);
-      item = (u32) uni((int) item);
-      if (item >= a.nwork)
-        break;
-      if (a.order)
-        item = (u32) uni((int) a.order[item]);
-      process_pair(a, trimtab, s, item);
+  for (int turn = 0; turn < njobs; turn++)
+    { const ReportArgs &a = g_jobs[(slot + turn) % njobs];
+      const SlotScratch s = slot_scratch(a, slot);
+      for (;;)
+        { u32 item = 0;
+          if (lane_id() == 0)
+            item = atomicAdd(a.cursor, 1u);
+          item = (u32) uni((int) item);
+          if (item >= a.nwork)
+            break;
+          if (a.order)
+            item = (u32) uni((int) a.order[item]);
+          process_pair(a, trimtab, s, item);
+        }
     }
 }
 
-void damar_launch_report(const ReportArgs *a, int nslots, hipStream_t st)
-{ if (a->nwork == 0)
-    return;
-  hipLaunchKernelGGL(report_kernel, dim3(nslots), dim3(64), 0, st, *a);
+void damar_launch_report(const ReportArgs *jobs, int njobs, int nslots, hipStream_t st)
+{ jobs_upload(jobs, njobs, st);
+  hipLaunchKernelGGL(report_kernel, dim3(nslots), dim3(64), 0, st, njobs);
 }
 
 /* batch Local_Alignment (tests): one wave per task, result always emitted */
 __global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
-void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
-{ __shared__ u32 trimtab[256];
+void la_batch_kernel(const LaTask *tasks, u32 ntasks)
+{ const ReportArgs &a = g_jobs[0];
+  __shared__ u32 trimtab[256];
   pk_fill_trimtab(trimtab, a.mscore, a.dscore);
   __syncthreads();
   const int slot = blockIdx.x;
@@ -1740,7 +1762,7 @@ void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
   for (;;)
     { u32 t = 0;
       if (lane_id() == 0)
-        t = atomicAdd(&a.counters[0], 1u);
+        t = atomicAdd(a.cursor, 1u);
       t = (u32) uni((int) t);
       if (t >= ntasks)
         break;
@@ -1763,14 +1785,15 @@ void la_batch_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
       c.atr = s.atr;  c.btr = s.btr;
       LaResult r;
       local_alignment(c, (u32) a.comp, tk.diag, tk.anti, &r);
-      emit_record(a, s, r, tk.aread, tk.bread, t, 0);
+      emit_record(a.job, s, r, tk.aread, tk.bread, t, 0);
     }
 }
 
 void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st)
 { if (ntasks == 0)
     return;
-  hipLaunchKernelGGL(la_batch_kernel, dim3(nslots), dim3(64), 0, st, *a, tasks, ntasks);
+  jobs_upload(a, 1, st);
+  hipLaunchKernelGGL(la_batch_kernel, dim3(nslots), dim3(64), 0, st, tasks, ntasks);
 }
 
 #include "report_packed.h"

@@ -47,13 +47,26 @@ __device__ __forceinline__ int upd_dpp_shr(int old, int v, int n)      /* lane i
 struct PkPair
 { int  a0, b0;              /* offsets of the two reads in the blocks' base arrays */
   int  alen, blen;
-  int  minp, maxp, aoff, boff;
+  int  minp, maxp, boff;    /* (aoff is 0 on this path: filter.c:2318 aligns A reads forward) */
 };
 
+/* What a direction touches only at events (a new trim point, a sequence end reached, clipping) lives in LDS, one
+   16-word record per half, not in registers: 13 VGPRs less across the wave loop.  A workgroup is one wavefront and
+   every lane of a half executes the same stores with the same values, so every lane reads back what it wrote itself. */
+__shared__ int pk_cold[2 * 16];
+enum { PKC_REACHM = 0, PKC_ACLIP, PKC_BCLIP, PKC_TRIM, PKC_REACH = PKC_TRIM + 5 };
+struct LdsInt
+{ int at;
+  __device__ __forceinline__ operator int() const { return pk_cold[at]; }
+  __device__ __forceinline__ LdsInt &operator=(int v) { pk_cold[at] = v; return *this; }
+  __device__ __forceinline__ LdsInt &operator=(const LdsInt &o) { pk_cold[at] = (int) o; return *this; }
+};
+struct LdsTip { LdsInt a, y, d, ha, hb; };
+__device__ __forceinline__ LdsTip pk_cold_tip(int at) { LdsTip t = { { at }, { at + 1 }, { at + 2 }, { at + 3 }, { at + 4 } }; return t; }
+
 struct PkDir
-{ int low, hgh, dif, besta, besty, lasta, more, reachm, aclip, bclip, kbase;
+{ int low, hgh, dif, besta, besty, lasta, more, kbase;
   int ncell;
-  Tip trim, reach;
   int ovf;                  /* the band outgrew the half: continue on the full-wave path */
   int bad;
   int fin;                  /* the direction is over for this half (ended, failed, or finished on the full-wave path) */
@@ -70,11 +83,13 @@ struct PkDir
   GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) uni_ptr((Cell *) a.cells);                          \
   const int cell_cap = (int) uni((int) a.cell_cap);                                                  \
   u32 *const errw = uni_ptr(&a.counters[3]);                                                         \
-  const int offa = p.aoff - PK_BIAS * TS, offb = p.boff - PK_BIAS * TS;  /* mark = index * TS + off */ \
+  const int offa = -PK_BIAS * TS, offb = p.boff - PK_BIAS * TS;          /* mark = index * TS + off */ \
   int &low = D.low, &hgh = D.hgh, &dif = D.dif, &besta = D.besta, &besty = D.besty, &lasta = D.lasta; \
-  int &more = D.more, &reachm = D.reachm, &aclip = D.aclip, &bclip = D.bclip, &kbase = D.kbase;      \
+  int &more = D.more, &kbase = D.kbase;                                                              \
   int &ncell = D.ncell, &ovf = D.ovf, &bad = D.bad;                                                  \
-  Tip &trim = D.trim, &reach = D.reach;                                                              \
+  const int cold0 = hb >> 1;                               /* this half's record in pk_cold */         \
+  LdsInt reachm = { cold0 + PKC_REACHM }, aclip = { cold0 + PKC_ACLIP }, bclip = { cold0 + PKC_BCLIP }; \
+  LdsTip trim = pk_cold_tip(cold0 + PKC_TRIM), reach = pk_cold_tip(cold0 + PKC_REACH);               \
   (void) lane; (void) hb; (void) s; (void) KS; (void) S; (void) edge; (void) TS; (void) ave; (void) apk; (void) bpk; \
   (void) gcell; (void) cell_cap; (void) errw; (void) offa; (void) offb; (void) abase; (void) bbase;
 /* derived on use, so that they do not sit in registers across the wave loop */
@@ -98,8 +113,8 @@ __device__ __forceinline__ void pk_init(const ReportArgs &a, bool on, const PkPa
   aclip = REV ? -BIG : BIG;  bclip = REV ? BIG : -BIG;
   ncell = 2;
   kbase = diag - KS * 15;
-  trim.a = reach.a = mida;  trim.y = reach.y = besty;  trim.d = reach.d = 0;
-  trim.ha = reach.ha = 0;   trim.hb = reach.hb = 1;
+  trim.a = mida;  reach.a = mida;  trim.y = besty;  reach.y = besty;  trim.d = 0;  reach.d = 0;
+  trim.ha = 0;  reach.ha = 0;  trim.hb = 1;  reach.hb = 1;
   ovf = 0;  bad = 0;
   D.fin = 0;
 
@@ -110,9 +125,9 @@ __device__ __forceinline__ void pk_init(const ReportArgs &a, bool on, const PkPa
       int y = (mida - k) >> 1, nai, nbi, hai, hbi, ha = 0, hb_ = 1, v;
       int qa, qb;
       if (!REV)
-        { qa = ((y + k) + (TS - p.aoff)) / TS;  qb = (y + (TS - p.boff)) / TS; }
+        { qa = ((y + k) + TS) / TS;  qb = (y + (TS - p.boff)) / TS; }
       else
-        { qa = ((y + k) + (TS - p.aoff) - 1) / TS;  qb = (y + (TS - p.boff) - 1) / TS; }
+        { qa = ((y + k) + TS - 1) / TS;  qb = (y + (TS - p.boff) - 1) / TS; }
       nai = qa - 1 + PK_BIAS;  nbi = qb - 1 + PK_BIAS;
       hai = REV ? nai + 1 : nai;  hbi = REV ? nbi + 1 : nbi;       /* reverse: the true start, rounded up to the grid */
       if (s == 0)
@@ -152,8 +167,8 @@ __device__ __forceinline__ void pk_init(const ReportArgs &a, bool on, const PkPa
           hb_ = ncell++;  hbi = nbi;  nbi += S;
         }
       if (REV ? (v < besta) : (v > besta))
-        { besta = lasta = trim.a = v;
-          besty = trim.y = y;
+        { besta = lasta = v;  trim.a = v;
+          besty = y;  trim.y = y;
           trim.ha = ha;  trim.hb = hb_;
         }
       if (s == 15)
@@ -191,25 +206,26 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
         { if (bseq[besty] != 4 && aseq[besta - besty] != 4)                                            \
             more = 1;                                                                                  \
         }                                                                                              \
-      { const bool ca_ = cl_ && (REV ? (low <= aclip) : (hgh >= aclip));                               \
-        const int  sl_ = ca_ ? KS * (aclip - kbase) : 0;                                               \
+      const int acl_ = aclip, bcl_ = bclip;                                                            \
+      { const bool ca_ = cl_ && (REV ? (low <= acl_) : (hgh >= acl_));                                 \
+        const int  sl_ = ca_ ? KS * (acl_ - kbase) : 0;                                                \
         const int  mm_ = hget(m_, hb, sl_), vv_ = hget(rV, hb, sl_);                                   \
         const int  ha_ = hget(rHA, hb, sl_), hb2_ = hget(rHB, hb, sl_);                                \
         if (ca_)                                                                                       \
-          { if (REV) low = aclip + 1; else hgh = aclip - 1;                                            \
+          { if (REV) low = acl_ + 1; else hgh = acl_ - 1;                                              \
             if (reachm <= mm_)                                                                         \
-              { reachm = mm_; reach.a = vv_; reach.y = (vv_ - aclip) / 2; reach.d = dif;               \
+              { reachm = mm_; reach.a = vv_; reach.y = (vv_ - acl_) / 2; reach.d = dif;                \
                 reach.ha = ha_ & PK_HMASK; reach.hb = hb2_ & PK_HMASK; }                               \
           }                                                                                            \
       }                                                                                                \
-      { const bool cb_ = cl_ && (REV ? (hgh >= bclip) : (low <= bclip));                               \
-        const int  sl_ = cb_ ? KS * (bclip - kbase) : 0;                                               \
+      { const bool cb_ = cl_ && (REV ? (hgh >= bcl_) : (low <= bcl_));                                 \
+        const int  sl_ = cb_ ? KS * (bcl_ - kbase) : 0;                                                \
         const int  mm_ = hget(m_, hb, sl_), vv_ = hget(rV, hb, sl_);                                   \
         const int  ha_ = hget(rHA, hb, sl_), hb2_ = hget(rHB, hb, sl_);                                \
         if (cb_)                                                                                       \
-          { if (REV) hgh = bclip - 1; else low = bclip + 1;                                            \
+          { if (REV) hgh = bcl_ - 1; else low = bcl_ + 1;                                              \
             if (reachm <= mm_)                                                                         \
-              { reachm = mm_; reach.a = vv_; reach.y = (vv_ - bclip) / 2; reach.d = dif;               \
+              { reachm = mm_; reach.a = vv_; reach.y = (vv_ - bcl_) / 2; reach.d = dif;                \
                 reach.ha = ha_ & PK_HMASK; reach.hb = hb2_ & PK_HMASK; }                               \
           }                                                                                            \
       }                                                                                                \
@@ -532,9 +548,10 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
  * direction there (through wave_mem<REV> if it outgrows the wavefront too).  Called for one half at a time with every
  * lane active; hsel = that half's lane base (0 or 32).  *Dp, *io are per-lane copies: only the half's lanes are changed. */
 template <int REV>
-__device__ __noinline__ void pk_solo(const ReportArgs &a, const u32 *trimtab, SlotScratch sc, PkPair p, int hsel, int mida,
+__device__ __noinline__ void pk_solo(int job, const u32 *trimtab, SlotScratch sc, PkPair p, int hsel, int mida,
                                      PkDir *Dp, LaneRegs *io)
-{ const int lane = lane_id();
+{ const ReportArgs &a = g_jobs[uni(job)];
+  const int lane = lane_id();
   const int KS = REV ? 1 : -1;
   const int TS = a.tspace;
   const int edge = REV ? BIG : -1;
@@ -550,7 +567,7 @@ __device__ __noinline__ void pk_solo(const ReportArgs &a, const u32 *trimtab, Sl
   c.ts = TS;  c.ave = a.ave_path;  c.reach = a.reach;
   c.score = a.score;  c.table = a.table;  c.trim8 = trimtab;
   c.minp = bcast_i(p.minp, src);  c.maxp = bcast_i(p.maxp, src);
-  c.aoff = bcast_i(p.aoff, src);  c.boff = bcast_i(p.boff, src);
+  c.aoff = 0;  c.boff = bcast_i(p.boff, src);
   c.st0 = PK_PTR_OF(DState *, sc.st0);  c.st1 = PK_PTR_OF(DState *, sc.st1);
   c.NA = PK_PTR_OF(int *, sc.NA);  c.NB = PK_PTR_OF(int *, sc.NB);
   c.koff = c.blen + 8;  c.ring = a.span;
@@ -560,13 +577,14 @@ __device__ __noinline__ void pk_solo(const ReportArgs &a, const u32 *trimtab, Sl
 #undef PK_PTR_OF
   ws.low = bcast_i(Dp->low, src);  ws.hgh = bcast_i(Dp->hgh, src);  ws.dif = bcast_i(Dp->dif, src);
   ws.besta = bcast_i(Dp->besta, src);  ws.besty = bcast_i(Dp->besty, src);  ws.lasta = bcast_i(Dp->lasta, src);
-  ws.more = bcast_i(Dp->more, src);  ws.reachm = bcast_i(Dp->reachm, src);
-  ws.aclip = bcast_i(Dp->aclip, src);  ws.bclip = bcast_i(Dp->bclip, src);
+  int *const cold = pk_cold + (hsel >> 1);                  /* the half's event record (every lane reads the same words) */
+  ws.more = bcast_i(Dp->more, src);  ws.reachm = uni(cold[PKC_REACHM]);
+  ws.aclip = uni(cold[PKC_ACLIP]);  ws.bclip = uni(cold[PKC_BCLIP]);
   ws.ncell = (u32) bcast_i(Dp->ncell, src);
-  ws.trim.a = bcast_i(Dp->trim.a, src);  ws.trim.y = bcast_i(Dp->trim.y, src);  ws.trim.d = bcast_i(Dp->trim.d, src);
-  ws.trim.ha = bcast_i(Dp->trim.ha, src);  ws.trim.hb = bcast_i(Dp->trim.hb, src);
-  ws.reach.a = bcast_i(Dp->reach.a, src);  ws.reach.y = bcast_i(Dp->reach.y, src);  ws.reach.d = bcast_i(Dp->reach.d, src);
-  ws.reach.ha = bcast_i(Dp->reach.ha, src);  ws.reach.hb = bcast_i(Dp->reach.hb, src);
+  ws.trim.a = uni(cold[PKC_TRIM]);  ws.trim.y = uni(cold[PKC_TRIM + 1]);  ws.trim.d = uni(cold[PKC_TRIM + 2]);
+  ws.trim.ha = uni(cold[PKC_TRIM + 3]);  ws.trim.hb = uni(cold[PKC_TRIM + 4]);
+  ws.reach.a = uni(cold[PKC_REACH]);  ws.reach.y = uni(cold[PKC_REACH + 1]);  ws.reach.d = uni(cold[PKC_REACH + 2]);
+  ws.reach.ha = uni(cold[PKC_REACH + 3]);  ws.reach.hb = uni(cold[PKC_REACH + 4]);
   ws.stopped = 0;  ws.bad = 0;  ws.narrow = 0;
   /* the half's band into the 64-lane layout (lane (k & 63) owns diagonal k) */
   LaneRegs r;
@@ -615,10 +633,14 @@ __device__ __noinline__ void pk_solo(const ReportArgs &a, const u32 *trimtab, Sl
     }
   if ((lane & 32) == hsel)
     { Dp->low = ws.low;  Dp->hgh = ws.hgh;  Dp->dif = ws.dif;  Dp->besta = ws.besta;  Dp->besty = ws.besty;
-      Dp->lasta = ws.lasta;  Dp->more = (ws.narrow ? ws.more : 0);  Dp->reachm = ws.reachm;
-      Dp->aclip = ws.aclip;  Dp->bclip = ws.bclip;  Dp->ncell = (int) ws.ncell;
-      Dp->trim = ws.trim;  Dp->reach = ws.reach;
+      Dp->lasta = ws.lasta;  Dp->more = (ws.narrow ? ws.more : 0);
+      Dp->ncell = (int) ws.ncell;
     }
+  cold[PKC_REACHM] = ws.reachm;  cold[PKC_ACLIP] = ws.aclip;  cold[PKC_BCLIP] = ws.bclip;
+  cold[PKC_TRIM] = ws.trim.a;  cold[PKC_TRIM + 1] = ws.trim.y;  cold[PKC_TRIM + 2] = ws.trim.d;
+  cold[PKC_TRIM + 3] = ws.trim.ha;  cold[PKC_TRIM + 4] = ws.trim.hb;
+  cold[PKC_REACH] = ws.reach.a;  cold[PKC_REACH + 1] = ws.reach.y;  cold[PKC_REACH + 2] = ws.reach.d;
+  cold[PKC_REACH + 3] = ws.reach.ha;  cold[PKC_REACH + 4] = ws.reach.hb;
 }
 
 /* End point and trace points of one direction (align.c:1001-1118 / 1699-1898) for the halves with `fin`: the first
@@ -780,9 +802,10 @@ __device__ __noinline__ void pk_finish(Cell *cells, u16 *atrace, u16 *btrace, bo
 struct PkOut { int x, y, d, atlen, btlen, aback, bback; };
 
 template <int REV>
-__device__ __noinline__ void pk_pass(const ReportArgs &a, const u32 *trimtab, SlotScratch sc, int task_, PkPair p, u32 cbase,
+__device__ __noinline__ void pk_pass(int job, const u32 *trimtab, SlotScratch sc, int task_, PkPair p, u32 cbase,
                                      int diag, int mida, PkOut *out)
-{ const bool task = task_ != 0;
+{ const ReportArgs &a = g_jobs[uni(job)];
+  const bool task = task_ != 0;
   PkDir D;
   int rV, rHA, rHB, rNA, rNB;
   u64 rT;
@@ -804,7 +827,7 @@ __device__ __noinline__ void pk_pass(const ReportArgs &a, const u32 *trimtab, Sl
           { PkDir Dc = D;                     /* copies: what a noinline callee may write must not pin the loop's state to memory */
             LaneRegs io;
             io.V = rV;  io.HA = rHA;  io.HB = rHB;  io.NA = rNA;  io.NB = rNB;  io.T = rT;
-            pk_solo<REV>(a, trimtab, sc, p, h, bcast_i(mida, h), &Dc, &io);
+            pk_solo<REV>(a.job, trimtab, sc, p, h, bcast_i(mida, h), &Dc, &io);
             D = Dc;
             rV = io.V;  rHA = io.HA;  rHB = io.HB;  rNA = io.NA;  rNB = io.NB;  rT = io.T;
           }
@@ -817,12 +840,14 @@ __device__ __noinline__ void pk_pass(const ReportArgs &a, const u32 *trimtab, Sl
   const unsigned long long pf_t2 = wall_clock64();
 #endif
   /* the direction's end point: the trim point, or the reach candidate (align.c:1009-1016) */
-  int ta = D.trim.a, ty = D.trim.y, td = D.trim.d, tha = D.trim.ha, thb = D.trim.hb;
-  if (D.reachm >= 0 && a.reach)
-    { ta = D.reach.a;  ty = D.reach.y;  td = D.reach.d;  tha = D.reach.ha;  thb = D.reach.hb; }
+  const int *const cold = pk_cold + ((lane_id() & 32) >> 1);
+  const int rm = cold[PKC_REACHM];
+  int ta = cold[PKC_TRIM], ty = cold[PKC_TRIM + 1], td = cold[PKC_TRIM + 2], tha = cold[PKC_TRIM + 3], thb = cold[PKC_TRIM + 4];
+  if (rm >= 0 && a.reach)
+    { ta = cold[PKC_REACH];  ty = cold[PKC_REACH + 1];  td = cold[PKC_REACH + 2];  tha = cold[PKC_REACH + 3];  thb = cold[PKC_REACH + 4]; }
   int ox = 0, oy = 0, od = 0, atl = out->atlen, btl = out->btlen, ab = out->aback, bb = out->bback;
-  pk_finish<REV>(sc.cells, sc.atr, sc.btr, task && !D.bad, a.tspace, p.aoff, p.boff, a.reach,
-                 4 * (p.alen + p.blen) + 1024, &a.counters[3], mida, D.reachm, ta, ty, td, tha, thb,
+  pk_finish<REV>(sc.cells, sc.atr, sc.btr, task && !D.bad, a.tspace, 0, p.boff, a.reach,
+                 4 * (p.alen + p.blen) + 1024, &a.counters[3], mida, rm, ta, ty, td, tha, thb,
                  &ox, &oy, &od, &atl, &btl, &ab, &bb);
   out->x = ox;  out->y = oy;  out->d = od;  out->atlen = atl;  out->btlen = btl;  out->aback = ab;  out->bback = bb;
 #ifdef DAMAR_PROF
@@ -871,7 +896,7 @@ __device__ __forceinline__ void pk_emit(const ReportArgs &a, const SlotScratch &
             { LaRecord rec;
               rec.abpos = r.abpos;  rec.bbpos = r.bbpos;  rec.aepos = r.aepos;  rec.bepos = r.bepos;
               rec.diffs = r.diffs;  rec.atlen = r.atlen;  rec.btlen = r.btlen;
-              rec.aread = ar;  rec.bread = br;  rec.item = item;  rec.seq = seq;  rec.toff = to;
+              rec.aread = ar;  rec.bread = br;  rec.item = item;  rec.seq = seq | ((u32) a.job << DAMAR_SEQ_BITS);  rec.toff = to;
               a.recs[ri] = rec;
             }
         }
@@ -883,16 +908,18 @@ __device__ __forceinline__ void pk_emit(const ReportArgs &a, const SlotScratch &
 enum { PK_ITEM = 0, PK_PANEL, PK_FIRE, PK_DONE };
 
 #ifndef PK_WAVES
-#define PK_WAVES 4                      /* resident wavefronts per SIMD the packed kernel is compiled for (VGPR budget 512 / PK_WAVES).
-                                           Measured report ms per config-2 step: 4 -> 356; 5 -> 347 when the wave loop happens to stay free of
-                                           spills, 845 when it does not (18 scratch accesses per step after an unrelated edit); 6 -> 676 */
+#define PK_WAVES 6                      /* resident wavefronts per SIMD the packed kernel is compiled for (VGPR budget 512 / PK_WAVES).
+                                           Report ms per config-2 step with the event state of a direction parked in LDS (pk_cold):
+                                           4 -> 327, 5 -> 291 (wave loop free of spills in both directions), 6 -> 286 (a dozen
+                                           reloads per step in the reverse loop), 7 spills throughout.  Limiting the launch to
+                                           1 / 2 / 3 / 4 wavefronts per SIMD (DAMAR_SLOTS) gives 1073 / 556 / 407 / 337 ms: the
+                                           kernel is bound by how long ONE wavefront takes per step, residency is what hides it */
 #endif
 int damar_report2_waves_per_simd(void) { return PK_WAVES; }
 
-__global__ __launch_bounds__(64, PK_WAVES)
-void report2_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
-{ __shared__ u32 trimtab[256];
-  const int lane = lane_id(), hb = lane & 32, s = lane & 31;
+/* one job of the launch: the two halves pull read pairs (or batch tasks) from its queue until it is empty */
+__device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trimtab, const LaTask *tasks, u32 ntasks)
+{ const int lane = lane_id(), hb = lane & 32, s = lane & 31;
   const int slot = 2 * (int) blockIdx.x + (hb >> 5);
   const SlotScratch sc = slot_scratch(a, slot);
   const u32 cbase = (u32) slot * a.cell_cap;
@@ -903,19 +930,12 @@ void report2_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
   const int mind = (-a.bblk.maxlen) >> W, maxd = a.ablk.maxlen >> W;
   const bool batch = tasks != NULL;
 
-  pk_fill_trimtab(trimtab, a.mscore, a.dscore);
-  __syncthreads();
-#ifdef DAMAR_PROF
-  struct PfExit { unsigned long long t0; __device__ ~PfExit() { unsigned long long d = wall_clock64() - t0;
-    if (lane_id() == 0) { atomicAdd(&g_prof[23], d); atomicAdd(&g_prof[25], 1ull); atomicMax(&g_prof[24], d); } } } pf_exit = { (unsigned long long) wall_clock64() };
-#endif
-
   int  phase = PK_ITEM;
   u32  item = 0, seq = 0;
   u64  nidx = 0, cpair = 0, lidx = 0, end = 0, h2 = 0, fp = 0;
   int  ar = 0, br = 0, amark2 = 0, clo = BIG, chi = -BIG;
   PkPair p;
-  p.a0 = p.b0 = 0;  p.alen = p.blen = 0;  p.minp = -BIG;  p.maxp = BIG;  p.aoff = p.boff = 0;
+  p.a0 = p.b0 = 0;  p.alen = p.blen = 0;  p.minp = -BIG;  p.maxp = BIG;  p.boff = 0;
 
   for (;;)
     { bool task = false;
@@ -926,7 +946,7 @@ void report2_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
         { if (phase == PK_ITEM && !task)
             { u32 it = 0;
               if (s == 0)
-                it = atomicAdd(&a.counters[0], 1u);
+                it = atomicAdd(a.cursor, 1u);
               it = (u32) hget((int) it, hb, 0);
               if (it >= (batch ? ntasks : a.nwork))
                 phase = PK_DONE;
@@ -1069,16 +1089,15 @@ void report2_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
       const bool selfie = (a.ablk.bases + p.a0 == a.bblk.bases + p.b0);
       p.minp = (selfie && diag >= 0) ? 1 : -BIG;
       p.maxp = (selfie && diag <= 0) ? -1 : BIG;
-      p.aoff = 0;
       p.boff = (a.comp & 1) ? (p.blen % a.tspace) : 0;
       if (task && s == 0 && !batch)
-        atomicAdd(&a.counters[4], 1u);
+        atomicAdd(a.nfilt, 1u);
       LaResult r;
       { PkOut o;
         o.x = o.y = o.d = o.atlen = o.btlen = o.aback = o.bback = 0;
-        pk_pass<0>(a, trimtab, sc, task ? 1 : 0, p, cbase, diag, anti, &o);
+        pk_pass<0>(a.job, trimtab, sc, task ? 1 : 0, p, cbase, diag, anti, &o);
         r.aepos = o.x;  r.bepos = o.y;  r.diffs = o.d;
-        pk_pass<1>(a, trimtab, sc, task ? 1 : 0, p, cbase, diag, anti, &o);
+        pk_pass<1>(a.job, trimtab, sc, task ? 1 : 0, p, cbase, diag, anti, &o);
         r.abpos = o.x;  r.bbpos = o.y;  r.diffs += o.d;
         r.atlen = o.atlen;  r.btlen = o.btlen;  r.aback = o.aback;  r.bback = o.bback;
       }
@@ -1124,8 +1143,20 @@ void report2_kernel(ReportArgs a, const LaTask *tasks, u32 ntasks)
     }
 }
 
-void damar_launch_report2(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st)
-{ if ((tasks ? ntasks : a->nwork) == 0)
-    return;
-  hipLaunchKernelGGL(report2_kernel, dim3(nslots / 2), dim3(64), 0, st, *a, tasks, ntasks);
+__global__ __launch_bounds__(64, PK_WAVES)
+void report2_kernel(int njobs, const LaTask *tasks, u32 ntasks)
+{ __shared__ u32 trimtab[256];
+  pk_fill_trimtab(trimtab, g_jobs[0].mscore, g_jobs[0].dscore);
+  __syncthreads();
+#ifdef DAMAR_PROF
+  struct PfExit { unsigned long long t0; __device__ ~PfExit() { unsigned long long d = wall_clock64() - t0;
+    if (lane_id() == 0) { atomicAdd(&g_prof[23], d); atomicAdd(&g_prof[25], 1ull); atomicMax(&g_prof[24], d); } } } pf_exit = { (unsigned long long) wall_clock64() };
+#endif
+  for (int turn = 0; turn < njobs; turn++)
+    report2_job(g_jobs[((int) blockIdx.x + turn) % njobs], trimtab, tasks, ntasks);
+}
+
+void damar_launch_report2(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st)
+{ jobs_upload(jobs, njobs, st);
+  hipLaunchKernelGGL(report2_kernel, dim3(nslots / 2), dim3(64), 0, st, njobs, tasks, ntasks);
 }

@@ -94,8 +94,11 @@ static int64        G_cnt[8];
 
 struct Arena { char *base; size_t cap, top; };
 static Arena G_work = { NULL, 0, 0 };       /* per-call temporaries, grow-only */
-static Arena G_hits = { NULL, 0, 0 };       /* seed pairs of the current Match_Filter   */
-static Arena G_ord  = { NULL, 0, 0 };       /* processing order of the work list        */
+static Arena G_hitsJ[DAMAR_MAX_JOBS];       /* sorted seed pairs of the comparisons of the current report launch, one arena each
+                                               (12 B per seed pair: what the report kernel reads) */
+static Arena G_ordJ[DAMAR_MAX_JOBS];        /* their work lists and processing orders   */
+static Arena G_tmp  = { NULL, 0, 0 };       /* sort ping-pong partner, flags, scan space of the seed stage: shared by the
+                                               comparisons (the stream orders them), 20 B per seed pair */
 
 static void *dmalloc(size_t n)
 { void *p = NULL;
@@ -679,8 +682,9 @@ static int default_slots(void)
 static int G_ring = 0;
 /* pebbles per slot to start with: an alignment drops about 200 per kb and direction; a pool that overflows is
    quadrupled and the launch repeated.  Kept small because the driver clears what it hands out: an 8 GB pool
-   (65536 cells x 8192 slots) cost every process 0.25 - 0.8 s in hipMalloc. */
-#define DEFAULT_CELLS (1u << 14)
+   (65536 cells x 8192 slots) cost every process 0.25 - 0.8 s in hipMalloc, and the 6.6 GB of 12288 slots with
+   16384 cells and rings of 4096 diagonals 0.2 - 0.7 s. */
+#define DEFAULT_CELLS (1u << 13)
 
 /* the pebble pool of a slot after an overflow: a chain head holds 18 bits of pebble index (report.hip PK_HBITS) */
 static u32 grow_cells(u32 cell_cap)
@@ -701,12 +705,12 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
       G_last_d2h = NULL;
     }
   /* The band state of a slot (used only while a band is wider than the 64 lanes) is a ring of G_ring
-     diagonals, not one entry per diagonal of the pair: 4096 instead of alen + blen keeps the scratch of
-     8192 slots at a few GB (the driver stalls for seconds whenever a process first grows past ~24 GB).
+     diagonals, not one entry per diagonal of the pair: 1024 instead of alen + blen keeps the scratch of
+     12288 slots at 2.5 GB (the driver stalls for seconds whenever a process first grows past ~24 GB).
      A band that outgrows the ring raises DAMAR_ERR_WIDE and the launch is repeated with a larger one. */
   if (G_ring == 0)
     { const char *e = getenv("DAMAR_RING");
-      G_ring = e ? atoi(e) : 4096;
+      G_ring = e ? atoi(e) : 1024;
       if (G_ring < 128) G_ring = 128;
       while (G_ring & (G_ring - 1)) G_ring += G_ring & -G_ring;      /* next power of two */
     }
@@ -773,8 +777,8 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
                 now_ms() - g2, RS.span, RS.bwidth, RS.cell_cap);
     }
   if (RS.counters == NULL)
-    { RS.counters = (u32 *) dmalloc(64);
-      RS.tables   = (short *) dmalloc(sizeof(short) * 65536);
+    { RS.counters = (u32 *) dmalloc(sizeof(u32) * DAMAR_COUNTER_WORDS);
+      RS.tables   = (short *) dmalloc(sizeof(short) * 65536 * DAMAR_MAX_JOBS);
     }
   HIP_CHECK(hipMemsetAsync(RS.buckets, 0, sizeof(int) * (size_t) RS.bucket_stride * RS.nslots, G_st));
 }
@@ -797,8 +801,9 @@ static void scratch_outputs(u32 rec_cap, u32 tpool_cap)
 }
 
 static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const damar_dev_block *bb,
-                             int comp, int self, Align_Spec *spec)
+                             int comp, int self, Align_Spec *spec, int job = 0)
 { memset(ra, 0, sizeof(*ra));
+  ra->job = job;
   ra->ablk = ab->d;  ra->bblk = bb->d;
   ra->kmer = P_kmer;  ra->hitmin = P_hitmin;  ra->binshift = P_binshift;
   ra->minhit = (P_hitmin - 1) / P_kmer + 1;
@@ -810,10 +815,10 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   /* SCORE/TABLE of this Align_Spec, every time (128 KB): remembering "the tables of spec X are
      already up" by X's address went wrong when a freed spec's address came back for a new one
      with another -e */
-  HIP_CHECK(hipMemcpyAsync(RS.tables, damar_spec_score_table(spec), sizeof(short) * 65536,
+  HIP_CHECK(hipMemcpyAsync(RS.tables + (size_t) job * 65536, damar_spec_score_table(spec), sizeof(short) * 65536,
                            hipMemcpyHostToDevice, G_st));
-  ra->score = RS.tables;
-  ra->table = RS.tables + 32768;
+  ra->score = RS.tables + (size_t) job * 65536;
+  ra->table = ra->score + 32768;
   { const int16 *sc = damar_spec_score_table(spec);          /* SCORE[x] = matches * mscore - (15 - matches) * dscore */
     ra->mscore = sc[32767] / 15;
     ra->dscore = -sc[0] / 15;
@@ -827,6 +832,8 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   ra->recs = RS.recs;  ra->rec_cap = RS.rec_cap;
   ra->tpool = RS.tpool;  ra->tpool_cap = RS.tpool_cap;
   ra->counters = RS.counters;
+  ra->cursor = RS.counters + 16 + job;
+  ra->nfilt  = RS.counters + 32 + job;
 }
 
 
@@ -870,6 +877,7 @@ struct HostBuf
   size_t    nrec, ntp;
   hipEvent_t e0, e1;               /* around the download; e1 is what the tail thread waits for */
   bool      pending;
+  int       users;                 /* comparisons of the launch whose tails have not run yet */
 };
 static std::mutex             &HB_mu   = *new std::mutex();
 static std::vector<HostBuf *> &HB_free = *new std::vector<HostBuf *>();
@@ -971,23 +979,34 @@ static int tail_threads(void)
   return n;
 }
 
-static int64 run_tail(LaRecord *recs, size_t nrecs, const u16 *tpool,
-                      const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec)
+static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
+                      const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec,
+                      int jobid = 0, int njobs = 1)
 { const int ts = Trace_Spacing(spec);
+  /* a launch over several comparisons: the records of this one (top byte of seq) */
+  std::vector<u32> mine;
+  size_t nrecs = nrecs_all;
+  if (njobs > 1)
+    { for (size_t q = 0; q < nrecs_all; q++)
+        if ((int) (recs[q].seq >> DAMAR_SEQ_BITS) == jobid)
+          mine.push_back((u32) q);
+      nrecs = mine.size();
+    }
+  auto at = [&](size_t q) -> size_t { return njobs > 1 ? mine[q] : q; };
   /* (work item, sequence) order = the reference's order of read pairs and of the alignments
      inside one: a counting sort on the item (a wave emits the records of its item in sequence
      order; the insertion pass below only guards that) */
   std::vector<u32> ord(nrecs);
   { u32 maxitem = 0;
     for (size_t q = 0; q < nrecs; q++)
-      if (recs[q].item > maxitem) maxitem = recs[q].item;
+      if (recs[at(q)].item > maxitem) maxitem = recs[at(q)].item;
     std::vector<u32> first((size_t) maxitem + 2, 0);
     for (size_t q = 0; q < nrecs; q++)
-      first[recs[q].item + 1] += 1;
+      first[recs[at(q)].item + 1] += 1;
     for (size_t q = 1; q < first.size(); q++)
       first[q] += first[q - 1];
     for (size_t q = 0; q < nrecs; q++)
-      ord[first[recs[q].item]++] = (u32) q;
+      ord[first[recs[at(q)].item]++] = (u32) at(q);
     for (size_t q = 1; q < nrecs; q++)
       { const u32 x = ord[q];
         size_t r = q;
@@ -1050,6 +1069,7 @@ static int64 run_tail(LaRecord *recs, size_t nrecs, const u16 *tpool,
 struct TailJob
 { int kind;                                  /* 0 = tail of one Match_Filter, 1 = write + reset */
   HostBuf *hb;
+  int  jobid, njobs;                         /* which comparison of the launch whose records hb holds */
   HITS_DB ablock, bblock;                    /* copies of the block records: the caller may reuse its structs
                                                 (the read tables and bases they point to must stay alive) */
   int  self, comp;
@@ -1120,13 +1140,15 @@ static void tail_worker(void)
               HIP_CHECK(hipSetDevice(G_device));          /* the current device is a per-thread setting */
               HIP_CHECK(hipEventSynchronize(job->hb->e1));
               HIP_CHECK(hipEventElapsedTime(&ms, job->hb->e0, job->hb->e1));
+              job->hb->pending = false;                   /* (the other comparisons of the launch share the buffer) */
               std::lock_guard<std::mutex> lk(A_mu);
               A_d2h_ms += ms;
               t0 = now_ms();
             }
           int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, &job->ablock, &job->bblock,
-                             job->self, job->comp, job->spec);
-          hostbuf_put(job->hb);
+                             job->self, job->comp, job->spec, job->jobid, job->njobs);
+          if (--job->hb->users == 0)
+            hostbuf_put(job->hb);
           delete job;
           std::lock_guard<std::mutex> lk(A_mu);
           A_ncheck += n;
@@ -1252,27 +1274,32 @@ static int64 sizeof_db(const HITS_DB *db)      /* db/DB.c:726 sizeof_DB without 
 }
 
 
-extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
-                            damar_dev_index *aidx, damar_dev_index *bidx,
-                            int self, int comp, Align_Spec *spec, int64 *counts)
-{ ensure_init();
-  const double h0 = now_ms();
-  double h1 = h0, h2 = h0, h3 = h0, h4 = h0;
-  int64 nhits = 0, nfilt = 0, ncheck = 0;
-  memset(G_cnt, 0, sizeof(G_cnt));
-  for (int i = DAMAR_T_MERGE; i < DAMAR_T_COUNT; i++)
-    G_ms[i] = 0;
-  if (counts)
-    counts[0] = counts[1] = counts[2] = 0;
+/* What the seed stage of one comparison leaves on the device for the report launch. */
+struct Front
+{ const u64 *keys;  const u32 *vals;  u64 total;
+  const u32 *work;  u32 nwork;
+  const u32 *order;
+  int pbits, abits;
+  size_t bytes;                 /* of the two arenas that hold the above */
+};
+
+/* Seed stage of one comparison (filter.c:2603-2760): merge-count, scan, emit, seed sort, work list and its
+   processing order, into the arenas of job slot `slot`.  Returns false when there is nothing to report. */
+static bool match_front(damar_match_job *job, int slot, Front *f)
+{ const HITS_DB *ablock = job->ablock, *bblock = job->bblock;
+  damar_dev_index *aidx = job->aidx, *bidx = job->bidx;
+  const int self = job->self, comp = job->comp;
+  Arena &G_hits = G_hitsJ[slot], &G_ord = G_ordJ[slot];
+  int64 nhits = 0;
+  memset(f, 0, sizeof(*f));
+  job->counts[0] = job->counts[1] = job->counts[2] = 0;
   if (aidx == NULL || bidx == NULL || aidx->n == 0 || bidx->n == 0)
-    return;
+    return false;
   if (aidx->kbits != bidx->kbits || aidx->tbits > aidx->kbits)
     { fprintf(stderr, "damar: internal error, index parameters differ\n");
       die();
     }
-
   const u32 alen = aidx->n, blen = bidx->n;
-  const int ts = Trace_Spacing(spec);
   MergeArgs m;
   memset(&m, 0, sizeof(m));
   m.acode = aidx->codes;  m.apos = aidx->pos;  m.alen = alen;  m.atab = aidx->table;
@@ -1397,44 +1424,55 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
       die();
     }
   if (total == 0)
-    { if (counts) counts[0] = 0;
-      return;
-    }
+    return false;
 
-  /* hits known: a second arena holds the seed pairs, their sort space and the work list */
-  arena_reserve(&G_hits, 2 * pad256(sizeof(u64) * (size_t) total) + 4 * pad256(sizeof(u32) * (size_t) total) +
+  /* hits known.  The sorted seed pairs stay in this comparison's own arena until the report launch; everything else
+     of the seed stage lives in an arena the comparisons share.  The sort ping-pongs: it is started from the side that
+     makes the result land in the comparison's arena (the number of passes is known). */
+  const int sbits = m.pbits + m.abits + bbits;
+  const int spasses = (sbits + 7) / 8;                        /* sort_scan.hip: 8 bits per pass */
+  arena_reserve(&G_hits, pad256(sizeof(u64) * (size_t) total) + pad256(sizeof(u32) * (size_t) total) + 4096);
+  arena_reserve(&G_tmp,  pad256(sizeof(u64) * (size_t) total) + 3 * pad256(sizeof(u32) * (size_t) total) +
                          pad256(damar_sort_workspace_bytes(total)) + pad256(damar_scan_workspace_bytes(total)) + 8192);
-  u64 *k0 = (u64 *) arena_take(&G_hits, sizeof(u64) * (size_t) total);
-  u64 *k1 = (u64 *) arena_take(&G_hits, sizeof(u64) * (size_t) total);
-  u32 *v0 = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
-  u32 *v1 = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
-  void *sw = arena_take(&G_hits, damar_sort_workspace_bytes(total));
-  u32 *flags = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
-  u32 *foff  = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
-  void *scw2 = arena_take(&G_hits, damar_scan_workspace_bytes(total));
-  u64 *sends = (u64 *) arena_take(&G_hits, 64 * sizeof(u64));
+  u64 *pk = (u64 *) arena_take(&G_hits, sizeof(u64) * (size_t) total);
+  u32 *pv = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
+  u64 *tk = (u64 *) arena_take(&G_tmp, sizeof(u64) * (size_t) total);
+  u32 *tv = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
+  u64 *k0 = (spasses & 1) ? tk : pk, *k1 = (spasses & 1) ? pk : tk;
+  u32 *v0 = (spasses & 1) ? tv : pv, *v1 = (spasses & 1) ? pv : tv;
+  void *sw = arena_take(&G_tmp, damar_sort_workspace_bytes(total));
+  u32 *flags = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
+  u32 *foff  = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
+  void *scw2 = arena_take(&G_tmp, damar_scan_workspace_bytes(total));
+  u64 *sends = (u64 *) arena_take(&G_tmp, 64 * sizeof(u64));
 
   damar_launch_merge_emit(&m, cnt, (const u32 *) scw, jb, total, k0, v0, G_st);
   stage("merge_emit");
   tick(1);
-  int side = damar_radix_sort_u64(k0, v0, k1, v1, total, m.pbits + m.abits + bbits, sw, G_st);
+  int side = damar_radix_sort_u64(k0, v0, k1, v1, total, sbits, sw, G_st);
   u64 *keys = side ? k1 : k0;
   u32 *vals = side ? v1 : v0;
+  if (keys != pk)
+    { fprintf(stderr, "damar: internal error, the seed sort ended on the wrong side\n");
+      die();
+    }
   stage("seed_sort");
   tick(2);
 
   /* ---- work list ---- */
   const int minhit = (P_hitmin - 1) / P_kmer + 1;
   u64 nwork64 = 0;
-  u32 *heads = side ? (u32 *) k0 : (u32 *) k1;         /* the idle key buffer holds the run heads */
+  u32 *heads = (u32 *) tk;                              /* the idle key buffer holds the run heads */
   damar_launch_pair_heads(keys, total, m.pbits, m.abits, minhit, P_nshift, sends, (u64 *) foff /* bit words */,
                           scw2, tot, heads, G_st);
   stage("run_heads");
   HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
   HIP_CHECK(hipStreamSynchronize(G_st));
   const u32 nheads = (u32) nwork64;
-  /* screen the heads (dense, one thread each), compact the survivors: flags/foff are reused */
-  u32 *work = heads + pad256(sizeof(u32) * (size_t) nheads) / sizeof(u32);
+  /* screen the heads (dense, one thread each), compact the survivors: flags/foff are reused.  The work list and
+     its processing order outlive the seed stage: the comparison's second arena */
+  arena_reserve(&G_ord, 5 * pad256(sizeof(u32) * (size_t) nheads) + pad256(damar_sort_workspace_bytes(nheads)) + 8192);
+  u32 *work = (u32 *) arena_take(&G_ord, sizeof(u32) * ((size_t) nheads + 1));
   nwork64 = 0;
   if (nheads > 0)
     { damar_launch_pair_screen(keys, vals, total, m.pbits, heads, nheads, minhit, P_binshift, P_kmer, P_hitmin, m.abits,
@@ -1447,10 +1485,11 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   tick(3);
   HIP_CHECK(hipStreamSynchronize(G_st));
   const u32 nwork = (u32) nwork64;
-  G_ms[DAMAR_T_MERGE] = lap(0, 1);
-  G_ms[DAMAR_T_SSORT] = lap(1, 2);
-  G_ms[DAMAR_T_WORK]  = lap(2, 3);
-  G_cnt[0] = nhits;  G_cnt[1] = nwork;
+  G_ms[DAMAR_T_MERGE] += lap(0, 1);
+  G_ms[DAMAR_T_SSORT] += lap(1, 2);
+  G_ms[DAMAR_T_WORK]  += lap(2, 3);
+  G_cnt[0] += nhits;  G_cnt[1] += nwork;
+  job->counts[0] = nhits;
 
   if (G_keep_seeds)
     { G_seed_keys.resize(total);  G_seed_vals.resize(total);
@@ -1459,7 +1498,6 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
       G_seed_pbits = m.pbits;  G_seed_abits = m.abits;
     }
 
-  h1 = now_ms();
   /* ---- largest pairs first (the order only schedules the kernel: records carry their work
           item's rank in the reference's order) ---- */
   const u32 *order = NULL;
@@ -1472,8 +1510,7 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
                                             9, 411 for 10), other n = runs of >= n seeds first */
     }
   if (nwork > 1 && order_mode > 0)
-    { arena_reserve(&G_ord, 4 * pad256(sizeof(u32) * (size_t) nwork) + pad256(damar_sort_workspace_bytes(nwork)) + 4096);
-      u32 *ok0 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
+    { u32 *ok0 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
       u32 *ov0 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
       u32 *ok1 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
       u32 *ov1 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
@@ -1485,135 +1522,201 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
       stage("work_order");
     }
 
-  h2 = now_ms();
-  /* ---- report kernel (retry with larger buffers if it reports an overflow) ---- */
-  HostBuf *hb = NULL;
-  u32 hc[16];
-  if (nwork > 0)
-    { u32 cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
-      u32 rec_cap  = std::max(RS.rec_cap, 2 * nwork + 4096);
-      u32 tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(RS.tpool_cap, (u64) rec_cap * 256u));
-      if (getenv("DAMAR_TEST_SMALL_CAPS") && RS.rec_cap == 0)      /* tests: start far too small, so that the
-                                                                      overflow flags and the re-launch are exercised */
-        { cell_cap = 64;  rec_cap = 16;  tp_cap = 512; }
-      for (int attempt = 0; ; attempt++)
-        { ReportArgs ra;
-          double q0 = now_ms();
-          scratch_prepare(ablock->maxlen, bblock->maxlen, P_binshift, ts, cell_cap);
-          double q1 = now_ms();
-          scratch_outputs(rec_cap, tp_cap);
-          double q2 = now_ms();
-          Q_ms[0] += q1 - q0;  Q_ms[1] += q2 - q1;
-          fill_report_args(&ra, aidx->blk, bidx->blk, comp, self, spec);
-          ra.keys = keys;  ra.vals = vals;  ra.nhits = total;
-          ra.work = work;  ra.nwork = nwork;
-          ra.pbits = m.pbits;  ra.abits = m.abits;
-          ra.order = order;
-          if (getenv("DAMAR_DUP_WORK") && order)     /* experiment: every item twice (timing only, output is garbage) */
-            { static u32 *dup = NULL;  static size_t dupn = 0;
-              const int f = atoi(getenv("DAMAR_DUP_WORK"));
-              if (dupn < (size_t) f * nwork)
-                { if (dup) HIP_CHECK(hipFree(dup));
-                  dupn = (size_t) f * nwork + 4096;
-                  HIP_CHECK(hipMalloc(&dup, 4 * dupn));
-                }
-              std::vector<u32> ho(nwork), hd((size_t) f * nwork);
-              HIP_CHECK(hipMemcpy(ho.data(), order, 4 * (size_t) nwork, hipMemcpyDeviceToHost));
-              for (size_t i = 0; i < (size_t) f * nwork; i++) hd[i] = ho[i / f];
-              HIP_CHECK(hipMemcpy(dup, hd.data(), 4 * hd.size(), hipMemcpyHostToDevice));
-              ra.order = dup;  ra.nwork = f * nwork;
-            }
-          HIP_CHECK(hipMemsetAsync(RS.counters, 0, 64, G_st));
-          tick(4);
-          stage("report_setup");
-          if (use_packed(&ra, ablock->maxlen, bblock->maxlen))
-            damar_launch_report2(&ra, NULL, 0, RS.nslots, G_st);
-          else
-            damar_launch_report(&ra, RS.nslots, G_st);
-          stage("report");
-          tick(5);
-          HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, G_st));
-          HIP_CHECK(hipStreamSynchronize(G_st));
-          HIP_CHECK(hipGetLastError());
-          G_ms[DAMAR_T_REPORT] += lap(4, 5);
-          if (hc[3] == 0)
-            break;
-          if ((hc[3] & DAMAR_ERR_BAND) && !(hc[3] & (DAMAR_ERR_CELLS | DAMAR_ERR_WIDE)))
-            { fprintf(stderr, "damar: FATAL: a Local_Alignment wave exceeded its loop bound (where=%u)\n", hc[6]);
-              die();
-            }
-          if (attempt >= 6)
-            { fprintf(stderr, "damar: FATAL: report kernel keeps overflowing its buffers (flags %u)\n", hc[3]);
-              die();
-            }
-          if (hc[3] & DAMAR_ERR_CELLS) cell_cap = grow_cells(cell_cap);
-          if (hc[3] & DAMAR_ERR_WIDE)  G_ring *= 4;
-          if (hc[3] & DAMAR_ERR_RECS)  rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
-          if (hc[3] & DAMAR_ERR_TPOOL)
-            { if (tp_cap >= 0xe0000000u)
-                { fprintf(stderr, "damar: FATAL: more than 2^32 trace values in one comparison, use smaller blocks\n");
-                  die();
-                }
-              tp_cap = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(2ull * tp_cap, (u64) hc[2] + 65536));
-            }
-          if (VERBOSE)
-            fprintf(stderr, "damar: report kernel overflow (flags %u), retrying with larger buffers\n", hc[3]);
-        }
-      tick(6);
-      h3 = now_ms();
-      hb = hostbuf_get(hc[1], hc[2]);
-      hipStream_t cs = A_on ? G_copy : G_st;
-      if (A_on)
-        HIP_CHECK(hipEventRecord(hb->e0, cs));       /* (the report kernel has completed: the host synced on it) */
-      if (hc[1] > 0)
-        { HIP_CHECK(hipMemcpyAsync(hb->recs, RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, cs));
-          HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, cs));
-        }
-      tick(7);
-      if (A_on)
-        { /* asynchronous mode: the download runs on its own stream beside the next Match_Filter's
-             merge and sorts; the tail thread waits for it, and so does the next report kernel
-             (which would overwrite the device buffers) */
-          HIP_CHECK(hipEventRecord(hb->e1, cs));
-          hb->pending = true;
-          G_last_d2h = hb->e1;
-        }
-      else
-        { HIP_CHECK(hipStreamSynchronize(G_st));
-          G_ms[DAMAR_T_D2H] = lap(6, 7);
-        }
-      nfilt = hc[4];
-      G_cnt[2] = hc[4];  G_cnt[3] = hc[1];  G_cnt[4] = hc[2];
-    }
 
-  h4 = now_ms();
-  /* ---- host tail: filter.c:2442-2483 per read pair (worker thread in asynchronous mode) ---- */
-  if (hb == NULL)
-    hb = hostbuf_get(0, 0);
+  f->keys = keys;  f->vals = vals;  f->total = total;
+  f->work = work;  f->nwork = nwork;  f->order = order;
+  f->pbits = m.pbits;  f->abits = m.abits;
+  f->bytes = G_hits.cap + G_ord.cap;
+  return nwork > 0;
+}
+
+/* One report launch over the comparisons jobs[0..n) whose seed stages are fr[0..n) (nwork > 0 each), the download of
+   its records, and the host tails in job order (filter.c:2442-2483 per read pair). */
+static void match_report(damar_match_job **jobs, const Front *fr, int n)
+{ HostBuf *hb = NULL;
+  u32 hc[DAMAR_COUNTER_WORDS];
+  int amax = 0, bmax = 0, tsmin = 0x7fffffff;
+  u64 nwork = 0;
+  for (int j = 0; j < n; j++)
+    { amax = std::max(amax, jobs[j]->ablock->maxlen);  bmax = std::max(bmax, jobs[j]->bblock->maxlen);
+      tsmin = std::min(tsmin, Trace_Spacing(jobs[j]->spec));
+      nwork += fr[j].nwork;
+    }
+  const double h2 = now_ms();
+  u32 cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
+  u32 rec_cap  = (u32) std::min<u64>(0x7fffffffu, std::max<u64>(RS.rec_cap, 2 * nwork + 4096));
+  u32 tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(RS.tpool_cap, (u64) rec_cap * 256u));
+  if (getenv("DAMAR_TEST_SMALL_CAPS") && RS.rec_cap == 0)      /* tests: start far too small, so that the
+                                                                  overflow flags and the re-launch are exercised */
+    { cell_cap = 64;  rec_cap = 16;  tp_cap = 512; }
+  for (int attempt = 0; ; attempt++)
+    { ReportArgs ra[DAMAR_MAX_JOBS];
+      double q0 = now_ms();
+      scratch_prepare(amax, bmax, P_binshift, tsmin, cell_cap);
+      double q1 = now_ms();
+      scratch_outputs(rec_cap, tp_cap);
+      double q2 = now_ms();
+      Q_ms[0] += q1 - q0;  Q_ms[1] += q2 - q1;
+      bool packed = true;
+      for (int j = 0; j < n; j++)
+        { fill_report_args(&ra[j], jobs[j]->aidx->blk, jobs[j]->bidx->blk, jobs[j]->comp, jobs[j]->self, jobs[j]->spec, j);
+          ra[j].keys = fr[j].keys;  ra[j].vals = fr[j].vals;  ra[j].nhits = fr[j].total;
+          ra[j].work = fr[j].work;  ra[j].nwork = fr[j].nwork;
+          ra[j].pbits = fr[j].pbits;  ra[j].abits = fr[j].abits;
+          ra[j].order = fr[j].order;
+          packed = packed && use_packed(&ra[j], amax, bmax);
+          if (ra[j].mscore != ra[0].mscore || ra[j].dscore != ra[0].dscore)
+            { fprintf(stderr, "damar: internal error, the comparisons of one report launch differ in their -e\n");
+              die();
+            }
+        }
+      HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
+      tick(4);
+      stage("report_setup");
+      if (packed)
+        damar_launch_report2(ra, n, NULL, 0, RS.nslots, G_st);
+      else
+        damar_launch_report(ra, n, RS.nslots, G_st);
+      stage("report");
+      tick(5);
+      HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      HIP_CHECK(hipGetLastError());
+      G_ms[DAMAR_T_REPORT] += lap(4, 5);
+      G_cnt[5] += 1;
+      if (hc[3] == 0)
+        break;
+      if ((hc[3] & DAMAR_ERR_BAND) && !(hc[3] & (DAMAR_ERR_CELLS | DAMAR_ERR_WIDE)))
+        { fprintf(stderr, "damar: FATAL: a Local_Alignment wave exceeded its loop bound (where=%u)\n", hc[6]);
+          die();
+        }
+      if (attempt >= 6)
+        { fprintf(stderr, "damar: FATAL: report kernel keeps overflowing its buffers (flags %u)\n", hc[3]);
+          die();
+        }
+      if (hc[3] & DAMAR_ERR_CELLS) cell_cap = grow_cells(cell_cap);
+      if (hc[3] & DAMAR_ERR_WIDE)  G_ring *= 4;
+      if (hc[3] & DAMAR_ERR_RECS)  rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
+      if (hc[3] & DAMAR_ERR_TPOOL)
+        { if (tp_cap >= 0xe0000000u)
+            { fprintf(stderr, "damar: FATAL: more than 2^32 trace values in one comparison, use smaller blocks\n");
+              die();
+            }
+          tp_cap = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(2ull * tp_cap, (u64) hc[2] + 65536));
+        }
+      if (VERBOSE)
+        fprintf(stderr, "damar: report kernel overflow (flags %u), retrying with larger buffers\n", hc[3]);
+    }
+  tick(6);
+  const double h3 = now_ms();
+  hb = hostbuf_get(hc[1], hc[2]);
+  hb->users = n;
+  hipStream_t cs = A_on ? G_copy : G_st;
   if (A_on)
-    { TailJob *job = new TailJob();
-      job->kind = 0;
-      job->hb = hb;
-      job->ablock = *ablock;  job->bblock = *bblock;  job->self = self;  job->comp = comp;  job->spec = spec;
-      async_submit(job);
+    HIP_CHECK(hipEventRecord(hb->e0, cs));       /* (the report kernel has completed: the host synced on it) */
+  if (hc[1] > 0)
+    { HIP_CHECK(hipMemcpyAsync(hb->recs, RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, cs));
+      HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, cs));
+    }
+  tick(7);
+  if (A_on)
+    { /* asynchronous mode: the download runs on its own stream beside the next comparison's merge and sorts; the
+         tail thread waits for it, and so does the next report kernel (which would overwrite the device buffers) */
+      HIP_CHECK(hipEventRecord(hb->e1, cs));
+      hb->pending = true;
+      G_last_d2h = hb->e1;
     }
   else
-    { double t0 = now_ms();
-      ncheck = run_tail(hb->recs, hb->nrec, hb->tpool, ablock, bblock, self, comp, spec);
-      hostbuf_put(hb);
-      G_ms[DAMAR_T_TAIL] = now_ms() - t0;
+    { HIP_CHECK(hipStreamSynchronize(G_st));
+      G_ms[DAMAR_T_D2H] += lap(6, 7);
     }
+  G_cnt[3] += hc[1];  G_cnt[4] += hc[2];
+  const double h4 = now_ms();
+  for (int j = 0; j < n; j++)
+    { jobs[j]->counts[1] = hc[32 + j];
+      G_cnt[2] += hc[32 + j];
+      if (A_on)
+        { TailJob *tj = new TailJob();
+          tj->kind = 0;
+          tj->hb = hb;  tj->jobid = j;  tj->njobs = n;
+          tj->ablock = *jobs[j]->ablock;  tj->bblock = *jobs[j]->bblock;
+          tj->self = jobs[j]->self;  tj->comp = jobs[j]->comp;  tj->spec = jobs[j]->spec;
+          async_submit(tj);
+        }
+      else
+        { double t0 = now_ms();
+          jobs[j]->counts[2] = run_tail(hb->recs, hb->nrec, hb->tpool, jobs[j]->ablock, jobs[j]->bblock, jobs[j]->self,
+                                       jobs[j]->comp, jobs[j]->spec, j, n);
+          if (--hb->users == 0)
+            hostbuf_put(hb);
+          G_ms[DAMAR_T_TAIL] += now_ms() - t0;
+        }
+    }
+  const double h5 = now_ms();
+  H_ms[3] += h3 - h2;  H_ms[4] += h4 - h3;  H_ms[5] += h5 - h4;
+}
 
-  { const double h5 = now_ms();
-    if (h3 == h0) h3 = h4;                 /* no work: no report, no download */
-    H_ms[1] += h1 - h0;  H_ms[2] += h2 - h1;  H_ms[3] += h3 - h2;  H_ms[4] += h4 - h3;  H_ms[5] += h5 - h4;
-    H_ms[6] += h5 - h0;
-  }
+static int batch_limit(void)
+{ static int n = 0;
+  if (n == 0)
+    { const char *e = getenv("DAMAR_BATCH");
+      n = e ? atoi(e) : 4;      /* report ms per config-2 step: 1 -> 357, 2 -> 340, 4 -> 335.5, 16 -> 335.3; every job in
+                                   flight keeps its sorted seed pairs (12 B each) in HBM, which a cold process pays for
+                                   at ~25 ms per GB */
+      if (n < 1) n = 1;
+      if (n > DAMAR_MAX_JOBS) n = DAMAR_MAX_JOBS;
+    }
+  return n;
+}
+
+/* Several comparisons with ONE report launch each time their seed stages are done (kernels.h: DAMAR_MAX_JOBS): the seed
+   stages run one after the other, each into its own arena, then every wavefront of the report kernel works through all
+   the work lists.  The output is that of damar_match called for jobs[0], jobs[1], ... in this order.  Launches are cut
+   at DAMAR_BATCH jobs (default 4, at most DAMAR_MAX_JOBS) and whenever the seed arenas would pass a quarter of HBM. */
+extern "C" void damar_match_batch(damar_match_job *jobs, int njobs)
+{ ensure_init();
+  const double h0 = now_ms();
+  memset(G_cnt, 0, sizeof(G_cnt));
+  for (int i = DAMAR_T_MERGE; i < DAMAR_T_COUNT; i++)
+    G_ms[i] = 0;
+  damar_match_job *run[DAMAR_MAX_JOBS];
+  Front fr[DAMAR_MAX_JOBS];
+  int   n = 0;
+  size_t bytes = 0;
+  const size_t budget = G_prop.totalGlobalMem / 4;
+  auto flush = [&]()
+    { if (n == 0) return;
+      match_report(run, fr, n);
+      n = 0;  bytes = 0;
+    };
+  for (int i = 0; i < njobs; i++)
+    { const double f0 = now_ms();
+      if (match_front(&jobs[i], n, &fr[n]))
+        { run[n] = &jobs[i];
+          bytes += fr[n].bytes;
+          n += 1;
+        }
+      H_ms[1] += now_ms() - f0;
+      if (n >= batch_limit() || bytes > budget)
+        flush();
+    }
+  flush();
+  H_ms[6] += now_ms() - h0;
+}
+
+extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
+                            damar_dev_index *aidx, damar_dev_index *bidx,
+                            int self, int comp, Align_Spec *spec, int64 *counts)
+{ damar_match_job job;
+  memset(&job, 0, sizeof(job));
+  job.ablock = ablock;  job.bblock = bblock;  job.aidx = aidx;  job.bidx = bidx;
+  job.self = self;  job.comp = comp;  job.spec = spec;
+  damar_match_batch(&job, 1);
   if (counts)
-    { counts[0] = nhits;  counts[1] = nfilt;  counts[2] = ncheck; }
+    { counts[0] = job.counts[0];  counts[1] = job.counts[1];  counts[2] = job.counts[2]; }
   if (VERBOSE)
     { printf("\n     %lld %d-mers\n     %lld seed hits\n     %lld confirmed hits\n",
-             (long long) nhits, P_kmer, (long long) nfilt, (long long) ncheck);
+             (long long) job.counts[0], P_kmer, (long long) job.counts[1], (long long) job.counts[2]);
       fflush(stdout);
     }
 }
@@ -1668,7 +1771,7 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
 
   std::vector<LaRecord> recs;
   std::vector<u16>      tpool;
-  u32 hc[16];
+  u32 hc[DAMAR_COUNTER_WORDS];
   { const int sk = P_kmer, sh = P_hitmin, sb = P_binshift;        /* the report args read the P_* set */
     P_kmer = T_kmer;  P_hitmin = T_hitmin;  P_binshift = T_binshift;
     u32 cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
@@ -1680,7 +1783,7 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
         scratch_outputs(rec_cap, tp_cap);
         fill_report_args(&ra, blk, blk, 0, 1, spec);
         ra.nwork = (u32) ablock->nreads;
-        HIP_CHECK(hipMemsetAsync(RS.counters, 0, 64, G_st));
+        HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
         tick(4);
         damar_launch_tandem_report(&ra, dist, RS.nslots, G_st);
         tick(5);
@@ -1707,7 +1810,7 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
     { HIP_CHECK(hipMemcpy(recs.data(), RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost));
       HIP_CHECK(hipMemcpy(tpool.data(), RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost));
     }
-  nfilt = hc[4];
+  nfilt = hc[32];
   HIP_CHECK(hipFree(dist));
   damar_index_free(ix);
 
@@ -1781,17 +1884,17 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
   u32 cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS, rec_cap = (u32) ntasks + 16, tp_cap = (u32) std::min<int64>(trace_cap + 1024, 0x7fffffff);
   LaTask *dt = (LaTask *) dmalloc(sizeof(LaTask) * (size_t) ntasks);
   HIP_CHECK(hipMemcpy(dt, tasks, sizeof(LaTask) * (size_t) ntasks, hipMemcpyHostToDevice));
-  u32 hc[8];
+  u32 hc[DAMAR_COUNTER_WORDS];
   for (int attempt = 0; ; attempt++)
     { ReportArgs ra;
       scratch_prepare(ablk->d.maxlen, bblk->d.maxlen, P_binshift, ts, cell_cap);
       stage("la_scratch");
       scratch_outputs(rec_cap, tp_cap);
       fill_report_args(&ra, ablk, bblk, comp, 0, spec);
-      HIP_CHECK(hipMemsetAsync(RS.counters, 0, 64, G_st));
+      HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
       stage("la_setup");
       if (use_packed(&ra, ablk->d.maxlen, bblk->d.maxlen))
-        damar_launch_report2(&ra, dt, (u32) ntasks, RS.nslots, G_st);
+        damar_launch_report2(&ra, 1, dt, (u32) ntasks, RS.nslots, G_st);
       else
         damar_launch_la_batch(&ra, dt, (u32) ntasks, RS.nslots, G_st);
       stage("la_kernel");

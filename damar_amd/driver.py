@@ -119,9 +119,12 @@ class Plan:
         # residency cap of the index cache (each index: 8 B per k-mer + a prefix table of up to 1 GB): least
         # recently used indexes are released beyond it.  Default: a third of a 288 GB MI355X.
         self.index_cache_bytes = (96 << 30) if index_cache_bytes is None else index_cache_bytes
-        self._pinned = ()
+        self._pinned = set()
         self._line_a = None
+        self._group = []         # index keys the comparisons of the group being prepared refer to
         self.index_builds = 0
+        self.matches = 0             # comparisons (block pair x orientation) run
+        self.report_launches = 0     # launches of the report kernel they took
         L.damar_set_async(1 if async_tail else 0)
 
     def finish(self):
@@ -175,7 +178,8 @@ class Plan:
         each line is its own process; here the sorted index (8 B per k-mer) simply stays in HBM
         until finish()."""
         key = (block.name, comp)
-        self._pinned = (self._line_a, key)    # the A index of the running line and this one stay resident
+        self._pinned = set(self._group) | {self._line_a, key}     # the indexes of the running group stay resident
+        self._group.append(key)
         idx = self._idx.pop(key, None)
         if idx is not None:
             self._idx[key] = idx              # most recently used last
@@ -193,34 +197,48 @@ class Plan:
             self._evict()
         return idx
 
-    def _match(self, adb, bdb, aidx, bidx, self_, comp, spec):
+    def _match_batch(self, jobs):
+        """jobs: list of (adb, bdb, aidx, bidx, self, comp, spec) -> ONE damar_match_batch: the seed stages one after
+        the other, one report launch over all of them (include/damar_hip.h)."""
         L = api.lib()
-        cnt = (api.c_int64 * 3)()
-        L.damar_match(C.byref(adb), C.byref(bdb), aidx, bidx, self_, comp, spec, cnt)
+        arr = (api.MatchJob * len(jobs))()
+        for q, (adb, bdb, aidx, bidx, self_, comp, spec) in enumerate(jobs):
+            arr[q].ablock = C.pointer(adb)
+            arr[q].bblock = C.pointer(bdb)
+            arr[q].aidx, arr[q].bidx = aidx, bidx
+            arr[q].self_, arr[q].comp, arr[q].spec = self_, comp, spec
+        L.damar_match_batch(arr, len(jobs))
+        self.matches += len(jobs)
+        self.report_launches += api.counters()[5]
         t = api.timings()
         for nme in ("merge", "ssort", "work", "report", "d2h", "tail"):
             self.timings[nme] = self.timings.get(nme, 0.) + t[nme]
-        for i in range(3):
-            self.counts[i] += cnt[i]
+        for q in range(len(jobs)):
+            for i in range(3):
+                self.counts[i] += arr[q].counts[i]
 
-    def _spec(self, a):
-        """One Align_Spec per A block and job (its tables depend on the block's base frequencies,
-        daligner.c:951); its overlap buffer is reset by every damar_write_overlaps."""
+    def _spec(self, a, slot=0):
+        """Align_Specs per A block and job (the tables depend on the block's base frequencies, daligner.c:951), one
+        per subject block of a group: each has its own overlap buffers, which damar_write_overlaps writes and resets."""
         L = api.lib()
-        sp = self._spec_of.get(a.name)
-        if sp is None:
+        sps = self._spec_of.setdefault(a.name, [])
+        while len(sps) <= slot:
             sp = L.New_Align_Spec(self.e, self.s, a.db.freq, self.j, self.symmetric, self.only_identity,
                                   self.no_trace, 1)
-            self._spec_of[a.name] = sp
+            sps.append(sp)
             self._specs.append(sp)
-        return sp
+        return sps[slot]
 
-    def run_pair(self, a, b, outdir, part=0, nparts=1):
-        """One block pair of a plan line, both orientations (daligner.c:958-1056 for one B argument); the
-        .las files go under outdir exactly as daligner.c:1006-1021, 1051-1056 name them.  With nparts > 1
-        only the read pairs whose B read falls into the part's share of B's reads are processed
-        (damar_set_bread_range): the parts' files merge into the unsplit pair's files (multi.merge_parts)."""
+    GROUP = 8        # subject blocks per report launch (x 2 orientations = DAMAR_MAX_JOBS comparisons)
+
+    def run_pairs(self, a, bs, outdir, part=0, nparts=1):
+        """Block `a` against the blocks `bs` (at most GROUP), both orientations each (daligner.c:958-1056 for these B
+        arguments), behind one launch of the report kernel; the .las files go under outdir exactly as
+        daligner.c:1006-1021, 1051-1056 name them.  With nparts > 1 only the read pairs whose B read falls into the
+        part's share of B's reads are processed (damar_set_bread_range; one subject block then): the parts' files merge
+        into the unsplit pair's files (multi.merge_parts)."""
         L = api.lib()
+        assert 1 <= len(bs) <= self.GROUP and (nparts == 1 or len(bs) == 1)
         os.makedirs(outdir, exist_ok=True)
         outabs = os.path.abspath(outdir)
 
@@ -229,36 +247,49 @@ class Plan:
         with _cwd(outdir):
             os.makedirs(api.get_dir(self.run, a.db.part), exist_ok=True)
             self._line_a = (a.name, 0)
-            spec = self._spec(a)
+            self._group = []
             aidx = self._index(a, 0)
-            same = b is a or b.name == a.name
-            if nparts > 1:
-                nb = (a if same else b).db.nreads
-                L.damar_set_bread_range(nb * part // nparts, nb * (part + 1) // nparts)
-            try:
-                if same:
-                    self._match(a.db, a.db, aidx, aidx, 1, 0, spec)
+            jobs = []
+            for q, b in enumerate(bs):
+                spec = self._spec(a, q)
+                if b is a or b.name == a.name:
                     cidx = self._index(a, 1)
-                    self._match(a.db, a.cdb, aidx, cidx, 1, 1, spec)
-                    L.damar_write_overlaps(spec, odir(a.db.part), None, a.root.encode(), a.root.encode(), a.last_read())
+                    jobs.append((a.db, a.db, aidx, aidx, 1, 0, spec))
+                    jobs.append((a.db, a.cdb, aidx, cidx, 1, 1, spec))
                 else:
                     if self.symmetric:
                         os.makedirs(api.get_dir(self.run, b.db.part), exist_ok=True)
-                    self._match(a.db, b.db, aidx, self._index(b, 0), 0, 0, spec)
+                    bidx = self._index(b, 0)
                     cidx = self._index(b, 1)
-                    self._match(a.db, b.cdb, aidx, cidx, 0, 1, spec)
-                    last = b.last_read() if b.db.part < a.db.part else a.last_read()
-                    L.damar_write_overlaps(spec, odir(a.db.part), odir(b.db.part), a.root.encode(), b.root.encode(), last)
+                    jobs.append((a.db, b.db, aidx, bidx, 0, 0, spec))
+                    jobs.append((a.db, b.cdb, aidx, cidx, 0, 1, spec))
+            if nparts > 1:
+                nb = bs[0].db.nreads
+                L.damar_set_bread_range(nb * part // nparts, nb * (part + 1) // nparts)
+            try:
+                self._match_batch(jobs)
             finally:
                 if nparts > 1:
                     L.damar_set_bread_range(0, -1)
-            if not self.async_tail or a.db.part <= 0 or b.db.part <= 0:
+            self._group = []
+            for q, b in enumerate(bs):
+                spec = self._spec(a, q)
+                if b is a or b.name == a.name:
+                    L.damar_write_overlaps(spec, odir(a.db.part), None, a.root.encode(), a.root.encode(), a.last_read())
+                else:
+                    last = b.last_read() if b.db.part < a.db.part else a.last_read()
+                    L.damar_write_overlaps(spec, odir(a.db.part), odir(b.db.part), a.root.encode(), b.root.encode(), last)
+            if not self.async_tail or a.db.part <= 0 or any(b.db.part <= 0 for b in bs):
                 self.finish()            # unsplit DBs write relative paths: finish inside this cwd
+
+    def run_pair(self, a, b, outdir, part=0, nparts=1):
+        """One block pair of a plan line, both orientations."""
+        self.run_pairs(a, [b], outdir, part, nparts)
 
     def run_line(self, a, bs, outdir):
         """One plan line: block `a` against every block in `bs` (daligner <A> <B1> <B2> ...)."""
-        for b in bs:
-            self.run_pair(a, b, outdir)
+        for k in range(0, len(bs), self.GROUP):
+            self.run_pairs(a, bs[k:k + self.GROUP], outdir)
 
 
 def run_datander(block, outdir, k=12, w=4, h=35, e=.70, l=500, s=100, j=4, verbose=0, out="tan"):

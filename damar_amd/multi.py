@@ -49,12 +49,35 @@ def shard_pairs(nblocks, world):
     return out, load
 
 
-def work_units(nblocks, world, units_per_rank=2):
-    """The queue's contents: (a, b, part, nparts) with b <= a, cross pairs first in plan order, then the
-    self pairs.  nparts > 1 only when the plan is too coarse for `world` ranks."""
+GROUP = 8        # subject blocks behind one report launch (driver.Plan.GROUP)
+
+
+def group_units(nblocks, g):
+    """The plan's lines (block a against a, a-1, ..., 1) cut into groups of at most g subject blocks:
+    (a, (b, ...), 0, 1), most expensive first (a cross pair costs 2, a self pair 1)."""
+    units = []
+    for a in range(1, nblocks + 1):
+        bs = list(range(a, 0, -1))
+        for k in range(0, len(bs), g):
+            units.append((a, tuple(bs[k:k + g]), 0, 1))
+    units.sort(key=lambda u: -sum(1 if b == u[0] else 2 for b in u[1]))
+    return units
+
+
+def work_units(nblocks, world, units_per_rank=2, fine=6):
+    """The queue's contents.  Enough block pairs for the ranks: groups (a, (b, ...), 0, 1) of one A block against up to
+    GROUP subject blocks -- one report launch each, the larger the group the smaller the share of the launch spent
+    waiting for its longest alignment -- as large as still leaves `fine` units per rank (one GPU: whole plan lines).
+    Too few pairs for `world` ranks: (a, b, part, nparts) with b <= a, cross pairs first in plan order, then the self
+    pairs, split by B-read range."""
     cross = [(a, b) for a in range(1, nblocks + 1) for b in range(a - 1, 0, -1)]
     selfs = [(a, a) for a in range(1, nblocks + 1)]
     npairs = len(cross) + len(selfs)
+    if world == 1 or npairs >= units_per_rank * world:
+        g = GROUP
+        while g > 1 and world > 1 and len(group_units(nblocks, g)) < fine * world:
+            g //= 2
+        return group_units(nblocks, g)
     ncross = nself = 1
     if world > 1 and npairs < units_per_rank * world:
         # cost units (cross = 2, self = 1) per rank wanted: split so that every rank gets about units_per_rank pieces
@@ -103,16 +126,19 @@ def part_dir(outdir, a, b, part, nparts):
 
 
 def run_queue(dbprefix, units, outdir, queue, runner):
-    """Pull units until the queue is empty.  runner(a_name, b_name, outdir, part, nparts) computes one unit;
-    a split unit is written under part_dir().  Returns the units this rank ran."""
+    """Pull units until the queue is empty.  runner(a_name, b_name or [b_names], outdir, part, nparts) computes one
+    unit; a split unit is written under part_dir().  Returns the units this rank ran."""
     mine = []
     while True:
         i = queue.next()
         if i is None:
             break
         a, b, part, nparts = units[i]
-        dst = outdir if nparts == 1 else part_dir(outdir, a, b, part, nparts)
-        runner("%s.%d" % (dbprefix, a), "%s.%d" % (dbprefix, b), dst, part, nparts)
+        if isinstance(b, tuple):             # a group of subject blocks
+            runner("%s.%d" % (dbprefix, a), ["%s.%d" % (dbprefix, x) for x in b], outdir, 0, 1)
+        else:
+            dst = outdir if nparts == 1 else part_dir(outdir, a, b, part, nparts)
+            runner("%s.%d" % (dbprefix, a), "%s.%d" % (dbprefix, b), dst, part, nparts)
         mine.append(units[i])
     return mine
 
@@ -133,7 +159,7 @@ def merge_parts(dbprefix, units, outdir, rank, world, run=1):
     dealt round-robin over the ranks.  Returns the files written."""
     from . import api, lib
     root = os.path.basename(dbprefix)
-    split = sorted({(a, b, n) for a, b, _, n in units if n > 1})
+    split = sorted({(a, b, n) for a, b, _, n in units if n > 1})       # (groups are never split)
     done = []
     for j, (a, b, n) in enumerate(split):
         if j % world != rank:
@@ -213,12 +239,13 @@ class GpuRunner:
 
     def __call__(self, a, b, outdir, part=0, nparts=1):
         ba = self.block(a)
-        bb = ba if b == a else self.block(b, keep=(a,))
-        self.plan.run_pair(ba, bb, outdir, part, nparts)
+        names = list(b) if isinstance(b, (list, tuple)) else [b]
+        bbs = [ba if x == a else self.block(x, keep=[a] + names) for x in names]
+        self.plan.run_pairs(ba, bbs, outdir, part, nparts)
 
     def run_line(self, a, bs, outdir):
-        for b in bs:
-            self(a, b, outdir)
+        for k in range(0, len(bs), GROUP):
+            self(a, bs[k:k + GROUP], outdir)
 
     def finish(self):
         self.plan.finish()

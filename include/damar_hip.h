@@ -65,6 +65,21 @@ void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
                  damar_dev_index *aidx, damar_dev_index *bidx,
                  int self, int comp, Align_Spec *spec, int64 *counts);
 
+/* Several comparisons behind ONE launch of the report kernel each time (4 per launch unless DAMAR_BATCH says otherwise, at most 16; fewer when their seed
+ * pairs would pass a quarter of HBM): the seed stages run one after the other, then every wavefront works through the
+ * work lists of all of them, so the wait for the longest alignment at the end of a launch is paid once per launch instead
+ * of once per comparison.  Records are appended as if damar_match had been called for jobs[0], jobs[1], ... in order
+ * (a daligner plan line, filter.c:2519 called per (B block, orientation) by daligner.c:993-1021, is one such batch);
+ * counts as for damar_match. */
+typedef struct
+{ const HITS_DB *ablock, *bblock;
+  damar_dev_index *aidx, *bidx;
+  int self, comp;
+  Align_Spec *spec;
+  int64 counts[3];
+} damar_match_job;
+void damar_match_batch(damar_match_job *jobs, int njobs);
+
 /* Restrict the following damar_match / Match_Filter calls to the read pairs whose B read (block-local
  * index) lies in [lo, hi); hi < 0 lifts the restriction.  The records of a range are exactly those the
  * unrestricted call writes for these B reads (the merge and the sort still cover the whole pair), so a
@@ -145,8 +160,9 @@ enum { DAMAR_T_TUPLES = 0, DAMAR_T_KSORT, DAMAR_T_TABLE, DAMAR_T_MERGE, DAMAR_T_
        DAMAR_T_WORK, DAMAR_T_REPORT, DAMAR_T_D2H, DAMAR_T_TAIL, DAMAR_T_COUNT };
 void damar_last_timings(double *ms /* [DAMAR_T_COUNT] */);
 
-/* Counters of the last damar_match: [0] seed pairs, [1] work items (read pairs entered),
- * [2] Local_Alignment calls, [3] records from the device, [4] trace values. */
+/* Counters of the last damar_match / damar_match_batch (summed over its comparisons): [0] seed pairs, [1] work items
+ * (read pairs entered), [2] Local_Alignment calls, [3] records from the device, [4] trace values, [5] launches of the
+ * report kernel (re-launches after a buffer overflow included). */
 void damar_last_counters(int64 *c /* [8] */);
 
 /* Sort kernels alone, for the roofline measurement: sorts n (u32 key, u32 payload)

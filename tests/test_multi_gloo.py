@@ -62,6 +62,10 @@ def filter_las(src, dst, keep):
 
 def oracle_runner(a, b, outdir, part, nparts):
     # test stand-in for the GPU: the CPU oracle computes the whole pair, the part keeps its B-read range
+    if isinstance(b, (list, tuple)):       # a group of subject blocks (one report launch on the GPU)
+        for x in b:
+            oracle_runner(a, x, outdir, part, nparts)
+        return
     ia, ib = int(a.rsplit(".", 1)[1]), int(b.rsplit(".", 1)[1])
     with tempfile.TemporaryDirectory() as tmp:
         for f in ("G.db", ".G.idx", ".G.bps"):
@@ -103,18 +107,24 @@ def test_work_units_cover_every_pair_once():
     for nb, world, upr in [(4, 1, 2), (4, 8, 2), (17, 8, 2), (2, 2, 4), (3, 4, 3)]:
         units = multi.work_units(nb, world, upr)
         pairs = {}
-        for a, b, i, n in units:
-            assert 1 <= b <= a <= nb and 0 <= i < n
-            pairs.setdefault((a, b), []).append((i, n))
+        for a, bs, i, n in units:
+            if isinstance(bs, tuple):          # a group: one A block, up to GROUP subject blocks, never split
+                assert 1 <= len(bs) <= multi.GROUP and (i, n) == (0, 1)
+            for b in (bs if isinstance(bs, tuple) else (bs,)):
+                assert 1 <= b <= a <= nb and 0 <= i < n
+                pairs.setdefault((a, b), []).append((i, n))
         assert sorted(pairs) == sorted((a, b) for a in range(1, nb + 1) for b in range(1, a + 1))
         for parts in pairs.values():
             n = parts[0][1]
             assert sorted(parts) == [(i, n) for i in range(n)]
         if world > 1:
             assert len(units) >= min(upr * world, 2 * len(pairs)) or all(n > 1 for _, _, _, n in units if _ != 0)
-        # cross pairs come first, self pairs last
-        kinds = [a == b for a, b, _, _ in units]
-        assert kinds == sorted(kinds)
+        if all(not isinstance(b, tuple) for _, b, _, _ in units):
+            kinds = [a == b for a, b, _, _ in units]      # split pairs: cross pairs come first, self pairs last
+            assert kinds == sorted(kinds)
+        else:
+            cost = [sum(1 if b == a else 2 for b in bs) for a, bs, _, _ in units]
+            assert cost == sorted(cost, reverse=True)     # groups: most expensive first
         q = multi.LocalQueue(len(units))
         got = []
         while True:
