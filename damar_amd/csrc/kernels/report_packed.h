@@ -43,6 +43,30 @@ __device__ __forceinline__ int upd_dpp_shr(int old, int v, int n)      /* lane i
     }
 }
 
+/* Inclusive prefix maximum (minimum for REV) in lane order inside each 32-lane half: Kogge-Stone inside the rows of
+   16 by DPP row_shr, then the last lane of rows 0 / 2 into rows 1 / 3.  In place: a lane whose DPP source does not
+   exist is simply not written (bound_ctrl off), which is the identity here -- one instruction per step instead of
+   the mov-identity / mov_dpp / max triple the update_dpp builtin compiles to.  (s_nop 1: a DPP operand needs two wait
+   states after the VALU write of its register, and the assembler does not add them inside inline asm.) */
+template <int REV>
+__device__ __forceinline__ int pk_prefix_best(int x)
+{ if (!REV)
+    asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1" : "+v"(x));
+  else
+    asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1" : "+v"(x));
+  return x;
+}
+
 /* per-half pair context and direction bookkeeping: every field holds the same value in the 32 lanes of a half */
 struct PkPair
 { int  a0, b0;              /* offsets of the two reads in the blocks' base arrays */
@@ -275,55 +299,55 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
           }
       }
 
-      int  k = kbase + KS * s;
-      bool act = false;
-      int  v = edge, y = 0, ha = 0, hb_ = 0, nai = rNA, nbi = rNB;
-      u64  b = 0;
+      const int k = kbase + KS * s;
+      bool act;
+      int  v, y = 0, ha, hb_, nai, nbi;
+      u64  b;
       int  ena = 1, enb = 1;
 
-      /* widen (align.c:675-776 / 1386-1486) and pick the predecessor (align.c:793-825 / 1502-1534) */
+      /* widen (align.c:675-776 / 1386-1486) and pick the predecessor (align.c:793-825 / 1502-1534).  Computed by every
+         lane, also those of a half that is not stepping (their values go nowhere: act is false, the bookkeeping is
+         selected by `on`): no divergent region, no defaults to set up for it */
       { const int upV = lane_up(rV), dnV = lane_dn(rV);
         const int upNA = lane_up(rNA), dnNA = lane_dn(rNA), upNB = lane_up(rNB), dnNB = lane_dn(rNB);
+        int nlow = low - 1, nhgh = hgh + 1;
+        if (nlow < p.minp) nlow += 1;
+        if (nhgh > p.maxp) nhgh -= 1;
+        const bool newlo = on && (nlow < low) && k == nlow, newhi = on && (nhgh > hgh) && k == nhgh;
+        /* the value of diagonal k+1 sits in lane s+KS, that of k-1 in lane s-KS */
+        const int kpNA = REV ? upNA : dnNA, kmNA = REV ? dnNA : upNA;
+        const int kpNB = REV ? upNB : dnNB, kmNB = REV ? dnNB : upNB;
+        if (newlo || newhi) rV = edge;
+        rNA = newlo ? kpNA : (newhi ? kmNA : rNA);
+        rNB = newlo ? kpNB : (newhi ? kmNB : rNB);
+        nai = rNA;  nbi = rNB;
+        /* (the neighbours' V was fetched before the new edge lanes were set: an edge lane's own old V is never
+           a neighbour of an active diagonal's predecessor choice except as `edge`, enforced below) */
+        act = on && k >= nlow && k <= nhgh;
+        int am = REV ? dnV : upV, ap = REV ? upV : dnV;              /* V[k-1], V[k+1] of the previous wave */
+        if (k - 1 < low || k - 1 > hgh) am = edge;                   /* outside the previous band */
+        if (k + 1 > hgh || k + 1 < low) ap = edge;
+        const int ac = (k < low || k > hgh) ? edge : rV;
         if (on)
-          { int nlow = low - 1, nhgh = hgh + 1;
-            if (nlow < p.minp) nlow += 1;
-            if (nhgh > p.maxp) nhgh -= 1;
-            const bool newlo = (nlow < low) && k == nlow, newhi = (nhgh > hgh) && k == nhgh;
-            /* the value of diagonal k+1 sits in lane s+KS, that of k-1 in lane s-KS */
-            const int kpNA = REV ? upNA : dnNA, kmNA = REV ? dnNA : upNA;
-            const int kpNB = REV ? upNB : dnNB, kmNB = REV ? dnNB : upNB;
-            if (newlo || newhi) rV = edge;
-            rNA = newlo ? kpNA : (newhi ? kmNA : rNA);
-            rNB = newlo ? kpNB : (newhi ? kmNB : rNB);
-            nai = rNA;  nbi = rNB;
-            /* (the neighbours' V was fetched before the new edge lanes were set: an edge lane's own old V is never
-               a neighbour of an active diagonal's predecessor choice except as `edge`, enforced below) */
-            act = k >= nlow && k <= nhgh;
-            int am = REV ? dnV : upV, ap = REV ? upV : dnV;              /* V[k-1], V[k+1] of the previous wave */
-            if (k - 1 < low || k - 1 > hgh) am = edge;                   /* outside the previous band */
-            if (k + 1 > hgh || k + 1 < low) ap = edge;
-            const int ac = (k < low || k > hgh) ? edge : rV;
-            low = nlow;  hgh = nhgh;
-            dif += 1;
-            int  nbv;
-            bool take, upk;                                              /* predecessor = a neighbour? diagonal k+1? */
-            if (!REV)
-              { nbv = am > ap ? am : ap;  take = ac < nbv;  upk = am < ap;
-                v = take ? nbv + 1 : ac + 2;
-              }
-            else
-              { nbv = am < ap ? am : ap;  take = ac > nbv;  upk = !(ap > am);
-                v = take ? nbv - 1 : ac - 2;
-              }
-            /* lane of the predecessor: k+1 -> s+KS, k-1 -> s-KS */
-            const int ds = take ? (upk ? KS : -KS) : 0;
-            const int src = (lane + ds) << 2;
-            ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
-            hb_ = __builtin_amdgcn_ds_bpermute(src, rHB);
-            const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
-            const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
-            b = ((u64) thi << 32) | tlo;
+          { low = nlow;  hgh = nhgh;  dif += 1; }
+        int  nbv;
+        bool take, upk;                                              /* predecessor = a neighbour? diagonal k+1? */
+        if (!REV)
+          { nbv = am > ap ? am : ap;  take = ac < nbv;  upk = am < ap;
+            v = take ? nbv + 1 : ac + 2;
           }
+        else
+          { nbv = am < ap ? am : ap;  take = ac > nbv;  upk = !(ap > am);
+            v = take ? nbv - 1 : ac - 2;
+          }
+        /* lane of the predecessor: k+1 -> s+KS, k-1 -> s-KS */
+        const int ds = take ? (upk ? KS : -KS) : 0;
+        const int src = (lane + ds) << 2;
+        ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
+        hb_ = __builtin_amdgcn_ds_bpermute(src, rHB);
+        const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+        const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+        b = ((u64) thi << 32) | tlo;
       }
 
       if (act)
@@ -475,14 +499,7 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
       { const bool cand = act && (REV ? (v < besta) : (v > besta));
         if (wany(cand))
           { const int worst = REV ? BIG : -BIG;
-            int x = cand ? v : worst;
-            for (int n = 1; n < 16; n <<= 1)
-              { const int t = upd_dpp_shr(worst, x, n);
-                x = REV ? (t < x ? t : x) : (t > x ? t : x);
-              }
-            { const int t = __builtin_amdgcn_update_dpp(worst, x, 0x142, 0xa, 0xf, false);     /* row_bcast:15 -> rows 1, 3 */
-              x = REV ? (t < x ? t : x) : (t > x ? t : x);
-            }
+            const int x = pk_prefix_best<REV>(cand ? v : worst);
             int e = __builtin_amdgcn_update_dpp(worst, x, 0x138, 0xf, 0xf, false);             /* wave_shr:1 */
             if (s == 0) e = worst;
             const bool rb = cand && (REV ? (v < e) : (v > e));
@@ -908,10 +925,11 @@ __device__ __forceinline__ void pk_emit(const ReportArgs &a, const SlotScratch &
 enum { PK_ITEM = 0, PK_PANEL, PK_FIRE, PK_DONE };
 
 #ifndef PK_WAVES
-#define PK_WAVES 6                      /* resident wavefronts per SIMD the packed kernel is compiled for (VGPR budget 512 / PK_WAVES).
+#define PK_WAVES 5                      /* resident wavefronts per SIMD the packed kernel is compiled for (VGPR budget 512 / PK_WAVES).
                                            Report ms per config-2 step with the event state of a direction parked in LDS (pk_cold):
-                                           4 -> 327, 5 -> 291 (wave loop free of spills in both directions), 6 -> 286 (a dozen
-                                           reloads per step in the reverse loop), 7 spills throughout.  Limiting the launch to
+                                           4 -> 327, 5 -> 288 (wave loop free of spills in both directions), 6 -> 286 with a dozen
+                                           reloads per step in the reverse loop but 395 after an unrelated edit (the allocation
+                                           at 80 VGPRs is a coin toss), 7 spills throughout.  Limiting the launch to
                                            1 / 2 / 3 / 4 wavefronts per SIMD (DAMAR_SLOTS) gives 1073 / 556 / 407 / 337 ms: the
                                            kernel is bound by how long ONE wavefront takes per step, residency is what hides it */
 #endif
