@@ -12,6 +12,7 @@ void   damar_tile_offsets_u32(const u32 *in, u64 n, void *work, u64 *total_dev, 
 void   damar_scan_tile_counts(u32 *tcount, u32 ntiles, u64 *total_dev, hipStream_t st);
 size_t damar_sort_workspace_bytes(u64 n);
 int    damar_radix_sort_u32(u32 *k0, u32 *v0, u32 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st);
+int    damar_radix_sort_keys_u32(u32 *k0, u32 *k1, u64 n, int nbits, void *work, hipStream_t st);    /* keys only */
 int    damar_radix_sort_u64(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st);
 
 /* A read block resident in HBM. */
@@ -70,8 +71,19 @@ void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32
 void damar_launch_merge_hitgram(const MergeArgs *m, const u32 *off, u64 total, u32 ngram, unsigned long long *gram,
                                 hipStream_t st);
 /* cnt = hits per A entry, toff = exclusive offset of each DAMAR_SCAN_TILE-sized tile of cnt */
+/* pid (optional): the read pair of every seed, bread << abits | aread, for the early cut */
 void damar_launch_merge_emit(const MergeArgs *m, const u32 *cnt, const u32 *toff, const u32 *jb, u64 nhits,
-                             u64 *keys, u32 *vals, hipStream_t st);
+                             u64 *keys, u32 *vals, u32 *pid, hipStream_t st);
+/* the early cut (seed_merge.hip): heads of the runs report_thread enters, on the SORTED pair ids; their pairs into a
+   bitmap over the pair ids; the seeds of those pairs out of the unsorted seeds */
+void damar_launch_pair_heads_ids(const u32 *pids, u64 nhits, int abits, int minhit, int nshift,
+                                 u64 *send, u64 *bits, void *scan_work, u64 *total_dev, u32 *heads, hipStream_t st);
+void damar_launch_pair_bitmap(const u32 *pids, const u32 *heads, u32 nheads, int abits, u32 b_lo, u32 b_hi, u32 *bitmap,
+                              hipStream_t st);
+void damar_launch_seed_cut_count(const u64 *keys, u64 nhits, int pbits, const u32 *bitmap, u32 *tcount, u64 *total_dev,
+                                 hipStream_t st);
+void damar_launch_seed_cut_scatter(const u64 *keys, const u32 *vals, u64 nhits, int pbits, const u32 *bitmap,
+                                   const u32 *toff, u64 *okeys, u32 *ovals, hipStream_t st);
 void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
                              u64 *send /* 64 entries of scratch */, u64 *bits, void *scan_work, u64 *total_dev,
                              u32 *heads, hipStream_t st);

@@ -167,7 +167,8 @@ void damar_launch_merge_hitgram(const MergeArgs *m, const u32 *off, u64 total, u
 #define ME_ITEMS (DAMAR_SCAN_TILE / 256)
 __global__ __launch_bounds__(256)
 void merge_emit(MergeArgs m, const u32 *__restrict__ cnt, const u32 *__restrict__ toff,
-                const u32 *__restrict__ jb, u64 nhits, u64 *__restrict__ keys, u32 *__restrict__ vals)
+                const u32 *__restrict__ jb, u64 nhits, u64 *__restrict__ keys, u32 *__restrict__ vals,
+                u32 *__restrict__ pid)
 { __shared__ u32 loc[DAMAR_SCAN_TILE + 1];
   __shared__ u32 wsum[4];
   const u32 a0 = blockIdx.x * (u32) DAMAR_SCAN_TILE;
@@ -213,16 +214,18 @@ void merge_emit(MergeArgs m, const u32 *__restrict__ cnt, const u32 *__restrict_
       if (h < nhits)
         { keys[h] = ((u64) rb << (m.abits + m.pbits)) | ((u64) ra << m.pbits) | (u64) xa;
           vals[h] = (u32) ((int) xa - (int) xb);
+          if (pid != NULL)                     /* the read pair alone, for the early cut (damar_launch_pair_cut) */
+            pid[h] = (rb << m.abits) | ra;
         }
     }
 }
 
 void damar_launch_merge_emit(const MergeArgs *m, const u32 *cnt, const u32 *toff, const u32 *jb, u64 nhits,
-                             u64 *keys, u32 *vals, hipStream_t st)
+                             u64 *keys, u32 *vals, u32 *pid, hipStream_t st)
 { if (nhits == 0)
     return;
   const u32 ntiles = (m->alen + DAMAR_SCAN_TILE - 1) / DAMAR_SCAN_TILE;
-  hipLaunchKernelGGL(merge_emit, dim3(ntiles), dim3(256), 0, st, *m, cnt, toff, jb, nhits, keys, vals);
+  hipLaunchKernelGGL(merge_emit, dim3(ntiles), dim3(256), 0, st, *m, cnt, toff, jb, nhits, keys, vals, pid);
 }
 
 /* flags[i] = 1 iff hit i starts a (bread,aread) run that report_thread would enter:
@@ -233,8 +236,9 @@ void damar_launch_merge_emit(const MergeArgs *m, const u32 *cnt, const u32 *toff
 #define SCREEN_MAX   48
 #define SCREEN_PANEL 50000                     /* PANEL_SIZE, filter.c:73 */
 /* ends of the reference's NTHREADS slices: once per launch, not once per block */
+template <typename K>
 __global__ __launch_bounds__(64)
-void slice_ends(const u64 *__restrict__ keys, u64 nhits, int bshift, int nshift, u64 *__restrict__ send)
+void slice_ends(const K *__restrict__ keys, u64 nhits, int bshift, int nshift, u64 *__restrict__ send)
 { const int nthr = 1 << nshift, t = threadIdx.x;
   if (t >= nthr)
     return;
@@ -260,11 +264,12 @@ void slice_ends(const u64 *__restrict__ keys, u64 nhits, int bshift, int nshift,
  * from the bit words (pair_heads_expand) after a scan over the tile counts only -- no 4-byte
  * flag and offset per seed, no device-wide scan over all seeds. */
 #define PH_ROUNDS (DAMAR_SCAN_TILE / 256)
+template <typename K>
 __global__ __launch_bounds__(256)
-void pair_heads_mark(const u64 *__restrict__ keys, u64 nhits, int pbits, int minhit, int nshift,
+void pair_heads_mark(const K *__restrict__ keys, u64 nhits, int pbits, int minhit, int nshift,
                      const u64 *__restrict__ send, u64 *__restrict__ bits, u32 *__restrict__ tcount)
 { __shared__ u32 wsum[4];
-  const int nthr = 1 << nshift;
+  const int nthr = nshift < 0 ? 0 : 1 << nshift;       /* nshift < 0: no slices (the seeds went through the early cut) */
   const int l = lane_id(), w = threadIdx.x >> 6;
   const u64 base = (u64) blockIdx.x * DAMAR_SCAN_TILE;
   u32 mine = 0;
@@ -272,7 +277,7 @@ void pair_heads_mark(const u64 *__restrict__ keys, u64 nhits, int pbits, int min
     { const u64 i = base + (u64) r * 256u + threadIdx.x;
       bool f = false;
       if (i < nhits)
-        { const u64 pr = keys[i] >> pbits;
+        { const K pr = keys[i] >> pbits;
           if ((i == 0 || (keys[i - 1] >> pbits) != pr) && i + (u64) (minhit - 1) < nhits &&
               (keys[i + (u64) (minhit - 1)] >> pbits) == pr)
             { f = true;
@@ -314,9 +319,10 @@ void pair_heads_expand(const u64 *__restrict__ bits, const u32 *__restrict__ tof
 
 /* heads = ascending indices of the run heads; *total_dev = their number.  bits: 64 u64 words per
  * tile of DAMAR_SCAN_TILE seeds; scan_work: damar_scan_workspace_bytes(nhits) */
-void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
-                             u64 *send /* 64 entries of scratch */, u64 *bits, void *scan_work, u64 *total_dev,
-                             u32 *heads, hipStream_t st)
+template <typename K>
+static void pair_heads_impl(const K *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
+                            u64 *send /* 64 entries of scratch */, u64 *bits, void *scan_work, u64 *total_dev,
+                            u32 *heads, hipStream_t st)
 { if (nhits == 0)
     { HIP_CHECK(hipMemsetAsync(total_dev, 0, sizeof(u64), st));
       return;
@@ -325,10 +331,127 @@ void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, i
     nshift = 6;
   const u32 ntiles = (u32) ((nhits + DAMAR_SCAN_TILE - 1) / DAMAR_SCAN_TILE);
   u32 *tcount = (u32 *) scan_work;
-  hipLaunchKernelGGL(slice_ends, dim3(1), dim3(64), 0, st, keys, nhits, abits + pbits, nshift, send);
-  hipLaunchKernelGGL(pair_heads_mark, dim3(ntiles), dim3(256), 0, st, keys, nhits, pbits, minhit, nshift, send, bits, tcount);
+  if (nshift >= 0)
+    hipLaunchKernelGGL(slice_ends<K>, dim3(1), dim3(64), 0, st, keys, nhits, abits + pbits, nshift, send);
+  hipLaunchKernelGGL(pair_heads_mark<K>, dim3(ntiles), dim3(256), 0, st, keys, nhits, pbits, minhit, nshift, send, bits, tcount);
   damar_scan_tile_counts(tcount, ntiles, total_dev, st);
   hipLaunchKernelGGL(pair_heads_expand, dim3(ntiles), dim3(64), 0, st, bits, tcount, heads);
+}
+
+void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
+                             u64 *send, u64 *bits, void *scan_work, u64 *total_dev, u32 *heads, hipStream_t st)
+{ pair_heads_impl<u64>(keys, nhits, pbits, abits, minhit, nshift, send, bits, scan_work, total_dev, heads, st);
+}
+
+/***** the early cut ***************************************************************************************
+ * Of the seed pairs two blocks share, a few per cent belong to read pairs with at least minhit seeds; the rest are
+ * chance k-mer matches between unrelated reads that report_thread skips at its first test (filter.c:2212-2215).
+ * Rather than carrying them through the six passes of the seed sort, the read pair of every seed (a u32,
+ * bread << abits | aread, written by merge_emit next to the seed) is sorted on its own -- the same order, so the
+ * same indices, as the seeds will have -- the reference's head test (run of >= minhit seeds, not inside the last
+ * minhit seeds of a thread slice) is evaluated there, the surviving pairs are marked in a bitmap over the pair ids,
+ * and only their seeds are kept for the sort.  Everything after the sort sees exactly the seeds of the read pairs the
+ * reference enters, in the reference's order. */
+
+/* heads = indices (in the sorted pair ids) of the runs report_thread enters; *total_dev = their number */
+void damar_launch_pair_heads_ids(const u32 *pids, u64 nhits, int abits, int minhit, int nshift,
+                                 u64 *send, u64 *bits, void *scan_work, u64 *total_dev, u32 *heads, hipStream_t st)
+{ pair_heads_impl<u32>(pids, nhits, 0, abits, minhit, nshift, send, bits, scan_work, total_dev, heads, st);
+}
+
+__global__ __launch_bounds__(256)
+void pair_bitmap_set(const u32 *__restrict__ pids, const u32 *__restrict__ heads, u32 nheads, int abits, u32 b_lo, u32 b_hi,
+                     u32 *__restrict__ bitmap)
+{ const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nheads)
+    return;
+  const u32 p = pids[heads[t]], rb = p >> abits;
+  if (rb < b_lo || rb >= b_hi)                    /* a scheduler may hand this call a B-read range only */
+    return;
+  atomicOr(&bitmap[p >> 5], 1u << (p & 31));
+}
+
+/* bitmap must be zero: (2^idbits + 31) / 32 words */
+void damar_launch_pair_bitmap(const u32 *pids, const u32 *heads, u32 nheads, int abits, u32 b_lo, u32 b_hi, u32 *bitmap,
+                              hipStream_t st)
+{ if (nheads == 0)
+    return;
+  hipLaunchKernelGGL(pair_bitmap_set, dim3((nheads + 255) / 256), dim3(256), 0, st, pids, heads, nheads, abits, b_lo, b_hi, bitmap);
+}
+
+/* survivors of a tile of DAMAR_SCAN_TILE seeds */
+__global__ __launch_bounds__(256)
+void seed_cut_count(const u64 *__restrict__ keys, u64 nhits, int pbits, const u32 *__restrict__ bitmap, u32 *__restrict__ tcount)
+{ __shared__ u32 wsum[4];
+  const int l = lane_id(), w = threadIdx.x >> 6;
+  const u64 base = (u64) blockIdx.x * DAMAR_SCAN_TILE;
+  u32 mine = 0;
+  for (int r = 0; r < PH_ROUNDS; r++)
+    { const u64 i = base + (u64) r * 256u + threadIdx.x;
+      bool f = false;
+      if (i < nhits)
+        { const u32 p = (u32) (keys[i] >> pbits);
+          f = (bitmap[p >> 5] >> (p & 31)) & 1;
+        }
+      mine += (u32) __popcll(__ballot(f));
+    }
+  if (l == 0) wsum[w] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    tcount[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+/* toff = exclusive scan of the tile counts; survivors keep their order */
+__global__ __launch_bounds__(256)
+void seed_cut_scatter(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits,
+                      const u32 *__restrict__ bitmap, const u32 *__restrict__ toff, u64 *__restrict__ okeys, u32 *__restrict__ ovals)
+{ __shared__ u32 wsum[PH_ROUNDS][4];
+  const int l = lane_id(), w = threadIdx.x >> 6;
+  const u64 base = (u64) blockIdx.x * DAMAR_SCAN_TILE;
+  u64 key[PH_ROUNDS];
+  u64 mask[PH_ROUNDS];
+  for (int r = 0; r < PH_ROUNDS; r++)
+    { const u64 i = base + (u64) r * 256u + threadIdx.x;
+      bool f = false;
+      key[r] = 0;
+      if (i < nhits)
+        { key[r] = keys[i];
+          const u32 p = (u32) (key[r] >> pbits);
+          f = (bitmap[p >> 5] >> (p & 31)) & 1;
+        }
+      mask[r] = __ballot(f);
+      if (l == 0) wsum[r][w] = (u32) __popcll(mask[r]);
+    }
+  __syncthreads();
+  u32 o = toff[blockIdx.x];
+  for (int r = 0; r < PH_ROUNDS; r++)
+    { u32 before = 0;
+      for (int x = 0; x < 4; x++)
+        { const u32 c = wsum[r][x];
+          if (x < w) before += c;
+        }
+      const u64 i = base + (u64) r * 256u + threadIdx.x;
+      if ((mask[r] >> l) & 1)
+        { const u32 g = o + before + (u32) __popcll(mask[r] & lanes_below(l));
+          okeys[g] = key[r];
+          ovals[g] = vals[i];
+        }
+      o += wsum[r][0] + wsum[r][1] + wsum[r][2] + wsum[r][3];
+    }
+}
+
+/* tcount: one u32 per tile of DAMAR_SCAN_TILE seeds (scan workspace); *total_dev = survivors after the first call */
+void damar_launch_seed_cut_count(const u64 *keys, u64 nhits, int pbits, const u32 *bitmap, u32 *tcount, u64 *total_dev,
+                                 hipStream_t st)
+{ const u32 ntiles = (u32) ((nhits + DAMAR_SCAN_TILE - 1) / DAMAR_SCAN_TILE);
+  hipLaunchKernelGGL(seed_cut_count, dim3(ntiles), dim3(256), 0, st, keys, nhits, pbits, bitmap, tcount);
+  damar_scan_tile_counts(tcount, ntiles, total_dev, st);
+}
+
+void damar_launch_seed_cut_scatter(const u64 *keys, const u32 *vals, u64 nhits, int pbits, const u32 *bitmap,
+                                   const u32 *toff, u64 *okeys, u32 *ovals, hipStream_t st)
+{ const u32 ntiles = (u32) ((nhits + DAMAR_SCAN_TILE - 1) / DAMAR_SCAN_TILE);
+  hipLaunchKernelGGL(seed_cut_scatter, dim3(ntiles), dim3(256), 0, st, keys, vals, nhits, pbits, bitmap, toff, okeys, ovals);
 }
 
 /* Screen of the run heads (the vast majority of runs are a few chance k-mer matches between

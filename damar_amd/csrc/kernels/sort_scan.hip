@@ -145,13 +145,13 @@ void radix_hist(const KeyT *__restrict__ keys, u64 n, int shift, u32 mask,
 
 /* Stable scatter of one tile.  Wave w owns items [w*1024,(w+1)*1024) of the tile in
  * rounds of 64 consecutive items, so (wave, round, lane) order == input order. */
-template <typename KeyT>
+template <typename KeyT, bool HV>          /* HV: a u32 payload travels with the key */
 __global__ __launch_bounds__(RS_THREADS)
 void radix_scatter(const KeyT *__restrict__ kin, const u32 *__restrict__ vin,
                    KeyT *__restrict__ kout, u32 *__restrict__ vout, u64 n,
                    int shift, u32 mask, const u32 *__restrict__ gscan, u32 ntiles)
 { __shared__ KeyT skey[RS_TILE];
-  __shared__ u32  sval[RS_TILE];
+  __shared__ u32  sval[HV ? RS_TILE : 1];
   __shared__ u32  cnt[4][256];
   __shared__ u32  dstart[256];
   __shared__ u32  gadj[256];
@@ -173,7 +173,7 @@ void radix_scatter(const KeyT *__restrict__ kin, const u32 *__restrict__ vin,
     { u64  i = wbase + (u64) r * 64 + l;
       bool ok = i < n;
       key[r] = ok ? kin[i] : (KeyT) 0;
-      val[r] = ok ? vin[i] : 0u;
+      if (HV) val[r] = ok ? vin[i] : 0u;
     }
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++)
@@ -214,7 +214,7 @@ void radix_scatter(const KeyT *__restrict__ kin, const u32 *__restrict__ vin,
         { u32 d  = (u32) (key[r] >> shift) & mask;
           u32 lp = dstart[d] + cnt[w][d] + rnk[r];
           skey[lp] = key[r];
-          sval[lp] = val[r];
+          if (HV) sval[lp] = val[r];
         }
     }
   __syncthreads();
@@ -225,7 +225,7 @@ void radix_scatter(const KeyT *__restrict__ kin, const u32 *__restrict__ vin,
       u32  d = (u32) (k >> shift) & mask;
       u64  g = (u64) gadj[d] + i;
       kout[g] = k;
-      vout[g] = sval[i];
+      if (HV) vout[g] = sval[i];
     }
 }
 
@@ -236,7 +236,7 @@ size_t damar_sort_workspace_bytes(u64 n)
 
 /* Sorts on key bits [0, nbits).  Ping-pongs between (k0,v0) and (k1,v1); returns 0 if
  * the result is in (k0,v0), 1 if in (k1,v1). */
-template <typename KeyT>
+template <typename KeyT, bool HV>
 static int radix_sort_impl(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int nbits,
                            void *work, hipStream_t st)
 { u32  ntiles = (u32) ((n + RS_TILE - 1) / RS_TILE);
@@ -253,7 +253,7 @@ static int radix_sort_impl(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int nbit
       u32  *vi = side ? v1 : v0, *vo = side ? v0 : v1;
       hipLaunchKernelGGL(radix_hist<KeyT>, dim3(ntiles), dim3(RS_THREADS), 0, st, ki, n, shift, mask, ghist, ntiles);
       damar_exclusive_scan_u32(ghist, ghist, (u64) 256 * ntiles, swork, tot, st);
-      hipLaunchKernelGGL(radix_scatter<KeyT>, dim3(ntiles), dim3(RS_THREADS), 0, st,
+      hipLaunchKernelGGL((radix_scatter<KeyT, HV>), dim3(ntiles), dim3(RS_THREADS), 0, st,
                          ki, vi, ko, vo, n, shift, mask, ghist, ntiles);
       side ^= 1;
     }
@@ -261,7 +261,11 @@ static int radix_sort_impl(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int nbit
 }
 
 int damar_radix_sort_u32(u32 *k0, u32 *v0, u32 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st)
-{ return radix_sort_impl<u32>(k0, v0, k1, v1, n, nbits, work, st); }
+{ return radix_sort_impl<u32, true>(k0, v0, k1, v1, n, nbits, work, st); }
+
+/* keys only */
+int damar_radix_sort_keys_u32(u32 *k0, u32 *k1, u64 n, int nbits, void *work, hipStream_t st)
+{ return radix_sort_impl<u32, false>(k0, NULL, k1, NULL, n, nbits, work, st); }
 
 int damar_radix_sort_u64(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st)
-{ return radix_sort_impl<u64>(k0, v0, k1, v1, n, nbits, work, st); }
+{ return radix_sort_impl<u64, true>(k0, v0, k1, v1, n, nbits, work, st); }

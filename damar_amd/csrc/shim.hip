@@ -97,6 +97,7 @@ static Arena G_work = { NULL, 0, 0 };       /* per-call temporaries, grow-only *
 static Arena G_hitsJ[DAMAR_MAX_JOBS];       /* sorted seed pairs of the comparisons of the current report launch, one arena each
                                                (12 B per seed pair: what the report kernel reads) */
 static Arena G_ordJ[DAMAR_MAX_JOBS];        /* their work lists and processing orders   */
+static Arena G_tmp2 = { NULL, 0, 0 };       /* the same for what is left after the early cut */
 static Arena G_tmp  = { NULL, 0, 0 };       /* sort ping-pong partner, flags, scan space of the seed stage: shared by the
                                                comparisons (the stream orders them), 20 B per seed pair */
 
@@ -1427,43 +1428,132 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
     return false;
 
   /* hits known.  The sorted seed pairs stay in this comparison's own arena until the report launch; everything else
-     of the seed stage lives in an arena the comparisons share.  The sort ping-pongs: it is started from the side that
+     of the seed stage lives in arenas the comparisons share.  The sort ping-pongs: it is started from the side that
      makes the result land in the comparison's arena (the number of passes is known). */
   const int sbits = m.pbits + m.abits + bbits;
   const int spasses = (sbits + 7) / 8;                        /* sort_scan.hip: 8 bits per pass */
-  arena_reserve(&G_hits, pad256(sizeof(u64) * (size_t) total) + pad256(sizeof(u32) * (size_t) total) + 4096);
-  arena_reserve(&G_tmp,  pad256(sizeof(u64) * (size_t) total) + 3 * pad256(sizeof(u32) * (size_t) total) +
-                         pad256(damar_sort_workspace_bytes(total)) + pad256(damar_scan_workspace_bytes(total)) + 8192);
-  u64 *pk = (u64 *) arena_take(&G_hits, sizeof(u64) * (size_t) total);
-  u32 *pv = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
-  u64 *tk = (u64 *) arena_take(&G_tmp, sizeof(u64) * (size_t) total);
-  u32 *tv = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
-  u64 *k0 = (spasses & 1) ? tk : pk, *k1 = (spasses & 1) ? pk : tk;
-  u32 *v0 = (spasses & 1) ? tv : pv, *v1 = (spasses & 1) ? pv : tv;
-  void *sw = arena_take(&G_tmp, damar_sort_workspace_bytes(total));
-  u32 *flags = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
-  u32 *foff  = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
-  void *scw2 = arena_take(&G_tmp, damar_scan_workspace_bytes(total));
-  u64 *sends = (u64 *) arena_take(&G_tmp, 64 * sizeof(u64));
+  const int minhit = (P_hitmin - 1) / P_kmer + 1;
+  const int idbits = m.abits + bbits;                         /* a read pair as one number: bread << abits | aread */
+  static int cut_on = -1;
+  if (cut_on < 0)
+    { const char *e = getenv("DAMAR_EARLY_CUT");
+      cut_on = e ? atoi(e) : 0;      /* measured on config 2: 38 % of the seed pairs belong to read pairs with >= 3 seeds
+                                        (76.4 M seeds, 42.9 M read pairs, 5.8 M of them with >= 3), so the cut saves 3.7 of
+                                        the 6 sort passes but costs a 4-pass sort of the pair ids and two more passes over
+                                        the seeds: merge + sort + work list 203 -> 209 ms per step.  Off unless asked for;
+                                        with a B-read range (a pair split over GPUs) it keeps only that range's seeds. */
+    }
+  const bool ranged = P_bread_lo > 0 || P_bread_hi != 0xffffffffu;      /* one part of a block pair split over GPUs */
+  const bool cut = (cut_on || ranged) && !G_keep_seeds && idbits <= 32;
+  u64 *keys, *tk;
+  u32 *vals, *flags, *foff;
+  void *scw2;
+  u64 *sends;
+  int  hshift = P_nshift;                                     /* slices of the reference's threads in the head test */
+  if (!cut)
+    { arena_reserve(&G_hits, pad256(sizeof(u64) * (size_t) total) + pad256(sizeof(u32) * (size_t) total) + 4096);
+      arena_reserve(&G_tmp,  pad256(sizeof(u64) * (size_t) total) + 3 * pad256(sizeof(u32) * (size_t) total) +
+                             pad256(damar_sort_workspace_bytes(total)) + pad256(damar_scan_workspace_bytes(total)) + 8192);
+      u64 *pk = (u64 *) arena_take(&G_hits, sizeof(u64) * (size_t) total);
+      u32 *pv = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
+      tk = (u64 *) arena_take(&G_tmp, sizeof(u64) * (size_t) total);
+      u32 *tv = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
+      u64 *k0 = (spasses & 1) ? tk : pk, *k1 = (spasses & 1) ? pk : tk;
+      u32 *v0 = (spasses & 1) ? tv : pv, *v1 = (spasses & 1) ? pv : tv;
+      void *sw = arena_take(&G_tmp, damar_sort_workspace_bytes(total));
+      flags = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
+      foff  = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
+      scw2  = arena_take(&G_tmp, damar_scan_workspace_bytes(total));
+      sends = (u64 *) arena_take(&G_tmp, 64 * sizeof(u64));
 
-  damar_launch_merge_emit(&m, cnt, (const u32 *) scw, jb, total, k0, v0, G_st);
-  stage("merge_emit");
-  tick(1);
-  int side = damar_radix_sort_u64(k0, v0, k1, v1, total, sbits, sw, G_st);
-  u64 *keys = side ? k1 : k0;
-  u32 *vals = side ? v1 : v0;
-  if (keys != pk)
-    { fprintf(stderr, "damar: internal error, the seed sort ended on the wrong side\n");
-      die();
+      damar_launch_merge_emit(&m, cnt, (const u32 *) scw, jb, total, k0, v0, NULL, G_st);
+      stage("merge_emit");
+      tick(1);
+      int side = damar_radix_sort_u64(k0, v0, k1, v1, total, sbits, sw, G_st);
+      keys = side ? k1 : k0;
+      vals = side ? v1 : v0;
+      if (keys != pk)
+        { fprintf(stderr, "damar: internal error, the seed sort ended on the wrong side\n");
+          die();
+        }
+    }
+  else
+    { /* The early cut (kernels/seed_merge.hip): only the seeds of the read pairs report_thread enters go through the
+         seed sort.  The pair ids are sorted on their own (4 B per seed instead of 12, 4 passes instead of 6), the
+         reference's head test runs on them, and the seeds of the surviving pairs -- a few per cent -- are compacted
+         out of the unsorted seeds. */
+      const size_t bmwords = (((size_t) 1 << idbits) + 31) / 32;
+      arena_reserve(&G_tmp, pad256(sizeof(u64) * (size_t) total) + 4 * pad256(sizeof(u32) * (size_t) total) +
+                            pad256(sizeof(u32) * ((size_t) total / minhit + 64)) +
+                            pad256(damar_sort_workspace_bytes(total)) + pad256(damar_scan_workspace_bytes(total)) +
+                            pad256(sizeof(u32) * bmwords) + 16384);
+      u64 *uk   = (u64 *) arena_take(&G_tmp, sizeof(u64) * (size_t) total);
+      u32 *uv   = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
+      u32 *pid0 = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
+      u32 *pid1 = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
+      u32 *hbit = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);          /* head bits: total / 8 bytes used */
+      u32 *hd   = (u32 *) arena_take(&G_tmp, sizeof(u32) * ((size_t) total / minhit + 64));
+      void *sw  = arena_take(&G_tmp, damar_sort_workspace_bytes(total));
+      void *scc = arena_take(&G_tmp, damar_scan_workspace_bytes(total));
+      u32 *bitmap = (u32 *) arena_take(&G_tmp, sizeof(u32) * bmwords);
+      u64 *snd  = (u64 *) arena_take(&G_tmp, 64 * sizeof(u64));
+
+      damar_launch_merge_emit(&m, cnt, (const u32 *) scw, jb, total, uk, uv, pid0, G_st);
+      stage("merge_emit");
+      tick(1);
+      const u32 *spid = damar_radix_sort_keys_u32(pid0, pid1, total, idbits, sw, G_st) ? pid1 : pid0;
+      u64 n64 = 0;
+      damar_launch_pair_heads_ids(spid, total, m.abits, minhit, P_nshift, snd, (u64 *) hbit, scc, tot, hd, G_st);
+      HIP_CHECK(hipMemsetAsync(bitmap, 0, sizeof(u32) * bmwords, G_st));
+      HIP_CHECK(hipMemcpyAsync(&n64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      damar_launch_pair_bitmap(spid, hd, (u32) n64, m.abits, P_bread_lo, P_bread_hi, bitmap, G_st);
+      damar_launch_seed_cut_count(uk, total, m.pbits, bitmap, (u32 *) scc, tot, G_st);
+      HIP_CHECK(hipMemcpyAsync(&n64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      stage("early_cut");
+      const u64 nsurv = n64;
+      G_cnt[6] += (int64) nsurv;
+      if (nsurv == 0)
+        { tick(2);  tick(3);
+          G_ms[DAMAR_T_MERGE] += lap(0, 1);
+          G_ms[DAMAR_T_SSORT] += lap(1, 2);
+          G_cnt[0] += nhits;
+          job->counts[0] = nhits;
+          return false;
+        }
+      arena_reserve(&G_hits, pad256(sizeof(u64) * (size_t) nsurv) + pad256(sizeof(u32) * (size_t) nsurv) + 4096);
+      arena_reserve(&G_tmp2, pad256(sizeof(u64) * (size_t) nsurv) + 3 * pad256(sizeof(u32) * (size_t) nsurv) +
+                             pad256(damar_sort_workspace_bytes(nsurv)) + pad256(damar_scan_workspace_bytes(nsurv)) + 8192);
+      u64 *pk = (u64 *) arena_take(&G_hits, sizeof(u64) * (size_t) nsurv);
+      u32 *pv = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) nsurv);
+      tk = (u64 *) arena_take(&G_tmp2, sizeof(u64) * (size_t) nsurv);
+      u32 *tv = (u32 *) arena_take(&G_tmp2, sizeof(u32) * (size_t) nsurv);
+      u64 *k0 = (spasses & 1) ? tk : pk, *k1 = (spasses & 1) ? pk : tk;
+      u32 *v0 = (spasses & 1) ? tv : pv, *v1 = (spasses & 1) ? pv : tv;
+      void *sw2 = arena_take(&G_tmp2, damar_sort_workspace_bytes(nsurv));
+      flags = (u32 *) arena_take(&G_tmp2, sizeof(u32) * (size_t) nsurv);
+      foff  = (u32 *) arena_take(&G_tmp2, sizeof(u32) * (size_t) nsurv);
+      scw2  = arena_take(&G_tmp2, damar_scan_workspace_bytes(nsurv));
+      sends = (u64 *) arena_take(&G_tmp2, 64 * sizeof(u64));
+      damar_launch_seed_cut_scatter(uk, uv, total, m.pbits, bitmap, (const u32 *) scc, k0, v0, G_st);
+      int side = damar_radix_sort_u64(k0, v0, k1, v1, nsurv, sbits, sw2, G_st);
+      keys = side ? k1 : k0;
+      vals = side ? v1 : v0;
+      if (keys != pk)
+        { fprintf(stderr, "damar: internal error, the seed sort ended on the wrong side\n");
+          die();
+        }
+      total  = nsurv;              /* from here on: the seeds of the read pairs that are entered, nothing else */
+      hshift = -1;                 /* (the slice rule of the head test has been applied on the pair ids) */
     }
   stage("seed_sort");
   tick(2);
 
   /* ---- work list ---- */
-  const int minhit = (P_hitmin - 1) / P_kmer + 1;
   u64 nwork64 = 0;
   u32 *heads = (u32 *) tk;                              /* the idle key buffer holds the run heads */
-  damar_launch_pair_heads(keys, total, m.pbits, m.abits, minhit, P_nshift, sends, (u64 *) foff /* bit words */,
+  damar_launch_pair_heads(keys, total, m.pbits, m.abits, minhit, hshift, sends, (u64 *) foff /* bit words */,
                           scw2, tot, heads, G_st);
   stage("run_heads");
   HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));

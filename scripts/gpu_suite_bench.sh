@@ -17,3 +17,4 @@ print(d["roofline"]["note"][-230:])
 print("e2e", d["end_to_end"])
 PY
 grep "damar host wall\|scratch grow" gpurun_out/quick_bench.err | tail -6
+if [ -n "$JUNK" ]; then timeout -k 10 300 python3 scripts/seed_junk.py 2>&1 | tail -6; fi

@@ -202,6 +202,26 @@ def test_gpu_cli_plan_mode_equals_reference_golden(gpu, tmp_path, name, front, c
     assert compare_las(case, work) == []
 
 
+@pytest.mark.parametrize("env_extra", [{"DAMAR_EARLY_CUT": "1"}, {"DAMAR_BATCH": "1"}, {"DAMAR_BATCH": "16"},
+                                       {"DAMAR_PACKED": "0", "DAMAR_BATCH": "2"}, {"DAMAR_EARLY_CUT": "1", "DAMAR_TEST_SMALL_CAPS": "1"}])
+@pytest.mark.parametrize("name", ["tiny2", "prod"])
+def test_gpu_cli_plan_mode_other_launch_shapes_equal_reference_golden(gpu, tmp_path, name, env_extra):
+    """The switches that change how the work reaches the report kernel -- the early cut of the seed pairs, the number of
+    comparisons per launch, one read pair per wavefront -- must not change a byte of the output."""
+    import subprocess
+    from conftest import read_case, link_db, compare_las
+    from damar_amd import api
+    case = read_case(name)
+    work = str(tmp_path)
+    link_db(case["dbdir"], work)
+    with open(os.path.join(work, "plan.txt"), "w") as f:
+        for a, bs in case["lines"]:
+            f.write("daligner %s G.%s %s\n" % (" ".join(case["opts"]), a, " ".join("G." + b for b in bs)))
+    subprocess.run([api.daligner_binary(), "-P", "plan.txt"], cwd=work, check=True, env=dict(os.environ, **env_extra),
+                   stdout=subprocess.DEVNULL)
+    assert compare_las(case, work) == []
+
+
 def test_gpu_cli_plan_mode_evicts_and_rereads_blocks(gpu, tmp_path):
     """A 4-block plan through `daligner -P` with room for 2 blocks only (DAMAR_PLAN_BLOCKS=2): every line's B
     blocks push each other out and are read, complemented and indexed again; files equal the CPU oracle's."""
