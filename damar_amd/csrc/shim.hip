@@ -1088,9 +1088,10 @@ struct Stage
 { std::mutex              mu;
   std::condition_variable cv, idle;
   std::deque<TailJob *>   queue;
-  bool                    busy, quit;
-  std::thread            *thread;
-  Stage() : busy(false), quit(false), thread(NULL) {}
+  int                     busy;              /* jobs taken off the queue and not finished yet */
+  bool                    quit;
+  std::vector<std::thread *> threads;
+  Stage() : busy(0), quit(false) {}
 };
 static bool   A_on = false;
 static Stage &A_s1 = *new Stage();
@@ -1113,20 +1114,20 @@ static TailJob *stage_next(Stage &st)
     return NULL;
   TailJob *job = st.queue.front();
   st.queue.pop_front();
-  st.busy = true;
+  st.busy += 1;
   return job;
 }
 
 static void stage_done(Stage &st)
 { { std::lock_guard<std::mutex> lk(st.mu);
-    st.busy = false;
+    st.busy -= 1;
   }
   st.idle.notify_all();
 }
 
 static void stage_drain(Stage &st)
 { std::unique_lock<std::mutex> lk(st.mu);
-  st.idle.wait(lk, [&st] { return st.queue.empty() && !st.busy; });
+  st.idle.wait(lk, [&st] { return st.queue.empty() && st.busy == 0; });
 }
 
 static void tail_worker(void)
@@ -1195,8 +1196,16 @@ extern "C" void damar_async_drain(void)
 extern "C" void damar_set_async(int on)
 { if (on && !A_on)
     { A_s1.quit = A_s2.quit = false;
-      A_s1.thread = new std::thread(tail_worker);
-      A_s2.thread = new std::thread(write_worker);
+      A_s1.threads.push_back(new std::thread(tail_worker));      /* one: the tails append to the overlap buffers in order */
+      /* the sort + write of a block pair's files is independent of every other pair's: two writers by default
+         (DAMAR_WRITE_THREADS), so that the files of the last pairs are not written one after the other at the drain */
+      { const char *e = getenv("DAMAR_WRITE_THREADS");
+        int n = e ? atoi(e) : 2;
+        if (n < 1) n = 1;
+        if (n > 16) n = 16;
+        for (int i = 0; i < n; i++)
+          A_s2.threads.push_back(new std::thread(write_worker));
+      }
       A_on = true;
     }
   else if (!on && A_on)
@@ -1207,9 +1216,11 @@ extern "C" void damar_set_async(int on)
             st[i]->quit = true;
           }
           st[i]->cv.notify_all();
-          st[i]->thread->join();
-          delete st[i]->thread;
-          st[i]->thread = NULL;
+          for (std::thread *th : st[i]->threads)
+            { th->join();
+              delete th;
+            }
+          st[i]->threads.clear();
         }
       A_on = false;
     }
