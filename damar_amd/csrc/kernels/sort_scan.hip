@@ -146,12 +146,14 @@ void radix_hist(const KeyT *__restrict__ keys, u64 n, int shift, u32 mask,
 /* Stable scatter of one tile.  Wave w owns items [w*1024,(w+1)*1024) of the tile in
  * rounds of 64 consecutive items, so (wave, round, lane) order == input order. */
 template <typename KeyT, bool HV>          /* HV: a u32 payload travels with the key */
-__global__ __launch_bounds__(RS_THREADS)
+__global__ __launch_bounds__(RS_THREADS, 4)
 void radix_scatter(const KeyT *__restrict__ kin, const u32 *__restrict__ vin,
                    KeyT *__restrict__ kout, u32 *__restrict__ vout, u64 n,
                    int shift, u32 mask, const u32 *__restrict__ gscan, u32 ntiles)
-{ __shared__ KeyT skey[RS_TILE];
-  __shared__ u32  sval[HV ? RS_TILE : 1];
+{ /* keys and payload are staged through the SAME buffer one after the other: 32 + 6 KB of LDS per workgroup for u64 keys
+     instead of 54 KB, i.e. 4 resident workgroups per CU instead of 2 (3 x 54 KB does not fit the 160 KB) */
+  __shared__ KeyT skey[RS_TILE];
+  u32 *const sval = (u32 *) skey;
   __shared__ u32  cnt[4][256];
   __shared__ u32  dstart[256];
   __shared__ u32  gadj[256];
@@ -166,14 +168,12 @@ void radix_scatter(const KeyT *__restrict__ kin, const u32 *__restrict__ vin,
   __syncthreads();
 
   KeyT key[RS_ROUNDS];
-  u32  val[RS_ROUNDS];
   u32  rnk[RS_ROUNDS];
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++)
     { u64  i = wbase + (u64) r * 64 + l;
       bool ok = i < n;
       key[r] = ok ? kin[i] : (KeyT) 0;
-      if (HV) val[r] = ok ? vin[i] : 0u;
     }
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++)
@@ -213,19 +213,39 @@ void radix_scatter(const KeyT *__restrict__ kin, const u32 *__restrict__ vin,
       if (i < n)
         { u32 d  = (u32) (key[r] >> shift) & mask;
           u32 lp = dstart[d] + cnt[w][d] + rnk[r];
+          rnk[r] = lp;                             /* position inside the tile's output */
           skey[lp] = key[r];
-          if (HV) sval[lp] = val[r];
         }
     }
   __syncthreads();
 
-  u32 have = (n - tbase < (u64) RS_TILE) ? (u32) (n - tbase) : (u32) RS_TILE;
-  for (u32 i = threadIdx.x; i < have; i += RS_THREADS)
-    { KeyT k = skey[i];
-      u32  d = (u32) (k >> shift) & mask;
-      u64  g = (u64) gadj[d] + i;
-      kout[g] = k;
-      if (HV) vout[g] = sval[i];
+  const u32 have = (n - tbase < (u64) RS_TILE) ? (u32) (n - tbase) : (u32) RS_TILE;
+  u32 gdst[RS_ROUNDS];                             /* where this thread's output positions go (n < 2^32) */
+#pragma unroll
+  for (int q = 0; q < RS_ROUNDS; q++)
+    { const u32 i = threadIdx.x + (u32) q * RS_THREADS;
+      if (i < have)
+        { KeyT k = skey[i];
+          u32  d = (u32) (k >> shift) & mask;
+          gdst[q] = gadj[d] + i;
+          kout[gdst[q]] = k;
+        }
+    }
+  if (HV)
+    { __syncthreads();
+#pragma unroll
+      for (int r = 0; r < RS_ROUNDS; r++)
+        { u64 i = wbase + (u64) r * 64 + l;
+          if (i < n)                                 /* (the payload is loaded only now: 16 registers less while ranking) */
+            sval[rnk[r]] = vin[i];
+        }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < RS_ROUNDS; q++)
+        { const u32 i = threadIdx.x + (u32) q * RS_THREADS;
+          if (i < have)
+            vout[gdst[q]] = sval[i];
+        }
     }
 }
 

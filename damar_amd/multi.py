@@ -9,10 +9,11 @@ from one shared cursor -- an atomic counter in the job's torch.distributed store
 unit, so a slow pair, a slow GPU or a busy host core delays nobody else (work stealing without victims).
 RCCL is used only for the barriers around the job and the final reduction of the counters.
 
-Units are ordered for the queue: cross pairs first (two index builds + twice the seeds of a self pair),
-row-major like the plan so that a rank's consecutive pulls mostly share the A block (its k-mer index is
-built once and stays in that rank's LRU index cache), self pairs last to even out the tail.  When the
-plan has fewer than two units per rank (config 2 on 8 GPUs: 10 pairs), cross pairs are split by B-read
+A unit of the queue is one A block against up to GROUP subject blocks, both orientations each (the plan's
+lines cut into groups, most expensive first): the comparisons of a unit share launches of the report kernel
+(damar_match_batch), and the A block's k-mer index is built once per rank and stays in its LRU index cache.
+The group size is halved until every rank can expect about six units.  When the plan has fewer than two
+block pairs per rank (config 2 on 8 GPUs: 10 pairs), the units are single pairs and cross pairs are split by B-read
 range (damar_set_bread_range): every part runs the index merge and the seed sort of the whole pair and
 then only its share of the read pairs -- the dominant 60 % -- and the parts' sorted files are merged
 into exactly the files the unsplit pair writes.
