@@ -304,7 +304,7 @@ def main():
             us = units if my_units is None else my_units
             runner = multi.GpuRunner(dict(j=args.threads_param), resident=blocks)
             if queue is None:
-                queue = multi.StoreQueue(store, tag, len(us)) if store is not None else multi.LocalQueue(len(us))
+                queue = multi.make_queue(store, tag, us, rank)
             mine = multi.run_queue(dbprefix, us, out, queue, runner)
             runner.finish()          # drains the asynchronous host tail: every .las of this rank is closed
             if any(n > 1 for _, _, _, n in us):
@@ -454,7 +454,8 @@ def main():
                                "index_builds_per_step": builds / steps,
                                "comparisons_per_step": nmatch, "report_launches_per_step": nlaunch,
                                "parallelism": "%d GPU(s), one process each, ONE database; %d work units per step (%s) "
-                                              "pulled from a shared cursor, no data-path collective; busiest rank ran %d units"
+                                              "pulled from cursors in the job's store (one region of the plan per rank, the others' "
+                                              "leftovers after it), no data-path collective; busiest rank ran %d units"
                                               % (world, len(units),
                                                  "block pairs split %d-way by B-read range" % nsplit if nsplit > 1 else
                                                  "one A block against up to %d subject blocks, both orientations, behind one "

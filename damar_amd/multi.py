@@ -65,10 +65,85 @@ def group_units(nblocks, g):
     return units
 
 
+class Units(list):
+    """The queue's contents; .parts = [(first, end), ...] index ranges, one per rank, when the units are dealt by region
+    (RegionQueue), else None (one cursor for all)."""
+    parts = None
+
+
+def _region_cost(reg):
+    alo, ahi, blo, bhi = reg
+    return sum(pair_cost(a, b) for a in range(alo, ahi + 1) for b in range(blo, min(a, bhi) + 1))
+
+
+def _split_region(reg, k):
+    """k regions of about equal cost out of the pairs {alo <= a <= ahi, blo <= b <= min(a, bhi)} by recursive bisection,
+    each time across the dimension that is longer in index builds (an A block costs one k-mer index, a subject block
+    two: both strands)."""
+    if k <= 1:
+        return [reg]
+    alo, ahi, blo, bhi = reg
+    alo = max(alo, blo)                                   # rows below blo are empty
+    bhi = min(bhi, ahi)
+    k1 = k // 2
+    want = _region_cost((alo, ahi, blo, bhi)) * k1 / float(k)
+    cuts = []
+    if ahi > alo:
+        cuts += [("a", t) for t in range(alo, ahi)]       # A <= t | A > t
+    if bhi > blo:
+        cuts += [("b", t) for t in range(blo, bhi)]       # B <= t | B > t
+    if not cuts:
+        return [(alo, ahi, blo, bhi)]
+    prefer = "a" if (ahi - alo + 1) >= 2 * (bhi - blo + 1) else "b"
+    best = None
+    for dim, t in cuts:
+        left = (alo, t, blo, bhi) if dim == "a" else (alo, ahi, blo, t)
+        right = (t + 1, ahi, blo, bhi) if dim == "a" else (alo, ahi, t + 1, bhi)
+        cl, cr = _region_cost(left), _region_cost(right)
+        if cl == 0 or cr == 0:
+            continue
+        key = (dim != prefer, abs(cl - want))
+        if best is None or key < best[0]:
+            best = (key, left, right)
+    if best is None:
+        return [(alo, ahi, blo, bhi)]
+    # the preferred dimension unless its best cut is badly off balance
+    alt = min(((abs(_region_cost((alo, t, blo, bhi) if d == "a" else (alo, ahi, blo, t)) - want), d, t) for d, t in cuts
+               if _region_cost((alo, t, blo, bhi) if d == "a" else (alo, ahi, blo, t)) > 0
+               and _region_cost((t + 1, ahi, blo, bhi) if d == "a" else (alo, ahi, t + 1, bhi)) > 0), default=None)
+    if alt is not None and best[0][1] > 0.15 * max(want, 1.) and alt[0] < best[0][1]:
+        d, t = alt[1], alt[2]
+        best = (None, (alo, t, blo, bhi) if d == "a" else (alo, ahi, blo, t),
+                (t + 1, ahi, blo, bhi) if d == "a" else (alo, ahi, t + 1, bhi))
+    return _split_region(best[1], k1) + _split_region(best[2], k - k1)
+
+
+def region_units(nblocks, world, g):
+    """The block pairs cut into `world` regions of about equal cost (A range x subject range of the plan's triangle), each
+    region's pairs as units (a, (b, ...), 0, 1) of at most g subject blocks.  A rank that works through ONE region builds
+    the k-mer indexes of that region's blocks only -- with pairs dealt from one list every rank ends up building nearly
+    every index of the database, which at 8 GPUs costs a quarter of the step."""
+    regs = _split_region((1, nblocks, 1, nblocks), world)
+    units = Units()
+    parts = []
+    for alo, ahi, blo, bhi in regs:
+        first = len(units)
+        for a in range(alo, ahi + 1):
+            bs = [b for b in range(min(a, bhi), blo - 1, -1)]
+            for k in range(0, len(bs), g):
+                units.append((a, tuple(bs[k:k + g]), 0, 1))
+        parts.append((first, len(units)))
+    while len(parts) < world:                              # fewer regions than ranks: the others only steal
+        parts.append((len(units), len(units)))
+    units.parts = parts
+    return units
+
+
 def work_units(nblocks, world, units_per_rank=2, fine=6):
     """The queue's contents.  Enough block pairs for the ranks: groups (a, (b, ...), 0, 1) of one A block against up to
     GROUP subject blocks -- one report launch each, the larger the group the smaller the share of the launch spent
-    waiting for its longest alignment -- as large as still leaves `fine` units per rank (one GPU: whole plan lines).
+    waiting for its longest alignment -- as large as still leaves `fine` units per rank (one GPU: whole plan lines), dealt
+    by region for several ranks (region_units).
     Too few pairs for `world` ranks: (a, b, part, nparts) with b <= a, cross pairs first in plan order, then the self
     pairs, split by B-read range."""
     cross = [(a, b) for a in range(1, nblocks + 1) for b in range(a - 1, 0, -1)]
@@ -78,13 +153,13 @@ def work_units(nblocks, world, units_per_rank=2, fine=6):
         g = GROUP
         while g > 1 and world > 1 and len(group_units(nblocks, g)) < fine * world:
             g //= 2
-        return group_units(nblocks, g)
+        return Units(group_units(nblocks, g)) if world == 1 else region_units(nblocks, world, g)
     ncross = nself = 1
     if world > 1 and npairs < units_per_rank * world:
         # cost units (cross = 2, self = 1) per rank wanted: split so that every rank gets about units_per_rank pieces
         ncross = -(-units_per_rank * world // npairs)          # ceil
         nself = max(1, ncross // 2)
-    units = [(a, b, i, ncross) for a, b in cross for i in range(ncross)]
+    units = Units((a, b, i, ncross) for a, b in cross for i in range(ncross))
     units += [(a, b, i, nself) for a, b in selfs for i in range(nself)]
     return units
 
@@ -111,6 +186,37 @@ class StoreQueue:
     def next(self):
         i = self.store.add(self.key, 1) - 1
         return i if i < self.n else None
+
+
+class RegionQueue:
+    """One cursor per region (`parts`: index ranges into the unit list, one per rank): a rank works through its own
+    region and then takes what is left of the others', the next rank's first -- affinity without giving up the
+    dynamic balance.  Cursors are atomic adds on the job's store like StoreQueue's."""
+
+    def __init__(self, store, name, parts, rank):
+        self.store, self.name, self.parts = store, name, list(parts)
+        self.order = [(rank + i) % len(self.parts) for i in range(len(self.parts))]
+        self.done = set()
+
+    def next(self):
+        for p in self.order:
+            if p in self.done:
+                continue
+            first, end = self.parts[p]
+            i = self.store.add("damar/cursor/%s/%d" % (self.name, p), 1) - 1 if end > first else end - first
+            if i < end - first:
+                return first + i
+            self.done.add(p)
+        return None
+
+
+def make_queue(store, name, units, rank=0):
+    """The queue for one pass over `units` (name must be new for every pass)."""
+    if store is None:
+        return LocalQueue(len(units))
+    if getattr(units, "parts", None):
+        return RegionQueue(store, name, units.parts, rank)
+    return StoreQueue(store, name, len(units))
 
 
 def default_store():
@@ -280,7 +386,7 @@ def main():
     api.lib().damar_hip_init(local)
     runner = GpuRunner()
     units = work_units(nblocks, world)
-    queue = StoreQueue(default_store(), "main", len(units))
+    queue = make_queue(default_store(), "main", units, rank)
     dist.barrier()
     t0 = time.time()
     mine = run_queue(dbprefix, units, outdir, queue, runner)

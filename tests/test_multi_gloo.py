@@ -88,7 +88,7 @@ def oracle_runner(a, b, outdir, part, nparts):
                 filter_las(os.path.join(dp, f), os.path.join(outdir, rel), keep)
 
 units = multi.work_units(nblocks, world, units_per_rank=upr)
-queue = multi.StoreQueue(multi.default_store(), "t", len(units))
+queue = multi.make_queue(multi.default_store(), "t", units, rank)
 dist.barrier()
 mine = multi.run_queue(os.path.join(work, "G"), units, work, queue, oracle_runner)
 dist.barrier()
@@ -122,9 +122,11 @@ def test_work_units_cover_every_pair_once():
         if all(not isinstance(b, tuple) for _, b, _, _ in units):
             kinds = [a == b for a, b, _, _ in units]      # split pairs: cross pairs come first, self pairs last
             assert kinds == sorted(kinds)
-        else:
+        elif world == 1:
             cost = [sum(1 if b == a else 2 for b in bs) for a, bs, _, _ in units]
-            assert cost == sorted(cost, reverse=True)     # groups: most expensive first
+            assert cost == sorted(cost, reverse=True)     # one GPU: groups, most expensive first
+        else:
+            assert units.parts is not None                # several ranks: groups dealt by region
         q = multi.LocalQueue(len(units))
         got = []
         while True:
@@ -133,6 +135,50 @@ def test_work_units_cover_every_pair_once():
                 break
             got.append(i)
         assert got == list(range(len(units)))
+
+
+def test_region_queue_hands_out_every_unit_once_own_region_first():
+    from damar_amd import multi
+
+    class FakeStore:                      # the store's atomic add
+        def __init__(self):
+            self.v = {}
+
+        def add(self, key, n):
+            self.v[key] = self.v.get(key, 0) + n
+            return self.v[key]
+
+    for nb, world in [(17, 8), (6, 3), (16, 2), (255, 8)]:
+        units = multi.work_units(nb, world)
+        assert units.parts is not None and len(units.parts) == world
+        assert units.parts[0][0] == 0 and units.parts[-1][1] == len(units)
+        assert all(units.parts[i][1] == units.parts[i + 1][0] for i in range(world - 1))
+        cost = [sum(sum(1 if b == a else 2 for b in bs) for a, bs, _, _ in units[f:e]) for f, e in units.parts]
+        assert max(cost) <= 1.5 * (sum(cost) / world) + 4                 # regions of about equal cost
+        # a region needs far fewer k-mer indexes than the whole database has (nb forward + nb complement)
+        if nb >= 16:
+            for f, e in units.parts:
+                blocks_a = {a for a, _, _, _ in units[f:e]}
+                blocks_b = {b for _, bs, _, _ in units[f:e] for b in bs}
+                assert len(blocks_a | blocks_b) + len(blocks_b) <= 0.7 * 2 * nb
+        store = FakeStore()
+        queues = [multi.RegionQueue(store, "t", units.parts, r) for r in range(world)]
+        got, first = [], {}
+        live = list(range(world))
+        turn = 0
+        while live:                        # ranks pull in turn; rank 0 stops early to be stolen from
+            r = live[turn % len(live)]
+            turn += 1
+            i = queues[r].next()
+            if i is None:
+                live.remove(r)
+                continue
+            first.setdefault(r, i)
+            got.append(i)
+        assert sorted(got) == list(range(len(units)))
+        for r, i in first.items():
+            f, e = units.parts[r]
+            assert f <= i < e or f == e    # a rank starts in its own region
 
 
 def _run_workers(script_text, work, args, port):
