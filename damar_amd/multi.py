@@ -128,10 +128,14 @@ def region_units(nblocks, world, g):
     parts = []
     for alo, ahi, blo, bhi in regs:
         first = len(units)
+        mine = []
         for a in range(alo, ahi + 1):
             bs = [b for b in range(min(a, bhi), blo - 1, -1)]
             for k in range(0, len(bs), g):
-                units.append((a, tuple(bs[k:k + g]), 0, 1))
+                mine.append((a, tuple(bs[k:k + g]), 0, 1))
+        # most expensive first: what a rank does last (and whose host tail it then waits for) is small
+        mine.sort(key=lambda u: -sum(pair_cost(u[0], b) for b in u[1]))
+        units.extend(mine)
         parts.append((first, len(units)))
     while len(parts) < world:                              # fewer regions than ranks: the others only steal
         parts.append((len(units), len(units)))
