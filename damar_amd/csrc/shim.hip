@@ -80,6 +80,8 @@ extern "C" int Set_Filter_Params(int kmer, int binshift, int suppress, int hitmi
 static int          G_ready = 0;
 static hipStream_t  G_st;
 static hipStream_t   G_copy;                /* record downloads of the asynchronous mode */
+static hipStream_t   G_rep;                 /* report launches of the asynchronous mode: beside the next comparisons' seed stages */
+static hipEvent_t    G_front_done;          /* the seed stages a report launch reads from are complete */
 static hipEvent_t    G_report_done;
 static hipEvent_t    G_last_d2h = NULL;     /* the next report kernel must not overwrite the buffers before it */
 static hipDeviceProp_t G_prop;
@@ -208,6 +210,8 @@ extern "C" int damar_hip_init(int device)
         }
       HIP_CHECK(hipStreamCreate(&G_st));
       HIP_CHECK(hipStreamCreate(&G_copy));
+      HIP_CHECK(hipStreamCreate(&G_rep));
+      HIP_CHECK(hipEventCreate(&G_front_done));
       HIP_CHECK(hipEventCreate(&G_report_done));
       for (int i = 0; i < 16; i++)
         HIP_CHECK(hipEventCreate(&G_ev[i]));
@@ -240,8 +244,11 @@ static void ensure_init(void)
     }
 }
 
+static void finish_pending(void);
+
 extern "C" void damar_hip_sync(void)
 { ensure_init();
+  finish_pending();
   HIP_CHECK(hipDeviceSynchronize());
 }
 
@@ -286,6 +293,7 @@ static void stage(const char *name)
     }
 }
 static void  tick(int i)            { HIP_CHECK(hipEventRecord(G_ev[i], G_st)); }
+static void  tick_on(int i, hipStream_t st) { HIP_CHECK(hipEventRecord(G_ev[i], st)); }
 static float lap(int i, int j)      { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, G_ev[i], G_ev[j])); return ms; }
 
 extern "C" void damar_last_timings(double *ms)  { memcpy(ms, G_ms, sizeof(G_ms)); }
@@ -420,9 +428,12 @@ static damar_dev_block *block_upload_on(const HITS_DB *block, hipStream_t st)
   return b;
 }
 
+static void finish_pending(void);
+
 extern "C" void damar_block_free(damar_dev_block *b)
 { if (b == NULL)
     return;
+  finish_pending();                            /* a report launch in flight may still read the bases */
   HIP_CHECK(hipStreamSynchronize(G_st));
   HIP_CHECK(hipFree(b->bases_alloc));
   HIP_CHECK(hipFree(b->pk_alloc));
@@ -672,10 +683,17 @@ struct ReportScratch
 };
 static ReportScratch RS = {};   /* (nslots_wanted: the slot count asked for when nslots was last sized) */
 
+static bool overlap_on(void);
+
 static int default_slots(void)
 { const char *e = getenv("DAMAR_SLOTS");
   if (e && atoi(e) > 0)
     return atoi(e);
+  /* a report launch that shares the machine with the next comparisons' seed stages leaves them a fifth of the register
+     file: 4 of the 5 wavefronts per SIMD the packed kernel is compiled for (measured, r02_sweeps.txt: 524 ms per step
+     against 549 at 5 and 543 at 3.5) */
+  if (overlap_on())
+    return G_prop.multiProcessorCount * 4 * 2 * std::min(4, damar_report2_waves_per_simd());
   /* every wave slot of the chip: one scratch slot per wavefront of the one-pair kernel, two per wavefront of the packed one */
   return G_prop.multiProcessorCount * 4 * std::max(damar_report_waves_per_simd(), 2 * damar_report2_waves_per_simd());
 }
@@ -696,13 +714,13 @@ static u32 grow_cells(u32 cell_cap)
   return std::min(cell_cap * 4, DAMAR_MAX_CELLS);
 }
 
-static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 cell_cap)
+static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 cell_cap, hipStream_t st)
 { if (tspace <= 0 || std::max(amax, bmax) / tspace + 8 > DAMAR_MAX_MARKS)      /* 14 bits of trace-grid index in a chain head */
     { fprintf(stderr, "damar: FATAL: reads of %d bases need a trace spacing (-s) of at least %d\n", std::max(amax, bmax),
               std::max(amax, bmax) / (DAMAR_MAX_MARKS - 8) + 1);
       die();
     } if (G_last_d2h != NULL)        /* whatever is launched next overwrites the record buffers */
-    { HIP_CHECK(hipStreamWaitEvent(G_st, G_last_d2h, 0));
+    { HIP_CHECK(hipStreamWaitEvent(st, G_last_d2h, 0));
       G_last_d2h = NULL;
     }
   /* The band state of a slot (used only while a band is wider than the 64 lanes) is a ring of G_ring
@@ -730,6 +748,7 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
   if (grow || (RS.nslots != nslots && RS.nslots_wanted != nslots))
     { const double g0 = now_ms();
       HIP_CHECK(hipStreamSynchronize(G_st));
+      HIP_CHECK(hipStreamSynchronize(G_rep));
       if (RS.state)   { HIP_CHECK(hipFree(RS.state)); HIP_CHECK(hipFree(RS.marks)); HIP_CHECK(hipFree(RS.cells));
                         HIP_CHECK(hipFree(RS.buckets)); HIP_CHECK(hipFree(RS.ttmp)); RS.state = NULL; }
       /* the scratch of all wave slots must fit what is left of HBM (very long reads: the
@@ -770,8 +789,8 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
       RS.cells   = dmalloc((size_t) 16 * RS.cell_cap * nslots);
       RS.buckets = (int *) dmalloc(sizeof(int) * (size_t) RS.bucket_stride * nslots);
       RS.ttmp    = (u16 *) dmalloc(sizeof(u16) * (size_t) RS.ttmp_stride * nslots);
-      HIP_CHECK(hipMemsetAsync(RS.state, 0, (size_t) RS.state_stride * nslots, G_st));
-      HIP_CHECK(hipMemsetAsync(RS.marks, 0, sizeof(int) * (size_t) RS.marks_stride * nslots, G_st));
+      HIP_CHECK(hipMemsetAsync(RS.state, 0, (size_t) RS.state_stride * nslots, st));
+      HIP_CHECK(hipMemsetAsync(RS.marks, 0, sizeof(int) * (size_t) RS.marks_stride * nslots, st));
       if (getenv("DAMAR_HOSTPROF"))
         fprintf(stderr, "damar: scratch grow: 5 allocations of %.2f GB in all %.1f ms (span %d bwidth %d cells %u)\n",
                 ((double) RS.state_stride + 4. * RS.marks_stride + 16. * RS.cell_cap + 4. * RS.bucket_stride + 2. * RS.ttmp_stride) * nslots / 1073741824.,
@@ -781,13 +800,14 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
     { RS.counters = (u32 *) dmalloc(sizeof(u32) * DAMAR_COUNTER_WORDS);
       RS.tables   = (short *) dmalloc(sizeof(short) * 65536 * DAMAR_MAX_JOBS);
     }
-  HIP_CHECK(hipMemsetAsync(RS.buckets, 0, sizeof(int) * (size_t) RS.bucket_stride * RS.nslots, G_st));
+  HIP_CHECK(hipMemsetAsync(RS.buckets, 0, sizeof(int) * (size_t) RS.bucket_stride * RS.nslots, st));
 }
 
 static void scratch_outputs(u32 rec_cap, u32 tpool_cap)
 { if (RS.rec_cap < rec_cap)
     { HIP_CHECK(hipStreamSynchronize(G_st));
       HIP_CHECK(hipStreamSynchronize(G_copy));
+      HIP_CHECK(hipStreamSynchronize(G_rep));
       if (RS.recs) HIP_CHECK(hipFree(RS.recs));
       RS.rec_cap = rec_cap + (rec_cap >> 2);
       RS.recs = (LaRecord *) dmalloc(sizeof(LaRecord) * (size_t) RS.rec_cap);
@@ -795,6 +815,7 @@ static void scratch_outputs(u32 rec_cap, u32 tpool_cap)
   if (RS.tpool_cap < tpool_cap)
     { HIP_CHECK(hipStreamSynchronize(G_st));
       HIP_CHECK(hipStreamSynchronize(G_copy));
+      HIP_CHECK(hipStreamSynchronize(G_rep));
       if (RS.tpool) HIP_CHECK(hipFree(RS.tpool));
       RS.tpool_cap = tpool_cap + (tpool_cap >> 2);
       RS.tpool = (u16 *) dmalloc(sizeof(u16) * (size_t) RS.tpool_cap);
@@ -802,7 +823,7 @@ static void scratch_outputs(u32 rec_cap, u32 tpool_cap)
 }
 
 static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const damar_dev_block *bb,
-                             int comp, int self, Align_Spec *spec, int job = 0)
+                             int comp, int self, Align_Spec *spec, hipStream_t st, int job = 0, int tslot = 0)
 { memset(ra, 0, sizeof(*ra));
   ra->job = job;
   ra->ablk = ab->d;  ra->bblk = bb->d;
@@ -816,9 +837,9 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   /* SCORE/TABLE of this Align_Spec, every time (128 KB): remembering "the tables of spec X are
      already up" by X's address went wrong when a freed spec's address came back for a new one
      with another -e */
-  HIP_CHECK(hipMemcpyAsync(RS.tables + (size_t) job * 65536, damar_spec_score_table(spec), sizeof(short) * 65536,
-                           hipMemcpyHostToDevice, G_st));
-  ra->score = RS.tables + (size_t) job * 65536;
+  HIP_CHECK(hipMemcpyAsync(RS.tables + (size_t) tslot * 65536, damar_spec_score_table(spec), sizeof(short) * 65536,
+                           hipMemcpyHostToDevice, st));
+  ra->score = RS.tables + (size_t) tslot * 65536;
   ra->table = ra->score + 32768;
   { const int16 *sc = damar_spec_score_table(spec);          /* SCORE[x] = matches * mscore - (15 - matches) * dscore */
     ra->mscore = sc[32767] / 15;
@@ -1189,6 +1210,7 @@ static void async_submit(TailJob *job)
 extern "C" void damar_async_drain(void)
 { if (!A_on)
     return;
+  finish_pending();
   stage_drain(A_s1);           /* stage 1 feeds stage 2: drain in pipeline order */
   stage_drain(A_s2);
 }
@@ -1253,24 +1275,6 @@ extern "C" double damar_async_d2h_ms(void)
   double v = A_d2h_ms;
   A_d2h_ms = 0;
   return v;
-}
-
-/* Write_Overlap_Buffer + Reset_Overlap_Buffer (daligner.c:1020-1021, 1055-1056), queued behind
- * the pending tails in asynchronous mode, immediate otherwise. */
-extern "C" void damar_write_overlaps(Align_Spec *spec, const char *d1, const char *d2,
-                                     const char *ablock, const char *bblock, int lastRead)
-{ if (!A_on)
-    { Write_Overlap_Buffer(spec, (char *) d1, (char *) d2, (char *) ablock, (char *) bblock, lastRead);
-      Reset_Overlap_Buffer(spec);
-      return;
-    }
-  TailJob *job = new TailJob();
-  job->kind = 1;  job->spec = spec;
-  job->has1 = d1 != NULL;  job->has2 = d2 != NULL;
-  if (d1) job->d1 = d1;
-  if (d2) job->d2 = d2;
-  job->a = ablock;  job->b = bblock;  job->last = lastRead;
-  async_submit(job);
 }
 
 /***** Match_Filter **********************************************************************************/
@@ -1631,59 +1635,86 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
   return nwork > 0;
 }
 
-/* One report launch over the comparisons jobs[0..n) whose seed stages are fr[0..n) (nwork > 0 each), the download of
-   its records, and the host tails in job order (filter.c:2442-2483 per read pair). */
-static void match_report(damar_match_job **jobs, const Front *fr, int n)
-{ HostBuf *hb = NULL;
-  u32 hc[DAMAR_COUNTER_WORDS];
-  int amax = 0, bmax = 0, tsmin = 0x7fffffff;
-  u64 nwork = 0;
-  for (int j = 0; j < n; j++)
-    { amax = std::max(amax, jobs[j]->ablock->maxlen);  bmax = std::max(bmax, jobs[j]->bblock->maxlen);
-      tsmin = std::min(tsmin, Trace_Spacing(jobs[j]->spec));
-      nwork += fr[j].nwork;
-    }
-  const double h2 = now_ms();
-  u32 cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
-  u32 rec_cap  = (u32) std::min<u64>(0x7fffffffu, std::max<u64>(RS.rec_cap, 2 * nwork + 4096));
-  u32 tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(RS.tpool_cap, (u64) rec_cap * 256u));
-  if (getenv("DAMAR_TEST_SMALL_CAPS") && RS.rec_cap == 0)      /* tests: start far too small, so that the
-                                                                  overflow flags and the re-launch are exercised */
-    { cell_cap = 64;  rec_cap = 16;  tp_cap = 512; }
-  for (int attempt = 0; ; attempt++)
-    { ReportArgs ra[DAMAR_MAX_JOBS];
-      double q0 = now_ms();
-      scratch_prepare(amax, bmax, P_binshift, tsmin, cell_cap);
-      double q1 = now_ms();
-      scratch_outputs(rec_cap, tp_cap);
-      double q2 = now_ms();
-      Q_ms[0] += q1 - q0;  Q_ms[1] += q2 - q1;
-      bool packed = true;
-      for (int j = 0; j < n; j++)
-        { fill_report_args(&ra[j], jobs[j]->aidx->blk, jobs[j]->bidx->blk, jobs[j]->comp, jobs[j]->self, jobs[j]->spec, j);
-          ra[j].keys = fr[j].keys;  ra[j].vals = fr[j].vals;  ra[j].nhits = fr[j].total;
-          ra[j].work = fr[j].work;  ra[j].nwork = fr[j].nwork;
-          ra[j].pbits = fr[j].pbits;  ra[j].abits = fr[j].abits;
-          ra[j].order = fr[j].order;
-          packed = packed && use_packed(&ra[j], amax, bmax);
-          if (ra[j].mscore != ra[0].mscore || ra[j].dscore != ra[0].dscore)
-            { fprintf(stderr, "damar: internal error, the comparisons of one report launch differ in their -e\n");
-              die();
-            }
+/* A report launch over up to DAMAR_MAX_JOBS comparisons, in two halves.  In asynchronous mode the launch goes to its own
+   stream and is completed only when the NEXT launch is due (or at a drain): the kernel is bound by instruction issue and
+   dependent latency, the seed stage of the following comparisons by HBM, and the two share the machine (tools/corun.hip:
+   a register-heavy persistent kernel and a streaming kernel finish together in 80 % of the time they take one after the
+   other).  At most one launch is in flight; the seed stages alternate between two sets of job arenas. */
+struct Pending
+{ bool live;
+  int  n, slot0;
+  damar_match_job  job[DAMAR_MAX_JOBS];           /* copies: the caller's array may be gone when the launch completes */
+  damar_match_job *orig[DAMAR_MAX_JOBS];          /* the caller's structs (counts) while its call is still running */
+  Front fr[DAMAR_MAX_JOBS];
+  const damar_dev_block *ablk[DAMAR_MAX_JOBS], *bblk[DAMAR_MAX_JOBS];     /* (an index may be released before a re-launch) */
+  int  amax, bmax, tsmin;
+  u32  cell_cap, rec_cap, tp_cap;
+  int  attempt;
+  hipStream_t st;
+  double t_launch;
+  std::vector<TailJob *> writes;                  /* damar_write_overlaps requests that wait for this launch's tails */
+};
+static Pending &PD = *new Pending();
+static int     G_set = 0;                          /* which set of job arenas the next seed stages use */
+static int64   A_nfilt = 0;                        /* totals of the asynchronous mode (damar_async_counts) */
+static double  A_report_ms = 0;
+static int64   A_launches = 0;
+
+static void report_launch(Pending &pd)
+{ ReportArgs ra[DAMAR_MAX_JOBS];
+  const hipStream_t st = pd.st;
+  double q0 = now_ms();
+  scratch_prepare(pd.amax, pd.bmax, P_binshift, pd.tsmin, pd.cell_cap, st);
+  double q1 = now_ms();
+  scratch_outputs(pd.rec_cap, pd.tp_cap);
+  double q2 = now_ms();
+  Q_ms[0] += q1 - q0;  Q_ms[1] += q2 - q1;
+  bool packed = true;
+  for (int j = 0; j < pd.n; j++)
+    { const damar_match_job &jb = pd.job[j];
+      fill_report_args(&ra[j], pd.ablk[j], pd.bblk[j], jb.comp, jb.self, jb.spec, st, j, pd.slot0 + j);
+      ra[j].keys = pd.fr[j].keys;  ra[j].vals = pd.fr[j].vals;  ra[j].nhits = pd.fr[j].total;
+      ra[j].work = pd.fr[j].work;  ra[j].nwork = pd.fr[j].nwork;
+      ra[j].pbits = pd.fr[j].pbits;  ra[j].abits = pd.fr[j].abits;
+      ra[j].order = pd.fr[j].order;
+      packed = packed && use_packed(&ra[j], pd.amax, pd.bmax);
+      if (ra[j].mscore != ra[0].mscore || ra[j].dscore != ra[0].dscore)
+        { fprintf(stderr, "damar: internal error, the comparisons of one report launch differ in their -e\n");
+          die();
         }
-      HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
-      tick(4);
-      stage("report_setup");
-      if (packed)
-        damar_launch_report2(ra, n, NULL, 0, RS.nslots, G_st);
-      else
-        damar_launch_report(ra, n, RS.nslots, G_st);
-      stage("report");
-      tick(5);
-      HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, G_st));
-      HIP_CHECK(hipStreamSynchronize(G_st));
+    }
+  HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, st));
+  tick_on(4, st);
+  if (packed)
+    damar_launch_report2(ra, pd.n, NULL, 0, RS.nslots, st);
+  else
+    damar_launch_report(ra, pd.n, RS.nslots, st);
+  tick_on(5, st);
+  pd.live = true;
+  pd.t_launch = now_ms();
+}
+
+/* Completes the launch in flight: waits for it, re-launches with larger buffers after an overflow, starts the download
+   of the records and hands the comparisons to the host tail in job order (filter.c:2442-2483 per read pair). */
+static void report_finish(Pending &pd)
+{ if (!pd.live)
+    return;
+  u32 hc[DAMAR_COUNTER_WORDS];
+  const hipStream_t st = pd.st;
+  const int n = pd.n;
+  const double h2 = now_ms();
+  for (;;)
+    { HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
       HIP_CHECK(hipGetLastError());
-      G_ms[DAMAR_T_REPORT] += lap(4, 5);
+      { const float ms = lap(4, 5);
+        G_ms[DAMAR_T_REPORT] += ms;
+        if (A_on)
+          { std::lock_guard<std::mutex> lk(A_mu);
+            A_report_ms += ms;
+            A_launches += 1;
+          }
+      }
       G_cnt[5] += 1;
       if (hc[3] == 0)
         break;
@@ -1691,35 +1722,38 @@ static void match_report(damar_match_job **jobs, const Front *fr, int n)
         { fprintf(stderr, "damar: FATAL: a Local_Alignment wave exceeded its loop bound (where=%u)\n", hc[6]);
           die();
         }
-      if (attempt >= 6)
+      if (pd.attempt >= 6)
         { fprintf(stderr, "damar: FATAL: report kernel keeps overflowing its buffers (flags %u)\n", hc[3]);
           die();
         }
-      if (hc[3] & DAMAR_ERR_CELLS) cell_cap = grow_cells(cell_cap);
+      pd.attempt += 1;
+      if (hc[3] & DAMAR_ERR_CELLS) pd.cell_cap = grow_cells(pd.cell_cap);
       if (hc[3] & DAMAR_ERR_WIDE)  G_ring *= 4;
-      if (hc[3] & DAMAR_ERR_RECS)  rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
+      if (hc[3] & DAMAR_ERR_RECS)  pd.rec_cap = std::max(2 * pd.rec_cap, hc[1] + 1024);
       if (hc[3] & DAMAR_ERR_TPOOL)
-        { if (tp_cap >= 0xe0000000u)
+        { if (pd.tp_cap >= 0xe0000000u)
             { fprintf(stderr, "damar: FATAL: more than 2^32 trace values in one comparison, use smaller blocks\n");
               die();
             }
-          tp_cap = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(2ull * tp_cap, (u64) hc[2] + 65536));
+          pd.tp_cap = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(2ull * pd.tp_cap, (u64) hc[2] + 65536));
         }
       if (VERBOSE)
         fprintf(stderr, "damar: report kernel overflow (flags %u), retrying with larger buffers\n", hc[3]);
+      report_launch(pd);
     }
-  tick(6);
+  pd.live = false;
+  tick_on(6, st);
   const double h3 = now_ms();
-  hb = hostbuf_get(hc[1], hc[2]);
+  HostBuf *hb = hostbuf_get(hc[1], hc[2]);
   hb->users = n;
-  hipStream_t cs = A_on ? G_copy : G_st;
+  hipStream_t cs = A_on ? G_copy : st;
   if (A_on)
     HIP_CHECK(hipEventRecord(hb->e0, cs));       /* (the report kernel has completed: the host synced on it) */
   if (hc[1] > 0)
     { HIP_CHECK(hipMemcpyAsync(hb->recs, RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, cs));
       HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, cs));
     }
-  tick(7);
+  tick_on(7, st);
   if (A_on)
     { /* asynchronous mode: the download runs on its own stream beside the next comparison's merge and sorts; the
          tail thread waits for it, and so does the next report kernel (which would overwrite the device buffers) */
@@ -1728,42 +1762,58 @@ static void match_report(damar_match_job **jobs, const Front *fr, int n)
       G_last_d2h = hb->e1;
     }
   else
-    { HIP_CHECK(hipStreamSynchronize(G_st));
+    { HIP_CHECK(hipStreamSynchronize(st));
       G_ms[DAMAR_T_D2H] += lap(6, 7);
     }
   G_cnt[3] += hc[1];  G_cnt[4] += hc[2];
   const double h4 = now_ms();
   for (int j = 0; j < n; j++)
-    { jobs[j]->counts[1] = hc[32 + j];
+    { const damar_match_job &jb = pd.job[j];
+      if (pd.orig[j] != NULL)
+        pd.orig[j]->counts[1] = hc[32 + j];
       G_cnt[2] += hc[32 + j];
       if (A_on)
-        { TailJob *tj = new TailJob();
+        { { std::lock_guard<std::mutex> lk(A_mu);
+            A_nfilt += hc[32 + j];
+          }
+          TailJob *tj = new TailJob();
           tj->kind = 0;
           tj->hb = hb;  tj->jobid = j;  tj->njobs = n;
-          tj->ablock = *jobs[j]->ablock;  tj->bblock = *jobs[j]->bblock;
-          tj->self = jobs[j]->self;  tj->comp = jobs[j]->comp;  tj->spec = jobs[j]->spec;
+          tj->ablock = *jb.ablock;  tj->bblock = *jb.bblock;
+          tj->self = jb.self;  tj->comp = jb.comp;  tj->spec = jb.spec;
           async_submit(tj);
         }
       else
         { double t0 = now_ms();
-          jobs[j]->counts[2] = run_tail(hb->recs, hb->nrec, hb->tpool, jobs[j]->ablock, jobs[j]->bblock, jobs[j]->self,
-                                       jobs[j]->comp, jobs[j]->spec, j, n);
+          const int64 got = run_tail(hb->recs, hb->nrec, hb->tpool, jb.ablock, jb.bblock, jb.self, jb.comp, jb.spec, j, n);
+          if (pd.orig[j] != NULL)
+            pd.orig[j]->counts[2] = got;
           if (--hb->users == 0)
             hostbuf_put(hb);
           G_ms[DAMAR_T_TAIL] += now_ms() - t0;
         }
     }
+  for (TailJob *w : pd.writes)                   /* the files of these comparisons: behind their tails */
+    async_submit(w);
+  pd.writes.clear();
   const double h5 = now_ms();
   H_ms[3] += h3 - h2;  H_ms[4] += h4 - h3;  H_ms[5] += h5 - h4;
+}
+
+static void finish_pending(void)
+{ if (PD.live)
+    report_finish(PD);
 }
 
 static int batch_limit(void)
 { static int n = 0;
   if (n == 0)
     { const char *e = getenv("DAMAR_BATCH");
-      n = e ? atoi(e) : 4;      /* report ms per config-2 step: 1 -> 357, 2 -> 340, 4 -> 335.5, 16 -> 335.3; every job in
+      n = e ? atoi(e) : 0;      /* report ms per config-2 step: 1 -> 357, 2 -> 340, 4 -> 335.5, 16 -> 335.3; every job in
                                    flight keeps its sorted seed pairs (12 B each) in HBM, which a cold process pays for
                                    at ~25 ms per GB */
+      if (n == 0)
+        return overlap_on() ? 2 : 4;            /* overlapped launches: short ones interleave better (548 against 590 ms) */
       if (n < 1) n = 1;
       if (n > DAMAR_MAX_JOBS) n = DAMAR_MAX_JOBS;
     }
@@ -1774,34 +1824,114 @@ static int batch_limit(void)
    stages run one after the other, each into its own arena, then every wavefront of the report kernel works through all
    the work lists.  The output is that of damar_match called for jobs[0], jobs[1], ... in this order.  Launches are cut
    at DAMAR_BATCH jobs (default 4, at most DAMAR_MAX_JOBS) and whenever the seed arenas would pass a quarter of HBM. */
+/* Write_Overlap_Buffer + Reset_Overlap_Buffer (daligner.c:1020-1021, 1055-1056), queued behind
+ * the pending tails in asynchronous mode, immediate otherwise. */
+extern "C" void damar_write_overlaps(Align_Spec *spec, const char *d1, const char *d2,
+                                     const char *ablock, const char *bblock, int lastRead)
+{ if (!A_on)
+    { Write_Overlap_Buffer(spec, (char *) d1, (char *) d2, (char *) ablock, (char *) bblock, lastRead);
+      Reset_Overlap_Buffer(spec);
+      return;
+    }
+  TailJob *job = new TailJob();
+  job->kind = 1;  job->spec = spec;
+  job->has1 = d1 != NULL;  job->has2 = d2 != NULL;
+  if (d1) job->d1 = d1;
+  if (d2) job->d2 = d2;
+  job->a = ablock;  job->b = bblock;  job->last = lastRead;
+  if (PD.live)                                   /* the tails of a launch in flight are not queued yet: behind them */
+    for (int j = 0; j < PD.n; j++)
+      if (PD.job[j].spec == spec)
+        { PD.writes.push_back(job);
+          return;
+        }
+  async_submit(job);
+}
+
+/* totals of the asynchronous mode since the last call (drains first): seed hits (what damar_match's counts[1] reports in
+   the synchronous mode) and the report kernel's milliseconds */
+extern "C" void damar_async_counts(int64 *nfilt, double *report_ms, int64 *launches)
+{ damar_async_drain();
+  std::lock_guard<std::mutex> lk(A_mu);
+  if (nfilt)     *nfilt = A_nfilt;
+  if (report_ms) *report_ms = A_report_ms;
+  if (launches)  *launches = A_launches;
+  A_nfilt = 0;  A_report_ms = 0;  A_launches = 0;
+}
+
+static bool overlap_on(void)
+{ static int on = -1;
+  if (on < 0)
+    { const char *e = getenv("DAMAR_OVERLAP");
+      on = e ? atoi(e) : 1;
+    }
+  /* only behind the asynchronous host tail (nobody reads the records at return), and not when the caller wants the
+     per-comparison counts printed (-v) or the seeds kept */
+  return on && A_on && !VERBOSE && !G_keep_seeds;
+}
+
 extern "C" void damar_match_batch(damar_match_job *jobs, int njobs)
 { ensure_init();
   const double h0 = now_ms();
   memset(G_cnt, 0, sizeof(G_cnt));
   for (int i = DAMAR_T_MERGE; i < DAMAR_T_COUNT; i++)
     G_ms[i] = 0;
+  const bool defer = overlap_on();
+  if (!defer)
+    finish_pending();
   damar_match_job *run[DAMAR_MAX_JOBS];
   Front fr[DAMAR_MAX_JOBS];
   int   n = 0;
   size_t bytes = 0;
   const size_t budget = G_prop.totalGlobalMem / 4;
+  const int    limit = std::min(batch_limit(), DAMAR_MAX_JOBS / 2);       /* two sets of job arenas */
   auto flush = [&]()
     { if (n == 0) return;
-      match_report(run, fr, n);
+      /* the launch in flight (it ran beside these seed stages) is completed first: one set of output buffers */
+      finish_pending();
+      Pending &pd = PD;
+      pd.n = n;  pd.slot0 = G_set * (DAMAR_MAX_JOBS / 2);
+      pd.amax = pd.bmax = 0;  pd.tsmin = 0x7fffffff;
+      u64 nwork = 0;
+      for (int j = 0; j < n; j++)
+        { pd.job[j] = *run[j];  pd.orig[j] = run[j];  pd.fr[j] = fr[j];
+          pd.ablk[j] = run[j]->aidx->blk;  pd.bblk[j] = run[j]->bidx->blk;
+          pd.amax = std::max(pd.amax, run[j]->ablock->maxlen);  pd.bmax = std::max(pd.bmax, run[j]->bblock->maxlen);
+          pd.tsmin = std::min(pd.tsmin, Trace_Spacing(run[j]->spec));
+          nwork += fr[j].nwork;
+        }
+      pd.cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
+      pd.rec_cap  = (u32) std::min<u64>(0x7fffffffu, std::max<u64>(RS.rec_cap, 2 * nwork + 4096));
+      pd.tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(RS.tpool_cap, (u64) pd.rec_cap * 256u));
+      if (getenv("DAMAR_TEST_SMALL_CAPS") && RS.rec_cap == 0)      /* tests: start far too small, so that the
+                                                                      overflow flags and the re-launch are exercised */
+        { pd.cell_cap = 64;  pd.rec_cap = 16;  pd.tp_cap = 512; }
+      pd.attempt = 0;
+      pd.st = defer ? G_rep : G_st;
+      if (defer)                                   /* the launch reads what the seed stages wrote on the other stream */
+        { HIP_CHECK(hipEventRecord(G_front_done, G_st));
+          HIP_CHECK(hipStreamWaitEvent(G_rep, G_front_done, 0));
+        }
+      report_launch(pd);
+      if (!defer)
+        report_finish(pd);
+      G_set ^= 1;
       n = 0;  bytes = 0;
     };
   for (int i = 0; i < njobs; i++)
     { const double f0 = now_ms();
-      if (match_front(&jobs[i], n, &fr[n]))
+      if (match_front(&jobs[i], G_set * (DAMAR_MAX_JOBS / 2) + n, &fr[n]))
         { run[n] = &jobs[i];
           bytes += fr[n].bytes;
           n += 1;
         }
       H_ms[1] += now_ms() - f0;
-      if (n >= batch_limit() || bytes > budget)
+      if (n >= limit || bytes > budget)
         flush();
     }
   flush();
+  for (int j = 0; j < DAMAR_MAX_JOBS; j++)         /* the caller's job structs end with this call */
+    PD.orig[j] = NULL;
   H_ms[6] += now_ms() - h0;
 }
 
@@ -1855,7 +1985,8 @@ extern "C" int damar_tandem_set_params(int kmer, int binshift, int hitmin, int n
 }
 
 extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Align_Spec *spec, int64 *counts)
-{ ensure_init();
+{ finish_pending();
+  ensure_init();
   int64 nfilt = 0, ncheck = 0;
   int   n = 0;
   if (counts)
@@ -1880,9 +2011,9 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
     u32 tp_cap   = std::max(RS.tpool_cap, rec_cap * 64u);
     for (int attempt = 0; ; attempt++)
       { ReportArgs ra;
-        scratch_prepare(ablock->maxlen, ablock->maxlen, T_binshift, ts, cell_cap);
+        scratch_prepare(ablock->maxlen, ablock->maxlen, T_binshift, ts, cell_cap, G_st);
         scratch_outputs(rec_cap, tp_cap);
-        fill_report_args(&ra, blk, blk, 0, 1, spec);
+        fill_report_args(&ra, blk, blk, 0, 1, spec, G_st);
         ra.nwork = (u32) ablock->nreads;
         HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
         tick(4);
@@ -1978,7 +2109,8 @@ extern "C" int64 damar_last_seeds(void *out, int64 cap)
 extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_block *bblk, int comp,
                                            Align_Spec *spec, const int *tasks, int ntasks,
                                            int *paths, int64 *trace_off, uint16 *traces, int64 trace_cap)
-{ ensure_init();
+{ finish_pending();
+  ensure_init();
   if (ntasks <= 0)
     return 0;
   const int ts = Trace_Spacing(spec);
@@ -1988,10 +2120,10 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
   u32 hc[DAMAR_COUNTER_WORDS];
   for (int attempt = 0; ; attempt++)
     { ReportArgs ra;
-      scratch_prepare(ablk->d.maxlen, bblk->d.maxlen, P_binshift, ts, cell_cap);
+      scratch_prepare(ablk->d.maxlen, bblk->d.maxlen, P_binshift, ts, cell_cap, G_st);
       stage("la_scratch");
       scratch_outputs(rec_cap, tp_cap);
-      fill_report_args(&ra, ablk, bblk, comp, 0, spec);
+      fill_report_args(&ra, ablk, bblk, comp, 0, spec, G_st);
       HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
       stage("la_setup");
       if (use_packed(&ra, ablk->d.maxlen, bblk->d.maxlen))

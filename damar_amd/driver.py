@@ -133,6 +133,11 @@ class Plan:
         n, t, w = api.c_int64(0), C.c_double(0), C.c_double(0)
         L.damar_async_totals(C.byref(n), C.byref(t), C.byref(w))
         if self.async_tail:
+            nf, rms, nl = api.c_int64(0), C.c_double(0), api.c_int64(0)
+            L.damar_async_counts(C.byref(nf), C.byref(rms), C.byref(nl))
+            self.counts[1] += nf.value
+            self.report_launches += nl.value
+            self.timings["report"] = self.timings.get("report", 0.) + rms.value
             self.counts[2] += n.value
             self.timings["tail"] = self.timings.get("tail", 0.) + t.value
             self.timings["write"] = self.timings.get("write", 0.) + w.value
@@ -209,12 +214,15 @@ class Plan:
             arr[q].self_, arr[q].comp, arr[q].spec = self_, comp, spec
         L.damar_match_batch(arr, len(jobs))
         self.matches += len(jobs)
-        self.report_launches += api.counters()[5]
+        if not self.async_tail:
+            self.report_launches += api.counters()[5]
         t = api.timings()
-        for nme in ("merge", "ssort", "work", "report", "d2h", "tail"):
+        # (asynchronous mode: the last report launch of the call is still in flight -- its time and its seed hits come
+        #  from damar_async_counts at finish())
+        for nme in ("merge", "ssort", "work", "d2h", "tail") + (() if self.async_tail else ("report",)):
             self.timings[nme] = self.timings.get(nme, 0.) + t[nme]
         for q in range(len(jobs)):
-            for i in range(3):
+            for i in ((0, 2) if self.async_tail else (0, 1, 2)):
                 self.counts[i] += arr[q].counts[i]
 
     def _spec(self, a, slot=0):

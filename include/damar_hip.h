@@ -96,6 +96,11 @@ void damar_set_bread_range(int lo, int hi);
 void damar_set_async(int on);
 void damar_async_drain(void);
 void damar_async_totals(int64 *ncheck, double *tail_ms, double *write_ms);
+/* In asynchronous mode the report launch of a damar_match_batch call is also left in flight when the call returns
+ * (its own stream; the seed stages of the NEXT call run beside it -- DAMAR_OVERLAP=0 turns that off): counts[1] of the
+ * comparisons of that last launch is then 0 at return.  Totals since the last call (drains first): seed hits, and the
+ * report kernel's milliseconds and launches. */
+void damar_async_counts(int64 *seed_hits, double *report_ms, int64 *launches);
 double damar_async_d2h_ms(void);        /* time of the asynchronous record downloads since the last call */
 /* Write_Overlap_Buffer + Reset_Overlap_Buffer (daligner.c:1020-1021), queued in async mode */
 void damar_write_overlaps(Align_Spec *spec, const char *dirName1, const char *dirName2,
