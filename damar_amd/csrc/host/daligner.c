@@ -576,7 +576,7 @@ static damar_dev_index *pblock_index(PBlock *b, int comp)
 static Align_Spec **PS;             /* the plan's Align_Specs, alive until the asynchronous tail has drained */
 static int PS_n, PS_cap;
 
-#define LINE_B 8                    /* subject blocks per report launch (x 2 orientations = DAMAR_MAX_JOBS comparisons) */
+#define LINE_B 2                    /* blocks that can be busy beyond the table's limit: the A block and one subject block */
 
 /* the queued tails and writes still use the spec: it is released when the plan is done (no drain per line) */
 static void plan_keep_spec(Align_Spec *spec)
@@ -612,59 +612,50 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
   if (SYMMETRIC)
     SYMMETRIC = symmetric_for(afile, aroot, bfiles, nb);
   make_subdir(&a->blk, o->runid);
-  /* The line is worked through in groups of up to LINE_B subject blocks: the seed stages of the group's comparisons
-     (both orientations of each block) run one after the other, ONE launch of the report kernel covers them all
-     (damar_match_batch), and the files are written per block as the reference does (daligner.c:1006-1021, 1051-1056).
-     Every subject block has its own Align_Spec, i.e. its own overlap buffers, so that the queued tails and writes
-     of the group cannot mix. */
-  for (k = 0; k < nb; k += LINE_B)
-    { const int n = (nb - k < LINE_B) ? nb - k : LINE_B;
-      damar_match_job jobs[2 * LINE_B];
-      PBlock     *bb[LINE_B];
-      Align_Spec *sp[LINE_B];
-      int     q;
-      double  t0;
+  /* One damar_match_batch per subject block (both orientations: one launch of the report kernel).  The library leaves
+     that launch in flight when the call returns: the next block's index builds and seed stages run beside it, and the
+     write request below is queued behind the launch's own tails (include/damar_hip.h).  Every subject block has its
+     own Align_Spec, i.e. its own overlap buffers, written and reset per block as the reference does
+     (daligner.c:1006-1021, 1051-1056). */
+  for (k = 0; k < nb; k++)
+    { const int same = (strcmp(afile, bfiles[k]) == 0);
+      damar_match_job jobs[2];
+      PBlock     *b;
+      Align_Spec *sp;
+      char       *d1 = NULL, *d2 = NULL;
+      double      t0;
       damar_dev_index *ai = pblock_index(a, 0);
       memset(jobs, 0, sizeof(jobs));
-      for (q = 0; q < n; q++)
-        { const int same = (strcmp(afile, bfiles[k + q]) == 0);
-          PBlock *b = same ? a : pblock_get(bfiles[k + q], o);
-          damar_match_job *jn = jobs + 2 * q, *jc = jn + 1;
-          b->busy = 1;
-          bb[q] = b;
-          sp[q] = New_Align_Spec(o->ecorr, o->spacing, a->blk.freq, o->nthreads, SYMMETRIC, o->only_id, o->notrace, 1);
-          plan_keep_spec(sp[q]);
-          if (!same && SYMMETRIC)
-            make_subdir(&b->blk, o->runid);
-          jn->ablock = jc->ablock = &a->blk;
-          jn->aidx = jc->aidx = ai;
-          jn->bblock = &b->blk;   jn->bidx = same ? ai : pblock_index(b, 0);
-          jc->bblock = &b->cblk;  jc->bidx = pblock_index(b, 1);
-          jn->self = jc->self = same;
-          jn->comp = 0;  jc->comp = 1;
-          jn->spec = jc->spec = sp[q];
-        }
+      b = same ? a : pblock_get(bfiles[k], o);
+      b->busy = 1;
+      sp = New_Align_Spec(o->ecorr, o->spacing, a->blk.freq, o->nthreads, SYMMETRIC, o->only_id, o->notrace, 1);
+      plan_keep_spec(sp);
+      if (!same && SYMMETRIC)
+        make_subdir(&b->blk, o->runid);
+      jobs[0].ablock = jobs[1].ablock = &a->blk;
+      jobs[0].aidx = jobs[1].aidx = ai;
+      jobs[0].bblock = &b->blk;   jobs[0].bidx = same ? ai : pblock_index(b, 0);
+      jobs[1].bblock = &b->cblk;  jobs[1].bidx = pblock_index(b, 1);
+      jobs[0].self = jobs[1].self = same;
+      jobs[0].comp = 0;  jobs[1].comp = 1;
+      jobs[0].spec = jobs[1].spec = sp;
       t0 = wall_ms();
-      damar_match_batch(jobs, 2 * n);
+      damar_match_batch(jobs, 2);
       P_ms[2] += wall_ms() - t0;
-      for (q = 0; q < n; q++)
-        { PBlock *b = bb[q];
-          char   *d1 = NULL, *d2 = NULL;
-          if (a->blk.part > 0) d1 = damar_get_dir(o->runid, a->blk.part);
-          if (b == a)
-            { TIMED(4, damar_write_overlaps(sp[q], d1, NULL, aroot, aroot, a->blk.ufirst + a->blk.nreads - 1)); }
-          else
-            { char *broot = damar_root(bfiles[k + q], ".db");
-              const int last_read = (b->blk.part < a->blk.part) ? b->blk.ufirst + b->blk.nreads - 1
-                                                                : a->blk.ufirst + a->blk.nreads - 1;
-              if (b->blk.part > 0) d2 = damar_get_dir(o->runid, b->blk.part);
-              TIMED(4, damar_write_overlaps(sp[q], d1, d2, aroot, broot, last_read));
-              free(broot);
-              b->busy = 0;
-            }
-          free(d1);
-          free(d2);
+      if (a->blk.part > 0) d1 = damar_get_dir(o->runid, a->blk.part);
+      if (same)
+        { TIMED(4, damar_write_overlaps(sp, d1, NULL, aroot, aroot, a->blk.ufirst + a->blk.nreads - 1)); }
+      else
+        { char *broot = damar_root(bfiles[k], ".db");
+          const int last_read = (b->blk.part < a->blk.part) ? b->blk.ufirst + b->blk.nreads - 1
+                                                            : a->blk.ufirst + a->blk.nreads - 1;
+          if (b->blk.part > 0) d2 = damar_get_dir(o->runid, b->blk.part);
+          TIMED(4, damar_write_overlaps(sp, d1, d2, aroot, broot, last_read));
+          free(broot);
+          b->busy = 0;
         }
+      free(d1);
+      free(d2);
     }
   a->busy = 0;
   free(aroot);

@@ -241,7 +241,7 @@ class Plan:
 
     def run_pairs(self, a, bs, outdir, part=0, nparts=1):
         """Block `a` against the blocks `bs` (at most GROUP), both orientations each (daligner.c:958-1056 for these B
-        arguments), behind one launch of the report kernel; the .las files go under outdir exactly as
+        arguments); the .las files go under outdir exactly as
         daligner.c:1006-1021, 1051-1056 name them.  With nparts > 1 only the read pairs whose B read falls into the
         part's share of B's reads are processed (damar_set_bread_range; one subject block then): the parts' files merge
         into the unsplit pair's files (multi.merge_parts)."""
@@ -257,36 +257,32 @@ class Plan:
             self._line_a = (a.name, 0)
             self._group = []
             aidx = self._index(a, 0)
-            jobs = []
-            for q, b in enumerate(bs):
-                spec = self._spec(a, q)
-                if b is a or b.name == a.name:
-                    cidx = self._index(a, 1)
-                    jobs.append((a.db, a.db, aidx, aidx, 1, 0, spec))
-                    jobs.append((a.db, a.cdb, aidx, cidx, 1, 1, spec))
-                else:
-                    if self.symmetric:
-                        os.makedirs(api.get_dir(self.run, b.db.part), exist_ok=True)
-                    bidx = self._index(b, 0)
-                    cidx = self._index(b, 1)
-                    jobs.append((a.db, b.db, aidx, bidx, 0, 0, spec))
-                    jobs.append((a.db, b.cdb, aidx, cidx, 0, 1, spec))
             if nparts > 1:
                 nb = bs[0].db.nreads
                 L.damar_set_bread_range(nb * part // nparts, nb * (part + 1) // nparts)
             try:
-                self._match_batch(jobs)
+                # One damar_match_batch per subject block (N and C): its k-mer indexes are built just before its seed
+                # stages, i.e. beside the report launch of the block before it (the library keeps that launch in flight
+                # across calls), and its files are queued behind its own tails.
+                for q, b in enumerate(bs):
+                    spec = self._spec(a, q)
+                    self._group = [(a.name, 0)]
+                    if b is a or b.name == a.name:
+                        cidx = self._index(a, 1)
+                        self._match_batch([(a.db, a.db, aidx, aidx, 1, 0, spec), (a.db, a.cdb, aidx, cidx, 1, 1, spec)])
+                        L.damar_write_overlaps(spec, odir(a.db.part), None, a.root.encode(), a.root.encode(), a.last_read())
+                    else:
+                        if self.symmetric:
+                            os.makedirs(api.get_dir(self.run, b.db.part), exist_ok=True)
+                        bidx = self._index(b, 0)
+                        cidx = self._index(b, 1)
+                        self._match_batch([(a.db, b.db, aidx, bidx, 0, 0, spec), (a.db, b.cdb, aidx, cidx, 0, 1, spec)])
+                        last = b.last_read() if b.db.part < a.db.part else a.last_read()
+                        L.damar_write_overlaps(spec, odir(a.db.part), odir(b.db.part), a.root.encode(), b.root.encode(), last)
             finally:
                 if nparts > 1:
                     L.damar_set_bread_range(0, -1)
             self._group = []
-            for q, b in enumerate(bs):
-                spec = self._spec(a, q)
-                if b is a or b.name == a.name:
-                    L.damar_write_overlaps(spec, odir(a.db.part), None, a.root.encode(), a.root.encode(), a.last_read())
-                else:
-                    last = b.last_read() if b.db.part < a.db.part else a.last_read()
-                    L.damar_write_overlaps(spec, odir(a.db.part), odir(b.db.part), a.root.encode(), b.root.encode(), last)
             if not self.async_tail or a.db.part <= 0 or any(b.db.part <= 0 for b in bs):
                 self.finish()            # unsplit DBs write relative paths: finish inside this cwd
 
