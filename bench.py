@@ -458,8 +458,9 @@ def main():
                                               "leftovers after it), no data-path collective; busiest rank ran %d units"
                                               % (world, len(units),
                                                  "block pairs split %d-way by B-read range" % nsplit if nsplit > 1 else
-                                                 "one A block against up to %d subject blocks, both orientations, behind one "
-                                                 "launch of the report kernel" % ngroup, int(units_max)),
+                                                 "one A block against up to %d subject blocks, both orientations; one report "
+                                                 "launch per subject block, in flight beside the next block's index builds and "
+                                                 "seed stages" % ngroup, int(units_max)),
                                "db_generation_s": t_gen},
                     "parity": parity,
                     "roofline": roof, "cpu_baseline": cpu, "end_to_end": e2e, "trace_expand": trace}
