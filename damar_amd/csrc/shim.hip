@@ -1652,6 +1652,7 @@ struct Pending
   int  attempt;
   hipStream_t st;
   double t_launch;
+  ReportArgs ra[DAMAR_MAX_JOBS];                  /* what the launch was given (the upload is asynchronous) */
   std::vector<TailJob *> writes;                  /* damar_write_overlaps requests that wait for this launch's tails */
 };
 static Pending &PD = *new Pending();
@@ -1661,7 +1662,7 @@ static double  A_report_ms = 0;
 static int64   A_launches = 0;
 
 static void report_launch(Pending &pd)
-{ ReportArgs ra[DAMAR_MAX_JOBS];
+{ ReportArgs *const ra = pd.ra;
   const hipStream_t st = pd.st;
   double q0 = now_ms();
   scratch_prepare(pd.amax, pd.bmax, P_binshift, pd.tsmin, pd.cell_cap, st);
