@@ -145,13 +145,41 @@ void radix_hist(const KeyT *__restrict__ keys, u64 n, int shift, u32 mask,
   ghist[(u64) threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
 }
 
+/* One workgroup per digit: exclusive prefix of the digit's tile counts in place (its row of ghist) and the digit's total.
+   With the 256 totals a scatter workgroup finds its global offsets itself -- one launch between histogram and scatter
+   instead of the three of a device-wide scan over all 256 x ntiles counts. */
+__global__ __launch_bounds__(RS_THREADS)
+void radix_row_scan(u32 *__restrict__ ghist, u32 ntiles, u32 *__restrict__ dtot)
+{ __shared__ u32 lds4[4];
+  u32 *row = ghist + (u64) blockIdx.x * ntiles;
+  u32 carry = 0;
+  for (u32 b = 0; b < ntiles; b += RS_THREADS * 8)
+    { const u32 base = b + threadIdx.x * 8;
+      u32 v[8], sum = 0, tot;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        { v[i] = (base + i < ntiles) ? row[base + i] : 0;
+          sum += v[i];
+        }
+      u32 ex = block_excl_scan_256(sum, lds4, &tot) + carry;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        { if (base + i < ntiles) row[base + i] = ex;
+          ex += v[i];
+        }
+      carry += tot;
+    }
+  if (threadIdx.x == 0)
+    dtot[blockIdx.x] = carry;
+}
+
 /* Stable scatter of one tile.  Wave w owns items [w*1024,(w+1)*1024) of the tile in
  * rounds of 64 consecutive items, so (wave, round, lane) order == input order. */
 template <typename KeyT, bool HV>          /* HV: a u32 payload travels with the key */
 __global__ __launch_bounds__(RS_THREADS, 4)
 void radix_scatter(const KeyT *__restrict__ kin, const u32 *__restrict__ vin,
                    KeyT *__restrict__ kout, u32 *__restrict__ vout, u64 n,
-                   int shift, u32 mask, const u32 *__restrict__ gscan, u32 ntiles)
+                   int shift, u32 mask, const u32 *__restrict__ gscan, const u32 *__restrict__ dtot, u32 ntiles)
 { /* keys and payload are staged through the SAME buffer one after the other: 32 + 6 KB of LDS per workgroup for u64 keys
      instead of 54 KB, i.e. 4 resident workgroups per CU instead of 2 (3 x 54 KB does not fit the 160 KB) */
   __shared__ KeyT skey[RS_TILE];
@@ -199,13 +227,14 @@ void radix_scatter(const KeyT *__restrict__ kin, const u32 *__restrict__ vin,
 
   { u32 c0 = cnt[0][threadIdx.x], c1 = cnt[1][threadIdx.x], c2 = cnt[2][threadIdx.x], c3 = cnt[3][threadIdx.x];
     u32 tot = c0 + c1 + c2 + c3, all;
+    const u32 dbase = block_excl_scan_256(dtot[threadIdx.x], lds4, &all);      /* where this digit's items start */
     u32 ex = block_excl_scan_256(tot, lds4, &all);
     cnt[0][threadIdx.x] = 0;
     cnt[1][threadIdx.x] = c0;
     cnt[2][threadIdx.x] = c0 + c1;
     cnt[3][threadIdx.x] = c0 + c1 + c2;
     dstart[threadIdx.x] = ex;
-    gadj[threadIdx.x]   = gscan[(u64) threadIdx.x * ntiles + blockIdx.x] - ex;
+    gadj[threadIdx.x]   = dbase + gscan[(u64) threadIdx.x * ntiles + blockIdx.x] - ex;
   }
   __syncthreads();
 
@@ -253,7 +282,7 @@ void radix_scatter(const KeyT *__restrict__ kin, const u32 *__restrict__ vin,
 
 size_t damar_sort_workspace_bytes(u64 n)
 { u64 ntiles = (n + RS_TILE - 1) / RS_TILE;
-  return (size_t) (256 * ntiles) * sizeof(u32) + damar_scan_workspace_bytes(256 * ntiles) + 256;
+  return (size_t) (256 * ntiles) * sizeof(u32) + 256 * sizeof(u32) + 256;
 }
 
 /* Sorts on key bits [0, nbits).  Ping-pongs between (k0,v0) and (k1,v1); returns 0 if
@@ -263,8 +292,7 @@ static int radix_sort_impl(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int nbit
                            void *work, hipStream_t st)
 { u32  ntiles = (u32) ((n + RS_TILE - 1) / RS_TILE);
   u32 *ghist = (u32 *) work;
-  char *swork = (char *) work + (((size_t) 256 * ntiles * sizeof(u32) + 63) & ~(size_t) 63);
-  u64 *tot = (u64 *) (swork + damar_scan_workspace_bytes((u64) 256 * ntiles) - 64);
+  u32 *dtot  = (u32 *) ((char *) work + (((size_t) 256 * ntiles * sizeof(u32) + 63) & ~(size_t) 63));
   int  side = 0;
   if (n == 0)
     return 0;
@@ -274,9 +302,9 @@ static int radix_sort_impl(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int nbit
       KeyT *ki = side ? k1 : k0, *ko = side ? k0 : k1;
       u32  *vi = side ? v1 : v0, *vo = side ? v0 : v1;
       hipLaunchKernelGGL(radix_hist<KeyT>, dim3(ntiles), dim3(RS_THREADS), 0, st, ki, n, shift, mask, ghist, ntiles);
-      damar_exclusive_scan_u32(ghist, ghist, (u64) 256 * ntiles, swork, tot, st);
+      hipLaunchKernelGGL(radix_row_scan, dim3(256), dim3(RS_THREADS), 0, st, ghist, ntiles, dtot);
       hipLaunchKernelGGL((radix_scatter<KeyT, HV>), dim3(ntiles), dim3(RS_THREADS), 0, st,
-                         ki, vi, ko, vo, n, shift, mask, ghist, ntiles);
+                         ki, vi, ko, vo, n, shift, mask, ghist, dtot, ntiles);
       side ^= 1;
     }
   return side;
