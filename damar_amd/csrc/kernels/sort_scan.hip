@@ -123,7 +123,9 @@ void damar_scan_tile_counts(u32 *tcount, u32 ntiles, u64 *total_dev, hipStream_t
 
 #define RS_THREADS 256
 #ifndef RS_ROUNDS
+#ifndef RS_ROUNDS
 #define RS_ROUNDS  16
+#endif
 #endif
 #define RS_TILE    (RS_THREADS * RS_ROUNDS)     /* 4096 items per workgroup            */
 #define RS_WSPAN   (RS_TILE / 4)                /* contiguous items owned by one wave  */
