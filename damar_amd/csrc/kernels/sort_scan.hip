@@ -124,7 +124,9 @@ void damar_scan_tile_counts(u32 *tcount, u32 ntiles, u64 *total_dev, hipStream_t
 #define RS_THREADS 256
 #ifndef RS_ROUNDS
 #ifndef RS_ROUNDS
-#define RS_ROUNDS  16
+#ifndef RS_ROUNDS
+#define RS_ROUNDS  16                              /* items per thread (scripts/gpu_rs8.sh builds 4 and 8) */
+#endif
 #endif
 #endif
 #define RS_TILE    (RS_THREADS * RS_ROUNDS)     /* 4096 items per workgroup            */
