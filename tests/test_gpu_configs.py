@@ -224,6 +224,52 @@ def test_gpu_cli_plan_mode_other_launch_shapes_equal_reference_golden(gpu, tmp_p
     assert compare_las(case, work) == []
 
 
+@pytest.mark.parametrize("async_tail", [False, True])
+def test_gpu_match_batch_with_different_a_blocks_in_one_call(gpu, tmp_path, async_tail):
+    """damar_match_batch takes arbitrary comparisons: here ALL six of the two-block fixture -- two A blocks, self and cross,
+    both orientations -- in one call (DAMAR_BATCH then cuts the launches), one Align_Spec per block pair, the files
+    written afterwards.  Synchronous (counts filled, launches completed inside the call) and asynchronous (the last launch in
+    flight at return, the write requests queued behind its tails)."""
+    import ctypes as C
+    from conftest import read_case, link_db, compare_las
+    from damar_amd import api, driver
+    from damar_amd.driver import _cwd
+    case = read_case("tiny2")
+    work = str(tmp_path)
+    link_db(case["dbdir"], work)
+    L = api.lib()
+    from conftest import opts_to_plan_kwargs
+    plan = driver.Plan(async_tail=async_tail, **opts_to_plan_kwargs(case["opts"]))
+    b1, b2 = driver.Block(os.path.join(work, "G.1")), driver.Block(os.path.join(work, "G.2"))
+    with _cwd(work):
+        for part in (1, 2):
+            os.makedirs(api.get_dir(1, part), exist_ok=True)
+        pairs = [(b1, b1), (b2, b2), (b2, b1)]
+        jobs, specs = [], []
+        for q, (a, b) in enumerate(pairs):
+            spec = plan._spec(a, q)
+            specs.append(spec)
+            aidx = plan._index(a, 0)
+            bidx, cidx = (aidx if b is a else plan._index(b, 0)), plan._index(b, 1)
+            same = 1 if b is a else 0
+            jobs += [(a.db, b.db, aidx, bidx, same, 0, spec), (a.db, b.cdb, aidx, cidx, same, 1, spec)]
+        plan._match_batch(jobs)
+        outabs = os.path.abspath(work)
+        for (a, b), spec in zip(pairs, specs):
+            d1 = os.path.join(outabs, api.get_dir(1, a.db.part)).encode()
+            if b is a:
+                L.damar_write_overlaps(spec, d1, None, a.root.encode(), a.root.encode(), a.last_read())
+            else:
+                d2 = os.path.join(outabs, api.get_dir(1, b.db.part)).encode()
+                last = b.last_read() if b.db.part < a.db.part else a.last_read()
+                L.damar_write_overlaps(spec, d1, d2, a.root.encode(), b.root.encode(), last)
+        plan.finish()
+    assert plan.matches == 6 and plan.counts[0] > 0 and plan.counts[1] > 0 and plan.counts[2] > 0
+    assert compare_las(case, work) == []
+    plan2 = driver.Plan(async_tail=False)       # (leave the library in synchronous mode for the tests that follow)
+    plan2.finish()
+
+
 def test_gpu_cli_plan_mode_evicts_and_rereads_blocks(gpu, tmp_path):
     """A 4-block plan through `daligner -P` with room for 2 blocks only (DAMAR_PLAN_BLOCKS=2): every line's B
     blocks push each other out and are read, complemented and indexed again; files equal the CPU oracle's."""
