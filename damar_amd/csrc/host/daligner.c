@@ -447,6 +447,7 @@ static int     PB_n, PB_cap, PB_max = 64;
 static long    PB_clock;
 static int     PB_builds;
 static pthread_mutex_t PB_mu = PTHREAD_MUTEX_INITIALIZER;
+static int PB_dev_ready = 0;        /* the device is selected: the reader thread may upload */
 static pthread_cond_t  PB_cv = PTHREAD_COND_INITIALIZER;
 static int     PB_ahead;            /* entries [0, PB_ahead) are prepared by the reader thread, in this order */
 static Opts    PB_opts;
@@ -467,7 +468,11 @@ static void pblock_load(PBlock *b, const Opts *o, int background)
   damar_complement_copy(&b->blk, &b->cblk);
   P_ms[3] += wall_ms() - t0;
   if (background)                   /* on the copy stream, beside the kernels of the main thread */
-    { t0 = wall_ms();
+    { pthread_mutex_lock(&PB_mu);     /* (reading and complementing started before the device was up: plan_main) */
+      while (!PB_dev_ready)
+        pthread_cond_wait(&PB_cv, &PB_mu);
+      pthread_mutex_unlock(&PB_mu);
+      t0 = wall_ms();
       b->dev[0] = damar_block_upload_bg(&b->blk);
       b->dev[1] = damar_block_upload_bg(&b->cblk);
       P_ms[7] += wall_ms() - t0;
@@ -704,15 +709,6 @@ static int plan_main(const Opts *base, const char *planfile)
   if (f != stdin)
     fclose(f);
 
-  select_device(base);
-  if (getenv("DAMAR_PREWARM_GB") && atoi(getenv("DAMAR_PREWARM_GB")) > 0)
-    { pthread_t th;                     /* grow the HBM footprint next to reading the first blocks (see damar_prewarm) */
-      static int gb;
-      gb = atoi(getenv("DAMAR_PREWARM_GB"));
-      if (pthread_create(&th, NULL, prewarm_thread, &gb) == 0)
-        pthread_detach(th);
-    }
-  damar_set_async(1);
 
   /* the block table, and what the reader thread prepares ahead: the blocks in order of first use */
   PB_cap = PB_max + LINE_B + 2;           /* a group of subject blocks and the A block can be busy beyond PB_max */
@@ -767,6 +763,22 @@ static int plan_main(const Opts *base, const char *planfile)
         have_reader = 1;
       }
   }
+
+  /* The device comes up (a few hundred ms in a cold process) while the reader thread already reads and complements the
+     first blocks; it uploads once the flag below is set. */
+  select_device(base);
+  if (getenv("DAMAR_PREWARM_GB") && atoi(getenv("DAMAR_PREWARM_GB")) > 0)
+    { pthread_t th;                     /* grow the HBM footprint next to reading the first blocks (see damar_prewarm) */
+      static int gb;
+      gb = atoi(getenv("DAMAR_PREWARM_GB"));
+      if (pthread_create(&th, NULL, prewarm_thread, &gb) == 0)
+        pthread_detach(th);
+    }
+  damar_set_async(1);
+  pthread_mutex_lock(&PB_mu);
+  PB_dev_ready = 1;
+  pthread_cond_broadcast(&PB_cv);
+  pthread_mutex_unlock(&PB_mu);
 
   for (i = 0; i < nl; i++)
     { Opts o = *base;
