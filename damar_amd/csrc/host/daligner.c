@@ -479,11 +479,18 @@ static void pblock_load(PBlock *b, const Opts *o, int background)
     }
 }
 
+static int PB_next;                 /* next entry a reader thread takes */
+
 static void *plan_reader(void *arg)
-{ int i;
-  (void) arg;
-  for (i = 0; i < PB_ahead; i++)
-    { pblock_load(PB + i, &PB_opts, 1);
+{ (void) arg;
+  for (;;)
+    { int i;
+      pthread_mutex_lock(&PB_mu);
+      i = PB_next++;
+      pthread_mutex_unlock(&PB_mu);
+      if (i >= PB_ahead)
+        break;
+      pblock_load(PB + i, &PB_opts, 1);
       pthread_mutex_lock(&PB_mu);
       PB[i].ready = 1;
       pthread_cond_broadcast(&PB_cv);
@@ -673,7 +680,7 @@ static int plan_main(const Opts *base, const char *planfile)
   char ***ltok = NULL;                 /* the plan's daligner lines, tokenised */
   int   *lntok = NULL, nl = 0, lcap = 0;
   int    i, j, same_masks = 1;
-  pthread_t reader;
+  pthread_t reader[2];                 /* two: a block's read + complement + upload take ~95 ms, a plan line less */
   int    have_reader = 0;
 
   if (f == NULL)
@@ -756,11 +763,11 @@ static int plan_main(const Opts *base, const char *planfile)
           }
         PB_ahead = PB_n;
         PB_opts = o0;
-        if (pthread_create(&reader, NULL, plan_reader, NULL) != 0)
-          { fprintf(stderr, "daligner: cannot start the block reader thread\n");
-            exit(1);
-          }
-        have_reader = 1;
+        for (have_reader = 0; have_reader < 2; have_reader++)
+          if (pthread_create(&reader[have_reader], NULL, plan_reader, NULL) != 0)
+            { fprintf(stderr, "daligner: cannot start the block reader thread\n");
+              exit(1);
+            }
       }
   }
 
@@ -788,8 +795,8 @@ static int plan_main(const Opts *base, const char *planfile)
       plan_line(&o, ltok[i][first], ltok[i] + first + 1, lntok[i] - first - 1);
     }
   TIMED(5, damar_async_drain());
-  if (have_reader)
-    pthread_join(reader, NULL);
+  while (have_reader > 0)
+    pthread_join(reader[--have_reader], NULL);
   for (i = 0; i < PS_n; i++)
     Free_Align_Spec(PS[i]);
   free(PS);
