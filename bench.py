@@ -421,9 +421,11 @@ def main():
                     "launches_per_step": nl, "avg_launch_ms": dom_ms / nl if nl else 0.,
                     "algorithmic_bytes_per_step": alg,
                     "valu_frac": pmc.get("valu_frac"), "salu_frac": pmc.get("salu_frac"),
+                    "valu_busy_weighted": pmc.get("valu_busy_weighted"),
                     "active_lane_frac": pmc.get("active_lane_frac"), "pmc_source": pmc.get("source"),
                     "note": "integer/branchy wave kernel: its limit is instruction issue and dependent latency, not HBM "
-                            "(valu_frac / salu_frac = share of the calibrated issue peaks, profiles/); phase ms per step "
+                            "(valu_frac / salu_frac = share of the calibrated issue peaks of the cheapest instructions, valu_busy_weighted "
+                            "= vector-pipe time with every instruction kind at its measured cost, profiles/); phase ms per step "
                             "(summed over ranks): " + ", ".join("%s=%.1f" % (k, v / steps) for k, v in sorted(tim.items()))}
             value = bp * args.steps / elapsed
             cpu = trace = None

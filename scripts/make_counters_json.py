@@ -13,7 +13,11 @@ import json
 import re
 import sys
 
-VALU_PEAK = 0.456 * 2.4e9 * 1024       # wave-instructions per second, whole chip (roofcal, 8 waves/SIMD)
+VALU_PEAK = 0.456 * 2.4e9 * 1024       # wave-instructions per second, whole chip (roofcal, 8 waves/SIMD): the CHEAPEST kind
+# `roofcal ops` (profiles/r02_roofcal_ops.txt): only v_add / v_sub / v_mov_b32 / and / or / xor / lshr / ashr issue that fast,
+# every other vector instruction costs 4.4 cycles of SIMD time at 5 wavefronts per SIMD; the wave loop's mix (scripts/
+# valu_weight.py on the compiler's assembly: 45 % cheap) averages 3.62 cycles per instruction
+VALU_WEIGHTED_CYCLES = 3.62
 SALU_PEAK = 0.953 * 2.4e9 * 256        # instructions per second, whole chip
 
 
@@ -42,6 +46,7 @@ def main():
            "fetch_bytes_per_launch_x2": 2 * tr.get("FETCH_SIZE", 0) / calls, "write_bytes_per_launch": tr.get("WRITE_SIZE", 0) / calls,
            "valu_frac": cnt["SQ_INSTS_VALU"] / dur_s / VALU_PEAK if "SQ_INSTS_VALU" in cnt else None,
            "salu_frac": cnt["SQ_INSTS_SALU"] / dur_s / SALU_PEAK if "SQ_INSTS_SALU" in cnt else None,
+           "valu_busy_weighted": cnt["SQ_INSTS_VALU"] * VALU_WEIGHTED_CYCLES / (dur_s * 2.4e9 * 1024) if "SQ_INSTS_VALU" in cnt else None,
            "active_lane_frac": lanes,
            "lds_bank_conflict_frac": cnt["SQ_LDS_BANK_CONFLICT"] / cnt["SQ_LDS_IDX_ACTIVE"] if cnt.get("SQ_LDS_IDX_ACTIVE") else None,
            "wave_cycles_share": {k: cnt[k] / cnt["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")
@@ -50,7 +55,7 @@ def main():
            "source": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu "
                      "--no-trace --no-e2e` (scripts/gpu_profile_round.sh); issue peaks from tools/roofcal.hip (profiles/r02_roofcal.txt)"}
     json.dump(out, open(dst, "w"), indent=1)
-    print(json.dumps({k: out[k] for k in ("kernel_symbol", "avg_launch_ms", "bytes_per_launch", "valu_frac", "salu_frac",
+    print(json.dumps({k: out[k] for k in ("kernel_symbol", "avg_launch_ms", "bytes_per_launch", "valu_frac", "salu_frac", "valu_busy_weighted",
                                           "active_lane_frac", "lds_bank_conflict_frac", "wave_cycles_share")}, indent=1))
 
 
