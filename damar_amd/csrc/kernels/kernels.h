@@ -10,7 +10,13 @@ void   damar_exclusive_scan_u32(const u32 *in, u32 *out, u64 n, void *work, u64 
 #define DAMAR_SCAN_TILE 4096      /* items per scan tile (sort_scan.hip) */
 void   damar_tile_offsets_u32(const u32 *in, u64 n, void *work, u64 *total_dev, hipStream_t st);
 void   damar_scan_tile_counts(u32 *tcount, u32 ntiles, u64 *total_dev, hipStream_t st);
+/* radix_sort.hip: stable LSD radix sorts; each returns the side (0: k0/v0, 1: k1/v1) the result is on */
 size_t damar_sort_workspace_bytes(u64 n);
+void   damar_sort_set_threads(int threads);               /* tile shape: 256 or 512 threads per workgroup */
+const u32 *damar_sort_error_word(const void *work);       /* device word, non-zero after a sort whose look-back timed out */
+int    damar_radix_sort_keys_u64(u64 *k0, u64 *k1, u64 n, int lobit, int hibit, void *work, hipStream_t st);
+void   damar_radix_sort_split_u64(u64 *k0, u64 *k1, u64 n, int lobit, int hibit, u32 *ohi, u32 *olo, void *work,
+                                  hipStream_t st);
 int    damar_radix_sort_u32(u32 *k0, u32 *v0, u32 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st);
 int    damar_radix_sort_keys_u32(u32 *k0, u32 *k1, u64 n, int nbits, void *work, hipStream_t st);    /* keys only */
 int    damar_radix_sort_u64(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st);
@@ -63,7 +69,8 @@ typedef struct
   int  self, comp, identity;
   u32  limit;
   DevBlock ablk, bblk;
-  int  pbits, abits;          /* key = bread << (abits+pbits) | aread << pbits | apos */
+  int  pbits, abits;          /* key = bread << (abits+pbits) | aread << pbits | apos, all of it << dbits */
+  int  dbits;                 /* > 0: bpos rides in the key's low dbits (packed seeds, no vals array); 0: diag in vals */
 } MergeArgs;
 
 void damar_launch_merge_count(const MergeArgs *m, u32 *cnt, u32 *jb, hipStream_t st);
@@ -89,12 +96,21 @@ void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, i
                              u32 *heads, hipStream_t st);
 #define WORK_COST_BITS 16
 #define WORK_COST_MAX  ((1u << WORK_COST_BITS) - 1)
-void damar_launch_work_cost(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, const u32 *aboff,
+void damar_launch_work_cost(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, int dbits, const u32 *aboff,
                             const u32 *bboff, const u32 *work, u32 nwork, u32 coarse, u32 *key, u32 *val, hipStream_t st);
-void damar_launch_pair_screen(const u64 *keys, const u32 *vals, u64 nhits, int pbits, const u32 *heads, u32 nheads,
+void damar_launch_pair_screen(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int dbits, const u32 *heads, u32 nheads,
                               int minhit, int binshift, int kmer, int hitmin, int abits, u32 b_lo, u32 b_hi, u32 *keep, hipStream_t st);
 void damar_launch_compact_u32(const u32 *src, const u32 *keep, const u32 *off, u32 n, u32 *out, hipStream_t st);
 void damar_launch_compact_index(const u32 *flags, const u32 *off, u64 n, u32 *out, hipStream_t st);
+
+#ifdef __HIPCC__
+/* diagonal (apos - bpos) of seed i: from the packed key, or from the vals array of the unpacked layout */
+__device__ __forceinline__ int seed_diag(u64 k, const u32 *__restrict__ vals, u64 i, u64 pmask, int dbits)
+{ if (dbits)
+    return (int) ((k >> dbits) & pmask) - (int) (k & ((1ull << dbits) - 1));
+  return (int) vals[i];
+}
+#endif
 
 /* report.hip */
 typedef struct
@@ -110,7 +126,7 @@ typedef struct
   const u64 *keys;  const u32 *vals;  u64 nhits;
   const u32 *work;  u32 nwork;
   DevBlock ablk, bblk;
-  int  pbits, abits;
+  int  pbits, abits, dbits;        /* seed key layout, see MergeArgs */
   int  kmer, hitmin, binshift, minhit;
   int  comp, self, symmetric, minover, hgap_min;
   int  tspace, ave_path, reach;

@@ -26,7 +26,8 @@ __device__ __forceinline__ u32 read_of_pos(const DevBlock &b, u32 p)
 /* One thread per base position p: the read through the coarse table (two dependent look-ups
  * instead of a search over all reads), then the k-mer ENDING at p if the read has K bases up to
  * there.  Read r owns k-mer indices [boff[r] - r*k, boff[r+1] - (r+1)*k), in position order. */
-template <typename CodeT>
+/* PACK (k <= 16): code << 32 | pos as one u64 per k-mer, the form the index sort runs on (radix_sort.hip). */
+template <typename CodeT, bool PACK>
 __global__ __launch_bounds__(256)
 void kmer_tuples(DevBlock blk, int kmer, u32 nkmers, CodeT *__restrict__ codes, u32 *__restrict__ pos)
 { const u32 p = blockIdx.x * 256u + threadIdx.x;
@@ -42,17 +43,23 @@ void kmer_tuples(DevBlock blk, int kmer, u32 nkmers, CodeT *__restrict__ codes, 
   CodeT c = 0;
   for (int j = 0; j < kmer; j++)
     c = (CodeT) (c << 2) | (CodeT) s[j];
-  codes[i] = c;
-  pos[i]   = p;
+  if (PACK)
+    codes[i] = (CodeT) ((u64) c << 32) | (CodeT) p;
+  else
+    { codes[i] = c;
+      pos[i]   = p;
+    }
 }
 
 void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, void *codes, int wide, u32 *pos, hipStream_t st)
 { if (nkmers == 0)
     return;
   if (wide)
-    hipLaunchKernelGGL(kmer_tuples<u64>, dim3((blk->total + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, (u64 *) codes, pos);
+    hipLaunchKernelGGL((kmer_tuples<u64, false>), dim3((blk->total + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, (u64 *) codes, pos);
+  else if (pos == NULL)         /* packed: codes holds one u64 per k-mer */
+    hipLaunchKernelGGL((kmer_tuples<u64, true>), dim3((blk->total + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, (u64 *) codes, pos);
   else
-    hipLaunchKernelGGL(kmer_tuples<u32>, dim3((blk->total + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, (u32 *) codes, pos);
+    hipLaunchKernelGGL((kmer_tuples<u32, false>), dim3((blk->total + 255) / 256), dim3(256), 0, st, *blk, kmer, nkmers, (u32 *) codes, pos);
 }
 
 /* The masked branch of tuple_thread (filter.c:474-526): between two mask intervals of a read
@@ -237,12 +244,23 @@ void compact_pairs(const CodeT *__restrict__ k, const u32 *__restrict__ v, const
     }
 }
 
+/* the same, leaving code << 32 | pos (u32 codes only) */
+__global__ __launch_bounds__(256)
+void compact_pack(const u32 *__restrict__ k, const u32 *__restrict__ v, const u32 *__restrict__ keep,
+                  const u32 *__restrict__ off, u32 n, u64 *__restrict__ ko)
+{ u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n && keep[i])
+    ko[off[i]] = ((u64) k[i] << 32) | (u64) v[i];
+}
+
 void damar_launch_compact_pairs(const void *k, int wide, const u32 *v, const u32 *keep, const u32 *off, u32 n,
                                 void *ko, u32 *vo, hipStream_t st)
 { if (n == 0)
     return;
   if (wide)
     hipLaunchKernelGGL(compact_pairs<u64>, dim3((n + 255) / 256), dim3(256), 0, st, (const u64 *) k, v, keep, off, n, (u64 *) ko, vo);
+  else if (vo == NULL)
+    hipLaunchKernelGGL(compact_pack, dim3((n + 255) / 256), dim3(256), 0, st, (const u32 *) k, v, keep, off, n, (u64 *) ko);
   else
     hipLaunchKernelGGL(compact_pairs<u32>, dim3((n + 255) / 256), dim3(256), 0, st, (const u32 *) k, v, keep, off, n, (u32 *) ko, vo);
 }

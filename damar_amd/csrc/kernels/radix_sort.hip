@@ -1,0 +1,380 @@
+/* radix_sort.hip -- stable LSD radix sort for gfx950 in ONE sweep per digit.
+ *
+ * Replaces the reference's threaded 16-byte-record radix sort (dalign/filter.c:230-435 lex_thread / lex_sort),
+ * which it uses for the k-mer index (filter.c:854) and for the seed pairs (filter.c:2776).  Both orders the
+ * reference produces are total orders on (key, original position), so any stable sort on the same key bits
+ * yields the same sequence.
+ *
+ * Shape of a sort of P 8-bit digits (P + 1 launches, every key read P + 1 times and written P times):
+ *
+ *   onesweep_hist   one read of the keys: the 256-bin histograms of ALL P digits at once (the reference gets the
+ *                   next digit's histogram out of the scatter of the current one, filter.c:245-300; here every
+ *                   digit's comes out of one pass up front), per-lane-class copies of the bins in LDS so that
+ *                   the LDS atomics of a wavefront spread over the banks; also clears the look-back words
+ *   onesweep_pass   x P: a workgroup takes the next tile from a ticket counter, ranks its keys (ballot match-any
+ *                   per wavefront, per-wavefront digit counts in LDS), publishes the tile's 256 digit counts,
+ *                   finds the counts of all earlier tiles by DECOUPLED LOOK-BACK (one thread per digit walks the
+ *                   earlier tiles' words back to the first inclusive prefix), stages the tile through LDS in
+ *                   output order and writes each digit's items as one contiguous run.  No per-pass histogram
+ *                   kernel, no scan kernel, no second read of the keys.
+ *
+ * Look-back words ("granules"): one word per (tile, digit) = status (2 bits: 0 empty, 1 tile count, 2 inclusive
+ * prefix) | value, written by ONE relaxed agent-scope store and polled by relaxed agent-scope loads -- the data is
+ * the flag, so no fence is needed (cdna_hip_programming.md Guideline 16, form R2).  Tiles are taken in ticket order,
+ * so every earlier tile belongs to a workgroup that is already running: the look-back cannot wait for a tile that
+ * has not started.  Every spin is bounded; a timeout raises the error word that the host checks.
+ * 32-bit granules serve sorts of fewer than 2^30 items, 64-bit ones the rest.
+ */
+#include "dev_common.h"
+#include "kernels.h"
+
+#ifndef OS_THREADS
+#define OS_THREADS 512                       /* threads per workgroup: 512 (tiles of 8192 keys: longer runs per digit, half the
+                                                look-back words) or 256 (one wavefront per SIMD: the shape that still finds room
+                                                on a CU whose register file is mostly held by a resident report launch) */
+#endif
+#ifndef OS_ITEMS
+#define OS_ITEMS   16                        /* keys per thread       */
+#endif
+#ifndef OS_MINW
+#define OS_MINW    4                         /* wavefronts per SIMD the pass kernel is compiled for */
+#endif
+#define OS_MINTILE (256 * OS_ITEMS)          /* the smaller of the two tile shapes (workspace bound) */
+#define OS_WSPAN   (64 * OS_ITEMS)           /* contiguous items owned by one wavefront */
+#define OS_MAXPASS 8
+
+#define OH_COPIES  8                         /* copies of every histogram bin, chosen by lane & 7 */
+#define OH_ITEMS   16
+
+#define LB_COUNT   1u
+#define LB_PREFIX  2u
+#define LB_SPINS   (1u << 24)
+
+/* workspace: [0] error word | [256..) P x 256 digit totals | [8448..) P tickets | [16384..) two look-back regions */
+#define WS_HIST    256
+#define WS_CTR     (256 + OS_MAXPASS * 256 * 4)
+#define WS_LB      16384
+
+template <typename GT> __device__ __forceinline__ GT lb_load(const GT *p)
+{ return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename GT> __device__ __forceinline__ void lb_store(GT *p, GT v)
+{ __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+/* exclusive scan over the first 256 threads of the workgroup (all threads call it) */
+__device__ __forceinline__ u32 os_scan256(u32 v, u32 *lds4)
+{ const int l = lane_id(), w = threadIdx.x >> 6;
+  const u32 inc = (u32) wave_incl_scan_i((int) v);
+  if (l == 63 && w < 4) lds4[w] = inc;
+  __syncthreads();
+  u32 base = 0;
+  for (int i = 0; i < 4; i++)
+    if (i < w) base += lds4[i];
+  __syncthreads();
+  return base + inc - v;
+}
+
+/***** all digits' histograms in one read ********************************************************************/
+
+template <typename KeyT>
+__global__ __launch_bounds__(256)
+void onesweep_hist(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u32 lastmask,
+                   u32 *__restrict__ ghist, uint4 *__restrict__ clr, u64 clr16)
+{ extern __shared__ u32 sh[];                                  /* [npass][256][OH_COPIES] */
+  const int nb = npass * 256 * OH_COPIES;
+  for (int j = threadIdx.x; j < nb; j += 256)
+    sh[j] = 0;
+  __syncthreads();
+  const u32 c = threadIdx.x & (OH_COPIES - 1);
+  const u64 ntile = (n + 256 * OH_ITEMS - 1) / (256 * OH_ITEMS);
+  for (u64 t = blockIdx.x; t < ntile; t += gridDim.x)
+    { const u64 base = t * (256 * OH_ITEMS);
+      KeyT k[OH_ITEMS];
+#pragma unroll
+      for (int r = 0; r < OH_ITEMS; r++)
+        { const u64 i = base + (u64) r * 256 + threadIdx.x;
+          k[r] = (i < n) ? keys[i] : (KeyT) 0;
+        }
+#pragma unroll
+      for (int r = 0; r < OH_ITEMS; r++)
+        { const u64 i = base + (u64) r * 256 + threadIdx.x;
+          if (i < n)
+            { const KeyT x = k[r] >> lobit;
+              for (int p = 0; p < npass; p++)
+                { u32 d = (u32) (x >> (8 * p)) & 0xffu;
+                  if (p == npass - 1) d &= lastmask;
+                  atomicAdd(&sh[(((u32) p << 8) + d) * OH_COPIES + c], 1u);
+                }
+            }
+        }
+    }
+  __syncthreads();
+  for (int j = threadIdx.x; j < npass * 256; j += 256)
+    { u32 s = 0;
+#pragma unroll
+      for (int q = 0; q < OH_COPIES; q++)
+        s += sh[j * OH_COPIES + q];
+      if (s)
+        atomicAdd(&ghist[j], s);
+    }
+  /* the first look-back region starts empty */
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (u64 i = (u64) blockIdx.x * 256 + threadIdx.x; i < clr16; i += (u64) gridDim.x * 256)
+    clr[i] = z;
+}
+
+/***** one digit: rank, look back, scatter ******************************************************************/
+
+/* Wavefront w owns items [w * OS_WSPAN, (w + 1) * OS_WSPAN) of its tile in rounds of 64 consecutive items, so
+ * (wavefront, round, lane) order is input order and the ranks below make the pass stable.
+ * HV: a u32 payload travels with the key.  SPLIT: the last pass of the packed k-mer index -- the key's high word
+ * goes to ohi, its low word to vout (no key array is written). */
+template <typename KeyT, typename GT, bool HV, bool SPLIT, int TH>
+__global__ __launch_bounds__(TH, OS_MINW)
+void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, KeyT *__restrict__ kout,
+                   u32 *__restrict__ vout, u32 *__restrict__ ohi, u64 n, int shift, u32 mask,
+                   const u32 *__restrict__ ghist, GT *__restrict__ lb, GT *__restrict__ lbclear,
+                   u32 *__restrict__ ctr, u32 *__restrict__ err)
+{ constexpr int OS_TILE = TH * OS_ITEMS, OS_WAVES = TH / 64;
+  /* keys and payload are staged through the SAME buffer one after the other */
+  __shared__ KeyT skey[OS_TILE];
+  u32 *const sval = (u32 *) skey;
+  __shared__ u32  cnt[OS_WAVES][256];
+  __shared__ u32  dstart[256];
+  __shared__ u32  gadj[256];
+  __shared__ u32  lds4[4];
+  __shared__ u32  s_tile;
+  constexpr int SH = (int) sizeof(GT) * 8 - 2;
+  constexpr GT  VM = (((GT) 1) << SH) - 1;
+
+  const int l = lane_id(), w = threadIdx.x >> 6;
+  if (threadIdx.x == 0)
+    s_tile = atomicAdd(ctr, 1u);
+  for (int i = 0; i < OS_WAVES; i++)
+    if (threadIdx.x < 256)
+      cnt[i][threadIdx.x] = 0;
+  __syncthreads();
+  const u32 tile  = s_tile;
+  const u64 tbase = (u64) tile * OS_TILE;
+  const u64 wbase = tbase + (u64) w * OS_WSPAN;
+
+  KeyT key[OS_ITEMS];
+  u32  rnk[OS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; r++)
+    { const u64 i = wbase + (u64) r * 64 + l;
+      key[r] = (i < n) ? kin[i] : (KeyT) 0;
+    }
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; r++)
+    { const u64  i  = wbase + (u64) r * 64 + l;
+      const bool ok = i < n;
+      const u32  d  = (u32) (key[r] >> shift) & mask;
+      u64 peers = __ballot(ok);
+#pragma unroll
+      for (int b = 0; b < 8; b++)
+        { const bool bit = (d >> b) & 1;
+          const u64  m = __ballot(bit);
+          peers &= bit ? m : ~m;
+        }
+      const u32 before = cnt[w][d];
+      const u32 mine   = (u32) __popcll(peers & lanes_below(l));
+      rnk[r] = before + mine;
+      if (ok && mine == 0)
+        cnt[w][d] = before + (u32) __popcll(peers);
+    }
+  __syncthreads();
+
+  /* thread d: digit d's count in this tile; publish it, then the places of the digits inside the tile */
+  u32 tot = 0;
+  if (threadIdx.x < 256)
+    { u32 run = 0;
+#pragma unroll
+      for (int i = 0; i < OS_WAVES; i++)
+        { const u32 c = cnt[i][threadIdx.x];
+          cnt[i][threadIdx.x] = run;
+          run += c;
+        }
+      tot = run;
+      lb_store<GT>(&lb[(u64) tile * 256 + threadIdx.x],
+                   ((GT) (tile == 0 ? LB_PREFIX : LB_COUNT) << SH) | (GT) tot);
+      lbclear[(u64) tile * 256 + threadIdx.x] = 0;            /* the other region, for the next pass */
+    }
+  const u32 dbase = os_scan256(threadIdx.x < 256 ? ghist[threadIdx.x] : 0u, lds4);   /* where digit d's items start */
+  const u32 ex    = os_scan256(tot, lds4);
+  if (threadIdx.x < 256)
+    dstart[threadIdx.x] = ex;
+  __syncthreads();
+
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; r++)
+    { const u64 i = wbase + (u64) r * 64 + l;
+      if (i < n)
+        { const u32 d  = (u32) (key[r] >> shift) & mask;
+          const u32 lp = dstart[d] + cnt[w][d] + rnk[r];
+          rnk[r] = lp;                                         /* position inside the tile's output */
+          skey[lp] = key[r];
+        }
+    }
+
+  /* look back: items of digit d in all earlier tiles */
+  if (threadIdx.x < 256)
+    { GT before = 0;
+      if (tile > 0)
+        { u32 t = tile - 1, spins = 0;
+          while (true)
+            { const GT g = lb_load<GT>(&lb[(u64) t * 256 + threadIdx.x]);
+              const u32 st = (u32) (g >> SH);
+              if (st == 0)
+                { if (++spins > LB_SPINS)
+                    { atomicOr(err, 1u);
+                      break;
+                    }
+                  __builtin_amdgcn_s_sleep(1);
+                  continue;
+                }
+              before += g & VM;
+              if (st == LB_PREFIX)
+                break;
+              t -= 1;                                          /* tile 0 publishes a prefix: t never passes it */
+            }
+          lb_store<GT>(&lb[(u64) tile * 256 + threadIdx.x], ((GT) LB_PREFIX << SH) | ((before + tot) & VM));
+        }
+      gadj[threadIdx.x] = dbase + (u32) before - ex;
+    }
+  __syncthreads();
+
+  const u32 have = (n - tbase < (u64) OS_TILE) ? (u32) (n - tbase) : (u32) OS_TILE;
+  u32 gdst[HV ? OS_ITEMS : 1];                                 /* where this thread's output positions go (n < 2^32) */
+#pragma unroll
+  for (int q = 0; q < OS_ITEMS; q++)
+    { const u32 i = threadIdx.x + (u32) q * TH;
+      if (i < have)
+        { const KeyT k = skey[i];
+          const u32  d = (u32) (k >> shift) & mask;
+          const u32  g = gadj[d] + i;
+          if (HV) gdst[q] = g;
+          if (SPLIT)
+            { ohi[g]  = (u32) ((u64) k >> 32);
+              vout[g] = (u32) k;
+            }
+          else
+            kout[g] = k;
+        }
+    }
+  if (HV)
+    { __syncthreads();
+#pragma unroll
+      for (int r = 0; r < OS_ITEMS; r++)
+        { const u64 i = wbase + (u64) r * 64 + l;
+          if (i < n)                                           /* (the payload is loaded only now: registers) */
+            sval[rnk[r]] = vin[i];
+        }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < OS_ITEMS; q++)
+        { const u32 i = threadIdx.x + (u32) q * TH;
+          if (i < have)
+            vout[gdst[q]] = sval[i];
+        }
+    }
+}
+
+/***** host side **********************************************************************************************/
+
+static int G_sort_threads = 0;              /* 0: not chosen yet */
+
+/* tile shape of the sorts to come: 256 or 512 threads per workgroup */
+void damar_sort_set_threads(int threads) { G_sort_threads = (threads == 256) ? 256 : 512; }
+
+static int sort_threads(void)
+{ if (G_sort_threads == 0)
+    { const char *e = getenv("DAMAR_SORT_THREADS");
+      damar_sort_set_threads(e ? atoi(e) : OS_THREADS);
+    }
+  return G_sort_threads;
+}
+
+size_t damar_sort_workspace_bytes(u64 n)
+{ const u64 ntiles = (n + OS_MINTILE - 1) / OS_MINTILE;
+  return (size_t) WS_LB + 2 * (((size_t) ntiles * 256 * sizeof(u64) + 255) & ~(size_t) 255) + 256;
+}
+
+const u32 *damar_sort_error_word(const void *work) { return (const u32 *) work; }
+
+template <typename KeyT, typename GT, bool HV, int TH>
+static void onesweep_passes(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lobit, int hibit, u32 *ohi, u32 *olo,
+                            char *ws, hipStream_t st)
+{ constexpr int OS_TILE = TH * OS_ITEMS;
+  const u32 ntiles = (u32) ((n + OS_TILE - 1) / OS_TILE);
+  const int npass  = (hibit - lobit + 7) / 8;
+  const int lastb  = hibit - lobit - 8 * (npass - 1);
+  const size_t region = ((size_t) ntiles * 256 * sizeof(GT) + 255) & ~(size_t) 255;
+  u32 *err = (u32 *) ws, *ghist = (u32 *) (ws + WS_HIST), *ctr = (u32 *) (ws + WS_CTR);
+  GT  *lbr[2] = { (GT *) (ws + WS_LB), (GT *) (ws + WS_LB + region) };
+  HIP_CHECK(hipMemsetAsync(ws, 0, WS_LB, st));
+  { const u64 nt = (n + 256 * OH_ITEMS - 1) / (256 * OH_ITEMS);
+    const u32 grid = (u32) (nt < 2048 ? nt : 2048);
+    hipLaunchKernelGGL(onesweep_hist<KeyT>, dim3(grid), dim3(256), (size_t) npass * 256 * OH_COPIES * sizeof(u32), st,
+                       k0, n, lobit, npass, (1u << lastb) - 1u, ghist, (uint4 *) lbr[0], (u64) (region / 16));
+  }
+  for (int p = 0; p < npass; p++)
+    { const int  side = p & 1;
+      const bool last = (p == npass - 1);
+      KeyT *ki = side ? k1 : k0, *ko = side ? k0 : k1;
+      u32  *vi = side ? v1 : v0, *vo = side ? v0 : v1;
+      const u32 mask = last ? (1u << lastb) - 1u : 0xffu;
+      if (last && ohi != NULL)
+        hipLaunchKernelGGL((onesweep_pass<KeyT, GT, false, true, TH>), dim3(ntiles), dim3(TH), 0, st,
+                           ki, (const u32 *) NULL, (KeyT *) NULL, olo, ohi, n, lobit + 8 * p, mask,
+                           ghist + 256 * p, lbr[side], lbr[side ^ 1], ctr + p, err);
+      else
+        hipLaunchKernelGGL((onesweep_pass<KeyT, GT, HV, false, TH>), dim3(ntiles), dim3(TH), 0, st,
+                           ki, vi, ko, vo, (u32 *) NULL, n, lobit + 8 * p, mask,
+                           ghist + 256 * p, lbr[side], lbr[side ^ 1], ctr + p, err);
+    }
+}
+
+/* Sorts on key bits [lobit, hibit).  Ping-pongs between (k0,v0) and (k1,v1); returns 0 if the result is in
+ * (k0,v0), 1 if in (k1,v1).  With ohi / olo the last pass writes the two halves of the keys there instead. */
+template <typename KeyT, bool HV>
+static int onesweep_impl(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lobit, int hibit, u32 *ohi, u32 *olo,
+                         void *work, hipStream_t st)
+{ const int npass = (hibit - lobit + 7) / 8;
+  if (n == 0 || npass <= 0)
+    return 0;
+  if (npass > OS_MAXPASS || n >= 0xfffffff0ull)
+    { fprintf(stderr, "damar: internal error, radix sort of %llu items on %d bits\n", (unsigned long long) n, hibit - lobit);
+      fflush(NULL);
+      _exit(1);
+    }
+  const bool big = sort_threads() == 512;
+  if (n < (1ull << 30))
+    { if (big) onesweep_passes<KeyT, u32, HV, 512>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+      else     onesweep_passes<KeyT, u32, HV, 256>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+    }
+  else
+    { if (big) onesweep_passes<KeyT, u64, HV, 512>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+      else     onesweep_passes<KeyT, u64, HV, 256>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+    }
+  return npass & 1;
+}
+
+int damar_radix_sort_u32(u32 *k0, u32 *v0, u32 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st)
+{ return onesweep_impl<u32, true>(k0, v0, k1, v1, n, 0, nbits, NULL, NULL, work, st); }
+
+/* keys only */
+int damar_radix_sort_keys_u32(u32 *k0, u32 *k1, u64 n, int nbits, void *work, hipStream_t st)
+{ return onesweep_impl<u32, false>(k0, NULL, k1, NULL, n, 0, nbits, NULL, NULL, work, st); }
+
+int damar_radix_sort_u64(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u64 n, int nbits, void *work, hipStream_t st)
+{ return onesweep_impl<u64, true>(k0, v0, k1, v1, n, 0, nbits, NULL, NULL, work, st); }
+
+/* keys only, on bits [lobit, hibit): whatever sits below lobit rides along as payload */
+int damar_radix_sort_keys_u64(u64 *k0, u64 *k1, u64 n, int lobit, int hibit, void *work, hipStream_t st)
+{ return onesweep_impl<u64, false>(k0, NULL, k1, NULL, n, lobit, hibit, NULL, NULL, work, st); }
+
+/* as damar_radix_sort_keys_u64, but the last pass writes the keys' high words to ohi and their low words to olo
+ * (neither may overlap the buffer that pass reads: k0 for an odd number of passes, k1 for an even one) */
+void damar_radix_sort_split_u64(u64 *k0, u64 *k1, u64 n, int lobit, int hibit, u32 *ohi, u32 *olo, void *work,
+                                hipStream_t st)
+{ onesweep_impl<u64, false>(k0, NULL, k1, NULL, n, lobit, hibit, ohi, olo, work, st); }

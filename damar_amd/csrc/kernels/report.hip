@@ -1386,11 +1386,12 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
   const u64 *keys = a.keys;
   const u32 *vals = a.vals;
   const u64  pmask = (1ull << a.pbits) - 1;
+  const int  dbits = a.dbits, pshift = a.pbits + a.dbits;      /* key = pair | apos | bpos (dbits) */
   const int  K = a.kmer, H = a.hitmin, W = a.binshift, minhit = a.minhit;
   const int  mind = (-a.bblk.maxlen) >> W, maxd = a.ablk.maxlen >> W;
 
   u64 nidx = a.work[item];
-  const u64 cpair = keys[nidx] >> a.pbits;
+  const u64 cpair = keys[nidx] >> pshift;
   const int ar = (int) (cpair & ((1ull << a.abits) - 1)), br = (int) (cpair >> a.abits);
   const int alen = (int) read_len(a.ablk, ar), blen = (int) read_len(a.bblk, br);
   if (alen < a.hgap_min && blen < a.hgap_min)
@@ -1418,7 +1419,7 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
   const unsigned long long pf_p0 = wall_clock64();
 #endif
 
-  while (nidx < a.nhits && (keys[nidx] >> a.pbits) == cpair)      /* A-panels, filter.c:2251 */
+  while (nidx < a.nhits && (keys[nidx] >> pshift) == cpair)      /* A-panels, filter.c:2251 */
     { const int amark = amark2 + PANEL_SIZE;
       amark2 = amark - PANEL_OVERLAP;
       const u64 lidx = nidx;
@@ -1426,9 +1427,9 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
       /* consume hits while the pair continues and the hit just consumed has apos <= amark */
       for (u64 base = lidx; ; base += 64)
         { u64  f = base + lane;
-          bool in = f < a.nhits && (keys[f] >> a.pbits) == cpair;
-          int  ap = in ? (int) (keys[f] & pmask) : 0;
-          bool nextsame = (f + 1 < a.nhits) && ((keys[f + 1] >> a.pbits) == cpair);
+          bool in = f < a.nhits && (keys[f] >> pshift) == cpair;
+          int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
+          bool nextsame = (f + 1 < a.nhits) && ((keys[f + 1] >> pshift) == cpair);
           bool stop = in && !(nextsame && ap <= amark);
           u64  le = wballot(in && ap <= amark2);
           u64  sm = wballot(stop);
@@ -1455,8 +1456,8 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
           for (u64 base = lidx; base < end; base += 64)
             { u64  f = base + lane;
               bool in = f < end;
-              int  ap = in ? (int) (keys[f] & pmask) : 0;
-              int  d  = in ? (((int) vals[f]) >> W) : BIG;
+              int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
+              int  d  = in ? (seed_diag(keys[f], vals, f, pmask, dbits) >> W) : BIG;
               int  prev = in ? s.lastp[d] : 0;
               /* lanes of this chunk that fall into the same bucket: the nearest one below
                  supplies lastp, the highest one stores it (match-any over the bucket bits) */
@@ -1490,8 +1491,8 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
           for (u64 base = lidx; base < end; base += 64)
             { u64  f = base + lane;
               bool in = f < end;
-              int  ap = in ? (int) (keys[f] & pmask) : 0;
-              int  dg = in ? (int) vals[f] : 0;
+              int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
+              int  dg = in ? seed_diag(keys[f], vals, f, pmask, dbits) : 0;
               int  d  = dg >> W;
               bool hot = false;
               if (in)
@@ -1543,7 +1544,7 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
           for (u64 base = lidx; base < end; base += 64)
             { u64 f = base + lane;
               if (f < end)
-                { int d = ((int) vals[f]) >> W;
+                { int d = seed_diag(keys[f], vals, f, pmask, dbits) >> W;
                   s.score[d] = 0;
                   s.lastp[d] = 0;
                 }

@@ -944,6 +944,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
   const u64 *keys = a.keys;
   const u32 *vals = a.vals;
   const u64 pmask = (1ull << a.pbits) - 1;
+  const int dbits = a.dbits, pshift = a.pbits + a.dbits;        /* key = pair | apos | bpos (dbits) */
   const int K = a.kmer, H = a.hitmin, W = a.binshift, minhit = a.minhit;
   const int mind = (-a.bblk.maxlen) >> W, maxd = a.ablk.maxlen >> W;
   const bool batch = tasks != NULL;
@@ -980,7 +981,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
               else
                 { item = a.order ? a.order[it] : it;
                   nidx = a.work[item];
-                  cpair = keys[nidx] >> a.pbits;
+                  cpair = keys[nidx] >> pshift;
                   ar = (int) (cpair & ((1ull << a.abits) - 1));  br = (int) (cpair >> a.abits);
                   p.a0 = (int) a.ablk.boff[ar];  p.b0 = (int) a.bblk.boff[br];
                   p.alen = (int) read_len(a.ablk, ar);  p.blen = (int) read_len(a.bblk, br);
@@ -990,7 +991,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                 }
             }
           else if (phase == PK_PANEL && !task)
-            { if (!(nidx < a.nhits && (keys[nidx] >> a.pbits) == cpair))
+            { if (!(nidx < a.nhits && (keys[nidx] >> pshift) == cpair))
                 { /* the pair is done: filter.c:2417-2432 leaves lasta all zero again */
                   if (clo <= chi)
                     for (int q = clo + s; q <= chi; q += 32)
@@ -1004,9 +1005,9 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                   lidx = nidx;  end = lidx;  h2 = lidx;
                   for (u64 base = lidx; ; base += 32)
                     { const u64  f = base + s;
-                      const bool in = f < a.nhits && (keys[f] >> a.pbits) == cpair;
-                      const int  ap = in ? (int) (keys[f] & pmask) : 0;
-                      const bool nextsame = (f + 1 < a.nhits) && ((keys[f + 1] >> a.pbits) == cpair);
+                      const bool in = f < a.nhits && (keys[f] >> pshift) == cpair;
+                      const int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
+                      const bool nextsame = (f + 1 < a.nhits) && ((keys[f + 1] >> pshift) == cpair);
                       const bool stop = in && !(nextsame && ap <= amark);
                       u32 le = hmask(wballot(in && ap <= amark2), hb);
                       const u32 sm = hmask(wballot(stop), hb);
@@ -1027,8 +1028,8 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                       for (u64 base = lidx; base < end; base += 32)
                         { const u64  f = base + s;
                           const bool in = f < end;
-                          const int  ap = in ? (int) (keys[f] & pmask) : 0;
-                          const int  d  = in ? (((int) vals[f]) >> W) : BIG;
+                          const int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
+                          const int  d  = in ? (seed_diag(keys[f], vals, f, pmask, dbits) >> W) : BIG;
                           int  prev = in ? sc.lastp[d] : 0;
                           u32  peers = hmask(wballot(in), hb);
                           { const u32 db = (u32) (d - mind);
@@ -1064,8 +1065,8 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
               for (u64 base = fp; base < end; base += 32)
                 { const u64  f = base + s;
                   const bool in = f < end;
-                  const int  ap = in ? (int) (keys[f] & pmask) : 0;
-                  const int  dg = in ? (int) vals[f] : 0;
+                  const int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
+                  const int  dg = in ? seed_diag(keys[f], vals, f, pmask, dbits) : 0;
                   const int  d  = dg >> W;
                   bool fire = false;
                   if (in)
@@ -1088,7 +1089,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                   for (u64 base = lidx; base < end; base += 32)
                     { const u64 f = base + s;
                       if (f < end)
-                        { const int d = ((int) vals[f]) >> W;
+                        { const int d = seed_diag(keys[f], vals, f, pmask, dbits) >> W;
                           sc.score[d] = 0;
                           sc.lastp[d] = 0;
                         }

@@ -212,8 +212,13 @@ void merge_emit(MergeArgs m, const u32 *__restrict__ cnt, const u32 *__restrict_
       const u32 xa = pa - m.ablk.boff[ra], xb = pb - m.bblk.boff[rb];
       const u64 h = h0 + t;
       if (h < nhits)
-        { keys[h] = ((u64) rb << (m.abits + m.pbits)) | ((u64) ra << m.pbits) | (u64) xa;
-          vals[h] = (u32) ((int) xa - (int) xb);
+        { const u64 key = ((u64) rb << (m.abits + m.pbits)) | ((u64) ra << m.pbits) | (u64) xa;
+          if (m.dbits)
+            keys[h] = (key << m.dbits) | (u64) xb;
+          else
+            { keys[h] = key;
+              vals[h] = (u32) ((int) xa - (int) xb);
+            }
           if (pid != NULL)                     /* the read pair alone, for the early cut (damar_launch_pair_cut) */
             pid[h] = (rb << m.abits) | ra;
         }
@@ -434,7 +439,8 @@ void seed_cut_scatter(const u64 *__restrict__ keys, const u32 *__restrict__ vals
       if ((mask[r] >> l) & 1)
         { const u32 g = o + before + (u32) __popcll(mask[r] & lanes_below(l));
           okeys[g] = key[r];
-          ovals[g] = vals[i];
+          if (vals != NULL)
+            ovals[g] = vals[i];
         }
       o += wsum[r][0] + wsum[r][1] + wsum[r][2] + wsum[r][3];
     }
@@ -462,14 +468,16 @@ void damar_launch_seed_cut_scatter(const u64 *keys, const u32 *vals, u64 nhits, 
  * work list: the report kernel would not have emitted anything for them.  One thread per head,
  * heads compacted first so that the wavefronts are full. */
 __global__ __launch_bounds__(256)
-void pair_screen(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits,
+void pair_screen(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits, int dbits,
                  const u32 *__restrict__ heads, u32 nheads, int minhit, int binshift, int kmer, int hitmin,
                  int abits, u32 b_lo, u32 b_hi, u32 *__restrict__ keep)
 { u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= nheads)
     return;
   const u64 i = heads[t];
-  const u64 pr = keys[i] >> pbits, pmask = (1ull << pbits) - 1;
+  const u64 pmask = (1ull << pbits) - 1;
+  pbits += dbits;                                 /* from here on: the shift that leaves the read pair */
+  const u64 pr = keys[i] >> pbits;
   u32 f = 1;
   int n = minhit;
   { const u32 rb = (u32) (pr >> abits);          /* a scheduler may hand this call a B-read range only */
@@ -480,14 +488,15 @@ void pair_screen(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64
   }
   while (n <= SCREEN_MAX && i + (u64) n < nhits && (keys[i + (u64) n] >> pbits) == pr)
     n += 1;
-  if (n <= SCREEN_MAX && (int) (keys[i + (u64) (n - 1)] & pmask) <= SCREEN_PANEL)
+  if (n <= SCREEN_MAX && (int) ((keys[i + (u64) (n - 1)] >> dbits) & pmask) <= SCREEN_PANEL)
     { bool ok = false;
       for (int x = 0; x < n && !ok; x++)
-        { const int dx = ((int) vals[i + (u64) x]) >> binshift;
+        { const int dx = seed_diag(keys[i + (u64) x], vals, i + (u64) x, pmask, dbits) >> binshift;
           int s0 = 0, s1 = 0, p0 = 0, p1 = 0;
           for (int y = 0; y < n; y++)
-            { const int dy = ((int) vals[i + (u64) y]) >> binshift;
-              const int ap = (int) (keys[i + (u64) y] & pmask);
+            { const u64 ky = keys[i + (u64) y];
+              const int dy = seed_diag(ky, vals, i + (u64) y, pmask, dbits) >> binshift;
+              const int ap = (int) ((ky >> dbits) & pmask);
               if (dy == dx)
                 { s0 += (ap - p0 >= kmer) ? kmer : ap - p0;  p0 = ap; }
               else if (dy == dx + 1)
@@ -501,12 +510,12 @@ void pair_screen(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64
   keep[t] = f;
 }
 
-void damar_launch_pair_screen(const u64 *keys, const u32 *vals, u64 nhits, int pbits, const u32 *heads, u32 nheads,
+void damar_launch_pair_screen(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int dbits, const u32 *heads, u32 nheads,
                               int minhit, int binshift, int kmer, int hitmin, int abits, u32 b_lo, u32 b_hi,
                               u32 *keep, hipStream_t st)
 { if (nheads == 0)
     return;
-  hipLaunchKernelGGL(pair_screen, dim3((nheads + 255) / 256), dim3(256), 0, st, keys, vals, nhits, pbits, heads, nheads,
+  hipLaunchKernelGGL(pair_screen, dim3((nheads + 255) / 256), dim3(256), 0, st, keys, vals, nhits, pbits, dbits, heads, nheads,
                      minhit, binshift, kmer, hitmin, abits, b_lo, b_hi, keep);
 }
 
@@ -543,12 +552,13 @@ void damar_launch_compact_index(const u32 *flags, const u32 *off, u64 n, u32 *ou
  * of the launch.  The number of seeds of a pair is a good stand-in for the length of its
  * alignment; key[j] sorts ascending into "most seeds first". */
 __global__ __launch_bounds__(256)
-void work_cost(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits, int abits,
+void work_cost(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits0, int abits, int dbits,
                const u32 *__restrict__ aboff, const u32 *__restrict__ bboff,
                const u32 *__restrict__ work, u32 nwork, u32 coarse, u32 *__restrict__ key, u32 *__restrict__ val)
 { u32 j = blockIdx.x * 256u + threadIdx.x;
   if (j >= nwork)
     return;
+  const int pbits = pbits0 + dbits;               /* the shift that leaves the read pair */
   const u64 i = work[j], pr = keys[i] >> pbits;
   u64 a = i + 1, b = (j + 1 < nwork) ? (u64) work[j + 1] : nhits;       /* run ends at or before the next head */
   while (a < b)
@@ -558,14 +568,14 @@ void work_cost(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 n
   u64 n = a - i;
   if (coarse >= 0xfffffffdu)    /* cost = the expected length of the alignment instead of a seed count: the wave kernel's
                                    launch ends with its longest serial chains, so those must start first */
-    { const u64 pm = (1ull << pbits) - 1;
-      const u64 ext = (keys[a - 1] & pm) - (keys[i] & pm);              /* extent of the seeds on A */
+    { const u64 pm = (1ull << pbits0) - 1;
+      const u64 ext = ((keys[a - 1] >> dbits) & pm) - ((keys[i] >> dbits) & pm);      /* extent of the seeds on A */
       const u32 ra = (u32) (pr & ((1ull << abits) - 1)), rb = (u32) (pr >> abits);
       const int alen = (int) (aboff[ra + 1] - aboff[ra]) - 1, blen = (int) (bboff[rb + 1] - bboff[rb]) - 1;
-      const int d = (int) vals[i];                                      /* diagonal a - b of the first seed */
+      const int d = seed_diag(keys[i], vals, i, pm, dbits);             /* diagonal a - b of the first seed */
       const int geo = min(alen, blen + d) - max(0, d);                  /* overlap of the two reads on it */
       u64 len = (coarse == 0xffffffffu) ? ext : (coarse == 0xfffffffeu ? (u64) max(geo, 0) : max(ext, (u64) max(geo, 0)));
-      n = len >> (pbits > 16 ? pbits - 16 : 0);
+      n = len >> (pbits0 > 16 ? pbits0 - 16 : 0);
       coarse = 0;
     }
   if (n > WORK_COST_MAX)
@@ -577,10 +587,10 @@ void work_cost(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 n
   val[j] = j;
 }
 
-void damar_launch_work_cost(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, const u32 *aboff,
+void damar_launch_work_cost(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, int dbits, const u32 *aboff,
                             const u32 *bboff, const u32 *work, u32 nwork, u32 coarse, u32 *key, u32 *val, hipStream_t st)
 { if (nwork == 0)
     return;
-  hipLaunchKernelGGL(work_cost, dim3((nwork + 255) / 256), dim3(256), 0, st, keys, vals, nhits, pbits, abits, aboff, bboff,
+  hipLaunchKernelGGL(work_cost, dim3((nwork + 255) / 256), dim3(256), 0, st, keys, vals, nhits, pbits, abits, dbits, aboff, bboff,
                      work, nwork, coarse, key, val);
 }

@@ -456,6 +456,28 @@ struct damar_dev_index
   int   kbits, tbits, wide;
 };
 
+/* The radix sort's look-back is bounded; a timeout (never seen) raises a device word.  sort_check queues its copy
+   behind the sort, sort_verify looks at the copies once the stream has been synchronised. */
+static u32 *H_serr = NULL;
+static int  H_nserr = 0;
+static void sort_verify(void)
+{ for (int i = 0; i < H_nserr; i++)
+    if (H_serr[i] != 0)
+      { fprintf(stderr, "damar: FATAL: the radix sort's look-back timed out\n");
+        die();
+      }
+  H_nserr = 0;
+}
+static void sort_check(const void *sw)
+{ if (H_serr == NULL)
+    HIP_CHECK(hipHostMalloc((void **) &H_serr, 64 * sizeof(u32), hipHostMallocDefault));
+  if (H_nserr == 64)
+    { HIP_CHECK(hipStreamSynchronize(G_st));
+      sort_verify();
+    }
+  HIP_CHECK(hipMemcpyAsync(&H_serr[H_nserr++], damar_sort_error_word(sw), sizeof(u32), hipMemcpyDeviceToHost, G_st));
+}
+
 static int ilog2_ceil(u64 n)
 { int b = 0;
   while ((1ull << b) < n)
@@ -504,13 +526,22 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
   const int npass = (kbits + 7) / 8;
   damar_dev_index *ix = (damar_dev_index *) calloc(1, sizeof(damar_dev_index));
   ix->blk = blk;  ix->own_block = own_block;  ix->kbits = kbits;  ix->wide = wide;
-  ix->codes = dpool_get(cs * (size_t) cap, &ix->codes_bytes);
-  ix->pos   = (u32 *) dpool_get(sizeof(u32) * (size_t) cap, &ix->pos_bytes);
+  /* k <= 16: the sort runs on ONE u64 per k-mer, code << 32 | pos, on the code bits only (radix_sort.hip), and its
+     last pass writes the two halves apart: codes[] and pos[] share one buffer of 8 bytes per k-mer.
+     k > 16: u64 codes and u32 positions as key and payload. */
+  if (wide)
+    { ix->codes = dpool_get(cs * (size_t) cap, &ix->codes_bytes);
+      ix->pos   = (u32 *) dpool_get(sizeof(u32) * (size_t) cap, &ix->pos_bytes);
+    }
+  else
+    { ix->codes = dpool_get(2 * sizeof(u32) * (size_t) cap, &ix->codes_bytes);
+      ix->pos   = (u32 *) ix->codes + cap;
+    }
 
   size_t swb = damar_sort_workspace_bytes(cap);
-  arena_reserve(&G_work, pad256(cs * (size_t) cap) + 3 * pad256(sizeof(u32) * (size_t) cap) + pad256(swb) +
+  arena_reserve(&G_work, pad256(sizeof(u64) * (size_t) cap) + 3 * pad256(sizeof(u32) * (size_t) cap) + pad256(swb) +
                          pad256(damar_scan_workspace_bytes(cap)) + (1 << 16));
-  void *tk = arena_take(&G_work, cs * (size_t) cap);
+  void *tk = arena_take(&G_work, sizeof(u64) * (size_t) cap);
   u32 *tv = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) cap);
   void *sw = arena_take(&G_work, swb);
   u32 *keep = NULL, *off = NULL;
@@ -523,17 +554,26 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
       tot  = (u64 *) arena_take(&G_work, 64);
     }
 
-  /* the sort ping-pongs: start on the side that makes it end in the index's own arrays */
-  void *k0 = (npass & 1) ? tk : ix->codes, *k1 = (npass & 1) ? ix->codes : tk;
-  u32  *v0 = (npass & 1) ? tv : ix->pos,   *v1 = (npass & 1) ? ix->pos : tv;
+  /* the sort ping-pongs: start on the side that makes it end in the index's own arrays (wide), resp. that makes
+     its last pass READ the temporary, so that it can write the index's buffer (packed) */
+  void *k0, *k1;
+  u32  *v0, *v1;
+  if (wide)
+    { k0 = (npass & 1) ? tk : ix->codes;  k1 = (npass & 1) ? ix->codes : tk;
+      v0 = (npass & 1) ? tv : ix->pos;    v1 = (npass & 1) ? ix->pos : tv;
+    }
+  else
+    { k0 = (npass & 1) ? tk : ix->codes;  k1 = (npass & 1) ? ix->codes : tk;
+      v0 = v1 = NULL;
+    }
 
   tick(0);
   if (biased || masked)
     { /* filter.c:474-526 / 549-688 + the filler squeeze of :855-888: only k-mers inside one
          unmasked stretch (resp. the windows the -b walk yields) enter the index; dropping the rest
-         before the sort leaves the same sorted list */
-      void *k9 = (k0 == tk) ? ix->codes : tk;
-      u32  *v9 = (v0 == tv) ? ix->pos : tv;
+         before the sort leaves the same sorted list.  The candidates sit in the sort's other buffer. */
+      void *k9 = k1;
+      u32  *v9 = wide ? ((v0 == tv) ? ix->pos : tv) : (u32 *) k1 + cap;
       u64   kept = 0;
       u32   nin = nk;
       if (biased)
@@ -546,7 +586,7 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
           damar_launch_mask_flags(&blk->d, K, v9, nk, keep, G_st);
         }
       damar_exclusive_scan_u32(keep, off, nin, scw, tot, G_st);
-      damar_launch_compact_pairs(k9, wide, v9, keep, off, nin, k0, v0, G_st);
+      damar_launch_compact_pairs(k9, wide, v9, keep, off, nin, k0, v0, G_st);      /* v0 == NULL: packed into k0 */
       HIP_CHECK(hipMemcpyAsync(&kept, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
       HIP_CHECK(hipStreamSynchronize(G_st));
       nk = (u32) kept;
@@ -559,15 +599,19 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
         printf("\n   Revised kmer count = %u\n", nk);
     }
   else
-    damar_launch_kmer_tuples(&blk->d, K, nk, k0, wide, v0, G_st);
+    damar_launch_kmer_tuples(&blk->d, K, nk, k0, wide, v0, G_st);                   /* v0 == NULL: packed */
   tick(1);
-  int side = wide ? damar_radix_sort_u64((u64 *) k0, v0, (u64 *) k1, v1, nk, kbits, sw, G_st)
-                  : damar_radix_sort_u32((u32 *) k0, v0, (u32 *) k1, v1, nk, kbits, sw, G_st);
-  tick(2);
-  if ((side ? k1 : k0) != ix->codes)
-    { fprintf(stderr, "damar: internal error, sort ended on the wrong side\n");
-      die();
+  if (wide)
+    { int side = damar_radix_sort_u64((u64 *) k0, v0, (u64 *) k1, v1, nk, kbits, sw, G_st);
+      if ((side ? k1 : k0) != ix->codes)
+        { fprintf(stderr, "damar: internal error, sort ended on the wrong side\n");
+          die();
+        }
     }
+  else
+    damar_radix_sort_split_u64((u64 *) k0, (u64 *) k1, nk, 32, 32 + kbits, (u32 *) ix->codes, ix->pos, sw, G_st);
+  sort_check(sw);
+  tick(2);
   u32 n = nk;
   /* Prefix table resolution: one entry per code when that is affordable (2^28 entries = 1 GB for
      k = 14; HBM is sized for it), so that a code's run is two adjacent table entries and no
@@ -597,6 +641,7 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
     }
   tick(3);
   HIP_CHECK(hipStreamSynchronize(G_st));
+  sort_verify();
   G_ms[DAMAR_T_TUPLES] = lap(0, 1);
   G_ms[DAMAR_T_KSORT]  = lap(1, 2);
   G_ms[DAMAR_T_TABLE]  = lap(2, 3);
@@ -626,7 +671,8 @@ extern "C" void damar_index_free(damar_dev_index *ix)
     return;
   HIP_CHECK(hipStreamSynchronize(G_st));
   dpool_put(ix->codes, ix->codes_bytes);       /* (the stream was synchronised above: nothing reads them any more) */
-  dpool_put(ix->pos, ix->pos_bytes);
+  if (ix->pos_bytes)                           /* (k <= 16: the positions live in the codes' buffer) */
+    dpool_put(ix->pos, ix->pos_bytes);
   dpool_put(ix->table, ix->table_bytes);
   if (ix->own_block)
     damar_block_free(ix->blk);
@@ -1281,7 +1327,7 @@ extern "C" double damar_async_d2h_ms(void)
 
 static std::vector<u64> G_seed_keys;
 static std::vector<u32> G_seed_vals;
-static int  G_seed_pbits = 0, G_seed_abits = 0;
+static int  G_seed_pbits = 0, G_seed_abits = 0, G_seed_dbits = 0;
 static int  G_keep_seeds = 0;
 
 static int64 sizeof_db(const HITS_DB *db)      /* db/DB.c:726 sizeof_DB without tracks */
@@ -1295,7 +1341,7 @@ struct Front
 { const u64 *keys;  const u32 *vals;  u64 total;
   const u32 *work;  u32 nwork;
   const u32 *order;
-  int pbits, abits;
+  int pbits, abits, dbits;
   size_t bytes;                 /* of the two arenas that hold the above */
 };
 
@@ -1334,6 +1380,16 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
     }
   m.atbits = aidx->tbits;
   m.btbits = bidx->tbits;
+  /* Packed seeds: when position-in-B fits beside the sort key, a seed is ONE u64 (pair | apos | bpos) and the sort moves
+     8 bytes per seed instead of 12; otherwise the diagonal travels in a second array (DAMAR_PACK_SEEDS=0 forces that) */
+  { static int pack_on = -1;
+    if (pack_on < 0)
+      { const char *e = getenv("DAMAR_PACK_SEEDS");
+        pack_on = e ? atoi(e) : 1;
+      }
+    const int db = std::max(1, ilog2_ceil((u64) bblock->maxlen + 1));
+    m.dbits = (pack_on && m.pbits + m.abits + bbits + db <= 64) ? db : 0;
+  }
 
   /* ---- merge: count, scan, (limit), emit ---- */
   size_t need = 3 * pad256(sizeof(u32) * (size_t) alen) + pad256(damar_scan_workspace_bytes(alen)) + 4096;
@@ -1470,9 +1526,9 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       arena_reserve(&G_tmp,  pad256(sizeof(u64) * (size_t) total) + 3 * pad256(sizeof(u32) * (size_t) total) +
                              pad256(damar_sort_workspace_bytes(total)) + pad256(damar_scan_workspace_bytes(total)) + 8192);
       u64 *pk = (u64 *) arena_take(&G_hits, sizeof(u64) * (size_t) total);
-      u32 *pv = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
+      u32 *pv = m.dbits ? NULL : (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
       tk = (u64 *) arena_take(&G_tmp, sizeof(u64) * (size_t) total);
-      u32 *tv = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
+      u32 *tv = m.dbits ? NULL : (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
       u64 *k0 = (spasses & 1) ? tk : pk, *k1 = (spasses & 1) ? pk : tk;
       u32 *v0 = (spasses & 1) ? tv : pv, *v1 = (spasses & 1) ? pv : tv;
       void *sw = arena_take(&G_tmp, damar_sort_workspace_bytes(total));
@@ -1484,7 +1540,9 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       damar_launch_merge_emit(&m, cnt, (const u32 *) scw, jb, total, k0, v0, NULL, G_st);
       stage("merge_emit");
       tick(1);
-      int side = damar_radix_sort_u64(k0, v0, k1, v1, total, sbits, sw, G_st);
+      int side = m.dbits ? damar_radix_sort_keys_u64(k0, k1, total, m.dbits, m.dbits + sbits, sw, G_st)
+                         : damar_radix_sort_u64(k0, v0, k1, v1, total, sbits, sw, G_st);
+      sort_check(sw);
       keys = side ? k1 : k0;
       vals = side ? v1 : v0;
       if (keys != pk)
@@ -1517,13 +1575,14 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       stage("merge_emit");
       tick(1);
       const u32 *spid = damar_radix_sort_keys_u32(pid0, pid1, total, idbits, sw, G_st) ? pid1 : pid0;
+      sort_check(sw);
       u64 n64 = 0;
       damar_launch_pair_heads_ids(spid, total, m.abits, minhit, P_nshift, snd, (u64 *) hbit, scc, tot, hd, G_st);
       HIP_CHECK(hipMemsetAsync(bitmap, 0, sizeof(u32) * bmwords, G_st));
       HIP_CHECK(hipMemcpyAsync(&n64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
       HIP_CHECK(hipStreamSynchronize(G_st));
       damar_launch_pair_bitmap(spid, hd, (u32) n64, m.abits, P_bread_lo, P_bread_hi, bitmap, G_st);
-      damar_launch_seed_cut_count(uk, total, m.pbits, bitmap, (u32 *) scc, tot, G_st);
+      damar_launch_seed_cut_count(uk, total, m.pbits + m.dbits, bitmap, (u32 *) scc, tot, G_st);
       HIP_CHECK(hipMemcpyAsync(&n64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
       HIP_CHECK(hipStreamSynchronize(G_st));
       stage("early_cut");
@@ -1541,9 +1600,9 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       arena_reserve(&G_tmp2, pad256(sizeof(u64) * (size_t) nsurv) + 3 * pad256(sizeof(u32) * (size_t) nsurv) +
                              pad256(damar_sort_workspace_bytes(nsurv)) + pad256(damar_scan_workspace_bytes(nsurv)) + 8192);
       u64 *pk = (u64 *) arena_take(&G_hits, sizeof(u64) * (size_t) nsurv);
-      u32 *pv = (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) nsurv);
+      u32 *pv = m.dbits ? NULL : (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) nsurv);
       tk = (u64 *) arena_take(&G_tmp2, sizeof(u64) * (size_t) nsurv);
-      u32 *tv = (u32 *) arena_take(&G_tmp2, sizeof(u32) * (size_t) nsurv);
+      u32 *tv = m.dbits ? NULL : (u32 *) arena_take(&G_tmp2, sizeof(u32) * (size_t) nsurv);
       u64 *k0 = (spasses & 1) ? tk : pk, *k1 = (spasses & 1) ? pk : tk;
       u32 *v0 = (spasses & 1) ? tv : pv, *v1 = (spasses & 1) ? pv : tv;
       void *sw2 = arena_take(&G_tmp2, damar_sort_workspace_bytes(nsurv));
@@ -1551,8 +1610,10 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       foff  = (u32 *) arena_take(&G_tmp2, sizeof(u32) * (size_t) nsurv);
       scw2  = arena_take(&G_tmp2, damar_scan_workspace_bytes(nsurv));
       sends = (u64 *) arena_take(&G_tmp2, 64 * sizeof(u64));
-      damar_launch_seed_cut_scatter(uk, uv, total, m.pbits, bitmap, (const u32 *) scc, k0, v0, G_st);
-      int side = damar_radix_sort_u64(k0, v0, k1, v1, nsurv, sbits, sw2, G_st);
+      damar_launch_seed_cut_scatter(uk, m.dbits ? NULL : uv, total, m.pbits + m.dbits, bitmap, (const u32 *) scc, k0, v0, G_st);
+      int side = m.dbits ? damar_radix_sort_keys_u64(k0, k1, nsurv, m.dbits, m.dbits + sbits, sw2, G_st)
+                         : damar_radix_sort_u64(k0, v0, k1, v1, nsurv, sbits, sw2, G_st);
+      sort_check(sw2);
       keys = side ? k1 : k0;
       vals = side ? v1 : v0;
       if (keys != pk)
@@ -1568,7 +1629,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
   /* ---- work list ---- */
   u64 nwork64 = 0;
   u32 *heads = (u32 *) tk;                              /* the idle key buffer holds the run heads */
-  damar_launch_pair_heads(keys, total, m.pbits, m.abits, minhit, hshift, sends, (u64 *) foff /* bit words */,
+  damar_launch_pair_heads(keys, total, m.pbits + m.dbits, m.abits, minhit, hshift, sends, (u64 *) foff /* bit words */,
                           scw2, tot, heads, G_st);
   stage("run_heads");
   HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
@@ -1580,7 +1641,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
   u32 *work = (u32 *) arena_take(&G_ord, sizeof(u32) * ((size_t) nheads + 1));
   nwork64 = 0;
   if (nheads > 0)
-    { damar_launch_pair_screen(keys, vals, total, m.pbits, heads, nheads, minhit, P_binshift, P_kmer, P_hitmin, m.abits,
+    { damar_launch_pair_screen(keys, vals, total, m.pbits, m.dbits, heads, nheads, minhit, P_binshift, P_kmer, P_hitmin, m.abits,
                                P_bread_lo, P_bread_hi, flags, G_st);
       damar_exclusive_scan_u32(flags, foff, nheads, scw2, tot, G_st);
       damar_launch_compact_u32(heads, flags, foff, nheads, work, G_st);
@@ -1589,6 +1650,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
     }
   tick(3);
   HIP_CHECK(hipStreamSynchronize(G_st));
+  sort_verify();
   const u32 nwork = (u32) nwork64;
   G_ms[DAMAR_T_MERGE] += lap(0, 1);
   G_ms[DAMAR_T_SSORT] += lap(1, 2);
@@ -1599,8 +1661,9 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
   if (G_keep_seeds)
     { G_seed_keys.resize(total);  G_seed_vals.resize(total);
       HIP_CHECK(hipMemcpy(G_seed_keys.data(), keys, sizeof(u64) * (size_t) total, hipMemcpyDeviceToHost));
-      HIP_CHECK(hipMemcpy(G_seed_vals.data(), vals, sizeof(u32) * (size_t) total, hipMemcpyDeviceToHost));
-      G_seed_pbits = m.pbits;  G_seed_abits = m.abits;
+      if (vals != NULL)
+        HIP_CHECK(hipMemcpy(G_seed_vals.data(), vals, sizeof(u32) * (size_t) total, hipMemcpyDeviceToHost));
+      G_seed_pbits = m.pbits;  G_seed_abits = m.abits;  G_seed_dbits = m.dbits;
     }
 
   /* ---- largest pairs first (the order only schedules the kernel: records carry their work
@@ -1622,15 +1685,16 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       void *osw = arena_take(&G_ord, damar_sort_workspace_bytes(nwork));
       const u32 cmode = order_mode == 2 ? 1u : order_mode == 9 ? 0xffffffffu : order_mode == 10 ? 0xfffffffeu :
                         order_mode == 11 ? 0xfffffffdu : (order_mode > 2 ? (u32) order_mode : 0u);
-      damar_launch_work_cost(keys, vals, total, m.pbits, m.abits, m.ablk.boff, m.bblk.boff, work, nwork, cmode, ok0, ov0, G_st);
+      damar_launch_work_cost(keys, vals, total, m.pbits, m.abits, m.dbits, m.ablk.boff, m.bblk.boff, work, nwork, cmode, ok0, ov0, G_st);
       order = damar_radix_sort_u32(ok0, ov0, ok1, ov1, nwork, WORK_COST_BITS, osw, G_st) ? ov1 : ov0;
+      sort_check(osw);
       stage("work_order");
     }
 
 
   f->keys = keys;  f->vals = vals;  f->total = total;
   f->work = work;  f->nwork = nwork;  f->order = order;
-  f->pbits = m.pbits;  f->abits = m.abits;
+  f->pbits = m.pbits;  f->abits = m.abits;  f->dbits = m.dbits;
   f->bytes = G_hits.cap + G_ord.cap;
   return nwork > 0;
 }
@@ -1676,7 +1740,7 @@ static void report_launch(Pending &pd)
       fill_report_args(&ra[j], pd.ablk[j], pd.bblk[j], jb.comp, jb.self, jb.spec, st, j, pd.slot0 + j);
       ra[j].keys = pd.fr[j].keys;  ra[j].vals = pd.fr[j].vals;  ra[j].nhits = pd.fr[j].total;
       ra[j].work = pd.fr[j].work;  ra[j].nwork = pd.fr[j].nwork;
-      ra[j].pbits = pd.fr[j].pbits;  ra[j].abits = pd.fr[j].abits;
+      ra[j].pbits = pd.fr[j].pbits;  ra[j].abits = pd.fr[j].abits;  ra[j].dbits = pd.fr[j].dbits;
       ra[j].order = pd.fr[j].order;
       packed = packed && use_packed(&ra[j], pd.amax, pd.bmax);
       if (ra[j].mscore != ra[0].mscore || ra[j].dscore != ra[0].dscore)
@@ -2099,10 +2163,12 @@ extern "C" int64 damar_last_seeds(void *out, int64 cap)
   int64 n = (int64) G_seed_keys.size();
   for (int64 i = 0; i < n && i < cap; i++)
     { u64 k = G_seed_keys[(size_t) i];
+      const int bpos = (int) (k & ((1ull << G_seed_dbits) - 1));
+      k >>= G_seed_dbits;
       sp[i].apos  = (int) (k & ((1ull << G_seed_pbits) - 1));
       sp[i].aread = (int) ((k >> G_seed_pbits) & ((1ull << G_seed_abits) - 1));
       sp[i].bread = (int) (k >> (G_seed_pbits + G_seed_abits));
-      sp[i].diag  = (int) G_seed_vals[(size_t) i];
+      sp[i].diag  = G_seed_dbits ? sp[i].apos - bpos : (int) G_seed_vals[(size_t) i];
     }
   return n;
 }
@@ -2350,6 +2416,7 @@ static u32 trace_wave_phase(TraceArgs t, int mode, int kind, u32 nwork, u32 rows
     { u32 *k1 = (u32 *) T_key1.need(sizeof(u32) * (size_t) nwork), *v1 = (u32 *) T_val1.need(sizeof(u32) * (size_t) nwork);
       void *sw = T_sortw.need(damar_sort_workspace_bytes(nwork));
       order = damar_radix_sort_u32(d_key, d_val, k1, v1, nwork, 8, sw, G_st) ? v1 : d_val;
+      sort_check(sw);
     }
   const size_t area = damar_trace_slot_area_cells();
   t.vf = (short *) T_vf.need((size_t) nblocks * damar_trace_slot_vf_bytes(mode, kind));
