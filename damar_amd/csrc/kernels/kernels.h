@@ -73,14 +73,17 @@ typedef struct
   int  dbits;                 /* > 0: bpos rides in the key's low dbits (packed seeds, no vals array); 0: diag in vals */
 } MergeArgs;
 
-void damar_launch_merge_count(const MergeArgs *m, u32 *cnt, u32 *jb, hipStream_t st);
-void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32 *cnt, hipStream_t st);
-void damar_launch_merge_hitgram(const MergeArgs *m, const u32 *off, u64 total, u32 ngram, unsigned long long *gram,
-                                hipStream_t st);
-/* cnt = hits per A entry, toff = exclusive offset of each DAMAR_SCAN_TILE-sized tile of cnt */
+typedef struct { u32 b0, b1, ja, ia; } MergeTile;     /* per tile of A entries: its piece of B, the ends of its border runs */
+
+/* The merge is two sweeps over tiles of the A index (seed_merge.hip): COUNT leaves the hits per tile in the workspace
+   (damar_merge_tile_counts; with gram != NULL also hitgram[ct] for ct < ngram, filter.c:1039-1165), the caller scans
+   them in place (damar_scan_tile_counts) and EMIT writes the seed pairs. */
+size_t damar_merge_workspace_bytes(u32 alen);
+u32   *damar_merge_tile_counts(void *work, u32 alen);
+u32    damar_merge_tiles(u32 alen);
+void   damar_launch_merge_count(const MergeArgs *m, void *work, unsigned long long *gram, u32 ngram, hipStream_t st);
 /* pid (optional): the read pair of every seed, bread << abits | aread, for the early cut */
-void damar_launch_merge_emit(const MergeArgs *m, const u32 *cnt, const u32 *toff, const u32 *jb, u64 nhits,
-                             u64 *keys, u32 *vals, u32 *pid, hipStream_t st);
+void damar_launch_merge_emit(const MergeArgs *m, void *work, u64 nhits, u64 *keys, u32 *vals, u32 *pid, hipStream_t st);
 /* the early cut (seed_merge.hip): heads of the runs report_thread enters, on the SORTED pair ids; their pairs into a
    bitmap over the pair ids; the seeds of those pairs out of the unsorted seeds */
 void damar_launch_pair_heads_ids(const u32 *pids, u64 nhits, int abits, int minhit, int nshift,

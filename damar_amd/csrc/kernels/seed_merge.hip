@@ -27,27 +27,6 @@ __device__ __forceinline__ u32 read_of_pos(const DevBlock &b, u32 p)
   return r;
 }
 
-template <typename CodeT>
-__device__ __forceinline__ void code_run(const CodeT *__restrict__ codes, const u32 *__restrict__ table,
-                                         int shift, CodeT c, u32 *lb, u32 *ub)
-{ u32 q = (u32) (c >> shift);
-  u32 lo = table[q], hi = table[q + 1];
-  if (shift == 0)
-    { *lb = lo; *ub = hi; return; }
-  u32 a = lo, b = hi;
-  while (a < b)
-    { u32 m = (a + b) >> 1;
-      if (codes[m] < c) a = m + 1; else b = m;
-    }
-  *lb = a;
-  b = hi;
-  while (a < b)
-    { u32 m = (a + b) >> 1;
-      if (codes[m] <= c) a = m + 1; else b = m;
-    }
-  *ub = a;
-}
-
 /* number of entries of bpos[jb,ib) strictly below `bound` (bpos ascending in a run) */
 __device__ __forceinline__ u32 count_below(const u32 *__restrict__ bpos, u32 jb, u32 ib, u32 bound)
 { u32 a = jb, b = ib;
@@ -58,179 +37,522 @@ __device__ __forceinline__ u32 count_below(const u32 *__restrict__ bpos, u32 jb,
   return a - jb;
 }
 
+/***** the merge of two sorted k-mer indexes ***************************************************************
+ * filter.c:1039-1165 (count_thread) and :1170-1358 (merge_thread) walk the two sorted lists with two pointers.
+ * Here the A index is cut into tiles of MT_A entries; a tile needs exactly the B entries whose codes lie between
+ * its first and its last code, a contiguous piece of the B index found once per tile (merge_tiles).  A workgroup
+ * streams its A codes into registers (8 consecutive entries per thread) and its B piece into LDS; a thread finds
+ * the B run of its first entry by one binary search in LDS and walks on from there -- both lists are sorted, so
+ * the walk advances about one B entry per A entry.  No prefix table, no per-entry search in HBM: the two code
+ * arrays are read once per sweep, front to back.
+ *
+ * Two sweeps per comparison: COUNT (hits per tile; the host needs the total before it sizes the seed arrays)
+ * and, after a scan over the tile totals, EMIT (the same counts again, then the seed pairs).  The caps of
+ * filter.c:1248 / 1335 need whole-run figures -- the length of an A run (cross comparisons) or the hits of a
+ * whole A run (self comparisons): runs are delimited by a max-/min-scan over the tile's head flags, and a run
+ * that crosses a tile border is completed from what merge_tiles found for the border runs. */
+
+#ifndef MT_PER
+#define MT_PER  4                        /* consecutive entries per thread */
+#endif
+#define MT_A    (MT_PER * 256)           /* A entries per tile            */
+#define MT_BCAP (3 * MT_A)               /* B codes staged in LDS per tile (a piece is about as long as the tile) */
+#define MT_HITS 4                        /* seed pairs a thread has in flight in the EMIT loop */
+
+template <typename CodeT>
+__device__ __forceinline__ u32 lower_bound_c(const CodeT *c, u32 lo, u32 hi, CodeT x)      /* first i in [lo,hi): c[i] >= x */
+{ while (lo < hi)
+    { const u32 mid = (lo + hi) >> 1;
+      if (c[mid] < x) lo = mid + 1; else hi = mid;
+    }
+  return lo;
+}
+template <typename CodeT>
+__device__ __forceinline__ u32 upper_bound_c(const CodeT *c, u32 lo, u32 hi, CodeT x)      /* first i in [lo,hi): c[i] > x */
+{ while (lo < hi)
+    { const u32 mid = (lo + hi) >> 1;
+      if (c[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+  return lo;
+}
+
+/* One thread per tile: the piece [b0,b1) of B that holds the codes of the tile, the start ja of the A run its first
+   entry belongs to and the end ia of the A run of its last entry. */
 template <typename CodeT>
 __global__ __launch_bounds__(256)
-void merge_count(MergeArgs m, u32 *__restrict__ cnt, u32 *__restrict__ jbout)
-{ u32 i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= m.alen)
+void merge_tiles(MergeArgs m, u32 ntiles, MergeTile *__restrict__ tiles)
+{ const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= ntiles)
     return;
   const CodeT *acode = (const CodeT *) m.acode, *bcode = (const CodeT *) m.bcode;
-  const CodeT c = acode[i];
-  u32 jb, ib, n = 0;
-  code_run<CodeT>(bcode, m.btab, m.kbits - m.btbits, c, &jb, &ib);
-  if (ib > jb)
-    { if (!m.self)
-        { u32 ja, ia;                                          /* filter.c:1334-1335 */
-          code_run<CodeT>(acode, m.atab, m.kbits - m.atbits, c, &ja, &ia);
-          if ((u64) (ia - ja) * (u64) (ib - jb) < (u64) m.limit)
-            n = ib - jb;
-        }
-      else
-        { u32 p = m.apos[i], bound;                            /* filter.c:1219-1246 */
-          if (m.identity)
-            bound = m.comp ? m.ablk.boff[read_of_pos(m.ablk, p) + 1] : p;
-          else
-            bound = m.ablk.boff[read_of_pos(m.ablk, p)];
-          n = count_below(m.bpos, jb, ib, bound);
+  const u32 a0 = t * (u32) MT_A, a1 = min(m.alen, a0 + (u32) MT_A);
+  const CodeT c0 = acode[a0], c1 = acode[a1 - 1];
+  MergeTile tl;
+  tl.b0 = lower_bound_c<CodeT>(bcode, 0, m.blen, c0);
+  tl.b1 = upper_bound_c<CodeT>(bcode, tl.b0, m.blen, c1);
+  tl.ja = (a0 > 0 && acode[a0 - 1] == c0) ? lower_bound_c<CodeT>(acode, 0, a0, c0) : a0;
+  tl.ia = (a1 < m.alen && acode[a1] == c1) ? upper_bound_c<CodeT>(acode, a1, m.alen, c1) : a1;
+  tiles[t] = tl;
+}
+
+/* hits of A entry i (block offset p of its k-mer) against the B run bpos[jb, jb+nb) in a self comparison:
+   the B entries before `bound` (filter.c:1219-1246) */
+__device__ __forceinline__ u32 self_hits(const MergeArgs &m, u32 p, u32 jb, u32 nb)
+{ u32 bound;
+  if (m.identity)
+    bound = m.comp ? m.ablk.boff[read_of_pos(m.ablk, p) + 1] : p;
+  else
+    bound = m.ablk.boff[read_of_pos(m.ablk, p)];
+  return count_below(m.bpos, jb, jb + nb, bound);
+}
+
+__device__ __forceinline__ u64 block_sum_u64(u64 v, u64 *red)      /* red: 4 words of LDS */
+{ for (int o = 32; o > 0; o >>= 1)
+    { const u32 lo = (u32) __shfl_xor((int) (u32) v, o), hi = (u32) __shfl_xor((int) (u32) (v >> 32), o);
+      v += ((u64) hi << 32) | lo;
+    }
+  __syncthreads();
+  if (lane_id() == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+/* tcount[tile] = hits of the tile, cnt[i] / jbg[i] = hits of A entry i and where its B run starts (and, with gram, the
+   histogram of the runs' mutual counts, filter.c:1039-1165).  INLDS: the tile's B piece fits the LDS stage. */
+template <typename CodeT, bool INLDS>
+__device__ __forceinline__ void merge_sweep_tile(const MergeArgs &m, const MergeTile tl, const u32 tile,
+                                                 u32 *__restrict__ tcount, u32 *__restrict__ cnt, u32 *__restrict__ jbg,
+                                                 unsigned long long *__restrict__ gram, u32 ngram,
+                                                 CodeT *sb, u32 *loc, u32 *sjb, u32 *sw4, u64 *red)
+{ const CodeT *acode = (const CodeT *) m.acode, *bcode = (const CodeT *) m.bcode;
+  const int l = lane_id(), w = threadIdx.x >> 6;
+  const u32 a0 = tile * (u32) MT_A, a1 = min(m.alen, a0 + (u32) MT_A), nat = a1 - a0;
+  const u32 nbt = tl.b1 - tl.b0;
+  const u32 e0 = threadIdx.x * MT_PER;                        /* tile-local index of this thread's first entry */
+  const int nv = (e0 >= nat) ? 0 : (int) min((u32) MT_PER, nat - e0);
+
+  constexpr u32 VPK = 16 / sizeof(CodeT);                     /* codes per 16-byte vector */
+  typedef CodeT VecT __attribute__((ext_vector_type(16 / sizeof(CodeT))));
+  CodeT a[MT_PER];
+  if (nv == MT_PER)                                            /* (a0 + e0 is a multiple of MT_PER: aligned) */
+    {
+#pragma unroll
+      for (int q = 0; q < MT_PER / (int) VPK; q++)
+        { const VecT v = ((const VecT *) (acode + a0 + e0))[q];
+#pragma unroll
+          for (int e = 0; e < (int) VPK; e++)
+            a[q * VPK + e] = v[e];
         }
     }
-  cnt[i]   = n;
-  jbout[i] = jb;
-}
-
-void damar_launch_merge_count(const MergeArgs *m, u32 *cnt, u32 *jb, hipStream_t st)
-{ if (m->alen == 0)
-    return;
-  if (m->wide)
-    hipLaunchKernelGGL(merge_count<u64>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, cnt, jb);
   else
-    hipLaunchKernelGGL(merge_count<u32>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, cnt, jb);
+    {
+#pragma unroll
+      for (int k = 0; k < MT_PER; k++)
+        a[k] = (k < nv) ? acode[a0 + e0 + k] : (CodeT) 0;
+    }
+  /* the tile's piece of B into LDS: 16-byte loads from the aligned address at or below b0, all issued before the first
+     is waited for; sb[sh + j] = B[j] */
+  const u32 b0a = tl.b0 & ~(VPK - 1), sh = tl.b0 - b0a;
+  const CodeT *B;
+  if (INLDS)
+    { const u32 nvec = (tl.b1 - b0a + VPK - 1) / VPK;
+      VecT v[MT_BCAP / (int) VPK / 256 + 1];
+#pragma unroll
+      for (int r = 0; r < MT_BCAP / (int) VPK / 256 + 1; r++)
+        { const u32 x = threadIdx.x + (u32) r * 256;
+          if (x < nvec)
+            { if (b0a + (x + 1) * VPK <= m.blen)
+                v[r] = ((const VecT *) (bcode + b0a))[x];
+              else                                               /* the last vector of the index: no read past its end */
+                {
+#pragma unroll
+                  for (int e = 0; e < (int) VPK; e++)
+                    v[r][e] = (b0a + x * VPK + e < m.blen) ? bcode[b0a + x * VPK + e] : (CodeT) 0;
+                }
+            }
+        }
+#pragma unroll
+      for (int r = 0; r < MT_BCAP / (int) VPK / 256 + 1; r++)
+        { const u32 x = threadIdx.x + (u32) r * 256;
+          if (x < nvec)
+            ((VecT *) sb)[x] = v[r];
+        }
+      B = sb + sh;
+    }
+  else
+    B = bcode + tl.b0;
+  /* the code before this thread's first entry decides whether that entry starts a run */
+  bool head0 = true;
+  { CodeT prev = a[MT_PER - 1];                               /* of the lane below (it holds MT_PER entries whenever this one holds any) */
+    if (sizeof(CodeT) == 8)
+      { const u32 lo = (u32) __shfl_up((int) (u32) prev, 1), hi = (u32) __shfl_up((int) (u32) ((u64) prev >> 32), 1);
+        prev = (CodeT) (((u64) hi << 32) | lo);
+      }
+    else
+      prev = (CodeT) (u32) __shfl_up((int) (u32) prev, 1);
+    if (nv > 0)
+      { if (e0 == 0)
+          head0 = (tl.ja == a0);
+        else
+          { if (l == 0) prev = acode[a0 + e0 - 1];
+            head0 = (prev != a[0]);
+          }
+      }
+  }
+  __syncthreads();
+
+  /* ---- B runs of the thread's entries: one search, then a walk ---- */
+  u32 jb[MT_PER], nb[MT_PER];
+  { u32 p = (nv > 0) ? lower_bound_c<CodeT>(B, 0, nbt, a[0]) : 0;
+#pragma unroll
+    for (int k = 0; k < MT_PER; k++)
+      { jb[k] = 0;  nb[k] = 0;
+        if (k < nv)
+          { const CodeT c = a[k];
+            if (k > 0 && c == a[k - 1])
+              { jb[k] = jb[k - 1];  nb[k] = nb[k - 1]; }
+            else
+              { int steps = 0;
+                while (p < nbt && B[p] < c)
+                  { p += 1;
+                    if (++steps == 4) { p = lower_bound_c<CodeT>(B, p, nbt, c);  break; }
+                  }
+                u32 q = p;
+                steps = 0;
+                while (q < nbt && B[q] == c)
+                  { q += 1;
+                    if (++steps == 4) { q = upper_bound_c<CodeT>(B, q, nbt, c);  break; }
+                  }
+                jb[k] = p;  nb[k] = q - p;
+                p = q;
+              }
+          }
+      }
+  }
+
+  /* ---- A runs: rs = start of the entry's run, re = its end, as tile-local indices (rs 0 with no head at or
+          before the entry: the run began in an earlier tile; re nat with no head after it: it may go on) ---- */
+  u32 hbits = 0;                                              /* head flags of the thread's entries */
+#pragma unroll
+  for (int k = 0; k < MT_PER; k++)
+    { const bool h = (k >= nv) ? true : (k == 0 ? head0 : a[k] != a[k - 1]);
+      hbits |= (u32) h << k;
+    }
+  u32 rs[MT_PER], re[MT_PER];
+  bool rs_open[MT_PER];                                       /* no head at or before the entry inside the tile */
+  { /* forward: latest head at or before the entry (1-based, 0 = none) */
+    u32 tmax = 0;
+#pragma unroll
+    for (int k = 0; k < MT_PER; k++)
+      if ((hbits >> k) & 1) tmax = e0 + k + 1;
+    u32 x = tmax;
+    for (int o = 1; o < 64; o <<= 1)
+      { const u32 t = (u32) __shfl_up((int) x, o);
+        if (l >= o) x = max(x, t);
+      }
+    if (l == 63) sw4[w] = x;
+    u32 carry = (u32) __shfl_up((int) x, 1);
+    if (l == 0) carry = 0;
+    __syncthreads();
+    for (int i = 0; i < 4; i++)
+      if (i < w) carry = max(carry, sw4[i]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MT_PER; k++)
+      { if ((hbits >> k) & 1) carry = e0 + k + 1;
+        rs_open[k] = (carry == 0);
+        rs[k] = carry ? carry - 1 : 0;
+      }
+    /* backward: first head after the entry (none: nat) */
+    const u32 NONE = 0xffffffffu;
+    u32 tmin = NONE;
+#pragma unroll
+    for (int k = MT_PER - 1; k >= 0; k--)
+      if ((hbits >> k) & 1) tmin = e0 + k;
+    x = tmin;
+    for (int o = 1; o < 64; o <<= 1)
+      { const u32 t = (u32) __shfl_down((int) x, o);
+        if (l + o < 64) x = min(x, t);
+      }
+    if (l == 0) sw4[w] = x;
+    u32 cb = (u32) __shfl_down((int) x, 1);
+    if (l == 63) cb = NONE;
+    __syncthreads();
+    for (int i = 0; i < 4; i++)
+      if (i > w) cb = min(cb, sw4[i]);
+    __syncthreads();
+#pragma unroll
+    for (int k = MT_PER - 1; k >= 0; k--)
+      { re[k] = (cb == NONE || cb > nat) ? nat : cb;
+        if ((hbits >> k) & 1) cb = e0 + k;
+      }
+  }
+
+  /* ---- hits per entry ---- */
+  u32 n[MT_PER];
+#pragma unroll
+  for (int k = 0; k < MT_PER; k++)
+    { n[k] = 0;
+      if (k < nv && nb[k] > 0)
+        { if (!m.self)
+            { const u32 ja = rs_open[k] ? tl.ja : a0 + rs[k];
+              const u32 ia = (re[k] >= nat) ? tl.ia : a0 + re[k];                 /* filter.c:1334-1335 */
+              if ((u64) (ia - ja) * (u64) nb[k] < (u64) m.limit)
+                n[k] = nb[k];
+            }
+          else
+            n[k] = self_hits(m, m.apos[a0 + e0 + k], tl.b0 + jb[k], nb[k]);
+        }
+    }
+
+  /* prefix of the hits inside the tile: loc[i] = hits of the entries before i */
+  u64 T64;
+  for (int round = 0; ; round++)
+    { u32 s = 0;
+      u64 s64 = 0;
+#pragma unroll
+      for (int k = 0; k < MT_PER; k++)
+        { s += n[k];  s64 += n[k]; }
+      u32 inc = (u32) wave_incl_scan_i((int) s);
+      if (l == 63) sw4[w] = inc;
+      __syncthreads();
+      u32 ex = inc - s;
+      for (int i = 0; i < 4; i++)
+        if (i < w) ex += sw4[i];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < MT_PER; k++)
+        { loc[e0 + k] = ex;
+          ex += n[k];
+        }
+      if (threadIdx.x == 255)
+        loc[MT_A] = ex;
+      T64 = block_sum_u64(s64, red);                          /* (its barriers also publish loc) */
+      if (!m.self || round == 1)
+        break;
+      /* self comparison: a run whose hits reach the cap contributes nothing (filter.c:1248).  The run's hits inside
+         the tile come from the prefix; the part of a border run that lies in another tile is counted here again. */
+      u64 xhead = 0, xtail = 0;
+      if (tl.ja < a0)
+        { if (threadIdx.x == 0) { sjb[0] = jb[0];  sjb[1] = nb[0]; }
+          __syncthreads();
+          const u32 j0 = tl.b0 + sjb[0], nn = sjb[1];
+          u64 acc = 0;
+          if (nn > 0)
+            for (u32 i = tl.ja + threadIdx.x; i < a0; i += 256)
+              acc += self_hits(m, m.apos[i], j0, nn);
+          xhead = block_sum_u64(acc, red);
+        }
+      if (tl.ia > a1)
+        { const u32 le = nat - 1;
+          if (threadIdx.x == le / MT_PER)
+            {
+#pragma unroll
+              for (int k = 0; k < MT_PER; k++)
+                if (k == (int) (le % MT_PER)) { sjb[0] = jb[k];  sjb[1] = nb[k]; }
+            }
+          __syncthreads();
+          const u32 j0 = tl.b0 + sjb[0], nn = sjb[1];
+          u64 acc = 0;
+          if (nn > 0)
+            for (u32 i = a1 + threadIdx.x; i < tl.ia; i += 256)
+              acc += self_hits(m, m.apos[i], j0, nn);
+          xtail = block_sum_u64(acc, red);
+        }
+#pragma unroll
+      for (int k = 0; k < MT_PER; k++)
+        if (k < nv && nb[k] > 0)
+          { u64 tot = (u64) (loc[re[k]] - loc[rs[k]]);
+            if (rs_open[k]) tot += xhead;
+            if (re[k] >= nat) tot += xtail;
+            if (gram != NULL && ((hbits >> k) & 1) && tot < (u64) m.limit && tot < (u64) ngram)
+              atomicAdd(&gram[tot], 1ull);                    /* one count per run, by its first entry */
+            if (tot >= (u64) m.limit)
+              n[k] = 0;
+          }
+      __syncthreads();
+    }
+
+  if (!m.self && gram != NULL)
+    {
+#pragma unroll
+      for (int k = 0; k < MT_PER; k++)
+        if (k < nv && nb[k] > 0 && ((hbits >> k) & 1))
+          { const u32 ia = (re[k] >= nat) ? tl.ia : a0 + re[k];
+            const u64 ct = (u64) (ia - (a0 + e0 + k)) * (u64) nb[k];
+            if (ct < (u64) ngram)
+              atomicAdd(&gram[ct], 1ull);
+          }
+    }
+  if (threadIdx.x == 0)
+    tcount[tile] = (T64 > 0xffffffffull) ? 0xffffffffu : (u32) T64;
+  /* what the EMIT pass needs of this sweep: 8 bytes per A entry instead of a second walk */
+  typedef u32 V4 __attribute__((ext_vector_type(4)));
+  if (nv == MT_PER && MT_PER == 4)
+    { V4 vc, vj;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        { vc[k] = n[k];  vj[k] = tl.b0 + jb[k]; }
+      *(V4 *) (cnt + a0 + e0) = vc;
+      *(V4 *) (jbg + a0 + e0) = vj;
+    }
+  else
+    {
+#pragma unroll
+      for (int k = 0; k < MT_PER; k++)
+        if (k < nv)
+          { cnt[a0 + e0 + k] = n[k];
+            jbg[a0 + e0 + k] = tl.b0 + jb[k];
+          }
+    }
 }
 
-/* self mode: a run's mutual count is off[run end] - off[run start]; runs at or over
- * the limit contribute nothing (filter.c:1248 `if (ct < limit)`). */
 template <typename CodeT>
 __global__ __launch_bounds__(256)
-void merge_limit(MergeArgs m, const u32 *__restrict__ off, u64 total, u32 *__restrict__ cnt)
-{ u32 i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= m.alen || cnt[i] == 0)
-    return;
-  u32 ja, ia;
-  const CodeT *acode = (const CodeT *) m.acode;
-  code_run<CodeT>(acode, m.atab, m.kbits - m.atbits, acode[i], &ja, &ia);
-  u64 hi = (ia >= m.alen) ? total : (u64) off[ia];
-  if (hi - (u64) off[ja] >= (u64) m.limit)
-    cnt[i] = 0;
-}
-
-void damar_launch_merge_limit(const MergeArgs *m, const u32 *off, u64 total, u32 *cnt, hipStream_t st)
-{ if (m->alen == 0)
-    return;
-  if (m->wide)
-    hipLaunchKernelGGL(merge_limit<u64>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, cnt);
+void merge_sweep(MergeArgs m, const MergeTile *__restrict__ tiles, u32 *__restrict__ tcount, u32 *__restrict__ cnt,
+                 u32 *__restrict__ jbg, unsigned long long *__restrict__ gram, u32 ngram)
+{ __shared__ __attribute__((aligned(16))) CodeT sb[MT_BCAP + 16 / sizeof(CodeT)];
+  __shared__ u32 loc[MT_A + 1];
+  __shared__ u32 sjb[2];
+  __shared__ u32 sw4[4];
+  __shared__ u64 red[4];
+  const MergeTile tl = tiles[blockIdx.x];
+  if (tl.b1 - tl.b0 <= MT_BCAP)                /* (the stage has room for the alignment slack on top) */
+    merge_sweep_tile<CodeT, true>(m, tl, blockIdx.x, tcount, cnt, jbg, gram, ngram, sb, loc, sjb, sw4, red);
   else
-    hipLaunchKernelGGL(merge_limit<u32>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, cnt);
+    merge_sweep_tile<CodeT, false>(m, tl, blockIdx.x, tcount, cnt, jbg, gram, ngram, sb, loc, sjb, sw4, red);
 }
 
-/* hitgram[ct] = number of equal-code runs whose mutual count is ct (< ngram), filter.c:1039-1165
- * count_thread.  Only launched when the host must lower the cap under memory pressure
- * (filter.c:2634-2699), so plain global atomics will do.  Cross: ct = na * nb; self: the run's
- * count is the sum of its entries' counts = off[run end] - off[run start] of the current scan. */
-template <typename CodeT>
+/* EMIT: one workgroup per tile of A entries; the tile's hit counts are scanned in LDS, then the tile's hits are dealt
+ * out to the threads in order, each finding its A entry by a search of the LDS prefix (no walk over global offsets),
+ * so that the seed pairs leave in fully coalesced runs; MT_HITS independent seed pairs per thread are in flight. */
 __global__ __launch_bounds__(256)
-void merge_hitgram(MergeArgs m, const u32 *__restrict__ off, u64 total, u32 ngram, unsigned long long *__restrict__ gram)
-{ u32 i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= m.alen)
-    return;
-  const CodeT *acode = (const CodeT *) m.acode, *bcode = (const CodeT *) m.bcode;
-  const CodeT c = acode[i];
-  if (i > 0 && acode[i - 1] == c)
-    return;                                     /* one thread per run of A */
-  u32 jb, ib, ja, ia;
-  code_run<CodeT>(bcode, m.btab, m.kbits - m.btbits, c, &jb, &ib);
-  if (ib <= jb)
-    return;
-  code_run<CodeT>(acode, m.atab, m.kbits - m.atbits, c, &ja, &ia);
-  u64 ct;
-  if (!m.self)
-    ct = (u64) (ia - ja) * (u64) (ib - jb);
-  else
-    ct = ((ia >= m.alen) ? total : (u64) off[ia]) - (u64) off[ja];
-  if (ct < (u64) ngram)
-    atomicAdd(&gram[ct], 1ull);
-}
-
-void damar_launch_merge_hitgram(const MergeArgs *m, const u32 *off, u64 total, u32 ngram, unsigned long long *gram,
-                                hipStream_t st)
-{ if (m->alen == 0)
-    return;
-  if (m->wide)
-    hipLaunchKernelGGL(merge_hitgram<u64>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, ngram, gram);
-  else
-    hipLaunchKernelGGL(merge_hitgram<u32>, dim3((m->alen + 255) / 256), dim3(256), 0, st, *m, off, total, ngram, gram);
-}
-
-/* One workgroup per tile of DAMAR_SCAN_TILE A entries: the tile's hit counts are scanned in
- * LDS, then the tile's hits are dealt out to the threads in order, each finding its A entry by
- * a search of the LDS prefix (no walk over the global offsets), so the seed pairs leave in
- * fully coalesced runs. */
-#define ME_ITEMS (DAMAR_SCAN_TILE / 256)
-__global__ __launch_bounds__(256)
-void merge_emit(MergeArgs m, const u32 *__restrict__ cnt, const u32 *__restrict__ toff,
-                const u32 *__restrict__ jb, u64 nhits, u64 *__restrict__ keys, u32 *__restrict__ vals,
-                u32 *__restrict__ pid)
-{ __shared__ u32 loc[DAMAR_SCAN_TILE + 1];
-  __shared__ u32 wsum[4];
-  const u32 a0 = blockIdx.x * (u32) DAMAR_SCAN_TILE;
+void merge_emit(MergeArgs m, const u32 *__restrict__ cnt, const u32 *__restrict__ jbg, const u32 *__restrict__ toff,
+                u64 nhits, u64 *__restrict__ keys, u32 *__restrict__ vals, u32 *__restrict__ pid)
+{ __shared__ u32 loc[MT_A + 1];
+  __shared__ u32 sjb[MT_A];
+  __shared__ u32 sw4[4];
   const int l = lane_id(), w = threadIdx.x >> 6;
-  /* thread t owns entries [t*ME_ITEMS, (t+1)*ME_ITEMS) of the tile */
-  u32 v[ME_ITEMS], s = 0;
-  for (int i = 0; i < ME_ITEMS; i++)
-    { const u32 a = a0 + threadIdx.x * ME_ITEMS + i;
-      v[i] = (a < m.alen) ? cnt[a] : 0;
-      s += v[i];
+  const u32 tile = blockIdx.x;
+  const u32 a0 = tile * (u32) MT_A, a1 = min(m.alen, a0 + (u32) MT_A), nat = a1 - a0;
+  const u32 e0 = threadIdx.x * MT_PER;
+  const u64 h0 = toff[tile];
+  const u64 hn = (tile + 1 < gridDim.x) ? (u64) toff[tile + 1] : nhits;
+  if (hn == h0)                                               /* nothing to emit here */
+    return;
+  u32 n[MT_PER], s = 0;
+#pragma unroll
+  for (int k = 0; k < MT_PER; k++)
+    { const bool ok = e0 + k < nat;
+      n[k] = ok ? cnt[a0 + e0 + k] : 0;
+      sjb[e0 + k] = ok ? jbg[a0 + e0 + k] : 0;
+      s += n[k];
     }
   u32 inc = (u32) wave_incl_scan_i((int) s);
-  if (l == 63) wsum[w] = inc;
+  if (l == 63) sw4[w] = inc;
   __syncthreads();
-  u32 base = 0, T = 0;
+  u32 ex = inc - s;
   for (int i = 0; i < 4; i++)
-    { const u32 x = wsum[i];
-      if (i < w) base += x;
-      T += x;
-    }
-  u32 ex = base + inc - s;
-  for (int i = 0; i < ME_ITEMS; i++)
-    { loc[threadIdx.x * ME_ITEMS + i] = ex;
-      ex += v[i];
+    if (i < w) ex += sw4[i];
+#pragma unroll
+  for (int k = 0; k < MT_PER; k++)
+    { loc[e0 + k] = ex;
+      ex += n[k];
     }
   if (threadIdx.x == 255)
-    loc[DAMAR_SCAN_TILE] = T;
+    loc[MT_A] = ex;
   __syncthreads();
-  const u64 h0 = toff[blockIdx.x];
-  for (u32 t = threadIdx.x; t < T; t += 256)
-    { /* last entry whose first hit is <= t */
-      u32 a = 0, b = DAMAR_SCAN_TILE;
-      while (b - a > 1)
-        { const u32 mid = (a + b) >> 1;
-          if (loc[mid] <= t) a = mid; else b = mid;
+  const u32 T = loc[MT_A];
+  for (u32 t0 = threadIdx.x; t0 < T; t0 += 256 * MT_HITS)
+    { u32 ai[MT_HITS], bi[MT_HITS], pa[MT_HITS], pb[MT_HITS];
+#pragma unroll
+      for (int x = 0; x < MT_HITS; x++)                       /* (the MT_HITS chains are independent: their latencies overlap) */
+        { const u32 t = t0 + (u32) x * 256;
+          u32 lo = 0, hi = MT_A;                              /* last entry whose first hit is <= t */
+          if (t < T)
+            while (hi - lo > 1)
+              { const u32 mid = (lo + hi) >> 1;
+                if (loc[mid] <= t) lo = mid; else hi = mid;
+              }
+          ai[x] = a0 + lo;
+          bi[x] = (t < T) ? sjb[lo] + (t - loc[lo]) : 0;
         }
-      const u32 ai = a0 + a;
-      const u32 bi = jb[ai] + (t - loc[a]);
-      const u32 pa = m.apos[ai], pb = m.bpos[bi];
-      const u32 ra = read_of_pos(m.ablk, pa), rb = read_of_pos(m.bblk, pb);
-      const u32 xa = pa - m.ablk.boff[ra], xb = pb - m.bblk.boff[rb];
-      const u64 h = h0 + t;
-      if (h < nhits)
-        { const u64 key = ((u64) rb << (m.abits + m.pbits)) | ((u64) ra << m.pbits) | (u64) xa;
-          if (m.dbits)
-            keys[h] = (key << m.dbits) | (u64) xb;
-          else
-            { keys[h] = key;
-              vals[h] = (u32) ((int) xa - (int) xb);
+#pragma unroll
+      for (int x = 0; x < MT_HITS; x++)
+        { const bool ok = t0 + (u32) x * 256 < T;
+          pa[x] = ok ? m.apos[ai[x]] : 0;
+          pb[x] = ok ? m.bpos[bi[x]] : 0;
+        }
+      u32 ra[MT_HITS], rb[MT_HITS];
+#pragma unroll
+      for (int x = 0; x < MT_HITS; x++)
+        { ra[x] = m.ablk.coarse[pa[x] >> COARSE_SHIFT];
+          rb[x] = m.bblk.coarse[pb[x] >> COARSE_SHIFT];
+        }
+#pragma unroll
+      for (int x = 0; x < MT_HITS; x++)
+        { while (m.ablk.boff[ra[x] + 1] <= pa[x]) ra[x] += 1;
+          while (m.bblk.boff[rb[x] + 1] <= pb[x]) rb[x] += 1;
+        }
+#pragma unroll
+      for (int x = 0; x < MT_HITS; x++)
+        { const u32 t = t0 + (u32) x * 256;
+          const u64 h = h0 + t;
+          if (t < T && h < nhits)
+            { const u32 xa = pa[x] - m.ablk.boff[ra[x]], xb = pb[x] - m.bblk.boff[rb[x]];
+              const u64 key = ((u64) rb[x] << (m.abits + m.pbits)) | ((u64) ra[x] << m.pbits) | (u64) xa;
+              if (m.dbits)
+                keys[h] = (key << m.dbits) | (u64) xb;
+              else
+                { keys[h] = key;
+                  vals[h] = (u32) ((int) xa - (int) xb);
+                }
+              if (pid != NULL)                 /* the read pair alone, for the early cut (damar_launch_pair_cut) */
+                pid[h] = (rb[x] << m.abits) | ra[x];
             }
-          if (pid != NULL)                     /* the read pair alone, for the early cut (damar_launch_pair_cut) */
-            pid[h] = (rb << m.abits) | ra;
         }
     }
 }
 
-void damar_launch_merge_emit(const MergeArgs *m, const u32 *cnt, const u32 *toff, const u32 *jb, u64 nhits,
-                             u64 *keys, u32 *vals, u32 *pid, hipStream_t st)
+/* workspace: tile descriptors | tile counts (scanned in place by the caller) | cnt[alen] | jb[alen] */
+static size_t mw_tiles(u32 alen)  { return ((size_t) alen + MT_A - 1) / MT_A; }
+static size_t mw_off_counts(u32 alen) { return (mw_tiles(alen) * sizeof(MergeTile) + 255) & ~(size_t) 255; }
+static size_t mw_off_cnt(u32 alen)    { return mw_off_counts(alen) + (((mw_tiles(alen) + 1) * sizeof(u32) + 255) & ~(size_t) 255); }
+static size_t mw_off_jb(u32 alen)     { return mw_off_cnt(alen) + (((size_t) alen * sizeof(u32) + 255) & ~(size_t) 255); }
+
+size_t damar_merge_workspace_bytes(u32 alen)
+{ return mw_off_jb(alen) + (((size_t) alen * sizeof(u32) + 255) & ~(size_t) 255); }
+
+u32 *damar_merge_tile_counts(void *work, u32 alen) { return (u32 *) ((char *) work + mw_off_counts(alen)); }
+
+u32 damar_merge_tiles(u32 alen) { return (u32) mw_tiles(alen); }
+
+/* COUNT sweep: hits per tile and per A entry into the workspace; with gram != NULL also the histogram of mutual counts */
+void damar_launch_merge_count(const MergeArgs *m, void *work, unsigned long long *gram, u32 ngram, hipStream_t st)
+{ if (m->alen == 0)
+    return;
+  const u32 ntiles = (u32) mw_tiles(m->alen);
+  MergeTile *tiles = (MergeTile *) work;
+  u32 *tcount = damar_merge_tile_counts(work, m->alen);
+  u32 *cnt = (u32 *) ((char *) work + mw_off_cnt(m->alen)), *jb = (u32 *) ((char *) work + mw_off_jb(m->alen));
+  if (m->wide)
+    { hipLaunchKernelGGL(merge_tiles<u64>, dim3((ntiles + 255) / 256), dim3(256), 0, st, *m, ntiles, tiles);
+      hipLaunchKernelGGL(merge_sweep<u64>, dim3(ntiles), dim3(256), 0, st, *m, tiles, tcount, cnt, jb, gram, ngram);
+    }
+  else
+    { hipLaunchKernelGGL(merge_tiles<u32>, dim3((ntiles + 255) / 256), dim3(256), 0, st, *m, ntiles, tiles);
+      hipLaunchKernelGGL(merge_sweep<u32>, dim3(ntiles), dim3(256), 0, st, *m, tiles, tcount, cnt, jb, gram, ngram);
+    }
+}
+
+/* EMIT, after the tile counts have been scanned in place */
+void damar_launch_merge_emit(const MergeArgs *m, void *work, u64 nhits, u64 *keys, u32 *vals, u32 *pid, hipStream_t st)
 { if (nhits == 0)
     return;
-  const u32 ntiles = (m->alen + DAMAR_SCAN_TILE - 1) / DAMAR_SCAN_TILE;
-  hipLaunchKernelGGL(merge_emit, dim3(ntiles), dim3(256), 0, st, *m, cnt, toff, jb, nhits, keys, vals, pid);
+  const u32 ntiles = (u32) mw_tiles(m->alen);
+  const u32 *toff = damar_merge_tile_counts(work, m->alen);
+  const u32 *cnt = (const u32 *) ((char *) work + mw_off_cnt(m->alen)), *jb = (const u32 *) ((char *) work + mw_off_jb(m->alen));
+  hipLaunchKernelGGL(merge_emit, dim3(ntiles), dim3(256), 0, st, *m, cnt, jb, toff, nhits, keys, vals, pid);
 }
 
 /* flags[i] = 1 iff hit i starts a (bread,aread) run that report_thread would enter:

@@ -478,6 +478,19 @@ static void sort_check(const void *sw)
   HIP_CHECK(hipMemcpyAsync(&H_serr[H_nserr++], damar_sort_error_word(sw), sizeof(u32), hipMemcpyDeviceToHost, G_st));
 }
 
+/* Tile shape of the radix sort (radix_sort.hip): workgroups of 512 threads are the faster shape on an empty machine; beside
+   a resident report launch (which leaves 128 registers per SIMD) only one wavefront per SIMD finds room, i.e. the
+   256-thread shape.  DAMAR_SORT_THREADS overrides. */
+static bool overlap_on(void);
+static void pick_sort_shape(void)
+{ static int forced = -1;
+  if (forced < 0)
+    { const char *e = getenv("DAMAR_SORT_THREADS");
+      forced = e ? atoi(e) : 0;
+    }
+  damar_sort_set_threads(forced ? forced : (overlap_on() ? 256 : 512));
+}
+
 static int ilog2_ceil(u64 n)
 { int b = 0;
   while ((1ull << b) < n)
@@ -493,6 +506,7 @@ extern "C" void damar_bias_reset(void) { B_have = 0; }
 
 static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *len, int K, int suppress, int use_bias)
 { ensure_init();
+  pick_sort_shape();
   if (K > 32)
     { fprintf(stderr, "damar: FATAL: -k%d: a k-mer code holds at most 32 bases\n", K);
       die();
@@ -1353,6 +1367,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
   const int self = job->self, comp = job->comp;
   Arena &G_hits = G_hitsJ[slot], &G_ord = G_ordJ[slot];
   int64 nhits = 0;
+  pick_sort_shape();
   memset(f, 0, sizeof(*f));
   job->counts[0] = job->counts[1] = job->counts[2] = 0;
   if (aidx == NULL || bidx == NULL || aidx->n == 0 || bidx->n == 0)
@@ -1391,34 +1406,25 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
     m.dbits = (pack_on && m.pbits + m.abits + bbits + db <= 64) ? db : 0;
   }
 
-  /* ---- merge: count, scan, (limit), emit ---- */
-  size_t need = 3 * pad256(sizeof(u32) * (size_t) alen) + pad256(damar_scan_workspace_bytes(alen)) + 4096;
-  arena_reserve(&G_work, need);       /* grown again below once nhits is known */
-  u32 *cnt = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) alen);
-  u32 *off = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) alen);
-  u32 *jb  = (u32 *) arena_take(&G_work, sizeof(u32) * (size_t) alen);
-  void *scw = arena_take(&G_work, damar_scan_workspace_bytes(alen));
-  u64 *tot = (u64 *) arena_take(&G_work, 64);
-  u64  total = 0;
+  /* ---- merge: COUNT sweep, scan of the tile totals, (lower cap and COUNT again), EMIT sweep ---- */
+  const u32 mtiles = damar_merge_tiles(alen);
+  void *mw;
+  u32  *tcount;
+  u64  *tot;
+  u64   total = 0;
 
   tick(0);
-  damar_launch_merge_count(&m, cnt, jb, G_st);
+  arena_reserve(&G_work, pad256(damar_merge_workspace_bytes(alen)) + pad256(damar_scan_workspace_bytes(mtiles)) + 4096);
+  mw = arena_take(&G_work, damar_merge_workspace_bytes(alen));
+  tcount = damar_merge_tile_counts(mw, alen);
+  tot = (u64 *) arena_take(&G_work, 64);
+  void *mscw = arena_take(&G_work, damar_scan_workspace_bytes(mtiles));
+  damar_launch_merge_count(&m, mw, NULL, 0, G_st);
   stage("merge_count");
-  /* the emit kernel rebuilds the offsets inside a tile of counts itself: only the tile offsets
-     are needed, except by the self-mode limit pass, which looks at whole runs */
-  if (self)
-    damar_exclusive_scan_u32(cnt, off, alen, scw, tot, G_st);
-  else
-    damar_tile_offsets_u32(cnt, alen, scw, tot, G_st);
+  damar_exclusive_scan_u32(tcount, tcount, mtiles, mscw, tot, G_st);
   stage("merge_scan");
   HIP_CHECK(hipMemcpyAsync(&total, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
   HIP_CHECK(hipStreamSynchronize(G_st));
-  if (self && total > 0)
-    { damar_launch_merge_limit(&m, off, total, cnt, G_st);
-      damar_tile_offsets_u32(cnt, alen, scw, tot, G_st);
-      HIP_CHECK(hipMemcpyAsync(&total, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
-      HIP_CHECK(hipStreamSynchronize(G_st));
-    }
   if (MEM_LIMIT > 0)
     { /* filter.c:2634-2699.  The counts above keep every run below MAXGRAM; the reference lowers
          that cap to the first mutual count at which the kept seeds no longer fit `avail`.  That
@@ -1434,9 +1440,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
         { std::vector<unsigned long long> histo(MAXGRAM);
           unsigned long long *dgram = (unsigned long long *) dmalloc(sizeof(unsigned long long) * MAXGRAM);
           HIP_CHECK(hipMemsetAsync(dgram, 0, sizeof(unsigned long long) * MAXGRAM, G_st));
-          if (self)                   /* run totals of the counts as they stand (runs >= MAXGRAM already dropped) */
-            damar_exclusive_scan_u32(cnt, off, alen, scw, tot, G_st);
-          damar_launch_merge_hitgram(&m, off, total, MAXGRAM, dgram, G_st);
+          damar_launch_merge_count(&m, mw, dgram, MAXGRAM, G_st);          /* the same sweep, with the run histogram */
           HIP_CHECK(hipMemcpyAsync(histo.data(), dgram, sizeof(unsigned long long) * MAXGRAM, hipMemcpyDeviceToHost, G_st));
           HIP_CHECK(hipStreamSynchronize(G_st));
           HIP_CHECK(hipFree(dgram));
@@ -1469,13 +1473,10 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
                 }
               fflush(stderr);
             }
-          /* recount with the lower cap */
+          /* count again with the lower cap */
           m.limit = (u32) limit;
-          if (self)
-            damar_launch_merge_limit(&m, off, total, cnt, G_st);
-          else
-            damar_launch_merge_count(&m, cnt, jb, G_st);
-          damar_tile_offsets_u32(cnt, alen, scw, tot, G_st);
+          damar_launch_merge_count(&m, mw, NULL, 0, G_st);
+          damar_exclusive_scan_u32(tcount, tcount, mtiles, mscw, tot, G_st);
           HIP_CHECK(hipMemcpyAsync(&total, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
           HIP_CHECK(hipStreamSynchronize(G_st));
         }
@@ -1537,7 +1538,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       scw2  = arena_take(&G_tmp, damar_scan_workspace_bytes(total));
       sends = (u64 *) arena_take(&G_tmp, 64 * sizeof(u64));
 
-      damar_launch_merge_emit(&m, cnt, (const u32 *) scw, jb, total, k0, v0, NULL, G_st);
+      damar_launch_merge_emit(&m, mw, total, k0, v0, NULL, G_st);
       stage("merge_emit");
       tick(1);
       int side = m.dbits ? damar_radix_sort_keys_u64(k0, k1, total, m.dbits, m.dbits + sbits, sw, G_st)
@@ -1571,7 +1572,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       u32 *bitmap = (u32 *) arena_take(&G_tmp, sizeof(u32) * bmwords);
       u64 *snd  = (u64 *) arena_take(&G_tmp, 64 * sizeof(u64));
 
-      damar_launch_merge_emit(&m, cnt, (const u32 *) scw, jb, total, uk, uv, pid0, G_st);
+      damar_launch_merge_emit(&m, mw, total, uk, uv, pid0, G_st);
       stage("merge_emit");
       tick(1);
       const u32 *spid = damar_radix_sort_keys_u32(pid0, pid1, total, idbits, sw, G_st) ? pid1 : pid0;
