@@ -74,6 +74,67 @@ def md5_file(path):
     return h.hexdigest()
 
 
+def kernel_src_sha16():
+    """sha256 (16 hex digits) over the sources the device code is built from: ties a counters file under profiles/ to the
+    kernels it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "damar_amd", "csrc")
+    names = sorted(os.listdir(os.path.join(d, "kernels")))
+    for f in [os.path.join(d, "kernels", n) for n in names if n.endswith((".hip", ".h"))] + [os.path.join(d, "shim.hip")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_counters():
+    """(counters of the newest profiles/rNN_counters.json, stale?): the PMC-derived fields of `roofline` cannot be measured
+    inside this process (rocprofv3 --pmc passes, scripts/gpu_profile_round.sh); they are carried from the file only while its
+    `kernel_src_sha16` equals the sha of the kernel sources of THIS tree, else they are reported as null with pmc_stale."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")):
+        m = re.match(r"r(\d+)_counters\.json$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return {}, True
+    try:
+        pmc = json.load(open(best[1]))
+    except Exception:
+        return {}, True
+    pmc["file"] = os.path.relpath(best[1], ROOT)
+    return pmc, pmc.get("kernel_src_sha16") != kernel_src_sha16()
+
+
+def sort_bytes_of(x):
+    n, p = 0, 1
+    while p < x:
+        p <<= 8
+        n += 1
+    return n
+
+
+def pipeline_bytes(kmers, bases, maxlen, nreads, pairs, builds, seeds, aligned_bp, trace_vals, k=14):
+    """SURVEY 8(d) algorithmic bytes of one pass over a plan (16-byte records, 8-bit digits, one read + one write per pass),
+    for the work actually done: `builds` index builds of blocks with kmers[i] k-mers and bases[i] bases, the block pairs
+    `pairs` (each: two comparisons, forward and complement), `seeds` seed pairs in all, the records written.
+      index build   1 B/base + 16 B x (1 + 2 P_k) per k-mer, P_k = ceil(2k/8)
+      merge         16 (K_a + K_b) x 2 (count + emit) + 16 H         seed sort   16 H x 2 P_s
+      filter        16 H                                              align       2 L_aln + 2 T"""
+    nb = len(kmers)
+    pk = (2 * k + 7) // 8
+    per_build = sum(bases[i] + 16. * kmers[i] * (1 + 2 * pk) for i in range(nb)) / max(nb, 1)
+    idx = per_build * builds
+    merge = sum(2 * 32. * (kmers[a] + kmers[b]) for a, b in pairs) + 16. * seeds
+    ps = sort_bytes_of(max(maxlen)) + 2 * sort_bytes_of(max(nreads))       # filter.c:2561-2580
+    ssort = 16. * seeds * 2 * ps
+    filt = 16. * seeds
+    align = 2. * aligned_bp + 2. * trace_vals
+    return {"index_build": idx, "merge": merge, "seed_sort": ssort, "filter": filt, "align": align,
+            "total": idx + merge + ssort + filt + align, "seed_sort_passes": ps}
+
+
 def check_against_reference(out_dir, md5_name):
     """{files, identical, missing}: every .las of out_dir against the reference's md5 fixture."""
     path = os.path.join(ROOT, "tests", "golden", md5_name)
@@ -81,6 +142,8 @@ def check_against_reference(out_dir, md5_name):
         return None
     bad, n = [], 0
     for ln in open(path):
+        if ln.startswith("#"):
+            continue
         m, rel = ln.split()
         n += 1
         f = os.path.join(out_dir, rel)
@@ -118,16 +181,20 @@ def sum_las(out_dir):
 
 def cpu_baseline(dbdir, root, nblocks, aligned_bp):
     """The reference daligner (oracle/_ref, compiled from /root/reference in the build container) over the
-    WHOLE plan on this host's cores, -j16 (more threads overflow its alloca, filter.c:767): the plan lines
-    one after the other as a cluster job script would run them on one node, and all lines at once."""
+    WHOLE plan on this host's cores: the plan lines one after the other as a cluster job script would run them on one
+    node (-j16), and all lines at once with -j16 and with -j32 (filter.c:767 allocas NTHREADS^2 x 2 KB: 2 MB at -j32 still fits
+    the default stack, -j64 does not); the best of the three is the baseline."""
     cores = host_cores()
     ref = os.path.join(ROOT, "oracle", "_ref", "daligner")
-    kind, nthr, exe = "reference", pow2_floor(min(cores, 16)), ref
+    kind, exe = "reference", ref
+    runs = [("sequential", pow2_floor(min(cores, 16))), ("concurrent", pow2_floor(min(cores, 16)))]
+    if cores >= 32 * nblocks:
+        runs.append(("concurrent", 32))
     if not os.path.exists(ref):
-        kind, nthr, exe = "port", 1, os.path.join(ROOT, "oracle", "oracle_daligner")
+        kind, exe, runs = "port", os.path.join(ROOT, "oracle", "oracle_daligner"), [("concurrent", 1)]
     lines = [["%s.%d" % (root, a)] + ["%s.%d" % (root, b) for b in range(a, 0, -1)] for a in range(1, nblocks + 1)]
     res = {}
-    for mode in (("concurrent",) if kind == "port" else ("sequential", "concurrent")):
+    for mode, nthr in runs:
         work = tempfile.mkdtemp(prefix="damar_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         try:
             link_db(dbdir, root, work)
@@ -139,15 +206,17 @@ def cpu_baseline(dbdir, root, nblocks, aligned_bp):
                 ps = [subprocess.Popen([exe, "-k14", "-j%d" % nthr] + ln, cwd=work, stdout=subprocess.DEVNULL) for ln in lines]
                 if any(p.wait() != 0 for p in ps):
                     raise RuntimeError("reference daligner failed")
-            res[mode] = time.time() - t0
+            res["%s -j%d" % (mode, nthr)] = time.time() - t0
         finally:
             shutil.rmtree(work, ignore_errors=True)
-    best = min(res.values())
-    used = nthr * (len(lines) if res.get("concurrent") == best else 1)
+    bestk = min(res, key=res.get)
+    best = res[bestk]
+    nthr = int(bestk.split("-j")[1])
+    used = nthr * (len(lines) if bestk.startswith("concurrent") else 1)
     return {"value": aligned_bp / best, "unit": "aligned bp/s", "cores": min(used, cores), "kind": kind,
-            "sample": "the whole plan of the step (%d lines, %d block pairs, every .las), daligner -k14 -j%d: %s; host has %d cores"
-                      % (len(lines), nblocks * (nblocks + 1) // 2, nthr,
-                         ", ".join("%s lines %.1f s" % (m, s) for m, s in sorted(res.items())), cores),
+            "sample": "the whole plan of the step (%d lines, %d block pairs, every .las), daligner -k14: %s; best: %s; host has %d cores"
+                      % (len(lines), nblocks * (nblocks + 1) // 2,
+                         ", ".join("%s lines %.1f s" % (m, s) for m, s in sorted(res.items())), bestk, cores),
             "wall_s": res}
 
 
@@ -219,6 +288,137 @@ def trace_expand_leg(dbdir, root, out_dir, with_cpu):
     return best
 
 
+def plan_leg(api, driver, multi, L, base, title, sim_kw, j, md5_name, md5_tag=None, cpu_line=None):
+    """One extra single-GPU measurement over a whole HPCdaligner plan (not part of `value`): database from its seed, blocks
+    to HBM (untimed), one warm-up pass and one timed pass of every block pair through the same queue and runner as the
+    headline, the md5 fixtures of the reference checked on the files they name, the pipeline's algorithmic bytes against
+    the HBM peak, and (cpu_line) the reference daligner timed on ONE plan line of the same database."""
+    work = tempfile.mkdtemp(prefix="damar_leg_", dir=base)
+    try:
+        t0 = time.time()
+        nb = api.sim_write_db(work, "SIM", **sim_kw)
+        t_gen = time.time() - t0
+        dbprefix = os.path.join(work, "SIM")
+        blocks = {}
+        for i in range(1, nb + 1):
+            b = driver.Block("%s.%d" % (dbprefix, i))
+            b.upload()
+            b.upload_complement()
+            blocks[b.name] = b
+        units = multi.work_units(nb, 1)
+
+        def one(tag):
+            out = os.path.join(work, "out_%s" % tag)
+            runner = multi.GpuRunner(dict(j=j), resident=blocks)
+            multi.run_queue(dbprefix, units, out, multi.LocalQueue(len(units)), runner)
+            runner.finish()
+            return out, runner.plan
+        out, _ = one("w")
+        shutil.rmtree(out, ignore_errors=True)
+        L.damar_hip_sync()
+        t0 = time.time()
+        out, plan = one("s")
+        L.damar_hip_sync()
+        wall = time.time() - t0
+        nrec, bp, tv = sum_las(out)
+        want = {}
+        for ln in open(os.path.join(ROOT, "tests", "golden", md5_name)):
+            if ln.startswith("#"):
+                continue
+            f = ln.split()
+            if md5_tag is None:
+                want[f[1]] = f[0]
+            elif f[1] == md5_tag:
+                want[f[4]] = f[0]
+        bad = [rel for rel, m in sorted(want.items()) if not os.path.exists(os.path.join(out, rel)) or md5_file(os.path.join(out, rel)) != m]
+        order = sorted(blocks.values(), key=lambda b: b.db.part)
+        kmers = [b.db.totlen - 14 * b.db.nreads for b in order]
+        pairs = [(a, b) for a in range(nb) for b in range(a + 1)]
+        pb = pipeline_bytes(kmers, [b.db.totlen for b in order], [b.db.maxlen for b in order], [b.db.nreads for b in order],
+                            pairs, plan.index_builds, plan.counts[0], bp, tv)
+        res = {"workload": title, "blocks": nb, "block_pairs": len(pairs), "comparisons": plan.matches,
+               "index_builds": plan.index_builds, "wall_s": wall, "ms_per_block_pair": 1e3 * wall / len(pairs),
+               "records": nrec, "aligned_bp": bp, "value": bp / wall, "unit": "aligned bp/s",
+               "seed_pairs": plan.counts[0], "local_alignments": plan.counts[1],
+               "phase_ms": {k: round(v, 1) for k, v in sorted(plan.timings.items())},
+               "parity": {"files": len(want), "identical": not bad, "differing": bad[:5],
+                          "against": "md5 of the reference daligner's files (tests/golden/%s%s)" % (md5_name, ", sample '%s'" % md5_tag if md5_tag else "")},
+               "pipeline": {"algorithmic_bytes": pb["total"], "achieved": pb["total"] / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": pb["total"] / wall / 1e9 / HBM_PEAK_GBS,
+                            "stages_bytes": {k: v for k, v in pb.items() if k not in ("total", "seed_sort_passes")}},
+               "db_generation_s": t_gen}
+        ref = os.path.join(ROOT, "oracle", "_ref", "daligner")
+        if cpu_line and os.path.exists(ref):
+            cw = tempfile.mkdtemp(prefix="damar_legcpu_", dir=base)
+            try:
+                link_db(work, "SIM", cw)
+                nthr = pow2_floor(min(host_cores(), 16))
+                t0 = time.time()
+                subprocess.run([ref, "-k14", "-j%d" % nthr] + ["SIM.%d" % x for x in cpu_line], cwd=cw, check=True, stdout=subprocess.DEVNULL)
+                dt = time.time() - t0
+                npl = len(cpu_line) - 1
+                res["cpu"] = {"kind": "reference", "cores": nthr, "wall_s": dt, "ms_per_block_pair": 1e3 * dt / npl,
+                              "sample": "daligner -k14 -j%d %s (%d block pair(s) of this plan, one process as the reference runs "
+                                        "a plan line)" % (nthr, " ".join("SIM.%d" % x for x in cpu_line), npl)}
+            finally:
+                shutil.rmtree(cw, ignore_errors=True)
+        for b in blocks.values():
+            b.close()
+        return res
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def datander_leg(api, driver, L, base, tandem_frac):
+    """BASELINE config 5: datander (scrub/tandem.c) on block 1 of the config-2 database with tandem arrays implanted into a
+    fraction of the reads (plain simulator reads hold no tandem seeds), through the in-process driver, md5 against the
+    reference's file, next to the reference datander on the host."""
+    work = tempfile.mkdtemp(prefix="damar_tan_", dir=base)
+    try:
+        api.sim_write_db(work, "SIM", 27., coverage=20., seed=2, block_mbp=135, tandem_frac=tandem_frac)
+        want = {}
+        for ln in open(os.path.join(ROOT, "tests", "golden", "config5_ref_md5.txt")):
+            if not ln.startswith("#"):
+                m, tag, blk, novl = ln.split()
+                if tag == ("tandem" if tandem_frac else "plain"):
+                    want[int(blk)] = (m, int(novl))
+        b = driver.Block(os.path.join(work, "SIM.1"))
+        b.upload()
+        best = None
+        for _ in range(2):                       # (the first call sizes the scratch)
+            shutil.rmtree(os.path.join(work, "tan"), ignore_errors=True)
+            L.damar_hip_sync()
+            t0 = time.time()
+            driver.run_datander(b, work, j=8)
+            L.damar_hip_sync()
+            dt = time.time() - t0
+            best = dt if best is None else min(best, dt)
+        las = os.path.join(work, "tan", "SIM.1.SIM.1.las")
+        n, bp = driver.las_stats(las)
+        res = {"workload": "config 5: datander -k12 -w4 -h35 -e.70 -l500 on block 1 (135 Mbp) of the config-2 database, tandem arrays "
+                           "implanted into %.0f %% of the reads" % (100 * tandem_frac),
+               "records": n, "aligned_bp": bp, "wall_s": best, "value": bp / best, "unit": "aligned bp/s",
+               "what": "block resident in HBM; index build, self-matching, band filter + waves, host tail, tan/*.las on tmpfs",
+               "identical_to_reference": (1 in want and md5_file(las) == want[1][0])}
+        b.close()
+        ref = os.path.join(ROOT, "oracle", "_ref", "datander")
+        if os.path.exists(ref):
+            cw = tempfile.mkdtemp(prefix="damar_tancpu_", dir=base)
+            try:
+                link_db(work, "SIM", cw)
+                nthr = pow2_floor(min(host_cores(), 16))
+                t0 = time.time()
+                subprocess.run([ref, "-j%d" % nthr, "SIM.1"], cwd=cw, check=True, stdout=subprocess.DEVNULL)
+                dt = time.time() - t0
+                res["cpu"] = {"kind": "reference", "cores": nthr, "wall_s": dt, "value": bp / dt,
+                              "sample": "datander -j%d SIM.1 (process start and DB read included)" % nthr}
+            finally:
+                shutil.rmtree(cw, ignore_errors=True)
+        return res
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +429,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-trace", action="store_true", help="skip the trace-expansion leg (SURVEY 8(f)4)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end leg")
+    ap.add_argument("--no-legs", action="store_true", help="skip the config-4 (lead 24 blocks), config-3 and config-5 legs")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
@@ -380,49 +581,57 @@ def main():
             parity = check_against_reference(last_out, cfg["md5"])
             nmatch = float(nmatch) / steps                   # comparisons (block pair x orientation) per step, all ranks
             nlaunch = float(nlaunch) / steps                 # launches of the report kernel they took
-            kern = {"report_kernel (band filter + Local_Alignment waves)": tim.get("report", 0.),
-                    "radix sort of seed pairs (hist+scan+scatter, u64 keys)": tim.get("ssort", 0.),
-                    "radix sort of the k-mer index (hist+scan+scatter, u32 keys)": tim.get("ksort", 0.),
-                    "seed merge (count+scan+emit)": tim.get("merge", 0.)}
+            kern = {"report2_kernel": tim.get("report", 0.),
+                    "onesweep_pass<u64> (seed-pair radix sort)": tim.get("ssort", 0.),
+                    "onesweep_pass<u64> (k-mer index radix sort)": tim.get("ksort", 0.),
+                    "merge_sweep + merge_emit": tim.get("merge", 0.)}
+            what = {"report2_kernel": "band filter + Local_Alignment waves, two read pairs per wavefront (kernels/report_packed.h)"}
             dom = max(kern, key=kern.get)
             H = cnts[0] / steps                      # seed pairs per step
             nsplit = max(n for _, _, _, n in units)
             ngroup = max(len(b) if isinstance(b, tuple) else 1 for _, b, _, _ in units)
+            order = sorted(blocks.values(), key=lambda b: b.db.part)
+            kmers_b = [b.db.totlen - 14 * b.db.nreads for b in order]
+            pb = pipeline_bytes(kmers_b, [b.db.totlen for b in order], [b.db.maxlen for b in order], [b.db.nreads for b in order],
+                                [(a, b) for a in range(nblocks) for b in range(a + 1)], builds / steps, H, bp, trace_vals)
             if dom.startswith("report"):
                 # filter 16 B/seed + align 2 B per aligned bp + 2 B per trace value
-                alg = 16. * H + 2. * bp + 2. * trace_vals
+                alg = pb["filter"] + pb["align"]
                 nl = nlaunch
-            elif dom.startswith("radix sort of seed"):
-                alg = 16. * H * 2 * 6                # 16-byte records, read+write, P_s = 6 passes
+            elif "seed-pair" in dom:
+                alg = pb["seed_sort"]
                 nl = nmatch
-            elif dom.startswith("radix sort of the k-mer"):
-                kmers = totbp - 14 * nreads
-                alg = (16. * 2 * 4) * kmers / nblocks * builds / steps   # per build: 16 B x (rd+wr) x 4 passes per k-mer
+            elif "k-mer" in dom:
+                alg = pb["index_build"]
                 nl = builds / steps
             else:
-                kmers = totbp - 14 * nreads
-                alg = 32. * 2 * kmers / nblocks * nmatch + 16. * H
+                alg = pb["merge"]
                 nl = nmatch
             dom_ms = kern[dom] / steps               # summed over ranks: the kernel's total device time per step
             ach = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.
-            # Counter-derived figures cannot be read from inside this process: they come from the separate
-            # rocprofv3 --pmc passes over this very command (scripts/gpu_profile_round.sh), committed under
-            # profiles/ per round and carried here
-            pmc = {}
-            for name in ("r02_counters.json", "r01_traffic.json"):
-                try:
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-                    break
-                except Exception:
-                    continue
-            traffic = pmc.get("bytes_per_launch") if dom.startswith(pmc.get("kernel", "\0")) else None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            # Counter-derived figures cannot be read from inside this process: they come from the separate rocprofv3 --pmc passes
+            # over this very command (scripts/gpu_profile_round.sh), committed under profiles/ per round and carried here
+            # ONLY while that file's kernel_src_sha16 matches the kernel sources of this tree
+            pmc, stale = load_counters()
+            mine = (not stale) and dom.startswith(pmc.get("kernel_symbol", "\0"))
+
+            def carried(key):
+                return pmc.get(key) if mine else None
+            step_s = elapsed / steps
+            roof = {"bound": "hbm", "kernel": dom, "kernel_what": what.get(dom), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": carried("bytes_per_launch"),
                     "launches_per_step": nl, "avg_launch_ms": dom_ms / nl if nl else 0.,
                     "algorithmic_bytes_per_step": alg,
-                    "valu_frac": pmc.get("valu_frac"), "salu_frac": pmc.get("salu_frac"),
-                    "valu_busy_weighted": pmc.get("valu_busy_weighted"),
-                    "active_lane_frac": pmc.get("active_lane_frac"), "pmc_source": pmc.get("source"),
+                    "valu_frac": carried("valu_frac"), "salu_frac": carried("salu_frac"),
+                    "valu_busy_weighted": carried("valu_busy_weighted"),
+                    "active_lane_frac": carried("active_lane_frac"),
+                    "pmc_source": pmc.get("source") if mine else None, "pmc_file": pmc.get("file"), "pmc_head": pmc.get("head"),
+                    "pmc_stale": not mine, "kernel_src_sha16": kernel_src_sha16(),
+                    "pipeline": {"what": "SURVEY 8(d) algorithmic bytes of ALL stages of a step (index builds actually done, merge, seed "
+                                         "sort, filter, align) / wall time of the step",
+                                 "algorithmic_bytes_per_step": pb["total"], "achieved": pb["total"] / step_s / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": pb["total"] / step_s / 1e9 / HBM_PEAK_GBS,
+                                 "stages_bytes": {k: v for k, v in pb.items() if k not in ("total", "seed_sort_passes")}},
                     "note": "integer/branchy wave kernel: its limit is instruction issue and dependent latency, not HBM "
                             "(valu_frac / salu_frac = share of the calibrated issue peaks of the cheapest instructions, valu_busy_weighted "
                             "= vector-pipe time with every instruction kind at its measured cost, profiles/); phase ms per step "
@@ -443,6 +652,29 @@ def main():
                     trace = trace_expand_leg(work, "SIM", last_out, not args.no_cpu)
                 except Exception as e:
                     trace = {"error": str(e)}
+            legs = None
+            if world == 1 and not args.no_legs:
+                for b in blocks.values():            # give the headline's blocks back before the other databases come
+                    b.close()
+                blocks.clear()
+                legs = {}
+                for key, fn in (
+                        ("config4_lead", lambda: plan_leg(
+                            api, driver, multi, L, base,
+                            "config 4, first 24 of its 255 blocks: simulator 248 -c80 -m15000 -s3000 -e.15 -r4, DBsplit -s78; the whole "
+                            "HPCdaligner plan of those blocks (300 block pairs x 2 orientations), daligner -k14 -j8",
+                            dict(genome_mbp=248., coverage=80., seed=4, rmean=15000, rsdev=3000, block_mbp=78, max_blocks=24), 8,
+                            "config4_ref_md5.txt", "lead", cpu_line=None if args.no_cpu else (24, 2))),
+                        ("config3", lambda: plan_leg(
+                            api, driver, multi, L, base,
+                            "config 3: simulator 4.6 -c87 -e.15 -r3, DBsplit -s25 -> 17 blocks, 153 block pairs x 2 orientations, "
+                            "daligner -k14 -j16", dict(genome_mbp=4.6, coverage=87., seed=3, block_mbp=25), 16,
+                            "config3_ref_md5.txt", None, cpu_line=None if args.no_cpu else (17, 17, 16, 15, 14))),
+                        ("config5_datander", lambda: datander_leg(api, driver, L, base, .3))):
+                    try:
+                        legs[key] = fn()
+                    except Exception as e:       # a leg is reported, never required
+                        legs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             line = {"metric": "aligned base-pairs/sec (daligner block-vs-block)",
                     "value": value, "unit": "aligned bp/s", "n_gpus": world, "steps": args.steps,
                     "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
@@ -465,7 +697,7 @@ def main():
                                                  "seed stages" % ngroup, int(units_max)),
                                "db_generation_s": t_gen},
                     "parity": parity,
-                    "roofline": roof, "cpu_baseline": cpu, "end_to_end": e2e, "trace_expand": trace}
+                    "roofline": roof, "cpu_baseline": cpu, "end_to_end": e2e, "trace_expand": trace, "legs": legs}
             if one_gpu is not None:
                 line["one_gpu_same_workload"] = {"ms_per_step": 1e3 * one_gpu, "value": bp / one_gpu,
                                                  "speedup_of_this_run": (bp * args.steps / elapsed) / (bp / one_gpu)}

@@ -49,9 +49,7 @@ void damar_launch_mask_flags(const DevBlock *blk, int kmer, const u32 *pos, u32 
 /* -b: keep[] (cleared by the caller, blk->total entries) marks the block offsets where a k-mer ends */
 void damar_launch_biased_tuples(const DevBlock *blk, int kmer, const int *logbase, void *codes, int wide, u32 *pos,
                                 u32 *keep, hipStream_t st);
-void damar_launch_code_table(const void *codes, int wide, u32 n, int kbits, int tbits, u32 *table, hipStream_t st);
-void damar_launch_suppress_flags(const void *codes, int wide, u32 n, const u32 *table, int kbits, int tbits, int suppress,
-                                 u32 *keep, hipStream_t st);
+void damar_launch_suppress_flags(const void *codes, int wide, u32 n, int suppress, u32 *keep, hipStream_t st);
 void damar_launch_compact_pairs(const void *k, int wide, const u32 *v, const u32 *keep, const u32 *off, u32 n,
                                 void *ko, u32 *vo, hipStream_t st);
 
@@ -62,10 +60,10 @@ void damar_launch_tandem_links(const DevBlock *blk, int kmer, const void *codes,
 
 /* seed_merge.hip */
 typedef struct
-{ const void *acode;  const u32 *apos;  u32 alen;  const u32 *atab;      /* codes: u32, or u64 when wide */
-  const void *bcode;  const u32 *bpos;  u32 blen;  const u32 *btab;
+{ const void *acode;  const u32 *apos;  u32 alen;                         /* codes: u32, or u64 when wide */
+  const void *bcode;  const u32 *bpos;  u32 blen;
   int  wide;
-  int  kbits, atbits, btbits;
+  int  kbits;
   int  self, comp, identity;
   u32  limit;
   DevBlock ablk, bblk;
@@ -147,8 +145,8 @@ typedef struct
   u16  *tpool;     u32 tpool_cap;
   const u32 *order; /* processing order of the work items (largest first), or NULL          */
   u32  *counters;  /* [1] records, [2] trace words, [3] error flags, [6] [7] where a wave gave up; shared by the jobs of a launch */
-  u32  *cursor;    /* next work item of THIS job (counters + 16 + job) */
-  u32  *nfilt;     /* seed hits of THIS job      (counters + 32 + job) */
+  u32  *cursor;    /* next work item of THIS job (counters + DAMAR_CNT_CURSOR + job) */
+  u32  *nfilt;     /* seed hits of THIS job      (counters + DAMAR_CNT_NFILT + job)  */
   int   job;       /* index of this job in the launch: rides in the top byte of LaRecord.seq */
 } ReportArgs;
 
@@ -156,8 +154,10 @@ typedef struct
    wave-uniform reads of a job's fields are scalar loads).  Every wavefront starts with job (block index mod njobs) and
    moves on to the next when a job's queue is empty, so the long alignments of ALL jobs start at once and the tail of
    the launch (waiting for the longest alignment) is paid once per launch, not once per comparison. */
-#define DAMAR_MAX_JOBS 16
-#define DAMAR_COUNTER_WORDS 64
+#define DAMAR_MAX_JOBS 32
+#define DAMAR_CNT_CURSOR  16      /* counters[16 + job]: next work item of a job  */
+#define DAMAR_CNT_NFILT   (DAMAR_CNT_CURSOR + DAMAR_MAX_JOBS)      /* counters[.. + job]: its seed hits */
+#define DAMAR_COUNTER_WORDS (DAMAR_CNT_NFILT + DAMAR_MAX_JOBS)
 #define DAMAR_SEQ_BITS 24
 
 #define DAMAR_ERR_CELLS   1u

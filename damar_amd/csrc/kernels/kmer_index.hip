@@ -8,9 +8,8 @@
  * pos[i] (u32 offset of the k-mer's LAST base in the block's base array).  The
  * reference's (read, rpos) pair is recoverable from pos through the block's read
  * offsets, and because reads are laid out in order, sorting stably by code leaves
- * entries in the reference's (code, read, rpos) order.  A prefix table
- * table[q] = first index with (code >> (kbits-tbits)) >= q turns "find the run of
- * code c" into one table look-up plus a few steps inside a tiny bucket.
+ * entries in the reference's (code, read, rpos) order.  The merge (seed_merge.hip) streams two such
+ * indexes against each other; there is no look-up structure beside the two sorted arrays.
  */
 #include "dev_common.h"
 #include "kernels.h"
@@ -39,10 +38,22 @@ void kmer_tuples(DevBlock blk, int kmer, u32 nkmers, CodeT *__restrict__ codes, 
   const u32 i = p - (r + 1) * (u32) kmer + 1;
   if (i >= nkmers)
     return;
-  const u8 *s = blk.bases + (p - (u32) (kmer - 1));
   CodeT c = 0;
-  for (int j = 0; j < kmer; j++)
-    c = (CodeT) (c << 2) | (CodeT) s[j];
+  if (PACK)
+    { /* k <= 16: the k-mer out of the 2-bit copy of the block (two adjacent words, base 16w in the low bits of word w)
+         instead of k byte loads; the code wants the FIRST base in its high bits, so the window is reversed pair-wise */
+      const u32 f = p - (u32) (kmer - 1), wq = f >> 4, o = (f & 15) << 1;
+      u64 win = ((u64) blk.pk[wq + 1] << 32) | (u64) blk.pk[wq];
+      win >>= o;
+      u64 r = __brevll(win);                                           /* base j now sits at bits 62-2j, its two bits swapped */
+      r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+      c = (CodeT) (r >> (64 - 2 * kmer));
+    }
+  else
+    { const u8 *s = blk.bases + (p - (u32) (kmer - 1));
+      for (int j = 0; j < kmer; j++)
+        c = (CodeT) (c << 2) | (CodeT) s[j];
+    }
   if (PACK)
     codes[i] = (CodeT) ((u64) c << 32) | (CodeT) p;
   else
@@ -165,72 +176,51 @@ void damar_launch_biased_tuples(const DevBlock *blk, int kmer, const int *logbas
                        logbase[0], logbase[1], logbase[2], logbase[3], (u32 *) codes, pos, keep);
 }
 
-/* table[q] for q in [0, 2^tbits]: written by the element that starts each prefix
- * change (it also fills the prefixes that do not occur at all). */
+/* -t (filter.c:700-751, 890-939): keep[i] = 1 iff the run of equal codes around sorted entry i is shorter than
+ * `suppress`.  Runs are short, so each entry gallops to the ends of its own run (doubling steps, then a binary search
+ * over the last stride) instead of consulting an index-wide table. */
 template <typename CodeT>
 __global__ __launch_bounds__(256)
-void code_table(const CodeT *__restrict__ codes, u32 n, int shift, u32 nq, u32 *__restrict__ table)
-{ u32 i = blockIdx.x * 256u + threadIdx.x;
-  if (i > n)
-    return;
-  u32 q1 = (i == n) ? nq : (u32) (codes[i] >> shift);      /* i == n: virtual end marker */
-  u32 q0 = (i == 0) ? 0u : (u32) (codes[i - 1] >> shift) + 1;
-  for (u32 q = q0; q <= q1 && q <= nq; q++)
-    table[q] = i;
-}
-
-void damar_launch_code_table(const void *codes, int wide, u32 n, int kbits, int tbits, u32 *table, hipStream_t st)
-{ u32 nq = 1u << tbits;
-  if (wide)
-    hipLaunchKernelGGL(code_table<u64>, dim3((n + 1 + 255) / 256), dim3(256), 0, st, (const u64 *) codes, n, kbits - tbits, nq, table);
-  else
-    hipLaunchKernelGGL(code_table<u32>, dim3((n + 1 + 255) / 256), dim3(256), 0, st, (const u32 *) codes, n, kbits - tbits, nq, table);
-}
-
-/* run [lb, ub) of code c in a sorted code array, through its prefix table */
-template <typename CodeT>
-__device__ __forceinline__ void code_run(const CodeT *__restrict__ codes, const u32 *__restrict__ table,
-                                         int shift, CodeT c, u32 *lb, u32 *ub)
-{ u32 q = (u32) (c >> shift);
-  u32 lo = table[q], hi = table[q + 1];
-  if (shift == 0)
-    { *lb = lo; *ub = hi; return; }
-  u32 a = lo, b = hi;
-  while (a < b)
-    { u32 m = (a + b) >> 1;
-      if (codes[m] < c) a = m + 1; else b = m;
-    }
-  *lb = a;
-  b = hi;
-  while (a < b)
-    { u32 m = (a + b) >> 1;
-      if (codes[m] <= c) a = m + 1; else b = m;
-    }
-  *ub = a;
-}
-
-template <typename CodeT>
-__global__ __launch_bounds__(256)
-void suppress_flags(const CodeT *__restrict__ codes, u32 n, const u32 *__restrict__ table, int shift,
-                    u32 suppress, u32 *__restrict__ keep)
-{ u32 i = blockIdx.x * 256u + threadIdx.x;
+void suppress_flags(const CodeT *__restrict__ codes, u32 n, u32 suppress, u32 *__restrict__ keep)
+{ const u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n)
     return;
-  u32 lb, ub;
-  code_run(codes, table, shift, codes[i], &lb, &ub);
-  keep[i] = (ub - lb < suppress) ? 1u : 0u;
+  const CodeT c = codes[i];
+  u32 lo = i, step = 1;                               /* codes[lo] == c throughout */
+  while (lo >= step && codes[lo - step] == c)
+    { lo -= step;
+      step <<= 1;
+    }
+  { u32 a = (lo >= step) ? lo - step + 1 : 0, b = lo;  /* first index of the run lies in [a, b] */
+    while (a < b)
+      { const u32 mid = (a + b) >> 1;
+        if (codes[mid] == c) b = mid; else a = mid + 1;
+      }
+    lo = a;
+  }
+  u32 hi = i;
+  step = 1;
+  while (hi + step < n && codes[hi + step] == c)
+    { hi += step;
+      step <<= 1;
+    }
+  { u32 a = hi, b = (hi + step < n) ? hi + step - 1 : n - 1;      /* last index of the run lies in [a, b] */
+    while (a < b)
+      { const u32 mid = (a + b + 1) >> 1;
+        if (codes[mid] == c) a = mid; else b = mid - 1;
+      }
+    hi = a;
+  }
+  keep[i] = (hi - lo + 1 < suppress) ? 1u : 0u;
 }
 
-void damar_launch_suppress_flags(const void *codes, int wide, u32 n, const u32 *table, int kbits, int tbits, int suppress,
-                                 u32 *keep, hipStream_t st)
+void damar_launch_suppress_flags(const void *codes, int wide, u32 n, int suppress, u32 *keep, hipStream_t st)
 { if (n == 0)
     return;
   if (wide)
-    hipLaunchKernelGGL(suppress_flags<u64>, dim3((n + 255) / 256), dim3(256), 0, st, (const u64 *) codes, n, table, kbits - tbits,
-                       (u32) suppress, keep);
+    hipLaunchKernelGGL(suppress_flags<u64>, dim3((n + 255) / 256), dim3(256), 0, st, (const u64 *) codes, n, (u32) suppress, keep);
   else
-    hipLaunchKernelGGL(suppress_flags<u32>, dim3((n + 255) / 256), dim3(256), 0, st, (const u32 *) codes, n, table, kbits - tbits,
-                       (u32) suppress, keep);
+    hipLaunchKernelGGL(suppress_flags<u32>, dim3((n + 255) / 256), dim3(256), 0, st, (const u32 *) codes, n, (u32) suppress, keep);
 }
 
 template <typename CodeT>

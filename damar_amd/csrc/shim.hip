@@ -92,6 +92,21 @@ static double       H_ms[8];              /* host wall clock per phase (DAMAR_HO
 static const char  *H_name[8] = { "index_build", "match:front", "match:order", "match:report", "match:d2h",
                                   "match:submit", "match:total", "final_drain" };
 static double now_ms(void);
+
+/* The filter parameters and option globals a comparison was set up under (filter.h:54-62).  A report launch may be made --
+   or made again after an overflow -- during a LATER call, after the caller has moved on to other options: launches and
+   host tails use this snapshot, taken when the comparison's seed stage ran, never the globals of the moment. */
+struct JobParams
+{ int kmer, hitmin, binshift, symmetric, minover, hgap_min; };
+
+static JobParams params_now(void)
+{ JobParams p;
+  p.kmer = P_kmer;  p.hitmin = P_hitmin;  p.binshift = P_binshift;
+  p.symmetric = SYMMETRIC;  p.minover = MINOVER;  p.hgap_min = HGAP_MIN;
+  return p;
+}
+
+
 static int64        G_cnt[8];
 
 struct Arena { char *base; size_t cap, top; };
@@ -115,7 +130,7 @@ static void *dmalloc(size_t n)
   return p;
 }
 
-/* The k-mer index arrays (8 B per k-mer plus a table of up to 1 GB) come and go with every index:
+/* The k-mer index arrays (8 B per k-mer) come and go with every index:
  * hipMalloc / hipFree of such sizes costs tens of milliseconds each and synchronises the device,
  * so released buffers are parked here and handed out again (best fit within 25 % slack).  The
  * pool is bounded; what does not fit is really freed. */
@@ -245,10 +260,11 @@ static void ensure_init(void)
 }
 
 static void finish_pending(void);
+static void finish_all(void);
 
 extern "C" void damar_hip_sync(void)
 { ensure_init();
-  finish_pending();
+  finish_all();
   HIP_CHECK(hipDeviceSynchronize());
 }
 
@@ -433,7 +449,7 @@ static void finish_pending(void);
 extern "C" void damar_block_free(damar_dev_block *b)
 { if (b == NULL)
     return;
-  finish_pending();                            /* a report launch in flight may still read the bases */
+  finish_all();                                /* a report launch in flight (or held back) may still read the bases */
   HIP_CHECK(hipStreamSynchronize(G_st));
   HIP_CHECK(hipFree(b->bases_alloc));
   HIP_CHECK(hipFree(b->pk_alloc));
@@ -447,13 +463,13 @@ extern "C" void damar_block_free(damar_dev_block *b)
 /***** index **************************************************************************************/
 
 struct damar_dev_index
-{ size_t codes_bytes, pos_bytes, table_bytes;      /* what the pool gave (dpool_get) */
+{ size_t codes_bytes, pos_bytes;                   /* what the pool gave (dpool_get) */
   damar_dev_block *blk;
   int   own_block;
   void *codes;                 /* u32 per k-mer, u64 when wide (k > 16) */
-  u32  *pos, *table;
+  u32  *pos;
   u32   n;
-  int   kbits, tbits, wide;
+  int   kbits, wide;
 };
 
 /* The radix sort's look-back is bounded; a timeout (never seen) raises a device word.  sort_check queues its copy
@@ -627,22 +643,9 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
   sort_check(sw);
   tick(2);
   u32 n = nk;
-  /* Prefix table resolution: one entry per code when that is affordable (2^28 entries = 1 GB for
-     k = 14; HBM is sized for it), so that a code's run is two adjacent table entries and no
-     dependent search at all -- the merge kernels are bound by the length of that chain. */
-  { static int tmax = -1;
-    if (tmax < 0)
-      { const char *e = getenv("DAMAR_TBITS");
-        tmax = e ? atoi(e) : 28;
-      }
-    ix->tbits = std::min(kbits, std::max(8, std::min(tmax, ilog2_ceil(nk) + 1)));
-  }
-  ix->table = (u32 *) dpool_get(sizeof(u32) * (((size_t) 1 << ix->tbits) + 2), &ix->table_bytes);
-  damar_launch_code_table(ix->codes, wide, n, kbits, ix->tbits, ix->table, G_st);
-
   if (suppress > 0)                         /* filter.c:890-939 */
     { u64  kept = 0;
-      damar_launch_suppress_flags(ix->codes, wide, n, ix->table, kbits, ix->tbits, suppress, keep, G_st);
+      damar_launch_suppress_flags(ix->codes, wide, n, suppress, keep, G_st);
       damar_exclusive_scan_u32(keep, off, n, scw, tot, G_st);
       damar_launch_compact_pairs(ix->codes, wide, ix->pos, keep, off, n, tk, tv, G_st);
       HIP_CHECK(hipMemcpyAsync(&kept, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
@@ -650,8 +653,6 @@ static damar_dev_index *index_build_k(damar_dev_block *blk, int own_block, int *
       n = (u32) kept;
       HIP_CHECK(hipMemcpyAsync(ix->codes, tk, cs * (size_t) n, hipMemcpyDeviceToDevice, G_st));
       HIP_CHECK(hipMemcpyAsync(ix->pos, tv, sizeof(u32) * (size_t) n, hipMemcpyDeviceToDevice, G_st));
-      if (n > 0)
-        damar_launch_code_table(ix->codes, wide, n, kbits, ix->tbits, ix->table, G_st);
     }
   tick(3);
   HIP_CHECK(hipStreamSynchronize(G_st));
@@ -687,7 +688,6 @@ extern "C" void damar_index_free(damar_dev_index *ix)
   dpool_put(ix->codes, ix->codes_bytes);       /* (the stream was synchronised above: nothing reads them any more) */
   if (ix->pos_bytes)                           /* (k <= 16: the positions live in the codes' buffer) */
     dpool_put(ix->pos, ix->pos_bytes);
-  dpool_put(ix->table, ix->table_bytes);
   if (ix->own_block)
     damar_block_free(ix->blk);
   free(ix);
@@ -695,7 +695,7 @@ extern "C" void damar_index_free(damar_dev_index *ix)
 
 /* HBM held by one index (what its three buffers took from the pool): lets a scheduler bound residency */
 extern "C" uint64_t damar_index_bytes(const damar_dev_index *ix)
-{ return ix == NULL ? 0 : (uint64_t) (ix->codes_bytes + ix->pos_bytes + ix->table_bytes); }
+{ return ix == NULL ? 0 : (uint64_t) (ix->codes_bytes + ix->pos_bytes); }
 
 extern "C" void damar_index_download(const damar_dev_index *ix, void *out)
 { struct KP { uint64 code; int rpos; int read; } *kp = (KP *) out;
@@ -883,14 +883,14 @@ static void scratch_outputs(u32 rec_cap, u32 tpool_cap)
 }
 
 static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const damar_dev_block *bb,
-                             int comp, int self, Align_Spec *spec, hipStream_t st, int job = 0, int tslot = 0)
+                             int comp, int self, Align_Spec *spec, hipStream_t st, int job, int tslot, const JobParams &jp)
 { memset(ra, 0, sizeof(*ra));
   ra->job = job;
   ra->ablk = ab->d;  ra->bblk = bb->d;
-  ra->kmer = P_kmer;  ra->hitmin = P_hitmin;  ra->binshift = P_binshift;
-  ra->minhit = (P_hitmin - 1) / P_kmer + 1;
-  ra->comp = comp;  ra->self = self;  ra->symmetric = SYMMETRIC;
-  ra->minover = MINOVER;  ra->hgap_min = HGAP_MIN;
+  ra->kmer = jp.kmer;  ra->hitmin = jp.hitmin;  ra->binshift = jp.binshift;
+  ra->minhit = (jp.hitmin - 1) / jp.kmer + 1;
+  ra->comp = comp;  ra->self = self;  ra->symmetric = jp.symmetric;
+  ra->minover = jp.minover;  ra->hgap_min = jp.hgap_min;
   ra->tspace = Trace_Spacing(spec);
   ra->ave_path = damar_spec_ave_path(spec);
   ra->reach = Overlap_If_Possible(spec);
@@ -914,8 +914,8 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   ra->recs = RS.recs;  ra->rec_cap = RS.rec_cap;
   ra->tpool = RS.tpool;  ra->tpool_cap = RS.tpool_cap;
   ra->counters = RS.counters;
-  ra->cursor = RS.counters + 16 + job;
-  ra->nfilt  = RS.counters + 32 + job;
+  ra->cursor = RS.counters + DAMAR_CNT_CURSOR + job;
+  ra->nfilt  = RS.counters + DAMAR_CNT_NFILT + job;
 }
 
 
@@ -1002,7 +1002,7 @@ static void hostbuf_put(HostBuf *h)
  * per pair, results appended to obuf. */
 static int64 tail_range(const LaRecord *recs, const u32 *ord, size_t lo, size_t hi, const u16 *tpool,
                         const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, int ts,
-                        Overlap_IO_Buffer *obuf)
+                        Overlap_IO_Buffer *obuf, int symmetric, int hgap_min)
 { int64 ncheck = 0;
   std::vector<damar_path> am, bm;
   damar_tpool tp = { NULL, 0, 0 };
@@ -1014,8 +1014,8 @@ static int64 tail_range(const LaRecord *recs, const u32 *ord, size_t lo, size_t 
         j += 1;
       const int ar = recs[ord[i]].aread, br = recs[ord[i]].bread;
       const int al = ablock->reads[ar].rlen, bl = bblock->reads[br].rlen;
-      const int doA = (al >= HGAP_MIN);
-      const int doB = (SYMMETRIC && bl >= HGAP_MIN && (ar != br || !self || !comp));   /* filter.c:2300-2301 */
+      const int doA = (al >= hgap_min);
+      const int doB = (symmetric && bl >= hgap_min && (ar != br || !self || !comp));   /* filter.c:2300-2301 */
       am.clear();  bm.clear();  tp.top = 0;
       for (size_t q = i; q < j; q++)
         { const LaRecord &r = recs[ord[q]];
@@ -1063,7 +1063,7 @@ static int tail_threads(void)
 
 static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
                       const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec,
-                      int jobid = 0, int njobs = 1)
+                      const JobParams &jp, int jobid = 0, int njobs = 1)
 { const int ts = Trace_Spacing(spec);
   /* a launch over several comparisons: the records of this one (top byte of seq) */
   std::vector<u32> mine;
@@ -1105,7 +1105,7 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
     }
   const int nthr = (nrecs >= tmin) ? tail_threads() : 1;
   if (nthr == 1)
-    return tail_range(recs, ord.data(), 0, nrecs, tpool, ablock, bblock, self, comp, ts, obuf);
+    return tail_range(recs, ord.data(), 0, nrecs, tpool, ablock, bblock, self, comp, ts, obuf, jp.symmetric, jp.hgap_min);
 
   /* Read pairs are independent: cut the ordered records into nthr ranges at pair boundaries,
      let each thread fill a private buffer, append the buffers in order. */
@@ -1125,7 +1125,7 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
       if (part[t] == NULL)
         die();
       th.emplace_back([&, t] { got[t] = tail_range(recs, ord.data(), cut[t], cut[t + 1], tpool, ablock, bblock,
-                                                    self, comp, ts, part[t]); });
+                                                    self, comp, ts, part[t], jp.symmetric, jp.hgap_min); });
     }
   int64 ncheck = 0;
   for (int t = 0; t < nthr; t++)
@@ -1155,6 +1155,7 @@ struct TailJob
   HITS_DB ablock, bblock;                    /* copies of the block records: the caller may reuse its structs
                                                 (the read tables and bases they point to must stay alive) */
   int  self, comp;
+  JobParams jp;                              /* the options the comparison ran under */
   Align_Spec *spec;
   std::string d1, d2, a, b;
   bool has1, has2;
@@ -1229,7 +1230,7 @@ static void tail_worker(void)
               t0 = now_ms();
             }
           int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, &job->ablock, &job->bblock,
-                             job->self, job->comp, job->spec, job->jobid, job->njobs);
+                             job->self, job->comp, job->spec, job->jp, job->jobid, job->njobs);
           if (--job->hb->users == 0)
             hostbuf_put(job->hb);
           delete job;
@@ -1270,7 +1271,7 @@ static void async_submit(TailJob *job)
 extern "C" void damar_async_drain(void)
 { if (!A_on)
     return;
-  finish_pending();
+  finish_all();
   stage_drain(A_s1);           /* stage 1 feeds stage 2: drain in pipeline order */
   stage_drain(A_s2);
 }
@@ -1356,6 +1357,7 @@ struct Front
   const u32 *work;  u32 nwork;
   const u32 *order;
   int pbits, abits, dbits;
+  JobParams jp;                 /* parameters and options of the moment the seed stage ran */
   size_t bytes;                 /* of the two arenas that hold the above */
 };
 
@@ -1369,18 +1371,19 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
   int64 nhits = 0;
   pick_sort_shape();
   memset(f, 0, sizeof(*f));
+  f->jp = params_now();
   job->counts[0] = job->counts[1] = job->counts[2] = 0;
   if (aidx == NULL || bidx == NULL || aidx->n == 0 || bidx->n == 0)
     return false;
-  if (aidx->kbits != bidx->kbits || aidx->tbits > aidx->kbits)
+  if (aidx->kbits != bidx->kbits)
     { fprintf(stderr, "damar: internal error, index parameters differ\n");
       die();
     }
   const u32 alen = aidx->n, blen = bidx->n;
   MergeArgs m;
   memset(&m, 0, sizeof(m));
-  m.acode = aidx->codes;  m.apos = aidx->pos;  m.alen = alen;  m.atab = aidx->table;
-  m.bcode = bidx->codes;  m.bpos = bidx->pos;  m.blen = blen;  m.btab = bidx->table;
+  m.acode = aidx->codes;  m.apos = aidx->pos;  m.alen = alen;
+  m.bcode = bidx->codes;  m.bpos = bidx->pos;  m.blen = blen;
   m.wide = aidx->wide;
   m.kbits = aidx->kbits;
   m.self = self;  m.comp = comp;  m.identity = IDENTITY;
@@ -1393,8 +1396,6 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
     { fprintf(stderr, "damar: FATAL: seed key needs %d bits (> 64)\n", m.pbits + m.abits + bbits);
       die();
     }
-  m.atbits = aidx->tbits;
-  m.btbits = bidx->tbits;
   /* Packed seeds: when position-in-B fits beside the sort key, a seed is ONE u64 (pair | apos | bpos) and the sort moves
      8 bytes per seed instead of 12; otherwise the diagonal travels in a second array (DAMAR_PACK_SEEDS=0 forces that) */
   { static int pack_on = -1;
@@ -1721,6 +1722,25 @@ struct Pending
   std::vector<TailJob *> writes;                  /* damar_write_overlaps requests that wait for this launch's tails */
 };
 static Pending &PD = *new Pending();
+
+/* Comparisons whose seed stages are done and whose report launch has not been made yet.  In asynchronous mode a launch is
+   held back while it would be SMALL: a launch ends by waiting for its longest alignment (a 15 kb read pair is some 10 ms of
+   serial wave steps), so a launch over two comparisons of a sparse block pair (config 4: ~1 600 alignments each) costs as
+   much as one over sixteen.  The comparisons of later calls join it until it holds batch_work() read pairs or its set of job
+   arenas is full; the files of the block pairs in it wait with it (damar_write_overlaps). */
+struct Accum
+{ int    n;
+  damar_match_job  job[DAMAR_MAX_JOBS / 2];
+  damar_match_job *orig[DAMAR_MAX_JOBS / 2];
+  Front  fr[DAMAR_MAX_JOBS / 2];
+  const damar_dev_block *ablk[DAMAR_MAX_JOBS / 2], *bblk[DAMAR_MAX_JOBS / 2];
+  size_t bytes;
+  u64    nwork;
+  std::vector<TailJob *> writes;
+};
+static Accum &AC = *new Accum();
+
+
 static int     G_set = 0;                          /* which set of job arenas the next seed stages use */
 static int64   A_nfilt = 0;                        /* totals of the asynchronous mode (damar_async_counts) */
 static double  A_report_ms = 0;
@@ -1730,7 +1750,7 @@ static void report_launch(Pending &pd)
 { ReportArgs *const ra = pd.ra;
   const hipStream_t st = pd.st;
   double q0 = now_ms();
-  scratch_prepare(pd.amax, pd.bmax, P_binshift, pd.tsmin, pd.cell_cap, st);
+  scratch_prepare(pd.amax, pd.bmax, pd.fr[0].jp.binshift, pd.tsmin, pd.cell_cap, st);
   double q1 = now_ms();
   scratch_outputs(pd.rec_cap, pd.tp_cap);
   double q2 = now_ms();
@@ -1738,7 +1758,7 @@ static void report_launch(Pending &pd)
   bool packed = true;
   for (int j = 0; j < pd.n; j++)
     { const damar_match_job &jb = pd.job[j];
-      fill_report_args(&ra[j], pd.ablk[j], pd.bblk[j], jb.comp, jb.self, jb.spec, st, j, pd.slot0 + j);
+      fill_report_args(&ra[j], pd.ablk[j], pd.bblk[j], jb.comp, jb.self, jb.spec, st, j, pd.slot0 + j, pd.fr[j].jp);
       ra[j].keys = pd.fr[j].keys;  ra[j].vals = pd.fr[j].vals;  ra[j].nhits = pd.fr[j].total;
       ra[j].work = pd.fr[j].work;  ra[j].nwork = pd.fr[j].nwork;
       ra[j].pbits = pd.fr[j].pbits;  ra[j].abits = pd.fr[j].abits;  ra[j].dbits = pd.fr[j].dbits;
@@ -1836,22 +1856,22 @@ static void report_finish(Pending &pd)
   for (int j = 0; j < n; j++)
     { const damar_match_job &jb = pd.job[j];
       if (pd.orig[j] != NULL)
-        pd.orig[j]->counts[1] = hc[32 + j];
-      G_cnt[2] += hc[32 + j];
+        pd.orig[j]->counts[1] = hc[DAMAR_CNT_NFILT + j];
+      G_cnt[2] += hc[DAMAR_CNT_NFILT + j];
       if (A_on)
         { { std::lock_guard<std::mutex> lk(A_mu);
-            A_nfilt += hc[32 + j];
+            A_nfilt += hc[DAMAR_CNT_NFILT + j];
           }
           TailJob *tj = new TailJob();
           tj->kind = 0;
           tj->hb = hb;  tj->jobid = j;  tj->njobs = n;
           tj->ablock = *jb.ablock;  tj->bblock = *jb.bblock;
-          tj->self = jb.self;  tj->comp = jb.comp;  tj->spec = jb.spec;
+          tj->self = jb.self;  tj->comp = jb.comp;  tj->spec = jb.spec;  tj->jp = pd.fr[j].jp;
           async_submit(tj);
         }
       else
         { double t0 = now_ms();
-          const int64 got = run_tail(hb->recs, hb->nrec, hb->tpool, jb.ablock, jb.bblock, jb.self, jb.comp, jb.spec, j, n);
+          const int64 got = run_tail(hb->recs, hb->nrec, hb->tpool, jb.ablock, jb.bblock, jb.self, jb.comp, jb.spec, pd.fr[j].jp, j, n);
           if (pd.orig[j] != NULL)
             pd.orig[j]->counts[2] = got;
           if (--hb->users == 0)
@@ -1905,6 +1925,11 @@ extern "C" void damar_write_overlaps(Align_Spec *spec, const char *d1, const cha
   if (d1) job->d1 = d1;
   if (d2) job->d2 = d2;
   job->a = ablock;  job->b = bblock;  job->last = lastRead;
+  for (int j = 0; j < AC.n; j++)                 /* comparisons of this spec are still waiting for their launch */
+    if (AC.job[j].spec == spec)
+      { AC.writes.push_back(job);
+        return;
+      }
   if (PD.live)                                   /* the tails of a launch in flight are not queued yet: behind them */
     for (int j = 0; j < PD.n; j++)
       if (PD.job[j].spec == spec)
@@ -1936,6 +1961,59 @@ static bool overlap_on(void)
   return on && A_on && !VERBOSE && !G_keep_seeds;
 }
 
+static u64 batch_work(void)
+{ static long long w = -1;
+  if (w < 0)
+    { const char *e = getenv("DAMAR_BATCH_WORK");
+      w = e ? atoll(e) : 32768;           /* read pairs: four per wave slot of the launch */
+    }
+  return (u64) w;
+}
+
+static void flush_accum(void)
+{ if (AC.n == 0)
+    return;
+  const bool defer = overlap_on();
+  /* the launch in flight (it ran beside these seed stages) is completed first: one set of output buffers */
+  finish_pending();
+  Pending &pd = PD;
+  const int n = AC.n;
+  pd.n = n;  pd.slot0 = G_set * (DAMAR_MAX_JOBS / 2);
+  pd.amax = pd.bmax = 0;  pd.tsmin = 0x7fffffff;
+  for (int j = 0; j < n; j++)
+    { pd.job[j] = AC.job[j];  pd.orig[j] = AC.orig[j];  pd.fr[j] = AC.fr[j];
+      pd.ablk[j] = AC.ablk[j];  pd.bblk[j] = AC.bblk[j];
+      pd.amax = std::max(pd.amax, AC.job[j].ablock->maxlen);  pd.bmax = std::max(pd.bmax, AC.job[j].bblock->maxlen);
+      pd.tsmin = std::min(pd.tsmin, Trace_Spacing(AC.job[j].spec));
+    }
+  pd.cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
+  pd.rec_cap  = (u32) std::min<u64>(0x7fffffffu, std::max<u64>(RS.rec_cap, 2 * AC.nwork + 4096));
+  pd.tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(RS.tpool_cap, (u64) pd.rec_cap * 256u));
+  if (getenv("DAMAR_TEST_SMALL_CAPS") && RS.rec_cap == 0)      /* tests: start far too small, so that the
+                                                                  overflow flags and the re-launch are exercised */
+    { pd.cell_cap = 64;  pd.rec_cap = 16;  pd.tp_cap = 512; }
+  pd.attempt = 0;
+  pd.st = defer ? G_rep : G_st;
+  for (TailJob *w : AC.writes)
+    pd.writes.push_back(w);
+  AC.writes.clear();
+  if (defer)                                   /* the launch reads what the seed stages wrote on the other stream */
+    { HIP_CHECK(hipEventRecord(G_front_done, G_st));
+      HIP_CHECK(hipStreamWaitEvent(G_rep, G_front_done, 0));
+    }
+  report_launch(pd);
+  if (!defer)
+    report_finish(pd);
+  G_set ^= 1;
+  AC.n = 0;  AC.bytes = 0;  AC.nwork = 0;
+}
+
+/* everything this library still owes: the comparisons held back, then the launch in flight */
+static void finish_all(void)
+{ flush_accum();
+  finish_pending();
+}
+
 extern "C" void damar_match_batch(damar_match_job *jobs, int njobs)
 { ensure_init();
   const double h0 = now_ms();
@@ -1944,60 +2022,45 @@ extern "C" void damar_match_batch(damar_match_job *jobs, int njobs)
     G_ms[i] = 0;
   const bool defer = overlap_on();
   if (!defer)
-    finish_pending();
-  damar_match_job *run[DAMAR_MAX_JOBS];
-  Front fr[DAMAR_MAX_JOBS];
-  int   n = 0;
-  size_t bytes = 0;
+    finish_all();
   const size_t budget = G_prop.totalGlobalMem / 4;
-  const int    limit = std::min(batch_limit(), DAMAR_MAX_JOBS / 2);       /* two sets of job arenas */
-  auto flush = [&]()
-    { if (n == 0) return;
-      /* the launch in flight (it ran beside these seed stages) is completed first: one set of output buffers */
-      finish_pending();
-      Pending &pd = PD;
-      pd.n = n;  pd.slot0 = G_set * (DAMAR_MAX_JOBS / 2);
-      pd.amax = pd.bmax = 0;  pd.tsmin = 0x7fffffff;
-      u64 nwork = 0;
-      for (int j = 0; j < n; j++)
-        { pd.job[j] = *run[j];  pd.orig[j] = run[j];  pd.fr[j] = fr[j];
-          pd.ablk[j] = run[j]->aidx->blk;  pd.bblk[j] = run[j]->bidx->blk;
-          pd.amax = std::max(pd.amax, run[j]->ablock->maxlen);  pd.bmax = std::max(pd.bmax, run[j]->bblock->maxlen);
-          pd.tsmin = std::min(pd.tsmin, Trace_Spacing(run[j]->spec));
-          nwork += fr[j].nwork;
-        }
-      pd.cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
-      pd.rec_cap  = (u32) std::min<u64>(0x7fffffffu, std::max<u64>(RS.rec_cap, 2 * nwork + 4096));
-      pd.tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(RS.tpool_cap, (u64) pd.rec_cap * 256u));
-      if (getenv("DAMAR_TEST_SMALL_CAPS") && RS.rec_cap == 0)      /* tests: start far too small, so that the
-                                                                      overflow flags and the re-launch are exercised */
-        { pd.cell_cap = 64;  pd.rec_cap = 16;  pd.tp_cap = 512; }
-      pd.attempt = 0;
-      pd.st = defer ? G_rep : G_st;
-      if (defer)                                   /* the launch reads what the seed stages wrote on the other stream */
-        { HIP_CHECK(hipEventRecord(G_front_done, G_st));
-          HIP_CHECK(hipStreamWaitEvent(G_rep, G_front_done, 0));
-        }
-      report_launch(pd);
-      if (!defer)
-        report_finish(pd);
-      G_set ^= 1;
-      n = 0;  bytes = 0;
-    };
+  const int    hard = DAMAR_MAX_JOBS / 2;                                 /* two sets of job arenas */
+  const int    soft = std::min(batch_limit(), hard);
   for (int i = 0; i < njobs; i++)
     { const double f0 = now_ms();
-      if (match_front(&jobs[i], G_set * (DAMAR_MAX_JOBS / 2) + n, &fr[n]))
-        { run[n] = &jobs[i];
-          bytes += fr[n].bytes;
-          n += 1;
+      /* one launch, one set of filter parameters and one scoring (the kernel's trim table): comparisons held back under
+         other options go first */
+      if (AC.n > 0)
+        { const JobParams now = params_now();
+          const JobParams &was = AC.fr[0].jp;
+          const int16 *s0 = damar_spec_score_table(AC.job[0].spec), *s1 = damar_spec_score_table(jobs[i].spec);
+          bool go = now.kmer != was.kmer || now.hitmin != was.hitmin || now.binshift != was.binshift ||
+                    s0[32767] != s1[32767] || s0[0] != s1[0];
+          /* an Align_Spec whose files are already asked for (damar_write_overlaps) belongs to a finished block pair: a
+             new pair on the same spec must not reach its overlap buffers before that write has detached them */
+          for (TailJob *w : AC.writes)
+            go = go || w->spec == jobs[i].spec;
+          if (go)
+            flush_accum();
+        }
+      const int n = AC.n;
+      if (match_front(&jobs[i], G_set * hard + n, &AC.fr[n]))
+        { AC.job[n] = jobs[i];  AC.orig[n] = &jobs[i];
+          AC.ablk[n] = jobs[i].aidx->blk;  AC.bblk[n] = jobs[i].bidx->blk;
+          AC.bytes += AC.fr[n].bytes;
+          AC.nwork += AC.fr[n].nwork;
+          AC.n = n + 1;
         }
       H_ms[1] += now_ms() - f0;
-      if (n >= limit || bytes > budget)
-        flush();
+      if (AC.n >= hard || AC.bytes > budget || (AC.n >= soft && (!defer || AC.nwork >= batch_work())))
+        flush_accum();
     }
-  flush();
+  if (!defer)
+    flush_accum();
   for (int j = 0; j < DAMAR_MAX_JOBS; j++)         /* the caller's job structs end with this call */
     PD.orig[j] = NULL;
+  for (int j = 0; j < DAMAR_MAX_JOBS / 2; j++)
+    AC.orig[j] = NULL;
   H_ms[6] += now_ms() - h0;
 }
 
@@ -2051,7 +2114,7 @@ extern "C" int damar_tandem_set_params(int kmer, int binshift, int hitmin, int n
 }
 
 extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Align_Spec *spec, int64 *counts)
-{ finish_pending();
+{ finish_all();
   ensure_init();
   int64 nfilt = 0, ncheck = 0;
   int   n = 0;
@@ -2079,7 +2142,7 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
       { ReportArgs ra;
         scratch_prepare(ablock->maxlen, ablock->maxlen, T_binshift, ts, cell_cap, G_st);
         scratch_outputs(rec_cap, tp_cap);
-        fill_report_args(&ra, blk, blk, 0, 1, spec, G_st);
+        fill_report_args(&ra, blk, blk, 0, 1, spec, G_st, 0, 0, params_now());
         ra.nwork = (u32) ablock->nreads;
         HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
         tick(4);
@@ -2108,7 +2171,7 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
     { HIP_CHECK(hipMemcpy(recs.data(), RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost));
       HIP_CHECK(hipMemcpy(tpool.data(), RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost));
     }
-  nfilt = hc[32];
+  nfilt = hc[DAMAR_CNT_NFILT];
   HIP_CHECK(hipFree(dist));
   damar_index_free(ix);
 
@@ -2177,7 +2240,7 @@ extern "C" int64 damar_last_seeds(void *out, int64 cap)
 extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_block *bblk, int comp,
                                            Align_Spec *spec, const int *tasks, int ntasks,
                                            int *paths, int64 *trace_off, uint16 *traces, int64 trace_cap)
-{ finish_pending();
+{ finish_all();
   ensure_init();
   if (ntasks <= 0)
     return 0;
@@ -2191,7 +2254,7 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
       scratch_prepare(ablk->d.maxlen, bblk->d.maxlen, P_binshift, ts, cell_cap, G_st);
       stage("la_scratch");
       scratch_outputs(rec_cap, tp_cap);
-      fill_report_args(&ra, ablk, bblk, comp, 0, spec, G_st);
+      fill_report_args(&ra, ablk, bblk, comp, 0, spec, G_st, 0, 0, params_now());
       HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
       stage("la_setup");
       if (use_packed(&ra, ablk->d.maxlen, bblk->d.maxlen))

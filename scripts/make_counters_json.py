@@ -10,8 +10,12 @@ nominal 2.4 GHz).
 """
 import csv
 import json
+import os
 import re
+import subprocess
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 VALU_PEAK = 0.456 * 2.4e9 * 1024       # wave-instructions per second, whole chip (roofcal, 8 waves/SIMD): the CHEAPEST kind
 # `roofcal ops` (profiles/r02_roofcal_ops.txt): only v_add / v_sub / v_mov_b32 / and / or / xor / lshr / ashr issue that fast,
@@ -54,6 +58,15 @@ def main():
            "counters_per_step": cnt,
            "source": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu "
                      "--no-trace --no-e2e` (scripts/gpu_profile_round.sh); issue peaks from tools/roofcal.hip (profiles/r02_roofcal.txt)"}
+    # what ties this file to a tree: bench.py carries its figures only while the kernel sources still hash to this
+    import bench
+    out["kernel_src_sha16"] = bench.kernel_src_sha16()
+    out["bench_py_sha16"] = __import__("hashlib").sha256(open(bench.__file__, "rb").read()).hexdigest()[:16]
+    try:
+        out["head"] = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=os.path.dirname(os.path.abspath(bench.__file__)),
+                                     stdout=subprocess.PIPE, text=True).stdout.strip() or None
+    except Exception:
+        out["head"] = None
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("kernel_symbol", "avg_launch_ms", "bytes_per_launch", "valu_frac", "salu_frac", "valu_busy_weighted",
                                           "active_lane_frac", "lds_bank_conflict_frac", "wave_cycles_share")}, indent=1))
