@@ -14,6 +14,16 @@
  * strand + 8 B per k-mer + the prefix table) for all the lines that name it, least recently used blocks
  * released beyond DAMAR_PLAN_BLOCKS (default 64).  Options in front of -P apply to every line; a line's own
  * options are parsed on top of them.  Output files are those of the separate commands.
+ *
+ * Node mode, `daligner [options] -P <plan> -G <n | i,j,...> [-L]`: the plan's block pairs over several GPUs of one node --
+ * the scheduler north_star asks for in place of dalign/daligner.c:958 under the work list of dalign/HPCdaligner.c:628-788.
+ * The parent parses the plan, cuts the block pairs into one region per GPU (an A range x subject range of the plan's
+ * triangle: a worker that stays inside its region builds few k-mer indexes), forks one worker per GPU BEFORE any HIP call
+ * and waits; a worker pulls units (one A block against up to 8 subject blocks, both orientations) from its region's
+ * cursor -- a C11 atomic in a page shared by the processes -- and, when that is empty, from the other regions' (work
+ * stealing without victims).  No data moves between the workers: every pair writes its own files.  When the plan has
+ * fewer than two pairs per GPU, cross pairs are split by B-read range and the parent merges the parts (LAmerge).
+ * With -L the parent also runs the plan's own LAmerge lines (HPCdaligner.c:790-808) once the pairs are done.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -22,6 +32,11 @@
 #include <unistd.h>
 #include <errno.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <stdatomic.h>
+#include <limits.h>
+#include <dirent.h>
 #include <pthread.h>
 
 #include "damar_filter.h"
@@ -32,11 +47,26 @@ static void usage(void)
   fprintf(stderr, "daligner [-vbAIOT] [-k<int(14)>] [-w<int(6)>] [-h<int(35)>] [-t<int>] [-M<int>] [-m<track>]+\n");
   fprintf(stderr, "         [-e<double(.70)] [-l<int(1000)>] [-s<int(100)>] [-H<int>] [-j<int>]\n");
   fprintf(stderr, "         [-r<int(1)>] [-g<gpu ordinal(0)>] <subject:db> <target:db> ...\n");
-  fprintf(stderr, "daligner [options] -P <HPCdaligner plan file, or - for stdin>\n");
+  fprintf(stderr, "daligner [options] -P <HPCdaligner plan file, or - for stdin> [-G <GPUs: n | i,j,...>] [-L]\n");
+}
+
+/* Output directories are named relative to the working directory, as the reference names them; a worker that runs one
+   PART of a split block pair writes under OUT_base instead (absolute: the files are written later, on another thread). */
+static char *OUT_base = NULL;
+
+static char *out_dir(int run, int part)
+{ char *d = damar_get_dir(run, part);
+  if (OUT_base != NULL)
+    { char *x = (char *) malloc(strlen(OUT_base) + strlen(d) + 2);
+      sprintf(x, "%s/%s", OUT_base, d);
+      free(d);
+      d = x;
+    }
+  return d;
 }
 
 static void make_subdir(const HITS_DB *block, int run)      /* daligner.c:630-660 */
-{ char *d = damar_get_dir(run, block->part);
+{ char *d = out_dir(run, block->part);
   struct stat s;
   if (stat(d, &s) != 0)
     { if (errno == ENOENT)
@@ -171,6 +201,8 @@ typedef struct
   char  *mask[64];
   int    mtop;
   char  *plan;
+  char  *gpus;          /* -G: node mode */
+  int    lamerge;       /* -L: run the plan's LAmerge lines too */
 } Opts;
 
 static void default_opts(Opts *o)
@@ -184,7 +216,7 @@ static int parse_opts(int argc, char *argv[], Opts *o)
 { int c;
   opterr = 0;
   optind = 1;
-  while ((c = getopt(argc, argv, "vbOTAIk:w:h:t:M:e:l:s:H:D:m:r:j:g:P:")) != -1)
+  while ((c = getopt(argc, argv, "vbOTAIk:w:h:t:M:e:l:s:H:D:m:r:j:g:P:G:L")) != -1)
     switch (c)
     { case 'v': o->verbose = 1; break;
       case 'T': o->notrace = 1; break;
@@ -203,6 +235,8 @@ static int parse_opts(int argc, char *argv[], Opts *o)
       case 'r': o->runid = atoi(optarg); break;
       case 'g': o->gpu = atoi(optarg); break;
       case 'P': o->plan = optarg; break;
+      case 'G': o->gpus = optarg; break;
+      case 'L': o->lamerge = 1; break;
       case 'M':
         o->mem_gb = atoi(optarg);
         if (o->mem_gb < 0)
@@ -654,14 +688,14 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
       t0 = wall_ms();
       damar_match_batch(jobs, 2);
       P_ms[2] += wall_ms() - t0;
-      if (a->blk.part > 0) d1 = damar_get_dir(o->runid, a->blk.part);
+      if (a->blk.part > 0) d1 = out_dir(o->runid, a->blk.part);
       if (same)
         { TIMED(4, damar_write_overlaps(sp, d1, NULL, aroot, aroot, a->blk.ufirst + a->blk.nreads - 1)); }
       else
         { char *broot = damar_root(bfiles[k], ".db");
           const int last_read = (b->blk.part < a->blk.part) ? b->blk.ufirst + b->blk.nreads - 1
                                                             : a->blk.ufirst + a->blk.nreads - 1;
-          if (b->blk.part > 0) d2 = damar_get_dir(o->runid, b->blk.part);
+          if (b->blk.part > 0) d2 = out_dir(o->runid, b->blk.part);
           TIMED(4, damar_write_overlaps(sp, d1, d2, aroot, broot, last_read));
           free(broot);
           b->busy = 0;
@@ -673,34 +707,44 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
   free(aroot);
 }
 
-static int plan_main(const Opts *base, const char *planfile)
+/* the `daligner ...` lines of a plan, tokenised (comments and other commands are skipped); with mtok / mn / nm also its
+   `LAmerge ...` lines (HPCdaligner.c:790-808) */
+static void read_plan(const char *planfile, char ****ltok_p, int **lntok_p, int *nl_p, char ****mtok_p, int **mn_p, int *nm_p)
 { FILE  *f = (strcmp(planfile, "-") == 0) ? stdin : fopen(planfile, "r");
   char  *line = NULL;
   size_t cap = 0;
-  char ***ltok = NULL;                 /* the plan's daligner lines, tokenised */
-  int   *lntok = NULL, nl = 0, lcap = 0;
-  int    i, j, same_masks = 1;
-  pthread_t reader[2];                 /* two: a block's read + complement + upload take ~95 ms, a plan line less */
-  int    have_reader = 0;
-
+  char ***ltok = NULL, ***mtok = NULL;
+  int   *lntok = NULL, *mn = NULL, nl = 0, lcap = 0, nm = 0, mcap = 0, j;
   if (f == NULL)
     { fprintf(stderr, "daligner: cannot open plan %s\n", planfile);
       exit(1);
     }
-  if (getenv("DAMAR_PLAN_BLOCKS") != NULL && atoi(getenv("DAMAR_PLAN_BLOCKS")) >= 2)
-    PB_max = atoi(getenv("DAMAR_PLAN_BLOCKS"));
   while (getline(&line, &cap, f) > 0)
     { char *tok[4096], *sp = NULL, *t;
-      int   n = 0;
+      int   n = 0, merge;
       for (t = strtok_r(line, " \t\r\n", &sp); t != NULL && n < 4095; t = strtok_r(NULL, " \t\r\n", &sp))
         tok[n++] = t;
       if (n == 0)
         continue;
       { const char *b0 = strrchr(tok[0], '/');
         b0 = b0 ? b0 + 1 : tok[0];
-        if (strcmp(b0, "daligner") != 0)              /* comments, LAmerge lines, ... */
+        merge = (strcmp(b0, "LAmerge") == 0);
+        if (strcmp(b0, "daligner") != 0 && !(merge && mtok_p != NULL))              /* comments, other commands */
           continue;
       }
+      if (merge)
+        { if (nm >= mcap)
+            { mcap = 2 * mcap + 64;
+              mtok = (char ***) realloc(mtok, sizeof(char **) * (size_t) mcap);
+              mn = (int *) realloc(mn, sizeof(int) * (size_t) mcap);
+            }
+          mtok[nm] = (char **) malloc(sizeof(char *) * (size_t) (n + 1));
+          for (j = 0; j < n; j++)
+            mtok[nm][j] = strdup(tok[j]);
+          mtok[nm][n] = NULL;
+          mn[nm++] = n;
+          continue;
+        }
       if (nl >= lcap)
         { lcap = 2 * lcap + 64;
           ltok = (char ***) realloc(ltok, sizeof(char **) * (size_t) lcap);
@@ -715,7 +759,29 @@ static int plan_main(const Opts *base, const char *planfile)
   free(line);
   if (f != stdin)
     fclose(f);
+  *ltok_p = ltok;  *lntok_p = lntok;  *nl_p = nl;
+  if (mtok_p != NULL)
+    { *mtok_p = mtok;  *mn_p = mn;  *nm_p = nm; }
+}
 
+static int node_main(const Opts *base, const char *planfile);
+
+static int plan_main(const Opts *base, const char *planfile)
+{ char ***ltok = NULL;                 /* the plan's daligner lines, tokenised */
+  int   *lntok = NULL, nl = 0;
+  int    i, j, same_masks = 1;
+  pthread_t reader[2];                 /* two: a block's read + complement + upload take ~95 ms, a plan line less */
+  int    have_reader = 0;
+
+  if (base->gpus != NULL)
+    return node_main(base, planfile);
+  if (base->lamerge)
+    { fprintf(stderr, "daligner: -L needs -G (the node scheduler runs the plan's LAmerge lines)\n");
+      exit(1);
+    }
+  if (getenv("DAMAR_PLAN_BLOCKS") != NULL && atoi(getenv("DAMAR_PLAN_BLOCKS")) >= 2)
+    PB_max = atoi(getenv("DAMAR_PLAN_BLOCKS"));
+  read_plan(planfile, &ltok, &lntok, &nl, NULL, NULL, NULL);
 
   /* the block table, and what the reader thread prepares ahead: the blocks in order of first use */
   PB_cap = PB_max + LINE_B + 2;           /* a group of subject blocks and the A block can be busy beyond PB_max */
@@ -819,4 +885,526 @@ static int plan_main(const Opts *base, const char *planfile)
       fprintf(stderr, "\n");
     }
   return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * Node mode: the plan's block pairs over the GPUs of one node (see the header).  The C counterpart of
+ * damar_amd/multi.py (region_units / RegionQueue / work_units / merge_parts), with fork() and a shared page
+ * of C11 atomics in place of torchrun and the store.
+ * ------------------------------------------------------------------------------------------------- */
+
+#define NODE_MAXW  64
+#define NODE_GROUP 8                      /* subject blocks per unit (multi.GROUP, driver.Plan.GROUP) */
+
+typedef struct
+{ int a;                                 /* A block number */
+  int b[NODE_GROUP], nb;                 /* subject blocks */
+  int part, nparts;                      /* nparts > 1: one B-read range of the single pair (a, b[0]) */
+  int cost;
+} Unit;
+
+typedef struct
+{ atomic_int cursor[NODE_MAXW];          /* next unit of each region */
+  int        first[NODE_MAXW], end[NODE_MAXW];
+  int        nregions;
+  struct { int units, stolen, builds;  double wall_ms; } stat[NODE_MAXW];
+} NodeShared;
+
+/* "<dir/>root.N" -> N (>= 1) and the length of "<dir/>root"; 0 if the name has no block number */
+static int block_no(const char *name, size_t *stem)
+{ const char *dot = strrchr(name, '.');
+  char *end;
+  long  n;
+  if (dot == NULL || dot[1] == '\0')
+    return 0;
+  n = strtol(dot + 1, &end, 10);
+  if (*end != '\0' || n < 1 || n > 1000000)
+    return 0;
+  *stem = (size_t) (dot - name);
+  return (int) n;
+}
+
+/* pair costs as a summed-area table: cost of a rectangle of the (a, b) plane in O(1) */
+static int   NB_lo, NB_hi;               /* block numbers that occur in the plan */
+static long *NS;                         /* (n+1) x (n+1) prefix sums, n = NB_hi - NB_lo + 1 */
+static unsigned char *NP;                /* n x n: the pair is in the plan */
+#define NIDX(a, b) ((size_t) ((a) - NB_lo) * (size_t) (NB_hi - NB_lo + 1) + (size_t) ((b) - NB_lo))
+
+static long rect_cost(int alo, int ahi, int blo, int bhi)
+{ const size_t w = (size_t) (NB_hi - NB_lo + 2);
+  if (alo > ahi || blo > bhi)
+    return 0;
+  #define SAT(i, j) NS[(size_t) (i) * w + (size_t) (j)]
+  { const int a0 = alo - NB_lo, a1 = ahi - NB_lo + 1, b0 = blo - NB_lo, b1 = bhi - NB_lo + 1;
+    return SAT(a1, b1) - SAT(a0, b1) - SAT(a1, b0) + SAT(a0, b0);
+  }
+  #undef SAT
+}
+
+typedef struct { int alo, ahi, blo, bhi; } Region;
+
+/* k regions of about equal cost by recursive bisection, each time across the dimension that is longer in index builds
+   (an A block costs one k-mer index, a subject block two: both strands) unless its best cut is badly off balance */
+static int split_region(Region r, int k, Region *out)
+{ int  k1 = k / 2, t, have = 0, have_alt = 0;
+  long want, best_err = 0, alt_err = 0;
+  int  best_dim = 0, best_t = 0, alt_dim = 0, alt_t = 0, prefer;
+  /* shrink to the rows and columns that hold pairs */
+  while (r.alo < r.ahi && rect_cost(r.alo, r.alo, r.blo, r.bhi) == 0) r.alo += 1;
+  while (r.ahi > r.alo && rect_cost(r.ahi, r.ahi, r.blo, r.bhi) == 0) r.ahi -= 1;
+  while (r.blo < r.bhi && rect_cost(r.alo, r.ahi, r.blo, r.blo) == 0) r.blo += 1;
+  while (r.bhi > r.blo && rect_cost(r.alo, r.ahi, r.bhi, r.bhi) == 0) r.bhi -= 1;
+  if (k <= 1)
+    { out[0] = r;
+      return 1;
+    }
+  want = rect_cost(r.alo, r.ahi, r.blo, r.bhi) * k1 / k;
+  prefer = ((r.ahi - r.alo + 1) >= 2 * (r.bhi - r.blo + 1)) ? 0 : 1;          /* 0: cut the A range, 1: the subject range */
+  for (int dim = 0; dim < 2; dim++)
+    for (t = (dim ? r.blo : r.alo); t < (dim ? r.bhi : r.ahi); t++)
+      { const long cl = dim ? rect_cost(r.alo, r.ahi, r.blo, t) : rect_cost(r.alo, t, r.blo, r.bhi);
+        const long cr = dim ? rect_cost(r.alo, r.ahi, t + 1, r.bhi) : rect_cost(t + 1, r.ahi, r.blo, r.bhi);
+        const long err = labs(cl - want);
+        if (cl == 0 || cr == 0)
+          continue;
+        if (dim == prefer && (!have || err < best_err))
+          { have = 1;  best_err = err;  best_dim = dim;  best_t = t; }
+        if (!have_alt || err < alt_err)
+          { have_alt = 1;  alt_err = err;  alt_dim = dim;  alt_t = t; }
+      }
+  if (!have_alt)
+    { out[0] = r;
+      return 1;
+    }
+  if (!have || (best_err > (want > 1 ? want : 1) * 15 / 100 && alt_err < best_err))
+    { best_dim = alt_dim;  best_t = alt_t; }
+  { Region left = r, right = r;
+    int    n;
+    if (best_dim == 0) { left.ahi = best_t;  right.alo = best_t + 1; }
+    else               { left.bhi = best_t;  right.blo = best_t + 1; }
+    n = split_region(left, k1, out);
+    return n + split_region(right, k - k1, out + n);
+  }
+}
+
+static int unit_cmp(const void *x, const void *y)             /* most expensive first; then plan order */
+{ const Unit *u = (const Unit *) x, *v = (const Unit *) y;
+  if (u->cost != v->cost) return v->cost - u->cost;
+  if (u->a != v->a) return u->a - v->a;
+  return v->b[0] - u->b[0];
+}
+
+/* the units of one region: per A block its subject blocks, highest first, in groups of at most g */
+static int region_units(Region r, int g, Unit *out)
+{ int n = 0, a, b;
+  for (a = r.alo; a <= r.ahi; a++)
+    { Unit *u = NULL;
+      for (b = r.bhi; b >= r.blo; b--)
+        if (NP[NIDX(a, b)])
+          { if (u == NULL || u->nb >= g)
+              { u = out + n++;
+                memset(u, 0, sizeof(*u));
+                u->a = a;  u->nparts = 1;
+              }
+            u->b[u->nb++] = b;
+            u->cost += (a == b) ? 1 : 2;
+          }
+    }
+  qsort(out, (size_t) n, sizeof(Unit), unit_cmp);
+  return n;
+}
+
+#pragma GCC diagnostic ignored "-Wformat-truncation"
+
+int lamerge_main(int argc, char *argv[]);                     /* host/lamerge.c, linked in: LAmerge without an exec */
+
+/* LAmerge on `argv` (NULL-terminated, argv[0] is only a name) in a forked child of this process */
+static pid_t spawn_merge(char **argv)
+{ pid_t pid;
+  int   argc = 0;
+  while (argv[argc] != NULL)
+    argc += 1;
+  fflush(NULL);
+  pid = fork();
+  if (pid == 0)
+    { optind = 1;
+      exit(lamerge_main(argc, argv));
+    }
+  return pid;
+}
+
+static void remove_tree(const char *path)                     /* rm -rf of the part directories */
+{ DIR *d = opendir(path);
+  struct dirent *e;
+  if (d != NULL)
+    { while ((e = readdir(d)) != NULL)
+        if (strcmp(e->d_name, ".") != 0 && strcmp(e->d_name, "..") != 0)
+          { char sub[PATH_MAX];
+            struct stat sb;
+            snprintf(sub, sizeof(sub), "%s/%s", path, e->d_name);
+            if (lstat(sub, &sb) == 0 && S_ISDIR(sb.st_mode))
+              remove_tree(sub);
+            else
+              unlink(sub);
+          }
+      closedir(d);
+    }
+  rmdir(path);
+}
+
+static int wait_ok(pid_t pid, const char *what)
+{ int st = 0;
+  if (pid < 0 || waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
+    { fprintf(stderr, "daligner: %s failed\n", what);
+      return 0;
+    }
+  return 1;
+}
+
+static void mkdir_p(const char *path)
+{ char *p = strdup(path), *q;
+  for (q = p + 1; *q; q++)
+    if (*q == '/')
+      { *q = '\0';
+        mkdir(p, 0777);
+        *q = '/';
+      }
+  mkdir(p, 0777);
+  free(p);
+}
+
+static void part_dir(char *out, size_t cap, const char *cwd, int a, int b, int part, int nparts)
+{ snprintf(out, cap, "%s/_parts/%d.%d/p%dof%d", cwd, a, b, part, nparts); }
+
+/* one worker: its GPU, its own block table and index cache, units from the shared cursors */
+static int node_worker(int w, int gpu, const Opts *o, const char *stem, const Unit *units, NodeShared *S, const char *cwd)
+{ Opts   ow = *o;
+  int    r, nunits = 0, stolen = 0;
+  double t0 = wall_ms();
+  ow.gpu = gpu;  ow.plan = NULL;  ow.gpus = NULL;
+  if (getenv("DAMAR_PLAN_BLOCKS") != NULL && atoi(getenv("DAMAR_PLAN_BLOCKS")) >= 2)
+    PB_max = atoi(getenv("DAMAR_PLAN_BLOCKS"));
+  PB_cap = PB_max + LINE_B + 2;
+  PB = (PBlock *) calloc((size_t) PB_cap, sizeof(PBlock));
+  select_device(&ow);
+  damar_set_async(1);
+  pthread_mutex_lock(&PB_mu);
+  PB_dev_ready = 1;
+  pthread_mutex_unlock(&PB_mu);
+  for (r = 0; r < S->nregions; r++)
+    { const int p = (w + r) % S->nregions;
+      for (;;)
+        { const int i = atomic_fetch_add(&S->cursor[p], 1);
+          const Unit *u;
+          char  aname[PATH_MAX], bname[NODE_GROUP][PATH_MAX], *bfiles[NODE_GROUP], base[PATH_MAX];
+          int   k;
+          if (S->first[p] + i >= S->end[p])
+            break;
+          u = units + S->first[p] + i;
+          snprintf(aname, sizeof(aname), "%s.%d", stem, u->a);
+          for (k = 0; k < u->nb; k++)
+            { snprintf(bname[k], sizeof(bname[k]), "%s.%d", stem, u->b[k]);
+              bfiles[k] = bname[k];
+            }
+          if (u->nparts > 1)                       /* one B-read range of a pair: its files go under the part's directory */
+            { PBlock *b = pblock_get(bfiles[0], &ow);
+              const int nr = b->blk.nreads;
+              part_dir(base, sizeof(base), cwd, u->a, u->b[0], u->part, u->nparts);
+              mkdir_p(base);
+              OUT_base = base;
+              damar_set_bread_range((int) ((long) nr * u->part / u->nparts), (int) ((long) nr * (u->part + 1) / u->nparts));
+            }
+          plan_line(&ow, aname, bfiles, u->nb);
+          if (u->nparts > 1)
+            { damar_async_drain();                 /* (the write requests hold pointers into `base`) */
+              damar_set_bread_range(0, -1);
+              OUT_base = NULL;
+            }
+          nunits += 1;
+          stolen += (r > 0);
+        }
+    }
+  damar_async_drain();
+  { int i;
+    for (i = 0; i < PS_n; i++)
+      Free_Align_Spec(PS[i]);
+    for (i = 0; i < PB_n; i++)
+      pblock_release(PB + i);
+  }
+  damar_set_async(0);
+  S->stat[w].units = nunits;  S->stat[w].stolen = stolen;  S->stat[w].builds = PB_builds;
+  S->stat[w].wall_ms = wall_ms() - t0;
+  return 0;
+}
+
+static int node_main(const Opts *base, const char *planfile)
+{ char ***ltok = NULL, ***mtok = NULL;
+  int   *lntok = NULL, *mn = NULL, nl = 0, nm = 0;
+  int    gpus[NODE_MAXW], W = 0, i, j;
+  char  *stem = NULL;
+  size_t stemlen = 0;
+  Opts   o0;
+  int    first0 = 0, npairs = 0, nself = 0;
+  Unit  *units;
+  int    nunits = 0;
+  NodeShared *S;
+  char   cwd[PATH_MAX];
+  pid_t  pid[NODE_MAXW];
+  int    ok = 1;
+  double t0 = wall_ms();
+
+  /* -G n: GPUs 0 .. n-1; -G i,j,...: those.  DAMAR_SHARE_GPU=1 puts every worker on the first (a rehearsal on one GPU) */
+  { const char *g = base->gpus;
+    if (strchr(g, ',') == NULL)
+      { int n = atoi(g);
+        for (i = 0; i < n && W < NODE_MAXW; i++)
+          gpus[W++] = i;
+      }
+    else
+      { char *copy = strdup(g), *sp = NULL, *t;
+        for (t = strtok_r(copy, ",", &sp); t != NULL && W < NODE_MAXW; t = strtok_r(NULL, ",", &sp))
+          gpus[W++] = atoi(t);
+        free(copy);
+      }
+    if (W < 1)
+      { fprintf(stderr, "daligner: -G wants a number of GPUs or a list of ordinals\n");
+        exit(1);
+      }
+    if (getenv("DAMAR_SHARE_GPU") != NULL && atoi(getenv("DAMAR_SHARE_GPU")) > 0)
+      for (i = 1; i < W; i++)
+        gpus[i] = gpus[0];
+  }
+  if (getcwd(cwd, sizeof(cwd)) == NULL)
+    { fprintf(stderr, "daligner: cannot determine the working directory\n");
+      exit(1);
+    }
+  read_plan(planfile, &ltok, &lntok, &nl, &mtok, &mn, &nm);
+  if (nl == 0)
+    return 0;
+
+  /* every line: the same options, blocks named <stem>.<number> */
+  NB_lo = INT_MAX;  NB_hi = 0;
+  for (i = 0; i < nl; i++)
+    { Opts o = *base;
+      int  first;
+      o.plan = NULL;  o.gpus = NULL;
+      first = parse_opts(lntok[i], ltok[i], &o);
+      if (o.plan != NULL || o.gpus != NULL)
+        { fprintf(stderr, "daligner: -P / -G inside a plan\n");
+          exit(1);
+        }
+      if (first + 2 > lntok[i])
+        { fprintf(stderr, "[ERROR] - at least one target and one subject block are required\n\n");
+          exit(1);
+        }
+      if (i == 0)
+        { o0 = o;  first0 = first; }
+      else
+        { int same = (first == first0);
+          for (j = 1; same && j < first; j++)
+            same = (strcmp(ltok[i][j], ltok[0][j]) == 0);
+          if (!same)
+            { fprintf(stderr, "daligner: -G needs a plan whose lines share their options (line %d differs)\n", i + 1);
+              exit(1);
+            }
+        }
+      for (j = first; j < lntok[i]; j++)
+        { size_t sl = 0;
+          const int n = block_no(ltok[i][j], &sl);
+          if (n == 0 || (stem != NULL && (sl != stemlen || strncmp(stem, ltok[i][j], sl) != 0)))
+            { fprintf(stderr, "daligner: -G needs blocks of ONE database named <db>.<number> (%s)\n", ltok[i][j]);
+              exit(1);
+            }
+          if (stem == NULL)
+            { stem = strndup(ltok[i][j], sl);
+              stemlen = sl;
+            }
+          if (n < NB_lo) NB_lo = n;
+          if (n > NB_hi) NB_hi = n;
+        }
+    }
+  if (NB_hi - NB_lo >= 30000)
+    { fprintf(stderr, "daligner: -G: block numbers span more than 30000\n");
+      exit(1);
+    }
+  { const size_t n = (size_t) ((NB_hi - NB_lo + 1) & 0x7fff), w = n + 1;
+    size_t a, b;
+    NP = (unsigned char *) calloc(n * n, 1);
+    NS = (long *) calloc(w * w, sizeof(long));
+    for (i = 0; i < nl; i++)
+      { size_t sl;
+        const int a = block_no(ltok[i][first0], &sl);
+        for (j = first0 + 1; j < lntok[i]; j++)
+          { const int b = block_no(ltok[i][j], &sl);
+            if (!NP[NIDX(a, b)])
+              { NP[NIDX(a, b)] = 1;
+                npairs += 1;
+                nself += (a == b);
+              }
+          }
+      }
+    for (a = 0; a < n; a++)
+      for (b = 0; b < n; b++)
+        NS[(a + 1) * w + (b + 1)] = NS[a * w + (b + 1)] + NS[(a + 1) * w + b] - NS[a * w + b] +
+                                    (NP[a * n + b] ? ((a == b) ? 1 : 2) : 0);
+  }
+
+  S = (NodeShared *) mmap(NULL, sizeof(NodeShared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+  if (S == MAP_FAILED)
+    { fprintf(stderr, "daligner: cannot map the shared page\n");
+      exit(1);
+    }
+  memset(S, 0, sizeof(*S));
+  units = (Unit *) calloc((size_t) npairs * NODE_MAXW + 1, sizeof(Unit));
+  if (npairs >= 2 * W)
+    { /* one region per worker, units of up to g subject blocks; g is halved until every worker can expect six units */
+      Region regs[NODE_MAXW], all;
+      int    g = NODE_GROUP, nreg;
+      all.alo = all.blo = NB_lo;  all.ahi = all.bhi = NB_hi;
+      nreg = split_region(all, W, regs);
+      for (;;)
+        { nunits = 0;
+          for (i = 0; i < nreg; i++)
+            { S->first[i] = nunits;
+              nunits += region_units(regs[i], g, units + nunits);
+              S->end[i] = nunits;
+            }
+          if (g == 1 || W == 1 || nunits >= 6 * W)
+            break;
+          g /= 2;
+        }
+      for (i = nreg; i < W; i++)                    /* fewer regions than workers: the others only steal */
+        S->first[i] = S->end[i] = nunits;
+      S->nregions = W;
+    }
+  else
+    { /* too few pairs for the GPUs: single pairs from ONE cursor, cross pairs first, split by B-read range so that every
+         worker gets about two pieces (multi.work_units) */
+      const int ncross = (2 * W + npairs - 1) / npairs, nsf = ncross / 2 > 1 ? ncross / 2 : 1;
+      int a, b, p;
+      for (a = NB_lo; a <= NB_hi; a++)
+        for (b = NB_hi; b >= NB_lo; b--)
+          if (a != b && NP[NIDX(a, b)])
+            for (p = 0; p < ncross; p++)
+              { Unit *u = units + nunits++;
+                u->a = a;  u->b[0] = b;  u->nb = 1;  u->part = p;  u->nparts = ncross;  u->cost = 2;
+              }
+      for (a = NB_lo; a <= NB_hi; a++)
+        if (NP[NIDX(a, a)])
+          for (p = 0; p < nsf; p++)
+            { Unit *u = units + nunits++;
+              u->a = a;  u->b[0] = a;  u->nb = 1;  u->part = p;  u->nparts = nsf;  u->cost = 1;
+            }
+      S->nregions = 1;
+      S->first[0] = 0;  S->end[0] = nunits;
+    }
+  if (o0.verbose)
+    printf("daligner: %d block pairs in %d units over %d GPU worker(s)\n", npairs, nunits, W);
+  if (getenv("DAMAR_NODE_DRYRUN") != NULL)        /* the work list only (tests/test_host.py): region, A block, subject blocks, part */
+    { for (i = 0; i < S->nregions; i++)
+        for (j = S->first[i]; j < S->end[i]; j++)
+          { int k;
+            printf("unit region %d a %d b", i, units[j].a);
+            for (k = 0; k < units[j].nb; k++)
+              printf(" %d", units[j].b[k]);
+            printf(" part %d of %d cost %d\n", units[j].part, units[j].nparts, units[j].cost);
+          }
+      return 0;
+    }
+  fflush(NULL);
+
+  /* ---- the workers: forked before this process has made a single HIP call ---- */
+  for (i = 0; i < W; i++)
+    { pid[i] = fork();
+      if (pid[i] < 0)
+        { fprintf(stderr, "daligner: fork failed\n");
+          ok = 0;
+          W = i;
+          break;
+        }
+      if (pid[i] == 0)
+        { const int rc = node_worker(i, gpus[i], &o0, stem, units, S, cwd);
+          fflush(NULL);
+          exit(rc);
+        }
+    }
+  for (i = 0; i < W; i++)
+    { int st = 0;
+      if (waitpid(pid[i], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
+        { fprintf(stderr, "daligner: the worker on GPU %d failed (%s %d): its units are missing\n", gpus[i],
+                  WIFSIGNALED(st) ? "signal" : "exit code", WIFSIGNALED(st) ? WTERMSIG(st) : WEXITSTATUS(st));
+          ok = 0;
+        }
+    }
+  if (!ok)
+    return 1;
+
+  /* ---- the files of split pairs: every part holds the records of its B-read range, sorted; records of one
+          (aread, bread) pair never span parts, so a merge on the record order restores the unsplit pair's files ---- */
+  { char  lam[] = "LAmerge", db[PATH_MAX];
+    snprintf(db, sizeof(db), "%s", stem);
+    for (i = 0; i < nunits; i++)
+      if (units[i].nparts > 1 && units[i].part == 0)
+        { const Unit *u = units + i;
+          const char *sl = strrchr(stem, '/');
+          const char *root = sl ? sl + 1 : stem;
+          int side;
+          for (side = 0; side < (u->a == u->b[0] ? 1 : 2); side++)
+            { const int x = side ? u->b[0] : u->a, y = side ? u->a : u->b[0];
+              char *d = damar_get_dir(o0.runid, x), rel[PATH_MAX], out[PATH_MAX];
+              char *argv[NODE_MAXW + 8];
+              char  srcs[NODE_MAXW][PATH_MAX];
+              int   na = 0, p;
+              snprintf(rel, sizeof(rel), "%s/%s.%d.%s.%d.las", d, root, x, root, y);
+              snprintf(out, sizeof(out), "%s/%s", cwd, rel);
+              argv[na++] = lam;  argv[na++] = db;  argv[na++] = out;
+              for (p = 0; p < u->nparts; p++)
+                { char pd[PATH_MAX];
+                  struct stat sb;
+                  part_dir(pd, sizeof(pd), cwd, u->a, u->b[0], p, u->nparts);
+                  snprintf(srcs[p], sizeof(srcs[p]), "%s/%s", pd, rel);
+                  if (stat(srcs[p], &sb) == 0)
+                    argv[na++] = srcs[p];
+                }
+              argv[na] = NULL;
+              if (na > 3)
+                { char dd[PATH_MAX];
+                  snprintf(dd, sizeof(dd), "%s/%s", cwd, d);
+                  mkdir_p(dd);
+                  ok = wait_ok(spawn_merge(argv), "LAmerge of the parts of a split block pair") && ok;
+                }
+              free(d);
+            }
+        }
+    if (S->nregions == 1 && ok)
+      { char pd[PATH_MAX];
+        snprintf(pd, sizeof(pd), "%s/_parts", cwd);
+        remove_tree(pd);
+      }
+    /* ---- -L: the plan's own LAmerge lines, the step that follows daligner in every plan, W at a time ---- */
+    if (base->lamerge && ok)
+      { pid_t run[NODE_MAXW];
+        int   nrun = 0;
+        for (i = 0; i < nm; i++)
+          { mtok[i][0] = lam;
+            if (nrun == W)
+              { int q;
+                for (q = 0; q < nrun; q++)
+                  ok = wait_ok(run[q], "LAmerge") && ok;
+                nrun = 0;
+              }
+            run[nrun++] = spawn_merge(mtok[i]);
+          }
+        for (i = 0; i < nrun; i++)
+          ok = wait_ok(run[i], "LAmerge") && ok;
+      }
+  }
+  if (o0.verbose || getenv("DAMAR_CLIPROF"))
+    { fprintf(stderr, "daligner: %d block pairs, %d units, %d GPU worker(s), %.2f s:", npairs, nunits, W, (wall_ms() - t0) * 1e-3);
+      for (i = 0; i < W; i++)
+        fprintf(stderr, " [gpu %d: %d units (%d stolen), %d index builds, %.2f s]", gpus[i], S->stat[i].units, S->stat[i].stolen,
+                S->stat[i].builds, S->stat[i].wall_ms * 1e-3);
+      fprintf(stderr, "\n");
+    }
+  return ok ? 0 : 1;
 }

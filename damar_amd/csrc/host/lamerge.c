@@ -121,7 +121,11 @@ static void usage(const char *prog)
 { fprintf(stderr, "Usage:\t%s\t[-hksv] [-n numFiles(8)] <db> <out.las> [<directory>| <in.1.las in.2.las ...>]\n", prog);
 }
 
+#ifdef LAMERGE_AS_LIB       /* linked into the daligner driver: its node scheduler merges in a forked child, without an exec */
+int lamerge_main(int argc, char *argv[])
+#else
 int main(int argc, char *argv[])
+#endif
 { char **files = NULL;
   int    nfiles = 0, cap = 0, c, i, tspace = -1;
   const char *out;

@@ -301,3 +301,146 @@ def test_gpu_cli_plan_mode_evicts_and_rereads_blocks(gpu, tmp_path):
                 assert filecmp.cmp(os.path.join(dp, f), os.path.join(g, rel), shallow=False), rel
                 n += 1
     assert n == nb * nb
+
+
+@pytest.mark.parametrize("name,ngpu", [("tiny2", 2), ("prod", 2), ("tiny2", 5)])
+def test_gpu_cli_node_mode_two_workers_sharing_the_gpu_equals_reference_golden(gpu, tmp_path, name, ngpu):
+    """`daligner -P <plan> -G<n>` (dalign/daligner.c:958 + the work list of HPCdaligner.c:628-788, for one node): the parent
+    forks n workers before any HIP call, here all on GPU 0 (DAMAR_SHARE_GPU=1); with more workers than half the block
+    pairs (tiny2 has 3 pairs: -G2 and -G5 both) the pairs are split by B-read range and the parent merges the parts; -L
+    also runs the plan's LAmerge line.  Files equal the reference's golden files, part directories are gone."""
+    import subprocess
+    from conftest import read_case, link_db, compare_las
+    from damar_amd import api
+    case = read_case(name)
+    work = str(tmp_path)
+    link_db(case["dbdir"], work)
+    dir1 = [os.path.dirname(rel) for rel in case["las"] if os.path.basename(rel).startswith("G.1.")][0]     # (-r<run> names it)
+    with open(os.path.join(work, "plan.txt"), "w") as f:
+        f.write("# Daligner jobs (%d)\n" % len(case["lines"]))
+        for a, bs in case["lines"]:
+            f.write("daligner %s G.%s %s\n" % (" ".join(case["opts"]), a, " ".join("G." + b for b in bs)))
+        f.write("# merge jobs\nLAmerge -n 8 G.db G.1.las %s\n" % dir1)
+    env = dict(os.environ, DAMAR_SHARE_GPU="1")
+    subprocess.run([api.daligner_binary(), "-P", "plan.txt", "-G%d" % ngpu, "-L"], cwd=work, check=True, env=env,
+                   stdout=subprocess.DEVNULL)
+    assert compare_las(case, work) == []
+    assert not os.path.exists(os.path.join(work, "_parts"))
+    merged = os.path.join(work, "G.1.las")
+    assert os.path.getsize(merged) > 12
+    # the merged block file holds exactly the records of the block's directory
+    from damar_amd import driver
+    n_dir = sum(driver.las_stats(os.path.join(work, dir1, f))[0] for f in os.listdir(os.path.join(work, dir1)))
+    assert driver.las_stats(merged)[0] == n_dir
+
+
+def test_gpu_cli_node_mode_config3_regions_and_stealing_equal_reference(gpu, tmp_path):
+    """Config 3 (17 blocks, 153 block pairs) through `daligner -P plan -G3` with the three workers sharing GPU 0: one region
+    of the plan's triangle per worker, cursors in the shared page, leftovers stolen; all 289 files against the reference's md5s."""
+    import subprocess
+    from damar_amd import api
+    d = str(tmp_path)
+    nb = api.sim_write_db(d, "SIM", 4.6, coverage=87., seed=3, block_mbp=25)
+    assert nb == 17
+    with open(os.path.join(d, "plan.txt"), "w") as f:
+        for a in range(1, nb + 1):
+            f.write("daligner -k14 -j16 SIM.%d %s\n" % (a, " ".join("SIM.%d" % b for b in range(a, 0, -1))))
+    r = subprocess.run([api.daligner_binary(), "-v", "-P", "plan.txt", "-G3"], cwd=d, env=dict(os.environ, DAMAR_SHARE_GPU="1"),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "153 block pairs" in r.stderr
+    bad = []
+    for ln in open(os.path.join(GOLDEN, "config3_ref_md5.txt")):
+        if ln.startswith("#"):
+            continue
+        m, f = ln.split()
+        if _md5(os.path.join(d, f)) != m:
+            bad.append(f)
+    assert not bad, bad[:5]
+
+
+def test_gpu_cli_node_mode_reports_a_failed_worker(gpu, tmp_path):
+    """A worker that cannot do its units (a block of the plan does not exist) exits non-zero; the parent says so and fails."""
+    import subprocess
+    from conftest import read_case, link_db
+    from damar_amd import api
+    case = read_case("tiny2")
+    work = str(tmp_path)
+    link_db(case["dbdir"], work)
+    with open(os.path.join(work, "plan.txt"), "w") as f:
+        f.write("daligner -k14 G.1 G.1\ndaligner -k14 G.2 G.2 G.1\ndaligner -k14 G.7 G.7 G.2 G.1\n")
+    r = subprocess.run([api.daligner_binary(), "-P", "plan.txt", "-G2"], cwd=work, env=dict(os.environ, DAMAR_SHARE_GPU="1"),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0
+    assert "failed" in r.stderr
+
+
+def test_gpu_two_processes_on_one_gpu_region_queue_and_split_pair(gpu, tmp_path):
+    """Two ranks (gloo, both on GPU 0) on a config-3-style database cut to 6 blocks: the plan's 21 pairs from the region
+    cursors in the job's store (damar_amd/multi.py), then ONE pair split by B-read range between the two ranks and merged;
+    the union of the files equals the CPU oracle's, file by file."""
+    import filecmp
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from damar_amd import api
+    g, o = os.path.join(str(tmp_path), "gpu"), os.path.join(str(tmp_path), "cpu")
+    os.makedirs(g)
+    os.makedirs(o)
+    nb = api.sim_write_db(g, "S", 0.7, coverage=30., seed=31, block_mbp=3, max_blocks=6)
+    assert nb == 6
+    for f in ("S.db", ".S.idx", ".S.bps"):
+        os.symlink(os.path.join(g, f), os.path.join(o, f))
+    script = os.path.join(str(tmp_path), "rank.py")
+    with open(script, "w") as f:
+        f.write('''
+import os, sys
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from damar_amd import api, multi
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+api.lib().damar_hip_init(0)
+db, nb, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+store = multi.default_store()
+runner = multi.GpuRunner(dict(j=4))
+units = multi.work_units(nb, world)                       # regions: one per rank
+assert units.parts is not None and len(units.parts) == world
+# keep the last cross pair of the plan out of the regions: it is run split by B-read range below
+split = (nb, 1)
+keep = multi.Units(u for u in units if not (u[0] == split[0] and split[1] in u[1]))
+cut = [u for u in units if u[0] == split[0] and split[1] in u[1]]
+keep.parts, at = [], 0
+for first, end in units.parts:
+    n = sum(1 for u in units[first:end] if not (u[0] == split[0] and split[1] in u[1]))
+    keep.parts.append((at, at + n)); at += n
+rest = multi.Units((a, tuple(b for b in bs if b != split[1]), 0, 1) for a, bs, _, _ in cut if len(bs) > 1)
+mine = multi.run_queue(db, keep, out, multi.make_queue(store, "main", keep, rank), runner)
+more = multi.Units(list(rest) + [(split[0], split[1], p, world) for p in range(world)])
+mine += multi.run_queue(db, more, out, multi.make_queue(store, "more", more, rank), runner)
+runner.finish()
+dist.barrier()
+multi.merge_parts(db, more, out, rank, world)
+dist.barrier()
+print("rank", rank, "ran", len(mine), "units", flush=True)
+assert len(mine) > 0
+runner.close()
+dist.destroy_process_group()
+''' % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", script, os.path.join(g, "S"), str(nb), g], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "rank 0 ran" in r.stdout and "rank 1 ran" in r.stdout
+    for a in range(1, nb + 1):
+        subprocess.run([os.path.join(ROOT, "oracle", "oracle_daligner"), "-k14", "-j4", "S.%d" % a] + ["S.%d" % b for b in range(a, 0, -1)],
+                       cwd=o, check=True, stdout=subprocess.DEVNULL)
+    n = 0
+    for dp, _, fs in os.walk(o):
+        for f in fs:
+            if f.endswith(".las"):
+                rel = os.path.relpath(os.path.join(dp, f), o)
+                assert filecmp.cmp(os.path.join(dp, f), os.path.join(g, rel), shallow=False), rel
+                n += 1
+    assert n == nb * nb

@@ -282,3 +282,36 @@ def test_lamerge_equals_reference(built, tmp_path):
         assert hashlib.md5(open(os.path.join(w, "m.las"), "rb").read()).hexdigest() == md5, ln
         n += 1
     assert n >= 8
+
+
+@pytest.mark.parametrize("nb,ngpu", [(17, 3), (4, 8), (24, 8), (255, 8), (2, 5)])
+def test_node_scheduler_work_list_covers_every_block_pair_once(built, tmp_path, nb, ngpu):
+    """`daligner -P plan -G<n>` (host/daligner.c node_main; dalign/daligner.c:958 under HPCdaligner.c:628-788): the work list the
+    parent builds before it forks -- every pair of the plan exactly once (split pairs: every part once), regions of about
+    equal cost, one region when pairs are split.  DAMAR_NODE_DRYRUN prints it instead of forking (no GPU needed)."""
+    import subprocess
+    from damar_amd import api
+    work = str(tmp_path)
+    with open(os.path.join(work, "plan.txt"), "w") as f:
+        for a in range(1, nb + 1):
+            f.write("daligner -k14 -j16 SIM.%d %s\n" % (a, " ".join("SIM.%d" % b for b in range(a, 0, -1))))
+    r = subprocess.run([api.daligner_binary(), "-P", "plan.txt", "-G%d" % ngpu], cwd=work, env=dict(os.environ, DAMAR_NODE_DRYRUN="1"),
+                       stdout=subprocess.PIPE, text=True, check=True)
+    pairs, cost = {}, {}
+    for ln in r.stdout.splitlines():
+        t = ln.split()
+        reg, a = int(t[2]), int(t[4])
+        bs = [int(x) for x in t[6:t.index("part")]]
+        part, nparts = int(t[t.index("part") + 1]), int(t[t.index("of") + 1])
+        assert 1 <= len(bs) <= 8 and all(b <= a for b in bs)
+        for b in bs:
+            pairs.setdefault((a, b), []).append((part, nparts))
+        cost[reg] = cost.get(reg, 0) + int(t[-1])
+    assert len(pairs) == nb * (nb + 1) // 2
+    for v in pairs.values():
+        assert sorted(p for p, _ in v) == list(range(v[0][1]))
+    npairs = nb * (nb + 1) // 2
+    if npairs >= 2 * ngpu:
+        assert len(cost) == ngpu and max(cost.values()) <= 1.35 * min(cost.values())
+    else:
+        assert len(cost) == 1 and max(n for v in pairs.values() for _, n in v) > 1
