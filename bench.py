@@ -220,9 +220,10 @@ def cpu_baseline(dbdir, root, nblocks, aligned_bp):
             "wall_s": res}
 
 
-def end_to_end(dbdir, root, nblocks, md5_name, repeats=3):
-    """SURVEY 8(d)'s wall: DB on tmpfs -> last .las closed, through the C driver in plan mode (one process,
-    cold: HIP start, block reads, reverse complements, PCIe, every index build).  Best of `repeats`; run before this
+def end_to_end(dbdir, root, nblocks, md5_name, repeats=3, gpus=1):
+    """SURVEY 8(d)'s wall: DB on tmpfs -> last .las closed, through the C driver in plan mode (one process per GPU,
+    cold: HIP start, block reads, reverse complements, PCIe, every index build); on several GPUs `daligner -P plan -G<n>`,
+    the node scheduler of host/daligner.c.  Best of `repeats`; on one GPU run before this
     process puts its own blocks into HBM (`value` is filled in once the step has said how many bp were aligned)."""
     exe = os.path.join(ROOT, "damar_amd", "bin", "daligner")
     best, chk = None, None
@@ -233,7 +234,8 @@ def end_to_end(dbdir, root, nblocks, md5_name, repeats=3):
             with open(os.path.join(work, "plan.txt"), "w") as f:
                 f.write(plan_text(root, nblocks))
             t0 = time.time()
-            subprocess.run([exe, "-P", "plan.txt"], cwd=work, check=True, stdout=subprocess.DEVNULL)
+            subprocess.run([exe, "-P", "plan.txt"] + (["-G%d" % gpus] if gpus > 1 else []), cwd=work, check=True,
+                           stdout=subprocess.DEVNULL)
             dt = time.time() - t0
             if best is None or dt < best:
                 best = dt
@@ -242,8 +244,9 @@ def end_to_end(dbdir, root, nblocks, md5_name, repeats=3):
         finally:
             shutil.rmtree(work, ignore_errors=True)
     return {"value": None, "unit": "aligned bp/s", "wall_s": best,
-            "what": "damar_amd/bin/daligner -P <HPCdaligner plan>: process start, DB read from tmpfs, complement, "
-                    "upload, index builds, all block pairs, sorted .las on tmpfs (best of %d cold runs)" % repeats,
+            "what": "damar_amd/bin/daligner -P <HPCdaligner plan>%s: process start, DB read from tmpfs, complement, "
+                    "upload, index builds, all block pairs, sorted .las on tmpfs (best of %d cold runs)"
+                    % (" -G%d (one forked worker per GPU, regions + stealing)" % gpus if gpus > 1 else "", repeats),
             "identical_to_reference": None if chk is None else chk["identical"]}
 
 
@@ -575,6 +578,16 @@ def main():
                 shutil.rmtree(o1, ignore_errors=True)
             barrier()
 
+        if world > 1 and not args.no_e2e:
+            # the contract's wall on N GPUs: the C driver's node mode (rank 0 starts it, the other ranks wait; the
+            # workers it forks share the GPUs with the idle ranks of this job)
+            barrier()
+            if rank == 0:
+                try:
+                    e2e = end_to_end(work, "SIM", nblocks, cfg["md5"], repeats=2, gpus=world)
+                except Exception as e:
+                    e2e = {"error": str(e)}
+            barrier()
         if rank == 0:
             steps = max(1, args.steps)
             nrec, bp, trace_vals = sum_las(last_out)

@@ -11,8 +11,9 @@
  * (dalign/HPCdaligner.c:628-788) in ONE process.  The reference runs one process per line
  * (daligner.c:662-1077), so every line reads its blocks again and sorts their k-mers again; here a block
  * is read, reverse-complemented, uploaded and indexed once and stays resident (HBM: 1.25 B per base and
- * strand + 8 B per k-mer + the prefix table) for all the lines that name it, least recently used blocks
- * released beyond DAMAR_PLAN_BLOCKS (default 64).  Options in front of -P apply to every line; a line's own
+ * strand + 8 B per k-mer) for all the lines that name it; least recently used idle blocks are released beyond
+ * DAMAR_PLAN_BLOCKS blocks (default 64) or beyond a byte budget (DAMAR_PLAN_GB, default 55 % of the GPU's memory: the
+ * seed arenas and the alignment scratch need the rest).  Options in front of -P apply to every line; a line's own
  * options are parsed on top of them.  Output files are those of the separate commands.
  *
  * Node mode, `daligner [options] -P <plan> -G <n | i,j,...> [-L]`: the plan's block pairs over several GPUs of one node --
@@ -560,6 +561,46 @@ static void pblock_flush_indexes(void)             /* the filter parameters chan
         }
 }
 
+/* HBM the table's blocks hold (bases of both strands and their indexes) against the byte budget: least recently used
+   idle blocks go first.  A block that is needed again is read, complemented and indexed again. */
+static uint64_t PB_budget = 0;
+
+static uint64_t pblock_bytes(const PBlock *b)
+{ return damar_block_bytes(b->dev[0]) + damar_block_bytes(b->dev[1]) + damar_index_bytes(b->idx[0]) + damar_index_bytes(b->idx[1]); }
+
+static void pblock_release(PBlock *b);
+
+static void pblock_trim(void)
+{ if (PB_budget == 0)
+    { uint64_t fr = 0, tot = 0;
+      damar_hbm_info(&fr, &tot);
+      PB_budget = (uint64_t) (.55 * (double) tot);
+      if (getenv("DAMAR_PLAN_GB") != NULL && atof(getenv("DAMAR_PLAN_GB")) > 0)
+        PB_budget = (uint64_t) (atof(getenv("DAMAR_PLAN_GB")) * 1073741824.);
+    }
+  for (;;)
+    { uint64_t sum = 0;
+      int i, v = -1;
+      for (i = 0; i < PB_n; i++)
+        if (PB[i].ready && PB[i].name != NULL)
+          { sum += pblock_bytes(PB + i);
+            if (!PB[i].busy && (PB[i].dev[0] || PB[i].dev[1] || PB[i].idx[0] || PB[i].idx[1]) && (v < 0 || PB[i].used < PB[v].used))
+              v = i;
+          }
+      if (sum <= PB_budget || v < 0)
+        return;
+      damar_async_drain();                          /* the host tail may still read its bases */
+      { int c;                                      /* device side only: the host copy stays for a cheap return */
+        for (c = 0; c < 2; c++)
+          { if (PB[v].idx[c] != NULL) damar_index_free(PB[v].idx[c]);
+            if (PB[v].dev[c] != NULL) damar_block_free(PB[v].dev[c]);
+            PB[v].idx[c] = NULL;  PB[v].dev[c] = NULL;
+          }
+      }
+      damar_pool_trim();                            /* (the freed index went to the library's pool: really give it back) */
+    }
+}
+
 static PBlock *pblock_get(const char *name, const Opts *o)
 { int i;
   for (i = 0; i < PB_n; i++)
@@ -615,6 +656,7 @@ static damar_dev_index *pblock_index(PBlock *b, int comp)
       b->idx[comp] = damar_index_build(b->dev[comp], 0, &b->ilen[comp]);
       P_ms[1] += wall_ms() - t0;
       PB_builds += 1;
+      pblock_trim();
     }
   return b->idx[comp];
 }
@@ -626,7 +668,15 @@ static int PS_n, PS_cap;
 
 /* the queued tails and writes still use the spec: it is released when the plan is done (no drain per line) */
 static void plan_keep_spec(Align_Spec *spec)
-{ if (PS_n >= PS_cap)
+{ if (PS_n >= 512)                                  /* a long plan: every 512 block pairs the queue is drained and the specs
+                                                      (tables and overlap buffers each) are released */
+    { int i;
+      damar_async_drain();
+      for (i = 0; i < PS_n; i++)
+        Free_Align_Spec(PS[i]);
+      PS_n = 0;
+    }
+  if (PS_n >= PS_cap)
     { PS_cap = 2 * PS_cap + 64;
       PS = (Align_Spec **) realloc(PS, sizeof(Align_Spec *) * (size_t) PS_cap);
     }
@@ -641,10 +691,15 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
   char   *aroot;
   int     k;
 
-  if (have_last && (last.kmer != o->kmer || last.maxreps != o->maxreps || last.biased != o->biased || last.mtop != o->mtop))
+  int masks_differ = have_last && last.mtop != o->mtop;
+  if (have_last && !masks_differ)
+    for (k = 0; k < o->mtop; k++)
+      if (strcmp(last.mask[k], o->mask[k]) != 0)
+        masks_differ = 1;
+  if (have_last && (last.kmer != o->kmer || last.maxreps != o->maxreps || last.biased != o->biased || masks_differ))
     { damar_async_drain();
       pblock_flush_indexes();
-      if (last.mtop != o->mtop)                   /* other mask tracks: the blocks themselves are stale
+      if (masks_differ)                           /* other mask tracks: the blocks themselves are stale
                                                      (plan_main starts no reader thread for such a plan) */
         { while (PB_n > 0)
             pblock_release(PB + --PB_n);

@@ -693,7 +693,33 @@ extern "C" void damar_index_free(damar_dev_index *ix)
   free(ix);
 }
 
-/* HBM held by one index (what its three buffers took from the pool): lets a scheduler bound residency */
+/* Residency figures for a scheduler that keeps blocks and indexes in HBM (daligner -P, driver.Plan): free and total bytes
+   of the device, the bytes one resident block holds, and a way to hand the pool of parked index buffers back. */
+extern "C" void damar_hbm_info(uint64_t *free_bytes, uint64_t *total_bytes)
+{ ensure_init();
+  size_t f = 0, t = 0;
+  HIP_CHECK(hipMemGetInfo(&f, &t));
+  if (free_bytes)  *free_bytes = (uint64_t) f + (uint64_t) DP_bytes;       /* (parked buffers are as good as free) */
+  if (total_bytes) *total_bytes = (uint64_t) t;
+}
+
+extern "C" uint64_t damar_block_bytes(const damar_dev_block *b)
+{ if (b == NULL)
+    return 0;
+  const uint64_t tot = b->d.total;
+  return tot + 128 + (tot >> 2) + 64 + sizeof(u32) * ((uint64_t) b->nreads + 1) + sizeof(u32) * ((tot >> COARSE_SHIFT) + 2);
+}
+
+extern "C" void damar_pool_trim(void)
+{ finish_all();
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  for (size_t i = 0; i < DP_free.size(); i++)
+    HIP_CHECK(hipFree(DP_free[i].p));
+  DP_free.clear();
+  DP_bytes = 0;
+}
+
+/* HBM held by one index (what its buffers took from the pool): lets a scheduler bound residency */
 extern "C" uint64_t damar_index_bytes(const damar_dev_index *ix)
 { return ix == NULL ? 0 : (uint64_t) (ix->codes_bytes + ix->pos_bytes); }
 

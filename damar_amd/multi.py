@@ -71,9 +71,34 @@ class Units(list):
     parts = None
 
 
+_SAT = {}
+
+
+def _sat(n):
+    """Summed-area table of pair_cost over the plan's triangle (b <= a) of n blocks: S[a][b] = cost of {1..a} x {1..b}."""
+    t = _SAT.get(n)
+    if t is None:
+        t = [[0] * (n + 1) for _ in range(n + 1)]
+        for a in range(1, n + 1):
+            row, up = t[a], t[a - 1]
+            for b in range(1, n + 1):
+                row[b] = up[b] + row[b - 1] - up[b - 1] + (pair_cost(a, b) if b <= a else 0)
+        _SAT[n] = t
+    return t
+
+
+_SAT_N = [0]
+
+
 def _region_cost(reg):
+    """Cost of the pairs {alo <= a <= ahi, blo <= b <= min(a, bhi)}, O(1) (the loops cost 10 s at 255 blocks)."""
     alo, ahi, blo, bhi = reg
-    return sum(pair_cost(a, b) for a in range(alo, ahi + 1) for b in range(blo, min(a, bhi) + 1))
+    if alo > ahi or blo > bhi:
+        return 0
+    n = max(_SAT_N[0], ahi, bhi)
+    _SAT_N[0] = n
+    t = _sat(n)
+    return t[ahi][bhi] - t[alo - 1][bhi] - t[ahi][blo - 1] + t[alo - 1][blo - 1]
 
 
 def _split_region(reg, k):

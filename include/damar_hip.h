@@ -54,6 +54,9 @@ typedef struct damar_dev_index damar_dev_index;
 damar_dev_index *damar_index_build(damar_dev_block *blk, int own_block, int *len);
 void             damar_index_free(damar_dev_index *idx);
 uint64_t         damar_index_bytes(const damar_dev_index *idx);   /* HBM the index holds, for residency caps */
+uint64_t         damar_block_bytes(const damar_dev_block *blk);   /* HBM a resident block holds (bases, packed bases, tables) */
+void             damar_hbm_info(uint64_t *free_bytes, uint64_t *total_bytes);   /* of the selected GPU (hipMemGetInfo) */
+void             damar_pool_trim(void);                            /* release the library's parked index buffers */
 /* Test hook: copy the index back as reference-layout KmerPos records
  * {uint64 code; int rpos; int read} (filter.c:121-126), out must hold *len records. */
 void             damar_index_download(const damar_dev_index *idx, void *out);

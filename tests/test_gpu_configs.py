@@ -270,9 +270,11 @@ def test_gpu_match_batch_with_different_a_blocks_in_one_call(gpu, tmp_path, asyn
     plan2.finish()
 
 
-def test_gpu_cli_plan_mode_evicts_and_rereads_blocks(gpu, tmp_path):
-    """A 4-block plan through `daligner -P` with room for 2 blocks only (DAMAR_PLAN_BLOCKS=2): every line's B
-    blocks push each other out and are read, complemented and indexed again; files equal the CPU oracle's."""
+@pytest.mark.parametrize("cap", [{"DAMAR_PLAN_BLOCKS": "2"}, {"DAMAR_PLAN_GB": "0.02"}])
+def test_gpu_cli_plan_mode_evicts_and_rereads_blocks(gpu, tmp_path, cap):
+    """A 4-block plan through `daligner -P` with room for 2 blocks only (DAMAR_PLAN_BLOCKS=2), or with a byte budget that
+    one block's strands and indexes fill (DAMAR_PLAN_GB: the idle blocks' device copies and indexes are released, the host
+    copies stay): every line's B blocks push each other out and are uploaded / indexed again; files equal the CPU oracle's."""
     import filecmp
     import subprocess
     from conftest import ROOT
@@ -288,8 +290,10 @@ def test_gpu_cli_plan_mode_evicts_and_rereads_blocks(gpu, tmp_path):
     with open(os.path.join(g, "plan.txt"), "w") as f:
         for a, bs in lines:
             f.write("daligner -k14 -j4 S.%d %s\n" % (a, " ".join("S.%d" % b for b in bs)))
-    subprocess.run([api.daligner_binary(), "-P", "plan.txt"], cwd=g, check=True, stdout=subprocess.DEVNULL,
-                   env=dict(os.environ, DAMAR_PLAN_BLOCKS="2"))
+    r = subprocess.run([api.daligner_binary(), "-P", "plan.txt"], cwd=g, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                       text=True, env=dict(os.environ, DAMAR_CLIPROF="1", **cap))
+    builds = int(r.stderr.split(" index builds")[0].split()[-1])
+    assert builds > 2 * nb                         # (more than once per block and strand: blocks came back)
     n = 0
     for a, bs in lines:
         subprocess.run([os.path.join(ROOT, "oracle", "oracle_daligner"), "-k14", "-j4", "S.%d" % a] + ["S.%d" % b for b in bs],
