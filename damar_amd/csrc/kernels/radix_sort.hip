@@ -33,14 +33,10 @@
                                                 look-back words) or 256 (one wavefront per SIMD: the shape that still finds room
                                                 on a CU whose register file is mostly held by a resident report launch) */
 #endif
-#ifndef OS_ITEMS
-#define OS_ITEMS   16                        /* keys per thread       */
-#endif
 #ifndef OS_MINW
 #define OS_MINW    4                         /* wavefronts per SIMD the pass kernel is compiled for */
 #endif
-#define OS_MINTILE (256 * OS_ITEMS)          /* the smaller of the two tile shapes (workspace bound) */
-#define OS_WSPAN   (64 * OS_ITEMS)           /* contiguous items owned by one wavefront */
+#define OS_MINTILE (256 * 8)                 /* the smallest tile shape (workspace bound) */
 #define OS_MAXPASS 8
 
 #define OH_COPIES  8                         /* copies of every histogram bin, chosen by lane & 7 */
@@ -128,13 +124,13 @@ void onesweep_hist(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u
  * (wavefront, round, lane) order is input order and the ranks below make the pass stable.
  * HV: a u32 payload travels with the key.  SPLIT: the last pass of the packed k-mer index -- the key's high word
  * goes to ohi, its low word to vout (no key array is written). */
-template <typename KeyT, typename GT, bool HV, bool SPLIT, int TH>
-__global__ __launch_bounds__(TH, OS_MINW)
+template <typename KeyT, typename GT, bool HV, bool SPLIT, int TH, int IT>
+__global__ __launch_bounds__(TH, (IT <= 8 ? 8 : OS_MINW))      /* the small shape asks for <= 64 VGPRs: two wavefronts per SIMD beside a report launch */
 void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, KeyT *__restrict__ kout,
                    u32 *__restrict__ vout, u32 *__restrict__ ohi, u64 n, int shift, u32 mask,
                    const u32 *__restrict__ ghist, GT *__restrict__ lb, GT *__restrict__ lbclear,
                    u32 *__restrict__ ctr, u32 *__restrict__ err)
-{ constexpr int OS_TILE = TH * OS_ITEMS, OS_WAVES = TH / 64;
+{ constexpr int OS_TILE = TH * IT, OS_WAVES = TH / 64, OS_WSPAN = 64 * IT;
   /* keys and payload are staged through the SAME buffer one after the other */
   __shared__ KeyT skey[OS_TILE];
   u32 *const sval = (u32 *) skey;
@@ -157,15 +153,15 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
   const u64 tbase = (u64) tile * OS_TILE;
   const u64 wbase = tbase + (u64) w * OS_WSPAN;
 
-  KeyT key[OS_ITEMS];
-  u32  rnk[OS_ITEMS];
+  KeyT key[IT];
+  u32  rnk[IT];
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; r++)
+  for (int r = 0; r < IT; r++)
     { const u64 i = wbase + (u64) r * 64 + l;
       key[r] = (i < n) ? kin[i] : (KeyT) 0;
     }
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; r++)
+  for (int r = 0; r < IT; r++)
     { const u64  i  = wbase + (u64) r * 64 + l;
       const bool ok = i < n;
       const u32  d  = (u32) (key[r] >> shift) & mask;
@@ -206,7 +202,7 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
   __syncthreads();
 
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; r++)
+  for (int r = 0; r < IT; r++)
     { const u64 i = wbase + (u64) r * 64 + l;
       if (i < n)
         { const u32 d  = (u32) (key[r] >> shift) & mask;
@@ -244,9 +240,9 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
   __syncthreads();
 
   const u32 have = (n - tbase < (u64) OS_TILE) ? (u32) (n - tbase) : (u32) OS_TILE;
-  u32 gdst[HV ? OS_ITEMS : 1];                                 /* where this thread's output positions go (n < 2^32) */
+  u32 gdst[HV ? IT : 1];                                 /* where this thread's output positions go (n < 2^32) */
 #pragma unroll
-  for (int q = 0; q < OS_ITEMS; q++)
+  for (int q = 0; q < IT; q++)
     { const u32 i = threadIdx.x + (u32) q * TH;
       if (i < have)
         { const KeyT k = skey[i];
@@ -264,14 +260,14 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
   if (HV)
     { __syncthreads();
 #pragma unroll
-      for (int r = 0; r < OS_ITEMS; r++)
+      for (int r = 0; r < IT; r++)
         { const u64 i = wbase + (u64) r * 64 + l;
           if (i < n)                                           /* (the payload is loaded only now: registers) */
             sval[rnk[r]] = vin[i];
         }
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < OS_ITEMS; q++)
+      for (int q = 0; q < IT; q++)
         { const u32 i = threadIdx.x + (u32) q * TH;
           if (i < have)
             vout[gdst[q]] = sval[i];
@@ -283,8 +279,8 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
 
 static int G_sort_threads = 0;              /* 0: not chosen yet */
 
-/* tile shape of the sorts to come: 256 or 512 threads per workgroup */
-void damar_sort_set_threads(int threads) { G_sort_threads = (threads == 256) ? 256 : 512; }
+/* tile shape of the sorts to come: 512 or 256 threads x 16 keys, or 128 = 256 threads x 8 keys (<= 64 VGPRs) */
+void damar_sort_set_threads(int threads) { G_sort_threads = (threads == 256 || threads == 128) ? threads : 512; }
 
 static int sort_threads(void)
 { if (G_sort_threads == 0)
@@ -301,10 +297,10 @@ size_t damar_sort_workspace_bytes(u64 n)
 
 const u32 *damar_sort_error_word(const void *work) { return (const u32 *) work; }
 
-template <typename KeyT, typename GT, bool HV, int TH>
+template <typename KeyT, typename GT, bool HV, int TH, int IT>
 static void onesweep_passes(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lobit, int hibit, u32 *ohi, u32 *olo,
                             char *ws, hipStream_t st)
-{ constexpr int OS_TILE = TH * OS_ITEMS;
+{ constexpr int OS_TILE = TH * IT;
   const u32 ntiles = (u32) ((n + OS_TILE - 1) / OS_TILE);
   const int npass  = (hibit - lobit + 7) / 8;
   const int lastb  = hibit - lobit - 8 * (npass - 1);
@@ -324,11 +320,11 @@ static void onesweep_passes(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lob
       u32  *vi = side ? v1 : v0, *vo = side ? v0 : v1;
       const u32 mask = last ? (1u << lastb) - 1u : 0xffu;
       if (last && ohi != NULL)
-        hipLaunchKernelGGL((onesweep_pass<KeyT, GT, false, true, TH>), dim3(ntiles), dim3(TH), 0, st,
+        hipLaunchKernelGGL((onesweep_pass<KeyT, GT, false, true, TH, IT>), dim3(ntiles), dim3(TH), 0, st,
                            ki, (const u32 *) NULL, (KeyT *) NULL, olo, ohi, n, lobit + 8 * p, mask,
                            ghist + 256 * p, lbr[side], lbr[side ^ 1], ctr + p, err);
       else
-        hipLaunchKernelGGL((onesweep_pass<KeyT, GT, HV, false, TH>), dim3(ntiles), dim3(TH), 0, st,
+        hipLaunchKernelGGL((onesweep_pass<KeyT, GT, HV, false, TH, IT>), dim3(ntiles), dim3(TH), 0, st,
                            ki, vi, ko, vo, (u32 *) NULL, n, lobit + 8 * p, mask,
                            ghist + 256 * p, lbr[side], lbr[side ^ 1], ctr + p, err);
     }
@@ -347,14 +343,16 @@ static int onesweep_impl(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lobit,
       fflush(NULL);
       _exit(1);
     }
-  const bool big = sort_threads() == 512;
+  const int shape = sort_threads();
   if (n < (1ull << 30))
-    { if (big) onesweep_passes<KeyT, u32, HV, 512>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
-      else     onesweep_passes<KeyT, u32, HV, 256>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+    { if (shape == 512)      onesweep_passes<KeyT, u32, HV, 512, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+      else if (shape == 256) onesweep_passes<KeyT, u32, HV, 256, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+      else                   onesweep_passes<KeyT, u32, HV, 256, 8>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
     }
   else
-    { if (big) onesweep_passes<KeyT, u64, HV, 512>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
-      else     onesweep_passes<KeyT, u64, HV, 256>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+    { if (shape == 512)      onesweep_passes<KeyT, u64, HV, 512, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+      else if (shape == 256) onesweep_passes<KeyT, u64, HV, 256, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+      else                   onesweep_passes<KeyT, u64, HV, 256, 8>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
     }
   return npass & 1;
 }

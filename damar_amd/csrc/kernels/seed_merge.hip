@@ -408,7 +408,7 @@ __device__ __forceinline__ void merge_sweep_tile(const MergeArgs &m, const Merge
 }
 
 template <typename CodeT>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 8)          /* <= 64 VGPRs: two wavefronts per SIMD still find room beside a resident report launch */
 void merge_sweep(MergeArgs m, const MergeTile *__restrict__ tiles, u32 *__restrict__ tcount, u32 *__restrict__ cnt,
                  u32 *__restrict__ jbg, unsigned long long *__restrict__ gram, u32 ngram)
 { __shared__ __attribute__((aligned(16))) CodeT sb[MT_BCAP + 16 / sizeof(CodeT)];
@@ -426,7 +426,7 @@ void merge_sweep(MergeArgs m, const MergeTile *__restrict__ tiles, u32 *__restri
 /* EMIT: one workgroup per tile of A entries; the tile's hit counts are scanned in LDS, then the tile's hits are dealt
  * out to the threads in order, each finding its A entry by a search of the LDS prefix (no walk over global offsets),
  * so that the seed pairs leave in fully coalesced runs; MT_HITS independent seed pairs per thread are in flight. */
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 8)
 void merge_emit(MergeArgs m, const u32 *__restrict__ cnt, const u32 *__restrict__ jbg, const u32 *__restrict__ toff,
                 u64 nhits, u64 *__restrict__ keys, u32 *__restrict__ vals, u32 *__restrict__ pid)
 { __shared__ u32 loc[MT_A + 1];
