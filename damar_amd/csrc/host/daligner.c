@@ -109,6 +109,11 @@ static double wall_ms(void)
   return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
 }
 #define TIMED(slot, stmt) do { double t0_ = wall_ms(); stmt; P_ms[slot] += wall_ms() - t0_; } while (0)
+static double T_start;                                  /* DAMAR_CLIPROF: when main() was entered */
+static void mark(const char *what)
+{ if (getenv("DAMAR_CLIPROF"))
+    fprintf(stderr, "cli: +%.1f ms %s\n", wall_ms() - T_start, what);
+}
 
 /* ---- B blocks prepared ahead (read_DB + Merge_Tracks + complement_DB of daligner.c:958-1034) ---- */
 typedef struct
@@ -326,6 +331,7 @@ int main(int argc, char *argv[])
   char  **mask;
   int     mtop, i;
 
+  T_start = wall_ms();
   default_opts(&O);
   optind = parse_opts(argc, argv, &O);
   if (O.plan != NULL)
@@ -820,6 +826,7 @@ static void read_plan(const char *planfile, char ****ltok_p, int **lntok_p, int 
 }
 
 static int node_main(const Opts *base, const char *planfile);
+static int PLAN_done_fd = -1;          /* the worker of plan mode writes one byte here when every .las is closed */
 
 static int plan_main(const Opts *base, const char *planfile)
 { char ***ltok = NULL;                 /* the plan's daligner lines, tokenised */
@@ -837,6 +844,40 @@ static int plan_main(const Opts *base, const char *planfile)
   if (getenv("DAMAR_PLAN_BLOCKS") != NULL && atoi(getenv("DAMAR_PLAN_BLOCKS")) >= 2)
     PB_max = atoi(getenv("DAMAR_PLAN_BLOCKS"));
   read_plan(planfile, &ltok, &lntok, &nl, NULL, NULL, NULL);
+
+  /* The work is done by a forked child (this process has not made a HIP call yet); the command returns as soon as the
+     child says that every .las is closed.  What the child still does then -- unmapping tens of GB of HBM and the pinned
+     landing buffers, tearing the HIP context down: a quarter of a second in the kernel driver -- changes nothing on disk
+     and finishes behind the caller's back.  A child that dies before it is done is waited for and reported.
+     DAMAR_PLAN_TIDY=1: one process that releases everything itself (debugging). */
+  if (getenv("DAMAR_PLAN_TIDY") == NULL)
+    { int   pfd[2];
+      pid_t pid;
+      fflush(NULL);
+      if (pipe(pfd) != 0 || (pid = fork()) < 0)
+        { fprintf(stderr, "daligner: cannot fork the worker\n");
+          exit(1);
+        }
+      if (pid > 0)
+        { char c = 0;
+          ssize_t got;
+          close(pfd[1]);
+          do
+            got = read(pfd[0], &c, 1);
+          while (got < 0 && errno == EINTR);
+          if (got == 1)
+            return 0;
+          { int st = 0;
+            waitpid(pid, &st, 0);
+            if (WIFEXITED(st) && WEXITSTATUS(st) != 0)
+              return WEXITSTATUS(st);
+            fprintf(stderr, "daligner: the worker ended before the plan was done\n");
+            return 1;
+          }
+        }
+      close(pfd[0]);
+      PLAN_done_fd = pfd[1];
+    }
 
   /* the block table, and what the reader thread prepares ahead: the blocks in order of first use */
   PB_cap = PB_max + LINE_B + 2;           /* a group of subject blocks and the A block can be busy beyond PB_max */
@@ -894,7 +935,9 @@ static int plan_main(const Opts *base, const char *planfile)
 
   /* The device comes up (a few hundred ms in a cold process) while the reader thread already reads and complements the
      first blocks; it uploads once the flag below is set. */
+  mark("plan parsed, reader threads started");
   select_device(base);
+  mark("device selected (HIP up)");
   if (getenv("DAMAR_PREWARM_GB") && atoi(getenv("DAMAR_PREWARM_GB")) > 0)
     { pthread_t th;                     /* grow the HBM footprint next to reading the first blocks (see damar_prewarm) */
       static int gb;
@@ -914,8 +957,29 @@ static int plan_main(const Opts *base, const char *planfile)
       o.plan = NULL;
       first = parse_opts(lntok[i], ltok[i], &o);
       plan_line(&o, ltok[i][first], ltok[i] + first + 1, lntok[i] - first - 1);
+      if (i == 0) mark("first plan line submitted");
     }
+  mark("last plan line submitted");
   TIMED(5, damar_async_drain());
+  mark("drained: every .las closed");
+  if (getenv("DAMAR_PLAN_TIDY") == NULL)
+    { /* every file is closed; releasing tens of GB of HBM buffer by buffer, joining the threads and tearing the HIP context
+         down costs a tenth of a second of wall time and changes nothing on disk: leave that to process exit */
+      if (getenv("DAMAR_CLIPROF"))
+        { fprintf(stderr, "cli: %d plan lines, %d index builds; wall ms:", nl, PB_builds);
+          for (i = 0; i < 8; i++)
+            fprintf(stderr, " %s=%.1f", P_name[i], P_ms[i]);
+          fprintf(stderr, "\n");
+        }
+      fflush(NULL);
+      if (PLAN_done_fd >= 0)
+        { char c = 1;
+          if (write(PLAN_done_fd, &c, 1) != 1)
+            _exit(1);
+          close(PLAN_done_fd);
+        }
+      _exit(0);
+    }
   while (have_reader > 0)
     pthread_join(reader[--have_reader], NULL);
   for (i = 0; i < PS_n; i++)
@@ -963,6 +1027,7 @@ typedef struct
   int        first[NODE_MAXW], end[NODE_MAXW];
   int        nregions;
   struct { int units, stolen, builds;  double wall_ms; } stat[NODE_MAXW];
+  atomic_int done[NODE_MAXW];            /* the worker has closed its last file (what it does after that is teardown) */
 } NodeShared;
 
 /* "<dir/>root.N" -> N (>= 1) and the length of "<dir/>root"; 0 if the name has no block number */
@@ -1180,15 +1245,9 @@ static int node_worker(int w, int gpu, const Opts *o, const char *stem, const Un
         }
     }
   damar_async_drain();
-  { int i;
-    for (i = 0; i < PS_n; i++)
-      Free_Align_Spec(PS[i]);
-    for (i = 0; i < PB_n; i++)
-      pblock_release(PB + i);
-  }
-  damar_set_async(0);
   S->stat[w].units = nunits;  S->stat[w].stolen = stolen;  S->stat[w].builds = PB_builds;
   S->stat[w].wall_ms = wall_ms() - t0;
+  atomic_store(&S->done[w], 1);
   return 0;
 }
 
@@ -1383,14 +1442,32 @@ static int node_main(const Opts *base, const char *planfile)
           exit(rc);
         }
     }
-  for (i = 0; i < W; i++)
-    { int st = 0;
-      if (waitpid(pid[i], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
-        { fprintf(stderr, "daligner: the worker on GPU %d failed (%s %d): its units are missing\n", gpus[i],
-                  WIFSIGNALED(st) ? "signal" : "exit code", WIFSIGNALED(st) ? WTERMSIG(st) : WEXITSTATUS(st));
-          ok = 0;
-        }
-    }
+  /* a worker is finished when it says so (its files are closed: releasing its HBM and its HIP context goes on behind the
+     parent's back) or when it has exited without saying so, which is a failure */
+  { int left = W;
+    char gone[NODE_MAXW];
+    memset(gone, 0, sizeof(gone));
+    while (left > 0)
+      { int progress = 0;
+        for (i = 0; i < W; i++)
+          if (!gone[i])
+            { int st = 0;
+              const pid_t r = waitpid(pid[i], &st, WNOHANG);
+              if (atomic_load(&S->done[i]))
+                { gone[i] = 1;  left -= 1;  progress = 1; }
+              else if (r == pid[i] || r < 0)
+                { if (!atomic_load(&S->done[i]))
+                    { fprintf(stderr, "daligner: the worker on GPU %d failed (%s %d): its units are missing\n", gpus[i],
+                              WIFSIGNALED(st) ? "signal" : "exit code", WIFSIGNALED(st) ? WTERMSIG(st) : WEXITSTATUS(st));
+                      ok = 0;
+                    }
+                  gone[i] = 1;  left -= 1;  progress = 1;
+                }
+            }
+        if (!progress)
+          usleep(500);
+      }
+  }
   if (!ok)
     return 1;
 

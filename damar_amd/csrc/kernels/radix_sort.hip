@@ -279,8 +279,9 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
 
 static int G_sort_threads = 0;              /* 0: not chosen yet */
 
-/* tile shape of the sorts to come: 512 or 256 threads x 16 keys, or 128 = 256 threads x 8 keys (<= 64 VGPRs) */
-void damar_sort_set_threads(int threads) { G_sort_threads = (threads == 256 || threads == 128) ? threads : 512; }
+/* tile shape of the sorts to come: 512 or 256 threads per workgroup, 16 keys per thread (a 256 x 8 shape within 64 VGPRs
+   was measured: slower alone and beside a report launch, profiles/r03_sweeps.txt) */
+void damar_sort_set_threads(int threads) { G_sort_threads = (threads == 256) ? 256 : 512; }
 
 static int sort_threads(void)
 { if (G_sort_threads == 0)
@@ -345,15 +346,11 @@ static int onesweep_impl(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lobit,
     }
   const int shape = sort_threads();
   if (n < (1ull << 30))
-    { if (shape == 512)      onesweep_passes<KeyT, u32, HV, 512, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
-      else if (shape == 256) onesweep_passes<KeyT, u32, HV, 256, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
-      else                   onesweep_passes<KeyT, u32, HV, 256, 8>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+    { if (shape == 512) onesweep_passes<KeyT, u32, HV, 512, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+      else              onesweep_passes<KeyT, u32, HV, 256, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
     }
-  else
-    { if (shape == 512)      onesweep_passes<KeyT, u64, HV, 512, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
-      else if (shape == 256) onesweep_passes<KeyT, u64, HV, 256, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
-      else                   onesweep_passes<KeyT, u64, HV, 256, 8>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
-    }
+  else                  /* 2^30 items and more: 64-bit look-back words, one shape */
+    onesweep_passes<KeyT, u64, HV, 256, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
   return npass & 1;
 }
 
