@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 if [ $# -eq 0 ]; then set -- "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS"; fi
 for set in "$@"; do
   tag=$(echo $set | tr ' ' '_')
-  timeout -k 10 280 rocprofv3 --pmc $set --kernel-trace -d $OUT/$tag -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-trace --no-e2e > $OUT/$tag.log 2>&1
+  timeout -k 10 280 rocprofv3 --pmc $set --kernel-trace -d $OUT/$tag -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-trace --no-e2e --no-legs > $OUT/$tag.log 2>&1
   echo "== $set"
   python3 - "$OUT/$tag" <<'PY'
 import csv, glob, sys, collections

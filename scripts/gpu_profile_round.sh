@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out/round
 rm -rf $OUT; mkdir -p $OUT
 if [ "$1" = packed ]; then export DAMAR_PACKED=1; fi
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-trace --no-e2e > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-trace --no-e2e --no-legs > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats done"
 cd $ROOT
 bash scripts/gpu_pmc.sh "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVES" \

@@ -5,7 +5,7 @@ OUT=$ROOT/gpurun_out/seqstats
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export DAMAR_OVERLAP=0
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-trace --no-e2e "$@" > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-trace --no-e2e --no-legs "$@" > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 cd $ROOT
 python3 - <<'PY'
 import csv, glob

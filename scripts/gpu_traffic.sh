@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/traffic
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "report" -d $OUT/$set -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-trace --no-e2e > $OUT/$set.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "report" -d $OUT/$set -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-trace --no-e2e --no-legs > $OUT/$set.log 2>&1
   python3 - "$OUT/$set" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(float); n = collections.Counter()

@@ -57,7 +57,7 @@ def main():
                                  if k in cnt and cnt.get("SQ_WAVE_CYCLES")},
            "counters_per_step": cnt,
            "source": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu "
-                     "--no-trace --no-e2e` (scripts/gpu_profile_round.sh); issue peaks from tools/roofcal.hip (profiles/r02_roofcal.txt)"}
+                     "--no-trace --no-e2e --no-legs` (scripts/gpu_profile_round.sh); issue peaks from tools/roofcal.hip (profiles/r02_roofcal.txt)"}
     # what ties this file to a tree: bench.py carries its figures only while the kernel sources still hash to this
     import bench
     out["kernel_src_sha16"] = bench.kernel_src_sha16()

@@ -6,7 +6,7 @@ import damar_amd.lib as dl
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dl.lib_path = lambda: os.path.join(root, "build", "prof", "libdamar_hip.so")
 import bench
-sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-trace", "--no-e2e"] + sys.argv[1:]
+sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-trace", "--no-e2e", "--no-legs"] + sys.argv[1:]
 bench.main()
 L = dl.load()
 out = (ctypes.c_ulonglong * 32)()
