@@ -155,6 +155,7 @@ typedef struct
    moves on to the next when a job's queue is empty, so the long alignments of ALL jobs start at once and the tail of
    the launch (waiting for the longest alignment) is paid once per launch, not once per comparison. */
 #define DAMAR_MAX_JOBS 32
+#define DAMAR_MAX_TSPACE 8192     /* consecutive pebbles of a chain then differ by < 2^15 diagonals and < 2^16 waves */
 #define DAMAR_CNT_CURSOR  16      /* counters[16 + job]: next work item of a job  */
 #define DAMAR_CNT_NFILT   (DAMAR_CNT_CURSOR + DAMAR_MAX_JOBS)      /* counters[.. + job]: its seed hits */
 #define DAMAR_COUNTER_WORDS (DAMAR_CNT_NFILT + DAMAR_MAX_JOBS)

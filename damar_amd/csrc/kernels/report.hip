@@ -68,7 +68,17 @@ struct __attribute__((aligned(16))) DState
 /* slot of diagonal e in the per-slot band arrays: the band is contiguous and never wider than the ring */
 #define RI(e) (((u32) ((e) + o)) & rmask)
 
-struct __attribute__((aligned(16))) Cell { int ptr, diag, diff, mark; };
+/* A pebble (align.c:89-173 Pebble {ptr, diag, diff, mark}, 16 bytes there) in 8 bytes: every live diagonal drops one at
+   every trace mark it crosses, and one chain per direction is ever read back -- the pebbles were two thirds of what the
+   report kernel writes to HBM.
+     w0 = predecessor's index (PK_HBITS = 18 bits) | grid index of the mark << 18 (14 bits: mark = (index - PK_BIAS) * TS + off)
+     w1 = diagonal & 0xffff | wave number << 16 (both modulo 2^16)
+   The chain walk (chains_to_traces) starts from the direction's end point, whose diagonal and wave number are exact, and
+   unwraps the 16-bit fields pebble by pebble: consecutive pebbles of a chain lie one trace spacing apart, so their
+   diagonals differ by less than 2^15 and their wave numbers by less than 2^16 while the spacing is at most PK_MAX_TS
+   (checked on the host).  The two chain ROOTS (cells 0 and 1 of a slot) hold the exact start instead: w0 = mark, w1 = diagonal. */
+struct __attribute__((aligned(8))) Cell { u32 w0, w1; };
+typedef u32 v2u32 __attribute__((ext_vector_type(2)));
 
 struct Tip { int a, y, d, ha, hb; };
 
@@ -150,6 +160,168 @@ __device__ __forceinline__ u64 load8(const u8 *p)
 #define PK_BIAS   3                       /* grid index = (mark - off) / TS + PK_BIAS, always >= 1 */
 #define PK_HBITS  18                      /* pebble index bits in a packed chain head (cell_cap <= 2^18): 14 bits of grid index */
 #define PK_HMASK  ((1 << PK_HBITS) - 1)
+
+/***** pebbles (see struct Cell) ************************************************************************/
+
+__device__ __forceinline__ v2u32 cell_pack(int ptr, int k, int dif, int gidx)
+{ v2u32 c = { (u32) ptr | ((u32) gidx << PK_HBITS), ((u32) k & 0xffffu) | ((u32) dif << 16) };
+  return c;
+}
+__device__ __forceinline__ v2u32 cell_root(int mark, int k) { v2u32 c = { (u32) mark, (u32) k };  return c; }
+
+/* One chain of a direction as trace values (align.c:1001-1118 forward, 1699-1898 reverse), walked by ONE lane.
+ *   BSIDE 0: the A chain -- a pebble's value is the B coordinate where the path crosses its A mark (mark - diag), the end
+ *            point is tested on its A coordinate ex and contributes its B coordinate ey;
+ *   BSIDE 1: the B chain -- value mark + diag, tested on ey, contributes ex.
+ * The reference walks root -> head after reversing the chain in place.  Here the cells are read-only: a first walk
+ * head -> root counts the pebbles, a second one decodes them from the exact end point down (diagonal and wave number are
+ * kept modulo 2^16) and puts every pair where the root -> head walk would have put it.
+ * Forward: returns the number of values written to T[0 ...).  Reverse: values are prepended (T[-1], T[-2], ...), the
+ * first partial segment goes into the forward trace's first pair if there is one (f0 > 0: its values so far), and the
+ * number of prepended values is returned. */
+template <int REV, int BSIDE>
+__device__ __forceinline__ int chain_to_trace(const Cell *cells, int head, int TS, int off, int mida, int ex, int ey, int ed,
+                                              u16 *T, int f0, int guard, int &gw, u32 *errw)
+{ const int sg = BSIDE ? 1 : -1;
+  const int P = BSIDE ? ey : ex, Q = BSIDE ? ex : ey;              /* coordinate tested / coordinate contributed by the end point */
+  const int goff = off - PK_BIAS * TS;                             /* mark = grid index * TS + goff */
+  const int root = BSIDE;                                          /* cells 0 / 1 hold the exact starts of the A / B chain */
+  const int k0 = (int) cells[root].w1, m0 = (int) cells[root].w0;
+  /* pass 1: how many pebbles between the root and the head */
+  int L = 0;
+  for (int h = head; h >= 2; h = (int) (cells[h].w0 & PK_HMASK))
+    { GUARD(gw, guard, 7)
+      L += 1;
+    }
+  /* the head, decoded against the end point (diagonal ex - ey, wave number ed) */
+  int kc = k0, dc = 0, ac;
+  int h = head;
+  if (L > 0)
+    { const Cell c = cells[h];
+      kc = (ex - ey) + (int) (short) (u16) ((c.w1 & 0xffffu) - (u32) (ex - ey));
+      dc = ed - (int) (((u32) ed - (c.w1 >> 16)) & 0xffffu);
+      ac = (int) (c.w0 >> PK_HBITS) * TS + goff + sg * kc;
+    }
+  else
+    ac = REV ? m0 + sg * k0 : (mida + sg * k0) / 2;
+  if (!REV)
+    { /* tail (align.c:1031-1041, 1085-1095): a new pair unless the end lies on the last pebble's mark; then its
+         remainder is added into the last pair, which the loop below accumulates into */
+      int n = 2 * L;
+      if (L > 0)
+        { T[2 * L - 1] = 0;  T[2 * L - 2] = 0; }
+      if (ac - sg * kc != P)
+        { T[n] = (u16) (ed - dc);
+          T[n + 1] = (u16) (Q - ac);
+          n += 2;
+        }
+      else if (ac != Q && L > 0)
+        { T[2 * L - 1] = (u16) (Q - ac);
+          T[2 * L - 2] = (u16) (ed - dc);
+        }
+      /* pairs L .. 1: pair j = (d_j - d_(j-1), a_j - a_(j-1)), with the root as pebble 0 */
+      for (int j = L; j >= 1; j--)
+        { GUARD(gw, guard, 8)
+          int kp, dp, ap;
+          h = (int) (cells[h].w0 & PK_HMASK);
+          if (j > 1)
+            { const Cell c = cells[h];
+              kp = kc + (int) (short) (u16) ((c.w1 & 0xffffu) - (u32) kc);
+              dp = dc - (int) (((u32) dc - (c.w1 >> 16)) & 0xffffu);
+              ap = (int) (c.w0 >> PK_HBITS) * TS + goff + sg * kp;
+            }
+          else
+            { kp = k0;  dp = 0;  ap = (mida + sg * k0) / 2; }
+          if (j == L)                                               /* (the tail may have been added into this pair) */
+            { T[2 * j - 2] = (u16) (T[2 * j - 2] + (dc - dp));
+              T[2 * j - 1] = (u16) (T[2 * j - 1] + (ac - ap));
+            }
+          else
+            { T[2 * j - 2] = (u16) (dc - dp);
+              T[2 * j - 1] = (u16) (ac - ap);
+            }
+          kc = kp;  dc = dp;  ac = ap;
+        }
+      return n;
+    }
+  else
+    { /* Root -> head the reference prepends: [first partial segment if the start is off the marks], the pairs between
+         consecutive pebbles, the tail.  With the start off the marks and a forward trace present the first segment is
+         merged into the forward trace's first pair instead of being prepended (align.c:1757-1766, 1836-1845). */
+      const int a0 = m0 + sg * k0;                                   /* value of the root: (mark - k) for A, (mark + k) for B */
+      const bool partial = (m0 % TS) != off;                        /* (a0 - sg*k0 = m0: the start coordinate on this chain's axis) */
+      const bool merged = partial && f0 > 0;                        /* pair 1 goes into T[0], T[1] */
+      if (partial && L == 0)
+        { /* no pebble at all: the end point stands in for the first pebble, and nothing else is emitted */
+          if (f0 == 0)
+            { T[-1] = (u16) (a0 - Q);
+              T[-2] = BSIDE ? (u16) (a0 - Q) : (u16) (ed - 0);      /* sic: align.c:1843-1844 writes (b - a) twice on the B side */
+              return 2;
+            }
+          T[1] = (u16) (T[1] + (a0 - Q));
+          T[0] = (u16) (T[0] + (ed - 0));
+          return 0;
+        }
+      /* position of pair j (j = 1 .. L): T[-2 jj], T[-2 jj + 1] with jj = j, or j - 1 when pair 1 is merged */
+      const int npush = merged ? L - 1 : L;
+      int n = 2 * npush;
+      /* tail: a new pair below everything pushed, or its remainder added into the lowest pair pushed (pair L, which the
+         loop below accumulates into), or -- nothing pushed -- into the forward trace's first pair */
+      if (npush > 0)
+        { T[-2 * npush + 1] = 0;  T[-2 * npush] = 0; }
+      if (ac - sg * kc != P)
+        { T[-n - 1] = (u16) (ac - Q);
+          T[-n - 2] = (u16) (ed - dc);
+          n += 2;
+        }
+      else if (ac != Q && (f0 + n) > 0)
+        { if (npush > 0)
+            { T[-2 * npush + 1] = (u16) (ac - Q);
+              T[-2 * npush]     = (u16) (ed - dc);
+            }
+          else
+            { T[1] = (u16) (T[1] + (ac - Q));
+              T[0] = (u16) (T[0] + (ed - dc));
+            }
+        }
+      for (int j = L; j >= 1; j--)
+        { GUARD(gw, guard, 10)
+          int kp, dp, ap;
+          h = (int) (cells[h].w0 & PK_HMASK);
+          if (j > 1)
+            { const Cell c = cells[h];
+              kp = kc + (int) (short) (u16) ((c.w1 & 0xffffu) - (u32) kc);
+              dp = dc - (int) (((u32) dc - (c.w1 >> 16)) & 0xffffu);
+              ap = (int) (c.w0 >> PK_HBITS) * TS + goff + sg * kp;
+            }
+          else
+            { kp = k0;  dp = 0;  ap = a0; }
+          /* pair j: second slot a_(j-1) - a_j, first slot d_j - d_(j-1) */
+          if (j == 1 && merged)
+            { T[1] = (u16) (T[1] + (ap - ac));
+              T[0] = (u16) (T[0] + (dc - dp));
+            }
+          else if (j == 1 && partial && BSIDE)                       /* pushed first partial segment on the B side: (b - a) twice */
+            { const u16 add0 = (L == 1) ? T[-2] : (u16) 0, add1 = (L == 1) ? T[-1] : (u16) 0;
+              T[-1] = (u16) (add1 + (ap - ac));
+              T[-2] = (u16) (add0 + (ap - ac));
+            }
+          else
+            { const int jj = merged ? j - 1 : j;
+              if (j == L)
+                { T[-2 * jj + 1] = (u16) (T[-2 * jj + 1] + (ap - ac));
+                  T[-2 * jj]     = (u16) (T[-2 * jj] + (dc - dp));
+                }
+              else
+                { T[-2 * jj + 1] = (u16) (ap - ac);
+                  T[-2 * jj]     = (u16) (dc - dp);
+                }
+            }
+          kc = kp;  dc = dp;  ac = ap;
+        }
+      return n;
+    }
+}
 
 /* one 8-column chunk of the trim test: low half = minimum suffix score, high half = total */
 __device__ __forceinline__ void pk_fill_trimtab(u32 *tab, int mscore, int dscore)
@@ -360,7 +532,7 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
   const int offa = aoff - PK_BIAS * TS, offb = boff - PK_BIAS * TS;        /* mark = index * TS + off */
   (void) trim8; (void) offa; (void) offb;
   Cell *const cellbuf = uni_ptr(c.cells);
-  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) cellbuf;          /* one 16-byte store per pebble */
+  GLOBAL_AS v2u32 *const gcell = (GLOBAL_AS v2u32 *) cellbuf;      /* one 8-byte store per pebble */
   u32 *const errw = uni_ptr(c.err);
   const int steplimit = uni(c.alen + c.blen + 64);
   const int guard = uni(4 * (c.alen + c.blen) + 1024);
@@ -396,7 +568,6 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
   if (!CONT)
   { int k = diag, y = (mida - k) >> 1, na, nb, nai, nbi, hai, hbi, ha, hb, v;
     const u8 *a = aseq + k;
-    Cell cl;
 
     if (!REV)
       { nai = ((y + k) + (TS - aoff)) / TS - 1 + PK_BIAS;
@@ -408,9 +579,10 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
         nbi = (y + (TS - boff) - 1) / TS - 1 + PK_BIAS;
         hai = nai + 1;  hbi = nbi + 1;            /* the true start, rounded up to the grid */
       }
-    cl.ptr = -1; cl.diag = k; cl.diff = 0;
-    cl.mark = REV ? y + k : nai * TS + offa;  if (lane == 0) cellbuf[0] = cl;
-    cl.mark = REV ? y : nbi * TS + offb;      if (lane == 0) cellbuf[1] = cl;
+    if (lane == 0)
+      { gcell[0] = cell_root(REV ? y + k : nai * TS + offa, k);
+        gcell[1] = cell_root(REV ? y : nbi * TS + offb, k);
+      }
     ha = 0;  hb = 1;  ncell = 2;
     if (!REV) { nai += 1; nbi += 1; }
     na = nai * TS + offa;  nb = nbi * TS + offb;
@@ -424,14 +596,12 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
     v = (y << 1) + k;
     while (REV ? (y + k <= na) : (y + k >= na))
       { GUARD(g0, guard, 2)
-        cl.ptr = ha; cl.mark = na;
-        if (lane == 0 && ncell < cell_cap) cellbuf[ncell] = cl;
+        if (lane == 0 && ncell < cell_cap) gcell[ncell] = cell_pack(ha, k, 0, nai);
         ha = (int) ncell++;  hai = nai;  nai += S;  na += S * TS;
       }
     while (REV ? (y <= nb) : (y >= nb))
       { GUARD(g0, guard, 3)
-        cl.ptr = hb; cl.mark = nb;
-        if (lane == 0 && ncell < cell_cap) cellbuf[ncell] = cl;
+        if (lane == 0 && ncell < cell_cap) gcell[ncell] = cell_pack(hb, k, 0, nbi);
         hb = (int) ncell++;  hbi = nbi;  nbi += S;  nb += S * TS;
       }
     if (REV ? (v < besta) : (v > besta))
@@ -589,9 +759,7 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
                     { const u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                       if (dropit)
                         { if (idx < cell_cap)
-                            { v4i cl = { ha & PK_HMASK, k, dif, nai * TS + offa };
-                              gcell[idx] = cl;
-                            }
+                            gcell[idx] = cell_pack(ha & PK_HMASK, k, dif, nai);
                           ha = (int) idx | (nai << PK_HBITS);
                         }
                       ncell += (u32) __popcll(mask);
@@ -607,9 +775,7 @@ __device__ __forceinline__ void wave_reg_impl(const WaveCtx &c, int diag, int mi
                     { const u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                       if (dropit)
                         { if (idx < cell_cap)
-                            { v4i cl = { hb & PK_HMASK, k, dif, nbi * TS + offb };
-                              gcell[idx] = cl;
-                            }
+                            gcell[idx] = cell_pack(hb & PK_HMASK, k, dif, nbi);
                           hb = (int) idx | (nbi << PK_HBITS);
                         }
                       ncell += (u32) __popcll(mask);
@@ -770,7 +936,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
   const u32 cell_cap = (u32) uni((int) c.cell_cap);
   const short *score_tab = uni_ptr(c.score), *trim_tab = uni_ptr(c.table);
   Cell *const cellbuf = uni_ptr(c.cells);
-  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) cellbuf;          /* one 16-byte store per pebble */
+  GLOBAL_AS v2u32 *const gcell = (GLOBAL_AS v2u32 *) cellbuf;      /* one 8-byte store per pebble */
   u32 *const errw = uni_ptr(c.err);
   const int steplimit = uni(c.alen + c.blen + 64);
   const int guard = uni(4 * (c.alen + c.blen) + 1024);
@@ -902,9 +1068,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
                 { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                   if (dropit)
                     { if (idx < cell_cap)
-                        { Cell cl; cl.ptr = ha; cl.diag = k; cl.diff = dif; cl.mark = na;
-                          cellbuf[idx] = cl;
-                        }
+                        gcell[idx] = cell_pack(ha, k, dif, (na - aoff) / TS + PK_BIAS);
                       ha = (int) idx;  ham = na;
                     }
                   ncell += (u32) __popcll(mask);
@@ -924,9 +1088,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
                 { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                   if (dropit)
                     { if (idx < cell_cap)
-                        { Cell cl; cl.ptr = hb; cl.diag = k; cl.diff = dif; cl.mark = nb;
-                          cellbuf[idx] = cl;
-                        }
+                        gcell[idx] = cell_pack(hb, k, dif, (nb - boff) / TS + PK_BIAS);
                       hb = (int) idx;  hbm = nb;
                     }
                   ncell += (u32) __popcll(mask);
@@ -1051,7 +1213,7 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
   const u32 cell_cap = (u32) uni((int) c.cell_cap);
   const short *score_tab = uni_ptr(c.score), *trim_tab = uni_ptr(c.table);
   Cell *const cellbuf = uni_ptr(c.cells);
-  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) cellbuf;          /* one 16-byte store per pebble */
+  GLOBAL_AS v2u32 *const gcell = (GLOBAL_AS v2u32 *) cellbuf;      /* one 8-byte store per pebble */
   u32 *const errw = uni_ptr(c.err);
   const int steplimit = uni(c.alen + c.blen + 64);
   const int guard = uni(4 * (c.alen + c.blen) + 1024);
@@ -1076,134 +1238,13 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
         { trimx = trim.a - trim.y; trimy = trim.y; trimd = trim.d; ha = trim.ha; hb = trim.hb; }
 
       int gw = 0;
-      /* reverse both chains in place so they can be walked root -> head */
-      for (int which = 0; which < 2; which++)
-        { int h = which ? hb : ha, prev = -1;
-          while (h >= 0)
-            { GUARD(gw, guard, 7)
-              int nx = cells[h].ptr;
-              cells[h].ptr = prev;
-              prev = h;
-              h = nx;
-            }
-          if (which) hb = prev; else ha = prev;
-        }
-
       if (!REV)
-        { int h = ha, k = cells[h].diag, b = (mida - k) / 2, e = 0, n = 0;
-          for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-            { GUARD(gw, guard, 8)
-              Cell p = cells[h];
-              int  a = p.mark - p.diag;
-              k = p.diag;
-              atrace[n++] = (u16) (p.diff - e);
-              atrace[n++] = (u16) (a - b);
-              b = a;  e = p.diff;
-            }
-          if (b + k != trimx)
-            { atrace[n++] = (u16) (trimd - e);
-              atrace[n++] = (u16) (trimy - b);
-            }
-          else if (b != trimy && n > 0)
-            { atrace[n - 1] = (u16) (atrace[n - 1] + (trimy - b));
-              atrace[n - 2] = (u16) (atrace[n - 2] + (trimd - e));
-            }
-          at = n;
-
-          h = hb;  k = cells[h].diag;  b = (mida + k) / 2;  e = 0;  n = 0;
-          for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-            { GUARD(gw, guard, 9)
-              Cell p = cells[h];
-              int  a = p.mark + p.diag;
-              k = p.diag;
-              btrace[n++] = (u16) (p.diff - e);
-              btrace[n++] = (u16) (a - b);
-              b = a;  e = p.diff;
-            }
-          if (b - k != trimy)
-            { btrace[n++] = (u16) (trimd - e);
-              btrace[n++] = (u16) (trimx - b);
-            }
-          else if (b != trimx && n > 0)
-            { btrace[n - 1] = (u16) (btrace[n - 1] + (trimx - b));
-              btrace[n - 2] = (u16) (btrace[n - 2] + (trimd - e));
-            }
-          bt = n;
+        { at = chain_to_trace<0, 0>(cells, ha, TS, aoff, mida, trimx, trimy, trimd, atrace, 0, guard, gw, errw);
+          bt = chain_to_trace<0, 1>(cells, hb, TS, boff, mida, trimx, trimy, trimd, btrace, 0, guard, gw, errw);
         }
       else
-        { const int fa = *atlen_io, fb = *btlen_io;
-          int h = ha, k = cells[h].diag, b = cells[h].mark - k, e = 0, n = 0, a, d;
-          bool walk = true;
-          if ((b + k) % TS != aoff)
-            { h = cells[h].ptr;
-              if (h < 0)
-                { a = trimy; d = trimd; walk = false; }
-              else
-                { k = cells[h].diag; a = cells[h].mark - k; d = cells[h].diff; }
-              if (fa == 0)
-                { atrace[--n] = (u16) (b - a);
-                  atrace[--n] = (u16) (d - e);
-                }
-              else
-                { atrace[1] = (u16) (atrace[1] + (b - a));
-                  atrace[0] = (u16) (atrace[0] + (d - e));
-                }
-              b = a;  e = d;
-            }
-          if (walk)
-            { for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-                { GUARD(gw, guard, 10)
-                  k = cells[h].diag;  a = cells[h].mark - k;  d = cells[h].diff;
-                  atrace[--n] = (u16) (b - a);
-                  atrace[--n] = (u16) (d - e);
-                  b = a;  e = d;
-                }
-              if (b + k != trimx)
-                { atrace[--n] = (u16) (b - trimy);
-                  atrace[--n] = (u16) (trimd - e);
-                }
-              else if (b != trimy && (fa - n) > 0)
-                { atrace[n + 1] = (u16) (atrace[n + 1] + (b - trimy));
-                  atrace[n]     = (u16) (atrace[n] + (trimd - e));
-                }
-            }
-          at = -n;
-
-          h = hb;  k = cells[h].diag;  b = cells[h].mark + k;  e = 0;  n = 0;  walk = true;
-          if ((b - k) % TS != boff)
-            { h = cells[h].ptr;
-              if (h < 0)
-                { a = trimx; d = trimd; walk = false; }
-              else
-                { k = cells[h].diag; a = cells[h].mark + k; d = cells[h].diff; }
-              if (fb == 0)
-                { btrace[--n] = (u16) (b - a);
-                  btrace[--n] = (u16) (b - a);          /* sic, align.c:1843-1844 */
-                }
-              else
-                { btrace[1] = (u16) (btrace[1] + (b - a));
-                  btrace[0] = (u16) (btrace[0] + (d - e));
-                }
-              b = a;  e = d;
-            }
-          if (walk)
-            { for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-                { GUARD(gw, guard, 11)
-                  k = cells[h].diag;  a = cells[h].mark + k;  d = cells[h].diff;
-                  btrace[--n] = (u16) (b - a);
-                  btrace[--n] = (u16) (d - e);
-                  b = a;  e = d;
-                }
-              if (b - k != trimy)
-                { btrace[--n] = (u16) (b - trimx);
-                  btrace[--n] = (u16) (trimd - e);
-                }
-              else if (b != trimx && (fb - n) > 0)
-                { btrace[n + 1] = (u16) (btrace[n + 1] + (b - trimx));
-                  btrace[n]     = (u16) (btrace[n] + (trimd - e));
-                }
-            }
-          bt = -n;
+        { at = chain_to_trace<1, 0>(cells, ha, TS, aoff, mida, trimx, trimy, trimd, atrace, *atlen_io, guard, gw, errw);
+          bt = chain_to_trace<1, 1>(cells, hb, TS, boff, mida, trimx, trimy, trimd, btrace, *btlen_io, guard, gw, errw);
         }
       rx = trimx;  ry = trimy;  rd = trimd;
     }

@@ -104,7 +104,7 @@ struct PkDir
   const int TS = uni(a.tspace), ave = uni(a.ave_path);                                               \
   const u32 *apk = uni_ptr(a.ablk.pk), *bpk = uni_ptr(a.bblk.pk);                                    \
   const u8 *abase = uni_ptr(a.ablk.bases), *bbase = uni_ptr(a.bblk.bases);                           \
-  GLOBAL_AS v4i *const gcell = (GLOBAL_AS v4i *) uni_ptr((Cell *) a.cells);                          \
+  GLOBAL_AS v2u32 *const gcell = (GLOBAL_AS v2u32 *) uni_ptr((Cell *) a.cells);                          \
   const int cell_cap = (int) uni((int) a.cell_cap);                                                  \
   u32 *const errw = uni_ptr(&a.counters[3]);                                                         \
   const int offa = -PK_BIAS * TS, offb = p.boff - PK_BIAS * TS;          /* mark = index * TS + off */ \
@@ -155,10 +155,8 @@ __device__ __forceinline__ void pk_init(const ReportArgs &a, bool on, const PkPa
       nai = qa - 1 + PK_BIAS;  nbi = qb - 1 + PK_BIAS;
       hai = REV ? nai + 1 : nai;  hbi = REV ? nbi + 1 : nbi;       /* reverse: the true start, rounded up to the grid */
       if (s == 0)
-        { v4i c0 = { -1, k, 0, REV ? y + k : nai * TS + offa };
-          v4i c1 = { -1, k, 0, REV ? y : nbi * TS + offb };
-          gcell[cbase] = c0;
-          gcell[cbase + 1] = c1;
+        { gcell[cbase] = cell_root(REV ? y + k : nai * TS + offa, k);
+          gcell[cbase + 1] = cell_root(REV ? y : nbi * TS + offb, k);
         }
       if (!REV) { nai += 1;  nbi += 1; }
       { const SnakeOut so = SNAKE_AT(k, y, 0, 0ull);
@@ -174,9 +172,7 @@ __device__ __forceinline__ void pk_init(const ReportArgs &a, bool on, const PkPa
             break;
           GUARD(g0, guard, 2)
           if (s == 0 && ncell < cell_cap)
-            { v4i cl = { ha, k, 0, na };
-              gcell[cbase + (u32) ncell] = cl;
-            }
+            gcell[cbase + (u32) ncell] = cell_pack(ha, k, 0, nai);
           ha = ncell++;  hai = nai;  nai += S;
         }
       for (;;)
@@ -185,9 +181,7 @@ __device__ __forceinline__ void pk_init(const ReportArgs &a, bool on, const PkPa
             break;
           GUARD(g0, guard, 3)
           if (s == 0 && ncell < cell_cap)
-            { v4i cl = { hb_, k, 0, nb };
-              gcell[cbase + (u32) ncell] = cl;
-            }
+            gcell[cbase + (u32) ncell] = cell_pack(hb_, k, 0, nbi);
           hb_ = ncell++;  hbi = nbi;  nbi += S;
         }
       if (REV ? (v < besta) : (v > besta))
@@ -438,9 +432,7 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
                     const int idx = ncell + __popc(hm & ((1u << s) - 1u));
                     if (dropit)
                       { if (idx < cell_cap)
-                          { v4i cl = { hax, k, dif, na };
-                            gcell[cbase + (u32) idx] = cl;
-                          }
+                          gcell[cbase + (u32) idx] = cell_pack(hax, k, dif, nai);
                         hax = idx;  hai = nai;
                       }
                     ncell += __popc(hm);
@@ -460,9 +452,7 @@ __device__ __forceinline__ void pk_loop(const ReportArgs &a, const u32 *trimtab,
                     const int idx = ncell + __popc(hm & ((1u << s) - 1u));
                     if (dropit)
                       { if (idx < cell_cap)
-                          { v4i cl = { hbx, k, dif, nb };
-                            gcell[cbase + (u32) idx] = cl;
-                          }
+                          gcell[cbase + (u32) idx] = cell_pack(hbx, k, dif, nbi);
                         hbx = idx;  hbi = nbi;
                       }
                     ncell += __popc(hm);
@@ -673,130 +663,13 @@ __device__ __noinline__ void pk_finish(Cell *cells, u16 *atrace, u16 *btrace, bo
   if (fin && s == 0)
     { int trimx = ta - ty, trimy = ty, trimd = td, ha = tha, hb_ = thb;
       int gw = 0;
-      for (int which = 0; which < 2; which++)
-        { int h = which ? hb_ : ha, prev = -1;
-          while (h >= 0)
-            { GUARD(gw, guard, 7)
-              int nx = cells[h].ptr;
-              cells[h].ptr = prev;
-              prev = h;
-              h = nx;
-            }
-          if (which) hb_ = prev; else ha = prev;
-        }
       if (!REV)
-        { int h = ha, k = cells[h].diag, b = (mida - k) / 2, e = 0, n = 0;
-          for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-            { GUARD(gw, guard, 8)
-              Cell p = cells[h];
-              int  a = p.mark - p.diag;
-              k = p.diag;
-              atrace[n++] = (u16) (p.diff - e);
-              atrace[n++] = (u16) (a - b);
-              b = a;  e = p.diff;
-            }
-          if (b + k != trimx)
-            { atrace[n++] = (u16) (trimd - e);
-              atrace[n++] = (u16) (trimy - b);
-            }
-          else if (b != trimy && n > 0)
-            { atrace[n - 1] = (u16) (atrace[n - 1] + (trimy - b));
-              atrace[n - 2] = (u16) (atrace[n - 2] + (trimd - e));
-            }
-          at = n;
-          h = hb_;  k = cells[h].diag;  b = (mida + k) / 2;  e = 0;  n = 0;
-          for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-            { GUARD(gw, guard, 9)
-              Cell p = cells[h];
-              int  a = p.mark + p.diag;
-              k = p.diag;
-              btrace[n++] = (u16) (p.diff - e);
-              btrace[n++] = (u16) (a - b);
-              b = a;  e = p.diff;
-            }
-          if (b - k != trimy)
-            { btrace[n++] = (u16) (trimd - e);
-              btrace[n++] = (u16) (trimx - b);
-            }
-          else if (b != trimx && n > 0)
-            { btrace[n - 1] = (u16) (btrace[n - 1] + (trimx - b));
-              btrace[n - 2] = (u16) (btrace[n - 2] + (trimd - e));
-            }
-          bt = n;
+        { at = chain_to_trace<0, 0>(cells, ha, TS, aoff, mida, trimx, trimy, trimd, atrace, 0, guard, gw, errw);
+          bt = chain_to_trace<0, 1>(cells, hb_, TS, boff, mida, trimx, trimy, trimd, btrace, 0, guard, gw, errw);
         }
       else
-        { const int fa = *atlen_io, fb = *btlen_io;
-          int h = ha, k = cells[h].diag, b = cells[h].mark - k, e = 0, n = 0, a, d;
-          bool walk = true;
-          if ((b + k) % TS != aoff)
-            { h = cells[h].ptr;
-              if (h < 0)
-                { a = trimy; d = trimd; walk = false; }
-              else
-                { k = cells[h].diag; a = cells[h].mark - k; d = cells[h].diff; }
-              if (fa == 0)
-                { atrace[--n] = (u16) (b - a);
-                  atrace[--n] = (u16) (d - e);
-                }
-              else
-                { atrace[1] = (u16) (atrace[1] + (b - a));
-                  atrace[0] = (u16) (atrace[0] + (d - e));
-                }
-              b = a;  e = d;
-            }
-          if (walk)
-            { for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-                { GUARD(gw, guard, 10)
-                  k = cells[h].diag;  a = cells[h].mark - k;  d = cells[h].diff;
-                  atrace[--n] = (u16) (b - a);
-                  atrace[--n] = (u16) (d - e);
-                  b = a;  e = d;
-                }
-              if (b + k != trimx)
-                { atrace[--n] = (u16) (b - trimy);
-                  atrace[--n] = (u16) (trimd - e);
-                }
-              else if (b != trimy && (fa - n) > 0)
-                { atrace[n + 1] = (u16) (atrace[n + 1] + (b - trimy));
-                  atrace[n]     = (u16) (atrace[n] + (trimd - e));
-                }
-            }
-          at = -n;
-          h = hb_;  k = cells[h].diag;  b = cells[h].mark + k;  e = 0;  n = 0;  walk = true;
-          if ((b - k) % TS != boff)
-            { h = cells[h].ptr;
-              if (h < 0)
-                { a = trimx; d = trimd; walk = false; }
-              else
-                { k = cells[h].diag; a = cells[h].mark + k; d = cells[h].diff; }
-              if (fb == 0)
-                { btrace[--n] = (u16) (b - a);
-                  btrace[--n] = (u16) (b - a);          /* sic, align.c:1843-1844 */
-                }
-              else
-                { btrace[1] = (u16) (btrace[1] + (b - a));
-                  btrace[0] = (u16) (btrace[0] + (d - e));
-                }
-              b = a;  e = d;
-            }
-          if (walk)
-            { for (h = cells[h].ptr; h >= 0; h = cells[h].ptr)
-                { GUARD(gw, guard, 11)
-                  k = cells[h].diag;  a = cells[h].mark + k;  d = cells[h].diff;
-                  btrace[--n] = (u16) (b - a);
-                  btrace[--n] = (u16) (d - e);
-                  b = a;  e = d;
-                }
-              if (b - k != trimy)
-                { btrace[--n] = (u16) (b - trimx);
-                  btrace[--n] = (u16) (trimd - e);
-                }
-              else if (b != trimx && (fb - n) > 0)
-                { btrace[n + 1] = (u16) (btrace[n + 1] + (b - trimx));
-                  btrace[n]     = (u16) (btrace[n] + (trimd - e));
-                }
-            }
-          bt = -n;
+        { at = chain_to_trace<1, 0>(cells, ha, TS, aoff, mida, trimx, trimy, trimd, atrace, *atlen_io, guard, gw, errw);
+          bt = chain_to_trace<1, 1>(cells, hb_, TS, boff, mida, trimx, trimy, trimd, btrace, *btlen_io, guard, gw, errw);
         }
       rx = trimx;  ry = trimy;  rd = trimd;
     }

@@ -805,7 +805,12 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
     { fprintf(stderr, "damar: FATAL: reads of %d bases need a trace spacing (-s) of at least %d\n", std::max(amax, bmax),
               std::max(amax, bmax) / (DAMAR_MAX_MARKS - 8) + 1);
       die();
-    } if (G_last_d2h != NULL)        /* whatever is launched next overwrites the record buffers */
+    }
+  if (tspace > DAMAR_MAX_TSPACE)                  /* pebbles carry diagonal and wave number modulo 2^16 (kernels/report.hip: struct Cell) */
+    { fprintf(stderr, "damar: FATAL: a trace spacing (-s) above %d is not supported by this build\n", DAMAR_MAX_TSPACE);
+      die();
+    }
+  if (G_last_d2h != NULL)        /* whatever is launched next overwrites the record buffers */
     { HIP_CHECK(hipStreamWaitEvent(st, G_last_d2h, 0));
       G_last_d2h = NULL;
     }
@@ -843,7 +848,7 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
       RS.nslots_wanted = nslots;
       { size_t freeb = 0, totb = 0;
         const u64 nspan = (u64) std::max(RS.span, span), ncell = std::max(RS.cell_cap, cell_cap);
-        const u64 per = damar_report_state_stride((int) nspan) + 4ull * 2 * nspan + 16ull * ncell +
+        const u64 per = damar_report_state_stride((int) nspan) + 4ull * 2 * nspan + 8ull * ncell +
                         4ull * (3ull * std::max(RS.bwidth, bwidth) + 16) + 2ull * std::max(RS.ttmp_stride, tstr);
         const double g1 = now_ms();
         HIP_CHECK(hipMemGetInfo(&freeb, &totb));
@@ -872,14 +877,14 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
       const double g2 = now_ms();
       RS.state   = dmalloc((size_t) RS.state_stride * nslots);
       RS.marks   = (int *) dmalloc(sizeof(int) * (size_t) RS.marks_stride * nslots);
-      RS.cells   = dmalloc((size_t) 16 * RS.cell_cap * nslots);
+      RS.cells   = dmalloc((size_t) 8 * RS.cell_cap * nslots);                /* 8-byte pebbles (kernels/report.hip: struct Cell) */
       RS.buckets = (int *) dmalloc(sizeof(int) * (size_t) RS.bucket_stride * nslots);
       RS.ttmp    = (u16 *) dmalloc(sizeof(u16) * (size_t) RS.ttmp_stride * nslots);
       HIP_CHECK(hipMemsetAsync(RS.state, 0, (size_t) RS.state_stride * nslots, st));
       HIP_CHECK(hipMemsetAsync(RS.marks, 0, sizeof(int) * (size_t) RS.marks_stride * nslots, st));
       if (getenv("DAMAR_HOSTPROF"))
         fprintf(stderr, "damar: scratch grow: 5 allocations of %.2f GB in all %.1f ms (span %d bwidth %d cells %u)\n",
-                ((double) RS.state_stride + 4. * RS.marks_stride + 16. * RS.cell_cap + 4. * RS.bucket_stride + 2. * RS.ttmp_stride) * nslots / 1073741824.,
+                ((double) RS.state_stride + 4. * RS.marks_stride + 8. * RS.cell_cap + 4. * RS.bucket_stride + 2. * RS.ttmp_stride) * nslots / 1073741824.,
                 now_ms() - g2, RS.span, RS.bwidth, RS.cell_cap);
     }
   if (RS.counters == NULL)
