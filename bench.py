@@ -432,6 +432,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-trace", action="store_true", help="skip the trace-expansion leg (SURVEY 8(f)4)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end leg")
+    ap.add_argument("--sync-steps", action="store_true", help="barrier + device sync around EVERY step (rounds 1-2), not around the K steps")
     ap.add_argument("--no-legs", action="store_true", help="skip the config-4 (lead 24 blocks), config-3 and config-5 legs")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
@@ -516,31 +517,65 @@ def main():
                 multi.merge_parts(dbprefix, us, out, rank, world)
             return out, runner.plan, len(mine)
 
-        for w in range(args.warmup):
-            out, _, _ = one_step("w%d" % w)
-            barrier()
-            if rank == 0:
-                shutil.rmtree(out, ignore_errors=True)
+        # Split pairs need every rank's parts closed before they are merged: such a job (config 2 on many GPUs) is timed
+        # step by step.  Otherwise the K steps run BACK TO BACK as the consecutive plans of one long job -- one runner, no
+        # drain between them, so that the last report launch of a step runs beside the first seed stages of the next, as it
+        # does between the lines of any real plan -- bracketed as a whole by barrier + device sync.  Every step still builds
+        # its own indexes (end_pass) and writes its own files (two output directories used in turn; the last step's are
+        # md5-checked).  --sync-steps gives the step-by-step timing of earlier rounds; `ms_per_step_synced` reports it beside.
+        split = any(n > 1 for _, _, _, n in units)
+        pipelined = not split and not args.sync_steps
 
-        # Every step is bracketed by barrier + device sync on both sides and the K step times are added up; between two
-        # steps (outside the clock) rank 0 deletes the previous step's output files, which are the harness's, not the path's.
-        tim, cnts, last_out, nmine, builds, nmatch, nlaunch = {}, [0, 0, 0], None, 0, 0, 0, 0
-        elapsed = 0.
-        for s in range(args.steps):
-            if last_out and rank == 0:
-                shutil.rmtree(last_out, ignore_errors=True)
+        def run_steps(tag, nsteps, synced):
+            """(elapsed, last_out, plans, units_run): nsteps passes; synced: each on its own between syncs"""
+            el, outs, plans, nrun = 0., None, [], 0
+            if synced:
+                for s in range(nsteps):
+                    if outs and rank == 0:
+                        shutil.rmtree(outs, ignore_errors=True)
+                    sync_all()
+                    t0 = time.time()
+                    outs, plan, n = one_step("%s%d" % (tag, s))
+                    sync_all()
+                    el += time.time() - t0
+                    plans.append(plan)
+                    nrun += n
+                return el, outs, plans, nrun
+            runner = multi.GpuRunner(dict(j=args.threads_param), resident=blocks)
             sync_all()
             t0 = time.time()
-            last_out, plan, n = one_step("s%d" % s)
+            for s in range(nsteps):
+                outs = os.path.join(work, "out_%s%d" % (tag, s & 1))
+                queue = multi.make_queue(store, "%s%d" % (tag, s), units, rank)
+                nrun += len(multi.run_queue(dbprefix, units, outs, queue, runner))
+                runner.end_pass()
+            runner.finish()
             sync_all()
-            elapsed += time.time() - t0
-            nmine += n
+            return time.time() - t0, outs, [runner.plan], nrun
+
+        if args.warmup > 0:
+            _, wout, _, _ = run_steps("w", args.warmup, not pipelined)
+            barrier()
+            if rank == 0:
+                for d in {wout, os.path.join(work, "out_w0"), os.path.join(work, "out_w1")}:
+                    shutil.rmtree(d, ignore_errors=True)
+
+        tim, cnts, last_out, nmine, builds, nmatch, nlaunch = {}, [0, 0, 0], None, 0, 0, 0, 0
+        elapsed, last_out, plans, nmine = run_steps("s", args.steps, not pipelined)
+        for plan in plans:
             builds += plan.index_builds
             nmatch += plan.matches
             nlaunch += plan.report_launches
             for k, v in plan.timings.items():
                 tim[k] = tim.get(k, 0.) + v
             cnts = [c + d for c, d in zip(cnts, plan.counts)]
+        synced_ms = None
+        if pipelined and world == 1 and args.steps > 0:
+            # the same measurement with every step on its own between syncs (the edge of a step exposed), 3 steps
+            es, so, _, _ = run_steps("y", 3, True)
+            synced_ms = 1e3 * es / 3
+            if rank == 0:
+                shutil.rmtree(so, ignore_errors=True)
 
         tkeys = ["report", "ssort", "ksort", "merge", "tuples", "table", "work", "d2h", "tail", "write"]
         if dist is not None:
@@ -691,6 +726,10 @@ def main():
             line = {"metric": "aligned base-pairs/sec (daligner block-vs-block)",
                     "value": value, "unit": "aligned bp/s", "n_gpus": world, "steps": args.steps,
                     "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
+                    "ms_per_step_synced": synced_ms,
+                    "timing": ("the %d steps back to back between one barrier + device sync on either side (one job, no drain "
+                               "between steps; every step builds its own indexes and writes its own files)" % steps) if pipelined else
+                              "every step on its own between barrier + device sync; the step times added up",
                     "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                     "dtype": "int32", "data": "synthetic",
                     "config": {"workload": "%s -> %d blocks, %d block pairs x 2 orientations per step, daligner -k14 -w6 -h35 "

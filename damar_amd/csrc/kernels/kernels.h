@@ -31,12 +31,39 @@ typedef struct
   u32        nreads;
   u32        total;     /* boff[nreads]                                                           */
   int        maxlen;
+  int        rpbits;    /* > 0: the index of this block keeps a k-mer's position as read << rpbits | offset in the
+                           read (both fit 32 bits); 0: as offset in the block (decoded through coarse / boff)      */
   const u32 *moff;      /* mask track (-m): intervals of read i are mdat[2j], mdat[2j+1] for       */
   const int *mdat;      /* j in [moff[i]/2, moff[i+1]/2); NULL when the block carries no mask      */
 } DevBlock;
 
 #define COARSE_SHIFT 9
 #define PK_PAD 4
+
+#ifdef __HIPCC__
+/* read containing base offset p (p is inside a read, never on a terminator) */
+__device__ __forceinline__ u32 read_of_pos(const DevBlock &b, u32 p)
+{ u32 r = b.coarse[p >> COARSE_SHIFT];
+  while (b.boff[r + 1] <= p)
+    r += 1;
+  return r;
+}
+/* the position word of an index entry -> read and offset of the k-mer's last base in it: free when the block's index
+   is packed (rpbits), two dependent look-ups otherwise */
+__device__ __forceinline__ void pos_decode(const DevBlock &b, u32 v, u32 *r, u32 *x)
+{ if (b.rpbits)
+    { *r = v >> b.rpbits;
+      *x = v & ((1u << b.rpbits) - 1u);
+    }
+  else
+    { const u32 rr = read_of_pos(b, v);
+      *r = rr;
+      *x = v - b.boff[rr];
+    }
+}
+__device__ __forceinline__ u32 pos_encode(const DevBlock &b, u32 r, u32 x, u32 p)
+{ return b.rpbits ? ((r << b.rpbits) | x) : p; }
+#endif
 
 /* pk[w] for w in [-PK_PAD, total/16 + PK_PAD] from bases (which carry 64 padding bytes either side) */
 void damar_launch_pack_bases(const u8 *bases, u32 total, u32 *pk, hipStream_t st);

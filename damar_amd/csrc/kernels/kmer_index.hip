@@ -14,13 +14,6 @@
 #include "dev_common.h"
 #include "kernels.h"
 
-/* read containing base offset p (p is inside a read, never on a terminator) */
-__device__ __forceinline__ u32 read_of_pos(const DevBlock &b, u32 p)
-{ u32 r = b.coarse[p >> COARSE_SHIFT];
-  while (b.boff[r + 1] <= p)
-    r += 1;
-  return r;
-}
 
 /* One thread per base position p: the read through the coarse table (two dependent look-ups
  * instead of a search over all reads), then the k-mer ENDING at p if the read has K bases up to
@@ -54,11 +47,12 @@ void kmer_tuples(DevBlock blk, int kmer, u32 nkmers, CodeT *__restrict__ codes, 
       for (int j = 0; j < kmer; j++)
         c = (CodeT) (c << 2) | (CodeT) s[j];
     }
+  const u32 pw = pos_encode(blk, r, p - b0, p);                  /* the position word (kernels.h) */
   if (PACK)
-    codes[i] = (CodeT) ((u64) c << 32) | (CodeT) p;
+    codes[i] = (CodeT) ((u64) c << 32) | (CodeT) pw;
   else
     { codes[i] = c;
-      pos[i]   = p;
+      pos[i]   = pw;
     }
 }
 
@@ -83,8 +77,9 @@ void mask_flags(DevBlock blk, int kmer, const u32 *__restrict__ pos, u32 n, u32 
 { u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n)
     return;
-  const u32 p = pos[i], r = read_of_pos(blk, p);
-  const int e = (int) (p - blk.boff[r]), s = e - (kmer - 1);
+  u32 r, x;
+  pos_decode(blk, pos[i], &r, &x);
+  const int e = (int) x, s = e - (kmer - 1);
   u32 lo = blk.moff[r] >> 1, hi = blk.moff[r + 1] >> 1;
   const u32 end = hi;
   while (lo < hi)                               /* first interval with end > s */
@@ -154,7 +149,7 @@ void biased_tuples(DevBlock blk, int kmer, int lb0, int lb1, int lb2, int lb3,
           if (a > LogThresh)
             { const u32 P = b0 + (u32) p;
               codes[P] = (CodeT) ((c << (2 * kmer - 2 * k)) & kmask);
-              pos[P]   = P;
+              pos[P]   = pos_encode(blk, r, (u32) p, P);
               keep[P]  = 1u;
             }
           p += 1;
@@ -267,14 +262,17 @@ void tandem_links(DevBlock blk, int kmer, const CodeT *__restrict__ codes, const
 { u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n)
     return;
-  const u32 p = pos[i], r = read_of_pos(blk, p);
+  u32 r, x;
+  pos_decode(blk, pos[i], &r, &x);
+  const u32 p = blk.boff[r] + x;
   int d = 0;
   if (i == 0)
     d = (int) codes[0];             /* tandem.c:571-573 leaves the first entry's (truncated) code in place */
   else if (codes[i] == codes[i - 1])
-    { const u32 q = pos[i - 1];
-      if (q >= blk.boff[r])                 /* same read: entries of a run are in position order */
-        d = (int) (p - q);
+    { u32 rq, xq;
+      pos_decode(blk, pos[i - 1], &rq, &xq);
+      if (rq == r)                          /* same read: entries of a run are in position order */
+        d = (int) (x - xq);
     }
   dist[p - (r + 1) * (u32) kmer + 1] = d;
 }

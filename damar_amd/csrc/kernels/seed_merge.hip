@@ -20,12 +20,6 @@
 #include "dev_common.h"
 #include "kernels.h"
 
-__device__ __forceinline__ u32 read_of_pos(const DevBlock &b, u32 p)
-{ u32 r = b.coarse[p >> COARSE_SHIFT];
-  while (b.boff[r + 1] <= p)
-    r += 1;
-  return r;
-}
 
 /* number of entries of bpos[jb,ib) strictly below `bound` (bpos ascending in a run) */
 __device__ __forceinline__ u32 count_below(const u32 *__restrict__ bpos, u32 jb, u32 ib, u32 bound)
@@ -95,11 +89,20 @@ void merge_tiles(MergeArgs m, u32 ntiles, MergeTile *__restrict__ tiles)
   tiles[t] = tl;
 }
 
-/* hits of A entry i (block offset p of its k-mer) against the B run bpos[jb, jb+nb) in a self comparison:
-   the B entries before `bound` (filter.c:1219-1246) */
+/* hits of A entry i (position word p of its k-mer) against the B run bpos[jb, jb+nb) in a self comparison:
+   the B entries before `bound` (filter.c:1219-1246).  Block and complement block have the same reads, so A's and B's
+   position words are of one kind; packed words (read << rpbits | offset) order like block offsets, and the bounds
+   "start of A's read", "end of A's read", "A's own position" need no look-up at all. */
 __device__ __forceinline__ u32 self_hits(const MergeArgs &m, u32 p, u32 jb, u32 nb)
 { u32 bound;
-  if (m.identity)
+  const int rp = m.ablk.rpbits;
+  if (rp)
+    { const u32 ra = p >> rp;
+      bound = m.identity ? (m.comp ? (ra + 1) << rp : p) : ra << rp;
+      if (m.identity && m.comp && ((ra + 1) >> (32 - rp)) != 0)        /* (ra + 1) << rp would wrap: every entry is below */
+        return nb;
+    }
+  else if (m.identity)
     bound = m.comp ? m.ablk.boff[read_of_pos(m.ablk, p) + 1] : p;
   else
     bound = m.ablk.boff[read_of_pos(m.ablk, p)];
@@ -483,29 +486,34 @@ void merge_emit(MergeArgs m, const u32 *__restrict__ cnt, const u32 *__restrict_
           pa[x] = ok ? m.apos[ai[x]] : 0;
           pb[x] = ok ? m.bpos[bi[x]] : 0;
         }
-      u32 ra[MT_HITS], rb[MT_HITS];
+      u32 ra[MT_HITS], rb[MT_HITS], xa[MT_HITS], xb[MT_HITS];
+      if (m.ablk.rpbits && m.bblk.rpbits)                     /* packed position words: nothing to look up */
+        {
 #pragma unroll
-      for (int x = 0; x < MT_HITS; x++)
-        { ra[x] = m.ablk.coarse[pa[x] >> COARSE_SHIFT];
-          rb[x] = m.bblk.coarse[pb[x] >> COARSE_SHIFT];
+          for (int x = 0; x < MT_HITS; x++)
+            { ra[x] = pa[x] >> m.ablk.rpbits;  xa[x] = pa[x] & ((1u << m.ablk.rpbits) - 1u);
+              rb[x] = pb[x] >> m.bblk.rpbits;  xb[x] = pb[x] & ((1u << m.bblk.rpbits) - 1u);
+            }
         }
+      else
+        {
 #pragma unroll
-      for (int x = 0; x < MT_HITS; x++)
-        { while (m.ablk.boff[ra[x] + 1] <= pa[x]) ra[x] += 1;
-          while (m.bblk.boff[rb[x] + 1] <= pb[x]) rb[x] += 1;
+          for (int x = 0; x < MT_HITS; x++)
+            { pos_decode(m.ablk, pa[x], &ra[x], &xa[x]);
+              pos_decode(m.bblk, pb[x], &rb[x], &xb[x]);
+            }
         }
 #pragma unroll
       for (int x = 0; x < MT_HITS; x++)
         { const u32 t = t0 + (u32) x * 256;
           const u64 h = h0 + t;
           if (t < T && h < nhits)
-            { const u32 xa = pa[x] - m.ablk.boff[ra[x]], xb = pb[x] - m.bblk.boff[rb[x]];
-              const u64 key = ((u64) rb[x] << (m.abits + m.pbits)) | ((u64) ra[x] << m.pbits) | (u64) xa;
+            { const u64 key = ((u64) rb[x] << (m.abits + m.pbits)) | ((u64) ra[x] << m.pbits) | (u64) xa[x];
               if (m.dbits)
-                keys[h] = (key << m.dbits) | (u64) xb;
+                keys[h] = (key << m.dbits) | (u64) xb[x];
               else
                 { keys[h] = key;
-                  vals[h] = (u32) ((int) xa - (int) xb);
+                  vals[h] = (u32) ((int) xa[x] - (int) xb[x]);
                 }
               if (pid != NULL)                 /* the read pair alone, for the early cut (damar_launch_pair_cut) */
                 pid[h] = (rb[x] << m.abits) | ra[x];

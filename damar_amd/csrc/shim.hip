@@ -92,6 +92,7 @@ static double       H_ms[8];              /* host wall clock per phase (DAMAR_HO
 static const char  *H_name[8] = { "index_build", "match:front", "match:order", "match:report", "match:d2h",
                                   "match:submit", "match:total", "final_drain" };
 static double now_ms(void);
+static int    ilog2_ceil(u64 n);
 
 /* The filter parameters and option globals a comparison was set up under (filter.h:54-62).  A report launch may be made --
    or made again after an overflow -- during a LATER call, after the caller has moved on to other options: launches and
@@ -425,6 +426,15 @@ static damar_dev_block *block_upload_on(const HITS_DB *block, hipStream_t st)
   b->d.nreads = (u32) n;
   b->d.total  = (u32) total;
   b->d.maxlen = block->maxlen;
+  /* position words of this block's k-mer indexes: read << rpbits | offset in the read when both fit 32 bits (kernels.h) */
+  { const int pb = std::max(1, ilog2_ceil((u64) block->maxlen + 1)), ab = std::max(1, ilog2_ceil((u64) n));
+    static int rp_on = -1;
+    if (rp_on < 0)
+      { const char *e = getenv("DAMAR_PACK_POS");
+        rp_on = e ? atoi(e) : 1;
+      }
+    b->d.rpbits = (rp_on && pb + ab <= 32 && pb < 32) ? pb : 0;
+  }
   if (block->tracks != NULL)                  /* the merged mask track of daligner.c:442-497 */
     { const int64 *anno = (const int64 *) block->tracks->anno;
       const int   *data = (const int *) block->tracks->data;
@@ -737,11 +747,18 @@ extern "C" void damar_index_download(const damar_dev_index *ix, void *out)
     }
   HIP_CHECK(hipMemcpy(pos.data(), ix->pos, sizeof(u32) * (size_t) ix->n, hipMemcpyDeviceToHost));
   HIP_CHECK(hipMemcpy(boff.data(), ix->blk->boff, sizeof(u32) * boff.size(), hipMemcpyDeviceToHost));
+  const int rp = ix->blk->d.rpbits;
   for (u32 i = 0; i < ix->n; i++)
-    { u32 r = (u32) (std::upper_bound(boff.begin(), boff.end(), pos[i]) - boff.begin()) - 1;
-      kp[i].code = codes[i];
-      kp[i].rpos = (int) (pos[i] - boff[r]);
-      kp[i].read = (int) r;
+    { kp[i].code = codes[i];
+      if (rp)                                   /* packed position word: read << rpbits | offset in the read */
+        { kp[i].rpos = (int) (pos[i] & ((1u << rp) - 1u));
+          kp[i].read = (int) (pos[i] >> rp);
+        }
+      else
+        { u32 r = (u32) (std::upper_bound(boff.begin(), boff.end(), pos[i]) - boff.begin()) - 1;
+          kp[i].rpos = (int) (pos[i] - boff[r]);
+          kp[i].read = (int) r;
+        }
     }
 }
 

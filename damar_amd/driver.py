@@ -151,6 +151,15 @@ class Plan:
         self._idx = {}
         self._idx_bytes = 0
 
+    def release_indexes(self):
+        """Forget every k-mer index (a new pass over the plan builds them again, as a new job would) WITHOUT draining the
+        pipeline: the report launch in flight and the host tail do not read indexes."""
+        L = api.lib()
+        for idx in self._idx.values():
+            L.damar_index_free(idx)
+        self._idx = {}
+        self._idx_bytes = 0
+
     def drop_block(self, block):
         """Release the indexes of a block (both strands) and its HBM copy: for a scheduler that knows the
         block is not needed again soon."""

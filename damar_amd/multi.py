@@ -383,6 +383,10 @@ class GpuRunner:
         for k in range(0, len(bs), GROUP):
             self(a, bs[k:k + GROUP], outdir)
 
+    def end_pass(self):
+        """End of one pass over the plan when another follows in the same job: the next pass builds its indexes again."""
+        self.plan.release_indexes()
+
     def finish(self):
         self.plan.finish()
 
