@@ -896,7 +896,7 @@ void work_cost(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 n
       if ((keys[mid] >> pbits) == pr) a = mid + 1; else b = mid;
     }
   u64 n = a - i;
-  if (coarse >= 0xfffffffdu)    /* cost = the expected length of the alignment instead of a seed count: the wave kernel's
+  if (coarse >= 0xfffffffcu)    /* cost = the expected length of the alignment instead of a seed count: the wave kernel's
                                    launch ends with its longest serial chains, so those must start first */
     { const u64 pm = (1ull << pbits0) - 1;
       const u64 ext = ((keys[a - 1] >> dbits) & pm) - ((keys[i] >> dbits) & pm);      /* extent of the seeds on A */
@@ -905,6 +905,12 @@ void work_cost(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 n
       const int d = seed_diag(keys[i], vals, i, pm, dbits);             /* diagonal a - b of the first seed */
       const int geo = min(alen, blen + d) - max(0, d);                  /* overlap of the two reads on it */
       u64 len = (coarse == 0xffffffffu) ? ext : (coarse == 0xfffffffeu ? (u64) max(geo, 0) : max(ext, (u64) max(geo, 0)));
+      if (coarse == 0xfffffffcu)  /* forward extent from the first seed: the two halves of a wavefront step in lockstep through
+                                     the forward and then the reverse pass, so similar forward lengths side by side matter */
+        { const int xa0 = (int) ((keys[i] >> dbits) & pm), xb0 = xa0 - d;
+          const int fw = min(alen - xa0, blen - xb0);
+          len = (u64) max(fw, 0);
+        }
       n = len >> (pbits0 > 16 ? pbits0 - 16 : 0);
       coarse = 0;
     }

@@ -1734,7 +1734,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       u32 *ov1 = (u32 *) arena_take(&G_ord, sizeof(u32) * (size_t) nwork);
       void *osw = arena_take(&G_ord, damar_sort_workspace_bytes(nwork));
       const u32 cmode = order_mode == 2 ? 1u : order_mode == 9 ? 0xffffffffu : order_mode == 10 ? 0xfffffffeu :
-                        order_mode == 11 ? 0xfffffffdu : (order_mode > 2 ? (u32) order_mode : 0u);
+                        order_mode == 11 ? 0xfffffffdu : order_mode == 12 ? 0xfffffffcu : (order_mode > 2 ? (u32) order_mode : 0u);
       damar_launch_work_cost(keys, vals, total, m.pbits, m.abits, m.dbits, m.ablk.boff, m.bblk.boff, work, nwork, cmode, ok0, ov0, G_st);
       order = damar_radix_sort_u32(ok0, ov0, ok1, ov1, nwork, WORK_COST_BITS, osw, G_st) ? ov1 : ov0;
       sort_check(osw);
