@@ -74,8 +74,7 @@ __device__ __forceinline__ u32 os_scan256(u32 v, u32 *lds4)
    32 lanes an LDS instruction serves per cycle hit 32 different banks whatever their digits are (lanes l and l + 32 are
    served in different cycles) -- and two 16-bit bins share a word: word (d >> 1) * 32 + copy, half (d & 1).  16 KB per digit
    place, one workgroup of 1024 threads per CU.  A 16-bit bin receives at most 32 threads x OH_ITEMS keys per tile: the grid
-   is sized so that no bin of a workgroup can pass OH_BINMAX.  Beside a resident report launch (one free wave slot per
-   SIMD) the workgroup is 256 threads, as for the passes. */
+   is sized so that no bin of a workgroup can pass OH_BINMAX. */
 #define OH_THREADS 1024
 #define OH_BINMAX  61440                    /* what a 16-bit bin may receive (< 2^16) */
 
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(OH_THREADS)
 void onesweep_hist(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u32 lastmask,
                    u32 *__restrict__ ghist, uint4 *__restrict__ clr, u64 clr16)
 { extern __shared__ u32 sh[];                                  /* [npass][128][32] */
-  const u32 nthr = blockDim.x;                                 /* 1024, or 256 beside a resident report launch */
+  constexpr u32 nthr = OH_THREADS;
   const int nw = npass * 128 * 32;
   for (int j = threadIdx.x; j < nw; j += nthr)
     sh[j] = 0;
@@ -126,6 +125,57 @@ void onesweep_hist(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u
   /* the first look-back region starts empty */
   const uint4 z = make_uint4(0, 0, 0, 0);
   for (u64 i = (u64) blockIdx.x * nthr + threadIdx.x; i < clr16; i += (u64) gridDim.x * nthr)
+    clr[i] = z;
+}
+
+/* The histogram beside a resident report launch: 256 threads (one free wave slot per SIMD) and 8 KB per digit place --
+   the bank-private layout above wants 16 KB per place in ONE piece, which the LDS of a CU shared with report workgroups
+   often cannot give (measured: launches waiting up to a whole report launch, profiles/r03_sweeps.txt). */
+#define OH_COPIES  8
+template <typename KeyT>
+__global__ __launch_bounds__(256)
+void onesweep_hist8(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u32 lastmask,
+                   u32 *__restrict__ ghist, uint4 *__restrict__ clr, u64 clr16)
+{ extern __shared__ u32 sh[];                                  /* [npass][256][OH_COPIES]: the bins of a digit place, OH_COPIES copies chosen by lane & 7 */
+  const int nb = npass * 256 * OH_COPIES;
+  for (int j = threadIdx.x; j < nb; j += 256)
+    sh[j] = 0;
+  __syncthreads();
+  const u32 c = threadIdx.x & (OH_COPIES - 1);
+  const u64 ntile = (n + 256 * OH_ITEMS - 1) / (256 * OH_ITEMS);
+  for (u64 t = blockIdx.x; t < ntile; t += gridDim.x)
+    { const u64 base = t * (256 * OH_ITEMS);
+      KeyT k[OH_ITEMS];
+#pragma unroll
+      for (int r = 0; r < OH_ITEMS; r++)
+        { const u64 i = base + (u64) r * 256 + threadIdx.x;
+          k[r] = (i < n) ? keys[i] : (KeyT) 0;
+        }
+#pragma unroll
+      for (int r = 0; r < OH_ITEMS; r++)
+        { const u64 i = base + (u64) r * 256 + threadIdx.x;
+          if (i < n)
+            { const KeyT x = k[r] >> lobit;
+              for (int p = 0; p < npass; p++)
+                { u32 d = (u32) (x >> (8 * p)) & 0xffu;
+                  if (p == npass - 1) d &= lastmask;
+                  atomicAdd(&sh[(((u32) p << 8) + d) * OH_COPIES + c], 1u);
+                }
+            }
+        }
+    }
+  __syncthreads();
+  for (int j = threadIdx.x; j < npass * 256; j += 256)
+    { u32 s = 0;
+#pragma unroll
+      for (int q = 0; q < OH_COPIES; q++)
+        s += sh[j * OH_COPIES + q];
+      if (s)
+        atomicAdd(&ghist[j], s);
+    }
+  /* the first look-back region starts empty */
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (u64 i = (u64) blockIdx.x * 256 + threadIdx.x; i < clr16; i += (u64) gridDim.x * 256)
     clr[i] = z;
 }
 
@@ -320,23 +370,28 @@ static void onesweep_passes(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lob
   u32 *err = (u32 *) ws, *ghist = (u32 *) (ws + WS_HIST), *ctr = (u32 *) (ws + WS_CTR);
   GT  *lbr[2] = { (GT *) (ws + WS_LB), (GT *) (ws + WS_LB + region) };
   HIP_CHECK(hipMemsetAsync(ws, 0, WS_LB, st));
-  { const u32 hthr = (sort_threads() == 512) ? OH_THREADS : 256;
-    const u64 nt = (n + (u64) hthr * OH_ITEMS - 1) / ((u64) hthr * OH_ITEMS);
-    const u64 maxit = OH_BINMAX / ((hthr / 32) * OH_ITEMS);     /* tiles one workgroup may see */
-    const u64 wgs = (hthr == OH_THREADS) ? 512 : 1024;
-    u64 grid = nt < wgs ? nt : wgs;
-    if ((nt + grid - 1) / grid > maxit)
-      grid = (nt + maxit - 1) / maxit;
-    const size_t lds = (size_t) npass * 128 * 32 * sizeof(u32);
-    static bool big_lds = false;
-    if (!big_lds)                                               /* up to 128 KB of dynamic LDS (8 digit places) */
-      { HIP_CHECK(hipFuncSetAttribute((const void *) onesweep_hist<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
-        HIP_CHECK(hipFuncSetAttribute((const void *) onesweep_hist<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
-        big_lds = true;
-      }
-    hipLaunchKernelGGL(onesweep_hist<KeyT>, dim3((u32) grid), dim3(hthr), lds, st,
-                       k0, n, lobit, npass, (1u << lastb) - 1u, ghist, (uint4 *) lbr[0], (u64) (region / 16));
-  }
+  if (sort_threads() == 512)
+    { const u64 nt = (n + (u64) OH_THREADS * OH_ITEMS - 1) / ((u64) OH_THREADS * OH_ITEMS);
+      const u64 maxit = OH_BINMAX / ((OH_THREADS / 32) * OH_ITEMS);   /* tiles one workgroup may see */
+      u64 grid = nt < 512 ? nt : 512;                                 /* two rounds of one workgroup per CU */
+      if ((nt + grid - 1) / grid > maxit)
+        grid = (nt + maxit - 1) / maxit;
+      const size_t lds = (size_t) npass * 128 * 32 * sizeof(u32);
+      static bool big_lds = false;
+      if (!big_lds)                                                   /* up to 128 KB of dynamic LDS (8 digit places) */
+        { HIP_CHECK(hipFuncSetAttribute((const void *) onesweep_hist<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+          HIP_CHECK(hipFuncSetAttribute((const void *) onesweep_hist<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+          big_lds = true;
+        }
+      hipLaunchKernelGGL(onesweep_hist<KeyT>, dim3((u32) grid), dim3(OH_THREADS), lds, st,
+                         k0, n, lobit, npass, (1u << lastb) - 1u, ghist, (uint4 *) lbr[0], (u64) (region / 16));
+    }
+  else
+    { const u64 nt = (n + 256 * OH_ITEMS - 1) / (256 * OH_ITEMS);
+      const u32 grid = (u32) (nt < 2048 ? nt : 2048);
+      hipLaunchKernelGGL(onesweep_hist8<KeyT>, dim3(grid), dim3(256), (size_t) npass * 256 * OH_COPIES * sizeof(u32), st,
+                         k0, n, lobit, npass, (1u << lastb) - 1u, ghist, (uint4 *) lbr[0], (u64) (region / 16));
+    }
   for (int p = 0; p < npass; p++)
     { const int  side = p & 1;
       const bool last = (p == npass - 1);

@@ -82,8 +82,11 @@ static hipStream_t  G_st;
 static hipStream_t   G_copy;                /* record downloads of the asynchronous mode */
 static hipStream_t   G_rep;                 /* report launches of the asynchronous mode: beside the next comparisons' seed stages */
 static hipEvent_t    G_front_done;          /* the seed stages a report launch reads from are complete */
+static hipEvent_t    G_rep_done;            /* the report launch in flight is complete (DAMAR_OVERLAP=2) */
 static hipEvent_t    G_report_done;
-static hipEvent_t    G_last_d2h = NULL;     /* the next report kernel must not overwrite the buffers before it */
+static hipEvent_t    G_set_d2h[2];
+static hipEvent_t    G_last_d2h[2] = { NULL, NULL };   /* per set of record buffers: the download the next kernel that writes
+                                                          into the set must not overtake */
 static hipDeviceProp_t G_prop;
 static hipEvent_t   G_ev[16];
 static double       G_ms[DAMAR_T_COUNT];
@@ -228,6 +231,9 @@ extern "C" int damar_hip_init(int device)
       HIP_CHECK(hipStreamCreate(&G_copy));
       HIP_CHECK(hipStreamCreate(&G_rep));
       HIP_CHECK(hipEventCreate(&G_front_done));
+      HIP_CHECK(hipEventCreateWithFlags(&G_rep_done, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&G_set_d2h[0], hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&G_set_d2h[1], hipEventDisableTiming));
       HIP_CHECK(hipEventCreate(&G_report_done));
       for (int i = 0; i < 16; i++)
         HIP_CHECK(hipEventCreate(&G_ev[i]));
@@ -242,7 +248,9 @@ extern "C" int damar_hip_init(int device)
   return ndev;
 }
 
-static double Q_ms[4];      /* DAMAR_HOSTPROF: scratch_prepare, scratch_outputs */
+static double Q_ms[4];      /* DAMAR_HOSTPROF: scratch_prepare, scratch_outputs, outside the library between two
+                               damar_match_batch calls, from a report launch to the next comparison's first kernel */
+static double Q_exit = 0, Q_flush = 0, Q_seg[4], Q_entry = 0;
 
 static void hostprof_at_exit(void)
 { fprintf(stderr, "damar host wall ms (at exit):");
@@ -508,13 +516,14 @@ static void sort_check(const void *sw)
    a resident report launch (which leaves 128 registers per SIMD) only one wavefront per SIMD finds room, i.e. the
    256-thread shape.  DAMAR_SORT_THREADS overrides. */
 static bool overlap_on(void);
+static bool corun_on(void);
 static void pick_sort_shape(void)
 { static int forced = -1;
   if (forced < 0)
     { const char *e = getenv("DAMAR_SORT_THREADS");
       forced = e ? atoi(e) : 0;
     }
-  damar_sort_set_threads(forced ? forced : (overlap_on() ? 256 : 512));
+  damar_sort_set_threads(forced ? forced : (corun_on() ? 256 : 512));
 }
 
 static int ilog2_ceil(u64 n)
@@ -781,12 +790,16 @@ struct ReportScratch
   short *tables;             /* SCORE then TABLE */
   const void *tables_of;     /* host spec they were copied from */
   u32  *counters;
-  LaRecord *recs;  u32 rec_cap;
+  LaRecord *recs;  u32 rec_cap;      /* the record / trace buffers of set `cur` */
   u16  *tpool;     u32 tpool_cap;
+  /* two sets of record / trace buffers: a launch writes into one set while the records of the launch before it are still
+     on their way to the host out of the other (measured: a launch waited 1.4 - 2.2 ms for that download) */
+  LaRecord *recs_set[2];  u16 *tpool_set[2];  int cur;
 };
 static ReportScratch RS = {};   /* (nslots_wanted: the slot count asked for when nslots was last sized) */
 
 static bool overlap_on(void);
+static bool corun_on(void);
 
 static int default_slots(void)
 { const char *e = getenv("DAMAR_SLOTS");
@@ -795,7 +808,7 @@ static int default_slots(void)
   /* a report launch that shares the machine with the next comparisons' seed stages leaves them a fifth of the register
      file: 4 of the 5 wavefronts per SIMD the packed kernel is compiled for (measured, r02_sweeps.txt: 524 ms per step
      against 549 at 5 and 543 at 3.5) */
-  if (overlap_on())
+  if (corun_on())
     return G_prop.multiProcessorCount * 4 * 2 * std::min(4, damar_report2_waves_per_simd());
   /* every wave slot of the chip: one scratch slot per wavefront of the one-pair kernel, two per wavefront of the packed one */
   return G_prop.multiProcessorCount * 4 * std::max(damar_report_waves_per_simd(), 2 * damar_report2_waves_per_simd());
@@ -827,9 +840,9 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
     { fprintf(stderr, "damar: FATAL: a trace spacing (-s) above %d is not supported by this build\n", DAMAR_MAX_TSPACE);
       die();
     }
-  if (G_last_d2h != NULL)        /* whatever is launched next overwrites the record buffers */
-    { HIP_CHECK(hipStreamWaitEvent(st, G_last_d2h, 0));
-      G_last_d2h = NULL;
+  if (G_last_d2h[RS.cur] != NULL)  /* whatever is launched next overwrites the record buffers of this set */
+    { HIP_CHECK(hipStreamWaitEvent(st, G_last_d2h[RS.cur], 0));
+      G_last_d2h[RS.cur] = NULL;
     }
   /* The band state of a slot (used only while a band is wider than the 64 lanes) is a ring of G_ring
      diagonals, not one entry per diagonal of the pair: 1024 instead of alen + blen keeps the scratch of
@@ -912,22 +925,28 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
 }
 
 static void scratch_outputs(u32 rec_cap, u32 tpool_cap)
-{ if (RS.rec_cap < rec_cap)
+{ if (RS.rec_cap < rec_cap || RS.tpool_cap < tpool_cap)
     { HIP_CHECK(hipStreamSynchronize(G_st));
       HIP_CHECK(hipStreamSynchronize(G_copy));
       HIP_CHECK(hipStreamSynchronize(G_rep));
-      if (RS.recs) HIP_CHECK(hipFree(RS.recs));
-      RS.rec_cap = rec_cap + (rec_cap >> 2);
-      RS.recs = (LaRecord *) dmalloc(sizeof(LaRecord) * (size_t) RS.rec_cap);
+      G_last_d2h[0] = G_last_d2h[1] = NULL;
+      if (RS.rec_cap < rec_cap)
+        { RS.rec_cap = rec_cap + (rec_cap >> 2);
+          for (int i = 0; i < 2; i++)
+            { if (RS.recs_set[i]) HIP_CHECK(hipFree(RS.recs_set[i]));
+              RS.recs_set[i] = (LaRecord *) dmalloc(sizeof(LaRecord) * (size_t) RS.rec_cap);
+            }
+        }
+      if (RS.tpool_cap < tpool_cap)
+        { RS.tpool_cap = tpool_cap + (tpool_cap >> 2);
+          for (int i = 0; i < 2; i++)
+            { if (RS.tpool_set[i]) HIP_CHECK(hipFree(RS.tpool_set[i]));
+              RS.tpool_set[i] = (u16 *) dmalloc(sizeof(u16) * (size_t) RS.tpool_cap);
+            }
+        }
     }
-  if (RS.tpool_cap < tpool_cap)
-    { HIP_CHECK(hipStreamSynchronize(G_st));
-      HIP_CHECK(hipStreamSynchronize(G_copy));
-      HIP_CHECK(hipStreamSynchronize(G_rep));
-      if (RS.tpool) HIP_CHECK(hipFree(RS.tpool));
-      RS.tpool_cap = tpool_cap + (tpool_cap >> 2);
-      RS.tpool = (u16 *) dmalloc(sizeof(u16) * (size_t) RS.tpool_cap);
-    }
+  RS.recs  = RS.recs_set[RS.cur];
+  RS.tpool = RS.tpool_set[RS.cur];
 }
 
 static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const damar_dev_block *bb,
@@ -945,8 +964,24 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   /* SCORE/TABLE of this Align_Spec, every time (128 KB): remembering "the tables of spec X are
      already up" by X's address went wrong when a freed spec's address came back for a new one
      with another -e */
-  HIP_CHECK(hipMemcpyAsync(RS.tables + (size_t) tslot * 65536, damar_spec_score_table(spec), sizeof(short) * 65536,
-                           hipMemcpyHostToDevice, st));
+  { /* ... but only when the slot does not hold these very values already (a host copy of what is up there is compared):
+       the copy comes out of pageable memory, and behind the download of the previous launch's records it held the
+       launch back by 1.4 - 7 ms (scripts/gpu_gaps_api.sh) */
+    static short *shadow = NULL;
+    static bool   valid[DAMAR_MAX_JOBS];
+    if (shadow == NULL)
+      shadow = (short *) malloc(sizeof(short) * 65536 * DAMAR_MAX_JOBS);
+    short *mine = shadow + (size_t) tslot * 65536;
+    if (shadow == NULL || !valid[tslot] || memcmp(mine, damar_spec_score_table(spec), sizeof(short) * 65536) != 0)
+      { HIP_CHECK(hipMemcpyAsync(RS.tables + (size_t) tslot * 65536, damar_spec_score_table(spec), sizeof(short) * 65536,
+                                 hipMemcpyHostToDevice, st));
+        if (shadow != NULL)
+          { memcpy(mine, damar_spec_score_table(spec), sizeof(short) * 65536);
+            valid[tslot] = true;
+            HIP_CHECK(hipStreamSynchronize(st));        /* (a later launch on another stream may find the slot "up") */
+          }
+      }
+  }
   ra->score = RS.tables + (size_t) tslot * 65536;
   ra->table = ra->score + 32768;
   { const int16 *sc = damar_spec_score_table(spec);          /* SCORE[x] = matches * mscore - (15 - matches) * dscore */
@@ -1368,7 +1403,9 @@ extern "C" void damar_async_totals(int64 *ncheck, double *tail_ms, double *write
         { fprintf(stderr, " %s=%.1f", H_name[i], H_ms[i]);
           H_ms[i] = 0;
         }
-      fprintf(stderr, "\n");
+      fprintf(stderr, " | between calls=%.1f launch->next front=%.1f flush->exit=%.1f entry->front=%.1f front->tick0=%.1f\n",
+              Q_ms[2], Q_ms[3], Q_seg[0], Q_seg[2], Q_seg[3]);
+      Q_ms[2] = Q_ms[3] = 0;  Q_exit = 0;  Q_seg[0] = Q_seg[2] = Q_seg[3] = 0;
     }
   std::lock_guard<std::mutex> lk(A_mu);
   if (ncheck)   *ncheck = A_ncheck;
@@ -1407,6 +1444,7 @@ struct Front
   int pbits, abits, dbits;
   JobParams jp;                 /* parameters and options of the moment the seed stage ran */
   size_t bytes;                 /* of the two arenas that hold the above */
+  double t_entry;
 };
 
 /* Seed stage of one comparison (filter.c:2603-2760): merge-count, scan, emit, seed sort, work list and its
@@ -1417,8 +1455,10 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
   const int self = job->self, comp = job->comp;
   Arena &G_hits = G_hitsJ[slot], &G_ord = G_ordJ[slot];
   int64 nhits = 0;
+  const double t_entry = now_ms();
   pick_sort_shape();
   memset(f, 0, sizeof(*f));
+  f->t_entry = t_entry;
   f->jp = params_now();
   job->counts[0] = job->counts[1] = job->counts[2] = 0;
   if (aidx == NULL || bidx == NULL || aidx->n == 0 || bidx->n == 0)
@@ -1462,6 +1502,9 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
   u64  *tot;
   u64   total = 0;
 
+  if (Q_flush > 0)
+    { Q_ms[3] += now_ms() - Q_flush;  Q_flush = 0; }
+  Q_seg[3] += now_ms() - f->t_entry;
   tick(0);
   arena_reserve(&G_work, pad256(damar_merge_workspace_bytes(alen)) + pad256(damar_scan_workspace_bytes(mtiles)) + 4096);
   mw = arena_take(&G_work, damar_merge_workspace_bytes(alen));
@@ -1764,6 +1807,7 @@ struct Pending
   int  amax, bmax, tsmin;
   u32  cell_cap, rec_cap, tp_cap;
   int  attempt;
+  int  oset;                                      /* the set of record buffers this launch writes into */
   hipStream_t st;
   double t_launch;
   ReportArgs ra[DAMAR_MAX_JOBS];                  /* what the launch was given (the upload is asynchronous) */
@@ -1790,6 +1834,7 @@ static Accum &AC = *new Accum();
 
 
 static int     G_set = 0;                          /* which set of job arenas the next seed stages use */
+static int     G_oset = 0;                         /* which set of record buffers the next report launch writes into */
 static int64   A_nfilt = 0;                        /* totals of the asynchronous mode (damar_async_counts) */
 static double  A_report_ms = 0;
 static int64   A_launches = 0;
@@ -1798,6 +1843,7 @@ static void report_launch(Pending &pd)
 { ReportArgs *const ra = pd.ra;
   const hipStream_t st = pd.st;
   double q0 = now_ms();
+  RS.cur = pd.oset;
   scratch_prepare(pd.amax, pd.bmax, pd.fr[0].jp.binshift, pd.tsmin, pd.cell_cap, st);
   double q1 = now_ms();
   scratch_outputs(pd.rec_cap, pd.tp_cap);
@@ -1884,8 +1930,8 @@ static void report_finish(Pending &pd)
   if (A_on)
     HIP_CHECK(hipEventRecord(hb->e0, cs));       /* (the report kernel has completed: the host synced on it) */
   if (hc[1] > 0)
-    { HIP_CHECK(hipMemcpyAsync(hb->recs, RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, cs));
-      HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, cs));
+    { HIP_CHECK(hipMemcpyAsync(hb->recs, RS.recs_set[pd.oset], sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, cs));
+      HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool_set[pd.oset], sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, cs));
     }
   tick_on(7, st);
   if (A_on)
@@ -1893,7 +1939,10 @@ static void report_finish(Pending &pd)
          tail thread waits for it, and so does the next report kernel (which would overwrite the device buffers) */
       HIP_CHECK(hipEventRecord(hb->e1, cs));
       hb->pending = true;
-      G_last_d2h = hb->e1;
+      /* (an event of the SET, not hb->e1: the host buffer is recycled, and a wait on its event would mean its next
+         download -- the one out of the other set that has just been started) */
+      HIP_CHECK(hipEventRecord(G_set_d2h[pd.oset], cs));
+      G_last_d2h[pd.oset] = G_set_d2h[pd.oset];
     }
   else
     { HIP_CHECK(hipStreamSynchronize(st));
@@ -1947,7 +1996,7 @@ static int batch_limit(void)
                                    flight keeps its sorted seed pairs (12 B each) in HBM, which a cold process pays for
                                    at ~25 ms per GB */
       if (n == 0)
-        return overlap_on() ? 2 : 4;            /* overlapped launches: short ones interleave better (548 against 590 ms) */
+        return corun_on() ? 2 : 4;            /* overlapped launches: short ones interleave better (548 against 590 ms) */
       if (n < 1) n = 1;
       if (n > DAMAR_MAX_JOBS) n = DAMAR_MAX_JOBS;
     }
@@ -1998,7 +2047,10 @@ extern "C" void damar_async_counts(int64 *nfilt, double *report_ms, int64 *launc
   A_nfilt = 0;  A_report_ms = 0;  A_launches = 0;
 }
 
-static bool overlap_on(void)
+/* DAMAR_OVERLAP: 1 = the report launch runs BESIDE the next comparisons' seed stages (its own stream, 4 of 5 wavefronts per
+   SIMD); 2 = it runs on its own stream but the next seed stages wait for it on the device: the kernels follow each other
+   as in mode 0, while the host (completion of the launch, download, tails) stays pipelined; 0 = launch, wait, tail. */
+static int overlap_mode(void)
 { static int on = -1;
   if (on < 0)
     { const char *e = getenv("DAMAR_OVERLAP");
@@ -2006,8 +2058,10 @@ static bool overlap_on(void)
     }
   /* only behind the asynchronous host tail (nobody reads the records at return), and not when the caller wants the
      per-comparison counts printed (-v) or the seeds kept */
-  return on && A_on && !VERBOSE && !G_keep_seeds;
+  return (A_on && !VERBOSE && !G_keep_seeds) ? on : 0;
 }
+static bool overlap_on(void) { return overlap_mode() != 0; }
+static bool corun_on(void)   { return overlap_mode() == 1; }
 
 static u64 batch_work(void)
 { static long long w = -1;
@@ -2041,6 +2095,7 @@ static void flush_accum(void)
                                                                   overflow flags and the re-launch are exercised */
     { pd.cell_cap = 64;  pd.rec_cap = 16;  pd.tp_cap = 512; }
   pd.attempt = 0;
+  pd.oset = G_oset;  G_oset ^= 1;
   pd.st = defer ? G_rep : G_st;
   for (TailJob *w : AC.writes)
     pd.writes.push_back(w);
@@ -2052,8 +2107,13 @@ static void flush_accum(void)
   report_launch(pd);
   if (!defer)
     report_finish(pd);
+  else if (!corun_on())                        /* in order on the device: the next seed stages start behind this launch */
+    { HIP_CHECK(hipEventRecord(G_rep_done, G_rep));
+      HIP_CHECK(hipStreamWaitEvent(G_st, G_rep_done, 0));
+    }
   G_set ^= 1;
   AC.n = 0;  AC.bytes = 0;  AC.nwork = 0;
+  Q_flush = now_ms();
 }
 
 /* everything this library still owes: the comparisons held back, then the launch in flight */
@@ -2065,6 +2125,8 @@ static void finish_all(void)
 extern "C" void damar_match_batch(damar_match_job *jobs, int njobs)
 { ensure_init();
   const double h0 = now_ms();
+  if (Q_exit > 0)
+    Q_ms[2] += h0 - Q_exit;
   memset(G_cnt, 0, sizeof(G_cnt));
   for (int i = DAMAR_T_MERGE; i < DAMAR_T_COUNT; i++)
     G_ms[i] = 0;
@@ -2092,6 +2154,8 @@ extern "C" void damar_match_batch(damar_match_job *jobs, int njobs)
             flush_accum();
         }
       const int n = AC.n;
+      if (i == 0)
+        Q_seg[2] += now_ms() - h0;
       if (match_front(&jobs[i], G_set * hard + n, &AC.fr[n]))
         { AC.job[n] = jobs[i];  AC.orig[n] = &jobs[i];
           AC.ablk[n] = jobs[i].aidx->blk;  AC.bblk[n] = jobs[i].bidx->blk;
@@ -2109,7 +2173,10 @@ extern "C" void damar_match_batch(damar_match_job *jobs, int njobs)
     PD.orig[j] = NULL;
   for (int j = 0; j < DAMAR_MAX_JOBS / 2; j++)
     AC.orig[j] = NULL;
-  H_ms[6] += now_ms() - h0;
+  Q_exit = now_ms();
+  if (Q_flush > 0)
+    Q_seg[0] += Q_exit - Q_flush;
+  H_ms[6] += Q_exit - h0;
 }
 
 extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
