@@ -81,6 +81,7 @@ static int          G_ready = 0;
 static hipStream_t  G_st;
 static hipStream_t   G_copy;                /* record downloads of the asynchronous mode */
 static hipStream_t   G_rep;                 /* report launches of the asynchronous mode: beside the next comparisons' seed stages */
+static hipStream_t   G_ctl;                 /* small downloads (a launch's counters) that must not queue behind anything */
 static hipEvent_t    G_front_done;          /* the seed stages a report launch reads from are complete */
 static hipEvent_t    G_rep_done;            /* the report launch in flight is complete (DAMAR_OVERLAP=2) */
 static hipEvent_t    G_report_done;
@@ -88,7 +89,7 @@ static hipEvent_t    G_set_d2h[2];
 static hipEvent_t    G_last_d2h[2] = { NULL, NULL };   /* per set of record buffers: the download the next kernel that writes
                                                           into the set must not overtake */
 static hipDeviceProp_t G_prop;
-static hipEvent_t   G_ev[16];
+static hipEvent_t   G_ev[24];
 static double       G_ms[DAMAR_T_COUNT];
 static int          G_limit = 0;          /* the mutual-count cap the last Match_Filter used */
 static double       H_ms[8];              /* host wall clock per phase (DAMAR_HOSTPROF=1 prints them at drain) */
@@ -230,12 +231,13 @@ extern "C" int damar_hip_init(int device)
       HIP_CHECK(hipStreamCreate(&G_st));
       HIP_CHECK(hipStreamCreate(&G_copy));
       HIP_CHECK(hipStreamCreate(&G_rep));
+      HIP_CHECK(hipStreamCreate(&G_ctl));
       HIP_CHECK(hipEventCreate(&G_front_done));
       HIP_CHECK(hipEventCreateWithFlags(&G_rep_done, hipEventDisableTiming));
       HIP_CHECK(hipEventCreateWithFlags(&G_set_d2h[0], hipEventDisableTiming));
       HIP_CHECK(hipEventCreateWithFlags(&G_set_d2h[1], hipEventDisableTiming));
       HIP_CHECK(hipEventCreate(&G_report_done));
-      for (int i = 0; i < 16; i++)
+      for (int i = 0; i < 24; i++)
         HIP_CHECK(hipEventCreate(&G_ev[i]));
       if (MEM_PHYSICAL == ~0ull)
         { uint64 phys = (uint64) sysconf(_SC_PHYS_PAGES) * (uint64) sysconf(_SC_PAGESIZE);
@@ -268,7 +270,6 @@ static void ensure_init(void)
     }
 }
 
-static void finish_pending(void);
 static void finish_all(void);
 
 extern "C" void damar_hip_sync(void)
@@ -462,7 +463,6 @@ static damar_dev_block *block_upload_on(const HITS_DB *block, hipStream_t st)
   return b;
 }
 
-static void finish_pending(void);
 
 extern "C" void damar_block_free(damar_dev_block *b)
 { if (b == NULL)
@@ -790,11 +790,13 @@ struct ReportScratch
   short *tables;             /* SCORE then TABLE */
   const void *tables_of;     /* host spec they were copied from */
   u32  *counters;
-  LaRecord *recs;  u32 rec_cap;      /* the record / trace buffers of set `cur` */
+  LaRecord *recs;  u32 rec_cap;      /* the record / trace buffers and the counters of set `cur` */
   u16  *tpool;     u32 tpool_cap;
-  /* two sets of record / trace buffers: a launch writes into one set while the records of the launch before it are still
-     on their way to the host out of the other (measured: a launch waited 1.4 - 2.2 ms for that download) */
-  LaRecord *recs_set[2];  u16 *tpool_set[2];  int cur;
+  u32  *ctr;
+  /* two sets of record / trace buffers and counters: a launch writes into one set while the records of the launch before
+     it are still on their way to the host out of the other (measured: a launch waited 1.4 - 2.2 ms for that download),
+     and the next launch can be queued behind a running one */
+  LaRecord *recs_set[2];  u16 *tpool_set[2];  u32 rec_cap_set[2], tpool_cap_set[2];  int cur;
 };
 static ReportScratch RS = {};   /* (nslots_wanted: the slot count asked for when nslots was last sized) */
 
@@ -918,35 +920,33 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
                 now_ms() - g2, RS.span, RS.bwidth, RS.cell_cap);
     }
   if (RS.counters == NULL)
-    { RS.counters = (u32 *) dmalloc(sizeof(u32) * DAMAR_COUNTER_WORDS);
+    { RS.counters = (u32 *) dmalloc(sizeof(u32) * DAMAR_COUNTER_WORDS * 2);
       RS.tables   = (short *) dmalloc(sizeof(short) * 65536 * DAMAR_MAX_JOBS);
     }
   HIP_CHECK(hipMemsetAsync(RS.buckets, 0, sizeof(int) * (size_t) RS.bucket_stride * RS.nslots, st));
 }
 
+/* the record / trace buffers of set RS.cur hold at least this much (nothing is in flight on that set: its last launch has
+   been completed; its download may still run) */
 static void scratch_outputs(u32 rec_cap, u32 tpool_cap)
-{ if (RS.rec_cap < rec_cap || RS.tpool_cap < tpool_cap)
-    { HIP_CHECK(hipStreamSynchronize(G_st));
-      HIP_CHECK(hipStreamSynchronize(G_copy));
-      HIP_CHECK(hipStreamSynchronize(G_rep));
-      G_last_d2h[0] = G_last_d2h[1] = NULL;
-      if (RS.rec_cap < rec_cap)
-        { RS.rec_cap = rec_cap + (rec_cap >> 2);
-          for (int i = 0; i < 2; i++)
-            { if (RS.recs_set[i]) HIP_CHECK(hipFree(RS.recs_set[i]));
-              RS.recs_set[i] = (LaRecord *) dmalloc(sizeof(LaRecord) * (size_t) RS.rec_cap);
-            }
+{ const int c = RS.cur;
+  if (RS.rec_cap_set[c] < rec_cap || RS.tpool_cap_set[c] < tpool_cap)
+    { HIP_CHECK(hipStreamSynchronize(G_copy));
+      G_last_d2h[c] = NULL;
+      if (RS.rec_cap_set[c] < rec_cap)
+        { RS.rec_cap_set[c] = rec_cap + (rec_cap >> 2);
+          if (RS.recs_set[c]) HIP_CHECK(hipFree(RS.recs_set[c]));
+          RS.recs_set[c] = (LaRecord *) dmalloc(sizeof(LaRecord) * (size_t) RS.rec_cap_set[c]);
         }
-      if (RS.tpool_cap < tpool_cap)
-        { RS.tpool_cap = tpool_cap + (tpool_cap >> 2);
-          for (int i = 0; i < 2; i++)
-            { if (RS.tpool_set[i]) HIP_CHECK(hipFree(RS.tpool_set[i]));
-              RS.tpool_set[i] = (u16 *) dmalloc(sizeof(u16) * (size_t) RS.tpool_cap);
-            }
+      if (RS.tpool_cap_set[c] < tpool_cap)
+        { RS.tpool_cap_set[c] = tpool_cap + (tpool_cap >> 2);
+          if (RS.tpool_set[c]) HIP_CHECK(hipFree(RS.tpool_set[c]));
+          RS.tpool_set[c] = (u16 *) dmalloc(sizeof(u16) * (size_t) RS.tpool_cap_set[c]);
         }
     }
-  RS.recs  = RS.recs_set[RS.cur];
-  RS.tpool = RS.tpool_set[RS.cur];
+  RS.recs  = RS.recs_set[c];   RS.rec_cap   = RS.rec_cap_set[c];
+  RS.tpool = RS.tpool_set[c];  RS.tpool_cap = RS.tpool_cap_set[c];
+  RS.ctr   = RS.counters + (size_t) c * DAMAR_COUNTER_WORDS;
 }
 
 static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const damar_dev_block *bb,
@@ -996,9 +996,9 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   ra->ttmp = RS.ttmp;  ra->ttmp_stride = RS.ttmp_stride;
   ra->recs = RS.recs;  ra->rec_cap = RS.rec_cap;
   ra->tpool = RS.tpool;  ra->tpool_cap = RS.tpool_cap;
-  ra->counters = RS.counters;
-  ra->cursor = RS.counters + DAMAR_CNT_CURSOR + job;
-  ra->nfilt  = RS.counters + DAMAR_CNT_NFILT + job;
+  ra->counters = RS.ctr;
+  ra->cursor = RS.ctr + DAMAR_CNT_CURSOR + job;
+  ra->nfilt  = RS.ctr + DAMAR_CNT_NFILT + job;
 }
 
 
@@ -1796,10 +1796,14 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
    stream and is completed only when the NEXT launch is due (or at a drain): the kernel is bound by instruction issue and
    dependent latency, the seed stage of the following comparisons by HBM, and the two share the machine (tools/corun.hip:
    a register-heavy persistent kernel and a streaming kernel finish together in 80 % of the time they take one after the
-   other).  At most one launch is in flight; the seed stages alternate between two sets of job arenas. */
+   other).  Up to two launches are in flight -- one running, one queued behind it on the stream, so that the device goes
+   from one to the next without the host -- while the seed stages of later comparisons accumulate; every comparison holds
+   one of DAMAR_MAX_JOBS slots (arenas of its sorted seeds and work list, its SCORE/TABLE copy) from its seed stage until
+   its launch has been completed. */
 struct Pending
 { bool live;
-  int  n, slot0;
+  int  n;
+  int  slot[DAMAR_MAX_JOBS];
   damar_match_job  job[DAMAR_MAX_JOBS];           /* copies: the caller's array may be gone when the launch completes */
   damar_match_job *orig[DAMAR_MAX_JOBS];          /* the caller's structs (counts) while its call is still running */
   Front fr[DAMAR_MAX_JOBS];
@@ -1807,13 +1811,16 @@ struct Pending
   int  amax, bmax, tsmin;
   u32  cell_cap, rec_cap, tp_cap;
   int  attempt;
-  int  oset;                                      /* the set of record buffers this launch writes into */
+  int  oset;                                      /* the set of record buffers, counters and timers this launch uses */
+  hipEvent_t done;                                /* behind the kernel */
   hipStream_t st;
   double t_launch;
   ReportArgs ra[DAMAR_MAX_JOBS];                  /* what the launch was given (the upload is asynchronous) */
   std::vector<TailJob *> writes;                  /* damar_write_overlaps requests that wait for this launch's tails */
 };
-static Pending &PD = *new Pending();
+static Pending *PQ = new Pending[2]();               /* PQ[i] uses output set i */
+static int      PQ_head = 0, PQ_n = 0;             /* the oldest launch in flight, how many there are */
+static bool     G_slot_busy[DAMAR_MAX_JOBS];
 
 /* Comparisons whose seed stages are done and whose report launch has not been made yet.  In asynchronous mode a launch is
    held back while it would be SMALL: a launch ends by waiting for its longest alignment (a 15 kb read pair is some 10 ms of
@@ -1822,6 +1829,7 @@ static Pending &PD = *new Pending();
    arenas is full; the files of the block pairs in it wait with it (damar_write_overlaps). */
 struct Accum
 { int    n;
+  int    slot[DAMAR_MAX_JOBS / 2];
   damar_match_job  job[DAMAR_MAX_JOBS / 2];
   damar_match_job *orig[DAMAR_MAX_JOBS / 2];
   Front  fr[DAMAR_MAX_JOBS / 2];
@@ -1833,8 +1841,6 @@ struct Accum
 static Accum &AC = *new Accum();
 
 
-static int     G_set = 0;                          /* which set of job arenas the next seed stages use */
-static int     G_oset = 0;                         /* which set of record buffers the next report launch writes into */
 static int64   A_nfilt = 0;                        /* totals of the asynchronous mode (damar_async_counts) */
 static double  A_report_ms = 0;
 static int64   A_launches = 0;
@@ -1852,7 +1858,7 @@ static void report_launch(Pending &pd)
   bool packed = true;
   for (int j = 0; j < pd.n; j++)
     { const damar_match_job &jb = pd.job[j];
-      fill_report_args(&ra[j], pd.ablk[j], pd.bblk[j], jb.comp, jb.self, jb.spec, st, j, pd.slot0 + j, pd.fr[j].jp);
+      fill_report_args(&ra[j], pd.ablk[j], pd.bblk[j], jb.comp, jb.self, jb.spec, st, j, pd.slot[j], pd.fr[j].jp);
       ra[j].keys = pd.fr[j].keys;  ra[j].vals = pd.fr[j].vals;  ra[j].nhits = pd.fr[j].total;
       ra[j].work = pd.fr[j].work;  ra[j].nwork = pd.fr[j].nwork;
       ra[j].pbits = pd.fr[j].pbits;  ra[j].abits = pd.fr[j].abits;  ra[j].dbits = pd.fr[j].dbits;
@@ -1863,13 +1869,16 @@ static void report_launch(Pending &pd)
           die();
         }
     }
-  HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, st));
-  tick_on(4, st);
+  HIP_CHECK(hipMemsetAsync(RS.ctr, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, st));
+  tick_on(16 + 4 * pd.oset, st);
   if (packed)
     damar_launch_report2(ra, pd.n, NULL, 0, RS.nslots, st);
   else
     damar_launch_report(ra, pd.n, RS.nslots, st);
-  tick_on(5, st);
+  tick_on(17 + 4 * pd.oset, st);
+  if (pd.done == NULL)
+    HIP_CHECK(hipEventCreateWithFlags(&pd.done, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(pd.done, st));
   pd.live = true;
   pd.t_launch = now_ms();
 }
@@ -1884,10 +1893,12 @@ static void report_finish(Pending &pd)
   const int n = pd.n;
   const double h2 = now_ms();
   for (;;)
-    { HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
+    { /* this launch only: a younger one may be queued behind it on the same stream */
+      HIP_CHECK(hipEventSynchronize(pd.done));
+      HIP_CHECK(hipMemcpyAsync(hc, RS.counters + (size_t) pd.oset * DAMAR_COUNTER_WORDS, sizeof(hc), hipMemcpyDeviceToHost, G_ctl));
+      HIP_CHECK(hipStreamSynchronize(G_ctl));
       HIP_CHECK(hipGetLastError());
-      { const float ms = lap(4, 5);
+      { const float ms = lap(16 + 4 * pd.oset, 17 + 4 * pd.oset);
         G_ms[DAMAR_T_REPORT] += ms;
         if (A_on)
           { std::lock_guard<std::mutex> lk(A_mu);
@@ -1922,7 +1933,7 @@ static void report_finish(Pending &pd)
       report_launch(pd);
     }
   pd.live = false;
-  tick_on(6, st);
+  tick_on(18 + 4 * pd.oset, st);
   const double h3 = now_ms();
   HostBuf *hb = hostbuf_get(hc[1], hc[2]);
   hb->users = n;
@@ -1933,7 +1944,7 @@ static void report_finish(Pending &pd)
     { HIP_CHECK(hipMemcpyAsync(hb->recs, RS.recs_set[pd.oset], sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, cs));
       HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool_set[pd.oset], sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, cs));
     }
-  tick_on(7, st);
+  tick_on(19 + 4 * pd.oset, st);
   if (A_on)
     { /* asynchronous mode: the download runs on its own stream beside the next comparison's merge and sorts; the
          tail thread waits for it, and so does the next report kernel (which would overwrite the device buffers) */
@@ -1946,7 +1957,7 @@ static void report_finish(Pending &pd)
     }
   else
     { HIP_CHECK(hipStreamSynchronize(st));
-      G_ms[DAMAR_T_D2H] += lap(6, 7);
+      G_ms[DAMAR_T_D2H] += lap(18 + 4 * pd.oset, 19 + 4 * pd.oset);
     }
   G_cnt[3] += hc[1];  G_cnt[4] += hc[2];
   const double h4 = now_ms();
@@ -1983,9 +1994,35 @@ static void report_finish(Pending &pd)
   H_ms[3] += h3 - h2;  H_ms[4] += h4 - h3;  H_ms[5] += h5 - h4;
 }
 
-static void finish_pending(void)
-{ if (PD.live)
-    report_finish(PD);
+/* completes the oldest launch in flight and releases its comparisons' slots */
+static void finish_oldest(void)
+{ if (PQ_n == 0)
+    return;
+  Pending &pd = PQ[PQ_head];
+  report_finish(pd);
+  for (int j = 0; j < pd.n; j++)
+    G_slot_busy[pd.slot[j]] = false;
+  pd.n = 0;
+  PQ_head ^= 1;
+  PQ_n -= 1;
+}
+
+static void flush_accum(void);
+
+/* a free comparison slot; when there is none, the oldest launch is completed (or, with nothing in flight, the comparisons
+   held back are launched) */
+static int slot_take(void)
+{ for (;;)
+    { for (int i = 0; i < DAMAR_MAX_JOBS; i++)
+        if (!G_slot_busy[i])
+          { G_slot_busy[i] = true;
+            return i;
+          }
+      if (PQ_n > 0)
+        finish_oldest();
+      else
+        flush_accum();
+    }
 }
 
 static int batch_limit(void)
@@ -2027,12 +2064,14 @@ extern "C" void damar_write_overlaps(Align_Spec *spec, const char *d1, const cha
       { AC.writes.push_back(job);
         return;
       }
-  if (PD.live)                                   /* the tails of a launch in flight are not queued yet: behind them */
-    for (int j = 0; j < PD.n; j++)
-      if (PD.job[j].spec == spec)
-        { PD.writes.push_back(job);
-          return;
-        }
+  for (int q = PQ_n - 1; q >= 0; q--)            /* the tails of a launch in flight are not queued yet: behind them */
+    { Pending &pd = PQ[(PQ_head + q) & 1];         /* (the youngest launch that holds the spec) */
+      for (int j = 0; j < pd.n; j++)
+        if (pd.job[j].spec == spec)
+          { pd.writes.push_back(job);
+            return;
+          }
+    }
   async_submit(job);
 }
 
@@ -2076,26 +2115,40 @@ static void flush_accum(void)
 { if (AC.n == 0)
     return;
   const bool defer = overlap_on();
-  /* the launch in flight (it ran beside these seed stages) is completed first: one set of output buffers */
-  finish_pending();
-  Pending &pd = PD;
+  /* an entry of the launch queue, i.e. a set of output buffers: the oldest launch in flight is completed first when both
+     are taken (it ran beside these seed stages) */
+  /* How many launches may be in flight.  Two (the next one queued behind the running one) takes the host out of the
+     hand-over, but measured SLOWER on config 2: 434 - 445 ms per step against 398 - 410 with one.  With one, the host
+     waits here for the running launch, so the seed stream is idle during the last third of every launch -- the phase in
+     which the kernel works through the many short read pairs, whose band filters hammer the bucket arrays; seed sorts that
+     run beside that phase take 180 instead of 100 ms per step. */
+  static int depth = 0;
+  if (depth == 0)
+    { const char *e = getenv("DAMAR_LAUNCH_QUEUE");
+      depth = (e && atoi(e) == 2) ? 2 : 1;
+    }
+  while (PQ_n >= depth)
+    finish_oldest();
+  Pending &pd = PQ[(PQ_head + PQ_n) & 1];
   const int n = AC.n;
-  pd.n = n;  pd.slot0 = G_set * (DAMAR_MAX_JOBS / 2);
+  pd.n = n;
+  pd.oset = (int) (&pd - PQ);
   pd.amax = pd.bmax = 0;  pd.tsmin = 0x7fffffff;
   for (int j = 0; j < n; j++)
-    { pd.job[j] = AC.job[j];  pd.orig[j] = AC.orig[j];  pd.fr[j] = AC.fr[j];
+    { pd.job[j] = AC.job[j];  pd.orig[j] = AC.orig[j];  pd.fr[j] = AC.fr[j];  pd.slot[j] = AC.slot[j];
       pd.ablk[j] = AC.ablk[j];  pd.bblk[j] = AC.bblk[j];
       pd.amax = std::max(pd.amax, AC.job[j].ablock->maxlen);  pd.bmax = std::max(pd.bmax, AC.job[j].bblock->maxlen);
       pd.tsmin = std::min(pd.tsmin, Trace_Spacing(AC.job[j].spec));
     }
+  const u32 rec_have = RS.rec_cap_set[pd.oset], tp_have = RS.tpool_cap_set[pd.oset];     /* (of ITS set: asking one set for the
+                                                                                             other's size plus headroom would grow both for ever) */
   pd.cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
-  pd.rec_cap  = (u32) std::min<u64>(0x7fffffffu, std::max<u64>(RS.rec_cap, 2 * AC.nwork + 4096));
-  pd.tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(RS.tpool_cap, (u64) pd.rec_cap * 256u));
-  if (getenv("DAMAR_TEST_SMALL_CAPS") && RS.rec_cap == 0)      /* tests: start far too small, so that the
+  pd.rec_cap  = (u32) std::min<u64>(0x7fffffffu, std::max<u64>(rec_have, 2 * AC.nwork + 4096));
+  pd.tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(tp_have, (u64) pd.rec_cap * 256u));
+  if (getenv("DAMAR_TEST_SMALL_CAPS") && RS.rec_cap_set[0] == 0 && RS.rec_cap_set[1] == 0)        /* tests: start far too small, so that the
                                                                   overflow flags and the re-launch are exercised */
     { pd.cell_cap = 64;  pd.rec_cap = 16;  pd.tp_cap = 512; }
   pd.attempt = 0;
-  pd.oset = G_oset;  G_oset ^= 1;
   pd.st = defer ? G_rep : G_st;
   for (TailJob *w : AC.writes)
     pd.writes.push_back(w);
@@ -2104,14 +2157,14 @@ static void flush_accum(void)
     { HIP_CHECK(hipEventRecord(G_front_done, G_st));
       HIP_CHECK(hipStreamWaitEvent(G_rep, G_front_done, 0));
     }
+  PQ_n += 1;
   report_launch(pd);
   if (!defer)
-    report_finish(pd);
+    finish_oldest();
   else if (!corun_on())                        /* in order on the device: the next seed stages start behind this launch */
     { HIP_CHECK(hipEventRecord(G_rep_done, G_rep));
       HIP_CHECK(hipStreamWaitEvent(G_st, G_rep_done, 0));
     }
-  G_set ^= 1;
   AC.n = 0;  AC.bytes = 0;  AC.nwork = 0;
   Q_flush = now_ms();
 }
@@ -2119,7 +2172,8 @@ static void flush_accum(void)
 /* everything this library still owes: the comparisons held back, then the launch in flight */
 static void finish_all(void)
 { flush_accum();
-  finish_pending();
+  while (PQ_n > 0)
+    finish_oldest();
 }
 
 extern "C" void damar_match_batch(damar_match_job *jobs, int njobs)
@@ -2133,7 +2187,7 @@ extern "C" void damar_match_batch(damar_match_job *jobs, int njobs)
   const bool defer = overlap_on();
   if (!defer)
     finish_all();
-  const size_t budget = G_prop.totalGlobalMem / 4;
+  const size_t budget = G_prop.totalGlobalMem / 8;                        /* per launch; up to three groups of comparisons hold arenas */
   const int    hard = DAMAR_MAX_JOBS / 2;                                 /* two sets of job arenas */
   const int    soft = std::min(batch_limit(), hard);
   for (int i = 0; i < njobs; i++)
@@ -2153,11 +2207,14 @@ extern "C" void damar_match_batch(damar_match_job *jobs, int njobs)
           if (go)
             flush_accum();
         }
+      const int slot = slot_take();               /* (may complete a launch, or launch what is held back) */
       const int n = AC.n;
       if (i == 0)
         Q_seg[2] += now_ms() - h0;
-      if (match_front(&jobs[i], G_set * hard + n, &AC.fr[n]))
-        { AC.job[n] = jobs[i];  AC.orig[n] = &jobs[i];
+      if (!match_front(&jobs[i], slot, &AC.fr[n]))
+        G_slot_busy[slot] = false;
+      else
+        { AC.job[n] = jobs[i];  AC.orig[n] = &jobs[i];  AC.slot[n] = slot;
           AC.ablk[n] = jobs[i].aidx->blk;  AC.bblk[n] = jobs[i].bidx->blk;
           AC.bytes += AC.fr[n].bytes;
           AC.nwork += AC.fr[n].nwork;
@@ -2170,7 +2227,7 @@ extern "C" void damar_match_batch(damar_match_job *jobs, int njobs)
   if (!defer)
     flush_accum();
   for (int j = 0; j < DAMAR_MAX_JOBS; j++)         /* the caller's job structs end with this call */
-    PD.orig[j] = NULL;
+    PQ[0].orig[j] = PQ[1].orig[j] = NULL;
   for (int j = 0; j < DAMAR_MAX_JOBS / 2; j++)
     AC.orig[j] = NULL;
   Q_exit = now_ms();
@@ -2259,11 +2316,11 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
         scratch_outputs(rec_cap, tp_cap);
         fill_report_args(&ra, blk, blk, 0, 1, spec, G_st, 0, 0, params_now());
         ra.nwork = (u32) ablock->nreads;
-        HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
+        HIP_CHECK(hipMemsetAsync(RS.ctr, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
         tick(4);
         damar_launch_tandem_report(&ra, dist, RS.nslots, G_st);
         tick(5);
-        HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, G_st));
+        HIP_CHECK(hipMemcpyAsync(hc, RS.ctr, sizeof(hc), hipMemcpyDeviceToHost, G_st));
         HIP_CHECK(hipStreamSynchronize(G_st));
         HIP_CHECK(hipGetLastError());
         G_ms[DAMAR_T_REPORT] = lap(4, 5);
@@ -2370,14 +2427,14 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
       stage("la_scratch");
       scratch_outputs(rec_cap, tp_cap);
       fill_report_args(&ra, ablk, bblk, comp, 0, spec, G_st, 0, 0, params_now());
-      HIP_CHECK(hipMemsetAsync(RS.counters, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
+      HIP_CHECK(hipMemsetAsync(RS.ctr, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
       stage("la_setup");
       if (use_packed(&ra, ablk->d.maxlen, bblk->d.maxlen))
         damar_launch_report2(&ra, 1, dt, (u32) ntasks, RS.nslots, G_st);
       else
         damar_launch_la_batch(&ra, dt, (u32) ntasks, RS.nslots, G_st);
       stage("la_kernel");
-      HIP_CHECK(hipMemcpyAsync(hc, RS.counters, sizeof(hc), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipMemcpyAsync(hc, RS.ctr, sizeof(hc), hipMemcpyDeviceToHost, G_st));
       HIP_CHECK(hipStreamSynchronize(G_st));
       HIP_CHECK(hipGetLastError());
       if (hc[3] == 0)

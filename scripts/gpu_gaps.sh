@@ -8,4 +8,6 @@ cd /tmp && export TMPDIR=/tmp
 export DAMAR_OVERLAP=${1:-2}
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o r -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-trace --no-e2e --no-legs > $OUT/bench.json 2> $OUT/err.txt
 cd $ROOT
-python3 scripts/trace_gaps.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) | tee $OUT/gaps.txt
+T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
+python3 scripts/trace_gaps.py $T | tee $OUT/gaps.txt
+python3 scripts/trace_streams.py $T | tee $OUT/streams.txt
