@@ -37,6 +37,15 @@ typedef struct
   const int *mdat;      /* j in [moff[i]/2, moff[i+1]/2); NULL when the block carries no mask      */
 } DevBlock;
 
+/* Seed-side kernels run beside a resident report launch that is bound by vector instruction issue: four report
+   wavefronts and one seed wavefront share a SIMD, and at equal priority the seed wavefront -- which mostly waits for memory --
+   gets a fifth of the issue slots whenever it is ready.  Raised priority lets it issue at once and go back to waiting.
+   Which kernels do so is a run-time choice per source file (damar_*_set_prio; shim.hip: DAMAR_SEED_PRIO). */
+#define SEED_PRIO_VAR(name) static __device__ int name = 0;
+#define SEED_PRIO(name)     do { if (name) __builtin_amdgcn_s_setprio(3); } while (0)
+#define SEED_PRIO_SETTER(fn, name) \
+  void fn(int on) { HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(name), &on, sizeof(int))); }
+
 #define COARSE_SHIFT 9
 #define PK_PAD 4
 
@@ -70,6 +79,9 @@ void damar_launch_pack_bases(const u8 *bases, u32 total, u32 *pk, hipStream_t st
 
 /* kmer_index.hip */
 /* codes: u32 (k <= 16) or, with wide != 0, u64 (k <= 32) */
+void damar_sort_set_prio(int on);
+void damar_merge_set_prio(int on);
+void damar_index_set_prio(int on);
 void damar_launch_kmer_tuples(const DevBlock *blk, int kmer, u32 nkmers, void *codes, int wide, u32 *pos, hipStream_t st);
 /* keep[i] = 1 iff k-mer i lies inside one unmasked stretch of its read (filter.c:474-526) */
 void damar_launch_mask_flags(const DevBlock *blk, int kmer, const u32 *pos, u32 n, u32 *keep, hipStream_t st);

@@ -14,6 +14,9 @@
 #include "dev_common.h"
 #include "kernels.h"
 
+SEED_PRIO_VAR(g_index_prio)
+SEED_PRIO_SETTER(damar_index_set_prio, g_index_prio)
+
 
 /* One thread per base position p: the read through the coarse table (two dependent look-ups
  * instead of a search over all reads), then the k-mer ENDING at p if the read has K bases up to
@@ -22,7 +25,8 @@
 template <typename CodeT, bool PACK>
 __global__ __launch_bounds__(256)
 void kmer_tuples(DevBlock blk, int kmer, u32 nkmers, CodeT *__restrict__ codes, u32 *__restrict__ pos)
-{ const u32 p = blockIdx.x * 256u + threadIdx.x;
+{ SEED_PRIO(g_index_prio);
+  const u32 p = blockIdx.x * 256u + threadIdx.x;
   if (p >= blk.total)
     return;
   const u32 r = read_of_pos(blk, p), b0 = blk.boff[r];

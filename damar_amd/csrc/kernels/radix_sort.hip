@@ -28,6 +28,9 @@
 #include "dev_common.h"
 #include "kernels.h"
 
+SEED_PRIO_VAR(g_sort_prio)
+SEED_PRIO_SETTER(damar_sort_set_prio, g_sort_prio)
+
 #ifndef OS_THREADS
 #define OS_THREADS 512                       /* threads per workgroup: 512 (tiles of 8192 keys: longer runs per digit, half the
                                                 look-back words) or 256 (one wavefront per SIMD: the shape that still finds room
@@ -136,7 +139,8 @@ template <typename KeyT>
 __global__ __launch_bounds__(256)
 void onesweep_hist8(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u32 lastmask,
                    u32 *__restrict__ ghist, uint4 *__restrict__ clr, u64 clr16)
-{ extern __shared__ u32 sh[];                                  /* [npass][256][OH_COPIES]: the bins of a digit place, OH_COPIES copies chosen by lane & 7 */
+{ SEED_PRIO(g_sort_prio);
+  extern __shared__ u32 sh[];                                  /* [npass][256][OH_COPIES]: the bins of a digit place, OH_COPIES copies chosen by lane & 7 */
   const int nb = npass * 256 * OH_COPIES;
   for (int j = threadIdx.x; j < nb; j += 256)
     sh[j] = 0;
@@ -191,7 +195,8 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
                    u32 *__restrict__ vout, u32 *__restrict__ ohi, u64 n, int shift, u32 mask,
                    const u32 *__restrict__ ghist, GT *__restrict__ lb, GT *__restrict__ lbclear,
                    u32 *__restrict__ ctr, u32 *__restrict__ err)
-{ constexpr int OS_TILE = TH * IT, OS_WAVES = TH / 64, OS_WSPAN = 64 * IT;
+{ SEED_PRIO(g_sort_prio);
+  constexpr int OS_TILE = TH * IT, OS_WAVES = TH / 64, OS_WSPAN = 64 * IT;
   /* keys and payload are staged through the SAME buffer one after the other */
   __shared__ KeyT skey[OS_TILE];
   u32 *const sval = (u32 *) skey;

@@ -20,6 +20,9 @@
 #include "dev_common.h"
 #include "kernels.h"
 
+SEED_PRIO_VAR(g_merge_prio)
+SEED_PRIO_SETTER(damar_merge_set_prio, g_merge_prio)
+
 
 /* number of entries of bpos[jb,ib) strictly below `bound` (bpos ascending in a run) */
 __device__ __forceinline__ u32 count_below(const u32 *__restrict__ bpos, u32 jb, u32 ib, u32 bound)
@@ -75,7 +78,8 @@ __device__ __forceinline__ u32 upper_bound_c(const CodeT *c, u32 lo, u32 hi, Cod
 template <typename CodeT>
 __global__ __launch_bounds__(256)
 void merge_tiles(MergeArgs m, u32 ntiles, MergeTile *__restrict__ tiles)
-{ const u32 t = blockIdx.x * 256u + threadIdx.x;
+{ SEED_PRIO(g_merge_prio);
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= ntiles)
     return;
   const CodeT *acode = (const CodeT *) m.acode, *bcode = (const CodeT *) m.bcode;
@@ -414,7 +418,8 @@ template <typename CodeT>
 __global__ __launch_bounds__(256, 8)          /* <= 64 VGPRs: two wavefronts per SIMD still find room beside a resident report launch */
 void merge_sweep(MergeArgs m, const MergeTile *__restrict__ tiles, u32 *__restrict__ tcount, u32 *__restrict__ cnt,
                  u32 *__restrict__ jbg, unsigned long long *__restrict__ gram, u32 ngram)
-{ __shared__ __attribute__((aligned(16))) CodeT sb[MT_BCAP + 16 / sizeof(CodeT)];
+{ SEED_PRIO(g_merge_prio);
+  __shared__ __attribute__((aligned(16))) CodeT sb[MT_BCAP + 16 / sizeof(CodeT)];
   __shared__ u32 loc[MT_A + 1];
   __shared__ u32 sjb[2];
   __shared__ u32 sw4[4];
@@ -432,7 +437,8 @@ void merge_sweep(MergeArgs m, const MergeTile *__restrict__ tiles, u32 *__restri
 __global__ __launch_bounds__(256, 8)
 void merge_emit(MergeArgs m, const u32 *__restrict__ cnt, const u32 *__restrict__ jbg, const u32 *__restrict__ toff,
                 u64 nhits, u64 *__restrict__ keys, u32 *__restrict__ vals, u32 *__restrict__ pid)
-{ __shared__ u32 loc[MT_A + 1];
+{ SEED_PRIO(g_merge_prio);
+  __shared__ u32 loc[MT_A + 1];
   __shared__ u32 sjb[MT_A];
   __shared__ u32 sw4[4];
   const int l = lane_id(), w = threadIdx.x >> 6;
@@ -603,7 +609,8 @@ template <typename K>
 __global__ __launch_bounds__(256)
 void pair_heads_mark(const K *__restrict__ keys, u64 nhits, int pbits, int minhit, int nshift,
                      const u64 *__restrict__ send, u64 *__restrict__ bits, u32 *__restrict__ tcount)
-{ __shared__ u32 wsum[4];
+{ SEED_PRIO(g_merge_prio);
+  __shared__ u32 wsum[4];
   const int nthr = nshift < 0 ? 0 : 1 << nshift;       /* nshift < 0: no slices (the seeds went through the early cut) */
   const int l = lane_id(), w = threadIdx.x >> 6;
   const u64 base = (u64) blockIdx.x * DAMAR_SCAN_TILE;
@@ -801,7 +808,8 @@ __global__ __launch_bounds__(256)
 void pair_screen(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int pbits, int dbits,
                  const u32 *__restrict__ heads, u32 nheads, int minhit, int binshift, int kmer, int hitmin,
                  int abits, u32 b_lo, u32 b_hi, u32 *__restrict__ keep)
-{ u32 t = blockIdx.x * 256u + threadIdx.x;
+{ SEED_PRIO(g_merge_prio);
+  u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= nheads)
     return;
   const u64 i = heads[t];

@@ -232,6 +232,16 @@ extern "C" int damar_hip_init(int device)
       HIP_CHECK(hipStreamCreate(&G_copy));
       HIP_CHECK(hipStreamCreate(&G_rep));
       HIP_CHECK(hipStreamCreate(&G_ctl));
+      { /* which seed-side kernels raise their wave priority (kernels/kernels.h SEED_PRIO): 1 = sorts, 2 = merge and
+           work list, 4 = k-mer tuples.  Config-2 step on three boxes (profiles/r03_sweeps.txt): none 398 / 415 / 434 ms,
+           sorts only 403 / 405, all 409 / 413 / 408: the sorts (a chain of tiles through the look-back) are the kernels
+           whose time beside a report launch varies threefold from box to box, and with priority it does not. */
+        const char *e = getenv("DAMAR_SEED_PRIO");
+        const int mask = e ? atoi(e) : 1;
+        damar_sort_set_prio(mask & 1);
+        damar_merge_set_prio((mask >> 1) & 1);
+        damar_index_set_prio((mask >> 2) & 1);
+      }
       HIP_CHECK(hipEventCreate(&G_front_done));
       HIP_CHECK(hipEventCreateWithFlags(&G_rep_done, hipEventDisableTiming));
       HIP_CHECK(hipEventCreateWithFlags(&G_set_d2h[0], hipEventDisableTiming));
@@ -895,7 +905,7 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
               }
             if (VERBOSE)
               fprintf(stderr, "damar: %d instead of %d resident alignments (%.1f MB of scratch each)\n", fit, nslots, per / 1048576.);
-            nslots = fit;
+            nslots = fit & ~1;                 /* (a wavefront of the packed kernel holds two slots) */
           }
       }
       RS.nslots = nslots;

@@ -11,3 +11,4 @@ cd $ROOT
 T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 python3 scripts/trace_gaps.py $T | tee $OUT/gaps.txt
 python3 scripts/trace_streams.py $T | tee $OUT/streams.txt
+python3 scripts/trace_phase.py $T | tee $OUT/phase.txt
