@@ -204,12 +204,17 @@ def test_gpu_cli_plan_mode_equals_reference_golden(gpu, tmp_path, name, front, c
 
 @pytest.mark.parametrize("env_extra", [{"DAMAR_EARLY_CUT": "1"}, {"DAMAR_BATCH": "1"}, {"DAMAR_BATCH": "16"},
                                        {"DAMAR_PACKED": "0", "DAMAR_BATCH": "2"}, {"DAMAR_EARLY_CUT": "1", "DAMAR_TEST_SMALL_CAPS": "1"},
-                                       {"DAMAR_OVERLAP": "0"}, {"DAMAR_OVERLAP": "1", "DAMAR_TEST_SMALL_CAPS": "1", "DAMAR_BATCH": "8"}])
+                                       {"DAMAR_OVERLAP": "0"}, {"DAMAR_OVERLAP": "1", "DAMAR_TEST_SMALL_CAPS": "1", "DAMAR_BATCH": "8"},
+                                       {"DAMAR_OVERLAP": "2"}, {"DAMAR_LAUNCH_QUEUE": "2", "DAMAR_BATCH": "1"},
+                                       {"DAMAR_LAUNCH_QUEUE": "2", "DAMAR_TEST_SMALL_CAPS": "1", "DAMAR_BATCH": "2"},
+                                       {"DAMAR_SEED_PRIO": "0"}, {"DAMAR_SEED_PRIO": "7", "DAMAR_BATCH_WORK": "1"}])
 @pytest.mark.parametrize("name", ["tiny2", "prod"])
 def test_gpu_cli_plan_mode_other_launch_shapes_equal_reference_golden(gpu, tmp_path, name, env_extra):
     """The switches that change how the work reaches the report kernel -- the early cut of the seed pairs, the number of
     comparisons per launch, one read pair per wavefront, report launches in flight beside the next seed stages or not
-    (with re-launches after buffer overflows) -- must not change a byte of the output."""
+    (with re-launches after buffer overflows), kernels in order on the device with the host pipelined, two launches in
+    flight (the second queued behind the first, also with re-launches), the wave priority of the seed kernels -- must not
+    change a byte of the output."""
     import subprocess
     from conftest import read_case, link_db, compare_las
     from damar_amd import api
