@@ -55,7 +55,8 @@ def main():
            "lds_bank_conflict_frac": cnt["SQ_LDS_BANK_CONFLICT"] / cnt["SQ_LDS_IDX_ACTIVE"] if cnt.get("SQ_LDS_IDX_ACTIVE") else None,
            "wave_cycles_share": {k: cnt[k] / cnt["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")
                                  if k in cnt and cnt.get("SQ_WAVE_CYCLES")},
-           "counters_per_step": cnt,
+           "counters_of_the_run": cnt,            # sums over the `launches` launches of the profiled command (4 passes over the plan)
+           "counters_per_launch": {k: v / calls for k, v in cnt.items()},
            "source": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu "
                      "--no-trace --no-e2e --no-legs` (scripts/gpu_profile_round.sh); issue peaks from tools/roofcal.hip (profiles/r02_roofcal.txt)"}
     # what ties this file to a tree: bench.py carries its figures only while the kernel sources still hash to this
