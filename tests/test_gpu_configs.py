@@ -431,7 +431,7 @@ runner.finish()
 dist.barrier()
 multi.merge_parts(db, more, out, rank, world)
 dist.barrier()
-sys.stdout.write("rank %d ran %d units\n" % (rank, len(mine))); sys.stdout.flush()      # one write: the ranks share the pipe
+sys.stdout.write("rank " + str(rank) + " ran " + str(len(mine)) + " units\\n"); sys.stdout.flush()      # one write: the ranks share the pipe
 assert len(mine) > 0
 runner.close()
 dist.destroy_process_group()
