@@ -234,8 +234,9 @@ def end_to_end(dbdir, root, nblocks, md5_name, repeats=3, gpus=1):
             with open(os.path.join(work, "plan.txt"), "w") as f:
                 f.write(plan_text(root, nblocks))
             t0 = time.time()
+            env = dict(os.environ, DAMAR_SHARE_GPU="1") if os.environ.get("DAMAR_BENCH_SHARE_GPU") else None   # (one-GPU rehearsal)
             subprocess.run([exe, "-P", "plan.txt"] + (["-G%d" % gpus] if gpus > 1 else []), cwd=work, check=True,
-                           stdout=subprocess.DEVNULL)
+                           stdout=subprocess.DEVNULL, env=env)
             dt = time.time() - t0
             if best is None or dt < best:
                 best = dt
