@@ -1,0 +1,930 @@
+/* report_duo.h -- the report loop with two read pairs per wavefront whose halves run INDEPENDENTLY (included by report.hip).
+ *
+ * report_packed.h gave each 32-lane half of a wavefront a read pair but ran the two halves through the same direction of
+ * Local_Alignment at the same time (the direction was a template parameter of the wave loop), so a round cost
+ * max(f1, f2) + max(r1, r2) wave steps and 1.58 of the 2 halves stepped per iteration.  Here the direction of a half is a
+ * run-time value and the wave loop is written ONCE, in coordinates in which both directions look the same:
+ *
+ *     sigma = +1 forward, -1 reverse (kept as the xor mask m = 0 / -1: sigma * x == (x ^ m) - m)
+ *     K = sigma * k,  V = sigma * v,  X = sigma * x,  Y = sigma * y            (k = x - y diagonal, v = x + y anti-diagonal)
+ *
+ * In these coordinates the reverse wave of align.c:1126-1898 IS the forward wave of align.c:409-1122: furthest point =
+ * maximum V, the sweep runs from the highest K down (hgh..low forward, low..hgh reverse: align.c:781, 1490), the
+ * predecessor rule, its tie breaks, the clipping at sequence ends, the lag rules and the pruning are literally the same
+ * expressions (shown case by case in DESIGN.md section 4).  What is left of the direction: the base compared at (X, Y) is
+ * a[X ^ m], b[Y ^ m] (the reverse wave compares a[x-1], b[y-1]), a packed window of 16 bases is bit-reversed for m = -1,
+ * and the trace grid is indexed by G = sigma * (grid index) (+ 2^14 for m = -1, so that it stays positive).
+ * So a half steps through whatever it has to do next -- forward pass, trace walk, reverse pass, emission, seed scan --
+ * while the other half does the same on its own: the wave loop is left when EITHER half has an event, the event is
+ * served (only that half's lanes are live), and the loop is entered again.
+ *
+ * Other differences to report_packed.h's loop (each removes vector instructions from the wave step):
+ *   - the next trace marks NA/NB of a diagonal (align.c:861-909) are not carried at all: at every use NA[k] is at most one
+ *     spacing beyond the mark of the inherited chain head (the predecessor's x is never behind the diagonal's own last
+ *     x, and a new edge diagonal inherits its neighbour's NA), so "push every mark in (head mark, x]" is what the
+ *     reference's loop does; the head's mark rides in the head word as before.  Checked with an assertion in the oracle
+ *     over every golden case (0 violations in 31 262 + ... alignments) and by the parity tests;
+ *   - the band is kept in LANE coordinates (ls..hs = lanes of the highest..lowest K) so that widening, pruning, clipping
+ *     and the recentring test need no conversion; lanes outside the band always hold V = EDGE (re-established after the
+ *     pruning of every step), so the neighbours read by DPP need no range tests; the band plus the two lanes it may grow
+ *     into stays within lanes 1..30, which keeps the two halves' DPP rotations apart;
+ *   - T, HA, HB are committed unconditionally (a lane outside the band is never anybody's predecessor).
+ * Reference semantics and citations are those of report_packed.h / report.hip.
+ */
+
+#define DUO_EDGE   (-BIG)
+#define DUO_GREV   (1 << 14)                    /* G = DUO_GREV - grid index in a reverse pass */
+#define DUO_LIMK   (1 << 29)
+
+enum { MD_SCAN = 0, MD_TASK, MD_RUN, MD_END, MD_OVF, MD_DONE };
+
+/* per-half event record in LDS (as report_packed.h's pk_cold, in the loop's coordinates): what a direction touches only
+   at events.  tip = a (V of the point), k (its K), d, ha, hb */
+enum { DC_REACHM = 0, DC_ACLIP, DC_BCLIP, DC_TRIM, DC_REACH = DC_TRIM + 5, DC_WORDS = 16 };
+__shared__ int duo_cold[2 * DC_WORDS];
+
+/* Lane predicates are kept as 64-bit lane masks in scalar registers: a ballot of ONE comparison is the comparison
+   itself (v_cmp writes the mask), masks combine on the scalar unit, a branch on "any lane" is s_cmp of the mask, and
+   inv() hands a mask back to the vector side as a condition for free.  (Left to bool expressions the compiler turns
+   every compound predicate into 0/1 per lane and compares it again: two vector instructions per wany(), measured 16 per
+   wave step.) */
+__device__ __forceinline__ u64  bal(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool inv(u64 m)  { return __builtin_amdgcn_inverse_ballot_w64(m); }
+/* find-first-bit from the top / from the bottom as the hardware has them: -1 for 0 */
+__device__ __forceinline__ int ffbh_raw(u32 x) { int r;  asm("v_ffbh_u32_e32 %0, %1" : "=v"(r) : "v"(x));  return r; }
+__device__ __forceinline__ int ffbl_raw(u32 x) { int r;  asm("v_ffbl_b32_e32 %0, %1" : "=v"(r) : "v"(x));  return r; }
+
+/* Everything a half carries between the pieces below (noinline functions with their own register allocation): one copy
+   per lane in private memory; all fields but the band state hold the same value in the 32 lanes of a half. */
+struct DuoCtx
+{ int V, HA, HB;  u32 Tlo, Thi;                 /* band state of this lane: lane s owns K = kbase - s */
+  int md;
+  int m;                                        /* direction: 0 forward, -1 reverse */
+  int ls, hs, kbase;                            /* band = lanes ls..hs (highest..lowest K) */
+  int dif, besta, bestk, lasta, more, ncell, bad;
+  int mlo, mhi;                                 /* the band may not grow below lane mlo / above lane mhi (minp, maxp) */
+  int alim, blim;                               /* bases left: alim - X in A, blim - Y in B */
+  int offa, offb;                               /* the mark after head index G is crossed when X >= G * TS + offa */
+  int va0, vb0, alen, blen;                     /* the reads: offsets in the packed bases (biased by the padding), lengths */
+  /* the task and what its passes have produced */
+  int diag, anti;
+  int aepos, bepos, abpos, bbpos, diffs, atlen, btlen, aback, bback;
+};
+
+struct DuoSnake { int Y, na, nb;  u64 b; };
+
+/* The snake (align.c:832-856 / 1542-1566) of diagonal K from Y, in the loop's coordinates: 16 bases per step off the
+   2-bit packed reads (window [x, x + 15] forward, [x - 16, x - 1] bit-reversed in reverse), bounded by the bases left
+   in either read; a lane that is past an end takes the byte path, which reads what the reference reads there. */
+__device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, const u8 *abase, const u8 *bbase,
+                                              int m, int alim, int blim, int va0, int vb0, int alen, int blen,
+                                              int K, int Y, u64 b)
+{ DuoSnake o;
+  const int X = Y + K;
+  int na = alim - X, nb = blim - Y;
+  if ((u32) na > (u32) alen || (u32) nb > (u32) blen)
+    { const int k = (K ^ m) - m, y = (Y ^ m) - m;
+      const u8 *ar = abase + (va0 - 16 * PK_PAD), *br = bbase + (vb0 - 16 * PK_PAD);
+      SnakeOut so;
+      if (m)
+        so = snake<1>(ar - 1 + k, br - 1, y, 0, b);
+      else
+        so = snake<0>(ar + k, br, y, 0, b);
+      o.Y = (so.y ^ m) - m;  o.b = so.b;  o.na = so.na;  o.nb = so.nb;
+      return o;
+    }
+  const int c15 = m & 15, st16 = (16 ^ m) - m;
+  u32 pa = (u32) (va0 + ((X + c15) ^ m)), pb = (u32) (vb0 + ((Y + c15) ^ m));
+  for (;;)
+    { u32 wa, wb;
+      load16x2(apk, pa, bpk, pb, &wa, &wb);
+      u32 x = wa ^ wb;
+      if (m)
+        x = __builtin_bitreverse32(x);
+      const u32 run = (u32) (__ffs((int) x) - 1) >> 1;         /* equal bases at the head of the window; huge if all 16 are */
+      const int lim = na < nb ? na : nb;
+      int n = (int) (run < 16u ? run : 16u);
+      n = n < lim ? n : lim;
+      b = (b << n) | (u64) ((1u << n) - 1);
+      Y += n;  na -= n;  nb -= n;
+      if (n < 16 || lim == 16)
+        break;
+      pa += (u32) st16;  pb += (u32) st16;
+    }
+  o.Y = Y;  o.b = b;  o.na = na;  o.nb = nb;
+  return o;
+}
+
+/* clipping at sequence ends (align.c:628-658 / 943-975) for the halves with `on`, in lane coordinates: the A-side clip
+   lane (the highest sweep index that reached A's end) cuts the band's low lanes, the B-side one its high lanes */
+#define DUO_CLIP()                                                                                     \
+  if (bal(on) & bal(more == 0))                                                                        \
+    { const bool cl_ = on && more == 0;                                                                \
+      const int  mp_ = pk_popc61(rT);                                                                  \
+      if (cl_)                                                                                         \
+        { const int by_ = (besta - bestk) >> 1, bx_ = besta - by_;                                     \
+          if (bbase[(vb0 - 16 * PK_PAD) + (by_ ^ m)] != 4 && abase[(va0 - 16 * PK_PAD) + (bx_ ^ m)] != 4) \
+            more = 1;                                                                                  \
+        }                                                                                              \
+      const int acl_ = cold[DC_ACLIP], bcl_ = cold[DC_BCLIP];                                          \
+      { const bool ca_ = cl_ && ls <= acl_;                                                            \
+        const int  sl_ = ca_ ? acl_ : 0;                                                               \
+        const int  mm_ = hget(mp_, hb, sl_), vv_ = hget(rV, hb, sl_);                                  \
+        const int  ha_ = hget(rHA, hb, sl_), hb2_ = hget(rHB, hb, sl_);                                \
+        if (ca_)                                                                                       \
+          { ls = acl_ + 1;                                                                             \
+            if (cold[DC_REACHM] <= mm_)                                                                \
+              { cold[DC_REACHM] = mm_;  cold[DC_REACH] = vv_;  cold[DC_REACH + 1] = kbase - acl_;      \
+                cold[DC_REACH + 2] = dif;                                                              \
+                cold[DC_REACH + 3] = ha_ & PK_HMASK;  cold[DC_REACH + 4] = hb2_ & PK_HMASK; }          \
+          }                                                                                            \
+      }                                                                                                \
+      { const bool cb_ = cl_ && hs >= bcl_;                                                            \
+        const int  sl_ = cb_ ? bcl_ : 0;                                                               \
+        const int  mm_ = hget(mp_, hb, sl_), vv_ = hget(rV, hb, sl_);                                  \
+        const int  ha_ = hget(rHA, hb, sl_), hb2_ = hget(rHB, hb, sl_);                                \
+        if (cb_)                                                                                       \
+          { hs = bcl_ - 1;                                                                             \
+            if (cold[DC_REACHM] <= mm_)                                                                \
+              { cold[DC_REACHM] = mm_;  cold[DC_REACH] = vv_;  cold[DC_REACH + 1] = kbase - bcl_;      \
+                cold[DC_REACH + 2] = dif;                                                              \
+                cold[DC_REACH + 3] = ha_ & PK_HMASK;  cold[DC_REACH + 4] = hb2_ & PK_HMASK; }          \
+          }                                                                                            \
+      }                                                                                                \
+      if (cl_)                                                                                         \
+        { cold[DC_ACLIP] = -1;  cold[DC_BCLIP] = 64; }                                                 \
+    }
+
+/* the names the pieces use for a job's constants */
+#define DUO_NAMES()                                                                                  \
+  const ReportArgs &a = g_jobs[uni(job)];                                                            \
+  const int lane = lane_id(), hb = lane & 32, s = lane & 31;                                         \
+  const int TS = uni(a.tspace);                                                                      \
+  const u32 *apk = uni_ptr(a.ablk.pk), *bpk = uni_ptr(a.bblk.pk);                                    \
+  const u8 *abase = uni_ptr(a.ablk.bases), *bbase = uni_ptr(a.bblk.bases);                           \
+  GLOBAL_AS v2u32 *const gcell = (GLOBAL_AS v2u32 *) uni_ptr((Cell *) a.cells);                      \
+  const int cell_cap = (int) uni((int) a.cell_cap);                                                  \
+  u32 *const errw = uni_ptr(&a.counters[3]);                                                         \
+  int *const cold = duo_cold + (hb >> 1);                                                            \
+  (void) lane; (void) hb; (void) s; (void) TS; (void) apk; (void) bpk; (void) abase; (void) bbase;   \
+  (void) gcell; (void) cell_cap; (void) errw; (void) cold;
+
+/* Wave 0 on the seed diagonal (align.c:491-626 / 1203-1340) and the clipping behind it, for the halves with
+   md == MD_TASK: sets up direction cx->m of the task (cx->diag, cx->anti).  Every lane of a half computes the same. */
+__device__ __noinline__ void duo_begin(int job, u32 cbase, DuoCtx *cx)
+{ DUO_NAMES()
+  const bool on = cx->md == MD_TASK;
+  const int m = cx->m;
+  const int va0 = cx->va0, vb0 = cx->vb0, alen = cx->alen, blen = cx->blen;
+  const int diag = cx->diag, anti = cx->anti;
+  const int guard = 4 * (alen + blen) + 1024;
+  const int boff = (a.comp & 1) ? (blen % TS) : 0;
+  const int offa0 = -PK_BIAS * TS, offb0 = boff - PK_BIAS * TS;          /* mark = grid index * TS + off */
+  int ls = 15, hs = 15, kbase = 0, dif = 0, besta = 0, bestk = 0, lasta = 0, more = 1, ncell = 2, bad = 0;
+  int mlo = 0, mhi = 0, alim = 0, blim = 0, offa = 0, offb = 0;
+  int rV = DUO_EDGE, rHA = 0, rHB = 0;
+  u64 rT = 0;
+  int md = cx->md;
+
+  if (on)
+    { const int K0 = (diag ^ m) - m, V0 = (anti ^ m) - m;
+      int Y = (V0 - K0) >> 1;
+      const int y = (anti - diag) >> 1, x = y + diag;
+      int ga, gb;
+      if (m == 0)
+        { ga = (x + TS) / TS - 1 + PK_BIAS;  gb = (y + (TS - boff)) / TS - 1 + PK_BIAS;
+          if (s == 0)
+            { gcell[cbase] = cell_root(ga * TS + offa0, diag);
+              gcell[cbase + 1] = cell_root(gb * TS + offb0, diag);
+            }
+          offa = offa0 + TS;  offb = offb0 + TS;
+          alim = alen;  blim = blen;
+        }
+      else
+        { const int hai = (x + TS - 1) / TS + PK_BIAS, hbi = (y + (TS - boff) - 1) / TS + PK_BIAS;     /* the true start, rounded up to the grid */
+          if (s == 0)
+            { gcell[cbase] = cell_root(x, diag);
+              gcell[cbase + 1] = cell_root(y, diag);
+            }
+          ga = DUO_GREV - hai;  gb = DUO_GREV - hbi;
+          offa = -offa0 - DUO_GREV * TS + TS;  offb = -offb0 - DUO_GREV * TS + TS;
+          alim = 0;  blim = 0;
+        }
+      { const bool selfie = (abase + va0 == bbase + vb0);
+        const int minp = (selfie && diag >= 0) ? 1 : -DUO_LIMK, maxp = (selfie && diag <= 0) ? -1 : DUO_LIMK;
+        const int minK = m ? -maxp : minp, maxK = m ? -minp : maxp;
+        kbase = K0 + 15;
+        mlo = kbase - maxK;  mhi = kbase - minK;
+      }
+      cold[DC_REACHM] = -1;  cold[DC_ACLIP] = -1;  cold[DC_BCLIP] = 64;
+      { const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, va0, vb0, alen, blen, K0, Y, 0ull);
+        Y = so.Y;
+        if (so.nb == 0)      { more = 0;  cold[DC_BCLIP] = 15; }
+        else if (so.na == 0) { more = 0;  cold[DC_ACLIP] = 15; }
+      }
+      const int v = (Y << 1) + K0, X = Y + K0;
+      int ha = 0, hb_ = 1, g0 = 0;
+      for (;;)
+        { if (!(X >= ga * TS + offa))
+            break;
+          GUARD(g0, guard, 2)
+          ga += 1;
+          if (s == 0 && ncell < cell_cap)
+            gcell[cbase + (u32) ncell] = cell_pack(ha, diag, 0, (ga ^ m) - m);
+          ha = ncell++;
+        }
+      for (;;)
+        { if (!(Y >= gb * TS + offb))
+            break;
+          GUARD(g0, guard, 3)
+          gb += 1;
+          if (s == 0 && ncell < cell_cap)
+            gcell[cbase + (u32) ncell] = cell_pack(hb_, diag, 0, (gb ^ m) - m);
+          hb_ = ncell++;
+        }
+      besta = lasta = V0;  bestk = K0;
+      cold[DC_TRIM] = V0;  cold[DC_TRIM + 1] = K0;  cold[DC_TRIM + 2] = 0;  cold[DC_TRIM + 3] = 0;  cold[DC_TRIM + 4] = 1;
+      cold[DC_REACH] = V0;  cold[DC_REACH + 1] = K0;  cold[DC_REACH + 2] = 0;  cold[DC_REACH + 3] = 0;  cold[DC_REACH + 4] = 1;
+      if (v > besta)
+        { besta = lasta = v;
+          cold[DC_TRIM] = v;  cold[DC_TRIM + 3] = ha;  cold[DC_TRIM + 4] = hb_;
+        }
+      if (s == 15)
+        rV = v;
+      rT = HIST_FULL;
+      rHA = ha | (ga << PK_HBITS);  rHB = hb_ | (gb << PK_HBITS);
+      md = MD_RUN;
+      if (ncell > cell_cap)              /* a seed diagonal that slides over more marks than the pool holds */
+        { if (s == 0) atomicOr(errw, DAMAR_ERR_CELLS);
+          more = 0;  ncell = 2;  bad = 1;  md = MD_END;
+        }
+    }
+  DUO_CLIP()
+  if (on)
+    { cx->V = rV;  cx->HA = rHA;  cx->HB = rHB;  cx->Tlo = (u32) rT;  cx->Thi = (u32) (rT >> 32);
+      cx->md = md;
+      cx->ls = ls;  cx->hs = hs;  cx->kbase = kbase;  cx->dif = dif;  cx->besta = besta;  cx->bestk = bestk;
+      cx->lasta = lasta;  cx->more = more;  cx->ncell = ncell;  cx->bad = bad;
+      cx->mlo = mlo;  cx->mhi = mhi;  cx->alim = alim;  cx->blim = blim;  cx->offa = offa;  cx->offb = offb;
+    }
+}
+
+/* The wave steps (align.c:667-999 / 1378-1697) of the halves with md == MD_RUN, until one of them has an event: its
+   direction is over (or failed), or its band no longer fits lanes 1..30.  The caller tells which from the state
+   (duo_classify); on entry every such half can step (duo_classify has been through). */
+__device__ __noinline__ void duo_loop(int job, const u32 *trimtab, u32 cbase, DuoCtx *cx)
+{ DUO_NAMES()
+  const int ave = uni(a.ave_path);
+  const u64 onm = bal(cx->md == MD_RUN);
+  const bool on = inv(onm);
+  const int m = cx->m;
+  const int va0 = cx->va0, vb0 = cx->vb0, alen = cx->alen, blen = cx->blen;
+  const int alim = cx->alim, blim = cx->blim, offa = cx->offa, offb = cx->offb;
+  const int steplimit = alen + blen + 64, guard = 4 * (alen + blen) + 1024;
+  const u32 below = (1u << s) - 1u;
+  const int lane4 = lane << 2, top4 = (hb + 31) << 2;
+  int ls = cx->ls, hs = cx->hs, kbase = cx->kbase, dif = cx->dif, besta = cx->besta, bestk = cx->bestk;
+  int lasta = cx->lasta, more = cx->more, ncell = cx->ncell, mlo = cx->mlo, mhi = cx->mhi;
+  int rV = cx->V, rHA = cx->HA, rHB = cx->HB;
+  u64 rT = ((u64) cx->Thi << 32) | cx->Tlo;
+#ifdef DAMAR_PROF
+  unsigned long long pf_iters = 0, pf_half = 0, pf_cells = 0;
+#endif
+  if (!onm)
+    return;
+
+  for (;;)
+    { /* (every few dozen steps) keep the band and the two lanes it may grow into within lanes 1 .. 30 of the half */
+      { const u64 mvm = onm & (bal(ls < 2) | bal(hs > 29));
+        if (mvm)
+          { const int dl = inv(mvm) ? ((31 - (hs - ls)) >> 1) - ls : 0;
+            const int src = (hb + ((s - dl) & 31)) << 2;
+            rV  = __builtin_amdgcn_ds_bpermute(src, rV);
+            rHA = __builtin_amdgcn_ds_bpermute(src, rHA);
+            rHB = __builtin_amdgcn_ds_bpermute(src, rHB);
+            { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+              const u32 th = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+              rT = ((u64) th << 32) | tl;
+            }
+            kbase += dl;  ls += dl;  hs += dl;  mlo += dl;  mhi += dl;
+          }
+      }
+      u64 gom;
+      do
+        {
+#ifdef DAMAR_PROF
+          pf_iters += 1;  pf_half += (unsigned long long) __popcll(onm) >> 5;
+#endif
+          /* widen (align.c:675-776) and pick the predecessor (align.c:793-825): K - 1 sits one lane up, K + 1 one lane down */
+          const int K = kbase - s;
+          u64  actm;
+          int  v, ha, hb_;
+          u64  b;
+          { const int nls = (ls - 1 > mlo) ? ls - 1 : mlo, nhs = (hs + 1 < mhi) ? hs + 1 : mhi;
+            actm = onm & bal(s >= nls) & bal(s <= nhs);
+            const int am = lane_up(rV), ap = lane_dn(rV), ac = rV;
+            const int nbv = am > ap ? am : ap;
+            const u64 takem = bal(ac < nbv), upm = bal(am < ap);
+            v = inv(takem) ? nbv + 1 : ac + 2;
+            int dsel = inv(upm) ? -4 : 4;
+            dsel = inv(takem) ? dsel : 0;
+            const int src = lane4 + dsel;
+            ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
+            hb_ = __builtin_amdgcn_ds_bpermute(src, rHB);
+            const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+            const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+            b = ((u64) thi << 32) | tlo;
+            ls = nls;  hs = nhs;  dif += 1;
+#ifdef DAMAR_PROF
+            pf_cells += (unsigned long long) __popcll(actm);
+#endif
+          }
+
+          int Y = 0, na = 1, nb = 1;
+          if (inv(actm))
+            { b <<= 1;
+              const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, va0, vb0, alen, blen, K, (v - K) >> 1, b);
+              Y = so.Y;  b = so.b;  na = so.na;  nb = so.nb;
+              v = (Y << 1) + K;
+            }
+          const u64 bhm = actm & bal(nb == 0), ahm = actm & ~bhm & bal(na == 0);
+
+          /* pebbles (align.c:859-909 / 1569-1618): every mark between the inherited head's and the new position */
+          { const int X = Y + K;
+            int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
+            u64 nam = actm & bal(X >= __mul24(ga, TS) + offa), nbm = actm & bal(Y >= __mul24(gb, TS) + offb);
+            if (nam | nbm)
+              { const int kk = (K ^ m) - m;
+                const u32 w1 = ((u32) kk & 0xffffu) | ((u32) dif << 16);
+                int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
+                int g2 = 0;
+                while (nam)
+                  { GUARD(g2, guard, 5)
+                    const u32 hm = hmask(nam, hb);
+                    const int idx = ncell + __popc(hm & below);
+                    if (inv(nam))
+                      { ga += 1;
+                        if (idx < cell_cap)
+                          { const v2u32 c = { (u32) hax | ((u32) ((ga ^ m) - m) << PK_HBITS), w1 };
+                            gcell[cbase + (u32) idx] = c;
+                          }
+                        hax = idx;
+                      }
+                    ncell += __popc(hm);
+                    nam &= bal(X >= __mul24(ga, TS) + offa);
+                  }
+                while (nbm)
+                  { GUARD(g2, guard, 6)
+                    const u32 hm = hmask(nbm, hb);
+                    const int idx = ncell + __popc(hm & below);
+                    if (inv(nbm))
+                      { gb += 1;
+                        if (idx < cell_cap)
+                          { const v2u32 c = { (u32) hbx | ((u32) ((gb ^ m) - m) << PK_HBITS), w1 };
+                            gcell[cbase + (u32) idx] = c;
+                          }
+                        hbx = idx;
+                      }
+                    ncell += __popc(hm);
+                    nbm &= bal(Y >= __mul24(gb, TS) + offb);
+                  }
+                ha = hax | (ga << PK_HBITS);  hb_ = hbx | (gb << PK_HBITS);
+              }
+          }
+
+          /* commit the new wave (lanes outside the band get V = EDGE again behind the pruning) */
+          rV = v;  rT = b;  rHA = ha;  rHB = hb_;
+
+          /* sequence ends reached: the largest sweep index for A, the smallest for B */
+          if (ahm | bhm)
+            { const u32 am_ = hmask(ahm, hb), bm_ = hmask(bhm, hb);
+              if (am_ | bm_)
+                { more = 0;
+                  if (am_) cold[DC_ACLIP] = 31 - __clz((int) am_);
+                  if (bm_) cold[DC_BCLIP] = __ffs((int) bm_) - 1;
+                }
+            }
+
+          /* new best / last / trim point in sweep order (align.c:911-928 / 1620-1637): record breakers of a prefix
+             maximum; their V is strictly monotone, so the LAST breaker with the wanted property is the one the serial
+             sweep leaves behind, and the new best is the maximum itself */
+          { const u64 candm = actm & bal(v > besta);
+            if (candm)
+              { const int x = pk_prefix_best<0>(inv(candm) ? v : -BIG);
+                int e = __builtin_amdgcn_update_dpp(-BIG, x, 0x138, 0xf, 0xf, false);             /* wave_shr:1 */
+                if (s == 0) e = -BIG;
+                const u64 rbm = candm & bal(v > e);
+                const u64 mokm = rbm & bal(pk_popc61(b) >= ave);
+                u64 tokm = 0;
+                if (mokm)
+                  tokm = mokm & bal(pk_trim_ok(trimtab, b));
+                const int xl = __builtin_amdgcn_ds_bpermute(top4, x);                             /* the maximum of the half's candidates */
+                const u32 h1 = hmask(rbm, hb), h2 = hmask(mokm, hb), h3 = hmask(tokm, hb);
+                const int l1 = 31 ^ ffbh_raw(h1), l2 = 31 ^ ffbh_raw(h2), l3 = 31 ^ ffbh_raw(h3);
+                const int v2 = hget(v, hb, l2);
+                besta = xl > besta ? xl : besta;
+                if (h1) bestk = kbase - l1;
+                if (h2) lasta = v2;
+                if (h3)
+                  { const int v3 = hget(v, hb, l3), h3a = hget(ha, hb, l3), h3b = hget(hb_, hb, l3);
+                    cold[DC_TRIM] = v3;  cold[DC_TRIM + 1] = kbase - l3;  cold[DC_TRIM + 2] = dif;
+                    cold[DC_TRIM + 3] = h3a & PK_HMASK;  cold[DC_TRIM + 4] = h3b & PK_HMASK;
+                  }
+              }
+          }
+
+          DUO_CLIP()
+
+          /* prune (align.c:977-986 / 1686-1695), and V = EDGE again in every lane outside the band (an empty band
+             comes out as hs < ls: the find-first-bit instructions return -1 for 0) */
+          { const int n = besta - MAX_WAVE_LAG;
+            const u32 keep = hmask(bal(s >= ls) & bal(s <= hs) & bal(rV >= n), hb);
+            ls = ffbl_raw(keep);  hs = 31 ^ ffbh_raw(keep);
+            rV = inv(bal(s >= ls) & bal(s <= hs)) ? rV : DUO_EDGE;
+          }
+
+          /* may every half go on as it is? */
+          gom = bal(more != 0) & bal(lasta >= besta - MAX_TRIM_LAG) & bal((u32) (hs - ls) <= 27u) & bal(dif <= steplimit)
+                & bal(ncell <= cell_cap);
+        }
+      while ((onm & ~(gom & bal(ls >= 2) & bal(hs <= 29))) == 0);
+      if (onm & ~gom)
+        break;
+    }
+#ifdef DAMAR_PROF
+  PROF_ADD(26, pf_iters);  PROF_ADD(27, pf_half);  PROF_ADD(29, 1);  PROF_ADD(30, pf_cells);
+#endif
+  if (on)
+    { cx->V = rV;  cx->HA = rHA;  cx->HB = rHB;  cx->Tlo = (u32) rT;  cx->Thi = (u32) (rT >> 32);
+      cx->ls = ls;  cx->hs = hs;  cx->kbase = kbase;  cx->dif = dif;  cx->besta = besta;  cx->bestk = bestk;
+      cx->lasta = lasta;  cx->more = more;  cx->ncell = ncell;  cx->mlo = mlo;  cx->mhi = mhi;
+    }
+}
+
+/* What the wave loop left for the halves with md == MD_RUN (the tests of report_packed.h's loop head, in its order) */
+__device__ __forceinline__ void duo_classify(const ReportArgs &a, DuoCtx *cx)
+{ const int s = lane_id() & 31;
+  u32 *const errw = &a.counters[3];
+  if (cx->md != MD_RUN)
+    return;
+  if (cx->ncell > (int) a.cell_cap)
+    { if (s == 0) atomicOr(errw, DAMAR_ERR_CELLS);
+      cx->more = 0;  cx->ncell = 2;  cx->bad = 1;  cx->md = MD_END;
+    }
+  else if (!(cx->more && cx->lasta >= cx->besta - MAX_TRIM_LAG))
+    cx->md = MD_END;
+  else if (cx->hs < cx->ls)
+    { if (s == 0) atomicAdd(errw + 2, 1u);
+      cx->md = MD_END;
+    }
+  else if (cx->dif > cx->alen + cx->blen + 64)
+    { if (s == 0) atomicOr(errw, DAMAR_ERR_BAND);
+      cx->md = MD_END;
+    }
+  else if (cx->hs - cx->ls > 27)
+    cx->md = MD_OVF;
+}
+
+/* A half whose band outgrew its lanes borrows the whole wavefront: the band goes to the one-alignment-per-wavefront
+ * register path in the reference's own coordinates (wave_reg_cont<REV>: lane (k & 63) owns diagonal k, marks as values,
+ * NA = the mark after the head's) and comes back as soon as it fits a half again (hgh - low + 3 <= PK_NARROW) or
+ * finishes the direction there (through wave_mem<REV> if it outgrows the wavefront too).  Called for one half at a time
+ * (hsel = its lane base) with every lane active. */
+template <int REV>
+__device__ __noinline__ void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel, DuoCtx *cx)
+{ const ReportArgs &a = g_jobs[uni(job)];
+  const int lane = lane_id();
+  const int TS = a.tspace;
+  const int m = REV ? -1 : 0;
+  const int edge = REV ? BIG : -1;
+  const int src = hsel;
+  int *const cold = duo_cold + (hsel >> 1);
+  WaveCtx c;
+  WaveState ws;
+#define DUO_PTR_OF(T, ptr) ((T) (uintptr_t) (((u64) (u32) bcast_i((int) (u32) ((u64) (uintptr_t) (ptr) >> 32), src) << 32) | \
+                                             (u32) bcast_i((int) (u32) (u64) (uintptr_t) (ptr), src)))
+#define DUO_SG(x) (REV ? -(x) : (x))
+  c.a0 = (u32) (bcast_i(cx->va0, src) - 16 * PK_PAD);  c.b0 = (u32) (bcast_i(cx->vb0, src) - 16 * PK_PAD);
+  c.aseq = a.ablk.bases + c.a0;  c.bseq = a.bblk.bases + c.b0;
+  c.apk = a.ablk.pk;  c.bpk = a.bblk.pk;
+  c.alen = bcast_i(cx->alen, src);  c.blen = bcast_i(cx->blen, src);
+  c.ts = TS;  c.ave = a.ave_path;  c.reach = a.reach;
+  c.score = a.score;  c.table = a.table;  c.trim8 = trimtab;
+  const int diag = bcast_i(cx->diag, src), mida = bcast_i(cx->anti, src);
+  { const bool selfie = (c.aseq == c.bseq);
+    c.minp = (selfie && diag >= 0) ? 1 : -BIG;
+    c.maxp = (selfie && diag <= 0) ? -1 : BIG;
+  }
+  c.aoff = 0;  c.boff = (a.comp & 1) ? (c.blen % TS) : 0;
+  c.st0 = DUO_PTR_OF(DState *, sc.st0);  c.st1 = DUO_PTR_OF(DState *, sc.st1);
+  c.NA = DUO_PTR_OF(int *, sc.NA);  c.NB = DUO_PTR_OF(int *, sc.NB);
+  c.koff = c.blen + 8;  c.ring = a.span;
+  c.cells = DUO_PTR_OF(Cell *, sc.cells);  c.cell_cap = a.cell_cap;
+  c.err = &a.counters[3];
+  c.atr = DUO_PTR_OF(u16 *, sc.atr);  c.btr = DUO_PTR_OF(u16 *, sc.btr);
+#undef DUO_PTR_OF
+  const int kbase = bcast_i(cx->kbase, src), ls = bcast_i(cx->ls, src), hs = bcast_i(cx->hs, src);
+  /* the band in the reference's coordinates: K = kbase - s, k = sigma * K */
+  ws.low = REV ? ls - kbase : kbase - hs;  ws.hgh = REV ? hs - kbase : kbase - ls;
+  ws.dif = bcast_i(cx->dif, src);
+  { const int besta = bcast_i(cx->besta, src), bestk = bcast_i(cx->bestk, src);
+    ws.besta = DUO_SG(besta);  ws.besty = DUO_SG((besta - bestk) >> 1);
+  }
+  ws.lasta = DUO_SG(bcast_i(cx->lasta, src));
+  ws.more = bcast_i(cx->more, src);  ws.reachm = uni(cold[DC_REACHM]);
+  ws.aclip = REV ? -BIG : BIG;  ws.bclip = REV ? BIG : -BIG;             /* (consumed by the clipping of the last step) */
+  ws.ncell = (u32) bcast_i(cx->ncell, src);
+  { const int ta = uni(cold[DC_TRIM]), tk = uni(cold[DC_TRIM + 1]), ra = uni(cold[DC_REACH]), rk = uni(cold[DC_REACH + 1]);
+    ws.trim.a = DUO_SG(ta);  ws.trim.y = DUO_SG((ta - tk) >> 1);  ws.trim.d = uni(cold[DC_TRIM + 2]);
+    ws.trim.ha = uni(cold[DC_TRIM + 3]);  ws.trim.hb = uni(cold[DC_TRIM + 4]);
+    ws.reach.a = DUO_SG(ra);  ws.reach.y = DUO_SG((ra - rk) >> 1);  ws.reach.d = uni(cold[DC_REACH + 2]);
+    ws.reach.ha = uni(cold[DC_REACH + 3]);  ws.reach.hb = uni(cold[DC_REACH + 4]);
+  }
+  ws.stopped = 0;  ws.bad = 0;  ws.narrow = 0;
+  /* the half's band into the 64-lane layout (lane (k & 63) owns diagonal k) */
+  LaneRegs r;
+  { const int k = ws.low + ((lane - ws.low) & 63);
+    const bool in = k <= ws.hgh;
+    const int sl = (hsel + (in ? kbase - DUO_SG(k) : 0)) << 2;
+    const int nV = __builtin_amdgcn_ds_bpermute(sl, cx->V);
+    const int nHA = __builtin_amdgcn_ds_bpermute(sl, cx->HA), nHB = __builtin_amdgcn_ds_bpermute(sl, cx->HB);
+    r.V = in ? DUO_SG(nV) : edge;
+    { const int ga = (int) ((u32) nHA >> PK_HBITS), gb = (int) ((u32) nHB >> PK_HBITS);
+      const int hai = REV ? DUO_GREV - ga : ga, hbi = REV ? DUO_GREV - gb : gb;
+      r.HA = (nHA & PK_HMASK) | (hai << PK_HBITS);  r.HB = (nHB & PK_HMASK) | (hbi << PK_HBITS);
+      r.NA = REV ? hai - 1 : hai + 1;  r.NB = REV ? hbi - 1 : hbi + 1;
+    }
+    { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) cx->Tlo);
+      const u32 th = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) cx->Thi);
+      r.T = ((u64) th << 32) | tl;
+    }
+  }
+  wave_mem_sync();
+  wave_reg_cont<REV>(c, mida, ws, &r);
+  const bool mine = (lane & 32) == hsel;
+  if (ws.narrow)
+    { /* back into the half, centred */
+      const int w = ws.hgh - ws.low + 1, slo = (32 - w) >> 1;
+      const int nls = slo, nhs = slo + w - 1;
+      const int nkbase = REV ? nls - ws.low : ws.hgh + nls;           /* K of lane nls is the highest: sigma * (REV ? low : hgh) */
+      const int k = DUO_SG(nkbase - (lane & 31));
+      const bool in = k >= ws.low && k <= ws.hgh;
+      const int sl = (k & 63) << 2;
+      const int nV = __builtin_amdgcn_ds_bpermute(sl, r.V);
+      const int nHA = __builtin_amdgcn_ds_bpermute(sl, r.HA), nHB = __builtin_amdgcn_ds_bpermute(sl, r.HB);
+      const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) r.T);
+      const u32 th = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) (r.T >> 32));
+      if (mine)
+        { const int hai = (int) ((u32) nHA >> PK_HBITS), hbi = (int) ((u32) nHB >> PK_HBITS);
+          cx->V = in ? DUO_SG(nV) : DUO_EDGE;
+          cx->HA = (nHA & PK_HMASK) | ((REV ? DUO_GREV - hai : hai) << PK_HBITS);
+          cx->HB = (nHB & PK_HMASK) | ((REV ? DUO_GREV - hbi : hbi) << PK_HBITS);
+          cx->Tlo = tl;  cx->Thi = th;
+          cx->mlo += nkbase - cx->kbase;  cx->mhi += nkbase - cx->kbase;
+          cx->kbase = nkbase;  cx->ls = nls;  cx->hs = nhs;
+          cx->md = MD_RUN;
+        }
+    }
+  else
+    { if (!ws.stopped)
+        wave_mem<REV>(c, mida, ws);
+      if (mine)
+        { cx->md = MD_END;  cx->bad = ws.bad; }
+    }
+  if (mine)
+    { cx->dif = ws.dif;  cx->besta = DUO_SG(ws.besta);  cx->bestk = DUO_SG(ws.besta) - 2 * DUO_SG(ws.besty);
+      cx->lasta = DUO_SG(ws.lasta);  cx->more = ws.narrow ? ws.more : 0;
+      cx->ncell = (int) ws.ncell;
+    }
+  cold[DC_REACHM] = ws.reachm;  cold[DC_ACLIP] = -1;  cold[DC_BCLIP] = 64;
+  cold[DC_TRIM] = DUO_SG(ws.trim.a);  cold[DC_TRIM + 1] = DUO_SG(ws.trim.a) - 2 * DUO_SG(ws.trim.y);  cold[DC_TRIM + 2] = ws.trim.d;
+  cold[DC_TRIM + 3] = ws.trim.ha;  cold[DC_TRIM + 4] = ws.trim.hb;
+  cold[DC_REACH] = DUO_SG(ws.reach.a);  cold[DC_REACH + 1] = DUO_SG(ws.reach.a) - 2 * DUO_SG(ws.reach.y);  cold[DC_REACH + 2] = ws.reach.d;
+  cold[DC_REACH + 3] = ws.reach.ha;  cold[DC_REACH + 4] = ws.reach.hb;
+#undef DUO_SG
+}
+
+/* End point and trace points of the direction that is over (align.c:1001-1118 / 1699-1898) for the halves with
+ * md == MD_END: the first lane of the half walks the two pebble chains (chain_to_trace).  Leaves the pass's results in
+ * cx and the half in MD_TASK with m = -1 (the reverse pass is next) or, after the reverse pass, in MD_END with m = 1
+ * as the sign that the alignment is complete. */
+__device__ __noinline__ void duo_finish(int job, SlotScratch sc, DuoCtx *cx)
+{ const ReportArgs &a = g_jobs[uni(job)];
+  const int lane = lane_id(), hb = lane & 32, s = lane & 31;
+  const bool fin = cx->md == MD_END;
+  const int m = cx->m;
+  const int *const cold = duo_cold + (hb >> 1);
+  const int TS = a.tspace;
+  const int boff = (a.comp & 1) ? (cx->blen % TS) : 0;
+  const int guard = 4 * (cx->alen + cx->blen) + 1024;
+  u32 *const errw = &a.counters[3];
+  int rx = 0, ry = 0, rd = 0, at = 0, bt = 0;
+  wave_mem_sync();
+  if (fin && !cx->bad && s == 0)
+    { int ta = cold[DC_TRIM], tk = cold[DC_TRIM + 1], td = cold[DC_TRIM + 2], tha = cold[DC_TRIM + 3], thb = cold[DC_TRIM + 4];
+      if (cold[DC_REACHM] >= 0 && a.reach)
+        { ta = cold[DC_REACH];  tk = cold[DC_REACH + 1];  td = cold[DC_REACH + 2];  tha = cold[DC_REACH + 3];  thb = cold[DC_REACH + 4]; }
+      const int ty_ = (ta - tk) >> 1;
+      const int trimy = (ty_ ^ m) - m, trimx = ((ta - ty_) ^ m) - m;
+      int gw = 0;
+      if (m == 0)
+        { at = chain_to_trace<0, 0>(sc.cells, tha, TS, 0, cx->anti, trimx, trimy, td, sc.atr, 0, guard, gw, errw);
+          bt = chain_to_trace<0, 1>(sc.cells, thb, TS, boff, cx->anti, trimx, trimy, td, sc.btr, 0, guard, gw, errw);
+        }
+      else
+        { at = chain_to_trace<1, 0>(sc.cells, tha, TS, 0, cx->anti, trimx, trimy, td, sc.atr, cx->atlen, guard, gw, errw);
+          bt = chain_to_trace<1, 1>(sc.cells, thb, TS, boff, cx->anti, trimx, trimy, td, sc.btr, cx->btlen, guard, gw, errw);
+        }
+      rx = trimx;  ry = trimy;  rd = td;
+    }
+  wave_mem_sync();
+  rx = hget(rx, hb, 0);  ry = hget(ry, hb, 0);  rd = hget(rd, hb, 0);  at = hget(at, hb, 0);  bt = hget(bt, hb, 0);
+  if (fin)
+    { if (m == 0)
+        { cx->aepos = rx;  cx->bepos = ry;  cx->diffs = rd;  cx->atlen = at;  cx->btlen = bt;
+          cx->aback = 0;  cx->bback = 0;
+          cx->m = -1;  cx->md = MD_TASK;  cx->bad = 0;
+        }
+      else
+        { cx->abpos = rx;  cx->bbpos = ry;  cx->diffs += rd;
+          cx->aback = at;  cx->bback = bt;  cx->atlen += at;  cx->btlen += bt;
+          cx->m = 1;
+        }
+    }
+}
+
+/***** the per-half state machine of the report loop ******************************************************/
+
+#ifndef DUO_WAVES
+#define DUO_WAVES 5                     /* resident wavefronts per SIMD the kernel is compiled for (VGPR budget 512 / DUO_WAVES) */
+#endif
+int damar_report3_waves_per_simd(void) { return DUO_WAVES; }
+
+/* one job of the launch: the two halves pull read pairs (or batch tasks) from its queue until it is empty */
+__device__ __forceinline__ void report3_job(const ReportArgs &a, const u32 *trimtab, const LaTask *tasks, u32 ntasks)
+{ const int lane = lane_id(), hb = lane & 32, s = lane & 31;
+  const int slot = 2 * (int) blockIdx.x + (hb >> 5);
+  const SlotScratch sc = slot_scratch(a, slot);
+  const u32 cbase = (u32) slot * a.cell_cap;
+  const u64 *keys = a.keys;
+  const u32 *vals = a.vals;
+  const u64 pmask = (1ull << a.pbits) - 1;
+  const int dbits = a.dbits, pshift = a.pbits + a.dbits;        /* key = pair | apos | bpos (dbits) */
+  const int K = a.kmer, H = a.hitmin, W = a.binshift, minhit = a.minhit;
+  const int mind = (-a.bblk.maxlen) >> W, maxd = a.ablk.maxlen >> W;
+  const bool batch = tasks != NULL;
+
+  int  phase = PK_ITEM;
+  u32  item = 0, seq = 0;
+  u64  nidx = 0, cpair = 0, lidx = 0, end = 0, h2 = 0, fp = 0;
+  int  ar = 0, br = 0, amark2 = 0, clo = BIG, chi = -BIG, sd = 0;
+  DuoCtx cx;
+  cx.md = MD_SCAN;  cx.m = 0;  cx.bad = 0;
+  cx.va0 = cx.vb0 = 16 * PK_PAD;  cx.alen = cx.blen = 0;
+  cx.V = DUO_EDGE;  cx.HA = cx.HB = 0;  cx.Tlo = cx.Thi = 0;
+  cx.ls = cx.hs = 15;  cx.kbase = 0;  cx.dif = 0;  cx.besta = cx.bestk = cx.lasta = 0;  cx.more = 0;  cx.ncell = 2;
+  cx.mlo = cx.mhi = 0;  cx.alim = cx.blim = 0;  cx.offa = cx.offb = 0;
+  cx.diag = cx.anti = 0;
+  cx.aepos = cx.bepos = cx.abpos = cx.bbpos = cx.diffs = cx.atlen = cx.btlen = cx.aback = cx.bback = 0;
+
+  for (;;)
+    { /* A: the halves without an alignment in hand advance their scan until they have one or have run out of work */
+      while (wany(cx.md == MD_SCAN))
+        { const bool sc_ = cx.md == MD_SCAN;
+          if (sc_ && phase == PK_ITEM)
+            { u32 it = 0;
+              if (s == 0)
+                it = atomicAdd(a.cursor, 1u);
+              it = (u32) hget((int) it, hb, 0);
+              if (it >= (batch ? ntasks : a.nwork))
+                { phase = PK_DONE;  cx.md = MD_DONE; }
+              else if (batch)
+                { const LaTask tk = tasks[it];
+                  item = it;  seq = 0;
+                  ar = tk.aread;  br = tk.bread;
+                  cx.va0 = (int) a.ablk.boff[ar] + 16 * PK_PAD;  cx.vb0 = (int) a.bblk.boff[br] + 16 * PK_PAD;
+                  cx.alen = (int) read_len(a.ablk, ar);  cx.blen = (int) read_len(a.bblk, br);
+                  cx.diag = tk.diag;  cx.anti = tk.anti;
+                  cx.m = 0;  cx.md = MD_TASK;
+                }
+              else
+                { item = a.order ? a.order[it] : it;
+                  nidx = a.work[item];
+                  cpair = keys[nidx] >> pshift;
+                  ar = (int) (cpair & ((1ull << a.abits) - 1));  br = (int) (cpair >> a.abits);
+                  cx.va0 = (int) a.ablk.boff[ar] + 16 * PK_PAD;  cx.vb0 = (int) a.bblk.boff[br] + 16 * PK_PAD;
+                  cx.alen = (int) read_len(a.ablk, ar);  cx.blen = (int) read_len(a.bblk, br);
+                  seq = 0;  amark2 = 0;  clo = BIG;  chi = -BIG;
+                  if (!(cx.alen < a.hgap_min && cx.blen < a.hgap_min))
+                    phase = PK_PANEL;
+                }
+            }
+          else if (sc_ && phase == PK_PANEL)
+            { if (!(nidx < a.nhits && (keys[nidx] >> pshift) == cpair))
+                { /* the pair is done: filter.c:2417-2432 leaves lasta all zero again */
+                  if (clo <= chi)
+                    for (int q = clo + s; q <= chi; q += 32)
+                      sc.lasta[q] = 0;
+                  phase = PK_ITEM;
+                }
+              else
+                { /* one A-panel (filter.c:2251-2266): hits while the pair continues and the hit just consumed has apos <= amark */
+                  const int amark = amark2 + PANEL_SIZE;
+                  amark2 = amark - PANEL_OVERLAP;
+                  lidx = nidx;  end = lidx;  h2 = lidx;
+                  for (u64 base = lidx; ; base += 32)
+                    { const u64  f = base + s;
+                      const bool in = f < a.nhits && (keys[f] >> pshift) == cpair;
+                      const int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
+                      const bool nextsame = (f + 1 < a.nhits) && ((keys[f + 1] >> pshift) == cpair);
+                      const bool stop = in && !(nextsame && ap <= amark);
+                      u32 le = hmask(wballot(in && ap <= amark2), hb);
+                      const u32 sm = hmask(wballot(stop), hb);
+                      if (sm)
+                        { const int l = __ffs((int) sm) - 1;
+                          end = base + l + 1;
+                          le &= (l == 31) ? ~0u : ((1u << (l + 1)) - 1);
+                          if (le) h2 = base + (31 - __clz((int) le)) + 1;
+                          break;
+                        }
+                      if (le) h2 = base + (31 - __clz((int) le)) + 1;
+                      if (hmask(wballot(in), hb) == 0)          /* cannot happen: a run always ends with a stop */
+                        { end = base; break; }
+                    }
+                  nidx = end;
+                  if (end - lidx >= (u64) minhit)
+                    { /* pass 1: bucket scores (filter.c:2268-2277) */
+                      for (u64 base = lidx; base < end; base += 32)
+                        { const u64  f = base + s;
+                          const bool in = f < end;
+                          const int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
+                          const int  d  = in ? (seed_diag(keys[f], vals, f, pmask, dbits) >> W) : BIG;
+                          int  prev = in ? sc.lastp[d] : 0;
+                          u32  peers = hmask(wballot(in), hb);
+                          { const u32 db = (u32) (d - mind);
+                            for (int bit = 0; bit < a.bucket_bits; bit++)
+                              { const bool one = (db >> bit) & 1;
+                                const u32  mk = hmask(wballot(one), hb);
+                                peers &= one ? mk : ~mk;
+                              }
+                          }
+                          const u32  below = peers & ((1u << s) - 1u);
+                          const int  pl = below ? 31 - __clz((int) below) : s;
+                          const int  pap = hget(ap, hb, pl);
+                          if (below) prev = pap;
+                          const bool last = in && ((peers >> s) >> 1) == 0;
+                          if (in)
+                            { const int add = (ap - prev >= K) ? K : ap - prev;
+                              atomicAdd(&sc.score[d], add);
+                              if (last)
+                                sc.lastp[d] = ap;
+                            }
+                          wave_mem_sync();
+                        }
+                      fp = lidx;
+                      phase = PK_FIRE;
+                    }
+                  else
+                    nidx = h2;
+                }
+            }
+          else if (sc_ && phase == PK_FIRE)
+            { /* pass 2 (filter.c:2283-2405): the next seed in order with enough score whose apos is beyond lasta */
+              bool found = false;
+              int  sap = 0, sdg = 0;
+              for (u64 base = fp; base < end; base += 32)
+                { const u64  f = base + s;
+                  const bool in = f < end;
+                  const int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
+                  const int  dg = in ? seed_diag(keys[f], vals, f, pmask, dbits) : 0;
+                  const int  d  = dg >> W;
+                  bool fire = false;
+                  if (in)
+                    { const int scv = sc.score[d];
+                      fire = ((scv + sc.score[d + 1] >= H) || (scv + sc.score[d - 1] >= H)) && ap > sc.lasta[d];
+                    }
+                  const u32 fm = hmask(wballot(fire), hb);
+                  if (fm)
+                    { const int l = __ffs((int) fm) - 1;
+                      sap = hget(ap, hb, l);  sdg = hget(dg, hb, l);  sd = sdg >> W;
+                      fp = base + l + 1;
+                      found = true;
+                      break;
+                    }
+                }
+              if (found)
+                { cx.diag = sdg;  cx.anti = sap + (sap - sdg);
+                  cx.m = 0;  cx.md = MD_TASK;
+                  if (s == 0)
+                    atomicAdd(a.nfilt, 1u);
+                }
+              else
+                { /* pass 3: reset the touched buckets (filter.c:2407-2411) */
+                  for (u64 base = lidx; base < end; base += 32)
+                    { const u64 f = base + s;
+                      if (f < end)
+                        { const int d = seed_diag(keys[f], vals, f, pmask, dbits) >> W;
+                          sc.score[d] = 0;
+                          sc.lastp[d] = 0;
+                        }
+                    }
+                  wave_mem_sync();
+                  nidx = h2;
+                  phase = PK_PANEL;
+                }
+            }
+        }
+
+      /* B: Local_Alignment (align.c:1904-2097 for low == hgh == diag), one pass at a time per half */
+      if (wany(cx.md == MD_TASK))
+        { duo_begin(a.job, cbase, &cx);
+          duo_classify(a, &cx);                           /* (the seed diagonal may already have ended the pass) */
+        }
+      if (wany(cx.md == MD_RUN))
+        { duo_loop(a.job, trimtab, cbase, &cx);           /* every half in MD_RUN can step: the loop tests behind a step */
+          duo_classify(a, &cx);
+        }
+      { const u64 ov = wballot(cx.md == MD_OVF);
+        if (ov)
+          { for (int h = 0; h < 64; h += 32)
+              if ((ov >> h) & 1)
+                { if (bcast_i(cx.m, h))
+                    duo_solo<1>(a.job, trimtab, sc, h, &cx);
+                  else
+                    duo_solo<0>(a.job, trimtab, sc, h, &cx);
+                }
+            duo_classify(a, &cx);
+          }
+      }
+      if (wany(cx.md == MD_END))
+        duo_finish(a.job, sc, &cx);
+
+      /* C: what the reference does with the path (filter.c:2318-2380), for the halves whose reverse pass is over */
+      if (wany(cx.md == MD_END))
+        { const bool task = cx.md == MD_END;
+          LaResult r;
+          r.abpos = cx.abpos;  r.bbpos = cx.bbpos;  r.aepos = cx.aepos;  r.bepos = cx.bepos;  r.diffs = cx.diffs;
+          r.atlen = cx.atlen;  r.btlen = cx.btlen;  r.aback = cx.aback;  r.bback = cx.bback;
+          if (batch)
+            { pk_emit(a, sc, task, r, ar, br, item, 0);
+              if (task)
+                { phase = PK_ITEM;  cx.md = MD_SCAN; }
+            }
+          else
+            { int lo = 0, hi = 0;
+              if (task && s == 0)                         /* Diagonal_Span (filter.c:2079-2110) on the A-view path */
+                { const u16 *pt = sc.atr - r.aback;
+                  int dd, tlen = r.atlen - 2;
+                  lo = hi = r.abpos - r.bbpos;
+                  dd = r.aepos - r.bepos;
+                  if (dd < lo) lo = dd; else if (dd > hi) hi = dd;
+                  dd = (r.abpos / a.tspace) * a.tspace - r.bbpos;
+                  for (int i = 1; i < tlen; i += 2)
+                    { dd += a.tspace - pt[i];
+                      if (dd < lo) lo = dd; else if (dd > hi) hi = dd;
+                    }
+                  lo = (lo >> W) - 1;
+                  hi = (hi >> W) + 1;
+                }
+              lo = hget(lo, hb, 0);  hi = hget(hi, hb, 0);
+              if (task)
+                { if (sd < lo) lo = sd; else if (sd > hi) hi = sd;
+                  if (lo < mind - 1) lo = mind - 1;
+                  if (hi > maxd + 1) hi = maxd + 1;
+                  for (int q = lo + s; q <= hi; q += 32)
+                    if (r.aepos > sc.lasta[q])
+                      sc.lasta[q] = r.aepos;
+                  if (lo < clo) clo = lo;
+                  if (hi > chi) chi = hi;
+                }
+              wave_mem_sync();
+              const bool keep = task && (r.aepos - r.abpos) + (r.bepos - r.bbpos) >= a.minover;
+              pk_emit(a, sc, keep, r, ar, br, item, seq);
+              if (keep)
+                seq += 1;
+              if (task)
+                cx.md = MD_SCAN;                          /* (phase is still PK_FIRE: the panel's next seed) */
+            }
+        }
+      if (!wany(cx.md != MD_DONE))
+        break;
+    }
+}
+
+__global__ __launch_bounds__(64, DUO_WAVES)
+void report3_kernel(int njobs, const LaTask *tasks, u32 ntasks)
+{ __shared__ u32 trimtab[256];
+  pk_fill_trimtab(trimtab, g_jobs[0].mscore, g_jobs[0].dscore);
+  __syncthreads();
+#ifdef DAMAR_PROF
+  struct PfExit { unsigned long long t0; __device__ ~PfExit() { unsigned long long d = wall_clock64() - t0;
+    if (lane_id() == 0) { atomicAdd(&g_prof[23], d); atomicAdd(&g_prof[25], 1ull); atomicMax(&g_prof[24], d); } } } pf_exit = { (unsigned long long) wall_clock64() };
+#endif
+  for (int turn = 0; turn < njobs; turn++)
+    report3_job(g_jobs[((int) blockIdx.x + turn) % njobs], trimtab, tasks, ntasks);
+}
+
+void damar_launch_report3(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st)
+{ jobs_upload(jobs, njobs, st);
+  hipLaunchKernelGGL(report3_kernel, dim3(nslots / 2), dim3(64), 0, st, njobs, tasks, ntasks);
+}

@@ -1048,7 +1048,17 @@ void report2_kernel(int njobs, const LaTask *tasks, u32 ntasks)
     report2_job(g_jobs[((int) blockIdx.x + turn) % njobs], trimtab, tasks, ntasks);
 }
 
+void damar_launch_report3(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
 void damar_launch_report2(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st)
-{ jobs_upload(jobs, njobs, st);
+{ static int duo = -1;
+  if (duo < 0)
+    { const char *e = getenv("DAMAR_DUO");
+      duo = e ? atoi(e) : 1;
+    }
+  if (duo)
+    { damar_launch_report3(jobs, njobs, tasks, ntasks, nslots, st);
+      return;
+    }
+  jobs_upload(jobs, njobs, st);
   hipLaunchKernelGGL(report2_kernel, dim3(nslots / 2), dim3(64), 0, st, njobs, tasks, ntasks);
 }
