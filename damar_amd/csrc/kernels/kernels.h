@@ -26,6 +26,8 @@ typedef struct
 { const u8  *bases;     /* byte per base 0..3, 4 = terminator; bases[-1] == 4 (reference layout) */
   const u32 *pk;        /* the same positions at 2 bits per base (terminators read as 0): word w
                            holds bases 16w .. 16w+15, base 16w in bits 0-1; PK_PAD words either side */
+  u32        rbias;     /* the bases in REVERSE order follow in the same array: base total-1-j sits at biased position
+                           rbias + j (position of base p in the forward part: p + 16 * PK_PAD), see pack_bases */
   const u32 *boff;      /* [nreads+1] offset of read i in bases                                   */
   const u32 *coarse;    /* [(total >> COARSE_SHIFT) + 2] read containing position q<<COARSE_SHIFT */
   u32        nreads;
@@ -74,7 +76,9 @@ __device__ __forceinline__ u32 pos_encode(const DevBlock &b, u32 r, u32 x, u32 p
 { return b.rpbits ? ((r << b.rpbits) | x) : p; }
 #endif
 
-/* pk[w] for w in [-PK_PAD, total/16 + PK_PAD] from bases (which carry 64 padding bytes either side) */
+/* pk[w] for w in [-PK_PAD, total/16 + PK_PAD] from bases (which carry 64 padding bytes either side), then as many words
+   of the reversed copy: pk points PK_PAD words into an array of 2 * damar_pack_words(total) words */
+long long damar_pack_words(u32 total);
 void damar_launch_pack_bases(const u8 *bases, u32 total, u32 *pk, hipStream_t st);
 
 /* kmer_index.hip */

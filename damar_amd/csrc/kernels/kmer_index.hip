@@ -291,20 +291,30 @@ void damar_launch_tandem_links(const DevBlock *blk, int kmer, const void *codes,
     hipLaunchKernelGGL(tandem_links<u32>, dim3((n + 255) / 256), dim3(256), 0, st, *blk, kmer, (const u32 *) codes, pos, n, dist);
 }
 
-/* 2-bit packed copy of a block's bases for the alignment wave (16 bases per dword) */
+/* 2-bit packed copy of a block's bases for the alignment wave (16 bases per dword), followed by the same bases in
+   REVERSE order (word nwords + w holds bases total-1-16w' ... downwards, w' = w - PK_PAD): a reverse pass of the wave
+   then slides along ascending addresses like a forward one and needs no bit reversal of its windows (report_duo.h) */
 __global__ __launch_bounds__(256)
-void pack_bases(const u8 *__restrict__ bases, long long nwords, u32 *__restrict__ pk)
+void pack_bases(const u8 *__restrict__ bases, long long nwords, long long total, u32 *__restrict__ pk)
 { long long w = (long long) blockIdx.x * 256 + threadIdx.x - PK_PAD;
   if (w >= nwords - PK_PAD)
     return;
   const u8 *s = bases + 16 * w;                     /* >= bases - 64: inside the padding */
-  u32 v = 0;
+  u32 v = 0, r = 0;
   for (int j = 0; j < 16; j++)
-    v |= (u32) (s[j] & 3) << (2 * j);
+    { v |= (u32) (s[j] & 3) << (2 * j);
+      const long long q = total - 1 - (16 * w + j);                  /* the base the reversed copy holds at 16 w + j */
+      const u32 c = (q >= -64 && q < total + 64) ? (u32) (bases[q] & 3) : 0u;
+      r |= c << (2 * j);
+    }
   pk[w] = v;
+  pk[nwords + w] = r;
 }
 
+/* pk must hold 2 * damar_pack_words(total) words */
+long long damar_pack_words(u32 total) { return (long long) (total >> 4) + 1 + 2 * PK_PAD; }      /* words -PK_PAD .. total/16 + PK_PAD */
+
 void damar_launch_pack_bases(const u8 *bases, u32 total, u32 *pk, hipStream_t st)
-{ long long nwords = (long long) (total >> 4) + 1 + 2 * PK_PAD;      /* words -PK_PAD .. total/16 + PK_PAD */
-  hipLaunchKernelGGL(pack_bases, dim3((u32) ((nwords + 255) / 256)), dim3(256), 0, st, bases, nwords, pk);
+{ const long long nwords = damar_pack_words(total);
+  hipLaunchKernelGGL(pack_bases, dim3((u32) ((nwords + 255) / 256)), dim3(256), 0, st, bases, nwords, (long long) total, pk);
 }

@@ -32,6 +32,10 @@
  * Reference semantics and citations are those of report_packed.h / report.hip.
  */
 
+/* DUO_WAVES (report_packed.h): resident wavefronts per SIMD the kernel and its pieces are compiled for (VGPR budget
+   512 / DUO_WAVES; the launch bound of the kernel is handed down to the functions it calls) */
+#define DUO_PIECE __device__ __noinline__
+
 #define DUO_EDGE   (-BIG)
 #define DUO_GREV   (1 << 14)                    /* G = DUO_GREV - grid index in a reverse pass */
 #define DUO_LIMK   (1 << 29)
@@ -66,6 +70,7 @@ struct DuoCtx
   int alim, blim;                               /* bases left: alim - X in A, blim - Y in B */
   int offa, offb;                               /* the mark after head index G is crossed when X >= G * TS + offa */
   int va0, vb0, alen, blen;                     /* the reads: offsets in the packed bases (biased by the padding), lengths */
+  int pa0, pb0;                                 /* where the pass's packed bases start: window of (X, Y) at pa0 + X, pb0 + Y */
   /* the task and what its passes have produced */
   int diag, anti;
   int aepos, bepos, abpos, bbpos, diffs, atlen, btlen, aback, bback;
@@ -74,10 +79,11 @@ struct DuoCtx
 struct DuoSnake { int Y, na, nb;  u64 b; };
 
 /* The snake (align.c:832-856 / 1542-1566) of diagonal K from Y, in the loop's coordinates: 16 bases per step off the
-   2-bit packed reads (window [x, x + 15] forward, [x - 16, x - 1] bit-reversed in reverse), bounded by the bases left
+   2-bit packed reads -- forward off the packed bases, reverse off their REVERSED copy (DevBlock.rbias), so that both
+   slide along ascending addresses: the window starts at biased position pa0 + X / pb0 + Y -- bounded by the bases left
    in either read; a lane that is past an end takes the byte path, which reads what the reference reads there. */
 __device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, const u8 *abase, const u8 *bbase,
-                                              int m, int alim, int blim, int va0, int vb0, int alen, int blen,
+                                              int m, int alim, int blim, int pa0, int pb0, int va0, int vb0, int alen, int blen,
                                               int K, int Y, u64 b)
 { DuoSnake o;
   const int X = Y + K;
@@ -93,23 +99,25 @@ __device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, co
       o.Y = (so.y ^ m) - m;  o.b = so.b;  o.na = so.na;  o.nb = so.nb;
       return o;
     }
-  const int c15 = m & 15, st16 = (16 ^ m) - m;
-  u32 pa = (u32) (va0 + ((X + c15) ^ m)), pb = (u32) (vb0 + ((Y + c15) ^ m));
+  u32 pa = 2u * (u32) (pa0 + X), pb = 2u * (u32) (pb0 + Y);         /* as bit positions: the window shift needs no doubling */
   for (;;)
     { u32 wa, wb;
-      load16x2(apk, pa, bpk, pb, &wa, &wb);
-      u32 x = wa ^ wb;
-      if (m)
-        x = __builtin_bitreverse32(x);
-      const u32 run = (u32) (__ffs((int) x) - 1) >> 1;         /* equal bases at the head of the window; huge if all 16 are */
+      { typedef u32 v2u __attribute__((ext_vector_type(2)));
+        const u32 oa = (pa >> 3) & ~3u, ob = (pb >> 3) & ~3u;
+        v2u ra, rb;                                                  /* both loads in flight together, ONE wait (as load16x2) */
+        asm volatile("global_load_dwordx2 %0, %2, %4\n\tglobal_load_dwordx2 %1, %3, %5\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(ra), "=&v"(rb) : "v"(oa), "v"(ob), "s"(apk - PK_PAD), "s"(bpk - PK_PAD) : "memory");
+        wa = __builtin_amdgcn_alignbit(ra.y, ra.x, pa);
+        wb = __builtin_amdgcn_alignbit(rb.y, rb.x, pb);
+      }
+      const u32 run = (u32) ffbl_raw(wa ^ wb) >> 1;            /* equal bases at the head of the window; huge if all 16 are */
       const int lim = na < nb ? na : nb;
-      int n = (int) (run < 16u ? run : 16u);
-      n = n < lim ? n : lim;
+      const int n = (int) __builtin_elementwise_min(__builtin_elementwise_min(run, 16u), (u32) lim);
       b = (b << n) | (u64) ((1u << n) - 1);
       Y += n;  na -= n;  nb -= n;
       if (n < 16 || lim == 16)
         break;
-      pa += (u32) st16;  pb += (u32) st16;
+      pa += 32;  pb += 32;
     }
   o.Y = Y;  o.b = b;  o.na = na;  o.nb = nb;
   return o;
@@ -118,7 +126,7 @@ __device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, co
 /* clipping at sequence ends (align.c:628-658 / 943-975) for the halves with `on`, in lane coordinates: the A-side clip
    lane (the highest sweep index that reached A's end) cuts the band's low lanes, the B-side one its high lanes */
 #define DUO_CLIP()                                                                                     \
-  if (bal(on) & bal(more == 0))                                                                        \
+  if (onm & bal(more == 0))                                                                            \
     { const bool cl_ = on && more == 0;                                                                \
       const int  mp_ = pk_popc61(rT);                                                                  \
       if (cl_)                                                                                         \
@@ -171,9 +179,10 @@ __device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, co
 
 /* Wave 0 on the seed diagonal (align.c:491-626 / 1203-1340) and the clipping behind it, for the halves with
    md == MD_TASK: sets up direction cx->m of the task (cx->diag, cx->anti).  Every lane of a half computes the same. */
-__device__ __noinline__ void duo_begin(int job, u32 cbase, DuoCtx *cx)
+DUO_PIECE void duo_begin(int job, u32 cbase, DuoCtx *cx)
 { DUO_NAMES()
   const bool on = cx->md == MD_TASK;
+  const u64 onm = bal(on);
   const int m = cx->m;
   const int va0 = cx->va0, vb0 = cx->vb0, alen = cx->alen, blen = cx->blen;
   const int diag = cx->diag, anti = cx->anti;
@@ -181,7 +190,7 @@ __device__ __noinline__ void duo_begin(int job, u32 cbase, DuoCtx *cx)
   const int boff = (a.comp & 1) ? (blen % TS) : 0;
   const int offa0 = -PK_BIAS * TS, offb0 = boff - PK_BIAS * TS;          /* mark = grid index * TS + off */
   int ls = 15, hs = 15, kbase = 0, dif = 0, besta = 0, bestk = 0, lasta = 0, more = 1, ncell = 2, bad = 0;
-  int mlo = 0, mhi = 0, alim = 0, blim = 0, offa = 0, offb = 0;
+  int mlo = 0, mhi = 0, alim = 0, blim = 0, offa = 0, offb = 0, pa0 = 0, pb0 = 0;
   int rV = DUO_EDGE, rHA = 0, rHB = 0;
   u64 rT = 0;
   int md = cx->md;
@@ -199,6 +208,7 @@ __device__ __noinline__ void duo_begin(int job, u32 cbase, DuoCtx *cx)
             }
           offa = offa0 + TS;  offb = offb0 + TS;
           alim = alen;  blim = blen;
+          pa0 = va0;  pb0 = vb0;
         }
       else
         { const int hai = (x + TS - 1) / TS + PK_BIAS, hbi = (y + (TS - boff) - 1) / TS + PK_BIAS;     /* the true start, rounded up to the grid */
@@ -209,6 +219,9 @@ __device__ __noinline__ void duo_begin(int job, u32 cbase, DuoCtx *cx)
           ga = DUO_GREV - hai;  gb = DUO_GREV - hbi;
           offa = -offa0 - DUO_GREV * TS + TS;  offb = -offb0 - DUO_GREV * TS + TS;
           alim = 0;  blim = 0;
+          /* base x - 1 of the read = block base a0 + x - 1 = reversed base total - a0 - x, at X = -x */
+          pa0 = (int) (a.ablk.rbias + a.ablk.total) - (va0 - 16 * PK_PAD);
+          pb0 = (int) (a.bblk.rbias + a.bblk.total) - (vb0 - 16 * PK_PAD);
         }
       { const bool selfie = (abase + va0 == bbase + vb0);
         const int minp = (selfie && diag >= 0) ? 1 : -DUO_LIMK, maxp = (selfie && diag <= 0) ? -1 : DUO_LIMK;
@@ -217,7 +230,7 @@ __device__ __noinline__ void duo_begin(int job, u32 cbase, DuoCtx *cx)
         mlo = kbase - maxK;  mhi = kbase - minK;
       }
       cold[DC_REACHM] = -1;  cold[DC_ACLIP] = -1;  cold[DC_BCLIP] = 64;
-      { const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, va0, vb0, alen, blen, K0, Y, 0ull);
+      { const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, pa0, pb0, va0, vb0, alen, blen, K0, Y, 0ull);
         Y = so.Y;
         if (so.nb == 0)      { more = 0;  cold[DC_BCLIP] = 15; }
         else if (so.na == 0) { more = 0;  cold[DC_ACLIP] = 15; }
@@ -266,20 +279,21 @@ __device__ __noinline__ void duo_begin(int job, u32 cbase, DuoCtx *cx)
       cx->ls = ls;  cx->hs = hs;  cx->kbase = kbase;  cx->dif = dif;  cx->besta = besta;  cx->bestk = bestk;
       cx->lasta = lasta;  cx->more = more;  cx->ncell = ncell;  cx->bad = bad;
       cx->mlo = mlo;  cx->mhi = mhi;  cx->alim = alim;  cx->blim = blim;  cx->offa = offa;  cx->offb = offb;
+      cx->pa0 = pa0;  cx->pb0 = pb0;
     }
 }
 
 /* The wave steps (align.c:667-999 / 1378-1697) of the halves with md == MD_RUN, until one of them has an event: its
    direction is over (or failed), or its band no longer fits lanes 1..30.  The caller tells which from the state
    (duo_classify); on entry every such half can step (duo_classify has been through). */
-__device__ __noinline__ void duo_loop(int job, const u32 *trimtab, u32 cbase, DuoCtx *cx)
+DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase, DuoCtx *cx)
 { DUO_NAMES()
   const int ave = uni(a.ave_path);
   const u64 onm = bal(cx->md == MD_RUN);
   const bool on = inv(onm);
   const int m = cx->m;
   const int va0 = cx->va0, vb0 = cx->vb0, alen = cx->alen, blen = cx->blen;
-  const int alim = cx->alim, blim = cx->blim, offa = cx->offa, offb = cx->offb;
+  const int alim = cx->alim, blim = cx->blim, offa = cx->offa, offb = cx->offb, pa0 = cx->pa0, pb0 = cx->pb0;
   const int steplimit = alen + blen + 64, guard = 4 * (alen + blen) + 1024;
   const u32 below = (1u << s) - 1u;
   const int lane4 = lane << 2, top4 = (hb + 31) << 2;
@@ -343,10 +357,11 @@ __device__ __noinline__ void duo_loop(int job, const u32 *trimtab, u32 cbase, Du
           int Y = 0, na = 1, nb = 1;
           if (inv(actm))
             { b <<= 1;
-              const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, va0, vb0, alen, blen, K, (v - K) >> 1, b);
+              const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, pa0, pb0, va0, vb0, alen, blen, K, (v - K) >> 1, b);
               Y = so.Y;  b = so.b;  na = so.na;  nb = so.nb;
               v = (Y << 1) + K;
             }
+          asm("" : "+v"(na), "+v"(nb));            /* (compare behind the join: a bool out of the branch would be made 0 / 1 per lane and compared again) */
           const u64 bhm = actm & bal(nb == 0), ahm = actm & ~bhm & bal(na == 0);
 
           /* pebbles (align.c:859-909 / 1569-1618): every mark between the inherited head's and the new position */
@@ -443,12 +458,12 @@ __device__ __noinline__ void duo_loop(int job, const u32 *trimtab, u32 cbase, Du
             rV = inv(bal(s >= ls) & bal(s <= hs)) ? rV : DUO_EDGE;
           }
 
-          /* may every half go on as it is? */
-          gom = bal(more != 0) & bal(lasta >= besta - MAX_TRIM_LAG) & bal((u32) (hs - ls) <= 27u) & bal(dif <= steplimit)
-                & bal(ncell <= cell_cap);
+          /* may every half go on as it is?  (a band within lanes 2 .. 29 is no wider than 28; a pebble pool that has
+             run over is noticed when the loop is left for any other reason: its stores are bounded) */
+          gom = bal(more != 0) & bal(lasta >= besta - MAX_TRIM_LAG) & bal(hs >= ls) & bal(dif <= steplimit);
         }
       while ((onm & ~(gom & bal(ls >= 2) & bal(hs <= 29))) == 0);
-      if (onm & ~gom)
+      if (onm & ~(gom & bal(hs - ls <= 27) & bal(ncell <= cell_cap)))
         break;
     }
 #ifdef DAMAR_PROF
@@ -491,7 +506,7 @@ __device__ __forceinline__ void duo_classify(const ReportArgs &a, DuoCtx *cx)
  * finishes the direction there (through wave_mem<REV> if it outgrows the wavefront too).  Called for one half at a time
  * (hsel = its lane base) with every lane active. */
 template <int REV>
-__device__ __noinline__ void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel, DuoCtx *cx)
+DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel, DuoCtx *cx)
 { const ReportArgs &a = g_jobs[uni(job)];
   const int lane = lane_id();
   const int TS = a.tspace;
@@ -608,7 +623,7 @@ __device__ __noinline__ void duo_solo(int job, const u32 *trimtab, SlotScratch s
  * md == MD_END: the first lane of the half walks the two pebble chains (chain_to_trace).  Leaves the pass's results in
  * cx and the half in MD_TASK with m = -1 (the reverse pass is next) or, after the reverse pass, in MD_END with m = 1
  * as the sign that the alignment is complete. */
-__device__ __noinline__ void duo_finish(int job, SlotScratch sc, DuoCtx *cx)
+DUO_PIECE void duo_finish(int job, SlotScratch sc, DuoCtx *cx)
 { const ReportArgs &a = g_jobs[uni(job)];
   const int lane = lane_id(), hb = lane & 32, s = lane & 31;
   const bool fin = cx->md == MD_END;
@@ -655,10 +670,6 @@ __device__ __noinline__ void duo_finish(int job, SlotScratch sc, DuoCtx *cx)
 
 /***** the per-half state machine of the report loop ******************************************************/
 
-#ifndef DUO_WAVES
-#define DUO_WAVES 5                     /* resident wavefronts per SIMD the kernel is compiled for (VGPR budget 512 / DUO_WAVES) */
-#endif
-int damar_report3_waves_per_simd(void) { return DUO_WAVES; }
 
 /* one job of the launch: the two halves pull read pairs (or batch tasks) from its queue until it is empty */
 __device__ __forceinline__ void report3_job(const ReportArgs &a, const u32 *trimtab, const LaTask *tasks, u32 ntasks)
@@ -683,7 +694,7 @@ __device__ __forceinline__ void report3_job(const ReportArgs &a, const u32 *trim
   cx.va0 = cx.vb0 = 16 * PK_PAD;  cx.alen = cx.blen = 0;
   cx.V = DUO_EDGE;  cx.HA = cx.HB = 0;  cx.Tlo = cx.Thi = 0;
   cx.ls = cx.hs = 15;  cx.kbase = 0;  cx.dif = 0;  cx.besta = cx.bestk = cx.lasta = 0;  cx.more = 0;  cx.ncell = 2;
-  cx.mlo = cx.mhi = 0;  cx.alim = cx.blim = 0;  cx.offa = cx.offb = 0;
+  cx.mlo = cx.mhi = 0;  cx.alim = cx.blim = 0;  cx.offa = cx.offb = 0;  cx.pa0 = cx.pb0 = 0;
   cx.diag = cx.anti = 0;
   cx.aepos = cx.bepos = cx.abpos = cx.bbpos = cx.diffs = cx.atlen = cx.btlen = cx.aback = cx.bback = 0;
 

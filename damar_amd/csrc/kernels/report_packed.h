@@ -806,7 +806,19 @@ enum { PK_ITEM = 0, PK_PANEL, PK_FIRE, PK_DONE };
                                            1 / 2 / 3 / 4 wavefronts per SIMD (DAMAR_SLOTS) gives 1073 / 556 / 407 / 337 ms: the
                                            kernel is bound by how long ONE wavefront takes per step, residency is what hides it */
 #endif
-int damar_report2_waves_per_simd(void) { return PK_WAVES; }
+#ifndef DUO_WAVES
+#define DUO_WAVES 8                     /* the same for report_duo.h's kernel, whose wave loop fits 64 VGPRs */
+#endif
+/* which of the two packed kernels runs: report_duo.h's (halves independent) unless DAMAR_DUO=0 asks for this file's */
+static int duo_enabled(void)
+{ static int duo = -1;
+  if (duo < 0)
+    { const char *e = getenv("DAMAR_DUO");
+      duo = e ? atoi(e) : 1;
+    }
+  return duo;
+}
+int damar_report2_waves_per_simd(void) { return duo_enabled() ? DUO_WAVES : PK_WAVES; }
 
 /* one job of the launch: the two halves pull read pairs (or batch tasks) from its queue until it is empty */
 __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trimtab, const LaTask *tasks, u32 ntasks)
@@ -1050,12 +1062,7 @@ void report2_kernel(int njobs, const LaTask *tasks, u32 ntasks)
 
 void damar_launch_report3(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
 void damar_launch_report2(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st)
-{ static int duo = -1;
-  if (duo < 0)
-    { const char *e = getenv("DAMAR_DUO");
-      duo = e ? atoi(e) : 1;
-    }
-  if (duo)
+{ if (duo_enabled())
     { damar_launch_report3(jobs, njobs, tasks, ntasks, nslots, st);
       return;
     }

@@ -433,8 +433,9 @@ static damar_dev_block *block_upload_on(const HITS_DB *block, hipStream_t st)
   HIP_CHECK(hipMemcpyAsync(b->coarse, coarse.data(), sizeof(u32) * nq, hipMemcpyHostToDevice, st));
   HIP_CHECK(hipStreamSynchronize(st));
   b->d.bases  = b->bases_alloc + 64;
-  b->pk_alloc = (u32 *) dmalloc(sizeof(u32) * (((size_t) total >> 4) + 1 + 2 * PK_PAD));
+  b->pk_alloc = (u32 *) dmalloc(sizeof(u32) * 2 * (size_t) damar_pack_words((u32) total));      /* forward, then reversed */
   b->d.pk     = b->pk_alloc + PK_PAD;
+  b->d.rbias  = (u32) (16 * damar_pack_words((u32) total) + 16 * PK_PAD);
   damar_launch_pack_bases(b->d.bases, (u32) total, b->pk_alloc + PK_PAD, st);
   HIP_CHECK(hipStreamSynchronize(st));
   b->d.boff   = b->boff;
@@ -817,11 +818,17 @@ static int default_slots(void)
 { const char *e = getenv("DAMAR_SLOTS");
   if (e && atoi(e) > 0)
     return atoi(e);
-  /* a report launch that shares the machine with the next comparisons' seed stages leaves them a fifth of the register
-     file: 4 of the 5 wavefronts per SIMD the packed kernel is compiled for (measured, r02_sweeps.txt: 524 ms per step
-     against 549 at 5 and 543 at 3.5) */
+  /* (rounds 2-3: a report launch that shares the machine with the next comparisons' seed stages left them a fifth of the
+     register file, 4 of the 5 wavefronts per SIMD report_packed.h's kernel is compiled for.  report_duo.h's kernel needs 64
+     VGPRs and a launch now takes every wave slot: measured per config-2 step 298 / 300 / 293 / 298 / 286 ms at 4 / 5 / 6 /
+     7 / 8 report wavefronts per SIMD, profiles/r04_sweeps.txt -- the seed kernels then run in the gaps the report
+     wavefronts leave as they retire, and nothing is gained by reserving registers for them) */
+  /* (DAMAR_REPORT_WPS: report wavefronts per SIMD of a launch, for sweeps) */
+  if (const char *w = getenv("DAMAR_REPORT_WPS"))
+    if (atoi(w) > 0)
+      return G_prop.multiProcessorCount * 4 * 2 * std::min(atoi(w), damar_report2_waves_per_simd());
   if (corun_on())
-    return G_prop.multiProcessorCount * 4 * 2 * std::min(4, damar_report2_waves_per_simd());
+    return G_prop.multiProcessorCount * 4 * 2 * (damar_report2_waves_per_simd() >= 8 ? 8 : std::min(4, damar_report2_waves_per_simd()));
   /* every wave slot of the chip: one scratch slot per wavefront of the one-pair kernel, two per wavefront of the packed one */
   return G_prop.multiProcessorCount * 4 * std::max(damar_report_waves_per_simd(), 2 * damar_report2_waves_per_simd());
 }

@@ -16,6 +16,6 @@ names = ["passes", "steps", "steps_in_passes_fit16", "steps_before_over16", "ste
          "passes_fit16", "passes_fit32", "clk_wave_mem", "clk_finish", "clk_wave_reg",
          "pairs", "seeds_scanned", "panels", "clk_to_scan_end", "clk_pass1", "clk_pass2_incl_LA", "clk_pass3",
          "clk_waves_busy_sum", "clk_wave_max(last launch max)", "waves",
-         "pk_loop_iterations", "pk_half_steps", "pk_overflows", "pk_passes"]
+         "pk_loop_iterations", "pk_half_steps", "pk_overflows", "pk_passes", "band_cells"]
 for n, v in zip(names, out):
     print("%-24s %d" % (n, v))
