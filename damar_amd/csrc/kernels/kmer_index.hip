@@ -293,7 +293,7 @@ void damar_launch_tandem_links(const DevBlock *blk, int kmer, const void *codes,
 
 /* 2-bit packed copy of a block's bases for the alignment wave (16 bases per dword), followed by the same bases in
    REVERSE order (word nwords + w holds bases total-1-16w' ... downwards, w' = w - PK_PAD): a reverse pass of the wave
-   then slides along ascending addresses like a forward one and needs no bit reversal of its windows (report_duo.h) */
+   then slides along ascending addresses like a forward one and needs no bit reversal of its windows (report_packed.h) */
 __global__ __launch_bounds__(256)
 void pack_bases(const u8 *__restrict__ bases, long long nwords, long long total, u32 *__restrict__ pk)
 { long long w = (long long) blockIdx.x * 256 + threadIdx.x - PK_PAD;

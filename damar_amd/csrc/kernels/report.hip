@@ -1839,4 +1839,3 @@ void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks,
 }
 
 #include "report_packed.h"
-#include "report_duo.h"

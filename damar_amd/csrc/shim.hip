@@ -819,7 +819,7 @@ static int default_slots(void)
   if (e && atoi(e) > 0)
     return atoi(e);
   /* (rounds 2-3: a report launch that shares the machine with the next comparisons' seed stages left them a fifth of the
-     register file, 4 of the 5 wavefronts per SIMD report_packed.h's kernel is compiled for.  report_duo.h's kernel needs 64
+     register file, 4 of the 5 wavefronts per SIMD the round-3 kernel was compiled for.  report_packed.h's kernel now needs 64
      VGPRs and a launch now takes every wave slot: measured per config-2 step 298 / 300 / 293 / 298 / 286 ms at 4 / 5 / 6 /
      7 / 8 report wavefronts per SIMD, profiles/r04_sweeps.txt -- the seed kernels then run in the gaps the report
      wavefronts leave as they retire, and nothing is gained by reserving registers for them) */
