@@ -193,6 +193,11 @@ def cpu_baseline(dbdir, root, nblocks, aligned_bp):
     if not os.path.exists(ref):
         kind, exe, runs = "port", os.path.join(ROOT, "oracle", "oracle_daligner"), [("concurrent", 1)]
     lines = [["%s.%d" % (root, a)] + ["%s.%d" % (root, b) for b in range(a, 0, -1)] for a in range(1, nblocks + 1)]
+    # one process per BLOCK PAIR, all at once (what `HPCdaligner -B1` would emit): the plan spread over more cores than its
+    # few lines can use; same output files
+    pairs = [["%s.%d" % (root, a), "%s.%d" % (root, b)] for a in range(1, nblocks + 1) for b in range(a, 0, -1)]
+    if kind == "reference" and cores >= 4 * len(pairs):
+        runs.append(("per-pair", pow2_floor(min(16, cores // len(pairs)))))
     res = {}
     for mode, nthr in runs:
         work = tempfile.mkdtemp(prefix="damar_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -203,7 +208,8 @@ def cpu_baseline(dbdir, root, nblocks, aligned_bp):
                 for ln in lines:
                     subprocess.run([exe, "-k14", "-j%d" % nthr] + ln, cwd=work, check=True, stdout=subprocess.DEVNULL)
             else:
-                ps = [subprocess.Popen([exe, "-k14", "-j%d" % nthr] + ln, cwd=work, stdout=subprocess.DEVNULL) for ln in lines]
+                ps = [subprocess.Popen([exe, "-k14", "-j%d" % nthr] + ln, cwd=work, stdout=subprocess.DEVNULL)
+                      for ln in (pairs if mode == "per-pair" else lines)]
                 if any(p.wait() != 0 for p in ps):
                     raise RuntimeError("reference daligner failed")
             res["%s -j%d" % (mode, nthr)] = time.time() - t0
@@ -212,7 +218,7 @@ def cpu_baseline(dbdir, root, nblocks, aligned_bp):
     bestk = min(res, key=res.get)
     best = res[bestk]
     nthr = int(bestk.split("-j")[1])
-    used = nthr * (len(lines) if bestk.startswith("concurrent") else 1)
+    used = nthr * (len(pairs) if bestk.startswith("per-pair") else len(lines) if bestk.startswith("concurrent") else 1)
     return {"value": aligned_bp / best, "unit": "aligned bp/s", "cores": min(used, cores), "kind": kind,
             "sample": "the whole plan of the step (%d lines, %d block pairs, every .las), daligner -k14: %s; best: %s; host has %d cores"
                       % (len(lines), nblocks * (nblocks + 1) // 2,
@@ -242,13 +248,48 @@ def end_to_end(dbdir, root, nblocks, md5_name, repeats=3, gpus=1):
                 best = dt
             if chk is None:
                 chk = check_against_reference(work, md5_name)
+            time.sleep(0.6)                               # a repeat is a COLD run: not beside the previous worker's teardown
         finally:
             shutil.rmtree(work, ignore_errors=True)
-    return {"value": None, "unit": "aligned bp/s", "wall_s": best,
-            "what": "damar_amd/bin/daligner -P <HPCdaligner plan>%s: process start, DB read from tmpfs, complement, "
-                    "upload, index builds, all block pairs, sorted .las on tmpfs (best of %d cold runs)"
-                    % (" -G%d (one forked worker per GPU, regions + stealing)" % gpus if gpus > 1 else "", repeats),
-            "identical_to_reference": None if chk is None else chk["identical"]}
+    extra = {}
+    if gpus == 1:
+        # The command returns when the last .las is closed; its forked worker then still releases HBM and tears the HIP
+        # context down (host/daligner.c: plan_main).  Two things show what that early return is worth and that it costs the
+        # NEXT command nothing: the same plan with DAMAR_PLAN_TIDY=1 (one process that releases everything before it
+        # exits), and two commands back to back (the second starts while the first one's worker is still tearing down).
+        def run_once(env_extra, n):
+            work = tempfile.mkdtemp(prefix="damar_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            try:
+                link_db(dbdir, root, work)
+                with open(os.path.join(work, "plan.txt"), "w") as f:
+                    f.write(plan_text(root, nblocks))
+                env = dict(os.environ, **env_extra)
+                t0 = time.time()
+                for _ in range(n):
+                    subprocess.run([exe, "-P", "plan.txt"], cwd=work, check=True, stdout=subprocess.DEVNULL, env=env)
+                dt = time.time() - t0
+                ok = check_against_reference(work, md5_name)["identical"]
+                return dt, ok
+            finally:
+                shutil.rmtree(work, ignore_errors=True)
+        time.sleep(1.0)                                   # (the last repeat's worker is gone)
+        try:
+            dt, ok = run_once({"DAMAR_PLAN_TIDY": "1"}, 1)
+            extra["tidy_wall_s"] = dt
+            time.sleep(0.5)
+            dt, ok2 = run_once({}, 2)
+            extra["back_to_back_wall_s"] = dt / 2
+            extra["back_to_back_identical"] = bool(ok and ok2)
+        except Exception as e:
+            extra["back_to_back_error"] = str(e)
+    out = {"value": None, "unit": "aligned bp/s", "wall_s": best,
+           "what": "damar_amd/bin/daligner -P <HPCdaligner plan>%s: process start, DB read from tmpfs, complement, "
+                   "upload, index builds, all block pairs, sorted .las on tmpfs (best of %d cold runs; tidy_wall_s = the same "
+                   "with the worker's teardown inside the command, back_to_back_wall_s = wall per command of two commands in a row)"
+                   % (" -G%d (one forked worker per GPU, regions + stealing)" % gpus if gpus > 1 else "", repeats),
+           "identical_to_reference": None if chk is None else chk["identical"]}
+    out.update(extra)
+    return out
 
 
 def trace_expand_leg(dbdir, root, out_dir, with_cpu):
@@ -562,8 +603,10 @@ def main():
                     shutil.rmtree(d, ignore_errors=True)
 
         tim, cnts, last_out, nmine, builds, nmatch, nlaunch = {}, [0, 0, 0], None, 0, 0, 0, 0
+        wave = [0, 0, 0]              # band cells, wave steps per alignment pass, wave-loop iterations (counted by the kernel)
         elapsed, last_out, plans, nmine = run_steps("s", args.steps, not pipelined)
         for plan in plans:
+            wave = [x + y for x, y in zip(wave, plan.wave)]
             builds += plan.index_builds
             nmatch += plan.matches
             nlaunch += plan.report_launches
@@ -585,12 +628,13 @@ def main():
             t = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            v = torch.tensor([tim.get(k, 0.) for k in tkeys] + [float(c) for c in cnts] +
+            v = torch.tensor([float(x) for x in wave] + [tim.get(k, 0.) for k in tkeys] + [float(c) for c in cnts] +
                              [float(nmatch), float(nlaunch), float(nmine), float(builds)], device=rdev, dtype=torch.float64)
             vmax = v.clone()
             dist.all_reduce(v, op=dist.ReduceOp.SUM)
             dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
             vals = [float(x) for x in v.tolist()]
+            wave, vals = vals[:3], vals[3:]
             tim = dict(zip(tkeys, vals[:len(tkeys)]))
             cnts = vals[len(tkeys):len(tkeys) + 3]
             nmatch, nlaunch, units_run, builds = vals[-4], vals[-3], vals[-2], vals[-1]
@@ -674,6 +718,13 @@ def main():
                     "valu_frac": carried("valu_frac"), "salu_frac": carried("salu_frac"),
                     "valu_busy_weighted": carried("valu_busy_weighted"),
                     "active_lane_frac": carried("active_lane_frac"),
+                    "lds_bank_conflict_frac": carried("lds_bank_conflict_frac"),
+                    # SURVEY 8(d)'s secondary unit of K6 (the reference's WAVE_STATS, align.c:81, 353-368), counted by the
+                    # kernel itself in this run: diagonals computed summed over all wave steps, per second of kernel time
+                    "band_cells_per_step": wave[0] / steps,
+                    "band_cells_per_s": (wave[0] / steps) / (dom_ms * 1e-3) if dom.startswith("report") and dom_ms > 0 else None,
+                    "wave_steps_per_step": wave[1] / steps,
+                    "halves_per_iteration": wave[1] / wave[2] if wave[2] else None,
                     "pmc_source": pmc.get("source") if mine else None, "pmc_file": pmc.get("file"), "pmc_head": pmc.get("head"),
                     "pmc_stale": not mine, "kernel_src_sha16": kernel_src_sha16(),
                     "pipeline": {"what": "SURVEY 8(d) algorithmic bytes of ALL stages of a step (index builds actually done, merge, seed "
@@ -724,14 +775,25 @@ def main():
                         legs[key] = fn()
                     except Exception as e:       # a leg is reported, never required
                         legs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            contract = None
+            if e2e is not None and e2e.get("wall_s"):
+                contract = {"what": "SURVEY 8(d)'s wall for the same plan: DB on tmpfs -> last .las closed, one cold `daligner -P` "
+                                    "command (process start, block reads, complement, PCIe, every index build, every block pair)",
+                            "value": e2e["value"], "unit": "aligned bp/s", "wall_s": e2e["wall_s"],
+                            "back_to_back_wall_s": e2e.get("back_to_back_wall_s"), "tidy_wall_s": e2e.get("tidy_wall_s"),
+                            "vs_cpu": e2e.get("vs_cpu_whole_plan")}
             line = {"metric": "aligned base-pairs/sec (daligner block-vs-block)",
                     "value": value, "unit": "aligned bp/s", "n_gpus": world, "steps": args.steps,
                     "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
                     "ms_per_step_synced": synced_ms,
-                    "timing": ("the %d steps back to back between one barrier + device sync on either side (one job, no drain "
-                               "between steps; every step builds its own indexes and writes its own files)" % steps) if pipelined else
-                              "every step on its own between barrier + device sync; the step times added up",
-                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                    "timing": (("the %d steps back to back between one barrier + device sync on either side (one job, no drain "
+                                "between steps; every step builds its own indexes and writes its own files)" % steps) if pipelined else
+                               "every step on its own between barrier + device sync; the step times added up") +
+                              "; `value` has the blocks already in HBM when the clock starts (block read, reverse complement and "
+                              "upload are NOT in it) -- the wall from the DB files on is `contract`",
+                    "contract": contract,
+                    "higher_is_better": True, "scaling": "strong",
+                    "vs_baseline": None,       # the reference publishes no number for this metric (vs the CPU: contract.vs_cpu)
                     "dtype": "int32", "data": "synthetic",
                     "config": {"workload": "%s -> %d blocks, %d block pairs x 2 orientations per step, daligner -k14 -w6 -h35 "
                                            "-e.70 -l1000 -s100" % (cfg["text"], nblocks, npairs),
@@ -754,6 +816,9 @@ def main():
             if one_gpu is not None:
                 line["one_gpu_same_workload"] = {"ms_per_step": 1e3 * one_gpu, "value": bp / one_gpu,
                                                  "speedup_of_this_run": (bp * args.steps / elapsed) / (bp / one_gpu)}
+                # the N = 1 line of a driver's scaling run is config 2: the like-for-like reference of THIS line is here
+                line["scale_ref"] = {"value": bp / one_gpu, "unit": "aligned bp/s", "n_gpus": 1,
+                                     "what": "the same database and plan on ONE GPU of this job (rank 0 alone, after the timed region)"}
             print(json.dumps(line))
             sys.stdout.flush()
         barrier()

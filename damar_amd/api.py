@@ -94,6 +94,7 @@ def _lib():
         L.damar_set_async.argtypes = [C.c_int]
         L.damar_async_totals.argtypes = [C.POINTER(c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.damar_async_counts.argtypes = [C.POINTER(c_int64), C.POINTER(C.c_double), C.POINTER(c_int64)]
+        L.damar_wave_totals.argtypes = [C.POINTER(c_int64)] * 3
         L.damar_write_overlaps.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.damar_tandem_set_params.argtypes = [C.c_int] * 4
         L.damar_tandem_set_params.restype = C.c_int

@@ -39,6 +39,8 @@
 #include <limits.h>
 #include <dirent.h>
 #include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
 
 #include "damar_filter.h"
 #include "damar_hip.h"
@@ -467,6 +469,15 @@ int main(int argc, char *argv[])
   return 0;
 }
 
+/* Plan mode and node mode fork their workers on the premise that this process has not touched the GPU yet.  Under
+   rocprofv3 (and anything else that preloads a tool library into the process) the HIP runtime is up before main(), and a
+   child of such a process must not use it: plan mode then runs in-process, node mode refuses. */
+static int profiler_preloaded(void)
+{ const char *t = getenv("ROCP_TOOL_LIBRARIES"), *p = getenv("LD_PRELOAD"), *h = getenv("HSA_TOOLS_LIB");
+  return (t != NULL && t[0] != 0) || (h != NULL && h[0] != 0) ||
+         (p != NULL && (strstr(p, "rocprof") != NULL || strstr(p, "roctracer") != NULL || strstr(p, "rocprofiler") != NULL));
+}
+
 /* ---------------------------------------------------------------------------------------------------
  * Plan mode: many `daligner` lines, one process, blocks and k-mer indexes resident (see the header).
  * The C mirror of damar_amd/driver.py's Plan on the device-resident entry points of damar_hip.h.
@@ -576,23 +587,32 @@ static uint64_t pblock_bytes(const PBlock *b)
 
 static void pblock_release(PBlock *b);
 
+static int PB_sharers = 1;          /* processes of this command on the same GPU (node mode with DAMAR_SHARE_GPU) */
+
 static void pblock_trim(void)
 { if (PB_budget == 0)
-    { uint64_t fr = 0, tot = 0;
+    { /* 55 % of the GPU -- of what is FREE when somebody else holds memory on it (the worker of the command before
+         this one may still be releasing its HBM: plan_main), and this process's share of it when the workers of a node
+         command sit on one GPU */
+      uint64_t fr = 0, tot = 0;
       damar_hbm_info(&fr, &tot);
-      PB_budget = (uint64_t) (.55 * (double) tot);
+      PB_budget = (uint64_t) (.55 * (double) (fr < tot ? fr : tot)) / (uint64_t) (PB_sharers > 0 ? PB_sharers : 1);
       if (getenv("DAMAR_PLAN_GB") != NULL && atof(getenv("DAMAR_PLAN_GB")) > 0)
         PB_budget = (uint64_t) (atof(getenv("DAMAR_PLAN_GB")) * 1073741824.);
     }
   for (;;)
     { uint64_t sum = 0;
       int i, v = -1;
+      pthread_mutex_lock(&PB_mu);                   /* (the reader threads set dev[] and ready under it) */
       for (i = 0; i < PB_n; i++)
         if (PB[i].ready && PB[i].name != NULL)
           { sum += pblock_bytes(PB + i);
-            if (!PB[i].busy && (PB[i].dev[0] || PB[i].dev[1] || PB[i].idx[0] || PB[i].idx[1]) && (v < 0 || PB[i].used < PB[v].used))
+            /* a victim is idle and has been used: a block the readers have just uploaded ahead of its first use stays */
+            if (!PB[i].busy && PB[i].used > 0 && (PB[i].dev[0] || PB[i].dev[1] || PB[i].idx[0] || PB[i].idx[1]) &&
+                (v < 0 || PB[i].used < PB[v].used))
               v = i;
           }
+      pthread_mutex_unlock(&PB_mu);
       if (sum <= PB_budget || v < 0)
         return;
       damar_async_drain();                          /* the host tail may still read its bases */
@@ -625,7 +645,7 @@ static PBlock *pblock_get(const char *name, const Opts *o)
   if (PB_n >= PB_max)                               /* replace the least recently used idle block */
     { int v = -1;
       for (i = 0; i < PB_n; i++)
-        if (!PB[i].busy && PB[i].ready && (v < 0 || PB[i].used < PB[v].used))
+        if (!PB[i].busy && PB[i].ready && PB[i].used > 0 && (v < 0 || PB[i].used < PB[v].used))
           v = i;
       if (v >= 0)
         { damar_async_drain();                      /* the host tail may still read its bases */
@@ -850,6 +870,11 @@ static int plan_main(const Opts *base, const char *planfile)
      landing buffers, tearing the HIP context down: a quarter of a second in the kernel driver -- changes nothing on disk
      and finishes behind the caller's back.  A child that dies before it is done is waited for and reported.
      DAMAR_PLAN_TIDY=1: one process that releases everything itself (debugging). */
+  if (getenv("DAMAR_PLAN_TIDY") == NULL && profiler_preloaded())
+    { fprintf(stderr, "daligner: a profiler is preloaded (the GPU runtime is up before main): running the plan in this "
+                      "process (DAMAR_PLAN_TIDY=1)\n");
+      setenv("DAMAR_PLAN_TIDY", "1", 1);
+    }
   if (getenv("DAMAR_PLAN_TIDY") == NULL)
     { int   pfd[2];
       pid_t pid;
@@ -1026,7 +1051,7 @@ typedef struct
 { atomic_int cursor[NODE_MAXW];          /* next unit of each region */
   int        first[NODE_MAXW], end[NODE_MAXW];
   int        nregions;
-  struct { int units, stolen, builds;  double wall_ms; } stat[NODE_MAXW];
+  struct { int units, stolen, builds, numa, cpus, tails, writers;  double wall_ms; } stat[NODE_MAXW];
   atomic_int done[NODE_MAXW];            /* the worker has closed its last file (what it does after that is teardown) */
 } NodeShared;
 
@@ -1197,7 +1222,82 @@ static void part_dir(char *out, size_t cap, const char *cwd, int a, int b, int p
 { snprintf(out, cap, "%s/_parts/%d.%d/p%dof%d", cwd, a, b, part, nparts); }
 
 /* one worker: its GPU, its own block table and index cache, units from the shared cursors */
-static int node_worker(int w, int gpu, const Opts *o, const char *stem, const Unit *units, NodeShared *S, const char *cwd)
+/* Host placement of one worker (one process per GPU on a node of 8).  Before the library creates its
+   streams, host threads and pinned landing buffers, the process is bound to the NUMA node its GPU hangs on: CPU affinity
+   of this thread (the threads started later inherit it) and a preferred-node memory policy (pinned buffers are faulted in
+   by the thread that allocates them).  The host tail's thread counts are cut to the worker's share of the host's cores:
+   at -G8 the defaults (4 tail + 2 writer threads per worker, plus readers) would be 64 unplaced threads. */
+static int cpulist_to_set(const char *text, cpu_set_t *set)
+{ int n = 0;
+  const char *p = text;
+  CPU_ZERO(set);
+  while (*p)
+    { char *e;
+      long a = strtol(p, &e, 10), b;
+      if (e == p)
+        break;
+      b = a;
+      if (*e == '-')
+        { p = e + 1;
+          b = strtol(p, &e, 10);
+        }
+      for (; a <= b; a++)
+        if (a >= 0 && a < CPU_SETSIZE)
+          { CPU_SET((int) a, set);  n += 1; }
+      p = (*e == ',') ? e + 1 : e;
+      if (*e != ',' )
+        break;
+    }
+  return n;
+}
+
+static void node_place(int w, int gpu, int nworkers, NodeShared *S)
+{ const int node = damar_hip_numa_node(gpu);
+  cpu_set_t cur;
+  int cores, tails, writers, bound = 0;
+  if (node >= 0 && getenv("DAMAR_NODE_NOBIND") == NULL)
+    { char path[96], text[4096];
+      FILE *f;
+      snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+      f = fopen(path, "r");
+      if (f != NULL)
+        { cpu_set_t set, both;
+          if (fgets(text, sizeof(text), f) != NULL && cpulist_to_set(text, &set) > 0 &&
+              sched_getaffinity(0, sizeof(cur), &cur) == 0)
+            { CPU_AND(&both, &set, &cur);             /* (never outside what the job was given) */
+              if (CPU_COUNT(&both) > 0 && sched_setaffinity(0, sizeof(both), &both) == 0)
+                bound = 1;
+            }
+          fclose(f);
+        }
+      if (node < 1024)
+        { unsigned long mask[16];
+          memset(mask, 0, sizeof(mask));
+          mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+          syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, (unsigned long) (8 * sizeof(mask)));
+        }
+    }
+  cores = (sched_getaffinity(0, sizeof(cur), &cur) == 0) ? CPU_COUNT(&cur) : 1;
+  if (!bound && nworkers > 1)                         /* no node to bind to: an even share of what the job has */
+    cores = cores / nworkers > 0 ? cores / nworkers : 1;
+  /* tail + writer threads within the worker's cores, leaving two for the launching thread and a reader */
+  tails = (cores - 2) / 2;    if (tails > 4) tails = 4;      if (tails < 1) tails = 1;
+  writers = (cores - 2) / 4;  if (writers > 2) writers = 2;  if (writers < 1) writers = 1;
+  { char v[16];
+    if (getenv("DAMAR_TAIL_THREADS") == NULL)
+      { snprintf(v, sizeof(v), "%d", tails);  setenv("DAMAR_TAIL_THREADS", v, 1); }
+    else
+      tails = atoi(getenv("DAMAR_TAIL_THREADS"));
+    if (getenv("DAMAR_WRITE_THREADS") == NULL)
+      { snprintf(v, sizeof(v), "%d", writers);  setenv("DAMAR_WRITE_THREADS", v, 1); }
+    else
+      writers = atoi(getenv("DAMAR_WRITE_THREADS"));
+  }
+  S->stat[w].numa = bound ? node : -1;  S->stat[w].cpus = cores;  S->stat[w].tails = tails;  S->stat[w].writers = writers;
+}
+
+static int node_worker(int w, int gpu, int nworkers, int sharers, const Opts *o, const char *stem, const Unit *units,
+                       NodeShared *S, const char *cwd)
 { Opts   ow = *o;
   int    r, nunits = 0, stolen = 0;
   double t0 = wall_ms();
@@ -1206,6 +1306,8 @@ static int node_worker(int w, int gpu, const Opts *o, const char *stem, const Un
     PB_max = atoi(getenv("DAMAR_PLAN_BLOCKS"));
   PB_cap = PB_max + LINE_B + 2;
   PB = (PBlock *) calloc((size_t) PB_cap, sizeof(PBlock));
+  PB_sharers = sharers;
+  node_place(w, gpu, nworkers, S);                  /* this worker's threads and pinned buffers next to its GPU */
   select_device(&ow);
   damar_set_async(1);
   pthread_mutex_lock(&PB_mu);
@@ -1282,6 +1384,15 @@ static int node_main(const Opts *base, const char *planfile)
       }
     if (W < 1)
       { fprintf(stderr, "daligner: -G wants a number of GPUs or a list of ordinals\n");
+        exit(1);
+      }
+    if ((strchr(g, ',') == NULL && atoi(g) > NODE_MAXW) || (strchr(g, ',') != NULL && W >= NODE_MAXW))
+      { fprintf(stderr, "daligner: -G: at most %d workers\n", NODE_MAXW);
+        exit(1);
+      }
+    if (profiler_preloaded())
+      { fprintf(stderr, "daligner: -G forks one worker per GPU, which a process with a preloaded profiler must not do: "
+                        "profile one worker's share with -P <plan> (it then runs in-process, as with DAMAR_PLAN_TIDY=1)\n");
         exit(1);
       }
     if (getenv("DAMAR_SHARE_GPU") != NULL && atoi(getenv("DAMAR_SHARE_GPU")) > 0)
@@ -1394,7 +1505,9 @@ static int node_main(const Opts *base, const char *planfile)
   else
     { /* too few pairs for the GPUs: single pairs from ONE cursor, cross pairs first, split by B-read range so that every
          worker gets about two pieces (multi.work_units) */
-      const int ncross = (2 * W + npairs - 1) / npairs, nsf = ncross / 2 > 1 ? ncross / 2 : 1;
+      const int nc_ = (2 * W + npairs - 1) / npairs, ncross = nc_ < NODE_MAXW ? nc_ : NODE_MAXW,     /* (the buffers of the
+                                                                                                      split-pair path hold NODE_MAXW parts) */
+                nsf = ncross / 2 > 1 ? ncross / 2 : 1;
       int a, b, p;
       for (a = NB_lo; a <= NB_hi; a++)
         for (b = NB_hi; b >= NB_lo; b--)
@@ -1437,7 +1550,10 @@ static int node_main(const Opts *base, const char *planfile)
           break;
         }
       if (pid[i] == 0)
-        { const int rc = node_worker(i, gpus[i], &o0, stem, units, S, cwd);
+        { int sh = 0, q;
+          for (q = 0; q < W; q++)
+            sh += (gpus[q] == gpus[i]);
+          const int rc = node_worker(i, gpus[i], W, sh, &o0, stem, units, S, cwd);
           fflush(NULL);
           exit(rc);
         }
@@ -1534,8 +1650,16 @@ static int node_main(const Opts *base, const char *planfile)
   if (o0.verbose || getenv("DAMAR_CLIPROF"))
     { fprintf(stderr, "daligner: %d block pairs, %d units, %d GPU worker(s), %.2f s:", npairs, nunits, W, (wall_ms() - t0) * 1e-3);
       for (i = 0; i < W; i++)
-        fprintf(stderr, " [gpu %d: %d units (%d stolen), %d index builds, %.2f s]", gpus[i], S->stat[i].units, S->stat[i].stolen,
-                S->stat[i].builds, S->stat[i].wall_ms * 1e-3);
+        fprintf(stderr, " [gpu %d: %d units (%d stolen), %d index builds, %.2f s busy, numa %d, %d cpus, %d+%d tail/write threads]",
+                gpus[i], S->stat[i].units, S->stat[i].stolen, S->stat[i].builds, S->stat[i].wall_ms * 1e-3, S->stat[i].numa,
+                S->stat[i].cpus, S->stat[i].tails, S->stat[i].writers);
+      { double mx = 0, sum = 0;
+        for (i = 0; i < W; i++)
+          { sum += S->stat[i].wall_ms;
+            if (S->stat[i].wall_ms > mx) mx = S->stat[i].wall_ms;
+          }
+        fprintf(stderr, " busy max/mean %.3f", sum > 0 ? mx * W / sum : 0.);
+      }
       fprintf(stderr, "\n");
     }
   return ok ? 0 : 1;

@@ -199,6 +199,9 @@ typedef struct
    the launch (waiting for the longest alignment) is paid once per launch, not once per comparison. */
 #define DAMAR_MAX_JOBS 32
 #define DAMAR_MAX_TSPACE 8192     /* consecutive pebbles of a chain then differ by < 2^15 diagonals and < 2^16 waves */
+#define DAMAR_CNT_CELLS     8     /* counters[8..9]   (64 bits): band cells of the launch's wave steps (packed kernel) */
+#define DAMAR_CNT_HALFSTEPS 10    /* counters[10..11] (64 bits): wave steps, counted per half-wavefront (= per alignment pass)   */
+#define DAMAR_CNT_ITERS     12    /* counters[12..13] (64 bits): iterations of the wave loop (each steps one or two halves)      */
 #define DAMAR_CNT_CURSOR  16      /* counters[16 + job]: next work item of a job  */
 #define DAMAR_CNT_NFILT   (DAMAR_CNT_CURSOR + DAMAR_MAX_JOBS)      /* counters[.. + job]: its seed hits */
 #define DAMAR_COUNTER_WORDS (DAMAR_CNT_NFILT + DAMAR_MAX_JOBS)

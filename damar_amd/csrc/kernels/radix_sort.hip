@@ -25,6 +25,7 @@
  * has not started.  Every spin is bounded; a timeout raises the error word that the host checks.
  * 32-bit granules serve sorts of fewer than 2^30 items, 64-bit ones the rest.
  */
+#include <atomic>
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -382,14 +383,21 @@ static void onesweep_passes(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lob
       if ((nt + grid - 1) / grid > maxit)
         grid = (nt + maxit - 1) / maxit;
       const size_t lds = (size_t) npass * 128 * 32 * sizeof(u32);
-      static bool big_lds = false;
-      if (!big_lds)                                                   /* up to 128 KB of dynamic LDS (8 digit places) */
-        { HIP_CHECK(hipFuncSetAttribute((const void *) onesweep_hist<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
-          HIP_CHECK(hipFuncSetAttribute((const void *) onesweep_hist<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
-          big_lds = true;
-        }
+      { /* up to 128 KB of dynamic LDS (8 digit places): a function attribute is kept per DEVICE, so it is set once for
+           every ordinal a thread of this process sorts on (the library itself is one GPU per process) */
+        static std::atomic<unsigned long long> big_lds(0ull);
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(big_lds.load(std::memory_order_acquire) & bit))
+          { HIP_CHECK(hipFuncSetAttribute((const void *) onesweep_hist<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+            HIP_CHECK(hipFuncSetAttribute((const void *) onesweep_hist<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+            big_lds.fetch_or(bit, std::memory_order_release);
+          }
+      }
       hipLaunchKernelGGL(onesweep_hist<KeyT>, dim3((u32) grid), dim3(OH_THREADS), lds, st,
                          k0, n, lobit, npass, (1u << lastb) - 1u, ghist, (uint4 *) lbr[0], (u64) (region / 16));
+      HIP_CHECK(hipGetLastError());
     }
   else
     { const u64 nt = (n + 256 * OH_ITEMS - 1) / (256 * OH_ITEMS);

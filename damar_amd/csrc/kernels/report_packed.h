@@ -107,6 +107,9 @@ struct DuoCtx
   /* the task and what its passes have produced */
   int diag, anti;
   int aepos, bepos, abpos, bbpos, diffs, atlen, btlen, aback, bback;
+  /* what the wavefront has stepped through so far (the same in every lane): SURVEY 8(d)'s secondary unit of K6 */
+  u64 n_cells;                                  /* band cells = diagonals computed, summed over the wave steps */
+  u32 n_iter, n_half;                           /* iterations of the wave loop, and halves that stepped in them */
 };
 
 struct DuoSnake { int Y, na, nb;  u64 b; };
@@ -334,9 +337,7 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase, DuoCtx *cx)
   int lasta = cx->lasta, more = cx->more, ncell = cx->ncell, mlo = cx->mlo, mhi = cx->mhi;
   int rV = cx->V, rHA = cx->HA, rHB = cx->HB;
   u64 rT = ((u64) cx->Thi << 32) | cx->Tlo;
-#ifdef DAMAR_PROF
-  unsigned long long pf_iters = 0, pf_half = 0, pf_cells = 0;
-#endif
+  u32 st_iter = 0, st_cells = 0;                /* (scalar: one s_bcnt1 + two s_add per step) */
   if (!onm)
     return;
 
@@ -358,11 +359,7 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase, DuoCtx *cx)
       }
       u64 gom;
       do
-        {
-#ifdef DAMAR_PROF
-          pf_iters += 1;  pf_half += (unsigned long long) __popcll(onm) >> 5;
-#endif
-          /* widen (align.c:675-776) and pick the predecessor (align.c:793-825): K - 1 sits one lane up, K + 1 one lane down */
+        { /* widen (align.c:675-776) and pick the predecessor (align.c:793-825): K - 1 sits one lane up, K + 1 one lane down */
           const int K = kbase - s;
           u64  actm;
           int  v, ha, hb_;
@@ -382,9 +379,7 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase, DuoCtx *cx)
             const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
             b = ((u64) thi << 32) | tlo;
             ls = nls;  hs = nhs;  dif += 1;
-#ifdef DAMAR_PROF
-            pf_cells += (unsigned long long) __popcll(actm);
-#endif
+            st_iter += 1;  st_cells += (u32) __popcll(actm);
           }
 
           int Y = 0, na = 1, nb = 1;
@@ -499,9 +494,7 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase, DuoCtx *cx)
       if (onm & ~(gom & bal(hs - ls <= 27) & bal(ncell <= cell_cap)))
         break;
     }
-#ifdef DAMAR_PROF
-  PROF_ADD(26, pf_iters);  PROF_ADD(27, pf_half);  PROF_ADD(29, 1);  PROF_ADD(30, pf_cells);
-#endif
+  cx->n_cells += st_cells;  cx->n_iter += st_iter;  cx->n_half += st_iter * ((u32) __popcll(onm) >> 5);
   if (on)
     { cx->V = rV;  cx->HA = rHA;  cx->HB = rHB;  cx->Tlo = (u32) rT;  cx->Thi = (u32) (rT >> 32);
       cx->ls = ls;  cx->hs = hs;  cx->kbase = kbase;  cx->dif = dif;  cx->besta = besta;  cx->bestk = bestk;
@@ -780,6 +773,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
   cx.mlo = cx.mhi = 0;  cx.alim = cx.blim = 0;  cx.offa = cx.offb = 0;  cx.pa0 = cx.pb0 = 0;
   cx.diag = cx.anti = 0;
   cx.aepos = cx.bepos = cx.abpos = cx.bbpos = cx.diffs = cx.atlen = cx.btlen = cx.aback = cx.bback = 0;
+  cx.n_cells = 0;  cx.n_iter = cx.n_half = 0;
 
   for (;;)
     { /* A: the halves without an alignment in hand advance their scan until they have one or have run out of work */
@@ -1002,6 +996,11 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
         }
       if (!wany(cx.md != MD_DONE))
         break;
+    }
+  if (lane == 0)
+    { atomicAdd((unsigned long long *) &a.counters[DAMAR_CNT_CELLS], (unsigned long long) cx.n_cells);
+      atomicAdd((unsigned long long *) &a.counters[DAMAR_CNT_HALFSTEPS], (unsigned long long) cx.n_half);
+      atomicAdd((unsigned long long *) &a.counters[DAMAR_CNT_ITERS], (unsigned long long) cx.n_iter);
     }
 }
 

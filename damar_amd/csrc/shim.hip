@@ -21,6 +21,7 @@
 #include <unistd.h>
 
 #include "kernels/dev_common.h"
+#include <ctype.h>
 #include "kernels/kernels.h"
 
 extern "C" {
@@ -199,6 +200,29 @@ static void *arena_take(Arena *a, size_t n)
 static size_t pad256(size_t n) { return (n + 511) & ~(size_t) 255; }
 
 static int G_device = 0;      /* the device of this process; threads that touch HIP select it first */
+
+/* NUMA node of the host memory next to GPU `device` (its PCI function's numa_node in sysfs), or -1 when the host says
+   nothing.  Makes the HIP runtime start but allocates nothing: a node worker calls it BEFORE damar_hip_init, binds its
+   threads and its memory policy to that node, and only then lets the library create streams and pinned landing buffers. */
+extern "C" int damar_hip_numa_node(int device)
+{ int ndev = 0;
+  char bus[64] = "", path[160];
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return -1;
+  if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus), device) != hipSuccess || bus[0] == 0)
+    return -1;
+  for (char *c = bus; *c; c++)
+    *c = (char) tolower(*c);
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+  FILE *f = fopen(path, "r");
+  int node = -1;
+  if (f != NULL)
+    { if (fscanf(f, "%d", &node) != 1)
+        node = -1;
+      fclose(f);
+    }
+  return node;
+}
 
 extern "C" int damar_hip_init(int device)
 { int ndev = 0;
@@ -1859,6 +1883,7 @@ static Accum &AC = *new Accum();
 
 
 static int64   A_nfilt = 0;                        /* totals of the asynchronous mode (damar_async_counts) */
+static int64   W_tot[3] = { 0, 0, 0 };             /* band cells, wave steps per pass, wave-loop iterations (damar_wave_totals) */
 static double  A_report_ms = 0;
 static int64   A_launches = 0;
 
@@ -1977,6 +2002,11 @@ static void report_finish(Pending &pd)
       G_ms[DAMAR_T_D2H] += lap(18 + 4 * pd.oset, 19 + 4 * pd.oset);
     }
   G_cnt[3] += hc[1];  G_cnt[4] += hc[2];
+  { std::lock_guard<std::mutex> lk(A_mu);
+    W_tot[0] += (int64) (((u64) hc[DAMAR_CNT_CELLS + 1] << 32) | hc[DAMAR_CNT_CELLS]);
+    W_tot[1] += (int64) (((u64) hc[DAMAR_CNT_HALFSTEPS + 1] << 32) | hc[DAMAR_CNT_HALFSTEPS]);
+    W_tot[2] += (int64) (((u64) hc[DAMAR_CNT_ITERS + 1] << 32) | hc[DAMAR_CNT_ITERS]);
+  }
   const double h4 = now_ms();
   for (int j = 0; j < n; j++)
     { const damar_match_job &jb = pd.job[j];
@@ -2090,6 +2120,18 @@ extern "C" void damar_write_overlaps(Align_Spec *spec, const char *d1, const cha
           }
     }
   async_submit(job);
+}
+
+/* SURVEY 8(d)'s secondary unit of K6, counted by the packed report kernel itself (scalar adds in its wave loop): band
+   cells (diagonals computed, summed over all wave steps), wave steps counted per alignment pass (= per half-wavefront),
+   and iterations of the wave loop (each steps one or two halves) -- totals since the last call (drains first) */
+extern "C" void damar_wave_totals(int64 *cells, int64 *half_steps, int64 *iterations)
+{ damar_async_drain();
+  std::lock_guard<std::mutex> lk(A_mu);
+  if (cells)      *cells = W_tot[0];
+  if (half_steps) *half_steps = W_tot[1];
+  if (iterations) *iterations = W_tot[2];
+  W_tot[0] = W_tot[1] = W_tot[2] = 0;
 }
 
 /* totals of the asynchronous mode since the last call (drains first): seed hits (what damar_match's counts[1] reports in

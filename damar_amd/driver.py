@@ -125,6 +125,7 @@ class Plan:
         self.index_builds = 0
         self.matches = 0             # comparisons (block pair x orientation) run
         self.report_launches = 0     # launches of the report kernel they took
+        self.wave = [0, 0, 0]        # band cells, wave steps per alignment pass, wave-loop iterations (damar_wave_totals)
         L.damar_set_async(1 if async_tail else 0)
 
     def finish(self):
@@ -142,6 +143,9 @@ class Plan:
             self.timings["tail"] = self.timings.get("tail", 0.) + t.value
             self.timings["write"] = self.timings.get("write", 0.) + w.value
             self.timings["d2h"] = self.timings.get("d2h", 0.) + L.damar_async_d2h_ms()
+        wc, wh, wi = api.c_int64(0), api.c_int64(0), api.c_int64(0)
+        L.damar_wave_totals(C.byref(wc), C.byref(wh), C.byref(wi))
+        self.wave = [self.wave[0] + wc.value, self.wave[1] + wh.value, self.wave[2] + wi.value]
         for sp in self._specs:
             L.Free_Align_Spec(sp)
         self._specs = []

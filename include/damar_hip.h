@@ -30,6 +30,9 @@ extern "C" {
  * visible devices.  Called implicitly with device 0 (or $DAMAR_DEVICE) on first use.
  * Exits with a message if no HIP device is present: there is no CPU fallback. */
 int   damar_hip_init(int device);
+/* NUMA node of the host memory next to GPU `device`, or -1 if the host does not say (callable before damar_hip_init:
+ * the node scheduler binds a worker's threads and memory policy to it first, host/daligner.c: node_worker) */
+int   damar_hip_numa_node(int device);
 const char *damar_hip_device_name(void);
 void  damar_hip_sync(void);          /* hipDeviceSynchronize on the selected GPU */
 /* Grow (and release again) the process's HBM footprint by `gigabytes`: a cold process pays ~25 ms per GB the first
@@ -105,6 +108,11 @@ void damar_async_totals(int64 *ncheck, double *tail_ms, double *write_ms);
  * report kernel's milliseconds and launches. */
 void damar_async_counts(int64 *seed_hits, double *report_ms, int64 *launches);
 double damar_async_d2h_ms(void);        /* time of the asynchronous record downloads since the last call */
+/* What the Local_Alignment waves (align.c:409-1898) of the report launches stepped through since the last call (drains
+ * first): band cells = sum over all wave steps of the diagonals computed (the reference's WAVE_STATS unit, align.c:81,
+ * 353-368), wave steps counted per alignment pass, and iterations of the kernel's wave loop (each steps one or two passes:
+ * half_steps / iterations of 2 means no idle half-wavefront). */
+void damar_wave_totals(int64 *cells, int64 *half_steps, int64 *iterations);
 /* Write_Overlap_Buffer + Reset_Overlap_Buffer (daligner.c:1020-1021), queued in async mode */
 void damar_write_overlaps(Align_Spec *spec, const char *dirName1, const char *dirName2,
                           const char *ablock, const char *bblock, int lastRead);

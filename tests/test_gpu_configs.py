@@ -103,7 +103,7 @@ def test_gpu_config4_sample_of_8_block_pairs_among_first_24_blocks_equal_referen
     assert plan.counts[2] > 10000          # (0.3x coverage per block: few overlaps per block pair)
 
 
-@pytest.mark.skipif(not os.environ.get("DAMAR_C4_FULL"), reason="needs the whole 19.8 Gbp database (2.7 min of simdb): DAMAR_C4_FULL=1")
+@pytest.mark.skipif(bool(os.environ.get("DAMAR_C4_SKIP")), reason="DAMAR_C4_SKIP set (the whole 19.8 Gbp database: about 100 s)")
 def test_gpu_config4_sample_of_8_block_pairs_of_all_255_blocks_equal_reference(gpu):
     import shutil
     import tempfile
@@ -344,8 +344,12 @@ def test_gpu_cli_node_mode_two_workers_sharing_the_gpu_equals_reference_golden(g
 
 
 def test_gpu_cli_node_mode_config3_regions_and_stealing_equal_reference(gpu, tmp_path):
-    """Config 3 (17 blocks, 153 block pairs) through `daligner -P plan -G3` with the three workers sharing GPU 0: one region
-    of the plan's triangle per worker, cursors in the shared page, leftovers stolen; all 289 files against the reference's md5s."""
+    """Config 3 (17 blocks, 153 block pairs) through `daligner -P plan -G5` with the five workers sharing GPU 0 (a rehearsal
+    of a node of GPUs within the box's limit of six processes on its card): one region of the plan's triangle per worker,
+    cursors in the shared page, leftovers stolen; all 289 files against the reference's md5s; the workers' busy times (start
+    to last file closed) within 10 % of their mean; every worker placed (NUMA node or -1, its share of the cores, its thread
+    counts) and logged with its units and index builds."""
+    import re
     import subprocess
     from damar_amd import api
     d = str(tmp_path)
@@ -354,10 +358,17 @@ def test_gpu_cli_node_mode_config3_regions_and_stealing_equal_reference(gpu, tmp
     with open(os.path.join(d, "plan.txt"), "w") as f:
         for a in range(1, nb + 1):
             f.write("daligner -k14 -j16 SIM.%d %s\n" % (a, " ".join("SIM.%d" % b for b in range(a, 0, -1))))
-    r = subprocess.run([api.daligner_binary(), "-v", "-P", "plan.txt", "-G3"], cwd=d, env=dict(os.environ, DAMAR_SHARE_GPU="1"),
+    r = subprocess.run([api.daligner_binary(), "-v", "-P", "plan.txt", "-G5"], cwd=d, env=dict(os.environ, DAMAR_SHARE_GPU="1"),
                        stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "153 block pairs" in r.stderr
+    line = [ln for ln in r.stderr.splitlines() if "block pairs," in ln and "GPU worker" in ln][-1]
+    print(line)
+    workers = re.findall(r"\[gpu (\d+): (\d+) units \((\d+) stolen\), (\d+) index builds, ([\d.]+) s busy, numa (-?\d+), (\d+) cpus, "
+                         r"(\d+)\+(\d+) tail/write threads\]", line)
+    assert len(workers) == 5 and all(int(w[1]) > 0 and int(w[3]) > 0 for w in workers), line
+    assert all(int(w[6]) >= 1 and 1 <= int(w[7]) <= 4 and 1 <= int(w[8]) <= 2 for w in workers), line
+    assert float(re.search(r"busy max/mean ([\d.]+)", line).group(1)) <= 1.10, line
     bad = []
     for ln in open(os.path.join(GOLDEN, "config3_ref_md5.txt")):
         if ln.startswith("#"):

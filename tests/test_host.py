@@ -313,5 +313,7 @@ def test_node_scheduler_work_list_covers_every_block_pair_once(built, tmp_path, 
     npairs = nb * (nb + 1) // 2
     if npairs >= 2 * ngpu:
         assert len(cost) == ngpu and max(cost.values()) <= 1.35 * min(cost.values())
+        if nb >= 200:          # config 4's plan on a node of 8: the regions of the triangle cost the same within 5 %
+            assert max(cost.values()) * len(cost) <= 1.05 * sum(cost.values()), cost
     else:
         assert len(cost) == 1 and max(n for v in pairs.values() for _, n in v) > 1
