@@ -48,6 +48,7 @@ CASES = {
     "indel":   dict(derive="indel", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "noisy":   dict(derive="noisy", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "tandem":  dict(derive="tandem", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
+    "tandem2": dict(derive="tandem2", opts=["-k14", "-j4"], plan=[("1", ["1"])], md5_only=True),      # (a 9.9 MB .las)
     "fusion":  dict(derive="fusion32", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "fusion2": dict(derive="fusion31", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     # mask tracks (-m): a DBdust track made by the reference's own DBdust on reads with
@@ -109,20 +110,25 @@ def derive(kind, work):
     rng = random.Random(12345)
     base = os.path.join(work, "base")
     os.makedirs(base)
-    if kind == "tandem":
+    if kind in ("tandem", "tandem2"):
+        # tandem2: the genome of SURVEY App. E at its full size (13 spacers of 25 kb, 12 arrays, 20x): the reference
+        # bridged 456 + 372 times on its like; "tandem" is the small version (6 arrays, 14x)
+        big = kind == "tandem2"
+        if big:
+            rng = random.Random(424242)
         units = [40, 75, 120, 200, 350]
         genome = ""
-        for i in range(6):
-            genome += rnd_seq(rng, 12000)
+        for i in range(12 if big else 6):
+            genome += rnd_seq(rng, 25000 if big else 12000)
             u = rnd_seq(rng, units[i % 5])
-            for c in range(rng.choice([8, 12, 20])):
+            for c in range(rng.choice([8, 12, 20, 30] if big else [8, 12, 20])):
                 genome += "".join(ch if rng.random() > .03 else rng.choice("acgt") for ch in u)
-        genome += rnd_seq(rng, 12000)
+        genome += rnd_seq(rng, 25000 if big else 12000)
         reads = []
         tot = 0
         comp = {"a": "t", "c": "g", "g": "c", "t": "a"}
-        while tot < 14 * len(genome):
-            ln = max(3000, int(rng.gauss(7000, 1500)))
+        while tot < (20 if big else 14) * len(genome):
+            ln = max(4000, int(rng.gauss(10000, 2000))) if big else max(3000, int(rng.gauss(7000, 1500)))
             ln = min(ln, len(genome))
             st = rng.randrange(0, len(genome) - ln + 1)
             out = []
@@ -473,8 +479,13 @@ def main():
                 for f in fs:
                     if f.endswith(".las"):
                         rel = os.path.relpath(os.path.join(dp, f), rdir)
-                        os.makedirs(os.path.join(out, "las", os.path.dirname(rel)), exist_ok=True)
-                        shutil.copy(os.path.join(dp, f), os.path.join(out, "las", rel))
+                        if c.get("md5_only"):
+                            import hashlib
+                            with open(os.path.join(out, "las.md5"), "a") as g:
+                                g.write("%s %s\n" % (hashlib.md5(open(os.path.join(dp, f), "rb").read()).hexdigest(), rel))
+                        else:
+                            os.makedirs(os.path.join(out, "las", os.path.dirname(rel)), exist_ok=True)
+                            shutil.copy(os.path.join(dp, f), os.path.join(out, "las", rel))
                         n += 1
             with open(os.path.join(out, "case.txt"), "w") as f:
                 f.write("db %s\nopts %s\ntool %s\n" % (c.get("db", name), " ".join(c["opts"]), c.get("tool", "daligner")))

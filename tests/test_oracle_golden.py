@@ -20,6 +20,19 @@ def test_oracle_matches_reference_las(built, tmp_path, name):
     assert compare_las(case, str(tmp_path)) == []
 
 
+@pytest.mark.parametrize("name", ["tandem", "tandem2", "tan_O", "fusion", "fusion2", "indel", "noisy", "prod", "tiny_s"])
+def test_product_host_tail_behind_the_oracle_front_matches_reference_las(built, tmp_path, name):
+    """The PRODUCT's bridge realignment (damar_amd/csrc/host/bridge.c, written from the algorithm; the oracle has its own
+    reference-shaped oracle/bridge.c) behind the oracle's CPU front: the cases with Bridge / Fusion / multi-record pairs
+    against the reference's files, where there is no GPU (oracle/oracle_daligner_hosttail, oracle/Makefile)."""
+    exe = os.path.join(ROOT, "oracle", "oracle_daligner_hosttail")
+    case = read_case(name)
+    if case.get("tool", "daligner") != "daligner":
+        pytest.skip("a datander case: no bridges there (scrub/tandem.c:767-850)")
+    run_cli(exe, case, str(tmp_path))
+    assert compare_las(case, str(tmp_path)) == []
+
+
 def test_golden_cases_present():
     names = golden_cases()
     for need in ("tiny2", "tiny_j1", "tiny_s", "tiny_t", "tiny_I", "tiny_A", "tiny_k12", "indel", "noisy", "tandem", "fusion", "fusion2"):
