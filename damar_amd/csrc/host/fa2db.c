@@ -6,17 +6,20 @@
  * 154-300 tracks; fileUtils.c:8-46 isPacBioHeader) -- except for the fields of the .idx header that the
  * reference leaves uninitialised, which are zero here.
  *
- *     FA2db [-v] [-a] [-b] [-x<int(1000)>] <path:db> (-f<file of fasta names> | <input:fasta> ...)
+ *     FA2db [-v] [-a] [-b] [-Q] [-c<track>]... [-x<int(1000)>] <path:db> (-f<file of fasta names> | <input:fasta> ...)
  *
  * Built: creating a database from .fasta / .fa files and adding files to an existing one (its block
- * partition is extended, FA2db.c:908-975; -a starts a new block), -b (longest read of a well), -x, -f.  Not built
- * (rejected with a message): -Q, -c.  Host code, C, no GPU.
+ * partition is extended, FA2db.c:908-975; -a starts a new block), -b (longest read of a well), -x, -f, -c (header
+ * arguments NAME=v1,v2,... of the reads become tracks .<path>.NAME.{anno,data}: FA2db.c:169-355 parse_header, :638-643)
+ * and -Q (only reads whose readType argument -- named with -c -- says FullHqRead: FA2db.c:809-837).  Host code, C, no GPU.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <strings.h>
+#include <dirent.h>
 
 #include "damar_db.h"
 
@@ -33,6 +36,115 @@ typedef struct
 static Track T_seq = { "seqID", NULL, 0, NULL, 0, 0 }, T_pac = { "pacbio", NULL, 0, NULL, 0, 0 };
 static int   T_pac_used = 0;
 
+/* -c: tracks made of header arguments, created when a value (or, adding to a database, an .anno file) first names them */
+static Track **T_hdr = NULL;
+static int     T_nhdr = 0;
+static char  **C_name = NULL;                 /* the names given with -c */
+static int     C_n = 0;
+
+static Track *hdr_track(const char *name)
+{ int i;
+  for (i = 0; i < T_nhdr; i++)
+    if (strcmp(T_hdr[i]->name, name) == 0)
+      return T_hdr[i];
+  T_hdr = (Track **) realloc(T_hdr, sizeof(Track *) * (size_t) (T_nhdr + 1));
+  T_hdr[T_nhdr] = (Track *) calloc(1, sizeof(Track));
+  T_hdr[T_nhdr]->name = strdup(name);
+  return T_hdr[T_nhdr++];
+}
+
+/* the header arguments of one read that -c asked for (FA2db.c:197-355) */
+typedef struct { char *name;  int nval, vmax;  int *val; } HdrArg;
+typedef struct { HdrArg *arg;  int n, max; } HdrArgs;
+
+static void hdr_arg_value(HdrArg *a, int v)
+{ if (a->nval >= a->vmax)
+    { a->vmax = a->vmax * 2 + 16;
+      a->val = (int *) realloc(a->val, sizeof(int) * (size_t) a->vmax);
+    }
+  a->val[a->nval++] = v;
+}
+
+/* `text` = what follows the read name in a header line: arguments NAME=v[,v...] separated by single blanks.  Arguments
+   whose name was not given with -c are skipped; a name must be letters, digits and '_' up to the '='; values are decimal
+   integers ("RQ=0.851" reads as 851; the characters of a "chemistry" argument are its values, up to the first comma). */
+static void parse_header_args(const char *text, HdrArgs *h)
+{ const char *c = text;
+  h->n = 0;
+  while (*c != '\0' && *c != '\n')
+    { const char *name = c;
+      size_t nlen;
+      int i, wanted = 0;
+      while ((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || *c == '_')
+        c++;
+      if (*c != '=')
+        { fprintf(stderr, "malformed track name: '%s'\n", c);
+          exit(1);
+        }
+      nlen = (size_t) (c - name);
+      for (i = 0; i < C_n; i++)
+        if (strlen(C_name[i]) == nlen && strncmp(C_name[i], name, nlen) == 0)
+          wanted = 1;
+      if (!wanted)
+        { c++;
+          while (*c != '\0' && *c != '\n' && *c != ' ')
+            c++;
+          if (*c != ' ')
+            break;
+          c++;
+          continue;
+        }
+      if (h->n >= h->max)
+        { const int old = h->max;
+          h->max = h->max * 2 + 8;
+          h->arg = (HdrArg *) realloc(h->arg, sizeof(HdrArg) * (size_t) h->max);
+          memset(h->arg + old, 0, sizeof(HdrArg) * (size_t) (h->max - old));
+        }
+      { HdrArg *a = h->arg + h->n++;
+        int more, blank;
+        free(a->name);
+        a->name = strndup(name, nlen);
+        a->nval = 0;
+        do
+          { const char *v;
+            c++;                                    /* past '=' or ',' */
+            if (strcmp(a->name, "RQ") == 0 && strncasecmp(c, "0.", 2) == 0)
+              c += 2;
+            v = c;
+            while (*c != '\0' && *c != '\n' && *c != ' ' && *c != ',')
+              c++;
+            more = (*c == ',');
+            blank = (*c == ' ');
+            if (strcmp(a->name, "chemistry") == 0)
+              { const char *q;
+                for (q = v; q < c; q++)
+                  hdr_arg_value(a, (int) *q);
+                if (more)                             /* (what follows the first comma goes with the rest of the line) */
+                  return;
+                break;
+              }
+            { char  num[64], *end;
+              size_t l = (size_t) (c - v);
+              long   val;
+              if (l >= sizeof(num)) l = sizeof(num) - 1;
+              memcpy(num, v, l);
+              num[l] = '\0';
+              val = strtol(num, &end, 10);
+              if (*end != '\0')
+                { printf("non-numeric value %s\n", num);
+                  exit(1);
+                }
+              hdr_arg_value(a, (int) val);
+            }
+          }
+        while (more);
+        if (!blank)
+          break;
+        c++;
+      }
+    }
+}
+
 static void track_add(Track *t, int64 read, int value)                   /* FA2x.c:63-94 */
 { if (read >= t->amax)
     { int64 n = (int64) (read * 1.2 + 1000);
@@ -44,7 +156,7 @@ static void track_add(Track *t, int64 read, int value)                   /* FA2x
     { t->dmax = (int64) (t->dtop * 1.2 + 1000);
       t->data = (int *) realloc(t->data, sizeof(int) * (size_t) t->dmax);
     }
-  t->anno[read] += sizeof(int);
+  t->anno[read] += (strcmp(t->name, "chemistry") == 0) ? sizeof(char) : sizeof(int);      /* FA2x.c:83-90: characters */
   t->data[t->dtop++] = value;
 }
 
@@ -101,7 +213,13 @@ static void track_write(Track *t, const char *dir, const char *root, int first, 
   snprintf(path, sizeof(path), "%s/.%s.%s.data", dir, root, t->name);
   if ((f = fopen(path, "a")) == NULL)
     return;
-  fwrite(t->data, sizeof(int), (size_t) t->dtop, f);
+  if (strcmp(t->name, "chemistry") == 0)              /* FA2x.c:272-281: its values go out as characters */
+    { int64 v;
+      for (v = 0; v < t->dtop; v++)
+        fputc((char) t->data[v], f);
+    }
+  else
+    fwrite(t->data, sizeof(int), (size_t) t->dtop, f);
   fclose(f);
 }
 
@@ -136,10 +254,10 @@ static const char *base_name(const char *path)
 typedef struct
 { FILE *idx, *bps, *stub;
   int64 off, totlen, count[4];
-  int   ureads, maxlen, minlen, verbose, nadded, best;
+  int   ureads, maxlen, minlen, verbose, nadded, best, fullhq;
 } Out;
 
-static void add_read(Out *o, char *seq, int len, int seqid, int pac, int well, int beg, int end)   /* FA2db.c:611-651 */
+static void add_read(Out *o, char *seq, int len, int seqid, int pac, int well, int beg, int end, const HdrArgs *ha)   /* FA2db.c:611-651 */
 { static unsigned char *buf = NULL;
   static int bmax = 0;
   int clen = (len + 3) >> 2, i;
@@ -175,11 +293,26 @@ static void add_read(Out *o, char *seq, int len, int seqid, int pac, int well, i
       track_add(&T_pac, o->ureads, end);
       T_pac_used = 1;
     }
+  if (ha != NULL)
+    { int a, v;
+      for (a = 0; a < ha->n; a++)
+        for (v = 0; v < ha->arg[a].nval; v++)
+          track_add(hdr_track(ha->arg[a].name), o->ureads, ha->arg[a].val[v]);
+    }
   o->off    += clen;
   o->ureads += 1;
   o->totlen += len;
   if (len > o->maxlen)
     o->maxlen = len;
+}
+
+/* -Q: the read carries exactly one readType value and it is FullHqRead0 / FullHqRead1 (1, 2) */
+static int full_hq_read(const HdrArgs *h)
+{ int i;
+  for (i = 0; i < h->n; i++)
+    if (strcmp(h->arg[i].name, "readType") == 0)
+      return h->arg[i].nval == 1 && (h->arg[i].val[0] == 1 || h->arg[i].val[0] == 2);
+  return 0;
 }
 
 static void read_fasta(Out *o, const char *name)                          /* FA2db.c:652-905 */
@@ -191,6 +324,8 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
   int    cnt[2] = { -1, -1 }, nxt = 0;
   char  *bseq = NULL;                                 /* -b: the best read of the current well */
   int    bmax = 0, blen = 0, bseqid = 0, bpac = 0, bwell = 0, bbeg = 0, bend = 0;
+  HdrArgs hargs[2];                                   /* (the reference's two alternating read records) */
+  int     bargs = 0;
   FILE  *in;
   const char *b = base_name(name);
   size_t bl = strlen(b);
@@ -239,8 +374,10 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
   else
     strcpy(prolog, "DAZZ_READ");
 
+  memset(hargs, 0, sizeof(hargs));
   for (;;)                                           /* line holds a header here, or n < 0 at the end */
     { int pac = 0, well = -1, beg = -1, end = -1;
+      const int cur = nxt;                           /* the record this header is parsed into */
 
       if (n < 0)
         break;
@@ -253,6 +390,14 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
       if (is_pacbio_header(header))
         { const char *slash = strchr(header, '/');
           pac = (sscanf(slash + 1, "%d/%d_%d\n", &well, &beg, &end) == 3);
+        }
+      if (C_n > 0)
+        { const char *c = header;                     /* past the read name and ONE blank */
+          while (*c != '\0' && *c != '\n' && *c != ' ')
+            c++;
+          if (*c == ' ' || *c == '\n')
+            c++;
+          parse_header_args(c, &hargs[cur]);
         }
       rlen = 0;
       have = 0;
@@ -274,8 +419,10 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
         { if (o->verbose > 1)
             fprintf(stderr, "Warning: skipping read of length %d\n", rlen);
         }
+      else if (C_n > 0 && o->fullhq && !full_hq_read(&hargs[cur]))
+        ;                                            /* -Q (FA2db.c:809-837): not a FullHqRead, or it does not say */
       else if (!o->best)
-        add_read(o, seq, rlen, seqid, pac, well, beg, end);
+        add_read(o, seq, rlen, seqid, pac, well, beg, end, C_n > 0 ? &hargs[cur] : NULL);
       else
         { /* -b (FA2db.c:858-893): of consecutive reads of one well only the longest enters the database (the
              first of equally long ones; reads without a PacBio header all count as well -1) */
@@ -285,7 +432,7 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
             }
           else
             { if (bseq != NULL)
-                add_read(o, bseq, blen, bseqid, bpac, bwell, bbeg, bend);
+                add_read(o, bseq, blen, bseqid, bpac, bwell, bbeg, bend, C_n > 0 ? &hargs[bargs] : NULL);
             take:
               if (rlen + 1 > bmax)
                 { bmax = rlen + rlen / 4 + 1000;
@@ -293,6 +440,7 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
                 }
               memcpy(bseq, seq, (size_t) rlen);
               blen = rlen;  bseqid = seqid;  bpac = pac;  bwell = well;  bbeg = beg;  bend = end;
+              bargs = cur;
               nxt ^= 1;                              /* the record just parsed is the best one now: parse into the other */
             }
         }
@@ -300,7 +448,7 @@ static void read_fasta(Out *o, const char *name)                          /* FA2
         break;
     }
   if (o->best && bseq != NULL)
-    add_read(o, bseq, blen, bseqid, bpac, bwell, bbeg, bend);
+    add_read(o, bseq, blen, bseqid, bpac, bwell, bbeg, bend, C_n > 0 ? &hargs[bargs] : NULL);
   free(bseq);
   fprintf(o->stub, "  %9d %s %s\n", o->ureads, core, prolog);
   fclose(in);
@@ -330,11 +478,13 @@ int main(int argc, char *argv[])
             exit(1);
           }
         break;
-      case 'Q': case 'c':
-        fprintf(stderr, "FA2db: option -%c is not built in this tool (-v, -a, -b, -x and -f are)\n", c);
-        exit(1);
+      case 'Q': o.fullhq = 1; break;
+      case 'c':
+        C_name = (char **) realloc(C_name, sizeof(char *) * (size_t) (C_n + 1));
+        C_name[C_n++] = optarg;
+        break;
       default:
-        fprintf(stderr, "usage: FA2db [-va] [-x<int(1000)>] <path:db> (-f<file> | <input:fasta> ...)\n");
+        fprintf(stderr, "usage: FA2db [-vabQ] [-c<track>] [-x<int(1000)>] <path:db> (-f<file> | <input:fasta> ...)\n");
         exit(1);
     }
   if (o.minlen < 0)
@@ -342,7 +492,7 @@ int main(int argc, char *argv[])
       exit(1);
     }
   if ((flist == NULL && argc - optind < 2) || argc - optind < 1)
-    { fprintf(stderr, "usage: FA2db [-va] [-x<int(1000)>] <path:db> (-f<file> | <input:fasta> ...)\n");
+    { fprintf(stderr, "usage: FA2db [-vabQ] [-c<track>] [-x<int(1000)>] <path:db> (-f<file> | <input:fasta> ...)\n");
       exit(1);
     }
   root = damar_root(argv[optind], ".db");
@@ -489,10 +639,36 @@ int main(int argc, char *argv[])
   fclose(o.bps);
   snprintf(path, sizeof(path), "%s/%s.db", dir, root);
   rename(newstub, path);
+  if (first > 0 && C_n > 0)
+    { /* adding to a database with -c: every track the database has is carried on over the new reads, whether they
+         name it or not (FA2db.c:406-494 looks the .anno files up in the directory) */
+      DIR *dp = opendir(dir);
+      struct dirent *e;
+      const size_t rl = strlen(root);
+      while (dp != NULL && (e = readdir(dp)) != NULL)
+        { const char *n = e->d_name;
+          const size_t l = strlen(n);
+          if (n[0] == '.' && l > rl + 7 && strncmp(n + 1, root, rl) == 0 && n[1 + rl] == '.' && strcmp(n + l - 5, ".anno") == 0)
+            { char tn[512];
+              snprintf(tn, sizeof(tn), "%.*s", (int) (l - rl - 7), n + rl + 2);
+              if (strchr(tn, '.') != NULL || strcmp(tn, "seqID") == 0)
+                continue;
+              if (strcmp(tn, "pacbio") == 0)
+                T_pac_used = 1;
+              else
+                (void) hdr_track(tn);
+            }
+        }
+      if (dp != NULL)
+        closedir(dp);
+    }
   if (o.ureads > first)                                /* FA2x.c:192: no read added, no track touched */
-    { track_write(&T_seq, dir, root, first, o.ureads);
+    { int t;
+      track_write(&T_seq, dir, root, first, o.ureads);
       if (T_pac_used)
         track_write(&T_pac, dir, root, first, o.ureads);
+      for (t = 0; t < T_nhdr; t++)
+        track_write(T_hdr[t], dir, root, first, o.ureads);
     }
   return 0;
 }

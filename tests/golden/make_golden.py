@@ -317,6 +317,12 @@ def fa2db_md5():
         for name, md5 in sorted(dig.items()):
             f.write("%s %s\n" % (md5, name))
     print(dig)
+    with tempfile.TemporaryDirectory() as d:          # -c / -Q: header arguments as tracks, FullHqRead filter
+        dig = test_host.header_track_digests(REF, d)
+    with open(os.path.join(HERE, "fa2db_tracks_ref_md5.txt"), "w") as f:
+        for name, md5 in sorted(dig.items()):
+            f.write("%s %s\n" % (md5, name))
+    print(dig)
 
 
 def trace_md5():

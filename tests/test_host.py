@@ -177,6 +177,73 @@ def fasta_inputs(d):
     return ["pb.fasta", "plain.fa", "mixed.fasta"]
 
 
+def fasta_header_inputs(d):
+    """Two FASTA files whose headers carry arguments (NAME=v1,v2,...) for FA2db -c / -Q: a quality value with the "0."
+    the reference strips, readType (some reads without it, some not FullHqRead), a list-valued argument, the chemistry
+    string (stored as characters), an argument nobody asks for."""
+    import random
+    rng = random.Random(3)
+
+    def seq(n):
+        return "".join(rng.choice("acgt") for _ in range(n))
+    with open(os.path.join(d, "h.fasta"), "w") as f:
+        for i in range(30):
+            n = rng.choice([900, 1500, 3000])
+            args = ["RQ=0.8%02d" % i]
+            if i % 3 != 2:
+                args.append("readType=%d" % rng.choice([0, 1, 2, 3]))
+            if i % 4 == 0:
+                args.append("SN=%d,%d,%d" % (i, 2 * i, 3 * i))
+            if i % 5 == 0:
+                args.append("chemistry=P6C4")
+            if i % 7 == 0:
+                args.append("other=5")
+            f.write(">m1/%d/%d_%d %s\n%s\n" % (i // 2 + 3, 10 * i, 10 * i + n, " ".join(args), seq(n)))
+    with open(os.path.join(d, "g.fasta"), "w") as f:
+        for i in range(10):
+            f.write(">m2/%d/0_2000 readType=%d SN=7\n%s\n" % (i + 1, 1 + i % 2, seq(2000)))
+    return ["h.fasta", "g.fasta"]
+
+
+HEADER_TRACK_RUNS = {          # FA2db -c / -Q (FA2db.c:169-355, 638-643, 809-837)
+    "c":      [["-x1000", "-cRQ", "-cSN", "-creadType", "-cchemistry", "T", "h.fasta", "g.fasta"]],
+    "Q":      [["-x1000", "-b", "-Q", "-creadType", "-cchemistry", "T", "h.fasta", "g.fasta"]],
+    "append": [["-x1000", "-cSN", "-creadType", "T", "h.fasta"], ["-x1000", "-cSN", "T", "g.fasta"]],
+}
+
+
+def header_track_digests(tools, base):
+    out = {}
+    for tag, cmds in HEADER_TRACK_RUNS.items():
+        d = os.path.join(base, tag)
+        os.makedirs(d)
+        fasta_header_inputs(d)
+        for cmd in cmds:
+            subprocess.run([os.path.join(tools, "FA2db")] + cmd, cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for f, m in db_digest(d).items():
+            out["%s/%s" % (tag, f)] = m
+    return out
+
+
+def test_fa2db_header_tracks_and_full_hq_filter_equal_reference(built, tmp_path):
+    """FA2db -c (header arguments -> tracks) and -Q (FullHqRead only), the part of SURVEY 8(f)3 rounds 1-3 left out: every
+    database file and every track against the reference's (tests/golden/fa2db_tracks_ref_md5.txt, made with oracle/_ref/FA2db
+    by `make_golden.py fa2db`; compared live as well where oracle/_ref exists)."""
+    got = header_track_digests(os.path.join(ROOT, "damar_amd", "bin"), str(tmp_path / "own"))
+    want = dict(ln.split()[::-1] for ln in open(os.path.join(GOLDEN, "fa2db_tracks_ref_md5.txt")))
+    assert got == want
+    assert any(k.endswith(".T.chemistry.data") for k in got) and any(k.startswith("Q/") and k.endswith(".T.readType.anno") for k in got)
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    if os.path.exists(os.path.join(ref, "FA2db")):
+        assert header_track_digests(ref, str(tmp_path / "ref")) == got
+    # a malformed argument name stops the tool as it stops the reference
+    bad = str(tmp_path / "bad")
+    os.makedirs(bad)
+    open(os.path.join(bad, "b.fasta"), "w").write(">x bad-name=3\nacgt\n")
+    r = subprocess.run([os.path.join(ROOT, "damar_amd", "bin", "FA2db"), "-x1", "-cSN", "U", "b.fasta"], cwd=bad, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "malformed track name" in r.stderr
+
+
 def db_digest(d, root="T"):
     """md5 of every file of a database; of the .idx only the fields the reference defines (it leaves the
     padding of its records and the tail of the header uninitialised)."""
@@ -248,9 +315,7 @@ def test_fa2db_and_dbsplit_equal_reference(built, tmp_path):
         os.makedirs(live)
         fasta_inputs(live)
         assert append_sequence(ref, live) == append_sequence.__wrapped_last__
-    # what is not built is refused, not ignored; a file cannot be added twice
-    r = subprocess.run([os.path.join(tools, "FA2db"), "-Q", "U"] + files, cwd=own, stderr=subprocess.PIPE, text=True)
-    assert r.returncode != 0 and "not built" in r.stderr
+    # a file cannot be added twice (below)
     # -b: only the longest read of a well (FA2db.c:858-893, the per-record file indices of the seqID track included)
     bst = str(tmp_path / "best")
     os.makedirs(bst)
