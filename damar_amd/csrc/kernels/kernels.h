@@ -224,6 +224,7 @@ typedef struct { int aread, bread, diag, anti; } LaTask;
 void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
 /* two read pairs (or batch tasks, tasks != NULL) per wavefront: report_packed.h; nslots must be even */
 void damar_launch_report2(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
+void damar_launch_tandem_report2(const ReportArgs *a, const int *dist, int nslots, hipStream_t st);     /* datander through the same kernel */
 #define DAMAR_MAX_MARKS 16000         /* trace-grid indexes ride in the top 14 bits of a chain head (report.hip PK_HBITS) */
 #define DAMAR_MAX_CELLS (1u << 18)    /* pebbles per slot: 18 bits of a chain head */
 

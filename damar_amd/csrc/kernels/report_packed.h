@@ -748,7 +748,11 @@ enum { PK_ITEM = 0, PK_PANEL, PK_FIRE, PK_DONE };
 
 
 /* one job of the launch: the two halves pull read pairs (or batch tasks) from its queue until it is empty */
-__device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trimtab, const LaTask *tasks, u32 ntasks)
+/* dist != NULL: datander (scrub/tandem.c:895-1175 report_thread) -- a work item is a READ, its "seeds" are the positions
+   apos of the read whose k-mer has an equal k-mer earlier in the same read, dist[...] back (damar_launch_tandem_links), and
+   the alignment is the read against itself (aseq == bseq: the band may not cross the main diagonal, align.c:1949-1968) */
+__device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trimtab, const LaTask *tasks, u32 ntasks,
+                                            const int *dist)
 { const int lane = lane_id(), hb = lane & 32, s = lane & 31;
   const int slot = 2 * (int) blockIdx.x + (hb >> 5);
   const SlotScratch sc = slot_scratch(a, slot);
@@ -759,12 +763,13 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
   const int dbits = a.dbits, pshift = a.pbits + a.dbits;        /* key = pair | apos | bpos (dbits) */
   const int K = a.kmer, H = a.hitmin, W = a.binshift, minhit = a.minhit;
   const int mind = (-a.bblk.maxlen) >> W, maxd = a.ablk.maxlen >> W;
-  const bool batch = tasks != NULL;
+  const bool batch = tasks != NULL, tandem = dist != NULL;
 
   int  phase = PK_ITEM;
   u32  item = 0, seq = 0;
   u64  nidx = 0, cpair = 0, lidx = 0, end = 0, h2 = 0, fp = 0;
   int  ar = 0, br = 0, amark2 = 0, clo = BIG, chi = -BIG, sd = 0;
+  int  tmb = 0, tme = 0;              /* datander: the panel of positions [tmb, tme) being scanned */
   DuoCtx cx;
   cx.md = MD_SCAN;  cx.m = 0;  cx.bad = 0;
   cx.va0 = cx.vb0 = 16 * PK_PAD;  cx.alen = cx.blen = 0;
@@ -779,7 +784,117 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
     { /* A: the halves without an alignment in hand advance their scan until they have one or have run out of work */
       while (wany(cx.md == MD_SCAN))
         { const bool sc_ = cx.md == MD_SCAN;
-          if (sc_ && phase == PK_ITEM)
+          if (tandem)
+            { /* nidx = where code[apos] of this read sits in dist: apos = index of a k-mer's last base + 1, in [K, alen] */
+              if (sc_ && phase == PK_ITEM)
+                { u32 it = 0;
+                  if (s == 0)
+                    it = atomicAdd(a.cursor, 1u);
+                  it = (u32) hget((int) it, hb, 0);
+                  if (it >= a.nwork)
+                    { phase = PK_DONE;  cx.md = MD_DONE; }
+                  else
+                    { item = it;  seq = 0;
+                      ar = br = (int) it;
+                      cx.va0 = cx.vb0 = (int) a.ablk.boff[ar] + 16 * PK_PAD;
+                      cx.alen = cx.blen = (int) read_len(a.ablk, ar);
+                      nidx = (u64) a.ablk.boff[ar] - (u64) ar * (u64) K - (u64) K;
+                      clo = BIG;  chi = -BIG;
+                      tmb = K;  tme = PANEL_SIZE;
+                      if (tme >= cx.alen)
+                        tme = cx.alen + 1;
+                      phase = PK_PANEL;
+                    }
+                }
+              else if (sc_ && phase == PK_PANEL)
+                { /* pass 1 (tandem.c:986-996): bucket scores of the panel */
+                  for (int base = tmb; base < tme; base += 32)
+                    { const int  apos = base + s;
+                      const int  dg = (apos < tme) ? dist[nidx + (u64) apos] : 0;
+                      const bool in = dg != 0;
+                      const int  d = dg >> W;
+                      int  prev = in ? sc.lastp[d] : 0;
+                      u32  peers = hmask(wballot(in), hb);
+                      { const u32 db = (u32) (d - mind);
+                        for (int bit = 0; bit < a.bucket_bits; bit++)
+                          { const bool one = (db >> bit) & 1;
+                            const u32  mk = hmask(wballot(one), hb);
+                            peers &= one ? mk : ~mk;
+                          }
+                      }
+                      const u32  below = peers & ((1u << s) - 1u);
+                      const int  pl = below ? 31 - __clz((int) below) : s;
+                      const int  pap = hget(apos, hb, pl);
+                      if (below) prev = pap;
+                      const bool last = in && ((peers >> s) >> 1) == 0;
+                      if (in)
+                        { const int add = (apos - prev >= K) ? K : apos - prev;
+                          atomicAdd(&sc.score[d], add);
+                          if (last)
+                            sc.lastp[d] = apos;
+                        }
+                      wave_mem_sync();
+                    }
+                  fp = (u64) tmb;
+                  phase = PK_FIRE;
+                }
+              else if (sc_ && phase == PK_FIRE)
+                { /* pass 2 (tandem.c:1000-1099): the next position with enough score that lies beyond lasta */
+                  bool found = false;
+                  int  sap = 0, sdg = 0;
+                  for (int base = (int) fp; base < tme; base += 32)
+                    { const int  apos = base + s;
+                      const int  dg = (apos < tme) ? dist[nidx + (u64) apos] : 0;
+                      const int  d = dg >> W;
+                      bool fire = false;
+                      if (dg != 0)
+                        { const int scv = sc.score[d];
+                          fire = ((scv + sc.score[d + 1] >= H) || (scv + sc.score[d - 1] >= H)) && apos > sc.lasta[d];
+                        }
+                      const u32 fm = hmask(wballot(fire), hb);
+                      if (fm)
+                        { const int l = __ffs((int) fm) - 1;
+                          sap = base + l;  sdg = hget(dg, hb, l);  sd = sdg >> W;
+                          fp = (u64) (base + l + 1);
+                          found = true;
+                          break;
+                        }
+                    }
+                  if (found)
+                    { cx.diag = sdg;  cx.anti = sap + (sap - sdg);
+                      cx.m = 0;  cx.md = MD_TASK;
+                      if (s == 0)
+                        atomicAdd(a.nfilt, 1u);
+                    }
+                  else
+                    { /* pass 3 (tandem.c:1103-1109), then the next panel of the read or the next read */
+                      for (int base = tmb; base < tme; base += 32)
+                        { const int apos = base + s;
+                          const int dg = (apos < tme) ? dist[nidx + (u64) apos] : 0;
+                          if (dg != 0)
+                            { sc.score[dg >> W] = 0;
+                              sc.lastp[dg >> W] = 0;
+                            }
+                        }
+                      wave_mem_sync();
+                      if (tme > cx.alen)
+                        { if (clo <= chi)
+                            for (int q = clo + s; q <= chi; q += 32)
+                              sc.lasta[q] = 0;
+                          wave_mem_sync();
+                          phase = PK_ITEM;
+                        }
+                      else
+                        { tmb = tme - PANEL_OVERLAP;
+                          tme = tmb + PANEL_SIZE;
+                          if (tme > cx.alen)
+                            tme = cx.alen + 1;
+                          phase = PK_PANEL;
+                        }
+                    }
+                }
+            }
+          else if (sc_ && phase == PK_ITEM)
             { u32 it = 0;
               if (s == 0)
                 it = atomicAdd(a.cursor, 1u);
@@ -1005,7 +1120,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
 }
 
 __global__ __launch_bounds__(64, DUO_WAVES)
-void report2_kernel(int njobs, const LaTask *tasks, u32 ntasks)
+void report2_kernel(int njobs, const LaTask *tasks, u32 ntasks, const int *dist)
 { __shared__ u32 trimtab[256];
   pk_fill_trimtab(trimtab, g_jobs[0].mscore, g_jobs[0].dscore);
   __syncthreads();
@@ -1014,10 +1129,18 @@ void report2_kernel(int njobs, const LaTask *tasks, u32 ntasks)
     if (lane_id() == 0) { atomicAdd(&g_prof[23], d); atomicAdd(&g_prof[25], 1ull); atomicMax(&g_prof[24], d); } } } pf_exit = { (unsigned long long) wall_clock64() };
 #endif
   for (int turn = 0; turn < njobs; turn++)
-    report2_job(g_jobs[((int) blockIdx.x + turn) % njobs], trimtab, tasks, ntasks);
+    report2_job(g_jobs[((int) blockIdx.x + turn) % njobs], trimtab, tasks, ntasks, dist);
 }
 
 void damar_launch_report2(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st)
 { jobs_upload(jobs, njobs, st);
-  hipLaunchKernelGGL(report2_kernel, dim3(nslots / 2), dim3(64), 0, st, njobs, tasks, ntasks);
+  hipLaunchKernelGGL(report2_kernel, dim3(nslots / 2), dim3(64), 0, st, njobs, tasks, ntasks, (const int *) NULL);
+}
+
+/* datander: one work item per read of a->ablk, dist as produced by damar_launch_tandem_links */
+void damar_launch_tandem_report2(const ReportArgs *a, const int *dist, int nslots, hipStream_t st)
+{ if (a->nwork == 0)
+    return;
+  jobs_upload(a, 1, st);
+  hipLaunchKernelGGL(report2_kernel, dim3(nslots / 2), dim3(64), 0, st, 1, (const LaTask *) NULL, 0u, dist);
 }

@@ -2377,7 +2377,10 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
         ra.nwork = (u32) ablock->nreads;
         HIP_CHECK(hipMemsetAsync(RS.ctr, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
         tick(4);
-        damar_launch_tandem_report(&ra, dist, RS.nslots, G_st);
+        if (use_packed(&ra, ablock->maxlen, ablock->maxlen))
+          damar_launch_tandem_report2(&ra, dist, RS.nslots, G_st);
+        else
+          damar_launch_tandem_report(&ra, dist, RS.nslots, G_st);
         tick(5);
         HIP_CHECK(hipMemcpyAsync(hc, RS.ctr, sizeof(hc), hipMemcpyDeviceToHost, G_st));
         HIP_CHECK(hipStreamSynchronize(G_st));

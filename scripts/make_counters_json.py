@@ -28,6 +28,17 @@ SALU_PEAK = 0.953 * 2.4e9 * 256        # instructions per second, whole chip
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     lanes = float(sys.argv[3]) if len(sys.argv) > 3 else None
+    # what the kernel counted itself in the plain bench run of the same round (bench.json: roofline.band_cells_per_step, ...)
+    live = {}
+    try:
+        live = json.loads(open(src + "/bench.json").read().strip().splitlines()[-1])["roofline"]
+    except Exception:
+        pass
+    iters = None
+    if live.get("wave_steps_per_step") and live.get("halves_per_iteration"):
+        iters = live["wave_steps_per_step"] / live["halves_per_iteration"]          # wave-loop iterations per step
+        if lanes is None and live.get("band_cells_per_step"):
+            lanes = live["band_cells_per_step"] / (iters * 64.)
     stats = list(csv.DictReader(open(src + "/stats/r_kernel_stats.csv")))
     dom = max(stats, key=lambda r: float(r["TotalDurationNs"]))
     name = dom["Name"].split("(")[0]
@@ -52,6 +63,8 @@ def main():
            "salu_frac": cnt["SQ_INSTS_SALU"] / dur_s / SALU_PEAK if "SQ_INSTS_SALU" in cnt else None,
            "valu_busy_weighted": cnt["SQ_INSTS_VALU"] * VALU_WEIGHTED_CYCLES / (dur_s * 2.4e9 * 1024) if "SQ_INSTS_VALU" in cnt else None,
            "active_lane_frac": lanes,
+           "halves_per_iteration": live.get("halves_per_iteration"), "band_cells_per_step": live.get("band_cells_per_step"),
+           "wave_loop_iterations_per_step": iters,
            "lds_bank_conflict_frac": cnt["SQ_LDS_BANK_CONFLICT"] / cnt["SQ_LDS_IDX_ACTIVE"] if cnt.get("SQ_LDS_IDX_ACTIVE") else None,
            "wave_cycles_share": {k: cnt[k] / cnt["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")
                                  if k in cnt and cnt.get("SQ_WAVE_CYCLES")},
@@ -59,6 +72,9 @@ def main():
            "counters_per_launch": {k: v / calls for k, v in cnt.items()},
            "source": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --steps 1 --warmup 0 --no-cpu "
                      "--no-trace --no-e2e --no-legs` (scripts/gpu_profile_round.sh); issue peaks from tools/roofcal.hip (profiles/r02_roofcal.txt)"}
+    if iters and live.get("launches_per_step"):
+        out["per_iteration"] = {k.replace("SQ_INSTS_", "").lower(): v / calls * live["launches_per_step"] / iters
+                                for k, v in cnt.items() if k.startswith("SQ_INSTS_")}
     # what ties this file to a tree: bench.py carries its figures only while the kernel sources still hash to this
     import bench
     out["kernel_src_sha16"] = bench.kernel_src_sha16()
@@ -70,7 +86,8 @@ def main():
         out["head"] = None
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("kernel_symbol", "avg_launch_ms", "bytes_per_launch", "valu_frac", "salu_frac", "valu_busy_weighted",
-                                          "active_lane_frac", "lds_bank_conflict_frac", "wave_cycles_share")}, indent=1))
+                                          "active_lane_frac", "halves_per_iteration", "per_iteration", "lds_bank_conflict_frac",
+                                          "wave_cycles_share") if k in out}, indent=1))
 
 
 if __name__ == "__main__":

@@ -407,6 +407,17 @@ def big_md5(dbdir=None):
                 print(tag, a, b, flush=True)
         with open(os.path.join(HERE, "config4_ref_md5.txt"), "w") as f:
             f.write("\n".join(lines) + "\n")
+    config5_md5()
+
+
+def config5_md5():
+    """config5_ref_md5.txt alone: `python make_golden.py c5` (every block of the config-2 DB, plain and with tandem arrays)."""
+    import hashlib
+    import tempfile
+
+    def md5(path):
+        return hashlib.md5(open(path, "rb").read()).hexdigest()
+
     with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
         lines = ["# config 5: reference datander -j8 SIM.<block> on the config-2 DB (simdb . SIM 27 -c20 -r2 -e.15 -S135),",
                  "# plain and with tandem arrays implanted into 30 % of the reads (simdb ... -T.3)",
@@ -415,7 +426,7 @@ def big_md5(dbdir=None):
             w = os.path.join(d, tag)
             os.makedirs(w)
             run([SIMDB, w, "SIM", "27", "-c20", "-r2", "-e.15", "-S135"] + extra, w, stdout=subprocess.DEVNULL)
-            for blk in (1, 4):
+            for blk in (1, 2, 3, 4):
                 run([os.path.join(REF, "datander"), "-j8", "SIM.%d" % blk], w, stdout=subprocess.DEVNULL)
                 las = os.path.join(w, "tan", "SIM.%d.SIM.%d.las" % (blk, blk))
                 import struct
@@ -431,6 +442,8 @@ def main():
         sys.exit("oracle/_ref/daligner missing: make -C oracle -f Makefile.ref")
     if sys.argv[1:2] == ["big"]:
         return big_md5(sys.argv[2] if len(sys.argv) > 2 else None)
+    if sys.argv[1:] == ["c5"]:
+        return config5_md5()
     if sys.argv[1:] == ["memlimit"]:
         return memlimit()
     if sys.argv[1:] == ["trace"]:

@@ -133,8 +133,10 @@ def test_gpu_config5_datander_on_config2_blocks_equals_reference(gpu, tmp_path, 
         m, tag, blk, novl = ln.split()
         if tag == variant:
             want[int(blk)] = (m, int(novl))
-    assert sorted(want) == [1, 4]
+    assert sorted(want) == [1, 2, 3, 4]
     for blk, (m, novl) in sorted(want.items()):
+        if blk in (2, 3):
+            continue                                   # (through the command below)
         b = driver.Block(os.path.join(d, "SIM.%d" % blk))
         driver.run_datander(b, d, j=8)
         las = os.path.join(d, "tan", "SIM.%d.SIM.%d.las" % (blk, blk))
@@ -144,6 +146,16 @@ def test_gpu_config5_datander_on_config2_blocks_equals_reference(gpu, tmp_path, 
         if variant == "tandem":
             assert n > 1000
         b.close()
+    # the command over all four blocks (one process: a reader thread ahead of the GPU, host/datander.c)
+    import subprocess
+    cli = os.path.join(d, "cli")
+    os.makedirs(cli)
+    for f in ("SIM.db", ".SIM.idx", ".SIM.bps"):
+        os.symlink(os.path.join(d, f), os.path.join(cli, f))
+    subprocess.run([os.path.join(os.path.dirname(api.daligner_binary()), "datander"), "-j16"] + ["SIM.%d" % b for b in sorted(want)],
+                   cwd=cli, check=True, stdout=subprocess.DEVNULL)
+    for blk, (m, novl) in sorted(want.items()):
+        assert _md5(os.path.join(cli, "tan", "SIM.%d.SIM.%d.las" % (blk, blk))) == m, blk
 
 
 @pytest.mark.parametrize("name,upr", [("tiny2", 1), ("tiny2", 5), ("tandem", 3)])
