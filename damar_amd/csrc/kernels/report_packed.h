@@ -106,6 +106,7 @@ struct DuoCtx
   int pa0, pb0;                                 /* where the pass's packed bases start: window of (X, Y) at pa0 + X, pb0 + Y */
   /* the task and what its passes have produced */
   int diag, anti;
+  int roota, rootb;                             /* trace-grid index the A / B chain of the pass starts from (its root) */
   int aepos, bepos, abpos, bbpos, diffs, atlen, btlen, aback, bback;
   /* what the wavefront has stepped through so far (the same in every lane): SURVEY 8(d)'s secondary unit of K6 */
   u64 n_cells;                                  /* band cells = diagonals computed, summed over the wave steps */
@@ -226,7 +227,7 @@ DUO_PIECE void duo_begin(int job, u32 cbase, DuoCtx *cx)
   const int boff = (a.comp & 1) ? (blen % TS) : 0;
   const int offa0 = -PK_BIAS * TS, offb0 = boff - PK_BIAS * TS;          /* mark = grid index * TS + off */
   int ls = 15, hs = 15, kbase = 0, dif = 0, besta = 0, bestk = 0, lasta = 0, more = 1, ncell = 2, bad = 0;
-  int mlo = 0, mhi = 0, alim = 0, blim = 0, offa = 0, offb = 0, pa0 = 0, pb0 = 0;
+  int mlo = 0, mhi = 0, alim = 0, blim = 0, offa = 0, offb = 0, pa0 = 0, pb0 = 0, roota = 0, rootb = 0;
   int rV = DUO_EDGE, rHA = 0, rHB = 0;
   u64 rT = 0;
   int md = cx->md;
@@ -245,6 +246,7 @@ DUO_PIECE void duo_begin(int job, u32 cbase, DuoCtx *cx)
           offa = offa0 + TS;  offb = offb0 + TS;
           alim = alen;  blim = blen;
           pa0 = va0;  pb0 = vb0;
+          roota = ga;  rootb = gb;
         }
       else
         { const int hai = (x + TS - 1) / TS + PK_BIAS, hbi = (y + (TS - boff) - 1) / TS + PK_BIAS;     /* the true start, rounded up to the grid */
@@ -253,6 +255,7 @@ DUO_PIECE void duo_begin(int job, u32 cbase, DuoCtx *cx)
               gcell[cbase + 1] = cell_root(y, diag);
             }
           ga = DUO_GREV - hai;  gb = DUO_GREV - hbi;
+          roota = hai;  rootb = hbi;
           offa = -offa0 - DUO_GREV * TS + TS;  offb = -offb0 - DUO_GREV * TS + TS;
           alim = 0;  blim = 0;
           /* base x - 1 of the read = block base a0 + x - 1 = reversed base total - a0 - x, at X = -x */
@@ -315,7 +318,7 @@ DUO_PIECE void duo_begin(int job, u32 cbase, DuoCtx *cx)
       cx->ls = ls;  cx->hs = hs;  cx->kbase = kbase;  cx->dif = dif;  cx->besta = besta;  cx->bestk = bestk;
       cx->lasta = lasta;  cx->more = more;  cx->ncell = ncell;  cx->bad = bad;
       cx->mlo = mlo;  cx->mhi = mhi;  cx->alim = alim;  cx->blim = blim;  cx->offa = offa;  cx->offb = offb;
-      cx->pa0 = pa0;  cx->pb0 = pb0;
+      cx->pa0 = pa0;  cx->pb0 = pb0;  cx->roota = roota;  cx->rootb = rootb;
     }
 }
 
@@ -645,6 +648,147 @@ DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel, D
 #undef DUO_SG
 }
 
+/* One chain of a pass as trace values: chain_to_trace (report.hip) with two differences that halve and halve again what a
+ * wavefront waits for here (the walk is a chain of dependent loads; it was 12 % of the wavefronts' time):
+ *   - the pebbles of a chain sit on CONSECUTIVE trace marks (every mark a path crosses gets one: the invariant that made
+ *     NA/NB redundant), so the number of pebbles is the distance between the head's and the root's grid index and the
+ *     counting walk is not needed;
+ *   - `side` (0: the A chain, 1: the B chain) is a run-time value: lanes 0 and 1 of a half walk the two chains of a pass
+ *     at the same time, their loads in flight together.
+ * Forward: returns the number of values written to T[0 ...).  Reverse: values are prepended (T[-1], T[-2], ...), the first
+ * partial segment goes into the forward trace's first pair if there is one (f0 > 0), and the number of prepended values is
+ * returned (align.c:1001-1118 / 1699-1898; the `(b - a), (b - a)` quirk of align.c:1843 on the B side included). */
+template <int REV>
+__device__ __forceinline__ int duo_walk(const Cell *cells, int side, int head, int rootidx, int TS, int off, int mida,
+                                        int ex, int ey, int ed, u16 *T, int f0, int guard, u32 *errw)
+{ const int sg = side ? 1 : -1;
+  const int P = side ? ey : ex, Q = side ? ex : ey;              /* coordinate tested / coordinate contributed by the end point */
+  const int goff = off - PK_BIAS * TS;                           /* mark = grid index * TS + goff */
+  const int k0 = (int) cells[side].w1, m0 = (int) cells[side].w0;   /* cells 0 / 1: the exact starts of the A / B chain */
+  int L = 0, kc = k0, dc = 0, ac, h = head, gw = 0;
+  if (head >= 2)
+    { const Cell c = cells[h];
+      const int hidx = (int) (c.w0 >> PK_HBITS);
+      L = REV ? rootidx - hidx : hidx - rootidx;
+      kc = (ex - ey) + (int) (short) (u16) ((c.w1 & 0xffffu) - (u32) (ex - ey));
+      dc = ed - (int) (((u32) ed - (c.w1 >> 16)) & 0xffffu);
+      ac = hidx * TS + goff + sg * kc;
+      if (L < 1 || L > DAMAR_MAX_MARKS)                          /* cannot happen: a chain off the grid */
+        { atomicOr(errw, DAMAR_ERR_BAND);
+          atomicMax(errw + 3, 11u);
+          return 0;
+        }
+    }
+  else
+    ac = REV ? m0 + sg * k0 : (mida + sg * k0) / 2;
+  if (!REV)
+    { int n = 2 * L;
+      if (L > 0)
+        { T[2 * L - 1] = 0;  T[2 * L - 2] = 0; }
+      if (ac - sg * kc != P)
+        { T[n] = (u16) (ed - dc);
+          T[n + 1] = (u16) (Q - ac);
+          n += 2;
+        }
+      else if (ac != Q && L > 0)
+        { T[2 * L - 1] = (u16) (Q - ac);
+          T[2 * L - 2] = (u16) (ed - dc);
+        }
+      for (int j = L; j >= 1; j--)
+        { GUARD(gw, guard, 8)
+          int kp, dp, ap;
+          h = (int) (cells[h].w0 & PK_HMASK);
+          if (j > 1)
+            { const Cell c = cells[h];
+              kp = kc + (int) (short) (u16) ((c.w1 & 0xffffu) - (u32) kc);
+              dp = dc - (int) (((u32) dc - (c.w1 >> 16)) & 0xffffu);
+              ap = (int) (c.w0 >> PK_HBITS) * TS + goff + sg * kp;
+            }
+          else
+            { kp = k0;  dp = 0;  ap = (mida + sg * k0) / 2; }
+          if (j == L)
+            { T[2 * j - 2] = (u16) (T[2 * j - 2] + (dc - dp));
+              T[2 * j - 1] = (u16) (T[2 * j - 1] + (ac - ap));
+            }
+          else
+            { T[2 * j - 2] = (u16) (dc - dp);
+              T[2 * j - 1] = (u16) (ac - ap);
+            }
+          kc = kp;  dc = dp;  ac = ap;
+        }
+      return n;
+    }
+  else
+    { const int a0 = m0 + sg * k0;
+      const bool partial = (m0 % TS) != off;
+      const bool merged = partial && f0 > 0;
+      if (partial && L == 0)
+        { if (f0 == 0)
+            { T[-1] = (u16) (a0 - Q);
+              T[-2] = side ? (u16) (a0 - Q) : (u16) (ed - 0);
+              return 2;
+            }
+          T[1] = (u16) (T[1] + (a0 - Q));
+          T[0] = (u16) (T[0] + (ed - 0));
+          return 0;
+        }
+      const int npush = merged ? L - 1 : L;
+      int n = 2 * npush;
+      if (npush > 0)
+        { T[-2 * npush + 1] = 0;  T[-2 * npush] = 0; }
+      if (ac - sg * kc != P)
+        { T[-n - 1] = (u16) (ac - Q);
+          T[-n - 2] = (u16) (ed - dc);
+          n += 2;
+        }
+      else if (ac != Q && (f0 + n) > 0)
+        { if (npush > 0)
+            { T[-2 * npush + 1] = (u16) (ac - Q);
+              T[-2 * npush]     = (u16) (ed - dc);
+            }
+          else
+            { T[1] = (u16) (T[1] + (ac - Q));
+              T[0] = (u16) (T[0] + (ed - dc));
+            }
+        }
+      for (int j = L; j >= 1; j--)
+        { GUARD(gw, guard, 10)
+          int kp, dp, ap;
+          h = (int) (cells[h].w0 & PK_HMASK);
+          if (j > 1)
+            { const Cell c = cells[h];
+              kp = kc + (int) (short) (u16) ((c.w1 & 0xffffu) - (u32) kc);
+              dp = dc - (int) (((u32) dc - (c.w1 >> 16)) & 0xffffu);
+              ap = (int) (c.w0 >> PK_HBITS) * TS + goff + sg * kp;
+            }
+          else
+            { kp = k0;  dp = 0;  ap = a0; }
+          if (j == 1 && merged)
+            { T[1] = (u16) (T[1] + (ap - ac));
+              T[0] = (u16) (T[0] + (dc - dp));
+            }
+          else if (j == 1 && partial && side)
+            { const u16 add0 = (L == 1) ? T[-2] : (u16) 0, add1 = (L == 1) ? T[-1] : (u16) 0;
+              T[-1] = (u16) (add1 + (ap - ac));
+              T[-2] = (u16) (add0 + (ap - ac));
+            }
+          else
+            { const int jj = merged ? j - 1 : j;
+              if (j == L)
+                { T[-2 * jj + 1] = (u16) (T[-2 * jj + 1] + (ap - ac));
+                  T[-2 * jj]     = (u16) (T[-2 * jj] + (dc - dp));
+                }
+              else
+                { T[-2 * jj + 1] = (u16) (ap - ac);
+                  T[-2 * jj]     = (u16) (dc - dp);
+                }
+            }
+          kc = kp;  dc = dp;  ac = ap;
+        }
+      return n;
+    }
+}
+
 /* End point and trace points of the direction that is over (align.c:1001-1118 / 1699-1898) for the halves with
  * md == MD_END: the first lane of the half walks the two pebble chains (chain_to_trace).  Leaves the pass's results in
  * cx and the half in MD_TASK with m = -1 (the reverse pass is next) or, after the reverse pass, in MD_END with m = 1
@@ -659,27 +803,25 @@ DUO_PIECE void duo_finish(int job, SlotScratch sc, DuoCtx *cx)
   const int boff = (a.comp & 1) ? (cx->blen % TS) : 0;
   const int guard = 4 * (cx->alen + cx->blen) + 1024;
   u32 *const errw = &a.counters[3];
-  int rx = 0, ry = 0, rd = 0, at = 0, bt = 0;
+  int rx = 0, ry = 0, rd = 0, nt = 0;
   wave_mem_sync();
-  if (fin && !cx->bad && s == 0)
+  if (fin && !cx->bad && s < 2)                      /* lane 0: the A chain, lane 1: the B chain */
     { int ta = cold[DC_TRIM], tk = cold[DC_TRIM + 1], td = cold[DC_TRIM + 2], tha = cold[DC_TRIM + 3], thb = cold[DC_TRIM + 4];
       if (cold[DC_REACHM] >= 0 && a.reach)
         { ta = cold[DC_REACH];  tk = cold[DC_REACH + 1];  td = cold[DC_REACH + 2];  tha = cold[DC_REACH + 3];  thb = cold[DC_REACH + 4]; }
       const int ty_ = (ta - tk) >> 1;
       const int trimy = (ty_ ^ m) - m, trimx = ((ta - ty_) ^ m) - m;
-      int gw = 0;
+      const int head = s ? thb : tha, rootidx = s ? cx->rootb : cx->roota, off = s ? boff : 0;
+      u16 *const T = s ? sc.btr : sc.atr;
       if (m == 0)
-        { at = chain_to_trace<0, 0>(sc.cells, tha, TS, 0, cx->anti, trimx, trimy, td, sc.atr, 0, guard, gw, errw);
-          bt = chain_to_trace<0, 1>(sc.cells, thb, TS, boff, cx->anti, trimx, trimy, td, sc.btr, 0, guard, gw, errw);
-        }
+        nt = duo_walk<0>(sc.cells, s, head, rootidx, TS, off, cx->anti, trimx, trimy, td, T, 0, guard, errw);
       else
-        { at = chain_to_trace<1, 0>(sc.cells, tha, TS, 0, cx->anti, trimx, trimy, td, sc.atr, cx->atlen, guard, gw, errw);
-          bt = chain_to_trace<1, 1>(sc.cells, thb, TS, boff, cx->anti, trimx, trimy, td, sc.btr, cx->btlen, guard, gw, errw);
-        }
+        nt = duo_walk<1>(sc.cells, s, head, rootidx, TS, off, cx->anti, trimx, trimy, td, T, s ? cx->btlen : cx->atlen, guard, errw);
       rx = trimx;  ry = trimy;  rd = td;
     }
   wave_mem_sync();
-  rx = hget(rx, hb, 0);  ry = hget(ry, hb, 0);  rd = hget(rd, hb, 0);  at = hget(at, hb, 0);  bt = hget(bt, hb, 0);
+  rx = hget(rx, hb, 0);  ry = hget(ry, hb, 0);  rd = hget(rd, hb, 0);
+  const int at = hget(nt, hb, 0), bt = hget(nt, hb, 1);
   if (fin)
     { if (m == 0)
         { cx->aepos = rx;  cx->bepos = ry;  cx->diffs = rd;  cx->atlen = at;  cx->btlen = bt;
@@ -776,7 +918,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
   cx.V = DUO_EDGE;  cx.HA = cx.HB = 0;  cx.Tlo = cx.Thi = 0;
   cx.ls = cx.hs = 15;  cx.kbase = 0;  cx.dif = 0;  cx.besta = cx.bestk = cx.lasta = 0;  cx.more = 0;  cx.ncell = 2;
   cx.mlo = cx.mhi = 0;  cx.alim = cx.blim = 0;  cx.offa = cx.offb = 0;  cx.pa0 = cx.pb0 = 0;
-  cx.diag = cx.anti = 0;
+  cx.diag = cx.anti = 0;  cx.roota = cx.rootb = 0;
   cx.aepos = cx.bepos = cx.abpos = cx.bbpos = cx.diffs = cx.atlen = cx.btlen = cx.aback = cx.bback = 0;
   cx.n_cells = 0;  cx.n_iter = cx.n_half = 0;
 
@@ -1044,12 +1186,24 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
           duo_classify(a, &cx);                           /* (the seed diagonal may already have ended the pass) */
         }
       if (wany(cx.md == MD_RUN))
-        { duo_loop(a.job, trimtab, cbase, &cx);           /* every half in MD_RUN can step: the loop tests behind a step */
+        {
+#ifdef DAMAR_PROF
+          const unsigned long long pf0 = wall_clock64();
+#endif
+          duo_loop(a.job, trimtab, cbase, &cx);           /* every half in MD_RUN can step: the loop tests behind a step */
           duo_classify(a, &cx);
+#ifdef DAMAR_PROF
+          PROF_ADD(15, wall_clock64() - pf0);  PROF_ADD(29, 1);
+#endif
         }
       { const u64 ov = wballot(cx.md == MD_OVF);
         if (ov)
-          { for (int h = 0; h < 64; h += 32)
+          {
+#ifdef DAMAR_PROF
+            const unsigned long long pf0 = wall_clock64();
+            PROF_ADD(28, __popcll(ov) >> 5);
+#endif
+            for (int h = 0; h < 64; h += 32)
               if ((ov >> h) & 1)
                 { if (bcast_i(cx.m, h))
                     duo_solo<1>(a.job, trimtab, sc, h, &cx);
@@ -1057,10 +1211,21 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                     duo_solo<0>(a.job, trimtab, sc, h, &cx);
                 }
             duo_classify(a, &cx);
+#ifdef DAMAR_PROF
+            PROF_ADD(13, wall_clock64() - pf0);
+#endif
           }
       }
       if (wany(cx.md == MD_END))
-        duo_finish(a.job, sc, &cx);
+        {
+#ifdef DAMAR_PROF
+          const unsigned long long pf0 = wall_clock64();
+#endif
+          duo_finish(a.job, sc, &cx);
+#ifdef DAMAR_PROF
+          PROF_ADD(14, wall_clock64() - pf0);
+#endif
+        }
 
       /* C: what the reference does with the path (filter.c:2318-2380), for the halves whose reverse pass is over */
       if (wany(cx.md == MD_END))
