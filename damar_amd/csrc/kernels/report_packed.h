@@ -91,11 +91,13 @@ __device__ __forceinline__ bool inv(u64 m)  { return __builtin_amdgcn_inverse_ba
 __device__ __forceinline__ int ffbh_raw(u32 x) { int r;  asm("v_ffbh_u32_e32 %0, %1" : "=v"(r) : "v"(x));  return r; }
 __device__ __forceinline__ int ffbl_raw(u32 x) { int r;  asm("v_ffbl_b32_e32 %0, %1" : "=v"(r) : "v"(x));  return r; }
 
-/* Everything a half carries between the pieces below (noinline functions with their own register allocation): one copy
-   per lane in private memory; all fields but the band state hold the same value in the 32 lanes of a half. */
+/* Everything a half carries between the pieces below (noinline functions with their own register allocation) lives in
+   LDS: one record per half (every lane of the half reads and writes the same words: broadcast reads, one write) and the
+   band state of the 64 lanes.  (Round 4's first version kept it in a struct in private memory handed to the pieces by
+   pointer: 6 M piece calls per config-2 step, each loading and storing ~11 KB of scratch per wavefront, were most of the
+   20 GB per launch the report kernel moved through L2 -- profiles/r04_traffic_summary.txt.) */
 struct DuoCtx
-{ int V, HA, HB;  u32 Tlo, Thi;                 /* band state of this lane: lane s owns K = kbase - s */
-  int md;
+{ int md;
   int m;                                        /* direction: 0 forward, -1 reverse */
   int ls, hs, kbase;                            /* band = lanes ls..hs (highest..lowest K) */
   int dif, besta, bestk, lasta, more, ncell, bad;
@@ -109,9 +111,14 @@ struct DuoCtx
   int roota, rootb;                             /* trace-grid index the A / B chain of the pass starts from (its root) */
   int aepos, bepos, abpos, bbpos, diffs, atlen, btlen, aback, bback;
   /* what the wavefront has stepped through so far (the same in every lane): SURVEY 8(d)'s secondary unit of K6 */
-  u64 n_cells;                                  /* band cells = diagonals computed, summed over the wave steps */
-  u32 n_iter, n_half;                           /* iterations of the wave loop, and halves that stepped in them */
+  u32 n_cells_lo, n_cells_hi;                   /* band cells = diagonals computed, summed over the wave steps */
+  u32 n_iter, n_half;                           /* iterations of the wave loop, and halves that stepped in them (counted by half 0's record) */
 };
+__shared__ DuoCtx duo_half[2];
+/* band state of the lanes: lane s of a half owns K = kbase - s */
+__shared__ int duo_V[64], duo_HA[64], duo_HB[64];
+__shared__ u32 duo_Tlo[64], duo_Thi[64];
+#define DUO_CX()  DuoCtx &cx = duo_half[lane_id() >> 5]
 
 struct DuoSnake { int Y, na, nb;  u64 b; };
 
@@ -215,14 +222,15 @@ __device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, co
   (void) gcell; (void) cell_cap; (void) errw; (void) cold;
 
 /* Wave 0 on the seed diagonal (align.c:491-626 / 1203-1340) and the clipping behind it, for the halves with
-   md == MD_TASK: sets up direction cx->m of the task (cx->diag, cx->anti).  Every lane of a half computes the same. */
-DUO_PIECE void duo_begin(int job, u32 cbase, DuoCtx *cx)
+   md == MD_TASK: sets up direction cx.m of the task (cx.diag, cx.anti).  Every lane of a half computes the same. */
+DUO_PIECE void duo_begin(int job, u32 cbase)
 { DUO_NAMES()
-  const bool on = cx->md == MD_TASK;
+  DUO_CX();
+  const bool on = cx.md == MD_TASK;
   const u64 onm = bal(on);
-  const int m = cx->m;
-  const int va0 = cx->va0, vb0 = cx->vb0, alen = cx->alen, blen = cx->blen;
-  const int diag = cx->diag, anti = cx->anti;
+  const int m = cx.m;
+  const int va0 = cx.va0, vb0 = cx.vb0, alen = cx.alen, blen = cx.blen;
+  const int diag = cx.diag, anti = cx.anti;
   const int guard = 4 * (alen + blen) + 1024;
   const int boff = (a.comp & 1) ? (blen % TS) : 0;
   const int offa0 = -PK_BIAS * TS, offb0 = boff - PK_BIAS * TS;          /* mark = grid index * TS + off */
@@ -230,7 +238,7 @@ DUO_PIECE void duo_begin(int job, u32 cbase, DuoCtx *cx)
   int mlo = 0, mhi = 0, alim = 0, blim = 0, offa = 0, offb = 0, pa0 = 0, pb0 = 0, roota = 0, rootb = 0;
   int rV = DUO_EDGE, rHA = 0, rHB = 0;
   u64 rT = 0;
-  int md = cx->md;
+  int md = cx.md;
 
   if (on)
     { const int K0 = (diag ^ m) - m, V0 = (anti ^ m) - m;
@@ -313,33 +321,34 @@ DUO_PIECE void duo_begin(int job, u32 cbase, DuoCtx *cx)
     }
   DUO_CLIP()
   if (on)
-    { cx->V = rV;  cx->HA = rHA;  cx->HB = rHB;  cx->Tlo = (u32) rT;  cx->Thi = (u32) (rT >> 32);
-      cx->md = md;
-      cx->ls = ls;  cx->hs = hs;  cx->kbase = kbase;  cx->dif = dif;  cx->besta = besta;  cx->bestk = bestk;
-      cx->lasta = lasta;  cx->more = more;  cx->ncell = ncell;  cx->bad = bad;
-      cx->mlo = mlo;  cx->mhi = mhi;  cx->alim = alim;  cx->blim = blim;  cx->offa = offa;  cx->offb = offb;
-      cx->pa0 = pa0;  cx->pb0 = pb0;  cx->roota = roota;  cx->rootb = rootb;
+    { duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
+      cx.md = md;
+      cx.ls = ls;  cx.hs = hs;  cx.kbase = kbase;  cx.dif = dif;  cx.besta = besta;  cx.bestk = bestk;
+      cx.lasta = lasta;  cx.more = more;  cx.ncell = ncell;  cx.bad = bad;
+      cx.mlo = mlo;  cx.mhi = mhi;  cx.alim = alim;  cx.blim = blim;  cx.offa = offa;  cx.offb = offb;
+      cx.pa0 = pa0;  cx.pb0 = pb0;  cx.roota = roota;  cx.rootb = rootb;
     }
 }
 
 /* The wave steps (align.c:667-999 / 1378-1697) of the halves with md == MD_RUN, until one of them has an event: its
    direction is over (or failed), or its band no longer fits lanes 1..30.  The caller tells which from the state
    (duo_classify); on entry every such half can step (duo_classify has been through). */
-DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase, DuoCtx *cx)
+DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
 { DUO_NAMES()
+  DUO_CX();
   const int ave = uni(a.ave_path);
-  const u64 onm = bal(cx->md == MD_RUN);
+  const u64 onm = bal(cx.md == MD_RUN);
   const bool on = inv(onm);
-  const int m = cx->m;
-  const int va0 = cx->va0, vb0 = cx->vb0, alen = cx->alen, blen = cx->blen;
-  const int alim = cx->alim, blim = cx->blim, offa = cx->offa, offb = cx->offb, pa0 = cx->pa0, pb0 = cx->pb0;
+  const int m = cx.m;
+  const int va0 = cx.va0, vb0 = cx.vb0, alen = cx.alen, blen = cx.blen;
+  const int alim = cx.alim, blim = cx.blim, offa = cx.offa, offb = cx.offb, pa0 = cx.pa0, pb0 = cx.pb0;
   const int steplimit = alen + blen + 64, guard = 4 * (alen + blen) + 1024;
   const u32 below = (1u << s) - 1u;
   const int lane4 = lane << 2, top4 = (hb + 31) << 2;
-  int ls = cx->ls, hs = cx->hs, kbase = cx->kbase, dif = cx->dif, besta = cx->besta, bestk = cx->bestk;
-  int lasta = cx->lasta, more = cx->more, ncell = cx->ncell, mlo = cx->mlo, mhi = cx->mhi;
-  int rV = cx->V, rHA = cx->HA, rHB = cx->HB;
-  u64 rT = ((u64) cx->Thi << 32) | cx->Tlo;
+  int ls = cx.ls, hs = cx.hs, kbase = cx.kbase, dif = cx.dif, besta = cx.besta, bestk = cx.bestk;
+  int lasta = cx.lasta, more = cx.more, ncell = cx.ncell, mlo = cx.mlo, mhi = cx.mhi;
+  int rV = duo_V[lane], rHA = duo_HA[lane], rHB = duo_HB[lane];
+  u64 rT = ((u64) duo_Thi[lane] << 32) | duo_Tlo[lane];
   u32 st_iter = 0, st_cells = 0;                /* (scalar: one s_bcnt1 + two s_add per step) */
   if (!onm)
     return;
@@ -497,36 +506,40 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase, DuoCtx *cx)
       if (onm & ~(gom & bal(hs - ls <= 27) & bal(ncell <= cell_cap)))
         break;
     }
-  cx->n_cells += st_cells;  cx->n_iter += st_iter;  cx->n_half += st_iter * ((u32) __popcll(onm) >> 5);
+  { DuoCtx &c0 = duo_half[0];                   /* (every lane adds the same: one record counts for the wavefront) */
+    const u32 lo = c0.n_cells_lo + st_cells;
+    c0.n_cells_hi += (lo < st_cells) ? 1u : 0u;  c0.n_cells_lo = lo;
+    c0.n_iter += st_iter;  c0.n_half += st_iter * ((u32) __popcll(onm) >> 5);
+  }
   if (on)
-    { cx->V = rV;  cx->HA = rHA;  cx->HB = rHB;  cx->Tlo = (u32) rT;  cx->Thi = (u32) (rT >> 32);
-      cx->ls = ls;  cx->hs = hs;  cx->kbase = kbase;  cx->dif = dif;  cx->besta = besta;  cx->bestk = bestk;
-      cx->lasta = lasta;  cx->more = more;  cx->ncell = ncell;  cx->mlo = mlo;  cx->mhi = mhi;
+    { duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
+      cx.ls = ls;  cx.hs = hs;  cx.kbase = kbase;  cx.dif = dif;  cx.besta = besta;  cx.bestk = bestk;
+      cx.lasta = lasta;  cx.more = more;  cx.ncell = ncell;  cx.mlo = mlo;  cx.mhi = mhi;
     }
 }
 
 /* What the wave loop left for the halves with md == MD_RUN (the reference's loop conditions, in their order) */
-__device__ __forceinline__ void duo_classify(const ReportArgs &a, DuoCtx *cx)
-{ const int s = lane_id() & 31;
+__device__ __forceinline__ void duo_classify(const ReportArgs &a)
+{ DUO_CX(); const int s = lane_id() & 31;
   u32 *const errw = &a.counters[3];
-  if (cx->md != MD_RUN)
+  if (cx.md != MD_RUN)
     return;
-  if (cx->ncell > (int) a.cell_cap)
+  if (cx.ncell > (int) a.cell_cap)
     { if (s == 0) atomicOr(errw, DAMAR_ERR_CELLS);
-      cx->more = 0;  cx->ncell = 2;  cx->bad = 1;  cx->md = MD_END;
+      cx.more = 0;  cx.ncell = 2;  cx.bad = 1;  cx.md = MD_END;
     }
-  else if (!(cx->more && cx->lasta >= cx->besta - MAX_TRIM_LAG))
-    cx->md = MD_END;
-  else if (cx->hs < cx->ls)
+  else if (!(cx.more && cx.lasta >= cx.besta - MAX_TRIM_LAG))
+    cx.md = MD_END;
+  else if (cx.hs < cx.ls)
     { if (s == 0) atomicAdd(errw + 2, 1u);
-      cx->md = MD_END;
+      cx.md = MD_END;
     }
-  else if (cx->dif > cx->alen + cx->blen + 64)
+  else if (cx.dif > cx.alen + cx.blen + 64)
     { if (s == 0) atomicOr(errw, DAMAR_ERR_BAND);
-      cx->md = MD_END;
+      cx.md = MD_END;
     }
-  else if (cx->hs - cx->ls > 27)
-    cx->md = MD_OVF;
+  else if (cx.hs - cx.ls > 27)
+    cx.md = MD_OVF;
 }
 
 /* A half whose band outgrew its lanes borrows the whole wavefront: the band goes to the one-alignment-per-wavefront
@@ -535,8 +548,8 @@ __device__ __forceinline__ void duo_classify(const ReportArgs &a, DuoCtx *cx)
  * finishes the direction there (through wave_mem<REV> if it outgrows the wavefront too).  Called for one half at a time
  * (hsel = its lane base) with every lane active. */
 template <int REV>
-DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel, DuoCtx *cx)
-{ const ReportArgs &a = g_jobs[uni(job)];
+DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel)
+{ DuoCtx &cx = duo_half[hsel >> 5];              /* the record of the half that borrows the wavefront (every lane reads it) */ const ReportArgs &a = g_jobs[uni(job)];
   const int lane = lane_id();
   const int TS = a.tspace;
   const int m = REV ? -1 : 0;
@@ -548,13 +561,13 @@ DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel, D
 #define DUO_PTR_OF(T, ptr) ((T) (uintptr_t) (((u64) (u32) bcast_i((int) (u32) ((u64) (uintptr_t) (ptr) >> 32), src) << 32) | \
                                              (u32) bcast_i((int) (u32) (u64) (uintptr_t) (ptr), src)))
 #define DUO_SG(x) (REV ? -(x) : (x))
-  c.a0 = (u32) (bcast_i(cx->va0, src) - 16 * PK_PAD);  c.b0 = (u32) (bcast_i(cx->vb0, src) - 16 * PK_PAD);
+  c.a0 = (u32) (uni(cx.va0) - 16 * PK_PAD);  c.b0 = (u32) (uni(cx.vb0) - 16 * PK_PAD);
   c.aseq = a.ablk.bases + c.a0;  c.bseq = a.bblk.bases + c.b0;
   c.apk = a.ablk.pk;  c.bpk = a.bblk.pk;
-  c.alen = bcast_i(cx->alen, src);  c.blen = bcast_i(cx->blen, src);
+  c.alen = uni(cx.alen);  c.blen = uni(cx.blen);
   c.ts = TS;  c.ave = a.ave_path;  c.reach = a.reach;
   c.score = a.score;  c.table = a.table;  c.trim8 = trimtab;
-  const int diag = bcast_i(cx->diag, src), mida = bcast_i(cx->anti, src);
+  const int diag = uni(cx.diag), mida = uni(cx.anti);
   { const bool selfie = (c.aseq == c.bseq);
     c.minp = (selfie && diag >= 0) ? 1 : -BIG;
     c.maxp = (selfie && diag <= 0) ? -1 : BIG;
@@ -567,17 +580,17 @@ DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel, D
   c.err = &a.counters[3];
   c.atr = DUO_PTR_OF(u16 *, sc.atr);  c.btr = DUO_PTR_OF(u16 *, sc.btr);
 #undef DUO_PTR_OF
-  const int kbase = bcast_i(cx->kbase, src), ls = bcast_i(cx->ls, src), hs = bcast_i(cx->hs, src);
+  const int kbase = uni(cx.kbase), ls = uni(cx.ls), hs = uni(cx.hs);
   /* the band in the reference's coordinates: K = kbase - s, k = sigma * K */
   ws.low = REV ? ls - kbase : kbase - hs;  ws.hgh = REV ? hs - kbase : kbase - ls;
-  ws.dif = bcast_i(cx->dif, src);
-  { const int besta = bcast_i(cx->besta, src), bestk = bcast_i(cx->bestk, src);
+  ws.dif = uni(cx.dif);
+  { const int besta = uni(cx.besta), bestk = uni(cx.bestk);
     ws.besta = DUO_SG(besta);  ws.besty = DUO_SG((besta - bestk) >> 1);
   }
-  ws.lasta = DUO_SG(bcast_i(cx->lasta, src));
-  ws.more = bcast_i(cx->more, src);  ws.reachm = uni(cold[DC_REACHM]);
+  ws.lasta = DUO_SG(uni(cx.lasta));
+  ws.more = uni(cx.more);  ws.reachm = uni(cold[DC_REACHM]);
   ws.aclip = REV ? -BIG : BIG;  ws.bclip = REV ? BIG : -BIG;             /* (consumed by the clipping of the last step) */
-  ws.ncell = (u32) bcast_i(cx->ncell, src);
+  ws.ncell = (u32) uni(cx.ncell);
   { const int ta = uni(cold[DC_TRIM]), tk = uni(cold[DC_TRIM + 1]), ra = uni(cold[DC_REACH]), rk = uni(cold[DC_REACH + 1]);
     ws.trim.a = DUO_SG(ta);  ws.trim.y = DUO_SG((ta - tk) >> 1);  ws.trim.d = uni(cold[DC_TRIM + 2]);
     ws.trim.ha = uni(cold[DC_TRIM + 3]);  ws.trim.hb = uni(cold[DC_TRIM + 4]);
@@ -590,16 +603,16 @@ DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel, D
   { const int k = ws.low + ((lane - ws.low) & 63);
     const bool in = k <= ws.hgh;
     const int sl = (hsel + (in ? kbase - DUO_SG(k) : 0)) << 2;
-    const int nV = __builtin_amdgcn_ds_bpermute(sl, cx->V);
-    const int nHA = __builtin_amdgcn_ds_bpermute(sl, cx->HA), nHB = __builtin_amdgcn_ds_bpermute(sl, cx->HB);
+    const int nV = duo_V[sl >> 2];
+    const int nHA = duo_HA[sl >> 2], nHB = duo_HB[sl >> 2];
     r.V = in ? DUO_SG(nV) : edge;
     { const int ga = (int) ((u32) nHA >> PK_HBITS), gb = (int) ((u32) nHB >> PK_HBITS);
       const int hai = REV ? DUO_GREV - ga : ga, hbi = REV ? DUO_GREV - gb : gb;
       r.HA = (nHA & PK_HMASK) | (hai << PK_HBITS);  r.HB = (nHB & PK_HMASK) | (hbi << PK_HBITS);
       r.NA = REV ? hai - 1 : hai + 1;  r.NB = REV ? hbi - 1 : hbi + 1;
     }
-    { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) cx->Tlo);
-      const u32 th = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) cx->Thi);
+    { const u32 tl = duo_Tlo[sl >> 2];
+      const u32 th = duo_Thi[sl >> 2];
       r.T = ((u64) th << 32) | tl;
     }
   }
@@ -620,25 +633,25 @@ DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel, D
       const u32 th = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) (r.T >> 32));
       if (mine)
         { const int hai = (int) ((u32) nHA >> PK_HBITS), hbi = (int) ((u32) nHB >> PK_HBITS);
-          cx->V = in ? DUO_SG(nV) : DUO_EDGE;
-          cx->HA = (nHA & PK_HMASK) | ((REV ? DUO_GREV - hai : hai) << PK_HBITS);
-          cx->HB = (nHB & PK_HMASK) | ((REV ? DUO_GREV - hbi : hbi) << PK_HBITS);
-          cx->Tlo = tl;  cx->Thi = th;
-          cx->mlo += nkbase - cx->kbase;  cx->mhi += nkbase - cx->kbase;
-          cx->kbase = nkbase;  cx->ls = nls;  cx->hs = nhs;
-          cx->md = MD_RUN;
+          duo_V[lane] = in ? DUO_SG(nV) : DUO_EDGE;
+          duo_HA[lane] = (nHA & PK_HMASK) | ((REV ? DUO_GREV - hai : hai) << PK_HBITS);
+          duo_HB[lane] = (nHB & PK_HMASK) | ((REV ? DUO_GREV - hbi : hbi) << PK_HBITS);
+          duo_Tlo[lane] = tl;  duo_Thi[lane] = th;
+          cx.mlo += nkbase - cx.kbase;  cx.mhi += nkbase - cx.kbase;
+          cx.kbase = nkbase;  cx.ls = nls;  cx.hs = nhs;
+          cx.md = MD_RUN;
         }
     }
   else
     { if (!ws.stopped)
         wave_mem<REV>(c, mida, ws);
       if (mine)
-        { cx->md = MD_END;  cx->bad = ws.bad; }
+        { cx.md = MD_END;  cx.bad = ws.bad; }
     }
   if (mine)
-    { cx->dif = ws.dif;  cx->besta = DUO_SG(ws.besta);  cx->bestk = DUO_SG(ws.besta) - 2 * DUO_SG(ws.besty);
-      cx->lasta = DUO_SG(ws.lasta);  cx->more = ws.narrow ? ws.more : 0;
-      cx->ncell = (int) ws.ncell;
+    { cx.dif = ws.dif;  cx.besta = DUO_SG(ws.besta);  cx.bestk = DUO_SG(ws.besta) - 2 * DUO_SG(ws.besty);
+      cx.lasta = DUO_SG(ws.lasta);  cx.more = ws.narrow ? ws.more : 0;
+      cx.ncell = (int) ws.ncell;
     }
   cold[DC_REACHM] = ws.reachm;  cold[DC_ACLIP] = -1;  cold[DC_BCLIP] = 64;
   cold[DC_TRIM] = DUO_SG(ws.trim.a);  cold[DC_TRIM + 1] = DUO_SG(ws.trim.a) - 2 * DUO_SG(ws.trim.y);  cold[DC_TRIM + 2] = ws.trim.d;
@@ -793,30 +806,30 @@ __device__ __forceinline__ int duo_walk(const Cell *cells, int side, int head, i
  * md == MD_END: the first lane of the half walks the two pebble chains (chain_to_trace).  Leaves the pass's results in
  * cx and the half in MD_TASK with m = -1 (the reverse pass is next) or, after the reverse pass, in MD_END with m = 1
  * as the sign that the alignment is complete. */
-DUO_PIECE void duo_finish(int job, SlotScratch sc, DuoCtx *cx)
-{ const ReportArgs &a = g_jobs[uni(job)];
+DUO_PIECE void duo_finish(int job, SlotScratch sc)
+{ DUO_CX(); const ReportArgs &a = g_jobs[uni(job)];
   const int lane = lane_id(), hb = lane & 32, s = lane & 31;
-  const bool fin = cx->md == MD_END;
-  const int m = cx->m;
+  const bool fin = cx.md == MD_END;
+  const int m = cx.m;
   const int *const cold = duo_cold + (hb >> 1);
   const int TS = a.tspace;
-  const int boff = (a.comp & 1) ? (cx->blen % TS) : 0;
-  const int guard = 4 * (cx->alen + cx->blen) + 1024;
+  const int boff = (a.comp & 1) ? (cx.blen % TS) : 0;
+  const int guard = 4 * (cx.alen + cx.blen) + 1024;
   u32 *const errw = &a.counters[3];
   int rx = 0, ry = 0, rd = 0, nt = 0;
   wave_mem_sync();
-  if (fin && !cx->bad && s < 2)                      /* lane 0: the A chain, lane 1: the B chain */
+  if (fin && !cx.bad && s < 2)                      /* lane 0: the A chain, lane 1: the B chain */
     { int ta = cold[DC_TRIM], tk = cold[DC_TRIM + 1], td = cold[DC_TRIM + 2], tha = cold[DC_TRIM + 3], thb = cold[DC_TRIM + 4];
       if (cold[DC_REACHM] >= 0 && a.reach)
         { ta = cold[DC_REACH];  tk = cold[DC_REACH + 1];  td = cold[DC_REACH + 2];  tha = cold[DC_REACH + 3];  thb = cold[DC_REACH + 4]; }
       const int ty_ = (ta - tk) >> 1;
       const int trimy = (ty_ ^ m) - m, trimx = ((ta - ty_) ^ m) - m;
-      const int head = s ? thb : tha, rootidx = s ? cx->rootb : cx->roota, off = s ? boff : 0;
+      const int head = s ? thb : tha, rootidx = s ? cx.rootb : cx.roota, off = s ? boff : 0;
       u16 *const T = s ? sc.btr : sc.atr;
       if (m == 0)
-        nt = duo_walk<0>(sc.cells, s, head, rootidx, TS, off, cx->anti, trimx, trimy, td, T, 0, guard, errw);
+        nt = duo_walk<0>(sc.cells, s, head, rootidx, TS, off, cx.anti, trimx, trimy, td, T, 0, guard, errw);
       else
-        nt = duo_walk<1>(sc.cells, s, head, rootidx, TS, off, cx->anti, trimx, trimy, td, T, s ? cx->btlen : cx->atlen, guard, errw);
+        nt = duo_walk<1>(sc.cells, s, head, rootidx, TS, off, cx.anti, trimx, trimy, td, T, s ? cx.btlen : cx.atlen, guard, errw);
       rx = trimx;  ry = trimy;  rd = td;
     }
   wave_mem_sync();
@@ -824,14 +837,14 @@ DUO_PIECE void duo_finish(int job, SlotScratch sc, DuoCtx *cx)
   const int at = hget(nt, hb, 0), bt = hget(nt, hb, 1);
   if (fin)
     { if (m == 0)
-        { cx->aepos = rx;  cx->bepos = ry;  cx->diffs = rd;  cx->atlen = at;  cx->btlen = bt;
-          cx->aback = 0;  cx->bback = 0;
-          cx->m = -1;  cx->md = MD_TASK;  cx->bad = 0;
+        { cx.aepos = rx;  cx.bepos = ry;  cx.diffs = rd;  cx.atlen = at;  cx.btlen = bt;
+          cx.aback = 0;  cx.bback = 0;
+          cx.m = -1;  cx.md = MD_TASK;  cx.bad = 0;
         }
       else
-        { cx->abpos = rx;  cx->bbpos = ry;  cx->diffs += rd;
-          cx->aback = at;  cx->bback = bt;  cx->atlen += at;  cx->btlen += bt;
-          cx->m = 1;
+        { cx.abpos = rx;  cx.bbpos = ry;  cx.diffs += rd;
+          cx.aback = at;  cx.bback = bt;  cx.atlen += at;  cx.btlen += bt;
+          cx.m = 1;
         }
     }
 }
@@ -912,15 +925,15 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
   u64  nidx = 0, cpair = 0, lidx = 0, end = 0, h2 = 0, fp = 0;
   int  ar = 0, br = 0, amark2 = 0, clo = BIG, chi = -BIG, sd = 0;
   int  tmb = 0, tme = 0;              /* datander: the panel of positions [tmb, tme) being scanned */
-  DuoCtx cx;
+  DUO_CX();
   cx.md = MD_SCAN;  cx.m = 0;  cx.bad = 0;
   cx.va0 = cx.vb0 = 16 * PK_PAD;  cx.alen = cx.blen = 0;
-  cx.V = DUO_EDGE;  cx.HA = cx.HB = 0;  cx.Tlo = cx.Thi = 0;
+  duo_V[lane] = DUO_EDGE;  duo_HA[lane] = duo_HB[lane] = 0;  duo_Tlo[lane] = duo_Thi[lane] = 0;
   cx.ls = cx.hs = 15;  cx.kbase = 0;  cx.dif = 0;  cx.besta = cx.bestk = cx.lasta = 0;  cx.more = 0;  cx.ncell = 2;
   cx.mlo = cx.mhi = 0;  cx.alim = cx.blim = 0;  cx.offa = cx.offb = 0;  cx.pa0 = cx.pb0 = 0;
   cx.diag = cx.anti = 0;  cx.roota = cx.rootb = 0;
   cx.aepos = cx.bepos = cx.abpos = cx.bbpos = cx.diffs = cx.atlen = cx.btlen = cx.aback = cx.bback = 0;
-  cx.n_cells = 0;  cx.n_iter = cx.n_half = 0;
+  cx.n_cells_lo = cx.n_cells_hi = 0;  cx.n_iter = cx.n_half = 0;
 
   for (;;)
     { /* A: the halves without an alignment in hand advance their scan until they have one or have run out of work */
@@ -1182,16 +1195,16 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
 
       /* B: Local_Alignment (align.c:1904-2097 for low == hgh == diag), one pass at a time per half */
       if (wany(cx.md == MD_TASK))
-        { duo_begin(a.job, cbase, &cx);
-          duo_classify(a, &cx);                           /* (the seed diagonal may already have ended the pass) */
+        { duo_begin(a.job, cbase);
+          duo_classify(a);                           /* (the seed diagonal may already have ended the pass) */
         }
       if (wany(cx.md == MD_RUN))
         {
 #ifdef DAMAR_PROF
           const unsigned long long pf0 = wall_clock64();
 #endif
-          duo_loop(a.job, trimtab, cbase, &cx);           /* every half in MD_RUN can step: the loop tests behind a step */
-          duo_classify(a, &cx);
+          duo_loop(a.job, trimtab, cbase);           /* every half in MD_RUN can step: the loop tests behind a step */
+          duo_classify(a);
 #ifdef DAMAR_PROF
           PROF_ADD(15, wall_clock64() - pf0);  PROF_ADD(29, 1);
 #endif
@@ -1205,12 +1218,12 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
 #endif
             for (int h = 0; h < 64; h += 32)
               if ((ov >> h) & 1)
-                { if (bcast_i(cx.m, h))
-                    duo_solo<1>(a.job, trimtab, sc, h, &cx);
+                { if (uni(duo_half[h >> 5].m))
+                    duo_solo<1>(a.job, trimtab, sc, h);
                   else
-                    duo_solo<0>(a.job, trimtab, sc, h, &cx);
+                    duo_solo<0>(a.job, trimtab, sc, h);
                 }
-            duo_classify(a, &cx);
+            duo_classify(a);
 #ifdef DAMAR_PROF
             PROF_ADD(13, wall_clock64() - pf0);
 #endif
@@ -1221,7 +1234,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
 #ifdef DAMAR_PROF
           const unsigned long long pf0 = wall_clock64();
 #endif
-          duo_finish(a.job, sc, &cx);
+          duo_finish(a.job, sc);
 #ifdef DAMAR_PROF
           PROF_ADD(14, wall_clock64() - pf0);
 #endif
@@ -1278,9 +1291,10 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
         break;
     }
   if (lane == 0)
-    { atomicAdd((unsigned long long *) &a.counters[DAMAR_CNT_CELLS], (unsigned long long) cx.n_cells);
-      atomicAdd((unsigned long long *) &a.counters[DAMAR_CNT_HALFSTEPS], (unsigned long long) cx.n_half);
-      atomicAdd((unsigned long long *) &a.counters[DAMAR_CNT_ITERS], (unsigned long long) cx.n_iter);
+    { const DuoCtx &c0 = duo_half[0];
+      atomicAdd((unsigned long long *) &a.counters[DAMAR_CNT_CELLS], ((unsigned long long) c0.n_cells_hi << 32) | c0.n_cells_lo);
+      atomicAdd((unsigned long long *) &a.counters[DAMAR_CNT_HALFSTEPS], (unsigned long long) c0.n_half);
+      atomicAdd((unsigned long long *) &a.counters[DAMAR_CNT_ITERS], (unsigned long long) c0.n_iter);
     }
 }
 
