@@ -43,7 +43,19 @@
  */
 
 #ifndef DUO_WAVES
-#define DUO_WAVES 8                     /* resident wavefronts per SIMD the kernel and its pieces are compiled for (VGPR budget 512 /
+#define DUO_WAVES 8
+
+/* experiment switches (scripts/build_exp.sh; results are WRONG with any of them -- they only price one part of the kernel):
+   DAMAR_EXP_SCANONLY seeds are scanned but no alignment is started, DAMAR_EXP_NOWALK the pebble chains are not walked,
+   DAMAR_EXP_NOPEBBLE (only with NOWALK) the pebbles are not stored */
+#ifdef DAMAR_EXP_NOPEBBLE
+#ifndef DAMAR_EXP_NOWALK
+#error "DAMAR_EXP_NOPEBBLE needs DAMAR_EXP_NOWALK: a walk over stale cells need not end"
+#endif
+#define DUO_EXP_PEBBLE(x)
+#else
+#define DUO_EXP_PEBBLE(x) x
+#endif                     /* resident wavefronts per SIMD the kernel and its pieces are compiled for (VGPR budget 512 /
                                            DUO_WAVES; the launch bound of the kernel is handed down to the functions it calls): the wave
                                            loop fits 64 VGPRs without a spill.  Report ms per config-2 step, every kernel alone on the
                                            machine: 180 / 167 / 153 at 5 / 6 / 8 wavefronts per SIMD (profiles/r04_sweeps.txt) */
@@ -116,7 +128,7 @@ struct DuoCtx
 };
 __shared__ DuoCtx duo_half[2];
 /* band state of the lanes: lane s of a half owns K = kbase - s */
-__shared__ int duo_V[64], duo_HA[64], duo_HB[64];
+__shared__ int duo_V[64], duo_HA[64], duo_HB[64], duo_acc[64];
 __shared__ u32 duo_Tlo[64], duo_Thi[64];
 #define DUO_CX()  DuoCtx &cx = duo_half[lane_id() >> 5]
 
@@ -421,7 +433,7 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
                       { ga += 1;
                         if (idx < cell_cap)
                           { const v2u32 c = { (u32) hax | ((u32) ((ga ^ m) - m) << PK_HBITS), w1 };
-                            gcell[cbase + (u32) idx] = c;
+                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
                           }
                         hax = idx;
                       }
@@ -436,7 +448,7 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
                       { gb += 1;
                         if (idx < cell_cap)
                           { const v2u32 c = { (u32) hbx | ((u32) ((gb ^ m) - m) << PK_HBITS), w1 };
-                            gcell[cbase + (u32) idx] = c;
+                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
                           }
                         hbx = idx;
                       }
@@ -826,10 +838,14 @@ DUO_PIECE void duo_finish(int job, SlotScratch sc)
       const int trimy = (ty_ ^ m) - m, trimx = ((ta - ty_) ^ m) - m;
       const int head = s ? thb : tha, rootidx = s ? cx.rootb : cx.roota, off = s ? boff : 0;
       u16 *const T = s ? sc.btr : sc.atr;
+#ifndef DAMAR_EXP_NOWALK
       if (m == 0)
         nt = duo_walk<0>(sc.cells, s, head, rootidx, TS, off, cx.anti, trimx, trimy, td, T, 0, guard, errw);
       else
         nt = duo_walk<1>(sc.cells, s, head, rootidx, TS, off, cx.anti, trimx, trimy, td, T, s ? cx.btlen : cx.atlen, guard, errw);
+#else
+      (void) head; (void) rootidx; (void) off; (void) T; (void) guard; (void) errw;
+#endif
       rx = trimx;  ry = trimy;  rd = td;
     }
   wave_mem_sync();
@@ -896,6 +912,34 @@ __device__ __forceinline__ void pk_emit(const ReportArgs &a, const SlotScratch &
               a.recs[ri] = rec;
             }
         }
+    }
+}
+
+/* The seeds of a 32-lane group that fall into one bucket (`peers`) add to its score through the LAST of them: the group's
+ * sums are formed in LDS and one lane per bucket does a plain read-modify-write.  (An atomic per seed is executed at the
+ * memory side on this machine -- TCC_EA0_ATOMIC == TCC_ATOMIC -- one 32-byte transaction each, and the slot's bucket
+ * arrays are private to its half anyway.)  sv = score[d] as read before the group. */
+__device__ __forceinline__ void duo_bucket_add(const SlotScratch &sc, bool in, bool last, u32 peers, int d, int sv, int add, int ap)
+{ const int lane = lane_id();
+  __hip_atomic_store(&duo_acc[lane], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                     /* (LDS executes one wavefront's operations in order) */
+  if (in)
+    __hip_atomic_fetch_add(&duo_acc[(lane & 32) + (31 - __clz((int) peers))], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  if (last)
+    { sc.score[d] = sv + __hip_atomic_load(&duo_acc[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      sc.lastp[d] = ap;
+    }
+}
+
+/* pass 3: a bucket is reset by the first lane of every run of seeds in it (every store is a line written through) */
+__device__ __forceinline__ void duo_bucket_reset(const SlotScratch &sc, bool in, int d)
+{ const int lane = lane_id(), hb = lane & 32, s = lane & 31;
+  const int dd = in ? d : BIG;
+  const int dp = hget(dd, hb, (s + 31) & 31);
+  if (in && (s == 0 || dp != dd))
+    { sc.score[d] = 0;
+      sc.lastp[d] = 0;
     }
 }
 
@@ -969,6 +1013,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                       const bool in = dg != 0;
                       const int  d = dg >> W;
                       int  prev = in ? sc.lastp[d] : 0;
+                      const int sv = in ? sc.score[d] : 0;
                       u32  peers = hmask(wballot(in), hb);
                       { const u32 db = (u32) (d - mind);
                         for (int bit = 0; bit < a.bucket_bits; bit++)
@@ -982,12 +1027,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                       const int  pap = hget(apos, hb, pl);
                       if (below) prev = pap;
                       const bool last = in && ((peers >> s) >> 1) == 0;
-                      if (in)
-                        { const int add = (apos - prev >= K) ? K : apos - prev;
-                          atomicAdd(&sc.score[d], add);
-                          if (last)
-                            sc.lastp[d] = apos;
-                        }
+                      duo_bucket_add(sc, in, last, peers, d, sv, (apos - prev >= K) ? K : apos - prev, apos);
                       wave_mem_sync();
                     }
                   fp = (u64) tmb;
@@ -1026,10 +1066,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                       for (int base = tmb; base < tme; base += 32)
                         { const int apos = base + s;
                           const int dg = (apos < tme) ? dist[nidx + (u64) apos] : 0;
-                          if (dg != 0)
-                            { sc.score[dg >> W] = 0;
-                              sc.lastp[dg >> W] = 0;
-                            }
+                          duo_bucket_reset(sc, dg != 0, dg >> W);
                         }
                       wave_mem_sync();
                       if (tme > cx.alen)
@@ -1118,6 +1155,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                           const int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
                           const int  d  = in ? (seed_diag(keys[f], vals, f, pmask, dbits) >> W) : BIG;
                           int  prev = in ? sc.lastp[d] : 0;
+                          const int sv = in ? sc.score[d] : 0;
                           u32  peers = hmask(wballot(in), hb);
                           { const u32 db = (u32) (d - mind);
                             for (int bit = 0; bit < a.bucket_bits; bit++)
@@ -1131,12 +1169,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                           const int  pap = hget(ap, hb, pl);
                           if (below) prev = pap;
                           const bool last = in && ((peers >> s) >> 1) == 0;
-                          if (in)
-                            { const int add = (ap - prev >= K) ? K : ap - prev;
-                              atomicAdd(&sc.score[d], add);
-                              if (last)
-                                sc.lastp[d] = ap;
-                            }
+                          duo_bucket_add(sc, in, last, peers, d, sv, (ap - prev >= K) ? K : ap - prev, ap);
                           wave_mem_sync();
                         }
                       fp = lidx;
@@ -1172,7 +1205,9 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                 }
               if (found)
                 { cx.diag = sdg;  cx.anti = sap + (sap - sdg);
+#ifndef DAMAR_EXP_SCANONLY
                   cx.m = 0;  cx.md = MD_TASK;
+#endif
                   if (s == 0)
                     atomicAdd(a.nfilt, 1u);
                 }
@@ -1180,11 +1215,8 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                 { /* pass 3: reset the touched buckets (filter.c:2407-2411) */
                   for (u64 base = lidx; base < end; base += 32)
                     { const u64 f = base + s;
-                      if (f < end)
-                        { const int d = seed_diag(keys[f], vals, f, pmask, dbits) >> W;
-                          sc.score[d] = 0;
-                          sc.lastp[d] = 0;
-                        }
+                      const bool in = f < end;
+                      duo_bucket_reset(sc, in, in ? (seed_diag(keys[f], vals, f, pmask, dbits) >> W) : 0);
                     }
                   wave_mem_sync();
                   nidx = h2;
