@@ -26,6 +26,7 @@
  * 32-bit granules serve sorts of fewer than 2^30 items, 64-bit ones the rest.
  */
 #include <atomic>
+#include <type_traits>
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -33,9 +34,9 @@ SEED_PRIO_VAR(g_sort_prio)
 SEED_PRIO_SETTER(damar_sort_set_prio, g_sort_prio)
 
 #ifndef OS_THREADS
-#define OS_THREADS 512                       /* threads per workgroup: 512 (tiles of 8192 keys: longer runs per digit, half the
-                                                look-back words) or 256 (one wavefront per SIMD: the shape that still finds room
-                                                on a CU whose register file is mostly held by a resident report launch) */
+#define OS_THREADS 1024                      /* threads per workgroup: 1024 (x 8 keys: 16 wavefronts of <= 64 registers, two workgroups
+                                                per CU) or 512 (x 16 keys) -- both tiles of 8192 keys: long runs per digit -- or
+                                                256 (x 16 keys: tiles of 4096) */
 #endif
 #ifndef OS_MINW
 #define OS_MINW    4                         /* wavefronts per SIMD the pass kernel is compiled for */
@@ -48,6 +49,9 @@ SEED_PRIO_SETTER(damar_sort_set_prio, g_sort_prio)
 #define LB_COUNT   1u
 #define LB_PREFIX  2u
 #define LB_SPINS   (1u << 24)
+#ifndef LB_AHEAD
+#define LB_AHEAD   8                         /* look-back words requested per round trip */
+#endif
 
 /* workspace: [0] error word | [256..) P x 256 digit totals | [8448..) P tickets | [16384..) two look-back regions */
 #define WS_HIST    256
@@ -201,7 +205,8 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
   /* keys and payload are staged through the SAME buffer one after the other */
   __shared__ KeyT skey[OS_TILE];
   u32 *const sval = (u32 *) skey;
-  __shared__ u32  cnt[OS_WAVES][256];
+  typedef typename std::conditional<(OS_WAVES > 8), u16, u32>::type CntT;      /* (a wavefront's count of a digit is at most 64 * IT) */
+  __shared__ CntT cnt[OS_WAVES][256];
   __shared__ u32  dstart[256];
   __shared__ u32  gadj[256];
   __shared__ u32  lds4[4];
@@ -216,34 +221,41 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
     if (threadIdx.x < 256)
       cnt[i][threadIdx.x] = 0;
   __syncthreads();
-  const u32 tile  = s_tile;
+  const u32 tile  = (u32) __builtin_amdgcn_readfirstlane((int) s_tile);
   const u64 tbase = (u64) tile * OS_TILE;
-  const u64 wbase = tbase + (u64) w * OS_WSPAN;
+  /* tile-local 32-bit indexes against lane-uniform tile pointers: one offset register per thread, 32-bit bound checks */
+  const u32 have = (n - tbase < (u64) OS_TILE) ? (u32) (n - tbase) : (u32) OS_TILE;
+  const u32 t0 = (u32) w * OS_WSPAN + (u32) l;
+  const KeyT *const tin = kin + tbase;
 
   KeyT key[IT];
   u32  rnk[IT];
 #pragma unroll
   for (int r = 0; r < IT; r++)
-    { const u64 i = wbase + (u64) r * 64 + l;
-      key[r] = (i < n) ? kin[i] : (KeyT) 0;
+    { const u32 ti = t0 + (u32) r * 64;
+      key[r] = tin[ti < have ? ti : have - 1];               /* (no branch around a load; what a lane beyond the end reads is never used) */
     }
 #pragma unroll
   for (int r = 0; r < IT; r++)
-    { const u64  i  = wbase + (u64) r * 64 + l;
-      const bool ok = i < n;
+    { const bool ok = t0 + (u32) r * 64 < have;
       const u32  d  = (u32) (key[r] >> shift) & mask;
-      u64 peers = __ballot(ok);
+      /* the lanes with my digit: for every bit, the ballot of the bit or its complement -- (~m) ^ (-bit) is m where the
+         bit is set and ~m where it is clear, so a bit costs a sign-extending field extract, a compare and two 3-input
+         logic operations (the plain `bit ? m : ~m` compiled to nine) */
+      const u64 okm = __ballot(ok);
+      u32 plo = (u32) okm, phi = (u32) (okm >> 32);
 #pragma unroll
       for (int b = 0; b < 8; b++)
-        { const bool bit = (d >> b) & 1;
-          const u64  m = __ballot(bit);
-          peers &= bit ? m : ~m;
+        { const int t  = ((int) (d << (31 - b))) >> 31;
+          const u64 nm = ~__ballot(t < 0);
+          plo &= (u32) nm ^ (u32) t;
+          phi &= (u32) (nm >> 32) ^ (u32) t;
         }
       const u32 before = cnt[w][d];
-      const u32 mine   = (u32) __popcll(peers & lanes_below(l));
+      const u32 mine   = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
       rnk[r] = before + mine;
       if (ok && mine == 0)
-        cnt[w][d] = before + (u32) __popcll(peers);
+        cnt[w][d] = (CntT) (before + (u32) __popc(plo) + (u32) __popc(phi));
     }
   __syncthreads();
 
@@ -254,7 +266,7 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
 #pragma unroll
       for (int i = 0; i < OS_WAVES; i++)
         { const u32 c = cnt[i][threadIdx.x];
-          cnt[i][threadIdx.x] = run;
+          cnt[i][threadIdx.x] = (CntT) run;
           run += c;
         }
       tot = run;
@@ -270,8 +282,7 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
 
 #pragma unroll
   for (int r = 0; r < IT; r++)
-    { const u64 i = wbase + (u64) r * 64 + l;
-      if (i < n)
+    { if (t0 + (u32) r * 64 < have)
         { const u32 d  = (u32) (key[r] >> shift) & mask;
           const u32 lp = dstart[d] + cnt[w][d] + rnk[r];
           rnk[r] = lp;                                         /* position inside the tile's output */
@@ -279,34 +290,60 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
         }
     }
 
-  /* look back: items of digit d in all earlier tiles */
+  /* look back: items of digit d in all earlier tiles.  A word is polled by a load that goes to memory (agent scope: the
+     L2s of the XCDs are not coherent), and in steady state the nearest inclusive prefix is about 20 tiles back
+     (tools/sortbench -DOS_STATS) -- walked one tile per round trip that was most of a tile's time.  LB_AHEAD words are
+     requested per round trip and consumed in order: a prefix ends the walk, an empty word ends the round. */
   if (threadIdx.x < 256)
     { GT before = 0;
       if (tile > 0)
         { u32 t = tile - 1, spins = 0;
-          while (true)
-            { const GT g = lb_load<GT>(&lb[(u64) t * 256 + threadIdx.x]);
-              const u32 st = (u32) (g >> SH);
-              if (st == 0)
+#ifdef OS_STATS
+          u32 nstep = 0;
+#endif
+          bool found = false;
+          while (!found)
+            { GT g[LB_AHEAD];
+#pragma unroll
+              for (int k = 0; k < LB_AHEAD; k++)                 /* (below tile 0 the word of tile 0 again: its prefix ends the walk before that) */
+                g[k] = lb_load<GT>(&lb[(u64) (t >= (u32) k ? t - (u32) k : 0u) * 256 + threadIdx.x]);
+              int used = LB_AHEAD;
+#pragma unroll
+              for (int k = 0; k < LB_AHEAD; k++)
+                if (used == LB_AHEAD)
+                  { const u32 st = (u32) (g[k] >> SH);
+                    if (st == 0)
+                      used = k;
+                    else
+                      { before += g[k] & VM;
+#ifdef OS_STATS
+                        nstep += 1;
+#endif
+                        if (st == LB_PREFIX)
+                          { found = true;  used = -1; }
+                      }
+                  }
+              if (found)
+                break;
+              t -= (u32) used;                                   /* tile 0 publishes a prefix: t never passes it */
+              if (used < LB_AHEAD)                               /* an earlier tile has not published its count yet */
                 { if (++spins > LB_SPINS)
                     { atomicOr(err, 1u);
                       break;
                     }
                   __builtin_amdgcn_s_sleep(1);
-                  continue;
                 }
-              before += g & VM;
-              if (st == LB_PREFIX)
-                break;
-              t -= 1;                                          /* tile 0 publishes a prefix: t never passes it */
             }
+#ifdef OS_STATS                                                /* tools/sortbench: look-back steps, polls of an empty word, tiles */
+          if (threadIdx.x == 0)
+            { atomicAdd(err + 1, nstep);  atomicAdd(err + 2, spins);  atomicAdd(err + 3, 1u); }
+#endif
           lb_store<GT>(&lb[(u64) tile * 256 + threadIdx.x], ((GT) LB_PREFIX << SH) | ((before + tot) & VM));
         }
       gadj[threadIdx.x] = dbase + (u32) before - ex;
     }
   __syncthreads();
 
-  const u32 have = (n - tbase < (u64) OS_TILE) ? (u32) (n - tbase) : (u32) OS_TILE;
   u32 gdst[HV ? IT : 1];                                 /* where this thread's output positions go (n < 2^32) */
 #pragma unroll
   for (int q = 0; q < IT; q++)
@@ -325,12 +362,13 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
         }
     }
   if (HV)
-    { __syncthreads();
+    { const u32 *const tvin = vin + tbase;
+      __syncthreads();
 #pragma unroll
       for (int r = 0; r < IT; r++)
-        { const u64 i = wbase + (u64) r * 64 + l;
-          if (i < n)                                           /* (the payload is loaded only now: registers) */
-            sval[rnk[r]] = vin[i];
+        { const u32 ti = t0 + (u32) r * 64;
+          if (ti < have)                                       /* (the payload is loaded only now: registers) */
+            sval[rnk[r]] = tvin[ti];
         }
       __syncthreads();
 #pragma unroll
@@ -348,7 +386,7 @@ static int G_sort_threads = 0;              /* 0: not chosen yet */
 
 /* tile shape of the sorts to come: 512 or 256 threads per workgroup, 16 keys per thread (a 256 x 8 shape within 64 VGPRs
    was measured: slower alone and beside a report launch, profiles/r03_sweeps.txt) */
-void damar_sort_set_threads(int threads) { G_sort_threads = (threads == 256) ? 256 : 512; }
+void damar_sort_set_threads(int threads) { G_sort_threads = (threads == 256 || threads == 512) ? threads : 1024; }
 
 static int sort_threads(void)
 { if (G_sort_threads == 0)
@@ -376,7 +414,7 @@ static void onesweep_passes(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lob
   u32 *err = (u32 *) ws, *ghist = (u32 *) (ws + WS_HIST), *ctr = (u32 *) (ws + WS_CTR);
   GT  *lbr[2] = { (GT *) (ws + WS_LB), (GT *) (ws + WS_LB + region) };
   HIP_CHECK(hipMemsetAsync(ws, 0, WS_LB, st));
-  if (sort_threads() == 512)
+  if (sort_threads() >= 512)
     { const u64 nt = (n + (u64) OH_THREADS * OH_ITEMS - 1) / ((u64) OH_THREADS * OH_ITEMS);
       const u64 maxit = OH_BINMAX / ((OH_THREADS / 32) * OH_ITEMS);   /* tiles one workgroup may see */
       u64 grid = nt < 512 ? nt : 512;                                 /* two rounds of one workgroup per CU */
@@ -437,7 +475,8 @@ static int onesweep_impl(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lobit,
     }
   const int shape = sort_threads();
   if (n < (1ull << 30))
-    { if (shape == 512) onesweep_passes<KeyT, u32, HV, 512, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+    { if (shape == 1024)     onesweep_passes<KeyT, u32, HV, 1024, 8>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
+      else if (shape == 512) onesweep_passes<KeyT, u32, HV, 512, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
       else              onesweep_passes<KeyT, u32, HV, 256, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
     }
   else                  /* 2^30 items and more: 64-bit look-back words, one shape */

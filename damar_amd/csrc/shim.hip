@@ -547,9 +547,10 @@ static void sort_check(const void *sw)
   HIP_CHECK(hipMemcpyAsync(&H_serr[H_nserr++], damar_sort_error_word(sw), sizeof(u32), hipMemcpyDeviceToHost, G_st));
 }
 
-/* Tile shape of the radix sort (radix_sort.hip): workgroups of 512 threads are the faster shape on an empty machine; beside
-   a resident report launch (which leaves 128 registers per SIMD) only one wavefront per SIMD finds room, i.e. the
-   256-thread shape.  DAMAR_SORT_THREADS overrides. */
+/* Tile shape of the radix sort (radix_sort.hip): 1024 threads x 8 keys -- the 8192-key tile of the 512 x 16 shape in half
+   the registers, so that two workgroups of 16 wavefronts fill a CU (measured alone and beside a resident report launch:
+   profiles/r04_sweeps.txt; the 256-thread shape of round 3 is the slowest of the three now that a report wavefront
+   holds 64 registers).  DAMAR_SORT_THREADS overrides. */
 static bool overlap_on(void);
 static bool corun_on(void);
 static void pick_sort_shape(void)
@@ -558,7 +559,7 @@ static void pick_sort_shape(void)
     { const char *e = getenv("DAMAR_SORT_THREADS");
       forced = e ? atoi(e) : 0;
     }
-  damar_sort_set_threads(forced ? forced : (corun_on() ? 256 : 512));
+  damar_sort_set_threads(forced ? forced : 1024);
 }
 
 static int ilog2_ceil(u64 n)

@@ -134,6 +134,12 @@ static double time_sort(int kind, u64 n, int lo, int hi, int reps)
       if (r > 0) tot += ms;
     }
   if (check_err(ws)) { fprintf(stderr, "look-back timeout flagged\n"); exit(1); }
+#ifdef OS_STATS
+  { u32 e[4];
+    HIP_CHECK(hipMemcpy(e, damar_sort_error_word(ws), 16, hipMemcpyDeviceToHost));
+    printf("   look-back of digit 0, last sort: %.2f steps and %.2f empty polls per tile (%u tiles)\n", e[1] / (double) e[3], e[2] / (double) e[3], e[3]);
+  }
+#endif
   hipFree(ws); hipFree(src); hipFree(k0); hipFree(k1); hipFree(v0); hipFree(v1);
   return tot / reps;
 }
