@@ -80,6 +80,7 @@ __device__ __forceinline__ int pk_prefix_max(int x)
 }
 
 #define DUO_PIECE __device__ __noinline__
+#define DUO_PART  __device__ __forceinline__   /* a part of the one piece duo_run: a call costs its callee-saved registers in scratch */
 
 #define DUO_EDGE   (-BIG)
 #define DUO_GREV   (1 << 14)                    /* G = DUO_GREV - grid index in a reverse pass */
@@ -235,7 +236,7 @@ __device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, co
 
 /* Wave 0 on the seed diagonal (align.c:491-626 / 1203-1340) and the clipping behind it, for the halves with
    md == MD_TASK: sets up direction cx.m of the task (cx.diag, cx.anti).  Every lane of a half computes the same. */
-DUO_PIECE void duo_begin(int job, u32 cbase)
+DUO_PART void duo_begin(int job, u32 cbase)
 { DUO_NAMES()
   DUO_CX();
   const bool on = cx.md == MD_TASK;
@@ -818,9 +819,10 @@ __device__ __forceinline__ int duo_walk(const Cell *cells, int side, int head, i
  * md == MD_END: the first lane of the half walks the two pebble chains (chain_to_trace).  Leaves the pass's results in
  * cx and the half in MD_TASK with m = -1 (the reverse pass is next) or, after the reverse pass, in MD_END with m = 1
  * as the sign that the alignment is complete. */
-DUO_PIECE void duo_finish(int job, SlotScratch sc)
+DUO_PART void duo_finish(int job)
 { DUO_CX(); const ReportArgs &a = g_jobs[uni(job)];
   const int lane = lane_id(), hb = lane & 32, s = lane & 31;
+  const SlotScratch sc = slot_scratch(a, 2 * (int) blockIdx.x + (hb >> 5));      /* (derived here: nothing of it is live across the wave loop) */
   const bool fin = cx.md == MD_END;
   const int m = cx.m;
   const int *const cold = duo_cold + (hb >> 1);
@@ -864,6 +866,44 @@ DUO_PIECE void duo_finish(int job, SlotScratch sc)
         }
     }
 }
+
+/* One turn of the Local_Alignment machine for the two halves, as ONE call: start the passes that are due, step the
+ * halves that can step until one of them has an event, and finish the passes that are over -- unless a half left the
+ * lanes (MD_OVF): then the caller sends it through duo_solo first and finishes with duo_finish_piece.  (begin, loop and
+ * finish were three calls; each call writes and re-reads the callee-saved registers it uses -- 4 KB per wavefront -- and
+ * that was most of the kernel's write traffic, profiles/r04_sweeps.txt.) */
+DUO_PIECE void duo_run(int job, const u32 *trimtab, u32 cbase)
+{ DUO_CX(); const ReportArgs &a = g_jobs[uni(job)];
+  if (wany(cx.md == MD_TASK))
+    { duo_begin(job, cbase);
+      duo_classify(a);                               /* (the seed diagonal may already have ended the pass) */
+    }
+  if (wany(cx.md == MD_RUN))
+    {
+#ifdef DAMAR_PROF
+      const unsigned long long pf0 = wall_clock64();
+#endif
+      duo_loop(job, trimtab, cbase);                 /* every half in MD_RUN can step: the loop tests behind a step */
+      duo_classify(a);
+#ifdef DAMAR_PROF
+      PROF_ADD(15, wall_clock64() - pf0);  PROF_ADD(29, 1);
+#endif
+    }
+  if (wany(cx.md == MD_OVF))
+    return;
+  if (wany(cx.md == MD_END))
+    {
+#ifdef DAMAR_PROF
+      const unsigned long long pf0 = wall_clock64();
+#endif
+      duo_finish(job);
+#ifdef DAMAR_PROF
+      PROF_ADD(14, wall_clock64() - pf0);
+#endif
+    }
+}
+
+DUO_PIECE void duo_finish_piece(int job) { duo_finish(job); }
 
 /***** the per-half state machine of the report loop ******************************************************/
 
@@ -1226,21 +1266,8 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
         }
 
       /* B: Local_Alignment (align.c:1904-2097 for low == hgh == diag), one pass at a time per half */
-      if (wany(cx.md == MD_TASK))
-        { duo_begin(a.job, cbase);
-          duo_classify(a);                           /* (the seed diagonal may already have ended the pass) */
-        }
-      if (wany(cx.md == MD_RUN))
-        {
-#ifdef DAMAR_PROF
-          const unsigned long long pf0 = wall_clock64();
-#endif
-          duo_loop(a.job, trimtab, cbase);           /* every half in MD_RUN can step: the loop tests behind a step */
-          duo_classify(a);
-#ifdef DAMAR_PROF
-          PROF_ADD(15, wall_clock64() - pf0);  PROF_ADD(29, 1);
-#endif
-        }
+      if (wany(cx.md == MD_TASK || cx.md == MD_RUN))
+        duo_run(a.job, trimtab, cbase);
       { const u64 ov = wballot(cx.md == MD_OVF);
         if (ov)
           {
@@ -1259,18 +1286,10 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
 #ifdef DAMAR_PROF
             PROF_ADD(13, wall_clock64() - pf0);
 #endif
+            if (wany(cx.md == MD_END))               /* (duo_run left them for behind the excursion) */
+              duo_finish_piece(a.job);
           }
       }
-      if (wany(cx.md == MD_END))
-        {
-#ifdef DAMAR_PROF
-          const unsigned long long pf0 = wall_clock64();
-#endif
-          duo_finish(a.job, sc);
-#ifdef DAMAR_PROF
-          PROF_ADD(14, wall_clock64() - pf0);
-#endif
-        }
 
       /* C: what the reference does with the path (filter.c:2318-2380), for the halves whose reverse pass is over */
       if (wany(cx.md == MD_END))
