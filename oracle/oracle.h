@@ -104,8 +104,8 @@ int oracle_compute_trace_pts(const char *aseq, int alen, const char *bseq, int b
 int oracle_compute_trace_mid(const char *aseq, int alen, const char *bseq, int blen, const Path *path,
                              int tspace, int mode, int *script, int *diffs);
 
-/* Redundancy handling shared with the product's host tail (filter.c:1804-2077);
- * implemented in damar_amd/csrc/host/redundancy.c. */
+/* Redundancy handling (filter.c:1573-2077): the oracle's own statement in oracle/redundancy.c, behind the interface of
+ * damar_amd/csrc/host/damar_host.h (the product's is damar_amd/csrc/host/redundancy.c and is not linked here). */
 
 #ifdef __cplusplus
 }
