@@ -501,7 +501,7 @@ def datander_leg(api, driver, L, base, tandem_frac):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)       # (2 until round 4: a step is 0.25 s, and two steps are mostly the pipeline filling and draining)
     ap.add_argument("--warmup", type=int, default=2)      # (the second warm-up step allocates the second pinned landing buffer of the host pipeline)
     ap.add_argument("--config", type=int, default=0, help="BASELINE config of the database: 2 or 3 (default: 2 on one GPU, 3 on several)")
     ap.add_argument("--threads-param", type=int, default=16, help="daligner -j (slice rule only; the reference md5s were made with -j16)")

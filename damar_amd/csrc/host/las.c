@@ -279,26 +279,28 @@ int Write_Overlap(FILE *out, Overlap *ovl, int tbytes)
   return 0;
 }
 
-typedef struct
-{ Overlap ovl;
-  int     seq;
+typedef struct                   /* one gathered record: where it lies, and its place in the gather */
+{ const Overlap *ovl;
+  const char    *trace;          /* its trace bytes (NULL: none) */
+  int            seq;
 } Keyed;
 
 /* align.c:6104-6164 SORT_OVL; the reference's last key is the record's address in
  * the gathered array, here its gather index (same order for a stable gather). */
 static int by_overlap(const void *x, const void *y)
-{ const Keyed *l = (const Keyed *) x, *r = (const Keyed *) y;
+{ const Keyed *kl = (const Keyed *) x, *kr = (const Keyed *) y;
+  const Overlap *l = kl->ovl, *r = kr->ovl;
   int cl, cr;
-  if (l->ovl.aread != r->ovl.aread) return l->ovl.aread - r->ovl.aread;
-  if (l->ovl.bread != r->ovl.bread) return l->ovl.bread - r->ovl.bread;
-  cl = COMP(l->ovl.flags);
-  cr = COMP(r->ovl.flags);
+  if (l->aread != r->aread) return l->aread - r->aread;
+  if (l->bread != r->bread) return l->bread - r->bread;
+  cl = COMP(l->flags);
+  cr = COMP(r->flags);
   if (cl != cr) return cl - cr;
-  if (l->ovl.path.abpos != r->ovl.path.abpos) return l->ovl.path.abpos - r->ovl.path.abpos;
-  if (l->ovl.path.aepos != r->ovl.path.aepos) return l->ovl.path.aepos - r->ovl.path.aepos;
-  if (l->ovl.path.bbpos != r->ovl.path.bbpos) return l->ovl.path.bbpos - r->ovl.path.bbpos;
-  if (l->ovl.path.bepos != r->ovl.path.bepos) return l->ovl.path.bepos - r->ovl.path.bepos;
-  return (l->seq < r->seq) ? -1 : (l->seq > r->seq);
+  if (l->path.abpos != r->path.abpos) return l->path.abpos - r->path.abpos;
+  if (l->path.aepos != r->path.aepos) return l->path.aepos - r->path.aepos;
+  if (l->path.bbpos != r->path.bbpos) return l->path.bbpos - r->path.bbpos;
+  if (l->path.bepos != r->path.bepos) return l->path.bepos - r->path.bepos;
+  return (kl->seq < kr->seq) ? -1 : (kl->seq > kr->seq);
 }
 
 static FILE *open_las(const char *path, int tspace)
@@ -308,6 +310,7 @@ static FILE *open_las(const char *path, int tspace)
     { fprintf(stderr, "[ERROR] - Write_Overlap_Buffer: Cannot open file %s for writing\n", path);
       exit(1);
     }
+  setvbuf(out, NULL, _IOFBF, 1 << 20);           /* (a record is two small fwrites: 4 KB of stdio buffer is a write() per 25 records) */
   fwrite(&zero, sizeof(int64), 1, out);
   fwrite(&tspace, sizeof(int), 1, out);
   return out;
@@ -342,10 +345,10 @@ static Keyed *sort_keyed(Keyed *all, int n)
     { qsort(all, (size_t) n, sizeof(Keyed), by_overlap);
       return all;
     }
-  lo = hi = all[0].ovl.aread;
+  lo = hi = all[0].ovl->aread;
   for (i = 1; i < n; i++)
-    { if (all[i].ovl.aread < lo) lo = all[i].ovl.aread;
-      if (all[i].ovl.aread > hi) hi = all[i].ovl.aread;
+    { if (all[i].ovl->aread < lo) lo = all[i].ovl->aread;
+      if (all[i].ovl->aread > hi) hi = all[i].ovl->aread;
     }
   first = (int *) calloc((size_t) (hi - lo) + 2, sizeof(int));
   out   = (Keyed *) malloc(sizeof(Keyed) * (size_t) n);
@@ -355,11 +358,11 @@ static Keyed *sort_keyed(Keyed *all, int n)
       return all;
     }
   for (i = 0; i < n; i++)
-    first[all[i].ovl.aread - lo + 1] += 1;
+    first[all[i].ovl->aread - lo + 1] += 1;
   for (i = 1; i <= hi - lo + 1; i++)
     first[i] += first[i - 1];
   for (i = 0; i < n; i++)
-    out[first[all[i].ovl.aread - lo]++] = all[i];
+    out[first[all[i].ovl->aread - lo]++] = all[i];
   /* first[b] is now the end of bucket b */
   for (i = 0, k = 0; k <= hi - lo; k++)
     { int e = first[k];
@@ -378,6 +381,12 @@ static Keyed *sort_keyed(Keyed *all, int n)
   free(first);
   free(all);
   return out;
+}
+
+static void write_keyed(FILE *out, const Keyed *k, int tbytes)
+{ Overlap o = *k->ovl;
+  o.path.trace = (void *) k->trace;
+  Write_Overlap(out, &o, tbytes);
 }
 
 /* align.c:6166-6367 on an explicit set of per-thread buffers */
@@ -405,9 +414,8 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
       for (j = 0; j < b->otop; j++)
         { if (s->only_identity && b->ovls[j].aread != b->ovls[j].bread)
             continue;
-          all[n].ovl = b->ovls[j];
-          if (all[n].ovl.path.trace != NULL)
-            all[n].ovl.path.trace = ((char *) b->trace) + ((uintptr_t) all[n].ovl.path.trace - 1);
+          all[n].ovl = b->ovls + j;                       /* (the records stay where they are: 16 bytes per record are sorted) */
+          all[n].trace = (b->ovls[j].path.trace != NULL) ? ((const char *) b->trace) + ((uintptr_t) b->ovls[j].path.trace - 1) : NULL;
           all[n].seq = n;
           n += 1;
         }
@@ -424,7 +432,7 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
         snprintf(path1, sizeof(path1), "%s.las", ablock);
       out = open_las(path1, tspace);
       for (j = 0; j < n; j++)
-        Write_Overlap(out, &all[j].ovl, tbytes);
+        write_keyed(out, all + j, tbytes);
       close_las(out, n);
     }
   else
@@ -453,14 +461,14 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
         const char *second = (bid < aid) ? path1 : path2;
         out = open_las(first, tspace);
         for (j = 0, nh = 0; j < n; j++, nh++)
-          { if (all[j].ovl.aread > lastRead)
+          { if (all[j].ovl->aread > lastRead)
               break;
-            Write_Overlap(out, &all[j].ovl, tbytes);
+            write_keyed(out, all + j, tbytes);
           }
         close_las(out, nh);
         out = open_las(second, tspace);
         for (nh = 0; j < n; j++, nh++)
-          Write_Overlap(out, &all[j].ovl, tbytes);
+          write_keyed(out, all + j, tbytes);
         close_las(out, nh);
       }
     }

@@ -1141,6 +1141,42 @@ static int64 tail_range(const LaRecord *recs, const u32 *ord, size_t lo, size_t 
       const int al = ablock->reads[ar].rlen, bl = bblock->reads[br].rlen;
       const int doA = (al >= hgap_min);
       const int doB = (symmetric && bl >= hgap_min && (ar != br || !self || !comp));   /* filter.c:2300-2301 */
+      if (j - i == 1)
+        { /* one alignment for the pair -- the common case: nothing for Handle_Redundancies to look at, so the records
+             (filter.c:2470-2483: the A view, then the B view) are written straight from the downloaded traces, which
+             Compress_TraceTo8 may shorten in place (the landing buffer is this comparison's own) */
+          const LaRecord &r = recs[ord[i]];
+          Overlap ovl;
+          memset(&ovl, 0, sizeof(ovl));
+          ovl.flags = (uint32) comp;
+          if (doA)
+            { ovl.aread = ar + ablock->ufirst;  ovl.bread = br + bblock->ufirst;
+              ovl.path.tlen = r.atlen;  ovl.path.diffs = r.diffs;
+              ovl.path.abpos = r.abpos;  ovl.path.bbpos = r.bbpos;  ovl.path.aepos = r.aepos;  ovl.path.bepos = r.bepos;
+              ovl.path.trace = (void *) (tpool + r.toff);
+              if (ts <= TRACE_XOVR)
+                Compress_TraceTo8(&ovl, 1);
+              AddOverlapToBuffer(obuf, &ovl, (ts <= TRACE_XOVR) ? 1 : 2);
+              ncheck += 1;
+            }
+          if (doB)
+            { ovl.aread = br + bblock->ufirst;  ovl.bread = ar + ablock->ufirst;
+              ovl.path.tlen = r.btlen;  ovl.path.diffs = r.diffs;
+              if (comp)                                          /* align.c:2039-2042 */
+                { ovl.path.abpos = bl - r.bepos;  ovl.path.bbpos = al - r.aepos;
+                  ovl.path.aepos = bl - r.bbpos;  ovl.path.bepos = al - r.abpos;
+                }
+              else                                               /* align.c:2059-2062 */
+                { ovl.path.abpos = r.bbpos;  ovl.path.bbpos = r.abpos;  ovl.path.aepos = r.bepos;  ovl.path.bepos = r.aepos; }
+              ovl.path.trace = (void *) (tpool + r.toff + r.atlen);
+              if (ts <= TRACE_XOVR)
+                Compress_TraceTo8(&ovl, 1);
+              AddOverlapToBuffer(obuf, &ovl, (ts <= TRACE_XOVR) ? 1 : 2);
+              ncheck += 1;
+            }
+          i = j;
+          continue;
+        }
       am.clear();  bm.clear();  tp.top = 0;
       for (size_t q = i; q < j; q++)
         { const LaRecord &r = recs[ord[q]];
@@ -1242,26 +1278,37 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
         c += 1;
       cut[t] = c;
     }
+  /* The Align_Spec holds one buffer per -j thread and the writer gathers them all and sorts (align.c:6166-6200), so tail
+     thread t appends to buffer t: no private buffer to copy over afterwards (a read pair's records stay together in one
+     buffer, which is all the sort's tie-break needs).  With fewer -j buffers than tail threads: private buffers, appended
+     in order. */
+  const bool direct = Num_Threads(spec) >= nthr;
   std::vector<Overlap_IO_Buffer *> part(nthr, (Overlap_IO_Buffer *) NULL);
   std::vector<int64> got(nthr, 0);
   std::vector<std::thread> th;
   for (int t = 0; t < nthr; t++)
-    { part[t] = CreateOverlapBuffer(4 * nthr, obuf->tbytes ? obuf->tbytes : 1, obuf->no_trace);
-      if (part[t] == NULL)
-        die();
+    { if (direct)
+        part[t] = obuf + t;
+      else
+        { part[t] = CreateOverlapBuffer(4 * nthr, obuf->tbytes ? obuf->tbytes : 1, obuf->no_trace);
+          if (part[t] == NULL)
+            die();
+        }
       th.emplace_back([&, t] { got[t] = tail_range(recs, ord.data(), cut[t], cut[t + 1], tpool, ablock, bblock,
                                                     self, comp, ts, part[t], jp.symmetric, jp.hgap_min); });
     }
   int64 ncheck = 0;
   for (int t = 0; t < nthr; t++)
     { th[t].join();
-      if (damar_append_overlap_buffer(obuf, part[t]))
-        { fprintf(stderr, "damar: FATAL: out of memory appending overlaps\n");
-          die();
+      if (!direct)
+        { if (damar_append_overlap_buffer(obuf, part[t]))
+            { fprintf(stderr, "damar: FATAL: out of memory appending overlaps\n");
+              die();
+            }
+          free(part[t]->ovls);
+          free(part[t]->trace);
+          free(part[t]);
         }
-      free(part[t]->ovls);
-      free(part[t]->trace);
-      free(part[t]);
       ncheck += got[t];
     }
   return ncheck;
