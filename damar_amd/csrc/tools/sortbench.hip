@@ -106,7 +106,7 @@ static int do_check(void)
         nbad += check_one(4, n, 32, 40, skew); ncase++;
         if (nbad) { printf("FAILED after %d cases\n", ncase); return 1; }
       }
-  printf("check ok: %d cases (threads %d, items %d)\n", ncase, sort_threads(), sort_threads() == 128 ? 8 : 16);
+  printf("check ok: %d cases (threads %d, items %d)\n", ncase, sort_threads(), sort_threads() == 1024 ? 8 : 16);
   return 0;
 }
 
@@ -159,7 +159,7 @@ int main(int argc, char **argv)
 { if (argc > 1 && strcmp(argv[1], "check") == 0)
     return do_check();
   const int reps = argc > 2 ? atoi(argv[2]) : 10;
-  printf("variant: shape %d (512 / 256: threads x 16 keys, 128: 256 threads x 8 keys), minw %d\n", sort_threads(), OS_MINW);
+  printf("variant: shape %d (1024: threads x 8 keys, 512 / 256: threads x 16 keys), minw %d\n", sort_threads(), OS_MINW);
   report("kmer index, packed u64 split", 4, 135000000ull, 32, 60, reps);
   report("kmer index, u32 + u32",        0, 135000000ull, 0, 28, reps);
   report("seed pairs, packed u64",       3, 61000000ull, 15, 58, reps);
