@@ -474,7 +474,10 @@ static int onesweep_impl(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lobit,
       _exit(1);
     }
   const int shape = sort_threads();
-  if (n < (1ull << 30))
+  static int lb64 = -1;                    /* test hook (tests/test_gpu_sort.py): the 64-bit look-back words at any size */
+  if (lb64 < 0)
+    lb64 = getenv("DAMAR_SORT_LB64") != NULL;
+  if (n < (1ull << 30) && !lb64)
     { if (shape == 1024)     onesweep_passes<KeyT, u32, HV, 1024, 8>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
       else if (shape == 512) onesweep_passes<KeyT, u32, HV, 512, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
       else              onesweep_passes<KeyT, u32, HV, 256, 16>(k0, v0, k1, v1, n, lobit, hibit, ohi, olo, (char *) work, st);
