@@ -285,7 +285,8 @@ def end_to_end(dbdir, root, nblocks, md5_name, repeats=3, gpus=1):
     out = {"value": None, "unit": "aligned bp/s", "wall_s": best,
            "what": "damar_amd/bin/daligner -P <HPCdaligner plan>%s: process start, DB read from tmpfs, complement, "
                    "upload, index builds, all block pairs, sorted .las on tmpfs (best of %d cold runs; tidy_wall_s = the same "
-                   "with the worker's teardown inside the command, back_to_back_wall_s = wall per command of two commands in a row)"
+                   "with the worker's teardown inside the command, back_to_back_wall_s = wall per command of two commands in a row: "
+                   "the second waits at the teardown gate, host/damar_gate.h, until the first one's worker has left the GPU)"
                    % (" -G%d (one forked worker per GPU, regions + stealing)" % gpus if gpus > 1 else "", repeats),
            "identical_to_reference": None if chk is None else chk["identical"]}
     out.update(extra)

@@ -19,6 +19,7 @@
 
 #include "damar_filter.h"
 #include "damar_hip.h"
+#include "damar_gate.h"
 
 typedef struct
 { char   **name;
@@ -163,7 +164,9 @@ int main(int argc, char *argv[])
     { fprintf(stderr, "datander: cannot start the reader thread\n");
       exit(1);
     }
-  damar_hip_init(gpu >= 0 ? gpu : (getenv("DAMAR_DEVICE") ? atoi(getenv("DAMAR_DEVICE")) : 0));    /* beside the first read */
+  gpu = gpu >= 0 ? gpu : (getenv("DAMAR_DEVICE") ? atoi(getenv("DAMAR_DEVICE")) : 0);
+  damar_gate_wait(gpu);                              /* not into the teardown of the command before this one (damar_gate.h) */
+  damar_hip_init(gpu);                               /* beside the first read */
 
   for (i = 0; i < R.n; i++)
     { HITS_DB *blk = R.blk + i;
@@ -192,6 +195,7 @@ int main(int argc, char *argv[])
   fflush(NULL);
   if (done_fd >= 0)
     { char b = 1;
+      damar_gate_hold(gpu);                          /* from here on this process is only tearing down */
       if (write(done_fd, &b, 1) != 1)
         _exit(1);
       close(done_fd);

@@ -382,3 +382,42 @@ def test_node_scheduler_work_list_covers_every_block_pair_once(built, tmp_path, 
             assert max(cost.values()) * len(cost) <= 1.05 * sum(cost.values()), cost
     else:
         assert len(cost) == 1 and max(n for v in pairs.values() for _, n in v) > 1
+
+
+def test_teardown_gate_makes_the_next_worker_wait_for_the_one_that_is_leaving(tmp_path):
+    """host/damar_gate.h: a worker takes the per-GPU lock before it reports "done" and keeps it until its process is gone;
+    a worker that starts waits at the gate (at most two seconds) -- and does not wait for one that is still computing."""
+    import time
+    src = tmp_path / "gate.c"
+    src.write_text('#include "damar_gate.h"\n#include <string.h>\n'
+                   'int main(int argc, char **argv)\n'
+                   '{ if (strcmp(argv[1], "hold") == 0) { damar_gate_hold(3); usleep(atoi(argv[2]) * 1000); return 0; }\n'
+                   '  if (strcmp(argv[1], "busy") == 0) { usleep(atoi(argv[2]) * 1000); return 0; }\n'
+                   '  damar_gate_wait(3); return 0; }\n')
+    exe = str(tmp_path / "gate")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(ROOT, "damar_amd", "csrc", "host"), "-o", exe, str(src)], check=True)
+    env = dict(os.environ, DAMAR_GATE_DIR=str(tmp_path))
+    t0 = time.time()
+    subprocess.run([exe, "wait"], env=env, check=True)
+    assert time.time() - t0 < 0.2                                  # nobody there: the gate is open
+    h = subprocess.Popen([exe, "hold", "600"], env=env)
+    time.sleep(0.15)
+    t0 = time.time()
+    subprocess.run([exe, "wait"], env=env, check=True)
+    dt = time.time() - t0
+    h.wait()
+    assert 0.3 < dt < 1.5, dt                                      # waited for the holder's process to go
+    b = subprocess.Popen([exe, "busy", "600"], env=env)
+    time.sleep(0.1)
+    t0 = time.time()
+    subprocess.run([exe, "wait"], env=env, check=True)
+    assert time.time() - t0 < 0.2                                  # a worker that still computes holds nothing
+    b.wait()
+    h = subprocess.Popen([exe, "hold", "4000"], env=env)
+    time.sleep(0.15)
+    t0 = time.time()
+    subprocess.run([exe, "wait"], env=env, check=True)
+    dt = time.time() - t0
+    h.kill()
+    h.wait()
+    assert 1.8 < dt < 3.0, dt                                      # a holder that does not go away: the gate opens after two seconds
