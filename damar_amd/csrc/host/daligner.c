@@ -857,7 +857,8 @@ static int plan_main(const Opts *base, const char *planfile)
 { char ***ltok = NULL;                 /* the plan's daligner lines, tokenised */
   int   *lntok = NULL, nl = 0;
   int    i, j, same_masks = 1;
-  pthread_t reader[2];                 /* two: a block's read + complement + upload take ~95 ms, a plan line less */
+  pthread_t reader[8];                 /* DAMAR_PLAN_READERS of them (2): a block's read + complement + upload take ~95 ms, a plan line less */
+  int nreaders = 2;
   int    have_reader = 0;
 
   if (base->gpus != NULL)
@@ -957,7 +958,9 @@ static int plan_main(const Opts *base, const char *planfile)
           }
         PB_ahead = PB_n;
         PB_opts = o0;
-        for (have_reader = 0; have_reader < 2; have_reader++)
+        if (getenv("DAMAR_PLAN_READERS") != NULL && atoi(getenv("DAMAR_PLAN_READERS")) >= 1)
+          nreaders = atoi(getenv("DAMAR_PLAN_READERS")) > 8 ? 8 : atoi(getenv("DAMAR_PLAN_READERS"));
+        for (have_reader = 0; have_reader < nreaders; have_reader++)
           if (pthread_create(&reader[have_reader], NULL, plan_reader, NULL) != 0)
             { fprintf(stderr, "daligner: cannot start the block reader thread\n");
               exit(1);
@@ -1029,7 +1032,9 @@ static int plan_main(const Opts *base, const char *planfile)
     }
   free(ltok);
   free(lntok);
+  mark("blocks and indexes released");
   damar_set_async(0);
+  mark("host pipeline stopped");
   if (getenv("DAMAR_CLIPROF"))
     { fprintf(stderr, "cli: %d plan lines, %d index builds; wall ms:", nl, PB_builds);
       for (i = 0; i < 8; i++)
