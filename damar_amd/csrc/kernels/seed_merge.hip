@@ -615,27 +615,42 @@ void pair_heads_mark(const K *__restrict__ keys, u64 nhits, int pbits, int minhi
   const int l = lane_id(), w = threadIdx.x >> 6;
   const u64 base = (u64) blockIdx.x * DAMAR_SCAN_TILE;
   u32 mine = 0;
-  for (int r = 0; r < PH_ROUNDS; r++)
-    { const u64 i = base + (u64) r * 256u + threadIdx.x;
-      bool f = false;
-      if (i < nhits)
-        { const K pr = keys[i] >> pbits;
-          if ((i == 0 || (keys[i - 1] >> pbits) != pr) && i + (u64) (minhit - 1) < nhits &&
-              (keys[i + (u64) (minhit - 1)] >> pbits) == pr)
-            { f = true;
-              for (int t = 0; t < nthr; t++)
-                { u64 e = send[t];
-                  if (i < e)
-                    { if (i + (u64) minhit >= e) f = false;
-                      break;
+  /* four rounds' loads are issued before the first is looked at (from clamped addresses, so that none sits behind a
+     branch): one round at a time the workgroup waited out a memory round trip per round, 16 per tile */
+  for (int r0 = 0; r0 < PH_ROUNDS; r0 += 4)
+    { K k0[4], km[4], kp[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        { const u64 i = base + (u64) (r0 + q) * 256u + threadIdx.x;
+          const u64 ic = i < nhits ? i : nhits - 1;
+          const u64 ip = ic + (u64) (minhit - 1);
+          k0[q] = keys[ic];
+          km[q] = keys[ic > 0 ? ic - 1 : 0];
+          kp[q] = keys[ip < nhits ? ip : nhits - 1];
+        }
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        { const int r = r0 + q;
+          const u64 i = base + (u64) r * 256u + threadIdx.x;
+          bool f = false;
+          if (i < nhits)
+            { const K pr = k0[q] >> pbits;
+              if ((i == 0 || (km[q] >> pbits) != pr) && i + (u64) (minhit - 1) < nhits && (kp[q] >> pbits) == pr)
+                { f = true;
+                  for (int t = 0; t < nthr; t++)
+                    { u64 e = send[t];
+                      if (i < e)
+                        { if (i + (u64) minhit >= e) f = false;
+                          break;
+                        }
                     }
                 }
             }
-        }
-      const u64 m = __ballot(f);
-      if (l == 0)
-        { bits[(base >> 6) + (u64) r * 4 + w] = m;
-          mine += (u32) __popcll(m);
+          const u64 m = __ballot(f);
+          if (l == 0)
+            { bits[(base >> 6) + (u64) r * 4 + w] = m;
+              mine += (u32) __popcll(m);
+            }
         }
     }
   if (l == 0) wsum[w] = mine;
@@ -828,8 +843,12 @@ void pair_screen(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64
     n += 1;
   if (n <= SCREEN_MAX && (int) ((keys[i + (u64) (n - 1)] >> dbits) & pmask) <= SCREEN_PANEL)
     { bool ok = false;
+      int dlast = 0x7fffffff;
       for (int x = 0; x < n && !ok; x++)
         { const int dx = seed_diag(keys[i + (u64) x], vals, i + (u64) x, pmask, dbits) >> binshift;
+          if (dx == dlast)                       /* the sums depend on the bucket only: the seed before this one had them */
+            continue;
+          dlast = dx;
           int s0 = 0, s1 = 0, p0 = 0, p1 = 0;
           for (int y = 0; y < n; y++)
             { const u64 ky = keys[i + (u64) y];
