@@ -1362,6 +1362,7 @@ static int node_worker(int w, int gpu, int nworkers, int sharers, const Opts *o,
   damar_async_drain();
   S->stat[w].units = nunits;  S->stat[w].stolen = stolen;  S->stat[w].builds = PB_builds;
   S->stat[w].wall_ms = wall_ms() - t0;
+  damar_gate_hold(GATE_gpu);                         /* from here on this worker is only tearing down (damar_gate.h) */
   atomic_store(&S->done[w], 1);
   return 0;
 }

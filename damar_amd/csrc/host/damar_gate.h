@@ -49,8 +49,16 @@ static void damar_gate_wait(int gpu)
 
 /* just before a worker tells its caller that every file is closed; the lock goes with the process */
 static void damar_gate_hold(int gpu)
-{ int fd = damar_gate_open(gpu);
-  if (fd >= 0)
-    (void) flock(fd, LOCK_EX);                       /* (behind another worker's teardown, if there is one) */
+{ int fd = damar_gate_open(gpu), i;
+  if (fd < 0)
+    return;
+  for (i = 0; i < 10; i++)                           /* another worker of the same GPU may be leaving just now: it holds the
+                                                        gate then, and this one does not queue up behind it for long */
+    { struct timespec ts = { 0, 5000000 };
+      if (flock(fd, LOCK_EX | LOCK_NB) == 0)
+        return;                                      /* (kept open: held until the process is gone) */
+      nanosleep(&ts, NULL);
+    }
+  close(fd);
 }
 #endif
