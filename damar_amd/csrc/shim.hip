@@ -1125,7 +1125,7 @@ static void hostbuf_put(HostBuf *h)
 
 /* One contiguous range [lo, hi) of the ordered records (whole read pairs): filter.c:2442-2483
  * per pair, results appended to obuf. */
-static int64 tail_range(const LaRecord *recs, const u32 *ord, size_t lo, size_t hi, const u16 *tpool,
+static int64 tail_range(const LaRecord *recs, const u32 *ord, const u64 *okey, size_t lo, size_t hi, const u16 *tpool,
                         const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, int ts,
                         Overlap_IO_Buffer *obuf, int symmetric, int hgap_min)
 { int64 ncheck = 0;
@@ -1135,7 +1135,18 @@ static int64 tail_range(const LaRecord *recs, const u32 *ord, size_t lo, size_t 
   size_t i = lo;
   while (i < hi)
     { size_t j = i;
-      while (j < hi && recs[ord[j]].item == recs[ord[i]].item)
+      /* the records arrive in completion order and are visited in item order: every record and every trace is a
+         cache miss in 300 MB of landing buffer unless it is asked for ahead (records 16 ahead, their traces 8 ahead) */
+      if (i + 16 < hi)
+        __builtin_prefetch(&recs[ord[i + 16]]);
+      if (i + 8 < hi)
+        { const LaRecord &pr = recs[ord[i + 8]];
+          const char *pt = (const char *) (tpool + pr.toff);
+          const size_t nb = sizeof(u16) * (size_t) (pr.atlen + pr.btlen);
+          for (size_t o = 0; o < nb; o += 64)
+            __builtin_prefetch(pt + o);
+        }
+      while (j < hi && (okey[j] >> 32) == (okey[i] >> 32))          /* (the item sits in the key: no record is touched for this) */
         j += 1;
       const int ar = recs[ord[i]].aread, br = recs[ord[i]].bread;
       const int al = ablock->reads[ar].rlen, bl = bblock->reads[br].rlen;
@@ -1226,38 +1237,47 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
                       const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec,
                       const JobParams &jp, int jobid = 0, int njobs = 1)
 { const int ts = Trace_Spacing(spec);
-  /* a launch over several comparisons: the records of this one (top byte of seq) */
-  std::vector<u32> mine;
-  size_t nrecs = nrecs_all;
-  if (njobs > 1)
-    { for (size_t q = 0; q < nrecs_all; q++)
-        if ((int) (recs[q].seq >> DAMAR_SEQ_BITS) == jobid)
-          mine.push_back((u32) q);
-      nrecs = mine.size();
-    }
-  auto at = [&](size_t q) -> size_t { return njobs > 1 ? mine[q] : q; };
-  /* (work item, sequence) order = the reference's order of read pairs and of the alignments
-     inside one: a counting sort on the item (a wave emits the records of its item in sequence
-     order; the insertion pass below only guards that) */
+  /* (work item, sequence) order = the reference's order of read pairs and of the alignments inside one.  ONE pass over
+     the records (of a launch over several comparisons: those of this one, top byte of seq) collects 8-byte keys
+     item << 32 | seq; everything after that -- a counting sort on the item (a wave emits the records of its item in
+     sequence order; the insertion pass only guards that), the pair boundaries, the thread cuts -- works on the keys,
+     which stay in cache, instead of on 48-byte records scattered over the landing buffer */
+  const bool tprof = getenv("DAMAR_HOSTPROF") != NULL;
+  const double tp0 = tprof ? now_ms() : 0.;
+  std::vector<u64> key;
+  std::vector<u32> idx;
+  key.reserve(nrecs_all);  idx.reserve(nrecs_all);
+  u32 maxitem = 0;
+  for (size_t q = 0; q < nrecs_all; q++)
+    if (njobs <= 1 || (int) (recs[q].seq >> DAMAR_SEQ_BITS) == jobid)
+      { const u32 it = recs[q].item;
+        key.push_back(((u64) it << 32) | (u64) recs[q].seq);
+        idx.push_back((u32) q);
+        if (it > maxitem) maxitem = it;
+      }
+  const size_t nrecs = key.size();
+  const double tp1 = tprof ? now_ms() : 0.;
   std::vector<u32> ord(nrecs);
-  { u32 maxitem = 0;
+  std::vector<u64> okey(nrecs);
+  { std::vector<u32> first((size_t) maxitem + 2, 0);
     for (size_t q = 0; q < nrecs; q++)
-      if (recs[at(q)].item > maxitem) maxitem = recs[at(q)].item;
-    std::vector<u32> first((size_t) maxitem + 2, 0);
-    for (size_t q = 0; q < nrecs; q++)
-      first[recs[at(q)].item + 1] += 1;
+      first[(size_t) (key[q] >> 32) + 1] += 1;
     for (size_t q = 1; q < first.size(); q++)
       first[q] += first[q - 1];
     for (size_t q = 0; q < nrecs; q++)
-      ord[first[recs[at(q)].item]++] = (u32) at(q);
+      { const u32 at = first[(size_t) (key[q] >> 32)]++;
+        ord[at] = idx[q];  okey[at] = key[q];
+      }
     for (size_t q = 1; q < nrecs; q++)
-      { const u32 x = ord[q];
+      { const u64 x = okey[q];
+        const u32 xi = ord[q];
         size_t r = q;
-        while (r > 0 && recs[ord[r - 1]].item == recs[x].item && recs[ord[r - 1]].seq > recs[x].seq)
-          { ord[r] = ord[r - 1];  r -= 1; }
-        ord[r] = x;
+        while (r > 0 && okey[r - 1] > x && (okey[r - 1] >> 32) == (x >> 32))
+          { okey[r] = okey[r - 1];  ord[r] = ord[r - 1];  r -= 1; }
+        okey[r] = x;  ord[r] = xi;
       }
   }
+  const double tp2 = tprof ? now_ms() : 0.;
   Overlap_IO_Buffer *obuf = OVL_IO_Buffer(spec);
   static size_t tmin = 0;                  /* below this many records one thread does it (DAMAR_TAIL_MIN) */
   if (tmin == 0)
@@ -1266,7 +1286,7 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
     }
   const int nthr = (nrecs >= tmin) ? tail_threads() : 1;
   if (nthr == 1)
-    return tail_range(recs, ord.data(), 0, nrecs, tpool, ablock, bblock, self, comp, ts, obuf, jp.symmetric, jp.hgap_min);
+    return tail_range(recs, ord.data(), okey.data(), 0, nrecs, tpool, ablock, bblock, self, comp, ts, obuf, jp.symmetric, jp.hgap_min);
 
   /* Read pairs are independent: cut the ordered records into nthr ranges at pair boundaries,
      let each thread fill a private buffer, append the buffers in order. */
@@ -1274,7 +1294,7 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
   cut[0] = 0;
   for (int t = 1; t < nthr; t++)
     { size_t c = std::max(cut[t - 1], nrecs * (size_t) t / nthr);
-      while (c < nrecs && c > 0 && recs[ord[c]].item == recs[ord[c - 1]].item)
+      while (c < nrecs && c > 0 && (okey[c] >> 32) == (okey[c - 1] >> 32))
         c += 1;
       cut[t] = c;
     }
@@ -1294,7 +1314,7 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
           if (part[t] == NULL)
             die();
         }
-      th.emplace_back([&, t] { got[t] = tail_range(recs, ord.data(), cut[t], cut[t + 1], tpool, ablock, bblock,
+      th.emplace_back([&, t] { got[t] = tail_range(recs, ord.data(), okey.data(), cut[t], cut[t + 1], tpool, ablock, bblock,
                                                     self, comp, ts, part[t], jp.symmetric, jp.hgap_min); });
     }
   int64 ncheck = 0;
@@ -1311,6 +1331,8 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
         }
       ncheck += got[t];
     }
+  if (tprof)
+    fprintf(stderr, "damar: tail of %zu records: keys %.2f ms, order %.2f ms, %d threads %.2f ms\n", nrecs, tp1 - tp0, tp2 - tp1, nthr, now_ms() - tp2);
   return ncheck;
 }
 
