@@ -77,6 +77,61 @@ static void unpack4_init(void)
     unpack4[b] = (uint32) ((b >> 6) & 3) | ((uint32) ((b >> 4) & 3) << 8) | ((uint32) ((b >> 2) & 3) << 16) | ((uint32) (b & 3) << 24);
 }
 
+/* Sequence arrays are hundreds of MB that are written once, front to back: on 2 MB pages (where the system hands them out
+   on request) first touch costs a 512th of the page faults. */
+#include <sys/mman.h>
+static void *big_alloc(size_t n, const char *what)
+{ void *p = NULL;
+  if (n >= ((size_t) 8 << 20) && posix_memalign(&p, (size_t) 2 << 20, n) == 0 && p != NULL)
+    {
+#ifdef MADV_HUGEPAGE
+      (void) madvise(p, n, MADV_HUGEPAGE);
+#endif
+      return p;
+    }
+  return xmalloc(n, what);
+}
+
+/* the bases of `nbytes` .bps bytes (four per byte, first base in the top bits), one byte per base */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("bmi2")))
+static void unpack_bmi2(const unsigned char *src, size_t nbytes, char *dst)
+{ size_t j = 0;
+  for (; j + 8 <= nbytes; j += 8)
+    { uint64 x, r;
+      memcpy(&x, src + j, 8);
+      /* reverse the four 2-bit groups inside every byte: the first base goes to the low bits, where pdep starts */
+      r = ((x & 0x0303030303030303ull) << 6) | ((x & 0x0c0c0c0c0c0c0c0cull) << 2) |
+          ((x >> 2) & 0x0c0c0c0c0c0c0c0cull) | ((x >> 6) & 0x0303030303030303ull);
+      { uint64 o0 = _pdep_u64(r, 0x0303030303030303ull), o1 = _pdep_u64(r >> 16, 0x0303030303030303ull),
+               o2 = _pdep_u64(r >> 32, 0x0303030303030303ull), o3 = _pdep_u64(r >> 48, 0x0303030303030303ull);
+        memcpy(dst + 4 * j, &o0, 8);  memcpy(dst + 4 * j + 8, &o1, 8);
+        memcpy(dst + 4 * j + 16, &o2, 8);  memcpy(dst + 4 * j + 24, &o3, 8);
+      }
+    }
+  for (; j < nbytes; j++)
+    memcpy(dst + 4 * j, &unpack4[src[j]], 4);
+}
+#endif
+
+static void unpack_bytes(const unsigned char *src, size_t nbytes, char *dst)
+{
+#if defined(__x86_64__)
+  static int have = -1;
+  if (have < 0)
+    have = __builtin_cpu_supports("bmi2") ? 1 : 0;
+  if (have)
+    { unpack_bmi2(src, nbytes, dst);
+      return;
+    }
+#endif
+  { size_t j;
+    for (j = 0; j < nbytes; j++)
+      memcpy(dst + 4 * j, &unpack4[src[j]], 4);
+  }
+}
+
 int damar_read_block(const char *name, HITS_DB *block)
 { char   *root = damar_root(name, ".db");
   char   *dir  = dir_of(name);
@@ -183,38 +238,63 @@ int damar_read_block(const char *name, HITS_DB *block)
       goto fail;
     }
 
-  { char  *seq = (char *) xmalloc((size_t) (block->totlen + block->nreads + 4), "block bases");
+  { char  *seq = (char *) big_alloc((size_t) (block->totlen + block->nreads + 4) + 64, "block bases");
     int64  o = 0;
+    /* the reads of a block lie back to back in the .bps file: ONE read of the stretch (a seek + read per read was 11 600
+       system calls for a 135 Mbp block), then every read is unpacked out of it, whole bytes eight at a time */
+    const int64 f0 = block->nreads > 0 ? reads[0].boff : 0;
+    int64  f1 = f0;
+    unsigned char *raw = NULL;
+    for (i = 0; i < block->nreads; i++)
+      { const int64 e = reads[i].boff + ((reads[i].rlen + 3) >> 2);
+        if (reads[i].boff < f0)
+          { f1 = -1;  break; }
+        if (e > f1) f1 = e;
+      }
+    if (f1 >= f0 && f1 - f0 <= 2 * (block->totlen / 4 + block->nreads) + 1024)          /* (a stretch, not a scatter) */
+      { raw = (unsigned char *) big_alloc((size_t) (f1 - f0) + 64, "packed bases");
+        if (fseeko(bps, (off_t) f0, SEEK_SET) != 0 || (f1 > f0 && fread(raw, (size_t) (f1 - f0), 1, bps) != 1))
+          { fprintf(stderr, "damar: read of %s failed\n", path);
+            free(raw);
+            goto fail;
+          }
+      }
 
     *seq++ = 4;
     for (i = 0; i < block->nreads; i++)
       { int    len  = reads[i].rlen;
         int    clen = (len + 3) >> 2;
-        int    j;
-        unsigned char *p;
         char  *s = seq + o;
+        const unsigned char *p;
+        unsigned char *own = NULL;
 
-        if (fseeko(bps, (off_t) reads[i].boff, SEEK_SET) != 0 ||
-            (clen > 0 && fread(s, (size_t) clen, 1, bps) != 1))
-          { fprintf(stderr, "damar: read of %s failed\n", path);
-            goto fail;
+        if (raw != NULL)
+          p = raw + (reads[i].boff - f0);
+        else
+          { own = (unsigned char *) xmalloc((size_t) clen + 8, "packed read");
+            if (fseeko(bps, (off_t) reads[i].boff, SEEK_SET) != 0 ||
+                (clen > 0 && fread(own, (size_t) clen, 1, bps) != 1))
+              { fprintf(stderr, "damar: read of %s failed\n", path);
+                free(own);
+                goto fail;
+              }
+            p = own;
           }
-        p = (unsigned char *) s;
-        j = clen - 1;                         /* expand in place, back to front: the last, possibly */
-        if (j >= 0)                           /* partial, byte base by base, the others 4 bases per look-up */
-          { unsigned byte = p[j];
-            int      q = 4 * j;
-            if (q + 3 < len) s[q + 3] = (char) (byte & 3);
-            if (q + 2 < len) s[q + 2] = (char) ((byte >> 2) & 3);
-            if (q + 1 < len) s[q + 1] = (char) ((byte >> 4) & 3);
+        if (clen > 0)
+          { unsigned byte = p[clen - 1];          /* the last, possibly partial, byte base by base */
+            int      q = 4 * (clen - 1);
+            unpack_bytes(p, (size_t) (clen - 1), s);
             s[q] = (char) ((byte >> 6) & 3);
+            if (q + 1 < len) s[q + 1] = (char) ((byte >> 4) & 3);
+            if (q + 2 < len) s[q + 2] = (char) ((byte >> 2) & 3);
+            if (q + 3 < len) s[q + 3] = (char) (byte & 3);
           }
-        for (j = clen - 2; j >= 0; j--)
-          memcpy(s + 4 * j, &unpack4[p[j]], 4);
+        free(own);
         s[len] = 4;
         reads[i].boff = o;
         o += len + 1;
       }
+    free(raw);
     reads[block->nreads].boff = o;
     block->bases  = (void *) seq;
     block->loaded = 1;
@@ -289,6 +369,19 @@ static void rc_inplace(char *s, int len)
     *a = (char) (3 - *a);
 }
 
+/* dst[j] = 3 - src[len - 1 - j], eight bases at a time */
+static void rc_copy(char *dst, const char *src, int len)
+{ int j = 0;
+  for (; j + 8 <= len; j += 8)
+    { uint64 x;
+      memcpy(&x, src + len - 8 - j, 8);
+      x = __builtin_bswap64(x) ^ 0x0303030303030303ull;
+      memcpy(dst + j, &x, 8);
+    }
+  for (; j < len; j++)
+    dst[j] = (char) (3 - src[len - 1 - j]);
+}
+
 /* Mirror the mask intervals of every read, [b,e) -> [rlen-e, rlen-b) (which also reverses their order),
    daligner.c:572-626: from (tano, tata) into (anno, data), which may be the same arrays. */
 static void mirror_track(const HITS_DB *block, const int64 *tano, const int *tata, int64 *anno, int *data)
@@ -313,20 +406,22 @@ static void mirror_track(const HITS_DB *block, const int64 *tano, const int *tat
    command-line driver prepares the next block on a second thread.  Release with damar_free_complement. */
 void damar_complement_copy(const HITS_DB *block, HITS_DB *out)
 { int64 n = block->reads[block->nreads].boff;
-  char *seq = (char *) xmalloc((size_t) n + 1, "complement block");
+  char *seq = (char *) big_alloc((size_t) n + 1 + 64, "complement block");
   const HITS_TRACK *src;
   float x;
   int   i;
 
   *seq++ = 4;
-  memcpy(seq, block->bases, (size_t) n);
   *out = *block;
   out->bases  = (void *) seq;
   out->tracks = NULL;
   x = out->freq[0]; out->freq[0] = out->freq[3]; out->freq[3] = x;
   x = out->freq[1]; out->freq[1] = out->freq[2]; out->freq[2] = x;
-  for (i = 0; i < block->nreads; i++)
-    rc_inplace(seq + block->reads[i].boff, block->reads[i].rlen);
+  for (i = 0; i < block->nreads; i++)             /* every read reversed and complemented straight out of the forward block */
+    { const int64 bo = block->reads[i].boff;
+      rc_copy(seq + bo, ((const char *) block->bases) + bo, block->reads[i].rlen);
+      seq[bo + block->reads[i].rlen] = 4;
+    }
   for (src = block->tracks; src != NULL; src = src->next)
     { const int64 *tano = (const int64 *) src->anno;
       HITS_TRACK  *trg = (HITS_TRACK *) xmalloc(sizeof(HITS_TRACK), "mask header");
