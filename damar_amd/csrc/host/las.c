@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <pthread.h>
 
 #include "damar_align.h"
 #include "damar_host.h"
@@ -389,6 +390,18 @@ static void write_keyed(FILE *out, const Keyed *k, int tbytes)
   Write_Overlap(out, &o, tbytes);
 }
 
+typedef struct { const char *path; int tspace, tbytes; const Keyed *recs; int n; } FilePart;
+
+static void *write_file_part(void *arg)
+{ const FilePart *f = (const FilePart *) arg;
+  FILE *out = open_las(f->path, f->tspace);
+  int   j;
+  for (j = 0; j < f->n; j++)
+    write_keyed(out, f->recs + j, f->tbytes);
+  close_las(out, f->n);
+  return NULL;
+}
+
 /* align.c:6166-6367 on an explicit set of per-thread buffers */
 static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
                           const char *dir1, const char *dir2, const char *ablock, const char *bblock, int lastRead)
@@ -400,7 +413,6 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
   int     aid, bid;
   char    path1[4300], path2[4300];
   FILE   *out;
-  int64   nh;
 
   for (i = 0; i < s->nthreads; i++)
     total += iobuf[i].otop;
@@ -459,17 +471,24 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
       /* records whose aread lies in the lower-numbered block go to its file */
       { const char *first = (bid < aid) ? path2 : path1;
         const char *second = (bid < aid) ? path1 : path2;
-        out = open_las(first, tspace);
-        for (j = 0, nh = 0; j < n; j++, nh++)
-          { if (all[j].ovl->aread > lastRead)
-              break;
-            write_keyed(out, all + j, tbytes);
-          }
-        close_las(out, nh);
-        out = open_las(second, tspace);
-        for (nh = 0; j < n; j++, nh++)
-          write_keyed(out, all + j, tbytes);
-        close_las(out, nh);
+        FilePart part2;
+        pthread_t th;
+        int       par;
+        for (j = 0; j < n; j++)
+          if (all[j].ovl->aread > lastRead)
+            break;
+        /* the two files are written side by side: the second by a thread of its own (the last block pair of a command
+           is written with nothing else left to do: its two files one after the other were a tenth of the drain) */
+        part2.path = second;  part2.tspace = tspace;  part2.tbytes = tbytes;  part2.recs = all + j;  part2.n = n - j;
+        par = (n - j > 4096) && pthread_create(&th, NULL, write_file_part, &part2) == 0;
+        { FilePart part1;
+          part1.path = first;  part1.tspace = tspace;  part1.tbytes = tbytes;  part1.recs = all;  part1.n = j;
+          write_file_part(&part1);
+        }
+        if (par)
+          pthread_join(th, NULL);
+        else
+          write_file_part(&part2);
       }
     }
   free(all);
