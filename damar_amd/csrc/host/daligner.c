@@ -497,6 +497,7 @@ typedef struct
   long     used;                    /* LRU stamp */
   int      busy;                    /* named by the pair being computed */
   int      ready;                   /* 0 while the reader thread is still preparing it */
+  int      hostready;               /* read and complemented on the host (the reader threads' first stage) */
 } PBlock;
 
 static PBlock *PB;                  /* fixed capacity (PB_max + 8): entries never move while the reader thread fills them */
@@ -510,7 +511,7 @@ static int     PB_ahead;            /* entries [0, PB_ahead) are prepared by the
 static Opts    PB_opts;
 
 /* read, mask, check, reverse-complement and (on the reader thread) upload one block, both strands */
-static void pblock_load(PBlock *b, const Opts *o, int background)
+static void pblock_load_host(PBlock *b, const Opts *o, int background)
 { double t0 = wall_ms();
   if (damar_read_block(b->name, &b->blk))
     { if (background) reader_fail(); else exit(1); }
@@ -524,35 +525,62 @@ static void pblock_load(PBlock *b, const Opts *o, int background)
   t0 = wall_ms();
   damar_complement_copy(&b->blk, &b->cblk);
   P_ms[3] += wall_ms() - t0;
-  if (background)                   /* on the copy stream, beside the kernels of the main thread */
+}
+
+static void pblock_upload(PBlock *b)         /* on the copy stream, beside the kernels of the main thread */
+{ double t0 = wall_ms();
+  b->dev[0] = damar_block_upload_bg(&b->blk);
+  b->dev[1] = damar_block_upload_bg(&b->cblk);
+  P_ms[7] += wall_ms() - t0;
+}
+
+static void pblock_load(PBlock *b, const Opts *o, int background)
+{ pblock_load_host(b, o, background);
+  if (background)
     { pthread_mutex_lock(&PB_mu);     /* (reading and complementing started before the device was up: plan_main) */
       while (!PB_dev_ready)
         pthread_cond_wait(&PB_cv, &PB_mu);
       pthread_mutex_unlock(&PB_mu);
-      t0 = wall_ms();
-      b->dev[0] = damar_block_upload_bg(&b->blk);
-      b->dev[1] = damar_block_upload_bg(&b->cblk);
-      P_ms[7] += wall_ms() - t0;
+      pblock_upload(b);
     }
 }
 
 static int PB_next;                 /* next entry a reader thread takes */
 
+static int PB_up_next;              /* next entry to upload (in order, once it is read and the device is up) */
+
+/* Two stages per block: read + complement (host only), then the upload.  A reader thread prefers an upload that is
+   due; while the device is still coming up -- a tenth of a second in a cold process -- it reads on instead of waiting
+   with its first block in hand, so that by then every block is ready to go up (plan of 4 blocks: the last block in HBM
+   at +170 instead of +205 ms). */
 static void *plan_reader(void *arg)
 { (void) arg;
+  pthread_mutex_lock(&PB_mu);
   for (;;)
     { int i;
-      pthread_mutex_lock(&PB_mu);
-      i = PB_next++;
-      pthread_mutex_unlock(&PB_mu);
-      if (i >= PB_ahead)
+      if (PB_dev_ready && PB_up_next < PB_ahead && PB[PB_up_next].hostready)
+        { i = PB_up_next++;
+          pthread_mutex_unlock(&PB_mu);
+          pblock_upload(PB + i);
+          pthread_mutex_lock(&PB_mu);
+          PB[i].ready = 1;
+          pthread_cond_broadcast(&PB_cv);
+          continue;
+        }
+      if (PB_next < PB_ahead)
+        { i = PB_next++;
+          pthread_mutex_unlock(&PB_mu);
+          pblock_load_host(PB + i, &PB_opts, 1);
+          pthread_mutex_lock(&PB_mu);
+          PB[i].hostready = 1;
+          pthread_cond_broadcast(&PB_cv);
+          continue;
+        }
+      if (PB_up_next >= PB_ahead)
         break;
-      pblock_load(PB + i, &PB_opts, 1);
-      pthread_mutex_lock(&PB_mu);
-      PB[i].ready = 1;
-      pthread_cond_broadcast(&PB_cv);
-      pthread_mutex_unlock(&PB_mu);
+      pthread_cond_wait(&PB_cv, &PB_mu);            /* for the device, or for the block that is next to go up */
     }
+  pthread_mutex_unlock(&PB_mu);
   return NULL;
 }
 
