@@ -251,7 +251,8 @@ int damar_read_block(const char *name, HITS_DB *block)
           { f1 = -1;  break; }
         if (e > f1) f1 = e;
       }
-    if (f1 >= f0 && f1 - f0 <= 2 * (block->totlen / 4 + block->nreads) + 1024)          /* (a stretch, not a scatter) */
+    if (f1 >= f0 && f1 - f0 <= 2 * (block->totlen / 4 + block->nreads) + 1024 &&        /* (a stretch, not a scatter) */
+        getenv("DAMAR_DB_READ_BY_READ") == NULL)                                          /* (test hook: the read-by-read path) */
       { raw = (unsigned char *) big_alloc((size_t) (f1 - f0) + 64, "packed bases");
         if (fseeko(bps, (off_t) f0, SEEK_SET) != 0 || (f1 > f0 && fread(raw, (size_t) (f1 - f0), 1, bps) != 1))
           { fprintf(stderr, "damar: read of %s failed\n", path);

@@ -421,3 +421,29 @@ def test_teardown_gate_makes_the_next_worker_wait_for_the_one_that_is_leaving(tm
     h.kill()
     h.wait()
     assert 1.8 < dt < 3.0, dt                                      # a holder that does not go away: the gate opens after two seconds
+
+
+def test_block_read_in_one_stretch_equals_read_by_read(built):
+    """damar_read_block: the block's stretch of the .bps file read at once and unpacked 32 bases per step (BMI2 where the CPU
+    has it) against the read-by-read path with the 4-base table (db/DB.c:1547-1608 Read_All_Sequences), in fresh processes
+    (the choice is made per call from the environment): bases with their terminators and read offsets."""
+    code = ("import sys, os, hashlib, ctypes as C\n"
+            "sys.path.insert(0, %r)\n"
+            "from damar_amd import api\n"
+            "L = api.lib()\n"
+            "for name in sys.argv[1:]:\n"
+            "    db = api.HITS_DB()\n"
+            "    assert L.damar_read_block(name.encode(), C.byref(db)) == 0\n"
+            "    reads = C.cast(db.reads, C.POINTER(api.HITS_READ))\n"
+            "    n = reads[db.nreads].boff\n"
+            "    raw = C.string_at(C.c_void_p(db.bases - 1), n + 1)\n"
+            "    offs = b''.join(int(reads[i].boff).to_bytes(8, 'little') for i in range(db.nreads + 1))\n"
+            "    print(name, db.nreads, hashlib.md5(raw).hexdigest(), hashlib.md5(offs).hexdigest())\n") % ROOT
+    names = [os.path.join(ROOT, "tests", "golden", d, "G.1") for d in ("mask_dust", "long", "tandem")] + \
+            [os.path.join(ROOT, "tests", "golden", "mask_dust", "G.2")]
+    outs = []
+    for env in (dict(os.environ), dict(os.environ, DAMAR_DB_READ_BY_READ="1")):
+        r = subprocess.run([os.sys.executable, "-c", code] + names, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and outs[0].count("\n") == len(names), outs
