@@ -120,7 +120,7 @@ static void unpack_bytes(const unsigned char *src, size_t nbytes, char *dst)
 #if defined(__x86_64__)
   static int have = -1;
   if (have < 0)
-    have = __builtin_cpu_supports("bmi2") ? 1 : 0;
+    have = (__builtin_cpu_supports("bmi2") && getenv("DAMAR_DB_NO_BMI2") == NULL) ? 1 : 0;       /* (the variable: a test hook) */
   if (have)
     { unpack_bmi2(src, nbytes, dst);
       return;

@@ -442,8 +442,8 @@ def test_block_read_in_one_stretch_equals_read_by_read(built):
     names = [os.path.join(ROOT, "tests", "golden", d, "G.1") for d in ("mask_dust", "long", "tandem")] + \
             [os.path.join(ROOT, "tests", "golden", "mask_dust", "G.2")]
     outs = []
-    for env in (dict(os.environ), dict(os.environ, DAMAR_DB_READ_BY_READ="1")):
+    for env in (dict(os.environ), dict(os.environ, DAMAR_DB_READ_BY_READ="1"), dict(os.environ, DAMAR_DB_NO_BMI2="1")):
         r = subprocess.run([os.sys.executable, "-c", code] + names, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout)
-    assert outs[0] == outs[1] and outs[0].count("\n") == len(names), outs
+    assert outs[0] == outs[1] == outs[2] and outs[0].count("\n") == len(names), outs
