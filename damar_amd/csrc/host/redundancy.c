@@ -1,309 +1,279 @@
-/* redundancy.c -- host tail of the overlap path for ONE read pair: fuse / bridge the
- * local alignments found for the pair, compress their traces and append the Overlap
- * records to an Overlap_IO_Buffer.
+/* redundancy.c -- host tail of the overlap path for ONE read pair: what becomes of the local alignments found for
+ * the pair before they are written (kept on the host: a handful of paths per pair, rare).
  *
- * SURVEY.md section 8 row a18 keeps this stage on the host (a handful of paths per
- * pair, pointer-chasing, rare): reference filter.c:1573-1741 (Entwine, Fusion),
- * :1804-2077 (Handle_Redundancies) and the record emission of :2442-2483.
+ * Results are the reference's (dalign/filter.c:1573-1686 Entwine, :1691-1741 Fusion, :1804-2077 Handle_Redundancies,
+ * :2442-2483 the records); the statement is this project's own.  A path is treated as a LADDER: its trace gives the B
+ * coordinate at every point of the A grid (multiples of the trace spacing) it crosses.  Two paths "meet" when their
+ * ladders agree at a grid point; everything below is phrased on a Walker that climbs a ladder rung by rung, and the
+ * reference's two mirrored branches (j starts first / k starts first) are ONE rule on (lead, trail) = (the path that
+ * starts first on A, the other).  The oracle keeps a separately worded statement (oracle/redundancy.c); the two share
+ * no text and are compared through the files they produce.
  */
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <limits.h>
 
 #include "damar_host.h"
 
 int64 damar_stat_redundancy_calls = 0, damar_stat_fusions = 0, damar_stat_bridges = 0;
 
-static int iabs(int x) { return x < 0 ? -x : x; }
+/***** trace pool: paths refer to their traces by offset, so the pool may move when it grows ********************/
 
-static void tpool_reserve(damar_tpool *tp, int64 extra)
-{ if (tp->top + extra >= tp->max)
-    { tp->max = (int64) (1.2 * (tp->top + extra)) + 1000;
+static int64 pool_take(damar_tpool *tp, int64 n)
+{ int64 at = tp->top;
+  if (at + n >= tp->max)
+    { tp->max = (int64) (1.2 * (at + n)) + 1000;              /* growth rule of filter.c:1703-1709 */
       tp->val = (uint16 *) realloc(tp->val, sizeof(uint16) * (size_t) tp->max);
       if (tp->val == NULL)
         { fprintf(stderr, "damar: out of memory (trace pool)\n");
           exit(1);
         }
     }
-}
-
-int64 damar_tpool_push(damar_tpool *tp, const uint16 *src, int n)
-{ int64 at;
-  tpool_reserve(tp, n);
-  at = tp->top;
-  memcpy(tp->val + at, src, sizeof(uint16) * (size_t) n);
-  tp->top += n;
+  tp->top = at + n;
   return at;
 }
 
-/* filter.c:1573-1686.  Walk two A-view paths over the trace points they share and
- * return the smallest B-distance between them (0 => they meet, *where = A coordinate
- * of the meeting trace point), or -1 if they share no interior trace point. */
-static int entwine(const damar_path *jp, const damar_path *kp, const damar_tpool *tp, int ts, int *where)
-{ const uint16 *jt = tp->val + jp->toff, *kt = tp->val + kp->toff;
-  int y2 = jp->bbpos, b2 = kp->bbpos;
-  int j = jp->abpos / ts, k = kp->abpos / ts;
-  int best = 10000, seen = 0;
-  int ac, ae, i, d;
-
-  if (jp->abpos == kp->abpos)
-    { best = iabs(y2 - b2);
-      if (best == 0)
-        *where = kp->abpos;
-    }
-  if (j < k)
-    { ac = k * ts;
-      j = 1 + 2 * (k - j);
-      k = 1;
-      for (i = 1; i < j; i += 2)
-        y2 += jt[i];
-    }
-  else
-    { ac = j * ts;
-      k = 1 + 2 * (j - k);
-      j = 1;
-      for (i = 1; i < k; i += 2)
-        b2 += kt[i];
-    }
-  ae = (jp->aepos < kp->aepos) ? jp->aepos : kp->aepos;
-  for (;;)
-    { ac += ts;
-      if (ac >= ae)
-        break;
-      y2 += jt[j];
-      b2 += kt[k];
-      j += 2;
-      k += 2;
-      d = iabs(y2 - b2);
-      if (d <= best)
-        { best = d;
-          if (d == 0)
-            *where = ac;
-        }
-      seen += 1;
-    }
-  if (jp->aepos == kp->aepos)
-    { d = iabs(jp->bepos - kp->bepos);
-      if (d <= best)
-        { best = d;
-          if (d == 0)
-            *where = kp->aepos;
-        }
-    }
-  return (seen == 0) ? -1 : best;
+int64 damar_tpool_push(damar_tpool *tp, const uint16 *src, int n)
+{ int64 at = pool_take(tp, n);
+  memcpy(tp->val + at, src, sizeof(uint16) * (size_t) n);
+  return at;
 }
 
-/* filter.c:1691-1741: p1 := p1[..ap] ++ p2[ap..], written to fresh pool space. */
-static void fuse(damar_path *p1, int ap, const damar_path *p2, damar_tpool *tp, int ts)
-{ int    k1 = 2 * ((ap / ts) - (p1->abpos / ts));
-  int    k2 = 2 * ((ap / ts) - (p2->abpos / ts));
-  int    len = k1 + (p2->tlen - k2);
-  int64  at;
-  int    n = 0, diff = 0, k;
-  uint16 *dst;
+/***** ladders *************************************************************************************************/
+
+/* A Walker stands on grid index `g` of a path with B coordinate `b`; `step` points at the (diffs, B length) pair
+ * of the segment that leads to g + 1.  At its creation it stands at the path's start, which counts as the grid index
+ * of the segment the start lies in (abpos / ts). */
+typedef struct
+{ const uint16 *step;
+  int           g, b;
+} Walker;
+
+static Walker walker_on(const damar_path *p, const damar_tpool *tp, int ts)
+{ Walker w;
+  w.step = tp->val + p->toff;
+  w.g    = p->abpos / ts;
+  w.b    = p->bbpos;
+  return w;
+}
+
+static int climb(Walker *w, int g)                 /* B coordinate of the path at grid index g >= w->g */
+{ for (; w->g < g; w->g++, w->step += 2)
+    w->b += w->step[1];
+  return w->b;
+}
+
+static int gap(int x, int y) { return x < y ? y - x : x - y; }
+
+/* How close do two paths of one read pair come on the A grid?  Compared are, in this order: the common start when both
+ * start at the same A position; the grid points strictly inside both (above the later first index, below the earlier
+ * end); the common end when both end at the same A position.  *meet receives the last compared point with distance 0.
+ * The answer is -1 when no INTERIOR grid point was compared, whatever the ends said (filter.c:1573-1686: its `cnt`). */
+static void compare_at(int at, int d, int *near, int *meet)
+{ if (d > *near)
+    return;
+  *near = d;
+  if (d == 0)
+    *meet = at;
+}
+
+static int nearest_approach(const damar_path *p, const damar_path *q, const damar_tpool *tp, int ts, int *meet)
+{ Walker wp = walker_on(p, tp, ts), wq = walker_on(q, tp, ts);
+  int    stop = p->aepos < q->aepos ? p->aepos : q->aepos;
+  int    g    = wp.g > wq.g ? wp.g : wq.g;
+  int    near = 10000, inside = 0;
+
+  if (p->abpos == q->abpos)
+    { near = INT_MAX;                                         /* the common start sets the distance outright */
+      compare_at(q->abpos, gap(p->bbpos, q->bbpos), &near, meet);
+    }
+  for (g += 1; g * ts < stop; g++, inside++)
+    compare_at(g * ts, gap(climb(&wp, g), climb(&wq, g)), &near, meet);
+  if (p->aepos == q->aepos)
+    compare_at(q->aepos, gap(p->bepos, q->bepos), &near, meet);
+  return inside > 0 ? near : -1;
+}
+
+/* front := front up to the grid point `at`, then back from `at` on (filter.c:1691-1741).  The spliced trace goes to
+ * fresh pool space: both sources stay valid for other paths that still refer to them. */
+static void splice_at(damar_path *front, int at, const damar_path *back, damar_tpool *tp, int ts)
+{ int   keep = 2 * (at / ts - front->abpos / ts);             /* trace values of front before the grid point */
+  int   skip = 2 * (at / ts - back->abpos / ts);              /* trace values of back before it */
+  int   rest = back->tlen - skip;
+  int64 to   = pool_take(tp, keep + rest);
+  uint16 *v  = tp->val + to;
+  int   i, diffs = 0;
 
   __atomic_fetch_add(&damar_stat_fusions, 1, __ATOMIC_RELAXED);
-  tpool_reserve(tp, len);
-  at  = tp->top;
-  tp->top += len;
-  dst = tp->val + at;
-  for (k = 0; k < k1; k += 2)
-    { dst[n++] = tp->val[p1->toff + k];
-      dst[n++] = tp->val[p1->toff + k + 1];
-      diff += tp->val[p1->toff + k];
-    }
-  for (k = k2; k < p2->tlen; k += 2)
-    { dst[n++] = tp->val[p2->toff + k];
-      dst[n++] = tp->val[p2->toff + k + 1];
-      diff += tp->val[p2->toff + k];
-    }
-  p1->aepos = p2->aepos;
-  p1->bepos = p2->bepos;
-  p1->diffs = diff;
-  p1->toff  = at;
-  p1->tlen  = n;
+  memcpy(v, tp->val + front->toff, sizeof(uint16) * (size_t) keep);
+  memcpy(v + keep, tp->val + back->toff + skip, sizeof(uint16) * (size_t) rest);
+  for (i = 0; i < keep + rest; i += 2)
+    diffs += v[i];
+  front->toff  = to;
+  front->tlen  = keep + rest;
+  front->diffs = diffs;
+  front->aepos = back->aepos;
+  front->bepos = back->bepos;
 }
 
-/* filter.c:1804-2077.  am[0..n) are the A-view paths of one read pair in discovery
- * order, bm (may be NULL) the matching B-view paths.  Returns the surviving count. */
+/***** pass 1: paths that share a trace point ********************************************************************/
+
+enum { APART, ABSORBED, GROWN };
+
+/* Slots j > k, both alive.  What the reference decides for them (filter.c:1833-1946), as one rule:
+ *   - they must be able to touch (trail starts no later than lead ends, on both reads) and meet on the grid;
+ *   - same start: the longer of the two survives;  trail ends inside lead: lead survives;
+ *   - trail runs on beyond lead: the two become lead[..meet] ++ trail[meet..] -- provided their B views meet as well.
+ *     On B the pair runs in the same order as on A, or in the opposite order when the B read is complemented.
+ * The survivor always ends up in slot j and slot k is retired; GROWN tells the caller that slot j got longer, so every
+ * earlier slot has to be looked at again. */
+static int settle(damar_path *am, damar_path *bm, int j, int k, int comp, int ts, damar_tpool *tp)
+{ int         j_leads = am[j].abpos < am[k].abpos;
+  int         li = j_leads ? j : k, ti = j_leads ? k : j;
+  damar_path *lead = am + li, *trail = am + ti;
+  int         ma = 0, mb = 0;
+
+  if (trail->abpos > lead->aepos || trail->bbpos > lead->bepos)
+    return APART;
+  if (nearest_approach(lead, trail, tp, ts, &ma) != 0)
+    return APART;
+
+  if (trail->aepos > lead->aepos && trail->abpos != lead->abpos)
+    { if (bm != NULL)
+        { damar_path *bfront = bm + (comp ? ti : li), *bback = bm + (comp ? li : ti);
+          if (nearest_approach(bfront, bback, tp, ts, &mb) != 0)
+            return APART;
+          splice_at(lead, ma, trail, tp, ts);
+          splice_at(bfront, mb, bback, tp, ts);
+          bm[j] = *bfront;
+        }
+      else
+        splice_at(lead, ma, trail, tp, ts);
+      am[j] = *lead;
+      am[k].abpos = -1;
+      return GROWN;
+    }
+
+  /* containment: with a common start (then k is the lead) the longer one, otherwise the lead */
+  if (!j_leads && (lead->abpos != trail->abpos || lead->aepos > trail->aepos))
+    { am[j] = am[k];
+      if (bm != NULL)
+        bm[j] = bm[k];
+    }
+  am[k].abpos = -1;
+  return ABSORBED;
+}
+
+/***** pass 2: narrow parallel overlaps (filter.c:1950-2059) *****************************************************/
+
+/* `first` starts before `second` on A.  A candidate for bridging is a pair that overlaps on both reads in the same
+ * sense, neither containing the other, whose overlap is square to within 20 % (the reference compares in double). */
+static int staggered(const damar_path *first, const damar_path *second, int *aovl, int *bovl)
+{ int a_ok = second->abpos < first->aepos && first->aepos < second->aepos;
+  int b_ok = first->bbpos < second->bbpos && second->bbpos < first->bepos && first->bepos < second->bepos;
+  if (!a_ok || !b_ok)
+    return 0;
+  *aovl = first->aepos - second->abpos;
+  *bovl = first->bepos - second->bbpos;
+  return gap(*aovl, *bovl) <= .2 * (*aovl + *bovl);
+}
+
+static void bridge_all(damar_path *am, int n, damar_path *bm, int comp, int ts, damar_tpool *tp,
+                       const damar_bridge_ctx *bridge)
+{ int j, k;
+  for (j = 1; j < n; j++)
+    for (k = j - 1; k >= 0 && am[j].abpos >= 0; k--)
+      { int         j_first = am[j].abpos < am[k].abpos, aovl, bovl;
+        damar_path *first  = am + (j_first ? j : k), *second = am + (j_first ? k : j);
+        damar_path *bfirst = NULL, *bsecond = NULL;
+
+        if (am[k].abpos < 0 || !staggered(first, second, &aovl, &bovl))
+          continue;
+        if (bm != NULL)
+          { int bj_first = comp ? !j_first : j_first;      /* on a complemented B read the two come in the opposite order */
+            bfirst  = bm + (bj_first ? j : k);
+            bsecond = bm + (bj_first ? k : j);
+            if (bfirst->abpos > bsecond->abpos)
+              { printf("  SYMFAIL %d %d\n", j, k);         /* the reference's diagnostic, on stdout as there */
+                continue;
+              }
+          }
+        damar_bridge_pair(bridge, am + j, am + k, first, second, bfirst, bsecond, aovl, bovl, comp, ts, tp, bm, j);
+      }
+}
+
+/* am[0..n): the A-view paths of one read pair in discovery order; bm: the matching B views, or NULL.  Returns how
+ * many survive, packed to the front in their slot order.  datander's variant (scrub/tandem.c:767-850) has no
+ * bridging pass: its callers hand in bridge == NULL. */
+static int close_ranks(damar_path *am, damar_path *bm, int n)      /* survivors to the front, slot order kept */
+{ int hole = 0, s;
+  while (hole < n && am[hole].abpos >= 0)      /* nothing moves before the first retired slot */
+    hole += 1;
+  for (s = hole + 1; s < n; s++)
+    { if (am[s].abpos < 0)
+        continue;
+      if (bm != NULL)
+        bm[hole] = bm[s];
+      am[hole++] = am[s];
+    }
+  return hole;
+}
+
 int damar_handle_redundancies(damar_path *am, int n, damar_path *bm, int comp, int ts,
                               damar_tpool *tp, const damar_bridge_ctx *bridge)
-{ int hasB = (bm != NULL);
-  int j, k, dist, awhen = 0, bwhen = 0, out;
+{ int j, k;
 
   __atomic_fetch_add(&damar_stat_redundancy_calls, 1, __ATOMIC_RELAXED);
 
-  /* pass 1: alignments that share a trace point are fused (filter.c:1833-1946) */
-  for (j = 1; j < n; j++)
-    { damar_path *jp = am + j;
-      for (k = j - 1; k >= 0; k--)
-        { damar_path *kp = am + k;
-          if (kp->abpos < 0)
-            continue;
-          if (jp->abpos < kp->abpos)
-            { if (!(kp->abpos <= jp->aepos && kp->bbpos <= jp->bepos))
-                continue;
-              dist = entwine(jp, kp, tp, ts, &awhen);
-              if (dist != 0)
-                continue;
-              if (kp->aepos > jp->aepos)
-                { if (hasB)
-                    { if (comp)
-                        { if (entwine(bm + k, bm + j, tp, ts, &bwhen) != 0)
-                            continue;
-                          fuse(jp, awhen, kp, tp, ts);
-                          fuse(bm + k, bwhen, bm + j, tp, ts);
-                          bm[j] = bm[k];
-                        }
-                      else
-                        { if (entwine(bm + j, bm + k, tp, ts, &bwhen) != 0)
-                            continue;
-                          fuse(jp, awhen, kp, tp, ts);
-                          fuse(bm + j, bwhen, bm + k, tp, ts);
-                        }
-                    }
-                  else
-                    fuse(jp, awhen, kp, tp, ts);
-                  kp->abpos = -1;
-                  k = j;                 /* rescan everything before j against the fusion */
-                  continue;
-                }
-              kp->abpos = -1;
-            }
-          else
-            { if (!(jp->abpos <= kp->aepos && jp->bbpos <= kp->bepos))
-                continue;
-              dist = entwine(kp, jp, tp, ts, &awhen);
-              if (dist != 0)
-                continue;
-              if (kp->abpos == jp->abpos)
-                { if (kp->aepos > jp->aepos)
-                    { *jp = *kp;
-                      if (hasB)
-                        bm[j] = bm[k];
-                    }
-                }
-              else if (jp->aepos > kp->aepos)
-                { if (hasB)
-                    { if (comp)
-                        { if (entwine(bm + j, bm + k, tp, ts, &bwhen) != 0)
-                            continue;
-                          fuse(kp, awhen, jp, tp, ts);
-                          *jp = *kp;
-                          fuse(bm + j, bwhen, bm + k, tp, ts);
-                        }
-                      else
-                        { if (entwine(bm + k, bm + j, tp, ts, &bwhen) != 0)
-                            continue;
-                          fuse(kp, awhen, jp, tp, ts);
-                          *jp = *kp;
-                          fuse(bm + k, bwhen, bm + j, tp, ts);
-                          bm[j] = bm[k];
-                        }
-                    }
-                  else
-                    { fuse(kp, awhen, jp, tp, ts);
-                      *jp = *kp;
-                    }
-                  kp->abpos = -1;
-                  k = j;
-                  continue;
-                }
-              else
-                { *jp = *kp;
-                  if (hasB)
-                    bm[j] = bm[k];
-                }
-              kp->abpos = -1;
-            }
-        }
+  for (j = 1; j < n; j++)                      /* slot j against every live earlier slot, latest first; again from */
+    { k = j;                                   /* the top whenever slot j has grown */
+      while (--k >= 0)
+        if (am[k].abpos >= 0 && settle(am, bm, j, k, comp, ts, tp) == GROWN)
+          k = j;
     }
-
-  /* pass 2: narrow parallel overlaps are bridged by an exact realignment
-   * (filter.c:1950-2059).  datander's variant (scrub/tandem.c:767-850) has no such pass:
-   * its callers hand in bridge == NULL. */
-  for (j = 1; bridge != NULL && j < n; j++)
-    { damar_path *jp = am + j;
-      if (jp->abpos < 0)
-        continue;
-      for (k = j - 1; k >= 0; k--)
-        { damar_path *kp = am + k, *p1, *p2, *b1 = NULL, *b2 = NULL;
-          int aovl, bovl;
-
-          if (kp->abpos < 0)
-            continue;
-          if (jp->abpos < kp->abpos)
-            { p1 = jp; p2 = kp; }
-          else
-            { p1 = kp; p2 = jp; }
-          if (p2->abpos >= p1->aepos || p1->aepos >= p2->aepos ||
-              p1->bbpos >= p2->bbpos || p2->bbpos >= p1->bepos || p1->bepos >= p2->bepos)
-            continue;
-          aovl = p1->aepos - p2->abpos;
-          bovl = p1->bepos - p2->bbpos;
-          if (iabs(aovl - bovl) > .2 * (aovl + bovl))
-            continue;
-          if (hasB)
-            { if (comp == (jp->abpos < kp->abpos))
-                { b1 = bm + k; b2 = bm + j; }
-              else
-                { b1 = bm + j; b2 = bm + k; }
-              if (b1->abpos > b2->abpos)
-                { printf("  SYMFAIL %d %d\n", j, k);
-                  continue;
-                }
-            }
-          if (damar_bridge_pair(bridge, jp, kp, p1, p2, b1, b2, aovl, bovl, comp, ts, tp, bm, j))
-            continue;
-        }
-    }
-
-  out = 0;
-  for (j = 0; j < n; j++)
-    if (am[j].abpos >= 0)
-      { if (hasB)
-          bm[out] = bm[j];
-        am[out++] = am[j];
-      }
-  return out;
+  if (bridge != NULL)
+    bridge_all(am, n, bm, comp, ts, tp, bridge);
+  return close_ranks(am, bm, n);
 }
 
-/* filter.c:2442-2483: redundancy handling, then A records, then B records. */
+/***** the records of a pair (filter.c:2442-2483): A views first, then B views with the reads exchanged ***********/
+
+static void write_views(const damar_path *v, int n, int aread, int bread, int comp, int ts, const damar_tpool *tp,
+                        Overlap_IO_Buffer *obuf)
+{ int     narrow = (ts <= TRACE_XOVR);
+  Overlap rec;
+
+  memset(&rec, 0, sizeof(rec));
+  rec.flags = (uint32) comp;
+  rec.aread = aread;
+  rec.bread = bread;
+  for (; n > 0; n--, v++)
+    { rec.path.abpos = v->abpos;
+      rec.path.bbpos = v->bbpos;
+      rec.path.aepos = v->aepos;
+      rec.path.bepos = v->bepos;
+      rec.path.diffs = v->diffs;
+      rec.path.tlen  = v->tlen;
+      rec.path.trace = tp->val + v->toff;
+      if (narrow)
+        Compress_TraceTo8(&rec, 1);
+      AddOverlapToBuffer(obuf, &rec, narrow ? 1 : 2);
+    }
+}
+
 void damar_emit_pair(damar_path *am, int na, damar_path *bm, int nb, damar_tpool *tp,
                      int comp, int ts, int aread, int bread,
                      const damar_bridge_ctx *bridge, Overlap_IO_Buffer *obuf,
                      int64 *nrec)
-{ int     small  = (ts <= TRACE_XOVR);
-  int     tbytes = small ? 1 : 2;
-  Overlap ovl;
-  int     i;
-
-  if (na > 1)
-    { if (nb > 1)
-        na = nb = damar_handle_redundancies(am, na, bm, comp, ts, tp, bridge);
-      else
-        na = damar_handle_redundancies(am, na, NULL, comp, ts, tp, bridge);
-    }
+{ if (na > 1 && nb > 1)
+    na = nb = damar_handle_redundancies(am, na, bm, comp, ts, tp, bridge);
+  else if (na > 1)
+    na = damar_handle_redundancies(am, na, NULL, comp, ts, tp, bridge);
   else if (nb > 1)
     nb = damar_handle_redundancies(bm, nb, NULL, comp, ts, tp, bridge);
-
-  memset(&ovl, 0, sizeof(ovl));
-  ovl.flags = (uint32) comp;
-  for (i = 0; i < na + nb; i++)
-    { const damar_path *p = (i < na) ? am + i : bm + (i - na);
-      ovl.aread      = (i < na) ? aread : bread;
-      ovl.bread      = (i < na) ? bread : aread;
-      ovl.path.tlen  = p->tlen;
-      ovl.path.diffs = p->diffs;
-      ovl.path.abpos = p->abpos;
-      ovl.path.bbpos = p->bbpos;
-      ovl.path.aepos = p->aepos;
-      ovl.path.bepos = p->bepos;
-      ovl.path.trace = tp->val + p->toff;
-      if (small)
-        Compress_TraceTo8(&ovl, 1);
-      AddOverlapToBuffer(obuf, &ovl, tbytes);
-    }
-  if (nrec)
+  write_views(am, na, aread, bread, comp, ts, tp, obuf);
+  write_views(bm, nb, bread, aread, comp, ts, tp, obuf);
+  if (nrec != NULL)
     *nrec += na + nb;
 }
