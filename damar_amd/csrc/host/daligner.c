@@ -477,11 +477,6 @@ int main(int argc, char *argv[])
 /* Plan mode and node mode fork their workers on the premise that this process has not touched the GPU yet.  Under
    rocprofv3 (and anything else that preloads a tool library into the process) the HIP runtime is up before main(), and a
    child of such a process must not use it: plan mode then runs in-process, node mode refuses. */
-static int profiler_preloaded(void)
-{ const char *t = getenv("ROCP_TOOL_LIBRARIES"), *p = getenv("LD_PRELOAD"), *h = getenv("HSA_TOOLS_LIB");
-  return (t != NULL && t[0] != 0) || (h != NULL && h[0] != 0) ||
-         (p != NULL && (strstr(p, "rocprof") != NULL || strstr(p, "roctracer") != NULL || strstr(p, "rocprofiler") != NULL));
-}
 
 /* ---------------------------------------------------------------------------------------------------
  * Plan mode: many `daligner` lines, one process, blocks and k-mer indexes resident (see the header).
@@ -624,12 +619,24 @@ static int PB_sharers = 1;          /* processes of this command on the same GPU
 
 static void pblock_trim(void)
 { if (PB_budget == 0)
-    { /* 55 % of the GPU -- of what is FREE when somebody else holds memory on it (the worker of the command before
-         this one may still be releasing its HBM: plan_main), and this process's share of it when the workers of a node
-         command sit on one GPU */
-      uint64_t fr = 0, tot = 0;
+    { /* 55 % of what this process can count on: the HBM that is free now PLUS what its own blocks already hold (the
+         readers have uploaded blocks and an index has been built by the time this runs first; sampling "free" alone
+         would discount them twice -- ADVICE r4).  Memory somebody else holds (the worker of the command before this one
+         may still be releasing its HBM: plan_main) is not counted on.  When the workers of a node command sit on one
+         GPU the others' allocations are already missing from "free": the share is then taken of the whole GPU, and
+         capped by what is there */
+      uint64_t fr = 0, tot = 0, own = 0, avail;
+      int i;
       damar_hbm_info(&fr, &tot);
-      PB_budget = (uint64_t) (.55 * (double) (fr < tot ? fr : tot)) / (uint64_t) (PB_sharers > 0 ? PB_sharers : 1);
+      pthread_mutex_lock(&PB_mu);
+      for (i = 0; i < PB_n; i++)
+        if (PB[i].ready && PB[i].name != NULL)
+          own += pblock_bytes(PB + i);
+      pthread_mutex_unlock(&PB_mu);
+      avail = fr + own < tot ? fr + own : tot;
+      if (PB_sharers > 1 && tot / (uint64_t) PB_sharers < avail)
+        avail = tot / (uint64_t) PB_sharers;
+      PB_budget = (uint64_t) (.55 * (double) avail);
       if (getenv("DAMAR_PLAN_GB") != NULL && atof(getenv("DAMAR_PLAN_GB")) > 0)
         PB_budget = (uint64_t) (atof(getenv("DAMAR_PLAN_GB")) * 1073741824.);
     }
@@ -906,7 +913,7 @@ static int plan_main(const Opts *base, const char *planfile)
      (damar_gate.h) instead of colliding with it; a caller that chains GPU commands without anything in between is
      better off with DAMAR_PLAN_TIDY=1 (one process that releases everything itself: 0.85 s per command against 1.0)
      or with one plan for all of them.  A child that dies before it is done is waited for and reported. */
-  if (getenv("DAMAR_PLAN_TIDY") == NULL && profiler_preloaded())
+  if (getenv("DAMAR_PLAN_TIDY") == NULL && damar_profiler_preloaded())
     { fprintf(stderr, "daligner: a profiler is preloaded (the GPU runtime is up before main): running the plan in this "
                       "process (DAMAR_PLAN_TIDY=1)\n");
       setenv("DAMAR_PLAN_TIDY", "1", 1);
@@ -979,7 +986,7 @@ static int plan_main(const Opts *base, const char *planfile)
                     seen = 1;
                 if (!seen)
                   { PB[PB_n].name = strdup(ltok[i][j]);
-                    PB[PB_n].used = ++PB_clock;
+                    PB[PB_n].used = 0;                   /* not used yet: pblock_get stamps it (pblock_trim spares it) */
                     PB_n += 1;
                   }
               }
@@ -1292,8 +1299,58 @@ static int cpulist_to_set(const char *text, cpu_set_t *set)
   return n;
 }
 
+/* NUMA node of HIP device `gpu` WITHOUT touching the HIP runtime (a worker binds its threads and memory policy, and
+   waits at the teardown gate, before its first HIP call: the runtime's helper threads and first allocations then start
+   out in the right place -- ADVICE r4).  The driver lists its nodes under /sys/class/kfd/kfd/topology/nodes: the GPUs are
+   the nodes with SIMDs, in the order the runtime numbers them; `domain` and `location_id` give the PCI address, whose
+   sysfs entry names the NUMA node.  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES given as ordinals are mapped through.
+   -1 when anything is missing: the worker then takes an even share of the job's cores, unbound. */
+static int gpu_numa_node_sysfs(int gpu)
+{ const char *vis = getenv("ROCR_VISIBLE_DEVICES") ? getenv("ROCR_VISIBLE_DEVICES") : getenv("HIP_VISIBLE_DEVICES");
+  int want = gpu, n, seen = 0;
+  if (vis != NULL && vis[0] != 0)
+    { const char *c = vis;
+      int i;
+      for (i = 0; i < gpu && c != NULL; i++)
+        c = strchr(c, ',') ? strchr(c, ',') + 1 : NULL;
+      if (c == NULL || *c < '0' || *c > '9')
+        return -1;                                     /* (a list of UUIDs, or shorter than the ordinal) */
+      want = atoi(c);
+    }
+  for (n = 0; n < 256; n++)
+    { char path[128], key[64];
+      unsigned long long val, simd = 0, loc = 0, dom = 0;
+      FILE *f;
+      snprintf(path, sizeof(path), "/sys/class/kfd/kfd/topology/nodes/%d/properties", n);
+      f = fopen(path, "r");
+      if (f == NULL)
+        break;
+      while (fscanf(f, "%63s %llu", key, &val) == 2)
+        { if (strcmp(key, "simd_count") == 0) simd = val;
+          else if (strcmp(key, "location_id") == 0) loc = val;
+          else if (strcmp(key, "domain") == 0) dom = val;
+        }
+      fclose(f);
+      if (simd == 0)
+        continue;                                      /* a CPU node */
+      if (seen++ == want)
+        { int node = -1;
+          snprintf(path, sizeof(path), "/sys/bus/pci/devices/%04llx:%02llx:%02llx.%llx/numa_node",
+                   dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7);
+          f = fopen(path, "r");
+          if (f != NULL)
+            { if (fscanf(f, "%d", &node) != 1)
+                node = -1;
+              fclose(f);
+            }
+          return node;
+        }
+    }
+  return -1;
+}
+
 static void node_place(int w, int gpu, int nworkers, NodeShared *S)
-{ const int node = damar_hip_numa_node(gpu);
+{ const int node = gpu_numa_node_sysfs(gpu);
   cpu_set_t cur;
   int cores, tails, writers, bound = 0;
   if (node >= 0 && getenv("DAMAR_NODE_NOBIND") == NULL)
@@ -1348,7 +1405,8 @@ static int node_worker(int w, int gpu, int nworkers, int sharers, const Opts *o,
   PB_cap = PB_max + LINE_B + 2;
   PB = (PBlock *) calloc((size_t) PB_cap, sizeof(PBlock));
   PB_sharers = sharers;
-  node_place(w, gpu, nworkers, S);                  /* this worker's threads and pinned buffers next to its GPU */
+  damar_gate_wait(gpu);                             /* before anything of the GPU runtime: not into a leaving worker's teardown */
+  node_place(w, gpu, nworkers, S);                  /* this worker's threads and pinned buffers next to its GPU (no HIP call) */
   select_device(&ow);
   damar_set_async(1);
   pthread_mutex_lock(&PB_mu);
@@ -1420,19 +1478,23 @@ static int node_main(const Opts *base, const char *planfile)
       }
     else
       { char *copy = strdup(g), *sp = NULL, *t;
-        for (t = strtok_r(copy, ",", &sp); t != NULL && W < NODE_MAXW; t = strtok_r(NULL, ",", &sp))
-          gpus[W++] = atoi(t);
+        int   ntok = 0;
+        for (t = strtok_r(copy, ",", &sp); t != NULL; t = strtok_r(NULL, ",", &sp), ntok++)
+          if (W < NODE_MAXW)
+            gpus[W++] = atoi(t);
         free(copy);
+        if (ntok > NODE_MAXW)
+          W = NODE_MAXW + 1;                           /* (refused below; a list of exactly NODE_MAXW ordinals is fine) */
       }
     if (W < 1)
       { fprintf(stderr, "daligner: -G wants a number of GPUs or a list of ordinals\n");
         exit(1);
       }
-    if ((strchr(g, ',') == NULL && atoi(g) > NODE_MAXW) || (strchr(g, ',') != NULL && W >= NODE_MAXW))
+    if ((strchr(g, ',') == NULL && atoi(g) > NODE_MAXW) || W > NODE_MAXW)
       { fprintf(stderr, "daligner: -G: at most %d workers\n", NODE_MAXW);
         exit(1);
       }
-    if (profiler_preloaded())
+    if (damar_profiler_preloaded())
       { fprintf(stderr, "daligner: -G forks one worker per GPU, which a process with a preloaded profiler must not do: "
                         "profile one worker's share with -P <plan> (it then runs in-process, as with DAMAR_PLAN_TIDY=1)\n");
         exit(1);

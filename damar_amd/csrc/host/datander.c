@@ -58,10 +58,6 @@ static void *read_ahead(void *arg)
   return NULL;
 }
 
-static int profiler_preloaded(void)
-{ const char *t = getenv("ROCP_TOOL_LIBRARIES"), *p = getenv("LD_PRELOAD"), *h = getenv("HSA_TOOLS_LIB");
-  return (t != NULL && t[0] != 0) || (h != NULL && h[0] != 0) || (p != NULL && strstr(p, "rocprof") != NULL);
-}
 
 int main(int argc, char *argv[])
 { int    kmer = 12, hitmin = 35, binshift = 4, spacing = 100, nthreads = 4, c, i, gpu = -1;
@@ -121,7 +117,7 @@ int main(int argc, char *argv[])
     }
 
   /* the worker: a child forked before any HIP call; the command returns when it says that every file is closed */
-  if (getenv("DAMAR_PLAN_TIDY") == NULL && !profiler_preloaded())
+  if (getenv("DAMAR_PLAN_TIDY") == NULL && !damar_profiler_preloaded())
     { int   pfd[2];
       pid_t pid;
       fflush(NULL);

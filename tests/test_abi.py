@@ -65,3 +65,25 @@ def test_product_does_not_link_the_oracle(built):
     assert "oracle_" not in out
     ldd = subprocess.run(["ldd", os.path.join(ROOT, "damar_amd", "bin", "daligner")], stdout=subprocess.PIPE, text=True).stdout
     assert "liboracle" not in ldd
+
+
+def test_tandem_library_is_the_second_boundary(built):
+    """scrub/tandem.h:54-60: a scrub/datander.c that links libdamar_tandem.so (before libdamar_hip.so) instead of
+    scrub/tandem.c finds the FOUR-argument Set_Filter_Params and SORT_PATH there, Match_Self and everything of align.h in
+    libdamar_hip.so, which the tandem library pulls in itself."""
+    tan = os.path.join(ROOT, "damar_amd", "libdamar_tandem.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", tan], check=True, stdout=subprocess.PIPE, text=True).stdout
+    exported = {ln.split()[-1]: ln.split()[-2] for ln in out.splitlines() if len(ln.split()) >= 2}
+    assert exported.get("Set_Filter_Params") == "T"
+    assert exported.get("SORT_PATH") in ("D", "B")
+    assert "Match_Self" not in exported                     # one definition, in the main library
+    needed = subprocess.run(["readelf", "-d", tan], check=True, stdout=subprocess.PIPE, text=True).stdout
+    assert "libdamar_hip.so" in needed
+    L = ctypes.CDLL(tan)
+    L.Set_Filter_Params.restype = ctypes.c_int
+    L.Set_Filter_Params.argtypes = [ctypes.c_int] * 4
+    assert L.Set_Filter_Params(1, 4, 35, 4) == 1            # tandem.c:160-162: k <= 1 is illegal
+    assert L.Set_Filter_Params(12, 4, 35, 4) == 0
+    assert ctypes.c_char_p.in_dll(L, "SORT_PATH").value == b"/tmp"
+    H = ctypes.CDLL(os.path.join(ROOT, "damar_amd", "libdamar_hip.so"))
+    assert hasattr(H, "Match_Self")

@@ -416,6 +416,27 @@ def test_reference_driver_linked_against_hip_library(gpu, tmp_path, name):
     assert compare_las(case, str(tmp_path)) == []
 
 
+@pytest.mark.parametrize("name", ["tan_tandem", "tan_k18", "tan_plain"])
+def test_reference_datander_linked_against_tandem_library(gpu, tmp_path, name):
+    """Drop-in proof of the SECOND boundary (scrub/tandem.h:54-60): the reference's OWN scrub/datander.c, compiled from
+    /root/reference and linked on libdamar_tandem.so + libdamar_hip.so instead of scrub/tandem.c + dalign/align.c
+    (oracle/Makefile.ref target `dropin`), writes the golden tan/*.las files: its main calls
+    the 4-argument Set_Filter_Params, New_Align_Spec, Match_Self, Write_Overlap_Buffer, Reset_Overlap_Buffer and
+    Free_Align_Spec of the libraries (scrub/datander.c:226-258)."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "datander_on_damar")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/datander_on_damar not built (needs /root/reference at build time)")
+    ldd = subprocess.run(["ldd", exe], check=True, stdout=subprocess.PIPE, text=True).stdout
+    assert "libdamar_tandem.so" in ldd and "libdamar_hip.so" in ldd
+    case = read_case(name)
+    assert case["tool"] == "datander"
+    link_db(case["dbdir"], str(tmp_path))
+    for a, _ in case["lines"]:
+        subprocess.run([exe] + case["opts"] + ["G." + a], cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL)
+    assert compare_las(case, str(tmp_path)) == []
+
+
 def test_gpu_sparse_coverage_equals_oracle(gpu, tmp_path):
     """Hardly any true overlaps (0.4x coverage): almost every read pair dies in the screen or in the
     band filter, some block pairs produce no record at all; the .las files (header-only ones

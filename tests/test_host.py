@@ -421,6 +421,20 @@ def test_teardown_gate_makes_the_next_worker_wait_for_the_one_that_is_leaving(tm
     h.kill()
     h.wait()
     assert 1.8 < dt < 3.0, dt                                      # a holder that does not go away: the gate opens after two seconds
+    # a planted symlink under the lock's name is not followed: nothing is created behind it and the gate is simply open
+    d2 = tmp_path / "planted"
+    d2.mkdir()
+    os.symlink(str(d2 / "victim"), str(d2 / "damar_gpu3.teardown"))
+    env2 = dict(os.environ, DAMAR_GATE_DIR=str(d2))
+    h = subprocess.Popen([exe, "hold", "400"], env=env2)
+    time.sleep(0.1)
+    t0 = time.time()
+    subprocess.run([exe, "wait"], env=env2, check=True)
+    assert time.time() - t0 < 0.2
+    h.wait()
+    assert not (d2 / "victim").exists()
+    # and the lock file itself is private to the user
+    assert (os.stat(str(tmp_path / "damar_gpu3.teardown")).st_mode & 0o077) == 0
 
 
 def test_block_read_in_one_stretch_equals_read_by_read(built):

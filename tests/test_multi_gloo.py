@@ -249,3 +249,52 @@ def test_two_rank_gloo_plan_equals_golden(built, tmp_path):
     for b in (1, 2):
         got = hashlib.md5(open(os.path.join(work, "G.%d.las" % b), "rb").read()).hexdigest()
         assert got == want["d001_%05d" % b]
+
+
+def test_bench_gpus_argument_starts_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher (the form the driver may use): the N ranks are started as children
+    under torch.distributed.run before the parent touches the GPU; fewer visible GPUs than N is an error unless the
+    one-GPU rehearsal is asked for; a launcher whose world size contradicts --gpus is an error too."""
+    import importlib
+    import pytest
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class Done:
+        returncode = 0
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("DAMAR_BENCH_SHARE_GPU", raising=False)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 8)
+    assert bench.relaunch_under_torchrun(4, argv=["--gpus", "4", "--steps", "3"], run=fake_run) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert "DAMAR_BENCH_BACKEND" not in seen["env"] or seen["env"]["DAMAR_BENCH_BACKEND"] != "gloo"
+
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.relaunch_under_torchrun(2, argv=["--gpus", "2"], run=fake_run)
+    assert "only 1 GPU" in str(e.value)
+    monkeypatch.setenv("DAMAR_BENCH_SHARE_GPU", "1")
+    assert bench.relaunch_under_torchrun(2, argv=["--gpus", "2"], run=fake_run) == 0
+    assert seen["env"]["DAMAR_BENCH_BACKEND"] == "gloo"
+
+    # main(): plain start with --gpus 2 goes through the relaunch and exits with the child's code ...
+    monkeypatch.setattr(bench, "relaunch_under_torchrun", lambda n: 7)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    # ... and a launcher with another world size than --gpus is refused before anything is set up
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "--gpus 4" in str(e.value)
