@@ -114,7 +114,8 @@ typedef struct
   int  dbits;                 /* > 0: bpos rides in the key's low dbits (packed seeds, no vals array); 0: diag in vals */
 } MergeArgs;
 
-typedef struct { u32 b0, b1, ja, ia; } MergeTile;     /* per tile of A entries: its piece of B, the ends of its border runs */
+typedef struct { u32 b0, b1, ja, ia;                   /* per tile of A entries: its piece of B, the ends of its border runs, */
+                 u32 sh, pad[3]; } MergeTile;           /* and the shift that maps (code - first code of the tile) onto < 2048 buckets */
 
 /* The merge is two sweeps over tiles of the A index (seed_merge.hip): COUNT leaves the hits per tile in the workspace
    (damar_merge_tile_counts; with gram != NULL also hitgram[ct] for ct < ngram, filter.c:1039-1165), the caller scans

@@ -55,6 +55,7 @@ __device__ __forceinline__ u32 count_below(const u32 *__restrict__ bpos, u32 jb,
 #define MT_A    (MT_PER * 256)           /* A entries per tile            */
 #define MT_BCAP (3 * MT_A)               /* B codes staged in LDS per tile (a piece is about as long as the tile) */
 #define MT_HITS 4                        /* seed pairs a thread has in flight in the EMIT loop */
+#define MT_NBK  2048                     /* buckets over a tile's code range: where a code's entries start in the staged B piece */
 
 template <typename CodeT>
 __device__ __forceinline__ u32 lower_bound_c(const CodeT *c, u32 lo, u32 hi, CodeT x)      /* first i in [lo,hi): c[i] >= x */
@@ -90,6 +91,13 @@ void merge_tiles(MergeArgs m, u32 ntiles, MergeTile *__restrict__ tiles)
   tl.b1 = upper_bound_c<CodeT>(bcode, tl.b0, m.blen, c1);
   tl.ja = (a0 > 0 && acode[a0 - 1] == c0) ? lower_bound_c<CodeT>(acode, 0, a0, c0) : a0;
   tl.ia = (a1 < m.alen && acode[a1] == c1) ? upper_bound_c<CodeT>(acode, a1, m.alen, c1) : a1;
+  { const u64 span = (u64) (c1 - c0);                        /* buckets of the tile's code range (merge_sweep_fast) */
+    u32 sh = 0;
+    while ((span >> sh) >= (u64) MT_NBK)
+      sh += 1;
+    tl.sh = sh;
+  }
+  tl.pad[0] = tl.pad[1] = tl.pad[2] = 0;
   tiles[t] = tl;
 }
 
@@ -414,10 +422,156 @@ __device__ __forceinline__ void merge_sweep_tile(const MergeArgs &m, const Merge
     }
 }
 
+/* The common tile in ONE pass over LDS, without a search: the tile's B piece is staged as before, and a table over the
+ * tile's code range -- MT_NBK buckets of 2^sh codes (merge_tiles chose sh so that the range fits), first[bucket] = where
+ * the bucket's entries start in the piece, filled by the B entries that open a bucket -- answers "where would code c
+ * sit" with one look-up and a walk over the bucket's few entries (both indexes sample the same code space: about one B
+ * entry per A entry, one or two per bucket).  An A code whose bucket is empty has no partner.  That replaces a binary
+ * search of ~10 dependent LDS reads per thread, which was what the sweep waited for (round 4: 1.0 ms per 135 M x 135 M
+ * comparison, ~350 instructions per 4 entries, issue / LDS-latency bound).
+ * The caps of filter.c:1248 / 1335 compare a run's mutual count with `limit` (10000 unless memory is short): a count is
+ * at most (length of the A run) x (length of the B run), and an A run of this tile is no longer than tl.ia - tl.ja, so
+ * when no entry of the tile has nb x (tl.ia - tl.ja) >= limit nothing can be capped and neither the run boundaries nor
+ * the per-run sums are needed.  Otherwise the workgroup returns false -- nothing written -- and the caller takes the
+ * general path. */
+template <typename CodeT>
+__device__ __forceinline__ bool merge_sweep_fast(const MergeArgs &m, const MergeTile tl, const u32 tile,
+                                                 u32 *__restrict__ tcount, u32 *__restrict__ cnt, u32 *__restrict__ jbg,
+                                                 CodeT *sb, u16 *first, u64 *red)
+{ const CodeT *acode = (const CodeT *) m.acode, *bcode = (const CodeT *) m.bcode;
+  const u32 a0 = tile * (u32) MT_A, a1 = min(m.alen, a0 + (u32) MT_A), nat = a1 - a0;
+  const u32 nbt = tl.b1 - tl.b0;
+  const u32 e0 = threadIdx.x * MT_PER;
+  const int nv = (e0 >= nat) ? 0 : (int) min((u32) MT_PER, nat - e0);
+  const u32 sh = tl.sh;
+  constexpr u32 VPK = 16 / sizeof(CodeT);
+  typedef CodeT VecT __attribute__((ext_vector_type(16 / sizeof(CodeT))));
+  typedef u32 V4 __attribute__((ext_vector_type(4)));
+
+  const CodeT c0 = acode[a0];
+  CodeT a[MT_PER];
+  if (nv == MT_PER)
+    {
+#pragma unroll
+      for (int q = 0; q < MT_PER / (int) VPK; q++)
+        { const VecT v = ((const VecT *) (acode + a0 + e0))[q];
+#pragma unroll
+          for (int e = 0; e < (int) VPK; e++)
+            a[q * VPK + e] = v[e];
+        }
+    }
+  else
+    {
+#pragma unroll
+      for (int k = 0; k < MT_PER; k++)
+        a[k] = (k < nv) ? acode[a0 + e0 + k] : (CodeT) 0;
+    }
+  /* the B piece into LDS (as in merge_sweep_tile), the table to "empty" */
+  const u32 b0a = tl.b0 & ~(VPK - 1), shf = tl.b0 - b0a;
+  { const u32 nvec = (tl.b1 - b0a + VPK - 1) / VPK;
+    VecT v[MT_BCAP / (int) VPK / 256 + 1];
+#pragma unroll
+    for (int r = 0; r < MT_BCAP / (int) VPK / 256 + 1; r++)
+      { const u32 x = threadIdx.x + (u32) r * 256;
+        if (x < nvec)
+          { if (b0a + (x + 1) * VPK <= m.blen)
+              v[r] = ((const VecT *) (bcode + b0a))[x];
+            else
+              {
+#pragma unroll
+                for (int e = 0; e < (int) VPK; e++)
+                  v[r][e] = (b0a + x * VPK + e < m.blen) ? bcode[b0a + x * VPK + e] : (CodeT) 0;
+              }
+          }
+      }
+    { const V4 ones = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
+      ((V4 *) first)[threadIdx.x] = ones;                     /* MT_NBK u16 = 256 x 16 bytes */
+    }
+#pragma unroll
+    for (int r = 0; r < MT_BCAP / (int) VPK / 256 + 1; r++)
+      { const u32 x = threadIdx.x + (u32) r * 256;
+        if (x < nvec)
+          ((VecT *) sb)[x] = v[r];
+      }
+  }
+  const CodeT *B = sb + shf;
+  __syncthreads();
+  /* every B entry that opens a bucket says where (the piece's codes lie in [c0, last code of the tile]) */
+  for (u32 j = threadIdx.x; j < nbt; j += 256)
+    { const u32 bk = (u32) ((B[j] - c0) >> sh);
+      if (j == 0 || (u32) ((B[j - 1] - c0) >> sh) != bk)
+        first[bk] = (u16) j;
+    }
+  __syncthreads();
+
+  u32 jb[MT_PER], n[MT_PER];
+  bool deep = false;                                          /* a cap might apply: the general path decides */
+  const u64 arun = (u64) (tl.ia - tl.ja);
+#pragma unroll
+  for (int k = 0; k < MT_PER; k++)
+    { jb[k] = 0;  n[k] = 0;
+      if (k < nv)
+        { const CodeT c = a[k];
+          if (k > 0 && c == a[k - 1])
+            { jb[k] = jb[k - 1];  n[k] = n[k - 1]; }
+          else
+            { u32 p = first[(u32) ((c - c0) >> sh)];
+              if (p != 0xffffu)
+                { int steps = 0;
+                  while (p < nbt && B[p] < c)
+                    { p += 1;
+                      if (++steps == 4) { p = lower_bound_c<CodeT>(B, p, nbt, c);  break; }
+                    }
+                  u32 q = p;
+                  steps = 0;
+                  while (q < nbt && B[q] == c)
+                    { q += 1;
+                      if (++steps == 4) { q = upper_bound_c<CodeT>(B, q, nbt, c);  break; }
+                    }
+                  jb[k] = p;  n[k] = q - p;
+                }
+            }
+          if (arun * (u64) n[k] >= (u64) m.limit)
+            deep = true;
+        }
+    }
+  if (__syncthreads_or(deep))
+    return false;
+  /* n[] holds the length of the B run so far: in a self comparison only the entries before A's bound count */
+  u64 s64 = 0;
+#pragma unroll
+  for (int k = 0; k < MT_PER; k++)
+    { if (m.self && n[k] > 0)
+        n[k] = self_hits(m, m.apos[a0 + e0 + k], tl.b0 + jb[k], n[k]);
+      s64 += n[k];
+    }
+  const u64 T64 = block_sum_u64(s64, red);
+  if (threadIdx.x == 0)
+    tcount[tile] = (T64 > 0xffffffffull) ? 0xffffffffu : (u32) T64;
+  if (nv == MT_PER && MT_PER == 4)
+    { V4 vc, vj;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        { vc[k] = n[k];  vj[k] = tl.b0 + jb[k]; }
+      *(V4 *) (cnt + a0 + e0) = vc;
+      *(V4 *) (jbg + a0 + e0) = vj;
+    }
+  else
+    {
+#pragma unroll
+      for (int k = 0; k < MT_PER; k++)
+        if (k < nv)
+          { cnt[a0 + e0 + k] = n[k];
+            jbg[a0 + e0 + k] = tl.b0 + jb[k];
+          }
+    }
+  return true;
+}
+
 template <typename CodeT>
 __global__ __launch_bounds__(256, 8)          /* <= 64 VGPRs: two wavefronts per SIMD still find room beside a resident report launch */
 void merge_sweep(MergeArgs m, const MergeTile *__restrict__ tiles, u32 *__restrict__ tcount, u32 *__restrict__ cnt,
-                 u32 *__restrict__ jbg, unsigned long long *__restrict__ gram, u32 ngram)
+                 u32 *__restrict__ jbg, unsigned long long *__restrict__ gram, u32 ngram, int general)
 { SEED_PRIO(g_merge_prio);
   __shared__ __attribute__((aligned(16))) CodeT sb[MT_BCAP + 16 / sizeof(CodeT)];
   __shared__ u32 loc[MT_A + 1];
@@ -425,6 +579,12 @@ void merge_sweep(MergeArgs m, const MergeTile *__restrict__ tiles, u32 *__restri
   __shared__ u32 sw4[4];
   __shared__ u64 red[4];
   const MergeTile tl = tiles[blockIdx.x];
+  if (gram == NULL && tl.b1 - tl.b0 <= MT_BCAP && !general)
+    { __shared__ __attribute__((aligned(16))) u16 first[MT_NBK];
+      if (merge_sweep_fast<CodeT>(m, tl, blockIdx.x, tcount, cnt, jbg, sb, first, red))
+        return;
+      __syncthreads();                         /* (a cap may apply: from the start again, the general way) */
+    }
   if (tl.b1 - tl.b0 <= MT_BCAP)                /* (the stage has room for the alignment slack on top) */
     merge_sweep_tile<CodeT, true>(m, tl, blockIdx.x, tcount, cnt, jbg, gram, ngram, sb, loc, sjb, sw4, red);
   else
@@ -549,13 +709,16 @@ void damar_launch_merge_count(const MergeArgs *m, void *work, unsigned long long
   MergeTile *tiles = (MergeTile *) work;
   u32 *tcount = damar_merge_tile_counts(work, m->alen);
   u32 *cnt = (u32 *) ((char *) work + mw_off_cnt(m->alen)), *jb = (u32 *) ((char *) work + mw_off_jb(m->alen));
+  static int general = -1;                   /* test hook (tests/test_gpu_parity.py): every tile the general way */
+  if (general < 0)
+    general = getenv("DAMAR_MERGE_GENERAL") != NULL;
   if (m->wide)
     { hipLaunchKernelGGL(merge_tiles<u64>, dim3((ntiles + 255) / 256), dim3(256), 0, st, *m, ntiles, tiles);
-      hipLaunchKernelGGL(merge_sweep<u64>, dim3(ntiles), dim3(256), 0, st, *m, tiles, tcount, cnt, jb, gram, ngram);
+      hipLaunchKernelGGL(merge_sweep<u64>, dim3(ntiles), dim3(256), 0, st, *m, tiles, tcount, cnt, jb, gram, ngram, general);
     }
   else
     { hipLaunchKernelGGL(merge_tiles<u32>, dim3((ntiles + 255) / 256), dim3(256), 0, st, *m, ntiles, tiles);
-      hipLaunchKernelGGL(merge_sweep<u32>, dim3(ntiles), dim3(256), 0, st, *m, tiles, tcount, cnt, jb, gram, ngram);
+      hipLaunchKernelGGL(merge_sweep<u32>, dim3(ntiles), dim3(256), 0, st, *m, tiles, tcount, cnt, jb, gram, ngram, general);
     }
 }
 

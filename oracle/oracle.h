@@ -68,6 +68,14 @@ typedef struct
   int64 bandhist[130]; /* wave steps by number of diagonals computed in the step (129 = more) */
   int64 dirs, dirs_over31, steps_after_over31;   /* directions, those that ever compute > 31 diagonals, their steps from then on */
   int   cur_over;
+  /* per PASS (one direction of one Local_Alignment): the widest step of the pass and its cells, classified when the
+     next pass starts: passes / cells of passes whose widest step computed <= 13, <= 14, <= 16, <= 29 diagonals, more */
+  int   pass_max;
+  int64 pass_cells, pass_n[5], pass_cellsum[5];
+  /* a 16-lane quarter mode with parking, simulated per pass: steps spent at <= 14 computed diagonals, and the number of
+     times a pass crosses from <= 12 (narrow again) to > 14 (must have a half) */
+  int   pass_wide;
+  int64 promotions, steps_narrow, steps_wide;
 } OWaveStats;
 
 void oracle_local_alignment(const char *aseq, int alen, const char *bseq, int blen,

@@ -147,6 +147,15 @@ int main(int argc, char *argv[])
   if (verbose && getenv("DAMAR_ORACLE_BANDHIST"))
     { int i;
       printf("directions %lld over31 %lld steps_after %lld\n", (long long) st.dirs, (long long) st.dirs_over31, (long long) st.steps_after_over31);
+      { static const char *cls[5] = { "<=13", "<=14", "<=16", "<=29", ">29" };
+        int q;
+        printf("passes by their widest step (computed diagonals): ");
+        for (q = 0; q < 5; q++)
+          printf(" %s: %lld passes %lld cells;", cls[q], (long long) st.pass_n[q], (long long) st.pass_cellsum[q]);
+        printf(" (the last pass of the run is not counted)\n");
+        printf("quarter mode with parking (leave at > 14 computed diagonals, return at <= 12): steps narrow %lld wide %lld promotions %lld\n",
+               (long long) st.steps_narrow, (long long) st.steps_wide, (long long) st.promotions);
+      }
       printf("bandhist");
       for (i = 0; i < 130; i++)
         printf(" %lld", (long long) st.bandhist[i]);

@@ -102,6 +102,29 @@ typedef struct
   OWaveStats *st;
 } Ctx;
 
+/* band statistics (DAMAR_ORACLE_BANDHIST, profiles/r05_bandhist.txt): per step and per pass */
+static void bandstat_pass_begin(OWaveStats *st)
+{ if (st->pass_cells > 0)
+    { const int m = st->pass_max;
+      const int c = m <= 13 ? 0 : m <= 14 ? 1 : m <= 16 ? 2 : m <= 29 ? 3 : 4;
+      st->pass_n[c] += 1;  st->pass_cellsum[c] += st->pass_cells;
+    }
+  st->pass_max = 0;  st->pass_cells = 0;  st->pass_wide = 0;
+  st->cur_over = 0;  st->dirs += 1;
+}
+
+static void bandstat_step(OWaveStats *st, int width)
+{ st->bandhist[width > 129 ? 129 : width] += 1;
+  if (width > 31 && !st->cur_over) { st->cur_over = 1; st->dirs_over31 += 1; }
+  if (st->cur_over) st->steps_after_over31 += 1;
+  st->pass_cells += width;
+  if (width > st->pass_max) st->pass_max = width;
+  if (!st->pass_wide && width > 14) { st->pass_wide = 1; st->promotions += 1; }
+  else if (st->pass_wide && width <= 12) st->pass_wide = 0;
+  if (st->pass_wide) st->steps_wide += 1; else st->steps_narrow += 1;
+}
+
+
 /* What the end point of one direction needs (align.c:436-442). */
 typedef struct
 { int a, y, d, ha, hb; } Tip;
@@ -110,7 +133,7 @@ typedef struct
 
 static void forward(const Ctx *c, Band *w, int diag, int mida,
                     Path *apath, uint16 *atrace, int *atlen_out, uint16 *btrace, int *btlen_out)
-{ if (c->st) { c->st->cur_over = 0; c->st->dirs += 1; }
+{ if (c->st) bandstat_pass_begin(c->st);
   const char *aseq = c->aseq, *bseq = c->bseq;
   const int   TS = c->ts;
   int   cur = 0, nxt = 1;
@@ -220,10 +243,7 @@ static void forward(const Ctx *c, Band *w, int diag, int mida,
       dif += 1;
 
       if (c->st)
-        { c->st->bandhist[hgh - low + 1 > 129 ? 129 : hgh - low + 1] += 1;
-          if (hgh - low + 1 > 31 && !c->st->cur_over) { c->st->cur_over = 1; c->st->dirs_over31 += 1; }
-          if (c->st->cur_over) c->st->steps_after_over31 += 1;
-        }
+        bandstat_step(c->st, hgh - low + 1);
       /* every diagonal of the new wave from the old wave (align.c:781-909) */
       for (k = low; k <= hgh; k++)
         { int ac = w->V[cur][k + o], am = w->V[cur][k - 1 + o], ap = w->V[cur][k + 1 + o];
@@ -392,7 +412,7 @@ static void forward(const Ctx *c, Band *w, int diag, int mida,
 static void reverse(const Ctx *c, Band *w, int diag, int mida,
                     Path *apath, uint16 *atrace, int *atlen_io, int *aback,
                     uint16 *btrace, int *btlen_io, int *bback)
-{ if (c->st) { c->st->cur_over = 0; c->st->dirs += 1; }
+{ if (c->st) bandstat_pass_begin(c->st);
   const char *aseq = c->aseq - 1, *bseq = c->bseq - 1;
   const int   TS = c->ts;
   int   cur = 0, nxt = 1;
@@ -499,10 +519,7 @@ static void reverse(const Ctx *c, Band *w, int diag, int mida,
       dif += 1;
 
       if (c->st)
-        { c->st->bandhist[hgh - low + 1 > 129 ? 129 : hgh - low + 1] += 1;
-          if (hgh - low + 1 > 31 && !c->st->cur_over) { c->st->cur_over = 1; c->st->dirs_over31 += 1; }
-          if (c->st->cur_over) c->st->steps_after_over31 += 1;
-        }
+        bandstat_step(c->st, hgh - low + 1);
       for (k = low; k <= hgh; k++)
         { int ac = w->V[cur][k + o], am = w->V[cur][k - 1 + o], ap = w->V[cur][k + 1 + o];
           int from, v, y, m, ha, hb;

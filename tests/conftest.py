@@ -65,14 +65,14 @@ def link_db(dbdir, dst, root="G"):
             os.symlink(os.path.join(dbdir, f), os.path.join(dst, f))
 
 
-def run_cli(exe, case, workdir):
+def run_cli(exe, case, workdir, env=None):
     """exe: the daligner-like binary; datander cases use its sibling *datander binary."""
     link_db(case["dbdir"], workdir)
     if case["tool"] == "datander":
         exe = exe.replace("daligner", "datander")
     for a, bs in case["lines"]:
         subprocess.run([exe] + case["opts"] + ["G." + a] + ["G." + b for b in bs], cwd=workdir, check=True,
-                       stdout=subprocess.DEVNULL)
+                       stdout=subprocess.DEVNULL, env=env)
 
 
 def opts_to_plan_kwargs(opts):

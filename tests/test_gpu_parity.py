@@ -61,6 +61,17 @@ def test_gpu_cli_binary_equals_reference_golden(gpu, tmp_path, name):
     assert compare_las(case, str(tmp_path)) == []
 
 
+@pytest.mark.parametrize("name", ["tiny2", "tandem", "tiny_I", "tiny_k12", "mask_two"])
+def test_gpu_cli_merge_general_path_equals_reference_golden(gpu, tmp_path, name):
+    """The seed merge has a fast path per tile of A entries (a bucket table over the tile's code range, no search, taken
+    when no cap on mutual k-mer matches can apply) and the general path of round 4; every other test takes whichever a
+    tile chooses -- here every tile goes the general way (test hook DAMAR_MERGE_GENERAL)."""
+    from conftest import run_cli
+    case = read_case(name)
+    run_cli(os.path.join(ROOT, "damar_amd", "bin", "daligner"), case, str(tmp_path), env=dict(os.environ, DAMAR_MERGE_GENERAL="1"))
+    assert compare_las(case, str(tmp_path)) == []
+
+
 def test_gpu_cli_memory_limit_known_answer(gpu, tmp_path):
     """daligner -M1 on a 25 Mbp block of 250x coverage: the REAL reference (oracle/_ref/daligner
     -v -k14 -M1 -j8 R R in the build container, tests/golden/make_golden.py memlimit) lowers the
