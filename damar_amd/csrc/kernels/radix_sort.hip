@@ -41,6 +41,9 @@ SEED_PRIO_SETTER(damar_sort_set_prio, g_sort_prio)
 #ifndef OS_MINW
 #define OS_MINW    4                         /* wavefronts per SIMD the pass kernel is compiled for */
 #endif
+#ifndef OS_RANK_LDS
+#define OS_RANK_LDS 1                        /* 1: the lanes with my digit through a 64-bit LDS word per (wavefront, digit); 0: eight ballots */
+#endif
 #define OS_MINTILE (256 * 8)                 /* the smallest tile shape (workspace bound) */
 #define OS_MAXPASS 8
 
@@ -203,7 +206,7 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
 { SEED_PRIO(g_sort_prio);
   constexpr int OS_TILE = TH * IT, OS_WAVES = TH / 64, OS_WSPAN = 64 * IT;
   /* keys and payload are staged through the SAME buffer one after the other */
-  __shared__ KeyT skey[OS_TILE];
+  __shared__ __attribute__((aligned(16))) KeyT skey[OS_TILE];
   u32 *const sval = (u32 *) skey;
   typedef typename std::conditional<(OS_WAVES > 8), u16, u32>::type CntT;      /* (a wavefront's count of a digit is at most 64 * IT) */
   __shared__ CntT cnt[OS_WAVES][256];
@@ -220,6 +223,11 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
   for (int i = 0; i < OS_WAVES; i++)
     if (threadIdx.x < 256)
       cnt[i][threadIdx.x] = 0;
+#if OS_RANK_LDS
+  static_assert((size_t) OS_TILE * sizeof(KeyT) >= (size_t) OS_WAVES * 256 * sizeof(u64), "the rank words do not fit the stage");
+  for (int i = threadIdx.x; i < OS_WAVES * 256; i += TH)
+    ((u64 *) skey)[i] = 0;
+#endif
   __syncthreads();
   const u32 tile  = (u32) __builtin_amdgcn_readfirstlane((int) s_tile);
   const u64 tbase = (u64) tile * OS_TILE;
@@ -235,6 +243,35 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
     { const u32 ti = t0 + (u32) r * 64;
       key[r] = tin[ti < have ? ti : have - 1];               /* (no branch around a load; what a lane beyond the end reads is never used) */
     }
+#if OS_RANK_LDS
+  /* Ranking through LDS (round 5): the lanes of a wavefront that hold the same digit find each other in a 64-bit word
+     per (wavefront, digit) -- every lane ORs its lane bit into the word of its digit, then reads the word back: the lanes
+     with my digit, in ONE round trip instead of eight ballots (4 vector instructions per digit bit, 32 of the pass's 89
+     per 64 keys; the pass was bound by vector issue at 61 % of the pipes).  LDS executes the
+     operations of one wavefront in order, so the read sees every lane's OR and the first lane's clear comes behind every
+     lane's read.  The words live where the tile is staged later (skey): nothing is staged before every wavefront is
+     through with its ranks. */
+  u64 *const wmask = (u64 *) skey + (u32) w * 256u;          /* (cleared before the first barrier) */
+  const u64 lanebit = 1ull << l;
+#pragma unroll
+  for (int r = 0; r < IT; r++)
+    { const bool ok = t0 + (u32) r * 64 < have;
+      const u32  d  = (u32) (key[r] >> shift) & mask;
+      if (ok)
+        __hip_atomic_fetch_or(&wmask[d], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      const u64 peers  = __hip_atomic_load(&wmask[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const u32 before = cnt[w][d];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      const u32 mine   = __builtin_amdgcn_mbcnt_hi((u32) (peers >> 32), __builtin_amdgcn_mbcnt_lo((u32) peers, 0u));
+      rnk[r] = before + mine;
+      if (ok && mine == 0)
+        { cnt[w][d] = (CntT) (before + (u32) __popcll(peers));
+          __hip_atomic_store(&wmask[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+#else
 #pragma unroll
   for (int r = 0; r < IT; r++)
     { const bool ok = t0 + (u32) r * 64 < have;
@@ -257,6 +294,7 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
       if (ok && mine == 0)
         cnt[w][d] = (CntT) (before + (u32) __popc(plo) + (u32) __popc(phi));
     }
+#endif
   __syncthreads();
 
   /* thread d: digit d's count in this tile; publish it, then the places of the digits inside the tile */
