@@ -493,6 +493,8 @@ typedef struct
   int      busy;                    /* named by the pair being computed */
   int      ready;                   /* 0 while the reader thread is still preparing it */
   int      hostready;               /* read and complemented on the host (the reader threads' first stage) */
+  damar_packed pk;                  /* packed != 0: the block is kept as its stretch of the .bps file (blk.bases == NULL), */
+  int      packed;                  /* the GPU unpacks and reverse-complements it (damar_block_upload_packed) */
 } PBlock;
 
 static PBlock *PB;                  /* fixed capacity (PB_max + 8): entries never move while the reader thread fills them */
@@ -508,8 +510,20 @@ static Opts    PB_opts;
 /* read, mask, check, reverse-complement and (on the reader thread) upload one block, both strands */
 static void pblock_load_host(PBlock *b, const Opts *o, int background)
 { double t0 = wall_ms();
-  if (damar_read_block(b->name, &b->blk))
-    { if (background) reader_fail(); else exit(1); }
+  static int unpacked = -1;          /* DAMAR_DB_UNPACKED=1: blocks unpacked and complemented on the host as until round 4 (test hook) */
+  if (unpacked < 0)
+    unpacked = getenv("DAMAR_DB_UNPACKED") != NULL;
+  b->packed = 0;
+  if (unpacked)
+    { if (damar_read_block(b->name, &b->blk))
+        { if (background) reader_fail(); else exit(1); }
+    }
+  else
+    { int r = damar_read_block_packed(b->name, &b->blk, &b->pk);
+      if (r < 0)
+        { if (background) reader_fail(); else exit(1); }
+      b->packed = (r == 0);
+    }
   if (damar_load_masks(&b->blk, (char **) o->mask, o->mtop))
     { printf("[ERROR] - Unable to load track!\n");
       if (background) reader_fail(); else exit(1);
@@ -524,8 +538,14 @@ static void pblock_load_host(PBlock *b, const Opts *o, int background)
 
 static void pblock_upload(PBlock *b)         /* on the copy stream, beside the kernels of the main thread */
 { double t0 = wall_ms();
-  b->dev[0] = damar_block_upload_bg(&b->blk);
-  b->dev[1] = damar_block_upload_bg(&b->cblk);
+  if (b->packed)
+    { b->dev[0] = damar_block_upload_packed(&b->blk, &b->pk, 0);
+      b->dev[1] = damar_block_upload_packed(&b->cblk, &b->pk, 1);
+    }
+  else
+    { b->dev[0] = damar_block_upload_bg(&b->blk);
+      b->dev[1] = damar_block_upload_bg(&b->cblk);
+    }
   P_ms[7] += wall_ms() - t0;
 }
 
@@ -590,6 +610,12 @@ static void pblock_release(PBlock *b)
     { if (b->idx[c] != NULL) damar_index_free(b->idx[c]);
       if (b->dev[c] != NULL) damar_block_free(b->dev[c]);
       b->idx[c] = NULL;  b->dev[c] = NULL;
+    }
+  if (b->packed)
+    { damar_packed_forget(&b->blk);
+      damar_packed_forget(&b->cblk);
+      damar_free_packed(&b->pk);
+      b->packed = 0;
     }
   damar_free_complement(&b->cblk);
   damar_close_block(&b->blk);
@@ -716,7 +742,8 @@ static damar_dev_index *pblock_index(PBlock *b, int comp)
 { if (b->idx[comp] == NULL)
     { double t0 = wall_ms();
       if (b->dev[comp] == NULL)
-        b->dev[comp] = damar_block_upload(comp ? &b->cblk : &b->blk);
+        b->dev[comp] = b->packed ? damar_block_upload_packed(comp ? &b->cblk : &b->blk, &b->pk, comp)
+                                 : damar_block_upload(comp ? &b->cblk : &b->blk);
       P_ms[7] += wall_ms() - t0;
       t0 = wall_ms();
       b->idx[comp] = damar_index_build(b->dev[comp], 0, &b->ilen[comp]);
@@ -1056,10 +1083,16 @@ static int plan_main(const Opts *base, const char *planfile)
   for (i = 0; i < PS_n; i++)
     Free_Align_Spec(PS[i]);
   free(PS);
-  for (i = 0; i < PB_n; i++)
-    pblock_release(PB + i);
-  PB_n = 0;
-  free(PB);
+  /* Releasing the blocks and indexes one by one costs 60 - 75 ms (measured: "drained" to "released" in the DAMAR_CLIPROF
+     timeline) and frees nothing sooner than the process exit that follows does (tools/startup.hip: leaving main with
+     32 GB allocated or with everything freed takes the same 90 - 110 ms of teardown).  DAMAR_PLAN_RELEASE=1 releases
+     anyway (leak checks, callers that keep the process). */
+  if (getenv("DAMAR_PLAN_RELEASE") != NULL)
+    { for (i = 0; i < PB_n; i++)
+        pblock_release(PB + i);
+      PB_n = 0;
+      free(PB);
+    }
   for (i = 0; i < nl; i++)
     { for (j = 0; j < lntok[i]; j++)
         free(ltok[i][j]);
@@ -1067,7 +1100,7 @@ static int plan_main(const Opts *base, const char *planfile)
     }
   free(ltok);
   free(lntok);
-  mark("blocks and indexes released");
+  mark("blocks and indexes released (only with DAMAR_PLAN_RELEASE)");
   damar_set_async(0);
   mark("host pipeline stopped");
   if (getenv("DAMAR_CLIPROF"))

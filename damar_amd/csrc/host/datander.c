@@ -25,6 +25,7 @@ typedef struct
 { char   **name;
   int      n, kmer;
   HITS_DB *blk;
+  damar_packed *pk;             /* pk[i].raw != NULL: block i is kept as its stretch of the .bps file, the GPU unpacks it */
   int     *ready;               /* 1: read, -1: failed */
   int      taken;               /* blocks the main thread has finished with: the reader stays two ahead */
   pthread_mutex_t mu;
@@ -40,7 +41,10 @@ static void *read_ahead(void *arg)
       while (i >= R->taken + 2)
         pthread_cond_wait(&R->cv, &R->mu);
       pthread_mutex_unlock(&R->mu);
-      ok = (damar_read_block(R->name[i], R->blk + i) == 0);
+      if (getenv("DAMAR_DB_UNPACKED") != NULL)                  /* (test hook: unpacked on the host as until round 4) */
+        ok = (damar_read_block(R->name[i], R->blk + i) == 0);
+      else
+        ok = (damar_read_block_packed(R->name[i], R->blk + i, R->pk + i) >= 0);
       if (ok)
         for (r = 0; r < R->blk[i].nreads; r++)
           if (R->blk[i].reads[r].rlen < R->kmer)
@@ -152,6 +156,7 @@ int main(int argc, char *argv[])
 
   R.name = argv + optind;  R.n = argc - optind;  R.kmer = kmer;
   R.blk = (HITS_DB *) calloc((size_t) R.n, sizeof(HITS_DB));
+  R.pk = (damar_packed *) calloc((size_t) R.n, sizeof(damar_packed));
   R.ready = (int *) calloc((size_t) R.n, sizeof(int));
   R.taken = 0;
   pthread_mutex_init(&R.mu, NULL);
@@ -176,7 +181,17 @@ int main(int argc, char *argv[])
         exit(1);
       root = damar_root(R.name[i], ".db");
       spec = New_Align_Spec(ecorr, spacing, blk->freq, nthreads, 1, 0, 0, 0);
-      Match_Self(root, blk, spec);
+      if (R.pk[i].raw != NULL)                       /* Match_Self (scrub/tandem.c:1182) on a block that stays packed on the host */
+        { damar_dev_block *dev = damar_block_upload_packed(blk, R.pk + i, 0);
+          if (VERBOSE)
+            printf("\nIndexing %s\n\nComparing %s to itself\n", root, root);
+          damar_match_self(blk, dev, spec, NULL);
+          damar_block_free(dev);
+          damar_packed_forget(blk);
+          damar_free_packed(R.pk + i);
+        }
+      else
+        Match_Self(root, blk, spec);
       Write_Overlap_Buffer(spec, outdir, outdir, root, root, blk->ufirst + blk->nreads - 1);
       Reset_Overlap_Buffer(spec);
       Free_Align_Spec(spec);

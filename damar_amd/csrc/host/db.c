@@ -132,7 +132,7 @@ static void unpack_bytes(const unsigned char *src, size_t nbytes, char *dst)
   }
 }
 
-int damar_read_block(const char *name, HITS_DB *block)
+static int read_block_impl(const char *name, HITS_DB *block, damar_packed *pk)
 { char   *root = damar_root(name, ".db");
   char   *dir  = dir_of(name);
   char   *dot;
@@ -238,7 +238,7 @@ int damar_read_block(const char *name, HITS_DB *block)
       goto fail;
     }
 
-  { char  *seq = (char *) big_alloc((size_t) (block->totlen + block->nreads + 4) + 64, "block bases");
+  { char  *seq;
     int64  o = 0;
     /* the reads of a block lie back to back in the .bps file: ONE read of the stretch (a seek + read per read was 11 600
        system calls for a 135 Mbp block), then every read is unpacked out of it, whole bytes eight at a time */
@@ -261,6 +261,30 @@ int damar_read_block(const char *name, HITS_DB *block)
           }
       }
 
+    if (pk != NULL && raw != NULL && f1 - f0 < 0xffffffffll)
+      { /* the caller keeps the block as it lies in the file */
+        { static int64 serial = 0;
+          pk->serial = __atomic_add_fetch(&serial, 1, __ATOMIC_RELAXED);
+        }
+        pk->raw  = raw;
+        pk->nraw = f1 - f0;
+        pk->foff = (uint32 *) xmalloc(sizeof(uint32) * (size_t) (block->nreads + 1), "read offsets");
+        for (i = 0; i < block->nreads; i++)
+          { pk->foff[i] = (uint32) (reads[i].boff - f0);
+            reads[i].boff = o;
+            o += reads[i].rlen + 1;
+          }
+        reads[block->nreads].boff = o;
+        block->bases  = NULL;
+        block->loaded = 0;
+        fclose(bps);
+        fclose(idx);
+        fclose(stub);
+        free(dir);
+        free(root);
+        return 0;
+      }
+    seq = (char *) big_alloc((size_t) (block->totlen + block->nreads + 4) + 64, "block bases");
     *seq++ = 4;
     for (i = 0; i < block->nreads; i++)
       { int    len  = reads[i].rlen;
@@ -317,6 +341,40 @@ fail:
   free(dir);
   free(root);
   return -1;
+}
+
+int damar_read_block(const char *name, HITS_DB *block)
+{ return read_block_impl(name, block, NULL);
+}
+
+int damar_read_block_packed(const char *name, HITS_DB *block, damar_packed *pk)
+{ int r;
+  pk->raw = NULL;  pk->nraw = 0;  pk->foff = NULL;  pk->serial = 0;
+  r = read_block_impl(name, block, pk);
+  if (r != 0)
+    return -1;
+  return pk->raw != NULL ? 0 : 1;
+}
+
+void damar_free_packed(damar_packed *pk)
+{ free(pk->raw);
+  free(pk->foff);
+  pk->raw = NULL;  pk->foff = NULL;  pk->nraw = 0;
+}
+
+void damar_unpack_read(const damar_packed *pk, const HITS_DB *block, int r, int comp, char *dst)
+{ const int len = block->reads[r].rlen;
+  const unsigned char *p = pk->raw + pk->foff[r];
+  int x;
+  for (x = 0; x < len; x++)
+    { const int b = (p[x >> 2] >> (6 - 2 * (x & 3))) & 3;
+      if (comp)
+        dst[len - 1 - x] = (char) (3 - b);
+      else
+        dst[x] = (char) b;
+    }
+  dst[-1] = 4;
+  dst[len] = 4;
 }
 
 static void free_tracks(HITS_TRACK *t)
@@ -407,21 +465,24 @@ static void mirror_track(const HITS_DB *block, const int64 *tano, const int *tat
    command-line driver prepares the next block on a second thread.  Release with damar_free_complement. */
 void damar_complement_copy(const HITS_DB *block, HITS_DB *out)
 { int64 n = block->reads[block->nreads].boff;
-  char *seq = (char *) big_alloc((size_t) n + 1 + 64, "complement block");
+  char *seq = NULL;
   const HITS_TRACK *src;
   float x;
   int   i;
 
-  *seq++ = 4;
   *out = *block;
-  out->bases  = (void *) seq;
   out->tracks = NULL;
   x = out->freq[0]; out->freq[0] = out->freq[3]; out->freq[3] = x;
   x = out->freq[1]; out->freq[1] = out->freq[2]; out->freq[2] = x;
-  for (i = 0; i < block->nreads; i++)             /* every read reversed and complemented straight out of the forward block */
-    { const int64 bo = block->reads[i].boff;
-      rc_copy(seq + bo, ((const char *) block->bases) + bo, block->reads[i].rlen);
-      seq[bo + block->reads[i].rlen] = 4;
+  if (block->bases != NULL)                        /* (a packed block has none: the GPU complements it, damar_block_upload_packed) */
+    { seq = (char *) big_alloc((size_t) n + 1 + 64, "complement block");
+      *seq++ = 4;
+      out->bases = (void *) seq;
+      for (i = 0; i < block->nreads; i++)         /* every read reversed and complemented straight out of the forward block */
+        { const int64 bo = block->reads[i].boff;
+          rc_copy(seq + bo, ((const char *) block->bases) + bo, block->reads[i].rlen);
+          seq[bo + block->reads[i].rlen] = 4;
+        }
     }
   for (src = block->tracks; src != NULL; src = src->next)
     { const int64 *tano = (const int64 *) src->anno;

@@ -43,10 +43,12 @@ typedef struct
    wavefronts and one seed wavefront share a SIMD, and at equal priority the seed wavefront -- which mostly waits for memory --
    gets a fifth of the issue slots whenever it is ready.  Raised priority lets it issue at once and go back to waiting.
    Which kernels do so is a run-time choice per source file (damar_*_set_prio; shim.hip: DAMAR_SEED_PRIO). */
-#define SEED_PRIO_VAR(name) static __device__ int name = 0;
+#define SEED_PRIO_VAR(name, dflt) static __device__ int name = dflt;  static int name##_host = dflt;
 #define SEED_PRIO(name)     do { if (name) __builtin_amdgcn_s_setprio(3); } while (0)
+/* (a copy to a device symbol loads the file's code object and waits for the copy: only when the value differs from what
+   the code object already holds -- the defaults are the compiled-in values, so that a cold command sets nothing) */
 #define SEED_PRIO_SETTER(fn, name) \
-  void fn(int on) { HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(name), &on, sizeof(int))); }
+  void fn(int on) { if (on != name##_host) { HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(name), &on, sizeof(int)));  name##_host = on; } }
 
 #define COARSE_SHIFT 9
 #define PK_PAD 4
@@ -80,9 +82,13 @@ __device__ __forceinline__ u32 pos_encode(const DevBlock &b, u32 r, u32 x, u32 p
    of the reversed copy: pk points PK_PAD words into an array of 2 * damar_pack_words(total) words */
 long long damar_pack_words(u32 total);
 void damar_launch_pack_bases(const u8 *bases, u32 total, u32 *pk, hipStream_t st);
+/* the block out of its .bps stretch (kmer_index.hip unpack_bps); blk needs boff, coarse, total; bases preset to 4 */
+void damar_launch_unpack_bps(const u8 *raw, const u32 *foff, const DevBlock *blk, int comp, u8 *bases, hipStream_t st);
 
 /* kmer_index.hip */
 /* codes: u32 (k <= 16) or, with wide != 0, u64 (k <= 32) */
+void damar_preload_index(void);  void damar_preload_scan(void);  void damar_preload_sort(void);
+void damar_preload_merge(void);  void damar_preload_report(void);
 void damar_sort_set_prio(int on);
 void damar_merge_set_prio(int on);
 void damar_index_set_prio(int on);

@@ -14,7 +14,7 @@
 #include "dev_common.h"
 #include "kernels.h"
 
-SEED_PRIO_VAR(g_index_prio)
+SEED_PRIO_VAR(g_index_prio, 0)
 SEED_PRIO_SETTER(damar_index_set_prio, g_index_prio)
 
 
@@ -311,10 +311,59 @@ void pack_bases(const u8 *__restrict__ bases, long long nwords, long long total,
   pk[nwords + w] = r;
 }
 
+/* A block as it lies in the .bps file (raw: 2 bits per base, four per byte, first base in the top bits, every read
+   padded to a byte; foff[r] = where read r starts in raw) into the layout Read_All_Sequences gives it (db/DB.c:1562-1600:
+   one byte per base, read r at boff[r], a 4 behind every read) -- or, with comp, into the layout of the block's reverse
+   complement (daligner.c:511-570: every read reversed in place, bases 3 - x).  One thread per four output bytes; bases
+   must have been set to 4 beforehand (the terminators are not written here).  The host used to do both (37 + 37 ms per
+   135 Mbp block and strand on a reader thread, then 2 x 135 MB over PCIe: round 5 sends 34 MB once). */
+__global__ __launch_bounds__(256)
+void unpack_bps(const u8 *__restrict__ raw, const u32 *__restrict__ foff, DevBlock blk, int comp, u8 *__restrict__ bases)
+{ const u32 p0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (p0 >= blk.total)
+    return;
+  u32 r = read_of_pos(blk, p0);
+  u32 b0 = blk.boff[r], len = blk.boff[r + 1] - b0 - 1, fo = foff[r];
+  u32 word = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    { const u32 p = p0 + (u32) j;
+      u32 v = 4;
+      if (p < blk.total)
+        { if (p >= b0 + len + 1)                         /* into the next read (reads are at least one base long) */
+            { r += 1;
+              b0 = blk.boff[r];  len = blk.boff[r + 1] - b0 - 1;  fo = foff[r];
+            }
+          const u32 x = p - b0;
+          if (x < len)
+            { const u32 y = comp ? len - 1 - x : x;
+              v = ((u32) raw[fo + (y >> 2)] >> (6 - 2 * (y & 3))) & 3u;
+              if (comp)
+                v = 3 - v;
+            }
+        }
+      word |= v << (8 * j);
+    }
+  *(u32 *) (bases + p0) = word;
+}
+
+void damar_launch_unpack_bps(const u8 *raw, const u32 *foff, const DevBlock *blk, int comp, u8 *bases, hipStream_t st)
+{ if (blk->total == 0)
+    return;
+  hipLaunchKernelGGL(unpack_bps, dim3((blk->total / 4 + 256) / 256), dim3(256), 0, st, raw, foff, *blk, comp, bases);
+}
+
 /* pk must hold 2 * damar_pack_words(total) words */
 long long damar_pack_words(u32 total) { return (long long) (total >> 4) + 1 + 2 * PK_PAD; }      /* words -PK_PAD .. total/16 + PK_PAD */
 
 void damar_launch_pack_bases(const u8 *bases, u32 total, u32 *pk, hipStream_t st)
 { const long long nwords = damar_pack_words(total);
   hipLaunchKernelGGL(pack_bases, dim3((u32) ((nwords + 255) / 256)), dim3(256), 0, st, bases, nwords, (long long) total, pk);
+}
+
+/* loads this file's code object now (a lazy load otherwise happens at the first launch, on the launching thread): called by
+   the library's start-up thread, beside the caller's first uploads (shim.hip damar_hip_init) */
+void damar_preload_index(void)
+{ hipFuncAttributes fa;
+  (void) hipFuncGetAttributes(&fa, (const void *) pack_bases);
 }

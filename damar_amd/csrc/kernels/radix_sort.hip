@@ -30,7 +30,7 @@
 #include "dev_common.h"
 #include "kernels.h"
 
-SEED_PRIO_VAR(g_sort_prio)
+SEED_PRIO_VAR(g_sort_prio, 1)
 SEED_PRIO_SETTER(damar_sort_set_prio, g_sort_prio)
 
 #ifndef OS_THREADS
@@ -544,3 +544,10 @@ int damar_radix_sort_keys_u64(u64 *k0, u64 *k1, u64 n, int lobit, int hibit, voi
 void damar_radix_sort_split_u64(u64 *k0, u64 *k1, u64 n, int lobit, int hibit, u32 *ohi, u32 *olo, void *work,
                                 hipStream_t st)
 { onesweep_impl<u64, false>(k0, NULL, k1, NULL, n, lobit, hibit, ohi, olo, work, st); }
+
+/* loads this file's code object now (a lazy load otherwise happens at the first launch, on the launching thread): called by
+   the library's start-up thread, beside the caller's first uploads (shim.hip damar_hip_init) */
+void damar_preload_sort(void)
+{ hipFuncAttributes fa;
+  (void) hipFuncGetAttributes(&fa, (const void *) onesweep_hist<u64>);
+}

@@ -1839,3 +1839,9 @@ void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks,
 }
 
 #include "report_packed.h"
+
+/* see damar_preload_index (kmer_index.hip) */
+void damar_preload_report(void)
+{ hipFuncAttributes fa;
+  (void) hipFuncGetAttributes(&fa, (const void *) report2_kernel);
+}

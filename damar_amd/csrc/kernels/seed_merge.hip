@@ -20,7 +20,7 @@
 #include "dev_common.h"
 #include "kernels.h"
 
-SEED_PRIO_VAR(g_merge_prio)
+SEED_PRIO_VAR(g_merge_prio, 0)
 SEED_PRIO_SETTER(damar_merge_set_prio, g_merge_prio)
 
 
@@ -1119,4 +1119,11 @@ void damar_launch_work_cost(const u64 *keys, const u32 *vals, u64 nhits, int pbi
     return;
   hipLaunchKernelGGL(work_cost, dim3((nwork + 255) / 256), dim3(256), 0, st, keys, vals, nhits, pbits, abits, dbits, aboff, bboff,
                      work, nwork, coarse, key, val);
+}
+
+/* loads this file's code object now (a lazy load otherwise happens at the first launch, on the launching thread): called by
+   the library's start-up thread, beside the caller's first uploads (shim.hip damar_hip_init) */
+void damar_preload_merge(void)
+{ hipFuncAttributes fa;
+  (void) hipFuncGetAttributes(&fa, (const void *) merge_emit);
 }

@@ -106,3 +106,10 @@ void damar_tile_offsets_u32(const u32 *in, u64 n, void *work, u64 *total_dev, hi
 void damar_scan_tile_counts(u32 *tcount, u32 ntiles, u64 *total_dev, hipStream_t st)
 { hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, st, tcount, ntiles, total_dev);
 }
+
+/* loads this file's code object now (a lazy load otherwise happens at the first launch, on the launching thread): called by
+   the library's start-up thread, beside the caller's first uploads (shim.hip damar_hip_init) */
+void damar_preload_scan(void)
+{ hipFuncAttributes fa;
+  (void) hipFuncGetAttributes(&fa, (const void *) scan_tile_sums);
+}

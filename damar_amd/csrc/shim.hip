@@ -15,6 +15,7 @@
 #include <deque>
 #include <string>
 #include <thread>
+#include <atomic>
 #include <mutex>
 #include <condition_variable>
 #include <string.h>
@@ -83,6 +84,21 @@ static hipStream_t  G_st;
 static hipStream_t   G_copy;                /* record downloads of the asynchronous mode */
 static hipStream_t   G_rep;                 /* report launches of the asynchronous mode: beside the next comparisons' seed stages */
 static hipStream_t   G_ctl;                 /* small downloads (a launch's counters) that must not queue behind anything */
+static std::thread  *G_late = NULL;         /* creates G_copy, G_rep, G_ctl behind damar_hip_init (see there) */
+static std::mutex    G_late_mu;
+static std::atomic<int> G_late_pending(0);
+static hipStream_t preload_stream(void);
+static void late_streams(void)              /* before the first use of G_copy / G_rep / G_ctl */
+{ if (G_late_pending.load(std::memory_order_acquire) == 0)
+    return;
+  std::lock_guard<std::mutex> lk(G_late_mu);
+  if (G_late != NULL)
+    { G_late->join();
+      delete G_late;
+      G_late = NULL;
+      G_late_pending.store(0, std::memory_order_release);
+    }
+}
 static hipEvent_t    G_front_done;          /* the seed stages a report launch reads from are complete */
 static hipEvent_t    G_rep_done;            /* the report launch in flight is complete (DAMAR_OVERLAP=2) */
 static hipEvent_t    G_report_done;
@@ -226,7 +242,11 @@ extern "C" int damar_hip_numa_node(int device)
 
 extern "C" int damar_hip_init(int device)
 { int ndev = 0;
+  const bool iprof = getenv("DAMAR_INITPROF") != NULL;      /* where the bring-up time goes, on stderr */
+  const double ip0 = now_ms();
+#define INIT_MARK(what) do { if (iprof) fprintf(stderr, "init: +%.1f ms %s\n", now_ms() - ip0, what); } while (0)
   hipError_t e = hipGetDeviceCount(&ndev);
+  INIT_MARK("hipGetDeviceCount");
   if (e != hipSuccess || ndev <= 0)
     { fprintf(stderr, "damar: FATAL: no HIP device visible (%s); libdamar_hip has no CPU fallback\n",
               hipGetErrorString(e));
@@ -246,16 +266,49 @@ extern "C" int damar_hip_init(int device)
   HIP_CHECK(hipSetDevice(device));
   G_device = device;
   HIP_CHECK(hipGetDeviceProperties(&G_prop, device));
+  INIT_MARK("hipSetDevice + hipGetDeviceProperties");
   if (!G_ready)
     { if (strncmp(G_prop.gcnArchName, "gfx950", 6) != 0 && getenv("DAMAR_ANY_ARCH") == NULL)
         { fprintf(stderr, "damar: FATAL: device %d is %s; the kernels of this library are built for gfx950 (MI355X)\n",
                   device, G_prop.gcnArchName);
           die();
         }
+      /* A stream costs 10 - 20 ms to create (a hardware queue each), a file's code object 4 - 10 ms to load, the first
+         host-to-device copy of a process another 10 - 15 ms (tools/startup.hip, scripts/gpu_hiptrace.sh,
+         profiles/r05_startup.txt) -- and a cold command is 0.25 s of kernels.  A start-up thread does, while this one
+         creates the main stream and returns to its caller: the preload stream the block readers are waiting for and a
+         first small copy on it, the seed side's code objects in the order a job needs them, the copy / report /
+         control streams (first used when the first report launch is due: late_streams() joins the thread), the
+         report kernel's code object. */
+      G_late_pending.store(1, std::memory_order_release);
+      G_late = new std::thread([device]()
+        { const double t0 = now_ms();
+          HIP_CHECK(hipSetDevice(device));
+          { hipStream_t ps = preload_stream();
+            void *d = NULL;
+            static char warm[4096];
+            HIP_CHECK(hipMalloc(&d, sizeof(warm)));
+            HIP_CHECK(hipMemcpyAsync(d, warm, sizeof(warm), hipMemcpyHostToDevice, ps));
+            HIP_CHECK(hipStreamSynchronize(ps));
+            HIP_CHECK(hipFree(d));
+          }
+          const double t1 = now_ms();
+          damar_preload_index();
+          damar_preload_sort();
+          damar_preload_merge();
+          damar_preload_scan();
+          const double t2 = now_ms();
+          HIP_CHECK(hipStreamCreate(&G_copy));
+          HIP_CHECK(hipStreamCreate(&G_rep));
+          HIP_CHECK(hipStreamCreate(&G_ctl));
+          const double t3 = now_ms();
+          damar_preload_report();
+          if (getenv("DAMAR_INITPROF") != NULL)
+            fprintf(stderr, "init: start-up thread: preload stream + first copy %.1f ms, code objects of the seed side %.1f ms, three "
+                            "streams %.1f ms, report code object %.1f ms\n", t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
+        });
       HIP_CHECK(hipStreamCreate(&G_st));
-      HIP_CHECK(hipStreamCreate(&G_copy));
-      HIP_CHECK(hipStreamCreate(&G_rep));
-      HIP_CHECK(hipStreamCreate(&G_ctl));
+      INIT_MARK("first stream");
       { /* which seed-side kernels raise their wave priority (kernels/kernels.h SEED_PRIO): 1 = sorts, 2 = merge and
            work list, 4 = k-mer tuples.  Config-2 step on three boxes (profiles/r03_sweeps.txt): none 398 / 415 / 434 ms,
            sorts only 403 / 405, all 409 / 413 / 408: the sorts (a chain of tiles through the look-back) are the kernels
@@ -280,7 +333,9 @@ extern "C" int damar_hip_init(int device)
           MEM_PHYSICAL = phys;
         }
       G_ready = 1;
+      INIT_MARK("events, done");
     }
+#undef INIT_MARK
   return ndev;
 }
 
@@ -374,7 +429,7 @@ struct damar_dev_block
   int  nreads;
 };
 
-static damar_dev_block *block_upload_on(const HITS_DB *block, hipStream_t st);
+static damar_dev_block *block_upload_on(const HITS_DB *block, hipStream_t st, const damar_packed *pk = NULL, int comp = 0);
 
 extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
 { ensure_init();
@@ -387,14 +442,27 @@ extern "C" damar_dev_block *damar_block_upload(const HITS_DB *block)
 static std::mutex PL_mu;
 static std::vector<std::pair<const void *, damar_dev_block *>> PL_ready;
 static hipStream_t PL_st = NULL;
+static std::atomic<int> PL_state(0);         /* 0: nobody has asked for it, 1: being created (by the start-up thread of damar_hip_init or
+                                                by the first caller), 2: there */
+static hipStream_t preload_stream(void)
+{ int s = PL_state.load(std::memory_order_acquire);
+  if (s == 2)
+    return PL_st;
+  int zero = 0;
+  if (s == 0 && PL_state.compare_exchange_strong(zero, 1))
+    { HIP_CHECK(hipStreamCreateWithFlags(&PL_st, hipStreamNonBlocking));
+      PL_state.store(2, std::memory_order_release);
+      return PL_st;
+    }
+  while (PL_state.load(std::memory_order_acquire) != 2)
+    usleep(50);
+  return PL_st;
+}
 
 extern "C" void damar_block_preload(const HITS_DB *block)
 { ensure_init();
   HIP_CHECK(hipSetDevice(G_device));          /* the current device is a per-thread setting */
-  { std::lock_guard<std::mutex> lk(PL_mu);
-    if (PL_st == NULL)
-      HIP_CHECK(hipStreamCreateWithFlags(&PL_st, hipStreamNonBlocking));
-  }
+  (void) preload_stream();
   damar_dev_block *b = block_upload_on(block, PL_st);
   std::lock_guard<std::mutex> lk(PL_mu);
   PL_ready.push_back(std::make_pair((const void *) block->bases, b));
@@ -405,11 +473,62 @@ extern "C" void damar_block_preload(const HITS_DB *block)
 extern "C" damar_dev_block *damar_block_upload_bg(const HITS_DB *block)
 { ensure_init();
   HIP_CHECK(hipSetDevice(G_device));          /* the current device is a per-thread setting */
-  { std::lock_guard<std::mutex> lk(PL_mu);
-    if (PL_st == NULL)
-      HIP_CHECK(hipStreamCreateWithFlags(&PL_st, hipStreamNonBlocking));
-  }
+  (void) preload_stream();
   return block_upload_on(block, PL_st);
+}
+
+/* A block that the host keeps packed (damar_read_block_packed: block->bases == NULL): the forward strand (comp 0) or the
+ * reverse complement (comp 1) is unpacked on the device, on the preload stream like damar_block_upload_bg.  The host
+ * tail needs the bases of a read pair only where two local alignments have to be bridged by a realignment (filter.c:1950
+ * -2059, a few pairs in a thousand): it unpacks those reads out of the registered stretch (host_read). */
+static std::mutex PK_mu;
+static std::vector<std::pair<const HITS_READ *, const damar_packed *>> PK_reg;      /* by the read table: the tail works on COPIES of
+                                                                                       the block records, and a block shares its
+                                                                                       read table with its complement */
+
+extern "C" damar_dev_block *damar_block_upload_packed(const HITS_DB *block, const damar_packed *pk, int comp)
+{ ensure_init();
+  HIP_CHECK(hipSetDevice(G_device));          /* the current device is a per-thread setting */
+  (void) preload_stream();
+  { std::lock_guard<std::mutex> lk(PK_mu);
+    bool have = false;
+    for (auto &e : PK_reg)
+      if (e.first == block->reads)
+        { e.second = pk;  have = true; }
+    if (!have)
+      PK_reg.push_back(std::make_pair((const HITS_READ *) block->reads, pk));
+  }
+  return block_upload_on(block, PL_st, pk, comp);
+}
+
+/* the block is about to be closed: the tail must have drained (damar_async_drain) */
+extern "C" void damar_packed_forget(const HITS_DB *block)
+{ std::lock_guard<std::mutex> lk(PK_mu);
+  for (size_t i = 0; i < PK_reg.size(); i++)
+    if (PK_reg[i].first == block->reads)
+      { PK_reg.erase(PK_reg.begin() + i);
+        break;
+      }
+}
+
+/* read r of a host block, one byte per base with a 4 on either side: straight out of an unpacked block, or unpacked
+   into buf out of a packed one (comp: the record is the block's reverse complement) */
+static const char *host_read(const HITS_DB *block, int r, int comp, std::vector<char> &buf)
+{ if (block->bases != NULL)
+    return (const char *) block->bases + block->reads[r].boff;
+  const damar_packed *pk = NULL;
+  { std::lock_guard<std::mutex> lk(PK_mu);
+    for (auto &e : PK_reg)
+      if (e.first == block->reads)
+        pk = e.second;
+  }
+  if (pk == NULL)
+    { fprintf(stderr, "damar: internal error, a block without bases that was never uploaded packed\n");
+      die();
+    }
+  buf.resize((size_t) block->reads[r].rlen + 2);
+  damar_unpack_read(pk, block, r, comp, buf.data() + 1);
+  return buf.data() + 1;
 }
 
 static damar_dev_block *take_preloaded(const HITS_DB *block)
@@ -423,7 +542,12 @@ static damar_dev_block *take_preloaded(const HITS_DB *block)
   return NULL;
 }
 
-static damar_dev_block *block_upload_on(const HITS_DB *block, hipStream_t st)
+struct PackStage { u8 *raw; size_t nraw; u32 *foff; size_t nfoff; int64 holds; };
+static thread_local PackStage TL_stage = { NULL, 0, NULL, 0, 0 };
+
+/* pk != NULL: the block comes as its stretch of the .bps file and is unpacked (comp: into its reverse complement) on the
+   device (kernels/kmer_index.hip unpack_bps); block->bases is not looked at then */
+static damar_dev_block *block_upload_on(const HITS_DB *block, hipStream_t st, const damar_packed *pk, int comp)
 { damar_dev_block *b = (damar_dev_block *) calloc(1, sizeof(damar_dev_block));
   int    n = block->nreads;
   int64  total = block->reads[n].boff;
@@ -451,10 +575,35 @@ static damar_dev_block *block_upload_on(const HITS_DB *block, hipStream_t st)
   HIP_CHECK(hipMemsetAsync(b->bases_alloc, 4, (size_t) total + 192, st));
   b->boff   = (u32 *) dmalloc(sizeof(u32) * ((size_t) n + 1));
   b->coarse = (u32 *) dmalloc(sizeof(u32) * nq);
-  HIP_CHECK(hipMemcpyAsync(b->bases_alloc + 63, ((const char *) block->bases) - 1, (size_t) total + 1,
-                           hipMemcpyHostToDevice, st));
+  if (pk == NULL)
+    HIP_CHECK(hipMemcpyAsync(b->bases_alloc + 63, ((const char *) block->bases) - 1, (size_t) total + 1,
+                             hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemcpyAsync(b->boff, boff.data(), sizeof(u32) * ((size_t) n + 1), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemcpyAsync(b->coarse, coarse.data(), sizeof(u32) * nq, hipMemcpyHostToDevice, st));
+  if (pk != NULL)
+    { /* the stretch goes up once per host thread and block: a block's two strands are unpacked out of the same copy
+         (TL_stage remembers what it holds).  The staging buffers belong to the thread and are never freed: a hipFree
+         waits for every stream of the device, i.e. for the kernels of the thread that computes */
+      DevBlock tmp;
+      memset(&tmp, 0, sizeof(tmp));
+      tmp.boff = b->boff;  tmp.coarse = b->coarse;  tmp.total = (u32) total;  tmp.nreads = (u32) n;
+      if (TL_stage.holds != pk->serial)
+        { if (TL_stage.nraw < (size_t) pk->nraw + 64)
+            { if (TL_stage.raw) HIP_CHECK(hipFree(TL_stage.raw));
+              TL_stage.nraw = (size_t) pk->nraw + ((size_t) pk->nraw >> 3) + 4096;
+              TL_stage.raw  = (u8 *) dmalloc(TL_stage.nraw);
+            }
+          if (TL_stage.nfoff < (size_t) n + 1)
+            { if (TL_stage.foff) HIP_CHECK(hipFree(TL_stage.foff));
+              TL_stage.nfoff = (size_t) n + ((size_t) n >> 3) + 1024;
+              TL_stage.foff  = (u32 *) dmalloc(sizeof(u32) * TL_stage.nfoff);
+            }
+          HIP_CHECK(hipMemcpyAsync(TL_stage.raw, pk->raw, (size_t) pk->nraw, hipMemcpyHostToDevice, st));
+          HIP_CHECK(hipMemcpyAsync(TL_stage.foff, pk->foff, sizeof(u32) * (size_t) n, hipMemcpyHostToDevice, st));
+          TL_stage.holds = pk->serial;
+        }
+      damar_launch_unpack_bps(TL_stage.raw, TL_stage.foff, &tmp, comp, b->bases_alloc + 64, st);
+    }
   HIP_CHECK(hipStreamSynchronize(st));
   b->d.bases  = b->bases_alloc + 64;
   b->pk_alloc = (u32 *) dmalloc(sizeof(u32) * 2 * (size_t) damar_pack_words((u32) total));      /* forward, then reversed */
@@ -913,6 +1062,7 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
   if (grow || (RS.nslots != nslots && RS.nslots_wanted != nslots))
     { const double g0 = now_ms();
       HIP_CHECK(hipStreamSynchronize(G_st));
+      late_streams();
       HIP_CHECK(hipStreamSynchronize(G_rep));
       if (RS.state)   { HIP_CHECK(hipFree(RS.state)); HIP_CHECK(hipFree(RS.marks)); HIP_CHECK(hipFree(RS.cells));
                         HIP_CHECK(hipFree(RS.buckets)); HIP_CHECK(hipFree(RS.ttmp)); RS.state = NULL; }
@@ -973,7 +1123,8 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
 static void scratch_outputs(u32 rec_cap, u32 tpool_cap)
 { const int c = RS.cur;
   if (RS.rec_cap_set[c] < rec_cap || RS.tpool_cap_set[c] < tpool_cap)
-    { HIP_CHECK(hipStreamSynchronize(G_copy));
+    { late_streams();
+      HIP_CHECK(hipStreamSynchronize(G_copy));
       G_last_d2h[c] = NULL;
       if (RS.rec_cap_set[c] < rec_cap)
         { RS.rec_cap_set[c] = rec_cap + (rec_cap >> 2);
@@ -1078,6 +1229,7 @@ static double now_ms(void)
 /* Page-locked landing buffers for the records and trace points of one report launch, recycled
  * through a small pool: the download runs at PCIe speed and nothing is allocated or touched
  * for the first time inside the timed loop. */
+static bool   A_on = false;                   /* the asynchronous host pipeline is running (damar_set_async) */
 struct HostBuf
 { LaRecord *recs;   size_t rec_cap;
   u16      *tpool;  size_t tp_cap;
@@ -1089,8 +1241,36 @@ struct HostBuf
 static std::mutex             &HB_mu   = *new std::mutex();
 static std::vector<HostBuf *> &HB_free = *new std::vector<HostBuf *>();
 
+/* Page-locking costs a millisecond per 4 - 5 MB (hipHostMalloc of 70 MB: 13 ms, a hipHostFree 5 ms: scripts/gpu_hiptrace.sh)
+   and the thread that asks is the one that launches the kernels: in a cold four-line plan the two buffers, each
+   allocated at its first launch and grown at its second (cross comparisons hold twice the records of the self
+   comparison a plan starts with), were 60 ms of that thread's 490.  So a buffer is sized for 2.5 x what its first launch
+   needs, and the first one brings a twin along, allocated by a thread of its own while the tail of the first launch
+   runs. */
+static void hostbuf_size(HostBuf *h, size_t nrec, size_t ntp, bool generous)
+{ if (h->rec_cap < nrec)
+    { if (h->recs) HIP_CHECK(hipHostFree(h->recs));
+      h->rec_cap = generous ? nrec + nrec + (nrec >> 1) + 4096 : nrec + (nrec >> 2) + 4096;
+      HIP_CHECK(hipHostMalloc((void **) &h->recs, sizeof(LaRecord) * h->rec_cap, hipHostMallocDefault));
+    }
+  if (h->tp_cap < ntp)
+    { if (h->tpool) HIP_CHECK(hipHostFree(h->tpool));
+      h->tp_cap = generous ? ntp + ntp + (ntp >> 1) + 65536 : ntp + (ntp >> 2) + 65536;
+      HIP_CHECK(hipHostMalloc((void **) &h->tpool, sizeof(u16) * h->tp_cap, hipHostMallocDefault));
+    }
+}
+
+static HostBuf *hostbuf_new(void)
+{ HostBuf *h = new HostBuf();
+  memset(h, 0, sizeof(*h));
+  HIP_CHECK(hipEventCreate(&h->e0));
+  HIP_CHECK(hipEventCreate(&h->e1));
+  return h;
+}
+
 static HostBuf *hostbuf_get(size_t nrec, size_t ntp)
 { HostBuf *h = NULL;
+  static std::atomic<int> made(0);
   { std::lock_guard<std::mutex> lk(HB_mu);
     if (!HB_free.empty())
       { h = HB_free.back();
@@ -1098,21 +1278,24 @@ static HostBuf *hostbuf_get(size_t nrec, size_t ntp)
       }
   }
   if (h == NULL)
-    { h = new HostBuf();
-      memset(h, 0, sizeof(*h));
-      HIP_CHECK(hipEventCreate(&h->e0));
-      HIP_CHECK(hipEventCreate(&h->e1));
-    }
+    h = hostbuf_new();
   h->pending = false;
-  if (h->rec_cap < nrec)
-    { if (h->recs) HIP_CHECK(hipHostFree(h->recs));
-      h->rec_cap = nrec + (nrec >> 2) + 4096;
-      HIP_CHECK(hipHostMalloc((void **) &h->recs, sizeof(LaRecord) * h->rec_cap, hipHostMallocDefault));
-    }
-  if (h->tp_cap < ntp)
-    { if (h->tpool) HIP_CHECK(hipHostFree(h->tpool));
-      h->tp_cap = ntp + (ntp >> 2) + 65536;
-      HIP_CHECK(hipHostMalloc((void **) &h->tpool, sizeof(u16) * h->tp_cap, hipHostMallocDefault));
+  const bool first = (h->rec_cap == 0 && h->tp_cap == 0);
+  hostbuf_size(h, nrec, ntp, first);
+  if (first && made.fetch_add(1) == 0 && A_on)
+    { /* the twin of the process's first buffer (asynchronous mode: a second launch's records land while the first
+         one's are with the tail) */
+      const size_t rc = h->rec_cap, tc = h->tp_cap;
+      const int dev = G_device;
+      std::thread([rc, tc, dev]()
+        { HIP_CHECK(hipSetDevice(dev));
+          HostBuf *t = hostbuf_new();
+          t->rec_cap = rc;  t->tp_cap = tc;
+          HIP_CHECK(hipHostMalloc((void **) &t->recs, sizeof(LaRecord) * rc, hipHostMallocDefault));
+          HIP_CHECK(hipHostMalloc((void **) &t->tpool, sizeof(u16) * tc, hipHostMallocDefault));
+          std::lock_guard<std::mutex> lk(HB_mu);
+          HB_free.push_back(t);
+        }).detach();
     }
   h->nrec = nrec;  h->ntp = ntp;
   return h;
@@ -1131,7 +1314,7 @@ static int64 tail_range(const LaRecord *recs, const u32 *ord, const u64 *okey, s
 { int64 ncheck = 0;
   std::vector<damar_path> am, bm;
   damar_tpool tp = { NULL, 0, 0 };
-  const char *abase = (const char *) ablock->bases, *bbase = (const char *) bblock->bases;
+  std::vector<char> aread_buf, bread_buf;                       /* (packed host blocks: the reads of a pair that is bridged) */
   size_t i = lo;
   while (i < hi)
     { size_t j = i;
@@ -1211,7 +1394,10 @@ static int64 tail_range(const LaRecord *recs, const u32 *ord, const u64 *okey, s
             }
         }
       damar_bridge_ctx bctx;
-      bctx.aseq = abase + ablock->reads[ar].boff;  bctx.bseq = bbase + bblock->reads[br].boff;
+      if (am.size() > 1 || bm.size() > 1)      /* (only Handle_Redundancies looks at the sequences) */
+        { bctx.aseq = host_read(ablock, ar, 0, aread_buf);  bctx.bseq = host_read(bblock, br, comp, bread_buf); }
+      else
+        { bctx.aseq = NULL;  bctx.bseq = NULL; }
       bctx.alen = al;  bctx.blen = bl;
       damar_emit_pair(am.data(), (int) am.size(), bm.data(), (int) bm.size(), &tp, comp, ts,
                       ar + ablock->ufirst, br + bblock->ufirst, &bctx, obuf, &ncheck);
@@ -1369,7 +1555,6 @@ struct Stage
   std::vector<std::thread *> threads;
   Stage() : busy(0), quit(false) {}
 };
-static bool   A_on = false;
 static Stage &A_s1 = *new Stage();
 static Stage &A_s2 = *new Stage();
 static std::mutex &A_mu = *new std::mutex();            /* the totals below */
@@ -2007,6 +2192,7 @@ static void report_finish(Pending &pd)
   for (;;)
     { /* this launch only: a younger one may be queued behind it on the same stream */
       HIP_CHECK(hipEventSynchronize(pd.done));
+      late_streams();
       HIP_CHECK(hipMemcpyAsync(hc, RS.counters + (size_t) pd.oset * DAMAR_COUNTER_WORDS, sizeof(hc), hipMemcpyDeviceToHost, G_ctl));
       HIP_CHECK(hipStreamSynchronize(G_ctl));
       HIP_CHECK(hipGetLastError());
@@ -2049,6 +2235,7 @@ static void report_finish(Pending &pd)
   const double h3 = now_ms();
   HostBuf *hb = hostbuf_get(hc[1], hc[2]);
   hb->users = n;
+  late_streams();
   hipStream_t cs = A_on ? G_copy : st;
   if (A_on)
     HIP_CHECK(hipEventRecord(hb->e0, cs));       /* (the report kernel has completed: the host synced on it) */
@@ -2278,6 +2465,7 @@ static void flush_accum(void)
                                                                   overflow flags and the re-launch are exercised */
     { pd.cell_cap = 64;  pd.rec_cap = 16;  pd.tp_cap = 512; }
   pd.attempt = 0;
+  late_streams();
   pd.st = defer ? G_rep : G_st;
   for (TailJob *w : AC.writes)
     pd.writes.push_back(w);

@@ -68,12 +68,33 @@ typedef struct
 int   damar_read_block(const char *name, HITS_DB *block);
 void  damar_close_block(HITS_DB *block);
 
+/* A block as it lies in the .bps file: the stretch of the file that holds its reads (2 bits per base, four bases per byte,
+ * first base in the top bits, every read padded to a byte: db/DB.h:292 COMPRESSED_LEN, db/DB.c:334-354 Compress_Read) and
+ * where each read starts in it.  damar_read_block_packed fills one INSTEAD of unpacking the bases (block->bases stays
+ * NULL, block->reads[i].boff are the offsets the unpacked block would have): a quarter of the bytes to read, to keep
+ * and to send to the GPU, which unpacks -- and reverse-complements -- them itself (damar_block_upload_packed,
+ * include/damar_hip.h).  Returns 0 (packed), 1 (the reads of this block do not lie back to back in the file: the block
+ * was read with damar_read_block's unpacking path instead, pk->raw == NULL) or -1. */
+typedef struct
+{ unsigned char *raw;      /* the stretch */
+  int64          nraw;
+  uint32        *foff;     /* [nreads] byte offset of read i in the stretch */
+  int64          serial;   /* a number no other packed block of this process has (what a staged copy is known by) */
+} damar_packed;
+
+int   damar_read_block_packed(const char *name, HITS_DB *block, damar_packed *pk);
+void  damar_free_packed(damar_packed *pk);
+/* read r of the block, one byte per base, into dst[0 .. rlen) (dst[-1] and dst[rlen] are set to 4): as the unpacked block
+ * holds it, or reversed and complemented as the block's complement holds it (daligner.c:511-570) */
+void  damar_unpack_read(const damar_packed *pk, const HITS_DB *block, int r, int comp, char *dst);
+
 /* Out-of-place / in-place reverse complement of a loaded block
  * (daligner.c:511-628 complement_DB, mask tracks not supported yet). */
 HITS_DB *damar_complement_block(HITS_DB *block, int inplace);
 
 /* The same as a re-entrant copy into *out: own bases and own (mirrored) mask tracks, reads and path shared
- * with `block`; released by damar_free_complement.  The command-line driver prepares blocks ahead with it. */
+ * with `block`; released by damar_free_complement.  The command-line driver prepares blocks ahead with it.
+ * A packed block (bases == NULL) gets its frequencies and mask tracks mirrored only. */
 void  damar_complement_copy(const HITS_DB *block, HITS_DB *out);
 void  damar_free_complement(HITS_DB *c);
 

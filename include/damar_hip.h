@@ -48,6 +48,12 @@ damar_dev_block *damar_block_upload(const HITS_DB *block);
 void damar_block_preload(const HITS_DB *block);
 /* damar_block_upload on that second stream, returning the block: for a host thread that prepares blocks ahead. */
 damar_dev_block *damar_block_upload_bg(const HITS_DB *block);
+/* A block the host keeps PACKED (damar_read_block_packed, include/damar_db.h): its .bps stretch goes up once per strand
+ * and the device unpacks it, comp = 1 into the reverse complement (daligner.c:511-570) -- no host unpacking, no host
+ * complement, a quarter of the PCIe bytes.  `block` carries reads / freq / tracks of the strand wanted (for comp 1: what
+ * damar_complement_copy made of the packed block); it stays registered for the host tail until damar_packed_forget. */
+damar_dev_block *damar_block_upload_packed(const HITS_DB *block, const damar_packed *pk, int comp);
+void             damar_packed_forget(const HITS_DB *block);
 void             damar_block_free(damar_dev_block *blk);
 
 /* The opaque index that Sort_Kmers returns (filter.c:753-994): sorted k-mer codes,

@@ -15,7 +15,7 @@ def clean():
     for root, dirs, files in os.walk(work):
         for f in files:
             if f.endswith(".las"): os.remove(os.path.join(root, f))
-for rep in range(2):
+for rep in range(3):
     for libdir in sys.argv[1:]:
         env = dict(os.environ)
         exe = os.path.join(bench.ROOT, libdir, "bin", "daligner")
@@ -27,5 +27,13 @@ for rep in range(2):
                 subprocess.run([exe, "-P", "plan.txt"], cwd=work, env=env, check=True, stdout=subprocess.DEVNULL)
             out.append((time.time() - t0) / n)
             time.sleep(1.0)
-        print("%-12s alone %.3f %.3f   two in a row, per command %.3f" % (libdir, out[0], out[1], out[2]), flush=True)
+        tidy = []
+        for _ in range(3):                               # to process exit, like the reference is timed
+            clean()
+            t0 = time.time()
+            subprocess.run([exe, "-P", "plan.txt"], cwd=work, env=dict(env, DAMAR_PLAN_TIDY="1"), check=True, stdout=subprocess.DEVNULL)
+            tidy.append(time.time() - t0)
+            time.sleep(1.0)
+        print("%-16s returns after %.3f %.3f   two in a row, per command %.3f   to process exit (tidy) %s"
+              % (libdir, out[0], out[1], out[2], " ".join("%.3f" % t for t in tidy)), flush=True)
 shutil.rmtree(work)

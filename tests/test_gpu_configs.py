@@ -183,7 +183,7 @@ def test_gpu_work_queue_and_split_pairs_equal_reference_golden(gpu, tmp_path, na
 
 
 @pytest.mark.parametrize("name,front,cap", [("tiny2", False, None), ("mask_two", True, None), ("tiny_s", False, "2"),
-                                            ("prod", True, "2")])
+                                            ("prod", True, "2"), ("tandem", False, None), ("fusion", False, None)])
 def test_gpu_cli_plan_mode_equals_reference_golden(gpu, tmp_path, name, front, cap):
     """`daligner -P <plan>`: all lines of an HPCdaligner-style plan (comment and LAmerge lines included) in one
     process with blocks and indexes resident; `front` puts the options before -P instead of into the lines,
@@ -219,14 +219,16 @@ def test_gpu_cli_plan_mode_equals_reference_golden(gpu, tmp_path, name, front, c
                                        {"DAMAR_OVERLAP": "0"}, {"DAMAR_OVERLAP": "1", "DAMAR_TEST_SMALL_CAPS": "1", "DAMAR_BATCH": "8"},
                                        {"DAMAR_OVERLAP": "2"}, {"DAMAR_LAUNCH_QUEUE": "2", "DAMAR_BATCH": "1"},
                                        {"DAMAR_LAUNCH_QUEUE": "2", "DAMAR_TEST_SMALL_CAPS": "1", "DAMAR_BATCH": "2"},
-                                       {"DAMAR_SEED_PRIO": "0"}, {"DAMAR_SEED_PRIO": "7", "DAMAR_BATCH_WORK": "1"}])
+                                       {"DAMAR_SEED_PRIO": "0"}, {"DAMAR_SEED_PRIO": "7", "DAMAR_BATCH_WORK": "1"},
+                                       {"DAMAR_DB_UNPACKED": "1"}, {"DAMAR_PLAN_TIDY": "1", "DAMAR_PLAN_RELEASE": "1"}])
 @pytest.mark.parametrize("name", ["tiny2", "prod"])
 def test_gpu_cli_plan_mode_other_launch_shapes_equal_reference_golden(gpu, tmp_path, name, env_extra):
     """The switches that change how the work reaches the report kernel -- the early cut of the seed pairs, the number of
     comparisons per launch, one read pair per wavefront, report launches in flight beside the next seed stages or not
     (with re-launches after buffer overflows), kernels in order on the device with the host pipelined, two launches in
-    flight (the second queued behind the first, also with re-launches), the wave priority of the seed kernels -- must not
-    change a byte of the output."""
+    flight (the second queued behind the first, also with re-launches), the wave priority of the seed kernels, blocks
+    unpacked and complemented on the host instead of kept packed and unpacked by the GPU (the default since round 5),
+    one process that releases everything itself -- must not change a byte of the output."""
     import subprocess
     from conftest import read_case, link_db, compare_las
     from damar_amd import api

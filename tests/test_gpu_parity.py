@@ -72,6 +72,16 @@ def test_gpu_cli_merge_general_path_equals_reference_golden(gpu, tmp_path, name)
     assert compare_las(case, str(tmp_path)) == []
 
 
+@pytest.mark.parametrize("name", ["tan_tandem", "tan_k18"])
+def test_gpu_cli_datander_with_blocks_unpacked_on_the_host_equals_reference_golden(gpu, tmp_path, name):
+    """The datander command keeps a block as its stretch of the .bps file and lets the GPU unpack it (the default, taken
+    by every other datander test); DAMAR_DB_UNPACKED=1 is the path of rounds 1-4: damar_read_block + Match_Self."""
+    from conftest import run_cli
+    case = read_case(name)
+    run_cli(os.path.join(ROOT, "damar_amd", "bin", "daligner"), case, str(tmp_path), env=dict(os.environ, DAMAR_DB_UNPACKED="1"))
+    assert compare_las(case, str(tmp_path)) == []
+
+
 def test_gpu_cli_memory_limit_known_answer(gpu, tmp_path):
     """daligner -M1 on a 25 Mbp block of 250x coverage: the REAL reference (oracle/_ref/daligner
     -v -k14 -M1 -j8 R R in the build container, tests/golden/make_golden.py memlimit) lowers the

@@ -461,3 +461,46 @@ def test_block_read_in_one_stretch_equals_read_by_read(built):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout)
     assert outs[0] == outs[1] == outs[2] and outs[0].count("\n") == len(names), outs
+
+
+def test_packed_block_unpacks_to_the_unpacked_block_and_its_complement(built):
+    """damar_read_block_packed keeps a block as its stretch of the .bps file (the GPU unpacks and reverse-complements it,
+    damar_block_upload_packed); damar_unpack_read is the host's view of one read of it (used by the tail where two local
+    alignments are bridged): every read of three blocks, both strands, against damar_read_block / damar_complement_copy,
+    and the read offsets, frequencies and mirrored mask tracks of the packed block's complement against the unpacked one's."""
+    import ctypes as C
+    from damar_amd import api
+    L = api.lib()
+
+    class Packed(C.Structure):
+        _fields_ = [("raw", C.c_void_p), ("nraw", C.c_int64), ("foff", C.POINTER(C.c_uint32)), ("serial", C.c_int64)]
+    L.damar_read_block_packed.argtypes = [C.c_char_p, C.POINTER(api.HITS_DB), C.POINTER(Packed)]
+    L.damar_read_block_packed.restype = C.c_int
+    L.damar_unpack_read.argtypes = [C.POINTER(Packed), C.POINTER(api.HITS_DB), C.c_int, C.c_int, C.c_void_p]
+    L.damar_unpack_read.restype = None
+    L.damar_free_packed.argtypes = [C.POINTER(Packed)]
+    for d, blk in (("mask_dust", "G.1"), ("long", "G.1"), ("tandem", "G.1")):
+        name = os.path.join(ROOT, "tests", "golden", d, blk)
+        full, cfull = api.HITS_DB(), api.HITS_DB()
+        assert L.damar_read_block(name.encode(), C.byref(full)) == 0
+        L.damar_complement_copy(C.byref(full), C.byref(cfull))
+        pdb, cpdb, pk = api.HITS_DB(), api.HITS_DB(), Packed()
+        assert L.damar_read_block_packed(name.encode(), C.byref(pdb), C.byref(pk)) == 0
+        assert not pdb.bases and pk.raw and pk.nraw > 0
+        L.damar_complement_copy(C.byref(pdb), C.byref(cpdb))
+        assert not cpdb.bases
+        assert [cpdb.freq[i] for i in range(4)] == [cfull.freq[i] for i in range(4)]
+        fr = C.cast(full.reads, C.POINTER(api.HITS_READ))
+        pr = C.cast(pdb.reads, C.POINTER(api.HITS_READ))
+        assert pdb.nreads == full.nreads and pdb.maxlen == full.maxlen and pdb.totlen == full.totlen
+        buf = C.create_string_buffer(full.maxlen + 2)
+        for r in range(full.nreads + 1):
+            assert pr[r].boff == fr[r].boff
+        for r in list(range(0, full.nreads, max(1, full.nreads // 40))) + [full.nreads - 1]:
+            n = fr[r].rlen
+            assert pr[r].rlen == n
+            for comp, src in ((0, full), (1, cfull)):
+                L.damar_unpack_read(C.byref(pk), C.byref(pdb), r, comp, C.addressof(buf) + 1)
+                want = C.string_at(C.c_void_p(src.bases + fr[r].boff - 1), n + 2)
+                assert buf.raw[:n + 2] == want, (d, r, comp)
+        L.damar_free_packed(C.byref(pk))
