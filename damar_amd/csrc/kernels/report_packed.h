@@ -345,6 +345,317 @@ DUO_PART void duo_begin(int job, u32 cbase)
 
 /* The wave steps (align.c:667-999 / 1378-1697) of the halves with md == MD_RUN, until one of them has an event: its
    direction is over (or failed), or its band no longer fits lanes 1..30.  The caller tells which from the state
+   (duo_classify); on entry every such half can step (duo_classify has been through).
+
+   Round 5: what is the same in all lanes of a half -- the band's bounds, the best / last points' coordinates, the loop
+   conditions -- is kept ONCE PER HALF IN SCALAR REGISTERS (x[0] for lanes 0..31, x[1] for lanes 32..63) and computed by the
+   scalar unit, which issues beside the vector pipes: round 4 kept such values in VGPRs (the same number in 32 lanes) and
+   spent a third of the loop's 154 vector instructions per step on them -- the widening bounds, the lane indexes of the
+   last record breakers (a 64-bit shift, a find-first-bit, an xor, a select each), the pruned band and the five loop
+   conditions.  Lane masks were scalar already (round 4); now a mask's half is looked at with s_flbit / s_ff1 / s_bcnt1,
+   the band of a half is s_bfm, the value of the lane a mask points at comes through v_readlane, and only what differs
+   from lane to lane (V, T, the chain heads, the snake, the pebble tests) is left on the vector side.  VERDICT r4 item 2
+   asked for this after the band histogram (profiles/r05_bandhist.txt) had ruled the 16-lane quarters out. */
+#ifndef DUO_SCALAR
+#define DUO_SCALAR 1
+#endif
+#ifndef DUO_DBG
+#define DUO_DBG 0
+#endif
+#if DUO_SCALAR
+#if DUO_DBG & 64
+__device__ int g_dbg[12 * 500];
+__device__ int g_dbgn;
+#endif
+#define DUO_H2 for (int h = 0; h < 2; h++)
+__device__ __forceinline__ int sc(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u32 mhalf(u64 m, int h) { return h ? (u32) (m >> 32) : (u32) m; }
+DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
+{ DUO_NAMES()
+  DUO_CX();
+  const int ave = uni(a.ave_path);
+  const u64 onm = bal(cx.md == MD_RUN);
+  const bool on = inv(onm);
+  const int m = cx.m;
+  const int va0 = cx.va0, vb0 = cx.vb0, alen = cx.alen, blen = cx.blen;
+  const int alim = cx.alim, blim = cx.blim, offa = cx.offa, offb = cx.offb, pa0 = cx.pa0, pb0 = cx.pb0;
+  const int guard = 4 * (alen + blen) + 1024;
+  const u32 below = (1u << s) - 1u;
+  const int lane4 = lane << 2, top4 = (hb + 31) << 2;
+  const u64 upper = 0xffffffff00000000ull;                /* the lanes of half 1 */
+  int dif = cx.dif, besta = cx.besta, ncell = cx.ncell;   /* (per lane: compared with per-lane values, or used by the pebble stores) */
+  int rV = duo_V[lane], rHA = duo_HA[lane], rHB = duo_HB[lane];
+  int Kv = cx.kbase - s;
+  u64 rT = ((u64) duo_Thi[lane] << 32) | duo_Tlo[lane];
+  u32 st_iter = 0, st_cells = 0;
+  if (!onm)
+    return;
+  /* the per-half scalars (a half that is not stepping carries whatever its record holds: nothing of it is written back) */
+  int ls[2], hs[2], kb[2], bk[2], la[2], be[2], mo[2], mlo[2], mhi[2];
+  int left = 0x7fffffff;                                  /* steps until the FIRST stepping half reaches the loop bound (dif <= alen + blen + 64:
+                                                             cannot happen; leaving early for the other half's sake only re-enters the loop) */
+  bool ov[2];                                             /* the pebble pool has run over (looked at when the loop is left) */
+  DUO_H2
+    { const DuoCtx &c = duo_half[h];
+      ls[h] = sc(c.ls);  hs[h] = sc(c.hs);  kb[h] = sc(c.kbase);  bk[h] = sc(c.bestk);  la[h] = sc(c.lasta);  be[h] = sc(c.besta);
+      mo[h] = sc(c.more);  mlo[h] = sc(c.mlo);  mhi[h] = sc(c.mhi);
+      ov[h] = false;
+    }
+  const bool on0 = (u32) onm != 0, on1 = (u32) (onm >> 32) != 0;
+  DUO_H2
+    if (h ? on1 : on0)
+      { const DuoCtx &c = duo_half[h];
+        const int l = sc(c.alen) + sc(c.blen) + 64 - sc(c.dif);
+        left = l < left ? l : left;
+      }
+
+  for (;;)
+    { /* (every few dozen steps) keep the band and the two lanes it may grow into within lanes 1 .. 30 of the half */
+      { int dl[2];
+        bool any = false;
+        DUO_H2
+          { const bool mv = (h ? on1 : on0) && (ls[h] < 2 || hs[h] > 29);
+            dl[h] = mv ? ((31 - (hs[h] - ls[h])) >> 1) - ls[h] : 0;
+            any |= mv;
+          }
+        if (any)
+          { const int dlv = hb ? dl[1] : dl[0];
+            const int src = (hb + ((s - dlv) & 31)) << 2;
+            rV  = __builtin_amdgcn_ds_bpermute(src, rV);
+            rHA = __builtin_amdgcn_ds_bpermute(src, rHA);
+            rHB = __builtin_amdgcn_ds_bpermute(src, rHB);
+            { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+              const u32 th = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+              rT = ((u64) th << 32) | tl;
+            }
+            Kv += dlv;
+            DUO_H2 { kb[h] += dl[h];  ls[h] += dl[h];  hs[h] += dl[h];  mlo[h] += dl[h];  mhi[h] += dl[h]; }
+          }
+      }
+      bool stay;
+      do
+        { /* widen (align.c:675-776) and pick the predecessor (align.c:793-825): K - 1 sits one lane up, K + 1 one lane down */
+          const int K = Kv;
+          u64  actm = 0;
+          int  v, ha, hb_;
+          u64  b;
+          DUO_H2
+            { ls[h] = (ls[h] - 1 > mlo[h]) ? ls[h] - 1 : mlo[h];
+              hs[h] = (hs[h] + 1 < mhi[h]) ? hs[h] + 1 : mhi[h];
+              /* (32-bit arithmetic: whatever the record of a half that is NOT stepping makes of this stays in that half's bits) */
+              const u32 band = (hs[h] >= ls[h]) ? ((2u << (hs[h] - ls[h])) - 1u) << ls[h] : 0u;
+              actm |= (u64) band << (32 * h);
+            }
+#if !(DUO_DBG & 4)
+          left -= 1;
+#endif
+          actm &= onm;
+          { const int am = lane_up(rV), ap = lane_dn(rV), ac = rV;
+            const int nbv = am > ap ? am : ap;
+            const u64 takem = bal(ac < nbv), upm = bal(am < ap);
+            v = inv(takem) ? nbv + 1 : ac + 2;
+            int dsel = inv(upm) ? -4 : 4;
+            dsel = inv(takem) ? dsel : 0;
+            const int src = lane4 + dsel;
+            ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
+            hb_ = __builtin_amdgcn_ds_bpermute(src, rHB);
+            const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+            const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+            b = ((u64) thi << 32) | tlo;
+            dif += 1;
+            st_iter += 1;  st_cells += (u32) __popcll(actm);
+          }
+
+          int Y = 0, na = 1, nb = 1;
+          if (inv(actm))
+            { b <<= 1;
+              const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, pa0, pb0, va0, vb0, alen, blen, K, (v - K) >> 1, b);
+              Y = so.Y;  b = so.b;  na = so.na;  nb = so.nb;
+              v = (Y << 1) + K;
+            }
+          asm("" : "+v"(na), "+v"(nb));            /* (compare behind the join: a bool out of the branch would be made 0 / 1 per lane and compared again) */
+          const u64 bhm = actm & bal(nb == 0), ahm = actm & ~bhm & bal(na == 0);
+
+          /* pebbles (align.c:859-909 / 1569-1618): every mark between the inherited head's and the new position */
+          { const int X = Y + K;
+            int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
+            u64 nam = actm & bal(X >= __mul24(ga, TS) + offa), nbm = actm & bal(Y >= __mul24(gb, TS) + offb);
+            if (nam | nbm)
+              { const int kk = (K ^ m) - m;
+                const u32 w1 = ((u32) kk & 0xffffu) | ((u32) dif << 16);
+                int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
+                int g2 = 0;
+                while (nam)
+                  { GUARD(g2, guard, 5)
+                    const u32 hm = hmask(nam, hb);
+                    const int idx = ncell + __popc(hm & below);
+                    if (inv(nam))
+                      { ga += 1;
+                        if (idx < cell_cap)
+                          { const v2u32 c = { (u32) hax | ((u32) ((ga ^ m) - m) << PK_HBITS), w1 };
+                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
+                          }
+                        hax = idx;
+                      }
+                    ncell += __popc(hm);
+                    nam &= bal(X >= __mul24(ga, TS) + offa);
+                  }
+                while (nbm)
+                  { GUARD(g2, guard, 6)
+                    const u32 hm = hmask(nbm, hb);
+                    const int idx = ncell + __popc(hm & below);
+                    if (inv(nbm))
+                      { gb += 1;
+                        if (idx < cell_cap)
+                          { const v2u32 c = { (u32) hbx | ((u32) ((gb ^ m) - m) << PK_HBITS), w1 };
+                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
+                          }
+                        hbx = idx;
+                      }
+                    ncell += __popc(hm);
+                    nbm &= bal(Y >= __mul24(gb, TS) + offb);
+                  }
+                ha = hax | (ga << PK_HBITS);  hb_ = hbx | (gb << PK_HBITS);
+                { const u64 ovm = bal(ncell > cell_cap);          /* (rare block: a vector compare here costs nothing per step) */
+                  ov[0] |= (u32) ovm != 0;  ov[1] |= (u32) (ovm >> 32) != 0;
+                }
+              }
+          }
+
+          /* commit the new wave (lanes outside the band get V = EDGE again behind the pruning) */
+          rV = v;  rT = b;  rHA = ha;  rHB = hb_;
+
+          /* sequence ends reached: the largest sweep index for A, the smallest for B */
+          if (ahm | bhm)
+            { const u32 am_ = hmask(ahm, hb), bm_ = hmask(bhm, hb);
+              if (am_ | bm_)
+                { if (am_) cold[DC_ACLIP] = 31 - __clz((int) am_);
+                  if (bm_) cold[DC_BCLIP] = __ffs((int) bm_) - 1;
+                }
+              DUO_H2
+                if (mhalf(ahm | bhm, h))
+                  mo[h] = 0;
+            }
+
+          /* new best / last / trim point in sweep order (align.c:911-928 / 1620-1637): record breakers of a prefix
+             maximum; their V is strictly monotone, so the LAST breaker with the wanted property is the one the serial
+             sweep leaves behind, and the new best is the maximum itself */
+          { const u64 candm = actm & bal(v > besta);
+            if (candm)
+              { const int x = pk_prefix_max(inv(candm) ? v : -BIG);
+                /* the maximum over the lanes before this one; what lane 0 of a half receives does not matter: the band
+                   lives in lanes 1 .. 30, lane 0 is never a candidate */
+                int e = __builtin_amdgcn_update_dpp(-BIG, x, 0x138, 0xf, 0xf, false);       /* wave_shr:1 */
+#if DUO_DBG & 1
+                if (s == 0) e = -BIG;
+#endif
+                const u64 rbm = candm & bal(v > e);
+                const u64 mokm = rbm & bal(pk_popc61(b) >= ave);
+                u64 tokm = 0;
+                if (mokm)
+                  tokm = mokm & bal(pk_trim_ok(trimtab, b));
+                const int xl = __builtin_amdgcn_ds_bpermute(top4, x);                             /* the maximum of the half's candidates */
+                besta = xl > besta ? xl : besta;
+                DUO_H2
+                  { const u32 h1 = mhalf(rbm, h), h2 = mhalf(mokm, h);
+                    if (h1)
+                      { bk[h] = kb[h] - (31 - __builtin_clz(h1));
+                        be[h] = __builtin_amdgcn_readlane(x, 32 * h + 31);
+                      }
+                    if (h2)
+                      la[h] = __builtin_amdgcn_readlane(v, 32 * h + 31 - __builtin_clz(h2));
+                  }
+                if (tokm)
+                  { const u32 h3 = hmask(tokm, hb);
+                    if (h3)
+                      { const int l3 = 31 ^ ffbh_raw(h3);
+                        const int v3 = hget(v, hb, l3), h3a = hget(ha, hb, l3), h3b = hget(hb_, hb, l3);
+                        cold[DC_TRIM] = v3;  cold[DC_TRIM + 1] = Kv + s - l3;  cold[DC_TRIM + 2] = dif;
+                        cold[DC_TRIM + 3] = h3a & PK_HMASK;  cold[DC_TRIM + 4] = h3b & PK_HMASK;
+                      }
+                  }
+              }
+          }
+
+          /* clipping at sequence ends (align.c:628-658 / 943-975): rare, on the vector side as in round 4 -- the scalars go
+             there and come back */
+#if DUO_DBG & 2
+          if (true)
+#else
+          if ((on0 && mo[0] == 0) || (on1 && mo[1] == 0))
+#endif
+            { int more = hb ? mo[1] : mo[0], bestk = hb ? bk[1] : bk[0], kbase = hb ? kb[1] : kb[0];
+              int ls_ = hb ? ls[1] : ls[0], hs_ = hb ? hs[1] : hs[0];
+#define ls ls_
+#define hs hs_
+              DUO_CLIP()
+#undef ls
+#undef hs
+              DUO_H2
+                { mo[h] = __builtin_amdgcn_readlane(more, 32 * h);
+                  ls[h] = __builtin_amdgcn_readlane(ls_, 32 * h);  hs[h] = __builtin_amdgcn_readlane(hs_, 32 * h);
+                }
+              (void) bestk;  (void) kbase;
+            }
+
+          /* prune (align.c:977-986 / 1686-1695), and V = EDGE again in every lane outside the band (an empty band
+             comes out as hs < ls) */
+          { const u64 livem = bal(rV >= besta - MAX_WAVE_LAG);
+            u64 bandm = 0;
+            DUO_H2
+              { const u32 was = (hs[h] >= ls[h]) ? ((2u << (hs[h] - ls[h])) - 1u) << ls[h] : 0u;
+                const u32 keep = was & mhalf(livem, h);
+                ls[h] = keep ? __builtin_ctz(keep) : 32;
+                hs[h] = keep ? 31 - __builtin_clz(keep) : -1;
+                const u32 now = keep ? ((2u << (hs[h] - ls[h])) - 1u) << ls[h] : 0u;
+                bandm |= (u64) now << (32 * h);
+              }
+            rV = inv(bandm) ? rV : DUO_EDGE;
+          }
+
+          /* may every half go on as it is?  (a band within lanes 2 .. 29 is no wider than 28; a pebble pool that has
+             run over is noticed when the loop is left for any other reason: its stores are bounded) */
+          stay = true;
+          DUO_H2
+            if (h ? on1 : on0)
+              stay = stay && mo[h] != 0 && la[h] >= be[h] - MAX_TRIM_LAG && hs[h] >= ls[h] && left >= 0 && ls[h] >= 2 && hs[h] <= 29;
+        }
+      while (stay);
+      { bool go = true;
+        DUO_H2
+          if (h ? on1 : on0)
+            go = go && mo[h] != 0 && la[h] >= be[h] - MAX_TRIM_LAG && hs[h] >= ls[h] && left >= 0 && hs[h] - ls[h] <= 27 && !ov[h];
+#if DUO_DBG & 64
+        if (!go && lane == 0)
+          DUO_H2
+            if (h ? on1 : on0)
+              { const int at = atomicAdd(&g_dbgn, 1);
+                if (at < 500)
+                  { int *d = g_dbg + 12 * at;
+                    d[0] = (int) blockIdx.x * 2 + h;  d[1] = (mo[h] == 0) | ((la[h] < be[h] - MAX_TRIM_LAG) << 1) | ((hs[h] < ls[h]) << 2) | ((left < 0) << 3) | ((hs[h] - ls[h] > 27) << 4) | (ov[h] << 5);
+                    d[2] = la[h];  d[3] = be[h];  d[4] = ls[h];  d[5] = hs[h];  d[6] = sc(duo_half[h].dif);  d[7] = sc(duo_half[h].m);  d[8] = left;  d[9] = bk[h];  d[10] = kb[h];  d[11] = sc(duo_half[h].besta);
+                  }
+              }
+#endif
+        if (!go)
+          break;
+      }
+    }
+  { DuoCtx &c0 = duo_half[0];                   /* (every lane adds the same: one record counts for the wavefront) */
+    const u32 lo = c0.n_cells_lo + st_cells;
+    c0.n_cells_hi += (lo < st_cells) ? 1u : 0u;  c0.n_cells_lo = lo;
+    c0.n_iter += st_iter;  c0.n_half += st_iter * ((u32) __popcll(onm) >> 5);
+  }
+  if (on)
+    { duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
+      cx.ls = hb ? ls[1] : ls[0];  cx.hs = hb ? hs[1] : hs[0];  cx.kbase = hb ? kb[1] : kb[0];  cx.dif = dif;  cx.besta = besta;
+      cx.bestk = hb ? bk[1] : bk[0];  cx.lasta = hb ? la[1] : la[0];  cx.more = hb ? mo[1] : mo[0];  cx.ncell = ncell;
+      cx.mlo = hb ? mlo[1] : mlo[0];  cx.mhi = hb ? mhi[1] : mhi[0];
+    }
+}
+#else
+/* The wave steps (align.c:667-999 / 1378-1697) of the halves with md == MD_RUN, until one of them has an event: its
+   direction is over (or failed), or its band no longer fits lanes 1..30.  The caller tells which from the state
    (duo_classify); on entry every such half can step (duo_classify has been through). */
 DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
 { DUO_NAMES()
@@ -530,6 +841,8 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
       cx.lasta = lasta;  cx.more = more;  cx.ncell = ncell;  cx.mlo = mlo;  cx.mhi = mhi;
     }
 }
+
+#endif
 
 /* What the wave loop left for the halves with md == MD_RUN (the reference's loop conditions, in their order) */
 __device__ __forceinline__ void duo_classify(const ReportArgs &a)
@@ -1374,3 +1687,12 @@ void damar_launch_tandem_report2(const ReportArgs *a, const int *dist, int nslot
   jobs_upload(a, 1, st);
   hipLaunchKernelGGL(report2_kernel, dim3(nslots / 2), dim3(64), 0, st, 1, (const LaTask *) NULL, 0u, dist);
 }
+
+#if DUO_DBG & 64
+extern "C" int damar_dbg_read(int *out)
+{ int n = 0;
+  hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_dbgn), sizeof(int));
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(int) * 12 * 500);
+  return n;
+}
+#endif

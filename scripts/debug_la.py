@@ -8,6 +8,9 @@ from damar_amd import api
 comp = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 ntask = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
 gold = sys.argv[3] if len(sys.argv) > 3 else "indel"
+if os.environ.get("DBG_LIBDIR"):               # an experiment build of the library (scripts/build_exp.sh)
+    import damar_amd.lib as dl
+    dl.lib_path = lambda: os.path.join(ROOT, os.environ["DBG_LIBDIR"], "libdamar_hip.so")
 L = api.lib()
 assert L.damar_hip_init(0) >= 1
 L.Set_Filter_Params(14, 6, 0, 35, 4)
@@ -29,6 +32,9 @@ for i in pick:
     if s["aread"] == s["bread"] and not comp:
         continue
     tasks += [int(s["aread"]), int(s["bread"]), int(s["diag"]), int(2 * s["apos"] - s["diag"])]
+if os.environ.get("DBG_ONLY"):                 # only these task indexes (debugging a difference that depends on what shares the wavefront)
+    keep = [int(x) for x in os.environ["DBG_ONLY"].split(",")]
+    tasks = sum((tasks[4 * t:4 * t + 4] for t in keep), [])
 nt = len(tasks) // 4
 ospec = O.lib().New_Align_Spec(.70, 100, oadb.freq, 1, 1, 0, 0, 1)
 spec = L.New_Align_Spec(.70, 100, adb.freq, 1, 1, 0, 0, 1)
@@ -66,3 +72,11 @@ for t in range(nt):
 print("bad", bad, "of", nt)
 for k, v in sorted(kinds.items(), key=lambda kv: -kv[1]):
     print(v, k)
+
+if hasattr(L, "damar_dbg_read"):
+    buf = (C.c_int * (12 * 500))()
+    n = L.damar_dbg_read(buf)
+    print("loop exits", n)
+    for i in range(min(n, 500)):
+        d = buf[12 * i:12 * i + 12]
+        print("  slot %d reason %s la %d be %d ls %d hs %d dif(entry) %d m %d left %d bk %d kb %d besta(entry) %d" % (d[0], bin(d[1]), d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11]))
