@@ -347,29 +347,34 @@ DUO_PART void duo_begin(int job, u32 cbase)
    direction is over (or failed), or its band no longer fits lanes 1..30.  The caller tells which from the state
    (duo_classify); on entry every such half can step (duo_classify has been through).
 
-   Round 5: what is the same in all lanes of a half -- the band's bounds, the best / last points' coordinates, the loop
-   conditions -- is kept ONCE PER HALF IN SCALAR REGISTERS (x[0] for lanes 0..31, x[1] for lanes 32..63) and computed by the
-   scalar unit, which issues beside the vector pipes: round 4 kept such values in VGPRs (the same number in 32 lanes) and
-   spent a third of the loop's 154 vector instructions per step on them -- the widening bounds, the lane indexes of the
-   last record breakers (a 64-bit shift, a find-first-bit, an xor, a select each), the pruned band and the five loop
-   conditions.  Lane masks were scalar already (round 4); now a mask's half is looked at with s_flbit / s_ff1 / s_bcnt1,
-   the band of a half is s_bfm, the value of the lane a mask points at comes through v_readlane, and only what differs
-   from lane to lane (V, T, the chain heads, the snake, the pebble tests) is left on the vector side.  VERDICT r4 item 2
-   asked for this after the band histogram (profiles/r05_bandhist.txt) had ruled the 16-lane quarters out. */
+   Round 5 EXPERIMENT (DUO_SCALAR=1; off by default because it is slower -- kept because the measurement is the point):
+   what is the same in all lanes of a half -- the band, the best / last points' coordinates, the loop conditions -- kept
+   once per half in SCALAR registers and computed by the scalar unit: the band of a half as a 32-bit lane mask (widening
+   = mask | mask << 1 | mask >> 1, within the lanes it may grow into; pruning = the span of the live lanes by s_ff1 /
+   s_flbit / s_bfm), the lane a mask points at read through v_readlane, one `bad` flag instead of five per-step
+   comparisons.  VERDICT r4 item 2 proposed taking the per-alignment bookkeeping out of the full-width stream after the
+   band histogram (profiles/r05_bandhist.txt) had ruled 16-lane quarters out.  Measured on config 2, every kernel alone
+   (scripts/gpu_ab_report.sh, gpu_pmc.sh; profiles/r05_scalar_loop.txt), per loop iteration:
+       round 4 loop (vector)             154 vector + 63 scalar instructions    145 ms of report kernel per step
+       scalars with lane bounds (v1)     140        + 166                       185 ms
+       scalars with band masks (below)   130        + 132                       160 ms
+   i.e. time = 0.75 ms x vector + 0.48 ms x scalar instructions per iteration: the scalar unit is NOT free beside the
+   vector pipes -- a wavefront issues its instructions in order, and what leaves the vector side comes back as 2 - 3
+   scalar instructions (64-bit shifts, compare + select pairs, SGPR spills into VGPR lanes) where one vector instruction
+   served both halves at once.  A conversion pays only below 1.5 scalar per vector instruction saved; the compiler's output
+   for this loop is at 2.9. */
 #ifndef DUO_SCALAR
-#define DUO_SCALAR 1
+#define DUO_SCALAR 0
 #endif
 #ifndef DUO_DBG
 #define DUO_DBG 0
 #endif
 #if DUO_SCALAR
-#if DUO_DBG & 64
-__device__ int g_dbg[12 * 500];
-__device__ int g_dbgn;
-#endif
-#define DUO_H2 for (int h = 0; h < 2; h++)
+/* 32-bit span [lo .. hi] of lane bits (s_bfm_b32) */
+__device__ __forceinline__ u32 span32(int lo, int hi) { return ((1u << (hi - lo + 1)) - 1u) << lo; }
 __device__ __forceinline__ int sc(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ u32 mhalf(u64 m, int h) { return h ? (u32) (m >> 32) : (u32) m; }
+#define DUO_H2 for (int h = 0; h < 2; h++)
+#define DUO_EDGES 0xC0000003C0000003ull                    /* lanes 0, 1, 30, 31 of either half */
 DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
 { DUO_NAMES()
   DUO_CX();
@@ -382,7 +387,6 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
   const int guard = 4 * (alen + blen) + 1024;
   const u32 below = (1u << s) - 1u;
   const int lane4 = lane << 2, top4 = (hb + 31) << 2;
-  const u64 upper = 0xffffffff00000000ull;                /* the lanes of half 1 */
   int dif = cx.dif, besta = cx.besta, ncell = cx.ncell;   /* (per lane: compared with per-lane values, or used by the pebble stores) */
   int rV = duo_V[lane], rHA = duo_HA[lane], rHB = duo_HB[lane];
   int Kv = cx.kbase - s;
@@ -390,66 +394,80 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
   u32 st_iter = 0, st_cells = 0;
   if (!onm)
     return;
-  /* the per-half scalars (a half that is not stepping carries whatever its record holds: nothing of it is written back) */
-  int ls[2], hs[2], kb[2], bk[2], la[2], be[2], mo[2], mlo[2], mhi[2];
-  int left = 0x7fffffff;                                  /* steps until the FIRST stepping half reaches the loop bound (dif <= alen + blen + 64:
+  /* Per-half scalars.  The BAND of a half is a mask of its lanes (the low / high word of `band`); `allow` holds the lanes it
+     may grow into (minp / maxp of align.c:675-776, within lanes 1 .. 30).  A half that is not stepping has an empty band and
+     nothing allowed: nothing of it moves, whatever its record holds (round 5's first version let such a half's stale
+     bounds run on, and its mask bits shifted into the other half's). */
+  const bool on0 = (u32) onm != 0, on1 = (u32) (onm >> 32) != 0;
+  u64 band = 0, allow = 0;
+  int kb[2], bk[2], la[2], be[2], mo[2];
+  int left = 0x7fffffff;                                  /* steps until the first stepping half reaches the loop bound (dif <= alen + blen + 64:
                                                              cannot happen; leaving early for the other half's sake only re-enters the loop) */
-  bool ov[2];                                             /* the pebble pool has run over (looked at when the loop is left) */
+  bool bad = false;                                       /* a stepping half cannot go on: its pass is over (or its pebble pool) */
   DUO_H2
     { const DuoCtx &c = duo_half[h];
-      ls[h] = sc(c.ls);  hs[h] = sc(c.hs);  kb[h] = sc(c.kbase);  bk[h] = sc(c.bestk);  la[h] = sc(c.lasta);  be[h] = sc(c.besta);
-      mo[h] = sc(c.more);  mlo[h] = sc(c.mlo);  mhi[h] = sc(c.mhi);
-      ov[h] = false;
+      kb[h] = sc(c.kbase);  bk[h] = sc(c.bestk);  la[h] = sc(c.lasta);  be[h] = sc(c.besta);  mo[h] = sc(c.more);
+      if (h ? on1 : on0)
+        { const int l0 = sc(c.ls), h0 = sc(c.hs), lo = max(sc(c.mlo), 1), hi = min(sc(c.mhi), 30);
+          const int lf = sc(c.alen) + sc(c.blen) + 64 - sc(c.dif);
+          if (h0 < l0)
+            bad = true;                                   /* (cannot happen: duo_classify has been through) */
+          else
+            band |= (u64) span32(l0, h0) << (32 * h);
+          allow |= (u64) (lo <= hi ? span32(lo, hi) : 0u) << (32 * h);
+          left = lf < left ? lf : left;
+        }
     }
-  const bool on0 = (u32) onm != 0, on1 = (u32) (onm >> 32) != 0;
-  DUO_H2
-    if (h ? on1 : on0)
-      { const DuoCtx &c = duo_half[h];
-        const int l = sc(c.alen) + sc(c.blen) + 64 - sc(c.dif);
-        left = l < left ? l : left;
-      }
 
   for (;;)
-    { /* (every few dozen steps) keep the band and the two lanes it may grow into within lanes 1 .. 30 of the half */
-      { int dl[2];
-        bool any = false;
-        DUO_H2
-          { const bool mv = (h ? on1 : on0) && (ls[h] < 2 || hs[h] > 29);
-            dl[h] = mv ? ((31 - (hs[h] - ls[h])) >> 1) - ls[h] : 0;
-            any |= mv;
-          }
-        if (any)
-          { const int dlv = hb ? dl[1] : dl[0];
-            const int src = (hb + ((s - dlv) & 31)) << 2;
-            rV  = __builtin_amdgcn_ds_bpermute(src, rV);
-            rHA = __builtin_amdgcn_ds_bpermute(src, rHA);
-            rHB = __builtin_amdgcn_ds_bpermute(src, rHB);
-            { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
-              const u32 th = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
-              rT = ((u64) th << 32) | tl;
+    { /* (every few dozen steps) keep the band and the two lanes it may grow into within lanes 1 .. 30 of the half; a band
+         that has outgrown the lanes leaves (duo_classify sends it on its excursion) */
+      if (band & DUO_EDGES)
+        { int dl[2];
+          bool wide = false;
+          DUO_H2
+            { const u32 bh = (u32) (band >> (32 * h));
+              dl[h] = 0;
+              if (bh & 0xC0000003u)
+                { const int l0 = __builtin_ctz(bh), h0 = 31 - __builtin_clz(bh);
+                  wide |= h0 - l0 > 27;
+                  dl[h] = ((31 - (h0 - l0)) >> 1) - l0;
+                }
             }
-            Kv += dlv;
-            DUO_H2 { kb[h] += dl[h];  ls[h] += dl[h];  hs[h] += dl[h];  mlo[h] += dl[h];  mhi[h] += dl[h]; }
+          if (wide)
+            break;
+          const int dlv = hb ? dl[1] : dl[0];
+          const int src = (hb + ((s - dlv) & 31)) << 2;
+          rV  = __builtin_amdgcn_ds_bpermute(src, rV);
+          rHA = __builtin_amdgcn_ds_bpermute(src, rHA);
+          rHB = __builtin_amdgcn_ds_bpermute(src, rHB);
+          { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+            const u32 th = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+            rT = ((u64) th << 32) | tl;
           }
-      }
-      bool stay;
+          Kv += dlv;
+          if (on)                                         /* the growth limits move with the lanes: through the record, they are needed here only */
+            { cx.mlo += dlv;  cx.mhi += dlv; }
+          u64 nb = 0, na = 0;
+          DUO_H2
+            if (h ? on1 : on0)
+              { const DuoCtx &c = duo_half[h];
+                const u32 bh = (u32) (band >> (32 * h));
+                const int lo = max(sc(c.mlo), 1), hi = min(sc(c.mhi), 30);
+                kb[h] += dl[h];
+                nb |= (u64) (dl[h] >= 0 ? bh << dl[h] : bh >> -dl[h]) << (32 * h);
+                na |= (u64) (lo <= hi ? span32(lo, hi) : 0u) << (32 * h);
+              }
+          band = nb;  allow = na;
+        }
+      bool stop;
       do
         { /* widen (align.c:675-776) and pick the predecessor (align.c:793-825): K - 1 sits one lane up, K + 1 one lane down */
           const int K = Kv;
-          u64  actm = 0;
           int  v, ha, hb_;
           u64  b;
-          DUO_H2
-            { ls[h] = (ls[h] - 1 > mlo[h]) ? ls[h] - 1 : mlo[h];
-              hs[h] = (hs[h] + 1 < mhi[h]) ? hs[h] + 1 : mhi[h];
-              /* (32-bit arithmetic: whatever the record of a half that is NOT stepping makes of this stays in that half's bits) */
-              const u32 band = (hs[h] >= ls[h]) ? ((2u << (hs[h] - ls[h])) - 1u) << ls[h] : 0u;
-              actm |= (u64) band << (32 * h);
-            }
-#if !(DUO_DBG & 4)
+          const u64 actm = (band | (band << 1) | (band >> 1)) & allow;       /* (lanes 0 and 31 of a half are never allowed: nothing crosses) */
           left -= 1;
-#endif
-          actm &= onm;
           { const int am = lane_up(rV), ap = lane_dn(rV), ac = rV;
             const int nbv = am > ap ? am : ap;
             const u64 takem = bal(ac < nbv), upm = bal(am < ap);
@@ -516,9 +534,8 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
                     nbm &= bal(Y >= __mul24(gb, TS) + offb);
                   }
                 ha = hax | (ga << PK_HBITS);  hb_ = hbx | (gb << PK_HBITS);
-                { const u64 ovm = bal(ncell > cell_cap);          /* (rare block: a vector compare here costs nothing per step) */
-                  ov[0] |= (u32) ovm != 0;  ov[1] |= (u32) (ovm >> 32) != 0;
-                }
+                if (onm & bal(ncell > cell_cap))                  /* (rare block: this compare costs nothing per step) */
+                  bad = true;
               }
           }
 
@@ -532,9 +549,8 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
                 { if (am_) cold[DC_ACLIP] = 31 - __clz((int) am_);
                   if (bm_) cold[DC_BCLIP] = __ffs((int) bm_) - 1;
                 }
-              DUO_H2
-                if (mhalf(ahm | bhm, h))
-                  mo[h] = 0;
+              if ((u32) (ahm | bhm)) mo[0] = 0;
+              if ((u32) ((ahm | bhm) >> 32)) mo[1] = 0;
             }
 
           /* new best / last / trim point in sweep order (align.c:911-928 / 1620-1637): record breakers of a prefix
@@ -545,10 +561,7 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
               { const int x = pk_prefix_max(inv(candm) ? v : -BIG);
                 /* the maximum over the lanes before this one; what lane 0 of a half receives does not matter: the band
                    lives in lanes 1 .. 30, lane 0 is never a candidate */
-                int e = __builtin_amdgcn_update_dpp(-BIG, x, 0x138, 0xf, 0xf, false);       /* wave_shr:1 */
-#if DUO_DBG & 1
-                if (s == 0) e = -BIG;
-#endif
+                const int e = __builtin_amdgcn_update_dpp(-BIG, x, 0x138, 0xf, 0xf, false);       /* wave_shr:1 */
                 const u64 rbm = candm & bal(v > e);
                 const u64 mokm = rbm & bal(pk_popc61(b) >= ave);
                 u64 tokm = 0;
@@ -557,13 +570,15 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
                 const int xl = __builtin_amdgcn_ds_bpermute(top4, x);                             /* the maximum of the half's candidates */
                 besta = xl > besta ? xl : besta;
                 DUO_H2
-                  { const u32 h1 = mhalf(rbm, h), h2 = mhalf(mokm, h);
+                  { const u32 h1 = (u32) (rbm >> (32 * h)), h2 = (u32) (mokm >> (32 * h));
                     if (h1)
                       { bk[h] = kb[h] - (31 - __builtin_clz(h1));
                         be[h] = __builtin_amdgcn_readlane(x, 32 * h + 31);
+                        if (h2)
+                          la[h] = __builtin_amdgcn_readlane(v, 32 * h + 31 - __builtin_clz(h2));
+                        if (la[h] < be[h] - MAX_TRIM_LAG)
+                          bad = true;
                       }
-                    if (h2)
-                      la[h] = __builtin_amdgcn_readlane(v, 32 * h + 31 - __builtin_clz(h2));
                   }
                 if (tokm)
                   { const u32 h3 = hmask(tokm, hb);
@@ -577,69 +592,47 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
               }
           }
 
-          /* clipping at sequence ends (align.c:628-658 / 943-975): rare, on the vector side as in round 4 -- the scalars go
-             there and come back */
-#if DUO_DBG & 2
-          if (true)
-#else
+          /* clipping at sequence ends (align.c:628-658 / 943-975): rare, on the vector side as in round 4 -- the band goes
+             there as lane bounds and comes back as a mask */
+          u64 wband = actm;                                       /* the band as widened: what the pruning starts from */
           if ((on0 && mo[0] == 0) || (on1 && mo[1] == 0))
-#endif
             { int more = hb ? mo[1] : mo[0], bestk = hb ? bk[1] : bk[0], kbase = hb ? kb[1] : kb[0];
-              int ls_ = hb ? ls[1] : ls[0], hs_ = hb ? hs[1] : hs[0];
-#define ls ls_
-#define hs hs_
+              const u32 wb0 = (u32) wband, wb1 = (u32) (wband >> 32);
+              int ls = hb ? (wb1 ? __builtin_ctz(wb1) : 32) : (wb0 ? __builtin_ctz(wb0) : 32);
+              int hs = hb ? (wb1 ? 31 - __builtin_clz(wb1) : -1) : (wb0 ? 31 - __builtin_clz(wb0) : -1);
               DUO_CLIP()
-#undef ls
-#undef hs
+              wband = 0;
               DUO_H2
-                { mo[h] = __builtin_amdgcn_readlane(more, 32 * h);
-                  ls[h] = __builtin_amdgcn_readlane(ls_, 32 * h);  hs[h] = __builtin_amdgcn_readlane(hs_, 32 * h);
-                }
+                if (h ? on1 : on0)
+                  { const int l1 = __builtin_amdgcn_readlane(ls, 32 * h), h1 = __builtin_amdgcn_readlane(hs, 32 * h);
+                    mo[h] = __builtin_amdgcn_readlane(more, 32 * h);
+                    if (mo[h] == 0)
+                      bad = true;
+                    if (h1 >= l1)
+                      wband |= (u64) span32(l1, h1) << (32 * h);
+                  }
               (void) bestk;  (void) kbase;
             }
 
-          /* prune (align.c:977-986 / 1686-1695), and V = EDGE again in every lane outside the band (an empty band
-             comes out as hs < ls) */
-          { const u64 livem = bal(rV >= besta - MAX_WAVE_LAG);
-            u64 bandm = 0;
-            DUO_H2
-              { const u32 was = (hs[h] >= ls[h]) ? ((2u << (hs[h] - ls[h])) - 1u) << ls[h] : 0u;
-                const u32 keep = was & mhalf(livem, h);
-                ls[h] = keep ? __builtin_ctz(keep) : 32;
-                hs[h] = keep ? 31 - __builtin_clz(keep) : -1;
-                const u32 now = keep ? ((2u << (hs[h] - ls[h])) - 1u) << ls[h] : 0u;
-                bandm |= (u64) now << (32 * h);
-              }
-            rV = inv(bandm) ? rV : DUO_EDGE;
+          /* prune (align.c:977-986 / 1686-1695): the band becomes the span of its lanes that are within reach of the best
+             point, and V = EDGE again in every lane outside it */
+          { const u64 keep = wband & bal(rV >= besta - MAX_WAVE_LAG);
+            const u32 k0 = (u32) keep, k1 = (u32) (keep >> 32);
+            const u32 s0 = k0 ? span32(__builtin_ctz(k0), 31 - __builtin_clz(k0)) : 0u;
+            const u32 s1 = k1 ? span32(__builtin_ctz(k1), 31 - __builtin_clz(k1)) : 0u;
+            if ((on0 && k0 == 0) || (on1 && k1 == 0))            /* an empty band */
+              bad = true;
+            band = ((u64) s1 << 32) | s0;
+            rV = inv(band) ? rV : DUO_EDGE;
           }
 
-          /* may every half go on as it is?  (a band within lanes 2 .. 29 is no wider than 28; a pebble pool that has
-             run over is noticed when the loop is left for any other reason: its stores are bounded) */
-          stay = true;
-          DUO_H2
-            if (h ? on1 : on0)
-              stay = stay && mo[h] != 0 && la[h] >= be[h] - MAX_TRIM_LAG && hs[h] >= ls[h] && left >= 0 && ls[h] >= 2 && hs[h] <= 29;
+          /* may every half go on as it is?  (a pebble pool that has run over is noticed when the loop is left for any
+             other reason: its stores are bounded) */
+          stop = bad || left < 0 || (band & DUO_EDGES) != 0;
         }
-      while (stay);
-      { bool go = true;
-        DUO_H2
-          if (h ? on1 : on0)
-            go = go && mo[h] != 0 && la[h] >= be[h] - MAX_TRIM_LAG && hs[h] >= ls[h] && left >= 0 && hs[h] - ls[h] <= 27 && !ov[h];
-#if DUO_DBG & 64
-        if (!go && lane == 0)
-          DUO_H2
-            if (h ? on1 : on0)
-              { const int at = atomicAdd(&g_dbgn, 1);
-                if (at < 500)
-                  { int *d = g_dbg + 12 * at;
-                    d[0] = (int) blockIdx.x * 2 + h;  d[1] = (mo[h] == 0) | ((la[h] < be[h] - MAX_TRIM_LAG) << 1) | ((hs[h] < ls[h]) << 2) | ((left < 0) << 3) | ((hs[h] - ls[h] > 27) << 4) | (ov[h] << 5);
-                    d[2] = la[h];  d[3] = be[h];  d[4] = ls[h];  d[5] = hs[h];  d[6] = sc(duo_half[h].dif);  d[7] = sc(duo_half[h].m);  d[8] = left;  d[9] = bk[h];  d[10] = kb[h];  d[11] = sc(duo_half[h].besta);
-                  }
-              }
-#endif
-        if (!go)
-          break;
-      }
+      while (!stop);
+      if (bad || left < 0)
+        break;
     }
   { DuoCtx &c0 = duo_half[0];                   /* (every lane adds the same: one record counts for the wavefront) */
     const u32 lo = c0.n_cells_lo + st_cells;
@@ -647,10 +640,12 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
     c0.n_iter += st_iter;  c0.n_half += st_iter * ((u32) __popcll(onm) >> 5);
   }
   if (on)
-    { duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
-      cx.ls = hb ? ls[1] : ls[0];  cx.hs = hb ? hs[1] : hs[0];  cx.kbase = hb ? kb[1] : kb[0];  cx.dif = dif;  cx.besta = besta;
+    { const u32 b0 = (u32) band, b1 = (u32) (band >> 32);
+      duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
+      cx.ls = hb ? (b1 ? __builtin_ctz(b1) : 32) : (b0 ? __builtin_ctz(b0) : 32);
+      cx.hs = hb ? (b1 ? 31 - __builtin_clz(b1) : -1) : (b0 ? 31 - __builtin_clz(b0) : -1);
+      cx.kbase = hb ? kb[1] : kb[0];  cx.dif = dif;  cx.besta = besta;
       cx.bestk = hb ? bk[1] : bk[0];  cx.lasta = hb ? la[1] : la[0];  cx.more = hb ? mo[1] : mo[0];  cx.ncell = ncell;
-      cx.mlo = hb ? mlo[1] : mlo[0];  cx.mhi = hb ? mhi[1] : mhi[0];
     }
 }
 #else
@@ -1687,12 +1682,3 @@ void damar_launch_tandem_report2(const ReportArgs *a, const int *dist, int nslot
   jobs_upload(a, 1, st);
   hipLaunchKernelGGL(report2_kernel, dim3(nslots / 2), dim3(64), 0, st, 1, (const LaTask *) NULL, 0u, dist);
 }
-
-#if DUO_DBG & 64
-extern "C" int damar_dbg_read(int *out)
-{ int n = 0;
-  hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_dbgn), sizeof(int));
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(int) * 12 * 500);
-  return n;
-}
-#endif
