@@ -97,7 +97,13 @@ void merge_tiles(MergeArgs m, u32 ntiles, MergeTile *__restrict__ tiles)
       sh += 1;
     tl.sh = sh;
   }
-  tl.pad[0] = tl.pad[1] = tl.pad[2] = 0;
+  /* pad[0]: set by merge_fast when the tile needs the general kernel; pad[1]: the longest B run whose mutual count with
+     the tile's longest possible A run (tl.ia - tl.ja entries) stays below the cap of filter.c:1248 / 1335 */
+  { const u32 arun = tl.ia - tl.ja;
+    tl.pad[0] = 0;
+    tl.pad[1] = (arun == 0) ? 0xffffffffu : (u32) (((u64) m.limit - 1) / (u64) arun);
+    tl.pad[2] = 0;
+  }
   tiles[t] = tl;
 }
 
@@ -422,28 +428,49 @@ __device__ __forceinline__ void merge_sweep_tile(const MergeArgs &m, const Merge
     }
 }
 
-/* The common tile in ONE pass over LDS, without a search: the tile's B piece is staged as before, and a table over the
- * tile's code range -- MT_NBK buckets of 2^sh codes (merge_tiles chose sh so that the range fits), first[bucket] = where
- * the bucket's entries start in the piece, filled by the B entries that open a bucket -- answers "where would code c
- * sit" with one look-up and a walk over the bucket's few entries (both indexes sample the same code space: about one B
- * entry per A entry, one or two per bucket).  An A code whose bucket is empty has no partner.  That replaces a binary
- * search of ~10 dependent LDS reads per thread, which was what the sweep waited for (round 4: 1.0 ms per 135 M x 135 M
- * comparison, ~350 instructions per 4 entries, issue / LDS-latency bound).
- * The caps of filter.c:1248 / 1335 compare a run's mutual count with `limit` (10000 unless memory is short): a count is
- * at most (length of the A run) x (length of the B run), and an A run of this tile is no longer than tl.ia - tl.ja, so
- * when no entry of the tile has nb x (tl.ia - tl.ja) >= limit nothing can be capped and neither the run boundaries nor
- * the per-run sums are needed.  Otherwise the workgroup returns false -- nothing written -- and the caller takes the
- * general path. */
+/* The common tile in ONE pass over LDS, without a search, as a kernel of its own (merge_fast): the tile's B piece is staged
+ * as in the general kernel, and a table over the tile's code range -- MT_NBK buckets of 2^sh codes (merge_tiles chose sh
+ * so that the range fits), first[bucket] = where the bucket's entries start in the piece, filled by the B entries that
+ * open a bucket -- answers "where would code c sit" with one look-up and a walk over the bucket's few entries (both
+ * indexes sample the same code space: about one B entry per A entry, one or two per bucket).  An A code whose bucket is
+ * empty has no partner.  That replaces a binary search of ~10 dependent LDS reads per thread.
+ * The caps of filter.c:1248 / 1335 compare a run's mutual count with `limit` (10000 unless memory is short): a count is at
+ * most (length of the A run) x (length of the B run), and an A run of this tile is no longer than tl.ia - tl.ja, so when
+ * no entry of the tile has a B run longer than tl.pad[1] (merge_tiles) nothing can be capped and neither the run
+ * boundaries nor the per-run sums are needed.  Otherwise -- or when the piece does not fit the stage -- the tile is
+ * flagged (tiles[].pad[0]) and left to the general kernel, which runs behind this one over the flagged tiles only.
+ * Round 5, measured (profiles/r05_seq_kernel_stats.csv): the general kernel alone 1.00 ms per 135 M x 135 M comparison,
+ * with the table inside it 0.85 (it stayed at 590 vector + 350 scalar instructions per wavefront: the kernel's many
+ * arguments -- two block descriptors -- live in scalar registers that spill), this kernel: see DESIGN.md section 3. */
+static_assert(MT_BCAP + 16 < (1 << 16), "a packed entry holds the piece-relative start and the hits in 16 bits each");
+struct MergeFastArgs
+{ const void *acode, *bcode;
+  const u32  *apos, *bpos;
+  u32 alen, blen;
+  int self, identity, comp, rpbits;          /* rpbits: position words are read << rpbits | offset (self comparisons need it here) */
+};
+
 template <typename CodeT>
-__device__ __forceinline__ bool merge_sweep_fast(const MergeArgs &m, const MergeTile tl, const u32 tile,
-                                                 u32 *__restrict__ tcount, u32 *__restrict__ cnt, u32 *__restrict__ jbg,
-                                                 CodeT *sb, u16 *first, u64 *red)
-{ const CodeT *acode = (const CodeT *) m.acode, *bcode = (const CodeT *) m.bcode;
+__global__ __launch_bounds__(256, 8)
+void merge_fast(MergeFastArgs m, MergeTile *__restrict__ tiles, u32 *__restrict__ tcount, u32 *__restrict__ cnt)
+{ SEED_PRIO(g_merge_prio);
+  __shared__ __attribute__((aligned(16))) CodeT sb[MT_BCAP + 16 / sizeof(CodeT)];
+  __shared__ __attribute__((aligned(16))) u16 first[MT_NBK];
+  __shared__ u32 wsum[4];
+  __shared__ u32 deep;
+  const CodeT *acode = (const CodeT *) m.acode, *bcode = (const CodeT *) m.bcode;
+  const u32 tile = blockIdx.x;
+  const MergeTile tl = tiles[tile];
   const u32 a0 = tile * (u32) MT_A, a1 = min(m.alen, a0 + (u32) MT_A), nat = a1 - a0;
   const u32 nbt = tl.b1 - tl.b0;
+  if (nbt > MT_BCAP || (m.self && m.rpbits == 0))
+    { if (threadIdx.x == 0)
+        tiles[tile].pad[0] = 1;
+      return;
+    }
   const u32 e0 = threadIdx.x * MT_PER;
   const int nv = (e0 >= nat) ? 0 : (int) min((u32) MT_PER, nat - e0);
-  const u32 sh = tl.sh;
+  const u32 sh = tl.sh, nmax = tl.pad[1];
   constexpr u32 VPK = 16 / sizeof(CodeT);
   typedef CodeT VecT __attribute__((ext_vector_type(16 / sizeof(CodeT))));
   typedef u32 V4 __attribute__((ext_vector_type(4)));
@@ -466,15 +493,16 @@ __device__ __forceinline__ bool merge_sweep_fast(const MergeArgs &m, const Merge
       for (int k = 0; k < MT_PER; k++)
         a[k] = (k < nv) ? acode[a0 + e0 + k] : (CodeT) 0;
     }
-  /* the B piece into LDS (as in merge_sweep_tile), the table to "empty" */
+  /* the B piece into LDS (16-byte loads from the aligned address at or below b0, all in flight together), the table to "empty" */
   const u32 b0a = tl.b0 & ~(VPK - 1), shf = tl.b0 - b0a;
   { const u32 nvec = (tl.b1 - b0a + VPK - 1) / VPK;
+    const u32 whole = (m.blen - b0a) / VPK;                    /* vectors that lie inside the index */
     VecT v[MT_BCAP / (int) VPK / 256 + 1];
 #pragma unroll
     for (int r = 0; r < MT_BCAP / (int) VPK / 256 + 1; r++)
       { const u32 x = threadIdx.x + (u32) r * 256;
         if (x < nvec)
-          { if (b0a + (x + 1) * VPK <= m.blen)
+          { if (x < whole)
               v[r] = ((const VecT *) (bcode + b0a))[x];
             else
               {
@@ -487,6 +515,8 @@ __device__ __forceinline__ bool merge_sweep_fast(const MergeArgs &m, const Merge
     { const V4 ones = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu };
       ((V4 *) first)[threadIdx.x] = ones;                     /* MT_NBK u16 = 256 x 16 bytes */
     }
+    if (threadIdx.x == 0)
+      deep = 0;
 #pragma unroll
     for (int r = 0; r < MT_BCAP / (int) VPK / 256 + 1; r++)
       { const u32 x = threadIdx.x + (u32) r * 256;
@@ -505,8 +535,7 @@ __device__ __forceinline__ bool merge_sweep_fast(const MergeArgs &m, const Merge
   __syncthreads();
 
   u32 jb[MT_PER], n[MT_PER];
-  bool deep = false;                                          /* a cap might apply: the general path decides */
-  const u64 arun = (u64) (tl.ia - tl.ja);
+  u32 longest = 0;
 #pragma unroll
   for (int k = 0; k < MT_PER; k++)
     { jb[k] = 0;  n[k] = 0;
@@ -531,47 +560,64 @@ __device__ __forceinline__ bool merge_sweep_fast(const MergeArgs &m, const Merge
                   jb[k] = p;  n[k] = q - p;
                 }
             }
-          if (arun * (u64) n[k] >= (u64) m.limit)
-            deep = true;
+          longest = max(longest, n[k]);
         }
     }
-  if (__syncthreads_or(deep))
-    return false;
-  /* n[] holds the length of the B run so far: in a self comparison only the entries before A's bound count */
-  u64 s64 = 0;
+  if (longest > nmax)
+    deep = 1;                                                 /* a cap might apply: the general kernel decides */
+  /* n[] holds the length of the B run so far: in a self comparison only the entries before A's bound count
+     (filter.c:1219-1246; packed position words order like block offsets, the bounds need no look-up) */
+  u32 sum = 0;
+  if (m.self)
+    { const int rp = m.rpbits;
+#pragma unroll
+      for (int k = 0; k < MT_PER; k++)
+        if (n[k] > 0)
+          { const u32 p = m.apos[a0 + e0 + k], ra = p >> rp;
+            u32 bound = m.identity ? (m.comp ? (ra + 1) << rp : p) : ra << rp;
+            if (!(m.identity && m.comp && ((ra + 1) >> (32 - rp)) != 0))      /* (else (ra + 1) << rp would wrap: every entry is below) */
+              n[k] = count_below(m.bpos, tl.b0 + jb[k], tl.b0 + jb[k] + n[k], bound);
+          }
+    }
 #pragma unroll
   for (int k = 0; k < MT_PER; k++)
-    { if (m.self && n[k] > 0)
-        n[k] = self_hits(m, m.apos[a0 + e0 + k], tl.b0 + jb[k], n[k]);
-      s64 += n[k];
+    sum += n[k];
+  sum = (u32) wave_sum_i((int) sum);
+  if (lane_id() == 0)
+    wsum[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (deep)
+    { if (threadIdx.x == 0)
+        tiles[tile].pad[0] = 1;
+      return;
     }
-  const u64 T64 = block_sum_u64(s64, red);
   if (threadIdx.x == 0)
-    tcount[tile] = (T64 > 0xffffffffull) ? 0xffffffffu : (u32) T64;
+    { tcount[tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];   /* (at most MT_A x MT_BCAP: no overflow) */
+      tiles[tile].pad[2] = 1;                                 /* done here: its entries are PACKED */
+    }
+  /* what the EMIT pass needs of an entry, in ONE word: hits << 16 | start of its B run inside the tile's piece (both below
+     MT_BCAP + 4 < 2^16) -- 4 bytes written and read per A entry instead of 8 (the general kernel keeps two arrays: its
+     pieces and counts know no such bound) */
   if (nv == MT_PER && MT_PER == 4)
-    { V4 vc, vj;
+    { V4 vc;
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        { vc[k] = n[k];  vj[k] = tl.b0 + jb[k]; }
+        vc[k] = (n[k] << 16) | jb[k];
       *(V4 *) (cnt + a0 + e0) = vc;
-      *(V4 *) (jbg + a0 + e0) = vj;
     }
   else
     {
 #pragma unroll
       for (int k = 0; k < MT_PER; k++)
         if (k < nv)
-          { cnt[a0 + e0 + k] = n[k];
-            jbg[a0 + e0 + k] = tl.b0 + jb[k];
-          }
+          cnt[a0 + e0 + k] = (n[k] << 16) | jb[k];
     }
-  return true;
 }
 
 template <typename CodeT>
 __global__ __launch_bounds__(256, 8)          /* <= 64 VGPRs: two wavefronts per SIMD still find room beside a resident report launch */
 void merge_sweep(MergeArgs m, const MergeTile *__restrict__ tiles, u32 *__restrict__ tcount, u32 *__restrict__ cnt,
-                 u32 *__restrict__ jbg, unsigned long long *__restrict__ gram, u32 ngram, int general)
+                 u32 *__restrict__ jbg, unsigned long long *__restrict__ gram, u32 ngram, int only_flagged)
 { SEED_PRIO(g_merge_prio);
   __shared__ __attribute__((aligned(16))) CodeT sb[MT_BCAP + 16 / sizeof(CodeT)];
   __shared__ u32 loc[MT_A + 1];
@@ -579,12 +625,8 @@ void merge_sweep(MergeArgs m, const MergeTile *__restrict__ tiles, u32 *__restri
   __shared__ u32 sw4[4];
   __shared__ u64 red[4];
   const MergeTile tl = tiles[blockIdx.x];
-  if (gram == NULL && tl.b1 - tl.b0 <= MT_BCAP && !general)
-    { __shared__ __attribute__((aligned(16))) u16 first[MT_NBK];
-      if (merge_sweep_fast<CodeT>(m, tl, blockIdx.x, tcount, cnt, jbg, sb, first, red))
-        return;
-      __syncthreads();                         /* (a cap may apply: from the start again, the general way) */
-    }
+  if (only_flagged && tl.pad[0] == 0)          /* merge_fast has done this tile */
+    return;
   if (tl.b1 - tl.b0 <= MT_BCAP)                /* (the stage has room for the alignment slack on top) */
     merge_sweep_tile<CodeT, true>(m, tl, blockIdx.x, tcount, cnt, jbg, gram, ngram, sb, loc, sjb, sw4, red);
   else
@@ -595,8 +637,8 @@ void merge_sweep(MergeArgs m, const MergeTile *__restrict__ tiles, u32 *__restri
  * out to the threads in order, each finding its A entry by a search of the LDS prefix (no walk over global offsets),
  * so that the seed pairs leave in fully coalesced runs; MT_HITS independent seed pairs per thread are in flight. */
 __global__ __launch_bounds__(256, 8)
-void merge_emit(MergeArgs m, const u32 *__restrict__ cnt, const u32 *__restrict__ jbg, const u32 *__restrict__ toff,
-                u64 nhits, u64 *__restrict__ keys, u32 *__restrict__ vals, u32 *__restrict__ pid)
+void merge_emit(MergeArgs m, const MergeTile *__restrict__ tiles, const u32 *__restrict__ cnt, const u32 *__restrict__ jbg,
+                const u32 *__restrict__ toff, u64 nhits, u64 *__restrict__ keys, u32 *__restrict__ vals, u32 *__restrict__ pid)
 { SEED_PRIO(g_merge_prio);
   __shared__ u32 loc[MT_A + 1];
   __shared__ u32 sjb[MT_A];
@@ -610,11 +652,14 @@ void merge_emit(MergeArgs m, const u32 *__restrict__ cnt, const u32 *__restrict_
   if (hn == h0)                                               /* nothing to emit here */
     return;
   u32 n[MT_PER], s = 0;
+  const bool packed = tiles[tile].pad[2] != 0;                /* merge_fast's tile: hits << 16 | start inside the piece, in cnt[] */
+  const u32 pb0 = tiles[tile].b0;
 #pragma unroll
   for (int k = 0; k < MT_PER; k++)
     { const bool ok = e0 + k < nat;
-      n[k] = ok ? cnt[a0 + e0 + k] : 0;
-      sjb[e0 + k] = ok ? jbg[a0 + e0 + k] : 0;
+      const u32 w = ok ? cnt[a0 + e0 + k] : 0;
+      n[k] = packed ? w >> 16 : w;
+      sjb[e0 + k] = !ok ? 0 : packed ? pb0 + (w & 0xffffu) : jbg[a0 + e0 + k];
       s += n[k];
     }
   u32 inc = (u32) wave_incl_scan_i((int) s);
@@ -712,13 +757,21 @@ void damar_launch_merge_count(const MergeArgs *m, void *work, unsigned long long
   static int general = -1;                   /* test hook (tests/test_gpu_parity.py): every tile the general way */
   if (general < 0)
     general = getenv("DAMAR_MERGE_GENERAL") != NULL;
+  const bool fast = gram == NULL && !general;  /* (the run histogram is the general kernel's) */
+  MergeFastArgs f;
+  f.acode = m->acode;  f.bcode = m->bcode;  f.apos = m->apos;  f.bpos = m->bpos;  f.alen = m->alen;  f.blen = m->blen;
+  f.self = m->self;  f.identity = m->identity;  f.comp = m->comp;  f.rpbits = m->ablk.rpbits;
   if (m->wide)
     { hipLaunchKernelGGL(merge_tiles<u64>, dim3((ntiles + 255) / 256), dim3(256), 0, st, *m, ntiles, tiles);
-      hipLaunchKernelGGL(merge_sweep<u64>, dim3(ntiles), dim3(256), 0, st, *m, tiles, tcount, cnt, jb, gram, ngram, general);
+      if (fast)
+        hipLaunchKernelGGL(merge_fast<u64>, dim3(ntiles), dim3(256), 0, st, f, tiles, tcount, cnt);
+      hipLaunchKernelGGL(merge_sweep<u64>, dim3(ntiles), dim3(256), 0, st, *m, tiles, tcount, cnt, jb, gram, ngram, fast ? 1 : 0);
     }
   else
     { hipLaunchKernelGGL(merge_tiles<u32>, dim3((ntiles + 255) / 256), dim3(256), 0, st, *m, ntiles, tiles);
-      hipLaunchKernelGGL(merge_sweep<u32>, dim3(ntiles), dim3(256), 0, st, *m, tiles, tcount, cnt, jb, gram, ngram, general);
+      if (fast)
+        hipLaunchKernelGGL(merge_fast<u32>, dim3(ntiles), dim3(256), 0, st, f, tiles, tcount, cnt);
+      hipLaunchKernelGGL(merge_sweep<u32>, dim3(ntiles), dim3(256), 0, st, *m, tiles, tcount, cnt, jb, gram, ngram, fast ? 1 : 0);
     }
 }
 
@@ -729,7 +782,7 @@ void damar_launch_merge_emit(const MergeArgs *m, void *work, u64 nhits, u64 *key
   const u32 ntiles = (u32) mw_tiles(m->alen);
   const u32 *toff = damar_merge_tile_counts(work, m->alen);
   const u32 *cnt = (const u32 *) ((char *) work + mw_off_cnt(m->alen)), *jb = (const u32 *) ((char *) work + mw_off_jb(m->alen));
-  hipLaunchKernelGGL(merge_emit, dim3(ntiles), dim3(256), 0, st, *m, cnt, jb, toff, nhits, keys, vals, pid);
+  hipLaunchKernelGGL(merge_emit, dim3(ntiles), dim3(256), 0, st, *m, (const MergeTile *) work, cnt, jb, toff, nhits, keys, vals, pid);
 }
 
 /* flags[i] = 1 iff hit i starts a (bread,aread) run that report_thread would enter:
