@@ -193,6 +193,10 @@ typedef struct
   /* outputs */
   LaRecord *recs;  u32 rec_cap;
   u16  *tpool;     u32 tpool_cap;
+  int  t8, t8max;                  /* t8: trace values leave as BYTES (tspace <= 125: align.c:3375-3396 Compress_TraceTo8 on the device, the
+                                      pool then holds tpool_cap bytes' worth of values in its first half); a value above t8max (255) raises
+                                      DAMAR_ERR_T8 and the host repeats the launch with 16-bit values, so that the reference's own check
+                                      decides (it looks only at the records that are written) */
   const u32 *order; /* processing order of the work items (largest first), or NULL          */
   u32  *counters;  /* [1] records, [2] trace words, [3] error flags, [6] [7] where a wave gave up; shared by the jobs of a launch */
   u32  *cursor;    /* next work item of THIS job (counters + DAMAR_CNT_CURSOR + job) */
@@ -218,6 +222,7 @@ typedef struct
 #define DAMAR_ERR_RECS    2u
 #define DAMAR_ERR_TPOOL   4u
 #define DAMAR_ERR_BAND    8u
+#define DAMAR_ERR_T8     32u    /* a trace value does not fit a byte (see ReportArgs.t8) */
 #define DAMAR_ERR_WIDE   16u    /* a band outgrew the ring of diagonals of the slot buffers: relaunch with a larger ring */
 
 int  damar_report_waves_per_simd(void);

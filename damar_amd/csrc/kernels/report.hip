@@ -1385,7 +1385,13 @@ __device__ __noinline__ void emit_record(int job, const SlotScratch &s, const La
                 j = (r.btlen - 2 - 2 * (j >> 1)) + (j & 1);
               v = bt[j];
             }
-          a.tpool[to + i] = v;
+          if (a.t8)
+            { ((u8 *) a.tpool)[to + i] = (u8) v;
+              if ((int) v > a.t8max)
+                atomicOr(&a.counters[3], DAMAR_ERR_T8);
+            }
+          else
+            a.tpool[to + i] = v;
         }
     }
   if (lane == 0)

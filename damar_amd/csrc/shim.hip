@@ -1189,6 +1189,12 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   ra->ttmp = RS.ttmp;  ra->ttmp_stride = RS.ttmp_stride;
   ra->recs = RS.recs;  ra->rec_cap = RS.rec_cap;
   ra->tpool = RS.tpool;  ra->tpool_cap = RS.tpool_cap;
+  ra->t8 = 0;                                   /* (the pipeline's launches set it: report_launch) */
+  { static int lim = -1;                        /* test hook: a lower limit makes the 16-bit re-launch happen (tests/test_gpu_configs.py) */
+    if (lim < 0)
+      lim = getenv("DAMAR_TEST_T8_LIMIT") ? atoi(getenv("DAMAR_TEST_T8_LIMIT")) : 255;
+    ra->t8max = lim;
+  }
   ra->counters = RS.ctr;
   ra->cursor = RS.ctr + DAMAR_CNT_CURSOR + job;
   ra->nfilt  = RS.ctr + DAMAR_CNT_NFILT + job;
@@ -1236,6 +1242,7 @@ struct HostBuf
   size_t    nrec, ntp;
   hipEvent_t e0, e1;               /* around the download; e1 is what the tail thread waits for */
   bool      pending;
+  int       t8;                    /* the trace values are bytes (the launch compressed them: ReportArgs.t8) */
   int       users;                 /* comparisons of the launch whose tails have not run yet */
 };
 static std::mutex             &HB_mu   = *new std::mutex();
@@ -1306,9 +1313,18 @@ static void hostbuf_put(HostBuf *h)
   HB_free.push_back(h);
 }
 
+/* byte trace values of the device (ReportArgs.t8) into the 16-bit pool the redundancy handling works on */
+static int64 tpool_push8(damar_tpool *tp, const u8 *src, int n)
+{ static thread_local std::vector<uint16> wide;
+  wide.resize((size_t) n);
+  for (int i = 0; i < n; i++)
+    wide[i] = src[i];
+  return damar_tpool_push(tp, wide.data(), n);
+}
+
 /* One contiguous range [lo, hi) of the ordered records (whole read pairs): filter.c:2442-2483
  * per pair, results appended to obuf. */
-static int64 tail_range(const LaRecord *recs, const u32 *ord, const u64 *okey, size_t lo, size_t hi, const u16 *tpool,
+static int64 tail_range(const LaRecord *recs, const u32 *ord, const u64 *okey, size_t lo, size_t hi, const u16 *tpool, int t8,
                         const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, int ts,
                         Overlap_IO_Buffer *obuf, int symmetric, int hgap_min)
 { int64 ncheck = 0;
@@ -1324,8 +1340,9 @@ static int64 tail_range(const LaRecord *recs, const u32 *ord, const u64 *okey, s
         __builtin_prefetch(&recs[ord[i + 16]]);
       if (i + 8 < hi)
         { const LaRecord &pr = recs[ord[i + 8]];
-          const char *pt = (const char *) (tpool + pr.toff);
-          const size_t nb = sizeof(u16) * (size_t) (pr.atlen + pr.btlen);
+          const size_t vb = t8 ? sizeof(u8) : sizeof(u16);
+          const char *pt = (const char *) tpool + vb * (size_t) pr.toff;
+          const size_t nb = vb * (size_t) (pr.atlen + pr.btlen);
           for (size_t o = 0; o < nb; o += 64)
             __builtin_prefetch(pt + o);
         }
@@ -1347,8 +1364,9 @@ static int64 tail_range(const LaRecord *recs, const u32 *ord, const u64 *okey, s
             { ovl.aread = ar + ablock->ufirst;  ovl.bread = br + bblock->ufirst;
               ovl.path.tlen = r.atlen;  ovl.path.diffs = r.diffs;
               ovl.path.abpos = r.abpos;  ovl.path.bbpos = r.bbpos;  ovl.path.aepos = r.aepos;  ovl.path.bepos = r.bepos;
-              ovl.path.trace = (void *) (tpool + r.toff);
-              if (ts <= TRACE_XOVR)
+              /* (t8: the device has compressed the values already -- and raised DAMAR_ERR_T8 had one not fitted) */
+              ovl.path.trace = t8 ? (void *) ((const u8 *) tpool + r.toff) : (void *) (tpool + r.toff);
+              if (ts <= TRACE_XOVR && !t8)
                 Compress_TraceTo8(&ovl, 1);
               AddOverlapToBuffer(obuf, &ovl, (ts <= TRACE_XOVR) ? 1 : 2);
               ncheck += 1;
@@ -1362,8 +1380,8 @@ static int64 tail_range(const LaRecord *recs, const u32 *ord, const u64 *okey, s
                 }
               else                                               /* align.c:2059-2062 */
                 { ovl.path.abpos = r.bbpos;  ovl.path.bbpos = r.abpos;  ovl.path.aepos = r.bepos;  ovl.path.bepos = r.aepos; }
-              ovl.path.trace = (void *) (tpool + r.toff + r.atlen);
-              if (ts <= TRACE_XOVR)
+              ovl.path.trace = t8 ? (void *) ((const u8 *) tpool + r.toff + r.atlen) : (void *) (tpool + r.toff + r.atlen);
+              if (ts <= TRACE_XOVR && !t8)
                 Compress_TraceTo8(&ovl, 1);
               AddOverlapToBuffer(obuf, &ovl, (ts <= TRACE_XOVR) ? 1 : 2);
               ncheck += 1;
@@ -1378,7 +1396,7 @@ static int64 tail_range(const LaRecord *recs, const u32 *ord, const u64 *okey, s
           if (doA)
             { p.tlen = r.atlen;  p.diffs = r.diffs;
               p.abpos = r.abpos;  p.bbpos = r.bbpos;  p.aepos = r.aepos;  p.bepos = r.bepos;
-              p.toff = damar_tpool_push(&tp, tpool + r.toff, r.atlen);
+              p.toff = t8 ? tpool_push8(&tp, (const u8 *) tpool + r.toff, r.atlen) : damar_tpool_push(&tp, tpool + r.toff, r.atlen);
               am.push_back(p);
             }
           if (doB)
@@ -1389,7 +1407,8 @@ static int64 tail_range(const LaRecord *recs, const u32 *ord, const u64 *okey, s
                 }
               else                                               /* align.c:2059-2062 */
                 { p.abpos = r.bbpos;  p.bbpos = r.abpos;  p.aepos = r.bepos;  p.bepos = r.aepos; }
-              p.toff = damar_tpool_push(&tp, tpool + r.toff + r.atlen, r.btlen);
+              p.toff = t8 ? tpool_push8(&tp, (const u8 *) tpool + r.toff + r.atlen, r.btlen)
+                          : damar_tpool_push(&tp, tpool + r.toff + r.atlen, r.btlen);
               bm.push_back(p);
             }
         }
@@ -1419,7 +1438,7 @@ static int tail_threads(void)
   return n;
 }
 
-static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
+static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool, int t8,
                       const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec,
                       const JobParams &jp, int jobid = 0, int njobs = 1)
 { const int ts = Trace_Spacing(spec);
@@ -1472,7 +1491,7 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
     }
   const int nthr = (nrecs >= tmin) ? tail_threads() : 1;
   if (nthr == 1)
-    return tail_range(recs, ord.data(), okey.data(), 0, nrecs, tpool, ablock, bblock, self, comp, ts, obuf, jp.symmetric, jp.hgap_min);
+    return tail_range(recs, ord.data(), okey.data(), 0, nrecs, tpool, t8, ablock, bblock, self, comp, ts, obuf, jp.symmetric, jp.hgap_min);
 
   /* Read pairs are independent: cut the ordered records into nthr ranges at pair boundaries,
      let each thread fill a private buffer, append the buffers in order. */
@@ -1500,7 +1519,7 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool,
           if (part[t] == NULL)
             die();
         }
-      th.emplace_back([&, t] { got[t] = tail_range(recs, ord.data(), okey.data(), cut[t], cut[t + 1], tpool, ablock, bblock,
+      th.emplace_back([&, t] { got[t] = tail_range(recs, ord.data(), okey.data(), cut[t], cut[t + 1], tpool, t8, ablock, bblock,
                                                     self, comp, ts, part[t], jp.symmetric, jp.hgap_min); });
     }
   int64 ncheck = 0;
@@ -1608,7 +1627,7 @@ static void tail_worker(void)
               A_d2h_ms += ms;
               t0 = now_ms();
             }
-          int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, &job->ablock, &job->bblock,
+          int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, job->hb->t8, &job->ablock, &job->bblock,
                              job->self, job->comp, job->spec, job->jp, job->jobid, job->njobs);
           if (--job->hb->users == 0)
             hostbuf_put(job->hb);
@@ -2106,6 +2125,7 @@ struct Pending
   const damar_dev_block *ablk[DAMAR_MAX_JOBS], *bblk[DAMAR_MAX_JOBS];     /* (an index may be released before a re-launch) */
   int  amax, bmax, tsmin;
   u32  cell_cap, rec_cap, tp_cap;
+  int  t8;                                        /* the launch's trace values leave the device as bytes (ReportArgs.t8) */
   int  attempt;
   int  oset;                                      /* the set of record buffers, counters and timers this launch uses */
   hipEvent_t done;                                /* behind the kernel */
@@ -2160,6 +2180,7 @@ static void report_launch(Pending &pd)
       ra[j].work = pd.fr[j].work;  ra[j].nwork = pd.fr[j].nwork;
       ra[j].pbits = pd.fr[j].pbits;  ra[j].abits = pd.fr[j].abits;  ra[j].dbits = pd.fr[j].dbits;
       ra[j].order = pd.fr[j].order;
+      ra[j].t8 = pd.t8;
       packed = packed && use_packed(&ra[j], pd.amax, pd.bmax);
       if (ra[j].mscore != ra[0].mscore || ra[j].dscore != ra[0].dscore)
         { fprintf(stderr, "damar: internal error, the comparisons of one report launch differ in their -e\n");
@@ -2218,6 +2239,7 @@ static void report_finish(Pending &pd)
       pd.attempt += 1;
       if (hc[3] & DAMAR_ERR_CELLS) pd.cell_cap = grow_cells(pd.cell_cap);
       if (hc[3] & DAMAR_ERR_WIDE)  G_ring *= 4;
+      if (hc[3] & DAMAR_ERR_T8)    pd.t8 = 0;     /* a value above 255: 16-bit values again, and the reference's check on what is written */
       if (hc[3] & DAMAR_ERR_RECS)  pd.rec_cap = std::max(2 * pd.rec_cap, hc[1] + 1024);
       if (hc[3] & DAMAR_ERR_TPOOL)
         { if (pd.tp_cap >= 0xe0000000u)
@@ -2241,8 +2263,9 @@ static void report_finish(Pending &pd)
     HIP_CHECK(hipEventRecord(hb->e0, cs));       /* (the report kernel has completed: the host synced on it) */
   if (hc[1] > 0)
     { HIP_CHECK(hipMemcpyAsync(hb->recs, RS.recs_set[pd.oset], sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost, cs));
-      HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool_set[pd.oset], sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost, cs));
+      HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool_set[pd.oset], (pd.t8 ? sizeof(u8) : sizeof(u16)) * (size_t) hc[2], hipMemcpyDeviceToHost, cs));
     }
+  hb->t8 = pd.t8;
   tick_on(19 + 4 * pd.oset, st);
   if (A_on)
     { /* asynchronous mode: the download runs on its own stream beside the next comparison's merge and sorts; the
@@ -2283,7 +2306,7 @@ static void report_finish(Pending &pd)
         }
       else
         { double t0 = now_ms();
-          const int64 got = run_tail(hb->recs, hb->nrec, hb->tpool, jb.ablock, jb.bblock, jb.self, jb.comp, jb.spec, pd.fr[j].jp, j, n);
+          const int64 got = run_tail(hb->recs, hb->nrec, hb->tpool, hb->t8, jb.ablock, jb.bblock, jb.self, jb.comp, jb.spec, pd.fr[j].jp, j, n);
           if (pd.orig[j] != NULL)
             pd.orig[j]->counts[2] = got;
           if (--hb->users == 0)
@@ -2461,6 +2484,17 @@ static void flush_accum(void)
   pd.cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
   pd.rec_cap  = (u32) std::min<u64>(0x7fffffffu, std::max<u64>(rec_have, 2 * AC.nwork + 4096));
   pd.tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(tp_have, (u64) pd.rec_cap * 256u));
+  { /* trace values as bytes off the device (align.c:3375-3396 Compress_TraceTo8, K8 of SURVEY 8a19) when every comparison
+       of the launch writes byte traces (-s <= 125); DAMAR_DEVICE_T8=0: 16-bit values, compressed by the host tail as
+       until round 4 */
+    static int want = -1;
+    if (want < 0)
+      want = getenv("DAMAR_DEVICE_T8") ? atoi(getenv("DAMAR_DEVICE_T8")) : 1;
+    pd.t8 = want;
+    for (int j = 0; j < n; j++)
+      if (Trace_Spacing(AC.job[j].spec) > TRACE_XOVR)
+        pd.t8 = 0;
+  }
   if (getenv("DAMAR_TEST_SMALL_CAPS") && RS.rec_cap_set[0] == 0 && RS.rec_cap_set[1] == 0)        /* tests: start far too small, so that the
                                                                   overflow flags and the re-launch are exercised */
     { pd.cell_cap = 64;  pd.rec_cap = 16;  pd.tp_cap = 512; }

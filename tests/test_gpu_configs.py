@@ -220,7 +220,8 @@ def test_gpu_cli_plan_mode_equals_reference_golden(gpu, tmp_path, name, front, c
                                        {"DAMAR_OVERLAP": "2"}, {"DAMAR_LAUNCH_QUEUE": "2", "DAMAR_BATCH": "1"},
                                        {"DAMAR_LAUNCH_QUEUE": "2", "DAMAR_TEST_SMALL_CAPS": "1", "DAMAR_BATCH": "2"},
                                        {"DAMAR_SEED_PRIO": "0"}, {"DAMAR_SEED_PRIO": "7", "DAMAR_BATCH_WORK": "1"},
-                                       {"DAMAR_DB_UNPACKED": "1"}, {"DAMAR_PLAN_TIDY": "1", "DAMAR_PLAN_RELEASE": "1"}])
+                                       {"DAMAR_DB_UNPACKED": "1"}, {"DAMAR_PLAN_TIDY": "1", "DAMAR_PLAN_RELEASE": "1"},
+                                       {"DAMAR_DEVICE_T8": "0"}, {"DAMAR_TEST_T8_LIMIT": "40", "DAMAR_BATCH": "2"}])
 @pytest.mark.parametrize("name", ["tiny2", "prod"])
 def test_gpu_cli_plan_mode_other_launch_shapes_equal_reference_golden(gpu, tmp_path, name, env_extra):
     """The switches that change how the work reaches the report kernel -- the early cut of the seed pairs, the number of
@@ -228,7 +229,9 @@ def test_gpu_cli_plan_mode_other_launch_shapes_equal_reference_golden(gpu, tmp_p
     (with re-launches after buffer overflows), kernels in order on the device with the host pipelined, two launches in
     flight (the second queued behind the first, also with re-launches), the wave priority of the seed kernels, blocks
     unpacked and complemented on the host instead of kept packed and unpacked by the GPU (the default since round 5),
-    one process that releases everything itself -- must not change a byte of the output."""
+    one process that releases everything itself, trace values compressed to bytes by the host instead of by the report
+    kernel, and a byte limit so low that every launch is repeated with 16-bit values (what a value above 255 does) --
+    must not change a byte of the output."""
     import subprocess
     from conftest import read_case, link_db, compare_las
     from damar_amd import api
