@@ -193,6 +193,9 @@ typedef struct
   /* outputs */
   LaRecord *recs;  u32 rec_cap;
   u16  *tpool;     u32 tpool_cap;
+  u32  *widemap;                   /* one bit per work item: the two-pair kernel gave the pair up (pebbles beyond the packed format);
+                                      NULL: no wide path behind this launch (the limits are fatal as until round 4) */
+  void *wcells;    u32 wcell_cap;  /* the wide kernel's 16-byte pebbles: wcell_cap per slot */
   int  t8, t8max;                  /* t8: trace values leave as BYTES (tspace <= 125: align.c:3375-3396 Compress_TraceTo8 on the device, the
                                       pool then holds tpool_cap bytes' worth of values in its first half); a value above t8max (255) raises
                                       DAMAR_ERR_T8 and the host repeats the launch with 16-bit values, so that the reference's own check
@@ -213,6 +216,8 @@ typedef struct
 #define DAMAR_CNT_CELLS     8     /* counters[8..9]   (64 bits): band cells of the launch's wave steps (packed kernel) */
 #define DAMAR_CNT_HALFSTEPS 10    /* counters[10..11] (64 bits): wave steps, counted per half-wavefront (= per alignment pass)   */
 #define DAMAR_CNT_ITERS     12    /* counters[12..13] (64 bits): iterations of the wave loop (each steps one or two halves)      */
+#define DAMAR_CNT_WIDE    14      /* counters[14]: read pairs left to the wide kernel (report_wide_kernel) */
+#define DAMAR_ITEM_WIDE   0x80000000u   /* in LaRecord.item: written by the wide kernel */
 #define DAMAR_CNT_CURSOR  16      /* counters[16 + job]: next work item of a job  */
 #define DAMAR_CNT_NFILT   (DAMAR_CNT_CURSOR + DAMAR_MAX_JOBS)      /* counters[.. + job]: its seed hits */
 #define DAMAR_COUNTER_WORDS (DAMAR_CNT_NFILT + DAMAR_MAX_JOBS)
@@ -228,6 +233,7 @@ typedef struct
 int  damar_report_waves_per_simd(void);
 int  damar_report2_waves_per_simd(void);     /* two scratch slots per wavefront */
 void damar_launch_report(const ReportArgs *jobs, int njobs, int nslots, hipStream_t st);
+void damar_launch_report_wide(const ReportArgs *jobs, int njobs, int nslots, hipStream_t st);
 /* datander report: one work item per read of a.ablk, dist as produced by damar_launch_tandem_links */
 void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots, hipStream_t st);
 

@@ -169,6 +169,42 @@ __device__ __forceinline__ v2u32 cell_pack(int ptr, int k, int dif, int gidx)
 }
 __device__ __forceinline__ v2u32 cell_root(int mark, int k) { v2u32 c = { (u32) mark, (u32) k };  return c; }
 
+/* The pebble formats of the one-pair path.  W = 0: the packed 8-byte Cell above (18 bits of pebble index, 14 of trace-grid
+   index, diagonal and wave number modulo 2^16) -- what the two-pair kernel writes as well.  W = 1: 16 bytes with every
+   field at full width, for the read pairs the packed format cannot hold (reads beyond DAMAR_MAX_MARKS trace spacings,
+   alignments of more than 2^18 pebbles a direction: align.c:399-407 Pebble, :505-513 the reference's pool grows without
+   bound): only report_wide_kernel uses it (round 5; VERDICT r2-r4 "a path past the packed-pebble limits"). */
+struct __attribute__((aligned(16))) WCell { u32 ptr, gidx;  int k, dif; };
+typedef u32 v4u32 __attribute__((ext_vector_type(4)));
+
+template <int W> struct CellIO;
+template <> struct CellIO<0>
+{ typedef Cell T;
+  static __device__ __forceinline__ void put(T *cells, u32 idx, int ptr, int k, int dif, int gidx)
+  { ((GLOBAL_AS v2u32 *) cells)[idx] = cell_pack(ptr, k, dif, gidx); }
+  static __device__ __forceinline__ void put_root(T *cells, u32 idx, int mark, int k)
+  { ((GLOBAL_AS v2u32 *) cells)[idx] = cell_root(mark, k); }
+  static __device__ __forceinline__ int ptr(const T &c)            { return (int) (c.w0 & PK_HMASK); }
+  static __device__ __forceinline__ int gidx(const T &c)           { return (int) (c.w0 >> PK_HBITS); }
+  static __device__ __forceinline__ int k(const T &c, int near)    { return near + (int) (short) (u16) ((c.w1 & 0xffffu) - (u32) near); }
+  static __device__ __forceinline__ int dif(const T &c, int above) { return above - (int) (((u32) above - (c.w1 >> 16)) & 0xffffu); }
+  static __device__ __forceinline__ int root_mark(const T &c)      { return (int) c.w0; }
+  static __device__ __forceinline__ int root_k(const T &c)         { return (int) c.w1; }
+};
+template <> struct CellIO<1>
+{ typedef WCell T;
+  static __device__ __forceinline__ void put(T *cells, u32 idx, int ptr, int k, int dif, int gidx)
+  { const v4u32 c = { (u32) ptr, (u32) gidx, (u32) k, (u32) dif };  ((GLOBAL_AS v4u32 *) cells)[idx] = c; }
+  static __device__ __forceinline__ void put_root(T *cells, u32 idx, int mark, int k)
+  { const v4u32 c = { (u32) mark, 0u, (u32) k, 0u };  ((GLOBAL_AS v4u32 *) cells)[idx] = c; }
+  static __device__ __forceinline__ int ptr(const T &c)            { return (int) c.ptr; }
+  static __device__ __forceinline__ int gidx(const T &c)           { return (int) c.gidx; }
+  static __device__ __forceinline__ int k(const T &c, int)         { return c.k; }
+  static __device__ __forceinline__ int dif(const T &c, int)       { return c.dif; }
+  static __device__ __forceinline__ int root_mark(const T &c)      { return (int) c.ptr; }
+  static __device__ __forceinline__ int root_k(const T &c)         { return c.k; }
+};
+
 /* One chain of a direction as trace values (align.c:1001-1118 forward, 1699-1898 reverse), walked by ONE lane.
  *   BSIDE 0: the A chain -- a pebble's value is the B coordinate where the path crosses its A mark (mark - diag), the end
  *            point is tested on its A coordinate ex and contributes its B coordinate ey;
@@ -179,17 +215,19 @@ __device__ __forceinline__ v2u32 cell_root(int mark, int k) { v2u32 c = { (u32) 
  * Forward: returns the number of values written to T[0 ...).  Reverse: values are prepended (T[-1], T[-2], ...), the
  * first partial segment goes into the forward trace's first pair if there is one (f0 > 0: its values so far), and the
  * number of prepended values is returned. */
-template <int REV, int BSIDE>
-__device__ __forceinline__ int chain_to_trace(const Cell *cells, int head, int TS, int off, int mida, int ex, int ey, int ed,
+template <int REV, int BSIDE, int W = 0>
+__device__ __forceinline__ int chain_to_trace(const typename CellIO<W>::T *cells, int head, int TS, int off, int mida, int ex, int ey, int ed,
                                               u16 *T, int f0, int guard, int &gw, u32 *errw)
 { const int sg = BSIDE ? 1 : -1;
   const int P = BSIDE ? ey : ex, Q = BSIDE ? ex : ey;              /* coordinate tested / coordinate contributed by the end point */
   const int goff = off - PK_BIAS * TS;                             /* mark = grid index * TS + goff */
   const int root = BSIDE;                                          /* cells 0 / 1 hold the exact starts of the A / B chain */
-  const int k0 = (int) cells[root].w1, m0 = (int) cells[root].w0;
+  typedef CellIO<W> IO;
+  typedef typename IO::T CellT;
+  const int k0 = IO::root_k(cells[root]), m0 = IO::root_mark(cells[root]);
   /* pass 1: how many pebbles between the root and the head */
   int L = 0;
-  for (int h = head; h >= 2; h = (int) (cells[h].w0 & PK_HMASK))
+  for (int h = head; h >= 2; h = IO::ptr(cells[h]))
     { GUARD(gw, guard, 7)
       L += 1;
     }
@@ -197,10 +235,10 @@ __device__ __forceinline__ int chain_to_trace(const Cell *cells, int head, int T
   int kc = k0, dc = 0, ac;
   int h = head;
   if (L > 0)
-    { const Cell c = cells[h];
-      kc = (ex - ey) + (int) (short) (u16) ((c.w1 & 0xffffu) - (u32) (ex - ey));
-      dc = ed - (int) (((u32) ed - (c.w1 >> 16)) & 0xffffu);
-      ac = (int) (c.w0 >> PK_HBITS) * TS + goff + sg * kc;
+    { const CellT c = cells[h];
+      kc = IO::k(c, ex - ey);
+      dc = IO::dif(c, ed);
+      ac = IO::gidx(c) * TS + goff + sg * kc;
     }
   else
     ac = REV ? m0 + sg * k0 : (mida + sg * k0) / 2;
@@ -223,12 +261,12 @@ __device__ __forceinline__ int chain_to_trace(const Cell *cells, int head, int T
       for (int j = L; j >= 1; j--)
         { GUARD(gw, guard, 8)
           int kp, dp, ap;
-          h = (int) (cells[h].w0 & PK_HMASK);
+          h = IO::ptr(cells[h]);
           if (j > 1)
-            { const Cell c = cells[h];
-              kp = kc + (int) (short) (u16) ((c.w1 & 0xffffu) - (u32) kc);
-              dp = dc - (int) (((u32) dc - (c.w1 >> 16)) & 0xffffu);
-              ap = (int) (c.w0 >> PK_HBITS) * TS + goff + sg * kp;
+            { const CellT c = cells[h];
+              kp = IO::k(c, kc);
+              dp = IO::dif(c, dc);
+              ap = IO::gidx(c) * TS + goff + sg * kp;
             }
           else
             { kp = k0;  dp = 0;  ap = (mida + sg * k0) / 2; }
@@ -287,12 +325,12 @@ __device__ __forceinline__ int chain_to_trace(const Cell *cells, int head, int T
       for (int j = L; j >= 1; j--)
         { GUARD(gw, guard, 10)
           int kp, dp, ap;
-          h = (int) (cells[h].w0 & PK_HMASK);
+          h = IO::ptr(cells[h]);
           if (j > 1)
-            { const Cell c = cells[h];
-              kp = kc + (int) (short) (u16) ((c.w1 & 0xffffu) - (u32) kc);
-              dp = dc - (int) (((u32) dc - (c.w1 >> 16)) & 0xffffu);
-              ap = (int) (c.w0 >> PK_HBITS) * TS + goff + sg * kp;
+            { const CellT c = cells[h];
+              kp = IO::k(c, kc);
+              dp = IO::dif(c, dc);
+              ap = IO::gidx(c) * TS + goff + sg * kp;
             }
           else
             { kp = k0;  dp = 0;  ap = a0; }
@@ -915,7 +953,7 @@ __device__ __noinline__ void wave_reg_cont(const WaveCtx &c, int mida, WaveState
 { wave_reg_impl<REV, 1>(c, 0, mida, ws, io); }
 
 /* Stage 2: the same wave steps with the band in memory, for bands wider than the wavefront. */
-template <int REV>
+template <int REV, int W = 0>
 __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
 {
   const int lane = lane_id();
@@ -935,8 +973,9 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
   const int ave = uni(c.ave), do_reach = uni(c.reach);
   const u32 cell_cap = (u32) uni((int) c.cell_cap);
   const short *score_tab = uni_ptr(c.score), *trim_tab = uni_ptr(c.table);
-  Cell *const cellbuf = uni_ptr(c.cells);
-  GLOBAL_AS v2u32 *const gcell = (GLOBAL_AS v2u32 *) cellbuf;      /* one 8-byte store per pebble */
+  typedef CellIO<W> IO;
+  typename IO::T *const cellbuf = (typename IO::T *) uni_ptr(c.cells);
+  typename IO::T *const gcell = cellbuf;
   u32 *const errw = uni_ptr(c.err);
   const int steplimit = uni(c.alen + c.blen + 64);
   const int guard = uni(4 * (c.alen + c.blen) + 1024);
@@ -1068,7 +1107,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
                 { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                   if (dropit)
                     { if (idx < cell_cap)
-                        gcell[idx] = cell_pack(ha, k, dif, (na - aoff) / TS + PK_BIAS);
+                        IO::put(gcell, idx, ha, k, dif, (na - aoff) / TS + PK_BIAS);
                       ha = (int) idx;  ham = na;
                     }
                   ncell += (u32) __popcll(mask);
@@ -1088,7 +1127,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
                 { u32 idx = ncell + (u32) __popcll(mask & lanes_below(lane));
                   if (dropit)
                     { if (idx < cell_cap)
-                        gcell[idx] = cell_pack(hb, k, dif, (nb - boff) / TS + PK_BIAS);
+                        IO::put(gcell, idx, hb, k, dif, (nb - boff) / TS + PK_BIAS);
                       hb = (int) idx;  hbm = nb;
                     }
                   ncell += (u32) __popcll(mask);
@@ -1191,7 +1230,7 @@ __device__ __noinline__ void wave_mem(const WaveCtx &c, int mida, WaveState &ws)
 }
 
 /* Stage 3: end point of this direction and its trace points (lane 0 walks the pebble chains). */
-template <int REV>
+template <int REV, int W = 0>
 __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveState &ws,
                                          int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
 {
@@ -1212,8 +1251,8 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
   const int ave = uni(c.ave), do_reach = uni(c.reach);
   const u32 cell_cap = (u32) uni((int) c.cell_cap);
   const short *score_tab = uni_ptr(c.score), *trim_tab = uni_ptr(c.table);
-  Cell *const cellbuf = uni_ptr(c.cells);
-  GLOBAL_AS v2u32 *const gcell = (GLOBAL_AS v2u32 *) cellbuf;      /* one 8-byte store per pebble */
+  typename CellIO<W>::T *const cellbuf = (typename CellIO<W>::T *) uni_ptr(c.cells);
+  typename CellIO<W>::T *const gcell = cellbuf;
   u32 *const errw = uni_ptr(c.err);
   const int steplimit = uni(c.alen + c.blen + 64);
   const int guard = uni(4 * (c.alen + c.blen) + 1024);
@@ -1230,7 +1269,7 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
   if (lane == 0 && !uni(ws.bad))
     { int  trimx, trimy, trimd, ha, hb;
       u16 *atrace = c.atr, *btrace = c.btr;
-      Cell *cells = cellbuf;
+      const typename CellIO<W>::T *cells = cellbuf;
 
       if (reachm >= 0 && do_reach)
         { trimx = reach.a - reach.y; trimy = reach.y; trimd = reach.d; ha = reach.ha; hb = reach.hb; }
@@ -1239,12 +1278,12 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
 
       int gw = 0;
       if (!REV)
-        { at = chain_to_trace<0, 0>(cells, ha, TS, aoff, mida, trimx, trimy, trimd, atrace, 0, guard, gw, errw);
-          bt = chain_to_trace<0, 1>(cells, hb, TS, boff, mida, trimx, trimy, trimd, btrace, 0, guard, gw, errw);
+        { at = chain_to_trace<0, 0, W>(cells, ha, TS, aoff, mida, trimx, trimy, trimd, atrace, 0, guard, gw, errw);
+          bt = chain_to_trace<0, 1, W>(cells, hb, TS, boff, mida, trimx, trimy, trimd, btrace, 0, guard, gw, errw);
         }
       else
-        { at = chain_to_trace<1, 0>(cells, ha, TS, aoff, mida, trimx, trimy, trimd, atrace, *atlen_io, guard, gw, errw);
-          bt = chain_to_trace<1, 1>(cells, hb, TS, boff, mida, trimx, trimy, trimd, btrace, *btlen_io, guard, gw, errw);
+        { at = chain_to_trace<1, 0, W>(cells, ha, TS, aoff, mida, trimx, trimy, trimd, atrace, *atlen_io, guard, gw, errw);
+          bt = chain_to_trace<1, 1, W>(cells, hb, TS, boff, mida, trimx, trimy, trimd, btrace, *btlen_io, guard, gw, errw);
         }
       rx = trimx;  ry = trimy;  rd = trimd;
     }
@@ -1259,23 +1298,135 @@ __device__ __noinline__ void wave_finish(const WaveCtx &c, int mida, const WaveS
   wave_mem_sync();
 }
 
+/* Wave 0 of a direction straight into the band buffers of the slot, for the wide path (W = 1): the seed diagonal's
+ * slide, its pebbles (16-byte cells), the clipping behind it (align.c:491-658 / 1203-1371) -- what the first part of
+ * wave_reg does in registers with packed heads, which cannot name a grid index beyond 14 bits.  wave_mem<REV, 1> goes on
+ * from the state left here: one diagonal in the ring, marks as positions. */
 template <int REV>
+__device__ __noinline__ void wave0_mem(const WaveCtx &c, int diag, int mida, WaveState &ws)
+{ typedef CellIO<1> IO;
+  const int lane = lane_id();
+  const int TS = uni(c.ts);
+  const int S = REV ? -1 : 1;
+  const u8 *aseq = uni_ptr(REV ? c.aseq - 1 : c.aseq);
+  const u8 *bseq = uni_ptr(REV ? c.bseq - 1 : c.bseq);
+  const u32 *apk = uni_ptr(c.apk), *bpk = uni_ptr(c.bpk);
+  const int va0 = (int) c.a0 + 16 * PK_PAD, vb0 = (int) c.b0 + 16 * PK_PAD, valen = c.alen, vblen = c.blen;
+  DState *cur = uni_ptr(c.st0);
+  const int o = uni(c.koff);
+  const u32 rmask = (u32) uni(c.ring) - 1u;
+  const int aoff = uni(c.aoff), boff = uni(c.boff);
+  const int offa = aoff - PK_BIAS * TS, offb = boff - PK_BIAS * TS;        /* mark = index * TS + off */
+  const u32 cell_cap = (u32) uni((int) c.cell_cap);
+  IO::T *const gcell = (IO::T *) uni_ptr(c.cells);
+  u32 *const errw = uni_ptr(c.err);
+  const int guard = uni(4 * (c.alen + c.blen) + 1024);
+  (void) apk; (void) bpk; (void) va0; (void) vb0; (void) valen; (void) vblen;
+  diag = uni(diag);
+  mida = uni(mida);
+  int low = diag, hgh = diag, dif = 0;
+  int besta = mida, lasta = mida, besty = (mida - diag) >> 1, more = 1;
+  Tip trim, reach;
+  int reachm = -1;
+  int aclip = REV ? -BIG : BIG, bclip = REV ? BIG : -BIG;
+  u32 ncell = 0;
+  trim.a = reach.a = mida;  trim.y = reach.y = besty;  trim.d = reach.d = 0;
+  trim.ha = reach.ha = 0;   trim.hb = reach.hb = 1;
+  ws.bad = 0;  ws.narrow = 0;
+
+  const int k = diag;
+  int y = (mida - k) >> 1, na, nb, nai, nbi, hai, hbi, ha, hb, v;
+  if (!REV)
+    { nai = ((y + k) + (TS - aoff)) / TS - 1 + PK_BIAS;
+      nbi = (y + (TS - boff)) / TS - 1 + PK_BIAS;
+      hai = nai;  hbi = nbi;
+    }
+  else
+    { nai = ((y + k) + (TS - aoff) - 1) / TS - 1 + PK_BIAS;
+      nbi = (y + (TS - boff) - 1) / TS - 1 + PK_BIAS;
+      hai = nai + 1;  hbi = nbi + 1;            /* the true start, rounded up to the grid */
+    }
+  if (lane == 0)
+    { IO::put_root(gcell, 0, REV ? y + k : nai * TS + offa, k);
+      IO::put_root(gcell, 1, REV ? y : nbi * TS + offb, k);
+    }
+  ha = 0;  hb = 1;  ncell = 2;
+  if (!REV) { nai += 1; nbi += 1; }
+  na = nai * TS + offa;  nb = nbi * TS + offb;
+  int g0 = 0;
+  { const SnakeOut so = SNAKE_AT(k, y, 0, 0ull);
+    y = uni(so.y);
+    if (uni(so.nb) == 0)      { more = 0; bclip = k; }
+    else if (uni(so.na) == 0) { more = 0; aclip = k; }
+  }
+  v = (y << 1) + k;
+  while (REV ? (y + k <= na) : (y + k >= na))
+    { GUARD(g0, guard, 2)
+      if (lane == 0 && ncell < cell_cap) IO::put(gcell, ncell, ha, k, 0, nai);
+      ha = (int) ncell++;  hai = nai;  nai += S;  na += S * TS;
+    }
+  while (REV ? (y <= nb) : (y >= nb))
+    { GUARD(g0, guard, 3)
+      if (lane == 0 && ncell < cell_cap) IO::put(gcell, ncell, hb, k, 0, nbi);
+      hb = (int) ncell++;  hbi = nbi;  nbi += S;  nb += S * TS;
+    }
+  if (REV ? (v < besta) : (v > besta))
+    { besta = lasta = trim.a = v;
+      besty = trim.y = y;
+      trim.ha = ha;  trim.hb = hb;
+    }
+  if (lane == 0)
+    { DState s0;
+      s0.V = v;  s0.M = pk_popc61(HIST_FULL);  s0.HA = ha;  s0.HB = hb;  s0.T = HIST_FULL;
+      s0.HAm = hai * TS + offa;  s0.HBm = hbi * TS + offb;
+      cur[RI(k)] = s0;
+      c.NA[RI(k)] = na;
+      c.NB[RI(k)] = nb;
+    }
+  int stopped = 0;
+  if (ncell > cell_cap)                        /* a seed diagonal that slides over more marks than the pool holds */
+    { if (lane == 0) atomicOr(errw, DAMAR_ERR_CELLS);
+      more = 0;  ncell = 2;  ws.bad = 1;  stopped = 1;
+    }
+  /* clipping behind wave 0: the band is the one diagonal */
+  if (more == 0 && !stopped)
+    { if (uni((int) bseq[besty]) != 4 && uni((int) aseq[besta - besty]) != 4)
+        more = 1;
+      if (aclip == k || bclip == k)
+        { const int m_ = pk_popc61(HIST_FULL);
+          if (aclip == k) { if (REV) low = k + 1; else hgh = k - 1; }
+          else            { if (REV) hgh = k - 1; else low = k + 1; }
+          if (reachm <= m_)
+            { reachm = m_;  reach.a = v;  reach.y = (v - k) / 2;  reach.d = dif;  reach.ha = ha;  reach.hb = hb; }
+        }
+      aclip = REV ? -BIG : BIG;
+      bclip = REV ? BIG : -BIG;
+    }
+  ws.stopped = stopped;
+  WS_STORE(ws)
+  wave_mem_sync();
+}
+
+template <int REV, int W = 0>
 __device__ __forceinline__ void wave_pass(const WaveCtx &c, int diag, int mida,
                                           int *ox, int *oy, int *od, int *atlen_io, int *btlen_io, int *aback, int *bback)
 { WaveState ws;
 #ifdef DAMAR_PROF
   const unsigned long long t0 = wall_clock64();
 #endif
-  wave_reg<REV>(c, diag, mida, ws);
+  if (W)
+    wave0_mem<REV>(c, diag, mida, ws);
+  else
+    wave_reg<REV>(c, diag, mida, ws);
 #ifdef DAMAR_PROF
   const unsigned long long t1 = wall_clock64();
 #endif
   if (!uni(ws.stopped))
-    wave_mem<REV>(c, mida, ws);
+    wave_mem<REV, W>(c, mida, ws);
 #ifdef DAMAR_PROF
   const unsigned long long t2 = wall_clock64();
 #endif
-  wave_finish<REV>(c, mida, ws, ox, oy, od, atlen_io, btlen_io, aback, bback);
+  wave_finish<REV, W>(c, mida, ws, ox, oy, od, atlen_io, btlen_io, aback, bback);
 #ifdef DAMAR_PROF
   PROF_ADD(15, t1 - t0);  PROF_ADD(13, t2 - t1);  PROF_ADD(14, wall_clock64() - t2);
 #endif
@@ -1288,6 +1439,7 @@ struct LaResult
 };
 
 /* align.c:1904-2097 for low == hgh == diag, lbord = hbord = -1 */
+template <int W = 0>
 __device__ void local_alignment(WaveCtx &c, u32 flags, int diag, int anti, LaResult *r)
 { const bool selfie = (c.aseq == c.bseq);
   int ax, ay, ad, bx, by, bd, atlen = 0, btlen = 0, aback = 0, bback = 0;
@@ -1297,8 +1449,8 @@ __device__ void local_alignment(WaveCtx &c, u32 flags, int diag, int anti, LaRes
   c.aoff = 0;
   c.boff = (flags & 1) ? (c.blen % c.ts) : 0;
 
-  wave_pass<0>(c, diag, anti, &ax, &ay, &ad, &atlen, &btlen, &aback, &bback);
-  wave_pass<1>(c, diag, anti, &bx, &by, &bd, &atlen, &btlen, &aback, &bback);
+  wave_pass<0, W>(c, diag, anti, &ax, &ay, &ad, &atlen, &btlen, &aback, &bback);
+  wave_pass<1, W>(c, diag, anti, &bx, &by, &bd, &atlen, &btlen, &aback, &bback);
 
   r->aepos = ax;  r->bepos = ay;
   r->abpos = bx;  r->bbpos = by;
@@ -1428,6 +1580,17 @@ __device__ void diagonal_span(const SlotScratch &s, const LaResult &r, int ts, i
   *hi = uni(hgh);
 }
 
+/* which kernel a read pair belongs to: the packed pebble format holds DAMAR_MAX_MARKS trace spacings of a read and 2^18
+   pebbles a direction (ReportArgs.widemap: the pairs the two-pair kernel gave up on for the latter) */
+__device__ __forceinline__ bool pair_is_wide(const ReportArgs &a, u32 item, int alen, int blen)
+{ if (a.widemap == NULL)
+    return false;
+  if ((alen > blen ? alen : blen) / a.tspace + 8 > DAMAR_MAX_MARKS)
+    return true;
+  return (a.widemap[item >> 5] >> (item & 31)) & 1u;
+}
+
+template <int WD = 0>
 __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const SlotScratch &s, u32 item)
 { const int  lane = lane_id();
   const u64 *keys = a.keys;
@@ -1443,6 +1606,8 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
   const int alen = (int) read_len(a.ablk, ar), blen = (int) read_len(a.bblk, br);
   if (alen < a.hgap_min && blen < a.hgap_min)
     return;
+  if (WD && !pair_is_wide(a, item, alen, blen))      /* the wide kernel walks the whole work list for its few pairs */
+    return;
 
   WaveCtx c;
   c.aseq = a.ablk.bases + a.ablk.boff[ar];
@@ -1455,6 +1620,10 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
   c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
   c.koff = blen + 8;  c.ring = a.span;
   c.cells = s.cells;  c.cell_cap = a.cell_cap;
+  if (WD)
+    { c.cells = (Cell *) ((WCell *) a.wcells + (u64) blockIdx.x * a.wcell_cap);
+      c.cell_cap = a.wcell_cap;
+    }
   c.err = &a.counters[3];
   c.atr = s.atr;  c.btr = s.btr;
 
@@ -1562,7 +1731,7 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
 #ifdef DAMAR_PROF
                   const unsigned long long pf_t0 = wall_clock64();
 #endif
-                  local_alignment(c, (u32) a.comp, sdg, sap + sbp, &r);
+                  local_alignment<WD>(c, (u32) a.comp, sdg, sap + sbp, &r);
 #ifdef DAMAR_PROF
                   PROF_ADD(pf_nla ? 7 : 6, wall_clock64() - pf_t0);
                   PROF_ADD(pf_nla ? 10 : 9, 1);
@@ -1579,7 +1748,7 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
                   if (hi > chi) chi = hi;
                   wave_mem_sync();
                   if ((r.aepos - r.abpos) + (r.bepos - r.bbpos) >= a.minover)
-                    emit_record(a.job, s, r, ar, br, item, seq++);
+                    emit_record(a.job, s, r, ar, br, item | (WD ? DAMAR_ITEM_WIDE : 0u), seq++);
                 }
             }
 
@@ -1791,6 +1960,39 @@ void report_kernel(int njobs)
           process_pair(a, trimtab, s, item);
         }
     }
+}
+
+/* The read pairs the packed pebble format cannot hold (pair_is_wide), one per wavefront with 16-byte pebbles and the band in
+   memory from wave 0 on: every slot walks the whole work list of every job and takes what is its kernel's.  Slow (a wave
+   step is a round trip to HBM) and rare: reads of more than DAMAR_MAX_MARKS trace spacings, alignments of more than 2^18
+   pebbles a direction -- a loud error until round 5.  Its records carry DAMAR_ITEM_WIDE in their item: the host drops what
+   the two-pair kernel had written for a pair before it gave up. */
+__global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
+void report_wide_kernel(int njobs)
+{ __shared__ u32 trimtab[256];
+  pk_fill_trimtab(trimtab, g_jobs[0].mscore, g_jobs[0].dscore);
+  __syncthreads();
+  const int slot = blockIdx.x;
+  for (int turn = 0; turn < njobs; turn++)
+    { const ReportArgs &a = g_jobs[(slot + turn) % njobs];
+      const SlotScratch s = slot_scratch(a, slot);
+      for (;;)
+        { u32 item = 0;
+          if (lane_id() == 0)
+            item = atomicAdd(a.cursor, 1u);
+          item = (u32) uni((int) item);
+          if (item >= a.nwork)
+            break;
+          if (a.order)
+            item = (u32) uni((int) a.order[item]);
+          process_pair<1>(a, trimtab, s, item);
+        }
+    }
+}
+
+void damar_launch_report_wide(const ReportArgs *jobs, int njobs, int nslots, hipStream_t st)
+{ jobs_upload(jobs, njobs, st);
+  hipLaunchKernelGGL(report_wide_kernel, dim3(nslots), dim3(64), 0, st, njobs);
 }
 
 void damar_launch_report(const ReportArgs *jobs, int njobs, int nslots, hipStream_t st)

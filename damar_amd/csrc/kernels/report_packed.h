@@ -121,6 +121,7 @@ struct DuoCtx
   int pa0, pb0;                                 /* where the pass's packed bases start: window of (X, Y) at pa0 + X, pb0 + Y */
   /* the task and what its passes have produced */
   int diag, anti;
+  u32 item;                                     /* the work item (read pair) of the half: named when its pebbles outgrow the packed format */
   int roota, rootb;                             /* trace-grid index the A / B chain of the pass starts from (its root) */
   int aepos, bepos, abpos, bbpos, diffs, atlen, btlen, aback, bback;
   /* what the wavefront has stepped through so far (the same in every lane): SURVEY 8(d)'s secondary unit of K6 */
@@ -178,6 +179,21 @@ __device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, co
     }
   o.Y = Y;  o.b = b;  o.na = na;  o.nb = nb;
   return o;
+}
+
+/* An alignment of the half has been abandoned because its pebbles do not fit the pool.  While the pool can still grow the
+   launch is repeated with a larger one (DAMAR_ERR_CELLS); at the packed format's limit of 2^18 the read pair is left to the
+   wide kernel (report.hip: report_wide_kernel) -- its bit in widemap, one count per pair -- and what this kernel has
+   written or will still write for the pair is dropped by the host.  Called by every lane of the half. */
+__device__ __forceinline__ void duo_pebbles_over(const ReportArgs &a, u32 item)
+{ if ((lane_id() & 31) != 0)
+    return;
+  atomicOr(&a.counters[3], DAMAR_ERR_CELLS);
+  if (a.widemap != NULL && a.cell_cap >= DAMAR_MAX_CELLS)
+    { const u32 bit = 1u << (item & 31);
+      if (!(atomicOr(&a.widemap[item >> 5], bit) & bit))
+        atomicAdd(&a.counters[DAMAR_CNT_WIDE], 1u);
+    }
 }
 
 /* clipping at sequence ends (align.c:628-658 / 943-975) for the halves with `on`, in lane coordinates: the A-side clip
@@ -328,7 +344,7 @@ DUO_PART void duo_begin(int job, u32 cbase)
       rHA = ha | (ga << PK_HBITS);  rHB = hb_ | (gb << PK_HBITS);
       md = MD_RUN;
       if (ncell > cell_cap)              /* a seed diagonal that slides over more marks than the pool holds */
-        { if (s == 0) atomicOr(errw, DAMAR_ERR_CELLS);
+        { duo_pebbles_over(a, cx.item);
           more = 0;  ncell = 2;  bad = 1;  md = MD_END;
         }
     }
@@ -846,7 +862,7 @@ __device__ __forceinline__ void duo_classify(const ReportArgs &a)
   if (cx.md != MD_RUN)
     return;
   if (cx.ncell > (int) a.cell_cap)
-    { if (s == 0) atomicOr(errw, DAMAR_ERR_CELLS);
+    { duo_pebbles_over(a, cx.item);
       cx.more = 0;  cx.ncell = 2;  cx.bad = 1;  cx.md = MD_END;
     }
   else if (!(cx.more && cx.lasta >= cx.besta - MAX_TRIM_LAG))
@@ -967,7 +983,15 @@ DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel)
     { if (!ws.stopped)
         wave_mem<REV>(c, mida, ws);
       if (mine)
-        { cx.md = MD_END;  cx.bad = ws.bad; }
+        { cx.md = MD_END;  cx.bad = ws.bad;
+          if (ws.bad)                                /* (the excursion's own stages raised DAMAR_ERR_CELLS or DAMAR_ERR_WIDE) */
+            { if (a.widemap != NULL && a.cell_cap >= DAMAR_MAX_CELLS && (lane & 31) == 0)
+                { const u32 bit = 1u << (cx.item & 31);
+                  if (!(atomicOr(&a.widemap[cx.item >> 5], bit) & bit))
+                    atomicAdd(&a.counters[DAMAR_CNT_WIDE], 1u);
+                }
+            }
+        }
     }
   if (mine)
     { cx.dif = ws.dif;  cx.besta = DUO_SG(ws.besta);  cx.bestk = DUO_SG(ws.besta) - 2 * DUO_SG(ws.besty);
@@ -1329,7 +1353,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
   duo_V[lane] = DUO_EDGE;  duo_HA[lane] = duo_HB[lane] = 0;  duo_Tlo[lane] = duo_Thi[lane] = 0;
   cx.ls = cx.hs = 15;  cx.kbase = 0;  cx.dif = 0;  cx.besta = cx.bestk = cx.lasta = 0;  cx.more = 0;  cx.ncell = 2;
   cx.mlo = cx.mhi = 0;  cx.alim = cx.blim = 0;  cx.offa = cx.offb = 0;  cx.pa0 = cx.pb0 = 0;
-  cx.diag = cx.anti = 0;  cx.roota = cx.rootb = 0;
+  cx.diag = cx.anti = 0;  cx.roota = cx.rootb = 0;  cx.item = 0;
   cx.aepos = cx.bepos = cx.abpos = cx.bbpos = cx.diffs = cx.atlen = cx.btlen = cx.aback = cx.bback = 0;
   cx.n_cells_lo = cx.n_cells_hi = 0;  cx.n_iter = cx.n_half = 0;
 
@@ -1463,8 +1487,14 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                   ar = (int) (cpair & ((1ull << a.abits) - 1));  br = (int) (cpair >> a.abits);
                   cx.va0 = (int) a.ablk.boff[ar] + 16 * PK_PAD;  cx.vb0 = (int) a.bblk.boff[br] + 16 * PK_PAD;
                   cx.alen = (int) read_len(a.ablk, ar);  cx.blen = (int) read_len(a.bblk, br);
+                  cx.item = item;
                   seq = 0;  amark2 = 0;  clo = BIG;  chi = -BIG;
-                  if (!(cx.alen < a.hgap_min && cx.blen < a.hgap_min))
+                  if (a.widemap != NULL && (cx.alen > cx.blen ? cx.alen : cx.blen) / a.tspace + 8 > DAMAR_MAX_MARKS)
+                    { /* a read of more trace spacings than a packed chain head can name: the wide kernel's pair */
+                      if (!(cx.alen < a.hgap_min && cx.blen < a.hgap_min) && s == 0)
+                        atomicAdd(&a.counters[DAMAR_CNT_WIDE], 1u);
+                    }
+                  else if (!(cx.alen < a.hgap_min && cx.blen < a.hgap_min))
                     phase = PK_PANEL;
                 }
             }

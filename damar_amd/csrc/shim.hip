@@ -982,6 +982,8 @@ struct ReportScratch
      it are still on their way to the host out of the other (measured: a launch waited 1.4 - 2.2 ms for that download),
      and the next launch can be queued behind a running one */
   LaRecord *recs_set[2];  u16 *tpool_set[2];  u32 rec_cap_set[2], tpool_cap_set[2];  int cur;
+  u32  *widemap[2];  u32 widemap_cap[2];          /* per output set: one bit per work item of the launch's jobs (ReportArgs.widemap) */
+  void *wcells;  u32 wcell_cap;  int wslots;      /* the wide kernel's 16-byte pebbles (allocated when a launch first needs them) */
 };
 static ReportScratch RS = {};   /* (nslots_wanted: the slot count asked for when nslots was last sized) */
 
@@ -1023,12 +1025,22 @@ static u32 grow_cells(u32 cell_cap)
   return std::min(cell_cap * 4, DAMAR_MAX_CELLS);
 }
 
-static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 cell_cap, hipStream_t st)
-{ if (tspace <= 0 || std::max(amax, bmax) / tspace + 8 > DAMAR_MAX_MARKS)      /* 14 bits of trace-grid index in a chain head */
-    { fprintf(stderr, "damar: FATAL: reads of %d bases need a trace spacing (-s) of at least %d\n", std::max(amax, bmax),
+/* datander and the Local_Alignment batch entry have no wide kernel behind them: there the packed format's limit stays loud */
+static void marks_must_fit(int amax, int bmax, int tspace)
+{ if (tspace > 0 && std::max(amax, bmax) / tspace + 8 > DAMAR_MAX_MARKS)
+    { fprintf(stderr, "damar: FATAL: reads of %d bases need a trace spacing (-s) of at least %d here\n", std::max(amax, bmax),
               std::max(amax, bmax) / (DAMAR_MAX_MARKS - 8) + 1);
       die();
     }
+}
+
+static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 cell_cap, hipStream_t st)
+{ if (tspace <= 0)
+    { fprintf(stderr, "damar: FATAL: trace spacing %d\n", tspace);
+      die();
+    }
+  /* (reads of more than DAMAR_MAX_MARKS trace spacings -- 14 bits of trace-grid index in a packed chain head -- are the wide
+     kernel's: report_launch, kernels/report.hip report_wide_kernel) */
   if (tspace > DAMAR_MAX_TSPACE)                  /* pebbles carry diagonal and wave number modulo 2^16 (kernels/report.hip: struct Cell) */
     { fprintf(stderr, "damar: FATAL: a trace spacing (-s) above %d is not supported by this build\n", DAMAR_MAX_TSPACE);
       die();
@@ -1243,6 +1255,8 @@ struct HostBuf
   hipEvent_t e0, e1;               /* around the download; e1 is what the tail thread waits for */
   bool      pending;
   int       t8;                    /* the trace values are bytes (the launch compressed them: ReportArgs.t8) */
+  u32      *wmap;  size_t wmap_cap;  /* nwide > 0: the jobs' bit maps of the read pairs the wide kernel took over (job j from wm_off[j]) */
+  u32       nwide, wm_off[DAMAR_MAX_JOBS + 1];
   int       users;                 /* comparisons of the launch whose tails have not run yet */
 };
 static std::mutex             &HB_mu   = *new std::mutex();
@@ -1438,7 +1452,7 @@ static int tail_threads(void)
   return n;
 }
 
-static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool, int t8,
+static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool, int t8, const u32 *wmap,
                       const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec,
                       const JobParams &jp, int jobid = 0, int njobs = 1)
 { const int ts = Trace_Spacing(spec);
@@ -1455,7 +1469,13 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool, int t8
   u32 maxitem = 0;
   for (size_t q = 0; q < nrecs_all; q++)
     if (njobs <= 1 || (int) (recs[q].seq >> DAMAR_SEQ_BITS) == jobid)
-      { const u32 it = recs[q].item;
+      { u32 it = recs[q].item;
+        if (it & DAMAR_ITEM_WIDE)                    /* the wide kernel's record */
+          { it &= ~DAMAR_ITEM_WIDE;
+            recs[q].item = it;
+          }
+        else if (wmap != NULL && ((wmap[it >> 5] >> (it & 31)) & 1u))
+          continue;                                   /* what the two-pair kernel wrote for a pair before it gave it up */
         key.push_back(((u64) it << 32) | (u64) recs[q].seq);
         idx.push_back((u32) q);
         if (it > maxitem) maxitem = it;
@@ -1627,7 +1647,8 @@ static void tail_worker(void)
               A_d2h_ms += ms;
               t0 = now_ms();
             }
-          int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, job->hb->t8, &job->ablock, &job->bblock,
+          int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, job->hb->t8,
+                               job->hb->nwide ? job->hb->wmap + job->hb->wm_off[job->jobid] : (const u32 *) NULL, &job->ablock, &job->bblock,
                              job->self, job->comp, job->spec, job->jp, job->jobid, job->njobs);
           if (--job->hb->users == 0)
             hostbuf_put(job->hb);
@@ -2126,6 +2147,9 @@ struct Pending
   int  amax, bmax, tsmin;
   u32  cell_cap, rec_cap, tp_cap;
   int  t8;                                        /* the launch's trace values leave the device as bytes (ReportArgs.t8) */
+  bool wide_ok;                                   /* the two-pair kernel runs: pairs beyond the packed pebble format go to the wide kernel */
+  bool wide_done;                                 /* the wide kernel has run behind this attempt's launch */
+  u32  wm_off[DAMAR_MAX_JOBS + 1];                /* the jobs' bit maps in RS.widemap (words) */
   int  attempt;
   int  oset;                                      /* the set of record buffers, counters and timers this launch uses */
   hipEvent_t done;                                /* behind the kernel */
@@ -2181,11 +2205,37 @@ static void report_launch(Pending &pd)
       ra[j].pbits = pd.fr[j].pbits;  ra[j].abits = pd.fr[j].abits;  ra[j].dbits = pd.fr[j].dbits;
       ra[j].order = pd.fr[j].order;
       ra[j].t8 = pd.t8;
+      ra[j].widemap = NULL;  ra[j].wcells = RS.wcells;  ra[j].wcell_cap = RS.wcell_cap;
       packed = packed && use_packed(&ra[j], pd.amax, pd.bmax);
       if (ra[j].mscore != ra[0].mscore || ra[j].dscore != ra[0].dscore)
         { fprintf(stderr, "damar: internal error, the comparisons of one report launch differ in their -e\n");
           die();
         }
+    }
+  pd.wide_ok = packed;  pd.wide_done = false;
+  if (!packed && std::max(pd.amax, pd.bmax) / std::max(1, pd.tsmin) + 8 > DAMAR_MAX_MARKS)
+    { fprintf(stderr, "damar: FATAL: reads of %d bases need a trace spacing (-s) of at least %d when one read pair per wavefront "
+                      "is asked for (DAMAR_PACKED=0): the wide kernel runs behind the two-pair kernel only\n",
+              std::max(pd.amax, pd.bmax), std::max(pd.amax, pd.bmax) / (DAMAR_MAX_MARKS - 8) + 1);
+      die();
+    }
+  if (packed)
+    { /* one bit per work item and job, zero at every launch: which read pairs are the wide kernel's (kernels/report.hip) */
+      u32 words = 0;
+      for (int j = 0; j < pd.n; j++)
+        { pd.wm_off[j] = words;
+          words += (ra[j].nwork + 31) / 32 + 1;
+        }
+      pd.wm_off[pd.n] = words;
+      const int c = pd.oset;
+      if (RS.widemap_cap[c] < words)
+        { if (RS.widemap[c]) HIP_CHECK(hipFree(RS.widemap[c]));
+          RS.widemap_cap[c] = words + (words >> 2) + 1024;
+          RS.widemap[c] = (u32 *) dmalloc(sizeof(u32) * (size_t) RS.widemap_cap[c]);
+        }
+      HIP_CHECK(hipMemsetAsync(RS.widemap[c], 0, sizeof(u32) * (size_t) words, st));
+      for (int j = 0; j < pd.n; j++)
+        ra[j].widemap = RS.widemap[c] + pd.wm_off[j];
     }
   HIP_CHECK(hipMemsetAsync(RS.ctr, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, st));
   tick_on(16 + 4 * pd.oset, st);
@@ -2226,8 +2276,52 @@ static void report_finish(Pending &pd)
           }
       }
       G_cnt[5] += 1;
+      /* Read pairs beyond the packed pebble format (reads of more than DAMAR_MAX_MARKS trace spacings; alignments that
+         overflowed the pebble pool at its largest, 2^18): the wide kernel takes them, into the same record buffers, behind
+         the launch that is otherwise complete.  Until round 5 both were fatal. */
+      if (pd.wide_ok && !pd.wide_done && hc[DAMAR_CNT_WIDE] > 0)
+        { u32 flags = hc[3];
+          if (pd.cell_cap >= DAMAR_MAX_CELLS)
+            flags &= ~DAMAR_ERR_CELLS;                         /* (those pairs are in the map: nothing to repeat for them) */
+          if (flags == 0)
+            { if (RS.wcells == NULL)
+                { RS.wslots = std::min(RS.nslots, 64);
+                  RS.wcell_cap = 1u << 21;
+                  RS.wcells = dmalloc((size_t) 16 * RS.wcell_cap * (size_t) RS.wslots);
+                }
+              for (int j = 0; j < n; j++)
+                { pd.ra[j].wcells = RS.wcells;  pd.ra[j].wcell_cap = RS.wcell_cap; }
+              if (VERBOSE)
+                fprintf(stderr, "damar: %u read pair(s) beyond the packed pebble format: wide kernel\n", hc[DAMAR_CNT_WIDE]);
+              { u32 *const ctr = RS.counters + (size_t) pd.oset * DAMAR_COUNTER_WORDS;
+                HIP_CHECK(hipMemsetAsync(ctr + DAMAR_CNT_CURSOR, 0, sizeof(u32) * DAMAR_MAX_JOBS, st));      /* the work lists once more */
+                HIP_CHECK(hipMemsetAsync(ctr + 3, 0, sizeof(u32), st));
+              }
+              damar_launch_report_wide(pd.ra, n, RS.wslots, st);
+              HIP_CHECK(hipEventRecord(pd.done, st));
+              pd.wide_done = true;
+              continue;                                         /* wait for it, read the counters again */
+            }
+        }
+      if (pd.wide_done && (hc[3] & DAMAR_ERR_CELLS))
+        { /* the wide kernel's own pool: four times the pebbles, and everything once more */
+          if (RS.wcell_cap >= (1u << 26))
+            { fprintf(stderr, "damar: FATAL: an alignment needs more than %u trace pebbles even in the wide format\n", RS.wcell_cap);
+              die();
+            }
+          HIP_CHECK(hipStreamSynchronize(st));
+          HIP_CHECK(hipFree(RS.wcells));
+          RS.wcell_cap *= 4;
+          RS.wslots = std::max(8, RS.wslots / 2);
+          RS.wcells = dmalloc((size_t) 16 * RS.wcell_cap * (size_t) RS.wslots);
+          hc[3] &= ~DAMAR_ERR_CELLS;
+          hc[3] |= 0x40000000u;                                /* (something to repeat the launch for) */
+        }
+      else if (pd.wide_ok && pd.cell_cap >= DAMAR_MAX_CELLS && hc[DAMAR_CNT_WIDE] > 0)
+        hc[3] &= ~DAMAR_ERR_CELLS;                             /* the packed kernel's overflows at 2^18 are the wide kernel's pairs */
       if (hc[3] == 0)
         break;
+      hc[3] &= ~0x40000000u;
       if ((hc[3] & DAMAR_ERR_BAND) && !(hc[3] & (DAMAR_ERR_CELLS | DAMAR_ERR_WIDE)))
         { fprintf(stderr, "damar: FATAL: a Local_Alignment wave exceeded its loop bound (where=%u)\n", hc[6]);
           die();
@@ -2266,6 +2360,17 @@ static void report_finish(Pending &pd)
       HIP_CHECK(hipMemcpyAsync(hb->tpool, RS.tpool_set[pd.oset], (pd.t8 ? sizeof(u8) : sizeof(u16)) * (size_t) hc[2], hipMemcpyDeviceToHost, cs));
     }
   hb->t8 = pd.t8;
+  hb->nwide = pd.wide_done ? hc[DAMAR_CNT_WIDE] : 0;
+  if (hb->nwide > 0)
+    { const u32 words = pd.wm_off[n];
+      if (hb->wmap_cap < words)
+        { free(hb->wmap);
+          hb->wmap_cap = words + 1024;
+          hb->wmap = (u32 *) malloc(sizeof(u32) * hb->wmap_cap);
+        }
+      memcpy(hb->wm_off, pd.wm_off, sizeof(hb->wm_off));
+      HIP_CHECK(hipMemcpy(hb->wmap, RS.widemap[pd.oset], sizeof(u32) * (size_t) words, hipMemcpyDeviceToHost));
+    }
   tick_on(19 + 4 * pd.oset, st);
   if (A_on)
     { /* asynchronous mode: the download runs on its own stream beside the next comparison's merge and sorts; the
@@ -2306,7 +2411,7 @@ static void report_finish(Pending &pd)
         }
       else
         { double t0 = now_ms();
-          const int64 got = run_tail(hb->recs, hb->nrec, hb->tpool, hb->t8, jb.ablock, jb.bblock, jb.self, jb.comp, jb.spec, pd.fr[j].jp, j, n);
+          const int64 got = run_tail(hb->recs, hb->nrec, hb->tpool, hb->t8, hb->nwide ? hb->wmap + hb->wm_off[j] : (const u32 *) NULL, jb.ablock, jb.bblock, jb.self, jb.comp, jb.spec, pd.fr[j].jp, j, n);
           if (pd.orig[j] != NULL)
             pd.orig[j]->counts[2] = got;
           if (--hb->users == 0)
@@ -2663,6 +2768,7 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
     u32 tp_cap   = std::max(RS.tpool_cap, rec_cap * 64u);
     for (int attempt = 0; ; attempt++)
       { ReportArgs ra;
+        marks_must_fit(ablock->maxlen, ablock->maxlen, ts);
         scratch_prepare(ablock->maxlen, ablock->maxlen, T_binshift, ts, cell_cap, G_st);
         scratch_outputs(rec_cap, tp_cap);
         fill_report_args(&ra, blk, blk, 0, 1, spec, G_st, 0, 0, params_now());
@@ -2777,6 +2883,7 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
   u32 hc[DAMAR_COUNTER_WORDS];
   for (int attempt = 0; ; attempt++)
     { ReportArgs ra;
+      marks_must_fit(ablk->d.maxlen, bblk->d.maxlen, ts);
       scratch_prepare(ablk->d.maxlen, bblk->d.maxlen, P_binshift, ts, cell_cap, G_st);
       stage("la_scratch");
       scratch_outputs(rec_cap, tp_cap);

@@ -49,6 +49,7 @@ CASES = {
     "noisy":   dict(derive="noisy", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "tandem":  dict(derive="tandem", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "tandem2": dict(derive="tandem2", opts=["-k14", "-j4"], plan=[("1", ["1"])], md5_only=True),      # (a 9.9 MB .las)
+    "wide":    dict(derive="wide2m", opts=["-k14", "-j1"], plan=[("1", ["1"])], md5_only=True),       # (reads of 2.1 Mb)
     "fusion":  dict(derive="fusion32", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     "fusion2": dict(derive="fusion31", opts=["-k14", "-j4"], plan=[("1", ["1"])]),
     # mask tracks (-m): a DBdust track made by the reference's own DBdust on reads with
@@ -146,6 +147,31 @@ def derive(kind, work):
                 s = "".join(comp[ch] for ch in reversed(s))
             reads.append(s)
             tot += len(s)
+    elif kind == "wide2m":
+        # two reads of 2.1 Mb that overlap by 1.6 Mb (one on the other strand), a 30 kb read inside the overlap and a
+        # second one beside it: at -s100 the long reads have 21 000 trace spacings (the packed pebbles of the GPU kernels hold
+        # 16 000) and their alignment drops far more than 2^18 pebbles -- the pairs with a long read are the wide kernel's
+        # (kernels/report.hip report_wide_kernel), the pair of the two short reads the two-pair kernel's
+        rng = random.Random(777)
+        genome = rnd_seq(rng, 2600000)
+        comp = {"a": "t", "c": "g", "g": "c", "t": "a"}
+
+        def noisy(seq):
+            out = []
+            for ch in seq:
+                x = rng.random()
+                if x < .03:
+                    continue
+                if x < .04:
+                    ch = rng.choice("acgt")
+                out.append(ch)
+                if rng.random() < .11:
+                    out.append(rng.choice("acgt"))
+            return "".join(out)
+        reads = [noisy(genome[0:2100000]),
+                 "".join(comp[ch] for ch in reversed(noisy(genome[500000:2600000]))),
+                 noisy(genome[1000000:1030000]),
+                 noisy(genome[1010000:1040000])]
     elif kind == "lowcomp":
         # homopolymer and short-period stretches dropped into ordinary simulated reads: what
         # DBdust masks, and what floods the seed filter with chance k-mer hits when unmasked

@@ -52,9 +52,12 @@ def test_gpu_las_equals_reference_golden(gpu, tmp_path, name):
     assert compare_las(case, str(tmp_path)) == []
 
 
-@pytest.mark.parametrize("name", ["tiny2", "tan_tandem", "mask_two", "bias_mask"])
+@pytest.mark.parametrize("name", ["tiny2", "tan_tandem", "mask_two", "bias_mask", "wide"])
 def test_gpu_cli_binary_equals_reference_golden(gpu, tmp_path, name):
-    """The C host drivers (the drop-in daligner / datander commands)."""
+    """The C host drivers (the drop-in daligner / datander commands).  `wide`: two reads of 2.1 Mb -- 21 000 trace spacings
+    at -s100, beyond the 16 000 a packed pebble can name -- and two of 30 kb: the pairs with a long read go through the
+    wide kernel (16-byte pebbles, kernels/report.hip report_wide_kernel), the short pair through the two-pair kernel; the
+    .las must be the reference's (md5 in tests/golden/wide/las.md5)."""
     from conftest import run_cli
     case = read_case(name)
     run_cli(os.path.join(ROOT, "damar_amd", "bin", "daligner"), case, str(tmp_path))
