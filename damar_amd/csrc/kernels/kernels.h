@@ -196,6 +196,7 @@ typedef struct
   u32  *widemap;                   /* one bit per work item: the two-pair kernel gave the pair up (pebbles beyond the packed format);
                                       NULL: no wide path behind this launch (the limits are fatal as until round 4) */
   void *wcells;    u32 wcell_cap;  /* the wide kernel's 16-byte pebbles: wcell_cap per slot */
+  u32  cell_max;                   /* the largest pool a slot can get (DAMAR_MAX_CELLS; a test hook lowers it): a pair that overflows it is the wide kernel's */
   int  t8, t8max;                  /* t8: trace values leave as BYTES (tspace <= 125: align.c:3375-3396 Compress_TraceTo8 on the device, the
                                       pool then holds tpool_cap bytes' worth of values in its first half); a value above t8max (255) raises
                                       DAMAR_ERR_T8 and the host repeats the launch with 16-bit values, so that the reference's own check

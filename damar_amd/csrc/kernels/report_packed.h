@@ -189,7 +189,7 @@ __device__ __forceinline__ void duo_pebbles_over(const ReportArgs &a, u32 item)
 { if ((lane_id() & 31) != 0)
     return;
   atomicOr(&a.counters[3], DAMAR_ERR_CELLS);
-  if (a.widemap != NULL && a.cell_cap >= DAMAR_MAX_CELLS)
+  if (a.widemap != NULL && a.cell_cap >= a.cell_max)
     { const u32 bit = 1u << (item & 31);
       if (!(atomicOr(&a.widemap[item >> 5], bit) & bit))
         atomicAdd(&a.counters[DAMAR_CNT_WIDE], 1u);
@@ -985,7 +985,7 @@ DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel)
       if (mine)
         { cx.md = MD_END;  cx.bad = ws.bad;
           if (ws.bad)                                /* (the excursion's own stages raised DAMAR_ERR_CELLS or DAMAR_ERR_WIDE) */
-            { if (a.widemap != NULL && a.cell_cap >= DAMAR_MAX_CELLS && (lane & 31) == 0)
+            { if (a.widemap != NULL && a.cell_cap >= a.cell_max && (lane & 31) == 0)
                 { const u32 bit = 1u << (cx.item & 31);
                   if (!(atomicOr(&a.widemap[cx.item >> 5], bit) & bit))
                     atomicAdd(&a.counters[DAMAR_CNT_WIDE], 1u);

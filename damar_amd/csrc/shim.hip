@@ -1017,12 +1017,21 @@ static int G_ring = 0;
 #define DEFAULT_CELLS (1u << 13)
 
 /* the pebble pool of a slot after an overflow: a chain head holds 18 bits of pebble index (report.hip PK_HBITS) */
+static u32 max_cells(void)                  /* (DAMAR_TEST_MAX_CELLS: a test hook that sends ordinary read pairs through the wide kernel) */
+{ static u32 m = 0;
+  if (m == 0)
+    { const char *e = getenv("DAMAR_TEST_MAX_CELLS");
+      m = (e && atoi(e) >= 64) ? std::min<u32>((u32) atoi(e), DAMAR_MAX_CELLS) : DAMAR_MAX_CELLS;
+    }
+  return m;
+}
+
 static u32 grow_cells(u32 cell_cap)
-{ if (cell_cap >= DAMAR_MAX_CELLS)
-    { fprintf(stderr, "damar: FATAL: an alignment needs more than %u trace pebbles; use a larger trace spacing (-s)\n", DAMAR_MAX_CELLS);
+{ if (cell_cap >= max_cells())
+    { fprintf(stderr, "damar: FATAL: an alignment needs more than %u trace pebbles; use a larger trace spacing (-s)\n", max_cells());
       die();
     }
-  return std::min(cell_cap * 4, DAMAR_MAX_CELLS);
+  return std::min(cell_cap * 4, max_cells());
 }
 
 /* datander and the Local_Alignment batch entry have no wide kernel behind them: there the packed format's limit stays loud */
@@ -1202,6 +1211,7 @@ static void fill_report_args(ReportArgs *ra, const damar_dev_block *ab, const da
   ra->recs = RS.recs;  ra->rec_cap = RS.rec_cap;
   ra->tpool = RS.tpool;  ra->tpool_cap = RS.tpool_cap;
   ra->t8 = 0;                                   /* (the pipeline's launches set it: report_launch) */
+  ra->widemap = NULL;  ra->wcells = NULL;  ra->wcell_cap = 0;  ra->cell_max = DAMAR_MAX_CELLS;
   { static int lim = -1;                        /* test hook: a lower limit makes the 16-bit re-launch happen (tests/test_gpu_configs.py) */
     if (lim < 0)
       lim = getenv("DAMAR_TEST_T8_LIMIT") ? atoi(getenv("DAMAR_TEST_T8_LIMIT")) : 255;
@@ -2205,7 +2215,7 @@ static void report_launch(Pending &pd)
       ra[j].pbits = pd.fr[j].pbits;  ra[j].abits = pd.fr[j].abits;  ra[j].dbits = pd.fr[j].dbits;
       ra[j].order = pd.fr[j].order;
       ra[j].t8 = pd.t8;
-      ra[j].widemap = NULL;  ra[j].wcells = RS.wcells;  ra[j].wcell_cap = RS.wcell_cap;
+      ra[j].widemap = NULL;  ra[j].wcells = RS.wcells;  ra[j].wcell_cap = RS.wcell_cap;  ra[j].cell_max = max_cells();
       packed = packed && use_packed(&ra[j], pd.amax, pd.bmax);
       if (ra[j].mscore != ra[0].mscore || ra[j].dscore != ra[0].dscore)
         { fprintf(stderr, "damar: internal error, the comparisons of one report launch differ in their -e\n");
@@ -2281,7 +2291,7 @@ static void report_finish(Pending &pd)
          the launch that is otherwise complete.  Until round 5 both were fatal. */
       if (pd.wide_ok && !pd.wide_done && hc[DAMAR_CNT_WIDE] > 0)
         { u32 flags = hc[3];
-          if (pd.cell_cap >= DAMAR_MAX_CELLS)
+          if (pd.cell_cap >= max_cells())
             flags &= ~DAMAR_ERR_CELLS;                         /* (those pairs are in the map: nothing to repeat for them) */
           if (flags == 0)
             { if (RS.wcells == NULL)
@@ -2317,7 +2327,7 @@ static void report_finish(Pending &pd)
           hc[3] &= ~DAMAR_ERR_CELLS;
           hc[3] |= 0x40000000u;                                /* (something to repeat the launch for) */
         }
-      else if (pd.wide_ok && pd.cell_cap >= DAMAR_MAX_CELLS && hc[DAMAR_CNT_WIDE] > 0)
+      else if (pd.wide_ok && pd.cell_cap >= max_cells() && hc[DAMAR_CNT_WIDE] > 0)
         hc[3] &= ~DAMAR_ERR_CELLS;                             /* the packed kernel's overflows at 2^18 are the wide kernel's pairs */
       if (hc[3] == 0)
         break;
@@ -2586,7 +2596,7 @@ static void flush_accum(void)
     }
   const u32 rec_have = RS.rec_cap_set[pd.oset], tp_have = RS.tpool_cap_set[pd.oset];     /* (of ITS set: asking one set for the
                                                                                              other's size plus headroom would grow both for ever) */
-  pd.cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
+  pd.cell_cap = std::min<u32>(RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS, max_cells());
   pd.rec_cap  = (u32) std::min<u64>(0x7fffffffu, std::max<u64>(rec_have, 2 * AC.nwork + 4096));
   pd.tp_cap   = (u32) std::min<u64>(0xe0000000ull, std::max<u64>(tp_have, (u64) pd.rec_cap * 256u));
   { /* trace values as bytes off the device (align.c:3375-3396 Compress_TraceTo8, K8 of SURVEY 8a19) when every comparison

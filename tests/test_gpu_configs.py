@@ -221,7 +221,8 @@ def test_gpu_cli_plan_mode_equals_reference_golden(gpu, tmp_path, name, front, c
                                        {"DAMAR_LAUNCH_QUEUE": "2", "DAMAR_TEST_SMALL_CAPS": "1", "DAMAR_BATCH": "2"},
                                        {"DAMAR_SEED_PRIO": "0"}, {"DAMAR_SEED_PRIO": "7", "DAMAR_BATCH_WORK": "1"},
                                        {"DAMAR_DB_UNPACKED": "1"}, {"DAMAR_PLAN_TIDY": "1", "DAMAR_PLAN_RELEASE": "1"},
-                                       {"DAMAR_DEVICE_T8": "0"}, {"DAMAR_TEST_T8_LIMIT": "40", "DAMAR_BATCH": "2"}])
+                                       {"DAMAR_DEVICE_T8": "0"}, {"DAMAR_TEST_T8_LIMIT": "40", "DAMAR_BATCH": "2"},
+                                       {"DAMAR_TEST_MAX_CELLS": "512"}, {"DAMAR_TEST_MAX_CELLS": "1024", "DAMAR_BATCH": "1", "DAMAR_DEVICE_T8": "0"}])
 @pytest.mark.parametrize("name", ["tiny2", "prod"])
 def test_gpu_cli_plan_mode_other_launch_shapes_equal_reference_golden(gpu, tmp_path, name, env_extra):
     """The switches that change how the work reaches the report kernel -- the early cut of the seed pairs, the number of
@@ -231,7 +232,8 @@ def test_gpu_cli_plan_mode_other_launch_shapes_equal_reference_golden(gpu, tmp_p
     unpacked and complemented on the host instead of kept packed and unpacked by the GPU (the default since round 5),
     one process that releases everything itself, trace values compressed to bytes by the host instead of by the report
     kernel, and a byte limit so low that every launch is repeated with 16-bit values (what a value above 255 does) --
-    must not change a byte of the output."""
+    a pebble pool so small that most read pairs overflow it and are done again by the wide kernel (16-byte pebbles; what a
+    pair beyond 2^18 pebbles a direction does) -- must not change a byte of the output."""
     import subprocess
     from conftest import read_case, link_db, compare_las
     from damar_amd import api
@@ -241,9 +243,11 @@ def test_gpu_cli_plan_mode_other_launch_shapes_equal_reference_golden(gpu, tmp_p
     with open(os.path.join(work, "plan.txt"), "w") as f:
         for a, bs in case["lines"]:
             f.write("daligner %s G.%s %s\n" % (" ".join(case["opts"]), a, " ".join("G." + b for b in bs)))
-    subprocess.run([api.daligner_binary(), "-P", "plan.txt"], cwd=work, check=True, env=dict(os.environ, **env_extra),
-                   stdout=subprocess.DEVNULL)
+    r = subprocess.run([api.daligner_binary(), "-v", "-P", "plan.txt"], cwd=work, check=True, env=dict(os.environ, **env_extra),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
     assert compare_las(case, work) == []
+    if "DAMAR_TEST_MAX_CELLS" in env_extra and name == "tiny2":
+        assert "wide kernel" in r.stderr                 # (the hook really sent pairs that way: 10 kb reads drop ~2 500 pebbles a direction)
 
 
 @pytest.mark.parametrize("async_tail", [False, True])
