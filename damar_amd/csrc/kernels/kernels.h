@@ -232,7 +232,8 @@ typedef struct
 #define DAMAR_ERR_WIDE   16u    /* a band outgrew the ring of diagonals of the slot buffers: relaunch with a larger ring */
 
 int  damar_report_waves_per_simd(void);
-int  damar_report2_waves_per_simd(void);     /* two scratch slots per wavefront */
+int  damar_report2_waves_per_simd(void);
+int  damar_report2_slots_per_wave(void);     /* scratch slots (read pairs in flight) per wavefront of the packed kernel */
 void damar_launch_report(const ReportArgs *jobs, int njobs, int nslots, hipStream_t st);
 void damar_launch_report_wide(const ReportArgs *jobs, int njobs, int nslots, hipStream_t st);
 /* datander report: one work item per read of a.ablk, dist as produced by damar_launch_tandem_links */
@@ -241,10 +242,12 @@ void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots
 /* batch Local_Alignment for tests: task i = (aread, bread, diag, anti) */
 typedef struct { int aread, bread, diag, anti; } LaTask;
 void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
-/* two read pairs (or batch tasks, tasks != NULL) per wavefront: report_packed.h; nslots must be even */
+/* several read pairs (or batch tasks, tasks != NULL) per wavefront: report_packed.h; nslots a multiple of damar_report2_slots_per_wave() */
 void damar_launch_report2(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
 void damar_launch_tandem_report2(const ReportArgs *a, const int *dist, int nslots, hipStream_t st);     /* datander through the same kernel */
 #define DAMAR_MAX_MARKS 16000         /* trace-grid indexes ride in the top 14 bits of a chain head (report.hip PK_HBITS) */
+#define DAMAR_MAX_ANTI  (1 << 26)     /* alen + blen of a pair of the slot kernel (the experiment kernels/report_slots.h, -DDAMAR_SLOT_KERNEL): its wave
+                                         loop lifts the anti-diagonals of a segment of lanes by its first lane x 2^25, segments at least 7 lanes apart */
 #define DAMAR_MAX_CELLS (1u << 18)    /* pebbles per slot: 18 bits of a chain head */
 
 u64 damar_report_state_stride(int span);

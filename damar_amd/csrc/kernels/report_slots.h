@@ -1,13 +1,22 @@
-/* report_packed.h -- the report loop with TWO read pairs per wavefront whose halves run INDEPENDENTLY (included by report.hip).
+/* report_slots.h -- EXPERIMENT of round 5 (built with -DDAMAR_SLOT_KERNEL instead of report_packed.h; scripts/build_exp.sh):
+ * the report loop with SEVERAL read pairs per wavefront that run INDEPENDENTLY, lanes dealt out by band width.
+ * Result (profiles/r05_slots.txt): identical .las; 30 % fewer wave-loop iterations, 3 % less time.
  *
- * Why two: the live band of a Local_Alignment wave is 12 diagonals wide on average and 99.9 % of the wave steps fit 30
- * lanes (band histogram of the oracle, profiles/), so one alignment per 64-lane wavefront leaves five lanes in six idle.
- * Each 32-lane half of a wavefront owns a read pair; everything that is uniform per alignment lives in VGPRs (the same
- * value in the 32 lanes of a half) or, as a predicate, in a 64-bit lane mask on the scalar side.
- * Why independently: rounds 2-3 ran the two halves through the same direction of Local_Alignment at the same time (the
- * direction was a template parameter of the wave loop), so a round cost max(f1, f2) + max(r1, r2) wave steps and 1.58 of
- * the 2 halves stepped per iteration (now 1.97).  Here the direction of a half is a run-time value and the wave loop is
- * written ONCE, in coordinates in which both directions look the same:
+ * Why several: the live band of a Local_Alignment wave is 12 diagonals wide on average (band histogram of the oracle,
+ * profiles/r05_bandhist.txt), so one alignment per 64-lane wavefront leaves five lanes in six idle, and two alignments in
+ * fixed halves of 32 lanes (rounds 2-5) still leave five in eight idle.  A wavefront holds DUO_NS SLOTS; a slot owns a
+ * read pair: its seed scan, its Local_Alignment calls one after the other, its scratch (buckets, pebbles, traces).
+ * Two lane layouts:
+ *   - outside the wave loop a slot owns DUO_L = 64 / DUO_NS fixed lanes: everything that is uniform per alignment lives in
+ *     VGPRs (the same value in the lanes of a slot) or, as a predicate, in a 64-bit lane mask on the scalar side;
+ *   - inside the wave loop (duo_loop) the 64 lanes are dealt out anew every time the loop is entered: a slot that can
+ *     step gets a SEGMENT of lanes as wide as its band plus room to grow (the band state travels through LDS), so the
+ *     lanes a narrow band does not need serve another alignment.  A segment that becomes too tight is an event like any
+ *     other: the loop is left, the lanes are dealt out again.
+ * Why independently: rounds 2-3 ran the alignments of a wavefront through the same direction of Local_Alignment at the
+ * same time (the direction was a template parameter of the wave loop), so a round cost max(f1, f2) + max(r1, r2) wave
+ * steps.  Here the direction of a slot is a run-time value and the wave loop is written ONCE, in coordinates in which both
+ * directions look the same:
  *
  *     sigma = +1 forward, -1 reverse (kept as the xor mask m = 0 / -1: sigma * x == (x ^ m) - m)
  *     K = sigma * k,  V = sigma * v,  X = sigma * x,  Y = sigma * y            (k = x - y diagonal, v = x + y anti-diagonal)
@@ -19,34 +28,46 @@
  * a[X ^ m], b[Y ^ m] (the reverse wave compares a[x-1], b[y-1]) -- read 16 at a time off the 2-bit packed bases, a
  * reverse pass off their REVERSED copy (DevBlock.rbias), so that its windows ascend like a forward pass's -- and the
  * trace grid is indexed by G = sigma * (grid index) (+ 2^14 for m = -1, so that it stays positive).
- * So a half steps through whatever it has to do next -- forward pass, trace walk, reverse pass, emission, seed scan --
- * while the other half does the same on its own: the wave loop is left when EITHER half has an event, the event is
- * served (only that half's lanes are live), and the loop is entered again.
+ * So a slot steps through whatever it has to do next -- forward pass, trace walk, reverse pass, emission, seed scan --
+ * while the others do the same on their own: the wave loop is left when ANY slot has an event, the event is served
+ * (only that slot's lanes are live), and the loop is entered again.
  *
- * What else keeps the wave step short (158 vector instructions per step of two halves, 266 in round 3):
+ * What else keeps the wave step short:
  *   - the next trace marks NA/NB of a diagonal (align.c:861-909) are not carried at all: at every use NA[k] is at most one
  *     spacing beyond the mark of the inherited chain head (the predecessor's x is never behind the diagonal's own last
  *     x, and a new edge diagonal inherits its neighbour's NA), so "push every mark in (head mark, x]" is what the
  *     reference's loop does; the head's mark rides in the head word as before.  Checked with an assertion in a copy of
  *     the oracle over config 1 (31 262 records, several trace spacings) and eleven golden cases: no violation;
- *   - the band is kept in LANE coordinates (ls..hs = lanes of the highest..lowest K) so that widening, pruning, clipping
- *     and the recentring test need no conversion; lanes outside the band always hold V = EDGE (re-established after the
- *     pruning of every step), so the neighbours read by DPP need no range tests; the band plus the two lanes it may grow
- *     into stays within lanes 1..30, which keeps the two halves' DPP rotations apart;
+ *   - the band is kept in LANE coordinates (ls..hs = lanes of the highest..lowest K, counted from the segment's first
+ *     lane) so that widening, pruning, clipping and the recentring test need no conversion; lanes outside the band always
+ *     hold V = EDGE (re-established after the pruning of every step), so the neighbours read by DPP need no range tests;
+ *     the band plus the two lanes it may grow into stays off the first and the last lane of its segment, which keeps
+ *     neighbouring segments apart;
  *   - T, HA, HB are committed unconditionally (a lane outside the band is never anybody's predecessor).
- *   - new best / last / trim point (align.c:911-928) by a prefix maximum in sweep order instead of a serial replay;
- *     TABLE/SCORE (2 x 64 KB in HBM) are replaced by one 1 KB table in LDS (pk_trim_ok, report.hip);
+ *   - new best / last / trim point (align.c:911-928) by a prefix maximum in sweep order instead of a serial replay -- ONE
+ *     prefix maximum over the 64 lanes serves all segments: a segment's values are lifted above those of the segments
+ *     before it; TABLE/SCORE (2 x 64 KB in HBM) are replaced by one 1 KB table in LDS (pk_trim_ok, report.hip);
  *   - the popcount M of the match history is not carried: M == popcount(T & (2^61 - 1)) at all times.
  * A band that needs more than 30 lanes borrows the whole wavefront (duo_solo) and comes back when it is narrow again.
  * Reference semantics and citations are those of report.hip: dalign/filter.c:2128-2432 report_thread,
  * dalign/align.c:409-1122 forward_wave, :1126-1898 reverse_wave, :1904-2097 Local_Alignment.
  */
 
+#ifndef DUO_NS
+#define DUO_NS 4                                /* read pairs (slots) per wavefront: 2 or 4 */
+#endif
+#define DUO_L     (64 / DUO_NS)                 /* lanes of a slot outside the wave loop */
+#define DUO_LMASK ((u32) ((1ull << DUO_L) - 1ull))
+#define DUO_LSH   (DUO_NS == 4 ? 4 : 5)         /* lane >> DUO_LSH = slot (outside the wave loop) */
+#define DUO_BW    32                            /* the widest segment of lanes a slot may get in the wave loop */
+static_assert(DUO_NS == 2 || DUO_NS == 4, "slots per wavefront");
+int damar_report2_slots_per_wave(void) { return DUO_NS; }
+
 #ifndef DUO_WAVES
 #define DUO_WAVES 8        /* resident wavefronts per SIMD the kernel and its pieces are compiled for (VGPR budget 512 / DUO_WAVES; the
                               launch bound of the kernel is handed down to the functions it calls): the wave loop fits 64 VGPRs
-                              without a spill.  Report ms per config-2 step, every kernel alone on the machine: 180 / 167 / 153 at
-                              5 / 6 / 8 wavefronts per SIMD (profiles/r04_sweeps.txt) */
+                              without a spill in its steps.  Report ms per config-2 step, every kernel alone on the machine:
+                              180 / 167 / 153 at 5 / 6 / 8 wavefronts per SIMD (profiles/r04_sweeps.txt) */
 #endif
 
 /* experiment switches (scripts/build_exp.sh; results are WRONG with any of them -- they only price one part of the kernel):
@@ -61,21 +82,21 @@
 #define DUO_EXP_PEBBLE(x) x
 #endif
 int damar_report2_waves_per_simd(void) { return DUO_WAVES; }
-int damar_report2_slots_per_wave(void) { return 2; }      /* (kernels/report_slots.h: the experiment with four) */
 
-__device__ __forceinline__ u32 hmask(u64 m, int hb) { return (u32) (m >> hb); }           /* this half's 32 bits */
+__device__ __forceinline__ u32 hmask(u64 m, int hb) { return (u32) (m >> hb) & DUO_LMASK; }     /* this slot's DUO_L bits (outside the wave loop) */
 __device__ __forceinline__ int hget(int v, int hb, int s) { return __builtin_amdgcn_ds_bpermute((hb + s) << 2, v); }
-/* Inclusive prefix maximum in lane order inside each 32-lane half: Kogge-Stone inside the rows of 16 by DPP row_shr,
-   then the last lane of rows 0 / 2 into rows 1 / 3.  In place: a lane whose DPP source does not exist is simply not written
-   (bound_ctrl off), which is the identity here -- one instruction per step instead of the mov-identity / mov_dpp / max
-   triple the update_dpp builtin compiles to.  (s_nop 1: a DPP operand needs two wait states after the VALU write of its
-   register, and the assembler does not add them inside inline asm.) */
+/* Inclusive prefix maximum in lane order over the 64 lanes: Kogge-Stone inside the rows of 16 by DPP row_shr, then the last
+   lane of rows 0 / 2 into rows 1 / 3 and the last lane of row 1 into rows 2 / 3.  In place: a lane whose DPP source does not
+   exist is simply not written (bound_ctrl off), which is the identity here -- one instruction per step instead of the
+   mov-identity / mov_dpp / max triple the update_dpp builtin compiles to.  (s_nop 1: a DPP operand needs two wait states
+   after the VALU write of its register, and the assembler does not add them inside inline asm.) */
 __device__ __forceinline__ int pk_prefix_max(int x)
 { asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
       "s_nop 1" : "+v"(x));
   return x;
 }
@@ -89,10 +110,10 @@ __device__ __forceinline__ int pk_prefix_max(int x)
 
 enum { MD_SCAN = 0, MD_TASK, MD_RUN, MD_END, MD_OVF, MD_DONE };
 
-/* per-half event record in LDS (in the loop's coordinates): what a direction touches only
+/* per-slot event record in LDS (in the loop's coordinates): what a direction touches only
    at events.  tip = a (V of the point), k (its K), d, ha, hb */
 enum { DC_REACHM = 0, DC_ACLIP, DC_BCLIP, DC_TRIM, DC_REACH = DC_TRIM + 5, DC_WORDS = 16 };
-__shared__ int duo_cold[2 * DC_WORDS];
+__shared__ int duo_cold[DUO_NS * DC_WORDS];
 
 /* Lane predicates are kept as 64-bit lane masks in scalar registers: a ballot of ONE comparison is the comparison
    itself (v_cmp writes the mask), masks combine on the scalar unit, a branch on "any lane" is s_cmp of the mask, and
@@ -105,50 +126,69 @@ __device__ __forceinline__ bool inv(u64 m)  { return __builtin_amdgcn_inverse_ba
 __device__ __forceinline__ int ffbh_raw(u32 x) { int r;  asm("v_ffbh_u32_e32 %0, %1" : "=v"(r) : "v"(x));  return r; }
 __device__ __forceinline__ int ffbl_raw(u32 x) { int r;  asm("v_ffbl_b32_e32 %0, %1" : "=v"(r) : "v"(x));  return r; }
 
-/* Everything a half carries between the pieces below (noinline functions with their own register allocation) lives in
-   LDS: one record per half (every lane of the half reads and writes the same words: broadcast reads, one write) and the
-   band state of the 64 lanes.  (Round 4's first version kept it in a struct in private memory handed to the pieces by
+/* Everything a slot carries between the pieces below (noinline functions with their own register allocation) lives in
+   LDS: one record per slot (every lane of the slot reads and writes the same words: broadcast reads, one write) and the
+   band state of the slot: DUO_BW entries, entry e = the diagonal K = kbase - e, whichever lanes hold it in the wave loop.  (Round 4's first version kept it in a struct in private memory handed to the pieces by
    pointer: 6 M piece calls per config-2 step, each loading and storing ~11 KB of scratch per wavefront, were most of the
    20 GB per launch the report kernel moved through L2 -- profiles/r04_traffic_summary.txt.) */
-struct DuoCtx
-{ int md;
+struct __attribute__((aligned(16))) DuoCtx
+{ int pa0, pb0, alen, blen;                     /* FIRST, 16-byte aligned: the wave loop reads the four with one ds_read_b128 per step (duo_loop).
+                                                   pa0, pb0: where the pass's packed bases start (window of (X, Y) at pa0 + X, pb0 + Y); alen, blen: the reads' lengths */
+  int md;
   int m;                                        /* direction: 0 forward, -1 reverse */
   int ls, hs, kbase;                            /* band = lanes ls..hs (highest..lowest K) */
   int dif, besta, bestk, lasta, more, ncell, bad;
   int mlo, mhi;                                 /* the band may not grow below lane mlo / above lane mhi (minp, maxp) */
   int alim, blim;                               /* bases left: alim - X in A, blim - Y in B */
   int offa, offb;                               /* the mark after head index G is crossed when X >= G * TS + offa */
-  int va0, vb0, alen, blen;                     /* the reads: offsets in the packed bases (biased by the padding), lengths */
-  int pa0, pb0;                                 /* where the pass's packed bases start: window of (X, Y) at pa0 + X, pb0 + Y */
+  int va0, vb0;                                 /* the reads: offsets in the packed bases (biased by the padding) */
   /* the task and what its passes have produced */
   int diag, anti;
-  u32 item;                                     /* the work item (read pair) of the half: named when its pebbles outgrow the packed format */
+  u32 item;                                     /* the work item (read pair) of the slot: named when its pebbles outgrow the packed format */
   int roota, rootb;                             /* trace-grid index the A / B chain of the pass starts from (its root) */
   int aepos, bepos, abpos, bbpos, diffs, atlen, btlen, aback, bback;
   /* what the wavefront has stepped through so far (the same in every lane): SURVEY 8(d)'s secondary unit of K6 */
   u32 n_cells_lo, n_cells_hi;                   /* band cells = diagonals computed, summed over the wave steps */
-  u32 n_iter, n_half;                           /* iterations of the wave loop, and halves that stepped in them (counted by half 0's record) */
+  u32 n_iter, n_half;                           /* iterations of the wave loop, and slots that stepped in them (counted by slot 0's record) */
+  u32 n_deal;                                   /* times the lanes were dealt out (slot 0's record) */
 };
-__shared__ DuoCtx duo_half[2];
-/* band state of the lanes: lane s of a half owns K = kbase - s */
-__shared__ int duo_V[64], duo_HA[64], duo_HB[64], duo_acc[64];
-__shared__ u32 duo_Tlo[64], duo_Thi[64];
-#define DUO_CX()  DuoCtx &cx = duo_half[lane_id() >> 5]
+__shared__ DuoCtx duo_half[DUO_NS];
+/* band state of the slots: entry e of slot q (at q * DUO_BW + e) is the diagonal K = kbase - e */
+__shared__ int duo_V[DUO_NS * DUO_BW], duo_HA[DUO_NS * DUO_BW], duo_HB[DUO_NS * DUO_BW], duo_acc[64];
+__shared__ u32 duo_Tlo[DUO_NS * DUO_BW], duo_Thi[DUO_NS * DUO_BW];
+#define DUO_CX()  DuoCtx &cx = duo_half[lane_id() >> DUO_LSH]
 
 struct DuoSnake { int Y, na, nb;  u64 b; };
+/* a word of a slot's record read where it is used: not hoisted out of the wave loop into a register (the pointer goes
+   through an opaque asm, as an LDS pointer so that the read stays a ds_read) */
+typedef __attribute__((address_space(3))) const int duo_lds_cint;
+__device__ __forceinline__ int duo_cold_read(const int *g)
+{ duo_lds_cint *p = (duo_lds_cint *) g;
+  asm volatile("" : "+v"(p));
+  return *p;
+}
+#define DUO_COLD_READ(x) duo_cold_read(&(x))
+typedef int DuoQuad __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ DuoQuad duo_quad_read(const int *g)         /* four words of a slot's record with one ds_read_b128, where they are used */
+{ typedef __attribute__((address_space(3))) const DuoQuad lds_quad;
+  lds_quad *p = (lds_quad *) g;
+  asm volatile("" : "+v"(p));
+  return *p;
+}
 
 /* The snake (align.c:832-856 / 1542-1566) of diagonal K from Y, in the loop's coordinates: 16 bases per step off the
    2-bit packed reads -- forward off the packed bases, reverse off their REVERSED copy (DevBlock.rbias), so that both
    slide along ascending addresses: the window starts at biased position pa0 + X / pb0 + Y -- bounded by the bases left
    in either read; a lane that is past an end takes the byte path, which reads what the reference reads there. */
-__device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, const u8 *abase, const u8 *bbase,
-                                              int m, int alim, int blim, int pa0, int pb0, int va0, int vb0, int alen, int blen,
+__device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, const u8 *abase, const u8 *bbase, const DuoCtx &cx,
+                                              int m, int alim, int blim, int pa0, int pb0, int alen, int blen,
                                               int K, int Y, u64 b)
 { DuoSnake o;
   const int X = Y + K;
   int na = alim - X, nb = blim - Y;
   if ((u32) na > (u32) alen || (u32) nb > (u32) blen)
     { const int k = (K ^ m) - m, y = (Y ^ m) - m;
+      const int va0 = DUO_COLD_READ(cx.va0), vb0 = DUO_COLD_READ(cx.vb0);      /* (rarely needed: not kept in registers across the wave loop) */
       const u8 *ar = abase + (va0 - 16 * PK_PAD), *br = bbase + (vb0 - 16 * PK_PAD);
       SnakeOut so;
       if (m)
@@ -182,12 +222,12 @@ __device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, co
   return o;
 }
 
-/* An alignment of the half has been abandoned because its pebbles do not fit the pool.  While the pool can still grow the
+/* An alignment of the slot has been abandoned because its pebbles do not fit the pool.  While the pool can still grow the
    launch is repeated with a larger one (DAMAR_ERR_CELLS); at the packed format's limit of 2^18 the read pair is left to the
    wide kernel (report.hip: report_wide_kernel) -- its bit in widemap, one count per pair -- and what this kernel has
-   written or will still write for the pair is dropped by the host.  Called by every lane of the half. */
+   written or will still write for the pair is dropped by the host.  Called by every lane of the slot. */
 __device__ __forceinline__ void duo_pebbles_over(const ReportArgs &a, u32 item)
-{ if ((lane_id() & 31) != 0)
+{ if ((lane_id() & (DUO_L - 1)) != 0)
     return;
   atomicOr(&a.counters[3], DAMAR_ERR_CELLS);
   if (a.widemap != NULL && a.cell_cap >= a.cell_max)
@@ -197,62 +237,67 @@ __device__ __forceinline__ void duo_pebbles_over(const ReportArgs &a, u32 item)
     }
 }
 
-/* clipping at sequence ends (align.c:628-658 / 943-975) for the halves with `on`, in lane coordinates: the A-side clip
-   lane (the highest sweep index that reached A's end) cuts the band's low lanes, the B-side one its high lanes */
-#define DUO_CLIP()                                                                                     \
+/* clipping at sequence ends (align.c:628-658 / 943-975) for the slots with `on`, in lane coordinates: the A-side clip
+   lane (the highest sweep index that reached A's end) cuts the band's low lanes, the B-side one its high lanes; LB = the
+   wavefront lane that holds the slot's entry 0 */
+#define DUO_CLIP(LB, COLD)                                                                              \
   if (onm & bal(more == 0))                                                                            \
-    { const bool cl_ = on && more == 0;                                                                \
+    { int *const cold_ = (COLD);                                                                       \
+      const bool cl_ = on && more == 0;                                                                \
       const int  mp_ = pk_popc61(rT);                                                                  \
       if (cl_)                                                                                         \
         { const int by_ = (besta - bestk) >> 1, bx_ = besta - by_;                                     \
-          if (bbase[(vb0 - 16 * PK_PAD) + (by_ ^ m)] != 4 && abase[(va0 - 16 * PK_PAD) + (bx_ ^ m)] != 4) \
+          if (bbase[(DUO_COLD_READ(cx.vb0) - 16 * PK_PAD) + (by_ ^ m)] != 4 &&                          \
+              abase[(DUO_COLD_READ(cx.va0) - 16 * PK_PAD) + (bx_ ^ m)] != 4)                           \
             more = 1;                                                                                  \
         }                                                                                              \
-      const int acl_ = cold[DC_ACLIP], bcl_ = cold[DC_BCLIP];                                          \
+      const int acl_ = cold_[DC_ACLIP], bcl_ = cold_[DC_BCLIP];                                          \
       { const bool ca_ = cl_ && ls <= acl_;                                                            \
         const int  sl_ = ca_ ? acl_ : 0;                                                               \
-        const int  mm_ = hget(mp_, hb, sl_), vv_ = hget(rV, hb, sl_);                                  \
-        const int  ha_ = hget(rHA, hb, sl_), hb2_ = hget(rHB, hb, sl_);                                \
+        const int  mm_ = hget(mp_, LB, sl_), vv_ = hget(rV, LB, sl_);                                  \
+        const int  ha_ = hget(rHA, LB, sl_), hb2_ = hget(rHB, LB, sl_);                                \
         if (ca_)                                                                                       \
           { ls = acl_ + 1;                                                                             \
-            if (cold[DC_REACHM] <= mm_)                                                                \
-              { cold[DC_REACHM] = mm_;  cold[DC_REACH] = vv_;  cold[DC_REACH + 1] = kbase - acl_;      \
-                cold[DC_REACH + 2] = dif;                                                              \
-                cold[DC_REACH + 3] = ha_ & PK_HMASK;  cold[DC_REACH + 4] = hb2_ & PK_HMASK; }          \
+            if (cold_[DC_REACHM] <= mm_)                                                                \
+              { cold_[DC_REACHM] = mm_;  cold_[DC_REACH] = vv_;  cold_[DC_REACH + 1] = kbase - acl_;      \
+                cold_[DC_REACH + 2] = dif;                                                              \
+                cold_[DC_REACH + 3] = ha_ & PK_HMASK;  cold_[DC_REACH + 4] = hb2_ & PK_HMASK; }          \
           }                                                                                            \
       }                                                                                                \
       { const bool cb_ = cl_ && hs >= bcl_;                                                            \
         const int  sl_ = cb_ ? bcl_ : 0;                                                               \
-        const int  mm_ = hget(mp_, hb, sl_), vv_ = hget(rV, hb, sl_);                                  \
-        const int  ha_ = hget(rHA, hb, sl_), hb2_ = hget(rHB, hb, sl_);                                \
+        const int  mm_ = hget(mp_, LB, sl_), vv_ = hget(rV, LB, sl_);                                  \
+        const int  ha_ = hget(rHA, LB, sl_), hb2_ = hget(rHB, LB, sl_);                                \
         if (cb_)                                                                                       \
           { hs = bcl_ - 1;                                                                             \
-            if (cold[DC_REACHM] <= mm_)                                                                \
-              { cold[DC_REACHM] = mm_;  cold[DC_REACH] = vv_;  cold[DC_REACH + 1] = kbase - bcl_;      \
-                cold[DC_REACH + 2] = dif;                                                              \
-                cold[DC_REACH + 3] = ha_ & PK_HMASK;  cold[DC_REACH + 4] = hb2_ & PK_HMASK; }          \
+            if (cold_[DC_REACHM] <= mm_)                                                                \
+              { cold_[DC_REACHM] = mm_;  cold_[DC_REACH] = vv_;  cold_[DC_REACH + 1] = kbase - bcl_;      \
+                cold_[DC_REACH + 2] = dif;                                                              \
+                cold_[DC_REACH + 3] = ha_ & PK_HMASK;  cold_[DC_REACH + 4] = hb2_ & PK_HMASK; }          \
           }                                                                                            \
       }                                                                                                \
       if (cl_)                                                                                         \
-        { cold[DC_ACLIP] = -1;  cold[DC_BCLIP] = 64; }                                                 \
+        { cold_[DC_ACLIP] = -1;  cold_[DC_BCLIP] = 64; }                                                 \
     }
 
-/* the names the pieces use for a job's constants */
-#define DUO_NAMES()                                                                                  \
+/* the names the pieces use for a job's constants, and for the lanes of a slot outside the wave loop */
+#define DUO_JOBC()                                                                                   \
   const ReportArgs &a = g_jobs[uni(job)];                                                            \
-  const int lane = lane_id(), hb = lane & 32, s = lane & 31;                                         \
   const int TS = uni(a.tspace);                                                                      \
   const u32 *apk = uni_ptr(a.ablk.pk), *bpk = uni_ptr(a.bblk.pk);                                    \
   const u8 *abase = uni_ptr(a.ablk.bases), *bbase = uni_ptr(a.bblk.bases);                           \
   GLOBAL_AS v2u32 *const gcell = (GLOBAL_AS v2u32 *) uni_ptr((Cell *) a.cells);                      \
   const int cell_cap = (int) uni((int) a.cell_cap);                                                  \
   u32 *const errw = uni_ptr(&a.counters[3]);                                                         \
-  int *const cold = duo_cold + (hb >> 1);                                                            \
-  (void) lane; (void) hb; (void) s; (void) TS; (void) apk; (void) bpk; (void) abase; (void) bbase;   \
-  (void) gcell; (void) cell_cap; (void) errw; (void) cold;
+  (void) TS; (void) apk; (void) bpk; (void) abase; (void) bbase; (void) gcell; (void) cell_cap; (void) errw;
+#define DUO_NAMES()                                                                                  \
+  DUO_JOBC()                                                                                         \
+  const int lane = lane_id(), hb = lane & ~(DUO_L - 1), s = lane & (DUO_L - 1);                      \
+  int *const cold = duo_cold + (lane >> DUO_LSH) * DC_WORDS;                                         \
+  (void) lane; (void) hb; (void) s; (void) cold;
 
-/* Wave 0 on the seed diagonal (align.c:491-626 / 1203-1340) and the clipping behind it, for the halves with
-   md == MD_TASK: sets up direction cx.m of the task (cx.diag, cx.anti).  Every lane of a half computes the same. */
+/* Wave 0 on the seed diagonal (align.c:491-626 / 1203-1340) and the clipping behind it, for the slots with
+   md == MD_TASK: sets up direction cx.m of the task (cx.diag, cx.anti).  Every lane of a slot computes the same. */
 DUO_PART void duo_begin(int job, u32 cbase)
 { DUO_NAMES()
   DUO_CX();
@@ -307,7 +352,7 @@ DUO_PART void duo_begin(int job, u32 cbase)
         mlo = kbase - maxK;  mhi = kbase - minK;
       }
       cold[DC_REACHM] = -1;  cold[DC_ACLIP] = -1;  cold[DC_BCLIP] = 64;
-      { const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, pa0, pb0, va0, vb0, alen, blen, K0, Y, 0ull);
+      { const DuoSnake so = duo_snake(apk, bpk, abase, bbase, cx, m, alim, blim, pa0, pb0, alen, blen, K0, Y, 0ull);
         Y = so.Y;
         if (so.nb == 0)      { more = 0;  cold[DC_BCLIP] = 15; }
         else if (so.na == 0) { more = 0;  cold[DC_ACLIP] = 15; }
@@ -339,8 +384,7 @@ DUO_PART void duo_begin(int job, u32 cbase)
         { besta = lasta = v;
           cold[DC_TRIM] = v;  cold[DC_TRIM + 3] = ha;  cold[DC_TRIM + 4] = hb_;
         }
-      if (s == 15)
-        rV = v;
+      rV = v;                                    /* (every lane of the slot: the band is the one entry 15) */
       rT = HIST_FULL;
       rHA = ha | (ga << PK_HBITS);  rHB = hb_ | (gb << PK_HBITS);
       md = MD_RUN;
@@ -349,9 +393,13 @@ DUO_PART void duo_begin(int job, u32 cbase)
           more = 0;  ncell = 2;  bad = 1;  md = MD_END;
         }
     }
-  DUO_CLIP()
+  DUO_CLIP(hb, cold)
   if (on)
-    { duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
+    { for (int e = s; e < DUO_BW; e += DUO_L)
+        { const int at = (lane >> DUO_LSH) * DUO_BW + e;
+          duo_V[at] = (e == 15) ? rV : DUO_EDGE;  duo_HA[at] = rHA;  duo_HB[at] = rHB;
+          duo_Tlo[at] = (u32) rT;  duo_Thi[at] = (u32) (rT >> 32);
+        }
       cx.md = md;
       cx.ls = ls;  cx.hs = hs;  cx.kbase = kbase;  cx.dif = dif;  cx.besta = besta;  cx.bestk = bestk;
       cx.lasta = lasta;  cx.more = more;  cx.ncell = ncell;  cx.bad = bad;
@@ -360,505 +408,380 @@ DUO_PART void duo_begin(int job, u32 cbase)
     }
 }
 
-/* The wave steps (align.c:667-999 / 1378-1697) of the halves with md == MD_RUN, until one of them has an event: its
-   direction is over (or failed), or its band no longer fits lanes 1..30.  The caller tells which from the state
-   (duo_classify); on entry every such half can step (duo_classify has been through).
+/* The wave steps (align.c:667-999 / 1378-1697) of the slots with md == MD_RUN, until one of them has an event: its
+   direction is over (or failed), or its band no longer fits a segment of DUO_BW lanes.  The caller tells which from the
+   state (duo_classify); on entry every such slot can step (duo_classify has been through).
 
-   Round 5 EXPERIMENT (DUO_SCALAR=1; off by default because it is slower -- kept because the measurement is the point):
-   what is the same in all lanes of a half -- the band, the best / last points' coordinates, the loop conditions -- kept
-   once per half in SCALAR registers and computed by the scalar unit: the band of a half as a 32-bit lane mask (widening
-   = mask | mask << 1 | mask >> 1, within the lanes it may grow into; pruning = the span of the live lanes by s_ff1 /
-   s_flbit / s_bfm), the lane a mask points at read through v_readlane, one `bad` flag instead of five per-step
-   comparisons.  VERDICT r4 item 2 proposed taking the per-alignment bookkeeping out of the full-width stream after the
-   band histogram (profiles/r05_bandhist.txt) had ruled 16-lane quarters out.  Measured on config 2, every kernel alone
-   (scripts/gpu_ab_report.sh, gpu_pmc.sh; profiles/r05_scalar_loop.txt), per loop iteration:
-       round 4 loop (vector)             154 vector + 63 scalar instructions    145 ms of report kernel per step
-       scalars with lane bounds (v1)     140        + 166                       185 ms
-       scalars with band masks (below)   130        + 132                       160 ms
-   i.e. time = 0.75 ms x vector + 0.48 ms x scalar instructions per iteration: the scalar unit is NOT free beside the
-   vector pipes -- a wavefront issues its instructions in order, and what leaves the vector side comes back as 2 - 3
-   scalar instructions (64-bit shifts, compare + select pairs, SGPR spills into VGPR lanes) where one vector instruction
-   served both halves at once.  A conversion pays only below 1.5 scalar per vector instruction saved; the compiler's output
-   for this loop is at 2.9. */
-#ifndef DUO_SCALAR
-#define DUO_SCALAR 0
+   DEALING THE LANES OUT.  Every slot that can step asks for its band + 4 lanes (the two lanes the band may grow into in
+   a step, and a first and a last lane that always hold EDGE and keep neighbouring segments apart) + DUO_MARGIN; the
+   slots are served in turn, starting one slot later every time; what is left of the 64 lanes is shared out among the
+   slots that were served (a segment is at most DUO_BW = 32 lanes: a segment's lane masks are 32-bit words).  A slot that
+   does not fit waits for the next deal -- after the next event of any other slot.  When a band comes too close to the
+   ends of its segment it is first moved to the middle (as the halves of rounds 4-5 did); when it needs more than the
+   segment, the band state goes back to LDS and the lanes are dealt out again, which costs about as much as one step.
+   Lane s of a segment (s = lane - slo) holds entry s of the slot's band frame: K = kbase - s. */
+#ifndef DUO_MARGIN
+#define DUO_MARGIN 6
 #endif
-#ifndef DUO_DBG
-#define DUO_DBG 0
-#endif
-#if DUO_SCALAR
-/* 32-bit span [lo .. hi] of lane bits (s_bfm_b32) */
-__device__ __forceinline__ u32 span32(int lo, int hi) { return ((1u << (hi - lo + 1)) - 1u) << lo; }
-__device__ __forceinline__ int sc(int v) { return __builtin_amdgcn_readfirstlane(v); }
-#define DUO_H2 for (int h = 0; h < 2; h++)
-#define DUO_EDGES 0xC0000003C0000003ull                    /* lanes 0, 1, 30, 31 of either half */
-DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
-{ DUO_NAMES()
-  DUO_CX();
+__device__ __forceinline__ u32 smask(u64 m, int slo, u32 wmask) { return (u32) (m >> slo) & wmask; }   /* a segment's bits of a lane mask */
+
+DUO_PIECE void duo_loop(int job, const u32 *trimtab)
+{ DUO_JOBC()
+  const int lane = lane_id();
   const int ave = uni(a.ave_path);
-  const u64 onm = bal(cx.md == MD_RUN);
-  const bool on = inv(onm);
-  const int m = cx.m;
-  const int va0 = cx.va0, vb0 = cx.vb0, alen = cx.alen, blen = cx.blen;
-  const int alim = cx.alim, blim = cx.blim, offa = cx.offa, offb = cx.offb, pa0 = cx.pa0, pb0 = cx.pb0;
-  const int guard = 4 * (alen + blen) + 1024;
-  const u32 below = (1u << s) - 1u;
-  const int lane4 = lane << 2, top4 = (hb + 31) << 2;
-  int dif = cx.dif, besta = cx.besta, ncell = cx.ncell;   /* (per lane: compared with per-lane values, or used by the pebble stores) */
-  int rV = duo_V[lane], rHA = duo_HA[lane], rHB = duo_HB[lane];
-  int Kv = cx.kbase - s;
-  u64 rT = ((u64) duo_Thi[lane] << 32) | duo_Tlo[lane];
-  u32 st_iter = 0, st_cells = 0;
-  if (!onm)
-    return;
-  /* Per-half scalars.  The BAND of a half is a mask of its lanes (the low / high word of `band`); `allow` holds the lanes it
-     may grow into (minp / maxp of align.c:675-776, within lanes 1 .. 30).  A half that is not stepping has an empty band and
-     nothing allowed: nothing of it moves, whatever its record holds (round 5's first version let such a half's stale
-     bounds run on, and its mask bits shifted into the other half's). */
-  const bool on0 = (u32) onm != 0, on1 = (u32) (onm >> 32) != 0;
-  u64 band = 0, allow = 0;
-  int kb[2], bk[2], la[2], be[2], mo[2];
-  int left = 0x7fffffff;                                  /* steps until the first stepping half reaches the loop bound (dif <= alen + blen + 64:
-                                                             cannot happen; leaving early for the other half's sake only re-enters the loop) */
-  bool bad = false;                                       /* a stepping half cannot go on: its pass is over (or its pebble pool) */
-  DUO_H2
-    { const DuoCtx &c = duo_half[h];
-      kb[h] = sc(c.kbase);  bk[h] = sc(c.bestk);  la[h] = sc(c.lasta);  be[h] = sc(c.besta);  mo[h] = sc(c.more);
-      if (h ? on1 : on0)
-        { const int l0 = sc(c.ls), h0 = sc(c.hs), lo = max(sc(c.mlo), 1), hi = min(sc(c.mhi), 30);
-          const int lf = sc(c.alen) + sc(c.blen) + 64 - sc(c.dif);
-          if (h0 < l0)
-            bad = true;                                   /* (cannot happen: duo_classify has been through) */
-          else
-            band |= (u64) span32(l0, h0) << (32 * h);
-          allow |= (u64) (lo <= hi ? span32(lo, hi) : 0u) << (32 * h);
-          left = lf < left ? lf : left;
-        }
-    }
+  u32 st_iter = 0, st_cells = 0, st_steps = 0, st_deal = 0, st_fast = 0;   /* (scalar: one s_bcnt1 + a few s_add per step) */
 
   for (;;)
-    { /* (every few dozen steps) keep the band and the two lanes it may grow into within lanes 1 .. 30 of the half; a band
-         that has outgrown the lanes leaves (duo_classify sends it on its excursion) */
-      if (band & DUO_EDGES)
-        { int dl[2];
-          bool wide = false;
-          DUO_H2
-            { const u32 bh = (u32) (band >> (32 * h));
-              dl[h] = 0;
-              if (bh & 0xC0000003u)
-                { const int l0 = __builtin_ctz(bh), h0 = 31 - __builtin_clz(bh);
-                  wide |= h0 - l0 > 27;
-                  dl[h] = ((31 - (h0 - l0)) >> 1) - l0;
-                }
-            }
-          if (wide)
-            break;
-          const int dlv = hb ? dl[1] : dl[0];
-          const int src = (hb + ((s - dlv) & 31)) << 2;
-          rV  = __builtin_amdgcn_ds_bpermute(src, rV);
-          rHA = __builtin_amdgcn_ds_bpermute(src, rHA);
-          rHB = __builtin_amdgcn_ds_bpermute(src, rHB);
-          { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
-            const u32 th = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
-            rT = ((u64) th << 32) | tl;
+    { /* deal: every lane computes the same in scalar registers; widths packed a byte per slot */
+      int q = 0, slo = 0, w = 8;
+      bool on = false;
+      int nin = 0;
+      u32 gslo = 0;                                 /* first lanes of the segments, a byte each, in lane order */
+      const u32 it0 = st_iter;
+      wave_mem_sync();                              /* (the band state was written by other lanes) */
+      { const int rot = uni((int) duo_half[0].n_deal) + (int) st_deal;
+        int tot = 0;
+        u32 wpk = 0;
+        for (int i = 0; i < DUO_NS; i++)
+          { const int j = (rot + i) & (DUO_NS - 1);
+            const DuoCtx &c = duo_half[j];
+            if (uni(c.md) != MD_RUN)
+              continue;
+            const int bw = uni(c.hs) - uni(c.ls) + 1, room = 64 - tot;
+            int want = bw + 4 + DUO_MARGIN;
+            if (want > DUO_BW) want = DUO_BW;
+            if (want > room) want = (room >= bw + 6) ? room : 0;
+            wpk |= (u32) want << (8 * j);
+            tot += want;  nin += (want > 0);
           }
-          Kv += dlv;
-          if (on)                                         /* the growth limits move with the lanes: through the record, they are needed here only */
-            { cx.mlo += dlv;  cx.mhi += dlv; }
-          u64 nb = 0, na = 0;
-          DUO_H2
-            if (h ? on1 : on0)
-              { const DuoCtx &c = duo_half[h];
-                const u32 bh = (u32) (band >> (32 * h));
-                const int lo = max(sc(c.mlo), 1), hi = min(sc(c.mhi), 30);
-                kb[h] += dl[h];
-                nb |= (u64) (dl[h] >= 0 ? bh << dl[h] : bh >> -dl[h]) << (32 * h);
-                na |= (u64) (lo <= hi ? span32(lo, hi) : 0u) << (32 * h);
-              }
-          band = nb;  allow = na;
+        const int extra = nin ? (64 - tot) / nin : 0;
+        int off = 0, k = 0;
+        for (int i = 0; i < DUO_NS; i++)
+          { const int j = (rot + i) & (DUO_NS - 1);
+            int wid = (int) ((wpk >> (8 * j)) & 0xffu);
+            if (wid == 0)
+              continue;
+            wid = (wid + extra > DUO_BW) ? DUO_BW : wid + extra;
+            if (lane >= off && lane < off + wid)
+              { q = j;  slo = off;  w = wid;  on = true; }
+            gslo |= (u32) off << (8 * k);  k += 1;
+            off += wid;
+          }
+        st_deal += 1;
+#ifdef DAMAR_PROF
+        { int nrun = 0, ndone = 0, bws = 0;
+          for (int j = 0; j < DUO_NS; j++)
+            { const int md = uni(duo_half[j].md);
+              nrun += md == MD_RUN;  ndone += md == MD_DONE;
+              if (md == MD_RUN) bws += uni(duo_half[j].hs) - uni(duo_half[j].ls) + 1;
+            }
+          PROF_ADD(26, 1);  PROF_ADD(27, nrun);  PROF_ADD(30, nin);  PROF_ADD(31, bws);  PROF_ADD(0, off);  PROF_ADD(1, ndone);
         }
-      bool stop;
-      do
-        { /* widen (align.c:675-776) and pick the predecessor (align.c:793-825): K - 1 sits one lane up, K + 1 one lane down */
-          const int K = Kv;
-          int  v, ha, hb_;
-          u64  b;
-          const u64 actm = (band | (band << 1) | (band >> 1)) & allow;       /* (lanes 0 and 31 of a half are never allowed: nothing crosses) */
-          left -= 1;
-          { const int am = lane_up(rV), ap = lane_dn(rV), ac = rV;
-            const int nbv = am > ap ? am : ap;
-            const u64 takem = bal(ac < nbv), upm = bal(am < ap);
-            v = inv(takem) ? nbv + 1 : ac + 2;
-            int dsel = inv(upm) ? -4 : 4;
-            dsel = inv(takem) ? dsel : 0;
-            const int src = lane4 + dsel;
-            ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
-            hb_ = __builtin_amdgcn_ds_bpermute(src, rHB);
-            const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
-            const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
-            b = ((u64) thi << 32) | tlo;
-            dif += 1;
-            st_iter += 1;  st_cells += (u32) __popcll(actm);
-          }
+#endif
+      }
+      u64 onm = bal(on);
+      if (!onm)
+        break;
+      if (!on)                                       /* a lane that is left over: a segment of its own that never steps */
+        { slo = lane;  w = 1; }
+      /* (registers: the wave loop keeps q, s, slo and w of the layout; everything else of it is formed where it is used --
+         with one more live value the compiler spills, and a reload in front of the snake's loads costs a memory latency) */
+#define cx          duo_half[q]                  /* (q changes when the lanes are dealt out in the registers) */
+#define DUO_COLDP   (duo_cold + q * DC_WORDS)
+#define DUO_WMASK   (on ? (u32) ((1ull << w) - 1ull) : 0u)
+#define DUO_CBASE   ((u32) (DUO_NS * (int) blockIdx.x + q) * (u32) cell_cap)
+      int s = lane - slo;
+      int m = cx.m;
+      int offb = cx.offb;
+      /* (not kept, to stay within the registers: cx.alim = forward ? alen : 0, cx.blim likewise, cx.offa -- duo_begin; pa0, pb0,
+         alen, blen are read from the record in every step: four registers less while the snake runs) */
+#define DUO_OFFA  (m ? TS + (PK_BIAS - DUO_GREV) * TS : TS - PK_BIAS * TS)
+#define DUO_STEPLIMIT (DUO_COLD_READ(cx.alen) + DUO_COLD_READ(cx.blen) + 64)
+      int ls = cx.ls, hs = cx.hs, kbase = cx.kbase, dif = cx.dif, besta = cx.besta, bestk = cx.bestk;
+      int lasta = cx.lasta, more = cx.more;
+      /* (cx.ncell is read and written where pebbles are pushed; cx.mlo / cx.mhi bound the band of an alignment of a read
+         against itself only: they stay in the record, and limm names the lanes that have to look at them) */
+      u64 limm = onm & (bal(cx.mlo > -(DUO_LIMK >> 1)) | bal(cx.mhi < (DUO_LIMK >> 1)));
+      int rV, rHA, rHB;
+      u64 rT;
+      { /* the band into the middle of the segment */
+        const int dl = ((w - (hs - ls + 1)) >> 1) - ls, e = s - dl;
+        const bool inb = on && e >= ls && e <= hs;
+        const int at = q * DUO_BW + (inb ? e : 0);
+        rV = inb ? duo_V[at] : DUO_EDGE;  rHA = duo_HA[at];  rHB = duo_HB[at];
+        rT = ((u64) duo_Thi[at] << 32) | duo_Tlo[at];
+        kbase += dl;  ls += dl;  hs += dl;
+        if (on)
+          { cx.mlo += dl;  cx.mhi += dl; }
+        else
+          { ls = 1;  hs = 0; }
+      }
+      u64 gom;
 
-          int Y = 0, na = 1, nb = 1;
-          if (inv(actm))
-            { b <<= 1;
-              const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, pa0, pb0, va0, vb0, alen, blen, K, (v - K) >> 1, b);
-              Y = so.Y;  b = so.b;  na = so.na;  nb = so.nb;
-              v = (Y << 1) + K;
-            }
-          asm("" : "+v"(na), "+v"(nb));            /* (compare behind the join: a bool out of the branch would be made 0 / 1 per lane and compared again) */
-          const u64 bhm = actm & bal(nb == 0), ahm = actm & ~bhm & bal(na == 0);
-
-          /* pebbles (align.c:859-909 / 1569-1618): every mark between the inherited head's and the new position */
-          { const int X = Y + K;
-            int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
-            u64 nam = actm & bal(X >= __mul24(ga, TS) + offa), nbm = actm & bal(Y >= __mul24(gb, TS) + offb);
-            if (nam | nbm)
-              { const int kk = (K ^ m) - m;
-                const u32 w1 = ((u32) kk & 0xffffu) | ((u32) dif << 16);
-                int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
-                int g2 = 0;
-                while (nam)
-                  { GUARD(g2, guard, 5)
-                    const u32 hm = hmask(nam, hb);
-                    const int idx = ncell + __popc(hm & below);
-                    if (inv(nam))
-                      { ga += 1;
-                        if (idx < cell_cap)
-                          { const v2u32 c = { (u32) hax | ((u32) ((ga ^ m) - m) << PK_HBITS), w1 };
-                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
-                          }
-                        hax = idx;
-                      }
-                    ncell += __popc(hm);
-                    nam &= bal(X >= __mul24(ga, TS) + offa);
-                  }
-                while (nbm)
-                  { GUARD(g2, guard, 6)
-                    const u32 hm = hmask(nbm, hb);
-                    const int idx = ncell + __popc(hm & below);
-                    if (inv(nbm))
-                      { gb += 1;
-                        if (idx < cell_cap)
-                          { const v2u32 c = { (u32) hbx | ((u32) ((gb ^ m) - m) << PK_HBITS), w1 };
-                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
-                          }
-                        hbx = idx;
-                      }
-                    ncell += __popc(hm);
-                    nbm &= bal(Y >= __mul24(gb, TS) + offb);
-                  }
-                ha = hax | (ga << PK_HBITS);  hb_ = hbx | (gb << PK_HBITS);
-                if (onm & bal(ncell > cell_cap))                  /* (rare block: this compare costs nothing per step) */
-                  bad = true;
+      for (;;)
+      {
+      for (;;)
+        { /* (every few dozen steps) keep the band and the two lanes it may grow into off the first and the last lane of the segment */
+          { const u64 mvm = onm & (bal(ls < 2) | bal(hs > w - 3));
+            if (mvm)
+              { const int dl = inv(mvm) ? ((w - 1 - (hs - ls)) >> 1) - ls : 0;
+                int from = s - dl;
+                from = from < 0 ? 0 : (from > w - 1 ? w - 1 : from);
+                const int src = (slo + from) << 2;
+                rV  = __builtin_amdgcn_ds_bpermute(src, rV);
+                rHA = __builtin_amdgcn_ds_bpermute(src, rHA);
+                rHB = __builtin_amdgcn_ds_bpermute(src, rHB);
+                { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+                  const u32 th = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+                  rT = ((u64) th << 32) | tl;
+                }
+                kbase += dl;  ls += dl;  hs += dl;
+                if (inv(mvm))
+                  { cx.mlo = DUO_COLD_READ(cx.mlo) + dl;  cx.mhi = DUO_COLD_READ(cx.mhi) + dl; }
               }
           }
-
-          /* commit the new wave (lanes outside the band get V = EDGE again behind the pruning) */
-          rV = v;  rT = b;  rHA = ha;  rHB = hb_;
-
-          /* sequence ends reached: the largest sweep index for A, the smallest for B */
-          if (ahm | bhm)
-            { const u32 am_ = hmask(ahm, hb), bm_ = hmask(bhm, hb);
-              if (am_ | bm_)
-                { if (am_) cold[DC_ACLIP] = 31 - __clz((int) am_);
-                  if (bm_) cold[DC_BCLIP] = __ffs((int) bm_) - 1;
-                }
-              if ((u32) (ahm | bhm)) mo[0] = 0;
-              if ((u32) ((ahm | bhm) >> 32)) mo[1] = 0;
-            }
-
-          /* new best / last / trim point in sweep order (align.c:911-928 / 1620-1637): record breakers of a prefix
-             maximum; their V is strictly monotone, so the LAST breaker with the wanted property is the one the serial
-             sweep leaves behind, and the new best is the maximum itself */
-          { const u64 candm = actm & bal(v > besta);
-            if (candm)
-              { const int x = pk_prefix_max(inv(candm) ? v : -BIG);
-                /* the maximum over the lanes before this one; what lane 0 of a half receives does not matter: the band
-                   lives in lanes 1 .. 30, lane 0 is never a candidate */
-                const int e = __builtin_amdgcn_update_dpp(-BIG, x, 0x138, 0xf, 0xf, false);       /* wave_shr:1 */
-                const u64 rbm = candm & bal(v > e);
-                const u64 mokm = rbm & bal(pk_popc61(b) >= ave);
-                u64 tokm = 0;
-                if (mokm)
-                  tokm = mokm & bal(pk_trim_ok(trimtab, b));
-                const int xl = __builtin_amdgcn_ds_bpermute(top4, x);                             /* the maximum of the half's candidates */
-                besta = xl > besta ? xl : besta;
-                DUO_H2
-                  { const u32 h1 = (u32) (rbm >> (32 * h)), h2 = (u32) (mokm >> (32 * h));
-                    if (h1)
-                      { bk[h] = kb[h] - (31 - __builtin_clz(h1));
-                        be[h] = __builtin_amdgcn_readlane(x, 32 * h + 31);
-                        if (h2)
-                          la[h] = __builtin_amdgcn_readlane(v, 32 * h + 31 - __builtin_clz(h2));
-                        if (la[h] < be[h] - MAX_TRIM_LAG)
-                          bad = true;
-                      }
+          do
+            { /* widen (align.c:675-776) and pick the predecessor (align.c:793-825): K - 1 sits one lane up, K + 1 one lane down */
+              const int K = kbase - s;
+              u64  actm;
+              int  v, ha, hb_;
+              u64  b;
+              { int nls = ls - 1, nhs = hs + 1;
+                if (limm)
+                  { const int mlo = DUO_COLD_READ(cx.mlo), mhi = DUO_COLD_READ(cx.mhi);
+                    nls = nls > mlo ? nls : mlo;  nhs = nhs < mhi ? nhs : mhi;
                   }
-                if (tokm)
-                  { const u32 h3 = hmask(tokm, hb);
+                actm = onm & bal(s >= nls) & bal(s <= nhs);
+                const int am = lane_up(rV), ap = lane_dn(rV), ac = rV;
+                const int nbv = am > ap ? am : ap;
+                const u64 takem = bal(ac < nbv), upm = bal(am < ap);
+                v = inv(takem) ? nbv + 1 : ac + 2;
+                int dsel = inv(upm) ? -4 : 4;
+                dsel = inv(takem) ? dsel : 0;
+                const int src = ((slo + s) << 2) + dsel;
+                ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
+                hb_ = __builtin_amdgcn_ds_bpermute(src, rHB);
+                const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+                const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+                b = ((u64) thi << 32) | tlo;
+                ls = nls;  hs = nhs;  dif += 1;
+                st_iter += 1;  st_cells += (u32) __popcll(actm);
+              }
+              const DuoQuad rd = duo_quad_read(&cx.pa0);                   /* pa0, pb0, alen, blen */
+              const u64 stepok = bal(dif <= rd.z + rd.w + 64);
+
+              int Y = 0, na = 1, nb = 1;
+              if (inv(actm))
+                { b <<= 1;
+                  const DuoSnake so = duo_snake(apk, bpk, abase, bbase, cx, m, rd.z & ~m, rd.w & ~m, rd.x, rd.y, rd.z, rd.w, K, (v - K) >> 1, b);
+                  Y = so.Y;  b = so.b;  na = so.na;  nb = so.nb;
+                  v = (Y << 1) + K;
+                }
+              asm("" : "+v"(na), "+v"(nb));            /* (compare behind the join: a bool out of the branch would be made 0 / 1 per lane and compared again) */
+              const u64 bhm = actm & bal(nb == 0), ahm = actm & ~bhm & bal(na == 0);
+
+              /* pebbles (align.c:859-909 / 1569-1618): every mark between the inherited head's and the new position */
+              { const int X = Y + K;
+                int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
+                u64 nam = actm & bal(X >= __mul24(ga, TS) + DUO_OFFA), nbm = actm & bal(Y >= __mul24(gb, TS) + offb);
+                if (nam | nbm)
+                  { const int kk = (K ^ m) - m;
+                    const u32 w1 = ((u32) kk & 0xffffu) | ((u32) dif << 16);
+                    int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
+                    int g2 = 0;
+                    int ncell = DUO_COLD_READ(cx.ncell);
+                    while (nam)
+                      { GUARD(g2, 4 * DUO_STEPLIMIT + 768, 5)
+                        const u32 hm = smask(nam, slo, DUO_WMASK);
+                        const int idx = ncell + __popc(hm & ((1u << (s & 31)) - 1u));
+                        if (inv(nam))
+                          { ga += 1;
+                            if (idx < cell_cap)
+                              { const v2u32 c = { (u32) hax | ((u32) ((ga ^ m) - m) << PK_HBITS), w1 };
+                                DUO_EXP_PEBBLE(gcell[DUO_CBASE + (u32) idx] = c;)
+                              }
+                            hax = idx;
+                          }
+                        ncell += __popc(hm);
+                        nam &= bal(X >= __mul24(ga, TS) + DUO_OFFA);
+                      }
+                    while (nbm)
+                      { GUARD(g2, 4 * DUO_STEPLIMIT + 768, 6)
+                        const u32 hm = smask(nbm, slo, DUO_WMASK);
+                        const int idx = ncell + __popc(hm & ((1u << (s & 31)) - 1u));
+                        if (inv(nbm))
+                          { gb += 1;
+                            if (idx < cell_cap)
+                              { const v2u32 c = { (u32) hbx | ((u32) ((gb ^ m) - m) << PK_HBITS), w1 };
+                                DUO_EXP_PEBBLE(gcell[DUO_CBASE + (u32) idx] = c;)
+                              }
+                            hbx = idx;
+                          }
+                        ncell += __popc(hm);
+                        nbm &= bal(Y >= __mul24(gb, TS) + offb);
+                      }
+                    ha = hax | (ga << PK_HBITS);  hb_ = hbx | (gb << PK_HBITS);
+                    if (on)
+                      cx.ncell = ncell;
+                  }
+              }
+
+              /* commit the new wave (lanes outside the band get V = EDGE again behind the pruning) */
+              rV = v;  rT = b;  rHA = ha;  rHB = hb_;
+
+              /* sequence ends reached: the largest sweep index for A, the smallest for B */
+              if (ahm | bhm)
+                { const u32 am_ = smask(ahm, slo, DUO_WMASK), bm_ = smask(bhm, slo, DUO_WMASK);
+                  if (am_ | bm_)
+                    { int *const cold = DUO_COLDP;
+                      more = 0;
+                      if (am_) cold[DC_ACLIP] = 31 - __clz((int) am_);
+                      if (bm_) cold[DC_BCLIP] = __ffs((int) bm_) - 1;
+                    }
+                }
+
+              /* new best / last / trim point in sweep order (align.c:911-928 / 1620-1637): record breakers of a prefix
+                 maximum; their V is strictly monotone, so the LAST breaker with the wanted property is the one the serial
+                 sweep leaves behind, and the new best is the maximum itself.  One prefix maximum for all segments: a
+                 segment's candidates are lifted above everything in the segments before it, so the maximum that reaches a
+                 segment's first candidate from the left never beats it. */
+              { const u64 candm = actm & bal(v > besta);
+                if (candm)
+                  { const int lift = slo << 25;      /* (|V| < 2^26: DAMAR_MAX_ANTI; a segment is at least 7 lanes) */
+                    const u32 wmask = DUO_WMASK;
+                    const int x = pk_prefix_max(inv(candm) ? v + lift : -BIG);
+                    const int e = __builtin_amdgcn_update_dpp(-BIG, x, 0x138, 0xf, 0xf, false);       /* wave_shr:1 */
+                    const u64 rbm = candm & bal(v + lift > e);
+                    const u64 mokm = rbm & bal(pk_popc61(b) >= ave);
+                    u64 tokm = 0;
+                    if (mokm)
+                      tokm = mokm & bal(pk_trim_ok(trimtab, b));
+                    const int xl = __builtin_amdgcn_ds_bpermute((slo + w - 1) << 2, x);                             /* the maximum of the segment's candidates, lifted */
+                    const u32 h1 = smask(rbm, slo, wmask), h2 = smask(mokm, slo, wmask), h3 = smask(tokm, slo, wmask);
+                    const int l1 = 31 ^ ffbh_raw(h1), l2 = 31 ^ ffbh_raw(h2), l3 = 31 ^ ffbh_raw(h3);
+                    const int v2 = hget(v, slo, l2);
+                    if (h1) { besta = xl - lift;  bestk = kbase - l1; }
+                    if (h2) lasta = v2;
                     if (h3)
-                      { const int l3 = 31 ^ ffbh_raw(h3);
-                        const int v3 = hget(v, hb, l3), h3a = hget(ha, hb, l3), h3b = hget(hb_, hb, l3);
-                        cold[DC_TRIM] = v3;  cold[DC_TRIM + 1] = Kv + s - l3;  cold[DC_TRIM + 2] = dif;
+                      { const int v3 = hget(v, slo, l3), h3a = hget(ha, slo, l3), h3b = hget(hb_, slo, l3);
+                        int *const cold = DUO_COLDP;
+                        cold[DC_TRIM] = v3;  cold[DC_TRIM + 1] = kbase - l3;  cold[DC_TRIM + 2] = dif;
                         cold[DC_TRIM + 3] = h3a & PK_HMASK;  cold[DC_TRIM + 4] = h3b & PK_HMASK;
                       }
                   }
               }
-          }
 
-          /* clipping at sequence ends (align.c:628-658 / 943-975): rare, on the vector side as in round 4 -- the band goes
-             there as lane bounds and comes back as a mask */
-          u64 wband = actm;                                       /* the band as widened: what the pruning starts from */
-          if ((on0 && mo[0] == 0) || (on1 && mo[1] == 0))
-            { int more = hb ? mo[1] : mo[0], bestk = hb ? bk[1] : bk[0], kbase = hb ? kb[1] : kb[0];
-              const u32 wb0 = (u32) wband, wb1 = (u32) (wband >> 32);
-              int ls = hb ? (wb1 ? __builtin_ctz(wb1) : 32) : (wb0 ? __builtin_ctz(wb0) : 32);
-              int hs = hb ? (wb1 ? 31 - __builtin_clz(wb1) : -1) : (wb0 ? 31 - __builtin_clz(wb0) : -1);
-              DUO_CLIP()
-              wband = 0;
-              DUO_H2
-                if (h ? on1 : on0)
-                  { const int l1 = __builtin_amdgcn_readlane(ls, 32 * h), h1 = __builtin_amdgcn_readlane(hs, 32 * h);
-                    mo[h] = __builtin_amdgcn_readlane(more, 32 * h);
-                    if (mo[h] == 0)
-                      bad = true;
-                    if (h1 >= l1)
-                      wband |= (u64) span32(l1, h1) << (32 * h);
-                  }
-              (void) bestk;  (void) kbase;
+              DUO_CLIP(slo, DUO_COLDP)
+
+              /* prune (align.c:977-986 / 1686-1695), and V = EDGE again in every lane outside the band (an empty band
+                 comes out as hs < ls: the find-first-bit instructions return -1 for 0) */
+              { const int n = besta - MAX_WAVE_LAG;
+                const u32 keep = smask(bal(s >= ls) & bal(s <= hs) & bal(rV >= n), slo, DUO_WMASK);
+                ls = ffbl_raw(keep);  hs = 31 ^ ffbh_raw(keep);
+                rV = inv(bal(s >= ls) & bal(s <= hs)) ? rV : DUO_EDGE;
+              }
+
+              /* may every slot go on as it is?  (a pebble pool that has run over is noticed when the loop is left for any
+                 other reason: its stores are bounded) */
+              gom = bal(more != 0) & bal(lasta >= besta - MAX_TRIM_LAG) & bal(hs >= ls) & stepok;
             }
-
-          /* prune (align.c:977-986 / 1686-1695): the band becomes the span of its lanes that are within reach of the best
-             point, and V = EDGE again in every lane outside it */
-          { const u64 keep = wband & bal(rV >= besta - MAX_WAVE_LAG);
-            const u32 k0 = (u32) keep, k1 = (u32) (keep >> 32);
-            const u32 s0 = k0 ? span32(__builtin_ctz(k0), 31 - __builtin_clz(k0)) : 0u;
-            const u32 s1 = k1 ? span32(__builtin_ctz(k1), 31 - __builtin_clz(k1)) : 0u;
-            if ((on0 && k0 == 0) || (on1 && k1 == 0))            /* an empty band */
-              bad = true;
-            band = ((u64) s1 << 32) | s0;
-            rV = inv(band) ? rV : DUO_EDGE;
-          }
-
-          /* may every half go on as it is?  (a pebble pool that has run over is noticed when the loop is left for any
-             other reason: its stores are bounded) */
-          stop = bad || left < 0 || (band & DUO_EDGES) != 0;
+          while ((onm & ~(gom & bal(ls >= 2) & bal(hs <= w - 3))) == 0);
+          if (onm & ~(gom & bal(hs - ls <= w - 5) & bal(DUO_COLD_READ(cx.ncell) <= cell_cap)))
+            break;
         }
-      while (!stop);
-      if (bad || left < 0)
+      /* an event, or only a segment that has become too tight? */
+      if (onm & ~(gom & bal(hs - ls <= DUO_BW - 5) & bal(DUO_COLD_READ(cx.ncell) <= cell_cap)))
         break;
-    }
-  { DuoCtx &c0 = duo_half[0];                   /* (every lane adds the same: one record counts for the wavefront) */
-    const u32 lo = c0.n_cells_lo + st_cells;
-    c0.n_cells_hi += (lo < st_cells) ? 1u : 0u;  c0.n_cells_lo = lo;
-    c0.n_iter += st_iter;  c0.n_half += st_iter * ((u32) __popcll(onm) >> 5);
-  }
-  if (on)
-    { const u32 b0 = (u32) band, b1 = (u32) (band >> 32);
-      duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
-      cx.ls = hb ? (b1 ? __builtin_ctz(b1) : 32) : (b0 ? __builtin_ctz(b0) : 32);
-      cx.hs = hb ? (b1 ? 31 - __builtin_clz(b1) : -1) : (b0 ? 31 - __builtin_clz(b0) : -1);
-      cx.kbase = hb ? kb[1] : kb[0];  cx.dif = dif;  cx.besta = besta;
-      cx.bestk = hb ? bk[1] : bk[0];  cx.lasta = hb ? la[1] : la[0];  cx.more = hb ? mo[1] : mo[0];  cx.ncell = ncell;
-    }
-}
-#else
-/* The wave steps (align.c:667-999 / 1378-1697) of the halves with md == MD_RUN, until one of them has an event: its
-   direction is over (or failed), or its band no longer fits lanes 1..30.  The caller tells which from the state
-   (duo_classify); on entry every such half can step (duo_classify has been through). */
-DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
-{ DUO_NAMES()
-  DUO_CX();
-  const int ave = uni(a.ave_path);
-  const u64 onm = bal(cx.md == MD_RUN);
-  const bool on = inv(onm);
-  const int m = cx.m;
-  const int va0 = cx.va0, vb0 = cx.vb0, alen = cx.alen, blen = cx.blen;
-  const int alim = cx.alim, blim = cx.blim, offa = cx.offa, offb = cx.offb, pa0 = cx.pa0, pb0 = cx.pb0;
-  const int steplimit = alen + blen + 64, guard = 4 * (alen + blen) + 1024;
-  const u32 below = (1u << s) - 1u;
-  const int lane4 = lane << 2, top4 = (hb + 31) << 2;
-  int ls = cx.ls, hs = cx.hs, kbase = cx.kbase, dif = cx.dif, besta = cx.besta, bestk = cx.bestk;
-  int lasta = cx.lasta, more = cx.more, ncell = cx.ncell, mlo = cx.mlo, mhi = cx.mhi;
-  int rV = duo_V[lane], rHA = duo_HA[lane], rHB = duo_HB[lane];
-  u64 rT = ((u64) duo_Thi[lane] << 32) | duo_Tlo[lane];
-  u32 st_iter = 0, st_cells = 0;                /* (scalar: one s_bcnt1 + two s_add per step) */
-  if (!onm)
-    return;
 
-  for (;;)
-    { /* (every few dozen steps) keep the band and the two lanes it may grow into within lanes 1 .. 30 of the half */
-      { const u64 mvm = onm & (bal(ls < 2) | bal(hs > 29));
-        if (mvm)
-          { const int dl = inv(mvm) ? ((31 - (hs - ls)) >> 1) - ls : 0;
-            const int src = (hb + ((s - dl) & 31)) << 2;
-            rV  = __builtin_amdgcn_ds_bpermute(src, rV);
-            rHA = __builtin_amdgcn_ds_bpermute(src, rHA);
-            rHB = __builtin_amdgcn_ds_bpermute(src, rHB);
-            { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
-              const u32 th = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
-              rT = ((u64) th << 32) | tl;
-            }
-            kbase += dl;  ls += dl;  hs += dl;  mlo += dl;  mhi += dl;
+      /* Only too tight: the same slots get new segments WITHOUT leaving the registers -- the band state moves from lane to
+         lane, and so does everything a segment's lanes hold about their slot (a lane may now serve another slot).  When
+         the slots no longer fit side by side one of them has to wait: that is the deal above, through LDS. */
+      { int lsk[DUO_NS], hsk[DUO_NS], osk[DUO_NS];
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < DUO_NS; k++)
+          { osk[k] = (int) ((gslo >> (8 * k)) & 0xffu);
+            lsk[k] = __builtin_amdgcn_readlane(ls, osk[k]);  hsk[k] = __builtin_amdgcn_readlane(hs, osk[k]);
+            if (k < nin)
+              tot += hsk[k] - lsk[k] + 1 + 4 + DUO_MARGIN;
           }
+        if (tot > 64)
+          break;
+        const int extra = (64 - tot) / nin;
+        int off = 0, osl = lane, nsl = lane, nwd = 1, dlv = 0, lsv = 1, hsv = 0;
+        bool non = false;
+        gslo = 0;
+#pragma unroll
+        for (int k = 0; k < DUO_NS; k++)
+          if (k < nin)
+            { const int bw = hsk[k] - lsk[k] + 1;
+              int wid = bw + 4 + DUO_MARGIN + extra;
+              if (wid > DUO_BW) wid = DUO_BW;
+              if (lane >= off && lane < off + wid)
+                { osl = osk[k];  nsl = off;  nwd = wid;  dlv = ((wid - bw) >> 1) - lsk[k];  lsv = lsk[k];  hsv = hsk[k];  non = true; }
+              gslo |= (u32) off << (8 * k);
+              off += wid;
+            }
+        const int ns = lane - nsl, e = ns - dlv;
+        const bool inb = non && e >= lsv && e <= hsv;
+        const int sb = (osl + (inb ? e : 0)) << 2, su = osl << 2;
+#define DUO_MOVE(x, from)  x = __builtin_amdgcn_ds_bpermute(from, x)
+        DUO_MOVE(rV, sb);  DUO_MOVE(rHA, sb);  DUO_MOVE(rHB, sb);
+        { u32 tl = (u32) rT, th = (u32) (rT >> 32);
+          tl = (u32) __builtin_amdgcn_ds_bpermute(sb, (int) tl);  th = (u32) __builtin_amdgcn_ds_bpermute(sb, (int) th);
+          rT = ((u64) th << 32) | tl;
+        }
+        if (!inb) rV = DUO_EDGE;
+        DUO_MOVE(q, su);  DUO_MOVE(kbase, su);  DUO_MOVE(dif, su);  DUO_MOVE(besta, su);  DUO_MOVE(bestk, su);
+        DUO_MOVE(lasta, su);  DUO_MOVE(more, su);  DUO_MOVE(m, su);  DUO_MOVE(offb, su);
+#undef DUO_MOVE
+        kbase += dlv;  ls = lsv + dlv;  hs = hsv + dlv;
+        slo = nsl;  w = nwd;  s = ns;  on = non;
+        onm = bal(on);
+        if (limm)
+          { if (on)
+              { const int nlo = DUO_COLD_READ(cx.mlo) + dlv, nhi = DUO_COLD_READ(cx.mhi) + dlv;
+                wave_mem_sync();
+                cx.mlo = nlo;  cx.mhi = nhi;
+              }
+            wave_mem_sync();
+            limm = onm & (bal(DUO_COLD_READ(cx.mlo) > -(DUO_LIMK >> 1)) | bal(DUO_COLD_READ(cx.mhi) < (DUO_LIMK >> 1)));
+          }
+        st_fast += 1;
       }
-      u64 gom;
-      do
-        { /* widen (align.c:675-776) and pick the predecessor (align.c:793-825): K - 1 sits one lane up, K + 1 one lane down */
-          const int K = kbase - s;
-          u64  actm;
-          int  v, ha, hb_;
-          u64  b;
-          { const int nls = (ls - 1 > mlo) ? ls - 1 : mlo, nhs = (hs + 1 < mhi) ? hs + 1 : mhi;
-            actm = onm & bal(s >= nls) & bal(s <= nhs);
-            const int am = lane_up(rV), ap = lane_dn(rV), ac = rV;
-            const int nbv = am > ap ? am : ap;
-            const u64 takem = bal(ac < nbv), upm = bal(am < ap);
-            v = inv(takem) ? nbv + 1 : ac + 2;
-            int dsel = inv(upm) ? -4 : 4;
-            dsel = inv(takem) ? dsel : 0;
-            const int src = lane4 + dsel;
-            ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
-            hb_ = __builtin_amdgcn_ds_bpermute(src, rHB);
-            const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
-            const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
-            b = ((u64) thi << 32) | tlo;
-            ls = nls;  hs = nhs;  dif += 1;
-            st_iter += 1;  st_cells += (u32) __popcll(actm);
-          }
-
-          int Y = 0, na = 1, nb = 1;
-          if (inv(actm))
-            { b <<= 1;
-              const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, pa0, pb0, va0, vb0, alen, blen, K, (v - K) >> 1, b);
-              Y = so.Y;  b = so.b;  na = so.na;  nb = so.nb;
-              v = (Y << 1) + K;
-            }
-          asm("" : "+v"(na), "+v"(nb));            /* (compare behind the join: a bool out of the branch would be made 0 / 1 per lane and compared again) */
-          const u64 bhm = actm & bal(nb == 0), ahm = actm & ~bhm & bal(na == 0);
-
-          /* pebbles (align.c:859-909 / 1569-1618): every mark between the inherited head's and the new position */
-          { const int X = Y + K;
-            int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
-            u64 nam = actm & bal(X >= __mul24(ga, TS) + offa), nbm = actm & bal(Y >= __mul24(gb, TS) + offb);
-            if (nam | nbm)
-              { const int kk = (K ^ m) - m;
-                const u32 w1 = ((u32) kk & 0xffffu) | ((u32) dif << 16);
-                int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
-                int g2 = 0;
-                while (nam)
-                  { GUARD(g2, guard, 5)
-                    const u32 hm = hmask(nam, hb);
-                    const int idx = ncell + __popc(hm & below);
-                    if (inv(nam))
-                      { ga += 1;
-                        if (idx < cell_cap)
-                          { const v2u32 c = { (u32) hax | ((u32) ((ga ^ m) - m) << PK_HBITS), w1 };
-                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
-                          }
-                        hax = idx;
-                      }
-                    ncell += __popc(hm);
-                    nam &= bal(X >= __mul24(ga, TS) + offa);
-                  }
-                while (nbm)
-                  { GUARD(g2, guard, 6)
-                    const u32 hm = hmask(nbm, hb);
-                    const int idx = ncell + __popc(hm & below);
-                    if (inv(nbm))
-                      { gb += 1;
-                        if (idx < cell_cap)
-                          { const v2u32 c = { (u32) hbx | ((u32) ((gb ^ m) - m) << PK_HBITS), w1 };
-                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
-                          }
-                        hbx = idx;
-                      }
-                    ncell += __popc(hm);
-                    nbm &= bal(Y >= __mul24(gb, TS) + offb);
-                  }
-                ha = hax | (ga << PK_HBITS);  hb_ = hbx | (gb << PK_HBITS);
-              }
-          }
-
-          /* commit the new wave (lanes outside the band get V = EDGE again behind the pruning) */
-          rV = v;  rT = b;  rHA = ha;  rHB = hb_;
-
-          /* sequence ends reached: the largest sweep index for A, the smallest for B */
-          if (ahm | bhm)
-            { const u32 am_ = hmask(ahm, hb), bm_ = hmask(bhm, hb);
-              if (am_ | bm_)
-                { more = 0;
-                  if (am_) cold[DC_ACLIP] = 31 - __clz((int) am_);
-                  if (bm_) cold[DC_BCLIP] = __ffs((int) bm_) - 1;
-                }
-            }
-
-          /* new best / last / trim point in sweep order (align.c:911-928 / 1620-1637): record breakers of a prefix
-             maximum; their V is strictly monotone, so the LAST breaker with the wanted property is the one the serial
-             sweep leaves behind, and the new best is the maximum itself */
-          { const u64 candm = actm & bal(v > besta);
-            if (candm)
-              { const int x = pk_prefix_max(inv(candm) ? v : -BIG);
-                int e = __builtin_amdgcn_update_dpp(-BIG, x, 0x138, 0xf, 0xf, false);             /* wave_shr:1 */
-                if (s == 0) e = -BIG;
-                const u64 rbm = candm & bal(v > e);
-                const u64 mokm = rbm & bal(pk_popc61(b) >= ave);
-                u64 tokm = 0;
-                if (mokm)
-                  tokm = mokm & bal(pk_trim_ok(trimtab, b));
-                const int xl = __builtin_amdgcn_ds_bpermute(top4, x);                             /* the maximum of the half's candidates */
-                const u32 h1 = hmask(rbm, hb), h2 = hmask(mokm, hb), h3 = hmask(tokm, hb);
-                const int l1 = 31 ^ ffbh_raw(h1), l2 = 31 ^ ffbh_raw(h2), l3 = 31 ^ ffbh_raw(h3);
-                const int v2 = hget(v, hb, l2);
-                besta = xl > besta ? xl : besta;
-                if (h1) bestk = kbase - l1;
-                if (h2) lasta = v2;
-                if (h3)
-                  { const int v3 = hget(v, hb, l3), h3a = hget(ha, hb, l3), h3b = hget(hb_, hb, l3);
-                    cold[DC_TRIM] = v3;  cold[DC_TRIM + 1] = kbase - l3;  cold[DC_TRIM + 2] = dif;
-                    cold[DC_TRIM + 3] = h3a & PK_HMASK;  cold[DC_TRIM + 4] = h3b & PK_HMASK;
-                  }
-              }
-          }
-
-          DUO_CLIP()
-
-          /* prune (align.c:977-986 / 1686-1695), and V = EDGE again in every lane outside the band (an empty band
-             comes out as hs < ls: the find-first-bit instructions return -1 for 0) */
-          { const int n = besta - MAX_WAVE_LAG;
-            const u32 keep = hmask(bal(s >= ls) & bal(s <= hs) & bal(rV >= n), hb);
-            ls = ffbl_raw(keep);  hs = 31 ^ ffbh_raw(keep);
-            rV = inv(bal(s >= ls) & bal(s <= hs)) ? rV : DUO_EDGE;
-          }
-
-          /* may every half go on as it is?  (a band within lanes 2 .. 29 is no wider than 28; a pebble pool that has
-             run over is noticed when the loop is left for any other reason: its stores are bounded) */
-          gom = bal(more != 0) & bal(lasta >= besta - MAX_TRIM_LAG) & bal(hs >= ls) & bal(dif <= steplimit);
+      }
+      st_steps += (st_iter - it0) * (u32) nin;
+      if (on)
+        { const int at = q * DUO_BW + s;
+          duo_V[at] = rV;  duo_HA[at] = rHA;  duo_HB[at] = rHB;  duo_Tlo[at] = (u32) rT;  duo_Thi[at] = (u32) (rT >> 32);
+          cx.ls = ls;  cx.hs = hs;  cx.kbase = kbase;  cx.dif = dif;  cx.besta = besta;  cx.bestk = bestk;
+          cx.lasta = lasta;  cx.more = more;
         }
-      while ((onm & ~(gom & bal(ls >= 2) & bal(hs <= 29))) == 0);
-      if (onm & ~(gom & bal(hs - ls <= 27) & bal(ncell <= cell_cap)))
+      wave_mem_sync();
+      /* an event, or slots that no longer fit side by side? */
+      if (onm & ~(gom & bal(hs - ls <= DUO_BW - 5) & bal(DUO_COLD_READ(cx.ncell) <= cell_cap)))
         break;
     }
+#undef cx
+#undef DUO_OFFA
+#undef DUO_STEPLIMIT
+#undef DUO_COLDP
+#undef DUO_WMASK
+#undef DUO_CBASE
   { DuoCtx &c0 = duo_half[0];                   /* (every lane adds the same: one record counts for the wavefront) */
     const u32 lo = c0.n_cells_lo + st_cells;
     c0.n_cells_hi += (lo < st_cells) ? 1u : 0u;  c0.n_cells_lo = lo;
-    c0.n_iter += st_iter;  c0.n_half += st_iter * ((u32) __popcll(onm) >> 5);
+    c0.n_iter += st_iter;  c0.n_half += st_steps;  c0.n_deal += st_deal;
+#ifdef DAMAR_PROF
+    PROF_ADD(6, st_fast);
+#endif
+    (void) st_fast;
   }
-  if (on)
-    { duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
-      cx.ls = ls;  cx.hs = hs;  cx.kbase = kbase;  cx.dif = dif;  cx.besta = besta;  cx.bestk = bestk;
-      cx.lasta = lasta;  cx.more = more;  cx.ncell = ncell;  cx.mlo = mlo;  cx.mhi = mhi;
-    }
 }
 
-#endif
-
-/* What the wave loop left for the halves with md == MD_RUN (the reference's loop conditions, in their order) */
+/* What the wave loop left for the slots with md == MD_RUN (the reference's loop conditions, in their order) */
 __device__ __forceinline__ void duo_classify(const ReportArgs &a)
-{ DUO_CX(); const int s = lane_id() & 31;
+{ DUO_CX(); const int s = lane_id() & (DUO_L - 1);
   u32 *const errw = &a.counters[3];
   if (cx.md != MD_RUN)
     return;
@@ -876,24 +799,25 @@ __device__ __forceinline__ void duo_classify(const ReportArgs &a)
     { if (s == 0) atomicOr(errw, DAMAR_ERR_BAND);
       cx.md = MD_END;
     }
-  else if (cx.hs - cx.ls > 27)
+  else if (cx.hs - cx.ls > DUO_BW - 5)
     cx.md = MD_OVF;
 }
 
-/* A half whose band outgrew its lanes borrows the whole wavefront: the band goes to the one-alignment-per-wavefront
+/* A slot whose band outgrew DUO_BW lanes borrows the whole wavefront: the band goes to the one-alignment-per-wavefront
  * register path in the reference's own coordinates (wave_reg_cont<REV>: lane (k & 63) owns diagonal k, marks as values,
- * NA = the mark after the head's) and comes back as soon as it fits a half again (hgh - low + 3 <= PK_NARROW) or
- * finishes the direction there (through wave_mem<REV> if it outgrows the wavefront too).  Called for one half at a time
- * (hsel = its lane base) with every lane active. */
+ * NA = the mark after the head's) and comes back as soon as it fits a segment again (hgh - low + 3 <= PK_NARROW) or
+ * finishes the direction there (through wave_mem<REV> if it outgrows the wavefront too).  Called for one slot at a time
+ * (hsel = the first of its lanes outside the wave loop) with every lane active. */
 template <int REV>
 DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel)
-{ DuoCtx &cx = duo_half[hsel >> 5];              /* the record of the half that borrows the wavefront (every lane reads it) */ const ReportArgs &a = g_jobs[uni(job)];
+{ const int qs = hsel >> DUO_LSH;                 /* the slot that borrows the wavefront (every lane reads its record) */
+  DuoCtx &cx = duo_half[qs];  const ReportArgs &a = g_jobs[uni(job)];
   const int lane = lane_id();
   const int TS = a.tspace;
   const int m = REV ? -1 : 0;
   const int edge = REV ? BIG : -1;
   const int src = hsel;
-  int *const cold = duo_cold + (hsel >> 1);
+  int *const cold = duo_cold + qs * DC_WORDS;
   WaveCtx c;
   WaveState ws;
 #define DUO_PTR_OF(T, ptr) ((T) (uintptr_t) (((u64) (u32) bcast_i((int) (u32) ((u64) (uintptr_t) (ptr) >> 32), src) << 32) | \
@@ -936,11 +860,11 @@ DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel)
     ws.reach.ha = uni(cold[DC_REACH + 3]);  ws.reach.hb = uni(cold[DC_REACH + 4]);
   }
   ws.stopped = 0;  ws.bad = 0;  ws.narrow = 0;
-  /* the half's band into the 64-lane layout (lane (k & 63) owns diagonal k) */
+  /* the slot's band into the 64-lane layout (lane (k & 63) owns diagonal k) */
   LaneRegs r;
   { const int k = ws.low + ((lane - ws.low) & 63);
     const bool in = k <= ws.hgh;
-    const int sl = (hsel + (in ? kbase - DUO_SG(k) : 0)) << 2;
+    const int sl = (qs * DUO_BW + (in ? kbase - DUO_SG(k) : 0)) << 2;
     const int nV = duo_V[sl >> 2];
     const int nHA = duo_HA[sl >> 2], nHB = duo_HB[sl >> 2];
     r.V = in ? DUO_SG(nV) : edge;
@@ -956,10 +880,10 @@ DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel)
   }
   wave_mem_sync();
   wave_reg_cont<REV>(c, mida, ws, &r);
-  const bool mine = (lane & 32) == hsel;
+  const bool mine = lane < DUO_BW;                 /* (one lane per entry of the slot's band frame; the record's words are the same from every lane) */
   if (ws.narrow)
-    { /* back into the half, centred */
-      const int w = ws.hgh - ws.low + 1, slo = (32 - w) >> 1;
+    { /* back into the slot's band frame, centred */
+      const int w = ws.hgh - ws.low + 1, slo = (DUO_BW - w) >> 1;
       const int nls = slo, nhs = slo + w - 1;
       const int nkbase = REV ? nls - ws.low : ws.hgh + nls;           /* K of lane nls is the highest: sigma * (REV ? low : hgh) */
       const int k = DUO_SG(nkbase - (lane & 31));
@@ -971,10 +895,11 @@ DUO_PIECE void duo_solo(int job, const u32 *trimtab, SlotScratch sc, int hsel)
       const u32 th = (u32) __builtin_amdgcn_ds_bpermute(sl, (int) (u32) (r.T >> 32));
       if (mine)
         { const int hai = (int) ((u32) nHA >> PK_HBITS), hbi = (int) ((u32) nHB >> PK_HBITS);
-          duo_V[lane] = in ? DUO_SG(nV) : DUO_EDGE;
-          duo_HA[lane] = (nHA & PK_HMASK) | ((REV ? DUO_GREV - hai : hai) << PK_HBITS);
-          duo_HB[lane] = (nHB & PK_HMASK) | ((REV ? DUO_GREV - hbi : hbi) << PK_HBITS);
-          duo_Tlo[lane] = tl;  duo_Thi[lane] = th;
+          const int at = qs * DUO_BW + lane;
+          duo_V[at] = in ? DUO_SG(nV) : DUO_EDGE;
+          duo_HA[at] = (nHA & PK_HMASK) | ((REV ? DUO_GREV - hai : hai) << PK_HBITS);
+          duo_HB[at] = (nHB & PK_HMASK) | ((REV ? DUO_GREV - hbi : hbi) << PK_HBITS);
+          duo_Tlo[at] = tl;  duo_Thi[at] = th;
           cx.mlo += nkbase - cx.kbase;  cx.mhi += nkbase - cx.kbase;
           cx.kbase = nkbase;  cx.ls = nls;  cx.hs = nhs;
           cx.md = MD_RUN;
@@ -1148,17 +1073,17 @@ __device__ __forceinline__ int duo_walk(const Cell *cells, int side, int head, i
     }
 }
 
-/* End point and trace points of the direction that is over (align.c:1001-1118 / 1699-1898) for the halves with
- * md == MD_END: the first lane of the half walks the two pebble chains (chain_to_trace).  Leaves the pass's results in
- * cx and the half in MD_TASK with m = -1 (the reverse pass is next) or, after the reverse pass, in MD_END with m = 1
+/* End point and trace points of the direction that is over (align.c:1001-1118 / 1699-1898) for the slots with
+ * md == MD_END: the first two lanes of the slot walk the two pebble chains (chain_to_trace).  Leaves the pass's results in
+ * cx and the slot in MD_TASK with m = -1 (the reverse pass is next) or, after the reverse pass, in MD_END with m = 1
  * as the sign that the alignment is complete. */
 DUO_PART void duo_finish(int job)
 { DUO_CX(); const ReportArgs &a = g_jobs[uni(job)];
-  const int lane = lane_id(), hb = lane & 32, s = lane & 31;
-  const SlotScratch sc = slot_scratch(a, 2 * (int) blockIdx.x + (hb >> 5));      /* (derived here: nothing of it is live across the wave loop) */
+  const int lane = lane_id(), hb = lane & ~(DUO_L - 1), s = lane & (DUO_L - 1);
+  const SlotScratch sc = slot_scratch(a, DUO_NS * (int) blockIdx.x + (lane >> DUO_LSH));      /* (derived here: nothing of it is live across the wave loop) */
   const bool fin = cx.md == MD_END;
   const int m = cx.m;
-  const int *const cold = duo_cold + (hb >> 1);
+  const int *const cold = duo_cold + (lane >> DUO_LSH) * DC_WORDS;
   const int TS = a.tspace;
   const int boff = (a.comp & 1) ? (cx.blen % TS) : 0;
   const int guard = 4 * (cx.alen + cx.blen) + 1024;
@@ -1200,8 +1125,8 @@ DUO_PART void duo_finish(int job)
     }
 }
 
-/* One turn of the Local_Alignment machine for the two halves, as ONE call: start the passes that are due, step the
- * halves that can step until one of them has an event, and finish the passes that are over -- unless a half left the
+/* One turn of the Local_Alignment machine for the slots of the wavefront, as ONE call: start the passes that are due, step
+ * the slots that can step until one of them has an event, and finish the passes that are over -- unless a slot left the
  * lanes (MD_OVF): then the caller sends it through duo_solo first and finishes with duo_finish_piece.  (begin, loop and
  * finish were three calls; each call writes and re-reads the callee-saved registers it uses -- 4 KB per wavefront -- and
  * that was most of the kernel's write traffic, profiles/r04_sweeps.txt.) */
@@ -1216,7 +1141,7 @@ DUO_PIECE void duo_run(int job, const u32 *trimtab, u32 cbase)
 #ifdef DAMAR_PROF
       const unsigned long long pf0 = wall_clock64();
 #endif
-      duo_loop(job, trimtab, cbase);                 /* every half in MD_RUN can step: the loop tests behind a step */
+      duo_loop(job, trimtab);                        /* every slot in MD_RUN can step: the loop tests behind a step */
       duo_classify(a);
 #ifdef DAMAR_PROF
       PROF_ADD(15, wall_clock64() - pf0);  PROF_ADD(29, 1);
@@ -1238,13 +1163,13 @@ DUO_PIECE void duo_run(int job, const u32 *trimtab, u32 cbase)
 
 DUO_PIECE void duo_finish_piece(int job) { duo_finish(job); }
 
-/***** the per-half state machine of the report loop ******************************************************/
+/***** the per-slot state machine of the report loop ******************************************************/
 
-/* emit one alignment per half with `keep` (emit_record for 32 lanes): both traces to the pool (B trace reversed
+/* emit one alignment per slot with `keep` (emit_record for DUO_L lanes): both traces to the pool (B trace reversed
  * pairwise for COMP, align.c:2033-2056) and the record */
 __device__ __forceinline__ void pk_emit(const ReportArgs &a, const SlotScratch &sc, bool keep, const LaResult &r,
                                         int ar, int br, u32 item, u32 seq)
-{ const int lane = lane_id(), hb = lane & 32, s = lane & 31;
+{ const int lane = lane_id(), hb = lane & ~(DUO_L - 1), s = lane & (DUO_L - 1);
   const int nval = r.atlen + r.btlen;
   u32 ri = 0, to = 0;
   if (keep && s == 0)
@@ -1261,7 +1186,7 @@ __device__ __forceinline__ void pk_emit(const ReportArgs &a, const SlotScratch &
         bad |= DAMAR_ERR_TPOOL;
       if (bad == 0)
         { const u16 *at = sc.atr - r.aback, *bt = sc.btr - r.bback;
-          for (int i = s; i < nval; i += 32)
+          for (int i = s; i < nval; i += DUO_L)
             { u16 v;
               if (i < r.atlen)
                 v = at[i];
@@ -1294,7 +1219,7 @@ __device__ __forceinline__ void pk_emit(const ReportArgs &a, const SlotScratch &
     }
 }
 
-/* The seeds of a 32-lane group that fall into one bucket (`peers`) add to its score through the LAST of them: the group's
+/* The seeds of a slot's lane group that fall into one bucket (`peers`) add to its score through the LAST of them: the group's
  * sums are formed in LDS and one lane per bucket does a plain read-modify-write.  (An atomic per seed is executed at the
  * memory side on this machine -- TCC_EA0_ATOMIC == TCC_ATOMIC -- one 32-byte transaction each, and the slot's bucket
  * arrays are private to its half anyway.)  sv = score[d] as read before the group. */
@@ -1303,7 +1228,7 @@ __device__ __forceinline__ void duo_bucket_add(const SlotScratch &sc, bool in, b
   __hip_atomic_store(&duo_acc[lane], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                     /* (LDS executes one wavefront's operations in order) */
   if (in)
-    __hip_atomic_fetch_add(&duo_acc[(lane & 32) + (31 - __clz((int) peers))], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_fetch_add(&duo_acc[(lane & ~(DUO_L - 1)) + (31 - __clz((int) peers))], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   if (last)
     { sc.score[d] = sv + __hip_atomic_load(&duo_acc[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1313,9 +1238,9 @@ __device__ __forceinline__ void duo_bucket_add(const SlotScratch &sc, bool in, b
 
 /* pass 3: a bucket is reset by the first lane of every run of seeds in it (every store is a line written through) */
 __device__ __forceinline__ void duo_bucket_reset(const SlotScratch &sc, bool in, int d)
-{ const int lane = lane_id(), hb = lane & 32, s = lane & 31;
+{ const int lane = lane_id(), hb = lane & ~(DUO_L - 1), s = lane & (DUO_L - 1);
   const int dd = in ? d : BIG;
-  const int dp = hget(dd, hb, (s + 31) & 31);
+  const int dp = hget(dd, hb, (s + DUO_L - 1) & (DUO_L - 1));
   if (in && (s == 0 || dp != dd))
     { sc.score[d] = 0;
       sc.lastp[d] = 0;
@@ -1325,14 +1250,14 @@ __device__ __forceinline__ void duo_bucket_reset(const SlotScratch &sc, bool in,
 enum { PK_ITEM = 0, PK_PANEL, PK_FIRE, PK_DONE };
 
 
-/* one job of the launch: the two halves pull read pairs (or batch tasks) from its queue until it is empty */
+/* one job of the launch: the slots pull read pairs (or batch tasks) from its queue until it is empty */
 /* dist != NULL: datander (scrub/tandem.c:895-1175 report_thread) -- a work item is a READ, its "seeds" are the positions
    apos of the read whose k-mer has an equal k-mer earlier in the same read, dist[...] back (damar_launch_tandem_links), and
    the alignment is the read against itself (aseq == bseq: the band may not cross the main diagonal, align.c:1949-1968) */
 __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trimtab, const LaTask *tasks, u32 ntasks,
                                             const int *dist)
-{ const int lane = lane_id(), hb = lane & 32, s = lane & 31;
-  const int slot = 2 * (int) blockIdx.x + (hb >> 5);
+{ const int lane = lane_id(), hb = lane & ~(DUO_L - 1), s = lane & (DUO_L - 1);
+  const int slot = DUO_NS * (int) blockIdx.x + (lane >> DUO_LSH);
   const SlotScratch sc = slot_scratch(a, slot);
   const u32 cbase = (u32) slot * a.cell_cap;
   const u64 *keys = a.keys;
@@ -1351,12 +1276,13 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
   DUO_CX();
   cx.md = MD_SCAN;  cx.m = 0;  cx.bad = 0;
   cx.va0 = cx.vb0 = 16 * PK_PAD;  cx.alen = cx.blen = 0;
-  duo_V[lane] = DUO_EDGE;  duo_HA[lane] = duo_HB[lane] = 0;  duo_Tlo[lane] = duo_Thi[lane] = 0;
+  for (int e = lane; e < DUO_NS * DUO_BW; e += 64)
+    { duo_V[e] = DUO_EDGE;  duo_HA[e] = duo_HB[e] = 0;  duo_Tlo[e] = duo_Thi[e] = 0; }
   cx.ls = cx.hs = 15;  cx.kbase = 0;  cx.dif = 0;  cx.besta = cx.bestk = cx.lasta = 0;  cx.more = 0;  cx.ncell = 2;
   cx.mlo = cx.mhi = 0;  cx.alim = cx.blim = 0;  cx.offa = cx.offb = 0;  cx.pa0 = cx.pb0 = 0;
   cx.diag = cx.anti = 0;  cx.roota = cx.rootb = 0;  cx.item = 0;
   cx.aepos = cx.bepos = cx.abpos = cx.bbpos = cx.diffs = cx.atlen = cx.btlen = cx.aback = cx.bback = 0;
-  cx.n_cells_lo = cx.n_cells_hi = 0;  cx.n_iter = cx.n_half = 0;
+  cx.n_cells_lo = cx.n_cells_hi = 0;  cx.n_iter = cx.n_half = 0;  cx.n_deal = 0;
 
   for (;;)
     { /* A: the halves without an alignment in hand advance their scan until they have one or have run out of work */
@@ -1386,7 +1312,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                 }
               else if (sc_ && phase == PK_PANEL)
                 { /* pass 1 (tandem.c:986-996): bucket scores of the panel */
-                  for (int base = tmb; base < tme; base += 32)
+                  for (int base = tmb; base < tme; base += DUO_L)
                     { const int  apos = base + s;
                       const int  dg = (apos < tme) ? dist[nidx + (u64) apos] : 0;
                       const bool in = dg != 0;
@@ -1416,7 +1342,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                 { /* pass 2 (tandem.c:1000-1099): the next position with enough score that lies beyond lasta */
                   bool found = false;
                   int  sap = 0, sdg = 0;
-                  for (int base = (int) fp; base < tme; base += 32)
+                  for (int base = (int) fp; base < tme; base += DUO_L)
                     { const int  apos = base + s;
                       const int  dg = (apos < tme) ? dist[nidx + (u64) apos] : 0;
                       const int  d = dg >> W;
@@ -1442,7 +1368,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                     }
                   else
                     { /* pass 3 (tandem.c:1103-1109), then the next panel of the read or the next read */
-                      for (int base = tmb; base < tme; base += 32)
+                      for (int base = tmb; base < tme; base += DUO_L)
                         { const int apos = base + s;
                           const int dg = (apos < tme) ? dist[nidx + (u64) apos] : 0;
                           duo_bucket_reset(sc, dg != 0, dg >> W);
@@ -1450,7 +1376,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                       wave_mem_sync();
                       if (tme > cx.alen)
                         { if (clo <= chi)
-                            for (int q = clo + s; q <= chi; q += 32)
+                            for (int q = clo + s; q <= chi; q += DUO_L)
                               sc.lasta[q] = 0;
                           wave_mem_sync();
                           phase = PK_ITEM;
@@ -1490,8 +1416,10 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                   cx.alen = (int) read_len(a.ablk, ar);  cx.blen = (int) read_len(a.bblk, br);
                   cx.item = item;
                   seq = 0;  amark2 = 0;  clo = BIG;  chi = -BIG;
-                  if (a.widemap != NULL && (cx.alen > cx.blen ? cx.alen : cx.blen) / a.tspace + 8 > DAMAR_MAX_MARKS)
-                    { /* a read of more trace spacings than a packed chain head can name: the wide kernel's pair */
+                  if (a.widemap != NULL && ((cx.alen > cx.blen ? cx.alen : cx.blen) / a.tspace + 8 > DAMAR_MAX_MARKS ||
+                                            cx.alen + cx.blen >= DAMAR_MAX_ANTI))
+                    { /* a read of more trace spacings than a packed chain head can name (or an anti-diagonal range the wave loop's
+                         prefix maximum cannot lift, duo_loop): the wide kernel's pair */
                       if (!(cx.alen < a.hgap_min && cx.blen < a.hgap_min) && s == 0)
                         atomicAdd(&a.counters[DAMAR_CNT_WIDE], 1u);
                     }
@@ -1503,7 +1431,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
             { if (!(nidx < a.nhits && (keys[nidx] >> pshift) == cpair))
                 { /* the pair is done: filter.c:2417-2432 leaves lasta all zero again */
                   if (clo <= chi)
-                    for (int q = clo + s; q <= chi; q += 32)
+                    for (int q = clo + s; q <= chi; q += DUO_L)
                       sc.lasta[q] = 0;
                   phase = PK_ITEM;
                 }
@@ -1512,7 +1440,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                   const int amark = amark2 + PANEL_SIZE;
                   amark2 = amark - PANEL_OVERLAP;
                   lidx = nidx;  end = lidx;  h2 = lidx;
-                  for (u64 base = lidx; ; base += 32)
+                  for (u64 base = lidx; ; base += DUO_L)
                     { const u64  f = base + s;
                       const bool in = f < a.nhits && (keys[f] >> pshift) == cpair;
                       const int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
@@ -1523,7 +1451,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                       if (sm)
                         { const int l = __ffs((int) sm) - 1;
                           end = base + l + 1;
-                          le &= (l == 31) ? ~0u : ((1u << (l + 1)) - 1);
+                          le &= (l == DUO_L - 1) ? ~0u : ((1u << (l + 1)) - 1);
                           if (le) h2 = base + (31 - __clz((int) le)) + 1;
                           break;
                         }
@@ -1534,7 +1462,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                   nidx = end;
                   if (end - lidx >= (u64) minhit)
                     { /* pass 1: bucket scores (filter.c:2268-2277) */
-                      for (u64 base = lidx; base < end; base += 32)
+                      for (u64 base = lidx; base < end; base += DUO_L)
                         { const u64  f = base + s;
                           const bool in = f < end;
                           const int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
@@ -1568,7 +1496,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
             { /* pass 2 (filter.c:2283-2405): the next seed in order with enough score whose apos is beyond lasta */
               bool found = false;
               int  sap = 0, sdg = 0;
-              for (u64 base = fp; base < end; base += 32)
+              for (u64 base = fp; base < end; base += DUO_L)
                 { const u64  f = base + s;
                   const bool in = f < end;
                   const int  ap = in ? (int) ((keys[f] >> dbits) & pmask) : 0;
@@ -1598,7 +1526,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                 }
               else
                 { /* pass 3: reset the touched buckets (filter.c:2407-2411) */
-                  for (u64 base = lidx; base < end; base += 32)
+                  for (u64 base = lidx; base < end; base += DUO_L)
                     { const u64 f = base + s;
                       const bool in = f < end;
                       duo_bucket_reset(sc, in, in ? (seed_diag(keys[f], vals, f, pmask, dbits) >> W) : 0);
@@ -1618,11 +1546,11 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
           {
 #ifdef DAMAR_PROF
             const unsigned long long pf0 = wall_clock64();
-            PROF_ADD(28, __popcll(ov) >> 5);
+            PROF_ADD(28, __popcll(ov) >> DUO_LSH);
 #endif
-            for (int h = 0; h < 64; h += 32)
+            for (int h = 0; h < 64; h += DUO_L)
               if ((ov >> h) & 1)
-                { if (uni(duo_half[h >> 5].m))
+                { if (uni(duo_half[h >> DUO_LSH].m))
                     duo_solo<1>(a.job, trimtab, sc, h);
                   else
                     duo_solo<0>(a.job, trimtab, sc, h);
@@ -1668,7 +1596,7 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                 { if (sd < lo) lo = sd; else if (sd > hi) hi = sd;
                   if (lo < mind - 1) lo = mind - 1;
                   if (hi > maxd + 1) hi = maxd + 1;
-                  for (int q = lo + s; q <= hi; q += 32)
+                  for (int q = lo + s; q <= hi; q += DUO_L)
                     if (r.aepos > sc.lasta[q])
                       sc.lasta[q] = r.aepos;
                   if (lo < clo) clo = lo;
@@ -1709,7 +1637,7 @@ void report2_kernel(int njobs, const LaTask *tasks, u32 ntasks, const int *dist)
 
 void damar_launch_report2(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st)
 { jobs_upload(jobs, njobs, st);
-  hipLaunchKernelGGL(report2_kernel, dim3(nslots / 2), dim3(64), 0, st, njobs, tasks, ntasks, (const int *) NULL);
+  hipLaunchKernelGGL(report2_kernel, dim3(nslots / DUO_NS), dim3(64), 0, st, njobs, tasks, ntasks, (const int *) NULL);
 }
 
 /* datander: one work item per read of a->ablk, dist as produced by damar_launch_tandem_links */
@@ -1717,5 +1645,5 @@ void damar_launch_tandem_report2(const ReportArgs *a, const int *dist, int nslot
 { if (a->nwork == 0)
     return;
   jobs_upload(a, 1, st);
-  hipLaunchKernelGGL(report2_kernel, dim3(nslots / 2), dim3(64), 0, st, 1, (const LaTask *) NULL, 0u, dist);
+  hipLaunchKernelGGL(report2_kernel, dim3(nslots / DUO_NS), dim3(64), 0, st, 1, (const LaTask *) NULL, 0u, dist);
 }

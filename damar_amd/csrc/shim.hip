@@ -1002,11 +1002,11 @@ static int default_slots(void)
   /* (DAMAR_REPORT_WPS: report wavefronts per SIMD of a launch, for sweeps) */
   if (const char *w = getenv("DAMAR_REPORT_WPS"))
     if (atoi(w) > 0)
-      return G_prop.multiProcessorCount * 4 * 2 * std::min(atoi(w), damar_report2_waves_per_simd());
+      return G_prop.multiProcessorCount * 4 * damar_report2_slots_per_wave() * std::min(atoi(w), damar_report2_waves_per_simd());
   if (corun_on())
-    return G_prop.multiProcessorCount * 4 * 2 * (damar_report2_waves_per_simd() >= 8 ? 8 : std::min(4, damar_report2_waves_per_simd()));
+    return G_prop.multiProcessorCount * 4 * damar_report2_slots_per_wave() * (damar_report2_waves_per_simd() >= 8 ? 8 : std::min(4, damar_report2_waves_per_simd()));
   /* every wave slot of the chip: one scratch slot per wavefront of the one-pair kernel, two per wavefront of the packed one */
-  return G_prop.multiProcessorCount * 4 * std::max(damar_report_waves_per_simd(), 2 * damar_report2_waves_per_simd());
+  return G_prop.multiProcessorCount * 4 * std::max(damar_report_waves_per_simd(), damar_report2_slots_per_wave() * damar_report2_waves_per_simd());
 }
 
 static int G_ring = 0;
@@ -1036,7 +1036,11 @@ static u32 grow_cells(u32 cell_cap)
 
 /* datander and the Local_Alignment batch entry have no wide kernel behind them: there the packed format's limit stays loud */
 static void marks_must_fit(int amax, int bmax, int tspace)
-{ if (tspace > 0 && std::max(amax, bmax) / tspace + 8 > DAMAR_MAX_MARKS)
+{ if (damar_report2_slots_per_wave() > 2 && (int64) amax + bmax >= DAMAR_MAX_ANTI)      /* (kernels/report_slots.h only) */
+    { fprintf(stderr, "damar: FATAL: reads of %d and %d bases are beyond this entry point (alen + blen < %d)\n", amax, bmax, DAMAR_MAX_ANTI);
+      die();
+    }
+  if (tspace > 0 && std::max(amax, bmax) / tspace + 8 > DAMAR_MAX_MARKS)
     { fprintf(stderr, "damar: FATAL: reads of %d bases need a trace spacing (-s) of at least %d here\n", std::max(amax, bmax),
               std::max(amax, bmax) / (DAMAR_MAX_MARKS - 8) + 1);
       die();
@@ -1108,7 +1112,7 @@ static void scratch_prepare(int amax, int bmax, int binshift, int tspace, u32 ce
               }
             if (VERBOSE)
               fprintf(stderr, "damar: %d instead of %d resident alignments (%.1f MB of scratch each)\n", fit, nslots, per / 1048576.);
-            nslots = fit & ~1;                 /* (a wavefront of the packed kernel holds two slots) */
+            nslots = fit - fit % damar_report2_slots_per_wave();      /* (a wavefront of the packed kernel holds that many slots) */
           }
       }
       RS.nslots = nslots;
@@ -1234,7 +1238,7 @@ static bool use_packed(const ReportArgs *ra, int amax, int bmax)
     { const char *e = getenv("DAMAR_PACKED");
       want = e ? atoi(e) : 1;
     }
-  if (!want || (RS.nslots & 1) || ra->tspace <= 0)
+  if (!want || (RS.nslots % damar_report2_slots_per_wave()) || ra->tspace <= 0)
     return false;
   if (ra->mscore * 8 > 32000 || ra->dscore * 8 > 32000)
     return false;
