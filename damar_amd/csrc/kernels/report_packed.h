@@ -158,11 +158,13 @@ __device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, co
       o.Y = (so.y ^ m) - m;  o.b = so.b;  o.na = so.na;  o.nb = so.nb;
       return o;
     }
-  u32 pa = 2u * (u32) (pa0 + X), pb = 2u * (u32) (pb0 + Y);         /* as bit positions: the window shift needs no doubling */
+  u32 pa = 2u * (u32) (pa0 + X), pb = 2u * (u32) (pb0 + Y);         /* as bit positions: the window shift needs no doubling (and is the
+                                                                       same for every 16 bases: only the word offsets move on) */
+  asm("" : "+v"(pa), "+v"(pb));                                      /* (one add-and-shift each; the offsets from them, not from the sums again) */
+  u32 oa = (pa >> 3) & ~3u, ob = (pb >> 3) & ~3u;
   for (;;)
     { u32 wa, wb;
       { typedef u32 v2u __attribute__((ext_vector_type(2)));
-        const u32 oa = (pa >> 3) & ~3u, ob = (pb >> 3) & ~3u;
         v2u ra, rb;                                                  /* both loads in flight together, ONE wait (as load16x2) */
         asm volatile("global_load_dwordx2 %0, %2, %4\n\tglobal_load_dwordx2 %1, %3, %5\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(ra), "=&v"(rb) : "v"(oa), "v"(ob), "s"(apk - PK_PAD), "s"(bpk - PK_PAD) : "memory");
@@ -176,7 +178,7 @@ __device__ __forceinline__ DuoSnake duo_snake(const u32 *apk, const u32 *bpk, co
       Y += n;  na -= n;  nb -= n;
       if (n < 16 || lim == 16)
         break;
-      pa += 32;  pb += 32;
+      oa += 4;  ob += 4;
     }
   o.Y = Y;  o.b = b;  o.na = na;  o.nb = nb;
   return o;
@@ -730,7 +732,8 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
             st_iter += 1;  st_cells += (u32) __popcll(actm);
           }
 
-          int Y = 0, na = 1, nb = 1;
+          int Y, na, nb;                            /* (of the lanes that do not step these stay undefined: every use is behind actm) */
+          asm volatile("" : "=v"(Y), "=v"(na), "=v"(nb));
           if (inv(actm))
             { b <<= 1;
               const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, pa0, pb0, va0, vb0, alen, blen, K, (v - K) >> 1, b);

@@ -1595,6 +1595,7 @@ struct TailJob
   int  last;
   damar_write_params wp;                     /* stage 2 */
   Overlap_IO_Buffer *bufs;
+  int64 *got;                                /* kind 0, -v only: where the caller wants the number of confirmed hits (it drains before it reads) */
 };
 
 /* Heap objects that are never destroyed: at process exit a worker may still be parked in
@@ -1664,6 +1665,8 @@ static void tail_worker(void)
           int64 n = run_tail(job->hb->recs, job->hb->nrec, job->hb->tpool, job->hb->t8,
                                job->hb->nwide ? job->hb->wmap + job->hb->wm_off[job->jobid] : (const u32 *) NULL, &job->ablock, &job->bblock,
                              job->self, job->comp, job->spec, job->jp, job->jobid, job->njobs);
+          if (job->got != NULL)
+            *job->got = n;
           if (--job->hb->users == 0)
             hostbuf_put(job->hb);
           delete job;
@@ -2421,6 +2424,7 @@ static void report_finish(Pending &pd)
           tj->hb = hb;  tj->jobid = j;  tj->njobs = n;
           tj->ablock = *jb.ablock;  tj->bblock = *jb.bblock;
           tj->self = jb.self;  tj->comp = jb.comp;  tj->spec = jb.spec;  tj->jp = pd.fr[j].jp;
+          tj->got = (VERBOSE && pd.orig[j] != NULL) ? &pd.orig[j]->counts[2] : NULL;
           async_submit(tj);
         }
       else
@@ -2714,6 +2718,8 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   job.ablock = ablock;  job.bblock = bblock;  job.aidx = aidx;  job.bidx = bidx;
   job.self = self;  job.comp = comp;  job.spec = spec;
   damar_match_batch(&job, 1);
+  if (VERBOSE)
+    damar_async_drain();                         /* (the confirmed hits are counted by the host tail) */
   if (counts)
     { counts[0] = job.counts[0];  counts[1] = job.counts[1];  counts[2] = job.counts[2]; }
   if (VERBOSE)
