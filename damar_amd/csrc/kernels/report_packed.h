@@ -671,7 +671,8 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
 /* The wave steps (align.c:667-999 / 1378-1697) of the halves with md == MD_RUN, until one of them has an event: its
    direction is over (or failed), or its band no longer fits lanes 1..30.  The caller tells which from the state
    (duo_classify); on entry every such half can step (duo_classify has been through). */
-DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
+DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)      /* (a part of duo_run since round 5: the loop still spills nothing, and the call's
+                                                                          callee-saved registers were a tenth of the kernel's memory traffic) */
 { DUO_NAMES()
   DUO_CX();
   const int ave = uni(a.ave_path);
