@@ -32,71 +32,77 @@ typedef struct
   int    only_identity;
 } Spec;
 
-/* align.c:198-199 */
+/* align.c:198-199: how much of the error rate a base composition leaves, by how far A+T is from one half */
 static const double bias_factor[10] = { .690, .690, .690, .690, .780, .850, .900, .933, .966, 1.000 };
 
-/* align.c:234-318: TABLE[x] = (score of the 15 columns in x) - (largest score of a
- * proper prefix of them), so TABLE[x] >= 0 iff every suffix scores non-negative;
- * SCORE[x] = total.  Bit 14 of x is the oldest column. */
-Align_Spec *New_Align_Spec(double ave_corr, int trace_space, float *freq, int nthreads,
-                           int symmetric, int only_identity, int no_trace_points, int reach)
-{ Spec  *s = (Spec *) malloc(sizeof(Spec));
-  double match;
-  int    bias, mscore, dscore, x, i;
-
-  if (s == NULL)
-    { fprintf(stderr, "damar: out of memory (alignment specification)\n");
-      exit(1);
-    }
-  s->ave_corr    = ave_corr;
-  s->trace_space = trace_space;
-  s->reach       = reach;
-  for (i = 0; i < 4; i++)
-    s->freq[i] = freq[i];
-
-  match = freq[0] + freq[3];
-  if (match > .5)
-    match = 1. - match;
-  bias = (int) ((match + .025) * 20. - 1.);
-  if (match < .2)
-    { fprintf(stderr, "Warning: Base bias worse than 80/20%% ! (New_Align_Spec)\n");
-      fprintf(stderr, "         Capping bias at this ratio.\n");
-      bias = 3;
-    }
-  s->ave_path = (int) (PATH_LEN * (1. - bias_factor[bias] * (1. - ave_corr)));
-  mscore = (int) (FRACTION * bias_factor[bias] * (1. - ave_corr));
-  dscore = FRACTION - mscore;
-
-  s->score = (int16 *) malloc(sizeof(int16) * 2 * TRIM_SIZE);
-  if (s->score == NULL)
+/* The two 15-column tables of the trim test (align.c:234-318).  A word x holds 15 columns of an alignment, bit 14 the
+ * oldest, 1 = match.  SCORE[x] = sum over its columns of (+mscore for a match, -dscore otherwise); TABLE[x] = SCORE[x]
+ * minus the largest score of a proper prefix (the empty one included), i.e. TABLE[x] >= 0 iff no suffix of x scores
+ * negative.  Built column by column: dropping the NEWEST column of x gives x >> 1 with one column less, so a word's
+ * prefix scores are those of (x >> 1) taken as a 14-column word, and so on down to the empty word. */
+static void trim_tables(int mscore, int dscore, int16 *score, int16 *table)
+{ int *total = (int *) malloc(sizeof(int) * TRIM_SIZE);        /* score of the columns seen so far */
+  int *best  = (int *) malloc(sizeof(int) * TRIM_SIZE);        /* largest score of a proper prefix of them */
+  int  cols, x;
+  if (total == NULL || best == NULL)
     { fprintf(stderr, "damar: out of memory (trim tables)\n");
       exit(1);
     }
-  s->table = s->score + TRIM_SIZE;
+  total[0] = best[0] = 0;                                       /* words of 0 columns: index 0 only */
+  for (cols = 1; cols <= TRIM_BITS; cols++)                     /* words of `cols` columns live at indexes < 2^cols */
+    for (x = (1 << cols) - 1; x >= 0; x--)                      /* (downwards: x >> 1 < x is still the shorter word's entry) */
+      { const int shorter = x >> 1;
+        const int before  = total[shorter];
+        best[x]  = best[shorter] > before ? best[shorter] : before;
+        total[x] = before + ((x & 1) ? mscore : -dscore);
+      }
   for (x = 0; x < TRIM_SIZE; x++)
-    { int sc = 0, mx = 0;
-      for (i = TRIM_BITS - 1; i >= 0; i--)
-        { if (sc > mx)
-            mx = sc;
-          if ((x >> i) & 1)
-            sc += mscore;
-          else
-            sc -= dscore;
-        }
-      s->table[x] = (int16) (sc - mx);
-      s->score[x] = (int16) sc;
+    { score[x] = (int16) total[x];
+      table[x] = (int16) (total[x] - best[x]);
     }
+  free(total);
+  free(best);
+}
 
-  s->nthreads      = nthreads;
-  s->symmetric     = symmetric;
-  s->only_identity = only_identity;
+Align_Spec *New_Align_Spec(double ave_corr, int trace_space, float *freq, int nthreads,
+                           int symmetric, int only_identity, int no_trace_points, int reach)
+{ Spec  *s = (Spec *) calloc(1, sizeof(Spec));
+  const int tbytes = (trace_space <= TRACE_XOVR) ? 1 : 2;
+  double at, left;
+  int    step, t;
+
+  if (s == NULL || (s->score = (int16 *) malloc(sizeof(int16) * 2 * TRIM_SIZE)) == NULL)
+    { fprintf(stderr, "damar: out of memory (alignment specification)\n");
+      exit(1);
+    }
+  s->table = s->score + TRIM_SIZE;
+  memcpy(s->freq, freq, sizeof(s->freq));
+  s->ave_corr = ave_corr;  s->trace_space = trace_space;  s->reach = reach;
+  s->nthreads = nthreads;  s->symmetric = symmetric;      s->only_identity = only_identity;
+
+  /* composition: the smaller of A+T and C+G, in steps of 5 % from 5 % on; below 20 % it is taken as 20 % */
+  at = (double) freq[0] + freq[3];
+  if (at > .5)
+    at = 1. - at;
+  step = (int) ((at + .025) * 20. - 1.);
+  if (at < .2)
+    { fprintf(stderr, "Warning: Base bias worse than 80/20%% ! (New_Align_Spec)\n");
+      fprintf(stderr, "         Capping bias at this ratio.\n");
+      step = 3;
+    }
+  left = bias_factor[step] * (1. - ave_corr);                   /* the share of columns that may differ */
+  s->ave_path = (int) (PATH_LEN * (1. - left));
+  { const int mscore = (int) (FRACTION * left);
+    trim_tables(mscore, FRACTION - mscore, s->score, s->table);
+  }
+
   s->iobuf = (Overlap_IO_Buffer *) malloc(sizeof(Overlap_IO_Buffer) * (size_t) (nthreads > 0 ? nthreads : 1));
-  for (i = 0; i < nthreads; i++)
-    { Overlap_IO_Buffer *ob = CreateOverlapBuffer(nthreads, (trace_space <= TRACE_XOVR) ? 1 : 2, no_trace_points);
-      if (ob == NULL)
+  for (t = 0; t < nthreads; t++)
+    { Overlap_IO_Buffer *one = CreateOverlapBuffer(nthreads, tbytes, no_trace_points);
+      if (one == NULL)
         exit(1);
-      s->iobuf[i] = *ob;
-      free(ob);
+      s->iobuf[t] = *one;
+      free(one);
     }
   return (Align_Spec *) s;
 }
@@ -127,35 +133,47 @@ const int16 *damar_spec_score_table(Align_Spec *spec) { return ((Spec *) spec)->
 const int16 *damar_spec_trim_table(Align_Spec *spec)  { return ((Spec *) spec)->table; }
 int          damar_spec_ave_path(Align_Spec *spec)    { return ((Spec *) spec)->ave_path; }
 
-/* align.c:5969-6018 */
+/* A thread's buffer of overlaps and their traces (align.c:5969-6018): room for 500 000 / nthreads records to start with and
+ * 150 trace values per record; both grow by a fifth + 1000 when they are full (AddOverlapToBuffer). */
 Overlap_IO_Buffer *CreateOverlapBuffer(int nthreads, int tbytes, int no_trace)
-{ Overlap_IO_Buffer *b = (Overlap_IO_Buffer *) calloc(1, sizeof(Overlap_IO_Buffer));
-  if (b == NULL)
-    return NULL;
-  b->omax = 500000 / nthreads + 1;
-  b->ovls = (Overlap *) calloc((size_t) b->omax, sizeof(Overlap));
-  b->no_trace = no_trace;
-  if (b->ovls == NULL)
-    return NULL;
-  if (no_trace)
-    return b;
-  if (tbytes < 1 || tbytes > 2)
+{ Overlap_IO_Buffer *buf;
+  const int records = 500000 / nthreads + 1;
+
+  if (!no_trace && tbytes != 1 && tbytes != 2)
     { fprintf(stderr, "[ERROR] - Unsupported size of trace: %d!\n", tbytes);
       return NULL;
     }
-  b->tbytes = tbytes;
-  b->tmax   = (uint64) b->omax * 150;
-  b->trace  = malloc((size_t) b->tmax * (size_t) tbytes);
-  if (b->trace == NULL)
+  buf = (Overlap_IO_Buffer *) calloc(1, sizeof(Overlap_IO_Buffer));
+  if (buf == NULL || (buf->ovls = (Overlap *) calloc((size_t) records, sizeof(Overlap))) == NULL)
     return NULL;
-  return b;
+  buf->omax = records;
+  buf->no_trace = no_trace;
+  if (!no_trace)
+    { buf->tbytes = tbytes;
+      buf->tmax   = 150ull * (uint64) records;
+      if ((buf->trace = malloc((size_t) buf->tmax * (size_t) tbytes)) == NULL)
+        return NULL;
+    }
+  return buf;
 }
 
-/* align.c:6020-6102.  Traces are kept as byte offsets while the pool may still
- * move; they are turned into pointers when the buffer is drained. */
+/* room for `more` further trace bytes behind ttop (the pool's size is tmax VALUES of tbytes bytes) */
+static int trace_room(Overlap_IO_Buffer *b, uint64 more)
+{ const uint64 want = b->ttop + more;
+  if (want < b->tmax * (uint64) b->tbytes)
+    return 0;
+  do
+    b->tmax = (uint64) (b->tmax * 1.2) + 1000;
+  while (want >= b->tmax * (uint64) b->tbytes);
+  b->trace = realloc(b->trace, (size_t) b->tmax * (size_t) b->tbytes);
+  return b->trace == NULL;
+}
+
+/* align.c:6020-6102.  A record's trace is kept as its byte offset in the pool + 1 while the pool may still move; the
+ * offsets become pointers when the buffer is drained (write_buffers). */
 int AddOverlapToBuffer(Overlap_IO_Buffer *b, Overlap *ovl, int tbytes)
-{ Overlap *o;
-  int      keep;
+{ const int traced = b != NULL && ovl->path.trace != NULL && !b->no_trace;
+  Overlap  *slot;
 
   if (b == NULL)
     { fprintf(stderr, "[ERROR] - Cannot add overlap to Overlap_IO_Buffer. Buffer is NULL!\n");
@@ -163,47 +181,26 @@ int AddOverlapToBuffer(Overlap_IO_Buffer *b, Overlap *ovl, int tbytes)
     }
   if (b->otop == b->omax)
     { b->omax = (int) (b->omax * 1.2) + 1000;
-      b->ovls = (Overlap *) realloc(b->ovls, sizeof(Overlap) * (size_t) b->omax);
-      if (b->ovls == NULL)
+      if ((b->ovls = (Overlap *) realloc(b->ovls, sizeof(Overlap) * (size_t) b->omax)) == NULL)
         { fprintf(stderr, "[ERROR] - Cannot increase overlap buffer size to %d!\n", b->omax);
           return 1;
         }
     }
-  keep = (ovl->path.trace != NULL && !b->no_trace);
-  if (keep)
-    { uint64 need = b->ttop + (uint64) tbytes * (uint64) ovl->path.tlen;
-      if (need >= b->tmax * (uint64) b->tbytes)
-        { while (need >= b->tmax * (uint64) b->tbytes)
-            b->tmax = (uint64) (b->tmax * 1.2) + 1000;
-          b->trace = realloc(b->trace, (size_t) b->tmax * (size_t) b->tbytes);
-          if (b->trace == NULL)
-            { fprintf(stderr, "[ERROR] - Cannot increase trace point buffer size to %llu!\n",
-                      (unsigned long long) b->tmax);
-              return 1;
-            }
+  slot  = b->ovls + b->otop++;
+  *slot = *ovl;                                   /* reads, flags, end points, differences */
+  slot->path.trace = NULL;
+  slot->path.tlen  = 0;
+  if (traced)
+    { const uint64 bytes = (uint64) tbytes * (uint64) ovl->path.tlen;
+      if (trace_room(b, bytes))
+        { fprintf(stderr, "[ERROR] - Cannot increase trace point buffer size to %llu!\n", (unsigned long long) b->tmax);
+          return 1;
         }
+      memcpy((char *) b->trace + b->ttop, ovl->path.trace, (size_t) bytes);
+      slot->path.tlen  = ovl->path.tlen;
+      slot->path.trace = (void *) (uintptr_t) (b->ttop + 1);
+      b->ttop += bytes;
     }
-  o = b->ovls + b->otop;
-  memset(o, 0, sizeof(Overlap));
-  o->aread      = ovl->aread;
-  o->bread      = ovl->bread;
-  o->flags      = ovl->flags;
-  o->path.abpos = ovl->path.abpos;
-  o->path.aepos = ovl->path.aepos;
-  o->path.bbpos = ovl->path.bbpos;
-  o->path.bepos = ovl->path.bepos;
-  o->path.diffs = ovl->path.diffs;
-  if (keep)
-    { o->path.tlen  = ovl->path.tlen;
-      memcpy(((char *) b->trace) + b->ttop, ovl->path.trace, (size_t) tbytes * (size_t) ovl->path.tlen);
-      o->path.trace = (void *) (uintptr_t) (b->ttop + 1);      /* offset+1, resolved on write */
-      b->ttop += (uint64) tbytes * (uint64) ovl->path.tlen;
-    }
-  else
-    { o->path.trace = NULL;
-      o->path.tlen  = 0;
-    }
-  b->otop += 1;
   return 0;
 }
 
@@ -223,14 +220,8 @@ int damar_append_overlap_buffer(Overlap_IO_Buffer *dst, const Overlap_IO_Buffer 
     }
   base = dst->ttop;
   if (!dst->no_trace && src->ttop > 0)
-    { uint64 need = dst->ttop + src->ttop;
-      if (need >= dst->tmax * (uint64) dst->tbytes)
-        { while (need >= dst->tmax * (uint64) dst->tbytes)
-            dst->tmax = (uint64) (dst->tmax * 1.2) + 1000;
-          dst->trace = realloc(dst->trace, (size_t) dst->tmax * (size_t) dst->tbytes);
-          if (dst->trace == NULL)
-            return 1;
-        }
+    { if (trace_room(dst, src->ttop))
+        return 1;
       memcpy(((char *) dst->trace) + dst->ttop, src->trace, (size_t) src->ttop);
       dst->ttop += src->ttop;
     }
@@ -244,18 +235,25 @@ int damar_append_overlap_buffer(Overlap_IO_Buffer *dst, const Overlap_IO_Buffer 
   return 0;
 }
 
-/* align.c:3375-3396 */
+/* A trace of 16-bit values narrowed to bytes in place (align.c:3375-3396); with `check`, a value that does not fit a byte
+ * ends the program.  The largest value is looked for first: nothing is narrowed of a trace that does not fit. */
 int Compress_TraceTo8(Overlap *ovl, int check)
-{ uint16 *t16 = (uint16 *) ovl->path.trace;
-  uint8  *t8  = (uint8 *) ovl->path.trace;
-  int     j;
-  for (j = 0; j < ovl->path.tlen; j++)
-    { if (check && t16[j] > 255)
+{ const int     n    = ovl->path.tlen;
+  const uint16 *wide = (const uint16 *) ovl->path.trace;
+  uint8        *out  = (uint8 *) ovl->path.trace;
+  int           k;
+  if (check)
+    { uint16 top = 0;
+      for (k = 0; k < n; k++)
+        if (wide[k] > top)
+          top = wide[k];
+      if (top > 255)
         { fprintf(stderr, "damar: Compression of trace to bytes fails, value too big\n");
           exit(1);
         }
-      t8[j] = (uint8) t16[j];
     }
+  for (k = 0; k < n; k++)
+    out[k] = (uint8) wide[k];
   return 0;
 }
 
@@ -304,22 +302,23 @@ static int by_overlap(const void *x, const void *y)
   return (kl->seq < kr->seq) ? -1 : (kl->seq > kr->seq);
 }
 
+/* a .las file: the number of records (8 bytes, filled in when the file is closed), the trace spacing (4), the records */
 static FILE *open_las(const char *path, int tspace)
-{ FILE *out = fopen(path, "w");
-  int64 zero = 0;
+{ unsigned char head[sizeof(int64) + sizeof(int)] = { 0 };
+  FILE *out = fopen(path, "w");
   if (out == NULL)
     { fprintf(stderr, "[ERROR] - Write_Overlap_Buffer: Cannot open file %s for writing\n", path);
       exit(1);
     }
   setvbuf(out, NULL, _IOFBF, 1 << 20);           /* (a record is two small fwrites: 4 KB of stdio buffer is a write() per 25 records) */
-  fwrite(&zero, sizeof(int64), 1, out);
-  fwrite(&tspace, sizeof(int), 1, out);
+  memcpy(head + sizeof(int64), &tspace, sizeof(int));
+  fwrite(head, sizeof(head), 1, out);
   return out;
 }
 
 static void close_las(FILE *out, int64 n)
-{ rewind(out);
-  fwrite(&n, sizeof(int64), 1, out);
+{ if (fseek(out, 0L, SEEK_SET) == 0)
+    fwrite(&n, sizeof(n), 1, out);
   fclose(out);
 }
 
