@@ -437,6 +437,7 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab)
       bool on = false;
       int nin = 0;
       u32 gslo = 0;                                 /* first lanes of the segments, a byte each, in lane order */
+      int wneed = 0;
       const u32 it0 = st_iter;
       wave_mem_sync();                              /* (the band state was written by other lanes) */
       { const int rot = uni((int) duo_half[0].n_deal) + (int) st_deal;
@@ -451,6 +452,8 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab)
             int want = bw + 4 + DUO_MARGIN;
             if (want > DUO_BW) want = DUO_BW;
             if (want > room) want = (room >= bw + 6) ? room : 0;
+            if (want == 0 && (wneed == 0 || bw + 4 + DUO_MARGIN < wneed))
+              wneed = bw + 4 + DUO_MARGIN;         /* the smallest segment a waiting slot would take (its band does not change while it waits) */
             wpk |= (u32) want << (8 * j);
             tot += want;  nin += (want > 0);
           }
@@ -705,7 +708,7 @@ DUO_PIECE void duo_loop(int job, const u32 *trimtab)
             if (k < nin)
               tot += hsk[k] - lsk[k] + 1 + 4 + DUO_MARGIN;
           }
-        if (tot > 64)
+        if (tot > 64 || (wneed != 0 && tot + wneed <= 64))          /* somebody has to wait, or somebody who waits fits now: deal through LDS */
           break;
         const int extra = (64 - tot) / nin;
         int off = 0, osl = lane, nsl = lane, nwd = 1, dlv = 0, lsv = 1, hsv = 0;
