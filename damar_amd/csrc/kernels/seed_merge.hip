@@ -831,6 +831,18 @@ void pair_heads_mark(const K *__restrict__ keys, u64 nhits, int pbits, int minhi
   const int l = lane_id(), w = threadIdx.x >> 6;
   const u64 base = (u64) blockIdx.x * DAMAR_SCAN_TILE;
   u32 mine = 0;
+  /* the slice ends that can matter to a seed of this tile: the first one beyond the tile's start and the one after it
+     (found once per workgroup; the walk over all of them per run head was most of this kernel's scalar instructions) */
+  u64 e0 = ~0ull, e1 = ~0ull;
+  for (int t = 0; t < nthr; t++)
+    { const u64 e = send[t];
+      if (e > base)
+        { e0 = e;
+          if (t + 1 < nthr)
+            e1 = send[t + 1];
+          break;
+        }
+    }
   /* four rounds' loads are issued before the first is looked at (from clamped addresses, so that none sits behind a
      branch): one round at a time the workgroup waited out a memory round trip per round, 16 per tile */
   for (int r0 = 0; r0 < PH_ROUNDS; r0 += 4)
@@ -853,13 +865,18 @@ void pair_heads_mark(const K *__restrict__ keys, u64 nhits, int pbits, int minhi
             { const K pr = k0[q] >> pbits;
               if ((i == 0 || (km[q] >> pbits) != pr) && i + (u64) (minhit - 1) < nhits && (kp[q] >> pbits) == pr)
                 { f = true;
-                  for (int t = 0; t < nthr; t++)
-                    { u64 e = send[t];
-                      if (i < e)
-                        { if (i + (u64) minhit >= e) f = false;
-                          break;
-                        }
-                    }
+                  if (i < e0)
+                    { if (i + (u64) minhit >= e0) f = false; }
+                  else if (i < e1)
+                    { if (i + (u64) minhit >= e1) f = false; }
+                  else                           /* (three slice ends inside one tile: slices of a few hundred seeds) */
+                    for (int t = 0; t < nthr; t++)
+                      { u64 e = send[t];
+                        if (i < e)
+                          { if (i + (u64) minhit >= e) f = false;
+                            break;
+                          }
+                      }
                 }
             }
           const u64 m = __ballot(f);
