@@ -1581,6 +1581,7 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool, int t8
  * second thread) sorts and writes the detached buffers.  The overlap buffers of an Align_Spec
  * are touched by stage 1 only; damar_async_drain() must be called before the blocks or the
  * Align_Spec involved are released, and before the counters are read. */
+static bool G_tail_reports = false;          /* a tail job writes its number of confirmed hits into the caller's job struct (damar_match with -v) */
 struct TailJob
 { int kind;                                  /* 0 = tail of one Match_Filter, 1 = write + reset */
   HostBuf *hb;
@@ -2424,7 +2425,7 @@ static void report_finish(Pending &pd)
           tj->hb = hb;  tj->jobid = j;  tj->njobs = n;
           tj->ablock = *jb.ablock;  tj->bblock = *jb.bblock;
           tj->self = jb.self;  tj->comp = jb.comp;  tj->spec = jb.spec;  tj->jp = pd.fr[j].jp;
-          tj->got = (VERBOSE && pd.orig[j] != NULL) ? &pd.orig[j]->counts[2] : NULL;
+          tj->got = (G_tail_reports && pd.orig[j] != NULL) ? &pd.orig[j]->counts[2] : NULL;   /* (only for a caller that drains before its job struct goes: damar_match) */
           async_submit(tj);
         }
       else
@@ -2717,9 +2718,11 @@ extern "C" void damar_match(const HITS_DB *ablock, const HITS_DB *bblock,
   memset(&job, 0, sizeof(job));
   job.ablock = ablock;  job.bblock = bblock;  job.aidx = aidx;  job.bidx = bidx;
   job.self = self;  job.comp = comp;  job.spec = spec;
+  G_tail_reports = VERBOSE != 0;                 /* -v: the confirmed hits are counted by the host tail, which may run behind this call */
   damar_match_batch(&job, 1);
-  if (VERBOSE)
-    damar_async_drain();                         /* (the confirmed hits are counted by the host tail) */
+  if (G_tail_reports)
+    damar_async_drain();
+  G_tail_reports = false;
   if (counts)
     { counts[0] = job.counts[0];  counts[1] = job.counts[1];  counts[2] = job.counts[2]; }
   if (VERBOSE)
