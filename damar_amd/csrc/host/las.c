@@ -9,6 +9,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <pthread.h>
+#include <unistd.h>
+#include <fcntl.h>
+#include <errno.h>
 
 #include "damar_align.h"
 #include "damar_host.h"
@@ -302,24 +305,78 @@ static int by_overlap(const void *x, const void *y)
   return (kl->seq < kr->seq) ? -1 : (kl->seq > kr->seq);
 }
 
-/* a .las file: the number of records (8 bytes, filled in when the file is closed), the trace spacing (4), the records */
-static FILE *open_las(const char *path, int tspace)
-{ unsigned char head[sizeof(int64) + sizeof(int)] = { 0 };
-  FILE *out = fopen(path, "w");
-  if (out == NULL)
-    { fprintf(stderr, "[ERROR] - Write_Overlap_Buffer: Cannot open file %s for writing\n", path);
-      exit(1);
-    }
-  setvbuf(out, NULL, _IOFBF, 1 << 20);           /* (a record is two small fwrites: 4 KB of stdio buffer is a write() per 25 records) */
-  memcpy(head + sizeof(int64), &tspace, sizeof(int));
-  fwrite(head, sizeof(head), 1, out);
-  return out;
+/* A .las file under construction: the number of records (8 bytes, filled in when the file is closed), the trace spacing
+ * (4), then the records.  Records are assembled in a buffer of the writer's own and leave with one write() per 4 MB:
+ * through stdio a record was two fwrite calls, which was most of a writer thread's time (1.7 M records per config-2
+ * step). */
+typedef struct { int fd; char *buf; size_t fill, cap; const char *path; } LasOut;
+
+static void las_fail(const LasOut *o, const char *what)
+{ fprintf(stderr, "[ERROR] - Write_Overlap_Buffer: Cannot %s file %s\n", what, o->path);
+  exit(1);
 }
 
-static void close_las(FILE *out, int64 n)
-{ if (fseek(out, 0L, SEEK_SET) == 0)
-    fwrite(&n, sizeof(n), 1, out);
-  fclose(out);
+static void las_flush(LasOut *o)
+{ size_t done = 0;
+  while (done < o->fill)
+    { const ssize_t w = write(o->fd, o->buf + done, o->fill - done);
+      if (w < 0)
+        { if (errno == EINTR)
+            continue;
+          las_fail(o, "write to");
+        }
+      done += (size_t) w;
+    }
+  o->fill = 0;
+}
+
+static void las_put(LasOut *o, const void *src, size_t n)
+{ if (o->fill + n > o->cap)
+    { las_flush(o);
+      if (n > o->cap)                              /* (a trace longer than the buffer: straight through) */
+        { LasOut big = *o;
+          big.buf = (char *) src;  big.fill = n;
+          las_flush(&big);
+          return;
+        }
+    }
+  memcpy(o->buf + o->fill, src, n);
+  o->fill += n;
+}
+
+static LasOut las_open(const char *path, int tspace)
+{ LasOut  o;
+  int64   none = 0;
+  o.path = path;
+  o.cap  = (size_t) 4 << 20;
+  o.fill = 0;
+  o.buf  = (char *) malloc(o.cap);
+  o.fd   = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  if (o.fd < 0 || o.buf == NULL)
+    las_fail(&o, "open for writing");
+  las_put(&o, &none, sizeof(none));
+  las_put(&o, &tspace, sizeof(tspace));
+  return o;
+}
+
+/* the 40 bytes of a record on disk (the Overlap minus its leading pointer, align.c:3345-3373) and its trace */
+static void las_record(LasOut *o, const Keyed *k, int tbytes)
+{ const Overlap *v = k->ovl;
+  int32_t rec[10];
+  rec[0] = v->path.tlen;   rec[1] = v->path.diffs;
+  rec[2] = v->path.abpos;  rec[3] = v->path.bbpos;  rec[4] = v->path.aepos;  rec[5] = v->path.bepos;
+  rec[6] = (int32_t) v->flags;
+  rec[7] = v->aread;       rec[8] = v->bread;       rec[9] = 0;
+  las_put(o, rec, sizeof(rec));
+  if (k->trace != NULL && v->path.tlen > 0)
+    las_put(o, k->trace, (size_t) tbytes * (size_t) v->path.tlen);
+}
+
+static void las_close(LasOut *o, int64 n)
+{ las_flush(o);
+  if (pwrite(o->fd, &n, sizeof(n), 0) != (ssize_t) sizeof(n) || close(o->fd) != 0)
+    las_fail(o, "finish");
+  free(o->buf);
 }
 
 /* "NAME.7" -> root "NAME", id 7; no dot -> id 0 (align.c:6206-6228) */
@@ -383,21 +440,15 @@ static Keyed *sort_keyed(Keyed *all, int n)
   return out;
 }
 
-static void write_keyed(FILE *out, const Keyed *k, int tbytes)
-{ Overlap o = *k->ovl;
-  o.path.trace = (void *) k->trace;
-  Write_Overlap(out, &o, tbytes);
-}
-
 typedef struct { const char *path; int tspace, tbytes; const Keyed *recs; int n; } FilePart;
 
 static void *write_file_part(void *arg)
 { const FilePart *f = (const FilePart *) arg;
-  FILE *out = open_las(f->path, f->tspace);
-  int   j;
+  LasOut out = las_open(f->path, f->tspace);
+  int    j;
   for (j = 0; j < f->n; j++)
-    write_keyed(out, f->recs + j, f->tbytes);
-  close_las(out, f->n);
+    las_record(&out, f->recs + j, f->tbytes);
+  las_close(&out, f->n);
   return NULL;
 }
 
@@ -411,7 +462,6 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
   char    aroot[2048], broot[2048];
   int     aid, bid;
   char    path1[4300], path2[4300];
-  FILE   *out;
 
   for (i = 0; i < s->nthreads; i++)
     total += iobuf[i].otop;
@@ -441,10 +491,10 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
         snprintf(path1, sizeof(path1), "%s/%s.%d.%s.%d.las", dir1, aroot, aid, broot, bid);
       else
         snprintf(path1, sizeof(path1), "%s.las", ablock);
-      out = open_las(path1, tspace);
-      for (j = 0; j < n; j++)
-        write_keyed(out, all + j, tbytes);
-      close_las(out, n);
+      { FilePart whole;
+        whole.path = path1;  whole.tspace = tspace;  whole.tbytes = tbytes;  whole.recs = all;  whole.n = n;
+        write_file_part(&whole);
+      }
     }
   else
     { if (aid > 0)
