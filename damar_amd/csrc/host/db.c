@@ -441,23 +441,28 @@ static void rc_copy(char *dst, const char *src, int len)
     dst[j] = (char) (3 - src[len - 1 - j]);
 }
 
-/* Mirror the mask intervals of every read, [b,e) -> [rlen-e, rlen-b) (which also reverses their order),
-   daligner.c:572-626: from (tano, tata) into (anno, data), which may be the same arrays. */
+/* The mask intervals of a block seen from the other strand (what daligner.c:572-626 leaves behind): an interval
+   [b, e) of a read of rlen bases is [rlen - e, rlen - b) there, and a read's intervals come in the opposite order.  A
+   read's stretch of the data array is its interval ends in ascending order; seen as ONE list of positions p_0 < p_1 < ...
+   < p_{n-1}, the other strand's list is rlen - p_{n-1}, ..., rlen - p_0: entry q of the result is rlen minus entry
+   n - 1 - q of the source.  (tano, tata) -> (anno, data); the two may be the same arrays, so a stretch is flipped by
+   exchanging its two ends' partners, the middle entry of an odd stretch with itself. */
 static void mirror_track(const HITS_DB *block, const int64 *tano, const int *tata, int64 *anno, int *data)
-{ int i;
-  for (i = 0; i < block->nreads; i++)
-    { int   rlen = block->reads[i].rlen;
-      int64 j = tano[i + 1] - 1, k = tano[i];
-      anno[i] = tano[i];
-      while (k < j)
-        { int y = tata[j];
-          data[j--] = rlen - tata[k];
-          data[k++] = rlen - y;
+{ const int nreads = block->nreads;
+  int r;
+  for (r = 0; r <= nreads; r++)
+    anno[r] = tano[r];
+  for (r = 0; r < nreads; r++)
+    { const int   rlen = block->reads[r].rlen;
+      const int64 first = tano[r], n = tano[r + 1] - first;
+      int64 q;
+      for (q = 0; 2 * q < n; q++)
+        { const int64 lo = first + q, hi = first + (n - 1 - q);
+          const int   plo = tata[lo], phi = tata[hi];
+          data[lo] = rlen - phi;
+          data[hi] = rlen - plo;
         }
-      if (k == j)
-        data[k] = rlen - tata[k];
     }
-  anno[block->nreads] = tano[block->nreads];
 }
 
 /* Reverse-complemented copy of a loaded block into *out (daligner.c:511-628 on a copy): own bases and own

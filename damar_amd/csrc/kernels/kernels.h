@@ -246,8 +246,6 @@ void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks,
 void damar_launch_report2(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
 void damar_launch_tandem_report2(const ReportArgs *a, const int *dist, int nslots, hipStream_t st);     /* datander through the same kernel */
 #define DAMAR_MAX_MARKS 16000         /* trace-grid indexes ride in the top 14 bits of a chain head (report.hip PK_HBITS) */
-#define DAMAR_MAX_ANTI  (1 << 26)     /* alen + blen of a pair of the slot kernel (the experiment kernels/report_slots.h, -DDAMAR_SLOT_KERNEL): its wave
-                                         loop lifts the anti-diagonals of a segment of lanes by its first lane x 2^25, segments at least 7 lanes apart */
 #define DAMAR_MAX_CELLS (1u << 18)    /* pebbles per slot: 18 bits of a chain head */
 
 u64 damar_report_state_stride(int span);

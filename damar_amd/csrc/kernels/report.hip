@@ -1587,10 +1587,6 @@ __device__ __forceinline__ bool pair_is_wide(const ReportArgs &a, u32 item, int 
     return false;
   if ((alen > blen ? alen : blen) / a.tspace + 8 > DAMAR_MAX_MARKS)
     return true;
-#ifdef DAMAR_SLOT_KERNEL
-  if (alen + blen >= DAMAR_MAX_ANTI)
-    return true;
-#endif
   return (a.widemap[item >> 5] >> (item & 31)) & 1u;
 }
 
@@ -2050,11 +2046,7 @@ void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks,
   hipLaunchKernelGGL(la_batch_kernel, dim3(nslots), dim3(64), 0, st, tasks, ntasks);
 }
 
-#ifdef DAMAR_SLOT_KERNEL
-#include "report_slots.h"        /* the experiment of round 5: four read pairs per wavefront, lanes dealt out by band width */
-#else
 #include "report_packed.h"
-#endif
 
 /* see damar_preload_index (kmer_index.hip) */
 void damar_preload_report(void)

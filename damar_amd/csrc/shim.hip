@@ -1036,11 +1036,7 @@ static u32 grow_cells(u32 cell_cap)
 
 /* datander and the Local_Alignment batch entry have no wide kernel behind them: there the packed format's limit stays loud */
 static void marks_must_fit(int amax, int bmax, int tspace)
-{ if (damar_report2_slots_per_wave() > 2 && (int64) amax + bmax >= DAMAR_MAX_ANTI)      /* (kernels/report_slots.h only) */
-    { fprintf(stderr, "damar: FATAL: reads of %d and %d bases are beyond this entry point (alen + blen < %d)\n", amax, bmax, DAMAR_MAX_ANTI);
-      die();
-    }
-  if (tspace > 0 && std::max(amax, bmax) / tspace + 8 > DAMAR_MAX_MARKS)
+{ if (tspace > 0 && std::max(amax, bmax) / tspace + 8 > DAMAR_MAX_MARKS)
     { fprintf(stderr, "damar: FATAL: reads of %d bases need a trace spacing (-s) of at least %d here\n", std::max(amax, bmax),
               std::max(amax, bmax) / (DAMAR_MAX_MARKS - 8) + 1);
       die();

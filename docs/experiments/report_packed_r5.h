@@ -61,7 +61,7 @@
 #define DUO_EXP_PEBBLE(x) x
 #endif
 int damar_report2_waves_per_simd(void) { return DUO_WAVES; }
-int damar_report2_slots_per_wave(void) { return 2; }
+int damar_report2_slots_per_wave(void) { return 2; }      /* (kernels/report_slots.h: the experiment with four) */
 
 __device__ __forceinline__ u32 hmask(u64 m, int hb) { return (u32) (m >> hb); }           /* this half's 32 bits */
 __device__ __forceinline__ int hget(int v, int hb, int s) { return __builtin_amdgcn_ds_bpermute((hb + s) << 2, v); }
@@ -134,34 +134,6 @@ __shared__ DuoCtx duo_half[2];
 __shared__ int duo_V[64], duo_HA[64], duo_HB[64], duo_acc[64];
 __shared__ u32 duo_Tlo[64], duo_Thi[64];
 #define DUO_CX()  DuoCtx &cx = duo_half[lane_id() >> 5]
-
-/* Trim points of the running pass (align.c:911-928 / 1620-1637), one slot per LANE: the wave loop only notes the event --
-   a record breaker with a good history and a good tail writes (V, K, head A, head B | dif) into the slot of the lane it
-   sits in -- and who was last is asked once, when the pass is over or the band leaves the lanes (duo_trim_settle): the V
-   of record breakers grows strictly from event to event, so the slot with the largest V is the reference's trim point,
-   whatever diagonal lived in its lane at the time.  (Round 5 elected the last such lane of a half in every step and
-   wrote the half's record from it: three find-first-bits, three gathers and four LDS writes in two steps of three.) */
-typedef int duo_v4i __attribute__((ext_vector_type(4)));
-__shared__ duo_v4i duo_tq[64];                  /* V, K, chain heads A / B as they ride in the lanes */
-__shared__ int     duo_td[64];                  /* dif */
-
-/* the trim events noted since the last call -> the half's record in duo_cold (every lane of the halves with `which`) */
-__device__ __forceinline__ void duo_trim_settle(bool which)
-{ const int lane = lane_id();
-  int *const cold = duo_cold + ((lane & 32) >> 1);
-  const int tv = duo_tq[lane].x;
-  int mx = tv;
-  for (int o = 1; o < 32; o <<= 1)
-    { const int t = __shfl_xor(mx, o);  mx = t > mx ? t : mx; }
-  if (which)
-    { if (tv == mx && tv != -BIG)
-        { const duo_v4i q = duo_tq[lane];
-          cold[DC_TRIM] = q.x;  cold[DC_TRIM + 1] = q.y;  cold[DC_TRIM + 2] = duo_td[lane];
-          cold[DC_TRIM + 3] = q.z & PK_HMASK;  cold[DC_TRIM + 4] = q.w & PK_HMASK;
-        }
-      duo_tq[lane].x = -BIG;
-    }
-}
 
 struct DuoSnake { int Y, na, nb;  u64 b; };
 
@@ -382,7 +354,6 @@ DUO_PART void duo_begin(int job, u32 cbase)
   DUO_CLIP()
   if (on)
     { duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
-      duo_tq[lane].x = -BIG;                       /* no trim event of this pass yet (duo_cold holds the seed diagonal's point) */
       cx.md = md;
       cx.ls = ls;  cx.hs = hs;  cx.kbase = kbase;  cx.dif = dif;  cx.besta = besta;  cx.bestk = bestk;
       cx.lasta = lasta;  cx.more = more;  cx.ncell = ncell;  cx.bad = bad;
@@ -395,396 +366,499 @@ DUO_PART void duo_begin(int job, u32 cbase)
    direction is over (or failed), or its band no longer fits lanes 1..30.  The caller tells which from the state
    (duo_classify); on entry every such half can step (duo_classify has been through).
 
-   Round 6: the step is written in the ONE coordinate the wave carries, v = 2 Y + K, against per-lane constants that only
-   change when the band is moved to the middle of its lanes (K = kbase - lane is fixed in between):
-     - the window of the packed bases starts at bit 2 (pa0 + X) = v + (2 pa0 + K) in A and at v + (2 pb0 - K) in B;
-     - bases left: 2 (alim - X) = (2 alim - K) - v, 2 (blim - Y) = (2 blim + K) - v, so the snake's bound is
-       cmin - v with cmin the smaller of the two, "a read's end was reached" is v == cmin, and "this lane lies outside
-       the reads" (the byte path) is ONE unsigned comparison of cmin - v with a per-lane span;
-     - the next trace mark is crossed when v >= G * 2 TS + (2 offa - K)  /  G * 2 TS + (2 offb + K);
-   Y, X, na, nb are not formed at all.  The band is a lane MASK: lanes outside it hold V = EDGE, so a lane takes part in a
-   step iff its own or a neighbour's V is real -- the new V says so by itself (v > EDGE + 2) -- and pruning leaves the
-   span of the lanes within reach of the best point; ls / hs exist only where a number is needed (recentring, clipping,
-   the record).  What a half needs to know about its best / last points only when something happens is left in the
-   lanes: R = V of the lane's last record, L = V of its last record with a good history; bestk and lasta are read out of
-   them when the loop is left, when a sequence end is clipped, and (lasta) when the cheap test against the last KNOWN
-   lasta fails; trim points go to per-lane slots (duo_tq above).  dif is the entry value plus the scalar iteration
-   count, `more` is 1 unless the rare block behind a sequence end says otherwise.
-   Per iteration (static, scripts/asm_blocks.py): see DESIGN.md section 4. */
-#define DUO_EDGES 0xC0000003C0000003ull                    /* lanes 0, 1, 30, 31 of either half */
-#ifndef DUO_EARLY
-#define DUO_EARLY 0
-#endif
-#ifndef DUO_ILV
-#define DUO_ILV 0
+   Round 5 EXPERIMENT (DUO_SCALAR=1; off by default because it is slower -- kept because the measurement is the point):
+   what is the same in all lanes of a half -- the band, the best / last points' coordinates, the loop conditions -- kept
+   once per half in SCALAR registers and computed by the scalar unit: the band of a half as a 32-bit lane mask (widening
+   = mask | mask << 1 | mask >> 1, within the lanes it may grow into; pruning = the span of the live lanes by s_ff1 /
+   s_flbit / s_bfm), the lane a mask points at read through v_readlane, one `bad` flag instead of five per-step
+   comparisons.  VERDICT r4 item 2 proposed taking the per-alignment bookkeeping out of the full-width stream after the
+   band histogram (profiles/r05_bandhist.txt) had ruled 16-lane quarters out.  Measured on config 2, every kernel alone
+   (scripts/gpu_ab_report.sh, gpu_pmc.sh; profiles/r05_scalar_loop.txt), per loop iteration:
+       round 4 loop (vector)             154 vector + 63 scalar instructions    145 ms of report kernel per step
+       scalars with lane bounds (v1)     140        + 166                       185 ms
+       scalars with band masks (below)   130        + 132                       160 ms
+   i.e. time = 0.75 ms x vector + 0.48 ms x scalar instructions per iteration: the scalar unit is NOT free beside the
+   vector pipes -- a wavefront issues its instructions in order, and what leaves the vector side comes back as 2 - 3
+   scalar instructions (64-bit shifts, compare + select pairs, SGPR spills into VGPR lanes) where one vector instruction
+   served both halves at once.  A conversion pays only below 1.5 scalar per vector instruction saved; the compiler's output
+   for this loop is at 2.9. */
+#ifndef DUO_SCALAR
+#define DUO_SCALAR 0
 #endif
 #ifndef DUO_DBG
 #define DUO_DBG 0
 #endif
-DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
+#if DUO_SCALAR
+/* 32-bit span [lo .. hi] of lane bits (s_bfm_b32) */
+__device__ __forceinline__ u32 span32(int lo, int hi) { return ((1u << (hi - lo + 1)) - 1u) << lo; }
+__device__ __forceinline__ int sc(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#define DUO_H2 for (int h = 0; h < 2; h++)
+#define DUO_EDGES 0xC0000003C0000003ull                    /* lanes 0, 1, 30, 31 of either half */
+DUO_PIECE void duo_loop(int job, const u32 *trimtab, u32 cbase)
 { DUO_NAMES()
   DUO_CX();
   const int ave = uni(a.ave_path);
   const u64 onm = bal(cx.md == MD_RUN);
-  if (!onm)
-    return;
   const bool on = inv(onm);
   const int m = cx.m;
-  const int TS2 = 2 * TS;
-  const int lane4 = lane << 2, top4 = (hb + 31) << 2, s31 = 31 - s;
-  int dif = cx.dif;
-  int guard;                                      /* (one bound for both halves, in a scalar register: a lane-varying one makes every exit
-                                                     of the pebble loops a divergent one) */
-  { const int gv = 4 * (cx.alen + cx.blen) + 1024;
-    const int g0 = __builtin_amdgcn_readlane(gv, 0), g1 = __builtin_amdgcn_readlane(gv, 32);
-    guard = g0 > g1 ? g0 : g1;
-  }
-  int besta = cx.besta, ncell = cx.ncell;
-  int lastlim = cx.lasta + MAX_TRIM_LAG;          /* the pass goes on while lasta + lag >= besta; this is the last KNOWN lasta's */
-  int R = -BIG, L = -BIG;
-  int K = cx.kbase - s;
+  const int va0 = cx.va0, vb0 = cx.vb0, alen = cx.alen, blen = cx.blen;
+  const int alim = cx.alim, blim = cx.blim, offa = cx.offa, offb = cx.offb, pa0 = cx.pa0, pb0 = cx.pb0;
+  const int guard = 4 * (alen + blen) + 1024;
+  const u32 below = (1u << s) - 1u;
+  const int lane4 = lane << 2, top4 = (hb + 31) << 2;
+  int dif = cx.dif, besta = cx.besta, ncell = cx.ncell;   /* (per lane: compared with per-lane values, or used by the pebble stores) */
   int rV = duo_V[lane], rHA = duo_HA[lane], rHB = duo_HB[lane];
+  int Kv = cx.kbase - s;
   u64 rT = ((u64) duo_Thi[lane] << 32) | duo_Tlo[lane];
-  u32 st_cells = 0;                               /* (scalar: one s_bcnt1 + one s_add per step; the steps themselves: left0 - left) */
-  int left;                                       /* steps until the first stepping half reaches the loop bound (dif <= alen + blen + 64:
-                                                     cannot happen; leaving early for the other half's sake only re-enters the loop) */
-  { const int lf = on ? cx.alen + cx.blen + 64 - dif : BIG;
-    const int l0 = __builtin_amdgcn_readlane(lf, 0), l1 = __builtin_amdgcn_readlane(lf, 32);
-    left = l0 < l1 ? l0 : l1;
-  }
-  const int left0 = left;
-  int cpa, cpb, cmin, cspan, cpA, cpB;
-  u64 allowm;
-  u64 spanm = onm & bal(rV > DUO_EDGE + 2);       /* the band: lanes outside it hold EDGE */
-  u64 stopm = 0;                                  /* lanes of the halves that cannot go on */
-  u64 edges = DUO_EDGES;
-  asm("" : "+s"(edges));                        /* (in a register pair: as a literal it is two 32-bit ands) */
+  u32 st_iter = 0, st_cells = 0;
+  if (!onm)
+    return;
+  /* Per-half scalars.  The BAND of a half is a mask of its lanes (the low / high word of `band`); `allow` holds the lanes it
+     may grow into (minp / maxp of align.c:675-776, within lanes 1 .. 30).  A half that is not stepping has an empty band and
+     nothing allowed: nothing of it moves, whatever its record holds (round 5's first version let such a half's stale
+     bounds run on, and its mask bits shifted into the other half's). */
+  const bool on0 = (u32) onm != 0, on1 = (u32) (onm >> 32) != 0;
+  u64 band = 0, allow = 0;
+  int kb[2], bk[2], la[2], be[2], mo[2];
+  int left = 0x7fffffff;                                  /* steps until the first stepping half reaches the loop bound (dif <= alen + blen + 64:
+                                                             cannot happen; leaving early for the other half's sake only re-enters the loop) */
+  bool bad = false;                                       /* a stepping half cannot go on: its pass is over (or its pebble pool) */
+  DUO_H2
+    { const DuoCtx &c = duo_half[h];
+      kb[h] = sc(c.kbase);  bk[h] = sc(c.bestk);  la[h] = sc(c.lasta);  be[h] = sc(c.besta);  mo[h] = sc(c.more);
+      if (h ? on1 : on0)
+        { const int l0 = sc(c.ls), h0 = sc(c.hs), lo = max(sc(c.mlo), 1), hi = min(sc(c.mhi), 30);
+          const int lf = sc(c.alen) + sc(c.blen) + 64 - sc(c.dif);
+          if (h0 < l0)
+            bad = true;                                   /* (cannot happen: duo_classify has been through) */
+          else
+            band |= (u64) span32(l0, h0) << (32 * h);
+          allow |= (u64) (lo <= hi ? span32(lo, hi) : 0u) << (32 * h);
+          left = lf < left ? lf : left;
+        }
+    }
 
   for (;;)
     { /* (every few dozen steps) keep the band and the two lanes it may grow into within lanes 1 .. 30 of the half; a band
-         that has outgrown the lanes, or a pebble pool that has run over (its stores are bounded), leaves */
-      if (spanm & edges)
-        { const u32 hk = hmask(spanm, hb);
-          const int ls = ffbl_raw(hk), hs = 31 ^ ffbh_raw(hk);
-          if (onm & (bal(hs - ls > 27) | bal(ncell > cell_cap)))
+         that has outgrown the lanes leaves (duo_classify sends it on its excursion) */
+      if (band & DUO_EDGES)
+        { int dl[2];
+          bool wide = false;
+          DUO_H2
+            { const u32 bh = (u32) (band >> (32 * h));
+              dl[h] = 0;
+              if (bh & 0xC0000003u)
+                { const int l0 = __builtin_ctz(bh), h0 = 31 - __builtin_clz(bh);
+                  wide |= h0 - l0 > 27;
+                  dl[h] = ((31 - (h0 - l0)) >> 1) - l0;
+                }
+            }
+          if (wide)
             break;
-          const u64 mvm = onm & (bal(ls < 2) | bal(hs > 29));
-          const int dl = inv(mvm) ? ((31 - (hs - ls)) >> 1) - ls : 0;
-          const int src = (hb + ((s - dl) & 31)) << 2;
+          const int dlv = hb ? dl[1] : dl[0];
+          const int src = (hb + ((s - dlv) & 31)) << 2;
           rV  = __builtin_amdgcn_ds_bpermute(src, rV);
           rHA = __builtin_amdgcn_ds_bpermute(src, rHA);
           rHB = __builtin_amdgcn_ds_bpermute(src, rHB);
-          R   = __builtin_amdgcn_ds_bpermute(src, R);
           { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
             const u32 th = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
             rT = ((u64) th << 32) | tl;
           }
-          K += dl;
-          if (on)                                 /* the growth limits move with the lanes: through the record, they are needed here only */
-            { cx.mlo += dl;  cx.mhi += dl; }
-          spanm = onm & bal(rV > DUO_EDGE + 2);
+          Kv += dlv;
+          if (on)                                         /* the growth limits move with the lanes: through the record, they are needed here only */
+            { cx.mlo += dlv;  cx.mhi += dlv; }
+          u64 nb = 0, na = 0;
+          DUO_H2
+            if (h ? on1 : on0)
+              { const DuoCtx &c = duo_half[h];
+                const u32 bh = (u32) (band >> (32 * h));
+                const int lo = max(sc(c.mlo), 1), hi = min(sc(c.mhi), 30);
+                kb[h] += dl[h];
+                nb |= (u64) (dl[h] >= 0 ? bh << dl[h] : bh >> -dl[h]) << (32 * h);
+                na |= (u64) (lo <= hi ? span32(lo, hi) : 0u) << (32 * h);
+              }
+          band = nb;  allow = na;
         }
-      /* the lane's constants (see above) */
-      { const int ca2 = 2 * cx.alim - K, cb2 = 2 * cx.blim + K;
-        const int clo = max(ca2 - 2 * cx.alen, cb2 - 2 * cx.blen);
-        cmin = min(ca2, cb2);  cspan = cmin - clo;
-        if (cspan < 0)                            /* a diagonal that misses a read altogether: never on the window path */
-          { cmin = -(1 << 30);  cspan = 0; }
-        cpa = 2 * cx.pa0 + K;  cpb = 2 * cx.pb0 - K;
-        cpA = 2 * cx.offa - K;  cpB = 2 * cx.offb + K;
-        const int alo = max(cx.mlo, 1), ahi = min(cx.mhi, 30);
-        allowm = onm & bal(s >= alo) & bal(s <= ahi);
-      }
-
+      bool stop;
       do
         { /* widen (align.c:675-776) and pick the predecessor (align.c:793-825): K - 1 sits one lane up, K + 1 one lane down */
+          const int K = Kv;
           int  v, ha, hb_;
           u64  b;
-          typedef u32 v2u __attribute__((ext_vector_type(2)));
-          const int am = lane_up(rV), ap = lane_dn(rV), ac = rV;
-          const int nbv = am > ap ? am : ap;
-          const u64 takem = bal(ac < nbv), upm = bal(am < ap);
-          v = inv(takem) ? nbv + 1 : ac + 2;
-          int dsel = inv(upm) ? -4 : 4;
-          dsel = inv(takem) ? dsel : 0;
-          const int src = lane4 + dsel;
-          const u64 actm = allowm & bal(v > DUO_EDGE + 2);
-#if !DUO_ILV
-          dif += 1;
-#endif
-          st_cells += (u32) __popcll(actm);
-          asm("s_sub_u32 %0, %0, 1\n\ts_cselect_b64 %1, -1, %1" : "+s"(left), "+s"(stopm) : : "scc");     /* (the bound: cannot happen) */
-          /* the snake (align.c:832-856 / 1542-1566): 16 bases per step off the packed reads; a lane outside the reads takes the
-             byte path, which compares what the reference compares there and says in `ef` whether it met an end (1: A's, 2: B's) */
-          const u64 bytem = actm & bal((u32) (cmin - v) > (u32) cspan);
-          const u64 fastm = actm & ~bytem;
-          const u32 pa = (u32) v + (u32) cpa, pb = (u32) v + (u32) cpb;          /* bit positions of the two windows */
-          u32 oa = (pa >> 3) & ~3u, ob = (pb >> 3) & ~3u;
-          v2u ra, rb;
-#if DUO_EARLY
-          /* the first window's loads leave BEFORE the gathers of the predecessor's state (their addresses need the new V only):
-             the round trip through LDS runs inside the one to L2.  The loads are for the lanes on the window path only; the
-             gathers for every lane */
-          { u64 et;
-            u32 tlo = (u32) rT, thi = (u32) (rT >> 32);
-            ha = rHA;  hb_ = rHB;
-            asm volatile("s_mov_b64 %[et], exec\n\t"
-                         "s_mov_b64 exec, %[fm]\n\t"
-                         "global_load_dwordx2 %[ra], %[oa], %[ap]\n\t"
-                         "global_load_dwordx2 %[rb], %[ob], %[bp]\n\t"
-                         "s_mov_b64 exec, %[et]\n\t"
-                         "ds_bpermute_b32 %[ha], %[src], %[ha]\n\t"
-                         "ds_bpermute_b32 %[hb], %[src], %[hb]\n\t"
-                         "ds_bpermute_b32 %[tl], %[src], %[tl]\n\t"
-                         "ds_bpermute_b32 %[th], %[src], %[th]\n\t"
-                         "s_waitcnt vmcnt(0) lgkmcnt(0)"
-                         : [ra] "=&v"(ra), [rb] "=&v"(rb), [ha] "+v"(ha), [hb] "+v"(hb_), [tl] "+v"(tlo), [th] "+v"(thi), [et] "=&s"(et)
-                         : [fm] "s"(fastm), [oa] "v"(oa), [ob] "v"(ob), [ap] "s"(apk - PK_PAD), [bp] "s"(bpk - PK_PAD), [src] "v"(src)
-                         : "memory");
-            b = ((u64) thi << 32) | tlo;
-          }
-#else
-          { ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
+          const u64 actm = (band | (band << 1) | (band >> 1)) & allow;       /* (lanes 0 and 31 of a half are never allowed: nothing crosses) */
+          left -= 1;
+          { const int am = lane_up(rV), ap = lane_dn(rV), ac = rV;
+            const int nbv = am > ap ? am : ap;
+            const u64 takem = bal(ac < nbv), upm = bal(am < ap);
+            v = inv(takem) ? nbv + 1 : ac + 2;
+            int dsel = inv(upm) ? -4 : 4;
+            dsel = inv(takem) ? dsel : 0;
+            const int src = lane4 + dsel;
+            ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
             hb_ = __builtin_amdgcn_ds_bpermute(src, rHB);
             const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
             const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
             b = ((u64) thi << 32) | tlo;
+            dif += 1;
+            st_iter += 1;  st_cells += (u32) __popcll(actm);
           }
-#endif
-          int ef;
-          asm volatile("" : "=v"(ef));              /* (only the byte path's lanes define it; every use is behind bytem) */
-          if (bytem)
-            { if (inv(bytem))
-                { const int Y = (v - K) >> 1;
-                  const int k = (K ^ m) - m, y = (Y ^ m) - m;
-                  const u8 *ar = abase + (cx.va0 - 16 * PK_PAD), *br = bbase + (cx.vb0 - 16 * PK_PAD);
-                  SnakeOut so;
-                  if (m)
-                    so = snake<1>(ar - 1 + k, br - 1, y, 0, b << 1);
-                  else
-                    so = snake<0>(ar + k, br, y, 0, b << 1);
-                  v = (((so.y ^ m) - m) << 1) + K;  b = so.b;
-                  ef = so.nb == 0 ? 2 : (so.na == 0 ? 1 : 0);
-                }
-            }
-          if (inv(fastm))
-            { u32 m2;
-#define DUO_LOADS()                                              /* both loads in flight together, ONE wait */  \
-                asm volatile("global_load_dwordx2 %0, %2, %4\n\tglobal_load_dwordx2 %1, %3, %5\n\ts_waitcnt vmcnt(0)" \
-                             : "=&v"(ra), "=&v"(rb) : "v"(oa), "v"(ob), "s"(apk - PK_PAD), "s"(bpk - PK_PAD) : "memory");
-#define DUO_WINDOW(FIRST)                                                                                     \
-              { const u32 wa = __builtin_amdgcn_alignbit(ra.y, ra.x, pa);                                     \
-                const u32 wb = __builtin_amdgcn_alignbit(rb.y, rb.x, pb);                                     \
-                const u32 run2 = (u32) ffbl_raw(wa ^ wb) & ~1u;  /* twice the equal bases at the head of the window; huge if all 16 are */ \
-                m2 = __builtin_elementwise_min(run2, (u32) (cmin - v));                                       \
-                const u32 n2 = __builtin_elementwise_min(m2, 32u), n = n2 >> 1;                               \
-                u32 ones;                                                                                     \
-                asm("v_bfm_b32 %0, %1, 0" : "=v"(ones) : "v"(n));                                             \
-                b = (b << (n + (FIRST))) | (u64) ones;         /* (the step's own 0 rides on the first window's shift) */ \
-                v += (int) n2;                                                                                \
-              }
-#if !DUO_EARLY
-              DUO_LOADS()
-#endif
-              DUO_WINDOW(1)
-              const u64 contm = bal(m2 > 32u);               /* all 16 equal and more than 16 left: one window in eight hundred */
-              if (contm)
-                { if (inv(contm))
-                    do
-                      { oa += 4;  ob += 4;
-                        DUO_LOADS()
-                        DUO_WINDOW(0)
-                      }
-                    while (m2 > 32u);
-                }
-#undef DUO_WINDOW
-#undef DUO_LOADS
-            }
 
-          /* What the rest of the step asks of the new V, in ONE stretch of instructions: the prefix maximum of the candidates
-             for a new best point (align.c:911-928 / 1620-1637) is five DPP steps that each wait two issue slots for their
-             operand; the slots are filled with the tests of the trace marks (align.c:859-909 / 1569-1618: a pebble is due when
-             v reaches the mark after the inherited head's), the popcount of the match history and the test for a read's end,
-             instead of s_nop.  Some lane passes the old best in every step (profiles/r05_loop_blocks.txt): no branch */
-          const u64 candm = actm & bal(v > besta);
-          int x = inv(candm) ? v : -BIG, e;
-          u64 nam, nbm, mokc, endc;
-#if DUO_ILV
-          { int t1, t2, t3, t4;
-            /* (three statements: one whose results are all scalar registers is known to be uniform; mixed with vector
-               results the compiler takes the masks for lane-varying values and computes with them in vector registers) */
-            asm volatile("v_lshrrev_b32 %[t1], 18, %[ha]\n\t"
-                         "v_lshrrev_b32 %[t2], 18, %[hb]\n\t"
-                         "v_max_i32_dpp %[x], %[x], %[x] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_and_b32 %[t3], 0x1fffffff, %[bhi]\n\t"
-                         "v_bcnt_u32_b32 %[t4], %[blo], 0\n\t"
-                         "v_max_i32_dpp %[x], %[x], %[x] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_mad_i32_i24 %[t1], %[t1], %[ts2], %[cpA]\n\t"
-                         "v_mad_i32_i24 %[t2], %[t2], %[ts2], %[cpB]\n\t"
-                         "v_max_i32_dpp %[x], %[x], %[x] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_bcnt_u32_b32 %[t4], %[t3], %[t4]\n\t"
-                         "v_add_u32 %[dif], 1, %[dif]\n\t"
-                         "v_max_i32_dpp %[x], %[x], %[x] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 1\n\t"
-                         "v_max_i32_dpp %[x], %[x], %[x] row_bcast:15 row_mask:0xa bank_mask:0xf"
-                         : [x] "+v"(x), [dif] "+v"(dif), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)
-                         : [ha] "v"(ha), [hb] "v"(hb_), [bhi] "v"((u32) (b >> 32)), [blo] "v"((u32) b),
-                           [cpA] "v"(cpA), [cpB] "v"(cpB), [ts2] "s"(TS2));
-            asm volatile("v_cmp_ge_i32_e64 %[nam], %[v], %[t1]\n\t"
-                         "v_cmp_ge_i32_e64 %[nbm], %[v], %[t2]\n\t"
-                         "v_cmp_le_i32_e64 %[mok], %[ave], %[t4]\n\t"
-                         "v_cmp_eq_u32_e64 %[end], %[v], %[cmin]"
-                         : [nam] "=&s"(nam), [nbm] "=&s"(nbm), [mok] "=&s"(mokc), [end] "=&s"(endc)
-                         : [v] "v"(v), [t1] "v"(t1), [t2] "v"(t2), [t4] "v"(t4), [cmin] "v"(cmin), [ave] "s"(ave));
-            /* the maximum over the lanes before this one; what lane 0 of a half receives does not matter: the band lives
-               in lanes 1 .. 30, lane 0 is never a candidate */
-            asm volatile("v_mov_b32_dpp %[e], %[x] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : [e] "=&v"(e) : [x] "v"(x));
-          }
-#else
-          { const int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
-            nam = bal(v >= __mul24(ga, TS2) + cpA);  nbm = bal(v >= __mul24(gb, TS2) + cpB);
-            x = pk_prefix_max(x);
-            /* the maximum over the lanes before this one; what lane 0 of a half receives does not matter: the band lives
-               in lanes 1 .. 30, lane 0 is never a candidate */
-            e = __builtin_amdgcn_mov_dpp(x, 0x138, 0xf, 0xf, true);                               /* wave_shr:1 */
-            mokc = bal(pk_popc61(b) >= ave);
-            endc = bal(v == cmin);
-          }
-#endif
-          nam &= actm;  nbm &= actm;
-          if (nam | nbm)
-            { const int kk = (K ^ m) - m;
-              const u32 w1 = ((u32) kk & 0xffffu) | ((u32) (dif) << 16);
-              const u32 below = (1u << s) - 1u;
-              int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
-              int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
-              int g2 = 0;
-              while (nam)
-                { GUARD(g2, guard, 5)
-                  const u32 hm = hmask(nam, hb);
-                  const int idx = ncell + __popc(hm & below);
-                  if (inv(nam))
-                    { ga += 1;
-                      if (idx < cell_cap)
-                        { const v2u32 c = { (u32) hax | ((u32) ((ga ^ m) - m) << PK_HBITS), w1 };
-                          DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
-                        }
-                      hax = idx;
-                    }
-                  ncell += __popc(hm);
-                  nam &= bal(v >= __mul24(ga, TS2) + cpA);
-                }
-              while (nbm)
-                { GUARD(g2, guard, 6)
-                  const u32 hm = hmask(nbm, hb);
-                  const int idx = ncell + __popc(hm & below);
-                  if (inv(nbm))
-                    { gb += 1;
-                      if (idx < cell_cap)
-                        { const v2u32 c = { (u32) hbx | ((u32) ((gb ^ m) - m) << PK_HBITS), w1 };
-                          DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
-                        }
-                      hbx = idx;
-                    }
-                  ncell += __popc(hm);
-                  nbm &= bal(v >= __mul24(gb, TS2) + cpB);
-                }
-              ha = hax | (ga << PK_HBITS);  hb_ = hbx | (gb << PK_HBITS);
+          int Y = 0, na = 1, nb = 1;
+          if (inv(actm))
+            { b <<= 1;
+              const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, pa0, pb0, va0, vb0, alen, blen, K, (v - K) >> 1, b);
+              Y = so.Y;  b = so.b;  na = so.na;  nb = so.nb;
+              v = (Y << 1) + K;
             }
+          asm("" : "+v"(na), "+v"(nb));            /* (compare behind the join: a bool out of the branch would be made 0 / 1 per lane and compared again) */
+          const u64 bhm = actm & bal(nb == 0), ahm = actm & ~bhm & bal(na == 0);
+
+          /* pebbles (align.c:859-909 / 1569-1618): every mark between the inherited head's and the new position */
+          { const int X = Y + K;
+            int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
+            u64 nam = actm & bal(X >= __mul24(ga, TS) + offa), nbm = actm & bal(Y >= __mul24(gb, TS) + offb);
+            if (nam | nbm)
+              { const int kk = (K ^ m) - m;
+                const u32 w1 = ((u32) kk & 0xffffu) | ((u32) dif << 16);
+                int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
+                int g2 = 0;
+                while (nam)
+                  { GUARD(g2, guard, 5)
+                    const u32 hm = hmask(nam, hb);
+                    const int idx = ncell + __popc(hm & below);
+                    if (inv(nam))
+                      { ga += 1;
+                        if (idx < cell_cap)
+                          { const v2u32 c = { (u32) hax | ((u32) ((ga ^ m) - m) << PK_HBITS), w1 };
+                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
+                          }
+                        hax = idx;
+                      }
+                    ncell += __popc(hm);
+                    nam &= bal(X >= __mul24(ga, TS) + offa);
+                  }
+                while (nbm)
+                  { GUARD(g2, guard, 6)
+                    const u32 hm = hmask(nbm, hb);
+                    const int idx = ncell + __popc(hm & below);
+                    if (inv(nbm))
+                      { gb += 1;
+                        if (idx < cell_cap)
+                          { const v2u32 c = { (u32) hbx | ((u32) ((gb ^ m) - m) << PK_HBITS), w1 };
+                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
+                          }
+                        hbx = idx;
+                      }
+                    ncell += __popc(hm);
+                    nbm &= bal(Y >= __mul24(gb, TS) + offb);
+                  }
+                ha = hax | (ga << PK_HBITS);  hb_ = hbx | (gb << PK_HBITS);
+                if (onm & bal(ncell > cell_cap))                  /* (rare block: this compare costs nothing per step) */
+                  bad = true;
+              }
+          }
 
           /* commit the new wave (lanes outside the band get V = EDGE again behind the pruning) */
           rV = v;  rT = b;  rHA = ha;  rHB = hb_;
 
-          /* new best / last / trim point in sweep order: the record breakers of the prefix maximum; their V is strictly
-             monotone, so the LAST breaker with the wanted property is the one the serial sweep leaves behind, and the new
-             best is the maximum itself */
-          { const u64 rbm = candm & bal(v > e);
-            R = inv(rbm) ? v : R;
-            const u64 mokm = rbm & mokc;
-            L = inv(mokm) ? v : L;
-            const int xl = __builtin_amdgcn_ds_bpermute(top4, x);                                 /* the maximum of the half's candidates */
-            besta = xl > besta ? xl : besta;
-            if (mokm)
-              { const u64 tokm = mokm & bal(pk_trim_ok(trimtab, b));
-                if (inv(tokm))
-                  { const duo_v4i q = { v, K, ha, hb_ };
-                    duo_tq[lane] = q;  duo_td[lane] = dif;
+          /* sequence ends reached: the largest sweep index for A, the smallest for B */
+          if (ahm | bhm)
+            { const u32 am_ = hmask(ahm, hb), bm_ = hmask(bhm, hb);
+              if (am_ | bm_)
+                { if (am_) cold[DC_ACLIP] = 31 - __clz((int) am_);
+                  if (bm_) cold[DC_BCLIP] = __ffs((int) bm_) - 1;
+                }
+              if ((u32) (ahm | bhm)) mo[0] = 0;
+              if ((u32) ((ahm | bhm) >> 32)) mo[1] = 0;
+            }
+
+          /* new best / last / trim point in sweep order (align.c:911-928 / 1620-1637): record breakers of a prefix
+             maximum; their V is strictly monotone, so the LAST breaker with the wanted property is the one the serial
+             sweep leaves behind, and the new best is the maximum itself */
+          { const u64 candm = actm & bal(v > besta);
+            if (candm)
+              { const int x = pk_prefix_max(inv(candm) ? v : -BIG);
+                /* the maximum over the lanes before this one; what lane 0 of a half receives does not matter: the band
+                   lives in lanes 1 .. 30, lane 0 is never a candidate */
+                const int e = __builtin_amdgcn_update_dpp(-BIG, x, 0x138, 0xf, 0xf, false);       /* wave_shr:1 */
+                const u64 rbm = candm & bal(v > e);
+                const u64 mokm = rbm & bal(pk_popc61(b) >= ave);
+                u64 tokm = 0;
+                if (mokm)
+                  tokm = mokm & bal(pk_trim_ok(trimtab, b));
+                const int xl = __builtin_amdgcn_ds_bpermute(top4, x);                             /* the maximum of the half's candidates */
+                besta = xl > besta ? xl : besta;
+                DUO_H2
+                  { const u32 h1 = (u32) (rbm >> (32 * h)), h2 = (u32) (mokm >> (32 * h));
+                    if (h1)
+                      { bk[h] = kb[h] - (31 - __builtin_clz(h1));
+                        be[h] = __builtin_amdgcn_readlane(x, 32 * h + 31);
+                        if (h2)
+                          la[h] = __builtin_amdgcn_readlane(v, 32 * h + 31 - __builtin_clz(h2));
+                        if (la[h] < be[h] - MAX_TRIM_LAG)
+                          bad = true;
+                      }
+                  }
+                if (tokm)
+                  { const u32 h3 = hmask(tokm, hb);
+                    if (h3)
+                      { const int l3 = 31 ^ ffbh_raw(h3);
+                        const int v3 = hget(v, hb, l3), h3a = hget(ha, hb, l3), h3b = hget(hb_, hb, l3);
+                        cold[DC_TRIM] = v3;  cold[DC_TRIM + 1] = Kv + s - l3;  cold[DC_TRIM + 2] = dif;
+                        cold[DC_TRIM + 3] = h3a & PK_HMASK;  cold[DC_TRIM + 4] = h3b & PK_HMASK;
+                      }
                   }
               }
           }
 
-          /* sequence ends reached (the largest sweep index for A, the smallest for B) and the clipping behind them
-             (align.c:628-658 / 943-975): rare; the band goes there as lane bounds and comes back as a mask */
-          u64 wband = actm;                                   /* the band as widened: what the pruning starts from */
-          { const u64 endm = (fastm & endc) | bytem;
-            if (endm)
-              { const int ca2 = 2 * cx.alim - K, cb2 = 2 * cx.blim + K;
-                const bool byl = inv(bytem), act = inv(actm);
-                const bool isB = act && (byl ? ef == 2 : v == cb2);
-                const bool isA = act && !isB && (byl ? ef == 1 : v == ca2);
-                const u32 am_ = hmask(bal(isA), hb), bm_ = hmask(bal(isB), hb);
-                if (am_) cold[DC_ACLIP] = 31 - __clz((int) am_);
-                if (bm_) cold[DC_BCLIP] = __ffs((int) bm_) - 1;
-                int more = (am_ | bm_) ? 0 : 1;
-                const int va0 = cx.va0, vb0 = cx.vb0, kbase = K + s;
-                int bestk = cx.bestk;
-                { const u32 hr = hmask(bal(R == besta), hb);
-                  if (hr) bestk = kbase - ffbl_raw(hr);
-                }
-                const u32 hw = hmask(actm, hb);
-                int ls = ffbl_raw(hw), hs = 31 ^ ffbh_raw(hw);
-                DUO_CLIP()
-                wband = onm & bal(s >= ls) & bal(s <= hs);
-                if (on && more == 0)
-                  cx.more = 0;
-                stopm |= onm & bal(more == 0);
-              }
-          }
+          /* clipping at sequence ends (align.c:628-658 / 943-975): rare, on the vector side as in round 4 -- the band goes
+             there as lane bounds and comes back as a mask */
+          u64 wband = actm;                                       /* the band as widened: what the pruning starts from */
+          if ((on0 && mo[0] == 0) || (on1 && mo[1] == 0))
+            { int more = hb ? mo[1] : mo[0], bestk = hb ? bk[1] : bk[0], kbase = hb ? kb[1] : kb[0];
+              const u32 wb0 = (u32) wband, wb1 = (u32) (wband >> 32);
+              int ls = hb ? (wb1 ? __builtin_ctz(wb1) : 32) : (wb0 ? __builtin_ctz(wb0) : 32);
+              int hs = hb ? (wb1 ? 31 - __builtin_clz(wb1) : -1) : (wb0 ? 31 - __builtin_clz(wb0) : -1);
+              DUO_CLIP()
+              wband = 0;
+              DUO_H2
+                if (h ? on1 : on0)
+                  { const int l1 = __builtin_amdgcn_readlane(ls, 32 * h), h1 = __builtin_amdgcn_readlane(hs, 32 * h);
+                    mo[h] = __builtin_amdgcn_readlane(more, 32 * h);
+                    if (mo[h] == 0)
+                      bad = true;
+                    if (h1 >= l1)
+                      wband |= (u64) span32(l1, h1) << (32 * h);
+                  }
+              (void) bestk;  (void) kbase;
+            }
 
           /* prune (align.c:977-986 / 1686-1695): the band becomes the span of its lanes that are within reach of the best
-             point, and V = EDGE again in every lane outside it (an empty band: the find-first-bit instructions return
-             -1 for 0, which no lane number reaches as an unsigned) */
-          { const u64 keepm = wband & bal(rV >= besta - MAX_WAVE_LAG);
-            const u32 hk = hmask(keepm, hb);
-            const u32 lo_ = (u32) ffbl_raw(hk), hi_ = (u32) ffbh_raw(hk);
-            spanm = bal((u32) s >= lo_) & bal((u32) s31 >= hi_);
-            rV = inv(spanm) ? rV : DUO_EDGE;
-            /* may every half go on?  lasta is at least the last known one */
-            const u64 badm = onm & (bal((int) lo_ < 0) | bal(lastlim < besta));
-            if (badm)
-              { int lm = L;
-                for (int o = 1; o < 32; o <<= 1)
-                  { const int t = __shfl_xor(lm, o);  lm = t > lm ? t : lm; }
-                lm += MAX_TRIM_LAG;
-                lastlim = lm > lastlim ? lm : lastlim;
-                stopm |= onm & (bal((int) lo_ < 0) | bal(lastlim < besta));
-              }
+             point, and V = EDGE again in every lane outside it */
+          { const u64 keep = wband & bal(rV >= besta - MAX_WAVE_LAG);
+            const u32 k0 = (u32) keep, k1 = (u32) (keep >> 32);
+            const u32 s0 = k0 ? span32(__builtin_ctz(k0), 31 - __builtin_clz(k0)) : 0u;
+            const u32 s1 = k1 ? span32(__builtin_ctz(k1), 31 - __builtin_clz(k1)) : 0u;
+            if ((on0 && k0 == 0) || (on1 && k1 == 0))            /* an empty band */
+              bad = true;
+            band = ((u64) s1 << 32) | s0;
+            rV = inv(band) ? rV : DUO_EDGE;
           }
+
+          /* may every half go on as it is?  (a pebble pool that has run over is noticed when the loop is left for any
+             other reason: its stores are bounded) */
+          stop = bad || left < 0 || (band & DUO_EDGES) != 0;
         }
-      while ((stopm | (spanm & edges)) == 0);
-      if (stopm)
+      while (!stop);
+      if (bad || left < 0)
         break;
     }
   { DuoCtx &c0 = duo_half[0];                   /* (every lane adds the same: one record counts for the wavefront) */
-    const u32 lo = c0.n_cells_lo + st_cells, st_iter = (u32) (left0 - left);
+    const u32 lo = c0.n_cells_lo + st_cells;
     c0.n_cells_hi += (lo < st_cells) ? 1u : 0u;  c0.n_cells_lo = lo;
     c0.n_iter += st_iter;  c0.n_half += st_iter * ((u32) __popcll(onm) >> 5);
   }
-  { int lm = L;                                  /* lasta and bestk out of the lanes */
-    for (int o = 1; o < 32; o <<= 1)
-      { const int t = __shfl_xor(lm, o);  lm = t > lm ? t : lm; }
-    const u32 hr = hmask(bal(R == besta), hb), hk = hmask(spanm, hb);
-    if (on)
-      { duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
-        cx.ls = ffbl_raw(hk);  cx.hs = 31 ^ ffbh_raw(hk);  cx.kbase = K + s;  cx.dif = dif;  cx.besta = besta;
-        if (hr)
-          cx.bestk = K + s - ffbl_raw(hr);
-        lastlim -= MAX_TRIM_LAG;
-        cx.lasta = lm > lastlim ? lm : lastlim;
-        cx.ncell = ncell;
-      }
-  }
+  if (on)
+    { const u32 b0 = (u32) band, b1 = (u32) (band >> 32);
+      duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
+      cx.ls = hb ? (b1 ? __builtin_ctz(b1) : 32) : (b0 ? __builtin_ctz(b0) : 32);
+      cx.hs = hb ? (b1 ? 31 - __builtin_clz(b1) : -1) : (b0 ? 31 - __builtin_clz(b0) : -1);
+      cx.kbase = hb ? kb[1] : kb[0];  cx.dif = dif;  cx.besta = besta;
+      cx.bestk = hb ? bk[1] : bk[0];  cx.lasta = hb ? la[1] : la[0];  cx.more = hb ? mo[1] : mo[0];  cx.ncell = ncell;
+    }
 }
+#else
+/* The wave steps (align.c:667-999 / 1378-1697) of the halves with md == MD_RUN, until one of them has an event: its
+   direction is over (or failed), or its band no longer fits lanes 1..30.  The caller tells which from the state
+   (duo_classify); on entry every such half can step (duo_classify has been through). */
+DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)      /* (a part of duo_run since round 5: the loop still spills nothing, and the call's
+                                                                          callee-saved registers were a tenth of the kernel's memory traffic) */
+{ DUO_NAMES()
+  DUO_CX();
+  const int ave = uni(a.ave_path);
+  const u64 onm = bal(cx.md == MD_RUN);
+  const bool on = inv(onm);
+  const int m = cx.m;
+  const int va0 = cx.va0, vb0 = cx.vb0, alen = cx.alen, blen = cx.blen;
+  const int alim = cx.alim, blim = cx.blim, offa = cx.offa, offb = cx.offb, pa0 = cx.pa0, pb0 = cx.pb0;
+  const int steplimit = alen + blen + 64, guard = 4 * (alen + blen) + 1024;
+  const u32 below = (1u << s) - 1u;
+  const int lane4 = lane << 2, top4 = (hb + 31) << 2;
+  int ls = cx.ls, hs = cx.hs, kbase = cx.kbase, dif = cx.dif, besta = cx.besta, bestk = cx.bestk;
+  int lasta = cx.lasta, more = cx.more, ncell = cx.ncell, mlo = cx.mlo, mhi = cx.mhi;
+  int rV = duo_V[lane], rHA = duo_HA[lane], rHB = duo_HB[lane];
+  u64 rT = ((u64) duo_Thi[lane] << 32) | duo_Tlo[lane];
+  u32 st_iter = 0, st_cells = 0;                /* (scalar: one s_bcnt1 + two s_add per step) */
+  if (!onm)
+    return;
+
+  for (;;)
+    { /* (every few dozen steps) keep the band and the two lanes it may grow into within lanes 1 .. 30 of the half */
+      { const u64 mvm = onm & (bal(ls < 2) | bal(hs > 29));
+        if (mvm)
+          { const int dl = inv(mvm) ? ((31 - (hs - ls)) >> 1) - ls : 0;
+            const int src = (hb + ((s - dl) & 31)) << 2;
+            rV  = __builtin_amdgcn_ds_bpermute(src, rV);
+            rHA = __builtin_amdgcn_ds_bpermute(src, rHA);
+            rHB = __builtin_amdgcn_ds_bpermute(src, rHB);
+            { const u32 tl = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+              const u32 th = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+              rT = ((u64) th << 32) | tl;
+            }
+            kbase += dl;  ls += dl;  hs += dl;  mlo += dl;  mhi += dl;
+          }
+      }
+      u64 gom;
+      do
+        { /* widen (align.c:675-776) and pick the predecessor (align.c:793-825): K - 1 sits one lane up, K + 1 one lane down */
+          const int K = kbase - s;
+          u64  actm;
+          int  v, ha, hb_;
+          u64  b;
+          { const int nls = (ls - 1 > mlo) ? ls - 1 : mlo, nhs = (hs + 1 < mhi) ? hs + 1 : mhi;
+            actm = onm & bal(s >= nls) & bal(s <= nhs);
+            const int am = lane_up(rV), ap = lane_dn(rV), ac = rV;
+            const int nbv = am > ap ? am : ap;
+            const u64 takem = bal(ac < nbv), upm = bal(am < ap);
+            v = inv(takem) ? nbv + 1 : ac + 2;
+            int dsel = inv(upm) ? -4 : 4;
+            dsel = inv(takem) ? dsel : 0;
+            const int src = lane4 + dsel;
+            ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
+            hb_ = __builtin_amdgcn_ds_bpermute(src, rHB);
+            const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
+            const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
+            b = ((u64) thi << 32) | tlo;
+            ls = nls;  hs = nhs;  dif += 1;
+            st_iter += 1;  st_cells += (u32) __popcll(actm);
+          }
+
+          int Y, na, nb;                            /* (of the lanes that do not step these stay undefined: every use is behind actm) */
+          asm volatile("" : "=v"(Y), "=v"(na), "=v"(nb));
+          if (inv(actm))
+            { b <<= 1;
+              const DuoSnake so = duo_snake(apk, bpk, abase, bbase, m, alim, blim, pa0, pb0, va0, vb0, alen, blen, K, (v - K) >> 1, b);
+              Y = so.Y;  b = so.b;  na = so.na;  nb = so.nb;
+              v = (Y << 1) + K;
+            }
+          asm("" : "+v"(na), "+v"(nb));            /* (compare behind the join: a bool out of the branch would be made 0 / 1 per lane and compared again) */
+          const u64 bhm = actm & bal(nb == 0), ahm = actm & ~bhm & bal(na == 0);
+
+          /* pebbles (align.c:859-909 / 1569-1618): every mark between the inherited head's and the new position */
+          { const int X = Y + K;
+            int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
+            u64 nam = actm & bal(X >= __mul24(ga, TS) + offa), nbm = actm & bal(Y >= __mul24(gb, TS) + offb);
+            if (nam | nbm)
+              { const int kk = (K ^ m) - m;
+                const u32 w1 = ((u32) kk & 0xffffu) | ((u32) dif << 16);
+                int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
+                int g2 = 0;
+                while (nam)
+                  { GUARD(g2, guard, 5)
+                    const u32 hm = hmask(nam, hb);
+                    const int idx = ncell + __popc(hm & below);
+                    if (inv(nam))
+                      { ga += 1;
+                        if (idx < cell_cap)
+                          { const v2u32 c = { (u32) hax | ((u32) ((ga ^ m) - m) << PK_HBITS), w1 };
+                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
+                          }
+                        hax = idx;
+                      }
+                    ncell += __popc(hm);
+                    nam &= bal(X >= __mul24(ga, TS) + offa);
+                  }
+                while (nbm)
+                  { GUARD(g2, guard, 6)
+                    const u32 hm = hmask(nbm, hb);
+                    const int idx = ncell + __popc(hm & below);
+                    if (inv(nbm))
+                      { gb += 1;
+                        if (idx < cell_cap)
+                          { const v2u32 c = { (u32) hbx | ((u32) ((gb ^ m) - m) << PK_HBITS), w1 };
+                            DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
+                          }
+                        hbx = idx;
+                      }
+                    ncell += __popc(hm);
+                    nbm &= bal(Y >= __mul24(gb, TS) + offb);
+                  }
+                ha = hax | (ga << PK_HBITS);  hb_ = hbx | (gb << PK_HBITS);
+              }
+          }
+
+          /* commit the new wave (lanes outside the band get V = EDGE again behind the pruning) */
+          rV = v;  rT = b;  rHA = ha;  rHB = hb_;
+
+          /* sequence ends reached: the largest sweep index for A, the smallest for B */
+          if (ahm | bhm)
+            { const u32 am_ = hmask(ahm, hb), bm_ = hmask(bhm, hb);
+              if (am_ | bm_)
+                { more = 0;
+                  if (am_) cold[DC_ACLIP] = 31 - __clz((int) am_);
+                  if (bm_) cold[DC_BCLIP] = __ffs((int) bm_) - 1;
+                }
+            }
+
+          /* new best / last / trim point in sweep order (align.c:911-928 / 1620-1637): record breakers of a prefix
+             maximum; their V is strictly monotone, so the LAST breaker with the wanted property is the one the serial
+             sweep leaves behind, and the new best is the maximum itself */
+          { const u64 candm = actm & bal(v > besta);
+            if (candm)
+              { const int x = pk_prefix_max(inv(candm) ? v : -BIG);
+                int e = __builtin_amdgcn_update_dpp(-BIG, x, 0x138, 0xf, 0xf, false);             /* wave_shr:1 */
+                if (s == 0) e = -BIG;
+                const u64 rbm = candm & bal(v > e);
+                const u64 mokm = rbm & bal(pk_popc61(b) >= ave);
+                u64 tokm = 0;
+                if (mokm)
+                  tokm = mokm & bal(pk_trim_ok(trimtab, b));
+                const int xl = __builtin_amdgcn_ds_bpermute(top4, x);                             /* the maximum of the half's candidates */
+                const u32 h1 = hmask(rbm, hb), h2 = hmask(mokm, hb), h3 = hmask(tokm, hb);
+                const int l1 = 31 ^ ffbh_raw(h1), l2 = 31 ^ ffbh_raw(h2), l3 = 31 ^ ffbh_raw(h3);
+                const int v2 = hget(v, hb, l2);
+                besta = xl > besta ? xl : besta;
+                if (h1) bestk = kbase - l1;
+                if (h2) lasta = v2;
+                if (h3)
+                  { const int v3 = hget(v, hb, l3), h3a = hget(ha, hb, l3), h3b = hget(hb_, hb, l3);
+                    cold[DC_TRIM] = v3;  cold[DC_TRIM + 1] = kbase - l3;  cold[DC_TRIM + 2] = dif;
+                    cold[DC_TRIM + 3] = h3a & PK_HMASK;  cold[DC_TRIM + 4] = h3b & PK_HMASK;
+                  }
+              }
+          }
+
+          DUO_CLIP()
+
+          /* prune (align.c:977-986 / 1686-1695), and V = EDGE again in every lane outside the band (an empty band
+             comes out as hs < ls: the find-first-bit instructions return -1 for 0) */
+          { const int n = besta - MAX_WAVE_LAG;
+            const u32 keep = hmask(bal(s >= ls) & bal(s <= hs) & bal(rV >= n), hb);
+            ls = ffbl_raw(keep);  hs = 31 ^ ffbh_raw(keep);
+            rV = inv(bal(s >= ls) & bal(s <= hs)) ? rV : DUO_EDGE;
+          }
+
+          /* may every half go on as it is?  (a band within lanes 2 .. 29 is no wider than 28; a pebble pool that has
+             run over is noticed when the loop is left for any other reason: its stores are bounded) */
+          gom = bal(more != 0) & bal(lasta >= besta - MAX_TRIM_LAG) & bal(hs >= ls) & bal(dif <= steplimit);
+        }
+      while ((onm & ~(gom & bal(ls >= 2) & bal(hs <= 29))) == 0);
+      if (onm & ~(gom & bal(hs - ls <= 27) & bal(ncell <= cell_cap)))
+        break;
+    }
+  { DuoCtx &c0 = duo_half[0];                   /* (every lane adds the same: one record counts for the wavefront) */
+    const u32 lo = c0.n_cells_lo + st_cells;
+    c0.n_cells_hi += (lo < st_cells) ? 1u : 0u;  c0.n_cells_lo = lo;
+    c0.n_iter += st_iter;  c0.n_half += st_iter * ((u32) __popcll(onm) >> 5);
+  }
+  if (on)
+    { duo_V[lane] = rV;  duo_HA[lane] = rHA;  duo_HB[lane] = rHB;  duo_Tlo[lane] = (u32) rT;  duo_Thi[lane] = (u32) (rT >> 32);
+      cx.ls = ls;  cx.hs = hs;  cx.kbase = kbase;  cx.dif = dif;  cx.besta = besta;  cx.bestk = bestk;
+      cx.lasta = lasta;  cx.more = more;  cx.ncell = ncell;  cx.mlo = mlo;  cx.mhi = mhi;
+    }
+}
+
+#endif
 
 /* What the wave loop left for the halves with md == MD_RUN (the reference's loop conditions, in their order) */
 __device__ __forceinline__ void duo_classify(const ReportArgs &a)
@@ -1094,7 +1168,6 @@ DUO_PART void duo_finish(int job)
   const int guard = 4 * (cx.alen + cx.blen) + 1024;
   u32 *const errw = &a.counters[3];
   int rx = 0, ry = 0, rd = 0, nt = 0;
-  duo_trim_settle(fin);
   wave_mem_sync();
   if (fin && !cx.bad && s < 2)                      /* lane 0: the A chain, lane 1: the B chain */
     { int ta = cold[DC_TRIM], tk = cold[DC_TRIM + 1], td = cold[DC_TRIM + 2], tha = cold[DC_TRIM + 3], thb = cold[DC_TRIM + 4];
@@ -1283,7 +1356,6 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
   cx.md = MD_SCAN;  cx.m = 0;  cx.bad = 0;
   cx.va0 = cx.vb0 = 16 * PK_PAD;  cx.alen = cx.blen = 0;
   duo_V[lane] = DUO_EDGE;  duo_HA[lane] = duo_HB[lane] = 0;  duo_Tlo[lane] = duo_Thi[lane] = 0;
-  duo_tq[lane].x = -BIG;
   cx.ls = cx.hs = 15;  cx.kbase = 0;  cx.dif = 0;  cx.besta = cx.bestk = cx.lasta = 0;  cx.more = 0;  cx.ncell = 2;
   cx.mlo = cx.mhi = 0;  cx.alim = cx.blim = 0;  cx.offa = cx.offb = 0;  cx.pa0 = cx.pb0 = 0;
   cx.diag = cx.anti = 0;  cx.roota = cx.rootb = 0;  cx.item = 0;
@@ -1552,7 +1624,6 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
             const unsigned long long pf0 = wall_clock64();
             PROF_ADD(28, __popcll(ov) >> 5);
 #endif
-            duo_trim_settle(cx.md == MD_OVF);           /* the excursion carries the trim point as a record */
             for (int h = 0; h < 64; h += 32)
               if ((ov >> h) & 1)
                 { if (uni(duo_half[h >> 5].m))

@@ -87,16 +87,3 @@ def test_tandem_library_is_the_second_boundary(built):
     assert ctypes.c_char_p.in_dll(L, "SORT_PATH").value == b"/tmp"
     H = ctypes.CDLL(os.path.join(ROOT, "damar_amd", "libdamar_hip.so"))
     assert hasattr(H, "Match_Self")
-
-
-def test_experiment_kernel_still_compiles(tmp_path):
-    """kernels/report_slots.h (four read pairs per wavefront) is not in the product but stays
-    buildable: report.hip with -DDAMAR_SLOT_KERNEL compiles for gfx950 and keeps the kernel the launchers name."""
-    hipcc = "/opt/rocm/bin/hipcc"
-    obj = str(tmp_path / "report_slots.o")
-    src = os.path.join(ROOT, "damar_amd", "csrc", "kernels", "report.hip")
-    subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                    "-I" + os.path.join(ROOT, "damar_amd", "csrc"), "-DDAMAR_SLOT_KERNEL", "-DDUO_MARGIN=0", "-Wno-unused-value",
-                    "-c", src, "-o", obj], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    out = subprocess.run(["nm", obj], check=True, stdout=subprocess.PIPE, text=True).stdout
-    assert "damar_report2_slots_per_wave" in out and "damar_launch_report2" in out
