@@ -412,12 +412,6 @@ DUO_PART void duo_begin(int job, u32 cbase)
    count, `more` is 1 unless the rare block behind a sequence end says otherwise.
    Per iteration (static, scripts/asm_blocks.py): see DESIGN.md section 4. */
 #define DUO_EDGES 0xC0000003C0000003ull                    /* lanes 0, 1, 30, 31 of either half */
-#ifndef DUO_EARLY
-#define DUO_EARLY 0
-#endif
-#ifndef DUO_ILV
-#define DUO_ILV 0
-#endif
 #ifndef DUO_DBG
 #define DUO_DBG 0
 #endif
@@ -509,9 +503,7 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
           dsel = inv(takem) ? dsel : 0;
           const int src = lane4 + dsel;
           const u64 actm = allowm & bal(v > DUO_EDGE + 2);
-#if !DUO_ILV
           dif += 1;
-#endif
           st_cells += (u32) __popcll(actm);
           asm("s_sub_u32 %0, %0, 1\n\ts_cselect_b64 %1, -1, %1" : "+s"(left), "+s"(stopm) : : "scc");     /* (the bound: cannot happen) */
           /* the snake (align.c:832-856 / 1542-1566): 16 bases per step off the packed reads; a lane outside the reads takes the
@@ -521,36 +513,12 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
           const u32 pa = (u32) v + (u32) cpa, pb = (u32) v + (u32) cpb;          /* bit positions of the two windows */
           u32 oa = (pa >> 3) & ~3u, ob = (pb >> 3) & ~3u;
           v2u ra, rb;
-#if DUO_EARLY
-          /* the first window's loads leave BEFORE the gathers of the predecessor's state (their addresses need the new V only):
-             the round trip through LDS runs inside the one to L2.  The loads are for the lanes on the window path only; the
-             gathers for every lane */
-          { u64 et;
-            u32 tlo = (u32) rT, thi = (u32) (rT >> 32);
-            ha = rHA;  hb_ = rHB;
-            asm volatile("s_mov_b64 %[et], exec\n\t"
-                         "s_mov_b64 exec, %[fm]\n\t"
-                         "global_load_dwordx2 %[ra], %[oa], %[ap]\n\t"
-                         "global_load_dwordx2 %[rb], %[ob], %[bp]\n\t"
-                         "s_mov_b64 exec, %[et]\n\t"
-                         "ds_bpermute_b32 %[ha], %[src], %[ha]\n\t"
-                         "ds_bpermute_b32 %[hb], %[src], %[hb]\n\t"
-                         "ds_bpermute_b32 %[tl], %[src], %[tl]\n\t"
-                         "ds_bpermute_b32 %[th], %[src], %[th]\n\t"
-                         "s_waitcnt vmcnt(0) lgkmcnt(0)"
-                         : [ra] "=&v"(ra), [rb] "=&v"(rb), [ha] "+v"(ha), [hb] "+v"(hb_), [tl] "+v"(tlo), [th] "+v"(thi), [et] "=&s"(et)
-                         : [fm] "s"(fastm), [oa] "v"(oa), [ob] "v"(ob), [ap] "s"(apk - PK_PAD), [bp] "s"(bpk - PK_PAD), [src] "v"(src)
-                         : "memory");
-            b = ((u64) thi << 32) | tlo;
-          }
-#else
           { ha  = __builtin_amdgcn_ds_bpermute(src, rHA);
             hb_ = __builtin_amdgcn_ds_bpermute(src, rHB);
             const u32 tlo = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) rT);
             const u32 thi = (u32) __builtin_amdgcn_ds_bpermute(src, (int) (u32) (rT >> 32));
             b = ((u64) thi << 32) | tlo;
           }
-#endif
           int ef;
           asm volatile("" : "=v"(ef));              /* (only the byte path's lanes define it; every use is behind bytem) */
           if (bytem)
@@ -583,9 +551,7 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
                 b = (b << (n + (FIRST))) | (u64) ones;         /* (the step's own 0 rides on the first window's shift) */ \
                 v += (int) n2;                                                                                \
               }
-#if !DUO_EARLY
               DUO_LOADS()
-#endif
               DUO_WINDOW(1)
               const u64 contm = bal(m2 > 32u);               /* all 16 equal and more than 16 left: one window in eight hundred */
               if (contm)
@@ -601,46 +567,13 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
 #undef DUO_LOADS
             }
 
-          /* What the rest of the step asks of the new V, in ONE stretch of instructions: the prefix maximum of the candidates
-             for a new best point (align.c:911-928 / 1620-1637) is five DPP steps that each wait two issue slots for their
-             operand; the slots are filled with the tests of the trace marks (align.c:859-909 / 1569-1618: a pebble is due when
-             v reaches the mark after the inherited head's), the popcount of the match history and the test for a read's end,
-             instead of s_nop.  Some lane passes the old best in every step (profiles/r05_loop_blocks.txt): no branch */
+          /* What the rest of the step asks of the new V: is a trace mark crossed (align.c:859-909 / 1569-1618: a pebble is due
+             when v reaches the mark after the inherited head's), is it a new best point (align.c:911-928 / 1620-1637: the
+             candidates' prefix maximum in sweep order), has the history enough matches, is it a read's end.  Some lane
+             passes the old best in every step (profiles/r05_loop_blocks.txt): no branch around the maximum */
           const u64 candm = actm & bal(v > besta);
           int x = inv(candm) ? v : -BIG, e;
           u64 nam, nbm, mokc, endc;
-#if DUO_ILV
-          { int t1, t2, t3, t4;
-            /* (three statements: one whose results are all scalar registers is known to be uniform; mixed with vector
-               results the compiler takes the masks for lane-varying values and computes with them in vector registers) */
-            asm volatile("v_lshrrev_b32 %[t1], 18, %[ha]\n\t"
-                         "v_lshrrev_b32 %[t2], 18, %[hb]\n\t"
-                         "v_max_i32_dpp %[x], %[x], %[x] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_and_b32 %[t3], 0x1fffffff, %[bhi]\n\t"
-                         "v_bcnt_u32_b32 %[t4], %[blo], 0\n\t"
-                         "v_max_i32_dpp %[x], %[x], %[x] row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_mad_i32_i24 %[t1], %[t1], %[ts2], %[cpA]\n\t"
-                         "v_mad_i32_i24 %[t2], %[t2], %[ts2], %[cpB]\n\t"
-                         "v_max_i32_dpp %[x], %[x], %[x] row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_bcnt_u32_b32 %[t4], %[t3], %[t4]\n\t"
-                         "v_add_u32 %[dif], 1, %[dif]\n\t"
-                         "v_max_i32_dpp %[x], %[x], %[x] row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 1\n\t"
-                         "v_max_i32_dpp %[x], %[x], %[x] row_bcast:15 row_mask:0xa bank_mask:0xf"
-                         : [x] "+v"(x), [dif] "+v"(dif), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)
-                         : [ha] "v"(ha), [hb] "v"(hb_), [bhi] "v"((u32) (b >> 32)), [blo] "v"((u32) b),
-                           [cpA] "v"(cpA), [cpB] "v"(cpB), [ts2] "s"(TS2));
-            asm volatile("v_cmp_ge_i32_e64 %[nam], %[v], %[t1]\n\t"
-                         "v_cmp_ge_i32_e64 %[nbm], %[v], %[t2]\n\t"
-                         "v_cmp_le_i32_e64 %[mok], %[ave], %[t4]\n\t"
-                         "v_cmp_eq_u32_e64 %[end], %[v], %[cmin]"
-                         : [nam] "=&s"(nam), [nbm] "=&s"(nbm), [mok] "=&s"(mokc), [end] "=&s"(endc)
-                         : [v] "v"(v), [t1] "v"(t1), [t2] "v"(t2), [t4] "v"(t4), [cmin] "v"(cmin), [ave] "s"(ave));
-            /* the maximum over the lanes before this one; what lane 0 of a half receives does not matter: the band lives
-               in lanes 1 .. 30, lane 0 is never a candidate */
-            asm volatile("v_mov_b32_dpp %[e], %[x] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : [e] "=&v"(e) : [x] "v"(x));
-          }
-#else
           { const int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
             nam = bal(v >= __mul24(ga, TS2) + cpA);  nbm = bal(v >= __mul24(gb, TS2) + cpB);
             x = pk_prefix_max(x);
@@ -650,7 +583,6 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
             mokc = bal(pk_popc61(b) >= ave);
             endc = bal(v == cmin);
           }
-#endif
           nam &= actm;  nbm &= actm;
           if (nam | nbm)
             { const int kk = (K ^ m) - m;
