@@ -508,8 +508,10 @@ static int     PB_ahead;            /* entries [0, PB_ahead) are prepared by the
 static Opts    PB_opts;
 
 /* read, mask, check, reverse-complement and (on the reader thread) upload one block, both strands */
+static int S_loads_;
 static void pblock_load_host(PBlock *b, const Opts *o, int background)
 { double t0 = wall_ms();
+  __atomic_fetch_add(&S_loads_, 1, __ATOMIC_RELAXED);
   static int unpacked = -1;          /* DAMAR_DB_UNPACKED=1: blocks unpacked and complemented on the host as until round 4 (test hook) */
   if (unpacked < 0)
     unpacked = getenv("DAMAR_DB_UNPACKED") != NULL;
@@ -668,25 +670,35 @@ static void pblock_trim(void)
     }
   for (;;)
     { uint64_t sum = 0;
-      int i, v = -1;
+      int i, v = -1, vi = -1;
       pthread_mutex_lock(&PB_mu);                   /* (the reader threads set dev[] and ready under it) */
       for (i = 0; i < PB_n; i++)
         if (PB[i].ready && PB[i].name != NULL)
           { sum += pblock_bytes(PB + i);
-            /* a victim is idle and has been used: a block the readers have just uploaded ahead of its first use stays */
-            if (!PB[i].busy && PB[i].used > 0 && (PB[i].dev[0] || PB[i].dev[1] || PB[i].idx[0] || PB[i].idx[1]) &&
-                (v < 0 || PB[i].used < PB[v].used))
+            /* a victim is idle and has been used: a block the readers have just uploaded ahead of its first use stays.
+               Indexes go first (8 bytes per k-mer against 1.5 per base, and a build is a few ms on the GPU while the bases
+               come over PCIe): a block loses its bases only when no idle block has an index left */
+            if (!PB[i].busy && PB[i].used > 0 && (PB[i].idx[0] || PB[i].idx[1]) && (vi < 0 || PB[i].used < PB[vi].used))
+              vi = i;
+            if (!PB[i].busy && PB[i].used > 0 && (PB[i].dev[0] || PB[i].dev[1]) && (v < 0 || PB[i].used < PB[v].used))
               v = i;
           }
       pthread_mutex_unlock(&PB_mu);
-      if (sum <= PB_budget || v < 0)
+      if (sum <= PB_budget || (v < 0 && vi < 0))
         return;
+      if (vi >= 0)
+        { int c;                                    /* (nothing in flight reads an index once damar_match_batch has returned) */
+          for (c = 0; c < 2; c++)
+            { if (PB[vi].idx[c] != NULL) damar_index_free(PB[vi].idx[c]);
+              PB[vi].idx[c] = NULL;              /* (its buffers are parked in the library's pool: the next build takes them) */
+            }
+          continue;
+        }
       damar_async_drain();                          /* the host tail may still read its bases */
       { int c;                                      /* device side only: the host copy stays for a cheap return */
         for (c = 0; c < 2; c++)
-          { if (PB[v].idx[c] != NULL) damar_index_free(PB[v].idx[c]);
-            if (PB[v].dev[c] != NULL) damar_block_free(PB[v].dev[c]);
-            PB[v].idx[c] = NULL;  PB[v].dev[c] = NULL;
+          { if (PB[v].dev[c] != NULL) damar_block_free(PB[v].dev[c]);
+            PB[v].dev[c] = NULL;
           }
       }
       damar_pool_trim();                            /* (the freed index went to the library's pool: really give it back) */
@@ -738,6 +750,7 @@ static PBlock *pblock_get(const char *name, const Opts *o)
   }
 }
 
+static void stats_take(int lo, int hi);
 static damar_dev_index *pblock_index(PBlock *b, int comp)
 { if (b->idx[comp] == NULL)
     { double t0 = wall_ms();
@@ -747,11 +760,59 @@ static damar_dev_index *pblock_index(PBlock *b, int comp)
       P_ms[7] += wall_ms() - t0;
       t0 = wall_ms();
       b->idx[comp] = damar_index_build(b->dev[comp], 0, &b->ilen[comp]);
+      stats_take(DAMAR_T_TUPLES, DAMAR_T_MERGE);
       P_ms[1] += wall_ms() - t0;
       PB_builds += 1;
       pblock_trim();
     }
   return b->idx[comp];
+}
+
+/* What a plan has cost, summed over its calls (the library's own clocks, include/damar_hip.h DAMAR_T_*), for the one
+   machine-readable line a run leaves behind: DAMAR_PLAN_STATS=<file> ("-": stderr) */
+static double S_ms[DAMAR_T_COUNT];
+static int64  S_seeds, S_pairs;
+static int    S_loads, S_tile, S_blocks, S_resident;
+static double S_budget_gb;
+
+static void stats_take(int lo, int hi)               /* the last call's timings [lo, hi) */
+{ double t[DAMAR_T_COUNT];
+  int    i;
+  damar_last_timings(t);
+  for (i = lo; i < hi; i++)
+    S_ms[i] += t[i];
+}
+
+static void plan_stats_write(int nlines, int worker, int nworkers, double wall)
+{ const char *dst = getenv("DAMAR_PLAN_STATS");
+  static const char *nm[DAMAR_T_COUNT] = { "tuples", "ksort", "table", "merge", "ssort", "work", "report", "d2h", "tail" };
+  int64  nf = 0, nl = 0, nrec = 0, las[4];
+  double rms = 0, tail = 0, wr = 0;
+  FILE  *f;
+  int    i;
+  if (dst == NULL)
+    return;
+  damar_async_counts(&nf, &rms, &nl);
+  damar_async_totals(&nrec, &tail, &wr);
+  S_ms[DAMAR_T_REPORT] += rms;  S_ms[DAMAR_T_TAIL] += tail;  S_ms[DAMAR_T_D2H] += damar_async_d2h_ms();
+  damar_las_totals(las);
+  f = (strcmp(dst, "-") == 0) ? stderr : fopen(dst, worker > 0 ? "a" : "w");
+  if (f == NULL)
+    return;
+  fprintf(f, "{\"tool\": \"daligner -P\", \"worker\": %d, \"workers\": %d, \"plan_lines\": %d, \"block_pairs\": %lld, \"blocks\": %d, "
+             "\"tile\": %d, \"bases_resident\": %d, \"budget_gb\": %.1f, \"index_builds\": %d, \"block_loads\": %d, \"wall_ms\": %.1f, "
+             "\"seed_pairs\": %lld, \"local_alignments\": %lld, \"report_launches\": %lld, \"records\": %lld, "
+             "\"aligned_bp\": %lld, \"las_bytes\": %lld, \"las_files\": %lld, \"phase_ms\": {",
+          worker, nworkers, nlines, (long long) S_pairs, S_blocks, S_tile, S_resident, S_budget_gb, PB_builds, S_loads, wall,
+          (long long) S_seeds, (long long) nf, (long long) nl, (long long) las[2], (long long) las[3], (long long) las[0], (long long) las[1]);
+  for (i = 0; i < DAMAR_T_COUNT; i++)
+    fprintf(f, "\"%s\": %.1f, ", nm[i], S_ms[i]);
+  fprintf(f, "\"write\": %.1f}, \"host_wall_ms\": {", wr);
+  for (i = 0; i < 8; i++)
+    fprintf(f, "%s\"%s\": %.1f", i ? ", " : "", P_name[i], P_ms[i]);
+  fprintf(f, "}}\n");
+  if (f != stderr)
+    fclose(f);
 }
 
 static Align_Spec **PS;             /* the plan's Align_Specs, alive until the asynchronous tail has drained */
@@ -835,6 +896,9 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
       jobs[0].spec = jobs[1].spec = sp;
       t0 = wall_ms();
       damar_match_batch(jobs, 2);
+      stats_take(DAMAR_T_MERGE, DAMAR_T_REPORT);
+      S_seeds += jobs[0].counts[0] + jobs[1].counts[0];
+      S_pairs += 1;
       P_ms[2] += wall_ms() - t0;
       if (a->blk.part > 0) d1 = out_dir(o->runid, a->blk.part);
       if (same)
@@ -912,6 +976,97 @@ static void read_plan(const char *planfile, char ****ltok_p, int **lntok_p, int 
     { *mtok_p = mtok;  *mn_p = mn;  *nm_p = nm; }
 }
 
+/* ---- long plans: more blocks than HBM holds indexes for ------------------------------------------------------
+   HPCdaligner writes one line per A block with all its subject blocks (HPCdaligner.c:628-788): in that order a plan of n
+   blocks touches 2 n indexes per line, and a least-recently-used cache smaller than that misses on EVERY block pair
+   (config 4: 255 blocks of 78 Mbp, 0.62 GB per index, 510 indexes against the ~150 that fit beside the bases).  The
+   block pairs of a plan are independent, so the lines are dealt out anew: the (A, subject) plane is cut into tiles of T x T
+   blocks and a tile's pairs are run together -- T forward indexes of its A blocks, 2 T of its subject blocks -- tile rows
+   in order, the subject tiles of a row back and forth so that consecutive tiles share their subject blocks.  Every
+   output file is the same file; only the order in which they appear changes.  DAMAR_PLAN_TILE=<T> sets T (0: plan order). */
+static int block_no(const char *name, size_t *stem);
+static int64 stub_block_size(const char *blockname)          /* the block size in bases from "size = ..." of the .db stub (DBsplit -s), 0 if unknown */
+{ size_t stem = 0;
+  char   path[4200], ln[512];
+  FILE  *f;
+  int64  size = 0;
+  if (block_no(blockname, &stem) == 0 || stem > 4000)
+    return 0;
+  snprintf(path, sizeof(path), "%.*s.db", (int) stem, blockname);
+  f = fopen(path, "r");
+  if (f == NULL)
+    return 0;
+  while (fgets(ln, sizeof(ln), f) != NULL)
+    { long long v;
+      if (sscanf(ln, " size = %lld", &v) == 1)
+        size = (int64) v * 1000000;                     /* (DBsplit writes its -s argument: Mbp, DBsplit.c:191) */
+    }
+  fclose(f);
+  return size;
+}
+
+/* the plan's lines dealt out by tiles of T x T block numbers; returns the new number of lines */
+static int tile_plan(const Opts *base, char ****ltok_p, int **lntok_p, int nl, int T)
+{ char ***ltok = *ltok_p, ***out = NULL;
+  int   *lntok = *lntok_p, *outn = NULL, *first, *atile;
+  int    i, j, no = 0, cap = 0, lo = 0x7fffffff, hi = 0, ntile, I, J, step;
+  size_t stem;
+  first = (int *) malloc(sizeof(int) * (size_t) (nl + 1));
+  atile = (int *) malloc(sizeof(int) * (size_t) (nl + 1));
+  for (i = 0; i < nl; i++)
+    { Opts o = *base;
+      o.plan = NULL;
+      first[i] = parse_opts(lntok[i], ltok[i], &o);
+      for (j = first[i]; j < lntok[i]; j++)
+        { const int n = block_no(ltok[i][j], &stem);
+          if (n == 0)
+            { free(first);  free(atile);             /* a plan that names whole databases: left as it is */
+              return nl;
+            }
+          if (n < lo) lo = n;
+          if (n > hi) hi = n;
+        }
+    }
+  ntile = (hi - lo) / T + 1;
+  for (i = 0; i < nl; i++)
+    atile[i] = (block_no(ltok[i][first[i]], &stem) - lo) / T;
+  for (I = 0; I < ntile; I++)
+    for (step = 0; step < ntile; step++)
+      { J = (I & 1) ? ntile - 1 - step : step;
+        for (i = 0; i < nl; i++)
+          if (atile[i] == I)
+            { int nb = 0;
+              for (j = first[i] + 1; j < lntok[i]; j++)
+                if ((block_no(ltok[i][j], &stem) - lo) / T == J)
+                  nb += 1;
+              if (nb == 0)
+                continue;
+              if (no >= cap)
+                { cap = 2 * cap + 256;
+                  out = (char ***) realloc(out, sizeof(char **) * (size_t) cap);
+                  outn = (int *) realloc(outn, sizeof(int) * (size_t) cap);
+                }
+              out[no] = (char **) malloc(sizeof(char *) * (size_t) (first[i] + nb + 2));
+              for (j = 0; j <= first[i]; j++)
+                out[no][j] = strdup(ltok[i][j]);
+              outn[no] = first[i] + 1;
+              for (j = first[i] + 1; j < lntok[i]; j++)
+                if ((block_no(ltok[i][j], &stem) - lo) / T == J)
+                  out[no][outn[no]++] = strdup(ltok[i][j]);
+              out[no][outn[no]] = NULL;
+              no += 1;
+            }
+      }
+  for (i = 0; i < nl; i++)
+    { for (j = 0; j < lntok[i]; j++)
+        free(ltok[i][j]);
+      free(ltok[i]);
+    }
+  free(ltok);  free(lntok);  free(first);  free(atile);
+  *ltok_p = out;  *lntok_p = outn;
+  return no;
+}
+
 static int node_main(const Opts *base, const char *planfile);
 static int PLAN_done_fd = -1;          /* the worker of plan mode writes one byte here when every .las is closed */
 
@@ -921,7 +1076,8 @@ static int plan_main(const Opts *base, const char *planfile)
   int    i, j, same_masks = 1;
   pthread_t reader[8];                 /* DAMAR_PLAN_READERS of them (2): a block's read + complement + upload take ~95 ms, a plan line less */
   int nreaders = 2;
-  int    have_reader = 0;
+  int    have_reader = 0, device_up = 0;
+  const double t_plan0 = wall_ms();
 
   if (base->gpus != NULL)
     return node_main(base, planfile);
@@ -940,6 +1096,8 @@ static int plan_main(const Opts *base, const char *planfile)
      (damar_gate.h) instead of colliding with it; a caller that chains GPU commands without anything in between is
      better off with DAMAR_PLAN_TIDY=1 (one process that releases everything itself: 0.85 s per command against 1.0)
      or with one plan for all of them.  A child that dies before it is done is waited for and reported. */
+  if (getenv("DAMAR_PLAN_DRYRUN") != NULL)
+    setenv("DAMAR_PLAN_TIDY", "1", 1);
   if (getenv("DAMAR_PLAN_TIDY") == NULL && damar_profiler_preloaded())
     { fprintf(stderr, "daligner: a profiler is preloaded (the GPU runtime is up before main): running the plan in this "
                       "process (DAMAR_PLAN_TIDY=1)\n");
@@ -972,6 +1130,81 @@ static int plan_main(const Opts *base, const char *planfile)
         }
       close(pfd[0]);
       PLAN_done_fd = pfd[1];
+    }
+
+  /* a long plan (see tile_plan): the device first -- its HBM decides the tile -- then the lines in tile order; the
+     bases of every block stay resident if they fit beside the indexes of a tile, and the reader threads bring them all */
+  { int nblk = 0, want_tile = -1;
+    char **seen = NULL;
+    for (i = 0; i < nl; i++)
+      { Opts o = *base;
+        int  first;
+        o.plan = NULL;
+        first = parse_opts(lntok[i], ltok[i], &o);
+        for (j = first; j < lntok[i]; j++)
+          { int k, dup = 0;
+            for (k = 0; k < nblk && !dup; k++)
+              dup = (strcmp(seen[k], ltok[i][j]) == 0);
+            if (!dup)
+              { seen = (char **) realloc(seen, sizeof(char *) * (size_t) (nblk + 1));
+                seen[nblk++] = ltok[i][j];
+              }
+          }
+      }
+    S_blocks = nblk;
+    if (getenv("DAMAR_PLAN_TILE") != NULL)
+      want_tile = atoi(getenv("DAMAR_PLAN_TILE"));
+    if (nl > 0 && nblk > 1 && (want_tile > 0 || (want_tile < 0 && nblk > PB_max)))
+      { const int64 size = stub_block_size(seen[0]);
+        uint64_t fr = 0, tot = 0, budget;
+        double   dev1, idx1;
+        int      T;
+        if (getenv("DAMAR_PLAN_DRYRUN") == NULL)
+          { select_device(base);
+            device_up = 1;
+            mark("device selected (HIP up): long plan");
+            damar_hbm_info(&fr, &tot);
+          }
+        budget = (uint64_t) (.55 * (double) (fr < tot ? fr : tot));
+        if (getenv("DAMAR_PLAN_GB") != NULL && atof(getenv("DAMAR_PLAN_GB")) > 0)
+          budget = (uint64_t) (atof(getenv("DAMAR_PLAN_GB")) * 1073741824.);
+        PB_budget = budget;
+        S_budget_gb = (double) budget / 1073741824.;
+        dev1 = 1.5 * (double) size;  idx1 = 8. * (double) size;            /* one strand: bases + two packed copies; 8 B per k-mer */
+        if (size > 0 && (double) nblk * 2. * dev1 <= .45 * (double) budget)
+          { T = (int) (((double) budget - (double) nblk * 2. * dev1) / (3. * idx1));
+            S_resident = 1;
+            if (getenv("DAMAR_PLAN_BLOCKS") == NULL)
+              PB_max = nblk;
+          }
+        else if (size > 0)
+          { T = (int) ((double) budget / (3. * (dev1 + idx1)));
+            if (getenv("DAMAR_PLAN_BLOCKS") == NULL && 2 * T + 8 > PB_max)
+              PB_max = 2 * T + 8 < nblk ? 2 * T + 8 : nblk;
+          }
+        else
+          T = 32;
+        if (want_tile > 0)
+          T = want_tile;
+        if (T < 4)
+          T = 4;
+        if (T < nblk)
+          { nl = tile_plan(base, &ltok, &lntok, nl, T);
+            S_tile = T;
+          }
+        if (VERBOSE || getenv("DAMAR_CLIPROF"))
+          fprintf(stderr, "daligner: long plan: %d blocks of %lld bases, budget %.1f GB, tiles of %d blocks%s, %d lines\n",
+                  nblk, (long long) size, S_budget_gb, S_tile, S_resident ? ", bases of every block resident" : "", nl);
+      }
+    free(seen);
+  }
+  if (getenv("DAMAR_PLAN_DRYRUN") != NULL)         /* the lines as they would be run (tests/test_host.py): no GPU needed */
+    { for (i = 0; i < nl; i++)
+        { for (j = 0; j < lntok[i]; j++)
+            printf("%s%s", j ? " " : "", ltok[i][j]);
+          printf("\n");
+        }
+      return 0;
     }
 
   /* the block table, and what the reader thread prepares ahead: the blocks in order of first use */
@@ -1033,8 +1266,10 @@ static int plan_main(const Opts *base, const char *planfile)
   /* The device comes up (a few hundred ms in a cold process) while the reader thread already reads and complements the
      first blocks; it uploads once the flag below is set. */
   mark("plan parsed, reader threads started");
-  select_device(base);
-  mark("device selected (HIP up)");
+  if (!device_up)
+    { select_device(base);
+      mark("device selected (HIP up)");
+    }
   if (getenv("DAMAR_PREWARM_GB") && atoi(getenv("DAMAR_PREWARM_GB")) > 0)
     { pthread_t th;                     /* grow the HBM footprint next to reading the first blocks (see damar_prewarm) */
       static int gb;
@@ -1059,6 +1294,8 @@ static int plan_main(const Opts *base, const char *planfile)
   mark("last plan line submitted");
   TIMED(5, damar_async_drain());
   mark("drained: every .las closed");
+  S_loads = __atomic_load_n(&S_loads_, __ATOMIC_RELAXED);
+  plan_stats_write(nl, 0, 1, wall_ms() - t_plan0);
   if (getenv("DAMAR_PLAN_TIDY") == NULL)
     { /* every file is closed; releasing tens of GB of HBM buffer by buffer, joining the threads and tearing the HIP context
          down costs a tenth of a second of wall time and changes nothing on disk: leave that to process exit */

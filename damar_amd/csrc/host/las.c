@@ -316,8 +316,64 @@ static void las_fail(const LasOut *o, const char *what)
   exit(1);
 }
 
+/* What the writers have produced since the process started (bytes, files, records): the output rate of a long plan is
+   stated beside its compute rate.  DAMAR_LAS_KEEP names a text file of path endings; with it set only
+   the .las files whose path ends in one of them are written where they belong, every other file goes through the same
+   record assembly and write() calls into /dev/null -- a measurement aid for plans whose output (config 4: ~55 GB) is not
+   wanted on the box, with the sampled files kept for their md5s. */
+static int64 LAS_total[4];               /* bytes, files, records, aligned bp = sum of aepos - abpos over the records */
+void damar_las_totals(int64 *out)
+{ int i;
+  for (i = 0; i < 4; i++)
+    out[i] = __atomic_load_n(&LAS_total[i], __ATOMIC_RELAXED);
+}
+
+static char **LAS_keep;
+static int    LAS_nkeep = -1;          /* -1: DAMAR_LAS_KEEP not read yet */
+static pthread_mutex_t LAS_keep_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static int las_is_kept(const char *path)
+{ int i;
+  size_t lp = strlen(path);
+  pthread_mutex_lock(&LAS_keep_mu);
+  if (LAS_nkeep < 0)
+    { const char *lst = getenv("DAMAR_LAS_KEEP");
+      LAS_nkeep = 0;
+      if (lst != NULL && lst[0] != '\0')
+        { FILE *f = fopen(lst, "r");
+          char  ln[4400];
+          if (f == NULL)
+            { fprintf(stderr, "damar: cannot read DAMAR_LAS_KEEP=%s\n", lst);
+              exit(1);
+            }
+          LAS_keep = (char **) malloc(sizeof(char *));
+          LAS_keep[0] = NULL;                        /* (set, possibly empty: everything else is discarded) */
+          while (fgets(ln, sizeof(ln), f) != NULL)
+            { size_t n = strlen(ln);
+              while (n > 0 && (ln[n - 1] == '\n' || ln[n - 1] == ' '))
+                ln[--n] = '\0';
+              if (n == 0)
+                continue;
+              LAS_keep = (char **) realloc(LAS_keep, sizeof(char *) * (size_t) (LAS_nkeep + 2));
+              LAS_keep[LAS_nkeep++] = strdup(ln);
+            }
+          fclose(f);
+        }
+    }
+  pthread_mutex_unlock(&LAS_keep_mu);
+  if (LAS_keep == NULL)
+    return 1;
+  for (i = 0; i < LAS_nkeep; i++)
+    { size_t lk = strlen(LAS_keep[i]);
+      if (lk <= lp && strcmp(path + (lp - lk), LAS_keep[i]) == 0)
+        return 1;
+    }
+  return 0;
+}
+
 static void las_flush(LasOut *o)
 { size_t done = 0;
+  __atomic_fetch_add(&LAS_total[0], (int64) o->fill, __ATOMIC_RELAXED);
   while (done < o->fill)
     { const ssize_t w = write(o->fd, o->buf + done, o->fill - done);
       if (w < 0)
@@ -351,7 +407,7 @@ static LasOut las_open(const char *path, int tspace)
   o.cap  = (size_t) 4 << 20;
   o.fill = 0;
   o.buf  = (char *) malloc(o.cap);
-  o.fd   = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+  o.fd   = las_is_kept(path) ? open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666) : open("/dev/null", O_WRONLY);
   if (o.fd < 0 || o.buf == NULL)
     las_fail(&o, "open for writing");
   las_put(&o, &none, sizeof(none));
@@ -374,6 +430,8 @@ static void las_record(LasOut *o, const Keyed *k, int tbytes)
 
 static void las_close(LasOut *o, int64 n)
 { las_flush(o);
+  __atomic_fetch_add(&LAS_total[1], 1, __ATOMIC_RELAXED);
+  __atomic_fetch_add(&LAS_total[2], n, __ATOMIC_RELAXED);
   if (pwrite(o->fd, &n, sizeof(n), 0) != (ssize_t) sizeof(n) || close(o->fd) != 0)
     las_fail(o, "finish");
   free(o->buf);
@@ -445,9 +503,13 @@ typedef struct { const char *path; int tspace, tbytes; const Keyed *recs; int n;
 static void *write_file_part(void *arg)
 { const FilePart *f = (const FilePart *) arg;
   LasOut out = las_open(f->path, f->tspace);
+  int64  bp = 0;
   int    j;
   for (j = 0; j < f->n; j++)
-    las_record(&out, f->recs + j, f->tbytes);
+    { las_record(&out, f->recs + j, f->tbytes);
+      bp += f->recs[j].ovl->path.aepos - f->recs[j].ovl->path.abpos;
+    }
+  __atomic_fetch_add(&LAS_total[3], bp, __ATOMIC_RELAXED);
   las_close(&out, f->n);
   return NULL;
 }

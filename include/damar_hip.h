@@ -181,6 +181,9 @@ void damar_trace_release(void);          /* frees the cached device buffers of d
 enum { DAMAR_T_TUPLES = 0, DAMAR_T_KSORT, DAMAR_T_TABLE, DAMAR_T_MERGE, DAMAR_T_SSORT,
        DAMAR_T_WORK, DAMAR_T_REPORT, DAMAR_T_D2H, DAMAR_T_TAIL, DAMAR_T_COUNT };
 void damar_last_timings(double *ms /* [DAMAR_T_COUNT] */);
+/* bytes, files, records and aligned base pairs (sum of aepos - abpos) the .las writers have produced since the process started (host/las.c; with DAMAR_LAS_KEEP=<list>
+   only the files whose path ends in a line of <list> reach the file system, the rest /dev/null: measurement of long plans) */
+void damar_las_totals(int64 *out /* [4] */);
 
 /* Counters of the last damar_match / damar_match_batch (summed over its comparisons): [0] seed pairs, [1] work items
  * (read pairs entered), [2] Local_Alignment calls, [3] records from the device, [4] trace values, [5] launches of the

@@ -383,6 +383,43 @@ def test_node_scheduler_work_list_covers_every_block_pair_once(built, tmp_path, 
     else:
         assert len(cost) == 1 and max(n for v in pairs.values() for _, n in v) > 1
 
+@pytest.mark.parametrize("nb,tile", [(10, 4), (255, 50), (17, 17), (9, 0)])
+def test_long_plan_lines_are_dealt_out_by_tiles_without_losing_a_pair(built, tmp_path, nb, tile):
+    """`daligner -P plan` on a plan with more blocks than HBM holds indexes for (host/daligner.c tile_plan; the work list of
+    HPCdaligner.c:628-788): the lines come out in tiles of T x T block numbers -- every (A, subject) pair of the plan exactly
+    once, a line's subject blocks within one tile, tile rows in order and the subject tiles of a row back and forth, so that
+    the blocks a stretch of lines names are at most 2 T.  DAMAR_PLAN_DRYRUN prints the lines instead of running them."""
+    import subprocess
+    from damar_amd import api
+    work = str(tmp_path)
+    want = set()
+    with open(os.path.join(work, "plan.txt"), "w") as f:
+        for a in range(1, nb + 1):
+            f.write("daligner -k14 -j16 SIM.%d %s\n" % (a, " ".join("SIM.%d" % b for b in range(a, 0, -1))))
+            want |= {(a, b) for b in range(1, a + 1)}
+    r = subprocess.run([api.daligner_binary(), "-P", "plan.txt"], cwd=work, stdout=subprocess.PIPE, text=True, check=True,
+                       env=dict(os.environ, DAMAR_PLAN_DRYRUN="1", DAMAR_PLAN_TILE=str(tile)))
+    got, tiles = [], []
+    for ln in r.stdout.splitlines():
+        t = ln.split()
+        assert t[:3] == ["daligner", "-k14", "-j16"]
+        a, bs = int(t[3].split(".")[1]), [int(x.split(".")[1]) for x in t[4:]]
+        assert bs
+        got += [(a, b) for b in bs]
+        if tile and tile < nb:
+            tj = {(b - 1) // tile for b in bs}
+            assert len(tj) == 1
+            tiles.append(((a - 1) // tile, tj.pop()))
+    assert len(got) == len(want) and set(got) == want
+    if tile and tile < nb:
+        order = [t for i, t in enumerate(tiles) if i == 0 or tiles[i - 1] != t]
+        assert len(order) == len(set(order))                      # a tile is run in one stretch
+        assert [t[0] for t in order] == sorted(t[0] for t in order)
+        for (i0, j0), (i1, j1) in zip(order, order[1:]):
+            assert (i1 == i0 and abs(j1 - j0) == 1) or i1 == i0 + 1
+    else:
+        assert len(r.stdout.splitlines()) == nb                   # plan order, untouched
+
 
 def test_teardown_gate_makes_the_next_worker_wait_for_the_one_that_is_leaving(tmp_path):
     """host/damar_gate.h: a worker takes the per-GPU lock before it reports "done" and keeps it until its process is gone;
