@@ -104,8 +104,9 @@ static void check_reads(const HITS_DB *b, const char *name, int kmer)
 
 /* DAMAR_CLIPROF=1: wall clock of the driver's phases on stderr at exit */
 #include <time.h>
-static double P_ms[8];
-static const char *P_name[8] = { "read_block(2nd thread)", "Sort_Kmers", "Match_Filter", "complement(2nd thread)", "write_submit", "drain", "wait_for_block", "upload(2nd thread)" };
+static double P_ms[12];
+static const char *P_name[12] = { "read_block(2nd thread)", "Sort_Kmers", "Match_Filter", "complement(2nd thread)", "write_submit", "drain", "wait_for_block", "upload(2nd thread)",
+                                  "New_Align_Spec", "line_setup", "block_get", "subdirs" };
 static double wall_ms(void)
 { struct timespec t;
   clock_gettime(CLOCK_MONOTONIC, &t);
@@ -467,7 +468,7 @@ int main(int argc, char *argv[])
   damar_set_async(0);
   if (getenv("DAMAR_CLIPROF"))
     { fprintf(stderr, "cli: wall ms:");
-      for (i = 0; i < 8; i++)
+      for (i = 0; i < 12; i++)
         fprintf(stderr, " %s=%.1f", P_name[i], P_ms[i]);
       fprintf(stderr, "\n");
     }
@@ -808,7 +809,7 @@ static void plan_stats_write(int nlines, int worker, int nworkers, double wall)
   for (i = 0; i < DAMAR_T_COUNT; i++)
     fprintf(f, "\"%s\": %.1f, ", nm[i], S_ms[i]);
   fprintf(f, "\"write\": %.1f}, \"host_wall_ms\": {", wr);
-  for (i = 0; i < 8; i++)
+  for (i = 0; i < 12; i++)
     fprintf(f, "%s\"%s\": %.1f", i ? ", " : "", P_name[i], P_ms[i]);
   fprintf(f, "}}\n");
   if (f != stderr)
@@ -860,13 +861,16 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
         }
     }
   last = *o;  have_last = 1;
-  apply_opts(o);
-  a = pblock_get(afile, o);
-  a->busy = 1;
-  aroot = damar_root(afile, ".db");
-  if (SYMMETRIC)
-    SYMMETRIC = symmetric_for(afile, aroot, bfiles, nb);
-  make_subdir(&a->blk, o->runid);
+  { const double t0 = wall_ms();
+    apply_opts(o);
+    a = pblock_get(afile, o);
+    a->busy = 1;
+    aroot = damar_root(afile, ".db");
+    if (SYMMETRIC)
+      SYMMETRIC = symmetric_for(afile, aroot, bfiles, nb);
+    make_subdir(&a->blk, o->runid);
+    P_ms[9] += wall_ms() - t0;
+  }
   /* One damar_match_batch per subject block (both orientations: one launch of the report kernel).  The library leaves
      that launch in flight when the call returns: the next block's index builds and seed stages run beside it, and the
      write request below is queued behind the launch's own tails (include/damar_hip.h).  Every subject block has its
@@ -881,12 +885,12 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
       double      t0;
       damar_dev_index *ai = pblock_index(a, 0);
       memset(jobs, 0, sizeof(jobs));
-      b = same ? a : pblock_get(bfiles[k], o);
+      TIMED(10, b = same ? a : pblock_get(bfiles[k], o));
       b->busy = 1;
-      sp = New_Align_Spec(o->ecorr, o->spacing, a->blk.freq, o->nthreads, SYMMETRIC, o->only_id, o->notrace, 1);
-      plan_keep_spec(sp);
+      TIMED(8, sp = New_Align_Spec(o->ecorr, o->spacing, a->blk.freq, o->nthreads, SYMMETRIC, o->only_id, o->notrace, 1);
+               plan_keep_spec(sp));
       if (!same && SYMMETRIC)
-        make_subdir(&b->blk, o->runid);
+        TIMED(11, make_subdir(&b->blk, o->runid));
       jobs[0].ablock = jobs[1].ablock = &a->blk;
       jobs[0].aidx = jobs[1].aidx = ai;
       jobs[0].bblock = &b->blk;   jobs[0].bidx = same ? ai : pblock_index(b, 0);
@@ -1301,7 +1305,7 @@ static int plan_main(const Opts *base, const char *planfile)
          down costs a tenth of a second of wall time and changes nothing on disk: leave that to process exit */
       if (getenv("DAMAR_CLIPROF"))
         { fprintf(stderr, "cli: %d plan lines, %d index builds; wall ms:", nl, PB_builds);
-          for (i = 0; i < 8; i++)
+          for (i = 0; i < 12; i++)
             fprintf(stderr, " %s=%.1f", P_name[i], P_ms[i]);
           fprintf(stderr, "\n");
         }
@@ -1342,7 +1346,7 @@ static int plan_main(const Opts *base, const char *planfile)
   mark("host pipeline stopped");
   if (getenv("DAMAR_CLIPROF"))
     { fprintf(stderr, "cli: %d plan lines, %d index builds; wall ms:", nl, PB_builds);
-      for (i = 0; i < 8; i++)
+      for (i = 0; i < 12; i++)
         fprintf(stderr, " %s=%.1f", P_name[i], P_ms[i]);
       fprintf(stderr, "\n");
     }

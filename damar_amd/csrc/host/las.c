@@ -95,8 +95,20 @@ Align_Spec *New_Align_Spec(double ave_corr, int trace_space, float *freq, int nt
     }
   left = bias_factor[step] * (1. - ave_corr);                   /* the share of columns that may differ */
   s->ave_path = (int) (PATH_LEN * (1. - left));
-  { const int mscore = (int) (FRACTION * left);
-    trim_tables(mscore, FRACTION - mscore, s->score, s->table);
+  { /* the two tables depend on the match score alone: a plan builds a specification per block pair (its overlap buffers
+       are the pair's own), the tables of the last one are copied while the score stays what it was (128 KB instead of
+       half a million table steps) */
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    static int    have = 0, last_mscore = 0;
+    static int16  last[2 * TRIM_SIZE];
+    const int mscore = (int) (FRACTION * left);
+    pthread_mutex_lock(&mu);
+    if (!have || last_mscore != mscore)
+      { trim_tables(mscore, FRACTION - mscore, last, last + TRIM_SIZE);
+        have = 1;  last_mscore = mscore;
+      }
+    memcpy(s->score, last, sizeof(last));
+    pthread_mutex_unlock(&mu);
   }
 
   s->iobuf = (Overlap_IO_Buffer *) malloc(sizeof(Overlap_IO_Buffer) * (size_t) (nthreads > 0 ? nthreads : 1));
@@ -147,7 +159,10 @@ Overlap_IO_Buffer *CreateOverlapBuffer(int nthreads, int tbytes, int no_trace)
       return NULL;
     }
   buf = (Overlap_IO_Buffer *) calloc(1, sizeof(Overlap_IO_Buffer));
-  if (buf == NULL || (buf->ovls = (Overlap *) calloc((size_t) records, sizeof(Overlap))) == NULL)
+  /* (the records are not cleared: every one is written as a whole before it is read -- AddOverlapToBuffer copies the
+     struct, the writer assembles its 40 bytes field by field -- and clearing 24 MB per block pair was 1.3 ms of the
+     thread that feeds the GPU) */
+  if (buf == NULL || (buf->ovls = (Overlap *) malloc((size_t) records * sizeof(Overlap))) == NULL)
     return NULL;
   buf->omax = records;
   buf->no_trace = no_trace;
