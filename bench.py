@@ -500,9 +500,33 @@ def datander_leg(api, driver, L, base, tandem_frac):
 
 
 def visible_gpus():
-    """GPUs this process could use, WITHOUT initialising the runtime (torch.cuda.device_count() does not, on this image)."""
-    import torch
-    return torch.cuda.device_count()
+    """GPUs this process could use, counted WITHOUT the HIP / HSA runtime: the kfd topology nodes that have SIMDs
+    (/sys/class/kfd/kfd/topology/nodes/*/properties, as host/daligner.c gpu_numa_node_sysfs does), cut down by the
+    *_VISIBLE_DEVICES lists the runtime would honour.  (torch.cuda.device_count() is hipGetDeviceCount on a torch without
+    amdsmi: the runtime would be up in the process that is about to start the ranks -- ADVICE r5.)"""
+    import glob
+    n = 0
+    for f in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")):
+        try:
+            props = dict(ln.split()[:2] for ln in open(f) if len(ln.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def profiler_preloaded(env=None):
+    """A profiler / tool library that initialises the GPU runtime before main() (rocprofv3 does): a process started under it
+    must not start GPU children of its own (the same rule as damar_profiler_preloaded() in host/daligner.c)."""
+    env = os.environ if env is None else env
+    if env.get("ROCP_TOOL_LIBRARIES") or env.get("HSA_TOOLS_LIB") or env.get("ROCPROFILER_LIBRARY_PATH"):
+        return True
+    return any(k in env.get("LD_PRELOAD", "") for k in ("rocprof", "roctracer", "rocprofiler"))
 
 
 def relaunch_under_torchrun(ngpus, argv=None, run=subprocess.run):
@@ -512,6 +536,10 @@ def relaunch_under_torchrun(ngpus, argv=None, run=subprocess.run):
     import socket
     argv = list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ)
+    if profiler_preloaded(env):
+        raise SystemExit("bench.py: --gpus %d under a preloaded profiler: this process's GPU runtime is already up and must not "
+                         "start the ranks.  Profile `python -m torch.distributed.run ... bench.py --gpus %d` started from outside, "
+                         "or one rank (--gpus 1)" % (ngpus, ngpus))
     have = visible_gpus()
     if have < ngpus:
         if not env.get("DAMAR_BENCH_SHARE_GPU"):
@@ -529,7 +557,7 @@ def relaunch_under_torchrun(ngpus, argv=None, run=subprocess.run):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="one rank per GPU (default: the launcher's WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=5)       # (2 until round 4: a step is 0.25 s, and two steps are mostly the pipeline filling and draining)
     ap.add_argument("--warmup", type=int, default=2)      # (the second warm-up step allocates the second pinned landing buffer of the host pipeline)
     ap.add_argument("--config", type=int, default=0, help="BASELINE config of the database: 2 or 3 (default: 2 on one GPU, 3 on several)")
@@ -542,6 +570,8 @@ def main():
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus is None:                 # `torchrun --nproc-per-node N bench.py`: the launcher says how many
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: start the N ranks as CHILDREN (one process per GPU under
         # torch.distributed.run, the same command the contract names) before this process has touched the GPU -- it never does

@@ -684,6 +684,12 @@ static void pblock_trim(void)
             if (!PB[i].busy && PB[i].used > 0 && (PB[i].dev[0] || PB[i].dev[1]) && (v < 0 || PB[i].used < PB[v].used))
               v = i;
           }
+      if (v < 0 && vi < 0 && sum > PB_budget)      /* nothing used and idle is left: the block the readers brought that is
+                                                      needed LAST gives its bases back (they are uploaded again from the
+                                                      host copy when its turn comes: pblock_index) -- ADVICE r5 */
+        for (i = PB_n - 1; i >= 0 && v < 0; i--)
+          if (PB[i].ready && PB[i].name != NULL && !PB[i].busy && PB[i].used == 0 && (PB[i].dev[0] || PB[i].dev[1]))
+            v = i;
       pthread_mutex_unlock(&PB_mu);
       if (sum <= PB_budget || (v < 0 && vi < 0))
         return;
@@ -1580,8 +1586,15 @@ static int cpulist_to_set(const char *text, cpu_set_t *set)
    sysfs entry names the NUMA node.  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES given as ordinals are mapped through.
    -1 when anything is missing: the worker then takes an even share of the job's cores, unbound. */
 static int gpu_numa_node_sysfs(int gpu)
-{ const char *vis = getenv("ROCR_VISIBLE_DEVICES") ? getenv("ROCR_VISIBLE_DEVICES") : getenv("HIP_VISIBLE_DEVICES");
+{ const char *rocr = getenv("ROCR_VISIBLE_DEVICES"), *hipv = getenv("HIP_VISIBLE_DEVICES");
+  const char *vis = rocr ? rocr : hipv;
   int want = gpu, n, seen = 0;
+  /* the runtime also honours CUDA_VISIBLE_DEVICES and GPU_DEVICE_ORDINAL, and with both a ROCR_ and a HIP_ list the second
+     indexes into the first: rather no binding than the threads and the memory policy on another GPU's node */
+  if ((getenv("CUDA_VISIBLE_DEVICES") != NULL && getenv("CUDA_VISIBLE_DEVICES")[0] != 0) ||
+      (getenv("GPU_DEVICE_ORDINAL") != NULL && getenv("GPU_DEVICE_ORDINAL")[0] != 0) ||
+      (rocr != NULL && rocr[0] != 0 && hipv != NULL && hipv[0] != 0))
+    return -1;
   if (vis != NULL && vis[0] != 0)
     { const char *c = vis;
       int i;

@@ -245,6 +245,9 @@ void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks,
 /* several read pairs (or batch tasks, tasks != NULL) per wavefront: report_packed.h; nslots a multiple of damar_report2_slots_per_wave() */
 void damar_launch_report2(const ReportArgs *jobs, int njobs, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
 void damar_launch_tandem_report2(const ReportArgs *a, const int *dist, int nslots, hipStream_t st);     /* datander through the same kernel */
+/* the reads / tasks the two-pair kernel left to the 16-byte pebbles (a->widemap, reads beyond DAMAR_MAX_MARKS spacings) */
+void damar_launch_tandem_report_wide(const ReportArgs *a, const int *dist, int nslots, hipStream_t st);
+void damar_launch_la_batch_wide(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st);
 #define DAMAR_MAX_MARKS 16000         /* trace-grid indexes ride in the top 14 bits of a chain head (report.hip PK_HBITS) */
 #define DAMAR_MAX_CELLS (1u << 18)    /* pebbles per slot: 18 bits of a chain head */
 

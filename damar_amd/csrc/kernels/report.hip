@@ -1788,6 +1788,7 @@ __device__ void process_pair(const ReportArgs &a, const u32 *trimtab, const Slot
  * a k-mer's last base + 1, in [K, alen]) is the distance to the previous equal k-mer of the
  * read, or 0.  Same three bucket passes as process_pair, but the "hits" are the positions of
  * the read itself and the alignment is the read against itself (selfie: minp = 1). */
+template <int WD = 0>
 __device__ void process_read(const ReportArgs &a, const u32 *trimtab, const SlotScratch &s, const int *dist, u32 item)
 { const int  lane = lane_id();
   const int  K = a.kmer, H = a.hitmin, W = a.binshift;
@@ -1795,6 +1796,8 @@ __device__ void process_read(const ReportArgs &a, const u32 *trimtab, const Slot
   const int  ar = (int) item;
   const int  alen = (int) read_len(a.ablk, ar);
   const int *code = dist + ((u64) a.ablk.boff[ar] - (u64) ar * (u64) K) - K;      /* code[apos] */
+  if (WD && !pair_is_wide(a, item, alen, alen))      /* the wide kernel walks the whole list of reads for its few */
+    return;
 
   WaveCtx c;
   c.aseq = a.ablk.bases + a.ablk.boff[ar];
@@ -1806,6 +1809,10 @@ __device__ void process_read(const ReportArgs &a, const u32 *trimtab, const Slot
   c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
   c.koff = alen + 8;  c.ring = a.span;
   c.cells = s.cells;  c.cell_cap = a.cell_cap;
+  if (WD)
+    { c.cells = (Cell *) ((WCell *) a.wcells + (u64) blockIdx.x * a.wcell_cap);
+      c.cell_cap = a.wcell_cap;
+    }
   c.err = &a.counters[3];
   c.atr = s.atr;  c.btr = s.btr;
 
@@ -1868,7 +1875,7 @@ __device__ void process_read(const ReportArgs &a, const u32 *trimtab, const Slot
               int lo, hi;
 
               if (lane == 0) atomicAdd(a.nfilt, 1u);
-              local_alignment(c, 0u, sdg, sap + sbp, &r);
+              local_alignment<WD>(c, 0u, sdg, sap + sbp, &r);
               diagonal_span(s, r, a.tspace, W, &lo, &hi);
               if (sd < lo) lo = sd; else if (sd > hi) hi = sd;
               if (lo < mind - 1) lo = mind - 1;
@@ -1880,7 +1887,7 @@ __device__ void process_read(const ReportArgs &a, const u32 *trimtab, const Slot
               if (hi > chi) chi = hi;
               wave_mem_sync();
               if ((r.aepos - r.abpos) + (r.bepos - r.bbpos) >= a.minover)
-                emit_record(a.job, s, r, ar, ar, item, seq++);
+                emit_record(a.job, s, r, ar, ar, item | (WD ? DAMAR_ITEM_WIDE : 0u), seq++);
             }
         }
 
@@ -1932,6 +1939,33 @@ void damar_launch_tandem_report(const ReportArgs *a, const int *dist, int nslots
     return;
   jobs_upload(a, 1, st);
   hipLaunchKernelGGL(tandem_kernel, dim3(nslots), dim3(64), 0, st, dist);
+}
+
+/* datander's reads beyond the packed pebble format (scrub/tandem.c:1026 calls Local_Alignment on reads of any length:
+   align.c:505-513 grows its vectors), behind the two-pair kernel like report_wide_kernel behind a daligner launch */
+__global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
+void tandem_wide_kernel(const int *dist)
+{ const ReportArgs &a = g_jobs[0];
+  __shared__ u32 trimtab[256];
+  pk_fill_trimtab(trimtab, a.mscore, a.dscore);
+  __syncthreads();
+  const SlotScratch s = slot_scratch(a, blockIdx.x);
+  for (;;)
+    { u32 item = 0;
+      if (lane_id() == 0)
+        item = atomicAdd(a.cursor, 1u);
+      item = (u32) uni((int) item);
+      if (item >= a.nwork)
+        break;
+      process_read<1>(a, trimtab, s, dist, item);
+    }
+}
+
+void damar_launch_tandem_report_wide(const ReportArgs *a, const int *dist, int nslots, hipStream_t st)
+{ if (a->nwork == 0)
+    return;
+  jobs_upload(a, 1, st);
+  hipLaunchKernelGGL(tandem_wide_kernel, dim3(nslots), dim3(64), 0, st, dist);
 }
 
 __global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
@@ -2000,7 +2034,9 @@ void damar_launch_report(const ReportArgs *jobs, int njobs, int nslots, hipStrea
   hipLaunchKernelGGL(report_kernel, dim3(nslots), dim3(64), 0, st, njobs);
 }
 
-/* batch Local_Alignment (tests): one wave per task, result always emitted */
+/* batch Local_Alignment (tests): one wave per task, result always emitted.  WD: only the tasks the two-pair kernel left
+   (reads beyond the packed trace grid, or flagged in the job's map), with 16-byte pebbles */
+template <int WD>
 __global__ __launch_bounds__(64, REPORT_WAVES_PER_SIMD)
 void la_batch_kernel(const LaTask *tasks, u32 ntasks)
 { const ReportArgs &a = g_jobs[0];
@@ -2026,16 +2062,22 @@ void la_batch_kernel(const LaTask *tasks, u32 ntasks)
       c.bpk = a.bblk.pk;  c.b0 = a.bblk.boff[tk.bread];
       c.alen = (int) read_len(a.ablk, tk.aread);
       c.blen = (int) read_len(a.bblk, tk.bread);
+      if (WD && !pair_is_wide(a, t, c.alen, c.blen))
+        continue;
       c.ts = a.tspace;  c.ave = a.ave_path;  c.reach = a.reach;
       c.score = a.score;  c.table = a.table;  c.trim8 = trimtab;
       c.st0 = s.st0;  c.st1 = s.st1;  c.NA = s.NA;  c.NB = s.NB;
       c.koff = c.blen + 8;  c.ring = a.span;
       c.cells = s.cells;  c.cell_cap = a.cell_cap;
+      if (WD)
+        { c.cells = (Cell *) ((WCell *) a.wcells + (u64) blockIdx.x * a.wcell_cap);
+          c.cell_cap = a.wcell_cap;
+        }
       c.err = &a.counters[3];
       c.atr = s.atr;  c.btr = s.btr;
       LaResult r;
-      local_alignment(c, (u32) a.comp, tk.diag, tk.anti, &r);
-      emit_record(a.job, s, r, tk.aread, tk.bread, t, 0);
+      local_alignment<WD>(c, (u32) a.comp, tk.diag, tk.anti, &r);
+      emit_record(a.job, s, r, tk.aread, tk.bread, t | (WD ? DAMAR_ITEM_WIDE : 0u), 0);
     }
 }
 
@@ -2043,7 +2085,14 @@ void damar_launch_la_batch(const ReportArgs *a, const LaTask *tasks, u32 ntasks,
 { if (ntasks == 0)
     return;
   jobs_upload(a, 1, st);
-  hipLaunchKernelGGL(la_batch_kernel, dim3(nslots), dim3(64), 0, st, tasks, ntasks);
+  hipLaunchKernelGGL(la_batch_kernel<0>, dim3(nslots), dim3(64), 0, st, tasks, ntasks);
+}
+
+void damar_launch_la_batch_wide(const ReportArgs *a, const LaTask *tasks, u32 ntasks, int nslots, hipStream_t st)
+{ if (ntasks == 0)
+    return;
+  jobs_upload(a, 1, st);
+  hipLaunchKernelGGL(la_batch_kernel<1>, dim3(nslots), dim3(64), 0, st, tasks, ntasks);
 }
 
 #include "report_packed.h"

@@ -1240,12 +1240,19 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                       ar = br = (int) it;
                       cx.va0 = cx.vb0 = (int) a.ablk.boff[ar] + 16 * PK_PAD;
                       cx.alen = cx.blen = (int) read_len(a.ablk, ar);
+                      cx.item = item;
                       nidx = (u64) a.ablk.boff[ar] - (u64) ar * (u64) K - (u64) K;
                       clo = BIG;  chi = -BIG;
                       tmb = K;  tme = PANEL_SIZE;
                       if (tme >= cx.alen)
                         tme = cx.alen + 1;
-                      phase = PK_PANEL;
+                      if (a.widemap != NULL && cx.alen / a.tspace + 8 > DAMAR_MAX_MARKS)
+                        { /* a read of more trace spacings than a packed chain head can name: the wide kernel's read */
+                          if (s == 0)
+                            atomicAdd(&a.counters[DAMAR_CNT_WIDE], 1u);
+                        }
+                      else
+                        phase = PK_PANEL;
                     }
                 }
               else if (sc_ && phase == PK_PANEL)
@@ -1343,7 +1350,13 @@ __device__ __forceinline__ void report2_job(const ReportArgs &a, const u32 *trim
                   cx.va0 = (int) a.ablk.boff[ar] + 16 * PK_PAD;  cx.vb0 = (int) a.bblk.boff[br] + 16 * PK_PAD;
                   cx.alen = (int) read_len(a.ablk, ar);  cx.blen = (int) read_len(a.bblk, br);
                   cx.diag = tk.diag;  cx.anti = tk.anti;
-                  cx.m = 0;  cx.md = MD_TASK;
+                  cx.item = item;
+                  if (a.widemap != NULL && (cx.alen > cx.blen ? cx.alen : cx.blen) / a.tspace + 8 > DAMAR_MAX_MARKS)
+                    { if (s == 0)                       /* (the wide kernel's task: see the pair branch below) */
+                        atomicAdd(&a.counters[DAMAR_CNT_WIDE], 1u);
+                    }
+                  else
+                    { cx.m = 0;  cx.md = MD_TASK; }
                 }
               else
                 { item = a.order ? a.order[it] : it;

@@ -99,6 +99,11 @@ static void late_streams(void)              /* before the first use of G_copy / 
       G_late_pending.store(0, std::memory_order_release);
     }
 }
+/* The helper threads of this library (the start-up thread above, the allocation of the second landing buffer) are inside
+   HIP calls; a process that leaves through exit() -- an error path of the caller, a plan with nothing to compare -- would
+   run the runtime's exit-time teardown beside them.  Registered with atexit by damar_hip_init and called by
+   damar_set_async(0): they are joined first. */
+static void helpers_join(void);
 static hipEvent_t    G_front_done;          /* the seed stages a report launch reads from are complete */
 static hipEvent_t    G_rep_done;            /* the report launch in flight is complete (DAMAR_OVERLAP=2) */
 static hipEvent_t    G_report_done;
@@ -299,7 +304,24 @@ extern "C" int damar_hip_init(int device)
           damar_preload_scan();
           const double t2 = now_ms();
           HIP_CHECK(hipStreamCreate(&G_copy));
-          HIP_CHECK(hipStreamCreate(&G_rep));
+          { /* EXPERIMENT (profiles/r06_sweeps.txt): the report stream on DAMAR_REPORT_CUS of the 256 CUs, so
+               that the one-wavefront-per-tile kernels of the seed stream do not queue for wave slots behind a report launch.
+               DAMAR_REPORT_CUPAT=1 spreads the CUs left out over the mask instead of taking them off its end. */
+            const char *e = getenv("DAMAR_REPORT_CUS");
+            const int ncu = G_prop.multiProcessorCount, want = e ? atoi(e) : 0;
+            if (want > 0 && want < ncu)
+              { const int pat = getenv("DAMAR_REPORT_CUPAT") ? atoi(getenv("DAMAR_REPORT_CUPAT")) : 0;
+                std::vector<uint32_t> mask((size_t) (ncu + 31) / 32, 0u);
+                for (int i = 0; i < ncu; i++)
+                  { const bool on = pat ? ((long long) (i + 1) * want / ncu != (long long) i * want / ncu) : (i < want);
+                    if (on)
+                      mask[(size_t) i / 32] |= 1u << (i % 32);
+                  }
+                HIP_CHECK(hipExtStreamCreateWithCUMask(&G_rep, (uint32_t) mask.size(), mask.data()));
+              }
+            else
+              HIP_CHECK(hipStreamCreate(&G_rep));
+          }
           HIP_CHECK(hipStreamCreate(&G_ctl));
           const double t3 = now_ms();
           damar_preload_report();
@@ -333,6 +355,7 @@ extern "C" int damar_hip_init(int device)
           MEM_PHYSICAL = phys;
         }
       G_ready = 1;
+      atexit(helpers_join);
       INIT_MARK("events, done");
     }
 #undef INIT_MARK
@@ -1021,7 +1044,7 @@ static u32 max_cells(void)                  /* (DAMAR_TEST_MAX_CELLS: a test hoo
 { static u32 m = 0;
   if (m == 0)
     { const char *e = getenv("DAMAR_TEST_MAX_CELLS");
-      m = (e && atoi(e) >= 64) ? std::min<u32>((u32) atoi(e), DAMAR_MAX_CELLS) : DAMAR_MAX_CELLS;
+      m = (e && atoi(e) >= 16) ? std::min<u32>((u32) atoi(e), DAMAR_MAX_CELLS) : DAMAR_MAX_CELLS;
     }
   return m;
 }
@@ -1034,7 +1057,7 @@ static u32 grow_cells(u32 cell_cap)
   return std::min(cell_cap * 4, max_cells());
 }
 
-/* datander and the Local_Alignment batch entry have no wide kernel behind them: there the packed format's limit stays loud */
+/* one read pair per wavefront with 8-byte pebbles (DAMAR_PACKED=0): no wide kernel runs behind that path, its limit stays loud */
 static void marks_must_fit(int amax, int bmax, int tspace)
 { if (tspace > 0 && std::max(amax, bmax) / tspace + 8 > DAMAR_MAX_MARKS)
     { fprintf(stderr, "damar: FATAL: reads of %d bases need a trace spacing (-s) of at least %d here\n", std::max(amax, bmax),
@@ -1291,12 +1314,25 @@ static void hostbuf_size(HostBuf *h, size_t nrec, size_t ntp, bool generous)
     }
 }
 
+static std::thread *HB_twin = NULL;           /* allocates the second landing buffer (hostbuf_get); joined by helpers_join() */
 static HostBuf *hostbuf_new(void)
 { HostBuf *h = new HostBuf();
   memset(h, 0, sizeof(*h));
   HIP_CHECK(hipEventCreate(&h->e0));
   HIP_CHECK(hipEventCreate(&h->e1));
   return h;
+}
+
+static void helpers_join(void)
+{ late_streams();
+  std::thread *t = NULL;
+  { std::lock_guard<std::mutex> lk(HB_mu);
+    t = HB_twin;  HB_twin = NULL;
+  }
+  if (t != NULL)
+    { t->join();
+      delete t;
+    }
 }
 
 static HostBuf *hostbuf_get(size_t nrec, size_t ntp)
@@ -1318,7 +1354,7 @@ static HostBuf *hostbuf_get(size_t nrec, size_t ntp)
          one's are with the tail) */
       const size_t rc = h->rec_cap, tc = h->tp_cap;
       const int dev = G_device;
-      std::thread([rc, tc, dev]()
+      HB_twin = new std::thread([rc, tc, dev]()
         { HIP_CHECK(hipSetDevice(dev));
           HostBuf *t = hostbuf_new();
           t->rec_cap = rc;  t->tp_cap = tc;
@@ -1326,7 +1362,7 @@ static HostBuf *hostbuf_get(size_t nrec, size_t ntp)
           HIP_CHECK(hipHostMalloc((void **) &t->tpool, sizeof(u16) * tc, hipHostMallocDefault));
           std::lock_guard<std::mutex> lk(HB_mu);
           HB_free.push_back(t);
-        }).detach();
+        });
     }
   h->nrec = nrec;  h->ntp = ntp;
   return h;
@@ -1739,6 +1775,7 @@ extern "C" void damar_set_async(int on)
           st[i]->threads.clear();
         }
       A_on = false;
+      helpers_join();
     }
 }
 
@@ -2760,6 +2797,67 @@ extern "C" int damar_tandem_set_params(int kmer, int binshift, int hitmin, int n
   return 0;
 }
 
+/* The wide kernel behind a two-pair launch of ONE job on G_st (datander: dist, the batch entry: tasks), for the reads /
+   tasks that launch left to it (DAMAR_CNT_WIDE: reads of more than DAMAR_MAX_MARKS trace spacings, alignments that
+   overflowed the pebble pool at its largest).  hc = the counters as read behind the launch, updated; a flag left in hc[3]
+   means that the whole launch is to be repeated.  Returns whether the wide kernel ran (then the job's map says whose
+   two-pair records are to be dropped). */
+static bool wide_behind(ReportArgs &ra, u32 *hc, u32 cell_cap, const int *dist, const LaTask *tasks, u32 ntasks)
+{ if (ra.widemap == NULL || hc[DAMAR_CNT_WIDE] == 0)
+    return false;
+  u32 flags = hc[3];
+  if (cell_cap >= max_cells())
+    flags &= ~DAMAR_ERR_CELLS;                     /* (those are in the map: nothing to repeat for them) */
+  if (flags != 0)
+    return false;                                  /* something else ran over: the caller grows it and repeats the launch */
+  if (RS.wcells == NULL)
+    { RS.wslots = std::min(RS.nslots, 64);
+      RS.wcell_cap = 1u << 21;
+      RS.wcells = dmalloc((size_t) 16 * RS.wcell_cap * (size_t) RS.wslots);
+    }
+  ra.wcells = RS.wcells;  ra.wcell_cap = RS.wcell_cap;
+  if (VERBOSE || getenv("DAMAR_TEST_MAX_CELLS") != NULL)
+    fprintf(stderr, "damar: %u read(s) / task(s) beyond the packed pebble format: wide kernel\n", hc[DAMAR_CNT_WIDE]);
+  HIP_CHECK(hipMemsetAsync(RS.ctr + DAMAR_CNT_CURSOR, 0, sizeof(u32) * DAMAR_MAX_JOBS, G_st));
+  HIP_CHECK(hipMemsetAsync(RS.ctr + 3, 0, sizeof(u32), G_st));
+  if (dist != NULL)
+    damar_launch_tandem_report_wide(&ra, dist, RS.wslots, G_st);
+  else
+    damar_launch_la_batch_wide(&ra, tasks, ntasks, RS.wslots, G_st);
+  HIP_CHECK(hipMemcpyAsync(hc, RS.ctr, sizeof(u32) * DAMAR_COUNTER_WORDS, hipMemcpyDeviceToHost, G_st));
+  HIP_CHECK(hipStreamSynchronize(G_st));
+  HIP_CHECK(hipGetLastError());
+  if (hc[3] & DAMAR_ERR_CELLS)                     /* the wide kernel's own pool: four times the pebbles, and everything once more */
+    { if (RS.wcell_cap >= (1u << 26))
+        { fprintf(stderr, "damar: FATAL: an alignment needs more than %u trace pebbles even in the wide format\n", RS.wcell_cap);
+          die();
+        }
+      HIP_CHECK(hipFree(RS.wcells));
+      RS.wcell_cap *= 4;
+      RS.wslots = std::max(8, RS.wslots / 2);
+      RS.wcells = dmalloc((size_t) 16 * RS.wcell_cap * (size_t) RS.wslots);
+      hc[3] = (hc[3] & ~DAMAR_ERR_CELLS) | 0x40000000u;
+    }
+  return true;
+}
+
+/* the records of a launch behind which the wide kernel ran: what the two-pair kernel wrote for a read / task before it
+   gave it up goes, the wide kernel's records lose their mark */
+static void wide_filter(std::vector<LaRecord> &recs, const u32 *dmap, u32 words)
+{ std::vector<u32> wmap(words);
+  HIP_CHECK(hipMemcpy(wmap.data(), dmap, sizeof(u32) * (size_t) words, hipMemcpyDeviceToHost));
+  size_t n = 0;
+  for (size_t q = 0; q < recs.size(); q++)
+    { u32 it = recs[q].item;
+      if (it & DAMAR_ITEM_WIDE)
+        recs[q].item = it & ~DAMAR_ITEM_WIDE;
+      else if ((wmap[it >> 5] >> (it & 31)) & 1u)
+        continue;
+      recs[n++] = recs[q];
+    }
+  recs.resize(n);
+}
+
 extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Align_Spec *spec, int64 *counts)
 { finish_all();
   ensure_init();
@@ -2780,21 +2878,33 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
   std::vector<LaRecord> recs;
   std::vector<u16>      tpool;
   u32 hc[DAMAR_COUNTER_WORDS];
+  u32 *wmap = NULL;
+  const u32 wwords = ((u32) ablock->nreads + 31) / 32 + 1;
+  bool wide_ran = false;
   { const int sk = P_kmer, sh = P_hitmin, sb = P_binshift;        /* the report args read the P_* set */
     P_kmer = T_kmer;  P_hitmin = T_hitmin;  P_binshift = T_binshift;
-    u32 cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS;
+    u32 cell_cap = std::min<u32>(RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS, max_cells());
     u32 rec_cap  = std::max(RS.rec_cap, (u32) (4 * ablock->nreads + 4096));
     u32 tp_cap   = std::max(RS.tpool_cap, rec_cap * 64u);
     for (int attempt = 0; ; attempt++)
       { ReportArgs ra;
-        marks_must_fit(ablock->maxlen, ablock->maxlen, ts);
         scratch_prepare(ablock->maxlen, ablock->maxlen, T_binshift, ts, cell_cap, G_st);
         scratch_outputs(rec_cap, tp_cap);
         fill_report_args(&ra, blk, blk, 0, 1, spec, G_st, 0, 0, params_now());
         ra.nwork = (u32) ablock->nreads;
+        const bool packed = use_packed(&ra, ablock->maxlen, ablock->maxlen);
+        if (!packed)
+          marks_must_fit(ablock->maxlen, ablock->maxlen, ts);      /* (one read per wavefront, DAMAR_PACKED=0: no wide kernel behind it) */
+        else
+          { /* one bit per read: which are the wide kernel's (kernels/report.hip tandem_wide_kernel) */
+            if (wmap == NULL)
+              wmap = (u32 *) dmalloc(sizeof(u32) * (size_t) wwords);
+            HIP_CHECK(hipMemsetAsync(wmap, 0, sizeof(u32) * (size_t) wwords, G_st));
+            ra.widemap = wmap;  ra.wcells = RS.wcells;  ra.wcell_cap = RS.wcell_cap;  ra.cell_max = max_cells();
+          }
         HIP_CHECK(hipMemsetAsync(RS.ctr, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
         tick(4);
-        if (use_packed(&ra, ablock->maxlen, ablock->maxlen))
+        if (packed)
           damar_launch_tandem_report2(&ra, dist, RS.nslots, G_st);
         else
           damar_launch_tandem_report(&ra, dist, RS.nslots, G_st);
@@ -2803,8 +2913,12 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
         HIP_CHECK(hipStreamSynchronize(G_st));
         HIP_CHECK(hipGetLastError());
         G_ms[DAMAR_T_REPORT] = lap(4, 5);
+        wide_ran = packed && wide_behind(ra, hc, cell_cap, dist, NULL, 0);
+        if (packed && !wide_ran && cell_cap >= max_cells() && hc[DAMAR_CNT_WIDE] > 0)
+          hc[3] &= ~DAMAR_ERR_CELLS;
         if (hc[3] == 0)
           break;
+        hc[3] &= ~0x40000000u;
         if (((hc[3] & DAMAR_ERR_BAND) && !(hc[3] & (DAMAR_ERR_CELLS | DAMAR_ERR_WIDE))) || attempt >= 6)
           { fprintf(stderr, "damar: FATAL: tandem report kernel failed (flags %u, where=%u)\n", hc[3], hc[6]);
             die();
@@ -2823,6 +2937,10 @@ extern "C" void damar_match_self(const HITS_DB *ablock, damar_dev_block *blk, Al
       HIP_CHECK(hipMemcpy(tpool.data(), RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost));
     }
   nfilt = hc[DAMAR_CNT_NFILT];
+  if (wide_ran)
+    wide_filter(recs, wmap, wwords);
+  if (wmap != NULL)
+    HIP_CHECK(hipFree(wmap));
   HIP_CHECK(hipFree(dist));
   damar_index_free(ix);
 
@@ -2896,20 +3014,32 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
   if (ntasks <= 0)
     return 0;
   const int ts = Trace_Spacing(spec);
-  u32 cell_cap = RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS, rec_cap = (u32) ntasks + 16, tp_cap = (u32) std::min<int64>(trace_cap + 1024, 0x7fffffff);
+  u32 cell_cap = std::min<u32>(RS.cell_cap ? RS.cell_cap : DEFAULT_CELLS, max_cells()), rec_cap = 2 * (u32) ntasks + 16,
+      tp_cap = (u32) std::min<int64>(trace_cap + 1024, 0x7fffffff);
   LaTask *dt = (LaTask *) dmalloc(sizeof(LaTask) * (size_t) ntasks);
   HIP_CHECK(hipMemcpy(dt, tasks, sizeof(LaTask) * (size_t) ntasks, hipMemcpyHostToDevice));
   u32 hc[DAMAR_COUNTER_WORDS];
+  u32 *wmap = NULL;
+  const u32 wwords = ((u32) ntasks + 31) / 32 + 1;
+  bool wide_ran = false;
   for (int attempt = 0; ; attempt++)
     { ReportArgs ra;
-      marks_must_fit(ablk->d.maxlen, bblk->d.maxlen, ts);
       scratch_prepare(ablk->d.maxlen, bblk->d.maxlen, P_binshift, ts, cell_cap, G_st);
       stage("la_scratch");
       scratch_outputs(rec_cap, tp_cap);
       fill_report_args(&ra, ablk, bblk, comp, 0, spec, G_st, 0, 0, params_now());
+      const bool packed = use_packed(&ra, ablk->d.maxlen, bblk->d.maxlen);
+      if (!packed)
+        marks_must_fit(ablk->d.maxlen, bblk->d.maxlen, ts);
+      else
+        { if (wmap == NULL)
+            wmap = (u32 *) dmalloc(sizeof(u32) * (size_t) wwords);
+          HIP_CHECK(hipMemsetAsync(wmap, 0, sizeof(u32) * (size_t) wwords, G_st));
+          ra.widemap = wmap;  ra.wcells = RS.wcells;  ra.wcell_cap = RS.wcell_cap;  ra.cell_max = max_cells();
+        }
       HIP_CHECK(hipMemsetAsync(RS.ctr, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, G_st));
       stage("la_setup");
-      if (use_packed(&ra, ablk->d.maxlen, bblk->d.maxlen))
+      if (packed)
         damar_launch_report2(&ra, 1, dt, (u32) ntasks, RS.nslots, G_st);
       else
         damar_launch_la_batch(&ra, dt, (u32) ntasks, RS.nslots, G_st);
@@ -2917,16 +3047,24 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
       HIP_CHECK(hipMemcpyAsync(hc, RS.ctr, sizeof(hc), hipMemcpyDeviceToHost, G_st));
       HIP_CHECK(hipStreamSynchronize(G_st));
       HIP_CHECK(hipGetLastError());
+      wide_ran = packed && wide_behind(ra, hc, cell_cap, NULL, dt, (u32) ntasks);
+      if (packed && !wide_ran && cell_cap >= max_cells() && hc[DAMAR_CNT_WIDE] > 0)
+        hc[3] &= ~DAMAR_ERR_CELLS;
       if (hc[3] == 0)
         break;
+      hc[3] &= ~0x40000000u;
       if (((hc[3] & DAMAR_ERR_BAND) && !(hc[3] & (DAMAR_ERR_CELLS | DAMAR_ERR_WIDE))) || attempt >= 6)
         { fprintf(stderr, "damar: FATAL: batch Local_Alignment failed (flags %u, where=%u)\n", hc[3], hc[6]);
           die();
         }
       if (hc[3] & DAMAR_ERR_CELLS) cell_cap = grow_cells(cell_cap);
       if (hc[3] & DAMAR_ERR_WIDE)  G_ring *= 4;
+      if (hc[3] & DAMAR_ERR_RECS)
+        rec_cap = std::max(2 * rec_cap, hc[1] + 1024);
       if (hc[3] & DAMAR_ERR_TPOOL)
         { HIP_CHECK(hipFree(dt));
+          if (wmap != NULL)
+            HIP_CHECK(hipFree(wmap));
           return -1;
         }
     }
@@ -2935,6 +3073,10 @@ extern "C" int damar_local_alignment_batch(damar_dev_block *ablk, damar_dev_bloc
   std::vector<u16> tp(hc[2]);
   HIP_CHECK(hipMemcpy(recs.data(), RS.recs, sizeof(LaRecord) * (size_t) hc[1], hipMemcpyDeviceToHost));
   HIP_CHECK(hipMemcpy(tp.data(), RS.tpool, sizeof(u16) * (size_t) hc[2], hipMemcpyDeviceToHost));
+  if (wide_ran)
+    wide_filter(recs, wmap, wwords);
+  if (wmap != NULL)
+    HIP_CHECK(hipFree(wmap));
   std::sort(recs.begin(), recs.end(), RecOrder());
   std::vector<u32> boffa((size_t) ablk->nreads + 1), boffb((size_t) bblk->nreads + 1);
   HIP_CHECK(hipMemcpy(boffa.data(), ablk->boff, sizeof(u32) * boffa.size(), hipMemcpyDeviceToHost));

@@ -69,6 +69,9 @@ CASES = {
     "tan_tandem": dict(db="tandem", tool="datander", opts=["-j4"], plan=[("1", [])]),
     "tan_k10":    dict(db="tandem", tool="datander", opts=["-k10", "-w3", "-h28", "-l400", "-j2"], plan=[("1", [])]),
     "tan_plain":  dict(db="tiny2", tool="datander", opts=["-j4"], plan=[("1", []), ("2", [])]),
+    # a read of 2.1 Mb with tandem arrays (21 000 trace spacings at -s100: beyond the packed pebbles of the GPU kernels, the
+    # wide kernel's work behind datander) beside an ordinary read with one array
+    "tan_wide":   dict(derive="tanwide", tool="datander", opts=["-j4"], plan=[("1", [])], md5_only=True),
     # k > 16: 64-bit k-mer codes (scrub/tandem.c:132-149)
     "tan_k18":    dict(db="tandem", tool="datander", opts=["-k18", "-w4", "-h40", "-l400", "-j2"], plan=[("1", [])]),
 }
@@ -172,6 +175,35 @@ def derive(kind, work):
                  "".join(comp[ch] for ch in reversed(noisy(genome[500000:2600000]))),
                  noisy(genome[1000000:1030000]),
                  noisy(genome[1010000:1040000])]
+    elif kind == "tanwide":
+        # one read of 2.1 Mb: ten stretches of 200 kb, each followed by a tandem array (unit 40 ... 350 bp, 8 ... 30 copies,
+        # 3 % divergence per copy), and a read of 42 kb with one array: datander's self-alignments lie on the long read,
+        # whose trace grid the packed chain heads of the GPU kernels cannot index
+        rng = random.Random(888)
+        units = [40, 75, 120, 200, 350]
+
+        def array(i):
+            u = rnd_seq(rng, units[i % 5])
+            return "".join("".join(ch if rng.random() > .03 else rng.choice("acgt") for ch in u)
+                           for _ in range(rng.choice([8, 12, 20, 30])))
+
+        def noisy(seq):
+            out = []
+            for ch in seq:
+                x = rng.random()
+                if x < .03:
+                    continue
+                if x < .04:
+                    ch = rng.choice("acgt")
+                out.append(ch)
+                if rng.random() < .11:
+                    out.append(rng.choice("acgt"))
+            return "".join(out)
+        genome = ""
+        for i in range(10):
+            genome += rnd_seq(rng, 200000) + array(i)
+        genome += rnd_seq(rng, 60000)
+        reads = [noisy(genome), noisy(rnd_seq(rng, 30000) + array(2) + rnd_seq(rng, 10000))]
     elif kind == "lowcomp":
         # homopolymer and short-period stretches dropped into ordinary simulated reads: what
         # DBdust masks, and what floods the seed filter with chance k-mer hits when unmasked

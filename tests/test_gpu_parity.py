@@ -4,6 +4,7 @@ import ctypes as C
 import hashlib
 import os
 import random
+import sys
 
 import numpy as np
 import pytest
@@ -52,7 +53,7 @@ def test_gpu_las_equals_reference_golden(gpu, tmp_path, name):
     assert compare_las(case, str(tmp_path)) == []
 
 
-@pytest.mark.parametrize("name", ["tiny2", "tan_tandem", "mask_two", "bias_mask", "wide"])
+@pytest.mark.parametrize("name", ["tiny2", "tan_tandem", "mask_two", "bias_mask", "wide", "tan_wide"])
 def test_gpu_cli_binary_equals_reference_golden(gpu, tmp_path, name):
     """The C host drivers (the drop-in daligner / datander commands).  `wide`: two reads of 2.1 Mb -- 21 000 trace spacings
     at -s100, beyond the 16 000 a packed pebble can name -- and two of 30 kb: the pairs with a long read go through the
@@ -83,6 +84,38 @@ def test_gpu_cli_datander_with_blocks_unpacked_on_the_host_equals_reference_gold
     case = read_case(name)
     run_cli(os.path.join(ROOT, "damar_amd", "bin", "daligner"), case, str(tmp_path), env=dict(os.environ, DAMAR_DB_UNPACKED="1"))
     assert compare_las(case, str(tmp_path)) == []
+
+
+@pytest.mark.parametrize("name", ["tan_tandem", "tan_k18"])
+def test_gpu_cli_datander_pebble_overflow_goes_to_the_wide_kernel(gpu, tmp_path, name):
+    """scrub/tandem.c:1026 calls Local_Alignment on reads of any length (align.c:505-513 grows its vectors); the two-pair
+    kernel's packed pebbles hold 2^18 per direction and 16 000 trace spacings.  What does not fit goes to the wide kernel
+    behind the datander launch (kernels/report.hip tandem_wide_kernel, 16-byte pebbles) -- by read length (golden
+    `tan_wide` in the tests above: a read of 2.1 Mb) or, here, because the pool ran over at its largest: the test hook
+    DAMAR_TEST_MAX_CELLS makes it so small that ordinary self-alignments overflow it.  The files are the reference's."""
+    import subprocess
+    case = read_case(name)
+    link_db(case["dbdir"], str(tmp_path))
+    exe = os.path.join(ROOT, "damar_amd", "bin", "datander")
+    err = ""
+    for a, _ in case["lines"]:
+        r = subprocess.run([exe] + case["opts"] + ["G." + a], cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.PIPE, text=True, env=dict(os.environ, DAMAR_TEST_MAX_CELLS="24"))
+        err += r.stderr
+    assert compare_las(case, str(tmp_path)) == []
+    assert "wide kernel" in err
+
+
+def test_gpu_local_alignment_batch_pebble_overflow_goes_to_the_wide_kernel():
+    """The batch entry of Local_Alignment (damar_local_alignment_batch) with a pebble pool so small that most tasks
+    overflow it: they are done again by la_batch_kernel<1> behind the two-pair launch, and every path and trace still
+    equals the oracle's.  The pool's limit is read once per process: the comparison runs in a child."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-s", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py") + "::test_gpu_local_alignment_batch_equals_oracle"],
+                       cwd=ROOT, env=dict(os.environ, DAMAR_TEST_MAX_CELLS="128"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout and "wide kernel" in r.stderr
 
 
 def test_gpu_cli_memory_limit_known_answer(gpu, tmp_path):
@@ -440,7 +473,7 @@ def test_reference_driver_linked_against_hip_library(gpu, tmp_path, name):
     assert compare_las(case, str(tmp_path)) == []
 
 
-@pytest.mark.parametrize("name", ["tan_tandem", "tan_k18", "tan_plain"])
+@pytest.mark.parametrize("name", ["tan_tandem", "tan_k18", "tan_plain", "tan_wide"])
 def test_reference_datander_linked_against_tandem_library(gpu, tmp_path, name):
     """Drop-in proof of the SECOND boundary (scrub/tandem.h:54-60): the reference's OWN scrub/datander.c, compiled from
     /root/reference and linked on libdamar_tandem.so + libdamar_hip.so instead of scrub/tandem.c + dalign/align.c

@@ -282,6 +282,26 @@ def test_bench_gpus_argument_starts_one_rank_per_gpu(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.relaunch_under_torchrun(2, argv=["--gpus", "2"], run=fake_run)
     assert "only 1 GPU" in str(e.value)
+    # under a preloaded profiler the parent's runtime is up: it must not start GPU ranks
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 8)
+    for var, val in (("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/librocprofiler-sdk-tool.so"), ("HSA_TOOLS_LIB", "libroctracer64.so"),
+                     ("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk.so")):
+        monkeypatch.setenv(var, val)
+        seen.clear()
+        with pytest.raises(SystemExit) as e:
+            bench.relaunch_under_torchrun(2, argv=["--gpus", "2"], run=fake_run)
+        assert "profiler" in str(e.value) and not seen
+        monkeypatch.delenv(var)
+    # the count of GPUs comes from the kfd topology (no runtime call) and honours the *_VISIBLE_DEVICES lists
+    monkeypatch.undo()
+    monkeypatch.setattr(bench.os, "environ", dict(os.environ, HIP_VISIBLE_DEVICES="0,1", ROCR_VISIBLE_DEVICES="3"))
+    import glob as _glob
+    monkeypatch.setattr(_glob, "glob", lambda pat: [])
+    assert bench.visible_gpus() == 0
+    monkeypatch.undo()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("DAMAR_BENCH_SHARE_GPU", raising=False)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 1)
     monkeypatch.setenv("DAMAR_BENCH_SHARE_GPU", "1")
     assert bench.relaunch_under_torchrun(2, argv=["--gpus", "2"], run=fake_run) == 0
     assert seen["env"]["DAMAR_BENCH_BACKEND"] == "gloo"
@@ -292,6 +312,7 @@ def test_bench_gpus_argument_starts_one_rank_per_gpu(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 7
+    # ... a launcher without --gpus says how many ranks there are (that form worked before --gpus was read) ...
     # ... and a launcher with another world size than --gpus is refused before anything is set up
     monkeypatch.setenv("WORLD_SIZE", "2")
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
