@@ -585,43 +585,74 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
           }
           nam &= actm;  nbm &= actm;
           if (nam | nbm)
-            { const int kk = (K ^ m) - m;
+            { /* ONE round for both chains: a slide crosses at most one mark of either grid unless it is longer than a trace
+                 spacing, so the lanes of the A list and of the B list take their cells out of the half's pool together (A's
+                 first) and each writes its pebble; only what is left after that goes round the loops.  In a packed head the
+                 grid index sits above the cell index: + 1 << PK_HBITS steps it, and the cell's own index field is that of
+                 the reference's coordinates, sigma * G = (G ^ m) - m, formed on the field where it sits */
+              const int kk = (K ^ m) - m;
               const u32 w1 = ((u32) kk & 0xffffu) | ((u32) (dif) << 16);
               const u32 below = (1u << s) - 1u;
-              int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
-              int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
-              int g2 = 0;
-              while (nam)
-                { GUARD(g2, guard, 5)
-                  const u32 hm = hmask(nam, hb);
-                  const int idx = ncell + __popc(hm & below);
-                  if (inv(nam))
-                    { ga += 1;
-                      if (idx < cell_cap)
-                        { const v2u32 c = { (u32) hax | ((u32) ((ga ^ m) - m) << PK_HBITS), w1 };
-                          DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
+              const u32 M18 = (u32) m << PK_HBITS;
+              { const u32 hmA = hmask(nam, hb), hmB = hmask(nbm, hb);
+                const int idxA = ncell + __popc(hmA & below), tA = ncell + __popc(hmA);
+                const int idxB = tA + __popc(hmB & below);
+                ncell = tA + __popc(hmB);
+                if (inv(nam))
+                  { const u32 t = (u32) ha + (1u << PK_HBITS);
+                    if (idxA < cell_cap)
+                      { const v2u32 c = { (((t & ~(u32) PK_HMASK) ^ M18) - M18) | ((u32) ha & (u32) PK_HMASK), w1 };
+                        DUO_EXP_PEBBLE(gcell[cbase + (u32) idxA] = c;)
+                      }
+                    ha = (int) ((t & ~(u32) PK_HMASK) | (u32) idxA);
+                  }
+                if (inv(nbm))
+                  { const u32 t = (u32) hb_ + (1u << PK_HBITS);
+                    if (idxB < cell_cap)
+                      { const v2u32 c = { (((t & ~(u32) PK_HMASK) ^ M18) - M18) | ((u32) hb_ & (u32) PK_HMASK), w1 };
+                        DUO_EXP_PEBBLE(gcell[cbase + (u32) idxB] = c;)
+                      }
+                    hb_ = (int) ((t & ~(u32) PK_HMASK) | (u32) idxB);
+                  }
+              }
+              nam &= bal(v >= __mul24((int) ((u32) ha >> PK_HBITS), TS2) + cpA);
+              nbm &= bal(v >= __mul24((int) ((u32) hb_ >> PK_HBITS), TS2) + cpB);
+              if (nam | nbm)
+                { int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
+                  int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
+                  int g2 = 0;
+                  while (nam)
+                    { GUARD(g2, guard, 5)
+                      const u32 hm = hmask(nam, hb);
+                      const int idx = ncell + __popc(hm & below);
+                      if (inv(nam))
+                        { ga += 1;
+                          if (idx < cell_cap)
+                            { const v2u32 c = { (u32) hax | ((u32) ((ga ^ m) - m) << PK_HBITS), w1 };
+                              DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
+                            }
+                          hax = idx;
                         }
-                      hax = idx;
+                      ncell += __popc(hm);
+                      nam &= bal(v >= __mul24(ga, TS2) + cpA);
                     }
-                  ncell += __popc(hm);
-                  nam &= bal(v >= __mul24(ga, TS2) + cpA);
-                }
-              while (nbm)
-                { GUARD(g2, guard, 6)
-                  const u32 hm = hmask(nbm, hb);
-                  const int idx = ncell + __popc(hm & below);
-                  if (inv(nbm))
-                    { gb += 1;
-                      if (idx < cell_cap)
-                        { const v2u32 c = { (u32) hbx | ((u32) ((gb ^ m) - m) << PK_HBITS), w1 };
-                          DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
+                  while (nbm)
+                    { GUARD(g2, guard, 6)
+                      const u32 hm = hmask(nbm, hb);
+                      const int idx = ncell + __popc(hm & below);
+                      if (inv(nbm))
+                        { gb += 1;
+                          if (idx < cell_cap)
+                            { const v2u32 c = { (u32) hbx | ((u32) ((gb ^ m) - m) << PK_HBITS), w1 };
+                              DUO_EXP_PEBBLE(gcell[cbase + (u32) idx] = c;)
+                            }
+                          hbx = idx;
                         }
-                      hbx = idx;
+                      ncell += __popc(hm);
+                      nbm &= bal(v >= __mul24(gb, TS2) + cpB);
                     }
-                  ncell += __popc(hm);
-                  nbm &= bal(v >= __mul24(gb, TS2) + cpB);
+                  ha = hax | (ga << PK_HBITS);  hb_ = hbx | (gb << PK_HBITS);
                 }
-              ha = hax | (ga << PK_HBITS);  hb_ = hbx | (gb << PK_HBITS);
             }
 
           /* commit the new wave (lanes outside the band get V = EDGE again behind the pruning) */
