@@ -232,7 +232,7 @@ def end_to_end(dbdir, root, nblocks, md5_name, repeats=3, gpus=1):
     the node scheduler of host/daligner.c.  Best of `repeats`; on one GPU run before this
     process puts its own blocks into HBM (`value` is filled in once the step has said how many bp were aligned)."""
     exe = os.path.join(ROOT, "damar_amd", "bin", "daligner")
-    best, chk = None, None
+    best, chk, node_stats = None, None, None
     for _ in range(repeats):
         work = tempfile.mkdtemp(prefix="damar_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         try:
@@ -240,12 +240,21 @@ def end_to_end(dbdir, root, nblocks, md5_name, repeats=3, gpus=1):
             with open(os.path.join(work, "plan.txt"), "w") as f:
                 f.write(plan_text(root, nblocks))
             t0 = time.time()
-            env = dict(os.environ, DAMAR_SHARE_GPU="1") if os.environ.get("DAMAR_BENCH_SHARE_GPU") else None   # (one-GPU rehearsal)
+            env = dict(os.environ)
+            if os.environ.get("DAMAR_BENCH_SHARE_GPU"):
+                env["DAMAR_SHARE_GPU"] = "1"              # (one-GPU rehearsal)
+            if gpus > 1:
+                env["DAMAR_PLAN_STATS"] = os.path.join(work, "node_stats.json")      # what every worker did (host/daligner.c node_main)
             subprocess.run([exe, "-P", "plan.txt"] + (["-G%d" % gpus] if gpus > 1 else []), cwd=work, check=True,
                            stdout=subprocess.DEVNULL, env=env)
             dt = time.time() - t0
             if best is None or dt < best:
                 best = dt
+                if gpus > 1:
+                    try:
+                        node_stats = json.loads(open(os.path.join(work, "node_stats.json")).read())
+                    except Exception:
+                        node_stats = None
             if chk is None:
                 chk = check_against_reference(work, md5_name)
             time.sleep(0.6)                               # a repeat is a COLD run: not beside the previous worker's teardown
@@ -290,6 +299,8 @@ def end_to_end(dbdir, root, nblocks, md5_name, repeats=3, gpus=1):
                    % (" -G%d (one forked worker per GPU, regions + stealing)" % gpus if gpus > 1 else "", repeats),
            "identical_to_reference": None if chk is None else chk["identical"]}
     out.update(extra)
+    if node_stats is not None:
+        out["node"] = node_stats
     return out
 
 
@@ -668,6 +679,9 @@ def main():
         split = any(n > 1 for _, _, _, n in units)
         pipelined = not split and not args.sync_steps
 
+        rank_stats = {"busy_s": 0., "stolen": 0}       # this rank's own time inside the timed region (until ITS last file is closed) and
+                                                        # the units it took out of other ranks' regions: the SCALE record explains itself
+
         def run_steps(tag, nsteps, synced):
             """(elapsed, last_out, plans, units_run): nsteps passes; synced: each on its own between syncs"""
             el, outs, plans, nrun = 0., None, [], 0
@@ -678,6 +692,8 @@ def main():
                     sync_all()
                     t0 = time.time()
                     outs, plan, n = one_step("%s%d" % (tag, s))
+                    if tag == "s":
+                        rank_stats["busy_s"] += time.time() - t0
                     sync_all()
                     el += time.time() - t0
                     plans.append(plan)
@@ -690,8 +706,12 @@ def main():
                 outs = os.path.join(work, "out_%s%d" % (tag, s & 1))
                 queue = multi.make_queue(store, "%s%d" % (tag, s), units, rank)
                 nrun += len(multi.run_queue(dbprefix, units, outs, queue, runner))
+                if tag == "s":
+                    rank_stats["stolen"] += getattr(queue, "stolen", 0)
                 runner.end_pass()
             runner.finish()
+            if tag == "s":
+                rank_stats["busy_s"] = time.time() - t0
             sync_all()
             return time.time() - t0, outs, [runner.plan], nrun
 
@@ -741,6 +761,20 @@ def main():
             units_max = float(vmax[-2].item())
         else:
             units_run, units_max = float(nmine), float(nmine)
+        per_rank = None
+        if dist is not None:
+            # one row per rank, gathered as it is (no reduction): units, stolen units, index builds, busy seconds, report ms,
+            # seed-side ms (tuples + k-mer sorts + merge + seed sorts + work list), host tail + write ms (thread time)
+            import torch
+            mine = torch.tensor([float(nmine), float(rank_stats["stolen"]), float(sum(p.index_builds for p in plans)),
+                                 float(rank_stats["busy_s"]), float(sum(p.timings.get("report", 0.) for p in plans)),
+                                 float(sum(p.timings.get(k, 0.) for p in plans for k in ("tuples", "ksort", "merge", "ssort", "work"))),
+                                 float(sum(p.timings.get(k, 0.) for p in plans for k in ("tail", "write")))],
+                                device=rdev, dtype=torch.float64)
+            rows = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(rows, mine)
+            per_rank = [dict(zip(("units", "stolen", "index_builds", "busy_s", "report_ms", "seed_side_ms", "tail_write_ms"),
+                                 [round(float(x), 3) for x in r.tolist()])) for r in rows]
 
         one_gpu = None
         if world > 1:
@@ -928,6 +962,9 @@ def main():
                                                  "launch per subject block, in flight beside the next block's index builds and "
                                                  "seed stages" % ngroup, int(units_max)),
                                "db_generation_s": t_gen,
+                               "per_rank": per_rank,
+                               "busy_max_over_mean": (max(r["busy_s"] for r in per_rank) * len(per_rank) /
+                                                      max(1e-9, sum(r["busy_s"] for r in per_rank))) if per_rank else None,
                                "contract_wall_s": contract["wall_s"] if contract else None,
                                "contract_value": contract["value"] if contract else None,
                                "contract_vs_cpu": contract["vs_cpu"] if contract else None,

@@ -1379,7 +1379,10 @@ typedef struct
 { atomic_int cursor[NODE_MAXW];          /* next unit of each region */
   int        first[NODE_MAXW], end[NODE_MAXW];
   int        nregions;
-  struct { int units, stolen, builds, numa, cpus, tails, writers;  double wall_ms; } stat[NODE_MAXW];
+  struct { int units, stolen, builds, numa, cpus, tails, writers, loads;  double wall_ms;
+           double phase_ms[DAMAR_T_COUNT + 1];                    /* the library's clocks (DAMAR_T_*), then the writers' */
+           long long pairs, seeds, aligns, records, aligned_bp, las_bytes;
+         } stat[NODE_MAXW];
   atomic_int done[NODE_MAXW];            /* the worker has closed its last file (what it does after that is teardown) */
 } NodeShared;
 
@@ -1735,6 +1738,20 @@ static int node_worker(int w, int gpu, int nworkers, int sharers, const Opts *o,
   damar_async_drain();
   S->stat[w].units = nunits;  S->stat[w].stolen = stolen;  S->stat[w].builds = PB_builds;
   S->stat[w].wall_ms = wall_ms() - t0;
+  { int64  nf = 0, nl = 0, nrec = 0, las[4];               /* what this worker's share cost (as plan_stats_write) */
+    double rms = 0, tail = 0, wr = 0;
+    int    q;
+    damar_async_counts(&nf, &rms, &nl);
+    damar_async_totals(&nrec, &tail, &wr);
+    S_ms[DAMAR_T_REPORT] += rms;  S_ms[DAMAR_T_TAIL] += tail;  S_ms[DAMAR_T_D2H] += damar_async_d2h_ms();
+    damar_las_totals(las);
+    for (q = 0; q < DAMAR_T_COUNT; q++)
+      S->stat[w].phase_ms[q] = S_ms[q];
+    S->stat[w].phase_ms[DAMAR_T_COUNT] = wr;
+    S->stat[w].pairs = S_pairs;  S->stat[w].seeds = S_seeds;  S->stat[w].aligns = nf;
+    S->stat[w].records = las[2];  S->stat[w].aligned_bp = las[3];  S->stat[w].las_bytes = las[0];
+    S->stat[w].loads = __atomic_load_n(&S_loads_, __ATOMIC_RELAXED);
+  }
   damar_gate_hold(GATE_gpu);                         /* from here on this worker is only tearing down (damar_gate.h) */
   atomic_store(&S->done[w], 1);
   return 0;
@@ -2038,6 +2055,36 @@ static int node_main(const Opts *base, const char *planfile)
           ok = wait_ok(run[i], "LAmerge") && ok;
       }
   }
+  if (getenv("DAMAR_PLAN_STATS") != NULL)            /* one machine-readable line per run: what every worker did */
+    { const char *dst = getenv("DAMAR_PLAN_STATS");
+      static const char *nm[DAMAR_T_COUNT + 1] = { "tuples", "ksort", "table", "merge", "ssort", "work", "report", "d2h", "tail", "write" };
+      FILE  *f = (strcmp(dst, "-") == 0) ? stderr : fopen(dst, "w");
+      double mx = 0, sum = 0;
+      int    q;
+      for (i = 0; i < W; i++)
+        { sum += S->stat[i].wall_ms;
+          if (S->stat[i].wall_ms > mx) mx = S->stat[i].wall_ms;
+        }
+      if (f != NULL)
+        { fprintf(f, "{\"tool\": \"daligner -P -G\", \"workers\": %d, \"block_pairs\": %d, \"units\": %d, \"regions\": %d, \"wall_ms\": %.1f, "
+                     "\"busy_max_over_mean\": %.4f, \"ok\": %d, \"worker\": [", W, npairs, nunits, S->nregions, wall_ms() - t0,
+                  sum > 0 ? mx * W / sum : 0., ok);
+          for (i = 0; i < W; i++)
+            { fprintf(f, "%s{\"gpu\": %d, \"units\": %d, \"stolen\": %d, \"index_builds\": %d, \"block_loads\": %d, \"busy_ms\": %.1f, "
+                         "\"numa\": %d, \"cpus\": %d, \"tail_threads\": %d, \"write_threads\": %d, \"block_pairs\": %lld, "
+                         "\"seed_pairs\": %lld, \"local_alignments\": %lld, \"records\": %lld, \"aligned_bp\": %lld, \"las_bytes\": %lld, "
+                         "\"phase_ms\": {", i ? ", " : "", gpus[i], S->stat[i].units, S->stat[i].stolen, S->stat[i].builds, S->stat[i].loads,
+                      S->stat[i].wall_ms, S->stat[i].numa, S->stat[i].cpus, S->stat[i].tails, S->stat[i].writers, S->stat[i].pairs,
+                      S->stat[i].seeds, S->stat[i].aligns, S->stat[i].records, S->stat[i].aligned_bp, S->stat[i].las_bytes);
+              for (q = 0; q <= DAMAR_T_COUNT; q++)
+                fprintf(f, "%s\"%s\": %.1f", q ? ", " : "", nm[q], S->stat[i].phase_ms[q]);
+              fprintf(f, "}}");
+            }
+          fprintf(f, "]}\n");
+          if (f != stderr)
+            fclose(f);
+        }
+    }
   if (o0.verbose || getenv("DAMAR_CLIPROF"))
     { fprintf(stderr, "daligner: %d block pairs, %d units, %d GPU worker(s), %.2f s:", npairs, nunits, W, (wall_ms() - t0) * 1e-3);
       for (i = 0; i < W; i++)

@@ -226,6 +226,7 @@ class RegionQueue:
         self.store, self.name, self.parts = store, name, list(parts)
         self.order = [(rank + i) % len(self.parts) for i in range(len(self.parts))]
         self.done = set()
+        self.stolen = 0          # units this rank took out of another rank's region
 
     def next(self):
         for p in self.order:
@@ -234,6 +235,8 @@ class RegionQueue:
             first, end = self.parts[p]
             i = self.store.add("damar/cursor/%s/%d" % (self.name, p), 1) - 1 if end > first else end - first
             if i < end - first:
+                if p != self.order[0]:
+                    self.stolen += 1
                 return first + i
             self.done.add(p)
         return None

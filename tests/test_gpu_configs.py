@@ -379,10 +379,19 @@ def test_gpu_cli_node_mode_config3_regions_and_stealing_equal_reference(gpu, tmp
     with open(os.path.join(d, "plan.txt"), "w") as f:
         for a in range(1, nb + 1):
             f.write("daligner -k14 -j16 SIM.%d %s\n" % (a, " ".join("SIM.%d" % b for b in range(a, 0, -1))))
-    r = subprocess.run([api.daligner_binary(), "-v", "-P", "plan.txt", "-G5"], cwd=d, env=dict(os.environ, DAMAR_SHARE_GPU="1"),
+    r = subprocess.run([api.daligner_binary(), "-v", "-P", "plan.txt", "-G5"], cwd=d,
+                       env=dict(os.environ, DAMAR_SHARE_GPU="1", DAMAR_PLAN_STATS=os.path.join(d, "node.json")),
                        stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "153 block pairs" in r.stderr
+    # the machine-readable line of the run (DAMAR_PLAN_STATS): every worker's units, stolen units, index builds, busy time,
+    # phases and output volume -- what a scaling record needs to explain itself
+    import json
+    st = json.loads(open(os.path.join(d, "node.json")).read())
+    assert st["workers"] == 5 and st["block_pairs"] == 153 and st["ok"] == 1 and len(st["worker"]) == 5
+    assert sum(w["block_pairs"] for w in st["worker"]) == 153 and sum(w["units"] for w in st["worker"]) == st["units"]
+    assert all(w["busy_ms"] > 0 and w["index_builds"] > 0 and w["phase_ms"]["report"] > 0 and w["las_bytes"] > 0 for w in st["worker"])
+    assert 1.0 <= st["busy_max_over_mean"] <= 1.5
     line = [ln for ln in r.stderr.splitlines() if "block pairs," in ln and "GPU worker" in ln][-1]
     print(line)
     workers = re.findall(r"\[gpu (\d+): (\d+) units \((\d+) stolen\), (\d+) index builds, ([\d.]+) s busy, numa (-?\d+), (\d+) cpus, "
