@@ -21,7 +21,7 @@ VALU_PEAK = 0.456 * 2.4e9 * 1024       # wave-instructions per second, whole chi
 # `roofcal ops` (profiles/r02_roofcal_ops.txt): only v_add / v_sub / v_mov_b32 / and / or / xor / lshr / ashr issue that fast,
 # every other vector instruction costs 4.4 cycles of SIMD time at 5 wavefronts per SIMD; the wave loop's mix (scripts/
 # valu_weight.py on the compiler's assembly: 45 % cheap) averages 3.62 cycles per instruction
-VALU_WEIGHTED_CYCLES = 3.62
+VALU_WEIGHTED_CYCLES = 3.66        # (round 6 loop: scripts/hotpath.py on the common path, 337 cycles over 92 instructions; 3.62 for the round 2-5 loops)
 SALU_PEAK = 0.953 * 2.4e9 * 256        # instructions per second, whole chip
 
 
