@@ -2291,7 +2291,31 @@ static void report_launch(Pending &pd)
   HIP_CHECK(hipMemsetAsync(RS.ctr, 0, sizeof(u32) * DAMAR_COUNTER_WORDS, st));
   tick_on(16 + 4 * pd.oset, st);
   if (packed)
-    damar_launch_report2(ra, pd.n, NULL, 0, RS.nslots, st);
+    { /* How much of the machine a launch takes (r6).  A launch that fills every wave slot keeps the seed stream's next
+         kernel waiting until its wavefronts retire; where the seed stages are the longer side -- a plan of many sparse block
+         pairs: config 4 has 9 000 seed pairs per read pair that reaches the kernel, config 2 1 300, config 3 300 -- the
+         launch runs on DAMAR_ADAPT_WPS wavefronts per SIMD (3) instead of all 8: it takes a quarter longer and the seed
+         kernels run beside it the whole time (first 300 block pairs of config 4: 1.69 -> 1.58 s, profiles/r06_sweeps.txt).
+         DAMAR_ADAPT_RATIO = seed pairs per work item above which that happens (4 000; 0 = never). */
+      static long long ratio = -1;
+      static int wps = 0;
+      if (ratio < 0)
+        { const char *e = getenv("DAMAR_ADAPT_RATIO"), *w = getenv("DAMAR_ADAPT_WPS");
+          ratio = e ? atoll(e) : 4000;
+          wps = w ? atoi(w) : 3;
+          if (wps < 1) wps = 1;
+        }
+      int nslots = RS.nslots;
+      if (ratio > 0 && corun_on() && pd.st == G_rep)
+        { u64 seeds = 0, work = 0;
+          for (int j = 0; j < pd.n; j++)
+            { seeds += pd.fr[j].total;  work += pd.fr[j].nwork; }
+          const int low = G_prop.multiProcessorCount * 4 * damar_report2_slots_per_wave() * wps;
+          if (work > 0 && seeds / work > (u64) ratio && low < nslots)
+            nslots = low;
+        }
+      damar_launch_report2(ra, pd.n, NULL, 0, nslots, st);
+    }
   else
     damar_launch_report(ra, pd.n, RS.nslots, st);
   tick_on(17 + 4 * pd.oset, st);
