@@ -67,12 +67,15 @@ static void trim_tables(int mscore, int dscore, int16 *score, int16 *table)
   free(best);
 }
 
+static Overlap_IO_Buffer *set_take(int nthreads, int tbytes, int no_trace);
+static void               set_give(Overlap_IO_Buffer *bufs, int nthreads);
+
 Align_Spec *New_Align_Spec(double ave_corr, int trace_space, float *freq, int nthreads,
                            int symmetric, int only_identity, int no_trace_points, int reach)
 { Spec  *s = (Spec *) calloc(1, sizeof(Spec));
   const int tbytes = (trace_space <= TRACE_XOVR) ? 1 : 2;
   double at, left;
-  int    step, t;
+  int    step;
 
   if (s == NULL || (s->score = (int16 *) malloc(sizeof(int16) * 2 * TRIM_SIZE)) == NULL)
     { fprintf(stderr, "damar: out of memory (alignment specification)\n");
@@ -111,26 +114,13 @@ Align_Spec *New_Align_Spec(double ave_corr, int trace_space, float *freq, int nt
     pthread_mutex_unlock(&mu);
   }
 
-  s->iobuf = (Overlap_IO_Buffer *) malloc(sizeof(Overlap_IO_Buffer) * (size_t) (nthreads > 0 ? nthreads : 1));
-  for (t = 0; t < nthreads; t++)
-    { Overlap_IO_Buffer *one = CreateOverlapBuffer(nthreads, tbytes, no_trace_points);
-      if (one == NULL)
-        exit(1);
-      s->iobuf[t] = *one;
-      free(one);
-    }
+  s->iobuf = set_take(nthreads, tbytes, no_trace_points);
   return (Align_Spec *) s;
 }
 
 void Free_Align_Spec(Align_Spec *spec)
 { Spec *s = (Spec *) spec;
-  int   i;
-  for (i = 0; i < s->nthreads; i++)
-    { free(s->iobuf[i].ovls);
-      if (!s->iobuf[i].no_trace)
-        free(s->iobuf[i].trace);
-    }
-  free(s->iobuf);
+  set_give(s->iobuf, s->nthreads);
   free(s->score);
   free(s);
 }
@@ -296,28 +286,30 @@ int Write_Overlap(FILE *out, Overlap *ovl, int tbytes)
   return 0;
 }
 
-typedef struct                   /* one gathered record: where it lies, and its place in the gather */
+typedef struct                   /* one gathered record: where it lies, its place in the gather, and its sort keys */
 { const Overlap *ovl;
   const char    *trace;          /* its trace bytes (NULL: none) */
-  int            seq;
+  int            aread, bread;   /* the keys of the order below, copied while the records are gathered -- they are read in */
+  uint64         k2, k3;         /* order there: sorting then stays inside this array instead of chasing 35 000 pointers into */
+  int            seq;            /* the threads' buffers.  k2 = comp | abpos | aepos, k3 = bbpos | bepos (none is negative) */
 } Keyed;
 
-/* align.c:6104-6164 SORT_OVL; the reference's last key is the record's address in
- * the gathered array, here its gather index (same order for a stable gather). */
+static void keyed_set(Keyed *k, const Overlap *v, const char *trace, int seq)
+{ k->ovl = v;  k->trace = trace;  k->seq = seq;
+  k->aread = v->aread;  k->bread = v->bread;
+  k->k2 = ((uint64) (COMP(v->flags) ? 1 : 0) << 63) | ((uint64) (uint32) v->path.abpos << 32) | (uint64) (uint32) v->path.aepos;
+  k->k3 = ((uint64) (uint32) v->path.bbpos << 32) | (uint64) (uint32) v->path.bepos;
+}
+
+/* align.c:6104-6164 SORT_OVL (aread, bread, COMP, abpos, aepos, bbpos, bepos); the reference's last key is the record's
+ * address in the gathered array, here its gather index (same order for a stable gather). */
 static int by_overlap(const void *x, const void *y)
-{ const Keyed *kl = (const Keyed *) x, *kr = (const Keyed *) y;
-  const Overlap *l = kl->ovl, *r = kr->ovl;
-  int cl, cr;
+{ const Keyed *l = (const Keyed *) x, *r = (const Keyed *) y;
   if (l->aread != r->aread) return l->aread - r->aread;
   if (l->bread != r->bread) return l->bread - r->bread;
-  cl = COMP(l->flags);
-  cr = COMP(r->flags);
-  if (cl != cr) return cl - cr;
-  if (l->path.abpos != r->path.abpos) return l->path.abpos - r->path.abpos;
-  if (l->path.aepos != r->path.aepos) return l->path.aepos - r->path.aepos;
-  if (l->path.bbpos != r->path.bbpos) return l->path.bbpos - r->path.bbpos;
-  if (l->path.bepos != r->path.bepos) return l->path.bepos - r->path.bepos;
-  return (kl->seq < kr->seq) ? -1 : (kl->seq > kr->seq);
+  if (l->k2 != r->k2) return (l->k2 < r->k2) ? -1 : 1;
+  if (l->k3 != r->k3) return (l->k3 < r->k3) ? -1 : 1;
+  return (l->seq < r->seq) ? -1 : (l->seq > r->seq);
 }
 
 /* A .las file under construction: the number of records (8 bytes, filled in when the file is closed), the trace spacing
@@ -475,10 +467,10 @@ static Keyed *sort_keyed(Keyed *all, int n)
     { qsort(all, (size_t) n, sizeof(Keyed), by_overlap);
       return all;
     }
-  lo = hi = all[0].ovl->aread;
+  lo = hi = all[0].aread;
   for (i = 1; i < n; i++)
-    { if (all[i].ovl->aread < lo) lo = all[i].ovl->aread;
-      if (all[i].ovl->aread > hi) hi = all[i].ovl->aread;
+    { if (all[i].aread < lo) lo = all[i].aread;
+      if (all[i].aread > hi) hi = all[i].aread;
     }
   first = (int *) calloc((size_t) (hi - lo) + 2, sizeof(int));
   out   = (Keyed *) malloc(sizeof(Keyed) * (size_t) n);
@@ -488,11 +480,11 @@ static Keyed *sort_keyed(Keyed *all, int n)
       return all;
     }
   for (i = 0; i < n; i++)
-    first[all[i].ovl->aread - lo + 1] += 1;
+    first[all[i].aread - lo + 1] += 1;
   for (i = 1; i <= hi - lo + 1; i++)
     first[i] += first[i - 1];
   for (i = 0; i < n; i++)
-    out[first[all[i].ovl->aread - lo]++] = all[i];
+    out[first[all[i].aread - lo]++] = all[i];
   /* first[b] is now the end of bucket b */
   for (i = 0, k = 0; k <= hi - lo; k++)
     { int e = first[k];
@@ -521,8 +513,12 @@ static void *write_file_part(void *arg)
   int64  bp = 0;
   int    j;
   for (j = 0; j < f->n; j++)
-    { las_record(&out, f->recs + j, f->tbytes);
-      bp += f->recs[j].ovl->path.aepos - f->recs[j].ovl->path.abpos;
+    { if (j + 12 < f->n)                            /* the records lie where the tails left them, in work-item order */
+        { __builtin_prefetch(f->recs[j + 12].ovl);
+          __builtin_prefetch(f->recs[j + 12].trace);
+        }
+      las_record(&out, f->recs + j, f->tbytes);
+      bp += (int64) (uint32) f->recs[j].k2 - (int64) (uint32) ((f->recs[j].k2 >> 32) & 0x7fffffffu);
     }
   __atomic_fetch_add(&LAS_total[3], bp, __ATOMIC_RELAXED);
   las_close(&out, f->n);
@@ -552,9 +548,9 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
       for (j = 0; j < b->otop; j++)
         { if (s->only_identity && b->ovls[j].aread != b->ovls[j].bread)
             continue;
-          all[n].ovl = b->ovls + j;                       /* (the records stay where they are: 16 bytes per record are sorted) */
-          all[n].trace = (b->ovls[j].path.trace != NULL) ? ((const char *) b->trace) + ((uintptr_t) b->ovls[j].path.trace - 1) : NULL;
-          all[n].seq = n;
+          /* (the records stay where they are: a reference with its keys is sorted) */
+          keyed_set(all + n, b->ovls + j,
+                    (b->ovls[j].path.trace != NULL) ? ((const char *) b->trace) + ((uintptr_t) b->ovls[j].path.trace - 1) : NULL, n);
           n += 1;
         }
     }
@@ -601,7 +597,7 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
         pthread_t th;
         int       par;
         for (j = 0; j < n; j++)
-          if (all[j].ovl->aread > lastRead)
+          if (all[j].aread > lastRead)
             break;
         /* the two files are written side by side: the second by a thread of its own (the last block pair of a command
            is written with nothing else left to do: its two files one after the other were a tenth of the drain) */
@@ -631,34 +627,79 @@ void Write_Overlap_Buffer(Align_Spec *spec, char *dir1, char *dir2, char *ablock
 
 /* For a writer thread: take the filled buffers away from the Align_Spec (which continues with
  * fresh, empty ones) so that sorting and writing them can overlap with the next block pair. */
+/* Sets of buffers that are done with (written out, or never filled) wait here for the next block pair: a fresh set is
+   16 x 12 MB of address space whose pages are faulted in as the tails fill them and unmapped again behind every pair --
+   a plan makes an Align_Spec per block pair and detaches its buffers for the writer. */
+#define SET_POOL      8
+#define SET_POOL_MAX  (1ull << 30)     /* a set that has grown beyond this is freed, not kept */
+static struct { Overlap_IO_Buffer *bufs; int nthreads, tbytes, no_trace; } SET_pool[SET_POOL];
+static int SET_n;
+static pthread_mutex_t SET_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static Overlap_IO_Buffer *set_take(int nthreads, int tbytes, int no_trace)
+{ Overlap_IO_Buffer *bufs;
+  int i;
+  pthread_mutex_lock(&SET_mu);
+  for (i = 0; i < SET_n; i++)
+    if (SET_pool[i].nthreads == nthreads && SET_pool[i].no_trace == no_trace && (no_trace || SET_pool[i].tbytes == tbytes))
+      { bufs = SET_pool[i].bufs;
+        SET_pool[i] = SET_pool[--SET_n];
+        pthread_mutex_unlock(&SET_mu);
+        return bufs;
+      }
+  pthread_mutex_unlock(&SET_mu);
+  bufs = (Overlap_IO_Buffer *) calloc((size_t) (nthreads > 0 ? nthreads : 1), sizeof(Overlap_IO_Buffer));
+  for (i = 0; bufs != NULL && i < nthreads; i++)
+    { Overlap_IO_Buffer *one = CreateOverlapBuffer(nthreads, tbytes, no_trace);
+      if (one == NULL)
+        { bufs = NULL;  break; }
+      bufs[i] = *one;
+      free(one);
+    }
+  if (bufs == NULL)
+    { fprintf(stderr, "[ERROR] - Cannot allocate overlap buffers\n");
+      exit(1);
+    }
+  return bufs;
+}
+
+static void set_give(Overlap_IO_Buffer *bufs, int nthreads)
+{ uint64 held = 0;
+  int    i;
+  for (i = 0; i < nthreads; i++)
+    { bufs[i].otop = 0;  bufs[i].ttop = 0;
+      held += (uint64) bufs[i].omax * sizeof(Overlap) + (bufs[i].no_trace ? 0 : bufs[i].tmax * (uint64) bufs[i].tbytes);
+    }
+  pthread_mutex_lock(&SET_mu);
+  if (SET_n < SET_POOL && nthreads > 0 && held <= SET_POOL_MAX)
+    { SET_pool[SET_n].bufs = bufs;  SET_pool[SET_n].nthreads = nthreads;
+      SET_pool[SET_n].tbytes = bufs[0].tbytes;  SET_pool[SET_n].no_trace = bufs[0].no_trace;
+      SET_n += 1;
+      pthread_mutex_unlock(&SET_mu);
+      return;
+    }
+  pthread_mutex_unlock(&SET_mu);
+  for (i = 0; i < nthreads; i++)
+    { free(bufs[i].ovls);
+      if (!bufs[i].no_trace)
+        free(bufs[i].trace);
+    }
+  free(bufs);
+}
+
 Overlap_IO_Buffer *damar_detach_overlap_buffers(Align_Spec *spec, damar_write_params *p)
 { Spec *s = (Spec *) spec;
   Overlap_IO_Buffer *old = s->iobuf;
-  int i;
   p->trace_space = s->trace_space;  p->nthreads = s->nthreads;
   p->symmetric = s->symmetric;      p->only_identity = s->only_identity;
-  s->iobuf = (Overlap_IO_Buffer *) calloc((size_t) s->nthreads, sizeof(Overlap_IO_Buffer));
-  for (i = 0; i < s->nthreads; i++)
-    { Overlap_IO_Buffer *b = CreateOverlapBuffer(s->nthreads, old[i].tbytes, old[i].no_trace);
-      if (b == NULL)
-        { fprintf(stderr, "[ERROR] - Cannot allocate overlap buffers\n");
-          exit(1);
-        }
-      s->iobuf[i] = *b;
-      free(b);
-    }
+  s->iobuf = set_take(s->nthreads, old[0].tbytes, old[0].no_trace);
   return old;
 }
 
 void damar_write_detached(const damar_write_params *p, Overlap_IO_Buffer *bufs,
                           const char *dir1, const char *dir2, const char *ablock, const char *bblock, int lastRead)
-{ int i;
-  write_buffers(p, bufs, dir1, dir2, ablock, bblock, lastRead);
-  for (i = 0; i < p->nthreads; i++)
-    { free(bufs[i].ovls);
-      free(bufs[i].trace);
-    }
-  free(bufs);
+{ write_buffers(p, bufs, dir1, dir2, ablock, bblock, lastRead);
+  set_give(bufs, p->nthreads);
 }
 
 /* align.c:6369-6380 */

@@ -145,6 +145,11 @@ void damar_launch_seed_cut_scatter(const u64 *keys, const u32 *vals, u64 nhits, 
 void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, int minhit, int nshift,
                              u64 *send /* 64 entries of scratch */, u64 *bits, void *scan_work, u64 *total_dev,
                              u32 *heads, hipStream_t st);
+/* run heads + screen in one pass (pair_work_mark): the first half leaves the number of work items in *total_dev */
+void damar_launch_pair_work(const u64 *keys, const u32 *vals, u64 nhits, int ppos, int dbits, int abits, int minhit, int nshift,
+                            u64 *send /* 64 entries of scratch */, u64 *bits, void *scan_work, u64 *total_dev,
+                            int binshift, int kmer, int hitmin, u32 b_lo, u32 b_hi, hipStream_t st);
+void damar_launch_pair_work_expand(const u64 *bits, const void *scan_work, u64 nhits, u32 *work, hipStream_t st);
 #define WORK_COST_BITS 16
 #define WORK_COST_MAX  ((1u << WORK_COST_BITS) - 1)
 void damar_launch_work_cost(const u64 *keys, const u32 *vals, u64 nhits, int pbits, int abits, int dbits, const u32 *aboff,

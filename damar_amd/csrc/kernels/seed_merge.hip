@@ -1109,6 +1109,303 @@ void damar_launch_pair_screen(const u64 *keys, const u32 *vals, u64 nhits, int p
                      minhit, binshift, kmer, hitmin, abits, b_lo, b_hi, keep);
 }
 
+/* Run heads and their screen in ONE pass over the sorted seeds (round 6).  pair_heads_mark + pair_screen above read the
+ * keys twice -- the second time one thread per head, from wherever the head's run lies -- and the heads went through a
+ * list, a flag per head, a second device-wide scan and a compaction before they were the work list.  Here a workgroup
+ * brings its tile of DAMAR_SCAN_TILE keys (and the 64 behind it: a screened run has at most SCREEN_MAX seeds) into LDS
+ * once, finds the heads there (same predicate, same slice rule), gathers them in an LDS list so that the screen runs
+ * with full wavefronts, screens each from LDS, and leaves ONE bit per seed: head AND kept.  The work list is then
+ * pair_heads_expand of those bit words after the scan over the tile counts: no head list, no flags, no second scan, no
+ * compaction, and one host synchronisation per comparison instead of two. */
+#define PW_HALO 64
+#define PW_SMALL 8                                       /* runs of up to this many seeds are screened by one lane */
+#define PW_SHORT 4                                       /* ... and those of up to this many in wavefronts of their own */
+
+/* The screen of a run of n <= N seeds of the packed layout, in registers: seed y's bucket and A position are unpacked once
+ * and everything is unrolled and predicated.  First what seed y adds to its bucket's sum, min(kmer, apos - apos of the seed
+ * before it in the same bucket) (two instructions per earlier seed), then for every seed x the sum of what the seeds of its
+ * bucket and of the next one add (four per pair) -- the loops over x and y with their LDS reads, unpacking and branches were
+ * 2 000 instructions per wavefront for the longest run among its 64 heads.  run[q] = key of the run's seed q; lanes with
+ * n = 0 take part and return false. */
+template <int N>
+__device__ __forceinline__ bool pw_screen_small(const u64 *run, int n, u64 pmask, int dbits, int binshift, int kmer, int hitmin)
+{ int d[N], c[N];                                        /* bucket and A position of seed q */
+  const u64 dmask = (1ull << dbits) - 1;
+#pragma unroll
+  for (int q = 0; q < N; q++)
+    { const u64 k = run[q < n ? q : 0];
+      c[q] = (int) ((k >> dbits) & pmask);
+      d[q] = (q < n) ? ((c[q] - (int) (k & dmask)) >> binshift) : 0x40000000 + 4 * q;       /* (a bucket of its own) */
+    }
+  /* contributions: add[q] = min(kmer, ap[q] - ap[last y < q in the same bucket, or 0]) */
+  int add[N];
+#pragma unroll
+  for (int q = 0; q < N; q++)
+    { int prev = 0;
+#pragma unroll
+      for (int y = 0; y < q; y++)
+        prev = (d[y] == d[q]) ? c[y] : prev;
+      add[q] = min(c[q] - prev, kmer);
+    }
+  bool ok = false;
+#pragma unroll
+  for (int x = 0; x < N; x++)
+    { int sum = 0;
+#pragma unroll
+      for (int y = 0; y < N; y++)
+        sum += ((u32) (d[y] - d[x]) <= 1u) ? add[y] : 0;
+      ok |= (x < n) && (sum >= hitmin);
+    }
+  return ok;
+}
+
+__global__ __launch_bounds__(256)
+void pair_work_mark(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int ppos, int dbits, int abits,
+                    int minhit, int nshift, const u64 *__restrict__ send, int binshift, int kmer, int hitmin,
+                    u32 b_lo, u32 b_hi, u64 *__restrict__ bits, u32 *__restrict__ tcount)
+{ SEED_PRIO(g_merge_prio);
+  __shared__ u64 sk[DAMAR_SCAN_TILE + PW_HALO + 1];     /* sk[j] = keys[base + j - 1] */
+  __shared__ u64 bb[(PH_ROUNDS + 1) * 4];               /* bit j: seed j of the tile (or of the halo) starts a read pair's run */
+  __shared__ u16 hl[DAMAR_SCAN_TILE];                   /* the tile's heads (offsets into the tile), in no particular order */
+  __shared__ u16 cl[DAMAR_SCAN_TILE];                   /* heads to screen, offset | seeds << 12: runs of up to PW_SHORT seeds
+                                                           from the front, of up to PW_SMALL from the back */
+  __shared__ u32 kb[DAMAR_SCAN_TILE / 32];              /* head AND kept, one bit per seed of the tile */
+  __shared__ u32 bl[DAMAR_SCAN_TILE / PW_SMALL];        /* heads of runs of more than PW_SMALL seeds: offset | seeds << 16 */
+  __shared__ u32 nh, nlo, nhi, nb;
+  const int  pshift = ppos + dbits;                     /* the shift that leaves the read pair */
+  const u64  pmask = (1ull << ppos) - 1;
+  const int  nthr = nshift < 0 ? 0 : 1 << nshift;       /* nshift < 0: no slices (the seeds went through the early cut) */
+  const int  l = lane_id(), w = threadIdx.x >> 6;
+  const u64  base = (u64) blockIdx.x * DAMAR_SCAN_TILE;
+  { /* all of a thread's 17 loads are issued before the first is stored (from clamped addresses, none behind a branch): one
+       at a time the workgroup waited out 17 memory round trips, and three workgroups per CU do not hide that */
+    constexpr int NLD = (DAMAR_SCAN_TILE + PW_HALO + 1 + 255) / 256;
+    u64 v[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
+      { u64 i = base + (u64) q * 256u + threadIdx.x;
+        i = i > 0 ? i - 1 : 0;
+        v[q] = keys[i < nhits ? i : nhits - 1];         /* (what lies beyond the last seed is never looked at) */
+      }
+#pragma unroll
+    for (int q = 0; q < NLD; q++)
+      { const u32 j = (u32) q * 256u + threadIdx.x;
+        if (j < DAMAR_SCAN_TILE + PW_HALO + 1)
+          sk[j] = v[q];
+      }
+  }
+  if (threadIdx.x < DAMAR_SCAN_TILE / 32)
+    kb[threadIdx.x] = 0;
+  if (threadIdx.x == 0)
+    nh = nlo = nhi = nb = 0;
+  u64 e0 = ~0ull, e1 = ~0ull;                            /* the two slice ends that can matter here (pair_heads_mark) */
+  for (int t = 0; t < nthr; t++)
+    { const u64 e = send[t];
+      if (e > base)
+        { e0 = e;
+          if (t + 1 < nthr)
+            e1 = send[t + 1];
+          break;
+        }
+    }
+  __syncthreads();
+
+  /* 1. where the runs start, as bits -- a run's length is then the distance to the next bit (what lies behind the last seed,
+        or behind the halo, counts as a start) -- and the heads of the tile as a list, so that what follows runs with full
+        wavefronts (inside this loop a wavefront has a head in one lane of eight) */
+  u64 mk[PH_ROUNDS];                                     /* the heads of this wavefront's 16 x 64 seeds (scalar registers) */
+  u32 tot = 0;
+#pragma unroll
+  for (int r = 0; r <= PH_ROUNDS; r++)
+    { const u32 off = (u32) r * 256u + threadIdx.x;
+      const u64 i = base + off;
+      bool st = true, f = false;
+      if (i < nhits && off < DAMAR_SCAN_TILE + PW_HALO)
+        { const u64 pr = sk[off + 1] >> pshift;
+          const u64 ip = i + (u64) (minhit - 1);
+          st = (i == 0) || (sk[off] >> pshift) != pr;
+          if (r < PH_ROUNDS && st && ip < nhits)
+            { const u64 kp = (minhit - 1 <= PW_HALO) ? sk[off + (u32) minhit] : keys[ip];
+              if ((kp >> pshift) == pr)                  /* filter.c:2215: seed i + minhit - 1 is the same pair */
+                { f = true;
+                  if (i < e0)
+                    { if (i + (u64) minhit >= e0) f = false; }
+                  else if (i < e1)
+                    { if (i + (u64) minhit >= e1) f = false; }
+                  else                                   /* (three slice ends inside one tile: slices of a few hundred seeds) */
+                    for (int t = 0; t < nthr; t++)
+                      { u64 e = send[t];
+                        if (i < e)
+                          { if (i + (u64) minhit >= e) f = false;
+                            break;
+                          }
+                      }
+                }
+            }
+        }
+      const u64 ms = __ballot(st);
+      if (l == 0)
+        bb[r * 4 + w] = ms;
+      if (r < PH_ROUNDS)
+        { mk[r] = __ballot(f);
+          tot += (u32) __popcll(mk[r]);
+        }
+    }
+  if (tot != 0)                                          /* one place in the list for all of them: one LDS atomic per wavefront */
+    { u32 at = 0;
+      if (l == 0)
+        at = atomicAdd(&nh, tot);
+      at = (u32) __shfl((int) at, 0);
+#pragma unroll
+      for (int r = 0; r < PH_ROUNDS; r++)
+        { if ((mk[r] >> l) & 1)
+            hl[at + (u32) __popcll(mk[r] & lanes_below(l))] = (u16) ((u32) r * 256u + threadIdx.x);
+          at += (u32) __popcll(mk[r]);
+        }
+    }
+  __syncthreads();
+
+  /* 2. every head's run: those the screen has nothing to say about are kept or dropped here, the others go to one of three
+        lists by the length of their run -- a wavefront of the screen costs what the longest of its 64 runs costs, and 80 %
+        of the runs have 3 or 4 seeds (scripts/seed_runs.py) */
+  const u32 nheads = nh;
+  for (u32 h0 = 0; h0 < nheads; h0 += 256)               /* (a loop every lane leaves together: the ballots below) */
+    { const u32 h = h0 + threadIdx.x;
+      u32 off = 0;
+      int n = 0, kind = 0;                               /* 1: short run, 2: small run */
+      if (h < nheads)
+        { off = hl[h];
+          const u32 rb = (u32) ((sk[off + 1] >> pshift) >> abits);      /* a scheduler may hand this call a B-read range only */
+          if (rb >= b_lo && rb < b_hi)
+            { const u32 p = off + 1;                     /* the run's seeds: 1 + the seeds from p on that start no run */
+              u64 ws = bb[p >> 6] >> (p & 63);
+              if (p & 63)
+                ws |= bb[(p >> 6) + 1] << (64 - (p & 63));
+              n = ws ? __ffsll((long long) ws) : 65;     /* (65: more than 64) */
+              if (n > SCREEN_MAX || minhit > SCREEN_MAX || (int) ((sk[off + (u32) n] >> dbits) & pmask) > SCREEN_PANEL)
+                atomicOr(&kb[off >> 5], 1u << (off & 31));       /* not screened (pair_screen): kept */
+              else if (n > PW_SMALL)
+                bl[atomicAdd(&nb, 1u)] = off | ((u32) n << 16);
+              else
+                kind = n > PW_SHORT ? 2 : 1;
+            }
+        }
+      const u64 m1 = __ballot(kind == 1), m2 = __ballot(kind == 2);
+      u32 a1 = 0, a2 = 0;
+      if (l == 0)
+        { if (m1) a1 = atomicAdd(&nlo, (u32) __popcll(m1));
+          if (m2) a2 = atomicAdd(&nhi, (u32) __popcll(m2));
+        }
+      a1 = (u32) __shfl((int) a1, 0);
+      a2 = (u32) __shfl((int) a2, 0);
+      if (kind == 1)
+        cl[a1 + (u32) __popcll(m1 & lanes_below(l))] = (u16) (off | ((u32) n << 12));
+      else if (kind == 2)
+        cl[DAMAR_SCAN_TILE - 1 - (a2 + (u32) __popcll(m2 & lanes_below(l)))] = (u16) (off | ((u32) n << 12));
+    }
+  __syncthreads();
+
+  /* 3. the screen.  Runs of up to PW_SMALL seeds: one lane each, the two lists one after the other */
+  const u32 n_lo = nlo, n_hi = nhi;
+  const u32 lo_rounds = (n_lo + 255u) & ~255u;           /* (the second list starts at a wavefront of its own) */
+  for (u32 h0 = 0; h0 < lo_rounds + n_hi; h0 += 256)
+    { const u32 h = h0 + threadIdx.x;
+      const bool act = h0 < lo_rounds ? h < n_lo : h - lo_rounds < n_hi;
+      const u32 e = act ? (u32) cl[h0 < lo_rounds ? h : DAMAR_SCAN_TILE - 1 - (h - lo_rounds)] : 0u;
+      const u32 off = e & 0xfffu;
+      const int n = act ? (int) (e >> 12) : 0;
+      bool keep = false;
+      if (dbits == 0)                                    /* (unpacked layout: the diagonals are in vals) */
+        { const u64 i = base + off;
+          int dlast = 0x7fffffff;
+          for (int x = 0; x < n && !keep; x++)
+            { const int dx = (int) vals[i + (u64) x] >> binshift;
+              if (dx == dlast)
+                continue;
+              dlast = dx;
+              int s0 = 0, s1 = 0, p0 = 0, p1 = 0;
+              for (int y = 0; y < n; y++)
+                { const int dy = (int) vals[i + (u64) y] >> binshift;
+                  const int ap = (int) ((sk[off + 1 + (u32) y] >> dbits) & pmask);
+                  if (dy == dx)
+                    { s0 += (ap - p0 >= kmer) ? kmer : ap - p0;  p0 = ap; }
+                  else if (dy == dx + 1)
+                    { s1 += (ap - p1 >= kmer) ? kmer : ap - p1;  p1 = ap; }
+                }
+              keep = s0 + s1 >= hitmin;
+            }
+        }
+      else if (__ballot(n > 0) != 0)                     /* all of the wavefront's runs with the code for its longest */
+        { if      (__ballot(n > 7) != 0) keep = pw_screen_small<8>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+          else if (__ballot(n > 6) != 0) keep = pw_screen_small<7>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+          else if (__ballot(n > 5) != 0) keep = pw_screen_small<6>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+          else if (__ballot(n > 4) != 0) keep = pw_screen_small<5>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+          else if (__ballot(n > 3) != 0) keep = pw_screen_small<4>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+          else                           keep = pw_screen_small<3>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+        }
+      if (keep)
+        atomicOr(&kb[off >> 5], 1u << (off & 31));
+    }
+  /* the longer runs (up to 48 x 48 steps: in one lane a wavefront waited 58 us for one of them): a wavefront each, lane x
+     takes seed x's bucket and all lanes walk the run together (the same LDS word for every lane) */
+  const u32 nbig = nb;
+  for (u32 q = threadIdx.x >> 6; q < nbig; q += 4)
+    { const u32 off = bl[q] & 0xffffu;
+      const int n = (int) (bl[q] >> 16);
+      const u64 i = base + off;
+      const int xl = l < n ? l : n - 1;                  /* (n <= SCREEN_MAX < 64) */
+      const int dx = seed_diag(sk[off + 1 + (u32) xl], vals, i + (u64) xl, pmask, dbits) >> binshift;
+      int s0 = 0, s1 = 0, p0 = 0, p1 = 0;
+#pragma unroll 4
+      for (int y = 0; y < n; y++)
+        { const u64 ky = sk[off + 1 + (u32) y];
+          const int dy = seed_diag(ky, vals, i + (u64) y, pmask, dbits) >> binshift;
+          const int ap = (int) ((ky >> dbits) & pmask);
+          if (dy == dx)
+            { s0 += (ap - p0 >= kmer) ? kmer : ap - p0;  p0 = ap; }
+          else if (dy == dx + 1)
+            { s1 += (ap - p1 >= kmer) ? kmer : ap - p1;  p1 = ap; }
+        }
+      if (__ballot(s0 + s1 >= hitmin) != 0 && l == 0)
+        atomicOr(&kb[off >> 5], 1u << (off & 31));
+    }
+  __syncthreads();
+  if (threadIdx.x < 64)
+    { const u64 m = (u64) kb[2 * threadIdx.x] | ((u64) kb[2 * threadIdx.x + 1] << 32);
+      bits[(base >> 6) + threadIdx.x] = m;
+      const int c = wave_incl_scan_i(__popcll(m));
+      if (threadIdx.x == 63)
+        tcount[blockIdx.x] = (u32) c;
+    }
+}
+
+/* first half: bit words + *total_dev = the number of work items; the caller reads the total, makes room, and calls the
+   second half.  bits: 64 u64 words per tile of DAMAR_SCAN_TILE seeds; scan_work: damar_scan_workspace_bytes(nhits) */
+void damar_launch_pair_work(const u64 *keys, const u32 *vals, u64 nhits, int ppos, int dbits, int abits, int minhit, int nshift,
+                            u64 *send, u64 *bits, void *scan_work, u64 *total_dev, int binshift, int kmer, int hitmin,
+                            u32 b_lo, u32 b_hi, hipStream_t st)
+{ if (nhits == 0)
+    { HIP_CHECK(hipMemsetAsync(total_dev, 0, sizeof(u64), st));
+      return;
+    }
+  if (nshift > 6)
+    nshift = 6;
+  const u32 ntiles = (u32) ((nhits + DAMAR_SCAN_TILE - 1) / DAMAR_SCAN_TILE);
+  u32 *tcount = (u32 *) scan_work;
+  if (nshift >= 0)
+    hipLaunchKernelGGL(slice_ends<u64>, dim3(1), dim3(64), 0, st, keys, nhits, abits + ppos + dbits, nshift, send);
+  hipLaunchKernelGGL(pair_work_mark, dim3(ntiles), dim3(256), 0, st, keys, vals, nhits, ppos, dbits, abits, minhit, nshift,
+                     (const u64 *) send, binshift, kmer, hitmin, b_lo, b_hi, bits, tcount);
+  damar_scan_tile_counts(tcount, ntiles, total_dev, st);
+}
+
+void damar_launch_pair_work_expand(const u64 *bits, const void *scan_work, u64 nhits, u32 *work, hipStream_t st)
+{ if (nhits == 0)
+    return;
+  const u32 ntiles = (u32) ((nhits + DAMAR_SCAN_TILE - 1) / DAMAR_SCAN_TILE);
+  hipLaunchKernelGGL(pair_heads_expand, dim3(ntiles), dim3(64), 0, st, bits, (const u32 *) scan_work, work);
+}
+
 /* out[off[i]] = src[i] for the kept entries */
 __global__ __launch_bounds__(256)
 void compact_u32(const u32 *__restrict__ src, const u32 *__restrict__ keep, const u32 *__restrict__ off, u32 n,

@@ -219,6 +219,8 @@ static void *arena_take(Arena *a, size_t n)
 }
 
 static size_t pad256(size_t n) { return (n + 511) & ~(size_t) 255; }
+/* one bit per seed in whole tiles of DAMAR_SCAN_TILE (pair_heads_mark / pair_work_mark write all 64 words of a tile) */
+static size_t bit_words_bytes(u64 n) { return (size_t) ((n + DAMAR_SCAN_TILE - 1) / DAMAR_SCAN_TILE) * (DAMAR_SCAN_TILE / 8); }
 
 static int G_device = 0;      /* the device of this process; threads that touch HIP select it first */
 
@@ -2013,7 +2015,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       u32 *v0 = (spasses & 1) ? tv : pv, *v1 = (spasses & 1) ? pv : tv;
       void *sw = arena_take(&G_tmp, damar_sort_workspace_bytes(total));
       flags = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
-      foff  = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
+      foff  = (u32 *) arena_take(&G_tmp, std::max(sizeof(u32) * (size_t) total, bit_words_bytes(total)));   /* (also the heads' bit words) */
       scw2  = arena_take(&G_tmp, damar_scan_workspace_bytes(total));
       sends = (u64 *) arena_take(&G_tmp, 64 * sizeof(u64));
 
@@ -2087,7 +2089,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       u32 *v0 = (spasses & 1) ? tv : pv, *v1 = (spasses & 1) ? pv : tv;
       void *sw2 = arena_take(&G_tmp2, damar_sort_workspace_bytes(nsurv));
       flags = (u32 *) arena_take(&G_tmp2, sizeof(u32) * (size_t) nsurv);
-      foff  = (u32 *) arena_take(&G_tmp2, sizeof(u32) * (size_t) nsurv);
+      foff  = (u32 *) arena_take(&G_tmp2, std::max(sizeof(u32) * (size_t) nsurv, bit_words_bytes(nsurv)));
       scw2  = arena_take(&G_tmp2, damar_scan_workspace_bytes(nsurv));
       sends = (u64 *) arena_take(&G_tmp2, 64 * sizeof(u64));
       damar_launch_seed_cut_scatter(uk, m.dbits ? NULL : uv, total, m.pbits + m.dbits, bitmap, (const u32 *) scc, k0, v0, G_st);
@@ -2108,25 +2110,46 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
 
   /* ---- work list ---- */
   u64 nwork64 = 0;
-  u32 *heads = (u32 *) tk;                              /* the idle key buffer holds the run heads */
-  damar_launch_pair_heads(keys, total, m.pbits + m.dbits, m.abits, minhit, hshift, sends, (u64 *) foff /* bit words */,
-                          scw2, tot, heads, G_st);
-  stage("run_heads");
-  HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
-  HIP_CHECK(hipStreamSynchronize(G_st));
-  const u32 nheads = (u32) nwork64;
-  /* screen the heads (dense, one thread each), compact the survivors: flags/foff are reused.  The work list and
-     its processing order outlive the seed stage: the comparison's second arena */
-  arena_reserve(&G_ord, 5 * pad256(sizeof(u32) * (size_t) nheads) + pad256(damar_sort_workspace_bytes(nheads)) + 8192);
-  u32 *work = (u32 *) arena_take(&G_ord, sizeof(u32) * ((size_t) nheads + 1));
-  nwork64 = 0;
-  if (nheads > 0)
-    { damar_launch_pair_screen(keys, vals, total, m.pbits, m.dbits, heads, nheads, minhit, P_binshift, P_kmer, P_hitmin, m.abits,
-                               P_bread_lo, P_bread_hi, flags, G_st);
-      damar_exclusive_scan_u32(flags, foff, nheads, scw2, tot, G_st);
-      damar_launch_compact_u32(heads, flags, foff, nheads, work, G_st);
-      stage("work_list");
+  u32 *work = NULL;
+  static int two_step = -1;                              /* DAMAR_WORK_TWOSTEP=1: heads, then their screen (rounds 1-5; tested) */
+  if (two_step < 0)
+    { const char *e = getenv("DAMAR_WORK_TWOSTEP");
+      two_step = (e && atoi(e) > 0) ? 1 : 0;
+    }
+  if (!two_step)
+    { /* heads and screen in one pass over the seeds: a bit per seed, the work list expanded from the bits once its
+         length is known (the work list and its processing order outlive the seed stage: the comparison's second arena) */
+      damar_launch_pair_work(keys, vals, total, m.pbits, m.dbits, m.abits, minhit, hshift, sends, (u64 *) foff /* bit words */,
+                             scw2, tot, P_binshift, P_kmer, P_hitmin, P_bread_lo, P_bread_hi, G_st);
+      stage("run_heads");
       HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      arena_reserve(&G_ord, 5 * pad256(sizeof(u32) * (size_t) nwork64) + pad256(damar_sort_workspace_bytes(nwork64)) + 8192);
+      work = (u32 *) arena_take(&G_ord, sizeof(u32) * ((size_t) nwork64 + 1));
+      if (nwork64 > 0)
+        damar_launch_pair_work_expand((const u64 *) foff, scw2, total, work, G_st);
+      stage("work_list");
+    }
+  else
+    { u32 *heads = (u32 *) tk;                              /* the idle key buffer holds the run heads */
+      damar_launch_pair_heads(keys, total, m.pbits + m.dbits, m.abits, minhit, hshift, sends, (u64 *) foff /* bit words */,
+                              scw2, tot, heads, G_st);
+      stage("run_heads");
+      HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipStreamSynchronize(G_st));
+      const u32 nheads = (u32) nwork64;
+      /* screen the heads (dense, one thread each), compact the survivors: flags/foff are reused */
+      arena_reserve(&G_ord, 5 * pad256(sizeof(u32) * (size_t) nheads) + pad256(damar_sort_workspace_bytes(nheads)) + 8192);
+      work = (u32 *) arena_take(&G_ord, sizeof(u32) * ((size_t) nheads + 1));
+      nwork64 = 0;
+      if (nheads > 0)
+        { damar_launch_pair_screen(keys, vals, total, m.pbits, m.dbits, heads, nheads, minhit, P_binshift, P_kmer, P_hitmin, m.abits,
+                                   P_bread_lo, P_bread_hi, flags, G_st);
+          damar_exclusive_scan_u32(flags, foff, nheads, scw2, tot, G_st);
+          damar_launch_compact_u32(heads, flags, foff, nheads, work, G_st);
+          stage("work_list");
+          HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+        }
     }
   tick(3);
   HIP_CHECK(hipStreamSynchronize(G_st));

@@ -76,6 +76,54 @@ def test_gpu_cli_merge_general_path_equals_reference_golden(gpu, tmp_path, name)
     assert compare_las(case, str(tmp_path)) == []
 
 
+@pytest.mark.parametrize("name", ["tiny2", "tandem", "tiny_I", "tiny_k12", "mask_two"])
+def test_gpu_cli_work_list_in_two_steps_equals_reference_golden(gpu, tmp_path, name):
+    """The work list of a comparison -- the heads of the (bread, aread) runs report_thread would enter (filter.c:2212-2215)
+    that survive the screen of pass 1's bucket sums (filter.c:2268-2297) -- is made in one pass over the sorted seeds
+    (kernels/seed_merge.hip pair_work_mark: every other test); DAMAR_WORK_TWOSTEP=1 is the path of rounds 1-5: the list of
+    heads, then one thread per head for the screen, a scan and a compaction."""
+    from conftest import run_cli
+    case = read_case(name)
+    run_cli(os.path.join(ROOT, "damar_amd", "bin", "daligner"), case, str(tmp_path), env=dict(os.environ, DAMAR_WORK_TWOSTEP="1"))
+    assert compare_las(case, str(tmp_path)) == []
+
+
+@pytest.mark.parametrize("cov,genome,opts", [(0.4, 3.0, "-k14"), (12.0, 0.3, "-k14"), (12.0, 0.3, "-k14 -h60 -t8"), (25.0, 0.1, "-k12 -w5")])
+def test_gpu_work_list_in_one_pass_has_the_items_of_heads_then_screen(gpu, tmp_path, cov, genome, opts):
+    """Both ways of making the work list (test above) over whole plans: the same number of work items -- a screen that kept
+    a pair the other drops would only cost time, one that dropped a pair the other keeps loses records -- and the same files.
+    Sparse coverage (almost every run dies in the screen), ordinary coverage, a higher -h with a -t cap (longer runs are
+    needed, capped k-mers), and a deep small genome with -k12 -w5 (runs beyond the screen's 48 seeds, narrow buckets)."""
+    import filecmp
+    import json
+    import subprocess
+    from damar_amd import api
+    dirs = [os.path.join(str(tmp_path), x) for x in ("one", "two")]
+    os.makedirs(dirs[0])
+    os.makedirs(dirs[1])
+    nb = api.sim_write_db(dirs[0], "S", genome, coverage=cov, seed=31, block_mbp=1)
+    for f in ("S.db", ".S.idx", ".S.bps"):
+        os.symlink(os.path.join(dirs[0], f), os.path.join(dirs[1], f))
+    items = []
+    for d, extra in zip(dirs, ({}, {"DAMAR_WORK_TWOSTEP": "1"})):
+        with open(os.path.join(d, "plan.txt"), "w") as f:
+            for a in range(1, nb + 1):
+                f.write("daligner %s -j4 S.%d %s\n" % (opts, a, " ".join("S.%d" % b for b in range(a, 0, -1))))
+        subprocess.run([api.daligner_binary(), "-P", "plan.txt"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                       env=dict(os.environ, DAMAR_PLAN_STATS=os.path.join(d, "stats.json"), **extra))
+        st = json.load(open(os.path.join(d, "stats.json")))
+        items.append((st["work_items"], st["seed_pairs"], st["local_alignments"], st["records"]))
+    assert items[0] == items[1] and items[0][0] > 0
+    n = 0
+    for dp, _, fs in os.walk(dirs[1]):
+        for f in fs:
+            if f.endswith(".las"):
+                rel = os.path.relpath(os.path.join(dp, f), dirs[1])
+                assert filecmp.cmp(os.path.join(dp, f), os.path.join(dirs[0], rel), shallow=False), rel
+                n += 1
+    assert n == nb * nb
+
+
 @pytest.mark.parametrize("name", ["tan_tandem", "tan_k18"])
 def test_gpu_cli_datander_with_blocks_unpacked_on_the_host_equals_reference_golden(gpu, tmp_path, name):
     """The datander command keeps a block as its stretch of the .bps file and lets the GPU unpack it (the default, taken
