@@ -2096,6 +2096,11 @@ void damar_launch_la_batch_wide(const ReportArgs *a, const LaTask *tasks, u32 nt
 }
 
 #include "report_packed.h"
+#ifdef DAMAR_LOOPC
+extern "C" void damar_loopc_read(unsigned long long *out)
+{ hipMemcpyFromSymbol(out, HIP_SYMBOL(g_loopc), sizeof(g_loopc));
+}
+#endif
 
 /* see damar_preload_index (kmer_index.hip) */
 void damar_preload_report(void)

@@ -415,9 +415,26 @@ DUO_PART void duo_begin(int job, u32 cbase)
 #ifndef DUO_DBG
 #define DUO_DBG 0
 #endif
+/* -DDAMAR_LOOPC (scripts/build_prof_var.sh loopc -DDAMAR_LOOPC, scripts/loop_blocks.py): how often the wave loop enters its
+   conditional blocks, counted in scalar registers and added to g_loopc when the loop is left.  Without the switch: nothing. */
+#ifdef DAMAR_LOOPC
+__device__ unsigned long long g_loopc[16];
+#define DUO_LC_DECL()   u32 lc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, lcv = 0;
+#define DUO_LC(i)       lc[i] += 1u;
+#define DUO_LCV()       lcv += 1u;               /* (inside divergent code: a count per lane, summed at the end) */
+#define DUO_LC_FLUSH()  { if (lane == 0) { _Pragma("unroll") for (int q_ = 0; q_ < 16; q_++) if (lc[q_]) atomicAdd(&g_loopc[q_], (unsigned long long) lc[q_]); } \
+                          if (lcv) atomicAdd(&g_loopc[3], (unsigned long long) lcv); }
+#else
+#define DUO_LC_DECL()
+#define DUO_LC(i)
+#define DUO_LCV()
+#define DUO_LC_FLUSH()
+#endif
+
 DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
 { DUO_NAMES()
   DUO_CX();
+  DUO_LC_DECL()
   const int ave = uni(a.ave_path);
   const u64 onm = bal(cx.md == MD_RUN);
   if (!onm)
@@ -458,7 +475,8 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
     { /* (every few dozen steps) keep the band and the two lanes it may grow into within lanes 1 .. 30 of the half; a band
          that has outgrown the lanes, or a pebble pool that has run over (its stores are bounded), leaves */
       if (spanm & edges)
-        { const u32 hk = hmask(spanm, hb);
+        { DUO_LC(1)
+          const u32 hk = hmask(spanm, hb);
           const int ls = ffbl_raw(hk), hs = 31 ^ ffbh_raw(hk);
           if (onm & (bal(hs - ls > 27) | bal(ncell > cell_cap)))
             break;
@@ -522,7 +540,8 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
           int ef;
           asm volatile("" : "=v"(ef));              /* (only the byte path's lanes define it; every use is behind bytem) */
           if (bytem)
-            { if (inv(bytem))
+            { DUO_LC(2)
+              if (inv(bytem))
                 { const int Y = (v - K) >> 1;
                   const int k = (K ^ m) - m, y = (Y ^ m) - m;
                   const u8 *ar = abase + (cx.va0 - 16 * PK_PAD), *br = bbase + (cx.vb0 - 16 * PK_PAD);
@@ -557,7 +576,8 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
               if (contm)
                 { if (inv(contm))
                     do
-                      { oa += 4;  ob += 4;
+                      { DUO_LCV()
+                        oa += 4;  ob += 4;
                         DUO_LOADS()
                         DUO_WINDOW(0)
                       }
@@ -571,7 +591,11 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
              when v reaches the mark after the inherited head's), is it a new best point (align.c:911-928 / 1620-1637: the
              candidates' prefix maximum in sweep order), has the history enough matches, is it a read's end.  Some lane
              passes the old best in every step (profiles/r05_loop_blocks.txt): no branch around the maximum */
+          DUO_LC(0)
           const u64 candm = actm & bal(v > besta);
+#ifdef DAMAR_LOOPC
+          if (candm) { DUO_LC(12) }
+#endif
           int x = inv(candm) ? v : -BIG, e;
           u64 nam, nbm, mokc, endc;
           { const int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
@@ -585,7 +609,8 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
           }
           nam &= actm;  nbm &= actm;
           if (nam | nbm)
-            { /* ONE round for both chains: a slide crosses at most one mark of either grid unless it is longer than a trace
+            { DUO_LC(4)
+              /* ONE round for both chains: a slide crosses at most one mark of either grid unless it is longer than a trace
                  spacing, so the lanes of the A list and of the B list take their cells out of the half's pool together (A's
                  first) and each writes its pebble; only what is left after that goes round the loops.  In a packed head the
                  grid index sits above the cell index: + 1 << PK_HBITS steps it, and the cell's own index field is that of
@@ -618,11 +643,13 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
               nam &= bal(v >= __mul24((int) ((u32) ha >> PK_HBITS), TS2) + cpA);
               nbm &= bal(v >= __mul24((int) ((u32) hb_ >> PK_HBITS), TS2) + cpB);
               if (nam | nbm)
-                { int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
+                { DUO_LC(5)
+                  int ga = (int) ((u32) ha >> PK_HBITS), gb = (int) ((u32) hb_ >> PK_HBITS);
                   int hax = ha & PK_HMASK, hbx = hb_ & PK_HMASK;
                   int g2 = 0;
                   while (nam)
                     { GUARD(g2, guard, 5)
+                      DUO_LC(10)
                       const u32 hm = hmask(nam, hb);
                       const int idx = ncell + __popc(hm & below);
                       if (inv(nam))
@@ -638,6 +665,7 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
                     }
                   while (nbm)
                     { GUARD(g2, guard, 6)
+                      DUO_LC(11)
                       const u32 hm = hmask(nbm, hb);
                       const int idx = ncell + __popc(hm & below);
                       if (inv(nbm))
@@ -668,7 +696,11 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
             const int xl = __builtin_amdgcn_ds_bpermute(top4, x);                                 /* the maximum of the half's candidates */
             besta = xl > besta ? xl : besta;
             if (mokm)
-              { const u64 tokm = mokm & bal(pk_trim_ok(trimtab, b));
+              { DUO_LC(6)
+                const u64 tokm = mokm & bal(pk_trim_ok(trimtab, b));
+#ifdef DAMAR_LOOPC
+                if (tokm) { DUO_LC(7) }
+#endif
                 if (inv(tokm))
                   { const duo_v4i q = { v, K, ha, hb_ };
                     duo_tq[lane] = q;  duo_td[lane] = dif;
@@ -681,7 +713,8 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
           u64 wband = actm;                                   /* the band as widened: what the pruning starts from */
           { const u64 endm = (fastm & endc) | bytem;
             if (endm)
-              { const int ca2 = 2 * cx.alim - K, cb2 = 2 * cx.blim + K;
+              { DUO_LC(8)
+                const int ca2 = 2 * cx.alim - K, cb2 = 2 * cx.blim + K;
                 const bool byl = inv(bytem), act = inv(actm);
                 const bool isB = act && (byl ? ef == 2 : v == cb2);
                 const bool isA = act && !isB && (byl ? ef == 1 : v == ca2);
@@ -715,7 +748,8 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
             /* may every half go on?  lasta is at least the last known one */
             const u64 badm = onm & (bal((int) lo_ < 0) | bal(lastlim < besta));
             if (badm)
-              { int lm = L;
+              { DUO_LC(9)
+                int lm = L;
                 for (int o = 1; o < 32; o <<= 1)
                   { const int t = __shfl_xor(lm, o);  lm = t > lm ? t : lm; }
                 lm += MAX_TRIM_LAG;
@@ -728,6 +762,7 @@ DUO_PART void duo_loop(int job, const u32 *trimtab, u32 cbase)
       if (stopm)
         break;
     }
+  DUO_LC_FLUSH()
   { DuoCtx &c0 = duo_half[0];                   /* (every lane adds the same: one record counts for the wavefront) */
     const u32 lo = c0.n_cells_lo + st_cells, st_iter = (u32) (left0 - left);
     c0.n_cells_hi += (lo < st_cells) ? 1u : 0u;  c0.n_cells_lo = lo;

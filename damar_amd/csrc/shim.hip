@@ -432,6 +432,27 @@ static void stage(const char *name)
       fflush(stderr);
     }
 }
+/* The host waits for a count from the device three times per comparison (seed pairs, work items, ...) with the stream's
+   next kernels depending on it: hipStreamSynchronize sleeps until an interrupt wakes it, 30 - 45 us after the copy has
+   landed (gaps on the seed stream in the kernel trace, config 4's first 24 blocks: 97 ms of 1 160).  DAMAR_SYNC_SPIN=1
+   polls the stream instead: measured, config-4 lead leg 1.178 -> 1.153 s, config 2 and 3 unchanged (profiles/r06_sweeps.txt);
+   not the default -- a polling thread per worker is a core less for the tails and writers of a node job. */
+static void stream_wait(hipStream_t st)
+{ static int spin = -1;
+  if (spin < 0)
+    { const char *e = getenv("DAMAR_SYNC_SPIN");
+      spin = e ? atoi(e) : 0;
+    }
+  if (spin)
+    { hipError_t q;
+      while ((q = hipStreamQuery(st)) == hipErrorNotReady)
+        __builtin_ia32_pause();
+      HIP_CHECK(q);
+      return;
+    }
+  HIP_CHECK(hipStreamSynchronize(st));
+}
+
 static void  tick(int i)            { HIP_CHECK(hipEventRecord(G_ev[i], G_st)); }
 static void  tick_on(int i, hipStream_t st) { HIP_CHECK(hipEventRecord(G_ev[i], st)); }
 static float lap(int i, int j)      { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, G_ev[i], G_ev[j])); return ms; }
@@ -1905,7 +1926,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
   damar_exclusive_scan_u32(tcount, tcount, mtiles, mscw, tot, G_st);
   stage("merge_scan");
   HIP_CHECK(hipMemcpyAsync(&total, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
-  HIP_CHECK(hipStreamSynchronize(G_st));
+  stream_wait(G_st);
   if (MEM_LIMIT > 0)
     { /* filter.c:2634-2699.  The counts above keep every run below MAXGRAM; the reference lowers
          that cap to the first mutual count at which the kept seeds no longer fit `avail`.  That
@@ -2122,8 +2143,9 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       damar_launch_pair_work(keys, vals, total, m.pbits, m.dbits, m.abits, minhit, hshift, sends, (u64 *) foff /* bit words */,
                              scw2, tot, P_binshift, P_kmer, P_hitmin, P_bread_lo, P_bread_hi, G_st);
       stage("run_heads");
+      tick(3);                                             /* (the expansion of the bits behind it is 4 us: outside the clock) */
       HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
-      HIP_CHECK(hipStreamSynchronize(G_st));
+      stream_wait(G_st);                                   /* the comparison's last wait: nothing below needs the host again */
       arena_reserve(&G_ord, 5 * pad256(sizeof(u32) * (size_t) nwork64) + pad256(damar_sort_workspace_bytes(nwork64)) + 8192);
       work = (u32 *) arena_take(&G_ord, sizeof(u32) * ((size_t) nwork64 + 1));
       if (nwork64 > 0)
@@ -2151,8 +2173,10 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
           HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
         }
     }
-  tick(3);
-  HIP_CHECK(hipStreamSynchronize(G_st));
+  if (two_step)
+    { tick(3);
+      HIP_CHECK(hipStreamSynchronize(G_st));
+    }
   sort_verify();
   const u32 nwork = (u32) nwork64;
   G_ms[DAMAR_T_MERGE] += lap(0, 1);
