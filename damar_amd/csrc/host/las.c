@@ -12,6 +12,7 @@
 #include <unistd.h>
 #include <fcntl.h>
 #include <errno.h>
+#include <time.h>
 
 #include "damar_align.h"
 #include "damar_host.h"
@@ -407,13 +408,39 @@ static void las_put(LasOut *o, const void *src, size_t n)
   o->fill += n;
 }
 
+/* a file's 4 MB of assembly buffer: kept between files (a fresh one is 1 000 page faults while it fills, per file) */
+#define LAS_BUF   ((size_t) 4 << 20)
+#define LAS_BUFS  8
+static char *LAS_buf[LAS_BUFS];
+static int   LAS_nbuf;
+static pthread_mutex_t LAS_buf_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static char *las_buf_take(void)
+{ char *b = NULL;
+  pthread_mutex_lock(&LAS_buf_mu);
+  if (LAS_nbuf > 0)
+    b = LAS_buf[--LAS_nbuf];
+  pthread_mutex_unlock(&LAS_buf_mu);
+  return b != NULL ? b : (char *) malloc(LAS_BUF);
+}
+
+static void las_buf_give(char *b)
+{ pthread_mutex_lock(&LAS_buf_mu);
+  if (LAS_nbuf < LAS_BUFS)
+    { LAS_buf[LAS_nbuf++] = b;
+      b = NULL;
+    }
+  pthread_mutex_unlock(&LAS_buf_mu);
+  free(b);
+}
+
 static LasOut las_open(const char *path, int tspace)
 { LasOut  o;
   int64   none = 0;
   o.path = path;
-  o.cap  = (size_t) 4 << 20;
+  o.cap  = LAS_BUF;
   o.fill = 0;
-  o.buf  = (char *) malloc(o.cap);
+  o.buf  = las_buf_take();
   o.fd   = las_is_kept(path) ? open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666) : open("/dev/null", O_WRONLY);
   if (o.fd < 0 || o.buf == NULL)
     las_fail(&o, "open for writing");
@@ -441,7 +468,7 @@ static void las_close(LasOut *o, int64 n)
   __atomic_fetch_add(&LAS_total[2], n, __ATOMIC_RELAXED);
   if (pwrite(o->fd, &n, sizeof(n), 0) != (ssize_t) sizeof(n) || close(o->fd) != 0)
     las_fail(o, "finish");
-  free(o->buf);
+  las_buf_give(o->buf);
 }
 
 /* "NAME.7" -> root "NAME", id 7; no dot -> id 0 (align.c:6206-6228) */
@@ -458,6 +485,31 @@ static int split_block_name(const char *name, char *root, size_t cap)
 /* The order of by_overlap (a total order, so any sorting method gives the same sequence):
  * records are dealt into their A-read's bucket first, which leaves only a handful per bucket
  * to order by the remaining keys. */
+/* The two arrays a gather is sorted through are the calling thread's own and are kept between block pairs while they are
+   small: a writer thread serves thousands of pairs of some 35 000 records, and 2 x 1.7 MB from malloc are mapped, faulted
+   in page by page and unmapped again for each of them. */
+#define SCRATCH_KEEP  ((size_t) 64 << 20)
+static __thread Keyed  *KS_buf[2];
+static __thread size_t  KS_cap[2];
+
+static Keyed *scratch(int which, size_t n)
+{ if (KS_cap[which] < n)
+    { const size_t cap = n + n / 4 + 1024;
+      free(KS_buf[which]);
+      KS_buf[which] = (Keyed *) malloc(sizeof(Keyed) * cap);
+      KS_cap[which] = (KS_buf[which] != NULL) ? cap : 0;
+    }
+  return KS_buf[which];
+}
+
+static void scratch_done(void)
+{ int w;
+  for (w = 0; w < 2; w++)
+    if (KS_cap[w] * sizeof(Keyed) > SCRATCH_KEEP)
+      { free(KS_buf[w]);  KS_buf[w] = NULL;  KS_cap[w] = 0; }
+}
+
+/* (all = scratch(0, ..); the result is all itself or scratch 1) */
 static Keyed *sort_keyed(Keyed *all, int n)
 { int     lo, hi, i, j, k;
   int    *first;
@@ -473,9 +525,9 @@ static Keyed *sort_keyed(Keyed *all, int n)
       if (all[i].aread > hi) hi = all[i].aread;
     }
   first = (int *) calloc((size_t) (hi - lo) + 2, sizeof(int));
-  out   = (Keyed *) malloc(sizeof(Keyed) * (size_t) n);
+  out   = scratch(1, (size_t) n);
   if (first == NULL || out == NULL)
-    { free(first);  free(out);
+    { free(first);
       qsort(all, (size_t) n, sizeof(Keyed), by_overlap);
       return all;
     }
@@ -501,7 +553,6 @@ static Keyed *sort_keyed(Keyed *all, int n)
       i = e;
     }
   free(first);
-  free(all);
   return out;
 }
 
@@ -526,6 +577,20 @@ static void *write_file_part(void *arg)
 }
 
 /* align.c:6166-6367 on an explicit set of per-thread buffers */
+/* DAMAR_HOSTPROF: where a writer's time goes (gathering the records with their keys, sorting, writing), summed over the
+   writers and printed when the process ends */
+static double W_ms[3];
+static int    W_prof = -1;
+static pthread_mutex_t W_mu = PTHREAD_MUTEX_INITIALIZER;
+static double w_now(void)
+{ struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+static void w_report(void)
+{ fprintf(stderr, "damar .las writers, ms: gather %.1f, sort %.1f, write %.1f\n", W_ms[0], W_ms[1], W_ms[2]);
+}
+
 static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
                           const char *dir1, const char *dir2, const char *ablock, const char *bblock, int lastRead)
 { int     tspace = s->trace_space;
@@ -536,9 +601,18 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
   int     aid, bid;
   char    path1[4300], path2[4300];
 
+  double  w0, w1, w2;
+  pthread_mutex_lock(&W_mu);
+  if (W_prof < 0)
+    { W_prof = getenv("DAMAR_HOSTPROF") != NULL;
+      if (W_prof)
+        atexit(w_report);
+    }
+  pthread_mutex_unlock(&W_mu);
+  w0 = W_prof ? w_now() : 0.;
   for (i = 0; i < s->nthreads; i++)
     total += iobuf[i].otop;
-  all = (Keyed *) malloc(sizeof(Keyed) * (size_t) (total > 0 ? total : 1));
+  all = scratch(0, (size_t) (total > 0 ? total : 1));
   if (all == NULL)
     { fprintf(stderr, "[ERROR] - Write_Overlap_Buffer: Cannot create file overlap buffer for all threads\n");
       exit(1);
@@ -554,7 +628,9 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
           n += 1;
         }
     }
+  w1 = W_prof ? w_now() : 0.;
   all = sort_keyed(all, n);
+  w2 = W_prof ? w_now() : 0.;
 
   aid = split_block_name(ablock, aroot, sizeof(aroot));
   bid = split_block_name(bblock, broot, sizeof(broot));
@@ -613,7 +689,13 @@ static void write_buffers(const damar_write_params *s, Overlap_IO_Buffer *iobuf,
           write_file_part(&part2);
       }
     }
-  free(all);
+  scratch_done();
+  if (W_prof)
+    { const double w3 = w_now();
+      pthread_mutex_lock(&W_mu);
+      W_ms[0] += w1 - w0;  W_ms[1] += w2 - w1;  W_ms[2] += w3 - w2;
+      pthread_mutex_unlock(&W_mu);
+    }
 }
 
 

@@ -18,6 +18,7 @@
 #include <atomic>
 #include <mutex>
 #include <condition_variable>
+#include <functional>
 #include <string.h>
 #include <unistd.h>
 
@@ -1346,8 +1347,10 @@ static HostBuf *hostbuf_new(void)
   return h;
 }
 
+static void tail_pool_join(void);
 static void helpers_join(void)
 { late_streams();
+  tail_pool_join();
   std::thread *t = NULL;
   { std::lock_guard<std::mutex> lk(HB_mu);
     t = HB_twin;  HB_twin = NULL;
@@ -1521,6 +1524,66 @@ static int tail_threads(void)
   return n;
 }
 
+/* The threads of the tail are kept between calls: a comparison's tail is 0.8 ms of work and four threads created and joined
+   for it were 0.15 ms of that (config 3: 306 tails).  tail_pool_run(n, fn) runs fn(0) .. fn(n - 1), fn(0) on the caller. */
+static struct TailPool
+{ std::mutex              mu, run_mu;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> th;
+  const std::function<void(int)> *fn = NULL;
+  int      n = 0, left = 0;
+  uint64_t gen = 0;
+  bool     stop = false;
+} TP;
+
+static void tail_pool_worker(int w)
+{ uint64_t seen = 0;
+  for (;;)
+    { const std::function<void(int)> *fn;
+      { std::unique_lock<std::mutex> lk(TP.mu);
+        TP.cv_work.wait(lk, [&] { return TP.stop || TP.gen != seen; });
+        if (TP.stop)
+          return;
+        seen = TP.gen;
+        if (w >= TP.n)
+          continue;
+        fn = TP.fn;
+      }
+      (*fn)(w);
+      { std::lock_guard<std::mutex> lk(TP.mu);
+        if (--TP.left == 0)
+          TP.cv_done.notify_one();
+      }
+    }
+}
+
+static void tail_pool_run(int n, const std::function<void(int)> &fn)
+{ std::lock_guard<std::mutex> one(TP.run_mu);
+  { std::lock_guard<std::mutex> lk(TP.mu);
+    while ((int) TP.th.size() < n - 1)
+      { const int w = (int) TP.th.size() + 1;
+        TP.th.emplace_back(tail_pool_worker, w);
+      }
+    TP.fn = &fn;  TP.n = n;  TP.left = n - 1;  TP.gen += 1;
+  }
+  TP.cv_work.notify_all();
+  fn(0);
+  std::unique_lock<std::mutex> lk(TP.mu);
+  TP.cv_done.wait(lk, [&] { return TP.left == 0; });
+  TP.fn = NULL;  TP.n = 0;
+}
+
+static void tail_pool_join(void)
+{ { std::lock_guard<std::mutex> lk(TP.mu);
+    TP.stop = true;
+  }
+  TP.cv_work.notify_all();
+  for (auto &t : TP.th)
+    t.join();
+  TP.th.clear();
+  TP.stop = false;
+}
+
 static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool, int t8, const u32 *wmap,
                       const HITS_DB *ablock, const HITS_DB *bblock, int self, int comp, Align_Spec *spec,
                       const JobParams &jp, int jobid = 0, int njobs = 1)
@@ -1599,7 +1662,6 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool, int t8
   const bool direct = Num_Threads(spec) >= nthr;
   std::vector<Overlap_IO_Buffer *> part(nthr, (Overlap_IO_Buffer *) NULL);
   std::vector<int64> got(nthr, 0);
-  std::vector<std::thread> th;
   for (int t = 0; t < nthr; t++)
     { if (direct)
         part[t] = obuf + t;
@@ -1608,13 +1670,12 @@ static int64 run_tail(LaRecord *recs, size_t nrecs_all, const u16 *tpool, int t8
           if (part[t] == NULL)
             die();
         }
-      th.emplace_back([&, t] { got[t] = tail_range(recs, ord.data(), okey.data(), cut[t], cut[t + 1], tpool, t8, ablock, bblock,
-                                                    self, comp, ts, part[t], jp.symmetric, jp.hgap_min); });
     }
+  tail_pool_run(nthr, [&](int t) { got[t] = tail_range(recs, ord.data(), okey.data(), cut[t], cut[t + 1], tpool, t8, ablock, bblock,
+                                                       self, comp, ts, part[t], jp.symmetric, jp.hgap_min); });
   int64 ncheck = 0;
   for (int t = 0; t < nthr; t++)
-    { th[t].join();
-      if (!direct)
+    { if (!direct)
         { if (damar_append_overlap_buffer(obuf, part[t]))
             { fprintf(stderr, "damar: FATAL: out of memory appending overlaps\n");
               die();
