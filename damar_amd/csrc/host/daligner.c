@@ -778,7 +778,7 @@ static damar_dev_index *pblock_index(PBlock *b, int comp)
 /* What a plan has cost, summed over its calls (the library's own clocks, include/damar_hip.h DAMAR_T_*), for the one
    machine-readable line a run leaves behind: DAMAR_PLAN_STATS=<file> ("-": stderr) */
 static double S_ms[DAMAR_T_COUNT];
-static int64  S_seeds, S_pairs, S_work;
+static int64  S_seeds, S_pairs, S_work, S_resort;
 static int    S_loads, S_tile, S_blocks, S_resident;
 static double S_budget_gb;
 
@@ -808,10 +808,10 @@ static void plan_stats_write(int nlines, int worker, int nworkers, double wall)
     return;
   fprintf(f, "{\"tool\": \"daligner -P\", \"worker\": %d, \"workers\": %d, \"plan_lines\": %d, \"block_pairs\": %lld, \"blocks\": %d, "
              "\"tile\": %d, \"bases_resident\": %d, \"budget_gb\": %.1f, \"index_builds\": %d, \"block_loads\": %d, \"wall_ms\": %.1f, "
-             "\"seed_pairs\": %lld, \"work_items\": %lld, \"local_alignments\": %lld, \"report_launches\": %lld, \"records\": %lld, "
+             "\"seed_pairs\": %lld, \"work_items\": %lld, \"resorted\": %lld, \"local_alignments\": %lld, \"report_launches\": %lld, \"records\": %lld, "
              "\"aligned_bp\": %lld, \"las_bytes\": %lld, \"las_files\": %lld, \"phase_ms\": {",
           worker, nworkers, nlines, (long long) S_pairs, S_blocks, S_tile, S_resident, S_budget_gb, PB_builds, S_loads, wall,
-          (long long) S_seeds, (long long) S_work, (long long) nf, (long long) nl, (long long) las[2], (long long) las[3], (long long) las[0], (long long) las[1]);
+          (long long) S_seeds, (long long) S_work, (long long) S_resort, (long long) nf, (long long) nl, (long long) las[2], (long long) las[3], (long long) las[0], (long long) las[1]);
   for (i = 0; i < DAMAR_T_COUNT; i++)
     fprintf(f, "\"%s\": %.1f, ", nm[i], S_ms[i]);
   fprintf(f, "\"write\": %.1f}, \"host_wall_ms\": {", wr);
@@ -911,6 +911,7 @@ static void plan_line(const Opts *o, const char *afile, char **bfiles, int nb)
       { int64 c[8];
         damar_last_counters(c);
         S_work += c[1];                               /* read pairs that passed the screen of the run heads */
+        S_resort += c[7];                             /* comparisons whose seeds were sorted over all the bits after all */
       }
       S_pairs += 1;
       P_ms[2] += wall_ms() - t0;

@@ -146,9 +146,14 @@ void damar_launch_pair_heads(const u64 *keys, u64 nhits, int pbits, int abits, i
                              u64 *send /* 64 entries of scratch */, u64 *bits, void *scan_work, u64 *total_dev,
                              u32 *heads, hipStream_t st);
 /* run heads + screen in one pass (pair_work_mark): the first half leaves the number of work items in *total_dev */
-void damar_launch_pair_work(const u64 *keys, const u32 *vals, u64 nhits, int ppos, int dbits, int abits, int minhit, int nshift,
-                            u64 *send /* 64 entries of scratch */, u64 *bits, void *scan_work, u64 *total_dev,
-                            int binshift, int kmer, int hitmin, u32 b_lo, u32 b_hi, hipStream_t st);
+/* (unsorted: the seed sort went over the read pair only -- the screen takes a run's seeds in any order, the caller puts the
+   kept heads' runs in order of their A positions (damar_launch_order_runs) unless total_dev[1] != 0: a run too long for that,
+   sort over all the bits) */
+void damar_launch_pair_work(u64 *keys, const u32 *vals, u64 nhits, int ppos, int dbits, int abits, int minhit, int nshift,
+                            u64 *send /* 64 entries of scratch */, u64 *bits, void *scan_work, u64 *total_dev /* [2] */,
+                            int binshift, int kmer, int hitmin, u32 b_lo, u32 b_hi, int unsorted, hipStream_t st);
+/* (unsorted only) the runs of the work list's heads into the order of their A positions, in place */
+void damar_launch_order_runs(u64 *keys, u64 nhits, int ppos, int dbits, const u32 *work, u32 nwork, hipStream_t st);
 void damar_launch_pair_work_expand(const u64 *bits, const void *scan_work, u64 nhits, u32 *work, hipStream_t st);
 #define WORK_COST_BITS 16
 #define WORK_COST_MAX  ((1u << WORK_COST_BITS) - 1)

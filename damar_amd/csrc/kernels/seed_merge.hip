@@ -1183,26 +1183,44 @@ void damar_launch_pair_screen(const u64 *keys, const u32 *vals, u64 nhits, int p
  * bucket and of the next one add (four per pair) -- the loops over x and y with their LDS reads, unpacking and branches were
  * 2 000 instructions per wavefront for the longest run among its 64 heads.  run[q] = key of the run's seed q; lanes with
  * n = 0 take part and return false. */
-template <int N>
+template <int N, bool UNS>
 __device__ __forceinline__ bool pw_screen_small(const u64 *run, int n, u64 pmask, int dbits, int binshift, int kmer, int hitmin)
 { int d[N], c[N];                                        /* bucket and A position of seed q */
   const u64 dmask = (1ull << dbits) - 1;
+  int top = 0;                                           /* (UNS) the run's largest A position */
 #pragma unroll
   for (int q = 0; q < N; q++)
     { const u64 k = run[q < n ? q : 0];
       c[q] = (int) ((k >> dbits) & pmask);
       d[q] = (q < n) ? ((c[q] - (int) (k & dmask)) >> binshift) : 0x40000000 + 4 * q;       /* (a bucket of its own) */
+      if (UNS)
+        top = (q < n && c[q] > top) ? c[q] : top;
     }
   /* contributions: add[q] = min(kmer, ap[q] - ap[last y < q in the same bucket, or 0]) */
   int add[N];
 #pragma unroll
   for (int q = 0; q < N; q++)
     { int prev = 0;
+      if (UNS)
+        { /* the seeds of a run in no particular order (the seed sort went over the read pair only): the seed before q in
+             its bucket is the one with the largest A position among those that order before q (position, then place) */
 #pragma unroll
-      for (int y = 0; y < q; y++)
-        prev = (d[y] == d[q]) ? c[y] : prev;
+          for (int y = 0; y < N; y++)
+            if (y != q)
+              { const bool before = (y < q) ? c[y] <= c[q] : c[y] < c[q];
+                prev = (d[y] == d[q] && before && c[y] > prev) ? c[y] : prev;
+              }
+        }
+      else
+        {
+#pragma unroll
+          for (int y = 0; y < q; y++)
+            prev = (d[y] == d[q]) ? c[y] : prev;
+        }
       add[q] = min(c[q] - prev, kmer);
     }
+  if (UNS && top > SCREEN_PANEL)                         /* beyond the first panel: not screened (pair_screen), kept */
+    return true;
   bool ok = false;
 #pragma unroll
   for (int x = 0; x < N; x++)
@@ -1215,6 +1233,7 @@ __device__ __forceinline__ bool pw_screen_small(const u64 *run, int n, u64 pmask
   return ok;
 }
 
+template <bool UNS>                                      /* UNS: the seeds of a read pair's run are in no particular order */
 __global__ __launch_bounds__(256)
 void pair_work_mark(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 nhits, int ppos, int dbits, int abits,
                     int minhit, int nshift, const u64 *__restrict__ send, int binshift, int kmer, int hitmin,
@@ -1338,7 +1357,8 @@ void pair_work_mark(const u64 *__restrict__ keys, const u32 *__restrict__ vals, 
               if (p & 63)
                 ws |= bb[(p >> 6) + 1] << (64 - (p & 63));
               n = ws ? __ffsll((long long) ws) : 65;     /* (65: more than 64) */
-              if (n > SCREEN_MAX || minhit > SCREEN_MAX || (int) ((sk[off + (u32) n] >> dbits) & pmask) > SCREEN_PANEL)
+              if (n > SCREEN_MAX || minhit > SCREEN_MAX ||
+                  (!UNS && (int) ((sk[off + (u32) n] >> dbits) & pmask) > SCREEN_PANEL))    /* (UNS: the screens look at the panel) */
                 atomicOr(&kb[off >> 5], 1u << (off & 31));       /* not screened (pair_screen): kept */
               else if (n > PW_SMALL)
                 bl[atomicAdd(&nb, 1u)] = off | ((u32) n << 16);
@@ -1392,12 +1412,12 @@ void pair_work_mark(const u64 *__restrict__ keys, const u32 *__restrict__ vals, 
             }
         }
       else if (__ballot(n > 0) != 0)                     /* all of the wavefront's runs with the code for its longest */
-        { if      (__ballot(n > 7) != 0) keep = pw_screen_small<8>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
-          else if (__ballot(n > 6) != 0) keep = pw_screen_small<7>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
-          else if (__ballot(n > 5) != 0) keep = pw_screen_small<6>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
-          else if (__ballot(n > 4) != 0) keep = pw_screen_small<5>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
-          else if (__ballot(n > 3) != 0) keep = pw_screen_small<4>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
-          else                           keep = pw_screen_small<3>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+        { if      (__ballot(n > 7) != 0) keep = pw_screen_small<8, UNS>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+          else if (__ballot(n > 6) != 0) keep = pw_screen_small<7, UNS>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+          else if (__ballot(n > 5) != 0) keep = pw_screen_small<6, UNS>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+          else if (__ballot(n > 4) != 0) keep = pw_screen_small<5, UNS>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+          else if (__ballot(n > 3) != 0) keep = pw_screen_small<4, UNS>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
+          else                           keep = pw_screen_small<3, UNS>(sk + off + 1, n, pmask, dbits, binshift, kmer, hitmin);
         }
       if (keep)
         atomicOr(&kb[off >> 5], 1u << (off & 31));
@@ -1411,6 +1431,29 @@ void pair_work_mark(const u64 *__restrict__ keys, const u32 *__restrict__ vals, 
       const u64 i = base + off;
       const int xl = l < n ? l : n - 1;                  /* (n <= SCREEN_MAX < 64) */
       const int dx = seed_diag(sk[off + 1 + (u32) xl], vals, i + (u64) xl, pmask, dbits) >> binshift;
+      if (UNS)
+        { /* seeds in no particular order: what seed x adds to its bucket first (the largest A position of its bucket
+             that orders before it), then the sums over the two buckets, the other lanes' figures by ds_bpermute */
+          const int apx = (int) ((sk[off + 1 + (u32) xl] >> dbits) & pmask);
+          int prev = 0, top = 0;
+          for (int y = 0; y < n; y++)
+            { const u64 ky = sk[off + 1 + (u32) y];
+              const int dy = seed_diag(ky, vals, i + (u64) y, pmask, dbits) >> binshift;
+              const int ap = (int) ((ky >> dbits) & pmask);
+              const bool before = ap < apx || (ap == apx && y < xl);
+              prev = (dy == dx && before && ap > prev) ? ap : prev;
+              top = ap > top ? ap : top;
+            }
+          const int addx = (l < n) ? min(apx - prev, kmer) : 0;
+          int sum = 0;
+          for (int y = 0; y < n; y++)
+            { const int ay = __shfl(addx, y), dy = __shfl(dx, y);
+              sum += ((u32) (dy - dx) <= 1u) ? ay : 0;
+            }
+          if ((top > SCREEN_PANEL || __ballot(l < n && sum >= hitmin) != 0) && l == 0)
+            atomicOr(&kb[off >> 5], 1u << (off & 31));
+          continue;
+        }
       int s0 = 0, s1 = 0, p0 = 0, p1 = 0;
 #pragma unroll 4
       for (int y = 0; y < n; y++)
@@ -1435,23 +1478,131 @@ void pair_work_mark(const u64 *__restrict__ keys, const u32 *__restrict__ vals, 
     }
 }
 
+/* The seed sort over the read pair only (4 passes instead of 6: 28 of the 43 key bits) leaves the seeds of a pair in index
+ * order; only the runs the report kernel will walk -- the kept heads' -- have to be in order of their A positions, ties in
+ * the order they have (what the stable sort over all the bits leaves).  order_sort, one wavefront per work item once the
+ * work list exists: the run's length (the lanes probe 64 seeds at a time), the run into LDS, a bitonic sort of
+ * (A position << 11 | place in the run) -- a strict order, so any sort is the stable one -- and the run back where it was.
+ * order_probe, before the host reads the number of work items: is any kept head's run longer than a wavefront sorts in
+ * LDS (OR_MAX)?  Then the caller sorts that comparison over all the bits after all. */
+#define OR_MAX 2048
+__device__ __forceinline__ u32 run_length(const u64 *__restrict__ keys, u64 nhits, u64 i, int pshift, u32 maxrun, int l)
+{ const u64 pr = keys[i] >> pshift;
+  u32 n = 0;
+  for (;;)                                                    /* 64 probes at a time */
+    { const u64 x = i + (u64) n + (u64) l;
+      const u64 same = __ballot(x < nhits && (keys[x] >> pshift) == pr);
+      if (same != ~0ull)
+        return n + (u32) __ffsll((long long) ~same) - 1u;
+      n += 64;
+      if (n > maxrun)
+        return n;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void order_probe(const u64 *__restrict__ keys, u64 nhits, int ppos, int dbits, const u64 *__restrict__ bits, u64 *__restrict__ flag,
+                 u32 maxrun)
+{ SEED_PRIO(g_merge_prio);
+  __shared__ u16 hl[DAMAR_SCAN_TILE];
+  __shared__ u32 nh;
+  const int  l = lane_id();
+  const u64  base = (u64) blockIdx.x * DAMAR_SCAN_TILE;
+  if (threadIdx.x == 0)
+    nh = 0;
+  __syncthreads();
+  if (threadIdx.x < DAMAR_SCAN_TILE / 64)
+    { u64 w = bits[(base >> 6) + threadIdx.x];
+      while (w)
+        { const int b = __ffsll((long long) w) - 1;
+          w &= w - 1;
+          hl[atomicAdd(&nh, 1u)] = (u16) (threadIdx.x * 64u + (u32) b);
+        }
+    }
+  __syncthreads();
+  const u32 n_h = nh;
+  bool over = false;
+  for (u32 h = threadIdx.x >> 6; h < n_h; h += 4)             /* a wavefront per kept head */
+    over |= run_length(keys, nhits, base + hl[h], ppos + dbits, maxrun, l) > maxrun;
+  if (over && l == 0)
+    atomicOr((unsigned long long *) flag, 1ull);
+}
+
+__global__ __launch_bounds__(64)
+void order_sort(u64 *__restrict__ keys, u64 nhits, int ppos, int dbits, const u32 *__restrict__ work, u32 nwork)
+{ SEED_PRIO(g_merge_prio);
+  __shared__ u64 rk[OR_MAX];
+  __shared__ u32 ck[OR_MAX];
+  const int  l = threadIdx.x;
+  const u64  pmask = (1ull << ppos) - 1;
+  if (blockIdx.x >= nwork)
+    return;
+  const u64 i = work[blockIdx.x];
+  const u32 n = run_length(keys, nhits, i, ppos + dbits, OR_MAX, l);
+  if (n < 2 || n > OR_MAX)                                   /* (longer: order_probe has sent the comparison the other way) */
+    return;
+  u32 P = 2;
+  while (P < n)
+    P <<= 1;
+  for (u32 j = (u32) l; j < P; j += 64)
+    { if (j < n)
+        { const u64 k = keys[i + j];
+          rk[j] = k;
+          ck[j] = ((u32) ((k >> dbits) & pmask) << 11) | j;
+        }
+      else
+        ck[j] = 0xffffffffu;
+    }
+  __syncthreads();
+  for (u32 k2 = 2; k2 <= P; k2 <<= 1)
+    for (u32 jj = k2 >> 1; jj > 0; jj >>= 1)
+      { for (u32 t = (u32) l; t < (P >> 1); t += 64)
+          { const u32 ix = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), px = ix | jj;
+            const bool up = (ix & k2) == 0;
+            const u32 a = ck[ix], c = ck[px];
+            if ((a > c) == up)
+              { ck[ix] = c;  ck[px] = a; }
+          }
+        __syncthreads();
+      }
+  for (u32 j = (u32) l; j < n; j += 64)
+    keys[i + j] = rk[ck[j] & 2047u];
+}
+
+void damar_launch_order_runs(u64 *keys, u64 nhits, int ppos, int dbits, const u32 *work, u32 nwork, hipStream_t st)
+{ if (nwork == 0)
+    return;
+  hipLaunchKernelGGL(order_sort, dim3(nwork), dim3(64), 0, st, keys, nhits, ppos, dbits, work, nwork);
+}
+
 /* first half: bit words + *total_dev = the number of work items; the caller reads the total, makes room, and calls the
    second half.  bits: 64 u64 words per tile of DAMAR_SCAN_TILE seeds; scan_work: damar_scan_workspace_bytes(nhits) */
-void damar_launch_pair_work(const u64 *keys, const u32 *vals, u64 nhits, int ppos, int dbits, int abits, int minhit, int nshift,
+void damar_launch_pair_work(u64 *keys, const u32 *vals, u64 nhits, int ppos, int dbits, int abits, int minhit, int nshift,
                             u64 *send, u64 *bits, void *scan_work, u64 *total_dev, int binshift, int kmer, int hitmin,
-                            u32 b_lo, u32 b_hi, hipStream_t st)
-{ if (nhits == 0)
-    { HIP_CHECK(hipMemsetAsync(total_dev, 0, sizeof(u64), st));
-      return;
-    }
+                            u32 b_lo, u32 b_hi, int unsorted, hipStream_t st)
+{ HIP_CHECK(hipMemsetAsync(total_dev, 0, 2 * sizeof(u64), st));         /* [1]: order_runs met a run it does not sort */
+  if (nhits == 0)
+    return;
   if (nshift > 6)
     nshift = 6;
   const u32 ntiles = (u32) ((nhits + DAMAR_SCAN_TILE - 1) / DAMAR_SCAN_TILE);
   u32 *tcount = (u32 *) scan_work;
   if (nshift >= 0)
     hipLaunchKernelGGL(slice_ends<u64>, dim3(1), dim3(64), 0, st, keys, nhits, abits + ppos + dbits, nshift, send);
-  hipLaunchKernelGGL(pair_work_mark, dim3(ntiles), dim3(256), 0, st, keys, vals, nhits, ppos, dbits, abits, minhit, nshift,
-                     (const u64 *) send, binshift, kmer, hitmin, b_lo, b_hi, bits, tcount);
+  if (!unsorted)
+    hipLaunchKernelGGL(pair_work_mark<false>, dim3(ntiles), dim3(256), 0, st, (const u64 *) keys, vals, nhits, ppos, dbits, abits, minhit,
+                       nshift, (const u64 *) send, binshift, kmer, hitmin, b_lo, b_hi, bits, tcount);
+  else
+    { hipLaunchKernelGGL(pair_work_mark<true>, dim3(ntiles), dim3(256), 0, st, (const u64 *) keys, vals, nhits, ppos, dbits, abits, minhit,
+                         nshift, (const u64 *) send, binshift, kmer, hitmin, b_lo, b_hi, bits, tcount);
+      static int maxrun = -1;                      /* test hook DAMAR_TEST_RUN_MAX: runs longer than this count as too long (<= OR_MAX) */
+      if (maxrun < 0)
+        { const char *e = getenv("DAMAR_TEST_RUN_MAX");
+          maxrun = (e && atoi(e) >= 2 && atoi(e) <= OR_MAX) ? atoi(e) : OR_MAX;
+        }
+      hipLaunchKernelGGL(order_probe, dim3(ntiles), dim3(256), 0, st, (const u64 *) keys, nhits, ppos, dbits, (const u64 *) bits, total_dev + 1,
+                         (u32) maxrun);
+    }
   damar_scan_tile_counts(tcount, ntiles, total_dev, st);
 }
 

@@ -2080,9 +2080,35 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
     }
   const bool ranged = P_bread_lo > 0 || P_bread_hi != 0xffffffffu;      /* one part of a block pair split over GPUs */
   const bool cut = (cut_on || ranged) && !G_keep_seeds && idbits <= 32;
+  static int two_step = -1;                              /* DAMAR_WORK_TWOSTEP=1: heads, then their screen (rounds 1-5; tested) */
+  if (two_step < 0)
+    { const char *e = getenv("DAMAR_WORK_TWOSTEP");
+      two_step = (e && atoi(e) > 0) ? 1 : 0;
+    }
+  /* The seed sort over the READ PAIR only (its abits + bbits of the key's sbits: 4 passes instead of 6).  The seeds of a
+     pair then lie in index order; the screen of the run heads takes them in any order and the runs of the kept heads -- all
+     the report kernel walks -- are put in order of their A positions where they lie (kernels/seed_merge.hip order_runs).
+     Not when something else reads the seeds (the tests' seed list, the two-step work list), not for the unpacked layout.
+     It pays where the seed stages are the longer side: first 300 block pairs of config 4 1.17 -> 1.11 s; config 2 gains
+     nothing (its two passes ran in the shadow of the report kernel) and config 3 loses 4 % (ordering 9 500 runs of a few
+     hundred seeds beside a report kernel that is the longer side there) -- so, like the report launch's shape (report_launch),
+     it goes by the seed pairs per work item of the comparison before this one: more than DAMAR_ADAPT_RATIO (4 000).
+     DAMAR_SORT_PAIR=0: never (the sort over all the bits, rounds 1-6), 1: always (both tested). */
+  static int pair_sort = -1;
+  static long long pair_ratio = 4000;
+  static u64 prev_seeds = 0, prev_work = 1;              /* of the comparison before this one */
+  if (pair_sort < 0)
+    { const char *e = getenv("DAMAR_SORT_PAIR"), *r = getenv("DAMAR_ADAPT_RATIO");
+      pair_sort = e ? atoi(e) : 2;
+      if (r)
+        pair_ratio = atoll(r);
+    }
+  const bool pair_on = pair_sort == 1 || (pair_sort == 2 && pair_ratio > 0 && prev_seeds / prev_work > (u64) pair_ratio);
+  bool psort = pair_on && !cut && !two_step && !G_keep_seeds && m.dbits != 0 && m.pbits + 11 <= 32 && m.pbits >= 8;
+  const int spasses_used = psort ? (sbits - m.pbits + 7) / 8 : spasses;
   u64 *keys, *tk;
   u32 *vals, *flags, *foff;
-  void *scw2;
+  void *scw2, *resort_ws = NULL;
   u64 *sends;
   int  hshift = P_nshift;                                     /* slices of the reference's threads in the head test */
   if (!cut)
@@ -2093,9 +2119,10 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       u32 *pv = m.dbits ? NULL : (u32 *) arena_take(&G_hits, sizeof(u32) * (size_t) total);
       tk = (u64 *) arena_take(&G_tmp, sizeof(u64) * (size_t) total);
       u32 *tv = m.dbits ? NULL : (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
-      u64 *k0 = (spasses & 1) ? tk : pk, *k1 = (spasses & 1) ? pk : tk;
-      u32 *v0 = (spasses & 1) ? tv : pv, *v1 = (spasses & 1) ? pv : tv;
+      u64 *k0 = (spasses_used & 1) ? tk : pk, *k1 = (spasses_used & 1) ? pk : tk;
+      u32 *v0 = (spasses_used & 1) ? tv : pv, *v1 = (spasses_used & 1) ? pv : tv;
       void *sw = arena_take(&G_tmp, damar_sort_workspace_bytes(total));
+      resort_ws = sw;
       flags = (u32 *) arena_take(&G_tmp, sizeof(u32) * (size_t) total);
       foff  = (u32 *) arena_take(&G_tmp, std::max(sizeof(u32) * (size_t) total, bit_words_bytes(total)));   /* (also the heads' bit words) */
       scw2  = arena_take(&G_tmp, damar_scan_workspace_bytes(total));
@@ -2104,7 +2131,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
       damar_launch_merge_emit(&m, mw, total, k0, v0, NULL, G_st);
       stage("merge_emit");
       tick(1);
-      int side = m.dbits ? damar_radix_sort_keys_u64(k0, k1, total, m.dbits, m.dbits + sbits, sw, G_st)
+      int side = m.dbits ? damar_radix_sort_keys_u64(k0, k1, total, m.dbits + (psort ? m.pbits : 0), m.dbits + sbits, sw, G_st)
                          : damar_radix_sort_u64(k0, v0, k1, v1, total, sbits, sw, G_st);
       sort_check(sw);
       keys = side ? k1 : k0;
@@ -2193,24 +2220,46 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
   /* ---- work list ---- */
   u64 nwork64 = 0;
   u32 *work = NULL;
-  static int two_step = -1;                              /* DAMAR_WORK_TWOSTEP=1: heads, then their screen (rounds 1-5; tested) */
-  if (two_step < 0)
-    { const char *e = getenv("DAMAR_WORK_TWOSTEP");
-      two_step = (e && atoi(e) > 0) ? 1 : 0;
-    }
   if (!two_step)
     { /* heads and screen in one pass over the seeds: a bit per seed, the work list expanded from the bits once its
          length is known (the work list and its processing order outlive the seed stage: the comparison's second arena) */
+      u64 got[2] = { 0, 0 };                               /* work items; a run order_runs would not sort */
+      if (cut)
+        psort = false;                                     /* (the early cut's survivors were sorted over all the bits) */
       damar_launch_pair_work(keys, vals, total, m.pbits, m.dbits, m.abits, minhit, hshift, sends, (u64 *) foff /* bit words */,
-                             scw2, tot, P_binshift, P_kmer, P_hitmin, P_bread_lo, P_bread_hi, G_st);
+                             scw2, tot, P_binshift, P_kmer, P_hitmin, P_bread_lo, P_bread_hi, psort ? 1 : 0, G_st);
       stage("run_heads");
       tick(3);                                             /* (the expansion of the bits behind it is 4 us: outside the clock) */
-      HIP_CHECK(hipMemcpyAsync(&nwork64, tot, sizeof(u64), hipMemcpyDeviceToHost, G_st));
+      HIP_CHECK(hipMemcpyAsync(got, tot, 2 * sizeof(u64), hipMemcpyDeviceToHost, G_st));
       stream_wait(G_st);                                   /* the comparison's last wait: nothing below needs the host again */
+      if (psort && got[1] != 0)
+        { /* a run of more than 2048 seeds among the kept ones (a tandem array against itself, a satellite): this comparison's
+             seeds are sorted over all the bits after all -- from where they lie, the order of equal keys has not changed --
+             and the work list is made again */
+          G_cnt[7] += 1;
+          u64 *other = (keys == tk) ? NULL : tk;
+          if (other == NULL || resort_ws == NULL)
+            { fprintf(stderr, "damar: internal error, no room to sort the seeds again\n");
+              die();
+            }
+          int side = damar_radix_sort_keys_u64(keys, other, total, m.dbits, m.dbits + sbits, resort_ws, G_st);
+          sort_check(resort_ws);
+          if (side)
+            HIP_CHECK(hipMemcpyAsync(keys, other, sizeof(u64) * (size_t) total, hipMemcpyDeviceToDevice, G_st));
+          damar_launch_pair_work(keys, vals, total, m.pbits, m.dbits, m.abits, minhit, hshift, sends, (u64 *) foff, scw2, tot,
+                                 P_binshift, P_kmer, P_hitmin, P_bread_lo, P_bread_hi, 0, G_st);
+          HIP_CHECK(hipMemcpyAsync(got, tot, 2 * sizeof(u64), hipMemcpyDeviceToHost, G_st));
+          stream_wait(G_st);
+          psort = false;
+        }
+      nwork64 = got[0];
       arena_reserve(&G_ord, 5 * pad256(sizeof(u32) * (size_t) nwork64) + pad256(damar_sort_workspace_bytes(nwork64)) + 8192);
       work = (u32 *) arena_take(&G_ord, sizeof(u32) * ((size_t) nwork64 + 1));
       if (nwork64 > 0)
-        damar_launch_pair_work_expand((const u64 *) foff, scw2, total, work, G_st);
+        { damar_launch_pair_work_expand((const u64 *) foff, scw2, total, work, G_st);
+          if (psort)                                       /* the runs the report kernel will walk, in the order of their A positions */
+            damar_launch_order_runs(keys, total, m.pbits, m.dbits, work, (u32) nwork64, G_st);
+        }
       stage("work_list");
     }
   else
@@ -2245,6 +2294,7 @@ static bool match_front(damar_match_job *job, int slot, Front *f)
   G_ms[DAMAR_T_WORK]  += lap(2, 3);
   G_cnt[0] += nhits;  G_cnt[1] += nwork;
   job->counts[0] = nhits;
+  prev_seeds = total;  prev_work = nwork > 0 ? nwork : 1;
 
   if (G_keep_seeds)
     { G_seed_keys.resize(total);  G_seed_vals.resize(total);

@@ -76,6 +76,31 @@ def test_gpu_cli_merge_general_path_equals_reference_golden(gpu, tmp_path, name)
     assert compare_las(case, str(tmp_path)) == []
 
 
+@pytest.mark.parametrize("mode", [{"DAMAR_SORT_PAIR": "1"}, {"DAMAR_SORT_PAIR": "0"}, {"DAMAR_SORT_PAIR": "1", "DAMAR_TEST_RUN_MAX": "6"}])
+@pytest.mark.parametrize("name", ["tiny2", "tandem", "tiny_I", "tiny_k12", "mask_two", "bias_mask"])
+def test_gpu_cli_seed_sort_over_the_read_pair_equals_reference_golden(gpu, tmp_path, name, mode):
+    """The seed pairs are sorted on (bread, aread) only -- 4 radix passes instead of 6 -- and the A-position order inside a read
+    pair, which only the report kernel's walk over a run needs (filter.c:2268-2297 adds up apos differences in order), is made
+    for the runs of the kept heads alone, where they lie (kernels/seed_merge.hip order_runs; the screen takes a run in any
+    order).  DAMAR_SORT_PAIR=0: the sort over all the key bits of rounds 1-6.  DAMAR_TEST_RUN_MAX=6: runs of more than 6 seeds
+    count as too long for order_runs, so the comparison is sorted over all the bits after all and its work list made again
+    (the path of a run beyond 2048 seeds); the line of DAMAR_PLAN_STATS says how often."""
+    import json
+    import subprocess
+    from damar_amd import api
+    case = read_case(name)
+    link_db(case["dbdir"], str(tmp_path))
+    with open(os.path.join(str(tmp_path), "plan.txt"), "w") as f:
+        for a, bs in case["lines"]:
+            f.write("daligner %s G.%s %s\n" % (" ".join(case["opts"]), a, " ".join("G." + b for b in bs)))
+    st = os.path.join(str(tmp_path), "stats.json")
+    subprocess.run([api.daligner_binary(), "-P", "plan.txt"], cwd=str(tmp_path), check=True, stdout=subprocess.DEVNULL,
+                   env=dict(os.environ, DAMAR_PLAN_STATS=st, **mode))
+    assert compare_las(case, str(tmp_path)) == []
+    resorted = json.load(open(st))["resorted"]
+    assert (resorted > 0) == ("DAMAR_TEST_RUN_MAX" in mode)
+
+
 @pytest.mark.parametrize("name", ["tiny2", "tandem", "tiny_I", "tiny_k12", "mask_two"])
 def test_gpu_cli_work_list_in_two_steps_equals_reference_golden(gpu, tmp_path, name):
     """The work list of a comparison -- the heads of the (bread, aread) runs report_thread would enter (filter.c:2212-2215)
