@@ -1480,8 +1480,8 @@ void pair_work_mark(const u64 *__restrict__ keys, const u32 *__restrict__ vals, 
 
 /* The seed sort over the read pair only (4 passes instead of 6: 28 of the 43 key bits) leaves the seeds of a pair in index
  * order; only the runs the report kernel will walk -- the kept heads' -- have to be in order of their A positions, ties in
- * the order they have (what the stable sort over all the bits leaves).  order_sort, one wavefront per work item once the
- * work list exists: the run's length (the lanes probe 64 seeds at a time), the run into LDS, a bitonic sort of
+ * the order they have (what the stable sort over all the bits leaves).  order_sort, one workgroup per work item once the
+ * work list exists (the rule of shim.hip match_front turns this on where the kept runs are few and long): the run's length (the lanes probe 64 seeds at a time), the run into LDS, a bitonic sort of
  * (A position << 11 | place in the run) -- a strict order, so any sort is the stable one -- and the run back where it was.
  * order_probe, before the host reads the number of work items: is any kept head's run longer than a wavefront sorts in
  * LDS (OR_MAX)?  Then the caller sorts that comparison over all the bits after all. */
@@ -1528,12 +1528,12 @@ void order_probe(const u64 *__restrict__ keys, u64 nhits, int ppos, int dbits, c
     atomicOr((unsigned long long *) flag, 1ull);
 }
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(256)
 void order_sort(u64 *__restrict__ keys, u64 nhits, int ppos, int dbits, const u32 *__restrict__ work, u32 nwork)
 { SEED_PRIO(g_merge_prio);
   __shared__ u64 rk[OR_MAX];
   __shared__ u32 ck[OR_MAX];
-  const int  l = threadIdx.x;
+  const int  l = lane_id();                                  /* (every wavefront finds the run's length for itself) */
   const u64  pmask = (1ull << ppos) - 1;
   if (blockIdx.x >= nwork)
     return;
@@ -1544,7 +1544,7 @@ void order_sort(u64 *__restrict__ keys, u64 nhits, int ppos, int dbits, const u3
   u32 P = 2;
   while (P < n)
     P <<= 1;
-  for (u32 j = (u32) l; j < P; j += 64)
+  for (u32 j = threadIdx.x; j < P; j += 256)
     { if (j < n)
         { const u64 k = keys[i + j];
           rk[j] = k;
@@ -1556,7 +1556,7 @@ void order_sort(u64 *__restrict__ keys, u64 nhits, int ppos, int dbits, const u3
   __syncthreads();
   for (u32 k2 = 2; k2 <= P; k2 <<= 1)
     for (u32 jj = k2 >> 1; jj > 0; jj >>= 1)
-      { for (u32 t = (u32) l; t < (P >> 1); t += 64)
+      { for (u32 t = threadIdx.x; t < (P >> 1); t += 256)
           { const u32 ix = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), px = ix | jj;
             const bool up = (ix & k2) == 0;
             const u32 a = ck[ix], c = ck[px];
@@ -1565,14 +1565,14 @@ void order_sort(u64 *__restrict__ keys, u64 nhits, int ppos, int dbits, const u3
           }
         __syncthreads();
       }
-  for (u32 j = (u32) l; j < n; j += 64)
+  for (u32 j = threadIdx.x; j < n; j += 256)
     keys[i + j] = rk[ck[j] & 2047u];
 }
 
 void damar_launch_order_runs(u64 *keys, u64 nhits, int ppos, int dbits, const u32 *work, u32 nwork, hipStream_t st)
 { if (nwork == 0)
     return;
-  hipLaunchKernelGGL(order_sort, dim3(nwork), dim3(64), 0, st, keys, nhits, ppos, dbits, work, nwork);
+  hipLaunchKernelGGL(order_sort, dim3(nwork), dim3(256), 0, st, keys, nhits, ppos, dbits, work, nwork);
 }
 
 /* first half: bit words + *total_dev = the number of work items; the caller reads the total, makes room, and calls the
