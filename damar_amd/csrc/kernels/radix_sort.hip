@@ -91,8 +91,8 @@ __device__ __forceinline__ u32 os_scan256(u32 v, u32 *lds4)
 
 template <typename KeyT>
 __global__ __launch_bounds__(OH_THREADS)
-void onesweep_hist(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u32 lastmask,
-                   u32 *__restrict__ ghist, uint4 *__restrict__ clr, u64 clr16)
+void onesweep_hist(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u64 dsh /* a byte per pass: where its digit starts */,
+                   u64 dwd /* a byte per pass: its mask */, u32 *__restrict__ ghist, uint4 *__restrict__ clr, u64 clr16)
 { extern __shared__ u32 sh[];                                  /* [npass][128][32] */
   constexpr u32 nthr = OH_THREADS;
   const int nw = npass * 128 * 32;
@@ -115,8 +115,7 @@ void onesweep_hist(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u
           if (i < n)
             { const KeyT x = k[r] >> lobit;
               for (int p = 0; p < npass; p++)
-                { u32 d = (u32) (x >> (8 * p)) & 0xffu;
-                  if (p == npass - 1) d &= lastmask;
+                { const u32 d = (u32) (x >> (int) ((dsh >> (8 * p)) & 0xffu)) & (u32) ((dwd >> (8 * p)) & 0xffu);
                   atomicAdd(&sh[((u32) p << 12) + ((d >> 1) << 5) + c], 1u << ((d & 1u) << 4));
                 }
             }
@@ -145,8 +144,8 @@ void onesweep_hist(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u
 #define OH_COPIES  8
 template <typename KeyT>
 __global__ __launch_bounds__(256)
-void onesweep_hist8(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u32 lastmask,
-                   u32 *__restrict__ ghist, uint4 *__restrict__ clr, u64 clr16)
+void onesweep_hist8(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, u64 dsh /* a byte per pass: where its digit starts */,
+                   u64 dwd /* a byte per pass: its mask */, u32 *__restrict__ ghist, uint4 *__restrict__ clr, u64 clr16)
 { SEED_PRIO(g_sort_prio);
   extern __shared__ u32 sh[];                                  /* [npass][256][OH_COPIES]: the bins of a digit place, OH_COPIES copies chosen by lane & 7 */
   const int nb = npass * 256 * OH_COPIES;
@@ -169,8 +168,7 @@ void onesweep_hist8(const KeyT *__restrict__ keys, u64 n, int lobit, int npass, 
           if (i < n)
             { const KeyT x = k[r] >> lobit;
               for (int p = 0; p < npass; p++)
-                { u32 d = (u32) (x >> (8 * p)) & 0xffu;
-                  if (p == npass - 1) d &= lastmask;
+                { const u32 d = (u32) (x >> (int) ((dsh >> (8 * p)) & 0xffu)) & (u32) ((dwd >> (8 * p)) & 0xffu);
                   atomicAdd(&sh[(((u32) p << 8) + d) * OH_COPIES + c], 1u);
                 }
             }
@@ -334,7 +332,7 @@ void onesweep_pass(const KeyT *__restrict__ kin, const u32 *__restrict__ vin, Ke
      requested per round trip and consumed in order: a prefix ends the walk, an empty word ends the round. */
   if (threadIdx.x < 256)
     { GT before = 0;
-      if (tile > 0)
+      if (tile > 0 && threadIdx.x <= mask)                   /* (a digit the pass does not have: nothing before it anywhere) */
         { u32 t = tile - 1, spins = 0;
 #ifdef OS_STATS
           u32 nstep = 0;
@@ -447,7 +445,26 @@ static void onesweep_passes(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lob
 { constexpr int OS_TILE = TH * IT;
   const u32 ntiles = (u32) ((n + OS_TILE - 1) / OS_TILE);
   const int npass  = (hibit - lobit + 7) / 8;
-  const int lastb  = hibit - lobit - 8 * (npass - 1);
+  /* The digits of a sort are as EVEN as its bits allow -- 28 bits are four digits of 7, 43 bits one of 8 and five of 7 -- not
+     8, 8, ... and a last one of what is left: the same number of passes, but a pass over a 7-bit digit has 128 look-back words
+     per tile to publish and poll instead of 256 and its scatter leaves the tile in runs twice as long (round 6). */
+  int dshift[OS_MAXPASS], dwidth[OS_MAXPASS];
+  u64 dsh = 0, dwd = 0;
+  { const int bits = hibit - lobit, base = bits / npass, extra = bits % npass;
+    int at = 0;
+    static int even = -1;                       /* DAMAR_SORT_EVEN=0: digits of 8 bits and a short last one (rounds 2-5) */
+    if (even < 0)
+      { const char *e = getenv("DAMAR_SORT_EVEN");
+        even = e ? atoi(e) : 1;
+      }
+    for (int p = 0; p < npass; p++)
+      { dshift[p] = at;
+        dwidth[p] = even ? base + (p < extra ? 1 : 0) : (p < npass - 1 ? 8 : bits - 8 * (npass - 1));
+        at += dwidth[p];
+        dsh |= (u64) dshift[p] << (8 * p);
+        dwd |= (u64) ((1u << dwidth[p]) - 1u) << (8 * p);
+      }
+  }
   const size_t region = ((size_t) ntiles * 256 * sizeof(GT) + 255) & ~(size_t) 255;
   u32 *err = (u32 *) ws, *ghist = (u32 *) (ws + WS_HIST), *ctr = (u32 *) (ws + WS_CTR);
   GT  *lbr[2] = { (GT *) (ws + WS_LB), (GT *) (ws + WS_LB + region) };
@@ -472,28 +489,28 @@ static void onesweep_passes(KeyT *k0, u32 *v0, KeyT *k1, u32 *v1, u64 n, int lob
           }
       }
       hipLaunchKernelGGL(onesweep_hist<KeyT>, dim3((u32) grid), dim3(OH_THREADS), lds, st,
-                         k0, n, lobit, npass, (1u << lastb) - 1u, ghist, (uint4 *) lbr[0], (u64) (region / 16));
+                         k0, n, lobit, npass, dsh, dwd, ghist, (uint4 *) lbr[0], (u64) (region / 16));
       HIP_CHECK(hipGetLastError());
     }
   else
     { const u64 nt = (n + 256 * OH_ITEMS - 1) / (256 * OH_ITEMS);
       const u32 grid = (u32) (nt < 2048 ? nt : 2048);
       hipLaunchKernelGGL(onesweep_hist8<KeyT>, dim3(grid), dim3(256), (size_t) npass * 256 * OH_COPIES * sizeof(u32), st,
-                         k0, n, lobit, npass, (1u << lastb) - 1u, ghist, (uint4 *) lbr[0], (u64) (region / 16));
+                         k0, n, lobit, npass, dsh, dwd, ghist, (uint4 *) lbr[0], (u64) (region / 16));
     }
   for (int p = 0; p < npass; p++)
     { const int  side = p & 1;
       const bool last = (p == npass - 1);
       KeyT *ki = side ? k1 : k0, *ko = side ? k0 : k1;
       u32  *vi = side ? v1 : v0, *vo = side ? v0 : v1;
-      const u32 mask = last ? (1u << lastb) - 1u : 0xffu;
+      const u32 mask = (1u << dwidth[p]) - 1u;
       if (last && ohi != NULL)
         hipLaunchKernelGGL((onesweep_pass<KeyT, GT, false, true, TH, IT>), dim3(ntiles), dim3(TH), 0, st,
-                           ki, (const u32 *) NULL, (KeyT *) NULL, olo, ohi, n, lobit + 8 * p, mask,
+                           ki, (const u32 *) NULL, (KeyT *) NULL, olo, ohi, n, lobit + dshift[p], mask,
                            ghist + 256 * p, lbr[side], lbr[side ^ 1], ctr + p, err);
       else
         hipLaunchKernelGGL((onesweep_pass<KeyT, GT, HV, false, TH, IT>), dim3(ntiles), dim3(TH), 0, st,
-                           ki, vi, ko, vo, (u32 *) NULL, n, lobit + 8 * p, mask,
+                           ki, vi, ko, vo, (u32 *) NULL, n, lobit + dshift[p], mask,
                            ghist + 256 * p, lbr[side], lbr[side ^ 1], ctr + p, err);
     }
 }
